@@ -1,0 +1,88 @@
+/*
+ * mpa_hip.h — C ABI of libmpa_hip.so, the MI355X (gfx950) native operator library for the
+ * multi-part-assembly training hot path.
+ *
+ * Every entry point takes raw DEVICE pointers, plain sizes and a HIP stream handle
+ * (`void* stream` == hipStream_t; NULL = the legacy default stream), returns 0 on success or a
+ * negative MPA_E* code, never allocates or frees user-visible memory, never synchronises the
+ * device, and keeps no mutable global state besides a thread-local last-error string
+ * (mpa_last_error).  All launches are asynchronous on `stream`.
+ *
+ * Each block below cites the reference interface (Wuziyi616/multi_part_assembly, file:line) that
+ * the entry point replaces; INTEGRATION.md shows the reference-side binding.
+ */
+#ifndef MPA_HIP_H_
+#define MPA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPA_OK 0
+#define MPA_EINVAL (-1)  /* bad argument (null pointer, negative size, size overflow) */
+#define MPA_ELAUNCH (-2) /* hipGetLastError() reported a launch failure */
+
+/* ABI version of this header; bumped whenever a signature changes. */
+#define MPA_ABI_VERSION 1
+int mpa_abi_version(void);
+
+/* Thread-local, NUL-terminated description of the last failure on this thread ("" if none). */
+const char* mpa_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Chamfer distance — replaces the `chamfer_cuda` extension module
+ *   chamfer_forward : multi_part_assembly/utils/chamfer/cuda/chamfer.cpp:21
+ *                     -> ChamferForward   chamfer_kernel.cu:116-168 (kernel :32-95)
+ *   chamfer_backward: multi_part_assembly/utils/chamfer/cuda/chamfer.cpp:22
+ *                     -> ChamferBackward  chamfer_kernel.cu:224-289 (kernel :175-210)
+ *
+ * Layout: xyz1 [batch, n1, 3], xyz2 [batch, n2, 3] contiguous fp32 (AoS), as CHECK_INPUT
+ * (chamfer_kernel.cu:20-22) demands.  Outputs dist1 [batch, n1], dist2 [batch, n2] fp32 and
+ * idx1, idx2 int64 — the dtypes ChamferForward allocates (:129-132).
+ *
+ * Semantics (bit-exact contract, see DESIGN.md "Chamfer arithmetic"):
+ *   d(p,q) = ((px-qx)*(px-qx) + (py-qy)*(py-qy)) + (pz-qz)*(pz-qz), every operation rounded to
+ *   fp32, no fused multiply-add; dist1[b,i] = min_j d(xyz1[b,i], xyz2[b,j]) and idx1[b,i] the LOWEST
+ *   j attaining it (strict `<` scan in index order, chamfer_kernel.cu:82); a query with no
+ *   candidate below 1e32 (n2 == 0, NaN/huge input) gets dist = 1e32f, idx = -1 (:60-61).
+ *   dist2/idx2: the same with the roles of the clouds swapped.
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_chamfer_forward(const float* xyz1, const float* xyz2, int64_t batch, int64_t n1, int64_t n2,
+                        float* dist1, int64_t* idx1, float* dist2, int64_t* idx2, void* stream);
+
+/* Diagnostic twin of mpa_chamfer_forward that pins the kernel variant: 0 = direct evaluation of the
+ * pinned arithmetic, 1 = fused-form filter + pinned recheck (the default; bit-identical results). */
+int mpa_chamfer_forward_variant(const float* xyz1, const float* xyz2, int64_t batch, int64_t n1,
+                                int64_t n2, float* dist1, int64_t* idx1, float* dist2,
+                                int64_t* idx2, int variant, void* stream);
+
+/*
+ * grad_xyz1 [batch, n1, 3] and grad_xyz2 [batch, n2, 3] are OVERWRITTEN (the library zero-fills
+ * them itself, as ChamferBackward does with at::zeros, chamfer_kernel.cu:252-253):
+ *   grad_xyz1[b,i]        += 2*grad_dist1[b,i] * (xyz1[b,i] - xyz2[b,idx1[b,i]])
+ *   grad_xyz2[b,idx1[b,i]] -= the same vector                 (and symmetrically for dist2/idx2)
+ * The scatter half uses fp32 hardware atomics, so the summation ORDER of colliding contributions
+ * is unspecified — exactly the reference's behaviour (chamfer_kernel.cu:203-208).
+ * Indices outside [0, n) (the -1 of an empty search) contribute nothing.
+ */
+int mpa_chamfer_backward(const float* grad_dist1, const float* grad_dist2, const float* xyz1,
+                         const float* xyz2, const int64_t* idx1, const int64_t* idx2, int64_t batch,
+                         int64_t n1, int64_t n2, float* grad_xyz1, float* grad_xyz2, void* stream);
+
+/* Double-precision twins (the reference dispatches float and double, chamfer_kernel.cu:145,156,
+ * and its own gradcheck runs in double, utils/chamfer/test_chamfer.py:92-101).  Same contract with
+ * every fp32 replaced by fp64 (initial distance 1e32 as a double). */
+int mpa_chamfer_forward_f64(const double* xyz1, const double* xyz2, int64_t batch, int64_t n1,
+                            int64_t n2, double* dist1, int64_t* idx1, double* dist2, int64_t* idx2,
+                            void* stream);
+int mpa_chamfer_backward_f64(const double* grad_dist1, const double* grad_dist2, const double* xyz1,
+                             const double* xyz2, const int64_t* idx1, const int64_t* idx2,
+                             int64_t batch, int64_t n1, int64_t n2, double* grad_xyz1,
+                             double* grad_xyz2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPA_HIP_H_ */

@@ -1,0 +1,87 @@
+"""ctypes binding of libmpa_hip.so — the only way the Python host reaches the HIP kernels.
+
+There is deliberately no fallback: if the shared library is missing or fails to load, every
+operator raises.  `import torch` happens first so that the library resolves `libamdhip64.so.7`
+to the HIP runtime torch already loaded (one runtime per process, shared streams and pointers).
+"""
+from __future__ import annotations
+
+import ctypes
+import re
+from pathlib import Path
+
+import torch  # noqa: F401  (must precede the dlopen, see module docstring)
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libmpa_hip.so"
+HEADER_PATH = PKG_DIR.parent / "include" / "mpa_hip.h"
+
+_c = ctypes
+_P = _c.c_void_p
+_I64 = _c.c_int64
+_INT = _c.c_int
+_F32 = _c.c_float
+
+# name -> (restype, argtypes); must list every function include/mpa_hip.h declares
+# (tests/test_abi.py cross-checks this table against the header and the .so's dynamic symbols).
+SIGNATURES: dict[str, tuple] = {
+    "mpa_abi_version": (_INT, []),
+    "mpa_last_error": (_c.c_char_p, []),
+    "mpa_chamfer_forward": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
+    "mpa_chamfer_forward_variant": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _INT, _P]),
+    "mpa_chamfer_backward": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
+    "mpa_chamfer_forward_f64": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
+    "mpa_chamfer_backward_f64": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class MpaError(RuntimeError):
+    """A libmpa_hip.so entry point returned a nonzero status."""
+
+
+def declared_functions() -> list[str]:
+    """Function names declared in include/mpa_hip.h."""
+    text = HEADER_PATH.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpa_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the operator library; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise MpaError(
+            f"{LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (there is no non-HIP fallback for these operators)"
+        )
+    handle = ctypes.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    got = handle.mpa_abi_version()
+    if got != ABI_VERSION:
+        raise MpaError(f"libmpa_hip.so ABI version {got}, python host expects {ABI_VERSION}")
+    _lib = handle
+    return handle
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().mpa_last_error().decode("utf-8", "replace")
+        raise MpaError(f"{what} failed (status {status}): {msg}")
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    """Raw device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device: torch.device) -> int:
+    """hipStream_t of torch's current stream on `device`, as an integer handle."""
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,154 @@
+"""Chamfer distance operator — host-side mirror of the reference's `chamfer_cuda` extension and of
+its autograd wrapper (reference: multi_part_assembly/utils/chamfer/chamfer.py:11-76,
+utils/chamfer/cuda/chamfer.cpp:20-23).
+
+`chamfer_forward` / `chamfer_backward` carry the extension module's two functions, the rest of the
+names and signatures are the wrapper's.  Everything runs through libmpa_hip.so (C ABI in
+include/mpa_hip.h) on torch's current HIP stream; there is no CPU implementation here — CPU tensors
+are rejected exactly like the reference rejects them (chamfer.py:18,30).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+__all__ = [
+    "chamfer_forward",
+    "chamfer_backward",
+    "ChamferDistanceFunction",
+    "chamfer_distance",
+    "nn_distance",
+    "safe_sqrt",
+]
+
+
+def _check_cloud(name: str, t: torch.Tensor) -> None:
+    # CHECK_INPUT + the size checks of ChamferForward (chamfer_kernel.cu:20-22,123-127)
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if t.dim() != 3 or t.size(2) != 3:
+        raise RuntimeError(f"{name} must have shape (B, N, 3), got {tuple(t.shape)}")
+    if t.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"{name}: only float32/float64 are dispatched, got {t.dtype}")
+
+
+def chamfer_forward(xyz1: torch.Tensor, xyz2: torch.Tensor, variant: int | None = None):
+    """`chamfer_cuda.chamfer_forward(xyz1, xyz2) -> [dist1, idx1, dist2, idx2]`.
+
+    xyz1 (B, N1, 3), xyz2 (B, N2, 3); dist in the input dtype, idx int64 (chamfer_kernel.cu:129-132).
+    `variant` (0/1, fp32 only) pins the kernel variant for tests and A/B timing.
+    """
+    _check_cloud("xyz1", xyz1)
+    _check_cloud("xyz2", xyz2)
+    if xyz2.size(0) != xyz1.size(0):
+        raise RuntimeError("xyz1 and xyz2 must have the same batch size")
+    if xyz2.dtype != xyz1.dtype or xyz2.device != xyz1.device:
+        raise RuntimeError("xyz1 and xyz2 must share dtype and device")
+    B, n1, n2 = xyz1.size(0), xyz1.size(1), xyz2.size(1)
+    dev = xyz1.device
+    dist1 = torch.empty((B, n1), dtype=xyz1.dtype, device=dev)
+    dist2 = torch.empty((B, n2), dtype=xyz1.dtype, device=dev)
+    idx1 = torch.empty((B, n1), dtype=torch.int64, device=dev)
+    idx2 = torch.empty((B, n2), dtype=torch.int64, device=dev)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        s = _lib.current_stream(dev)
+        args = (_lib.ptr(xyz1), _lib.ptr(xyz2), B, n1, n2, _lib.ptr(dist1), _lib.ptr(idx1),
+                _lib.ptr(dist2), _lib.ptr(idx2))
+        if xyz1.dtype == torch.float64:
+            st = L.mpa_chamfer_forward_f64(*args, s)
+        elif variant is None:
+            st = L.mpa_chamfer_forward(*args, s)
+        else:
+            st = L.mpa_chamfer_forward_variant(*args, int(variant), s)
+    _lib.check(st, "mpa_chamfer_forward")
+    return [dist1, idx1, dist2, idx2]
+
+
+def chamfer_backward(grad_dist1, grad_dist2, xyz1, xyz2, idx1, idx2):
+    """`chamfer_cuda.chamfer_backward(g1, g2, xyz1, xyz2, idx1, idx2) -> [grad_xyz1, grad_xyz2]`."""
+    _check_cloud("xyz1", xyz1)
+    _check_cloud("xyz2", xyz2)
+    B, n1, n2 = xyz1.size(0), xyz1.size(1), xyz2.size(1)
+    for name, t, shape, dt in (
+        ("grad_dist1", grad_dist1, (B, n1), xyz1.dtype),
+        ("grad_dist2", grad_dist2, (B, n2), xyz1.dtype),
+        ("idx1", idx1, (B, n1), torch.int64),
+        ("idx2", idx2, (B, n2), torch.int64),
+    ):
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError(f"{name} must be a contiguous CUDA tensor")
+        if tuple(t.shape) != shape or t.dtype != dt:
+            raise RuntimeError(f"{name}: expected {shape} {dt}, got {tuple(t.shape)} {t.dtype}")
+    if xyz2.size(0) != B or xyz2.dtype != xyz1.dtype:
+        raise RuntimeError("xyz1 and xyz2 must share batch size and dtype")
+    dev = xyz1.device
+    grad_xyz1 = torch.empty((B, n1, 3), dtype=xyz1.dtype, device=dev)
+    grad_xyz2 = torch.empty((B, n2, 3), dtype=xyz1.dtype, device=dev)
+    L = _lib.lib()
+    fn = L.mpa_chamfer_backward_f64 if xyz1.dtype == torch.float64 else L.mpa_chamfer_backward
+    with torch.cuda.device(dev):
+        st = fn(_lib.ptr(grad_dist1), _lib.ptr(grad_dist2), _lib.ptr(xyz1), _lib.ptr(xyz2),
+                _lib.ptr(idx1), _lib.ptr(idx2), B, n1, n2, _lib.ptr(grad_xyz1),
+                _lib.ptr(grad_xyz2), _lib.current_stream(dev))
+    _lib.check(st, "mpa_chamfer_backward")
+    return [grad_xyz1, grad_xyz2]
+
+
+def safe_sqrt(x, eps=1e-12):
+    return torch.sqrt(torch.clamp(x, eps))
+
+
+class ChamferDistanceFunction(torch.autograd.Function):
+    """Autograd glue (reference chamfer.py:11-33): fp32 even under autocast, idx kept for backward."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, xyz1, xyz2):
+        xyz1 = xyz1.contiguous()
+        xyz2 = xyz2.contiguous()
+        assert xyz1.is_cuda and xyz2.is_cuda, "Only support cuda currently."
+        dist1, idx1, dist2, idx2 = chamfer_forward(xyz1, xyz2)
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        ctx.mark_non_differentiable(idx1, idx2)
+        return dist1, dist2
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_dist1, grad_dist2):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        grad_dist1 = grad_dist1.contiguous()
+        grad_dist2 = grad_dist2.contiguous()
+        assert grad_dist1.is_cuda and grad_dist2.is_cuda, "Only support cuda currently."
+        grad_xyz1, grad_xyz2 = chamfer_backward(grad_dist1, grad_dist2, xyz1, xyz2, idx1, idx2)
+        return grad_xyz1, grad_xyz2
+
+
+def _batched_bnc(cloud: torch.Tensor, channels_first: bool) -> torch.Tensor:
+    """(n, 3) -> (1, n, 3); BCN -> BNC view when `channels_first`."""
+    cloud = cloud[None] if cloud.dim() == 2 else cloud
+    return cloud.transpose(1, 2) if channels_first else cloud
+
+
+def chamfer_distance(xyz1, xyz2, transpose=False, sqrt=False, eps=1e-12):
+    """Bidirectional squared nearest-neighbour distances; signature of reference chamfer.py:36-64.
+
+    xyz1 (b, n1, 3) or (n1, 3), xyz2 likewise.  `transpose=True` accepts BCN inputs, `sqrt=True`
+    returns clamped (>= eps) Euclidean distances.  Returns (dist1 (b, n1), dist2 (b, n2)).
+    """
+    dists = ChamferDistanceFunction.apply(_batched_bnc(xyz1, transpose), _batched_bnc(xyz2, transpose))
+    if sqrt:
+        dists = tuple(safe_sqrt(d, eps) for d in dists)
+    return dists[0], dists[1]
+
+
+def nn_distance(xyz1, xyz2, transpose=True):
+    """No-autograd interface that also returns the indices; signature of reference chamfer.py:67-76.
+
+    Note the reference's default: inputs are BCN unless `transpose=False`.
+    """
+    return chamfer_forward(_batched_bnc(xyz1, transpose).contiguous(),
+                           _batched_bnc(xyz2, transpose).contiguous())

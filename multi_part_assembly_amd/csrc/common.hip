@@ -1,0 +1,29 @@
+// Error plumbing of the C ABI (include/mpa_hip.h): thread-local last-error string.
+#include "common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace mpa {
+
+static thread_local char g_last_error[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return MPA_OK;
+  return fail(MPA_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+}  // namespace mpa
+
+extern "C" int mpa_abi_version(void) { return MPA_ABI_VERSION; }
+
+extern "C" const char* mpa_last_error(void) { return mpa::g_last_error; }
