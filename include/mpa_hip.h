@@ -82,6 +82,30 @@ int mpa_chamfer_backward_f64(const double* grad_dist1, const double* grad_dist2,
                              int64_t batch, int64_t n1, int64_t n2, double* grad_xyz1,
                              double* grad_xyz2, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Rigid pose application — replaces the tensor-op chain of
+ *   rot_pc / transform_pc : multi_part_assembly/utils/transforms.py:199-244
+ *   qrot / qtransform     : multi_part_assembly/utils/transforms.py:75-109
+ *   (pytorch3d.transforms.quaternion_apply underneath, transforms.py:87)
+ *
+ * pc [num_parts, num_points, 3] fp32, quat [num_parts, 4] (real part first, NOT normalised here),
+ * trans [num_parts, 3] or NULL (rotation only), mask [num_parts] or NULL: where mask[m] == 0 every
+ * point of part m is replaced by (fill, fill, fill) BEFORE the transform — the padded-part fill of
+ * shape_cd_loss (utils/loss.py:173-175).  out [num_parts, num_points, 3].
+ * Arithmetic: the two Hamilton products of quaternion_apply evaluated term by term, left to right,
+ * no FMA — bit-identical to the reference CPU path.
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_pose_apply_forward(const float* pc, const float* quat, const float* trans,
+                           const float* mask, float fill, int64_t num_parts, int64_t num_points,
+                           float* out, void* stream);
+
+/* Backward of the above: given grad_out [num_parts, num_points, 3] writes grad_quat [num_parts, 4],
+ * grad_trans [num_parts, 3] (skipped if NULL) and grad_pc [num_parts, num_points, 3] (skipped if
+ * NULL; zero for masked parts).  Deterministic (fixed reduction tree, no atomics). */
+int mpa_pose_apply_backward(const float* grad_out, const float* pc, const float* quat,
+                            const float* mask, float fill, int64_t num_parts, int64_t num_points,
+                            float* grad_quat, float* grad_trans, float* grad_pc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

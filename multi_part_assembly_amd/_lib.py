@@ -32,6 +32,8 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_chamfer_backward": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_chamfer_forward_f64": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
     "mpa_chamfer_backward_f64": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
+    "mpa_pose_apply_forward": (_INT, [_P, _P, _P, _P, _F32, _I64, _I64, _P, _P]),
+    "mpa_pose_apply_backward": (_INT, [_P, _P, _P, _P, _F32, _I64, _I64, _P, _P, _P, _P]),
 }
 
 ABI_VERSION = 1

@@ -1,0 +1,92 @@
+"""`Rotation3D` — quaternion-only mirror of the reference's rotation value type
+(reference: multi_part_assembly/utils/rotation.py:91-309).
+
+Scope: every shipped model config sets `rot_type='quat'`, so only the
+quaternion representation is carried; asking for 'rmat'/'axis' raises NotImplementedError.
+Semantics kept from the reference constructor (rotation.py:115-147): the tensor is cast to fp32
+and quaternions whose norm is <= 0.5 (the all-zero rows of padded parts) are replaced by the
+identity (1, 0, 0, 0); nothing is normalised.
+"""
+from __future__ import annotations
+
+import torch
+
+_TENSOR_METHODS = ("reshape", "view", "squeeze", "unsqueeze", "flatten", "unflatten", "transpose",
+                   "permute", "contiguous", "to", "cuda", "type", "type_as", "detach", "clone")
+
+
+class Rotation3D:
+    ROT_TYPE = ["quat"]
+
+    def __init__(self, rot, rot_type="quat"):
+        if rot_type != "quat":
+            raise NotImplementedError(
+                f"rotation {rot_type!r}: only 'quat' is on the MI355X hot path (every shipped "
+                "model config uses it)")
+        assert isinstance(rot, torch.Tensor), "rotation must be a tensor"
+        assert rot.shape[-1] == 4, "wrong quaternion shape"
+        rot = rot.float()
+        with torch.no_grad():
+            keep = rot.norm(p=2, dim=-1, keepdim=True) > 0.5
+            ident = torch.zeros_like(rot)
+            ident[..., 0] = 1.0
+        self._rot = torch.where(keep, rot, ident)
+        self._rot_type = rot_type
+
+    # --- value access -----------------------------------------------------------------------
+    @property
+    def rot(self):
+        return self._rot
+
+    @rot.setter
+    def rot(self, value):
+        self.__init__(value, self._rot_type)
+
+    @property
+    def rot_type(self):
+        return self._rot_type
+
+    def convert(self, rot_type):
+        if rot_type != "quat":
+            raise NotImplementedError(f"conversion to {rot_type!r} is outside the quaternion hot path")
+        return self.clone()
+
+    def to_quat(self):
+        return self.convert("quat").rot
+
+    # --- tensor-like surface ------------------------------------------------------------------
+    shape = property(lambda self: self._rot.shape)
+    device = property(lambda self: self._rot.device)
+    dtype = property(lambda self: self._rot.dtype)
+
+    def __len__(self):
+        return self._rot.shape[0]
+
+    def __getitem__(self, key):
+        return Rotation3D(self._rot[key], self._rot_type)
+
+    @staticmethod
+    def _combine(op, rot_lst, dim):
+        assert isinstance(rot_lst, (list, tuple)) and all(isinstance(r, Rotation3D) for r in rot_lst)
+        return Rotation3D(op([r.rot for r in rot_lst], dim=dim), rot_lst[0].rot_type)
+
+    @staticmethod
+    def cat(rot_lst, dim=0):
+        return Rotation3D._combine(torch.cat, rot_lst, dim)
+
+    @staticmethod
+    def stack(rot_lst, dim=0):
+        return Rotation3D._combine(torch.stack, rot_lst, dim)
+
+
+def _delegate(name):
+    def method(self, *args, **kwargs):
+        return Rotation3D(getattr(self._rot, name)(*args, **kwargs), self._rot_type)
+
+    method.__name__ = name
+    method.__doc__ = f"torch.Tensor.{name} applied to the wrapped quaternion tensor."
+    return method
+
+
+for _name in _TENSOR_METHODS:
+    setattr(Rotation3D, _name, _delegate(_name))

@@ -1,0 +1,353 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE, in this container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--only chamfer,transforms,...]
+
+Needs /root/reference (read-only mount, absent on the GPU box) and the import shims of
+_reference_shim.py.  Outputs are plain .npz files holding inputs and the reference's outputs —
+data only, no reference source.  Every fixture is seeded; re-running reproduces the files bit for
+bit on the same torch build (torch 2.10.0 CPU here).
+
+Fixture -> reference entry points exercised
+  chamfer.npz       utils/chamfer/test_chamfer.py:8-31  bpdist2 / nn_distance_torch (the reference's
+                    own ground truth for ChamferForwardKernel), fp64 autograd for the backward
+  transforms.npz    utils/transforms.py:75-109,199-244  qrot/qtransform/rot_pc/transform_pc,
+                    utils/rotation.py:115-167           Rotation3D (zero-quaternion handling)
+  losses.npz        utils/loss.py:7-202                 every loss on the geometric path + input grads
+  pointnet.npz      models/modules/encoder/pointnet.py:6-41
+  dgcnn.npz         models/modules/encoder/dgcnn.py:8-109
+  transformer.npz   models/pn_transformer/transformer.py:37-79, models/modules/regressor.py:30-84
+  pn_transformer_step.npz  models/pn_transformer/network.py:70-139 + models/modules/base_model.py
+                    forward_pass/loss_function/_calc_loss on a seeded synthetic batch (+ all grads)
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import os
+import sys
+from pathlib import Path
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import _reference_shim as shim  # noqa: E402
+
+torch.set_num_threads(4)
+torch.use_deterministic_algorithms(True)
+
+
+def npy(t):
+    if hasattr(t, "rot"):  # Rotation3D
+        t = t.rot
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = HERE / f"{name}.npz"
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path.name}: {len(arrays)} arrays, {path.stat().st_size / 1024:.1f} KiB")
+
+
+def unit_quats(g, *shape):
+    q = torch.randn(*shape, 4, generator=g)
+    return F.normalize(q, dim=-1)
+
+
+# --------------------------------------------------------------------------------------------------
+def gen_chamfer():
+    _, nn_distance_torch = shim.load_reference_bruteforce()
+    g = torch.Generator().manual_seed(1001)
+    out = {}
+    cases = {"a": (2, 64, 64), "b": (3, 100, 77), "c": (1, 1000, 1000), "d": (1, 1100, 900)}
+    for k, (B, n1, n2) in cases.items():
+        x1 = torch.rand(B, n1, 3, generator=g)
+        x2 = torch.rand(B, n2, 3, generator=g)
+        d1, i1, d2, i2 = nn_distance_torch(x1, x2, "NWC")
+        out.update({f"{k}_xyz1": npy(x1), f"{k}_xyz2": npy(x2), f"{k}_dist1": npy(d1),
+                    f"{k}_idx1": npy(i1), f"{k}_dist2": npy(d2), f"{k}_idx2": npy(i2)})
+    # the reference's commented-out hand example (test_chamfer.py:42-43)
+    x1 = torch.tensor([[[0, 0, 1], [1, 0, 0]]]).float()
+    x2 = torch.tensor([[[0, 0, 1.1], [1.2, 0, 0]]]).float()
+    d1, i1, d2, i2 = nn_distance_torch(x1, x2, "NWC")
+    out.update({"hand_xyz1": npy(x1), "hand_xyz2": npy(x2), "hand_dist1": npy(d1),
+                "hand_idx1": npy(i1), "hand_dist2": npy(d2), "hand_idx2": npy(i2)})
+    # exact ties: points on a 4x4x4 lattice (torch.min on CPU returns the first minimum, which is
+    # the lowest-index rule of chamfer_kernel.cu:82; asserted below against a sequential scan)
+    x1 = (torch.randint(0, 4, (3, 200, 3), generator=g) * 0.25).float()
+    x2 = (torch.randint(0, 4, (3, 300, 3), generator=g) * 0.25).float()
+    d1, i1, d2, i2 = nn_distance_torch(x1, x2, "NWC")
+    dm = ((x1[:, :, None] - x2[:, None]) ** 2).sum(-1)
+    first1 = (dm == dm.min(2, keepdim=True)[0]).int().argmax(2)
+    first2 = (dm == dm.min(1, keepdim=True)[0]).int().argmax(1)
+    assert torch.equal(first1, i1) and torch.equal(first2, i2), "torch.min tie order changed"
+    out.update({"tie_xyz1": npy(x1), "tie_xyz2": npy(x2), "tie_dist1": npy(d1),
+                "tie_idx1": npy(i1), "tie_dist2": npy(d2), "tie_idx2": npy(i2)})
+    # backward in float64 (the reference's gradcheck precision, test_chamfer.py:92-101):
+    # autograd through min == ChamferBackwardKernel's formula (chamfer_kernel.cu:199-208)
+    x1 = torch.rand(2, 64, 3, generator=g, dtype=torch.float64).requires_grad_()
+    x2 = torch.rand(2, 48, 3, generator=g, dtype=torch.float64).requires_grad_()
+    g1 = torch.randn(2, 64, generator=g, dtype=torch.float64)
+    g2 = torch.randn(2, 48, generator=g, dtype=torch.float64)
+    d1, i1, d2, i2 = nn_distance_torch(x1, x2, "NWC")
+    ((d1 * g1).sum() + (d2 * g2).sum()).backward()
+    out.update({"bwd_xyz1": npy(x1), "bwd_xyz2": npy(x2), "bwd_g1": npy(g1), "bwd_g2": npy(g2),
+                "bwd_idx1": npy(i1), "bwd_idx2": npy(i2), "bwd_dist1": npy(d1),
+                "bwd_dist2": npy(d2), "bwd_gxyz1": npy(x1.grad), "bwd_gxyz2": npy(x2.grad)})
+    save("chamfer", **out)
+
+
+# --------------------------------------------------------------------------------------------------
+def gen_transforms(U):
+    from scipy.spatial.transform import Rotation as R
+
+    g = torch.Generator().manual_seed(1002)
+    B, P, N = 2, 4, 64
+    q = unit_quats(g, B, P)
+    q[0, 3] = 0.0                      # padded part: zero quaternion -> identity (rotation.py:121-128)
+    q[1, 2] = q[1, 2] * 0.3            # |q| = 0.3 <= 0.5 also becomes identity
+    q[1, 3] = q[1, 3] * 1.7            # non-unit, kept as is: quaternion_apply scales by |q|^2
+    t = torch.randn(B, P, 3, generator=g)
+    pc = torch.randn(B, P, N, 3, generator=g)
+    rot = U.Rotation3D(q, rot_type="quat")
+    out = {"quat_in": npy(q), "quat_checked": npy(rot), "trans": npy(t), "pc": npy(pc),
+           "rot_pc": npy(U.rot_pc(rot, pc)), "transform_pc": npy(U.transform_pc(t, rot, pc)),
+           "qrot_flat": npy(U.qrot(rot.rot.reshape(-1, 4), pc[:, :, 0].reshape(-1, 3)))}
+    # cross-check of the pytorch3d stand-in against scipy (unit quaternions only)
+    qq = npy(rot)[0, :3].reshape(-1, 4)
+    want = R.from_quat(qq[:, [1, 2, 3, 0]]).apply(npy(pc)[0, :3, 5])
+    got = out["rot_pc"][0, :3, 5]
+    assert np.abs(want - got).max() < 1e-5, np.abs(want - got).max()
+    save("transforms", **out)
+
+
+# --------------------------------------------------------------------------------------------------
+def gen_losses(U):
+    from multi_part_assembly.utils import loss as L
+
+    g = torch.Generator().manual_seed(1003)
+    B, P, N = 4, 5, 64
+    pts = torch.randn(B, P, N, 3, generator=g) * 0.2
+    valids = torch.tensor([[1, 0, 0, 0, 0], [1, 1, 0, 0, 0], [1, 1, 1, 1, 0], [1, 1, 1, 1, 1.0]])
+    pts = pts * valids[..., None, None]
+    q_gt = unit_quats(g, B, P) * valids[..., None]
+    t_gt = torch.randn(B, P, 3, generator=g) * 0.3 * valids[..., None]
+    q_pr = unit_quats(g, B, P).requires_grad_()
+    t_pr = (torch.randn(B, P, 3, generator=g) * 0.3).requires_grad_()
+    w = torch.rand(B, generator=g) + 0.5  # per-sample weights so every [B] entry gets a gradient
+    out = {"pts": npy(pts), "valids": npy(valids), "quat_gt": npy(q_gt), "trans_gt": npy(t_gt),
+           "quat_pred": npy(q_pr), "trans_pred": npy(t_pr), "w": npy(w)}
+
+    def run(name, fn):
+        for p in (q_pr, t_pr):
+            p.grad = None
+        r_pr = U.Rotation3D(q_pr, rot_type="quat")
+        r_gt = U.Rotation3D(q_gt, rot_type="quat")
+        res = fn(r_pr, r_gt)
+        extra = ()
+        if isinstance(res, tuple):
+            res, *extra = res
+        (res * w).sum().backward()
+        out[name] = npy(res)
+        out[name + "_gquat"] = npy(q_pr.grad) if q_pr.grad is not None else np.zeros((B, P, 4), "f4")
+        out[name + "_gtrans"] = npy(t_pr.grad) if t_pr.grad is not None else np.zeros((B, P, 3), "f4")
+        for i, e in enumerate(extra):
+            out[f"{name}_pts{i + 1}"] = npy(e)
+
+    run("trans_l2", lambda rp, rg: L.trans_l2_loss(t_pr, t_gt, valids))
+    run("rot_cosine", lambda rp, rg: L.rot_cosine_loss(rp, rg, valids))
+    run("rot_l2", lambda rp, rg: L.rot_l2_loss(rp, rg, valids))
+    run("rot_points_l2", lambda rp, rg: L.rot_points_l2_loss(pts, rp, rg, valids))
+    run("rot_points_cd", lambda rp, rg: L.rot_points_cd_loss(pts, rp, rg, valids, ret_pts=True))
+    run("shape_cd_train", lambda rp, rg: L.shape_cd_loss(pts, t_pr, t_gt, rp, rg, valids,
+                                                         ret_pts=True, training=True))
+    run("shape_cd_eval", lambda rp, rg: L.shape_cd_loss(pts, t_pr, t_gt, rp, rg, valids,
+                                                        ret_pts=False, training=False))
+    save("losses", **out)
+
+
+# --------------------------------------------------------------------------------------------------
+def randomize_norm_params(model, g):
+    """Non-trivial affine + running stats so that BN/LN parameters matter in the fixtures."""
+    for m in model.modules():
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.LayerNorm)):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                if hasattr(m, "running_mean") and m.running_mean is not None:
+                    m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                    m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
+def state_arrays(model, prefix="sd."):
+    return {prefix + k: npy(v) for k, v in model.state_dict().items()}
+
+
+def grad_arrays(model, prefix="grad."):
+    return {prefix + k: npy(p.grad) for k, p in model.named_parameters()}
+
+
+def gen_encoder(name, feat_dim, n, N, seed):
+    from multi_part_assembly.models import build_encoder
+
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    enc = build_encoder(name, feat_dim=feat_dim, global_feat=True)
+    randomize_norm_params(enc, g)
+    x = torch.randn(n, N, 3, generator=g) * 0.3
+    w = torch.randn(n, feat_dim, generator=g)
+    out = {"x": npy(x), "w": npy(w)}
+    out.update(state_arrays(enc, "sd0."))          # state before the training-mode forward
+    enc.train()
+    xin = x.clone().requires_grad_()
+    feat = enc(xin)
+    (feat * w).sum().backward()
+    out["feat_train"] = npy(feat)
+    out["grad_x"] = npy(xin.grad)
+    out.update(grad_arrays(enc))
+    out.update(state_arrays(enc, "sd1."))          # running stats after one training step
+    enc.eval()
+    with torch.no_grad():
+        out["feat_eval"] = npy(enc(x))
+    if name == "dgcnn":
+        from multi_part_assembly.models.modules.encoder import dgcnn as D
+        with torch.no_grad():
+            out["knn_idx_layer1"] = npy(D.knn(x.transpose(2, 1).contiguous(), k=20))
+    save(name, **out)
+
+
+def gen_transformer():
+    from multi_part_assembly.models.pn_transformer.transformer import TransformerEncoder
+    from multi_part_assembly.models.modules.regressor import StocasticPoseRegressor
+
+    g = torch.Generator().manual_seed(1006)
+    torch.manual_seed(1006)
+    d, heads, ffn, layers = 64, 4, 128, 2
+    enc = TransformerEncoder(d_model=d, num_heads=heads, ffn_dim=ffn, num_layers=layers,
+                             norm_first=True, dropout=0.0)
+    randomize_norm_params(enc, g)
+    head = StocasticPoseRegressor(feat_dim=d, noise_dim=0, rot_type="quat")
+    B, P = 3, 6
+    tok = torch.randn(B, P, d, generator=g)
+    valid = torch.tensor([[1, 1, 0, 0, 0, 0], [1, 1, 1, 1, 0, 0], [1, 1, 1, 1, 1, 1]]).bool()
+    wr = torch.randn(B, P, 4, generator=g)
+    wt = torch.randn(B, P, 3, generator=g)
+    out = {"tokens": npy(tok), "valid": npy(valid), "w_rot": npy(wr), "w_trans": npy(wt),
+           "cfg": np.array([d, heads, ffn, layers])}
+    out.update(state_arrays(enc, "enc."))
+    out.update(state_arrays(head, "head."))
+    enc.train()
+    head.train()
+    tin = tok.clone().requires_grad_()
+    feats = enc(tin, valid)
+    rot, trans = head(feats)
+    vm = valid[..., None].float()
+    ((rot * wr * vm).sum() + (trans * wt * vm).sum()).backward()
+    out.update({"feats": npy(feats), "rot": npy(rot), "trans": npy(trans), "grad_tokens": npy(tin.grad)})
+    out.update(grad_arrays(enc, "genc."))
+    out.update(grad_arrays(head, "ghead."))
+    save("transformer", **out)
+
+
+def synthetic_batch(g, B, P, N, num_parts):
+    """Seeded stand-in for the data_dict contract (datasets/geometry_data.py:173-207)."""
+    valids = torch.zeros(B, P)
+    for b, k in enumerate(num_parts):
+        valids[b, :k] = 1
+    pcs = torch.randn(B, P, N, 3, generator=g) * 0.15
+    pcs = pcs - pcs.mean(2, keepdim=True)
+    pcs = pcs * valids[..., None, None]
+    quat = unit_quats(g, B, P) * valids[..., None]
+    trans = torch.randn(B, P, 3, generator=g) * 0.3 * valids[..., None]
+    return {
+        "part_pcs": pcs, "part_trans": trans, "part_quat": quat, "part_valids": valids,
+        "part_label": torch.zeros(B, P, 0), "instance_label": torch.zeros(B, P, 0),
+        "part_ids": torch.arange(P)[None].repeat(B, 1) * valids.long(),
+        "valid_matrix": valids[:, :, None] * valids[:, None, :],
+    }
+
+
+def zero_dropout(model):
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, nn.MultiheadAttention):
+            m.dropout = 0.0
+
+
+def gen_pn_transformer_step():
+    from multi_part_assembly.models import build_model
+
+    sys.path.insert(0, os.path.join(shim.REFERENCE_ROOT, "configs/pn_transformer/pn_transformer"))
+    cfg = importlib.import_module("pn_transformer-32x1-cosine_400e-everyday").get_cfg_defaults()
+    # shrink the widths so the fixture stays small; structure and loss config are the shipped ones
+    cfg.model.pc_feat_dim = 64
+    cfg.model.transformer_feat_dim = 128
+    cfg.model.transformer_heads = 4
+    cfg.model.transformer_layers = 2
+    cfg.data.max_num_part = 5
+    g = torch.Generator().manual_seed(1007)
+    torch.manual_seed(1007)
+    model = build_model(cfg)
+    randomize_norm_params(model, g)
+    zero_dropout(model)
+    B, P, N = 3, 5, 64
+    data = synthetic_batch(g, B, P, N, [2, 4, 5])
+    out = {f"data.{k}": npy(v) for k, v in data.items()}
+    out["cfg"] = np.array([64, 4, 128, 2])
+    out.update(state_arrays(model, "sd0."))
+    model.train()
+    # forward_pass(mode='val') skips only the rank-0 logging block that needs a pl.Trainer
+    # (base_model.py:137-146); self.training stays True so the training loss semantics apply.
+    loss_dict = model.forward_pass({k: v.clone() for k, v in data.items()}, mode="val",
+                                   optimizer_idx=-1)
+    loss_dict["loss"].backward()
+    for k, v in loss_dict.items():
+        out[f"loss.{k}"] = npy(v)
+    out.update(grad_arrays(model))
+    out.update(state_arrays(model, "sd1."))
+    # intermediate activations from a second, identical forward (BN in train mode uses batch stats,
+    # so the values are the same; running stats are not re-saved)
+    with torch.no_grad():
+        pc_feats = model._extract_part_feats(data["part_pcs"], data["part_valids"])
+        pred = model.forward({"part_pcs": data["part_pcs"], "part_valids": data["part_valids"],
+                              "part_label": data["part_label"],
+                              "instance_label": data["instance_label"]})
+    out["act.pc_feats"] = npy(pc_feats)
+    out["act.pred_rot"] = npy(pred["rot"])
+    out["act.pred_trans"] = npy(pred["trans"])
+    save("pn_transformer_step", **out)
+
+
+# --------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    shim.import_reference()
+    import multi_part_assembly.utils as U
+
+    todo = {
+        "chamfer": gen_chamfer,
+        "transforms": lambda: gen_transforms(U),
+        "losses": lambda: gen_losses(U),
+        "pointnet": lambda: gen_encoder("pointnet", 256, 5, 128, 1004),
+        "dgcnn": lambda: gen_encoder("dgcnn", 128, 3, 96, 1005),
+        "transformer": gen_transformer,
+        "pn_transformer_step": gen_pn_transformer_step,
+    }
+    for name, fn in todo.items():
+        if not only or name in only:
+            fn()
+
+
+if __name__ == "__main__":
+    main()

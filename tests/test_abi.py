@@ -1,0 +1,65 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports exactly what
+include/mpa_hip.h declares (no compute calls — those need a GPU)."""
+import ctypes
+import subprocess
+
+import pytest
+
+from multi_part_assembly_amd import _build, _lib
+
+
+@pytest.fixture(scope="module")
+def built():
+    return _build.build()
+
+
+def test_header_and_signature_table_agree():
+    assert sorted(_lib.SIGNATURES) == _lib.declared_functions()
+
+
+def test_library_exports_every_declared_symbol(built):
+    out = subprocess.run(["nm", "-D", "--defined-only", str(built)], capture_output=True, text=True,
+                         check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [f for f in _lib.declared_functions() if f not in exported]
+    assert not missing, f"declared in mpa_hip.h but not exported: {missing}"
+    stray = sorted(s for s in exported if s.startswith("mpa_") and s not in _lib.SIGNATURES)
+    assert not stray, f"exported but undeclared: {stray}"
+
+
+def test_library_loads_and_reports_abi(built):
+    handle = _lib.lib()
+    assert handle.mpa_abi_version() == _lib.ABI_VERSION
+    assert handle.mpa_last_error() == b""
+
+
+def test_argument_validation_needs_no_gpu(built):
+    L = _lib.lib()
+    # negative sizes are rejected before anything touches the device
+    st = L.mpa_chamfer_forward(None, None, -1, 4, 4, None, None, None, None, None)
+    assert st == -1 and b"negative" in L.mpa_last_error()
+    st = L.mpa_chamfer_forward(None, None, 2, 4, 4, None, None, None, None, None)
+    assert st == -1 and b"null" in L.mpa_last_error()
+    # empty problems are a no-op success
+    assert L.mpa_chamfer_forward(None, None, 0, 4, 4, None, None, None, None, None) == 0
+    assert L.mpa_pose_apply_forward(None, None, None, None, ctypes.c_float(0), 0, 10, None, None) == 0
+
+
+def test_code_object_targets_gfx950_only(built):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(built)],
+                         capture_output=True, text=True).stdout
+    blob = built.read_bytes()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_"):
+        assert other not in blob, f"unexpected target {other!r} in the fat binary"
+
+
+def test_host_wrappers_reject_cpu_tensors():
+    import torch
+    from multi_part_assembly_amd import chamfer
+
+    a = torch.zeros(1, 4, 3)
+    with pytest.raises((RuntimeError, AssertionError)):
+        chamfer.chamfer_distance(a, a)
+    with pytest.raises(RuntimeError):
+        chamfer.chamfer_forward(a, a)
