@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one full training step (forward + losses + backward + gradient
+all-reduce + fused Adam) of PNTransformer + PointNet on synthetic Breaking-Bad-"everyday"-like part
+clouds, B = 32 per GPU, P = 20, N = 1000 (BASELINE.json configs[1]; weak scaling over GPUs).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = parts (B x P slots, padded slots included, as the metric is
+defined) processed per second by the whole job, inputs resident in HBM before the timed region.
+`roofline` describes the dominant kernel (the whole-shape Chamfer search), timed per launch with HIP
+events on its own stream inside the timed region; `cpu_baseline` is the oracle's reference-equivalent
+PyTorch-CPU step timed on this host (rank 0, N = 1 only) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch
+import torch.distributed as dist
+
+BATCH, PARTS, POINTS = 32, 20, 1000
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_LANE_OPS = 78.6e12  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (non-packed fp32 VALU issue)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="samples in the CPU-baseline step")
+    return ap.parse_args()
+
+
+def cpu_baseline(cpu_batch):
+    """Reference-equivalent CPU training step (oracle/nets.py + oracle/chamfer_ref.c), bounded sample:
+    the same workload at B = cpu_batch instead of 32 (cost is linear in B), 1 warm-up + 2 timed steps."""
+    from multi_part_assembly_amd import config
+    from multi_part_assembly_amd.pn_transformer import build_model
+    from oracle import nets as on
+
+    cores = len(os.sched_getaffinity(0))
+    threads = max(1, min(64, cores))
+    torch.set_num_threads(threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    cfg = config.pn_transformer_everyday()
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    params = {k: sd[k].requires_grad_() for k, _ in model.named_parameters()}
+    g = torch.Generator().manual_seed(1234)
+    B, P, N = cpu_batch, PARTS, POINTS
+    num_parts = torch.randint(2, P + 1, (B,), generator=g).tolist()
+    valids = torch.zeros(B, P)
+    for b, k in enumerate(num_parts):
+        valids[b, :k] = 1
+    pcs = (torch.rand(B, P, N, 3, generator=g) - 0.5) * 0.3 * valids[..., None, None]
+    quat = torch.nn.functional.normalize(torch.randn(B, P, 4, generator=g), dim=-1) * valids[..., None]
+    batch = {"part_pcs": pcs, "part_quat": quat, "part_valids": valids,
+             "part_trans": (torch.rand(B, P, 3, generator=g) * 0.8 - 0.4) * valids[..., None]}
+    state = {}
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        stats = {}
+        losses, _ = on.pn_transformer_loss(sd, batch, cfg.model.transformer_layers,
+                                           cfg.model.transformer_heads, training=True, stats_out=stats)
+        losses["loss"].backward()
+        on.adam_step(params, {k: p.grad for k, p in params.items()}, state, lr=cfg.optimizer.lr)
+        for k, v in stats.items():
+            sd[k] = v
+
+    step()
+    t0 = time.perf_counter()
+    timed = 2
+    for _ in range(timed):
+        step()
+    dt = (time.perf_counter() - t0) / timed
+    return {"value": B * P / dt, "unit": "parts/s", "cores": threads, "kind": "port",
+            "sample": f"full train step (fwd+loss+bwd+Adam) of the same model at B={B} (vs 32), P={P}, "
+                      f"N={N}; {timed} timed steps after 1 warm-up; {dt:.2f} s/step; torch CPU ops + "
+                      f"OpenMP C Chamfer on {threads} threads of {cores} visible"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from multi_part_assembly_amd import _lib, config, synthetic
+    from multi_part_assembly_amd.pn_transformer import build_model
+    from multi_part_assembly_amd.trainer import Trainer
+
+    cfg = config.pn_transformer_everyday()
+    torch.manual_seed(0)  # same initial weights on every rank (and broadcast from rank 0 anyway)
+    model = build_model(cfg).to(dev)
+    trainer = Trainer(model, cfg)
+    batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234 + rank, device=dev)
+    valid_parts = int(sum(batch["num_parts"]))
+
+    for i in range(args.warmup):
+        trainer.train_step(batch, i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    timer = _lib.KernelTimer()
+    _lib.KernelTimer.active = timer
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.train_step(batch, i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    _lib.KernelTimer.active = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / max(1, args.steps)
+        value = world * BATCH * PARTS * args.steps / elapsed
+        kernels = timer.summary()
+        dom = f"chamfer_forward[{BATCH}x{PARTS * POINTS}x{PARTS * POINTS}]"
+        roofline = None
+        if dom in kernels:
+            k = kernels[dom]
+            alg_bytes = 24.0 * BATCH * 2 * PARTS * POINTS          # 24 B/point
+            pairs = 2.0 * BATCH * (PARTS * POINTS) ** 2
+            achieved = alg_bytes / (k["avg_ms"] * 1e-3) / 1e9
+            roofline = {
+                "kernel": "chamfer_nn_kernel<float,4,filter> (whole-shape Chamfer, both directions)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
+                "algorithmic_bytes_per_launch": alg_bytes,
+                # exact brute force is VALU-bound, not HBM-bound: also report
+                # the pair-evaluation rate against the fp32 VALU issue peak at ~3.6 lane-ops/pair
+                "valu": {"pair_evals_per_s": pairs / (k["avg_ms"] * 1e-3),
+                         "lane_ops_per_pair_est": 5.6,
+                         "frac_of_valu_issue_peak": pairs * 5.6 / (k["avg_ms"] * 1e-3) / VALU_PEAK_LANE_OPS},
+            }
+        line = {
+            "metric": "train-step parts/sec (BxP) at N=1000 pts",
+            "value": value, "unit": "parts/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "pn_transformer + PointNet encoder, Breaking-Bad-everyday-like "
+                                   "synthetic clouds, B=32 per GPU, P=20, N=1000, geometric loss, Adam "
+                                   "(BASELINE.json configs[1])",
+                       "per_gpu_batch": BATCH, "max_parts": PARTS, "points_per_part": POINTS,
+                       "valid_parts_rank0": valid_parts, "parallelism": f"dp{world}"},
+            "final_loss": final_loss,
+            "kernels": kernels,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

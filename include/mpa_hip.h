@@ -106,6 +106,18 @@ int mpa_pose_apply_backward(const float* grad_out, const float* pc, const float*
                             const float* mask, float fill, int64_t num_parts, int64_t num_points,
                             float* grad_quat, float* grad_trans, float* grad_pc, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused optimiser step — replaces torch.optim.Adam / AdamW as configured by
+ *   BaseModel.configure_optimizers : multi_part_assembly/models/modules/base_model.py:389-406
+ * One streaming pass over flat, 16-byte-aligned fp32 buffers of `numel` elements (parameters,
+ * gradients, first and second moments).  `step` is the 1-based step count (bias correction),
+ * `grad_scale` multiplies the gradient first (1/world_size of the data-parallel mean),
+ * `decoupled_weight_decay` selects AdamW (p *= 1 - lr*wd) over Adam's L2 form (g += wd*p).
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int decoupled_weight_decay, int64_t step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

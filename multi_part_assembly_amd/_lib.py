@@ -34,6 +34,7 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_chamfer_backward_f64": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_pose_apply_forward": (_INT, [_P, _P, _P, _P, _F32, _I64, _I64, _P, _P]),
     "mpa_pose_apply_backward": (_INT, [_P, _P, _P, _P, _F32, _I64, _I64, _P, _P, _P, _P]),
+    "mpa_adam_step": (_INT, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _INT, _I64, _F32, _P]),
 }
 
 ABI_VERSION = 1
@@ -87,3 +88,42 @@ def ptr(t: torch.Tensor | None) -> int | None:
 def current_stream(device: torch.device) -> int:
     """hipStream_t of torch's current stream on `device`, as an integer handle."""
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class KernelTimer:
+    """Optional per-launch HIP-event timing of named kernels, on the stream they are launched on.
+
+    bench.py sets `KernelTimer.active = KernelTimer()` around its timed region; the operator
+    wrappers then bracket their launches with torch.cuda.Event records (torch events are recorded
+    on torch's current stream, which is the stream the launch uses).  Inactive (None) by default:
+    zero overhead on the training path.
+    """
+
+    active: "KernelTimer | None" = None
+
+    def __init__(self):
+        self.events: dict[str, list] = {}
+
+    @classmethod
+    def start(cls, name: str):
+        if cls.active is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return (name, ev)
+
+    @classmethod
+    def stop(cls, token) -> None:
+        if token is None or cls.active is None:
+            return
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        cls.active.events.setdefault(token[0], []).append((token[1], end))
+
+    def summary(self) -> dict[str, dict]:
+        """name -> {launches, avg_ms, total_ms}; call after torch.cuda.synchronize()."""
+        out = {}
+        for name, pairs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms)}
+        return out

@@ -1,0 +1,168 @@
+"""`BaseModel` — the training-step contract of the reference's LightningModule, without Lightning
+(reference: multi_part_assembly/models/modules/base_model.py:17-464).
+
+Kept: the subclass contract (`forward(data_dict) -> {'rot': Rotation3D, 'trans': Tensor}` plus
+`_loss_function`), `training_step / validation_step / forward_pass / loss_function (MoN) /
+_calc_loss / _match_parts / _linear_sum_assignment / configure_optimizers`, the loss-term names and
+the weighting by `cfg.loss.<term>_w`.  Dropped: everything that needs a pl.Trainer (per-step
+`.item()` logging through `self.trainer.profiler`, base_model.py:137-146 — which also removes one
+device sync per loss term per step), wandb visualisation and the eval-only metrics (SURVEY.md §8
+row N2, next).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+from scipy.optimize import linear_sum_assignment
+
+from .chamfer import chamfer_distance
+from .loss import (rot_cosine_loss, rot_points_cd_loss, rot_points_l2_loss, shape_cd_loss,
+                   trans_l2_loss)
+from .rotation import Rotation3D
+from .transforms import transform_pc
+
+
+class BaseModel(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.rot_type = cfg.model.rot_type
+        if self.rot_type != "quat":
+            raise NotImplementedError(f"rotation {self.rot_type} is not supported")
+        self.pose_dim = 7
+        self.semantic = cfg.data.dataset != "geometry"
+        self.max_num_part = cfg.data.max_num_part
+        self.pc_feat_dim = cfg.model.pc_feat_dim
+        self.use_part_label = "part_label" in cfg.data.data_keys
+        self.sample_iter = cfg.loss.get("sample_iter", 1)
+
+    # ---- hooks a trainer calls ---------------------------------------------------------------
+    def training_step(self, data_dict, batch_idx=0, optimizer_idx=-1):
+        return self.forward_pass(data_dict, mode="train", optimizer_idx=optimizer_idx)["loss"]
+
+    def validation_step(self, data_dict, batch_idx=0):
+        return self.forward_pass(data_dict, mode="val", optimizer_idx=-1)
+
+    test_step = validation_step
+
+    def forward_pass(self, data_dict, mode="train", optimizer_idx=-1):
+        """data_dict as produced by the reference datasets (geometry_data.py:173-207); `part_quat` is
+        wrapped into `part_rot` here, like base_model.py:128-132 (non-destructively)."""
+        data_dict = dict(data_dict)
+        if "part_rot" not in data_dict:
+            data_dict["part_rot"] = Rotation3D(data_dict.pop("part_quat"), rot_type="quat")
+        return self.loss_function(data_dict, optimizer_idx=optimizer_idx)
+
+    # ---- GT <-> prediction matching (semantic datasets only) --------------------------------------
+    @torch.no_grad()
+    def _linear_sum_assignment(self, pts, trans1, rot1, trans2, rot2):
+        """Hungarian match between two pose sets of one equivalence group (base_model.py:150-179):
+        100 sub-sampled points, p x p Chamfer cost matrix on the GPU, scipy on the host."""
+        p, N, _ = pts.shape
+        n = 100
+        sample_idx = torch.randperm(N)[:n].to(pts.device).long()
+        pts = pts[:, sample_idx]
+        pts1 = transform_pc(trans1, rot1, pts, self.rot_type)
+        pts2 = transform_pc(trans2, rot2, pts, self.rot_type)
+        pts1 = pts1[:, None].expand(p, p, n, 3).reshape(-1, n, 3)
+        pts2 = pts2[None].expand(p, p, n, 3).reshape(-1, n, 3)
+        dist1, dist2 = chamfer_distance(pts1, pts2)
+        cost = (dist1.mean(1) + dist2.mean(1)).view(p, p)
+        rind, cind = linear_sum_assignment(cost.cpu().numpy())
+        return (torch.from_numpy(rind).type_as(sample_idx), torch.from_numpy(cind).type_as(sample_idx))
+
+    @torch.no_grad()
+    def _match_parts(self, part_pcs, pred_trans, pred_rot, gt_trans, gt_rot, match_ids):
+        """Permute the GT poses inside every group of geometrically equivalent parts so that they
+        line up with the predictions at minimum Chamfer cost (base_model.py:181-238)."""
+        match_ids = match_ids.long()
+        ids_host = match_ids.cpu().numpy()  # one sync instead of one .item() per sample
+        new_trans = gt_trans.detach().clone()
+        gt_q, pred_q = gt_rot.rot, pred_rot.rot
+        new_q = gt_q.detach().clone()
+        for b in range(part_pcs.shape[0]):
+            for group in range(1, int(ids_host[b].max()) + 1):
+                members = np.nonzero(ids_host[b] == group)[0].tolist()
+                if not members:
+                    continue
+                _, matched = self._linear_sum_assignment(
+                    part_pcs[b, members], pred_trans[b, members], pred_q[b, members],
+                    gt_trans[b, members], new_q[b, members])
+                new_trans[b, members] = gt_trans[b, members][matched]
+                new_q[b, members] = gt_q[b, members][matched]
+        return new_trans, Rotation3D(new_q, rot_type=self.rot_type)
+
+    # ---- loss assembly ------------------------------------------------------------------------------
+    def _calc_loss(self, out_dict, data_dict):
+        """Loss terms of one prediction, each [B] (base_model.py:240-314)."""
+        pred_trans, pred_rot = out_dict["trans"], out_dict["rot"]
+        part_pcs, valids = data_dict["part_pcs"], data_dict["part_valids"]
+        gt_trans, gt_rot = data_dict["part_trans"], data_dict["part_rot"]
+        if self.semantic:
+            new_trans, new_rot = self._match_parts(part_pcs, pred_trans, pred_rot, gt_trans, gt_rot,
+                                                   data_dict["match_ids"])
+        else:
+            new_trans, new_rot = gt_trans.detach(), gt_rot.detach()
+
+        loss_dict = {
+            "trans_loss": trans_l2_loss(pred_trans, new_trans, valids),
+            "rot_pt_cd_loss": rot_points_cd_loss(part_pcs, pred_rot, new_rot, valids),
+        }
+        loss_dict["transform_pt_cd_loss"], pred_pts, gt_pts = shape_cd_loss(
+            part_pcs, pred_trans, new_trans, pred_rot, new_rot, valids, ret_pts=True,
+            training=self.semantic or self.training)
+        if self.cfg.loss.use_rot_loss:
+            loss_dict["rot_loss"] = rot_cosine_loss(pred_rot, new_rot, valids)
+        if self.cfg.loss.use_rot_pt_l2_loss:
+            loss_dict["rot_pt_l2_loss"] = rot_points_l2_loss(part_pcs, pred_rot, new_rot, valids)
+        out_dict = {"pred_trans": pred_trans, "pred_rot": pred_rot, "gt_trans_pts": gt_pts,
+                    "pred_trans_pts": pred_pts}
+        return loss_dict, out_dict
+
+    def _loss_function(self, data_dict, out_dict={}, optimizer_idx=-1):
+        raise NotImplementedError
+
+    def loss_function(self, data_dict, optimizer_idx=-1):
+        """Min-of-N over `sample_iter` stochastic predictions, per sample (base_model.py:348-387)."""
+        samples, out_dict = None, {}
+        for _ in range(self.sample_iter):
+            sample_loss, out_dict = self._loss_function(data_dict, out_dict, optimizer_idx=optimizer_idx)
+            if samples is None:
+                samples = {k: [] for k in sample_loss}
+            for k, v in sample_loss.items():
+                samples[k].append(v)
+        stacked = {k: torch.stack(v, dim=0) for k, v in samples.items()}  # [sample_iter, B]
+        total = 0.0
+        for k, v in stacked.items():
+            if k.endswith("_loss"):
+                total = total + v * self.cfg.loss[f"{k}_w"]
+        stacked["loss"] = total
+        if self.sample_iter == 1:
+            result = {k: v[0].mean() for k, v in stacked.items()}
+        else:
+            best = total.argmin(0)
+            cols = torch.arange(best.shape[0], device=best.device)
+            result = {k: v[best, cols].mean() for k, v in stacked.items()}
+        if not self.training:
+            result["batch_size"] = total.shape[1]
+        return result
+
+    # ---- optimiser ------------------------------------------------------------------------------------
+    def configure_optimizers(self, steps_per_epoch=None):
+        """Adam(lr, wd=0) [AdamW when wd > 0], cosine schedule with warm-up stepped per epoch
+        (base_model.py:389-425).  Returns (optimizer, lr_lambda_or_None)."""
+        from .optim import FusedAdam, cosine_warmup_lr
+
+        opt_cfg = self.cfg.optimizer
+        optimizer = FusedAdam(self.parameters(), lr=opt_cfg.lr, weight_decay=opt_cfg.weight_decay)
+        schedule = None
+        if opt_cfg.lr_scheduler:
+            assert opt_cfg.lr_scheduler == "cosine"
+            total = self.cfg.exp.num_epochs
+            schedule = cosine_warmup_lr(total, int(total * opt_cfg.warmup_ratio), opt_cfg.lr,
+                                        opt_cfg.lr / opt_cfg.lr_decay_factor)
+        return optimizer, schedule
+
+    def _wrap_rotation(self, rot_tensor):
+        return Rotation3D(rot_tensor, rot_type=self.rot_type)

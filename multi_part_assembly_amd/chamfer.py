@@ -58,12 +58,14 @@ def chamfer_forward(xyz1: torch.Tensor, xyz2: torch.Tensor, variant: int | None 
         s = _lib.current_stream(dev)
         args = (_lib.ptr(xyz1), _lib.ptr(xyz2), B, n1, n2, _lib.ptr(dist1), _lib.ptr(idx1),
                 _lib.ptr(dist2), _lib.ptr(idx2))
+        tok = _lib.KernelTimer.start(f"chamfer_forward[{B}x{n1}x{n2}]")
         if xyz1.dtype == torch.float64:
             st = L.mpa_chamfer_forward_f64(*args, s)
         elif variant is None:
             st = L.mpa_chamfer_forward(*args, s)
         else:
             st = L.mpa_chamfer_forward_variant(*args, int(variant), s)
+        _lib.KernelTimer.stop(tok)
     _lib.check(st, "mpa_chamfer_forward")
     return [dist1, idx1, dist2, idx2]
 

@@ -47,7 +47,7 @@ torch.use_deterministic_algorithms(True)
 def npy(t):
     if hasattr(t, "rot"):  # Rotation3D
         t = t.rot
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()  # copy: buffers are updated in place later on
 
 
 def save(name, **arrays):

@@ -1,0 +1,166 @@
+"""Model-level parity on the GPU: PNTransformer step vs the fixture captured from the reference
+(forward_pass + backward on the same weights and batch), encoders / transformer vs their fixtures,
+fused Adam vs torch.optim.Adam, and the Trainer step vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from multi_part_assembly_amd import config
+from multi_part_assembly_amd.encoder import build_encoder
+from multi_part_assembly_amd.optim import FusedAdam
+from multi_part_assembly_amd.pn_transformer import build_model
+from multi_part_assembly_amd.regressor import StocasticPoseRegressor
+from multi_part_assembly_amd.trainer import Trainer
+from multi_part_assembly_amd.transformer import TransformerEncoder
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _load(module, z, prefix):
+    sd = {k[len(prefix):]: T(v.copy()) for k, v in z.items() if k.startswith(prefix)}
+    missing = module.load_state_dict(sd, strict=True)
+    return missing
+
+
+def _no_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+
+
+@pytest.mark.parametrize("name,feat", [("pointnet", 256), ("dgcnn", 128)])
+def test_encoder_matches_reference(golden, cuda_device, name, feat):
+    z = golden(name)
+    enc = build_encoder(name, feat)
+    _load(enc, z, "sd0.")
+    enc.to(cuda_device).train()
+    x = T(z["x"]).to(cuda_device).requires_grad_()
+    out = enc(x)
+    (out * T(z["w"]).to(cuda_device)).sum().backward()
+    assert _rel(out.detach().cpu().numpy(), z["feat_train"]) < 1e-4
+    # DGCNN (library-op path for now): rocBLAS evaluates the Gram-form kNN scores in a different
+    # summation order than the CPU, so a few near-tie neighbours differ (SURVEY.md §7 hard part 3)
+    # and the input gradient — a sum over neighbour edges — moves by ~1e-2 at isolated points.
+    gtol = 1e-3 if name == "pointnet" else 3e-2
+    assert _rel(x.grad.cpu().numpy(), z["grad_x"]) < gtol
+    for k, p in enc.named_parameters():
+        assert _rel(p.grad.cpu().numpy(), z["grad." + k]) < gtol, k
+    for k, v in enc.state_dict().items():  # running statistics after the training-mode forward
+        np.testing.assert_allclose(v.cpu().numpy(), z["sd1." + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    enc.eval()
+    with torch.no_grad():
+        assert _rel(enc(x).cpu().numpy(), z["feat_eval"]) < 1e-4
+
+
+def test_transformer_and_pose_head_match_reference(golden, cuda_device):
+    z = golden("transformer")
+    d, heads, ffn, layers = (int(v) for v in z["cfg"])
+    enc = TransformerEncoder(d, heads, ffn, layers, norm_first=True, dropout=0.0)
+    head = StocasticPoseRegressor(feat_dim=d, noise_dim=0)
+    _load(enc, z, "enc.")
+    _load(head, z, "head.")
+    enc.to(cuda_device).train()
+    head.to(cuda_device).train()
+    tok = T(z["tokens"]).to(cuda_device).requires_grad_()
+    valid = T(z["valid"]).to(cuda_device)
+    feats = enc(tok, valid)
+    rot, trans = head(feats)
+    vm = valid[..., None].float()
+    ((rot * T(z["w_rot"]).to(cuda_device) * vm).sum() + (trans * T(z["w_trans"]).to(cuda_device) * vm).sum()).backward()
+    v = z["valid"]
+    assert _rel(feats.detach().cpu().numpy()[v], z["feats"][v]) < 1e-4
+    assert _rel(rot.detach().cpu().numpy()[v], z["rot"][v]) < 1e-4
+    assert _rel(trans.detach().cpu().numpy()[v], z["trans"][v]) < 1e-4
+    for k, p in enc.named_parameters():
+        assert _rel(p.grad.cpu().numpy(), z["genc." + k]) < 1e-3, k
+    for k, p in head.named_parameters():
+        assert _rel(p.grad.cpu().numpy(), z["ghead." + k]) < 1e-3, k
+
+
+def _small_cfg(z):
+    d, heads, ffn, layers = (int(v) for v in z["cfg"])
+    cfg = config.pn_transformer_everyday()
+    cfg.model.pc_feat_dim, cfg.model.transformer_heads = d, heads
+    cfg.model.transformer_feat_dim, cfg.model.transformer_layers = ffn, layers
+    cfg.data.max_num_part = 5
+    return cfg
+
+
+def test_pn_transformer_step_matches_reference(golden, cuda_device):
+    z = golden("pn_transformer_step")
+    model = build_model(_small_cfg(z))
+    _load(model, z, "sd0.")
+    _no_dropout(model)
+    model.to(cuda_device).train()
+    batch = {k[5:]: T(v).to(cuda_device) for k, v in z.items() if k.startswith("data.")}
+    losses = model.forward_pass(batch, mode="train")
+    losses["loss"].backward()
+    for k in ("trans_loss", "rot_pt_cd_loss", "transform_pt_cd_loss", "rot_loss", "rot_pt_l2_loss", "loss"):
+        np.testing.assert_allclose(float(losses[k]), float(z["loss." + k]), rtol=1e-4, err_msg=k)
+    assert "part_quat" in batch  # forward_pass must not mutate the caller's dict
+    for k, p in model.named_parameters():
+        assert _rel(p.grad.cpu().numpy(), z["grad." + k]) < 2e-3, k
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.cpu().numpy(), z["sd1." + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    with torch.no_grad():
+        feats = model._extract_part_feats(batch["part_pcs"], batch["part_valids"])
+    assert _rel(feats.cpu().numpy(), z["act.pc_feats"]) < 1e-4
+
+
+def test_fused_adam_matches_torch_adam(cuda_device):
+    torch.manual_seed(0)
+    ref_p = [torch.randn(37, 5, device=cuda_device), torch.randn(11, device=cuda_device), torch.randn(3, 3, 3, device=cuda_device)]
+    for wd in (0.0, 0.01):
+        mine = [torch.nn.Parameter(p.clone()) for p in ref_p]
+        theirs = [torch.nn.Parameter(p.clone()) for p in ref_p]
+        opt = FusedAdam(mine, lr=1e-2, weight_decay=wd)
+        topt = (torch.optim.AdamW if wd > 0 else torch.optim.Adam)(theirs, lr=1e-2, weight_decay=wd)
+        for step in range(5):
+            opt.zero_grad()
+            topt.zero_grad()
+            gs = [torch.randn_like(p) for p in ref_p]
+            for a, b, g in zip(mine, theirs, gs):
+                a.grad.copy_(g)
+                b.grad = g.clone()
+            opt.step()
+            topt.step()
+        for a, b in zip(mine, theirs):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+
+
+def test_trainer_step_matches_oracle_step(golden, cuda_device):
+    """Full optimiser step: the updated parameters must equal the oracle's (CPU autograd + Adam)."""
+    from oracle import nets as on
+
+    z = golden("pn_transformer_step")
+    cfg = _small_cfg(z)
+    cfg.optimizer.lr_scheduler = ""  # constant lr = 1e-3 so the oracle step is directly comparable
+    model = build_model(cfg)
+    _load(model, z, "sd0.")
+    _no_dropout(model)
+    model.to(cuda_device)
+    trainer = Trainer(model, cfg)
+    batch = {k[5:]: T(v).to(cuda_device) for k, v in z.items() if k.startswith("data.")}
+    loss = trainer.train_step(batch)
+    np.testing.assert_allclose(float(loss), float(z["loss.loss"]), rtol=1e-4)
+
+    sd = {k[4:]: T(v.copy()) for k, v in z.items() if k.startswith("sd0.")}
+    names = [k for k, _ in model.named_parameters()]
+    params = {k: sd[k].requires_grad_() for k in names}
+    cpu_batch = {k[5:]: T(v) for k, v in z.items() if k.startswith("data.")}
+    losses, _ = on.pn_transformer_loss(sd, cpu_batch, cfg.model.transformer_layers, cfg.model.transformer_heads)
+    losses["loss"].backward()
+    on.adam_step(params, {k: p.grad for k, p in params.items()}, {}, lr=cfg.optimizer.lr)
+    for k, p in model.named_parameters():
+        # Adam's first step moves every weight by ~lr*sign(g): compare the UPDATE, not the weight
+        got = p.detach().cpu().numpy() - z["sd0." + k]
+        want = params[k].detach().numpy() - z["sd0." + k]
+        assert np.abs(got - want).max() < 2e-4 * cfg.optimizer.lr * 10 + 1e-7, k

@@ -100,3 +100,89 @@ def test_losses_match_reference(golden, name):
     np.testing.assert_allclose(gt, z[name + "_gtrans"], rtol=1e-4, atol=1e-6)
     for i, e in enumerate(extra):
         np.testing.assert_array_equal(e.detach().numpy(), z[f"{name}_pts{i + 1}"])
+
+
+# ---- network half (oracle/nets.py) -------------------------------------------------------------
+from oracle import nets as on  # noqa: E402
+
+
+def _sd(z, prefix, grad=False):
+    out = {}
+    for k, v in z.items():
+        if k.startswith(prefix):
+            t = T(v.copy())
+            if grad and t.is_floating_point() and "running" not in k:
+                t.requires_grad_()
+            out[k[len(prefix):]] = t
+    return out
+
+
+@pytest.mark.parametrize("name,fn", [("pointnet", on.pointnet), ("dgcnn", on.dgcnn)])
+def test_encoders_match_reference(golden, name, fn):
+    z = golden(name)
+    sd = _sd(z, "sd0.", grad=True)
+    x = T(z["x"]).clone().requires_grad_()
+    stats = {}
+    feat = fn(x, sd, "", True, stats)
+    (feat * T(z["w"])).sum().backward()
+    np.testing.assert_allclose(feat.detach().numpy(), z["feat_train"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x.grad.numpy(), z["grad_x"], rtol=1e-4, atol=1e-5)
+    for k, t in sd.items():
+        if t.requires_grad and "grad." + k in z:  # DGCNN lists each BN twice; grads saved once
+            scale = np.abs(z["grad." + k]).max() + 1e-12
+            assert np.abs(t.grad.numpy() - z["grad." + k]).max() / scale < 1e-4, k
+    for k, v in stats.items():  # running statistics after one training-mode forward
+        np.testing.assert_allclose(v.numpy(), z["sd1." + k], rtol=1e-5, atol=1e-6)
+    sd1 = _sd(z, "sd1.")
+    with torch.no_grad():
+        np.testing.assert_allclose(fn(T(z["x"]), sd1, "", False).numpy(), z["feat_eval"], rtol=1e-5, atol=1e-5)
+
+
+def test_dgcnn_knn_sets_match_reference(golden):
+    z = golden("dgcnn")
+    idx = on.knn_indices(T(z["x"]).transpose(2, 1).contiguous(), 20).numpy()
+    want = z["knn_idx_layer1"]
+    assert (np.sort(idx, -1) == np.sort(want, -1)).all()
+
+
+def test_transformer_and_pose_head_match_reference(golden):
+    z = golden("transformer")
+    d, heads, ffn, layers = (int(v) for v in z["cfg"])
+    enc, head = _sd(z, "enc.", grad=True), _sd(z, "head.", grad=True)
+    tok = T(z["tokens"]).clone().requires_grad_()
+    valid = T(z["valid"])
+    feats = on.transformer_encoder(tok, valid, enc, "", layers, heads)
+    rot, trans = on.pose_head(feats, head, "")
+    vm = valid[..., None].float()
+    ((rot * T(z["w_rot"]) * vm).sum() + (trans * T(z["w_trans"]) * vm).sum()).backward()
+    v = z["valid"]
+    np.testing.assert_allclose(feats.detach().numpy()[v], z["feats"][v], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rot.detach().numpy()[v], z["rot"][v], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(trans.detach().numpy()[v], z["trans"][v], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(tok.grad.numpy()[v], z["grad_tokens"][v], rtol=1e-3, atol=1e-5)
+    for k, t in enc.items():
+        scale = np.abs(z["genc." + k]).max() + 1e-12
+        assert np.abs(t.grad.numpy() - z["genc." + k]).max() / scale < 1e-4, k
+    for k, t in head.items():
+        scale = np.abs(z["ghead." + k]).max() + 1e-12
+        assert np.abs(t.grad.numpy() - z["ghead." + k]).max() / scale < 1e-4, k
+
+
+def test_full_pn_transformer_step_matches_reference(golden):
+    z = golden("pn_transformer_step")
+    d, heads, ffn, layers = (int(v) for v in z["cfg"])
+    sd = _sd(z, "sd0.", grad=True)
+    batch = {k[5:]: T(v) for k, v in z.items() if k.startswith("data.")}
+    stats = {}
+    losses, out = on.pn_transformer_loss(sd, batch, layers, heads, training=True, stats_out=stats)
+    losses["loss"].backward()
+    for k, v in losses.items():
+        np.testing.assert_allclose(float(v), float(z["loss." + k]), rtol=1e-4, err_msg=k)
+    np.testing.assert_allclose(out["pc_feats"].detach().numpy(), z["act.pc_feats"], rtol=1e-4, atol=1e-5)
+    vmask = z["data.part_valids"] == 1
+    np.testing.assert_allclose(out["rot"].detach().numpy()[vmask], z["act.pred_rot"][vmask], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["trans"].detach().numpy()[vmask], z["act.pred_trans"][vmask], rtol=1e-4, atol=1e-5)
+    for k, t in sd.items():
+        if t.requires_grad:
+            scale = np.abs(z["grad." + k]).max() + 1e-12
+            assert np.abs(t.grad.numpy() - z["grad." + k]).max() / scale < 2e-3, (k, scale)
