@@ -52,8 +52,9 @@ const char* mpa_last_error(void);
 int mpa_chamfer_forward(const float* xyz1, const float* xyz2, int64_t batch, int64_t n1, int64_t n2,
                         float* dist1, int64_t* idx1, float* dist2, int64_t* idx2, void* stream);
 
-/* Diagnostic twin of mpa_chamfer_forward that pins the kernel variant: 0 = direct evaluation of the
- * pinned arithmetic, 1 = fused-form filter + pinned recheck (the default; bit-identical results). */
+/* Diagnostic twin of mpa_chamfer_forward that pins the scan variant (all bit-identical in their
+ * results): 0 = direct compare/select per pair, 1 = fused-form gate + exact recheck (fastest on
+ * tie-free clouds), 2 = exact chunk-minimum scan (the default: insensitive to duplicated points). */
 int mpa_chamfer_forward_variant(const float* xyz1, const float* xyz2, int64_t batch, int64_t n1,
                                 int64_t n2, float* dist1, int64_t* idx1, float* dist2,
                                 int64_t* idx2, int variant, void* stream);
@@ -105,6 +106,40 @@ int mpa_pose_apply_forward(const float* pc, const float* quat, const float* tran
 int mpa_pose_apply_backward(const float* grad_out, const float* pc, const float* quat,
                             const float* mask, float fill, int64_t num_parts, int64_t num_points,
                             float* grad_quat, float* grad_trans, float* grad_pc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused geometric-assembly loss — replaces, for the geometric datasets, the loss half of
+ *   BaseModel._calc_loss : multi_part_assembly/models/modules/base_model.py:240-314
+ * i.e. trans_l2_loss, rot_cosine_loss, rot_points_l2_loss, rot_points_cd_loss, shape_cd_loss
+ * (utils/loss.py:22-35,59-202) together with their rot_pc / transform_pc / chamfer_distance calls and
+ * the autograd graph behind them.  Same values as composing mpa_pose_apply_* and mpa_chamfer_*,
+ * without touching padded slots: padded target parts enter the whole-shape search as ONE
+ * representative point (all their points coincide after the 1e3 fill), padded query points are
+ * skipped (the loss multiplies their distances by zero).
+ *
+ * part_pcs [B,P,N,3]; valids [B,P] (1/0); quat_* [B,P,4] real-first, already passed through
+ * Rotation3D's zero-quaternion rule; trans_* [B,P,3].  P <= 64.
+ * losses [5,B]: 0 trans_loss, 1 rot_pt_cd_loss, 2 transform_pt_cd_loss, 3 rot_loss, 4 rot_pt_l2_loss
+ * (names of base_model.py:283-298), `training` selects the whole-shape normalisation of
+ * utils/loss.py:185-198.  The caller provides the workspaces sized by mpa_assembly_loss_workspace
+ * and keeps them untouched until the backward call.  The four transformed clouds are the first
+ * 4*B*P*N*3 floats of float_ws: rot(pred), rot(gt), transform(pred), transform(gt), each [B,P,N,3];
+ * with fill_pad_points != 0 the padded parts of the last two are filled completely (the `ret_pts`
+ * outputs of shape_cd_loss), otherwise only their first point is defined.
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_assembly_loss_workspace(int64_t B, int64_t P, int64_t N, int64_t* float_elems,
+                                int64_t* int_elems);
+int mpa_assembly_loss_forward(const float* part_pcs, const float* valids, const float* quat_pred,
+                              const float* trans_pred, const float* quat_gt, const float* trans_gt,
+                              int64_t B, int64_t P, int64_t N, int training, int fill_pad_points,
+                              float* float_ws, int32_t* int_ws, float* losses, void* stream);
+/* grad_losses [5,B] = d(objective)/d(losses); writes grad_quat [B,P,4] and grad_trans [B,P,3] of the
+ * PREDICTED pose.  Deterministic (no atomics). */
+int mpa_assembly_loss_backward(const float* grad_losses, const float* part_pcs, const float* valids,
+                               const float* quat_pred, const float* trans_pred, const float* quat_gt,
+                               const float* trans_gt, int64_t B, int64_t P, int64_t N, int training,
+                               const float* float_ws, const int32_t* int_ws, float* grad_quat,
+                               float* grad_trans, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused optimiser step — replaces torch.optim.Adam / AdamW as configured by

@@ -34,6 +34,9 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_chamfer_backward_f64": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_pose_apply_forward": (_INT, [_P, _P, _P, _P, _F32, _I64, _I64, _P, _P]),
     "mpa_pose_apply_backward": (_INT, [_P, _P, _P, _P, _F32, _I64, _I64, _P, _P, _P, _P]),
+    "mpa_assembly_loss_workspace": (_INT, [_I64, _I64, _I64, _P, _P]),
+    "mpa_assembly_loss_forward": (_INT, [_P] * 6 + [_I64, _I64, _I64, _INT, _INT, _P, _P, _P, _P]),
+    "mpa_assembly_loss_backward": (_INT, [_P] * 7 + [_I64, _I64, _I64, _INT, _P, _P, _P, _P, _P]),
     "mpa_adam_step": (_INT, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _INT, _I64, _F32, _P]),
 }
 

@@ -17,8 +17,8 @@ import torch.nn as nn
 from scipy.optimize import linear_sum_assignment
 
 from .chamfer import chamfer_distance
-from .loss import (rot_cosine_loss, rot_points_cd_loss, rot_points_l2_loss, shape_cd_loss,
-                   trans_l2_loss)
+from .loss import (geometric_assembly_loss, rot_cosine_loss, rot_points_cd_loss,
+                   rot_points_l2_loss, shape_cd_loss, trans_l2_loss)
 from .rotation import Rotation3D
 from .transforms import transform_pc
 
@@ -36,6 +36,11 @@ class BaseModel(nn.Module):
         self.pc_feat_dim = cfg.model.pc_feat_dim
         self.use_part_label = "part_label" in cfg.data.data_keys
         self.sample_iter = cfg.loss.get("sample_iter", 1)
+        # fused HIP loss path for geometric data (csrc/assembly_loss.hip); the per-function path is
+        # kept for the semantic datasets and as a cross-check.  keep_pts: also return the transformed
+        # clouds (only visualisation needs them).
+        self.fused_loss = True
+        self.keep_pts = False
 
     # ---- hooks a trainer calls ---------------------------------------------------------------
     def training_step(self, data_dict, batch_idx=0, optimizer_idx=-1):
@@ -104,6 +109,18 @@ class BaseModel(nn.Module):
                                                    data_dict["match_ids"])
         else:
             new_trans, new_rot = gt_trans.detach(), gt_rot.detach()
+        if self.fused_loss and not self.semantic:
+            # one fused forward/backward pair instead of the per-function composition below
+            terms, pts = geometric_assembly_loss(part_pcs, pred_trans, pred_rot, new_trans, new_rot,
+                                                 valids, training=self.training, ret_pts=self.keep_pts)
+            loss_dict = {k: terms[k] for k in ("trans_loss", "rot_pt_cd_loss", "transform_pt_cd_loss")}
+            if self.cfg.loss.use_rot_loss:
+                loss_dict["rot_loss"] = terms["rot_loss"]
+            if self.cfg.loss.use_rot_pt_l2_loss:
+                loss_dict["rot_pt_l2_loss"] = terms["rot_pt_l2_loss"]
+            out_dict = {"pred_trans": pred_trans, "pred_rot": pred_rot,
+                        "pred_trans_pts": pts[0] if pts else None, "gt_trans_pts": pts[1] if pts else None}
+            return loss_dict, out_dict
 
         loss_dict = {
             "trans_loss": trans_l2_loss(pred_trans, new_trans, valids),

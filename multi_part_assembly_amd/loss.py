@@ -9,10 +9,13 @@ from __future__ import annotations
 
 import torch
 
+import ctypes
+
+from . import _lib
 from .chamfer import chamfer_distance
 from .transforms import pose_apply, rot_pc
 
-__all__ = ["trans_l2_loss", "rot_l2_loss", "rot_cosine_loss", "rot_points_l2_loss",
+__all__ = ["geometric_assembly_loss", "LOSS_TERMS", "trans_l2_loss", "rot_l2_loss", "rot_cosine_loss", "rot_points_l2_loss",
            "rot_points_cd_loss", "shape_cd_loss", "repulsion_cd_loss"]
 
 PAD_FILL = 1e3  # coordinate given to the points of padded parts in shape_cd_loss (loss.py:173-175)
@@ -96,3 +99,73 @@ def repulsion_cd_loss(part_pcs, valids, thre):
     cd = (thre - (dist1.mean(1) + dist2.mean(1)).view(B, P, P)).clamp_min(0.0)
     pair = (valids[:, :, None] * valids[:, None, :]).type_as(cd)
     return (cd * pair).sum([1, 2]) / pair.sum([1, 2])
+
+
+# ---- fused path ------------------------------------------------------------------------------------
+LOSS_TERMS = ("trans_loss", "rot_pt_cd_loss", "transform_pt_cd_loss", "rot_loss", "rot_pt_l2_loss")
+
+
+class _AssemblyLoss(torch.autograd.Function):
+    """All five geometric loss terms in 5 launches forward / 1 launch backward (csrc/assembly_loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, training, fill_pads):
+        B, P, N, _ = part_pcs.shape
+        dev = part_pcs.device
+        L = _lib.lib()
+        nf, ni = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(L.mpa_assembly_loss_workspace(B, P, N, ctypes.byref(nf), ctypes.byref(ni)),
+                   "mpa_assembly_loss_workspace")
+        fws = torch.empty(nf.value, dtype=torch.float32, device=dev)
+        iws = torch.empty(ni.value, dtype=torch.int32, device=dev)
+        losses = torch.empty((5, B), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"assembly_loss_forward[{B}x{P}x{N}]")
+            st = L.mpa_assembly_loss_forward(
+                _lib.ptr(part_pcs), _lib.ptr(valids), _lib.ptr(quat_pred), _lib.ptr(trans_pred),
+                _lib.ptr(quat_gt), _lib.ptr(trans_gt), B, P, N, int(training), int(fill_pads),
+                _lib.ptr(fws), _lib.ptr(iws), _lib.ptr(losses), _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_assembly_loss_forward")
+        ctx.save_for_backward(part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, fws, iws)
+        ctx.training = int(training)
+        cloud = B * P * N * 3
+        pts = fws[: 4 * cloud].view(4, B, P, N, 3)
+        ctx.mark_non_differentiable(pts)
+        return losses, pts
+
+    @staticmethod
+    def backward(ctx, grad_losses, _grad_pts):
+        part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, fws, iws = ctx.saved_tensors
+        B, P, N, _ = part_pcs.shape
+        dev = part_pcs.device
+        gq = torch.empty_like(quat_pred)
+        gt = torch.empty_like(trans_pred)
+        grad_losses = grad_losses.contiguous()
+        with torch.cuda.device(dev):
+            st = _lib.lib().mpa_assembly_loss_backward(
+                _lib.ptr(grad_losses), _lib.ptr(part_pcs), _lib.ptr(valids), _lib.ptr(quat_pred),
+                _lib.ptr(trans_pred), _lib.ptr(quat_gt), _lib.ptr(trans_gt), B, P, N, ctx.training,
+                _lib.ptr(fws), _lib.ptr(iws), _lib.ptr(gq), _lib.ptr(gt), _lib.current_stream(dev))
+        _lib.check(st, "mpa_assembly_loss_backward")
+        return None, None, gq, gt, None, None, None, None
+
+
+def geometric_assembly_loss(part_pcs, pred_trans, pred_rot, gt_trans, gt_rot, valids, training=True,
+                            ret_pts=False):
+    """The loss terms of `BaseModel._calc_loss` for geometric data, fused (no GT re-matching).
+
+    Returns ({name: [B]} for LOSS_TERMS, pts) where pts is None or, with ret_pts,
+    (pred_trans_pts, gt_trans_pts) [B,P,N,3] as shape_cd_loss(..., ret_pts=True) returns them.
+    Gradients flow to pred_trans and pred_rot only (the GT pose is detached, as in the reference).
+    """
+    if not part_pcs.is_cuda:
+        raise RuntimeError("geometric_assembly_loss: only CUDA (HIP) tensors are supported")
+    B, P, N, _ = part_pcs.shape
+    f = lambda t: t.detach().to(torch.float32).contiguous()
+    losses, pts = _AssemblyLoss.apply(
+        f(part_pcs), f(valids), _quat(pred_rot).to(torch.float32).contiguous(),
+        pred_trans.to(torch.float32).contiguous(), f(_quat(gt_rot)), f(gt_trans), bool(training),
+        bool(ret_pts))
+    terms = {name: losses[i] for i, name in enumerate(LOSS_TERMS)}
+    return terms, ((pts[2], pts[3]) if ret_pts else None)

@@ -18,7 +18,7 @@ def _dev(x, dev):
 
 
 @pytest.mark.parametrize("case", ["a", "b", "c", "d", "hand", "tie"])
-@pytest.mark.parametrize("variant", [0, 1, None])
+@pytest.mark.parametrize("variant", [0, 1, 2, None])
 def test_forward_matches_golden(golden, cuda_device, case, variant):
     z = golden("chamfer")
     out = C.chamfer_forward(_dev(z[f"{case}_xyz1"], cuda_device), _dev(z[f"{case}_xyz2"], cuda_device),
@@ -36,7 +36,7 @@ def test_forward_matches_oracle_ragged(cuda_device, shape):
     a = rng.standard_normal((B, n1, 3)).astype(np.float32)
     b = rng.standard_normal((B, n2, 3)).astype(np.float32)
     ref = oc.chamfer_forward(a, b)
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         out = C.chamfer_forward(_dev(a, cuda_device), _dev(b, cuda_device), variant=variant)
         for got, want in zip(out, ref):
             np.testing.assert_array_equal(got.cpu().numpy(), want)
@@ -125,7 +125,7 @@ def test_autocast_keeps_fp32(cuda_device):
 
 def test_full_size_properties(cuda_device):
     """BASELINE sizes, checked through size-independent properties instead of the (slow) oracle:
-    (1) both kernel variants agree bit for bit; (2) dist equals the distance to the returned index
+    (1) all three scan variants agree bit for bit; (2) dist equals the distance to the returned index
     recomputed in torch; (3) symmetry: swapping the clouds swaps the outputs; (4) a cloud against
     itself gives zero distance and the identity (lowest duplicate) index."""
     g = torch.Generator().manual_seed(21)
@@ -134,8 +134,9 @@ def test_full_size_properties(cuda_device):
         b = (torch.rand(B, n, 3, generator=g) - 0.5).to(cuda_device)
         o0 = C.chamfer_forward(a, b, variant=0)
         o1 = C.chamfer_forward(a, b, variant=1)
-        for x, y in zip(o0, o1):
-            assert torch.equal(x, y)
+        o2 = C.chamfer_forward(a, b, variant=2)
+        for x, y, w in zip(o0, o1, o2):
+            assert torch.equal(x, y) and torch.equal(x, w)
         d1, i1, d2, i2 = o1
         near = torch.gather(b, 1, i1[..., None].expand(-1, -1, 3))
         diff = a - near
