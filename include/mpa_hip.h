@@ -142,6 +142,35 @@ int mpa_assembly_loss_backward(const float* grad_losses, const float* part_pcs, 
                                float* grad_trans, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * PointNet part encoder — replaces
+ *   PointNet.forward           : multi_part_assembly/models/modules/encoder/pointnet.py:29-41
+ *   _extract_part_feats        : multi_part_assembly/models/pn_transformer/network.py:59-68
+ *                                (boolean-mask compaction + scatter; here: mask in, zeros out)
+ * 5 x [1x1 conv (no bias) -> BatchNorm1d -> ReLU (none after the last)], widths 3-64-64-64-128-F,
+ * max over the N points of every part.  F must be a multiple of 64.
+ *
+ * points [M,N,3]; valids [M] (1/0): padded parts are skipped everywhere (they do not enter the
+ * BatchNorm statistics) and get feat = 0.  conv_w[l] = [C_l, C_{l-1}] row-major (the Conv1d weight
+ * with its trailing 1 dropped), bn_w / bn_b / running_mean / running_var [C_l], l = 0..4 — HOST
+ * arrays of 5 DEVICE pointers each.  training != 0: batch statistics (biased variance) and running
+ * statistics updated in place with `momentum` (unbiased variance), else running statistics.
+ * feat [M,F].  Workspaces sized by mpa_pointnet_workspace must stay untouched until backward.
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_pointnet_workspace(int64_t M, int64_t N, int64_t F, int64_t* float_elems, int64_t* int_elems);
+int mpa_pointnet_forward(const float* points, const float* valids, const float* const* conv_w,
+                         const float* const* bn_w, const float* const* bn_b,
+                         float* const* running_mean, float* const* running_var, int training,
+                         float momentum, float eps, int64_t M, int64_t N, int64_t F, float* float_ws,
+                         int32_t* int_ws, float* feat, void* stream);
+/* Training-mode backward: grad_feat [M,F] -> grad_conv_w[l] [C_l, C_{l-1}], grad_bn_w[l], grad_bn_b[l]
+ * (host arrays of 5 device pointers; every buffer is overwritten).  No gradient w.r.t. the points.
+ * Deterministic: two-stage reductions, no atomics. */
+int mpa_pointnet_backward(const float* grad_feat, const float* points, const float* valids,
+                          const float* const* conv_w, const float* const* bn_w, int64_t M, int64_t N,
+                          int64_t F, float* float_ws, const int32_t* int_ws, float* const* grad_conv_w,
+                          float* const* grad_bn_w, float* const* grad_bn_b, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused optimiser step — replaces torch.optim.Adam / AdamW as configured by
  *   BaseModel.configure_optimizers : multi_part_assembly/models/modules/base_model.py:389-406
  * One streaming pass over flat, 16-byte-aligned fp32 buffers of `numel` elements (parameters,

@@ -37,6 +37,9 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_assembly_loss_workspace": (_INT, [_I64, _I64, _I64, _P, _P]),
     "mpa_assembly_loss_forward": (_INT, [_P] * 6 + [_I64, _I64, _I64, _INT, _INT, _P, _P, _P, _P]),
     "mpa_assembly_loss_backward": (_INT, [_P] * 7 + [_I64, _I64, _I64, _INT, _P, _P, _P, _P, _P]),
+    "mpa_pointnet_workspace": (_INT, [_I64, _I64, _I64, _P, _P]),
+    "mpa_pointnet_forward": (_INT, [_P] * 7 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "mpa_pointnet_backward": (_INT, [_P] * 5 + [_I64, _I64, _I64] + [_P] * 6),
     "mpa_adam_step": (_INT, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _INT, _I64, _F32, _P]),
 }
 
@@ -81,6 +84,11 @@ def check(status: int, what: str) -> None:
     if status != 0:
         msg = lib().mpa_last_error().decode("utf-8", "replace")
         raise MpaError(f"{what} failed (status {status}): {msg}")
+
+
+def ptr_array(tensors) -> ctypes.Array:
+    """Host array of raw device pointers (for the `const float* const*` parameters)."""
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
 def ptr(t: torch.Tensor | None) -> int | None:

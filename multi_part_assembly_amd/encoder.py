@@ -6,18 +6,84 @@ reference checkpoint loads unchanged (DGCNN registers every BatchNorm under two 
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
+
+
+class _PointNetFn(torch.autograd.Function):
+    """PointNet forward/backward on the HIP library (csrc/pointnet.hip)."""
+
+    @staticmethod
+    def forward(ctx, points, valids, training, momentum, eps, running, *params):
+        conv_w, bn_w, bn_b = params[0:5], params[5:10], params[10:15]
+        run_mean, run_var = running
+        M, N, _ = points.shape
+        F_ = conv_w[4].shape[0]
+        dev = points.device
+        L = _lib.lib()
+        nf, ni = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(L.mpa_pointnet_workspace(M, N, F_, ctypes.byref(nf), ctypes.byref(ni)),
+                   "mpa_pointnet_workspace")
+        fws = torch.empty(nf.value, dtype=torch.float32, device=dev)
+        iws = torch.empty(ni.value, dtype=torch.int32, device=dev)
+        feat = torch.empty((M, F_), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"pointnet_forward[{M}x{N}x{F_}]")
+            st = L.mpa_pointnet_forward(
+                _lib.ptr(points), _lib.ptr(valids), _lib.ptr_array(conv_w), _lib.ptr_array(bn_w),
+                _lib.ptr_array(bn_b), _lib.ptr_array(run_mean), _lib.ptr_array(run_var), int(training),
+                float(momentum), float(eps), M, N, F_, _lib.ptr(fws), _lib.ptr(iws), _lib.ptr(feat),
+                _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_pointnet_forward")
+        ctx.training = bool(training)
+        ctx.save_for_backward(points, valids, fws, iws, *conv_w, *bn_w)
+        return feat
+
+    @staticmethod
+    def backward(ctx, grad_feat):
+        if not ctx.training:
+            raise RuntimeError("PointNet: backward is implemented for training-mode BatchNorm only")
+        points, valids, fws, iws, *rest = ctx.saved_tensors
+        conv_w, bn_w = rest[0:5], rest[5:10]
+        M, N, _ = points.shape
+        F_ = conv_w[4].shape[0]
+        dev = points.device
+        g_conv = [torch.empty_like(w) for w in conv_w]
+        g_bnw = [torch.empty_like(w) for w in bn_w]
+        g_bnb = [torch.empty_like(w) for w in bn_w]
+        grad_feat = grad_feat.contiguous()
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"pointnet_backward[{M}x{N}x{F_}]")
+            st = _lib.lib().mpa_pointnet_backward(
+                _lib.ptr(grad_feat), _lib.ptr(points), _lib.ptr(valids), _lib.ptr_array(conv_w),
+                _lib.ptr_array(bn_w), M, N, F_, _lib.ptr(fws), _lib.ptr(iws), _lib.ptr_array(g_conv),
+                _lib.ptr_array(g_bnw), _lib.ptr_array(g_bnb), _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_pointnet_backward")
+        return (None, None, None, None, None, None, *g_conv, *g_bnw, *g_bnb)
+
 
 class PointNet(nn.Module):
-    """Shared MLP 3-64-64-64-128-F (1x1 conv, no bias, BN, ReLU except after the last) + max over N."""
+    """Shared MLP 3-64-64-64-128-F (1x1 conv, no bias, BN, ReLU except after the last) + max over N.
+
+    The Conv1d / BatchNorm1d sub-modules only hold the parameters and buffers (so state_dict keys and
+    shapes equal the reference's); the computation runs on csrc/pointnet.hip.  `forward_parts` is the
+    sync-free entry the assembly models use: all B*P part slots plus the validity mask."""
 
     WIDTHS = (3, 64, 64, 64, 128)
 
     def __init__(self, feat_dim, global_feat=True):
         super().__init__()
+        if not global_feat:
+            raise NotImplementedError("per-point PointNet features are outside the hot path")
+        if feat_dim % 64 != 0:
+            raise NotImplementedError("the HIP PointNet needs feat_dim to be a multiple of 64")
         dims = (*self.WIDTHS, feat_dim)
         for i in range(5):
             setattr(self, f"conv{i + 1}", nn.Conv1d(dims[i], dims[i + 1], kernel_size=1, bias=False))
@@ -25,13 +91,25 @@ class PointNet(nn.Module):
             setattr(self, f"bn{i + 1}", nn.BatchNorm1d(dims[i + 1]))
         self.global_feat = global_feat
 
+    def forward_parts(self, part_pcs, valids):
+        """part_pcs [M, N, 3], valids [M] (1/0) -> [M, feat_dim]; rows of padded parts are zero."""
+        if not part_pcs.is_cuda:
+            raise RuntimeError("PointNet: only CUDA (HIP) tensors are supported — no CPU fallback")
+        convs = [getattr(self, f"conv{i}") for i in range(1, 6)]
+        bns = [getattr(self, f"bn{i}") for i in range(1, 6)]
+        if self.training:
+            with torch.no_grad():
+                for bn in bns:
+                    bn.num_batches_tracked += 1
+        running = ([bn.running_mean for bn in bns], [bn.running_var for bn in bns])
+        return _PointNetFn.apply(
+            part_pcs.detach().float().contiguous(), valids.detach().float().contiguous(), self.training,
+            bns[0].momentum, bns[0].eps, running, *[c.weight for c in convs], *[b.weight for b in bns],
+            *[b.bias for b in bns])
+
     def forward(self, x):
-        h = x.transpose(2, 1).contiguous()  # [n, 3, N]
-        for i in range(1, 6):
-            h = getattr(self, f"bn{i}")(getattr(self, f"conv{i}")(h))
-            if i < 5:
-                h = F.relu(h)
-        return h.max(dim=-1)[0] if self.global_feat else h.transpose(2, 1).contiguous()
+        """x [n, N, 3] (every part valid) -> [n, feat_dim]; the reference's signature."""
+        return self.forward_parts(x, torch.ones(x.shape[0], device=x.device))
 
 
 def knn(x, k):

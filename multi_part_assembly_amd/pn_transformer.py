@@ -35,6 +35,9 @@ class PNTransformer(BaseModel):
     def _extract_part_feats(self, part_pcs, part_valids):
         """[B, P, N, 3] -> [B, P, C]; padded slots get zeros (network.py:59-68)."""
         B, P, N, _ = part_pcs.shape
+        if hasattr(self.encoder, "forward_parts"):  # HIP PointNet: mask in, zeros out, no host sync
+            feats = self.encoder.forward_parts(part_pcs.reshape(B * P, N, 3), part_valids.reshape(-1))
+            return feats.view(B, P, self.pc_feat_dim)
         valid = (part_valids == 1).reshape(-1)
         slots = torch.nonzero(valid, as_tuple=False).squeeze(1)          # [n] flat part indices
         feats = self.encoder(part_pcs.reshape(B * P, N, 3).index_select(0, slots))
