@@ -6,29 +6,33 @@
 // kernels take ALL B*P part slots plus the validity mask and simply skip padded parts, so launch
 // shapes are static and no device->host sync is needed.
 //
-// Design ("scalar-weight FMA panels", the same scalar-cache idea as chamfer_core.h):
-//   * fp32 throughout (parity bar 1e-4; gfx950's fp32 MFMA has the same peak as the fp32 VALU).
-//   * activations are point-major  [row = part*N + point][channel]  so one LANE owns one point (row):
-//     its 64 output channels live in 64 accumulator VGPRs, the weight W[k][c0..c0+63] of the current
-//     input channel k is wave-uniform and arrives through the scalar cache in 64 SGPRs, and the inner
-//     loop is 64 independent v_fmac_f32 with a scalar operand — no LDS traffic and no cross-lane
-//     shuffles in the main loop.
-//   * per 64x64 output panel the wave transposes through LDS once: that gives coalesced row stores
-//     AND the per-channel column sums BatchNorm needs (sum, sum of squares) in the same pass.
-//   * BatchNorm+ReLU of layer l-1 is applied on the fly when layer l loads its input (the activated
-//     values are also written out, they are the scalar operand of the weight-gradient kernel).
-//   * backward: dY = alpha*dZ + gamma'*Y + beta' per channel (BatchNorm backward written as an affine
-//     map, coefficients from two column sums), input-gradient = the same panel kernel with the
-//     untransposed weights, weight-gradient = lane-per-output-channel panels with the activated
-//     input as the scalar operand, summed over parts by a deterministic second stage.  No atomics.
+// Design:
+//   * fp32 throughout (parity bar 1e-4).  The 1x1 convolutions are GEMMs over [points x channels]
+//     and run on the matrix cores with the exact-fp32 MFMA  v_mfma_f32_32x32x2_f32  (same peak as the
+//     fp32 VALU on gfx950, but one instruction consumes a 32x2 and a 2x32 operand slice from ONE VGPR
+//     each, so operand traffic per FLOP is 32x lower than with scalar-operand FMAs).
+//   * activations are point-major  [row = part*N + point][channel].  With the MFMA K index split as
+//     "lanes 0-31 take k in [0,K/2), lanes 32-63 take [K/2,K)", every lane's operand fragments are
+//     CONTIGUOUS runs of its own row (activations) or of a weight row — plain float4 loads straight
+//     from global/L2, no LDS staging, no transposes.  Weights stay register-resident while a wave
+//     walks its 32-point tiles.
+//   * BatchNorm+ReLU of layer l-1 is applied on the fly wherever layer l needs its input (forward GEMM,
+//     weight-gradient GEMM): only the pre-BatchNorm outputs Y_l are ever stored; the
+//     per-channel sums BatchNorm needs fall out of the accumulator layout (a lane holds 16 rows of
+//     one output channel) and are reduced in a fixed order: deterministic, no atomics.
+//   * backward: BatchNorm backward is the per-channel affine map dY = alpha*dZ + gamma'*Y + beta'
+//     (coefficients from two column sums), applied on the fly as the operand of the input-gradient
+//     GEMM (dA = dY W) and of the weight-gradient GEMM (dW = dY^T A, K = points, one part per block,
+//     parts summed by a second deterministic stage).  The 3-channel first layer uses scalar-operand
+//     VALU panels (weights through the scalar cache), K = 3 being far too thin for a matrix core.
 #include "common.h"
 
 namespace {
 
-constexpr int kT = 256;           // threads per block (4 waves)
-constexpr int kRows = 256;        // rows (points) per block: one row per lane
-constexpr int kPanel = 64;        // output channels per accumulator panel
-constexpr int kKB = 16;           // input channels per unrolled k-block
+constexpr int kT = 256;      // threads per block (4 waves)
+constexpr int kSlices = 16;  // m-slices in the per-channel reduction kernels (64 channels x 16 = 1024 thr)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -36,18 +40,27 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// bnp layout per channel: {scale, shift, mean, invstd}
-struct BnP {
-  float scale, shift, mean, invstd;
-};
+// MFMA 32x32 accumulator layout: lane l holds column (l & 31) and, in register r, row acc_row(r, l >> 5).
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
-// ---- K0: transpose the conv weights, count the valid rows ----------------------------------------------
-__global__ void pn_prep_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int cin) {
+// Returns `p` through an opaque asm so that loads from it are NOT hoisted out of the enclosing loop: the
+// per-channel tables (BatchNorm scale/shift, backward coefficients) are loop-invariant, and LICM would
+// otherwise pin K/2 x 5 values per lane in registers (and spill).  They are L1-resident; re-reading per
+// tile is cheap.
+template <typename T>
+__device__ __forceinline__ const T* opaque(const T* p) {
+  asm volatile("" : "+v"(p));
+  return p;
+}
+
+// Per-layer BatchNorm parameters, struct-of-arrays [4][C]: scale, shift, mean, invstd
+//   z = y * scale + shift  ==  gamma * (y - mean) * invstd + beta
+// Backward coefficients [3][C]: alpha, gammap, betap  with  dY = alpha*dZ + gammap*Y + betap.
+
+// ---- small kernels ---------------------------------------------------------------------------------------
+__global__ void pn_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int cin) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < cout * cin) {
-    const int co = i / cin, ci = i % cin;
-    wt[ci * cout + co] = w[i];
-  }
+  if (i < cout * cin) wt[(i % cin) * cout + i / cin] = w[i];
 }
 
 __global__ void pn_count_kernel(const float* __restrict__ valids, int M, int N, float* __restrict__ count) {
@@ -57,127 +70,55 @@ __global__ void pn_count_kernel(const float* __restrict__ valids, int M, int N, 
   if (threadIdx.x == 0) count[0] = s * (float)N;
 }
 
-// ---- K1: forward layer ----------------------------------------------------------------------------------
-// in: CIN == 3 ? points [M*N][3] : pre-BN output of the previous layer [M*N][CIN]
-// grid = (ceil(N/256), M), block 256.  partial [M*tiles][cout][2].
-template <int CIN>
-__global__ __launch_bounds__(kT) void pn_fwd_layer_kernel(
-    const float* __restrict__ in, const BnP* __restrict__ bnp_prev, float* __restrict__ a_out,
-    const float* __restrict__ wt, int cout, const float* __restrict__ valids, int N,
-    float* __restrict__ y_out, float* __restrict__ partial) {
-  __shared__ float tile[kT / 64][64][kPanel + 1];
-  __shared__ float red[kT / 64][kPanel][2];
-  const int m = blockIdx.y;
-  if (valids[m] == 0.0f) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n0 = blockIdx.x * kRows + wave * 64;  // first row of this wave's tile
-  const int n = n0 + lane;
-  const bool rowok = n < N;
-  const long long row = (long long)m * N + (rowok ? n : N - 1);
-  const int rows_here = N - n0 < 64 ? (N - n0 < 0 ? 0 : N - n0) : 64;
-  const int blk = m * gridDim.x + blockIdx.x;
-
-  for (int c0 = 0; c0 < cout; c0 += kPanel) {
-    float acc[kPanel];
+// Sum the per-block (sum0, sum1) partials of 64 channels over all valid parts; 1024 threads =
+// 64 channels x 16 slices, fixed-order LDS tree.  Result valid for threads < 64 (slice 0).
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ partial,
+                                                const float* __restrict__ valids, int M, int splits, int C,
+                                                int c, double& s0, double& s1) {
+  __shared__ double sm[kSlices][64][2];
+  const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  double a = 0.0, b = 0.0;
+  for (int e = slice; e < M * splits; e += kSlices) {
+    if (valids[e / splits] == 0.0f) continue;
+    const long long o = ((long long)e * C + c) * 2;
+    a += (double)partial[o];
+    b += (double)partial[o + 1];
+  }
+  sm[slice][cl][0] = a;
+  sm[slice][cl][1] = b;
+  __syncthreads();
+  s0 = 0.0;
+  s1 = 0.0;
+  if (slice == 0) {
 #pragma unroll
-    for (int c = 0; c < kPanel; ++c) acc[c] = 0.0f;
-    if constexpr (CIN == 3) {
-      const float a0 = in[row * 3 + 0], a1 = in[row * 3 + 1], a2 = in[row * 3 + 2];
-#pragma unroll
-      for (int c = 0; c < kPanel; ++c) {
-        acc[c] = __builtin_fmaf(a0, wt[0 * cout + c0 + c], acc[c]);
-        acc[c] = __builtin_fmaf(a1, wt[1 * cout + c0 + c], acc[c]);
-        acc[c] = __builtin_fmaf(a2, wt[2 * cout + c0 + c], acc[c]);
-      }
-    } else {
-      for (int kb = 0; kb < CIN; kb += kKB) {
-        float a[kKB];
-        const float4* src = reinterpret_cast<const float4*>(in + row * CIN + kb);
-#pragma unroll
-        for (int v = 0; v < kKB / 4; ++v) {
-          const float4 y = src[v];
-          a[4 * v + 0] = y.x;
-          a[4 * v + 1] = y.y;
-          a[4 * v + 2] = y.z;
-          a[4 * v + 3] = y.w;
-        }
-#pragma unroll
-        for (int k = 0; k < kKB; ++k) {  // BatchNorm + ReLU of the previous layer, per input channel
-          const BnP p = bnp_prev[kb + k];
-          a[k] = __builtin_fmaxf(__builtin_fmaf(a[k], p.scale, p.shift), 0.0f);
-        }
-        if (c0 == 0 && rowok) {  // side output: activated input (scalar operand of the weight gradient)
-          float4* dst = reinterpret_cast<float4*>(a_out + row * CIN + kb);
-#pragma unroll
-          for (int v = 0; v < kKB / 4; ++v) dst[v] = make_float4(a[4 * v], a[4 * v + 1], a[4 * v + 2], a[4 * v + 3]);
-        }
-#pragma unroll
-        for (int k = 0; k < kKB; ++k) {
-          const float* wk = wt + (long long)(kb + k) * cout + c0;  // wave-uniform -> SGPRs
-#pragma unroll
-          for (int c = 0; c < kPanel; ++c) acc[c] = __builtin_fmaf(a[k], wk[c], acc[c]);
-        }
-      }
+    for (int k = 0; k < kSlices; ++k) {
+      s0 += sm[k][cl][0];
+      s1 += sm[k][cl][1];
     }
-    // panel epilogue: transpose through LDS -> coalesced stores + per-channel column sums
-#pragma unroll
-    for (int c = 0; c < kPanel; ++c) tile[wave][lane][c] = acc[c];
-    __builtin_amdgcn_wave_barrier();
-    float s = 0.0f, ss = 0.0f;
-    float* dst = y_out + ((long long)m * N + n0) * cout + c0 + lane;
-    for (int i = 0; i < rows_here; ++i) {
-      const float v = tile[wave][i][lane];
-      dst[(long long)i * cout] = v;
-      s += v;
-      ss = __builtin_fmaf(v, v, ss);
-    }
-    red[wave][lane][0] = s;
-    red[wave][lane][1] = ss;
-    __syncthreads();
-    if (threadIdx.x < kPanel) {
-      float t0 = 0.0f, t1 = 0.0f;
-#pragma unroll
-      for (int w = 0; w < kT / 64; ++w) {
-        t0 += red[w][threadIdx.x][0];
-        t1 += red[w][threadIdx.x][1];
-      }
-      partial[((long long)blk * cout + c0 + threadIdx.x) * 2 + 0] = t0;
-      partial[((long long)blk * cout + c0 + threadIdx.x) * 2 + 1] = t1;
-    }
-    __syncthreads();
   }
 }
 
-// ---- K2: BatchNorm statistics -> scale/shift (+ running statistics) ---------------------------------------
-// grid = ceil(C/64) blocks of 64 threads.
-__global__ void pn_bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ valids,
-                                      int M, int tiles, int C, const float* __restrict__ count,
-                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                      float* __restrict__ running_mean, float* __restrict__ running_var,
-                                      float momentum, float eps, BnP* __restrict__ bnp) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int m = 0; m < M; ++m) {
-    if (valids[m] == 0.0f) continue;
-    for (int t = 0; t < tiles; ++t) {
-      const long long o = (((long long)m * tiles + t) * C + c) * 2;
-      s += (double)partial[o];
-      ss += (double)partial[o + 1];
-    }
-  }
+// BatchNorm statistics -> scale/shift (+ running statistics).  grid = C/64, block 1024.
+__global__ __launch_bounds__(64 * kSlices) void pn_bn_finalize_kernel(
+    const float* __restrict__ partial, const float* __restrict__ valids, int M, int splits, int C,
+    const float* __restrict__ count, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+    float* __restrict__ bn) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s, ss;
+  reduce_partials(partial, valids, M, splits, C, c, s, ss);
+  if (threadIdx.x >= 64) return;
   const double n = (double)count[0];
   const double mean = s / n;
-  double var = ss / n - mean * mean;  // biased, as BatchNorm normalises with
+  double var = ss / n - mean * mean;  // biased: what BatchNorm normalises with
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / __builtin_sqrt(var + (double)eps));
-  BnP p;
-  p.mean = (float)mean;
-  p.invstd = invstd;
-  p.scale = gamma[c] * invstd;
-  p.shift = beta[c] - (float)mean * p.scale;
-  bnp[c] = p;
-  if (running_mean != nullptr) {  // running_var uses the unbiased estimate
+  const float scale = gamma[c] * invstd;
+  bn[c] = scale;
+  bn[C + c] = beta[c] - (float)mean * scale;
+  bn[2 * C + c] = (float)mean;
+  bn[3 * C + c] = invstd;
+  if (running_mean != nullptr) {  // running_var tracks the unbiased estimate
     const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
     running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
     running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
@@ -189,21 +130,78 @@ __global__ void pn_bn_from_running_kernel(int C, const float* __restrict__ gamma
                                           const float* __restrict__ beta,
                                           const float* __restrict__ running_mean,
                                           const float* __restrict__ running_var, float eps,
-                                          BnP* __restrict__ bnp) {
+                                          float* __restrict__ bn) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
-  BnP p;
-  p.mean = running_mean[c];
-  p.invstd = 1.0f / __builtin_sqrtf(running_var[c] + eps);
-  p.scale = gamma[c] * p.invstd;
-  p.shift = beta[c] - p.mean * p.scale;
-  bnp[c] = p;
+  const float invstd = 1.0f / __builtin_sqrtf(running_var[c] + eps);
+  const float scale = gamma[c] * invstd;
+  bn[c] = scale;
+  bn[C + c] = beta[c] - running_mean[c] * scale;
+  bn[2 * C + c] = running_mean[c];
+  bn[3 * C + c] = invstd;
 }
 
-// ---- K3: BatchNorm of the last layer + max over the points of each part -----------------------------------
-// grid = (F/64, M), block 256: wave w scans rows n = w, w+4, ...; lane = channel.
+__device__ __forceinline__ void write_coef(float* __restrict__ coef, int C, int c, float gamma,
+                                           const float* __restrict__ bn, double s1, double s2, double n) {
+  const float mean = bn[2 * C + c], invstd = bn[3 * C + c];
+  const float alpha = gamma * invstd;
+  const float gammap = (float)(-(double)alpha * s2 / n * (double)invstd);
+  coef[c] = alpha;
+  coef[C + c] = gammap;
+  coef[2 * C + c] = (float)(-(double)alpha * s1 / n - (double)gammap * (double)mean);
+}
+
+// coefficients of layer l from the (s1, s2) partials written by the input-gradient kernel of layer l+1
+__global__ __launch_bounds__(64 * kSlices) void pn_bwd_coef_kernel(
+    const float* __restrict__ partial, const float* __restrict__ valids, int M, int splits, int C,
+    const float* __restrict__ count, const float* __restrict__ gamma, const float* __restrict__ bn,
+    float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s1, s2;
+  reduce_partials(partial, valids, M, splits, C, c, s1, s2);
+  if (threadIdx.x >= 64) return;
+  write_coef(coef, C, c, gamma[c], bn, s1, s2, (double)count[0]);
+  dgamma[c] = (float)s2;
+  dbeta[c] = (float)s1;
+}
+
+// layer-5 coefficients: dZ5 is sparse, grad_feat[m,c] sits at row argmax[m,c].  grid = F/64, block 1024.
+__global__ __launch_bounds__(64 * kSlices) void pn_bwd_top_kernel(
+    const float* __restrict__ gfeat, const int* __restrict__ argmax, const float* __restrict__ y5,
+    const float* __restrict__ valids, int M, int N, int F, const float* __restrict__ count,
+    const float* __restrict__ gamma, const float* __restrict__ bn, float* __restrict__ coef,
+    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double sm[kSlices][64][2];
+  const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  const float mean = bn[2 * F + c], invstd = bn[3 * F + c];
+  double a = 0.0, b = 0.0;
+  for (int m = slice; m < M; m += kSlices) {
+    if (valids[m] == 0.0f) continue;
+    const int n = argmax[(long long)m * F + c];
+    if (n < 0) continue;  // all-NaN column: no arg-max, no gradient
+    const float g = gfeat[(long long)m * F + c];
+    const float y = y5[((long long)m * N + n) * F + c];
+    a += (double)g;
+    b += (double)g * (double)((y - mean) * invstd);
+  }
+  sm[slice][cl][0] = a;
+  sm[slice][cl][1] = b;
+  __syncthreads();
+  if (slice != 0) return;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < kSlices; ++k) {
+    s1 += sm[k][cl][0];
+    s2 += sm[k][cl][1];
+  }
+  write_coef(coef, F, c, gamma[c], bn, s1, s2, (double)count[0]);
+  dgamma[c] = (float)s2;
+  dbeta[c] = (float)s1;
+}
+
+// BatchNorm of the last layer + max over the points of each part.  grid = (F/64, M), block 256.
 __global__ __launch_bounds__(kT) void pn_maxpool_kernel(const float* __restrict__ y5,
-                                                        const BnP* __restrict__ bnp,
+                                                        const float* __restrict__ bn,
                                                         const float* __restrict__ valids, int N, int F,
                                                         float* __restrict__ feat, int* __restrict__ argmax) {
   __shared__ float smv[kT / 64][64];
@@ -216,12 +214,12 @@ __global__ __launch_bounds__(kT) void pn_maxpool_kernel(const float* __restrict_
     }
     return;
   }
-  const BnP p = bnp[c];
+  const float scale = bn[c], shift = bn[F + c];
   float best = -__builtin_inff();
   int arg = -1;
   const float* src = y5 + (long long)m * N * F + c;
   for (int n = wave; n < N; n += kT / 64) {
-    const float z = __builtin_fmaf(src[(long long)n * F], p.scale, p.shift);
+    const float z = __builtin_fmaf(src[(long long)n * F], scale, shift);
     if (z > best) {
       best = z;
       arg = n;
@@ -246,239 +244,474 @@ __global__ __launch_bounds__(kT) void pn_maxpool_kernel(const float* __restrict_
   }
 }
 
-// ---- backward -----------------------------------------------------------------------------------------------
-// coef layout per channel: {alpha, gammap, betap, pad}:  dY = alpha*dZ + gammap*Y + betap
-struct Coef {
-  float alpha, gammap, betap, pad;
-};
-
-__device__ __forceinline__ Coef make_coef(float gamma, const BnP p, double s1, double s2, double n) {
-  Coef k;
-  k.alpha = gamma * p.invstd;
-  k.gammap = (float)(-(double)k.alpha * s2 / n * (double)p.invstd);
-  k.betap = (float)(-(double)k.alpha * s1 / n - (double)k.gammap * (double)p.mean);
-  k.pad = 0.0f;
-  return k;
-}
-
-// K4: layer-5 coefficients.  dZ5 is sparse: grad_feat[m,c] at row argmax[m,c].  One block per 64 channels.
-__global__ void pn_bwd_top_kernel(const float* __restrict__ gfeat, const int* __restrict__ argmax,
-                                  const float* __restrict__ y5, const float* __restrict__ valids, int M,
-                                  int N, int F, const float* __restrict__ count,
-                                  const float* __restrict__ gamma, const BnP* __restrict__ bnp,
-                                  Coef* __restrict__ coef, float* __restrict__ dgamma,
-                                  float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= F) return;
-  const BnP p = bnp[c];
-  double s1 = 0.0, s2 = 0.0;
-  for (int m = 0; m < M; ++m) {
-    if (valids[m] == 0.0f) continue;
-    const float g = gfeat[(long long)m * F + c];
-    const int n = argmax[(long long)m * F + c];
-    if (n < 0) continue;  // all-NaN column: no arg-max, no gradient
-    const float y = y5[((long long)m * N + n) * F + c];
-    s1 += (double)g;
-    s2 += (double)g * (double)((y - p.mean) * p.invstd);
-  }
-  coef[c] = make_coef(gamma[c], p, s1, s2, (double)count[0]);
-  dgamma[c] = (float)s2;
-  dbeta[c] = (float)s1;
-}
-
-// K7: coefficients of layer l from the (s1, s2) partials written by the input-gradient kernel of layer l+1.
-__global__ void pn_bwd_coef_kernel(const float* __restrict__ partial, const float* __restrict__ valids,
-                                   int M, int tiles, int C, const float* __restrict__ count,
-                                   const float* __restrict__ gamma, const BnP* __restrict__ bnp,
-                                   Coef* __restrict__ coef, float* __restrict__ dgamma,
-                                   float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int m = 0; m < M; ++m) {
-    if (valids[m] == 0.0f) continue;
-    for (int t = 0; t < tiles; ++t) {
-      const long long o = (((long long)m * tiles + t) * C + c) * 2;
-      s1 += (double)partial[o];
-      s2 += (double)partial[o + 1];
-    }
-  }
-  coef[c] = make_coef(gamma[c], bnp[c], s1, s2, (double)count[0]);
-  dgamma[c] = (float)s2;
-  dbeta[c] = (float)s1;
-}
-
-// K6: input gradient of layer l (COUT channels -> CIN channels), fused with the ReLU mask and the
-// BatchNorm-backward column sums of layer l-1.
-//   dY_l[r,co] = alpha*dZ_l + gammap*Y_l + betap   (TOP: dZ_l[r,co] = gfeat[m,co] iff argmax[m,co] == n)
-//   dA[r,ci]   = sum_co dY_l[r,co] * W[co][ci]
-//   dZ_{l-1}   = dA where BN_{l-1}(Y_{l-1}) > 0 else 0;  s1 += dZ, s2 += dZ * xhat_{l-1}
-// grid = (ceil(N/256), M), block 256; lane = row.
-template <bool TOP>
-__global__ __launch_bounds__(kT) void pn_dgrad_kernel(
-    const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ gfeat,
-    const int* __restrict__ argmax, const Coef* __restrict__ coef, const float* __restrict__ w, int cout,
-    int cin, const float* __restrict__ y_prev, const BnP* __restrict__ bnp_prev,
-    const float* __restrict__ valids, int N, float* __restrict__ dz_prev, float* __restrict__ partial) {
-  __shared__ float tile[kT / 64][64][kPanel + 1];
-  __shared__ float red[kT / 64][kPanel][2];
+// ---- first layer (3 -> 64): scalar-operand VALU panel ------------------------------------------------------
+// lane = point; the 3x64 transposed weights are wave-uniform (scalar cache).  grid = (ceil(N/256), M).
+// partial [M*tiles][64][2].
+__global__ __launch_bounds__(kT) void pn_fwd_first_kernel(const float* __restrict__ pts,
+                                                          const float* __restrict__ wt,
+                                                          const float* __restrict__ valids, int N,
+                                                          float* __restrict__ y_out,
+                                                          float* __restrict__ partial) {
+  __shared__ float tile[kT / 64][64][65];
+  __shared__ float red[kT / 64][64][2];
   const int m = blockIdx.y;
   if (valids[m] == 0.0f) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n0 = blockIdx.x * kRows + wave * 64;
-  const int n = n0 + lane;
-  const bool rowok = n < N;
-  const long long row = (long long)m * N + (rowok ? n : N - 1);
+  const int n0 = blockIdx.x * kT + wave * 64, n = n0 + lane;
+  const long long row = (long long)m * N + (n < N ? n : N - 1);
   const int rows_here = N - n0 < 64 ? (N - n0 < 0 ? 0 : N - n0) : 64;
-  const int blk = m * gridDim.x + blockIdx.x;
-
-  for (int c0 = 0; c0 < cin; c0 += kPanel) {
-    float acc[kPanel];
+  const float a0 = pts[row * 3 + 0], a1 = pts[row * 3 + 1], a2 = pts[row * 3 + 2];
 #pragma unroll
-    for (int c = 0; c < kPanel; ++c) acc[c] = 0.0f;
-    for (int kb = 0; kb < cout; kb += kKB) {
-      float dy[kKB];
-      const float4* ys = reinterpret_cast<const float4*>(y + row * cout + kb);
+  for (int c = 0; c < 64; ++c) {
+    float v = a0 * wt[c];
+    v = __builtin_fmaf(a1, wt[64 + c], v);
+    v = __builtin_fmaf(a2, wt[128 + c], v);
+    tile[wave][lane][c] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float s = 0.0f, ss = 0.0f;
+  float* dst = y_out + ((long long)m * N + n0) * 64 + lane;
+  for (int i = 0; i < rows_here; ++i) {
+    const float v = tile[wave][i][lane];
+    dst[(long long)i * 64] = v;
+    s += v;
+    ss = __builtin_fmaf(v, v, ss);
+  }
+  red[wave][lane][0] = s;
+  red[wave][lane][1] = ss;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t0 = 0.0f, t1 = 0.0f;
 #pragma unroll
-      for (int v = 0; v < kKB / 4; ++v) {
-        const float4 t = ys[v];
-        dy[4 * v + 0] = t.x;
-        dy[4 * v + 1] = t.y;
-        dy[4 * v + 2] = t.z;
-        dy[4 * v + 3] = t.w;
-      }
-      if constexpr (TOP) {
-#pragma unroll
-        for (int k = 0; k < kKB; ++k) {
-          const Coef q = coef[kb + k];
-          const int am = argmax[(long long)m * cout + kb + k];   // wave-uniform
-          const float g = gfeat[(long long)m * cout + kb + k];   // wave-uniform
-          const float dzv = (am == n) ? g : 0.0f;
-          dy[k] = __builtin_fmaf(q.alpha, dzv, __builtin_fmaf(q.gammap, dy[k], q.betap));
-        }
-      } else {
-        const float4* zs = reinterpret_cast<const float4*>(dz + row * cout + kb);
-        float dzv[kKB];
-#pragma unroll
-        for (int v = 0; v < kKB / 4; ++v) {
-          const float4 t = zs[v];
-          dzv[4 * v + 0] = t.x;
-          dzv[4 * v + 1] = t.y;
-          dzv[4 * v + 2] = t.z;
-          dzv[4 * v + 3] = t.w;
-        }
-#pragma unroll
-        for (int k = 0; k < kKB; ++k) {
-          const Coef q = coef[kb + k];
-          dy[k] = __builtin_fmaf(q.alpha, dzv[k], __builtin_fmaf(q.gammap, dy[k], q.betap));
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < kKB; ++k) {
-        const float* wk = w + (long long)(kb + k) * cin + c0;  // W[co][ci0..]: wave-uniform -> SGPRs
-#pragma unroll
-        for (int c = 0; c < kPanel; ++c) acc[c] = __builtin_fmaf(dy[k], wk[c], acc[c]);
-      }
+    for (int w = 0; w < kT / 64; ++w) {
+      t0 += red[w][threadIdx.x][0];
+      t1 += red[w][threadIdx.x][1];
     }
-#pragma unroll
-    for (int c = 0; c < kPanel; ++c) tile[wave][lane][c] = acc[c];
-    __builtin_amdgcn_wave_barrier();
-    // lane = input channel ci: ReLU mask of layer l-1, store dZ_{l-1}, column sums for its BN backward
-    const BnP p = bnp_prev[c0 + lane];
-    float s1 = 0.0f, s2 = 0.0f;
-    const long long o = ((long long)m * N + n0) * cin + c0 + lane;
-    for (int i = 0; i < rows_here; ++i) {
-      const float yp = y_prev[o + (long long)i * cin];
-      const float z = __builtin_fmaf(yp, p.scale, p.shift);
-      const float d = z > 0.0f ? tile[wave][i][lane] : 0.0f;
-      dz_prev[o + (long long)i * cin] = d;
-      s1 += d;
-      s2 = __builtin_fmaf(d, (yp - p.mean) * p.invstd, s2);
-    }
-    red[wave][lane][0] = s1;
-    red[wave][lane][1] = s2;
-    __syncthreads();
-    if (threadIdx.x < kPanel) {
-      float t0 = 0.0f, t1 = 0.0f;
-#pragma unroll
-      for (int wv = 0; wv < kT / 64; ++wv) {
-        t0 += red[wv][threadIdx.x][0];
-        t1 += red[wv][threadIdx.x][1];
-      }
-      partial[((long long)blk * cin + c0 + threadIdx.x) * 2 + 0] = t0;
-      partial[((long long)blk * cin + c0 + threadIdx.x) * 2 + 1] = t1;
-    }
-    __syncthreads();
+    const long long blk = (long long)m * gridDim.x + blockIdx.x;
+    partial[(blk * 64 + threadIdx.x) * 2 + 0] = t0;
+    partial[(blk * 64 + threadIdx.x) * 2 + 1] = t1;
   }
 }
 
-// K5: weight gradient of layer l, one part per block.column:  dWpart[m][co][ci] = sum_n dY[r,co] * A[r,ci].
-// lane = output channel co (64 per wave-panel); the activated input row A[r, ci0..ci0+CI) is the scalar
-// operand.  grid = (cout/64 * ceil(cin/64), M), block 256: the 4 waves split the part's rows, LDS-combine.
-template <bool TOP, int CI>  // CI = input channels per pass: 64, or 3 for the first layer
-__global__ __launch_bounds__(kT) void pn_wgrad_kernel(
-    const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ gfeat,
-    const int* __restrict__ argmax, const Coef* __restrict__ coef, const float* __restrict__ a_prev,
-    int cout, int cin, const float* __restrict__ valids, int N, float* __restrict__ dwpart) {
-  __shared__ float red[kT / 64][CI][64 + 1];
+// first-layer weight gradient: dWpart[m][co][0..2] = sum_n dY1[r,co] * pts[r,0..2]; lane = co.
+// grid = (1, M), block 256: the 4 waves split the rows.
+__global__ __launch_bounds__(kT) void pn_wgrad_first_kernel(const float* __restrict__ y,
+                                                            const float* __restrict__ dz,
+                                                            const float* __restrict__ coef,
+                                                            const float* __restrict__ pts,
+                                                            const float* __restrict__ valids, int N,
+                                                            float* __restrict__ dwpart) {
+  __shared__ float red[kT / 64][3][64];
   const int m = blockIdx.y;
   if (valids[m] == 0.0f) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ci_groups = (cin + 63) / 64;
-  const int co = (blockIdx.x / ci_groups) * 64 + lane;
-  const int ci0 = (blockIdx.x % ci_groups) * 64;
-  const Coef q = coef[co];
-  float g = 0.0f;
-  int am = -1;
-  if constexpr (TOP) {
-    g = gfeat[(long long)m * cout + co];
-    am = argmax[(long long)m * cout + co];
-  }
-  float acc[CI];
-#pragma unroll
-  for (int c = 0; c < CI; ++c) acc[c] = 0.0f;
+  const int wave = threadIdx.x >> 6, co = threadIdx.x & 63;
+  const float al = coef[co], gp = coef[64 + co], bp = coef[128 + co];
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
   const int per = (N + kT / 64 - 1) / (kT / 64);
   const int nb = wave * per, ne = nb + per < N ? nb + per : N;
   for (int n = nb; n < ne; ++n) {
     const long long r = (long long)m * N + n;
-    float dzv;
-    if constexpr (TOP) dzv = (am == n) ? g : 0.0f;
-    else dzv = dz[r * cout + co];
-    const float dy = __builtin_fmaf(q.alpha, dzv, __builtin_fmaf(q.gammap, y[r * cout + co], q.betap));
-    const float* ar = a_prev + r * cin + ci0;  // wave-uniform -> SGPRs
-#pragma unroll
-    for (int c = 0; c < CI; ++c) acc[c] = __builtin_fmaf(dy, ar[c], acc[c]);
+    const float dy = __builtin_fmaf(al, dz[r * 64 + co], __builtin_fmaf(gp, y[r * 64 + co], bp));
+    a0 = __builtin_fmaf(dy, pts[r * 3 + 0], a0);  // pts[r]: wave-uniform -> scalar loads
+    a1 = __builtin_fmaf(dy, pts[r * 3 + 1], a1);
+    a2 = __builtin_fmaf(dy, pts[r * 3 + 2], a2);
   }
-#pragma unroll
-  for (int c = 0; c < CI; ++c) red[wave][c][lane] = acc[c];
+  red[wave][0][co] = a0;
+  red[wave][1][co] = a1;
+  red[wave][2][co] = a2;
   __syncthreads();
-  // dwpart[m][co][ci]: lane = ci (contiguous 256 B stores), each wave takes every 4th output channel
-  const int co_base = (blockIdx.x / ci_groups) * 64;
-  if (lane < CI) {
-    for (int cl = wave; cl < 64; cl += kT / 64) {
-      float s = 0.0f;
+  if (threadIdx.x < 192) {
+    const int c = threadIdx.x / 3, k = threadIdx.x % 3;
+    float s = 0.0f;
 #pragma unroll
-      for (int wv = 0; wv < kT / 64; ++wv) s += red[wv][lane][cl];
-      dwpart[((long long)m * cout + co_base + cl) * cin + ci0 + lane] = s;
-    }
+    for (int w = 0; w < kT / 64; ++w) s += red[w][k][c];
+    dwpart[(long long)m * 192 + threadIdx.x] = s;
   }
 }
 
-// sum over valid parts: dW[i] = sum_m dwpart[m][i]
-__global__ void pn_wgrad_reduce_kernel(const float* __restrict__ dwpart, const float* __restrict__ valids,
-                                       int M, int elems, float* __restrict__ dw) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= elems) return;
+// ---- MFMA forward layer ---------------------------------------------------------------------------------------
+// Y[rows x cout] = relu(bn_prev(Yprev))[rows x CIN] . W[cout x CIN]^T, one 64-channel output panel per block.y.
+// grid = (M*splits, cout/64), block 256: wave w walks the 32-row tiles t0+w, t0+w+4, ... of its split.
+template <int CIN>
+__global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
+    const float* __restrict__ in, const float* __restrict__ bn_prev, const float* __restrict__ w, int cout,
+    const float* __restrict__ valids, int N, int splits, float* __restrict__ y_out,
+    float* __restrict__ partial) {
+  constexpr int KH = CIN / 2;   // K values per lane-half
+  constexpr int LD = CIN + 4;   // padded LDS row: conflict-free ds_read_b128 across rows
+  constexpr int Q4 = CIN / 4;   // float4 per row
+  __shared__ __attribute__((aligned(16))) float stage[kT / 64][32 * LD];
+  __shared__ float red[kT / 64][64][2];
+  const int m = blockIdx.x / splits, sp = blockIdx.x % splits;
+  if (valids[m] == 0.0f) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int c0 = blockIdx.y * 64;
+  // B fragments (weights): tile t covers output channels c0+32t .. c0+32t+31; lane holds W[c][h*KH + s]
+  float bw[2][KH];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float4* src = reinterpret_cast<const float4*>(w + (long long)(c0 + 32 * t + j) * CIN + h * KH);
+#pragma unroll
+    for (int v = 0; v < KH / 4; ++v) {
+      const float4 q = src[v];
+      bw[t][4 * v + 0] = q.x;
+      bw[t][4 * v + 1] = q.y;
+      bw[t][4 * v + 2] = q.z;
+      bw[t][4 * v + 3] = q.w;
+    }
+  }
+  const int T = (N + 31) / 32;
+  const int t_begin = (int)((long long)sp * T / splits), t_end = (int)((long long)(sp + 1) * T / splits);
+  float s_[2] = {0.0f, 0.0f}, ss_[2] = {0.0f, 0.0f};
+  const float4* sc4_ = reinterpret_cast<const float4*>(bn_prev);
+  const float4* sh4_ = reinterpret_cast<const float4*>(bn_prev + CIN);
+  float* lds = stage[wave];
+  for (int tile = t_begin + wave; tile < t_end; tile += kT / 64) {
+    const int r0 = tile * 32;
+    // 1. stage the tile: its 32 rows are ONE contiguous 32*CIN-float run -> fully coalesced float4 loads;
+    //    BatchNorm + ReLU of the previous layer applied here, result to LDS.
+    const float4* src = reinterpret_cast<const float4*>(in + ((long long)m * N + r0) * CIN);
+    const float4 *sc4 = opaque(sc4_), *sh4 = opaque(sh4_);
+#pragma unroll 4
+    for (int it = 0; it < Q4 / 2; ++it) {
+      const int idx = it * 64 + lane, rl = idx / Q4, c4 = idx % Q4;
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (r0 + rl < N) {
+        const float4 y = src[idx], sc = sc4[c4], sh = sh4[c4];
+        v.x = __builtin_fmaxf(__builtin_fmaf(y.x, sc.x, sh.x), 0.0f);
+        v.y = __builtin_fmaxf(__builtin_fmaf(y.y, sc.y, sh.y), 0.0f);
+        v.z = __builtin_fmaxf(__builtin_fmaf(y.z, sc.z, sh.z), 0.0f);
+        v.w = __builtin_fmaxf(__builtin_fmaf(y.w, sc.w, sh.w), 0.0f);
+      }
+      *reinterpret_cast<float4*>(lds + rl * LD + 4 * c4) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 2. A fragments from LDS (row j, K half h) and the MFMA chain
+    const float4* frag = reinterpret_cast<const float4*>(lds + j * LD + h * KH);
+    f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+    for (int v = 0; v < KH / 4; ++v) {
+      const float4 a = frag[v];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw[0][4 * v + 0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw[1][4 * v + 0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw[0][4 * v + 1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw[1][4 * v + 1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw[0][4 * v + 2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw[1][4 * v + 2], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[0][4 * v + 3], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[1][4 * v + 3], acc1, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();  // the next tile's staging must not overtake these LDS reads
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gn = r0 + acc_row(r, h);
+      if (gn < N) {
+        float* dst = y_out + ((long long)m * N + gn) * cout + c0 + j;
+        dst[0] = acc0[r];
+        dst[32] = acc1[r];
+        s_[0] += acc0[r];
+        ss_[0] = __builtin_fmaf(acc0[r], acc0[r], ss_[0]);
+        s_[1] += acc1[r];
+        ss_[1] = __builtin_fmaf(acc1[r], acc1[r], ss_[1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {  // lanes l and l+32 hold the same channel
+    s_[t] += __shfl_xor(s_[t], 32, 64);
+    ss_[t] += __shfl_xor(ss_[t], 32, 64);
+  }
+  if (h == 0) {
+    red[wave][j][0] = s_[0];
+    red[wave][j][1] = ss_[0];
+    red[wave][32 + j][0] = s_[1];
+    red[wave][32 + j][1] = ss_[1];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < kT / 64; ++wv) {
+      t0 += red[wv][threadIdx.x][0];
+      t1 += red[wv][threadIdx.x][1];
+    }
+    const long long o = ((long long)blockIdx.x * cout + c0 + threadIdx.x) * 2;
+    partial[o] = t0;
+    partial[o + 1] = t1;
+  }
+}
+
+// ---- MFMA input gradient -----------------------------------------------------------------------------------------
+// dA[rows x cin] = dY[rows x K] . W[K x cin] with dY = alpha*dZ + gammap*Y + betap built on the fly
+// (TOP: dZ[r,k] = gfeat[m,k] iff argmax[m,k] == point), then the ReLU mask and the BatchNorm-backward
+// column sums of layer l-1:  dZprev = dA where bn_prev(Yprev) > 0;  s1 += dZprev, s2 += dZprev * xhat_prev.
+// NT = 32-channel output tiles per wave (register budget: NT * K/2 weight registers).
+// grid = (M*splits, cin/(32*NT)), block 256.
+template <int K, int NT, bool TOP>
+__global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
+    const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ gfeat,
+    const int* __restrict__ argmax, const float* __restrict__ coef, const float* __restrict__ w, int cin,
+    const float* __restrict__ y_prev, const float* __restrict__ bn_prev, const float* __restrict__ valids,
+    int N, int splits, float* __restrict__ dz_prev, float* __restrict__ partial) {
+  constexpr int PC = K < 128 ? K : 128;  // columns of dY staged per phase
+  constexpr int PH = K / PC;             // phases
+  constexpr int KH = PC / 2;             // K values per lane-half and phase
+  constexpr int LD = PC + 4;
+  constexpr int Q4 = PC / 4;
+  __shared__ __attribute__((aligned(16))) float stage[kT / 64][32 * LD];
+  __shared__ float red[kT / 64][32 * NT][2];
+  const int m = blockIdx.x / splits, sp = blockIdx.x % splits;
+  if (valids[m] == 0.0f) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int d0 = blockIdx.y * 32 * NT;
+  // B fragments: phase p, lane-half h, step s  <->  k = p*PC + h*KH + s;  bw = W[k][d0 + 32t + j]
+  float bw[NT][PH][KH];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int ph = 0; ph < PH; ++ph)
+#pragma unroll
+      for (int s = 0; s < KH; ++s) bw[t][ph][s] = w[(long long)(ph * PC + h * KH + s) * cin + d0 + 32 * t + j];
+  float scp[NT], shp[NT], mnp[NT], isp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ci = d0 + 32 * t + j;
+    scp[t] = bn_prev[ci];
+    shp[t] = bn_prev[cin + ci];
+    mnp[t] = bn_prev[2 * cin + ci];
+    isp[t] = bn_prev[3 * cin + ci];
+  }
+  const int T = (N + 31) / 32;
+  const int t_begin = (int)((long long)sp * T / splits), t_end = (int)((long long)(sp + 1) * T / splits);
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.0f;
+  const float4* al4_ = reinterpret_cast<const float4*>(coef);
+  const float4* gp4_ = reinterpret_cast<const float4*>(coef + K);
+  const float4* bp4_ = reinterpret_cast<const float4*>(coef + 2 * K);
+  const float4* gf4_ = reinterpret_cast<const float4*>(TOP ? gfeat + (long long)m * K : nullptr);
+  const int4* am4_ = reinterpret_cast<const int4*>(TOP ? argmax + (long long)m * K : nullptr);
+  float* lds = stage[wave];
+
+  for (int tile = t_begin + wave; tile < t_end; tile += kT / 64) {
+    const int r0 = tile * 32;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+#pragma unroll
+    for (int ph = 0; ph < PH; ++ph) {
+      // 1. stage dY[32 rows][PC columns of phase ph] = alpha*dZ + gammap*Y + betap  (coalesced row segments)
+      const float4 *al4 = opaque(al4_), *gp4 = opaque(gp4_), *bp4 = opaque(bp4_), *gf4 = opaque(gf4_);
+      const int4* am4 = opaque(am4_);
+#pragma unroll 4
+      for (int it = 0; it < Q4 / 2; ++it) {
+        const int idx = it * 64 + lane, rl = idx / Q4, c4 = idx % Q4, k4 = ph * Q4 + c4;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const int n = r0 + rl;
+        if (n < N) {
+          const long long o4 = ((long long)m * N + n) * (K / 4) + k4;
+          const float4 yv = reinterpret_cast<const float4*>(y)[o4];
+          const float4 al = al4[k4], gp = gp4[k4], bp = bp4[k4];
+          float4 zv;
+          if constexpr (TOP) {
+            const float4 g = gf4[k4];
+            const int4 am = am4[k4];
+            zv = make_float4(am.x == n ? g.x : 0.0f, am.y == n ? g.y : 0.0f, am.z == n ? g.z : 0.0f,
+                             am.w == n ? g.w : 0.0f);
+          } else {
+            zv = reinterpret_cast<const float4*>(dz)[o4];
+          }
+          v.x = __builtin_fmaf(al.x, zv.x, __builtin_fmaf(gp.x, yv.x, bp.x));
+          v.y = __builtin_fmaf(al.y, zv.y, __builtin_fmaf(gp.y, yv.y, bp.y));
+          v.z = __builtin_fmaf(al.z, zv.z, __builtin_fmaf(gp.z, yv.z, bp.z));
+          v.w = __builtin_fmaf(al.w, zv.w, __builtin_fmaf(gp.w, yv.w, bp.w));
+        }
+        *reinterpret_cast<float4*>(lds + rl * LD + 4 * c4) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // 2. fragments (row j, lane-half h) and the MFMA chain of this phase
+      const float4* frag = reinterpret_cast<const float4*>(lds + j * LD + h * KH);
+#pragma unroll
+      for (int v = 0; v < KH / 4; ++v) {
+        const float4 a = frag[v];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw[t][ph][4 * v + 0], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw[t][ph][4 * v + 1], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw[t][ph][4 * v + 2], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[t][ph][4 * v + 3], acc[t], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // the next staging must not overtake these LDS reads
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gn = r0 + acc_row(r, h);
+      if (gn < N) {
+        const long long o = ((long long)m * N + gn) * cin + d0 + j;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float yp = y_prev[o + 32 * t];
+          const float zz = __builtin_fmaf(yp, scp[t], shp[t]);
+          const float d = zz > 0.0f ? acc[t][r] : 0.0f;
+          dz_prev[o + 32 * t] = d;
+          s1[t] += d;
+          s2[t] = __builtin_fmaf(d, (yp - mnp[t]) * isp[t], s2[t]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    s1[t] += __shfl_xor(s1[t], 32, 64);
+    s2[t] += __shfl_xor(s2[t], 32, 64);
+  }
+  if (h == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      red[wave][32 * t + j][0] = s1[t];
+      red[wave][32 * t + j][1] = s2[t];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32 * NT) {
+    float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < kT / 64; ++wv) {
+      t0 += red[wv][threadIdx.x][0];
+      t1 += red[wv][threadIdx.x][1];
+    }
+    const long long o = ((long long)blockIdx.x * cin + d0 + threadIdx.x) * 2;
+    partial[o] = t0;
+    partial[o + 1] = t1;
+  }
+}
+
+// ---- MFMA weight gradient --------------------------------------------------------------------------------------
+// dWpart[m][co][ci] = sum_n dY[r,co] * A[r,ci]  (GEMM with K = the part's points), 64x64 per block.x.
+// MFMA A operand = dY^T (lane: channel co = c0 + 32t + (l&31), row from the lane's half of the wave's
+// row range), B operand = A (lane: channel ci).  grid = ((cout/64)*(cin/64), M), block 256: the 4 waves
+// split the part's rows and are summed through LDS.
+template <bool TOP>
+__global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
+    const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ gfeat,
+    const int* __restrict__ argmax, const float* __restrict__ coef, const float* __restrict__ y_prev,
+    const float* __restrict__ bn_prev, int cout, int cin, const float* __restrict__ valids, int N,
+    float* __restrict__ dwpart) {
+  __shared__ float sm[kT / 64][4][16][64];  // 64 KiB
+  const int m = blockIdx.y;
+  if (valids[m] == 0.0f) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int cgroups = cin / 64;
+  const int c0 = (blockIdx.x / cgroups) * 64, d0 = (blockIdx.x % cgroups) * 64;
+  float al[2], gp[2], bp[2], g[2] = {0.0f, 0.0f};
+  int am[2] = {-1, -1};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int co = c0 + 32 * t + j;
+    al[t] = coef[co];
+    gp[t] = coef[cout + co];
+    bp[t] = coef[2 * cout + co];
+    if constexpr (TOP) {
+      g[t] = gfeat[(long long)m * cout + co];
+      am[t] = argmax[(long long)m * cout + co];
+    }
+  }
+  float scp[2], shp[2];  // BatchNorm + ReLU of the previous layer, recomputed on the fly for operand B
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    scp[u] = bn_prev[d0 + 32 * u + j];
+    shp[u] = bn_prev[cin + d0 + 32 * u + j];
+  }
+  const int per = (N + kT / 64 - 1) / (kT / 64);
+  const int nb = wave * per, ne = nb + per < N ? nb + per : N;
+  const int cnt = ne > nb ? ne - nb : 0, half = (cnt + 1) / 2;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[t][u] = f32x16{0};
+  // one K step = one point per lane-half; operands of step s+1 are fetched before the 4 MFMAs of step s
+  float ny[2], nz[2], nbv[2];
+  bool nok;
+  auto fetch = [&](int s) {
+    const int n = nb + h * half + s;
+    nok = s < half && n < ne;
+    const long long r = (long long)m * N + (nok ? n : nb);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const long long o = r * cout + c0 + 32 * t + j;
+      ny[t] = y[o];
+      if constexpr (TOP) nz[t] = (am[t] == n) ? g[t] : 0.0f;
+      else nz[t] = dz[o];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) nbv[u] = y_prev[r * cin + d0 + 32 * u + j];
+  };
+  if (half > 0) fetch(0);
+  for (int s = 0; s < half; ++s) {
+    float dy[2], b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float v = __builtin_fmaf(al[t], nz[t], __builtin_fmaf(gp[t], ny[t], bp[t]));
+      dy[t] = nok ? v : 0.0f;
+    }
+    b[0] = __builtin_fmaxf(__builtin_fmaf(nbv[0], scp[0], shp[0]), 0.0f);
+    b[1] = __builtin_fmaxf(__builtin_fmaf(nbv[1], scp[1], shp[1]), 0.0f);
+    fetch(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy[t], b[u], acc[t][u], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sm[wave][2 * t + u][r][lane] = acc[t][u][r];
+  __syncthreads();
+  // 4 tiles x 16 regs x 64 lanes = 4096 outputs, 16 per thread; D[i = co][jj = ci]
+  for (int e = threadIdx.x; e < 4096; e += kT) {
+    const int ln = e & 63, r = (e >> 6) & 15, tu = e >> 10;
+    float sum = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < kT / 64; ++wv) sum += sm[wv][tu][r][ln];
+    const int co = c0 + 32 * (tu >> 1) + acc_row(r, ln >> 5);
+    const int ci = d0 + 32 * (tu & 1) + (ln & 31);
+    dwpart[((long long)m * cout + co) * cin + ci] = sum;
+  }
+}
+
+// dW[i] = sum over valid parts of dwpart[m][i].  block 1024 = 64 elements x 16 part-slices.
+__global__ __launch_bounds__(64 * kSlices) void pn_wgrad_reduce_kernel(const float* __restrict__ dwpart,
+                                                                      const float* __restrict__ valids,
+                                                                      int M, int elems,
+                                                                      float* __restrict__ dw) {
+  __shared__ float sm[kSlices][64];
+  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6, i = blockIdx.x * 64 + el;
   float s = 0.0f;
-  for (int m = 0; m < M; ++m)
-    if (valids[m] != 0.0f) s += dwpart[(long long)m * elems + i];
-  dw[i] = s;
+  if (i < elems)
+    for (int m = slice; m < M; m += kSlices)
+      if (valids[m] != 0.0f) s += dwpart[(long long)m * elems + i];
+  sm[slice][el] = s;
+  __syncthreads();
+  if (slice == 0 && i < elems) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kSlices; ++k) t += sm[k][el];
+    dw[i] = t;
+  }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
 struct Dims {
-  int64_t M, N, F, rows, tiles;
-  int C[6];  // channel widths: C[0] = 3 ... C[5] = F
+  int64_t M, N, F, rows;
+  int splits, tiles1;  // row splits of the MFMA kernels; 256-row tiles of the first-layer kernel
+  int C[6];            // channel widths: C[0] = 3 ... C[5] = F
 };
 
 Dims make_dims(int64_t M, int64_t N, int64_t F) {
@@ -487,7 +720,9 @@ Dims make_dims(int64_t M, int64_t N, int64_t F) {
   d.N = N;
   d.F = F;
   d.rows = M * N;
-  d.tiles = (N + kRows - 1) / kRows;
+  d.tiles1 = (int)((N + kT - 1) / kT);
+  const int T = (int)((N + 31) / 32);
+  d.splits = T >= 16 ? 2 : 1;  // >= 8 tiles (2 per wave) per block
   d.C[0] = 3;
   d.C[1] = 64;
   d.C[2] = 64;
@@ -499,13 +734,12 @@ Dims make_dims(int64_t M, int64_t N, int64_t F) {
 
 struct PnWs {
   float* Y[6];    // pre-BN outputs, Y[1..5]
-  float* A[6];    // activated outputs A[1..4] (A[0] = input points)
   float* dZ[6];   // backward: dZ[1..4]
-  float* Wt[6];   // transposed weights [cin][cout]
-  BnP* bnp[6];
-  Coef* coef[6];
-  float* partial;  // [M*tiles][maxC][2]
-  float* dwpart;   // [M][128*F]
+  float* Wt1;     // transposed first-layer weights [3][64]
+  float* bn[6];   // [4][C] scale, shift, mean, invstd
+  float* coef[6]; // [3][C] alpha, gammap, betap
+  float* partial; // per-block column sums
+  float* dwpart;  // [M][cout*cin]
   float* count;
   int64_t total;
 };
@@ -519,13 +753,13 @@ PnWs carve(float* base, const Dims& d) {
     return r;
   };
   for (int l = 1; l <= 5; ++l) w.Y[l] = take(d.rows * d.C[l]);
-  for (int l = 1; l <= 4; ++l) w.A[l] = take(d.rows * d.C[l]);
   for (int l = 1; l <= 4; ++l) w.dZ[l] = take(d.rows * d.C[l]);
-  for (int l = 1; l <= 5; ++l) w.Wt[l] = take((int64_t)d.C[l - 1] * d.C[l]);
-  for (int l = 1; l <= 5; ++l) w.bnp[l] = reinterpret_cast<BnP*>(take(4LL * d.C[l]));
-  for (int l = 1; l <= 5; ++l) w.coef[l] = reinterpret_cast<Coef*>(take(4LL * d.C[l]));
+  w.Wt1 = take(192);
+  for (int l = 1; l <= 5; ++l) w.bn[l] = take(4LL * d.C[l]);
+  for (int l = 1; l <= 5; ++l) w.coef[l] = take(4LL * d.C[l]);
   const int64_t maxc = d.F > 128 ? d.F : 128;
-  w.partial = take(d.M * d.tiles * maxc * 2);
+  const int64_t blocks = d.M * (d.tiles1 > d.splits ? d.tiles1 : d.splits);
+  w.partial = take(blocks * maxc * 2);
   w.dwpart = take(d.M * 128 * maxc);
   w.count = take(4);
   w.total = p - base;
@@ -534,9 +768,24 @@ PnWs carve(float* base, const Dims& d) {
 
 int check_dims(int64_t M, int64_t N, int64_t F, const char* who) {
   MPA_REQUIRE(M >= 0 && N >= 1 && F >= 64, "%s: bad sizes", who);
-  MPA_REQUIRE(F % 64 == 0 && F <= 1024, "%s: feat_dim must be a multiple of 64 (<= 1024)", who);
-  MPA_REQUIRE(M <= 65535 && N < (1 << 24), "%s: too many parts / points", who);
+  MPA_REQUIRE(F == 64 || F == 128 || F == 256, "%s: feat_dim must be 64, 128 or 256", who);
+  MPA_REQUIRE(M <= 32767 && N < (1 << 24), "%s: too many parts / points", who);
   return MPA_OK;
+}
+
+template <bool TOP>
+void launch_dgrad(int K, const float* y, const float* dz, const float* gfeat, const int* argmax,
+                  const float* coef, const float* w, int cin, const float* y_prev, const float* bn_prev,
+                  const float* valids, const Dims& d, float* dz_prev, float* partial, hipStream_t s) {
+  const unsigned gx = (unsigned)(d.M * d.splits);
+#define MPA_DGRAD(KK, NT)                                                                                  \
+  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<KK, NT, TOP>), dim3(gx, cin / (32 * NT)), dim3(kT), 0, s, y, dz, \
+                     gfeat, argmax, coef, w, cin, y_prev, bn_prev, valids, (int)d.N, d.splits, dz_prev,    \
+                     partial)
+  if (K == 64) MPA_DGRAD(64, 2);
+  else if (K == 128) MPA_DGRAD(128, 2);
+  else MPA_DGRAD(256, 1);
+#undef MPA_DGRAD
 }
 
 }  // namespace
@@ -563,34 +812,34 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
   hipStream_t s = mpa::as_stream(stream);
   const Dims d = make_dims(M, N, F);
   const PnWs w = carve(float_ws, d);
-  for (int l = 1; l <= 5; ++l) {
-    const int e = d.C[l] * d.C[l - 1];
-    hipLaunchKernelGGL(pn_prep_kernel, dim3((e + 255) / 256), dim3(256), 0, s, conv_w[l - 1], w.Wt[l],
-                       d.C[l], d.C[l - 1]);
-  }
+  hipLaunchKernelGGL(pn_transpose_kernel, dim3(1), dim3(192), 0, s, conv_w[0], w.Wt1, 64, 3);
   hipLaunchKernelGGL(pn_count_kernel, dim3(1), dim3(64), 0, s, valids, (int)M, (int)N, w.count);
-  const dim3 grid((unsigned)d.tiles, (unsigned)M), blk(kT);
   for (int l = 1; l <= 5; ++l) {
-    const float* in = l == 1 ? points : w.Y[l - 1];
-    if (l == 1)
-      hipLaunchKernelGGL(pn_fwd_layer_kernel<3>, grid, blk, 0, s, in, (const BnP*)nullptr, (float*)nullptr,
-                         w.Wt[l], d.C[l], valids, (int)N, w.Y[l], w.partial);
-    else if (d.C[l - 1] == 64)
-      hipLaunchKernelGGL(pn_fwd_layer_kernel<64>, grid, blk, 0, s, in, w.bnp[l - 1], w.A[l - 1], w.Wt[l],
-                         d.C[l], valids, (int)N, w.Y[l], w.partial);
-    else
-      hipLaunchKernelGGL(pn_fwd_layer_kernel<128>, grid, blk, 0, s, in, w.bnp[l - 1], w.A[l - 1], w.Wt[l],
-                         d.C[l], valids, (int)N, w.Y[l], w.partial);
-    const dim3 cg((d.C[l] + 63) / 64);
+    int splits;
+    if (l == 1) {
+      splits = d.tiles1;
+      hipLaunchKernelGGL(pn_fwd_first_kernel, dim3((unsigned)d.tiles1, (unsigned)M), dim3(kT), 0, s, points,
+                         w.Wt1, valids, (int)N, w.Y[1], w.partial);
+    } else {
+      splits = d.splits;
+      const dim3 grid((unsigned)(M * d.splits), (unsigned)(d.C[l] / 64));
+      if (d.C[l - 1] == 64)
+        hipLaunchKernelGGL(pn_fwd_mfma_kernel<64>, grid, dim3(kT), 0, s, w.Y[l - 1], w.bn[l - 1], conv_w[l - 1],
+                           d.C[l], valids, (int)N, d.splits, w.Y[l], w.partial);
+      else
+        hipLaunchKernelGGL(pn_fwd_mfma_kernel<128>, grid, dim3(kT), 0, s, w.Y[l - 1], w.bn[l - 1], conv_w[l - 1],
+                           d.C[l], valids, (int)N, d.splits, w.Y[l], w.partial);
+    }
+    const dim3 cg((unsigned)(d.C[l] / 64));
     if (training)
-      hipLaunchKernelGGL(pn_bn_finalize_kernel, cg, dim3(64), 0, s, w.partial, valids, (int)M, (int)d.tiles,
+      hipLaunchKernelGGL(pn_bn_finalize_kernel, cg, dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, splits,
                          d.C[l], w.count, bn_w[l - 1], bn_b[l - 1], running_mean[l - 1], running_var[l - 1],
-                         momentum, eps, w.bnp[l]);
+                         momentum, eps, w.bn[l]);
     else
       hipLaunchKernelGGL(pn_bn_from_running_kernel, cg, dim3(64), 0, s, d.C[l], bn_w[l - 1], bn_b[l - 1],
-                         running_mean[l - 1], running_var[l - 1], eps, w.bnp[l]);
+                         running_mean[l - 1], running_var[l - 1], eps, w.bn[l]);
   }
-  hipLaunchKernelGGL(pn_maxpool_kernel, dim3((unsigned)(F / 64), (unsigned)M), blk, 0, s, w.Y[5], w.bnp[5],
+  hipLaunchKernelGGL(pn_maxpool_kernel, dim3((unsigned)(F / 64), (unsigned)M), dim3(kT), 0, s, w.Y[5], w.bn[5],
                      valids, (int)N, (int)F, feat, int_ws);
   return mpa::check_launch("pointnet_forward");
 }
@@ -607,37 +856,37 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   hipStream_t s = mpa::as_stream(stream);
   const Dims d = make_dims(M, N, F);
   const PnWs w = carve(float_ws, d);
-  const dim3 grid((unsigned)d.tiles, (unsigned)M), blk(kT);
-  hipLaunchKernelGGL(pn_bwd_top_kernel, dim3((unsigned)(F / 64)), dim3(64), 0, s, grad_feat, int_ws, w.Y[5],
-                     valids, (int)M, (int)N, (int)F, w.count, bn_w[4], w.bnp[5], w.coef[5], grad_bn_w[4],
-                     grad_bn_b[4]);
+  hipLaunchKernelGGL(pn_bwd_top_kernel, dim3((unsigned)(F / 64)), dim3(64 * kSlices), 0, s, grad_feat, int_ws,
+                     w.Y[5], valids, (int)M, (int)N, (int)F, w.count, bn_w[4], w.bn[5], w.coef[5],
+                     grad_bn_w[4], grad_bn_b[4]);
   for (int l = 5; l >= 1; --l) {
     const int cout = d.C[l], cin = d.C[l - 1];
-    const float* a_prev = l == 1 ? points : w.A[l - 1];
-    const dim3 wg((unsigned)((cout / 64) * ((cin + 63) / 64)), (unsigned)M);
-    if (l == 5)
-      hipLaunchKernelGGL((pn_wgrad_kernel<true, 64>), wg, blk, 0, s, w.Y[l], (const float*)nullptr, grad_feat,
-                         int_ws, w.coef[l], a_prev, cout, cin, valids, (int)N, w.dwpart);
-    else if (l == 1)
-      hipLaunchKernelGGL((pn_wgrad_kernel<false, 3>), wg, blk, 0, s, w.Y[l], w.dZ[l], (const float*)nullptr,
-                         (const int*)nullptr, w.coef[l], a_prev, cout, cin, valids, (int)N, w.dwpart);
-    else
-      hipLaunchKernelGGL((pn_wgrad_kernel<false, 64>), wg, blk, 0, s, w.Y[l], w.dZ[l], (const float*)nullptr,
-                         (const int*)nullptr, w.coef[l], a_prev, cout, cin, valids, (int)N, w.dwpart);
+    if (l == 1) {
+      hipLaunchKernelGGL(pn_wgrad_first_kernel, dim3(1, (unsigned)M), dim3(kT), 0, s, w.Y[1], w.dZ[1], w.coef[1],
+                         points, valids, (int)N, w.dwpart);
+    } else {
+      const dim3 wg((unsigned)((cout / 64) * (cin / 64)), (unsigned)M);
+      if (l == 5)
+        hipLaunchKernelGGL(pn_wgrad_mfma_kernel<true>, wg, dim3(kT), 0, s, w.Y[l], (const float*)nullptr,
+                           grad_feat, int_ws, w.coef[l], w.Y[l - 1], w.bn[l - 1], cout, cin, valids, (int)N,
+                           w.dwpart);
+      else
+        hipLaunchKernelGGL(pn_wgrad_mfma_kernel<false>, wg, dim3(kT), 0, s, w.Y[l], w.dZ[l],
+                           (const float*)nullptr, (const int*)nullptr, w.coef[l], w.Y[l - 1], w.bn[l - 1], cout,
+                           cin, valids, (int)N, w.dwpart);
+    }
     const int elems = cout * cin;
-    hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((elems + 255) / 256), dim3(256), 0, s, w.dwpart, valids,
-                       (int)M, elems, grad_conv_w[l - 1]);
+    hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * kSlices), 0, s,
+                       w.dwpart, valids, (int)M, elems, grad_conv_w[l - 1]);
     if (l == 1) break;
     if (l == 5)
-      hipLaunchKernelGGL(pn_dgrad_kernel<true>, grid, blk, 0, s, w.Y[l], (const float*)nullptr, grad_feat,
-                         int_ws, w.coef[l], conv_w[l - 1], cout, cin, w.Y[l - 1], w.bnp[l - 1], valids, (int)N,
-                         w.dZ[l - 1], w.partial);
+      launch_dgrad<true>(cout, w.Y[l], nullptr, grad_feat, int_ws, w.coef[l], conv_w[l - 1], cin, w.Y[l - 1],
+                         w.bn[l - 1], valids, d, w.dZ[l - 1], w.partial, s);
     else
-      hipLaunchKernelGGL(pn_dgrad_kernel<false>, grid, blk, 0, s, w.Y[l], w.dZ[l], (const float*)nullptr,
-                         (const int*)nullptr, w.coef[l], conv_w[l - 1], cout, cin, w.Y[l - 1], w.bnp[l - 1],
-                         valids, (int)N, w.dZ[l - 1], w.partial);
-    hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)((cin + 63) / 64)), dim3(64), 0, s, w.partial, valids,
-                       (int)M, (int)d.tiles, cin, w.count, bn_w[l - 2], w.bnp[l - 1], w.coef[l - 1],
+      launch_dgrad<false>(cout, w.Y[l], w.dZ[l], nullptr, nullptr, w.coef[l], conv_w[l - 1], cin, w.Y[l - 1],
+                          w.bn[l - 1], valids, d, w.dZ[l - 1], w.partial, s);
+    hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(cin / 64)), dim3(64 * kSlices), 0, s, w.partial,
+                       valids, (int)M, d.splits, cin, w.count, bn_w[l - 2], w.bn[l - 1], w.coef[l - 1],
                        grad_bn_w[l - 2], grad_bn_b[l - 2]);
   }
   return mpa::check_launch("pointnet_backward");

@@ -82,8 +82,8 @@ class PointNet(nn.Module):
         super().__init__()
         if not global_feat:
             raise NotImplementedError("per-point PointNet features are outside the hot path")
-        if feat_dim % 64 != 0:
-            raise NotImplementedError("the HIP PointNet needs feat_dim to be a multiple of 64")
+        if feat_dim not in (64, 128, 256):
+            raise NotImplementedError("the HIP PointNet is instantiated for feat_dim 64, 128 and 256")
         dims = (*self.WIDTHS, feat_dim)
         for i in range(5):
             setattr(self, f"conv{i + 1}", nn.Conv1d(dims[i], dims[i + 1], kernel_size=1, bias=False))
