@@ -9,9 +9,11 @@ clouds, B = 32 per GPU, P = 20, N = 1000 (BASELINE.json configs[1]; weak scaling
 
 Rank 0 prints ONE JSON line.  `value` = parts (B x P slots, padded slots included, as the metric is
 defined) processed per second by the whole job, inputs resident in HBM before the timed region.
-`roofline` describes the dominant kernel (the whole-shape Chamfer search), timed per launch with HIP
-events on its own stream inside the timed region; `cpu_baseline` is the oracle's reference-equivalent
-PyTorch-CPU step timed on this host (rank 0, N = 1 only) on a bounded sample.
+The timed K steps replay the HIP graph of the whole step (disable with --no-graph).  `roofline`
+describes the dominant kernel (the whole-shape Chamfer search of the fused loss): a second pass of the
+SAME K steps is run eagerly with HIP events recorded by the library around that kernel on its launch
+stream (individual kernels cannot be bracketed inside a graph replay).  `cpu_baseline` is the oracle's
+reference-equivalent PyTorch-CPU step timed on this host (rank 0, N = 1 only) on a bounded sample.
 """
 from __future__ import annotations
 
@@ -39,6 +41,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly")
     ap.add_argument("--cpu-batch", type=int, default=4, help="samples in the CPU-baseline step")
     return ap.parse_args()
 
@@ -99,7 +102,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -114,56 +118,77 @@ def main():
     cfg = config.pn_transformer_everyday()
     torch.manual_seed(0)  # same initial weights on every rank (and broadcast from rank 0 anyway)
     model = build_model(cfg).to(dev)
-    trainer = Trainer(model, cfg)
+    use_graph = not args.no_graph
+    trainer = Trainer(model, cfg, use_graph=use_graph)
     batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234 + rank, device=dev)
-    valid_parts = int(sum(batch["num_parts"]))
+    num_parts = batch.pop("num_parts")
+    valid_parts = int(sum(num_parts))
 
-    for i in range(args.warmup):
+    # untimed: W warm-up steps (+ the eager settle steps and the capture itself in graph mode)
+    for i in range(args.warmup + (trainer.graph_warmup + 1 if use_graph else 0)):
         trainer.train_step(batch, i)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
     fence()
     timer = _lib.KernelTimer()
-    _lib.KernelTimer.active = timer
+    if not use_graph:
+        _lib.KernelTimer.active = timer
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = trainer.train_step(batch, i)
     fence()
     elapsed = time.perf_counter() - t0
     _lib.KernelTimer.active = None
-    if world > 1:
+    final_loss = float(loss)
+    if use_graph and rank == 0:
+        # per-kernel timing pass: the same K steps launched eagerly, library-recorded HIP events
+        _lib.KernelTimer.active = timer
+        for i in range(args.steps):
+            trainer._fwd_bwd(batch)
+            trainer.optimizer.prepare_hyper()
+            trainer.optimizer.step_dev()
+        torch.cuda.synchronize()
+        _lib.KernelTimer.active = None
+    if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(loss)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(1, args.steps)
         value = world * BATCH * PARTS * args.steps / elapsed
         kernels = timer.summary()
-        dom = f"chamfer_forward[{BATCH}x{PARTS * POINTS}x{PARTS * POINTS}]"
+        dom = f"assembly_shape_chamfer[{BATCH}x{PARTS}x{POINTS}]"
         roofline = None
         if dom in kernels:
             k = kernels[dom]
-            alg_bytes = 24.0 * BATCH * 2 * PARTS * POINTS          # 24 B/point
-            pairs = 2.0 * BATCH * (PARTS * POINTS) ** 2
-            achieved = alg_bytes / (k["avg_ms"] * 1e-3) / 1e9
+            # algorithmic traffic of the fused whole-shape search: per VALID point and
+            # direction 12 B coordinates read + 4 B index written (distances are reduced in-kernel to one
+            # partial sum per block), both clouds -> 32 B per valid point; padded slots cost nothing.
+            alg_bytes = 32.0 * valid_parts * POINTS
+            pairs = 2.0 * POINTS * POINTS * sum(n * n for n in num_parts)
+            secs = k["avg_ms"] * 1e-3
+            achieved = alg_bytes / secs / 1e9
             roofline = {
-                "kernel": "chamfer_nn_kernel<float,4,filter> (whole-shape Chamfer, both directions)",
+                "kernel": "assembly_nn_kernel<Q=2, chunk-min, SHAPE> (whole-shape Chamfer of the fused loss, "
+                          "both directions, pad representatives)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
                 "algorithmic_bytes_per_launch": alg_bytes,
-                # exact brute force is VALU-bound, not HBM-bound: also report
-                # the pair-evaluation rate against the fp32 VALU issue peak at ~3.6 lane-ops/pair
-                "valu": {"pair_evals_per_s": pairs / (k["avg_ms"] * 1e-3),
-                         "lane_ops_per_pair_est": 5.6,
-                         "frac_of_valu_issue_peak": pairs * 5.6 / (k["avg_ms"] * 1e-3) / VALU_PEAK_LANE_OPS},
+                "timing": "HIP events recorded by libmpa_hip.so around the kernel on its launch stream"
+                          + (", eager pass of the same K steps after the graph-replay timed region"
+                             if use_graph else ", inside the timed region"),
+                # exact brute force is VALU-bound, not HBM-bound: the binding roof is
+                # the fp32 VALU issue rate; 8.6 lane-slots per pair (3 sub, 3 mul, 2 add, 0.6 min/compare)
+                "valu": {"pair_evals_per_launch": pairs, "pair_evals_per_s": pairs / secs,
+                         "lane_slots_per_pair": 8.6,
+                         "frac_of_valu_issue_peak": pairs * 8.6 / secs / VALU_PEAK_LANE_OPS},
             }
         line = {
             "metric": "train-step parts/sec (BxP) at N=1000 pts",
@@ -174,7 +199,8 @@ def main():
                                    "synthetic clouds, B=32 per GPU, P=20, N=1000, geometric loss, Adam "
                                    "(BASELINE.json configs[1])",
                        "per_gpu_batch": BATCH, "max_parts": PARTS, "points_per_part": POINTS,
-                       "valid_parts_rank0": valid_parts, "parallelism": f"dp{world}"},
+                       "valid_parts_rank0": valid_parts, "parallelism": f"dp{world}",
+                       "launch": "hip-graph replay" if use_graph else "eager"},
             "final_loss": final_loss,
             "kernels": kernels,
             "roofline": roofline,
@@ -182,7 +208,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -133,6 +133,14 @@ int mpa_assembly_loss_forward(const float* part_pcs, const float* valids, const 
                               const float* trans_pred, const float* quat_gt, const float* trans_gt,
                               int64_t B, int64_t P, int64_t N, int training, int fill_pad_points,
                               float* float_ws, int32_t* int_ws, float* losses, void* stream);
+/* Profiling twin: identical launches; `events` (may be NULL) is a host array of 5 hipEvent_t recorded on
+ * `stream` at the phase boundaries — start, after pose kernel, after per-part Chamfer, after whole-shape
+ * Chamfer, after finalize — so a benchmark can time the dominant kernel inside its timed region. */
+int mpa_assembly_loss_forward_timed(const float* part_pcs, const float* valids, const float* quat_pred,
+                                    const float* trans_pred, const float* quat_gt, const float* trans_gt,
+                                    int64_t B, int64_t P, int64_t N, int training, int fill_pad_points,
+                                    float* float_ws, int32_t* int_ws, float* losses, void* const* events,
+                                    void* stream);
 /* grad_losses [5,B] = d(objective)/d(losses); writes grad_quat [B,P,4] and grad_trans [B,P,3] of the
  * PREDICTED pose.  Deterministic (no atomics). */
 int mpa_assembly_loss_backward(const float* grad_losses, const float* part_pcs, const float* valids,
@@ -181,6 +189,12 @@ int mpa_pointnet_backward(const float* grad_feat, const float* points, const flo
 int mpa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
                   float lr, float beta1, float beta2, float eps, float weight_decay,
                   int decoupled_weight_decay, int64_t step, float grad_scale, void* stream);
+
+/* Graph-capturable twin: `hyper` is a DEVICE buffer {lr, 1-beta1^step, sqrt(1-beta2^step), grad_scale}
+ * that the host refreshes between replays of a captured step (the launch arguments stay constant). */
+int mpa_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                      const float* hyper, float beta1, float beta2, float eps, float weight_decay,
+                      int decoupled_weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -36,11 +36,13 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_pose_apply_backward": (_INT, [_P, _P, _P, _P, _F32, _I64, _I64, _P, _P, _P, _P]),
     "mpa_assembly_loss_workspace": (_INT, [_I64, _I64, _I64, _P, _P]),
     "mpa_assembly_loss_forward": (_INT, [_P] * 6 + [_I64, _I64, _I64, _INT, _INT, _P, _P, _P, _P]),
+    "mpa_assembly_loss_forward_timed": (_INT, [_P] * 6 + [_I64, _I64, _I64, _INT, _INT, _P, _P, _P, _P, _P]),
     "mpa_assembly_loss_backward": (_INT, [_P] * 7 + [_I64, _I64, _I64, _INT, _P, _P, _P, _P, _P]),
     "mpa_pointnet_workspace": (_INT, [_I64, _I64, _I64, _P, _P]),
     "mpa_pointnet_forward": (_INT, [_P] * 7 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
     "mpa_pointnet_backward": (_INT, [_P] * 5 + [_I64, _I64, _I64] + [_P] * 6),
     "mpa_adam_step": (_INT, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _INT, _I64, _F32, _P]),
+    "mpa_adam_step_dev": (_INT, [_P, _P, _P, _P, _I64, _P, _F32, _F32, _F32, _F32, _INT, _P]),
 }
 
 ABI_VERSION = 1
@@ -130,6 +132,23 @@ class KernelTimer:
         end = torch.cuda.Event(enable_timing=True)
         end.record()
         cls.active.events.setdefault(token[0], []).append((token[1], end))
+
+    @classmethod
+    def phase_events(cls, count: int):
+        """`count` timing events for a library call that records its own phase boundaries, or None."""
+        if cls.active is None:
+            return None
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(count)]
+        for e in evs:
+            e.record()  # materialise the hipEvent_t handle; the library re-records it at the right place
+        return evs
+
+    @classmethod
+    def add_phases(cls, names, evs) -> None:
+        if evs is None or cls.active is None:
+            return
+        for i, name in enumerate(names):
+            cls.active.events.setdefault(name, []).append((evs[i], evs[i + 1]))
 
     def summary(self) -> dict[str, dict]:
         """name -> {launches, avg_ms, total_ms}; call after torch.cuda.synchronize()."""

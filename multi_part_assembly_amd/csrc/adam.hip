@@ -6,6 +6,8 @@
 // moments of the model live in four flat buffers here (multi_part_assembly_amd/optim.py), so one
 // step is ONE streaming kernel: 16 B read + 12 B written per element, float4-vectorised.
 // `grad_scale` folds the 1/world_size of the data-parallel gradient mean into the same pass.
+// mpa_adam_step_dev is the graph-capturable twin: learning rate, bias corrections and grad_scale are read
+// from a 4-float DEVICE buffer, so a captured launch stays valid while the host advances the schedule.
 //
 // Update rule = torch.optim.Adam's (single-tensor path), term by term:
 //   g  = grad*grad_scale (+ wd*p for Adam's L2 form);   p *= 1 - lr*wd  for AdamW's decoupled form
@@ -38,7 +40,14 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ para
                                                         const float* __restrict__ grad,
                                                         float* __restrict__ exp_avg,
                                                         float* __restrict__ exp_avg_sq,
-                                                        long long n, AdamArgs a) {
+                                                        long long n, AdamArgs a,
+                                                        const float* __restrict__ dev_hyper) {
+  if (dev_hyper != nullptr) {  // {lr, bc1, bc2_sqrt, grad_scale} refreshed by the host between replays
+    a.lr = dev_hyper[0];
+    a.bc1 = dev_hyper[1];
+    a.bc2_sqrt = dev_hyper[2];
+    a.grad_scale = dev_hyper[3];
+  }
   const long long n4 = n / 4;
   const long long stride = (long long)gridDim.x * kThreads;
   for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
@@ -85,6 +94,29 @@ extern "C" int mpa_adam_step(float* param, const float* grad, float* exp_avg, fl
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, mpa::as_stream(stream),
-                     param, grad, exp_avg, exp_avg_sq, (long long)numel, a);
+                     param, grad, exp_avg, exp_avg_sq, (long long)numel, a, (const float*)nullptr);
   return mpa::check_launch("adam_step");
+}
+
+extern "C" int mpa_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                 int64_t numel, const float* hyper, float beta1, float beta2, float eps,
+                                 float weight_decay, int decoupled_weight_decay, void* stream) {
+  MPA_REQUIRE(numel >= 0, "adam_step_dev: bad numel");
+  if (numel == 0) return MPA_OK;
+  MPA_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper, "adam_step_dev: null pointer");
+  MPA_REQUIRE(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
+              "adam_step_dev: buffers must be 16-byte aligned");
+  AdamArgs a;
+  a.lr = a.bc1 = a.bc2_sqrt = a.grad_scale = 0.0f;  // taken from `hyper` on the device
+  a.beta1 = beta1;
+  a.beta2 = beta2;
+  a.eps = eps;
+  a.weight_decay = weight_decay;
+  a.decoupled = decoupled_weight_decay;
+  long long blocks = (numel / 4 + kThreads - 1) / kThreads;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, mpa::as_stream(stream),
+                     param, grad, exp_avg, exp_avg_sq, (long long)numel, a, hyper);
+  return mpa::check_launch("adam_step_dev");
 }

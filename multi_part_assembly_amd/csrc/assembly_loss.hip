@@ -463,12 +463,35 @@ Workspace carve(float* fws, int32_t* iws, int64_t B, int64_t P, int64_t N, int q
 }
 }  // namespace
 
+extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const float* valids,
+                                               const float* quat_pred, const float* trans_pred,
+                                               const float* quat_gt, const float* trans_gt, int64_t B,
+                                               int64_t P, int64_t N, int training, int fill_pad_points,
+                                               float* float_ws, int32_t* int_ws, float* losses,
+                                               void* const* events, void* stream);
+
 extern "C" int mpa_assembly_loss_forward(const float* part_pcs, const float* valids,
                                          const float* quat_pred, const float* trans_pred,
                                          const float* quat_gt, const float* trans_gt, int64_t B,
                                          int64_t P, int64_t N, int training, int fill_pad_points,
                                          float* float_ws, int32_t* int_ws, float* losses,
                                          void* stream) {
+  return mpa_assembly_loss_forward_timed(part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, B, P, N,
+                                         training, fill_pad_points, float_ws, int_ws, losses, nullptr, stream);
+}
+
+// Same launches; when `events` is non-null it holds 5 hipEvent_t recorded on `stream` at the phase
+// boundaries: [0] start, [1] after the pose kernel, [2] after the per-part Chamfer, [3] after the
+// whole-shape Chamfer, [4] after the finalize kernel (bench.py times the dominant kernel with them).
+extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const float* valids,
+                                               const float* quat_pred, const float* trans_pred,
+                                               const float* quat_gt, const float* trans_gt, int64_t B,
+                                               int64_t P, int64_t N, int training, int fill_pad_points,
+                                               float* float_ws, int32_t* int_ws, float* losses,
+                                               void* const* events, void* stream) {
+  auto mark = [&](int k) {
+    if (events != nullptr) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(events[k]), mpa::as_stream(stream));
+  };
   MPA_REQUIRE(B >= 0 && P >= 0 && N >= 0, "assembly_loss_forward: negative size");
   if (B == 0) return MPA_OK;
   MPA_REQUIRE(P >= 1 && P <= 64 && N >= 1, "assembly_loss_forward: need 1 <= P <= 64 and N >= 1");
@@ -480,31 +503,37 @@ extern "C" int mpa_assembly_loss_forward(const float* part_pcs, const float* val
   const int q = pick_q(B, P, N);
   const Workspace w = carve(float_ws, int_ws, B, P, N, q);
   const unsigned parts = (unsigned)(B * P);
-  hipLaunchKernelGGL(assembly_pose_kernel, dim3(parts), dim3(kThreads), 0, s, part_pcs, valids,
-                     quat_pred, trans_pred, quat_gt, trans_gt, (int)N, fill_pad_points, w.R1, w.R2,
-                     w.S1, w.S2, w.partial);
   // padded parts never write their tile sums: clear them (2 directions x B*P*tiles, both arrays)
   if (hipMemsetAsync(w.part_tiles, 0, sizeof(float) * 4 * B * P * w.tiles, s) != hipSuccess)
     return mpa::check_launch("assembly_loss_forward(memset)");
+  mark(0);
+  hipLaunchKernelGGL(assembly_pose_kernel, dim3(parts), dim3(kThreads), 0, s, part_pcs, valids,
+                     quat_pred, trans_pred, quat_gt, trans_gt, (int)N, fill_pad_points, w.R1, w.R2,
+                     w.S1, w.S2, w.partial);
+  mark(1);
   const dim3 grid(parts * w.tiles, 2, 1);
   // Steering a sample's blocks to one XCD (L2 affinity) loses more to the static load imbalance between
   // XCDs than it gains (measured 2.56 vs 2.21 ms at B=32, P=20, N=1000): off unless MPA_XCD_REMAP=1.
   const char* re = getenv("MPA_XCD_REMAP");
   const int remap = re ? (re[0] != '0') : 0;
-  if (q == 4) {
+  if (q == 4)
     hipLaunchKernelGGL((assembly_nn_kernel<4, mpa::kChunkMin, false>), grid, dim3(kThreads), 0, s, valids,
                        w.R1, w.R2, (int)B, (int)P, (int)N, w.tiles, remap, w.ip1, w.ip2, w.part_tiles);
-    hipLaunchKernelGGL((assembly_nn_kernel<4, mpa::kChunkMin, true>), grid, dim3(kThreads), 0, s, valids,
-                       w.S1, w.S2, (int)B, (int)P, (int)N, w.tiles, remap, w.is1, w.is2, w.shape_tiles);
-  } else {
+  else
     hipLaunchKernelGGL((assembly_nn_kernel<2, mpa::kChunkMin, false>), grid, dim3(kThreads), 0, s, valids,
                        w.R1, w.R2, (int)B, (int)P, (int)N, w.tiles, remap, w.ip1, w.ip2, w.part_tiles);
+  mark(2);
+  if (q == 4)
+    hipLaunchKernelGGL((assembly_nn_kernel<4, mpa::kChunkMin, true>), grid, dim3(kThreads), 0, s, valids,
+                       w.S1, w.S2, (int)B, (int)P, (int)N, w.tiles, remap, w.is1, w.is2, w.shape_tiles);
+  else
     hipLaunchKernelGGL((assembly_nn_kernel<2, mpa::kChunkMin, true>), grid, dim3(kThreads), 0, s, valids,
                        w.S1, w.S2, (int)B, (int)P, (int)N, w.tiles, remap, w.is1, w.is2, w.shape_tiles);
-  }
+  mark(3);
   hipLaunchKernelGGL(assembly_finalize_kernel, dim3((unsigned)B), dim3(64), 0, s, valids, quat_pred,
                      trans_pred, quat_gt, trans_gt, w.partial, w.part_tiles, w.shape_tiles, (int)B,
                      (int)P, (int)N, w.tiles, training, losses);
+  mark(4);
   return mpa::check_launch("assembly_loss_forward");
 }
 

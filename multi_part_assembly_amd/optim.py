@@ -88,6 +88,32 @@ class FusedAdam:
                 self.step_count, float(self.grad_scale), _lib.current_stream(dev))
         _lib.check(st, "mpa_adam_step")
 
+    # ---- graph-capturable form: hyper-parameters live in a 4-float device buffer -----------------------
+    def _hyper_values(self, step):
+        b1, b2 = self.betas
+        return [float(self.lr), 1.0 - b1 ** step, math.sqrt(1.0 - b2 ** step), float(self.grad_scale)]
+
+    def prepare_hyper(self):
+        """Advance the step count and upload {lr, bias corrections, grad_scale} for the next captured or
+        eager `step_dev` launch (async copy from pinned memory on the current stream)."""
+        if not hasattr(self, "_hyper_dev"):
+            self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=self.flat_param.device)
+            self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        self.step_count += 1
+        self._hyper_host.copy_(torch.tensor(self._hyper_values(self.step_count)))
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+
+    def step_dev(self):
+        """The Adam launch with device-resident hyper-parameters (safe to capture in a HIP graph)."""
+        dev = self.flat_param.device
+        with torch.cuda.device(dev):
+            st = _lib.lib().mpa_adam_step_dev(
+                _lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
+                _lib.ptr(self.exp_avg_sq), self.numel, _lib.ptr(self._hyper_dev), float(self.betas[0]),
+                float(self.betas[1]), float(self.eps), float(self.weight_decay), int(self.decoupled),
+                _lib.current_stream(dev))
+        _lib.check(st, "mpa_adam_step_dev")
+
     def state_dict(self):
         return {"step": self.step_count, "lr": self.lr, "exp_avg": self.exp_avg.clone(),
                 "exp_avg_sq": self.exp_avg_sq.clone()}

@@ -3,6 +3,13 @@
 zero_grad -> training_step -> backward (gradient buckets all-reduced while it runs) -> fused Adam,
 with the per-epoch cosine schedule.  No host synchronisation inside a step: the loss is returned as
 a device tensor.
+
+With `use_graph=True` the whole step (several hundred launches, most of them tiny) is captured once
+into a HIP graph and replayed: the launch shapes are static by construction (all B*P part slots +
+masks, no compaction), the batch is copied into static input tensors, and the optimiser's
+per-step scalars live in device memory.  On one GPU the graph holds zero_grad + forward + backward +
+Adam; with data parallelism it holds zero_grad + forward + backward, the gradient all-reduce and Adam
+run eagerly behind it.
 """
 from __future__ import annotations
 
@@ -14,8 +21,10 @@ from .optim import FlatBuffers, FusedAdam, cosine_warmup_lr
 
 
 class Trainer:
-    def __init__(self, model, cfg=None, process_group=None):
+    def __init__(self, model, cfg=None, process_group=None, use_graph=False, graph_warmup=3):
         self.model = model
+        self.use_graph, self.graph_warmup = use_graph, graph_warmup
+        self._graph, self._static_batch, self._static_loss, self._eager_steps = None, None, None, 0
         cfg = cfg if cfg is not None else model.cfg
         opt = cfg.optimizer
         self.flat = FlatBuffers(ordered_parameters(model))
@@ -28,7 +37,10 @@ class Trainer:
         self.epoch = 0
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         broadcast_from_rank0(self.flat, model, process_group)
-        self.reducer = BucketedGradReducer(self.flat, bucket_sizes_for(model, self.flat), process_group)
+        self.group = process_group
+        # graph mode replaces the backward-overlapped bucket hooks by one all-reduce after the replay
+        self.reducer = None if use_graph else BucketedGradReducer(
+            self.flat, bucket_sizes_for(model, self.flat), process_group)
         self.set_epoch(0)
 
     def set_epoch(self, epoch):
@@ -36,8 +48,53 @@ class Trainer:
         if self.schedule is not None:
             self.optimizer.lr = self.schedule(epoch)
 
+    # ---- graph mode -----------------------------------------------------------------------------------
+    def _tensor_items(self, data_dict):
+        return {k: v for k, v in data_dict.items() if isinstance(v, torch.Tensor)}
+
+    def _fwd_bwd(self, batch):
+        self.optimizer.zero_grad()
+        loss = self.model.training_step(batch, 0)
+        loss.backward()
+        return loss.detach()
+
+    def _capture(self, data_dict):
+        self._static_batch = {k: v.clone() for k, v in self._tensor_items(data_dict).items()}
+        self._graph = torch.cuda.CUDAGraph()
+        # thread_local: RCCL's watchdog thread may touch the HIP runtime while we capture
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+            self._static_loss = self._fwd_bwd(self._static_batch)
+            if self.world == 1:
+                self.optimizer.step_dev()
+
+    def _graph_step(self, data_dict):
+        self.model.train()
+        self.optimizer.grad_scale = 1.0 / self.world
+        if self._graph is None:
+            if self._eager_steps < self.graph_warmup:  # let allocator / library state settle first
+                self._eager_steps += 1
+                loss = self._fwd_bwd(self._tensor_items(data_dict))
+                if self.world > 1:
+                    dist.all_reduce(self.flat.flat_grad, group=self.group)
+                self.optimizer.prepare_hyper()
+                self.optimizer.step_dev()
+                return loss
+            torch.cuda.synchronize()
+            self._capture(data_dict)
+        for k, v in self._tensor_items(data_dict).items():
+            if v.data_ptr() != self._static_batch[k].data_ptr():
+                self._static_batch[k].copy_(v, non_blocking=True)
+        self.optimizer.prepare_hyper()
+        self._graph.replay()
+        if self.world > 1:
+            dist.all_reduce(self.flat.flat_grad, group=self.group)
+            self.optimizer.step_dev()
+        return self._static_loss
+
     def train_step(self, data_dict, batch_idx=0):
         """One optimiser step on this rank's shard; returns the (detached) scalar loss tensor."""
+        if self.use_graph:
+            return self._graph_step(data_dict)
         self.model.train()
         self.optimizer.zero_grad()
         loss = self.model.training_step(data_dict, batch_idx)
