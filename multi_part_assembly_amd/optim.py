@@ -90,7 +90,8 @@ class FusedAdam:
 
     # ---- graph-capturable form: hyper-parameters live in a 4-float device buffer -----------------------
     def _hyper_values(self, step):
-        b1, b2 = self.betas
+        # same arithmetic as mpa_adam_step: betas rounded to fp32 first, powers and sqrt in double
+        b1, b2 = (float(torch.tensor(b, dtype=torch.float32)) for b in self.betas)
         return [float(self.lr), 1.0 - b1 ** step, math.sqrt(1.0 - b2 ** step), float(self.grad_scale)]
 
     def prepare_hyper(self):

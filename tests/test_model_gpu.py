@@ -214,3 +214,61 @@ def test_trainer_step_matches_oracle_step(golden, cuda_device):
     g = trainer.flat.flat_grad
     want = before - cfg.optimizer.lr * g / (g.abs() + 1e-8)
     np.testing.assert_allclose(trainer.flat.flat_param.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def _fresh_trainer(golden, cuda_device, **kw):
+    z = golden("pn_transformer_step")
+    cfg = _small_cfg(z)
+    cfg.optimizer.lr_scheduler = ""
+    model = build_model(cfg)
+    _load(model, z, "sd0.")
+    _no_dropout(model)
+    model.to(cuda_device)
+    batch = {k[5:]: T(v).to(cuda_device) for k, v in z.items() if k.startswith("data.")}
+    return Trainer(model, cfg, **kw), batch
+
+
+def _same_trajectory(a, b):
+    """The pipeline is deterministic (no atomics on this path) and the graph-mode Adam uses the same
+    arithmetic as the eager one, so the two trajectories must agree to the last bit."""
+    assert torch.equal(a, b), float((a - b).abs().max())
+
+
+def test_graph_replay_equals_eager_steps(golden, cuda_device):
+    """The captured HIP graph of the whole step (zero_grad + forward + backward + Adam with device-side
+    scalars) must walk the same parameter trajectory as eager launches."""
+    eager, batch = _fresh_trainer(golden, cuda_device)
+    graph, _ = _fresh_trainer(golden, cuda_device, use_graph=True, graph_warmup=1)
+    for step in range(5):
+        le = eager.train_step(batch)
+        lg = graph.train_step(batch)
+        assert float(lg) == float(le)
+    assert graph._graph is not None  # steps 2.. were replays
+    _same_trajectory(graph.flat.flat_param, eager.flat.flat_param)
+
+
+def test_graph_trainer_data_parallel_path(golden, cuda_device):
+    """world > 1 code path of graph mode on one GPU: a 1-rank RCCL group with the trainer told it is one of
+    two ranks — the graph then holds forward+backward only, the all-reduce and Adam (grad_scale = 1/2) run
+    behind it.  Equals an eager single-rank trainer whose optimiser scales gradients by 1/2."""
+    import os
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda_device)
+    try:
+        dp, batch = _fresh_trainer(golden, cuda_device, use_graph=True, graph_warmup=1)
+        dp.world = 2
+        ref, _ = _fresh_trainer(golden, cuda_device)
+        for step in range(4):
+            dp.train_step(batch)
+            ref.model.train()
+            ref.optimizer.zero_grad()
+            ref.model.training_step(batch).backward()
+            ref.optimizer.grad_scale = 0.5
+            ref.optimizer.step()
+        _same_trajectory(dp.flat.flat_param, ref.flat.flat_param)
+    finally:
+        dist.destroy_process_group()
