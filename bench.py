@@ -9,11 +9,11 @@ clouds, B = 32 per GPU, P = 20, N = 1000 (BASELINE.json configs[1]; weak scaling
 
 Rank 0 prints ONE JSON line.  `value` = parts (B x P slots, padded slots included, as the metric is
 defined) processed per second by the whole job, inputs resident in HBM before the timed region.
-The timed K steps replay the HIP graph of the whole step (disable with --no-graph).  `roofline`
-describes the dominant kernel (the whole-shape Chamfer search of the fused loss): a second pass of the
-SAME K steps is run eagerly with HIP events recorded by the library around that kernel on its launch
-stream (individual kernels cannot be bracketed inside a graph replay).  `cpu_baseline` is the oracle's
-reference-equivalent PyTorch-CPU step timed on this host (rank 0, N = 1 only) on a bounded sample.
+Kernels are launched eagerly (the step is GPU-bound: a HIP-graph replay of the whole step, --graph,
+measures the same ms/step).  `roofline` describes the dominant kernel (the whole-shape Chamfer search of
+the fused loss), timed per launch with HIP events that the library records around it on its launch
+stream inside the timed region.  `cpu_baseline` is the oracle's reference-equivalent PyTorch-CPU step
+timed on this host (rank 0, N = 1 only) on a bounded sample.
 """
 from __future__ import annotations
 
@@ -41,7 +41,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one HIP graph (default: eager launches; see trainer.py)")
     ap.add_argument("--cpu-batch", type=int, default=4, help="samples in the CPU-baseline step")
     return ap.parse_args()
 
@@ -118,7 +119,7 @@ def main():
     cfg = config.pn_transformer_everyday()
     torch.manual_seed(0)  # same initial weights on every rank (and broadcast from rank 0 anyway)
     model = build_model(cfg).to(dev)
-    use_graph = not args.no_graph
+    use_graph = args.graph
     trainer = Trainer(model, cfg, use_graph=use_graph)
     batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234 + rank, device=dev)
     num_parts = batch.pop("num_parts")
@@ -163,32 +164,31 @@ def main():
         ms_per_step = 1e3 * elapsed / max(1, args.steps)
         value = world * BATCH * PARTS * args.steps / elapsed
         kernels = timer.summary()
-        dom = f"assembly_shape_chamfer[{BATCH}x{PARTS}x{POINTS}]"
+        dom = f"grid_search_kernel[{BATCH}x{PARTS}x{POINTS}]"
+        phase = f"assembly_shape_chamfer[{BATCH}x{PARTS}x{POINTS}]"
         roofline = None
         if dom in kernels:
             k = kernels[dom]
-            # algorithmic traffic of the fused whole-shape search: per VALID point and
-            # direction 12 B coordinates read + 4 B index written (distances are reduced in-kernel to one
-            # partial sum per block), both clouds -> 32 B per valid point; padded slots cost nothing.
-            alg_bytes = 32.0 * valid_parts * POINTS
-            pairs = 2.0 * POINTS * POINTS * sum(n * n for n in num_parts)
+            # algorithmic traffic of the whole-shape search kernel: every valid point of both
+            # shapes is read once as a 16 B query record and once as a 16 B target record and produces a 4 B
+            # distance and a 4 B index -> 40 B per valid point and shape; padded slots cost nothing.
+            alg_bytes = 2.0 * 40.0 * valid_parts * POINTS
+            brute_pairs = 2.0 * POINTS * POINTS * sum(n * n for n in num_parts)
             secs = k["avg_ms"] * 1e-3
             achieved = alg_bytes / secs / 1e9
             roofline = {
-                "kernel": "assembly_nn_kernel<Q=2, chunk-min, SHAPE> (whole-shape Chamfer of the fused loss, "
-                          "both directions, pad representatives)",
+                "kernel": "mpa::grid_search_kernel (exact grid-pruned whole-shape Chamfer search of the fused "
+                          "loss, both directions)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "timing": "HIP events recorded by libmpa_hip.so around the kernel on its launch stream"
-                          + (", eager pass of the same K steps after the graph-replay timed region"
-                             if use_graph else ", inside the timed region"),
-                # exact brute force is VALU-bound, not HBM-bound: the binding roof is
-                # the fp32 VALU issue rate; 8.6 lane-slots per pair (3 sub, 3 mul, 2 add, 0.6 min/compare)
-                "valu": {"pair_evals_per_launch": pairs, "pair_evals_per_s": pairs / secs,
-                         "lane_slots_per_pair": 8.6,
-                         "frac_of_valu_issue_peak": pairs * 8.6 / secs / VALU_PEAK_LANE_OPS},
+                "timing": "HIP events recorded by libmpa_hip.so right before/after the kernel on its launch "
+                          "stream, inside the timed region",
+                "whole_phase_avg_ms": kernels[phase]["avg_ms"] if phase in kernels else None,
+                # the search is VALU-bound, not HBM-bound: pair evaluations an exhaustive scan of
+                # the same valid points would need, per second of this kernel
+                "equivalent_brute_force_pair_evals_per_s": brute_pairs / secs,
             }
         line = {
             "metric": "train-step parts/sec (BxP) at N=1000 pts",

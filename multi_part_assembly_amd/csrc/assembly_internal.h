@@ -1,0 +1,21 @@
+// Internal (non-ABI) interface between assembly_loss.hip and grid_nn.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mpa {
+
+// extra workspace the grid-pruned whole-shape search needs (floats / int32s)
+int64_t grid_workspace_floats(int64_t B, int64_t P, int64_t N);
+int64_t grid_workspace_ints(int64_t B);
+
+// Exact NN of every valid point of S1 in S2 and vice versa (whole shapes of each sample, padded parts as
+// one representative).  Writes idx1/idx2 [B,P,N] (index within the sample, -1 if none) and the per-part
+// distance sums into tile_sums[dir][m*tiles + 0].  fws/iws: scratch sized by the functions above.
+// before_search / after_search (nullable) are recorded around the search kernel proper.
+int launch_grid_shape_search(const float* valids, const float* S1, const float* S2, int64_t B, int64_t P,
+                             int64_t N, int tiles, float* fws, int32_t* iws, int32_t* idx1, int32_t* idx2,
+                             float* tile_sums, hipEvent_t before_search, hipEvent_t after_search, hipStream_t s);
+
+}  // namespace mpa

@@ -27,6 +27,7 @@
 // 4 rot_pt_l2_loss (the names of base_model.py:283-298).
 #include <stdlib.h>
 
+#include "assembly_internal.h"
 #include "chamfer_core.h"
 #include "common.h"
 
@@ -421,18 +422,25 @@ extern "C" int mpa_assembly_loss_workspace(int64_t B, int64_t P, int64_t N, int6
                                            int64_t* int_elems) {
   MPA_REQUIRE(B >= 0 && P >= 0 && N >= 0 && float_elems && int_elems, "assembly_loss_workspace: bad args");
   const int64_t tiles = (N + kMinTile - 1) / kMinTile;
-  // 4 clouds + partial[5] + 2 tile-sum arrays (2 directions each)
-  *float_elems = 4 * B * P * N * 3 + 5 * B * P + 4 * B * P * tiles;
-  *int_elems = 4 * B * P * N;
+  // 4 clouds + partial[5] + 2 tile-sum arrays (2 directions each), rounded to 16 B, + grid-search scratch
+  *float_elems = (4 * B * P * N * 3 + 5 * B * P + 4 * B * P * tiles + 3) / 4 * 4 + mpa::grid_workspace_floats(B, P, N);
+  *int_elems = 4 * B * P * N + mpa::grid_workspace_ints(B);
   return MPA_OK;
 }
 
 namespace {
 struct Workspace {
-  float *R1, *R2, *S1, *S2, *partial, *part_tiles, *shape_tiles;
-  int *ip1, *ip2, *is1, *is2;
+  float *R1, *R2, *S1, *S2, *partial, *part_tiles, *shape_tiles, *grid_f;
+  int *ip1, *ip2, *is1, *is2, *grid_i;
   int tiles;
 };
+
+// Whole-shape search: exact grid-pruned search (default) or the brute-force scan (MPA_SHAPE_SEARCH=brute);
+// identical results, the brute force stays as the cross-check (tests/test_loss_gpu.py).
+bool use_grid_search() {
+  const char* e = getenv("MPA_SHAPE_SEARCH");
+  return !(e && e[0] == 'b');
+}
 // Queries per lane of the NN scans: 4 (fewer, fatter blocks) when there is enough work to fill the chip,
 // else 2.  MPA_ASSEMBLY_Q=2|4 overrides (tuning only).
 int pick_q(int64_t B, int64_t P, int64_t N) {
@@ -459,6 +467,9 @@ Workspace carve(float* fws, int32_t* iws, int64_t B, int64_t P, int64_t N, int q
   w.ip2 = iws + pn;
   w.is1 = iws + 2 * pn;
   w.is2 = iws + 3 * pn;
+  w.grid_i = iws + 4 * pn;
+  const int64_t min_tiles = (N + kMinTile - 1) / kMinTile;
+  w.grid_f = fws + (4 * cloud + 5 * B * P + 4 * B * P * min_tiles + 3) / 4 * 4;
   return w;
 }
 }  // namespace
@@ -480,9 +491,10 @@ extern "C" int mpa_assembly_loss_forward(const float* part_pcs, const float* val
                                          training, fill_pad_points, float_ws, int_ws, losses, nullptr, stream);
 }
 
-// Same launches; when `events` is non-null it holds 5 hipEvent_t recorded on `stream` at the phase
-// boundaries: [0] start, [1] after the pose kernel, [2] after the per-part Chamfer, [3] after the
-// whole-shape Chamfer, [4] after the finalize kernel (bench.py times the dominant kernel with them).
+// Same launches; when `events` is non-null it holds 7 hipEvent_t recorded on `stream`: [0] start, [1] after
+// the pose kernel, [2] after the per-part Chamfer, [3] after the whole-shape Chamfer phase (grid build +
+// search + part sums), [4] after the finalize kernel, [5]/[6] immediately before/after the grid search kernel
+// itself (left untouched by the brute-force path).  bench.py times the dominant kernel with them.
 extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const float* valids,
                                                const float* quat_pred, const float* trans_pred,
                                                const float* quat_gt, const float* trans_gt, int64_t B,
@@ -523,7 +535,11 @@ extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const floa
     hipLaunchKernelGGL((assembly_nn_kernel<2, mpa::kChunkMin, false>), grid, dim3(kThreads), 0, s, valids,
                        w.R1, w.R2, (int)B, (int)P, (int)N, w.tiles, remap, w.ip1, w.ip2, w.part_tiles);
   mark(2);
-  if (q == 4)
+  if (use_grid_search())
+    mpa::launch_grid_shape_search(valids, w.S1, w.S2, B, P, N, w.tiles, w.grid_f, w.grid_i, w.is1, w.is2,
+                                  w.shape_tiles, events ? reinterpret_cast<hipEvent_t>(events[5]) : nullptr,
+                                  events ? reinterpret_cast<hipEvent_t>(events[6]) : nullptr, s);
+  else if (q == 4)
     hipLaunchKernelGGL((assembly_nn_kernel<4, mpa::kChunkMin, true>), grid, dim3(kThreads), 0, s, valids,
                        w.S1, w.S2, (int)B, (int)P, (int)N, w.tiles, remap, w.is1, w.is2, w.shape_tiles);
   else

@@ -1,0 +1,497 @@
+// Exact nearest-neighbour search with spatial pruning for the whole-shape Chamfer term of the fused
+// assembly loss (assembly_loss.hip).  Same results as the brute-force scan, bit for bit — distances
+// computed with the pinned arithmetic of chamfer_core.h, lowest original index on ties — but each
+// query only visits the targets that can matter.
+//
+// Per sample (both transformed shapes, <= 20 000 valid points each):
+//   1. grid_params : bounding box of BOTH shapes' valid points -> one uniform grid per sample, <= 32768
+//                    cells (~1.5 points of each shape per cell), <= 64 cells per axis.  Covering the union
+//                    means no query is ever outside the grid.
+//   2. grid_count / grid_scan / grid_scatter : counting sort (global-memory histogram) of each shape,
+//                      role TARGET : by fine cell -> (x, y, z, original index) records + cell start offsets;
+//                                    cells are x-fastest, so a row of cells is one contiguous run of records;
+//                      role QUERY  : by SUPER-cell (2x2x2 fine cells) + a prefix of 128-query batches.
+//   3. grid_search : one wave per (super-cell, batch of <= 128 queries, 2 per lane).  All queries of the wave
+//                    lie inside one known box (the super-cell), so the candidate set is wave-uniform:
+//                      seed  — the super-cell grown by one fine cell per side;
+//                      sweep — with B = the largest best-distance in the wave, every cell row (y, z) whose
+//                              box distance to the super-cell box is below B is visited over exactly the
+//                              x-interval of cells that are closer than B; B shrinks as the sweep goes.
+//                    Every cell that intersects ANY lane's search ball is visited, so the search is exact;
+//                    the walk reuses the scalar-operand scan (records in SGPRs via the scalar cache, 8 per
+//                    chunk, one compare per chunk).  Candidates are not visited in index order, so the update
+//                    rule is lexicographic: smaller d, then smaller original index — exactly the answer of the
+//                    strict-`<` in-order scan.  The <= P padded parts' representatives are checked last.
+//
+// Rounding safety: a record may be binned one ulp across a cell face; cell-box distances are therefore
+// shrunk by 1e-3 of a cell before they are compared with B, and B is inflated by 1e-5.
+#include "assembly_internal.h"
+#include "chamfer_core.h"
+#include "common.h"
+
+namespace mpa {
+namespace {
+
+constexpr int kMaxCells = 32768;
+constexpr int kMaxAxis = 64;
+constexpr int kStartStride = kMaxCells + 8;   // ints per (sample, shape, role) slot
+constexpr int kBatch = 128;                   // queries per search wave (2 per lane)
+
+struct __attribute__((aligned(16))) GridParams {
+  float ox, oy, oz, h;
+  float inv_h;
+  int gx, gy, gz;
+  int sgx, sgy, sgz, ncells;
+  int nsuper, nvalid, pad0, pad1;
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ void cell_of(const GridParams& g, float x, float y, float z, int& ix, int& iy,
+                                        int& iz) {
+  ix = clampi((int)((x - g.ox) * g.inv_h), 0, g.gx - 1);
+  iy = clampi((int)((y - g.oy) * g.inv_h), 0, g.gy - 1);
+  iz = clampi((int)((z - g.oz) * g.inv_h), 0, g.gz - 1);
+}
+
+__device__ __forceinline__ int key_of(const GridParams& g, int role, float x, float y, float z) {
+  int ix, iy, iz;
+  cell_of(g, x, y, z, ix, iy, iz);
+  if (role == 0) return (iz * g.gy + iy) * g.gx + ix;
+  return ((iz >> 1) * g.sgy + (iy >> 1)) * g.sgx + (ix >> 1);
+}
+
+// ---- 1. grid parameters: one block per sample, 1024 threads -----------------------------------------------------
+__global__ __launch_bounds__(1024) void grid_params_kernel(const float* __restrict__ valids,
+                                                          const float* __restrict__ S1,
+                                                          const float* __restrict__ S2, int P, int N,
+                                                          GridParams* __restrict__ params) {
+  __shared__ float red[6][1024];
+  const int b = blockIdx.x;
+  const float* vb = valids + (long long)b * P;
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  int nvalid = 0;
+  for (int p = 0; p < P; ++p) {
+    if (vb[p] == 0.0f) continue;
+    nvalid += N;
+    for (int n = threadIdx.x; n < 2 * N; n += 1024) {
+      const float* cloud = (n < N ? S1 : S2) + 3LL * b * P * N;
+      const float* q = cloud + 3LL * (p * N + (n < N ? n : n - N));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = __builtin_fminf(lo[k], q[k]);
+        hi[k] = __builtin_fmaxf(hi[k], q[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    red[k][threadIdx.x] = lo[k];
+    red[3 + k][threadIdx.x] = hi[k];
+  }
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        red[k][threadIdx.x] = __builtin_fminf(red[k][threadIdx.x], red[k][threadIdx.x + s]);
+        red[3 + k][threadIdx.x] = __builtin_fmaxf(red[3 + k][threadIdx.x], red[3 + k][threadIdx.x + s]);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    GridParams g;
+    float ex = red[3][0] - red[0][0], ey = red[4][0] - red[1][0], ez = red[5][0] - red[2][0];
+    const float emax = __builtin_fmaxf(__builtin_fmaxf(ex, ey), __builtin_fmaxf(ez, 1e-12f));
+    if (!(emax < 1e30f) || nvalid == 0) {  // non-finite coordinates or nothing to index: one cell
+      g.ox = g.oy = g.oz = 0.0f;
+      g.h = 1.0f;
+      g.inv_h = 0.0f;
+      g.gx = g.gy = g.gz = 2;
+    } else {
+      const float floor_e = emax / (float)kMaxAxis;  // flat clouds: no axis thinner than this
+      ex = __builtin_fmaxf(ex, floor_e);
+      ey = __builtin_fmaxf(ey, floor_e);
+      ez = __builtin_fmaxf(ez, floor_e);
+      float want = (float)nvalid / 1.5f;
+      want = want < 8.0f ? 8.0f : (want > (float)kMaxCells ? (float)kMaxCells : want);
+      float h = cbrtf(ex * ey * ez / want);
+      h = __builtin_fmaxf(h, emax / (float)kMaxAxis);
+      for (int it = 0; it < 64; ++it) {
+        // even cell counts: every super-cell is a full 2x2x2 block, so nsuper = ncells / 8 <= kMaxCells / 8
+        g.gx = (clampi((int)__builtin_ceilf(ex / h), 1, kMaxAxis) + 1) & ~1;
+        g.gy = (clampi((int)__builtin_ceilf(ey / h), 1, kMaxAxis) + 1) & ~1;
+        g.gz = (clampi((int)__builtin_ceilf(ez / h), 1, kMaxAxis) + 1) & ~1;
+        if (g.gx * g.gy * g.gz <= kMaxCells) break;
+        h *= 1.1f;
+      }
+      g.ox = red[0][0];
+      g.oy = red[1][0];
+      g.oz = red[2][0];
+      g.h = h;
+      g.inv_h = 1.0f / h;
+    }
+    g.sgx = (g.gx + 1) >> 1;
+    g.sgy = (g.gy + 1) >> 1;
+    g.sgz = (g.gz + 1) >> 1;
+    g.ncells = g.gx * g.gy * g.gz;
+    g.nsuper = g.sgx * g.sgy * g.sgz;
+    g.nvalid = nvalid;
+    g.pad0 = g.pad1 = 0;
+    params[b] = g;
+  }
+}
+
+// ---- 2. counting sort.  slot = (b*2 + shape)*2 + role; role 0 = TARGET (fine cells), 1 = QUERY (super-cells) ------
+// count: grid = (P, 4*B), 256 threads; histogram in starts[slot][key] (zeroed by the caller).
+__global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict__ valids,
+                                                         const float* __restrict__ S1,
+                                                         const float* __restrict__ S2, int P, int N,
+                                                         const GridParams* __restrict__ params,
+                                                         int* __restrict__ starts) {
+  const int slot = blockIdx.y, role = slot & 1, c = (slot >> 1) & 1, b = slot >> 2, p = blockIdx.x;
+  if (valids[(long long)b * P + p] == 0.0f) return;
+  const GridParams g = params[b];
+  const float* cloud = (c == 0 ? S1 : S2) + 3LL * ((long long)b * P + p) * N;
+  int* cnt = starts + (long long)slot * kStartStride;
+  for (int n = threadIdx.x; n < N; n += 256)
+    atomicAdd(&cnt[key_of(g, role, cloud[3 * n], cloud[3 * n + 1], cloud[3 * n + 2])], 1);
+}
+
+// scan: one block of 1024 threads per slot: counts -> exclusive starts (in place, nkeys+1 entries), a cursor copy,
+// and for QUERY slots the exclusive prefix of ceil(count / kBatch) (search work list).
+__global__ __launch_bounds__(1024) void grid_scan_kernel(const GridParams* __restrict__ params,
+                                                         int* __restrict__ starts, int* __restrict__ cursor,
+                                                         int* __restrict__ batches) {
+  __shared__ int wsum[16][2];
+  const int slot = blockIdx.x, role = slot & 1, b = slot >> 2;
+  const GridParams g = params[b];
+  const int nkeys = role == 0 ? g.ncells : g.nsuper;
+  int* st = starts + (long long)slot * kStartStride;
+  int* cu = cursor + (long long)slot * kStartStride;
+  int* ba = batches + (long long)slot * kStartStride;
+  constexpr int PER = kMaxCells / 1024;  // 32 keys per thread
+  const int base = threadIdx.x * PER;
+  int sum = 0, bsum = 0;
+  for (int k = 0; k < PER; ++k) {
+    const int v = base + k < nkeys ? st[base + k] : 0;
+    sum += v;
+    bsum += (v + kBatch - 1) / kBatch;
+  }
+  int incl = sum, bincl = bsum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64), u = __shfl_up(bincl, off, 64);
+    if ((int)(threadIdx.x & 63) >= off) {
+      incl += t;
+      bincl += u;
+    }
+  }
+  if ((threadIdx.x & 63) == 63) {
+    wsum[threadIdx.x >> 6][0] = incl;
+    wsum[threadIdx.x >> 6][1] = bincl;
+  }
+  __syncthreads();
+  int run = incl - sum, brun = bincl - bsum;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) {
+    run += wsum[w][0];
+    brun += wsum[w][1];
+  }
+  for (int k = 0; k < PER; ++k) {
+    if (base + k < nkeys) {
+      const int v = st[base + k];
+      st[base + k] = run;
+      cu[base + k] = run;
+      if (role == 1) ba[base + k] = brun;
+      run += v;
+      brun += (v + kBatch - 1) / kBatch;
+    }
+  }
+  if (threadIdx.x == 1023) {
+    st[nkeys] = run;
+    if (role == 1) ba[nkeys] = brun;
+  }
+}
+
+// scatter: grid = (P, 4*B); records float4 (x, y, z, bits(flat index p*N+n)).
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restrict__ valids,
+                                                           const float* __restrict__ S1,
+                                                           const float* __restrict__ S2, int P, int N,
+                                                           const GridParams* __restrict__ params,
+                                                           int* __restrict__ cursor,
+                                                           float4* __restrict__ records, int rec_stride) {
+  const int slot = blockIdx.y, role = slot & 1, c = (slot >> 1) & 1, b = slot >> 2, p = blockIdx.x;
+  const GridParams g = params[b];
+  float4* out = records + (long long)slot * rec_stride;
+  if (role == 0 && p == 0 && threadIdx.x < 8) {  // sentinels: chunked reads may run past the last record
+    const float inf = __builtin_inff();
+    out[g.nvalid + threadIdx.x] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
+  }
+  if (valids[(long long)b * P + p] == 0.0f) return;
+  const float* cloud = (c == 0 ? S1 : S2) + 3LL * ((long long)b * P + p) * N;
+  int* cu = cursor + (long long)slot * kStartStride;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float x = cloud[3 * n], y = cloud[3 * n + 1], z = cloud[3 * n + 2];
+    const int pos = atomicAdd(&cu[key_of(g, role, x, y, z)], 1);
+    out[pos] = make_float4(x, y, z, __int_as_float(p * N + n));
+  }
+}
+
+__global__ void grid_zero_kernel(int4* __restrict__ p, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    p[i] = make_int4(0, 0, 0, 0);
+}
+
+// ---- 3. search ----------------------------------------------------------------------------------------------------
+constexpr int kQ = 2;  // queries per lane
+
+struct LaneState {
+  f32x2 X, Y, Z;
+  float best[kQ];
+  int bidx[kQ];
+};
+
+// lexicographic update with one candidate given as scalars
+__device__ __forceinline__ void consider(LaneState& s, float tx, float ty, float tz, int tidx) {
+  const f32x2 d = dist_exact_v(s.X - tx, s.Y - ty, s.Z - tz);
+#pragma unroll
+  for (int e = 0; e < kQ; ++e) {
+    if (d[e] < s.best[e] || (d[e] == s.best[e] && tidx < s.bidx[e])) {
+      s.best[e] = d[e];
+      s.bidx[e] = tidx;
+    }
+  }
+}
+
+// records [begin, end) of the target array, 8 per chunk (reads may run past `end`: the extra records are
+// real targets or sentinels, both harmless), scalar loads prefetched one chunk ahead.
+__device__ __forceinline__ void scan_records(LaneState& s, const float4* __restrict__ rec, int begin, int end) {
+  constexpr int T = kScanChunk;
+  if (begin >= end) return;
+  float4 nx[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) nx[t] = rec[begin + t];
+  for (int j0 = begin; j0 < end; j0 += T) {
+    float4 cur[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) cur[t] = nx[t];
+    const int jn = j0 + T < end ? j0 + T : j0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) nx[t] = rec[jn + t];
+    f32x2 v[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) v[t] = dist_exact_v(s.X - cur[t].x, s.Y - cur[t].y, s.Z - cur[t].z);
+#pragma unroll
+    for (int e = 0; e < kQ; ++e) {
+      float d[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) d[t] = v[t][e];
+      const float cmin = min8(d);
+      if (cmin <= s.best[e]) {  // rare: an improvement, or a tie that may carry a lower index
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const int ti = __float_as_int(cur[t].w);
+          if (d[t] < s.best[e] || (d[t] == s.best[e] && ti < s.bidx[e])) {
+            s.best[e] = d[t];
+            s.bidx[e] = ti;
+          }
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// squared distance between the intervals [a0, a1] and [b0, b1] on one axis
+__device__ __forceinline__ float gap(float a0, float a1, float b0, float b1) {
+  const float g = __builtin_fmaxf(__builtin_fmaxf(b0 - a1, a0 - b1), 0.0f);
+  return g;
+}
+
+// grid = (max batches per (sample, dir), 2*B), block 64.  blockIdx.y = b*2 + dir; dir 0: shape 1 queries
+// against shape 2 targets.
+__global__ __launch_bounds__(64) void grid_search_kernel(
+    const float* __restrict__ valids, const float* __restrict__ S1, const float* __restrict__ S2, int P,
+    int N, const GridParams* __restrict__ params, const float4* __restrict__ records,
+    const int* __restrict__ starts, const int* __restrict__ batches, int rec_stride,
+    float* __restrict__ dist1, float* __restrict__ dist2, int* __restrict__ idx1, int* __restrict__ idx2) {
+  const int b = blockIdx.y >> 1, dir = blockIdx.y & 1;
+  const int qc = dir, tc = 1 - dir;  // query / target shape
+  const GridParams g = params[b];
+  const int qslot = (b * 2 + qc) * 2 + 1, tslot = (b * 2 + tc) * 2 + 0;
+  const float4* qrec = records + (long long)qslot * rec_stride;
+  const float4* trec = records + (long long)tslot * rec_stride;
+  const int* tst = starts + (long long)tslot * kStartStride;
+  const float* tcloud = (tc == 0 ? S1 : S2) + 3LL * b * P * N;
+  const float* vb = valids + (long long)b * P;
+  float* dout = (dir == 0 ? dist1 : dist2) + (long long)b * P * N;
+  int* iout = (dir == 0 ? idx1 : idx2) + (long long)b * P * N;
+  const int* bst = batches + (long long)qslot * kStartStride;
+  const int total_work = bst[g.nsuper];
+  for (int work = blockIdx.x; work < total_work; work += gridDim.x) {  // persistent walk over the work list
+  // binary search: super-cell sc with bst[sc] <= work < bst[sc+1]
+  int lo = 0, hi = g.nsuper;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (bst[mid] <= work) lo = mid;
+    else hi = mid;
+  }
+  const int sc = lo;
+  const int* qst = starts + (long long)qslot * kStartStride;
+  const int qb = qst[sc] + (work - bst[sc]) * kBatch, q_end = qst[sc + 1];
+  const int sx = sc % g.sgx, sy = (sc / g.sgx) % g.sgy, sz = sc / (g.sgx * g.sgy);
+  const int lane = threadIdx.x;
+
+  LaneState s;
+  int qflat[kQ];
+  bool has[kQ];
+#pragma unroll
+  for (int e = 0; e < kQ; ++e) {
+    const int qi = qb + e * 64 + lane;
+    has[e] = qi < q_end;
+    const float4 r = qrec[has[e] ? qi : q_end - 1];
+    s.X[e] = r.x;
+    s.Y[e] = r.y;
+    s.Z[e] = r.z;
+    qflat[e] = __float_as_int(r.w);
+    s.best[e] = 1e32f;
+    s.bidx[e] = 0x7fffffff;
+  }
+  // seed: the super-cell grown by one fine cell per side
+  const int x0 = clampi(2 * sx - 1, 0, g.gx - 1), x1 = clampi(2 * sx + 2, 0, g.gx - 1);
+  const int y0 = clampi(2 * sy - 1, 0, g.gy - 1), y1 = clampi(2 * sy + 2, 0, g.gy - 1);
+  const int z0 = clampi(2 * sz - 1, 0, g.gz - 1), z1 = clampi(2 * sz + 2, 0, g.gz - 1);
+  for (int z = z0; z <= z1; ++z)
+    for (int y = y0; y <= y1; ++y) {
+      const int row = (z * g.gy + y) * g.gx;
+      scan_records(s, trec, tst[row + x0], tst[row + x1 + 1]);
+    }
+  // sweep: every cell whose box can hold a point closer than the worst best-distance of this wave.  The queries
+  // lie in the super-cell box (inflated by the binning slack).
+  const float slack = 1e-3f * g.h;
+  const float bx0 = g.ox + (float)(2 * sx) * g.h - slack, bx1 = g.ox + (float)(2 * sx + 2) * g.h + slack;
+  const float by0 = g.oy + (float)(2 * sy) * g.h - slack, by1 = g.oy + (float)(2 * sy + 2) * g.h + slack;
+  const float bz0 = g.oz + (float)(2 * sz) * g.h - slack, bz1 = g.oz + (float)(2 * sz + 2) * g.h + slack;
+  float bound = wave_max(__builtin_fmaxf(s.best[0], s.best[1])) * 1.00001f;
+  // Rows (y, z) are visited nearest-first, as square rings around the super-cell's own 2x2 rows, so the bound
+  // tightens early; a ring whose nearest row is already farther than the bound ends the sweep.
+  const int yc0 = 2 * sy, yc1 = 2 * sy + 1, zc0 = 2 * sz, zc1 = 2 * sz + 1;
+  const int rmax = max(max(yc0, g.gy - 1 - yc1), max(zc0, g.gz - 1 - zc1));
+  for (int r = 0; r <= rmax; ++r) {
+    if (r >= 2) {
+      const float ring_gap = (float)(r - 1) * g.h - 2.0f * slack;
+      if (ring_gap * ring_gap >= bound) break;
+    }
+    const int zlo = zc0 - r, zhi = zc1 + r, ylo = yc0 - r, yhi = yc1 + r;
+    for (int z = zlo < 0 ? 0 : zlo; z <= (zhi > g.gz - 1 ? g.gz - 1 : zhi); ++z) {
+      const float cz0 = g.oz + (float)z * g.h - slack, cz1 = g.oz + (float)(z + 1) * g.h + slack;
+      const float dz = gap(bz0, bz1, cz0, cz1);
+      if (dz * dz >= bound) continue;
+      const bool edge_z = z == zlo || z == zhi;
+      const int ystep = (edge_z || r == 0) ? 1 : (yhi - ylo);  // interior z: only the two frame columns
+      for (int y = ylo; y <= yhi; y += ystep) {
+        if (y < 0 || y > g.gy - 1) continue;
+        const float cy0 = g.oy + (float)y * g.h - slack, cy1 = g.oy + (float)(y + 1) * g.h + slack;
+        const float dy = gap(by0, by1, cy0, cy1);
+        const float rem = bound - dz * dz - dy * dy;
+        if (!(rem > 0.0f)) continue;
+        // cells x with gap_x(x)^2 < rem: an interval around the super-cell
+        const float reach = __builtin_sqrtf(rem) + slack;
+        int xa = clampi((int)__builtin_floorf((bx0 - reach - g.ox) * g.inv_h), 0, g.gx - 1);
+        int xb = clampi((int)__builtin_floorf((bx1 + reach - g.ox) * g.inv_h), 0, g.gx - 1);
+        if (bound > 1e31f) {  // nothing found yet: the whole row
+          xa = 0;
+          xb = g.gx - 1;
+        }
+        const bool seeded = z >= z0 && z <= z1 && y >= y0 && y <= y1;
+        const int row = (z * g.gy + y) * g.gx;
+        if (seeded) {  // skip the part already scanned
+          if (xa < x0) scan_records(s, trec, tst[row + xa], tst[row + x0]);
+          if (xb > x1) scan_records(s, trec, tst[row + x1 + 1], tst[row + xb + 1]);
+        } else {
+          scan_records(s, trec, tst[row + xa], tst[row + xb + 1]);
+        }
+        bound = wave_max(__builtin_fmaxf(s.best[0], s.best[1])) * 1.00001f;
+      }
+    }
+  }
+  for (int p = 0; p < P; ++p) {  // padded parts: one representative each (index p*N)
+    if (vb[p] != 0.0f) continue;
+    const float* t = tcloud + 3LL * p * N;
+    consider(s, t[0], t[1], t[2], p * N);
+  }
+#pragma unroll
+  for (int e = 0; e < kQ; ++e) {
+    if (has[e]) {
+      dout[qflat[e]] = s.best[e];
+      iout[qflat[e]] = s.bidx[e] == 0x7fffffff ? -1 : s.bidx[e];
+    }
+  }
+  }  // work loop
+}
+
+// per-part sums of the distances, written where the finalize kernel expects the tile sums (tile 0 of each part;
+// the other tiles were cleared).  grid = (B*P, 2), block 256; fixed-order reduction.
+__global__ __launch_bounds__(256) void grid_part_sum_kernel(const float* __restrict__ valids,
+                                                            const float* __restrict__ dist1,
+                                                            const float* __restrict__ dist2, int N, int tiles,
+                                                            float* __restrict__ tile_sums) {
+  __shared__ float red[4];
+  const int m = blockIdx.x, dir = blockIdx.y;
+  if (valids[m] == 0.0f) return;
+  const float* d = (dir == 0 ? dist1 : dist2) + (long long)m * N;
+  float s = 0.0f;
+  for (int n = threadIdx.x; n < N; n += 256) s += d[n];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    tile_sums[(long long)dir * gridDim.x * tiles + (long long)m * tiles] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace
+
+int64_t grid_workspace_floats(int64_t B, int64_t P, int64_t N) {
+  const int64_t rec = (P * N + 8) * 4;  // float4 records (+ sentinels) per slot
+  return 4 * B * rec + B * (int64_t)(sizeof(GridParams) / 4) + 2 * B * P * N;  // + 2 distance arrays
+}
+int64_t grid_workspace_ints(int64_t B) { return 3 * 4 * B * (int64_t)kStartStride; }  // starts, cursor, batches
+
+int launch_grid_shape_search(const float* valids, const float* S1, const float* S2, int64_t B, int64_t P,
+                             int64_t N, int tiles, float* fws, int32_t* iws, int32_t* idx1, int32_t* idx2,
+                             float* tile_sums, hipEvent_t before_search, hipEvent_t after_search, hipStream_t s) {
+  const int rec_stride = (int)(P * N + 8);
+  float4* records = reinterpret_cast<float4*>(fws);
+  GridParams* params = reinterpret_cast<GridParams*>(fws + 4 * B * (int64_t)rec_stride * 4);
+  float* dist1 = reinterpret_cast<float*>(params + B);
+  float* dist2 = dist1 + B * P * N;
+  int* starts = iws;
+  int* cursor = iws + 4 * B * (int64_t)kStartStride;
+  int* batches = cursor + 4 * B * (int64_t)kStartStride;
+  hipLaunchKernelGGL(grid_zero_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<int4*>(starts),
+                     (long long)(B * (int64_t)kStartStride));  // 4*B*kStartStride ints = B*kStartStride int4
+  hipLaunchKernelGGL(grid_params_kernel, dim3((unsigned)B), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N, params);
+  hipLaunchKernelGGL(grid_count_kernel, dim3((unsigned)P, (unsigned)(4 * B)), dim3(256), 0, s, valids, S1, S2, (int)P,
+                     (int)N, params, starts);
+  hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, params, starts, cursor, batches);
+  hipLaunchKernelGGL(grid_scatter_kernel, dim3((unsigned)P, (unsigned)(4 * B)), dim3(256), 0, s, valids, S1, S2, (int)P,
+                     (int)N, params, cursor, records, rec_stride);
+  // persistent waves: 128 per (sample, direction) walk that pair's work list of (super-cell, 128-query batch) items
+  if (before_search != nullptr) (void)hipEventRecord(before_search, s);
+  hipLaunchKernelGGL(grid_search_kernel, dim3(128, (unsigned)(2 * B)), dim3(64), 0, s, valids, S1, S2, (int)P,
+                     (int)N, params, records, starts, batches, rec_stride, dist1, dist2, idx1, idx2);
+  if (after_search != nullptr) (void)hipEventRecord(after_search, s);
+  hipLaunchKernelGGL(grid_part_sum_kernel, dim3((unsigned)(B * P), 2), dim3(256), 0, s, valids, dist1, dist2, (int)N,
+                     tiles, tile_sums);
+  return MPA_OK;
+}
+
+}  // namespace mpa

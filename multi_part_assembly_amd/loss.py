@@ -120,8 +120,8 @@ class _AssemblyLoss(torch.autograd.Function):
         iws = torch.empty(ni.value, dtype=torch.int32, device=dev)
         losses = torch.empty((5, B), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            evs = _lib.KernelTimer.phase_events(5)
-            ev_arr = None if evs is None else (ctypes.c_void_p * 5)(*[e.cuda_event for e in evs])
+            evs = _lib.KernelTimer.phase_events(7)
+            ev_arr = None if evs is None else (ctypes.c_void_p * 7)(*[e.cuda_event for e in evs])
             st = L.mpa_assembly_loss_forward_timed(
                 _lib.ptr(part_pcs), _lib.ptr(valids), _lib.ptr(quat_pred), _lib.ptr(trans_pred),
                 _lib.ptr(quat_gt), _lib.ptr(trans_gt), B, P, N, int(training), int(fill_pads),
@@ -129,6 +129,8 @@ class _AssemblyLoss(torch.autograd.Function):
             _lib.KernelTimer.add_phases(
                 [f"{k}[{B}x{P}x{N}]" for k in ("assembly_pose", "assembly_part_chamfer",
                                                 "assembly_shape_chamfer", "assembly_finalize")], evs)
+            if evs is not None:
+                _lib.KernelTimer.add_phases([f"grid_search_kernel[{B}x{P}x{N}]"], evs[5:7])
         _lib.check(st, "mpa_assembly_loss_forward")
         ctx.save_for_backward(part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, fws, iws)
         ctx.training = int(training)

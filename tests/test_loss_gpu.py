@@ -141,3 +141,68 @@ def test_fused_loss_equals_composed_path_at_full_size(cuda_device):
         np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-8, err_msg=name)
     np.testing.assert_allclose(gqf, gqc, rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(gtf, gtc, rtol=1e-4, atol=1e-6)
+
+
+def _raw_assembly_forward(batch, qp, tp, mode, monkeypatch):
+    """Call the C ABI directly so that the arg-min arrays in the int workspace can be inspected."""
+    import ctypes
+    from multi_part_assembly_amd import _lib
+
+    monkeypatch.setenv("MPA_SHAPE_SEARCH", mode)
+    pcs, v = batch["part_pcs"], batch["part_valids"]
+    qg, tg = Rotation3D(batch["part_quat"]).rot.contiguous(), batch["part_trans"].contiguous()
+    B, P, N, _ = pcs.shape
+    L_ = _lib.lib()
+    nf, ni = ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(L_.mpa_assembly_loss_workspace(B, P, N, ctypes.byref(nf), ctypes.byref(ni)), "ws")
+    # poison the workspaces: nothing may depend on what a previous user left in them
+    fws = torch.full((nf.value,), float("nan"), device=pcs.device)
+    iws = torch.full((ni.value,), 0x7F7F7F7F, dtype=torch.int32, device=pcs.device)
+    losses = torch.empty(5, B, device=pcs.device)
+    st = L_.mpa_assembly_loss_forward(_lib.ptr(pcs), _lib.ptr(v), _lib.ptr(qp), _lib.ptr(tp), _lib.ptr(qg),
+                                      _lib.ptr(tg), B, P, N, 1, 0, _lib.ptr(fws), _lib.ptr(iws),
+                                      _lib.ptr(losses), _lib.current_stream(pcs.device))
+    _lib.check(st, "fwd")
+    torch.cuda.synchronize()
+    pn = B * P * N
+    return losses, iws[2 * pn:3 * pn].view(B, P, N), iws[3 * pn:4 * pn].view(B, P, N)
+
+
+@pytest.mark.parametrize("spread", [0.05, 0.6, 30.0])
+def test_grid_pruned_search_is_bit_identical_to_brute_force(cuda_device, monkeypatch, spread):
+    """The spatially pruned whole-shape search must return exactly the brute-force arg-mins (same distance
+    arithmetic, lowest index on ties) — for predicted poses that pile all parts at the origin (spread 0.05),
+    spread them like the ground truth (0.6) or throw them far outside the target cloud (30)."""
+    from multi_part_assembly_amd import synthetic
+
+    batch = synthetic.make_batch(8, 20, 1000, seed=11, device=cuda_device, num_parts=[1, 20, 2, 13, 5, 17, 9, 20])
+    g = torch.Generator().manual_seed(int(spread * 100))
+    qp = torch.nn.functional.normalize(torch.randn(8, 20, 4, generator=g), dim=-1).to(cuda_device)
+    tp = (torch.randn(8, 20, 3, generator=g) * spread).to(cuda_device)
+    lb, b1, b2 = _raw_assembly_forward(batch, qp, tp, "brute", monkeypatch)
+    lg, g1, g2 = _raw_assembly_forward(batch, qp, tp, "grid", monkeypatch)
+    valid = batch["part_valids"].bool()
+    assert torch.equal(b1[valid], g1[valid]) and torch.equal(b2[valid], g2[valid])
+    np.testing.assert_allclose(lg.cpu().numpy(), lb.cpu().numpy(), rtol=2e-6, atol=1e-9)
+
+
+def test_grid_pruned_search_handles_duplicates_and_flat_clouds(cuda_device, monkeypatch):
+    """Degenerate geometry: every part is the same flat (z = 0) lattice patch, so there are exact distance
+    ties everywhere and the grid is one cell thick — indices must still match the in-order scan."""
+    B, P, N = 8, 4, 256
+    xs = torch.arange(16.0).repeat_interleave(16) * 0.05
+    ys = torch.arange(16.0).repeat(16) * 0.05
+    part = torch.stack([xs, ys, torch.zeros(256)], -1)
+    pcs = part[None, None].repeat(B, P, 1, 1).to(cuda_device).contiguous()
+    v = torch.ones(B, P, device=cuda_device)
+    v[:, 3] = 0
+    ident = torch.tensor([1.0, 0, 0, 0], device=cuda_device).repeat(B, P, 1)
+    batch = {"part_pcs": pcs, "part_valids": v, "part_quat": ident.clone(),
+             "part_trans": torch.zeros(B, P, 3, device=cuda_device)}
+    tp = torch.zeros(B, P, 3, device=cuda_device)
+    tp[:, 1, 0] = 0.05  # part 1 shifted by exactly one lattice step
+    lb, b1, b2 = _raw_assembly_forward(batch, ident.contiguous(), tp, "brute", monkeypatch)
+    lg, g1, g2 = _raw_assembly_forward(batch, ident.contiguous(), tp, "grid", monkeypatch)
+    valid = v.bool()
+    assert torch.equal(b1[valid], g1[valid]) and torch.equal(b2[valid], g2[valid])
+    np.testing.assert_allclose(lg.cpu().numpy(), lb.cpu().numpy(), rtol=2e-6, atol=1e-9)

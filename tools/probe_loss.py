@@ -29,8 +29,16 @@ def fwdbwd():
     terms = fwd()
     sum(x.sum() for x in terms.values()).backward()
 
-for remap in ("1", "0"):
-    os.environ["MPA_XCD_REMAP"] = remap
-    for q in ("2", "4"):
-        os.environ["MPA_ASSEMBLY_Q"] = q
-        print(f"remap={remap} Q={q}: forward {t(fwd):.3f} ms, forward+backward {t(fwdbwd):.3f} ms")
+for mode in ("brute", "grid"):
+    os.environ["MPA_SHAPE_SEARCH"] = mode
+    print(f"shape search={mode}: forward {t(fwd):.3f} ms, forward+backward {t(fwdbwd):.3f} ms")
+
+# "trained" regime: predicted poses close to the ground truth (both shapes overlap)
+qp2 = torch.nn.functional.normalize(batch["part_quat"] + 0.05 * torch.randn(32, 20, 4, device=dev), dim=-1)
+qp2 = torch.where(v[..., None] > 0, qp2, qp.detach()).requires_grad_()
+tp2 = (batch["part_trans"] + 0.02 * torch.randn(32, 20, 3, device=dev)).requires_grad_()
+def fwd2():
+    return L.geometric_assembly_loss(pcs, tp2, Rotation3D(qp2), tg, rg, v, training=True)[0]
+for mode in ("brute", "grid"):
+    os.environ["MPA_SHAPE_SEARCH"] = mode
+    print(f"near-GT poses, shape search={mode}: forward {t(fwd2):.3f} ms")
