@@ -180,6 +180,52 @@ int mpa_pointnet_backward(const float* grad_feat, const float* points, const flo
                           float* const* grad_bn_w, float* const* grad_bn_b, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Part-relation transformer encoder — replaces
+ *   TransformerEncoder.forward : multi_part_assembly/models/pn_transformer/transformer.py:63-79
+ *   (nn.TransformerEncoder of pre-LN nn.TransformerEncoderLayer, ReLU FFN, batch_first,
+ *    src_key_padding_mask = ~valid, final LayerNorm; transformer.py:20-39)
+ * tokens [B,P,D] (P <= 64 parts), valid [B*P] (1/0: padded parts are masked as KEYS; their own rows are
+ * still computed, as upstream).  D and FF multiples of 64, head dim D/H <= 64, L <= 16 layers.
+ * params: HOST array of 12*L + 2 DEVICE pointers, per layer in nn.TransformerEncoderLayer's
+ * named_parameters() order — self_attn.in_proj_weight [3D,D], in_proj_bias [3D], out_proj.weight [D,D],
+ * out_proj.bias [D], linear1.weight [FF,D], linear1.bias [FF], linear2.weight [D,FF], linear2.bias [D],
+ * norm1.weight, norm1.bias, norm2.weight, norm2.bias [D] — then the final norm.weight, norm.bias [D].
+ * dropout_p in [0,1) applies to the 4 dropout sites of every layer (attention probabilities, attention
+ * output, FFN hidden, FFN output) with a counter-based generator keyed by (seed, site, element): backward
+ * must receive the same seed.  Pass 0 for evaluation.  ws (mpa_transformer_workspace floats) carries the
+ * saved activations from forward to backward.  out [B,P,D].
+ * backward: grad_out [B,P,D] -> grad_tokens [B,P,D] and grad_params (same layout as params; every buffer
+ * is overwritten).  Deterministic: fixed-order reductions, no atomics.
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_transformer_workspace(int64_t B, int64_t P, int64_t D, int64_t H, int64_t FF, int64_t L,
+                              int64_t* float_elems);
+int mpa_transformer_forward(const float* tokens, const float* valid, const float* const* params, int64_t B,
+                            int64_t P, int64_t D, int64_t H, int64_t FF, int64_t L, float dropout_p,
+                            uint64_t seed, float* ws, float* out, void* stream);
+int mpa_transformer_backward(const float* grad_out, const float* valid, const float* const* params, int64_t B,
+                             int64_t P, int64_t D, int64_t H, int64_t FF, int64_t L, float dropout_p,
+                             uint64_t seed, float* ws, float* grad_tokens, float* const* grad_params,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pose head — replaces
+ *   PoseRegressor.forward : multi_part_assembly/models/modules/regressor.py:50-68
+ *   (Linear F-256, LeakyReLU 0.2, Linear 256-128, LeakyReLU 0.2, rot_head 128-4 + F.normalize,
+ *    trans_head 128-3; regressor.py:33-48)
+ * x [M,F] (F multiple of 64; M = B*P tokens).  params: HOST array of 8 DEVICE pointers — fc_layers.0.weight
+ * [256,F], .bias, fc_layers.2.weight [128,256], .bias, rot_head.weight [4,128], .bias, trans_head.weight
+ * [3,128], .bias.  rot [M,4] unit quaternions (x / max(|x|, 1e-12)), trans [M,3].
+ * ws (mpa_pose_head_workspace floats) carries activations to backward, which overwrites grad_x [M,F] and
+ * the 8 grad_params buffers.
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_pose_head_workspace(int64_t M, int64_t F, int64_t* float_elems);
+int mpa_pose_head_forward(const float* x, const float* const* params, int64_t M, int64_t F, float* ws,
+                          float* rot, float* trans, void* stream);
+int mpa_pose_head_backward(const float* grad_rot, const float* grad_trans, const float* x,
+                           const float* const* params, int64_t M, int64_t F, float* ws, float* grad_x,
+                           float* const* grad_params, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused optimiser step — replaces torch.optim.Adam / AdamW as configured by
  *   BaseModel.configure_optimizers : multi_part_assembly/models/modules/base_model.py:389-406
  * One streaming pass over flat, 16-byte-aligned fp32 buffers of `numel` elements (parameters,

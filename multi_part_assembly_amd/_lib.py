@@ -21,6 +21,7 @@ _P = _c.c_void_p
 _I64 = _c.c_int64
 _INT = _c.c_int
 _F32 = _c.c_float
+_U64 = _c.c_uint64
 
 # name -> (restype, argtypes); must list every function include/mpa_hip.h declares
 # (tests/test_abi.py cross-checks this table against the header and the .so's dynamic symbols).
@@ -41,6 +42,12 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_pointnet_workspace": (_INT, [_I64, _I64, _I64, _P, _P]),
     "mpa_pointnet_forward": (_INT, [_P] * 7 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
     "mpa_pointnet_backward": (_INT, [_P] * 5 + [_I64, _I64, _I64] + [_P] * 6),
+    "mpa_transformer_workspace": (_INT, [_I64] * 6 + [_P]),
+    "mpa_transformer_forward": (_INT, [_P, _P, _P] + [_I64] * 6 + [_F32, _U64, _P, _P, _P]),
+    "mpa_transformer_backward": (_INT, [_P, _P, _P] + [_I64] * 6 + [_F32, _U64, _P, _P, _P, _P]),
+    "mpa_pose_head_workspace": (_INT, [_I64, _I64, _P]),
+    "mpa_pose_head_forward": (_INT, [_P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "mpa_pose_head_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "mpa_adam_step": (_INT, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _INT, _I64, _F32, _P]),
     "mpa_adam_step_dev": (_INT, [_P, _P, _P, _P, _I64, _P, _F32, _F32, _F32, _F32, _INT, _P]),
 }

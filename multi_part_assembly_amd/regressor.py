@@ -2,13 +2,56 @@
 (multi_part_assembly/models/modules/regressor.py:30-84); identical state_dict keys
 (`fc_layers.{0,2}.*`, `rot_head.*`, `trans_head.*`).  Quaternion output only.
 
-Compute: three small Linear layers over B*P <= 640 tokens — library GEMMs via PyTorch-ROCm.
+Compute: csrc/transformer.hip (`mpa_pose_head_*`): two fp32-MFMA GEMMs with the LeakyReLU fused, one
+kernel for both heads + the quaternion normalisation, deterministic backward.
 """
 from __future__ import annotations
+
+import ctypes
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import _lib
+
+
+class _PoseHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, *params):
+        M, Fdim = x.shape
+        dev = x.device
+        lib = _lib.lib()
+        n = ctypes.c_int64()
+        _lib.check(lib.mpa_pose_head_workspace(M, Fdim, ctypes.byref(n)), "mpa_pose_head_workspace")
+        ws = torch.empty(n.value, dtype=torch.float32, device=dev)
+        rot = torch.empty((M, 4), dtype=torch.float32, device=dev)
+        trans = torch.empty((M, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"pose_head_forward[{M}x{Fdim}]")
+            st = lib.mpa_pose_head_forward(_lib.ptr(x), _lib.ptr_array(params), M, Fdim, _lib.ptr(ws),
+                                           _lib.ptr(rot), _lib.ptr(trans), _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_pose_head_forward")
+        ctx.save_for_backward(x, ws, *params)
+        return rot, trans
+
+    @staticmethod
+    def backward(ctx, grad_rot, grad_trans):
+        x, ws, *params = ctx.saved_tensors
+        M, Fdim = x.shape
+        dev = x.device
+        grad_x = torch.empty_like(x)
+        grads = [torch.empty_like(p) for p in params]
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"pose_head_backward[{M}x{Fdim}]")
+            st = _lib.lib().mpa_pose_head_backward(
+                _lib.ptr(grad_rot.contiguous()), _lib.ptr(grad_trans.contiguous()), _lib.ptr(x),
+                _lib.ptr_array(params), M, Fdim, _lib.ptr(ws), _lib.ptr(grad_x), _lib.ptr_array(grads),
+                _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_pose_head_backward")
+        return (grad_x, *grads)
 
 
 class PoseRegressor(nn.Module):
@@ -21,10 +64,20 @@ class PoseRegressor(nn.Module):
                                        nn.Linear(256, 128), nn.LeakyReLU(0.2))
         self.rot_head = nn.Linear(128, 4)
         self.trans_head = nn.Linear(128, 3)
+        self.native = norm_rot and feat_dim % 64 == 0  # what csrc/transformer.hip is instantiated for
 
     def forward(self, x):
         """x [B, C] or [B, P, C] -> (rot [.., 4] unit-normalised, trans [.., 3])."""
-        hidden = self.fc_layers(x)
+        if not x.is_cuda:
+            raise RuntimeError("PoseRegressor: only CUDA (HIP) tensors are supported — no CPU fallback")
+        if self.native:
+            lead = x.shape[:-1]
+            rot, trans = _PoseHeadFn.apply(
+                x.reshape(-1, x.shape[-1]).float().contiguous(), self.fc_layers[0].weight,
+                self.fc_layers[0].bias, self.fc_layers[2].weight, self.fc_layers[2].bias, self.rot_head.weight,
+                self.rot_head.bias, self.trans_head.weight, self.trans_head.bias)
+            return rot.view(*lead, 4), trans.view(*lead, 3)
+        hidden = self.fc_layers(x)  # widths outside the HIP instantiation (semantic labels appended): library ops
         rot = self.rot_head(hidden)
         if self.norm_rot:
             rot = F.normalize(rot, p=2, dim=-1)
@@ -39,5 +92,7 @@ class StocasticPoseRegressor(PoseRegressor):
         self.noise_dim = noise_dim
 
     def forward(self, x):
+        if self.noise_dim == 0:
+            return super().forward(x)
         noise = torch.randn(*x.shape[:-1], self.noise_dim).type_as(x)
         return super().forward(torch.cat([x, noise], dim=-1))

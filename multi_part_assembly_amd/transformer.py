@@ -2,11 +2,65 @@
 (multi_part_assembly/models/pn_transformer/transformer.py:4-79): pre-LN encoder layers over <= 20
 part tokens with a key-padding mask, final LayerNorm, optional output projection.  Parameters live in
 an `nn.TransformerEncoder` so the state_dict keys equal the reference's
-(`transformer_encoder.layers.{i}.self_attn.in_proj_weight`, ...).
+(`transformer_encoder.layers.{i}.self_attn.in_proj_weight`, ...); the computation runs on
+csrc/transformer.hip (fp32 MFMA GEMMs with LayerNorm / dropout / residual fused in, one-block
+attention over the part tokens, deterministic backward).
 """
 from __future__ import annotations
 
+import ctypes
+
+import torch
 import torch.nn as nn
+
+from . import _lib
+
+_LAYER_PARAMS = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+                 "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight",
+                 "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
+
+
+class _TransformerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tokens, valid, heads, dropout_p, seed, *params):
+        B, P, D = tokens.shape
+        L = (len(params) - 2) // len(_LAYER_PARAMS)
+        FF = params[4].shape[0]
+        dev = tokens.device
+        lib = _lib.lib()
+        n = ctypes.c_int64()
+        _lib.check(lib.mpa_transformer_workspace(B, P, D, heads, FF, L, ctypes.byref(n)),
+                   "mpa_transformer_workspace")
+        ws = torch.empty(n.value, dtype=torch.float32, device=dev)
+        out = torch.empty_like(tokens)
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"transformer_forward[{B}x{P}x{D}]")
+            st = lib.mpa_transformer_forward(_lib.ptr(tokens), _lib.ptr(valid), _lib.ptr_array(params), B, P, D,
+                                             heads, FF, L, float(dropout_p), int(seed), _lib.ptr(ws),
+                                             _lib.ptr(out), _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_transformer_forward")
+        ctx.meta = (heads, FF, L, float(dropout_p), int(seed))
+        ctx.save_for_backward(valid, ws, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        valid, ws, *params = ctx.saved_tensors
+        heads, FF, L, dropout_p, seed = ctx.meta
+        B, P, D = grad_out.shape
+        dev = grad_out.device
+        grad_out = grad_out.contiguous()
+        grad_tokens = torch.empty_like(grad_out)
+        grads = [torch.empty_like(p) for p in params]
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"transformer_backward[{B}x{P}x{D}]")
+            st = _lib.lib().mpa_transformer_backward(
+                _lib.ptr(grad_out), _lib.ptr(valid), _lib.ptr_array(params), B, P, D, heads, FF, L, dropout_p,
+                seed, _lib.ptr(ws), _lib.ptr(grad_tokens), _lib.ptr_array(grads), _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_transformer_backward")
+        return (grad_tokens, None, None, None, None, *grads)
 
 
 class TransformerEncoder(nn.Module):
@@ -19,11 +73,47 @@ class TransformerEncoder(nn.Module):
             layer, num_layers=num_layers, norm=nn.LayerNorm(d_model) if norm_first else None,
             enable_nested_tensor=False)
         self.out_fc = nn.Linear(d_model, out_dim) if out_dim is not None else nn.Identity()
+        self.num_heads, self.norm_first = num_heads, norm_first
+        self._calls = 0
+        # shapes csrc/transformer.hip is built for (every shipped config: 256 / 8 heads / 1024 / pre-LN)
+        self.native = (norm_first and d_model % 64 == 0 and ffn_dim % 64 == 0 and d_model % num_heads == 0
+                       and d_model // num_heads <= 64 and num_layers <= 16)
+
+    def _dropout_p(self):
+        """The (single) dropout probability of the stack; 0 in eval mode."""
+        if not self.training:
+            return 0.0
+        ps = set()
+        for layer in self.transformer_encoder.layers:
+            ps.update((layer.dropout.p, layer.dropout1.p, layer.dropout2.p, layer.self_attn.dropout))
+        if len(ps) != 1:
+            raise NotImplementedError(f"the HIP transformer uses one dropout probability, found {sorted(ps)}")
+        return float(ps.pop())
+
+    def _params(self):
+        enc = self.transformer_encoder
+        ps = []
+        for layer in enc.layers:
+            named = dict(layer.named_parameters())
+            ps += [named[k] for k in _LAYER_PARAMS]
+        return ps + [enc.norm.weight, enc.norm.bias]
 
     def forward(self, tokens, valid_masks):
         """tokens [B, N, C]; valid_masks [B, N] bool (True = real part) or None -> [B, N, C]."""
-        pad = None
+        if not tokens.is_cuda:
+            raise RuntimeError("TransformerEncoder: only CUDA (HIP) tensors are supported — no CPU fallback")
         if valid_masks is not None:
             assert valid_masks.shape == tokens.shape[:2]
-            pad = ~valid_masks
-        return self.out_fc(self.transformer_encoder(tokens, src_key_padding_mask=pad))
+        if not self.native or tokens.shape[1] > 64:
+            # configurations outside the HIP kernels' instantiation (post-LN, odd widths): library ops
+            pad = None if valid_masks is None else ~valid_masks
+            return self.out_fc(self.transformer_encoder(tokens, src_key_padding_mask=pad))
+        B, P, _ = tokens.shape
+        valid = (torch.ones(B * P, device=tokens.device) if valid_masks is None
+                 else valid_masks.reshape(-1).float())
+        p = self._dropout_p()
+        self._calls += 1
+        seed = (torch.initial_seed() * 0x9E3779B1 + self._calls * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
+        out = _TransformerFn.apply(tokens.float().contiguous(), valid.contiguous(), self.num_heads, p, seed,
+                                   *self._params())
+        return self.out_fc(out)

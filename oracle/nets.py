@@ -75,25 +75,55 @@ def dgcnn(x, sd, prefix="", training=True, stats_out=None):
     return F.linear(pooled, sd[f"{prefix}out_fc.weight"], sd[f"{prefix}out_fc.bias"])
 
 
-def transformer_encoder(tokens, valid, sd, prefix, num_layers, num_heads):
-    """models/pn_transformer/transformer.py:63-79 with norm_first=True, dropout disabled:
-    x += MHA(LN1(x)) ; x += W2 relu(W1 LN2(x)) per layer, final LayerNorm; padded keys masked."""
+def dropout_keep_scale(seed, site, numel, p):
+    """Keep-scale (0 or 1/(1-p)) of the `numel` elements of dropout site `site`: numpy restatement of the
+    counter-based generator of csrc/transformer.hip (splitmix64 finaliser of seed + golden*(site+1) + index,
+    top 24 bits as a uniform in [0, 1), dropped when u < p).  Test infrastructure only: it lets the oracle
+    apply the SAME masks as the HIP kernels, so training-mode dropout is checked value by value."""
+    import numpy as np
+    m64 = (1 << 64) - 1
+    base = (int(seed) + 0x9E3779B97F4A7C15 * (int(site) + 1)) & m64
+    with np.errstate(over="ignore"):
+        x = np.uint64(base) + np.arange(numel, dtype=np.uint64)
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    u = (x >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return torch.from_numpy(np.where(u < np.float32(p), np.float32(0.0), scale).astype(np.float32))
+
+
+def transformer_encoder(tokens, valid, sd, prefix, num_layers, num_heads, dropout_p=0.0, seed=0):
+    """models/pn_transformer/transformer.py:63-79 with norm_first=True:
+    x += drop(MHA(LN1(x))) ; x += drop(W2 drop(relu(W1 LN2(x)))) per layer, final LayerNorm; padded keys
+    masked.  dropout_p = 0 (the default) disables the 4 dropout sites of nn.TransformerEncoderLayer; otherwise
+    their masks come from `dropout_keep_scale` (sites 4l .. 4l+3: attention probabilities, attention output,
+    FFN hidden, FFN output)."""
     x = tokens
     B, P, D = x.shape
     hd = D // num_heads
+
+    def drop(t, site):
+        if dropout_p <= 0.0:
+            return t
+        return t * dropout_keep_scale(seed, site, t.numel(), dropout_p).view(t.shape)
+
     neg = torch.zeros(B, 1, 1, P).masked_fill(~valid[:, None, None, :], float("-inf"))
     for l in range(num_layers):
         p = f"{prefix}transformer_encoder.layers.{l}."
         h = F.layer_norm(x, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], LN_EPS)
         qkv = F.linear(h, sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"])
         q, k, v = (t.view(B, P, num_heads, hd).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
-        att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd) + neg, dim=-1)
+        att = drop(torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd) + neg, dim=-1), 4 * l)
         h = (att @ v).transpose(1, 2).reshape(B, P, D)
-        x = x + F.linear(h, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+        h = F.linear(h, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+        x = x + drop(h, 4 * l + 1)
         h = F.layer_norm(x, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], LN_EPS)
-        h = F.linear(F.relu(F.linear(h, sd[p + "linear1.weight"], sd[p + "linear1.bias"])),
-                     sd[p + "linear2.weight"], sd[p + "linear2.bias"])
-        x = x + h
+        h = drop(F.relu(F.linear(h, sd[p + "linear1.weight"], sd[p + "linear1.bias"])), 4 * l + 2)
+        h = F.linear(h, sd[p + "linear2.weight"], sd[p + "linear2.bias"])
+        x = x + drop(h, 4 * l + 3)
     n = f"{prefix}transformer_encoder.norm."
     return F.layer_norm(x, (D,), sd[n + "weight"], sd[n + "bias"], LN_EPS)
 

@@ -131,6 +131,85 @@ def test_transformer_and_pose_head_match_reference(golden, cuda_device):
         assert _rel(p.grad.cpu().numpy(), z["ghead." + k]) < 1e-3, k
 
 
+def test_transformer_dropout_matches_oracle_with_same_masks(golden, cuda_device):
+    """Training-mode dropout (p = 0.1 upstream, transformer.py:10): the oracle regenerates the HIP kernels'
+    counter-based masks (oracle.nets.dropout_keep_scale), so outputs and every gradient are compared value by
+    value — forward masks, the masks regenerated in backward and the ReLU/dropout gradient gates included."""
+    from multi_part_assembly_amd.transformer import _TransformerFn
+    from oracle import nets as on
+    z = golden("transformer")
+    d, heads, ffn, layers = (int(v) for v in z["cfg"])
+    enc = TransformerEncoder(d, heads, ffn, layers, norm_first=True, dropout=0.1)
+    _load(enc, z, "enc.")
+    p_drop, seed = 0.1, 0xC0FFEE1234567
+    sd = {k: v.detach().clone().requires_grad_() for k, v in enc.state_dict().items()}
+    tok_ref = T(z["tokens"]).requires_grad_()
+    valid = T(z["valid"])
+    w = torch.randn(*z["tokens"].shape, generator=torch.Generator().manual_seed(5))
+    ref = on.transformer_encoder(tok_ref, valid, sd, "", layers, heads, dropout_p=p_drop, seed=seed)
+    (ref * w).sum().backward()
+    assert not torch.allclose(ref, on.transformer_encoder(tok_ref, valid, sd, "", layers, heads))  # masks bite
+    enc.to(cuda_device).train()
+    tok = T(z["tokens"]).to(cuda_device).requires_grad_()
+    out = _TransformerFn.apply(tok, valid.reshape(-1).float().to(cuda_device), heads, p_drop, seed, *enc._params())
+    (out * w.to(cuda_device)).sum().backward()
+    assert _rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
+    assert _rel(tok.grad.cpu().numpy(), tok_ref.grad.numpy()) < 1e-3
+    for k, p in enc.named_parameters():
+        assert _rel(p.grad.cpu().numpy(), sd[k].grad.numpy()) < 1e-3, k
+    # module-level behaviour: a fresh mask per call in train mode, none in eval mode
+    with torch.no_grad():
+        a, b = enc(tok, valid.to(cuda_device)), enc(tok, valid.to(cuda_device))
+        assert not torch.equal(a, b)
+        enc.eval()
+        a, b = enc(tok, valid.to(cuda_device)), enc(tok, valid.to(cuda_device))
+        assert torch.equal(a, b)
+        clean = on.transformer_encoder(T(z["tokens"]), valid, {k: v.detach() for k, v in sd.items()}, "", layers, heads)
+        assert _rel(a.cpu().numpy(), clean.numpy()) < 1e-4
+
+
+def test_transformer_and_pose_head_full_size_match_library_ops(cuda_device):
+    """BASELINE.json configs[1] shapes (B=32, P=20, D=256, 8 heads, FF=1024, 4 layers; head F=256): the HIP
+    kernels against PyTorch-ROCm's nn.TransformerEncoder / Linear stack on the same device, dropout off."""
+    torch.manual_seed(3)
+    B, P, D, H, FF, L = 32, 20, 256, 8, 1024, 4
+    enc = TransformerEncoder(D, H, FF, L, norm_first=True, dropout=0.0).to(cuda_device).train()
+    head = StocasticPoseRegressor(feat_dim=D, noise_dim=0).to(cuda_device).train()
+    with torch.no_grad():  # non-trivial LayerNorm affine parameters and biases
+        for p in list(enc.parameters()) + list(head.parameters()):
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(7)
+    num = torch.randint(2, P + 1, (B,), generator=g)
+    valid = (torch.arange(P)[None] < num[:, None]).to(cuda_device)
+    tok = (torch.randn(B, P, D, generator=g) * valid.cpu()[..., None]).to(cuda_device)
+    w_r, w_t = torch.randn(B, P, 4, generator=g).to(cuda_device), torch.randn(B, P, 3, generator=g).to(cuda_device)
+
+    def run(native):
+        enc.native = head.native = native
+        for p in list(enc.parameters()) + list(head.parameters()):
+            p.grad = None
+        x = tok.clone().requires_grad_()
+        feats = enc(x, valid)
+        rot, trans = head(feats)
+        vm = valid[..., None].float()
+        ((rot * w_r * vm).sum() + (trans * w_t * vm).sum() + 0.01 * (feats * vm).sum()).backward()
+        grads = {k: p.grad.clone() for k, p in list(enc.named_parameters()) + list(head.named_parameters())}
+        return feats.detach(), rot.detach(), trans.detach(), x.grad.clone(), grads
+
+    f1, r1, t1, gx1, g1 = run(True)
+    f0, r0, t0, gx0, g0 = run(False)
+    v = valid.cpu().numpy()
+    for a, b in ((f1, f0), (r1, r0), (t1, t0)):
+        assert _rel(a.cpu().numpy()[v], b.cpu().numpy()[v]) < 1e-4
+    assert _rel(gx1.cpu().numpy(), gx0.cpu().numpy()) < 1e-3
+    for k in g0:
+        assert _rel(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 1e-3, k
+    # bit-reproducible: the same call twice gives identical gradients (fixed-order reductions)
+    f2, _, _, gx2, g2 = run(True)
+    assert torch.equal(f1, f2) and torch.equal(gx1, gx2) and all(torch.equal(g1[k], g2[k]) for k in g1)
+
+
 def _small_cfg(z):
     d, heads, ffn, layers = (int(v) for v in z["cfg"])
     cfg = config.pn_transformer_everyday()
