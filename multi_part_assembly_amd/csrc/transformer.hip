@@ -55,9 +55,10 @@ __device__ __forceinline__ float drop_scale(const Drop d, unsigned site, unsigne
   return u < d.p ? 0.0f : d.scale;
 }
 
-// ---- LayerNorm row statistics: one wave per row -------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void ln_stats_kernel(const float* __restrict__ x, int M, int D,
-                                                      float eps, float* __restrict__ stats) {
+// ---- LayerNorm forward: one wave per row; writes the row statistics (for backward) and y = LN(x) ---------------------
+__global__ __launch_bounds__(kT) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int M, int D, float eps,
+                                                    float* __restrict__ stats, float* __restrict__ y) {
   const int row = blockIdx.x * (kT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float* r = x + (long long)row * D;
@@ -69,126 +70,176 @@ __global__ __launch_bounds__(kT) void ln_stats_kernel(const float* __restrict__ 
     const float d = r[k] - mean;
     v += d * d;
   }
-  const float var = wave_sum(v) / (float)D;
+  const float rstd = 1.0f / __builtin_sqrtf(wave_sum(v) / (float)D + eps);
   if (lane == 0) {
     stats[2 * row] = mean;
-    stats[2 * row + 1] = 1.0f / __builtin_sqrtf(var + eps);
+    stats[2 * row + 1] = rstd;
   }
-}
-
-// out = LayerNorm(x) with precomputed stats (final norm).  grid = ceil(M*D / 256).
-__global__ void ln_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, int M, int D,
-                                float* __restrict__ out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)M * D) return;
-  const int row = (int)(i / D), k = (int)(i % D);
-  out[i] = (x[i] - stats[2 * row]) * stats[2 * row + 1] * gamma[k] + beta[k];
+  for (int k = lane; k < D; k += 64) y[(long long)row * D + k] = (r[k] - mean) * rstd * gamma[k] + beta[k];
 }
 
 // ---- GEMM  C[M,N] = epi(pro(A)[M,K] . W[N,K]^T + bias) ---------------------------------------------------------------
-enum Pro { PRO_NONE = 0, PRO_LN = 1, PRO_DROP = 2 };
-enum Epi { EPI_NONE = 0, EPI_RELU_DROP = 1, EPI_DROP_RESID = 2, EPI_LEAKY = 3, EPI_RELU_MASK = 4 };
+enum Pro { PRO_NONE = 0, PRO_DROP = 2 };
+enum Epi { EPI_NONE = 0, EPI_RELU_DROP = 1, EPI_DROP_RESID = 2, EPI_LEAKY = 3, EPI_RELU_MASK = 4, EPI_LEAKY_MASK = 5 };
 
 struct GemmArgs {
   const float* A;      // [M, K]
-  const float* W;      // [N, K]
+  const float* W;      // [N, K]  (WT: [K, N])
   const float* bias;   // [N] or null
   float* C;            // [M, N]
   int M, N, K;
-  // prologue
-  const float* stats;  // PRO_LN: [M, 2]
-  const float* gamma;  // PRO_LN: [K]
-  const float* beta;   // PRO_LN: [K]
-  // epilogue
-  const float* resid;  // EPI_DROP_RESID: [M, N];  EPI_RELU_MASK: the saved post-ReLU activations [M, N]
+  const float* resid;  // EPI_DROP_RESID: [M, N];  EPI_*_MASK: the saved activations [M, N]
   Drop drop;
   unsigned pro_site, epi_site;
 };
 
-// grid = (ceil(M/32), N/64), block = ONE wave owning rows [bx*32, +32) and columns [by*64, +64): with
-// M = B*P <= a few hundred tokens the launch is latency-bound, so the tile is kept small to spread it over
-// as many CUs as possible (640 x 768 -> 240 single-wave blocks).
-template <int PRO, int EPI>
-__global__ __launch_bounds__(64) void gemm_kernel(const GemmArgs g) {
-  constexpr int KP = 64, LD = KP + 4;
-  __shared__ __attribute__((aligned(16))) float lds[32 * LD];
-  const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
-  const int r0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
-  f32x16 acc0 = {0}, acc1 = {0};
-  for (int k0 = 0; k0 < g.K; k0 += KP) {
-    // stage A[r0..r0+32, k0..k0+64) (row segments of 256 B: 16 lanes per row, coalesced)
-#pragma unroll 4
-    for (int it = 0; it < 8; ++it) {
-      const int idx = it * 64 + lane, rl = idx >> 4, c4 = idx & 15;
-      const int row = r0 + rl, k = k0 + 4 * c4;
-      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (row < g.M) {
-        v = *reinterpret_cast<const float4*>(g.A + (long long)row * g.K + k);
-        if constexpr (PRO == PRO_LN) {
-          const float mean = g.stats[2 * row], rstd = g.stats[2 * row + 1];
-          const float4 ga = *reinterpret_cast<const float4*>(g.gamma + k);
-          const float4 be = *reinterpret_cast<const float4*>(g.beta + k);
-          v.x = (v.x - mean) * rstd * ga.x + be.x;
-          v.y = (v.y - mean) * rstd * ga.y + be.y;
-          v.z = (v.z - mean) * rstd * ga.z + be.z;
-          v.w = (v.w - mean) * rstd * ga.w + be.w;
-        } else if constexpr (PRO == PRO_DROP) {
-          const unsigned long long e = (unsigned long long)row * g.K + k;
-          v.x *= drop_scale(g.drop, g.pro_site, e);
-          v.y *= drop_scale(g.drop, g.pro_site, e + 1);
-          v.z *= drop_scale(g.drop, g.pro_site, e + 2);
-          v.w *= drop_scale(g.drop, g.pro_site, e + 3);
+// grid = (ceil(M/32), N/32), block = 8 waves: the block owns ONE 32 x 32 MFMA tile and the waves split K.
+// Why so small a tile: M = B*P is a few hundred tokens, so the whole GEMM is ~0.3 GFLOP; the fp32 MFMA pipe of
+// one CU retires 256 FLOP/clk, and only many small blocks (160..640 here) put all 256 CUs to work.
+// K is walked in phases of kp <= 128 (34 KB of LDS per block, so four blocks share a CU and hide each other's
+// latencies): the block copies the 32 x kp panels of A and W into LDS with fully
+// coalesced 16-byte loads (a lane-per-row fragment load would touch 64 cache lines per instruction and thrash the
+// 32 KB L1), the next phase's global loads are issued before the MFMAs of the current one, and inside a phase
+// wave w / lane half h owns the k-run [(2w+h) kp/16, +kp/16) which it reads from LDS as float4.  The eight
+// partial tiles meet in LDS (fixed order) and the epilogue writes 128-byte row segments.
+// Requires N % 32 == 0 and K % 64 == 0.
+// WT: the weight is given as W^T, i.e. [K, N] row-major (input gradients reuse the forward weights untransposed).
+constexpr int kGW = 8, kGT = kGW * 64, kKP = 128, kLD = kKP + 4;
+
+__host__ __device__ inline int gemm_phase(int K) {
+  if (K <= kKP) return K;
+  for (int kp = kKP; kp > 64; kp -= 64)  // kKP, kKP - 64, ...
+    if (K % kp == 0) return kp;
+  return 64;
+}
+
+// NPH > 0: K is exactly NPH phases and ALL global loads of the block are issued up front (NPH * 16 B * 2 per
+// thread in registers), so the block pays the L2/HBM latency once instead of once per phase; with NPH >= 3 the LDS
+// panels are double-buffered (one barrier per phase).  NPH == 0: any K, loads one phase ahead.
+template <int PRO, int EPI, bool WT, int NPH>
+__global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
+  constexpr int kBuf = NPH >= 3 ? 2 : 1, kPanel = 2 * 32 * kLD;
+  __shared__ __attribute__((aligned(16))) float lds[kBuf * kPanel];  // A panel | W panel; later the 8 partial tiles
+  float* la = lds;
+  float* lw = lds + 32 * kLD;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int r0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int kp = gemm_phase(g.K), nph = g.K / kp, ld = kp + 4, q4 = kp / 4, cnt = 32 * q4;
+  constexpr int kFI = 32 * (kKP / 4) / kGT;  // float4 per thread, operand and phase
+  struct Stage {
+    float4 a[kFI], w[kFI];
+  };
+  auto fetch = [&](int ph, Stage& st) {
+#pragma unroll
+    for (int i = 0; i < kFI; ++i) {
+      const int idx = threadIdx.x + kGT * i;
+      if (idx < cnt) {
+        const int row = idx / q4, c4 = idx % q4;
+        const int ar = r0 + row < g.M ? r0 + row : g.M - 1;
+        st.a[i] = *reinterpret_cast<const float4*>(g.A + (long long)ar * g.K + ph * kp + 4 * c4);
+        if constexpr (WT) {  // [kp, 32] slab of W^T: 8 lanes per 128-byte row
+          st.w[i] = *reinterpret_cast<const float4*>(g.W + (long long)(ph * kp + (idx >> 3)) * g.N + n0 + 4 * (idx & 7));
+        } else {
+          st.w[i] = *reinterpret_cast<const float4*>(g.W + (long long)(n0 + row) * g.K + ph * kp + 4 * c4);
         }
       }
-      *reinterpret_cast<float4*>(lds + rl * LD + 4 * c4) = v;
     }
-    __builtin_amdgcn_wave_barrier();
-    const float4* fa = reinterpret_cast<const float4*>(lds + j * LD + h * (KP / 2));
-    const float4* w0 = reinterpret_cast<const float4*>(g.W + (long long)(n0 + j) * g.K + k0 + h * (KP / 2));
-    const float4* w1 = reinterpret_cast<const float4*>(g.W + (long long)(n0 + 32 + j) * g.K + k0 + h * (KP / 2));
+  };
+  auto stash = [&](int ph, const Stage& st, int buf) {
 #pragma unroll
-    for (int v = 0; v < KP / 8; ++v) {
-      const float4 a = fa[v], b0 = w0[v], b1 = w1[v];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+    for (int i = 0; i < kFI; ++i) {
+      const int idx = threadIdx.x + kGT * i;
+      if (idx < cnt) {
+        const int row = idx / q4, c4 = idx % q4;
+        float4 a = st.a[i];
+        if constexpr (PRO == PRO_DROP) {
+          const int ar = r0 + row < g.M ? r0 + row : g.M - 1;
+          const unsigned long long e = (unsigned long long)ar * g.K + ph * kp + 4 * c4;
+          a.x *= drop_scale(g.drop, g.pro_site, e);
+          a.y *= drop_scale(g.drop, g.pro_site, e + 1);
+          a.z *= drop_scale(g.drop, g.pro_site, e + 2);
+          a.w *= drop_scale(g.drop, g.pro_site, e + 3);
+        }
+        *reinterpret_cast<float4*>(la + buf * kPanel + row * ld + 4 * c4) = a;
+        if constexpr (WT) *reinterpret_cast<float4*>(lw + buf * kPanel + (idx >> 3) * 32 + 4 * (idx & 7)) = st.w[i];
+        else *reinterpret_cast<float4*>(lw + buf * kPanel + row * ld + 4 * c4) = st.w[i];
+      }
     }
-    __builtin_amdgcn_wave_barrier();
+  };
+  const int kh = kp / (2 * kGW), kb = (wave * 2 + h) * kh, nv = kh / 4;
+  f32x16 acc = {0};
+  auto compute = [&](int buf) {
+    const float* pa = la + buf * kPanel + j * ld + kb;
+    const float* pw = lw + buf * kPanel + (WT ? kb * 32 + j : j * ld + kb);
+    for (int v = 0; v < nv; ++v) {
+      const float4 a = *reinterpret_cast<const float4*>(pa + 4 * v);
+      float4 b;
+      if constexpr (WT) b = make_float4(pw[128 * v], pw[128 * v + 32], pw[128 * v + 64], pw[128 * v + 96]);  // [k][n]
+      else b = *reinterpret_cast<const float4*>(pw + 4 * v);                                                 // [n][k]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+  };
+  if constexpr (NPH > 0) {
+    Stage st[NPH];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) fetch(ph, st[ph]);
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+      stash(ph, st[ph], ph % kBuf);
+      __syncthreads();
+      compute(ph % kBuf);
+      if (kBuf == 1) __syncthreads();  // double-buffered: the next stash goes to the other panel pair
+    }
+    if (kBuf == 2) __syncthreads();
+  } else {
+    Stage st;
+    fetch(0, st);
+    for (int ph = 0; ph < nph; ++ph) {
+      stash(ph, st, 0);
+      __syncthreads();
+      if (ph + 1 < nph) fetch(ph + 1, st);  // in flight while this phase computes
+      compute(0);
+      __syncthreads();
+    }
   }
-  const float bias0 = g.bias ? g.bias[n0 + j] : 0.0f, bias1 = g.bias ? g.bias[n0 + 32 + j] : 0.0f;
+  float(*red)[16][64] = reinterpret_cast<float(*)[16][64]>(lds);  // 32 KB, the panels are dead
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = r0 + acc_row(r, h);
-    if (row >= g.M) continue;
-    const long long o = (long long)row * g.N + n0 + j;
-    float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  // thread -> (row, column) of the 32 x 32 tile: 32 consecutive columns per half-wave
+  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const float bias = g.bias ? g.bias[n0 + col] : 0.0f;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int rl = it * 16 + rg, orow = r0 + rl;
+    if (orow >= g.M) continue;
+    const int reg = (rl & 3) + 4 * (rl >> 3), src = ((rl >> 2) & 1) * 32 + col;
+    float v = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kGW; ++w) v += red[w][reg][src];
+    v += bias;
+    const long long o = (long long)orow * g.N + n0 + col;
     if constexpr (EPI == EPI_RELU_DROP) {
-      v0 = __builtin_fmaxf(v0, 0.0f) * drop_scale(g.drop, g.epi_site, (unsigned long long)o);
-      v1 = __builtin_fmaxf(v1, 0.0f) * drop_scale(g.drop, g.epi_site, (unsigned long long)o + 32);
+      v = __builtin_fmaxf(v, 0.0f) * drop_scale(g.drop, g.epi_site, (unsigned long long)o);
     } else if constexpr (EPI == EPI_DROP_RESID) {
-      v0 = g.resid[o] + v0 * drop_scale(g.drop, g.epi_site, (unsigned long long)o);
-      v1 = g.resid[o + 32] + v1 * drop_scale(g.drop, g.epi_site, (unsigned long long)o + 32);
+      v = g.resid[o] + v * drop_scale(g.drop, g.epi_site, (unsigned long long)o);
     } else if constexpr (EPI == EPI_LEAKY) {
-      v0 = v0 > 0.0f ? v0 : 0.2f * v0;
-      v1 = v1 > 0.0f ? v1 : 0.2f * v1;
+      v = v > 0.0f ? v : 0.2f * v;
     } else if constexpr (EPI == EPI_RELU_MASK) {
       // gradient through dropout(relu(z)) given the saved activations a = relu(z) * keep_scale
-      v0 = g.resid[o] > 0.0f ? v0 * g.drop.scale : 0.0f;
-      v1 = g.resid[o + 32] > 0.0f ? v1 * g.drop.scale : 0.0f;
+      v = g.resid[o] > 0.0f ? v * g.drop.scale : 0.0f;
+    } else if constexpr (EPI == EPI_LEAKY_MASK) {
+      v = g.resid[o] > 0.0f ? v : 0.2f * v;  // gradient through LeakyReLU(0.2), resid = saved activations
     }
-    g.C[o] = v0;
-    g.C[o + 32] = v1;
+    g.C[o] = v;
   }
 }
 
-// ---- weight gradient  dW[N,K] = pro_a(dY)[M,N]^T . pro_b(X)[M,K],  db[N] = column sums of pro_a(dY) -------------------
-enum WPro { WP_NONE = 0, WP_LN = 1, WP_DROP = 2, WP_LEAKY_MASK = 3 };
+// ---- weight gradient  dW[N,K] = pro(dY)[M,N]^T . X[M,K],  db[N] = column sums of pro(dY) -----------------------------
+enum WPro { WP_NONE = 0, WP_DROP = 2 };
 
 struct WgradArgs {
   const float* dY;     // [M, N]
@@ -196,120 +247,93 @@ struct WgradArgs {
   float* dW;           // [N, K]
   float* db;           // [N] or null
   int M, N, K;
-  const float* stats;  // WP_LN on X
-  const float* gamma;
-  const float* beta;
   Drop drop;           // WP_DROP on dY
   unsigned site;
 };
 
-// grid = (N/64 * K/64), block 256: the 4 waves split the M rows; 64x64 output tile per block.
-template <int APRO, int BPRO>
-__global__ __launch_bounds__(kT) void wgrad_kernel(const WgradArgs g) {
-  __shared__ float sm[kT / 64][4][16][64];
-  __shared__ float sb[kT / 64][64];
+// grid = (N/32 * K/32), block = 16 waves that split the M rows (640 tokens -> 40 rows = 20 MFMA k-steps each);
+// ONE 32 x 32 output tile per block, again so that the ~0.3 GFLOP spread over every CU (64..256 blocks).  Lane
+// (j, h) reads, per step, dY[row 2s+h][n0+j] and X[row 2s+h][k0+j] (128 B per half-wave each), all issued before
+// the first MFMA.  The 16 partial tiles are summed by a fixed-order tree through LDS
+// (deterministic), the bias gradient likewise.
+constexpr int kWT = 1024, kWW = kWT / 64;
+
+template <int APRO>
+__global__ __launch_bounds__(kWT) void wgrad_kernel(const WgradArgs g) {
+  __shared__ float sm[kWW / 2][16][64];
+  __shared__ float sb[kWW][32];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int kg = g.K / 64;
-  const int n0 = (blockIdx.x / kg) * 64, k0 = (blockIdx.x % kg) * 64;
-  const int per = (g.M + kT / 64 - 1) / (kT / 64);
-  const int mb = wave * per, me = mb + per < g.M ? mb + per : g.M;
-  const int cnt = me > mb ? me - mb : 0, half = (cnt + 1) / 2;
-  float ga[2] = {1.0f, 1.0f}, be[2] = {0.0f, 0.0f};
-  if constexpr (BPRO == WP_LN) {
+  const int kg = g.K / 32;
+  const int n0 = (blockIdx.x / kg) * 32, k0 = (blockIdx.x % kg) * 32;
+  const int per = ((g.M + kWW - 1) / kWW + 1) & ~1;  // rows per wave, even
+  const int mb = wave * per, me = mb + per < g.M ? mb + per : g.M, ns = per / 2;
+  f32x16 acc = {0};
+  float bsum = 0.0f;
+  struct Frag {
+    float a, b;
+  };
+  auto load = [&](int s, Frag& f) {
+    const int row = mb + 2 * s + h;
+    const long long r = row < me ? row : 0;  // out-of-range steps read row 0 and are zeroed in `step`
+    f.a = g.dY[r * g.N + n0 + j];
+    f.b = g.X[r * g.K + k0 + j];
+  };
+  auto step = [&](int s, const Frag& f) {
+    if (s >= ns) return;
+    const int row = mb + 2 * s + h;
+    float a = f.a, b = f.b;
+    if constexpr (APRO == WP_DROP) a *= drop_scale(g.drop, g.site, (unsigned long long)row * g.N + n0 + j);
+    if (row >= me) a = b = 0.0f;
+    bsum += a;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  };
+  constexpr int U = 20;  // 640 tokens -> 20 steps per wave: every load of the wave is in flight at once
+  for (int s0 = 0; s0 < ns; s0 += U) {
+    Frag f[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      ga[u] = g.gamma[k0 + 32 * u + j];
-      be[u] = g.beta[k0 + 32 * u + j];
+    for (int u = 0; u < U; ++u) load(s0 + u, f[u]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(s0 + u, f[u]);
+  }
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (h == 0) sb[wave][j] = bsum;
+  // fixed-order tree: waves [half, 2*half) hand their tile to waves [0, half)
+  for (int half = kWW / 2; half >= 1; half >>= 1) {
+    if (wave >= half && wave < 2 * half) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sm[wave - half][r][lane] = acc[r];
     }
-  }
-  f32x16 acc[2][2];
+    __syncthreads();
+    if (wave < half) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int u = 0; u < 2; ++u) acc[t][u] = f32x16{0};
-  float bsum[2] = {0.0f, 0.0f};
-  for (int s = 0; s < half; ++s) {
-    const int row = mb + h * half + s;
-    const bool ok = row < me;
-    const long long r = ok ? row : mb;
-    float a[2], b[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const long long o = r * g.N + n0 + 32 * t + j;
-      float v = g.dY[o];
-      if constexpr (APRO == WP_DROP) v *= drop_scale(g.drop, g.site, (unsigned long long)o);
-      a[t] = ok ? v : 0.0f;
-      bsum[t] += a[t];
+      for (int r = 0; r < 16; ++r) acc[r] += sm[wave][r][lane];
     }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float v = g.X[r * g.K + k0 + 32 * u + j];
-      if constexpr (BPRO == WP_LN) v = (v - g.stats[2 * r]) * g.stats[2 * r + 1] * ga[u] + be[u];
-      b[u] = v;
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
+    __syncthreads();
   }
+  if (wave == 0) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sm[wave][2 * t + u][r][lane] = acc[t][u][r];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) bsum[t] += __shfl_xor(bsum[t], 32, 64);
-  if (h == 0) {
-    sb[wave][j] = bsum[0];
-    sb[wave][32 + j] = bsum[1];
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < 4096; e += kT) {
-    const int ln = e & 63, r = (e >> 6) & 15, tu = e >> 10;
-    float sum = 0.0f;
-#pragma unroll
-    for (int wv = 0; wv < kT / 64; ++wv) sum += sm[wv][tu][r][ln];
-    const int n = n0 + 32 * (tu >> 1) + acc_row(r, ln >> 5);
-    const int k = k0 + 32 * (tu & 1) + (ln & 31);
-    g.dW[(long long)n * g.K + k] = sum;
-  }
-  if (g.db != nullptr && k0 == 0 && threadIdx.x < 64) {
+    for (int r = 0; r < 16; ++r) g.dW[(long long)(n0 + acc_row(r, h)) * g.K + k0 + j] = acc[r];
+  } else if (wave == 1 && g.db != nullptr && k0 == 0 && lane < 32) {
     float s = 0.0f;
 #pragma unroll
-    for (int wv = 0; wv < kT / 64; ++wv) s += sb[wv][threadIdx.x];
-    g.db[n0 + threadIdx.x] = s;
+    for (int wv = 0; wv < kWW; ++wv) s += sb[wv][lane];
+    g.db[n0 + lane] = s;
   }
 }
 
-// ---- transposes ---------------------------------------------------------------------------------------------------------
-__global__ void transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int rows, int cols) {
-  __shared__ float tile[32][33];
-  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-  for (int i = threadIdx.y; i < 32; i += 8) {
-    const int r = by + i, c = bx + threadIdx.x;
-    if (r < rows && c < cols) tile[i][threadIdx.x] = w[(long long)r * cols + c];
-  }
-  __syncthreads();
-  for (int i = threadIdx.y; i < 32; i += 8) {
-    const int r = bx + i, c = by + threadIdx.x;  // wt[cols][rows]
-    if (r < cols && c < rows) wt[(long long)r * rows + c] = tile[threadIdx.x][i];
-  }
-}
-
-// ---- attention: one 64-lane block per (sample, head) ----------------------------------------------------------------------
-constexpr int kMaxP = 64, kMaxDh = 64;
+// ---- attention: one 256-thread block per (sample, head) ----------------------------------------------------------------------
+constexpr int kMaxP = 64, kMaxDh = 64, kAT = 256;
 
 // qkv [B*P, 3D] (q | k | v), valid [B*P]; probs [B, H, P, P] (post-softmax, pre-dropout); out [B*P, D]
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(kAT) void attn_fwd_kernel(const float* __restrict__ qkv,
                                                       const float* __restrict__ valid, int P, int D, int H,
                                                       Drop drop, unsigned site, float* __restrict__ probs,
                                                       float* __restrict__ out) {
   __shared__ float q[kMaxP][kMaxDh + 1], k[kMaxP][kMaxDh + 1], v[kMaxP][kMaxDh + 1], s[kMaxP][kMaxP + 1];
   const int b = blockIdx.x / H, hd = blockIdx.x % H, dh = D / H, t = threadIdx.x;
   const float scale = 1.0f / __builtin_sqrtf((float)dh);
-  for (int e = t; e < P * dh; e += 64) {
+  for (int e = t; e < P * dh; e += kAT) {
     const int i = e / dh, d = e % dh;
     const float* row = qkv + (long long)(b * P + i) * 3 * D + hd * dh + d;
     q[i][d] = row[0] * scale;  // torch scales q before the product
@@ -317,7 +341,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
     v[i][d] = row[2 * D];
   }
   __syncthreads();
-  for (int e = t; e < P * P; e += 64) {
+  for (int e = t; e < P * P; e += kAT) {
     const int i = e / P, jx = e % P;
     float a = 0.0f;
     for (int d = 0; d < dh; ++d) a = __builtin_fmaf(q[i][d], k[jx][d], a);
@@ -342,7 +366,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
-  for (int e = t; e < P * dh; e += 64) {
+  for (int e = t; e < P * dh; e += kAT) {
     const int i = e / dh, d = e % dh;
     float a = 0.0f;
     for (int jx = 0; jx < P; ++jx) a = __builtin_fmaf(s[i][jx], v[jx][d], a);
@@ -351,7 +375,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
 }
 
 // dO [B*P, D] -> dqkv [B*P, 3D]
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(kAT) void attn_bwd_kernel(const float* __restrict__ qkv,
                                                       const float* __restrict__ probs,
                                                       const float* __restrict__ dout, int P, int D, int H,
                                                       Drop drop, unsigned site, float* __restrict__ dqkv) {
@@ -359,7 +383,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
   __shared__ float pd[kMaxP][kMaxP + 1], ds[kMaxP][kMaxP + 1];
   const int b = blockIdx.x / H, hd = blockIdx.x % H, dh = D / H, t = threadIdx.x;
   const float scale = 1.0f / __builtin_sqrtf((float)dh);
-  for (int e = t; e < P * dh; e += 64) {
+  for (int e = t; e < P * dh; e += kAT) {
     const int i = e / dh, d = e % dh;
     const float* row = qkv + (long long)(b * P + i) * 3 * D + hd * dh + d;
     q[i][d] = row[0];
@@ -370,7 +394,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
   const float* pr = probs + (long long)(b * H + hd) * P * P;
   __syncthreads();
   // pd = dropped probabilities (for dV), ds = dP = dOut . V^T (through the dropout mask)
-  for (int e = t; e < P * P; e += 64) {
+  for (int e = t; e < P * P; e += kAT) {
     const int i = e / P, jx = e % P;
     const float m = drop_scale(drop, site, (unsigned long long)((b * H + hd) * P + i) * P + jx);
     float a = 0.0f;
@@ -380,7 +404,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
   }
   __syncthreads();
   // dV[jx][d] = sum_i pd[i][jx] * go[i][d]
-  for (int e = t; e < P * dh; e += 64) {
+  for (int e = t; e < P * dh; e += kAT) {
     const int jx = e / dh, d = e % dh;
     float a = 0.0f;
     for (int i = 0; i < P; ++i) a = __builtin_fmaf(pd[i][jx], go[i][d], a);
@@ -393,7 +417,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
     for (int jx = 0; jx < P; ++jx) ds[t][jx] = pr[t * P + jx] * (ds[t][jx] - dot);
   }
   __syncthreads();
-  for (int e = t; e < P * dh; e += 64) {
+  for (int e = t; e < P * dh; e += kAT) {
     const int i = e / dh, d = e % dh;
     float aq = 0.0f, ak = 0.0f;
     for (int jx = 0; jx < P; ++jx) {
@@ -447,22 +471,24 @@ __global__ __launch_bounds__(kT) void ln_bwd_kernel(const float* __restrict__ dh
   }
 }
 
-// dgamma[k] = sum_blocks part[b][0][k], dbeta likewise.  grid = ceil(2D/256)
-__global__ void ln_reduce_kernel(const float* __restrict__ part, int blocks, int D, float* __restrict__ dgamma,
-                                 float* __restrict__ dbeta) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= 2 * D) return;
+// dgamma[k] = sum_blocks part[b][0][k], dbeta likewise.  grid = 2D/64 blocks of 1024: 16 groups of 64 columns,
+// group q sums blocks q, q+16, ... and the groups meet in LDS (fixed order).
+__global__ __launch_bounds__(1024) void ln_reduce_kernel(const float* __restrict__ part, int blocks, int D,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float sm[16][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6, k = blockIdx.x * 64 + c;
   float s = 0.0f;
-  for (int b = 0; b < blocks; ++b) s += part[(long long)b * 2 * D + k];
-  if (k < D) dgamma[k] = s;
-  else dbeta[k - D] = s;
-}
-
-// y = x * drop_scale (materialised dropout of a gradient); n elements
-__global__ void drop_apply_kernel(const float* __restrict__ x, Drop drop, unsigned site, long long n,
-                                  float* __restrict__ y) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) y[i] = x[i] * drop_scale(drop, site, (unsigned long long)i);
+#pragma unroll 4
+  for (int b = q; b < blocks; b += 16) s += part[(long long)b * 2 * D + k];
+  sm[q][c] = s;
+  __syncthreads();
+  if (q == 0) {
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sm[i][c];
+    if (k < D) dgamma[k] = t;
+    else dbeta[k - D] = t;
+  }
 }
 
 // ---- pose head tail: rot = normalize(h . Wr^T + br), trans = h . Wt^T + bt; one wave per token -------------------------------
@@ -505,8 +531,8 @@ __global__ __launch_bounds__(kT) void head_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ grot,
                                                       const float* __restrict__ gtrans,
                                                       const float* __restrict__ wr, const float* __restrict__ wt,
-                                                      int M, int K, float* __restrict__ dqt,
-                                                      float* __restrict__ dh) {
+                                                      const float* __restrict__ act, int M, int K,
+                                                      float* __restrict__ dqt, float* __restrict__ dh) {
   const int row = blockIdx.x * (kT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   float q[4], g[4], n2 = 0.0f, dot = 0.0f;
@@ -531,65 +557,68 @@ __global__ __launch_bounds__(kT) void head_bwd_kernel(const float* __restrict__ 
     for (int c = 0; c < 4; ++c) a = __builtin_fmaf(dq[c], wr[c * K + k], a);
 #pragma unroll
     for (int c = 0; c < 3; ++c) a = __builtin_fmaf(dt[c], wt[c * K + k], a);
-    dh[(long long)row * K + k] = a;
+    dh[(long long)row * K + k] = act[(long long)row * K + k] > 0.0f ? a : 0.2f * a;  // LeakyReLU(0.2) gate
   }
 }
 
 // dWr[c][k] = sum_rows dqt[row][c] * h[row][k] (c < 4), dWt likewise (c = 4..6), biases = column sums of dqt.
-// grid = ceil(K/64) blocks of 256: wave w sums rows w, w+4, ...; lane = k.
-__global__ __launch_bounds__(kT) void head_wgrad_kernel(const float* __restrict__ dqt,
-                                                        const float* __restrict__ hfeat, int M, int K,
-                                                        float* __restrict__ dwr, float* __restrict__ dbr,
-                                                        float* __restrict__ dwt, float* __restrict__ dbt) {
-  __shared__ float sm[kT / 64][8][64];
+// grid = ceil(K/64) blocks of 1024: wave w sums rows w, w+16, ...; lane = k.
+__global__ __launch_bounds__(1024) void head_wgrad_kernel(const float* __restrict__ dqt,
+                                                          const float* __restrict__ hfeat, int M, int K,
+                                                          float* __restrict__ dwr, float* __restrict__ dbr,
+                                                          float* __restrict__ dwt, float* __restrict__ dbt) {
+  __shared__ float sm[16][8][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, k = blockIdx.x * 64 + lane;
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int row = wave; row < M; row += kT / 64) {
+#pragma unroll 4
+  for (int row = wave; row < M; row += 16) {
     const float x = k < K ? hfeat[(long long)row * K + k] : 0.0f;
-#pragma unroll
-    for (int c = 0; c < 7; ++c) a[c] = __builtin_fmaf(dqt[8 * row + c], x, a[c]);
-    if (blockIdx.x == 0 && lane < 7) a[7] += dqt[8 * row + lane];  // bias gradients, lane = output
+    const float4 d0 = *reinterpret_cast<const float4*>(dqt + 8 * row);
+    const float4 d1 = *reinterpret_cast<const float4*>(dqt + 8 * row + 4);
+    a[0] = __builtin_fmaf(d0.x, x, a[0]);
+    a[1] = __builtin_fmaf(d0.y, x, a[1]);
+    a[2] = __builtin_fmaf(d0.z, x, a[2]);
+    a[3] = __builtin_fmaf(d0.w, x, a[3]);
+    a[4] = __builtin_fmaf(d1.x, x, a[4]);
+    a[5] = __builtin_fmaf(d1.y, x, a[5]);
+    a[6] = __builtin_fmaf(d1.z, x, a[6]);
+    if (lane < 7) a[7] += dqt[8 * row + lane];  // bias gradients, lane = output
   }
 #pragma unroll
   for (int c = 0; c < 8; ++c) sm[wave][c][lane] = a[c];
   __syncthreads();
-  if (wave == 0) {
-    float s[8];
+  if (wave < 8) {  // wave c reduces channel c over the 16 partials
+    float s = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) s[c] = (sm[0][c][lane] + sm[1][c][lane]) + (sm[2][c][lane] + sm[3][c][lane]);
-    if (k < K) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) dwr[c * K + k] = s[c];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) dwt[c * K + k] = s[4 + c];
-    }
-    if (blockIdx.x == 0 && lane < 7) {
-      if (lane < 4) dbr[lane] = s[7];
-      else dbt[lane - 4] = s[7];
+    for (int w = 0; w < 16; ++w) s += sm[w][wave][lane];
+    if (wave < 4) {
+      if (k < K) dwr[wave * K + k] = s;
+    } else if (wave < 7) {
+      if (k < K) dwt[(wave - 4) * K + k] = s;
+    } else if (blockIdx.x == 0 && lane < 7) {
+      if (lane < 4) dbr[lane] = s;
+      else dbt[lane - 4] = s;
     }
   }
 }
 
-// LeakyReLU(0.2) gradient mask: y = dy where act > 0 else 0.2 * dy  (act = saved post-activation values)
-__global__ void leaky_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ act, long long n,
-                                 float* __restrict__ out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = act[i] > 0.0f ? dy[i] : 0.2f * dy[i];
-}
-
 // ---- host helpers ---------------------------------------------------------------------------------------------------------------
-template <int PRO, int EPI>
+template <int PRO, int EPI, bool WT = false>
 void launch_gemm(const GemmArgs& g, hipStream_t s) {
-  hipLaunchKernelGGL((gemm_kernel<PRO, EPI>), dim3((g.M + 31) / 32, g.N / 64), dim3(64), 0, s, g);
+  const dim3 grid((g.M + 31) / 32, g.N / 32), block(kGT);
+  const int kp = gemm_phase(g.K);
+  switch (kp == kKP || g.K <= kKP ? g.K / kp : 0) {  // full-size phases only
+    case 1: hipLaunchKernelGGL((gemm_kernel<PRO, EPI, WT, 1>), grid, block, 0, s, g); break;
+    case 2: hipLaunchKernelGGL((gemm_kernel<PRO, EPI, WT, 2>), grid, block, 0, s, g); break;
+    case 6: hipLaunchKernelGGL((gemm_kernel<PRO, EPI, WT, 6>), grid, block, 0, s, g); break;
+    case 8: hipLaunchKernelGGL((gemm_kernel<PRO, EPI, WT, 8>), grid, block, 0, s, g); break;
+    default: hipLaunchKernelGGL((gemm_kernel<PRO, EPI, WT, 0>), grid, block, 0, s, g); break;
+  }
 }
 
-template <int APRO, int BPRO>
+template <int APRO>
 void launch_wgrad(const WgradArgs& g, hipStream_t s) {
-  hipLaunchKernelGGL((wgrad_kernel<APRO, BPRO>), dim3((g.N / 64) * (g.K / 64)), dim3(kT), 0, s, g);
-}
-
-void launch_transpose(const float* w, float* wt, int rows, int cols, hipStream_t s) {
-  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s, w, wt, rows, cols);
+  hipLaunchKernelGGL((wgrad_kernel<APRO>), dim3((g.N / 32) * (g.K / 32)), dim3(kWT), 0, s, g);
 }
 
 GemmArgs gemm_args(const float* A, const float* W, const float* bias, float* C, int M, int N, int K) {
@@ -627,14 +656,14 @@ struct TfDims {
 };
 
 struct TfWs {  // per-layer saved tensors + scratch
-  float *x_in, *stats1, *qkv, *probs, *o, *x_mid, *stats2, *f;
+  float *x_in, *stats1, *h1, *qkv, *probs, *o, *x_mid, *stats2, *h2, *f;
 };
 
 struct TfLayout {
   TfWs layer[16];
   float *x_final, *stats_f;
   // backward scratch
-  float *g_a, *g_b, *g_c, *dz, *dqkv, *wt_a, *lnpart;
+  float *g_a, *g_b, *g_c, *dz, *dqkv, *lnpart;
   int64_t total;
 };
 
@@ -649,11 +678,13 @@ TfLayout tf_carve(float* base, const TfDims& d) {
   for (int l = 0; l < d.L; ++l) {
     w.layer[l].x_in = take(d.M * d.D);
     w.layer[l].stats1 = take(2 * d.M);
+    w.layer[l].h1 = take(d.M * d.D);
     w.layer[l].qkv = take(d.M * 3 * d.D);
     w.layer[l].probs = take(d.B * d.H * d.P * d.P);
     w.layer[l].o = take(d.M * d.D);
     w.layer[l].x_mid = take(d.M * d.D);
     w.layer[l].stats2 = take(2 * d.M);
+    w.layer[l].h2 = take(d.M * d.D);
     w.layer[l].f = take(d.M * d.FF);
   }
   w.x_final = take(d.M * d.D);
@@ -663,8 +694,6 @@ TfLayout tf_carve(float* base, const TfDims& d) {
   w.g_c = take(d.M * d.D);
   w.dz = take(d.M * d.FF);
   w.dqkv = take(d.M * 3 * d.D);
-  const int64_t wmax = d.D * (d.FF > 3 * d.D ? d.FF : 3 * d.D);
-  w.wt_a = take(wmax);
   w.lnpart = take(((d.M + 3) / 4) * 2 * d.D);
   w.total = p - base;
   return w;
@@ -709,27 +738,21 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
     const unsigned site0 = (unsigned)(l * S_PER_LAYER);
     if (l == 0 && hipMemcpyAsync(t.x_in, tokens, sizeof(float) * d.M * D, hipMemcpyDeviceToDevice, s) != hipSuccess)
       return mpa::check_launch("transformer_forward(copy)");
-    hipLaunchKernelGGL(ln_stats_kernel, rows, dim3(kT), 0, s, t.x_in, M, Di, eps, t.stats1);
-    GemmArgs g = gemm_args(t.x_in, pp[P_WQKV], pp[P_BQKV], t.qkv, M, 3 * Di, Di);
-    g.stats = t.stats1;
-    g.gamma = pp[P_G1];
-    g.beta = pp[P_BE1];
-    launch_gemm<PRO_LN, EPI_NONE>(g, s);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, valid, (int)P, Di, (int)H,
+    hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, t.x_in, pp[P_G1], pp[P_BE1], M, Di, eps, t.stats1, t.h1);
+    GemmArgs g = gemm_args(t.h1, pp[P_WQKV], pp[P_BQKV], t.qkv, M, 3 * Di, Di);
+    launch_gemm<PRO_NONE, EPI_NONE>(g, s);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, valid, (int)P, Di, (int)H,
                        drop, site0 + S_ATTN, t.probs, t.o);
     g = gemm_args(t.o, pp[P_WO], pp[P_BO], t.x_mid, M, Di, Di);
     g.resid = t.x_in;
     g.drop = drop;
     g.epi_site = site0 + S_SA_OUT;
     launch_gemm<PRO_NONE, EPI_DROP_RESID>(g, s);
-    hipLaunchKernelGGL(ln_stats_kernel, rows, dim3(kT), 0, s, t.x_mid, M, Di, eps, t.stats2);
-    g = gemm_args(t.x_mid, pp[P_W1], pp[P_B1], t.f, M, FFi, Di);
-    g.stats = t.stats2;
-    g.gamma = pp[P_G2];
-    g.beta = pp[P_BE2];
+    hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, t.x_mid, pp[P_G2], pp[P_BE2], M, Di, eps, t.stats2, t.h2);
+    g = gemm_args(t.h2, pp[P_W1], pp[P_B1], t.f, M, FFi, Di);
     g.drop = drop;
     g.epi_site = site0 + S_FFN;
-    launch_gemm<PRO_LN, EPI_RELU_DROP>(g, s);
+    launch_gemm<PRO_NONE, EPI_RELU_DROP>(g, s);
     float* x_out = l + 1 < L ? w.layer[l + 1].x_in : w.x_final;
     g = gemm_args(t.f, pp[P_W2], pp[P_B2], x_out, M, Di, FFi);
     g.resid = t.x_mid;
@@ -737,10 +760,8 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
     g.epi_site = site0 + S_FFN_OUT;
     launch_gemm<PRO_NONE, EPI_DROP_RESID>(g, s);
   }
-  hipLaunchKernelGGL(ln_stats_kernel, rows, dim3(kT), 0, s, w.x_final, M, Di, eps, w.stats_f);
   const float* const* fin = params + L * P_PER_LAYER;
-  hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)((d.M * D + 255) / 256)), dim3(256), 0, s, w.x_final, w.stats_f,
-                     fin[0], fin[1], M, Di, out);
+  hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, w.x_final, fin[0], fin[1], M, Di, eps, w.stats_f, out);
   return mpa::check_launch("transformer_forward");
 }
 
@@ -755,18 +776,17 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
   hipStream_t s = mpa::as_stream(stream);
   const TfLayout w = tf_carve(ws, d);
   const Drop drop{seed, dropout_p, 1.0f / (1.0f - dropout_p)};
-  const Drop nodrop{0, 0.0f, 1.0f};
   const int M = (int)d.M, Di = (int)D, FFi = (int)FF;
   const dim3 rows((M + 3) / 4);
   const unsigned lnblocks = (unsigned)((M + 3) / 4);
   const size_t ln_smem = sizeof(float) * 4 * 2 * D;
-  const dim3 red((unsigned)((2 * D + 255) / 256));
+  const dim3 red((unsigned)(2 * D / 64));
   const float* const* fin = params + L * P_PER_LAYER;
   float* const* gfin = grad_params + L * P_PER_LAYER;
   // final LayerNorm backward -> g_a = d x_final
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, grad_out, w.x_final, w.stats_f, fin[0],
                      (const float*)nullptr, M, Di, w.g_a, w.lnpart);
-  hipLaunchKernelGGL(ln_reduce_kernel, red, dim3(256), 0, s, w.lnpart, (int)lnblocks, Di, gfin[0], gfin[1]);
+  hipLaunchKernelGGL(ln_reduce_kernel, red, dim3(1024), 0, s, w.lnpart, (int)lnblocks, Di, gfin[0], gfin[1]);
   float* g = w.g_a;      // gradient w.r.t. the current layer's output
   float* spare = w.g_b;  // rotating buffers
   float* spare2 = w.g_c;
@@ -775,60 +795,46 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     float* const* gp = grad_params + l * P_PER_LAYER;
     const TfWs& t = w.layer[l];
     const unsigned site0 = (unsigned)(l * S_PER_LAYER);
-    // ---- FFN: x_out = x_mid + drop(f . W2^T + b2),  f = drop(relu(LN2(x_mid) . W1^T + b1))
-    const float* gd = g;  // g with the output-dropout mask applied
-    if (dropout_p > 0.0f) {
-      hipLaunchKernelGGL(drop_apply_kernel, dim3((unsigned)((d.M * D + 255) / 256)), dim3(256), 0, s, g, drop,
-                         site0 + S_FFN_OUT, (long long)(d.M * D), spare);
-      gd = spare;
-    }
-    launch_wgrad<WP_NONE, WP_NONE>(wgrad_args(gd, t.f, gp[P_W2], gp[P_B2], M, Di, FFi), s);
-    launch_transpose(pp[P_W2], w.wt_a, Di, FFi, s);  // W2 [D, FF] -> [FF, D]
-    GemmArgs ga = gemm_args(gd, w.wt_a, nullptr, w.dz, M, FFi, Di);
+    // ---- FFN: x_out = x_mid + drop(f . W2^T + b2),  f = drop(relu(LN2(x_mid) . W1^T + b1));  the dropout mask of
+    // the incoming gradient is regenerated inside the consumers (no masked copy is materialised)
+    WgradArgs wa = wgrad_args(g, t.f, gp[P_W2], gp[P_B2], M, Di, FFi);
+    wa.drop = drop;
+    wa.site = site0 + S_FFN_OUT;
+    launch_wgrad<WP_DROP>(wa, s);
+    GemmArgs ga = gemm_args(g, pp[P_W2], nullptr, w.dz, M, FFi, Di);  // W2 is [D, FF] = [K, N]
     ga.resid = t.f;
-    ga.drop = dropout_p > 0.0f ? drop : nodrop;
-    launch_gemm<PRO_NONE, EPI_RELU_MASK>(ga, s);  // dz = d(pre-activation)
-    WgradArgs wa = wgrad_args(w.dz, t.x_mid, gp[P_W1], gp[P_B1], M, FFi, Di);
-    wa.stats = t.stats2;
-    wa.gamma = pp[P_G2];
-    wa.beta = pp[P_BE2];
-    launch_wgrad<WP_NONE, WP_LN>(wa, s);
-    launch_transpose(pp[P_W1], w.wt_a, FFi, Di, s);  // W1 [FF, D] -> [D, FF]
-    launch_gemm<PRO_NONE, EPI_NONE>(gemm_args(w.dz, w.wt_a, nullptr, spare2, M, Di, FFi), s);  // d LN2 output
+    ga.drop = drop;
+    ga.pro_site = site0 + S_FFN_OUT;
+    launch_gemm<PRO_DROP, EPI_RELU_MASK, true>(ga, s);  // dz = d(pre-activation)
+    wa = wgrad_args(w.dz, t.h2, gp[P_W1], gp[P_B1], M, FFi, Di);
+    launch_wgrad<WP_NONE>(wa, s);
+    launch_gemm<PRO_NONE, EPI_NONE, true>(gemm_args(w.dz, pp[P_W1], nullptr, spare2, M, Di, FFi), s);  // d LN2 output
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, spare2, t.x_mid, t.stats2, pp[P_G2], g,
                        M, Di, spare, w.lnpart);  // spare = d x_mid
-    hipLaunchKernelGGL(ln_reduce_kernel, red, dim3(256), 0, s, w.lnpart, (int)lnblocks, Di, gp[P_G2], gp[P_BE2]);
-    // rotate: g_mid lives in `spare`
+    hipLaunchKernelGGL(ln_reduce_kernel, red, dim3(1024), 0, s, w.lnpart, (int)lnblocks, Di, gp[P_G2], gp[P_BE2]);
     float* g_mid = spare;
     spare = g;
     // ---- attention block: x_mid = x_in + drop(o . Wo^T + bo)
-    const float* gmd = g_mid;
-    if (dropout_p > 0.0f) {
-      hipLaunchKernelGGL(drop_apply_kernel, dim3((unsigned)((d.M * D + 255) / 256)), dim3(256), 0, s, g_mid, drop,
-                         site0 + S_SA_OUT, (long long)(d.M * D), spare);
-      gmd = spare;
-    }
-    launch_wgrad<WP_NONE, WP_NONE>(wgrad_args(gmd, t.o, gp[P_WO], gp[P_BO], M, Di, Di), s);
-    launch_transpose(pp[P_WO], w.wt_a, Di, Di, s);
-    launch_gemm<PRO_NONE, EPI_NONE>(gemm_args(gmd, w.wt_a, nullptr, spare2, M, Di, Di), s);  // d o
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
-                       (int)H, dropout_p > 0.0f ? drop : nodrop, site0 + S_ATTN, w.dqkv);
-    wa = wgrad_args(w.dqkv, t.x_in, gp[P_WQKV], gp[P_BQKV], M, 3 * Di, Di);
-    wa.stats = t.stats1;
-    wa.gamma = pp[P_G1];
-    wa.beta = pp[P_BE1];
-    launch_wgrad<WP_NONE, WP_LN>(wa, s);
-    launch_transpose(pp[P_WQKV], w.wt_a, 3 * Di, Di, s);  // [3D, D] -> [D, 3D]
-    launch_gemm<PRO_NONE, EPI_NONE>(gemm_args(w.dqkv, w.wt_a, nullptr, spare2, M, Di, 3 * Di), s);  // d LN1 output
+    wa = wgrad_args(g_mid, t.o, gp[P_WO], gp[P_BO], M, Di, Di);
+    wa.drop = drop;
+    wa.site = site0 + S_SA_OUT;
+    launch_wgrad<WP_DROP>(wa, s);
+    ga = gemm_args(g_mid, pp[P_WO], nullptr, spare2, M, Di, Di);
+    ga.drop = drop;
+    ga.pro_site = site0 + S_SA_OUT;
+    launch_gemm<PRO_DROP, EPI_NONE, true>(ga, s);  // d o
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
+                       (int)H, drop, site0 + S_ATTN, w.dqkv);
+    wa = wgrad_args(w.dqkv, t.h1, gp[P_WQKV], gp[P_BQKV], M, 3 * Di, Di);
+    launch_wgrad<WP_NONE>(wa, s);
+    launch_gemm<PRO_NONE, EPI_NONE, true>(gemm_args(w.dqkv, pp[P_WQKV], nullptr, spare2, M, Di, 3 * Di), s);  // d LN1 out
     float* g_in = l == 0 ? grad_tokens : spare;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, spare2, t.x_in, t.stats1, pp[P_G1], g_mid,
                        M, Di, g_in, w.lnpart);
-    hipLaunchKernelGGL(ln_reduce_kernel, red, dim3(256), 0, s, w.lnpart, (int)lnblocks, Di, gp[P_G1], gp[P_BE1]);
-    // rotate buffers: next g = g_in (in `spare`), free ones: g_mid's buffer
-    if (l > 0) {
-      float* old_gmid = g_mid;
+    hipLaunchKernelGGL(ln_reduce_kernel, red, dim3(1024), 0, s, w.lnpart, (int)lnblocks, Di, gp[P_G1], gp[P_BE1]);
+    if (l > 0) {  // next layer down: its output gradient is g_in; g_mid's buffer is free again
       g = spare;
-      spare = old_gmid;
+      spare = g_mid;
     }
   }
   return mpa::check_launch("transformer_backward");
@@ -836,11 +842,10 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
 
 // ---- pose head -------------------------------------------------------------------------------------------------------------------
 // params: fc1.w [256,F], fc1.b, fc2.w [128,256], fc2.b, rot.w [4,128], rot.b, trans.w [3,128], trans.b
-// ws: h1 [M,256] | h2 [M,128] | rot_raw [M,4] | dqt [M,8] | d2 [M,128] | d1 [M,256] | wt [max]
+// ws: h1 [M,256] | h2 [M,128] | rot_raw [M,4] | dqt [M,8] | d2 [M,128] | d1 [M,256]
 extern "C" int mpa_pose_head_workspace(int64_t M, int64_t F, int64_t* float_elems) {
   MPA_REQUIRE(M >= 0 && F >= 64 && F % 64 == 0 && float_elems, "pose_head_workspace: need F multiple of 64");
-  const int64_t wmax = 256 * (F > 256 ? F : 256);
-  *float_elems = M * (256 + 128 + 4 + 8 + 128 + 256) + wmax + 64;
+  *float_elems = M * (256 + 128 + 4 + 8 + 128 + 256) + 64;
   return MPA_OK;
 }
 
@@ -873,21 +878,16 @@ extern "C" int mpa_pose_head_backward(const float* grad_rot, const float* grad_t
   float* dqt = rot_raw + M * 4;
   float* d2 = dqt + M * 8;
   float* d1 = d2 + M * 128;
-  float* wt = d1 + M * 256;
   const int Mi = (int)M;
   hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(kT), 0, s, rot_raw, grad_rot, grad_trans,
-                     params[4], params[6], Mi, 128, dqt, d2);
-  hipLaunchKernelGGL(head_wgrad_kernel, dim3(2), dim3(kT), 0, s, dqt, h2, Mi, 128, grad_params[4], grad_params[5],
+                     params[4], params[6], h2, Mi, 128, dqt, d2);  // d2 = gradient at fc2's pre-activation
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(2), dim3(1024), 0, s, dqt, h2, Mi, 128, grad_params[4], grad_params[5],
                      grad_params[6], grad_params[7]);
-  hipLaunchKernelGGL(leaky_bwd_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, s, d2, h2,
-                     (long long)(M * 128), d2);
-  launch_wgrad<WP_NONE, WP_NONE>(wgrad_args(d2, h1, grad_params[2], grad_params[3], Mi, 128, 256), s);
-  launch_transpose(params[2], wt, 128, 256, s);  // [128,256] -> [256,128]
-  launch_gemm<PRO_NONE, EPI_NONE>(gemm_args(d2, wt, nullptr, d1, Mi, 256, 128), s);
-  hipLaunchKernelGGL(leaky_bwd_kernel, dim3((unsigned)((M * 256 + 255) / 256)), dim3(256), 0, s, d1, h1,
-                     (long long)(M * 256), d1);
-  launch_wgrad<WP_NONE, WP_NONE>(wgrad_args(d1, x, grad_params[0], grad_params[1], Mi, 256, (int)F), s);
-  launch_transpose(params[0], wt, 256, (int)F, s);  // [256,F] -> [F,256]
-  launch_gemm<PRO_NONE, EPI_NONE>(gemm_args(d1, wt, nullptr, grad_x, Mi, (int)F, 256), s);
+  launch_wgrad<WP_NONE>(wgrad_args(d2, h1, grad_params[2], grad_params[3], Mi, 128, 256), s);
+  GemmArgs ga = gemm_args(d2, params[2], nullptr, d1, Mi, 256, 128);  // fc2.weight is [128, 256] = [K, N]
+  ga.resid = h1;
+  launch_gemm<PRO_NONE, EPI_LEAKY_MASK, true>(ga, s);
+  launch_wgrad<WP_NONE>(wgrad_args(d1, x, grad_params[0], grad_params[1], Mi, 256, (int)F), s);
+  launch_gemm<PRO_NONE, EPI_NONE, true>(gemm_args(d1, params[0], nullptr, grad_x, Mi, (int)F, 256), s);
   return mpa::check_launch("pose_head_backward");
 }
