@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from .gradsink import GradSink
 
 
 class _PointNetFn(torch.autograd.Function):
@@ -42,21 +43,23 @@ class _PointNetFn(torch.autograd.Function):
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_pointnet_forward")
         ctx.training = bool(training)
-        ctx.save_for_backward(points, valids, fws, iws, *conv_w, *bn_w)
+        ctx.params = params
+        GradSink.note_use(params)
+        ctx.save_for_backward(points, valids, fws, iws)
         return feat
 
     @staticmethod
     def backward(ctx, grad_feat):
         if not ctx.training:
             raise RuntimeError("PointNet: backward is implemented for training-mode BatchNorm only")
-        points, valids, fws, iws, *rest = ctx.saved_tensors
-        conv_w, bn_w = rest[0:5], rest[5:10]
+        points, valids, fws, iws = ctx.saved_tensors
+        params = ctx.params
+        conv_w, bn_w = params[0:5], params[5:10]
         M, N, _ = points.shape
         F_ = conv_w[4].shape[0]
         dev = points.device
-        g_conv = [torch.empty_like(w) for w in conv_w]
-        g_bnw = [torch.empty_like(w) for w in bn_w]
-        g_bnb = [torch.empty_like(w) for w in bn_w]
+        grads, direct = GradSink.outputs(params)
+        g_conv, g_bnw, g_bnb = grads[0:5], grads[5:10], grads[10:15]
         grad_feat = grad_feat.contiguous()
         with torch.cuda.device(dev):
             tok = _lib.KernelTimer.start(f"pointnet_backward[{M}x{N}x{F_}]")
@@ -66,7 +69,10 @@ class _PointNetFn(torch.autograd.Function):
                 _lib.ptr_array(g_bnw), _lib.ptr_array(g_bnb), _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_pointnet_backward")
-        return (None, None, None, None, None, None, *g_conv, *g_bnw, *g_bnb)
+        if direct:
+            GradSink.delivered(params)
+            return (None,) * (6 + len(params))
+        return (None, None, None, None, None, None, *grads)
 
 
 class PointNet(nn.Module):

@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from .gradsink import GradSink
 
 
 class _PoseHeadFn(torch.autograd.Function):
@@ -33,16 +34,19 @@ class _PoseHeadFn(torch.autograd.Function):
                                            _lib.ptr(rot), _lib.ptr(trans), _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_pose_head_forward")
-        ctx.save_for_backward(x, ws, *params)
+        ctx.params = params
+        GradSink.note_use(params)
+        ctx.save_for_backward(x, ws)
         return rot, trans
 
     @staticmethod
     def backward(ctx, grad_rot, grad_trans):
-        x, ws, *params = ctx.saved_tensors
+        x, ws = ctx.saved_tensors
+        params = ctx.params
         M, Fdim = x.shape
         dev = x.device
         grad_x = torch.empty_like(x)
-        grads = [torch.empty_like(p) for p in params]
+        grads, direct = GradSink.outputs(params)
         with torch.cuda.device(dev):
             tok = _lib.KernelTimer.start(f"pose_head_backward[{M}x{Fdim}]")
             st = _lib.lib().mpa_pose_head_backward(
@@ -51,6 +55,9 @@ class _PoseHeadFn(torch.autograd.Function):
                 _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_pose_head_backward")
+        if direct:
+            GradSink.delivered(params)
+            return (grad_x, *([None] * len(params)))
         return (grad_x, *grads)
 
 

@@ -23,6 +23,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from .gradsink import GradSink
 from .dp import BucketedGradReducer, broadcast_from_rank0, bucket_sizes_for, ordered_parameters
 from .optim import FlatBuffers, FusedAdam, cosine_warmup_lr
 
@@ -48,6 +49,7 @@ class Trainer:
         # graph mode replaces the backward-overlapped bucket hooks by one all-reduce after the replay
         self.reducer = None if use_graph else BucketedGradReducer(
             self.flat, bucket_sizes_for(model, self.flat), process_group)
+        self.sink = GradSink(on_ready=self.reducer._on_grad if self.reducer is not None and self.world > 1 else None)
         self.set_epoch(0)
 
     def set_epoch(self, epoch):
@@ -61,8 +63,9 @@ class Trainer:
 
     def _fwd_bwd(self, batch):
         self.optimizer.zero_grad()
-        loss = self.model.training_step(batch, 0)
-        loss.backward()
+        with self.sink:  # HIP backward kernels write straight into the flat gradient buffer
+            loss = self.model.training_step(batch, 0)
+            loss.backward()
         return loss.detach()
 
     def _capture(self, data_dict):
@@ -104,8 +107,9 @@ class Trainer:
             return self._graph_step(data_dict)
         self.model.train()
         self.optimizer.zero_grad()
-        loss = self.model.training_step(data_dict, batch_idx)
-        loss.backward()
+        with self.sink:  # HIP backward kernels write straight into the flat gradient buffer
+            loss = self.model.training_step(data_dict, batch_idx)
+            loss.backward()
         self.optimizer.grad_scale = self.reducer.finish()
         self.optimizer.step()
         return loss.detach()

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .gradsink import GradSink
 
 _LAYER_PARAMS = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
                  "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight",
@@ -41,18 +42,21 @@ class _TransformerFn(torch.autograd.Function):
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_transformer_forward")
         ctx.meta = (heads, FF, L, float(dropout_p), int(seed))
-        ctx.save_for_backward(valid, ws, *params)
+        ctx.params = params  # the Parameter objects themselves (GradSink writes into their .grad)
+        GradSink.note_use(params)
+        ctx.save_for_backward(valid, ws)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        valid, ws, *params = ctx.saved_tensors
+        valid, ws = ctx.saved_tensors
+        params = ctx.params
         heads, FF, L, dropout_p, seed = ctx.meta
         B, P, D = grad_out.shape
         dev = grad_out.device
         grad_out = grad_out.contiguous()
         grad_tokens = torch.empty_like(grad_out)
-        grads = [torch.empty_like(p) for p in params]
+        grads, direct = GradSink.outputs(params)
         with torch.cuda.device(dev):
             tok = _lib.KernelTimer.start(f"transformer_backward[{B}x{P}x{D}]")
             st = _lib.lib().mpa_transformer_backward(
@@ -60,6 +64,9 @@ class _TransformerFn(torch.autograd.Function):
                 seed, _lib.ptr(ws), _lib.ptr(grad_tokens), _lib.ptr_array(grads), _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_transformer_backward")
+        if direct:
+            GradSink.delivered(params)
+            return (grad_tokens, None, None, None, None, *([None] * len(params)))
         return (grad_tokens, None, None, None, None, *grads)
 
 
