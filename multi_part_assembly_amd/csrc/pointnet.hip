@@ -63,32 +63,79 @@ __global__ void pn_transpose_kernel(const float* __restrict__ w, float* __restri
   if (i < cout * cin) wt[(i % cin) * cout + i / cin] = w[i];
 }
 
-__global__ void pn_count_kernel(const float* __restrict__ valids, int M, int N, float* __restrict__ count) {
+__global__ void pn_count_kernel(const float* __restrict__ valids, int M, int N, float* __restrict__ count,
+                                unsigned* __restrict__ ticket) {
+  if (threadIdx.x < 4) ticket[threadIdx.x] = 0u;  // the cooperative reductions' counters (reset after every use)
   float s = 0.0f;
   for (int m = threadIdx.x; m < M; m += 64) s += valids[m] != 0.0f ? 1.0f : 0.0f;
   s = wave_sum(s);
   if (threadIdx.x == 0) count[0] = s * (float)N;
 }
 
-// Sum the per-block (sum0, sum1) partials of 64 channels over all valid parts; 1024 threads =
-// 64 channels x 16 slices, fixed-order LDS tree.  Result valid for threads < 64 (slice 0).
-__device__ __forceinline__ void reduce_partials(const float* __restrict__ partial,
+// Sum the per-block (sum0, sum1) partials of 64 channels over all valid parts — cooperatively: a single CU
+// streaming the M*splits x 64 x 2 table takes ~25-50 us, so the table is cut into groups of kEB rows, one
+// block (64 channels x 16 slices) per group and channel panel (grid = (C/64, G)).  Every block leaves its
+// fp64 group sums in `stage`, takes a ticket, and the LAST block of the panel adds the G group sums in fixed
+// order: deterministic, one launch.  Returns true in that block only (totals valid for threads < 64).
+constexpr int kEB = 64;  // table rows per block
+
+struct CoopWs {
+  double* stage;       // [G][C][2]
+  unsigned* ticket;    // [C/64], zero between launches
+};
+
+__device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial,
                                                 const float* __restrict__ valids, int M, int splits, int C,
-                                                int c, double& s0, double& s1) {
+                                                int c, const CoopWs ws, double& s0, double& s1) {
   __shared__ double sm[kSlices][64][2];
+  __shared__ bool last;
   const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int total = M * splits, g = blockIdx.y, G = gridDim.y;
+  constexpr int U = kEB / kSlices;
+  float2 v[U];
+  float ok[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {  // independent loads; rows of padded parts hold garbage and are skipped
+    const int e = g * kEB + slice + u * kSlices, ee = e < total ? e : total - 1;
+    v[u] = *reinterpret_cast<const float2*>(partial + ((long long)ee * C + c) * 2);
+    ok[u] = e < total ? valids[ee / splits] : 0.0f;
+  }
   double a = 0.0, b = 0.0;
-  for (int e = slice; e < M * splits; e += kSlices) {
-    if (valids[e / splits] == 0.0f) continue;
-    const long long o = ((long long)e * C + c) * 2;
-    a += (double)partial[o];
-    b += (double)partial[o + 1];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (ok[u] != 0.0f) {
+      a += (double)v[u].x;
+      b += (double)v[u].y;
+    }
   }
   sm[slice][cl][0] = a;
   sm[slice][cl][1] = b;
   __syncthreads();
-  s0 = 0.0;
-  s1 = 0.0;
+  if (slice == 0) {
+    a = b = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSlices; ++k) {
+      a += sm[k][cl][0];
+      b += sm[k][cl][1];
+    }
+    ws.stage[((long long)g * C + c) * 2] = a;
+    ws.stage[((long long)g * C + c) * 2 + 1] = b;
+    __threadfence();  // release: the group sums are visible device-wide before the ticket is taken
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(ws.ticket + blockIdx.x, 1u) == (unsigned)(G - 1);
+  __syncthreads();
+  if (!last) return false;
+  __threadfence();  // acquire
+  a = b = 0.0;
+  for (int gg = slice; gg < G; gg += kSlices) {
+    a += ws.stage[((long long)gg * C + c) * 2];
+    b += ws.stage[((long long)gg * C + c) * 2 + 1];
+  }
+  sm[slice][cl][0] = a;
+  sm[slice][cl][1] = b;
+  __syncthreads();
+  s0 = s1 = 0.0;
   if (slice == 0) {
 #pragma unroll
     for (int k = 0; k < kSlices; ++k) {
@@ -96,17 +143,19 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ partia
       s1 += sm[k][cl][1];
     }
   }
+  if (threadIdx.x == 0) ws.ticket[blockIdx.x] = 0u;  // ready for the next launch
+  return true;
 }
 
-// BatchNorm statistics -> scale/shift (+ running statistics).  grid = C/64, block 1024.
+// BatchNorm statistics -> scale/shift (+ running statistics).  grid = (C/64, ceil(M*splits/kEB)), block 1024.
 __global__ __launch_bounds__(64 * kSlices) void pn_bn_finalize_kernel(
     const float* __restrict__ partial, const float* __restrict__ valids, int M, int splits, int C,
     const float* __restrict__ count, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
-    float* __restrict__ bn) {
+    float* __restrict__ bn, const CoopWs cw) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   double s, ss;
-  reduce_partials(partial, valids, M, splits, C, c, s, ss);
+  if (!reduce_partials(partial, valids, M, splits, C, c, cw, s, ss)) return;
   if (threadIdx.x >= 64) return;
   const double n = (double)count[0];
   const double mean = s / n;
@@ -155,10 +204,10 @@ __device__ __forceinline__ void write_coef(float* __restrict__ coef, int C, int 
 __global__ __launch_bounds__(64 * kSlices) void pn_bwd_coef_kernel(
     const float* __restrict__ partial, const float* __restrict__ valids, int M, int splits, int C,
     const float* __restrict__ count, const float* __restrict__ gamma, const float* __restrict__ bn,
-    float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta, const CoopWs cw) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   double s1, s2;
-  reduce_partials(partial, valids, M, splits, C, c, s1, s2);
+  if (!reduce_partials(partial, valids, M, splits, C, c, cw, s1, s2)) return;
   if (threadIdx.x >= 64) return;
   write_coef(coef, C, c, gamma[c], bn, s1, s2, (double)count[0]);
   dgamma[c] = (float)s2;
@@ -175,14 +224,26 @@ __global__ __launch_bounds__(64 * kSlices) void pn_bwd_top_kernel(
   const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   const float mean = bn[2 * F + c], invstd = bn[3 * F + c];
   double a = 0.0, b = 0.0;
-  for (int m = slice; m < M; m += kSlices) {
-    if (valids[m] == 0.0f) continue;
-    const int n = argmax[(long long)m * F + c];
-    if (n < 0) continue;  // all-NaN column: no arg-max, no gradient
-    const float g = gfeat[(long long)m * F + c];
-    const float y = y5[((long long)m * N + n) * F + c];
-    a += (double)g;
-    b += (double)g * (double)((y - mean) * invstd);
+  constexpr int U = 8;  // independent (argmax -> y5) chains in flight per thread
+  for (int m0 = slice; m0 < M; m0 += kSlices * U) {
+    float g[U], y[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = m0 + u * kSlices, mm = m < M ? m : M - 1;
+      const int n = argmax[(long long)mm * F + c];  // -1 for padded parts and all-NaN columns: no gradient
+      ok[u] = m < M && valids[mm] != 0.0f && n >= 0;
+      g[u] = gfeat[(long long)mm * F + c];
+      y[u] = y5[((long long)mm * N + (n >= 0 ? n : 0)) * F + c];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ok[u]) {
+        a += (double)g[u];
+        b += (double)g[u] * (double)((y[u] - mean) * invstd);
+      }
+    }
   }
   sm[slice][cl][0] = a;
   sm[slice][cl][1] = b;
@@ -694,9 +755,22 @@ __global__ __launch_bounds__(64 * kSlices) void pn_wgrad_reduce_kernel(const flo
   __shared__ float sm[kSlices][64];
   const int el = threadIdx.x & 63, slice = threadIdx.x >> 6, i = blockIdx.x * 64 + el;
   float s = 0.0f;
-  if (i < elems)
-    for (int m = slice; m < M; m += kSlices)
-      if (valids[m] != 0.0f) s += dwpart[(long long)m * elems + i];
+  if (i < elems) {
+    constexpr int U = 8;  // independent loads in flight; padded parts' rows hold garbage and are skipped
+    for (int m0 = slice; m0 < M; m0 += kSlices * U) {
+      float v[U], ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int m = m0 + u * kSlices, mm = m < M ? m : M - 1;
+        v[u] = dwpart[(long long)mm * elems + i];
+        ok[u] = m < M ? valids[mm] : 0.0f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (ok[u] != 0.0f) s += v[u];
+    }
+  }
   sm[slice][el] = s;
   __syncthreads();
   if (slice == 0 && i < elems) {
@@ -741,6 +815,7 @@ struct PnWs {
   float* partial; // per-block column sums
   float* dwpart;  // [M][cout*cin]
   float* count;
+  CoopWs coop;    // fp64 group sums + tickets of the cooperative reductions
   int64_t total;
 };
 
@@ -762,6 +837,8 @@ PnWs carve(float* base, const Dims& d) {
   w.partial = take(blocks * maxc * 2);
   w.dwpart = take(d.M * 128 * maxc);
   w.count = take(4);
+  w.coop.ticket = reinterpret_cast<unsigned*>(take(4));
+  w.coop.stage = reinterpret_cast<double*>(take(2 * 2 * maxc * ((blocks + kEB - 1) / kEB)));
   w.total = p - base;
   return w;
 }
@@ -813,7 +890,7 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
   const Dims d = make_dims(M, N, F);
   const PnWs w = carve(float_ws, d);
   hipLaunchKernelGGL(pn_transpose_kernel, dim3(1), dim3(192), 0, s, conv_w[0], w.Wt1, 64, 3);
-  hipLaunchKernelGGL(pn_count_kernel, dim3(1), dim3(64), 0, s, valids, (int)M, (int)N, w.count);
+  hipLaunchKernelGGL(pn_count_kernel, dim3(1), dim3(64), 0, s, valids, (int)M, (int)N, w.count, w.coop.ticket);
   for (int l = 1; l <= 5; ++l) {
     int splits;
     if (l == 1) {
@@ -832,9 +909,9 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
     }
     const dim3 cg((unsigned)(d.C[l] / 64));
     if (training)
-      hipLaunchKernelGGL(pn_bn_finalize_kernel, cg, dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, splits,
-                         d.C[l], w.count, bn_w[l - 1], bn_b[l - 1], running_mean[l - 1], running_var[l - 1],
-                         momentum, eps, w.bn[l]);
+      hipLaunchKernelGGL(pn_bn_finalize_kernel, dim3(cg.x, (unsigned)((M * splits + kEB - 1) / kEB)),
+                         dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, splits, d.C[l], w.count, bn_w[l - 1],
+                         bn_b[l - 1], running_mean[l - 1], running_var[l - 1], momentum, eps, w.bn[l], w.coop);
     else
       hipLaunchKernelGGL(pn_bn_from_running_kernel, cg, dim3(64), 0, s, d.C[l], bn_w[l - 1], bn_b[l - 1],
                          running_mean[l - 1], running_var[l - 1], eps, w.bn[l]);
@@ -885,9 +962,9 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
     else
       launch_dgrad<false>(cout, w.Y[l], w.dZ[l], nullptr, nullptr, w.coef[l], conv_w[l - 1], cin, w.Y[l - 1],
                           w.bn[l - 1], valids, d, w.dZ[l - 1], w.partial, s);
-    hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(cin / 64)), dim3(64 * kSlices), 0, s, w.partial,
-                       valids, (int)M, d.splits, cin, w.count, bn_w[l - 2], w.bn[l - 1], w.coef[l - 1],
-                       grad_bn_w[l - 2], grad_bn_b[l - 2]);
+    hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(cin / 64), (unsigned)((M * d.splits + kEB - 1) / kEB)),
+                       dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, d.splits, cin, w.count, bn_w[l - 2],
+                       w.bn[l - 1], w.coef[l - 1], grad_bn_w[l - 2], grad_bn_b[l - 2], w.coop);
   }
   return mpa::check_launch("pointnet_backward");
 }
