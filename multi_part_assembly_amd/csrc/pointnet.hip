@@ -84,28 +84,29 @@ struct CoopWs {
   unsigned* ticket;    // [C/64], zero between launches
 };
 
-__device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial,
-                                                const float* __restrict__ valids, int M, int splits, int C,
-                                                int c, const CoopWs ws, double& s0, double& s1) {
+// row(e, ok, x, y): the two addends of table row e (ok = false: skip the row)
+template <typename Row>
+__device__ __forceinline__ bool coop_colsum(int total, int C, int c, const CoopWs ws, Row row, double& s0,
+                                            double& s1) {
   __shared__ double sm[kSlices][64][2];
   __shared__ bool last;
   const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int total = M * splits, g = blockIdx.y, G = gridDim.y;
+  const int g = blockIdx.y, G = gridDim.y;
   constexpr int U = kEB / kSlices;
-  float2 v[U];
-  float ok[U];
+  double x[U], y[U];
+  bool ok[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {  // independent loads; rows of padded parts hold garbage and are skipped
-    const int e = g * kEB + slice + u * kSlices, ee = e < total ? e : total - 1;
-    v[u] = *reinterpret_cast<const float2*>(partial + ((long long)ee * C + c) * 2);
-    ok[u] = e < total ? valids[ee / splits] : 0.0f;
+  for (int u = 0; u < U; ++u) {  // independent loads
+    const int e = g * kEB + slice + u * kSlices;
+    row(e < total ? e : total - 1, ok[u], x[u], y[u]);
+    ok[u] = ok[u] && e < total;
   }
   double a = 0.0, b = 0.0;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    if (ok[u] != 0.0f) {
-      a += (double)v[u].x;
-      b += (double)v[u].y;
+    if (ok[u]) {
+      a += x[u];
+      b += y[u];
     }
   }
   sm[slice][cl][0] = a;
@@ -145,6 +146,21 @@ __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partia
   }
   if (threadIdx.x == 0) ws.ticket[blockIdx.x] = 0u;  // ready for the next launch
   return true;
+}
+
+// the (sum0, sum1) partial tables written by the forward / input-gradient kernels; rows of padded parts hold
+// garbage and are skipped
+__device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial,
+                                                const float* __restrict__ valids, int M, int splits, int C,
+                                                int c, const CoopWs ws, double& s0, double& s1) {
+  return coop_colsum(M * splits, C, c, ws,
+                     [&](int e, bool& ok, double& x, double& y) {
+                       const float2 v = *reinterpret_cast<const float2*>(partial + ((long long)e * C + c) * 2);
+                       ok = valids[e / splits] != 0.0f;
+                       x = (double)v.x;
+                       y = (double)v.y;
+                     },
+                     s0, s1);
 }
 
 // BatchNorm statistics -> scale/shift (+ running statistics).  grid = (C/64, ceil(M*splits/kEB)), block 1024.
@@ -214,95 +230,219 @@ __global__ __launch_bounds__(64 * kSlices) void pn_bwd_coef_kernel(
   dbeta[c] = (float)s1;
 }
 
-// layer-5 coefficients: dZ5 is sparse, grad_feat[m,c] sits at row argmax[m,c].  grid = F/64, block 1024.
+// layer-5 coefficients: dZ5 is sparse, grad_feat[m,c] sits at row argmax[m,c] whose pre-BatchNorm value the
+// forward saved in ybest[m,c].  grid = (F/64, ceil(M/kEB)), block 1024.
 __global__ __launch_bounds__(64 * kSlices) void pn_bwd_top_kernel(
-    const float* __restrict__ gfeat, const int* __restrict__ argmax, const float* __restrict__ y5,
-    const float* __restrict__ valids, int M, int N, int F, const float* __restrict__ count,
+    const float* __restrict__ gfeat, const int* __restrict__ argmax, const float* __restrict__ ybest,
+    const float* __restrict__ valids, int M, int F, const float* __restrict__ count,
     const float* __restrict__ gamma, const float* __restrict__ bn, float* __restrict__ coef,
-    float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double sm[kSlices][64][2];
-  const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float* __restrict__ dgamma, float* __restrict__ dbeta, const CoopWs cw) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const float mean = bn[2 * F + c], invstd = bn[3 * F + c];
-  double a = 0.0, b = 0.0;
-  constexpr int U = 8;  // independent (argmax -> y5) chains in flight per thread
-  for (int m0 = slice; m0 < M; m0 += kSlices * U) {
-    float g[U], y[U];
-    bool ok[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int m = m0 + u * kSlices, mm = m < M ? m : M - 1;
-      const int n = argmax[(long long)mm * F + c];  // -1 for padded parts and all-NaN columns: no gradient
-      ok[u] = m < M && valids[mm] != 0.0f && n >= 0;
-      g[u] = gfeat[(long long)mm * F + c];
-      y[u] = y5[((long long)mm * N + (n >= 0 ? n : 0)) * F + c];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (ok[u]) {
-        a += (double)g[u];
-        b += (double)g[u] * (double)((y[u] - mean) * invstd);
-      }
-    }
-  }
-  sm[slice][cl][0] = a;
-  sm[slice][cl][1] = b;
-  __syncthreads();
-  if (slice != 0) return;
-  double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-  for (int k = 0; k < kSlices; ++k) {
-    s1 += sm[k][cl][0];
-    s2 += sm[k][cl][1];
-  }
+  double s1, s2;
+  const bool last = coop_colsum(M, F, c, cw,
+                                [&](int m, bool& ok, double& x, double& y) {
+                                  const long long o = (long long)m * F + c;
+                                  const float g = gfeat[o];
+                                  ok = valids[m] != 0.0f && argmax[o] >= 0;  // all-NaN column: no gradient
+                                  x = (double)g;
+                                  y = (double)g * (double)((ybest[o] - mean) * invstd);
+                                },
+                                s1, s2);
+  if (!last || threadIdx.x >= 64) return;
   write_coef(coef, F, c, gamma[c], bn, s1, s2, (double)count[0]);
   dgamma[c] = (float)s2;
   dbeta[c] = (float)s1;
 }
 
-// BatchNorm of the last layer + max over the points of each part.  grid = (F/64, M), block 256.
-__global__ __launch_bounds__(kT) void pn_maxpool_kernel(const float* __restrict__ y5,
-                                                        const float* __restrict__ bn,
-                                                        const float* __restrict__ valids, int N, int F,
-                                                        float* __restrict__ feat, int* __restrict__ argmax) {
-  __shared__ float smv[kT / 64][64];
-  __shared__ int smi[kT / 64][64];
-  const int m = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+// ---- top-2 extrema records (last layer) --------------------------------------------------------------------------
+// The last layer has no ReLU and feeds a max over the points, so its output tensor is never stored: BatchNorm being
+// a per-channel monotone map, max_n z[n] is the image of max_n y[n] (scale > 0) or min_n y[n] (scale < 0).  The
+// forward GEMM keeps, per (part, channel), the two largest y and the two largest -y with their point indices
+// (order: value descending, index ascending).  Two, because z = fma(y, scale, shift) can round two distinct y to
+// the SAME z, and the reference's arg-max then is the lower index of the two — decided once scale/shift are known.
+struct Top2 {
+  float v1, v2;
+  int n1, n2;
+};
+constexpr int kNoIdx = 0x7fffffff;
+
+__device__ __forceinline__ Top2 top2_empty() { return Top2{-__builtin_inff(), -__builtin_inff(), kNoIdx, kNoIdx}; }
+__device__ __forceinline__ bool top2_before(float y, int n, float y2, int n2) {
+  return y > y2 || (y == y2 && n < n2);
+}
+// n is larger than every index pushed before
+__device__ __forceinline__ void top2_push(Top2& t, float y, int n) {
+  if (y > t.v1) {
+    t.v2 = t.v1;
+    t.n2 = t.n1;
+    t.v1 = y;
+    t.n1 = n;
+  } else if (y > t.v2) {
+    t.v2 = y;
+    t.n2 = n;
+  }
+}
+__device__ __forceinline__ Top2 top2_merge(const Top2 a, const Top2 b) {
+  Top2 r;
+  if (top2_before(b.v1, b.n1, a.v1, a.n1)) {
+    r.v1 = b.v1;
+    r.n1 = b.n1;
+    const bool s = top2_before(a.v1, a.n1, b.v2, b.n2);
+    r.v2 = s ? a.v1 : b.v2;
+    r.n2 = s ? a.n1 : b.n2;
+  } else {
+    r.v1 = a.v1;
+    r.n1 = a.n1;
+    const bool s = top2_before(a.v2, a.n2, b.v1, b.n1);
+    r.v2 = s ? a.v2 : b.v1;
+    r.n2 = s ? a.n2 : b.n1;
+  }
+  return r;
+}
+__device__ __forceinline__ Top2 top2_shfl_xor(const Top2 t, int mask) {
+  return Top2{__shfl_xor(t.v1, mask, 64), __shfl_xor(t.v2, mask, 64), __shfl_xor(t.n1, mask, 64),
+              __shfl_xor(t.n2, mask, 64)};
+}
+
+// BatchNorm of the last layer + max over the points of each part from the per-block top-2 records.
+// topv/topn [M*splits][F][4] = (hi.v1, hi.v2, lo.v1, lo.v2) / indices, lo tracking -y.  One thread per (m, c).
+__global__ void pn_top_finalize_kernel(const float* __restrict__ topv, const int* __restrict__ topn,
+                                       const float* __restrict__ bn, const float* __restrict__ valids,
+                                       const float* __restrict__ y4, const float* __restrict__ bn4,
+                                       const float* __restrict__ w5, int M, int N, int F, int C4, int splits,
+                                       float* __restrict__ feat, int* __restrict__ argmax,
+                                       float* __restrict__ ybest) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * F) return;
+  const int m = (int)(i / F), c = (int)(i % F);
   if (valids[m] == 0.0f) {
-    if (wave == 0) {
-      feat[(long long)m * F + c] = 0.0f;  // padded slots hold zeros (network.py:66)
-      argmax[(long long)m * F + c] = -1;
-    }
+    feat[i] = 0.0f;  // padded slots hold zeros (network.py:66)
+    argmax[i] = -1;
+    ybest[i] = 0.0f;
     return;
   }
+  Top2 hi = top2_empty(), lo = top2_empty();
+  for (int sp = 0; sp < splits; ++sp) {
+    const long long o = (((long long)m * splits + sp) * F + c) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(topv + o);
+    const int4 n = *reinterpret_cast<const int4*>(topn + o);
+    hi = top2_merge(hi, Top2{v.x, v.y, n.x, n.y});
+    lo = top2_merge(lo, Top2{v.z, v.w, n.z, n.w});
+  }
   const float scale = bn[c], shift = bn[F + c];
-  float best = -__builtin_inff();
-  int arg = -1;
-  const float* src = y5 + (long long)m * N * F + c;
-  for (int n = wave; n < N; n += kT / 64) {
-    const float z = __builtin_fmaf(src[(long long)n * F], scale, shift);
-    if (z > best) {
-      best = z;
-      arg = n;
-    }
+  float z, y;
+  int arg;
+  if (scale != 0.0f) {
+    const Top2 t = scale > 0.0f ? hi : lo;
+    const float sg = scale > 0.0f ? 1.0f : -1.0f;
+    const float y1 = sg * t.v1, y2 = sg * t.v2;
+    const float z1 = __builtin_fmaf(y1, scale, shift), z2 = __builtin_fmaf(y2, scale, shift);
+    const bool second = t.n2 != kNoIdx && z2 == z1 && t.n2 < t.n1;
+    arg = t.n1 == kNoIdx ? -1 : (second ? t.n2 : t.n1);  // no candidate: an all-NaN column
+    y = second ? y2 : y1;
+    z = z1;
+  } else {  // gamma == 0: every point maps to `shift`, the arg-max is the first point; its y is recomputed
+    arg = 0;
+    z = shift;
+    const float* row = y4 + (long long)m * N * C4;
+    y = 0.0f;
+    for (int k = 0; k < C4; ++k)
+      y = __builtin_fmaf(__builtin_fmaxf(__builtin_fmaf(row[k], bn4[k], bn4[C4 + k]), 0.0f), w5[(long long)c * C4 + k], y);
   }
-  smv[wave][threadIdx.x & 63] = best;
-  smi[wave][threadIdx.x & 63] = arg;
+  feat[i] = z;
+  argmax[i] = arg;
+  ybest[i] = y;
+}
+
+// Per part: the arg-max entries (row, channel, alpha*grad) sorted by 32-row tile (ties: channel order), and the
+// tile offsets — the sparse operand of the last layer's input gradient.  grid = M, block = F threads.
+__global__ void pn_top_csr_kernel(const int* __restrict__ argmax, const float* __restrict__ gfeat,
+                                  const float* __restrict__ coef, const float* __restrict__ valids, int N, int F,
+                                  int* __restrict__ erow, int* __restrict__ ech, float* __restrict__ eval,
+                                  int* __restrict__ tptr) {
+  extern __shared__ int bins[];  // [F]
+  const int m = blockIdx.x, c = threadIdx.x, T = (N + 31) / 32;
+  if (valids[m] == 0.0f) return;
+  const int arg = argmax[(long long)m * F + c];
+  const int bin = arg >= 0 ? arg >> 5 : T;  // T: no entry
+  bins[c] = bin;
   __syncthreads();
-  if (wave == 0) {
-    const int l = threadIdx.x;
-#pragma unroll
-    for (int w = 1; w < kT / 64; ++w) {
-      const float v = smv[w][l];
-      const int i = smi[w][l];
-      if (v > best || (v == best && i >= 0 && i < arg)) {
-        best = v;
-        arg = i;
-      }
-    }
-    feat[(long long)m * F + c] = best;
-    argmax[(long long)m * F + c] = arg;
+  int below = 0, rank = 0;
+  for (int k = 0; k < F; ++k) {
+    const int b = bins[k];
+    below += b < bin ? 1 : 0;
+    rank += (b == bin && k < c) ? 1 : 0;
   }
+  if (arg >= 0) {
+    const long long o = (long long)m * F + below + rank;
+    erow[o] = arg;
+    ech[o] = c;
+    eval[o] = coef[c] * gfeat[(long long)m * F + c];  // alpha_c * grad_feat[m, c]
+  }
+  for (int t = c; t <= T; t += blockDim.x) {
+    int cnt = 0;
+    for (int k = 0; k < F; ++k) cnt += bins[k] < t ? 1 : 0;
+    tptr[(long long)m * (T + 1) + t] = cnt;
+  }
+}
+
+// Q[k][d] = sum_c gammap_c W5[c][k] W5[c][d]  (dA4 = A4 Q + c0 + sparse),  c0[d] = sum_c betap_c W5[c][d].
+// grid = C4 + 1 (row k; the extra block writes c0), block = C4 threads (d).
+__global__ void pn_top_q_kernel(const float* __restrict__ w5, const float* __restrict__ coef, int F, int C4,
+                                float* __restrict__ q) {
+  const int k = blockIdx.x, d = threadIdx.x;
+  float acc = 0.0f;
+  if (k < C4) {
+#pragma unroll 8
+    for (int c = 0; c < F; ++c)
+      acc = __builtin_fmaf(coef[F + c] * w5[(long long)c * C4 + k], w5[(long long)c * C4 + d], acc);
+  } else {
+#pragma unroll 8
+    for (int c = 0; c < F; ++c) acc = __builtin_fmaf(coef[2 * F + c], w5[(long long)c * C4 + d], acc);
+  }
+  q[(long long)k * C4 + d] = acc;
+}
+
+// Weight gradient of the last layer:
+//   dW5[c][ci] = alpha_c sum_m g[m,c] A4[m, argmax[m,c], ci]  +  gammap_c (W5 G)[c][ci]  +  betap_c a4sum[ci]
+// with G = A4^T A4 and a4sum the column sums of A4 over all valid points (gram[C4][C4] followed by a4sum[C4]).
+// grid = F (channel c), block 1024 = C4(=128) columns x 8 part-slices.
+__global__ __launch_bounds__(1024) void pn_top_wgrad_kernel(
+    const float* __restrict__ gfeat, const int* __restrict__ argmax, const float* __restrict__ valids,
+    const float* __restrict__ y4, const float* __restrict__ bn4, const float* __restrict__ w5,
+    const float* __restrict__ coef, const float* __restrict__ gram, int M, int N, int F,
+    float* __restrict__ dw5) {
+  constexpr int C4 = 128, S = 8, U = 8;
+  __shared__ float sm[S][C4];
+  const int c = blockIdx.x, ci = threadIdx.x & (C4 - 1), slice = threadIdx.x >> 7;
+  const float sc = bn4[ci], sh = bn4[C4 + ci];
+  float acc = 0.0f;
+  for (int m0 = slice; m0 < M; m0 += S * U) {
+    float g[U], yv[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = m0 + u * S, mm = m < M ? m : M - 1;
+      const int arg = argmax[(long long)mm * F + c];
+      ok[u] = m < M && valids[mm] != 0.0f && arg >= 0;
+      g[u] = gfeat[(long long)mm * F + c];
+      yv[u] = y4[((long long)mm * N + (arg >= 0 ? arg : 0)) * C4 + ci];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (ok[u]) acc = __builtin_fmaf(g[u], __builtin_fmaxf(__builtin_fmaf(yv[u], sc, sh), 0.0f), acc);
+  }
+  sm[slice][ci] = acc;
+  __syncthreads();
+  if (slice != 0) return;
+  float sparse = 0.0f;
+#pragma unroll
+  for (int k = 0; k < S; ++k) sparse += sm[k][ci];
+  float wg = 0.0f;
+#pragma unroll 8
+  for (int k = 0; k < C4; ++k) wg = __builtin_fmaf(w5[(long long)c * C4 + k], gram[k * C4 + ci], wg);
+  dw5[(long long)c * C4 + ci] = coef[c] * sparse + coef[F + c] * wg + coef[2 * F + c] * gram[C4 * C4 + ci];
 }
 
 // ---- first layer (3 -> 64): scalar-operand VALU panel ------------------------------------------------------
@@ -393,11 +533,12 @@ __global__ __launch_bounds__(kT) void pn_wgrad_first_kernel(const float* __restr
 // ---- MFMA forward layer ---------------------------------------------------------------------------------------
 // Y[rows x cout] = relu(bn_prev(Yprev))[rows x CIN] . W[cout x CIN]^T, one 64-channel output panel per block.y.
 // grid = (M*splits, cout/64), block 256: wave w walks the 32-row tiles t0+w, t0+w+4, ... of its split.
-template <int CIN>
+// TOP (last layer): Y is not stored; the block leaves the per-channel top-2 records of its rows instead.
+template <int CIN, bool TOP>
 __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ bn_prev, const float* __restrict__ w, int cout,
     const float* __restrict__ valids, int N, int splits, float* __restrict__ y_out,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, float* __restrict__ topv, int* __restrict__ topn) {
   constexpr int KH = CIN / 2;   // K values per lane-half
   constexpr int LD = CIN + 4;   // padded LDS row: conflict-free ds_read_b128 across rows
   constexpr int Q4 = CIN / 4;   // float4 per row
@@ -424,6 +565,7 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
   const int T = (N + 31) / 32;
   const int t_begin = (int)((long long)sp * T / splits), t_end = (int)((long long)(sp + 1) * T / splits);
   float s_[2] = {0.0f, 0.0f}, ss_[2] = {0.0f, 0.0f};
+  Top2 hi[2] = {top2_empty(), top2_empty()}, lo[2] = {top2_empty(), top2_empty()};
   const float4* sc4_ = reinterpret_cast<const float4*>(bn_prev);
   const float4* sh4_ = reinterpret_cast<const float4*>(bn_prev + CIN);
   float* lds = stage[wave];
@@ -467,9 +609,16 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
     for (int r = 0; r < 16; ++r) {
       const int gn = r0 + acc_row(r, h);
       if (gn < N) {
-        float* dst = y_out + ((long long)m * N + gn) * cout + c0 + j;
-        dst[0] = acc0[r];
-        dst[32] = acc1[r];
+        if constexpr (TOP) {
+          top2_push(hi[0], acc0[r], gn);
+          top2_push(lo[0], -acc0[r], gn);
+          top2_push(hi[1], acc1[r], gn);
+          top2_push(lo[1], -acc1[r], gn);
+        } else {
+          float* dst = y_out + ((long long)m * N + gn) * cout + c0 + j;
+          dst[0] = acc0[r];
+          dst[32] = acc1[r];
+        }
         s_[0] += acc0[r];
         ss_[0] = __builtin_fmaf(acc0[r], acc0[r], ss_[0]);
         s_[1] += acc1[r];
@@ -500,20 +649,52 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
     partial[o] = t0;
     partial[o + 1] = t1;
   }
+  if constexpr (TOP) {
+    __shared__ Top2 tsm[kT / 64][64][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {  // lanes l and l+32 hold the same channel
+      hi[t] = top2_merge(hi[t], top2_shfl_xor(hi[t], 32));
+      lo[t] = top2_merge(lo[t], top2_shfl_xor(lo[t], 32));
+    }
+    if (h == 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        tsm[wave][32 * t + j][0] = hi[t];
+        tsm[wave][32 * t + j][1] = lo[t];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      Top2 a = tsm[0][threadIdx.x][0], b = tsm[0][threadIdx.x][1];
+#pragma unroll
+      for (int wv = 1; wv < kT / 64; ++wv) {
+        a = top2_merge(a, tsm[wv][threadIdx.x][0]);
+        b = top2_merge(b, tsm[wv][threadIdx.x][1]);
+      }
+      const long long o = ((long long)blockIdx.x * cout + c0 + threadIdx.x) * 4;
+      *reinterpret_cast<float4*>(topv + o) = make_float4(a.v1, a.v2, b.v1, b.v2);
+      *reinterpret_cast<int4*>(topn + o) = make_int4(a.n1, a.n2, b.n1, b.n2);
+    }
+  }
 }
 
 // ---- MFMA input gradient -----------------------------------------------------------------------------------------
-// dA[rows x cin] = dY[rows x K] . W[K x cin] with dY = alpha*dZ + gammap*Y + betap built on the fly
-// (TOP: dZ[r,k] = gfeat[m,k] iff argmax[m,k] == point), then the ReLU mask and the BatchNorm-backward
+// dA[rows x cin] = dY[rows x K] . W[K x cin] with dY = alpha*dZ + gammap*Y + betap built on the fly,
+// then the ReLU mask and the BatchNorm-backward
 // column sums of layer l-1:  dZprev = dA where bn_prev(Yprev) > 0;  s1 += dZprev, s2 += dZprev * xhat_prev.
+// TOP (last layer, whose Y was never stored; K = cin = 128):  dA = A Q + c0 + S W5  with A = relu(bn_prev(Yprev))
+// staged like the forward operand, w = Q (symmetric 128 x 128, c0 behind it) and S the sparse arg-max gradient:
+// per tile a short extra MFMA chain over the part's CSR entries (erow, ech, eval; tptr = tile offsets) with the
+// one-hot row selector as A operand and the W5 row of the entry's channel as B operand.
 // NT = 32-channel output tiles per wave (register budget: NT * K/2 weight registers).
 // grid = (M*splits, cin/(32*NT)), block 256.
 template <int K, int NT, bool TOP>
 __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
-    const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ gfeat,
-    const int* __restrict__ argmax, const float* __restrict__ coef, const float* __restrict__ w, int cin,
-    const float* __restrict__ y_prev, const float* __restrict__ bn_prev, const float* __restrict__ valids,
-    int N, int splits, float* __restrict__ dz_prev, float* __restrict__ partial) {
+    const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
+    const float* __restrict__ w, int cin, const float* __restrict__ y_prev, const float* __restrict__ bn_prev,
+    const float* __restrict__ valids, int N, int splits, float* __restrict__ dz_prev,
+    float* __restrict__ partial, const int* __restrict__ erow, const int* __restrict__ ech,
+    const float* __restrict__ eval, const int* __restrict__ tptr, const float* __restrict__ w5, int F) {
   constexpr int PC = K < 128 ? K : 128;  // columns of dY staged per phase
   constexpr int PH = K / PC;             // phases
   constexpr int KH = PC / 2;             // K values per lane-half and phase
@@ -547,11 +728,13 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
   float s1[NT], s2[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.0f;
-  const float4* al4_ = reinterpret_cast<const float4*>(coef);
-  const float4* gp4_ = reinterpret_cast<const float4*>(coef + K);
-  const float4* bp4_ = reinterpret_cast<const float4*>(coef + 2 * K);
-  const float4* gf4_ = reinterpret_cast<const float4*>(TOP ? gfeat + (long long)m * K : nullptr);
-  const int4* am4_ = reinterpret_cast<const int4*>(TOP ? argmax + (long long)m * K : nullptr);
+  // TOP: the staged operand is relu(bn_prev(Yprev)), so the three tables are scale, shift (and unused)
+  const float4* al4_ = reinterpret_cast<const float4*>(TOP ? bn_prev : coef);
+  const float4* gp4_ = reinterpret_cast<const float4*>(TOP ? bn_prev + K : coef + K);
+  const float4* bp4_ = reinterpret_cast<const float4*>(TOP ? bn_prev : coef + 2 * K);
+  float c0v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) c0v[t] = TOP ? w[(long long)K * cin + d0 + 32 * t + j] : 0.0f;
   float* lds = stage[wave];
 
   for (int tile = t_begin + wave; tile < t_end; tile += kT / 64) {
@@ -562,8 +745,7 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
 #pragma unroll
     for (int ph = 0; ph < PH; ++ph) {
       // 1. stage dY[32 rows][PC columns of phase ph] = alpha*dZ + gammap*Y + betap  (coalesced row segments)
-      const float4 *al4 = opaque(al4_), *gp4 = opaque(gp4_), *bp4 = opaque(bp4_), *gf4 = opaque(gf4_);
-      const int4* am4 = opaque(am4_);
+      const float4 *al4 = opaque(al4_), *gp4 = opaque(gp4_), *bp4 = opaque(bp4_);
 #pragma unroll 4
       for (int it = 0; it < Q4 / 2; ++it) {
         const int idx = it * 64 + lane, rl = idx / Q4, c4 = idx % Q4, k4 = ph * Q4 + c4;
@@ -571,21 +753,22 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
         const int n = r0 + rl;
         if (n < N) {
           const long long o4 = ((long long)m * N + n) * (K / 4) + k4;
-          const float4 yv = reinterpret_cast<const float4*>(y)[o4];
-          const float4 al = al4[k4], gp = gp4[k4], bp = bp4[k4];
-          float4 zv;
+          const float4 al = al4[k4], gp = gp4[k4];
           if constexpr (TOP) {
-            const float4 g = gf4[k4];
-            const int4 am = am4[k4];
-            zv = make_float4(am.x == n ? g.x : 0.0f, am.y == n ? g.y : 0.0f, am.z == n ? g.z : 0.0f,
-                             am.w == n ? g.w : 0.0f);
+            const float4 yv = reinterpret_cast<const float4*>(y_prev)[o4];
+            v.x = __builtin_fmaxf(__builtin_fmaf(yv.x, al.x, gp.x), 0.0f);
+            v.y = __builtin_fmaxf(__builtin_fmaf(yv.y, al.y, gp.y), 0.0f);
+            v.z = __builtin_fmaxf(__builtin_fmaf(yv.z, al.z, gp.z), 0.0f);
+            v.w = __builtin_fmaxf(__builtin_fmaf(yv.w, al.w, gp.w), 0.0f);
           } else {
-            zv = reinterpret_cast<const float4*>(dz)[o4];
+            const float4 yv = reinterpret_cast<const float4*>(y)[o4];
+            const float4 zv = reinterpret_cast<const float4*>(dz)[o4];
+            const float4 bp = bp4[k4];
+            v.x = __builtin_fmaf(al.x, zv.x, __builtin_fmaf(gp.x, yv.x, bp.x));
+            v.y = __builtin_fmaf(al.y, zv.y, __builtin_fmaf(gp.y, yv.y, bp.y));
+            v.z = __builtin_fmaf(al.z, zv.z, __builtin_fmaf(gp.z, yv.z, bp.z));
+            v.w = __builtin_fmaf(al.w, zv.w, __builtin_fmaf(gp.w, yv.w, bp.w));
           }
-          v.x = __builtin_fmaf(al.x, zv.x, __builtin_fmaf(gp.x, yv.x, bp.x));
-          v.y = __builtin_fmaf(al.y, zv.y, __builtin_fmaf(gp.y, yv.y, bp.y));
-          v.z = __builtin_fmaf(al.z, zv.z, __builtin_fmaf(gp.z, yv.z, bp.z));
-          v.w = __builtin_fmaf(al.w, zv.w, __builtin_fmaf(gp.w, yv.w, bp.w));
         }
         *reinterpret_cast<float4*>(lds + rl * LD + 4 * c4) = v;
       }
@@ -605,6 +788,20 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
       }
       __builtin_amdgcn_wave_barrier();  // the next staging must not overtake these LDS reads
     }
+    if constexpr (TOP) {  // + S W5: the entries whose arg-max row lies in this tile, two per MFMA
+      const int T1 = (N + 31) / 32 + 1;
+      const int pb = tptr[(long long)m * T1 + tile], pe = tptr[(long long)m * T1 + tile + 1];
+      for (int e = pb; e < pe; e += 2) {
+        const int ee = e + h;
+        const bool okk = ee < pe;
+        const long long eo = (long long)m * F + (okk ? ee : pb);
+        const float a = (okk && erow[eo] - r0 == j) ? eval[eo] : 0.0f;
+        const float* wrow = w5 + (long long)ech[eo] * cin + d0 + j;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[32 * t], acc[t], 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int gn = r0 + acc_row(r, h);
@@ -614,7 +811,7 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
         for (int t = 0; t < NT; ++t) {
           const float yp = y_prev[o + 32 * t];
           const float zz = __builtin_fmaf(yp, scp[t], shp[t]);
-          const float d = zz > 0.0f ? acc[t][r] : 0.0f;
+          const float d = zz > 0.0f ? acc[t][r] + c0v[t] : 0.0f;
           dz_prev[o + 32 * t] = d;
           s1[t] += d;
           s2[t] = __builtin_fmaf(d, (yp - mnp[t]) * isp[t], s2[t]);
@@ -653,30 +850,29 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
 // MFMA A operand = dY^T (lane: channel co = c0 + 32t + (l&31), row from the lane's half of the wave's
 // row range), B operand = A (lane: channel ci).  grid = ((cout/64)*(cin/64), M), block 256: the 4 waves
 // split the part's rows and are summed through LDS.
-template <bool TOP>
+// GRAM (last layer, cout == cin): both operands are A = relu(bn_prev(Yprev)), i.e. the part's Gram matrix
+// A^T A, and row `cin` of the output receives the column sums of A (what the weight gradient of the
+// never-stored last layer needs, see pn_top_wgrad_kernel).
+template <bool GRAM>
 __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
-    const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ gfeat,
-    const int* __restrict__ argmax, const float* __restrict__ coef, const float* __restrict__ y_prev,
-    const float* __restrict__ bn_prev, int cout, int cin, const float* __restrict__ valids, int N,
-    float* __restrict__ dwpart) {
+    const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
+    const float* __restrict__ y_prev, const float* __restrict__ bn_prev, int cout, int cin,
+    const float* __restrict__ valids, int N, float* __restrict__ dwpart) {
   __shared__ float sm[kT / 64][4][16][64];  // 64 KiB
+  __shared__ float sb[kT / 64][64];
   const int m = blockIdx.y;
   if (valids[m] == 0.0f) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int cgroups = cin / 64;
   const int c0 = (blockIdx.x / cgroups) * 64, d0 = (blockIdx.x % cgroups) * 64;
-  float al[2], gp[2], bp[2], g[2] = {0.0f, 0.0f};
-  int am[2] = {-1, -1};
+  const long long out_stride = (long long)cout * cin + (GRAM ? cin : 0);
+  float al[2], gp[2], bp[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int co = c0 + 32 * t + j;
-    al[t] = coef[co];
-    gp[t] = coef[cout + co];
-    bp[t] = coef[2 * cout + co];
-    if constexpr (TOP) {
-      g[t] = gfeat[(long long)m * cout + co];
-      am[t] = argmax[(long long)m * cout + co];
-    }
+    al[t] = GRAM ? bn_prev[co] : coef[co];
+    gp[t] = GRAM ? bn_prev[cin + co] : coef[cout + co];
+    bp[t] = GRAM ? 0.0f : coef[2 * cout + co];
   }
   float scp[2], shp[2];  // BatchNorm + ReLU of the previous layer, recomputed on the fly for operand B
 #pragma unroll
@@ -692,6 +888,7 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int u = 0; u < 2; ++u) acc[t][u] = f32x16{0};
+  float bsum[2] = {0.0f, 0.0f};
   // one K step = one point per lane-half; operands of step s+1 are fetched before the 4 MFMAs of step s
   float ny[2], nz[2], nbv[2];
   bool nok;
@@ -702,9 +899,13 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const long long o = r * cout + c0 + 32 * t + j;
-      ny[t] = y[o];
-      if constexpr (TOP) nz[t] = (am[t] == n) ? g[t] : 0.0f;
-      else nz[t] = dz[o];
+      if constexpr (GRAM) {
+        ny[t] = y_prev[o];
+        nz[t] = 0.0f;
+      } else {
+        ny[t] = y[o];
+        nz[t] = dz[o];
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) nbv[u] = y_prev[r * cin + d0 + 32 * u + j];
@@ -714,11 +915,16 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
     float dy[2], b[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const float v = __builtin_fmaf(al[t], nz[t], __builtin_fmaf(gp[t], ny[t], bp[t]));
+      const float v = GRAM ? __builtin_fmaxf(__builtin_fmaf(ny[t], al[t], gp[t]), 0.0f)
+                           : __builtin_fmaf(al[t], nz[t], __builtin_fmaf(gp[t], ny[t], bp[t]));
       dy[t] = nok ? v : 0.0f;
     }
     b[0] = __builtin_fmaxf(__builtin_fmaf(nbv[0], scp[0], shp[0]), 0.0f);
     b[1] = __builtin_fmaxf(__builtin_fmaf(nbv[1], scp[1], shp[1]), 0.0f);
+    if constexpr (GRAM) {
+      bsum[0] += nok ? b[0] : 0.0f;
+      bsum[1] += nok ? b[1] : 0.0f;
+    }
     fetch(s + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -734,6 +940,14 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sm[wave][2 * t + u][r][lane] = acc[t][u][r];
+  if constexpr (GRAM) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) bsum[u] += __shfl_xor(bsum[u], 32, 64);
+    if (h == 0) {
+      sb[wave][j] = bsum[0];
+      sb[wave][32 + j] = bsum[1];
+    }
+  }
   __syncthreads();
   // 4 tiles x 16 regs x 64 lanes = 4096 outputs, 16 per thread; D[i = co][jj = ci]
   for (int e = threadIdx.x; e < 4096; e += kT) {
@@ -743,7 +957,13 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
     for (int wv = 0; wv < kT / 64; ++wv) sum += sm[wv][tu][r][ln];
     const int co = c0 + 32 * (tu >> 1) + acc_row(r, ln >> 5);
     const int ci = d0 + 32 * (tu & 1) + (ln & 31);
-    dwpart[((long long)m * cout + co) * cin + ci] = sum;
+    dwpart[(long long)m * out_stride + (long long)co * cin + ci] = sum;
+  }
+  if (GRAM && c0 == 0 && threadIdx.x < 64) {
+    float t = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < kT / 64; ++wv) t += sb[wv][threadIdx.x];
+    dwpart[(long long)m * out_stride + (long long)cout * cin + d0 + threadIdx.x] = t;
   }
 }
 
@@ -807,15 +1027,29 @@ Dims make_dims(int64_t M, int64_t N, int64_t F) {
 }
 
 struct PnWs {
-  float* Y[6];    // pre-BN outputs, Y[1..5]
+  float* Y[6];    // pre-BN outputs Y[1..4] (the last layer's output is never stored)
   float* dZ[6];   // backward: dZ[1..4]
   float* Wt1;     // transposed first-layer weights [3][64]
   float* bn[6];   // [4][C] scale, shift, mean, invstd
   float* coef[6]; // [3][C] alpha, gammap, betap
   float* partial; // per-block column sums
-  float* dwpart;  // [M][cout*cin]
+  float* dwpart;  // [M][cout*cin]  (last layer: [M][128*128 + 128] Gram matrices + column sums)
   float* count;
   CoopWs coop;    // fp64 group sums + tickets of the cooperative reductions
+  float* topv;    // [M*splits][F][4] top-2 records of the last layer (values)
+  float* ybest;   // [M][F] pre-BatchNorm value at the arg-max
+  float* eval;    // [M][F] CSR values alpha*grad_feat
+  float* q;       // [129][128] Q then c0
+  float* gram;    // [129][128] Gram matrix then column sums of A4
+  int64_t total;
+};
+
+struct PnIws {
+  int* argmax;  // [M][F]
+  int* topn;    // [M*splits][F][4]
+  int* erow;    // [M][F] CSR rows
+  int* ech;     // [M][F] CSR channels
+  int* tptr;    // [M][T+1] CSR tile offsets
   int64_t total;
 };
 
@@ -827,7 +1061,8 @@ PnWs carve(float* base, const Dims& d) {
     p += (n + 3) / 4 * 4;  // keep 16-byte alignment for float4 accesses
     return r;
   };
-  for (int l = 1; l <= 5; ++l) w.Y[l] = take(d.rows * d.C[l]);
+  for (int l = 1; l <= 4; ++l) w.Y[l] = take(d.rows * d.C[l]);
+  w.Y[5] = nullptr;
   for (int l = 1; l <= 4; ++l) w.dZ[l] = take(d.rows * d.C[l]);
   w.Wt1 = take(192);
   for (int l = 1; l <= 5; ++l) w.bn[l] = take(4LL * d.C[l]);
@@ -835,10 +1070,32 @@ PnWs carve(float* base, const Dims& d) {
   const int64_t maxc = d.F > 128 ? d.F : 128;
   const int64_t blocks = d.M * (d.tiles1 > d.splits ? d.tiles1 : d.splits);
   w.partial = take(blocks * maxc * 2);
-  w.dwpart = take(d.M * 128 * maxc);
+  w.dwpart = take(d.M * (128 * 128 + 128));
   w.count = take(4);
   w.coop.ticket = reinterpret_cast<unsigned*>(take(4));
   w.coop.stage = reinterpret_cast<double*>(take(2 * 2 * maxc * ((blocks + kEB - 1) / kEB)));
+  w.topv = take(d.M * d.splits * d.F * 4);
+  w.ybest = take(d.M * d.F);
+  w.eval = take(d.M * d.F);
+  w.q = take(129 * 128);
+  w.gram = take(129 * 128);
+  w.total = p - base;
+  return w;
+}
+
+PnIws carve_int(int32_t* base, const Dims& d) {
+  PnIws w;
+  int32_t* p = base;
+  auto take = [&](int64_t n) {
+    int32_t* r = p;
+    p += (n + 3) / 4 * 4;
+    return r;
+  };
+  w.argmax = take(d.M * d.F);
+  w.topn = take(d.M * d.splits * d.F * 4);
+  w.erow = take(d.M * d.F);
+  w.ech = take(d.M * d.F);
+  w.tptr = take(d.M * ((d.N + 31) / 32 + 1));
   w.total = p - base;
   return w;
 }
@@ -850,18 +1107,16 @@ int check_dims(int64_t M, int64_t N, int64_t F, const char* who) {
   return MPA_OK;
 }
 
-template <bool TOP>
-void launch_dgrad(int K, const float* y, const float* dz, const float* gfeat, const int* argmax,
-                  const float* coef, const float* w, int cin, const float* y_prev, const float* bn_prev,
-                  const float* valids, const Dims& d, float* dz_prev, float* partial, hipStream_t s) {
+void launch_dgrad(int K, const float* y, const float* dz, const float* coef, const float* w, int cin,
+                  const float* y_prev, const float* bn_prev, const float* valids, const Dims& d, float* dz_prev,
+                  float* partial, hipStream_t s) {
   const unsigned gx = (unsigned)(d.M * d.splits);
-#define MPA_DGRAD(KK, NT)                                                                                  \
-  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<KK, NT, TOP>), dim3(gx, cin / (32 * NT)), dim3(kT), 0, s, y, dz, \
-                     gfeat, argmax, coef, w, cin, y_prev, bn_prev, valids, (int)d.N, d.splits, dz_prev,    \
-                     partial)
+#define MPA_DGRAD(KK, NT)                                                                                        \
+  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<KK, NT, false>), dim3(gx, cin / (32 * NT)), dim3(kT), 0, s, y, dz, coef, \
+                     w, cin, y_prev, bn_prev, valids, (int)d.N, d.splits, dz_prev, partial, (const int*)nullptr,  \
+                     (const int*)nullptr, (const float*)nullptr, (const int*)nullptr, (const float*)nullptr, 0)
   if (K == 64) MPA_DGRAD(64, 2);
-  else if (K == 128) MPA_DGRAD(128, 2);
-  else MPA_DGRAD(256, 1);
+  else MPA_DGRAD(128, 2);
 #undef MPA_DGRAD
 }
 
@@ -873,7 +1128,7 @@ extern "C" int mpa_pointnet_workspace(int64_t M, int64_t N, int64_t F, int64_t* 
   MPA_REQUIRE(float_elems && int_elems, "pointnet_workspace: null pointer");
   const Dims d = make_dims(M, N, F);
   *float_elems = carve(nullptr, d).total;
-  *int_elems = M * F;
+  *int_elems = carve_int(nullptr, d).total;
   return MPA_OK;
 }
 
@@ -889,6 +1144,7 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
   hipStream_t s = mpa::as_stream(stream);
   const Dims d = make_dims(M, N, F);
   const PnWs w = carve(float_ws, d);
+  const PnIws iw = carve_int(int_ws, d);
   hipLaunchKernelGGL(pn_transpose_kernel, dim3(1), dim3(192), 0, s, conv_w[0], w.Wt1, 64, 3);
   hipLaunchKernelGGL(pn_count_kernel, dim3(1), dim3(64), 0, s, valids, (int)M, (int)N, w.count, w.coop.ticket);
   for (int l = 1; l <= 5; ++l) {
@@ -900,12 +1156,17 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
     } else {
       splits = d.splits;
       const dim3 grid((unsigned)(M * d.splits), (unsigned)(d.C[l] / 64));
-      if (d.C[l - 1] == 64)
-        hipLaunchKernelGGL(pn_fwd_mfma_kernel<64>, grid, dim3(kT), 0, s, w.Y[l - 1], w.bn[l - 1], conv_w[l - 1],
-                           d.C[l], valids, (int)N, d.splits, w.Y[l], w.partial);
+      if (l == 5)
+        hipLaunchKernelGGL((pn_fwd_mfma_kernel<128, true>), grid, dim3(kT), 0, s, w.Y[4], w.bn[4], conv_w[4], d.C[5],
+                           valids, (int)N, d.splits, (float*)nullptr, w.partial, w.topv, iw.topn);
+      else if (d.C[l - 1] == 64)
+        hipLaunchKernelGGL((pn_fwd_mfma_kernel<64, false>), grid, dim3(kT), 0, s, w.Y[l - 1], w.bn[l - 1],
+                           conv_w[l - 1], d.C[l], valids, (int)N, d.splits, w.Y[l], w.partial, (float*)nullptr,
+                           (int*)nullptr);
       else
-        hipLaunchKernelGGL(pn_fwd_mfma_kernel<128>, grid, dim3(kT), 0, s, w.Y[l - 1], w.bn[l - 1], conv_w[l - 1],
-                           d.C[l], valids, (int)N, d.splits, w.Y[l], w.partial);
+        hipLaunchKernelGGL((pn_fwd_mfma_kernel<128, false>), grid, dim3(kT), 0, s, w.Y[l - 1], w.bn[l - 1],
+                           conv_w[l - 1], d.C[l], valids, (int)N, d.splits, w.Y[l], w.partial, (float*)nullptr,
+                           (int*)nullptr);
     }
     const dim3 cg((unsigned)(d.C[l] / 64));
     if (training)
@@ -916,8 +1177,9 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
       hipLaunchKernelGGL(pn_bn_from_running_kernel, cg, dim3(64), 0, s, d.C[l], bn_w[l - 1], bn_b[l - 1],
                          running_mean[l - 1], running_var[l - 1], eps, w.bn[l]);
   }
-  hipLaunchKernelGGL(pn_maxpool_kernel, dim3((unsigned)(F / 64), (unsigned)M), dim3(kT), 0, s, w.Y[5], w.bn[5],
-                     valids, (int)N, (int)F, feat, int_ws);
+  hipLaunchKernelGGL(pn_top_finalize_kernel, dim3((unsigned)((M * F + 255) / 256)), dim3(256), 0, s, w.topv, iw.topn,
+                     w.bn[5], valids, w.Y[4], w.bn[4], conv_w[4], (int)M, (int)N, (int)F, d.C[4], d.splits, feat,
+                     iw.argmax, w.ybest);
   return mpa::check_launch("pointnet_forward");
 }
 
@@ -933,35 +1195,50 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   hipStream_t s = mpa::as_stream(stream);
   const Dims d = make_dims(M, N, F);
   const PnWs w = carve(float_ws, d);
-  hipLaunchKernelGGL(pn_bwd_top_kernel, dim3((unsigned)(F / 64)), dim3(64 * kSlices), 0, s, grad_feat, int_ws,
-                     w.Y[5], valids, (int)M, (int)N, (int)F, w.count, bn_w[4], w.bn[5], w.coef[5],
-                     grad_bn_w[4], grad_bn_b[4]);
-  for (int l = 5; l >= 1; --l) {
+  const PnIws iw = carve_int(const_cast<int32_t*>(int_ws), d);
+  const int C4 = d.C[4];
+  // ---- last layer: its output was never stored (see the Top2 notes); dY5 = alpha*dZ5 + gammap*Y5 + betap with
+  //      dZ5 sparse and Y5 = A4 W5^T gives  dA4 = A4 Q + c0 + S W5  and  dW5 = S^T A4 + gammap (W5 G) + betap a4sum
+  hipLaunchKernelGGL(pn_bwd_top_kernel, dim3((unsigned)(F / 64), (unsigned)((M + kEB - 1) / kEB)), dim3(64 * kSlices),
+                     0, s, grad_feat, iw.argmax, w.ybest, valids, (int)M, (int)F, w.count, bn_w[4], w.bn[5],
+                     w.coef[5], grad_bn_w[4], grad_bn_b[4], w.coop);
+  hipLaunchKernelGGL(pn_top_csr_kernel, dim3((unsigned)M), dim3((unsigned)F), sizeof(int) * F, s, iw.argmax,
+                     grad_feat, w.coef[5], valids, (int)N, (int)F, iw.erow, iw.ech, w.eval, iw.tptr);
+  hipLaunchKernelGGL(pn_top_q_kernel, dim3((unsigned)(C4 + 1)), dim3((unsigned)C4), 0, s, conv_w[4], w.coef[5], (int)F,
+                     C4, w.q);
+  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 2, true>), dim3((unsigned)(M * d.splits), (unsigned)(C4 / 64)),
+                     dim3(kT), 0, s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w.q, C4,
+                     w.Y[4], w.bn[4], valids, (int)N, d.splits, w.dZ[4], w.partial, iw.erow, iw.ech, w.eval, iw.tptr,
+                     conv_w[4], (int)F);
+  hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(C4 / 64), (unsigned)((M * d.splits + kEB - 1) / kEB)),
+                     dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, d.splits, C4, w.count, bn_w[3], w.bn[4],
+                     w.coef[4], grad_bn_w[3], grad_bn_b[3], w.coop);
+  {
+    const int elems = C4 * C4 + C4;
+    hipLaunchKernelGGL(pn_wgrad_mfma_kernel<true>, dim3((unsigned)((C4 / 64) * (C4 / 64)), (unsigned)M), dim3(kT), 0, s,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w.Y[4], w.bn[4], C4, C4,
+                       valids, (int)N, w.dwpart);
+    hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * kSlices), 0, s,
+                       w.dwpart, valids, (int)M, elems, w.gram);
+    hipLaunchKernelGGL(pn_top_wgrad_kernel, dim3((unsigned)F), dim3(1024), 0, s, grad_feat, iw.argmax, valids, w.Y[4],
+                       w.bn[4], conv_w[4], w.coef[5], w.gram, (int)M, (int)N, (int)F, grad_conv_w[4]);
+  }
+  for (int l = 4; l >= 1; --l) {
     const int cout = d.C[l], cin = d.C[l - 1];
     if (l == 1) {
       hipLaunchKernelGGL(pn_wgrad_first_kernel, dim3(1, (unsigned)M), dim3(kT), 0, s, w.Y[1], w.dZ[1], w.coef[1],
                          points, valids, (int)N, w.dwpart);
     } else {
       const dim3 wg((unsigned)((cout / 64) * (cin / 64)), (unsigned)M);
-      if (l == 5)
-        hipLaunchKernelGGL(pn_wgrad_mfma_kernel<true>, wg, dim3(kT), 0, s, w.Y[l], (const float*)nullptr,
-                           grad_feat, int_ws, w.coef[l], w.Y[l - 1], w.bn[l - 1], cout, cin, valids, (int)N,
-                           w.dwpart);
-      else
-        hipLaunchKernelGGL(pn_wgrad_mfma_kernel<false>, wg, dim3(kT), 0, s, w.Y[l], w.dZ[l],
-                           (const float*)nullptr, (const int*)nullptr, w.coef[l], w.Y[l - 1], w.bn[l - 1], cout,
-                           cin, valids, (int)N, w.dwpart);
+      hipLaunchKernelGGL(pn_wgrad_mfma_kernel<false>, wg, dim3(kT), 0, s, w.Y[l], w.dZ[l], w.coef[l], w.Y[l - 1],
+                         w.bn[l - 1], cout, cin, valids, (int)N, w.dwpart);
     }
     const int elems = cout * cin;
     hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * kSlices), 0, s,
                        w.dwpart, valids, (int)M, elems, grad_conv_w[l - 1]);
     if (l == 1) break;
-    if (l == 5)
-      launch_dgrad<true>(cout, w.Y[l], nullptr, grad_feat, int_ws, w.coef[l], conv_w[l - 1], cin, w.Y[l - 1],
-                         w.bn[l - 1], valids, d, w.dZ[l - 1], w.partial, s);
-    else
-      launch_dgrad<false>(cout, w.Y[l], w.dZ[l], nullptr, nullptr, w.coef[l], conv_w[l - 1], cin, w.Y[l - 1],
-                          w.bn[l - 1], valids, d, w.dZ[l - 1], w.partial, s);
+    launch_dgrad(cout, w.Y[l], w.dZ[l], w.coef[l], conv_w[l - 1], cin, w.Y[l - 1], w.bn[l - 1], valids, d,
+                 w.dZ[l - 1], w.partial, s);
     hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(cin / 64), (unsigned)((M * d.splits + kEB - 1) / kEB)),
                        dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, d.splits, cin, w.count, bn_w[l - 2],
                        w.bn[l - 1], w.coef[l - 1], grad_bn_w[l - 2], grad_bn_b[l - 2], w.coop);

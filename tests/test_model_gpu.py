@@ -81,13 +81,22 @@ def test_pointnet_masked_parts_equal_compacted(cuda_device):
         np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
 
 
-def test_pointnet_matches_torch_ops_at_full_width(cuda_device):
+@pytest.mark.parametrize("mixed_gamma", [False, True])
+def test_pointnet_matches_torch_ops_at_full_width(cuda_device, mixed_gamma):
     """N=1000 (4 row tiles per part, ragged tail), F=256: against the same network written with stock
-    torch ops on the GPU (Conv1d/BatchNorm1d), forward and all parameter gradients."""
+    torch ops on the GPU (Conv1d/BatchNorm1d), forward and all parameter gradients.  mixed_gamma: the last
+    BatchNorm has negative and zero weights too (its max over points then is a min / a constant of the
+    pre-BatchNorm values, which the HIP path never stores)."""
     import torch.nn.functional as Fn
 
     torch.manual_seed(4)
     enc = build_encoder("pointnet", 256).to(cuda_device).train()
+    if mixed_gamma:
+        with torch.no_grad():
+            enc.bn5.weight[::3] *= -1.0
+            enc.bn5.weight[1::7] = 0.0
+            enc.bn5.bias.normal_()
+            enc.bn4.weight[::5] *= -0.5
     x = (torch.randn(9, 1000, 3) * 0.2).to(cuda_device)
     w = torch.randn(9, 256, device=cuda_device)
     ref_params = {k: v.detach().clone().requires_grad_() for k, v in enc.named_parameters()}
