@@ -156,7 +156,8 @@ int mpa_assembly_loss_backward(const float* grad_losses, const float* part_pcs, 
  *   _extract_part_feats        : multi_part_assembly/models/pn_transformer/network.py:59-68
  *                                (boolean-mask compaction + scatter; here: mask in, zeros out)
  * 5 x [1x1 conv (no bias) -> BatchNorm1d -> ReLU (none after the last)], widths 3-64-64-64-128-F,
- * max over the N points of every part.  F must be 64, 128 or 256 (the shipped configs use 128 / 256).
+ * max over the N points of every part.  F must be 64, 128 or 256 (the shipped configs use 128 / 256),
+ * N <= 8192 points per part (the reference samples 1000).
  *
  * points [M,N,3]; valids [M] (1/0): padded parts are skipped everywhere (they do not enter the
  * BatchNorm statistics) and get feat = 0.  conv_w[l] = [C_l, C_{l-1}] row-major (the Conv1d weight

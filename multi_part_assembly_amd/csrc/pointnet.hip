@@ -273,15 +273,12 @@ __device__ __forceinline__ bool top2_before(float y, int n, float y2, int n2) {
 }
 // n is larger than every index pushed before
 __device__ __forceinline__ void top2_push(Top2& t, float y, int n) {
-  if (y > t.v1) {
-    t.v2 = t.v1;
-    t.n2 = t.n1;
-    t.v1 = y;
-    t.n1 = n;
-  } else if (y > t.v2) {
-    t.v2 = y;
-    t.n2 = n;
-  }
+  // selects, not branches: this runs once per accumulator element in the forward GEMM's epilogue
+  const bool g1 = y > t.v1, g2 = y > t.v2;
+  t.v2 = g1 ? t.v1 : (g2 ? y : t.v2);
+  t.n2 = g1 ? t.n1 : (g2 ? n : t.n2);
+  t.v1 = g1 ? y : t.v1;
+  t.n1 = g1 ? n : t.n1;
 }
 __device__ __forceinline__ Top2 top2_merge(const Top2 a, const Top2 b) {
   Top2 r;
@@ -531,23 +528,34 @@ __global__ __launch_bounds__(kT) void pn_wgrad_first_kernel(const float* __restr
 }
 
 // ---- MFMA forward layer ---------------------------------------------------------------------------------------
-// Y[rows x cout] = relu(bn_prev(Yprev))[rows x CIN] . W[cout x CIN]^T, one 64-channel output panel per block.y.
-// grid = (M*splits, cout/64), block 256: wave w walks the 32-row tiles t0+w, t0+w+4, ... of its split.
+// Y[rows x cout] = relu(bn_prev(Yprev))[rows x CIN] . W[cout x CIN]^T.
+// A block owns 64*PANELS output channels and walks block tiles of RB = 32 * (4 / PANELS) rows of its (part, split):
+// wave w computes the 32-row sub-tile w / PANELS for the 64-channel panel w % PANELS, its 64 x CIN weight panel
+// register-resident (K split by lane half, so every fragment is a contiguous run).  The block tile — one
+// contiguous RB*CIN-float run of the point-major input — is fetched by all 256 threads with coalesced 16-byte
+// loads ONE TILE AHEAD (registers), gets the previous layer's BatchNorm + ReLU on its way into a double-buffered
+// LDS panel, and is read back as MFMA fragments: the input crosses HBM/L2 once per block and the global latency
+// hides behind the previous tile's MFMA chain.  grid = (M*splits, cout / (64*PANELS)), block 256.
+// BatchNorm statistics fall out of the accumulator layout (fixed-order reduction, no atomics).
 // TOP (last layer): Y is not stored; the block leaves the per-channel top-2 records of its rows instead.
-template <int CIN, bool TOP>
+template <int CIN, int PANELS, bool TOP>
 __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ bn_prev, const float* __restrict__ w, int cout,
     const float* __restrict__ valids, int N, int splits, float* __restrict__ y_out,
     float* __restrict__ partial, float* __restrict__ topv, int* __restrict__ topn) {
-  constexpr int KH = CIN / 2;   // K values per lane-half
-  constexpr int LD = CIN + 4;   // padded LDS row: conflict-free ds_read_b128 across rows
-  constexpr int Q4 = CIN / 4;   // float4 per row
-  __shared__ __attribute__((aligned(16))) float stage[kT / 64][32 * LD];
+  constexpr int KH = CIN / 2;           // K values per lane-half
+  constexpr int LD = CIN + 4;           // padded LDS row: conflict-free ds_read_b128 across rows
+  constexpr int Q4 = CIN / 4;           // float4 per row
+  constexpr int RT = 4 / PANELS;        // 32-row sub-tiles per block tile
+  constexpr int RB = 32 * RT;           // rows per block tile
+  constexpr int NLD = RB * Q4 / kT;     // float4 per thread and tile
+  __shared__ __attribute__((aligned(16))) float buf[2][RB * LD];
   __shared__ float red[kT / 64][64][2];
   const int m = blockIdx.x / splits, sp = blockIdx.x % splits;
   if (valids[m] == 0.0f) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int c0 = blockIdx.y * 64;
+  const int panel = wave % PANELS, rt = wave / PANELS;
+  const int cb = blockIdx.y * 64 * PANELS, c0 = cb + panel * 64;
   // B fragments (weights): tile t covers output channels c0+32t .. c0+32t+31; lane holds W[c][h*KH + s]
   float bw[2][KH];
 #pragma unroll
@@ -562,35 +570,45 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
       bw[t][4 * v + 3] = q.w;
     }
   }
-  const int T = (N + 31) / 32;
-  const int t_begin = (int)((long long)sp * T / splits), t_end = (int)((long long)(sp + 1) * T / splits);
+  // staging role of this thread: float4 column c4 of rows rl0, rl0 + kT/Q4, ... (kT % Q4 == 0)
+  const int c4 = threadIdx.x % Q4, rl0 = threadIdx.x / Q4;
+  const float4 sc = reinterpret_cast<const float4*>(bn_prev)[c4];
+  const float4 sh = reinterpret_cast<const float4*>(bn_prev + CIN)[c4];
+  const int TB = (N + RB - 1) / RB;
+  const int t_begin = (int)((long long)sp * TB / splits), t_end = (int)((long long)(sp + 1) * TB / splits);
+  float4 raw[NLD];
+  auto fetch = [&](int tile) {
+    const float4* src = reinterpret_cast<const float4*>(in + ((long long)m * N + (long long)tile * RB) * CIN);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int rl = rl0 + i * (kT / Q4);
+      raw[i] = tile * RB + rl < N ? src[i * kT + threadIdx.x] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+  };
+  auto stash = [&](int tile, float* dst) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int rl = rl0 + i * (kT / Q4);
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (tile * RB + rl < N) {  // rows past the part's end enter the MFMA as zeros
+        v.x = __builtin_fmaxf(__builtin_fmaf(raw[i].x, sc.x, sh.x), 0.0f);
+        v.y = __builtin_fmaxf(__builtin_fmaf(raw[i].y, sc.y, sh.y), 0.0f);
+        v.z = __builtin_fmaxf(__builtin_fmaf(raw[i].z, sc.z, sh.z), 0.0f);
+        v.w = __builtin_fmaxf(__builtin_fmaf(raw[i].w, sc.w, sh.w), 0.0f);
+      }
+      *reinterpret_cast<float4*>(dst + rl * LD + 4 * c4) = v;
+    }
+  };
   float s_[2] = {0.0f, 0.0f}, ss_[2] = {0.0f, 0.0f};
   Top2 hi[2] = {top2_empty(), top2_empty()}, lo[2] = {top2_empty(), top2_empty()};
-  const float4* sc4_ = reinterpret_cast<const float4*>(bn_prev);
-  const float4* sh4_ = reinterpret_cast<const float4*>(bn_prev + CIN);
-  float* lds = stage[wave];
-  for (int tile = t_begin + wave; tile < t_end; tile += kT / 64) {
-    const int r0 = tile * 32;
-    // 1. stage the tile: its 32 rows are ONE contiguous 32*CIN-float run -> fully coalesced float4 loads;
-    //    BatchNorm + ReLU of the previous layer applied here, result to LDS.
-    const float4* src = reinterpret_cast<const float4*>(in + ((long long)m * N + r0) * CIN);
-    const float4 *sc4 = opaque(sc4_), *sh4 = opaque(sh4_);
-#pragma unroll 4
-    for (int it = 0; it < Q4 / 2; ++it) {
-      const int idx = it * 64 + lane, rl = idx / Q4, c4 = idx % Q4;
-      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (r0 + rl < N) {
-        const float4 y = src[idx], sc = sc4[c4], sh = sh4[c4];
-        v.x = __builtin_fmaxf(__builtin_fmaf(y.x, sc.x, sh.x), 0.0f);
-        v.y = __builtin_fmaxf(__builtin_fmaf(y.y, sc.y, sh.y), 0.0f);
-        v.z = __builtin_fmaxf(__builtin_fmaf(y.z, sc.z, sh.z), 0.0f);
-        v.w = __builtin_fmaxf(__builtin_fmaf(y.w, sc.w, sh.w), 0.0f);
-      }
-      *reinterpret_cast<float4*>(lds + rl * LD + 4 * c4) = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-    // 2. A fragments from LDS (row j, K half h) and the MFMA chain
-    const float4* frag = reinterpret_cast<const float4*>(lds + j * LD + h * KH);
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    float* cur = buf[(tile - t_begin) & 1];
+    stash(tile, cur);
+    __syncthreads();  // also orders this buffer's reuse: its previous readers finished before the last barrier
+    if (tile + 1 < t_end) fetch(tile + 1);  // in flight during the MFMA chain below
+    const int r0 = tile * RB + rt * 32;
+    const float4* frag = reinterpret_cast<const float4*>(cur + (rt * 32 + j) * LD + h * KH);
     f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll
     for (int v = 0; v < KH / 4; ++v) {
@@ -604,26 +622,25 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[0][4 * v + 3], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[1][4 * v + 3], acc1, 0, 0, 0);
     }
-    __builtin_amdgcn_wave_barrier();  // the next tile's staging must not overtake these LDS reads
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int gn = r0 + acc_row(r, h);
-      if (gn < N) {
-        if constexpr (TOP) {
-          top2_push(hi[0], acc0[r], gn);
-          top2_push(lo[0], -acc0[r], gn);
-          top2_push(hi[1], acc1[r], gn);
-          top2_push(lo[1], -acc1[r], gn);
-        } else {
-          float* dst = y_out + ((long long)m * N + gn) * cout + c0 + j;
-          dst[0] = acc0[r];
-          dst[32] = acc1[r];
-        }
-        s_[0] += acc0[r];
-        ss_[0] = __builtin_fmaf(acc0[r], acc0[r], ss_[0]);
-        s_[1] += acc1[r];
-        ss_[1] = __builtin_fmaf(acc1[r], acc1[r], ss_[1]);
+      if constexpr (TOP) {  // rows past the part's end (all-zero operand rows) must not enter the extrema
+        const float ninf = -__builtin_inff();
+        const bool ok = gn < N;
+        top2_push(hi[0], ok ? acc0[r] : ninf, gn);
+        top2_push(lo[0], ok ? -acc0[r] : ninf, gn);
+        top2_push(hi[1], ok ? acc1[r] : ninf, gn);
+        top2_push(lo[1], ok ? -acc1[r] : ninf, gn);
+      } else if (gn < N) {
+        float* dst = y_out + ((long long)m * N + gn) * cout + c0 + j;
+        dst[0] = acc0[r];
+        dst[32] = acc1[r];
       }
+      s_[0] += acc0[r];  // zero operand rows give exactly 0: no mask needed for the statistics
+      ss_[0] = __builtin_fmaf(acc0[r], acc0[r], ss_[0]);
+      s_[1] += acc1[r];
+      ss_[1] = __builtin_fmaf(acc1[r], acc1[r], ss_[1]);
     }
   }
 #pragma unroll
@@ -638,14 +655,15 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
     red[wave][32 + j][1] = ss_[1];
   }
   __syncthreads();
-  if (threadIdx.x < 64) {
+  if (threadIdx.x < 64 * PANELS) {  // thread -> (panel, channel); the RT waves of the panel in fixed order
+    const int pn = threadIdx.x >> 6, ch = threadIdx.x & 63;
     float t0 = 0.0f, t1 = 0.0f;
 #pragma unroll
-    for (int wv = 0; wv < kT / 64; ++wv) {
-      t0 += red[wv][threadIdx.x][0];
-      t1 += red[wv][threadIdx.x][1];
+    for (int q = 0; q < RT; ++q) {
+      t0 += red[q * PANELS + pn][ch][0];
+      t1 += red[q * PANELS + pn][ch][1];
     }
-    const long long o = ((long long)blockIdx.x * cout + c0 + threadIdx.x) * 2;
+    const long long o = ((long long)blockIdx.x * cout + cb + threadIdx.x) * 2;
     partial[o] = t0;
     partial[o + 1] = t1;
   }
@@ -664,14 +682,15 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
       }
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
-      Top2 a = tsm[0][threadIdx.x][0], b = tsm[0][threadIdx.x][1];
+    if (threadIdx.x < 64 * PANELS) {
+      const int pn = threadIdx.x >> 6, ch = threadIdx.x & 63;
+      Top2 a = tsm[pn][ch][0], b = tsm[pn][ch][1];
 #pragma unroll
-      for (int wv = 1; wv < kT / 64; ++wv) {
-        a = top2_merge(a, tsm[wv][threadIdx.x][0]);
-        b = top2_merge(b, tsm[wv][threadIdx.x][1]);
+      for (int q = 1; q < RT; ++q) {
+        a = top2_merge(a, tsm[q * PANELS + pn][ch][0]);
+        b = top2_merge(b, tsm[q * PANELS + pn][ch][1]);
       }
-      const long long o = ((long long)blockIdx.x * cout + c0 + threadIdx.x) * 4;
+      const long long o = ((long long)blockIdx.x * cout + cb + threadIdx.x) * 4;
       *reinterpret_cast<float4*>(topv + o) = make_float4(a.v1, a.v2, b.v1, b.v2);
       *reinterpret_cast<int4*>(topn + o) = make_int4(a.n1, a.n2, b.n1, b.n2);
     }
@@ -736,12 +755,43 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
 #pragma unroll
   for (int t = 0; t < NT; ++t) c0v[t] = TOP ? w[(long long)K * cin + d0 + 32 * t + j] : 0.0f;
   float* lds = stage[wave];
+  // TOP: the part's CSR (<= 256 entries, <= 257 tile offsets) lives in LDS so that the per-tile sparse chain has
+  // a single level of global loads (the W5 rows), issued before the tile's main MFMA chain
+  constexpr int kMaxF = 256, kMaxT1 = 260, kSP = 6;
+  __shared__ int s_row[TOP ? kMaxF : 1], s_ch[TOP ? kMaxF : 1], s_ptr[TOP ? kMaxT1 : 1];
+  __shared__ float s_val[TOP ? kMaxF : 1];
+  if constexpr (TOP) {
+    const int T1 = T + 1;
+    for (int i = threadIdx.x; i < F; i += kT) {
+      s_row[i] = erow[(long long)m * F + i];  // slots past the part's entry count hold garbage, never addressed
+      s_ch[i] = ech[(long long)m * F + i];
+      s_val[i] = eval[(long long)m * F + i];
+    }
+    for (int i = threadIdx.x; i < T1 && i < kMaxT1; i += kT) s_ptr[i] = tptr[(long long)m * T1 + i];
+    __syncthreads();
+  }
 
   for (int tile = t_begin + wave; tile < t_end; tile += kT / 64) {
     const int r0 = tile * 32;
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+    float sa[kSP], sbv[kSP][NT];  // TOP: the first kSP sparse steps (2 entries each), operands fetched now
+    int pb = 0, pe = 0;
+    if constexpr (TOP) {
+      pb = s_ptr[tile];
+      pe = s_ptr[tile + 1];
+#pragma unroll
+      for (int q = 0; q < kSP; ++q) {
+        const int ee = pb + 2 * q + h;
+        const bool okk = ee < pe;
+        const int es = okk ? ee : 0;
+        sa[q] = (okk && s_row[es] - r0 == j) ? s_val[es] : 0.0f;
+        const float* wrow = w5 + (long long)(okk ? s_ch[es] : 0) * cin + d0 + j;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sbv[q][t] = wrow[32 * t];
+      }
+    }
 #pragma unroll
     for (int ph = 0; ph < PH; ++ph) {
       // 1. stage dY[32 rows][PC columns of phase ph] = alpha*dZ + gammap*Y + betap  (coalesced row segments)
@@ -789,14 +839,19 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
       __builtin_amdgcn_wave_barrier();  // the next staging must not overtake these LDS reads
     }
     if constexpr (TOP) {  // + S W5: the entries whose arg-max row lies in this tile, two per MFMA
-      const int T1 = (N + 31) / 32 + 1;
-      const int pb = tptr[(long long)m * T1 + tile], pe = tptr[(long long)m * T1 + tile + 1];
-      for (int e = pb; e < pe; e += 2) {
+#pragma unroll
+      for (int q = 0; q < kSP; ++q) {
+        if (pb + 2 * q < pe) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[q], sbv[q][t], acc[t], 0, 0, 0);
+        }
+      }
+      for (int e = pb + 2 * kSP; e < pe; e += 2) {  // unusually crowded tile
         const int ee = e + h;
         const bool okk = ee < pe;
-        const long long eo = (long long)m * F + (okk ? ee : pb);
-        const float a = (okk && erow[eo] - r0 == j) ? eval[eo] : 0.0f;
-        const float* wrow = w5 + (long long)ech[eo] * cin + d0 + j;
+        const int es = okk ? ee : 0;
+        const float a = (okk && s_row[es] - r0 == j) ? s_val[es] : 0.0f;
+        const float* wrow = w5 + (long long)(okk ? s_ch[es] : 0) * cin + d0 + j;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[32 * t], acc[t], 0, 0, 0);
@@ -1103,7 +1158,7 @@ PnIws carve_int(int32_t* base, const Dims& d) {
 int check_dims(int64_t M, int64_t N, int64_t F, const char* who) {
   MPA_REQUIRE(M >= 0 && N >= 1 && F >= 64, "%s: bad sizes", who);
   MPA_REQUIRE(F == 64 || F == 128 || F == 256, "%s: feat_dim must be 64, 128 or 256", who);
-  MPA_REQUIRE(M <= 32767 && N < (1 << 24), "%s: too many parts / points", who);
+  MPA_REQUIRE(M <= 32767 && N <= 8192, "%s: at most 32767 parts of at most 8192 points", who);
   return MPA_OK;
 }
 
@@ -1155,18 +1210,20 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
                          w.Wt1, valids, (int)N, w.Y[1], w.partial);
     } else {
       splits = d.splits;
-      const dim3 grid((unsigned)(M * d.splits), (unsigned)(d.C[l] / 64));
-      if (l == 5)
-        hipLaunchKernelGGL((pn_fwd_mfma_kernel<128, true>), grid, dim3(kT), 0, s, w.Y[4], w.bn[4], conv_w[4], d.C[5],
-                           valids, (int)N, d.splits, (float*)nullptr, w.partial, w.topv, iw.topn);
-      else if (d.C[l - 1] == 64)
-        hipLaunchKernelGGL((pn_fwd_mfma_kernel<64, false>), grid, dim3(kT), 0, s, w.Y[l - 1], w.bn[l - 1],
-                           conv_w[l - 1], d.C[l], valids, (int)N, d.splits, w.Y[l], w.partial, (float*)nullptr,
-                           (int*)nullptr);
-      else
-        hipLaunchKernelGGL((pn_fwd_mfma_kernel<128, false>), grid, dim3(kT), 0, s, w.Y[l - 1], w.bn[l - 1],
-                           conv_w[l - 1], d.C[l], valids, (int)N, d.splits, w.Y[l], w.partial, (float*)nullptr,
-                           (int*)nullptr);
+      const unsigned gx = (unsigned)(M * d.splits);
+#define MPA_FWD(CI, PN, TP, IN, YO, TV, TN)                                                                          \
+  hipLaunchKernelGGL((pn_fwd_mfma_kernel<CI, PN, TP>), dim3(gx, (unsigned)(d.C[l] / (64 * PN))), dim3(kT), 0, s, IN, \
+                     w.bn[l - 1], conv_w[l - 1], d.C[l], valids, (int)N, d.splits, YO, w.partial, TV, TN)
+      if (l == 5) {
+        if (F == 256) MPA_FWD(128, 4, true, w.Y[4], (float*)nullptr, w.topv, iw.topn);
+        else if (F == 128) MPA_FWD(128, 2, true, w.Y[4], (float*)nullptr, w.topv, iw.topn);
+        else MPA_FWD(128, 1, true, w.Y[4], (float*)nullptr, w.topv, iw.topn);
+      } else if (d.C[l] == 128) {
+        MPA_FWD(64, 2, false, w.Y[l - 1], w.Y[l], (float*)nullptr, (int*)nullptr);
+      } else {
+        MPA_FWD(64, 1, false, w.Y[l - 1], w.Y[l], (float*)nullptr, (int*)nullptr);
+      }
+#undef MPA_FWD
     }
     const dim3 cg((unsigned)(d.C[l] / 64));
     if (training)
