@@ -699,41 +699,46 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
 
 // ---- MFMA input gradient -----------------------------------------------------------------------------------------
 // dA[rows x cin] = dY[rows x K] . W[K x cin] with dY = alpha*dZ + gammap*Y + betap built on the fly,
-// then the ReLU mask and the BatchNorm-backward
-// column sums of layer l-1:  dZprev = dA where bn_prev(Yprev) > 0;  s1 += dZprev, s2 += dZprev * xhat_prev.
+// then the ReLU mask and the BatchNorm-backward column sums of layer l-1:
+//   dZprev = dA where bn_prev(Yprev) > 0;  s1 += dZprev, s2 += dZprev * xhat_prev.
+// Same block organisation as the forward GEMM: a block owns 32*NT*PANELS output channels and walks block tiles of
+// RB = 32 * (4 / PANELS) rows; the dY tile is built by all 256 threads from Y and dZ fetched ONE TILE AHEAD with
+// coalesced 16-byte loads, staged in a double-buffered LDS panel and read back as MFMA fragments; wave w computes
+// the 32-row sub-tile w / PANELS for the channel panel w % PANELS with its K x 32*NT weight slab in registers.
+// The Yprev values of the epilogue are requested before the MFMA chain.
 // TOP (last layer, whose Y was never stored; K = cin = 128):  dA = A Q + c0 + S W5  with A = relu(bn_prev(Yprev))
 // staged like the forward operand, w = Q (symmetric 128 x 128, c0 behind it) and S the sparse arg-max gradient:
 // per tile a short extra MFMA chain over the part's CSR entries (erow, ech, eval; tptr = tile offsets) with the
 // one-hot row selector as A operand and the W5 row of the entry's channel as B operand.
-// NT = 32-channel output tiles per wave (register budget: NT * K/2 weight registers).
-// grid = (M*splits, cin/(32*NT)), block 256.
-template <int K, int NT, bool TOP>
+// grid = (M*splits, cin / (32*NT*PANELS)), block 256.
+template <int K, int NT, int PANELS, bool TOP>
 __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
     const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
     const float* __restrict__ w, int cin, const float* __restrict__ y_prev, const float* __restrict__ bn_prev,
     const float* __restrict__ valids, int N, int splits, float* __restrict__ dz_prev,
     float* __restrict__ partial, const int* __restrict__ erow, const int* __restrict__ ech,
     const float* __restrict__ eval, const int* __restrict__ tptr, const float* __restrict__ w5, int F) {
-  constexpr int PC = K < 128 ? K : 128;  // columns of dY staged per phase
-  constexpr int PH = K / PC;             // phases
-  constexpr int KH = PC / 2;             // K values per lane-half and phase
-  constexpr int LD = PC + 4;
-  constexpr int Q4 = PC / 4;
-  __shared__ __attribute__((aligned(16))) float stage[kT / 64][32 * LD];
-  __shared__ float red[kT / 64][32 * NT][2];
+  constexpr int KH = K / 2;            // K values per lane-half
+  constexpr int LD = K + 4;
+  constexpr int Q4 = K / 4;
+  constexpr int RT = 4 / PANELS;       // 32-row sub-tiles per block tile
+  constexpr int RB = 32 * RT;          // rows per block tile
+  constexpr int NLD = RB * Q4 / kT;    // float4 per thread, tensor and tile
+  constexpr int CW = 32 * NT;          // output channels per wave
+  __shared__ __attribute__((aligned(16))) float buf[2][RB * LD];
+  __shared__ float red[kT / 64][CW][2];
   const int m = blockIdx.x / splits, sp = blockIdx.x % splits;
   if (valids[m] == 0.0f) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int d0 = blockIdx.y * 32 * NT;
-  // B fragments: phase p, lane-half h, step s  <->  k = p*PC + h*KH + s;  bw = W[k][d0 + 32t + j]
-  float bw[NT][PH][KH];
+  const int panel = wave % PANELS, rt = wave / PANELS;
+  const int db = blockIdx.y * CW * PANELS, d0 = db + panel * CW;
+  // B fragments: lane-half h, step s  <->  k = h*KH + s;  bw = W[k][d0 + 32t + j]
+  float bw[NT][KH];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int ph = 0; ph < PH; ++ph)
-#pragma unroll
-      for (int s = 0; s < KH; ++s) bw[t][ph][s] = w[(long long)(ph * PC + h * KH + s) * cin + d0 + 32 * t + j];
-  float scp[NT], shp[NT], mnp[NT], isp[NT];
+    for (int s = 0; s < KH; ++s) bw[t][s] = w[(long long)(h * KH + s) * cin + d0 + 32 * t + j];
+  float scp[NT], shp[NT], mnp[NT], isp[NT], c0v[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int ci = d0 + 32 * t + j;
@@ -741,46 +746,93 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
     shp[t] = bn_prev[cin + ci];
     mnp[t] = bn_prev[2 * cin + ci];
     isp[t] = bn_prev[3 * cin + ci];
+    c0v[t] = TOP ? w[(long long)K * cin + ci] : 0.0f;
   }
-  const int T = (N + 31) / 32;
-  const int t_begin = (int)((long long)sp * T / splits), t_end = (int)((long long)(sp + 1) * T / splits);
-  float s1[NT], s2[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.0f;
-  // TOP: the staged operand is relu(bn_prev(Yprev)), so the three tables are scale, shift (and unused)
-  const float4* al4_ = reinterpret_cast<const float4*>(TOP ? bn_prev : coef);
-  const float4* gp4_ = reinterpret_cast<const float4*>(TOP ? bn_prev + K : coef + K);
-  const float4* bp4_ = reinterpret_cast<const float4*>(TOP ? bn_prev : coef + 2 * K);
-  float c0v[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) c0v[t] = TOP ? w[(long long)K * cin + d0 + 32 * t + j] : 0.0f;
-  float* lds = stage[wave];
+  // staging role of this thread: float4 column c4 of rows rl0, rl0 + kT/Q4, ...; its per-column tables.
+  // TOP: the staged operand is relu(bn_prev(Yprev)), tables = scale, shift; else alpha, gammap, betap.
+  const int c4 = threadIdx.x % Q4, rl0 = threadIdx.x / Q4;
+  const float4 ta = reinterpret_cast<const float4*>(TOP ? bn_prev : coef)[c4];
+  const float4 tb = reinterpret_cast<const float4*>(TOP ? bn_prev + K : coef + K)[c4];
+  const float4 tc = TOP ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : reinterpret_cast<const float4*>(coef + 2 * K)[c4];
+  const int TB = (N + RB - 1) / RB;
+  const int t_begin = (int)((long long)sp * TB / splits), t_end = (int)((long long)(sp + 1) * TB / splits);
   // TOP: the part's CSR (<= 256 entries, <= 257 tile offsets) lives in LDS so that the per-tile sparse chain has
   // a single level of global loads (the W5 rows), issued before the tile's main MFMA chain
   constexpr int kMaxF = 256, kMaxT1 = 260, kSP = 6;
   __shared__ int s_row[TOP ? kMaxF : 1], s_ch[TOP ? kMaxF : 1], s_ptr[TOP ? kMaxT1 : 1];
   __shared__ float s_val[TOP ? kMaxF : 1];
   if constexpr (TOP) {
-    const int T1 = T + 1;
+    const int T1 = (N + 31) / 32 + 1;
     for (int i = threadIdx.x; i < F; i += kT) {
       s_row[i] = erow[(long long)m * F + i];  // slots past the part's entry count hold garbage, never addressed
       s_ch[i] = ech[(long long)m * F + i];
       s_val[i] = eval[(long long)m * F + i];
     }
     for (int i = threadIdx.x; i < T1 && i < kMaxT1; i += kT) s_ptr[i] = tptr[(long long)m * T1 + i];
-    __syncthreads();
+    // visible after the first barrier of the tile loop
   }
-
-  for (int tile = t_begin + wave; tile < t_end; tile += kT / 64) {
-    const int r0 = tile * 32;
-    f32x16 acc[NT];
+  float4 ry[NLD], rz[TOP ? 1 : NLD];
+  auto fetch = [&](int tile) {
+    const long long base = ((long long)m * N + (long long)tile * RB) * Q4;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
-    float sa[kSP], sbv[kSP][NT];  // TOP: the first kSP sparse steps (2 entries each), operands fetched now
+    for (int i = 0; i < NLD; ++i) {
+      const int rl = rl0 + i * (kT / Q4);
+      const bool ok = tile * RB + rl < N;
+      const long long o = base + i * kT + threadIdx.x;
+      if constexpr (TOP) {
+        ry[i] = ok ? reinterpret_cast<const float4*>(y_prev)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      } else {
+        ry[i] = ok ? reinterpret_cast<const float4*>(y)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        rz[i] = ok ? reinterpret_cast<const float4*>(dz)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+    }
+  };
+  auto stash = [&](int tile, float* dst) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int rl = rl0 + i * (kT / Q4);
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (tile * RB + rl < N) {  // rows past the part's end enter the MFMA as zeros
+        if constexpr (TOP) {
+          v.x = __builtin_fmaxf(__builtin_fmaf(ry[i].x, ta.x, tb.x), 0.0f);
+          v.y = __builtin_fmaxf(__builtin_fmaf(ry[i].y, ta.y, tb.y), 0.0f);
+          v.z = __builtin_fmaxf(__builtin_fmaf(ry[i].z, ta.z, tb.z), 0.0f);
+          v.w = __builtin_fmaxf(__builtin_fmaf(ry[i].w, ta.w, tb.w), 0.0f);
+        } else {
+          v.x = __builtin_fmaf(ta.x, rz[i].x, __builtin_fmaf(tb.x, ry[i].x, tc.x));
+          v.y = __builtin_fmaf(ta.y, rz[i].y, __builtin_fmaf(tb.y, ry[i].y, tc.y));
+          v.z = __builtin_fmaf(ta.z, rz[i].z, __builtin_fmaf(tb.z, ry[i].z, tc.z));
+          v.w = __builtin_fmaf(ta.w, rz[i].w, __builtin_fmaf(tb.w, ry[i].w, tc.w));
+        }
+      }
+      *reinterpret_cast<float4*>(dst + rl * LD + 4 * c4) = v;
+    }
+  };
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.0f;
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    float* cur = buf[(tile - t_begin) & 1];
+    stash(tile, cur);
+    __syncthreads();  // also orders this buffer's reuse: its previous readers finished before the last barrier
+    if (tile + 1 < t_end) fetch(tile + 1);  // in flight during the MFMA chain below
+    const int r0 = tile * RB + rt * 32;
+    // Yprev of the epilogue (row of register r, columns d0 + 32t + j); rows past the end read row N-1, unused
+    float yp[NT][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gn = r0 + acc_row(r, h);
+      const long long o = ((long long)m * N + (gn < N ? gn : N - 1)) * cin + d0 + j;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) yp[t][r] = y_prev[o + 32 * t];
+    }
+    float sa[TOP ? kSP : 1], sbv[TOP ? kSP : 1][NT];  // TOP: the first kSP sparse steps (2 entries each)
     int pb = 0, pe = 0;
     if constexpr (TOP) {
-      pb = s_ptr[tile];
-      pe = s_ptr[tile + 1];
+      const int st = r0 >> 5;  // this wave's 32-row tile
+      pb = s_ptr[st];
+      pe = s_ptr[st + 1];
 #pragma unroll
       for (int q = 0; q < kSP; ++q) {
         const int ee = pb + 2 * q + h;
@@ -792,51 +844,20 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
         for (int t = 0; t < NT; ++t) sbv[q][t] = wrow[32 * t];
       }
     }
+    const float4* frag = reinterpret_cast<const float4*>(cur + (rt * 32 + j) * LD + h * KH);
+    f32x16 acc[NT];
 #pragma unroll
-    for (int ph = 0; ph < PH; ++ph) {
-      // 1. stage dY[32 rows][PC columns of phase ph] = alpha*dZ + gammap*Y + betap  (coalesced row segments)
-      const float4 *al4 = opaque(al4_), *gp4 = opaque(gp4_), *bp4 = opaque(bp4_);
-#pragma unroll 4
-      for (int it = 0; it < Q4 / 2; ++it) {
-        const int idx = it * 64 + lane, rl = idx / Q4, c4 = idx % Q4, k4 = ph * Q4 + c4;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const int n = r0 + rl;
-        if (n < N) {
-          const long long o4 = ((long long)m * N + n) * (K / 4) + k4;
-          const float4 al = al4[k4], gp = gp4[k4];
-          if constexpr (TOP) {
-            const float4 yv = reinterpret_cast<const float4*>(y_prev)[o4];
-            v.x = __builtin_fmaxf(__builtin_fmaf(yv.x, al.x, gp.x), 0.0f);
-            v.y = __builtin_fmaxf(__builtin_fmaf(yv.y, al.y, gp.y), 0.0f);
-            v.z = __builtin_fmaxf(__builtin_fmaf(yv.z, al.z, gp.z), 0.0f);
-            v.w = __builtin_fmaxf(__builtin_fmaf(yv.w, al.w, gp.w), 0.0f);
-          } else {
-            const float4 yv = reinterpret_cast<const float4*>(y)[o4];
-            const float4 zv = reinterpret_cast<const float4*>(dz)[o4];
-            const float4 bp = bp4[k4];
-            v.x = __builtin_fmaf(al.x, zv.x, __builtin_fmaf(gp.x, yv.x, bp.x));
-            v.y = __builtin_fmaf(al.y, zv.y, __builtin_fmaf(gp.y, yv.y, bp.y));
-            v.z = __builtin_fmaf(al.z, zv.z, __builtin_fmaf(gp.z, yv.z, bp.z));
-            v.w = __builtin_fmaf(al.w, zv.w, __builtin_fmaf(gp.w, yv.w, bp.w));
-          }
-        }
-        *reinterpret_cast<float4*>(lds + rl * LD + 4 * c4) = v;
+    for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+#pragma unroll
+    for (int v = 0; v < KH / 4; ++v) {
+      const float4 a = frag[v];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw[t][4 * v + 0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw[t][4 * v + 1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw[t][4 * v + 2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[t][4 * v + 3], acc[t], 0, 0, 0);
       }
-      __builtin_amdgcn_wave_barrier();
-      // 2. fragments (row j, lane-half h) and the MFMA chain of this phase
-      const float4* frag = reinterpret_cast<const float4*>(lds + j * LD + h * KH);
-#pragma unroll
-      for (int v = 0; v < KH / 4; ++v) {
-        const float4 a = frag[v];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw[t][ph][4 * v + 0], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw[t][ph][4 * v + 1], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw[t][ph][4 * v + 2], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[t][ph][4 * v + 3], acc[t], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();  // the next staging must not overtake these LDS reads
     }
     if constexpr (TOP) {  // + S W5: the entries whose arg-max row lies in this tile, two per MFMA
 #pragma unroll
@@ -857,20 +878,19 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[32 * t], acc[t], 0, 0, 0);
       }
     }
+    const bool full = r0 + 32 <= N;  // wave-uniform: only a part's last tile is ragged
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int gn = r0 + acc_row(r, h);
-      if (gn < N) {
-        const long long o = ((long long)m * N + gn) * cin + d0 + j;
+      const bool ok = full || gn < N;
+      const long long o = ((long long)m * N + gn) * cin + d0 + j;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const float yp = y_prev[o + 32 * t];
-          const float zz = __builtin_fmaf(yp, scp[t], shp[t]);
-          const float d = zz > 0.0f ? acc[t][r] + c0v[t] : 0.0f;
-          dz_prev[o + 32 * t] = d;
-          s1[t] += d;
-          s2[t] = __builtin_fmaf(d, (yp - mnp[t]) * isp[t], s2[t]);
-        }
+      for (int t = 0; t < NT; ++t) {
+        const float zz = __builtin_fmaf(yp[t][r], scp[t], shp[t]);
+        const float d = (ok && zz > 0.0f) ? acc[t][r] + c0v[t] : 0.0f;
+        if (ok) dz_prev[o + 32 * t] = d;
+        s1[t] += d;
+        s2[t] = __builtin_fmaf(d, (yp[t][r] - mnp[t]) * isp[t], s2[t]);
       }
     }
   }
@@ -887,14 +907,15 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
     }
   }
   __syncthreads();
-  if (threadIdx.x < 32 * NT) {
+  if (threadIdx.x < CW * PANELS) {  // thread -> (panel, channel); the RT waves of the panel in fixed order
+    const int pn = threadIdx.x / CW, ch = threadIdx.x % CW;
     float t0 = 0.0f, t1 = 0.0f;
 #pragma unroll
-    for (int wv = 0; wv < kT / 64; ++wv) {
-      t0 += red[wv][threadIdx.x][0];
-      t1 += red[wv][threadIdx.x][1];
+    for (int q = 0; q < RT; ++q) {
+      t0 += red[q * PANELS + pn][ch][0];
+      t1 += red[q * PANELS + pn][ch][1];
     }
-    const long long o = ((long long)blockIdx.x * cin + d0 + threadIdx.x) * 2;
+    const long long o = ((long long)blockIdx.x * cin + db + threadIdx.x) * 2;
     partial[o] = t0;
     partial[o + 1] = t1;
   }
@@ -1166,12 +1187,13 @@ void launch_dgrad(int K, const float* y, const float* dz, const float* coef, con
                   const float* y_prev, const float* bn_prev, const float* valids, const Dims& d, float* dz_prev,
                   float* partial, hipStream_t s) {
   const unsigned gx = (unsigned)(d.M * d.splits);
-#define MPA_DGRAD(KK, NT)                                                                                        \
-  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<KK, NT, false>), dim3(gx, cin / (32 * NT)), dim3(kT), 0, s, y, dz, coef, \
-                     w, cin, y_prev, bn_prev, valids, (int)d.N, d.splits, dz_prev, partial, (const int*)nullptr,  \
-                     (const int*)nullptr, (const float*)nullptr, (const int*)nullptr, (const float*)nullptr, 0)
-  if (K == 64) MPA_DGRAD(64, 2);
-  else MPA_DGRAD(128, 2);
+#define MPA_DGRAD(KK, NT, PN)                                                                                      \
+  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<KK, NT, PN, false>), dim3(gx, cin / (32 * NT * PN)), dim3(kT), 0, s, y, \
+                     dz, coef, w, cin, y_prev, bn_prev, valids, (int)d.N, d.splits, dz_prev, partial,              \
+                     (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, (const int*)nullptr,         \
+                     (const float*)nullptr, 0)
+  if (K == 64) MPA_DGRAD(64, 2, 1);   // 64 -> 64: one 64-channel panel, 128-row block tiles
+  else MPA_DGRAD(128, 1, 2);          // 128 -> 64: two 32-channel panels, 64-row block tiles
 #undef MPA_DGRAD
 }
 
@@ -1263,7 +1285,7 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
                      grad_feat, w.coef[5], valids, (int)N, (int)F, iw.erow, iw.ech, w.eval, iw.tptr);
   hipLaunchKernelGGL(pn_top_q_kernel, dim3((unsigned)(C4 + 1)), dim3((unsigned)C4), 0, s, conv_w[4], w.coef[5], (int)F,
                      C4, w.q);
-  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 2, true>), dim3((unsigned)(M * d.splits), (unsigned)(C4 / 64)),
+  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 2, 2, true>), dim3((unsigned)(M * d.splits), (unsigned)(C4 / 128)),
                      dim3(kT), 0, s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w.q, C4,
                      w.Y[4], w.bn[4], valids, (int)N, d.splits, w.dZ[4], w.partial, iw.erow, iw.ech, w.eval, iw.tptr,
                      conv_w[4], (int)F);
