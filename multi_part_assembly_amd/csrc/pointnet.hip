@@ -491,42 +491,6 @@ __global__ __launch_bounds__(kT) void pn_fwd_first_kernel(const float* __restric
   }
 }
 
-// first-layer weight gradient: dWpart[m][co][0..2] = sum_n dY1[r,co] * pts[r,0..2]; lane = co.
-// grid = (1, M), block 256: the 4 waves split the rows.
-__global__ __launch_bounds__(kT) void pn_wgrad_first_kernel(const float* __restrict__ y,
-                                                            const float* __restrict__ dz,
-                                                            const float* __restrict__ coef,
-                                                            const float* __restrict__ pts,
-                                                            const float* __restrict__ valids, int N,
-                                                            float* __restrict__ dwpart) {
-  __shared__ float red[kT / 64][3][64];
-  const int m = blockIdx.y;
-  if (valids[m] == 0.0f) return;
-  const int wave = threadIdx.x >> 6, co = threadIdx.x & 63;
-  const float al = coef[co], gp = coef[64 + co], bp = coef[128 + co];
-  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-  const int per = (N + kT / 64 - 1) / (kT / 64);
-  const int nb = wave * per, ne = nb + per < N ? nb + per : N;
-  for (int n = nb; n < ne; ++n) {
-    const long long r = (long long)m * N + n;
-    const float dy = __builtin_fmaf(al, dz[r * 64 + co], __builtin_fmaf(gp, y[r * 64 + co], bp));
-    a0 = __builtin_fmaf(dy, pts[r * 3 + 0], a0);  // pts[r]: wave-uniform -> scalar loads
-    a1 = __builtin_fmaf(dy, pts[r * 3 + 1], a1);
-    a2 = __builtin_fmaf(dy, pts[r * 3 + 2], a2);
-  }
-  red[wave][0][co] = a0;
-  red[wave][1][co] = a1;
-  red[wave][2][co] = a2;
-  __syncthreads();
-  if (threadIdx.x < 192) {
-    const int c = threadIdx.x / 3, k = threadIdx.x % 3;
-    float s = 0.0f;
-#pragma unroll
-    for (int w = 0; w < kT / 64; ++w) s += red[w][k][c];
-    dwpart[(long long)m * 192 + threadIdx.x] = s;
-  }
-}
-
 // ---- MFMA forward layer ---------------------------------------------------------------------------------------
 // Y[rows x cout] = relu(bn_prev(Yprev))[rows x CIN] . W[cout x CIN]^T.
 // A block owns 64*PANELS output channels and walks block tiles of RB = 32 * (4 / PANELS) rows of its (part, split):
@@ -922,128 +886,175 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
 }
 
 // ---- MFMA weight gradient --------------------------------------------------------------------------------------
-// dWpart[m][co][ci] = sum_n dY[r,co] * A[r,ci]  (GEMM with K = the part's points), 64x64 per block.x.
-// MFMA A operand = dY^T (lane: channel co = c0 + 32t + (l&31), row from the lane's half of the wave's
-// row range), B operand = A (lane: channel ci).  grid = ((cout/64)*(cin/64), M), block 256: the 4 waves
-// split the part's rows and are summed through LDS.
-// GRAM (last layer, cout == cin): both operands are A = relu(bn_prev(Yprev)), i.e. the part's Gram matrix
-// A^T A, and row `cin` of the output receives the column sums of A (what the weight gradient of the
-// never-stored last layer needs, see pn_top_wgrad_kernel).
-template <bool GRAM>
+// dW[co][ci] = sum over all valid rows of dY[r,co] * A[r,ci]   (a GEMM whose K dimension is the point rows), with
+// dY = alpha*dZ + gammap*Y + betap and A = relu(bn_prev(Yprev)) built on the fly.
+// The work is cut into units of RB rows of one part; kWG persistent blocks take the units round-robin (units of
+// padded parts are skipped).  Per unit the block builds the dY [RB x COUT] and A [RB x CINP] panels in LDS from
+// coalesced 16-byte loads issued ONE UNIT AHEAD (double-buffered), and each wave accumulates its share of the
+// (COUT/32) x (CINP/32) output tiles across all units of the block: MFMA A operand = dY^T (lane: channel co,
+// k = the row pair 2s + lane half), B operand = A (lane: channel ci), both plain 4-byte LDS reads.  Every block
+// leaves one partial dW (deterministic fixed-order sum in pn_wgrad_reduce_kernel).
+//   WG_FIRST : A = the raw input points (3 columns, zero-padded to one 32-wide tile) — first layer.
+//   WG_GRAM  : dY := A (COUT == CIN): the Gram matrix A^T A plus, in row COUT, the column sums of A — what the
+//              weight gradient of the never-stored last layer needs (pn_top_wgrad_kernel).
+constexpr int kWG = 512;  // persistent blocks (2 per CU)
+enum { WG_NORMAL = 0, WG_FIRST = 1, WG_GRAM = 2 };
+
+// LDY / co0: the block handles the COUT output channels starting at column co0 of a layer that is LDY wide
+// (the 64 -> 128 layer runs as two 64-channel slices, which keeps the double-buffered panels at 64 KB).
+template <int COUT, int CIN, int MODE, int LDY = COUT>
 __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
     const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
-    const float* __restrict__ y_prev, const float* __restrict__ bn_prev, int cout, int cin,
-    const float* __restrict__ valids, int N, float* __restrict__ dwpart) {
-  __shared__ float sm[kT / 64][4][16][64];  // 64 KiB
-  __shared__ float sb[kT / 64][64];
-  const int m = blockIdx.y;
-  if (valids[m] == 0.0f) return;
+    const float* __restrict__ y_prev, const float* __restrict__ bn_prev, const float* __restrict__ valids, int M,
+    int N, float* __restrict__ dwpart, int co0) {
+  constexpr int CINP = MODE == WG_FIRST ? 32 : CIN;       // width of the B panel
+  constexpr int CT = COUT / 32, IT = CINP / 32, NTILE = CT * IT, TPW = (NTILE + 3) / 4;
+  constexpr int RB = 64;
+  constexpr int DYW = MODE == WG_GRAM ? 0 : COUT;         // the dY panel does not exist in GRAM mode
+  constexpr int STAGE = RB * (DYW + CINP);
+  constexpr int QO = COUT / 4, QI = CIN / 4;
+  constexpr int NLO = MODE == WG_GRAM ? 1 : RB * QO / kT;      // float4 per thread: Y and dZ
+  constexpr int NLI = MODE == WG_FIRST ? 1 : RB * QI / kT;     // float4 per thread: Yprev
+  __shared__ __attribute__((aligned(16))) float buf[2][STAGE];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int cgroups = cin / 64;
-  const int c0 = (blockIdx.x / cgroups) * 64, d0 = (blockIdx.x % cgroups) * 64;
-  const long long out_stride = (long long)cout * cin + (GRAM ? cin : 0);
-  float al[2], gp[2], bp[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int co = c0 + 32 * t + j;
-    al[t] = GRAM ? bn_prev[co] : coef[co];
-    gp[t] = GRAM ? bn_prev[cin + co] : coef[cout + co];
-    bp[t] = GRAM ? 0.0f : coef[2 * cout + co];
+  const int TB = (N + RB - 1) / RB, U = M * TB;
+  // staging roles and per-column tables
+  const int co4 = threadIdx.x % QO, ro0 = threadIdx.x / QO;
+  const int ci4 = threadIdx.x % QI, ri0 = threadIdx.x / QI;
+  float4 al = {}, gp = {}, bp = {}, sc = {}, sh = {};
+  if constexpr (MODE != WG_GRAM) {
+    al = reinterpret_cast<const float4*>(coef + co0)[co4];
+    gp = reinterpret_cast<const float4*>(coef + LDY + co0)[co4];
+    bp = reinterpret_cast<const float4*>(coef + 2 * LDY + co0)[co4];
   }
-  float scp[2], shp[2];  // BatchNorm + ReLU of the previous layer, recomputed on the fly for operand B
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    scp[u] = bn_prev[d0 + 32 * u + j];
-    shp[u] = bn_prev[cin + d0 + 32 * u + j];
+  if constexpr (MODE != WG_FIRST) {
+    sc = reinterpret_cast<const float4*>(bn_prev)[ci4];
+    sh = reinterpret_cast<const float4*>(bn_prev + CIN)[ci4];
+  } else {  // the zero padding of the point panel (columns 3..31) is written once
+    for (int i = threadIdx.x; i < 2 * RB * 32; i += kT) buf[i / (RB * 32)][RB * DYW + i % (RB * 32)] = 0.0f;
+    __syncthreads();
   }
-  const int per = (N + kT / 64 - 1) / (kT / 64);
-  const int nb = wave * per, ne = nb + per < N ? nb + per : N;
-  const int cnt = ne > nb ? ne - nb : 0, half = (cnt + 1) / 2;
-  f32x16 acc[2][2];
+  float4 ry[NLO], rz[NLO], rp[NLI];
+  float rpt = 0.0f;
+  auto fetch = [&](int u) {
+    const int m = u / TB, n0 = (u % TB) * RB;
+    const long long row0 = (long long)m * N + n0;
+    if constexpr (MODE != WG_GRAM) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int u = 0; u < 2; ++u) acc[t][u] = f32x16{0};
-  float bsum[2] = {0.0f, 0.0f};
-  // one K step = one point per lane-half; operands of step s+1 are fetched before the 4 MFMAs of step s
-  float ny[2], nz[2], nbv[2];
-  bool nok;
-  auto fetch = [&](int s) {
-    const int n = nb + h * half + s;
-    nok = s < half && n < ne;
-    const long long r = (long long)m * N + (nok ? n : nb);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const long long o = r * cout + c0 + 32 * t + j;
-      if constexpr (GRAM) {
-        ny[t] = y_prev[o];
-        nz[t] = 0.0f;
-      } else {
-        ny[t] = y[o];
-        nz[t] = dz[o];
+      for (int i = 0; i < NLO; ++i) {
+        const int rl = ro0 + i * (kT / QO);
+        const bool ok = n0 + rl < N;
+        const long long o = ((row0 + rl) * LDY + co0) / 4 + co4;
+        ry[i] = ok ? reinterpret_cast<const float4*>(y)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        rz[i] = ok ? reinterpret_cast<const float4*>(dz)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
     }
+    if constexpr (MODE == WG_FIRST) {
+      const int rl = threadIdx.x / 3;
+      rpt = (threadIdx.x < RB * 3 && n0 + rl < N) ? y_prev[row0 * 3 + threadIdx.x] : 0.0f;
+    } else {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) nbv[u] = y_prev[r * cin + d0 + 32 * u + j];
+      for (int i = 0; i < NLI; ++i) {
+        const bool ok = n0 + ri0 + i * (kT / QI) < N;
+        rp[i] = ok ? reinterpret_cast<const float4*>(y_prev)[row0 * QI + i * kT + threadIdx.x]
+                   : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+    }
   };
-  if (half > 0) fetch(0);
-  for (int s = 0; s < half; ++s) {
-    float dy[2], b[2];
+  auto stash = [&](int u, float* dst) {  // rows past the part's end are staged as zeros (both panels)
+    const int n0 = (u % TB) * RB;
+    if constexpr (MODE != WG_GRAM) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float v = GRAM ? __builtin_fmaxf(__builtin_fmaf(ny[t], al[t], gp[t]), 0.0f)
-                           : __builtin_fmaf(al[t], nz[t], __builtin_fmaf(gp[t], ny[t], bp[t]));
-      dy[t] = nok ? v : 0.0f;
+      for (int i = 0; i < NLO; ++i) {
+        const int rl = ro0 + i * (kT / QO);
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (n0 + rl < N) {
+          v.x = __builtin_fmaf(al.x, rz[i].x, __builtin_fmaf(gp.x, ry[i].x, bp.x));
+          v.y = __builtin_fmaf(al.y, rz[i].y, __builtin_fmaf(gp.y, ry[i].y, bp.y));
+          v.z = __builtin_fmaf(al.z, rz[i].z, __builtin_fmaf(gp.z, ry[i].z, bp.z));
+          v.w = __builtin_fmaf(al.w, rz[i].w, __builtin_fmaf(gp.w, ry[i].w, bp.w));
+        }
+        *reinterpret_cast<float4*>(dst + rl * COUT + 4 * co4) = v;
+      }
     }
-    b[0] = __builtin_fmaxf(__builtin_fmaf(nbv[0], scp[0], shp[0]), 0.0f);
-    b[1] = __builtin_fmaxf(__builtin_fmaf(nbv[1], scp[1], shp[1]), 0.0f);
-    if constexpr (GRAM) {
-      bsum[0] += nok ? b[0] : 0.0f;
-      bsum[1] += nok ? b[1] : 0.0f;
+    float* da = dst + RB * DYW;
+    if constexpr (MODE == WG_FIRST) {
+      if (threadIdx.x < RB * 3) da[(threadIdx.x / 3) * 32 + threadIdx.x % 3] = rpt;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NLI; ++i) {
+        const int rl = ri0 + i * (kT / QI);
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (n0 + rl < N) {
+          v.x = __builtin_fmaxf(__builtin_fmaf(rp[i].x, sc.x, sh.x), 0.0f);
+          v.y = __builtin_fmaxf(__builtin_fmaf(rp[i].y, sc.y, sh.y), 0.0f);
+          v.z = __builtin_fmaxf(__builtin_fmaf(rp[i].z, sc.z, sh.z), 0.0f);
+          v.w = __builtin_fmaxf(__builtin_fmaf(rp[i].w, sc.w, sh.w), 0.0f);
+        }
+        *reinterpret_cast<float4*>(da + rl * CINP + 4 * ci4) = v;
+      }
     }
-    fetch(s + 1);
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto advance = [&](int u) {  // next unit of this block that belongs to a real part
+    while (u < U && valids[u / TB] == 0.0f) u += kWG;
+    return u;
+  };
+  f32x16 acc[TPW];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+  for (int i = 0; i < TPW; ++i) acc[i] = f32x16{0};
+  float bsum = 0.0f;
+  int u = advance(blockIdx.x), k = 0;
+  if (u < U) fetch(u);
+  while (u < U) {
+    float* cur = buf[k];
+    stash(u, cur);
+    __syncthreads();  // also orders the reuse of this buffer (its readers passed the previous barrier)
+    const int un = advance(u + kWG);
+    if (un < U) fetch(un);  // in flight during the MFMAs below
+    const float* pa = cur + h * (MODE == WG_GRAM ? CINP : COUT) + j;
+    const float* pb = cur + RB * DYW + h * CINP + j;
+    constexpr int AW = MODE == WG_GRAM ? CINP : COUT;  // row stride of the A-operand panel
+#pragma unroll 4
+    for (int s = 0; s < RB / 2; ++s) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy[t], b[u], acc[t][u], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < TPW; ++i) {
+        const int q = wave + 4 * i;
+        if (q < NTILE) {
+          const float a = pa[2 * s * AW + (q / IT) * 32];
+          const float b = pb[2 * s * CINP + (q % IT) * 32];
+          if (MODE == WG_GRAM && i == 0) bsum += b;  // tile row 0: its B operand covers columns 32*wave + j
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        }
+      }
+    }
+    u = un;
+    k ^= 1;
   }
+  constexpr int ELEMS = MODE == WG_FIRST ? COUT * 3 : COUT * CIN + (MODE == WG_GRAM ? CIN : 0);
+  float* out = dwpart + (long long)blockIdx.x * ELEMS;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int i = 0; i < TPW; ++i) {
+    const int q = wave + 4 * i;
+    if (q < NTILE) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sm[wave][2 * t + u][r][lane] = acc[t][u][r];
-  if constexpr (GRAM) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) bsum[u] += __shfl_xor(bsum[u], 32, 64);
-    if (h == 0) {
-      sb[wave][j] = bsum[0];
-      sb[wave][32 + j] = bsum[1];
+      for (int r = 0; r < 16; ++r) {
+        const int co = (q / IT) * 32 + acc_row(r, h), ci = (q % IT) * 32 + j;
+        if constexpr (MODE == WG_FIRST) {
+          if (j < 3) out[co * 3 + j] = acc[i][r];
+        } else {
+          out[co * CIN + ci] = acc[i][r];
+        }
+      }
     }
   }
-  __syncthreads();
-  // 4 tiles x 16 regs x 64 lanes = 4096 outputs, 16 per thread; D[i = co][jj = ci]
-  for (int e = threadIdx.x; e < 4096; e += kT) {
-    const int ln = e & 63, r = (e >> 6) & 15, tu = e >> 10;
-    float sum = 0.0f;
-#pragma unroll
-    for (int wv = 0; wv < kT / 64; ++wv) sum += sm[wv][tu][r][ln];
-    const int co = c0 + 32 * (tu >> 1) + acc_row(r, ln >> 5);
-    const int ci = d0 + 32 * (tu & 1) + (ln & 31);
-    dwpart[(long long)m * out_stride + (long long)co * cin + ci] = sum;
-  }
-  if (GRAM && c0 == 0 && threadIdx.x < 64) {
-    float t = 0.0f;
-#pragma unroll
-    for (int wv = 0; wv < kT / 64; ++wv) t += sb[wv][threadIdx.x];
-    dwpart[(long long)m * out_stride + (long long)cout * cin + d0 + threadIdx.x] = t;
+  if constexpr (MODE == WG_GRAM) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (h == 0) out[COUT * CIN + wave * 32 + j] = bsum;
   }
 }
 
-// dW[i] = sum over valid parts of dwpart[m][i].  block 1024 = 64 elements x 16 part-slices.
+// dW[i] = sum over the blocks' partial dW (valids == nullptr) or over valid parts of dwpart[m][i].
+// block 1024 = 64 elements x 16 slices.
 __global__ __launch_bounds__(64 * kSlices) void pn_wgrad_reduce_kernel(const float* __restrict__ dwpart,
                                                                       const float* __restrict__ valids,
                                                                       int M, int elems,
@@ -1059,7 +1070,7 @@ __global__ __launch_bounds__(64 * kSlices) void pn_wgrad_reduce_kernel(const flo
       for (int u = 0; u < U; ++u) {
         const int m = m0 + u * kSlices, mm = m < M ? m : M - 1;
         v[u] = dwpart[(long long)mm * elems + i];
-        ok[u] = m < M ? valids[mm] : 0.0f;
+        ok[u] = m < M ? (valids != nullptr ? valids[mm] : 1.0f) : 0.0f;
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1109,7 +1120,7 @@ struct PnWs {
   float* bn[6];   // [4][C] scale, shift, mean, invstd
   float* coef[6]; // [3][C] alpha, gammap, betap
   float* partial; // per-block column sums
-  float* dwpart;  // [M][cout*cin]  (last layer: [M][128*128 + 128] Gram matrices + column sums)
+  float* dwpart;  // [kWG][cout*cin] per-block partial weight gradients (last layer: Gram matrix + column sums)
   float* count;
   CoopWs coop;    // fp64 group sums + tickets of the cooperative reductions
   float* topv;    // [M*splits][F][4] top-2 records of the last layer (values)
@@ -1146,7 +1157,7 @@ PnWs carve(float* base, const Dims& d) {
   const int64_t maxc = d.F > 128 ? d.F : 128;
   const int64_t blocks = d.M * (d.tiles1 > d.splits ? d.tiles1 : d.splits);
   w.partial = take(blocks * maxc * 2);
-  w.dwpart = take(d.M * (128 * 128 + 128));
+  w.dwpart = take((int64_t)kWG * (128 * 128 + 128));
   w.count = take(4);
   w.coop.ticket = reinterpret_cast<unsigned*>(take(4));
   w.coop.stage = reinterpret_cast<double*>(take(2 * 2 * maxc * ((blocks + kEB - 1) / kEB)));
@@ -1292,29 +1303,30 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(C4 / 64), (unsigned)((M * d.splits + kEB - 1) / kEB)),
                      dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, d.splits, C4, w.count, bn_w[3], w.bn[4],
                      w.coef[4], grad_bn_w[3], grad_bn_b[3], w.coop);
-  {
-    const int elems = C4 * C4 + C4;
-    hipLaunchKernelGGL(pn_wgrad_mfma_kernel<true>, dim3((unsigned)((C4 / 64) * (C4 / 64)), (unsigned)M), dim3(kT), 0, s,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w.Y[4], w.bn[4], C4, C4,
-                       valids, (int)N, w.dwpart);
-    hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * kSlices), 0, s,
-                       w.dwpart, valids, (int)M, elems, w.gram);
-    hipLaunchKernelGGL(pn_top_wgrad_kernel, dim3((unsigned)F), dim3(1024), 0, s, grad_feat, iw.argmax, valids, w.Y[4],
-                       w.bn[4], conv_w[4], w.coef[5], w.gram, (int)M, (int)N, (int)F, grad_conv_w[4]);
-  }
+  auto reduce_dw = [&](int elems, float* dst) {
+    hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * kSlices), 0, s, w.dwpart,
+                       (const float*)nullptr, kWG, elems, dst);
+  };
+  hipLaunchKernelGGL((pn_wgrad_mfma_kernel<128, 128, WG_GRAM>), dim3(kWG), dim3(kT), 0, s, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, w.Y[4], w.bn[4], valids, (int)M, (int)N, w.dwpart, 0);
+  reduce_dw(C4 * C4 + C4, w.gram);
+  hipLaunchKernelGGL(pn_top_wgrad_kernel, dim3((unsigned)F), dim3(1024), 0, s, grad_feat, iw.argmax, valids, w.Y[4],
+                     w.bn[4], conv_w[4], w.coef[5], w.gram, (int)M, (int)N, (int)F, grad_conv_w[4]);
   for (int l = 4; l >= 1; --l) {
     const int cout = d.C[l], cin = d.C[l - 1];
-    if (l == 1) {
-      hipLaunchKernelGGL(pn_wgrad_first_kernel, dim3(1, (unsigned)M), dim3(kT), 0, s, w.Y[1], w.dZ[1], w.coef[1],
-                         points, valids, (int)N, w.dwpart);
-    } else {
-      const dim3 wg((unsigned)((cout / 64) * (cin / 64)), (unsigned)M);
-      hipLaunchKernelGGL(pn_wgrad_mfma_kernel<false>, wg, dim3(kT), 0, s, w.Y[l], w.dZ[l], w.coef[l], w.Y[l - 1],
-                         w.bn[l - 1], cout, cin, valids, (int)N, w.dwpart);
-    }
-    const int elems = cout * cin;
-    hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * kSlices), 0, s,
-                       w.dwpart, valids, (int)M, elems, grad_conv_w[l - 1]);
+    if (l == 1)
+      hipLaunchKernelGGL((pn_wgrad_mfma_kernel<64, 4, WG_FIRST>), dim3(kWG), dim3(kT), 0, s, w.Y[1], w.dZ[1], w.coef[1],
+                         points, (const float*)nullptr, valids, (int)M, (int)N, w.dwpart, 0);
+    else if (l == 4)  // two 64-channel slices of the 128 outputs
+      for (int half = 0; half < 2; ++half) {
+        hipLaunchKernelGGL((pn_wgrad_mfma_kernel<64, 64, WG_NORMAL, 128>), dim3(kWG), dim3(kT), 0, s, w.Y[4], w.dZ[4],
+                           w.coef[4], w.Y[3], w.bn[3], valids, (int)M, (int)N, w.dwpart, 64 * half);
+        reduce_dw(64 * cin, grad_conv_w[3] + (long long)half * 64 * cin);
+      }
+    else
+      hipLaunchKernelGGL((pn_wgrad_mfma_kernel<64, 64, WG_NORMAL>), dim3(kWG), dim3(kT), 0, s, w.Y[l], w.dZ[l],
+                         w.coef[l], w.Y[l - 1], w.bn[l - 1], valids, (int)M, (int)N, w.dwpart, 0);
+    if (l != 4) reduce_dw(cout * cin, grad_conv_w[l - 1]);
     if (l == 1) break;
     launch_dgrad(cout, w.Y[l], w.dZ[l], w.coef[l], conv_w[l - 1], cin, w.Y[l - 1], w.bn[l - 1], valids, d,
                  w.dZ[l - 1], w.partial, s);
