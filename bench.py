@@ -176,11 +176,16 @@ def main():
             brute_pairs = 2.0 * POINTS * POINTS * sum(n * n for n in num_parts)
             secs = k["avg_ms"] * 1e-3
             achieved = alg_bytes / secs / 1e9
+            traffic, traffic_src = None, None
+            pmc = sorted((ROOT / "profiles").glob("r*_pmc_dominant_kernel.json"))
+            if pmc:  # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes
+                rec = json.loads(pmc[-1].read_text())
+                traffic, traffic_src = rec["traffic_bytes_per_launch"], f"profiles/{pmc[-1].name}: {rec['correction']}"
             roofline = {
                 "kernel": "mpa::grid_search_kernel (exact grid-pruned whole-shape Chamfer search of the fused "
                           "loss, both directions)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "timing": "HIP events recorded by libmpa_hip.so right before/after the kernel on its launch "
