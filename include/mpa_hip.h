@@ -193,7 +193,9 @@ int mpa_pointnet_backward(const float* grad_feat, const float* points, const flo
  * norm1.weight, norm1.bias, norm2.weight, norm2.bias [D] — then the final norm.weight, norm.bias [D].
  * dropout_p in [0,1) applies to the 4 dropout sites of every layer (attention probabilities, attention
  * output, FFN hidden, FFN output) with a counter-based generator keyed by (seed, site, element): backward
- * must receive the same seed.  Pass 0 for evaluation.  ws (mpa_transformer_workspace floats) carries the
+ * must receive the same seed.  seed_dev (nullable): DEVICE address of the seed, read by the kernels instead of
+ * `seed` — lets a captured HIP graph draw fresh masks on every replay (the host updates the word between replays).
+ * dropout_p = 0 for evaluation.  ws (mpa_transformer_workspace floats) carries the
  * saved activations from forward to backward.  out [B,P,D].
  * backward: grad_out [B,P,D] -> grad_tokens [B,P,D] and grad_params (same layout as params; every buffer
  * is overwritten).  Deterministic: fixed-order reductions, no atomics.
@@ -202,11 +204,11 @@ int mpa_transformer_workspace(int64_t B, int64_t P, int64_t D, int64_t H, int64_
                               int64_t* float_elems);
 int mpa_transformer_forward(const float* tokens, const float* valid, const float* const* params, int64_t B,
                             int64_t P, int64_t D, int64_t H, int64_t FF, int64_t L, float dropout_p,
-                            uint64_t seed, float* ws, float* out, void* stream);
+                            uint64_t seed, const uint64_t* seed_dev, float* ws, float* out, void* stream);
 int mpa_transformer_backward(const float* grad_out, const float* valid, const float* const* params, int64_t B,
                              int64_t P, int64_t D, int64_t H, int64_t FF, int64_t L, float dropout_p,
-                             uint64_t seed, float* ws, float* grad_tokens, float* const* grad_params,
-                             void* stream);
+                             uint64_t seed, const uint64_t* seed_dev, float* ws, float* grad_tokens,
+                             float* const* grad_params, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pose head — replaces

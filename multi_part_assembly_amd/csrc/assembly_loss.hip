@@ -516,8 +516,7 @@ extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const floa
   const Workspace w = carve(float_ws, int_ws, B, P, N, q);
   const unsigned parts = (unsigned)(B * P);
   // padded parts never write their tile sums: clear them (2 directions x B*P*tiles, both arrays)
-  if (hipMemsetAsync(w.part_tiles, 0, sizeof(float) * 4 * B * P * w.tiles, s) != hipSuccess)
-    return mpa::check_launch("assembly_loss_forward(memset)");
+  mpa::zero_words_async(w.part_tiles, 4 * B * P * w.tiles, s);
   mark(0);
   hipLaunchKernelGGL(assembly_pose_kernel, dim3(parts), dim3(kThreads), 0, s, part_pcs, valids,
                      quat_pred, trans_pred, quat_gt, trans_gt, (int)N, fill_pad_points, w.R1, w.R2,

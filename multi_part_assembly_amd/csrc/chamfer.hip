@@ -166,10 +166,8 @@ int chamfer_backward_impl(const S* grad_dist1, const S* grad_dist2, const S* xyz
   MPA_REQUIRE((total1 == 0 || (grad_dist1 && xyz1 && idx1 && grad_xyz1)) &&
                   (total2 == 0 || (grad_dist2 && xyz2 && idx2 && grad_xyz2)),
               "chamfer_backward: null pointer");
-  if (total1 && hipMemsetAsync(grad_xyz1, 0, sizeof(S) * 3 * total1, s) != hipSuccess)
-    return mpa::check_launch("chamfer_backward(memset)");
-  if (total2 && hipMemsetAsync(grad_xyz2, 0, sizeof(S) * 3 * total2, s) != hipSuccess)
-    return mpa::check_launch("chamfer_backward(memset)");
+  mpa::zero_words_async(grad_xyz1, (int64_t)(sizeof(S) / 4) * 3 * total1, s);
+  mpa::zero_words_async(grad_xyz2, (int64_t)(sizeof(S) / 4) * 3 * total2, s);
   if (total1 == 0 || total2 == 0) return MPA_OK;  // every idx is -1: nothing to scatter
   const long long tmax = total1 > total2 ? total1 : total2;
   long long blocks = (tmax + kThreads - 1) / kThreads;

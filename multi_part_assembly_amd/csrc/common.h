@@ -16,6 +16,11 @@ int check_launch(const char* what);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Zero-fills `words` 32-bit words with a KERNEL.  hipMemsetAsync is deliberately not used anywhere in the library:
+// as a node of a captured HIP graph it misbehaved on replay (ROCm 7.0/7.2: faults on large fills, stale data on
+// small ones), and every entry point must stay graph-capturable.
+void zero_words_async(void* p, int64_t words, hipStream_t s);
+
 constexpr int kWave = 64;  // gfx950 wavefront width
 
 }  // namespace mpa

@@ -22,6 +22,20 @@ int check_launch(const char* what) {
   return fail(MPA_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
 }
 
+namespace {
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    p[i] = 0u;
+}
+}  // namespace
+
+void zero_words_async(void* p, int64_t words, hipStream_t s) {
+  if (words <= 0) return;
+  const int64_t blocks = (words + 255) / 256;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s,
+                     static_cast<uint32_t*>(p), (long long)words);
+}
+
 }  // namespace mpa
 
 extern "C" int mpa_abi_version(void) { return MPA_ABI_VERSION; }

@@ -41,11 +41,13 @@ struct Drop {
   unsigned long long seed;
   float p;       // drop probability; 0 disables
   float scale;   // 1 / (1 - p)
+  const unsigned long long* seed_dev;  // if set, the seed is read from device memory (HIP-graph replays)
 };
 
 __device__ __forceinline__ float drop_scale(const Drop d, unsigned site, unsigned long long idx) {
   if (d.p <= 0.0f) return 1.0f;
-  unsigned long long x = d.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(site + 1) + idx;
+  const unsigned long long seed = d.seed_dev != nullptr ? *d.seed_dev : d.seed;  // wave-uniform scalar load
+  unsigned long long x = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(site + 1) + idx;
   x ^= x >> 30;
   x *= 0xBF58476D1CE4E5B9ull;
   x ^= x >> 27;
@@ -56,9 +58,11 @@ __device__ __forceinline__ float drop_scale(const Drop d, unsigned site, unsigne
 }
 
 // ---- LayerNorm forward: one wave per row; writes the row statistics (for backward) and y = LN(x) ---------------------
+// x_copy (nullable): also saves x itself (the first layer keeps its input for backward without a memcpy node).
 __global__ __launch_bounds__(kT) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, int M, int D, float eps,
-                                                    float* __restrict__ stats, float* __restrict__ y) {
+                                                    float* __restrict__ stats, float* __restrict__ y,
+                                                    float* __restrict__ x_copy) {
   const int row = blockIdx.x * (kT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float* r = x + (long long)row * D;
@@ -75,7 +79,11 @@ __global__ __launch_bounds__(kT) void ln_fwd_kernel(const float* __restrict__ x,
     stats[2 * row] = mean;
     stats[2 * row + 1] = rstd;
   }
-  for (int k = lane; k < D; k += 64) y[(long long)row * D + k] = (r[k] - mean) * rstd * gamma[k] + beta[k];
+  for (int k = lane; k < D; k += 64) {
+    const float v = r[k];
+    y[(long long)row * D + k] = (v - mean) * rstd * gamma[k] + beta[k];
+    if (x_copy != nullptr) x_copy[(long long)row * D + k] = v;
+  }
 }
 
 // ---- GEMM  C[M,N] = epi(pro(A)[M,K] . W[N,K]^T + bias) ---------------------------------------------------------------
@@ -630,7 +638,7 @@ GemmArgs gemm_args(const float* A, const float* W, const float* bias, float* C, 
   g.M = M;
   g.N = N;
   g.K = K;
-  g.drop = Drop{0, 0.0f, 1.0f};
+  g.drop = Drop{0, 0.0f, 1.0f, nullptr};
   return g;
 }
 
@@ -643,7 +651,7 @@ WgradArgs wgrad_args(const float* dY, const float* X, float* dW, float* db, int 
   g.M = M;
   g.N = N;
   g.K = K;
-  g.drop = Drop{0, 0.0f, 1.0f};
+  g.drop = Drop{0, 0.0f, 1.0f, nullptr};
   return g;
 }
 
@@ -720,7 +728,8 @@ extern "C" int mpa_transformer_workspace(int64_t B, int64_t P, int64_t D, int64_
 
 extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, const float* const* params,
                                        int64_t B, int64_t P, int64_t D, int64_t H, int64_t FF, int64_t L,
-                                       float dropout_p, uint64_t seed, float* ws, float* out, void* stream) {
+                                       float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* ws, float* out,
+                                       void* stream) {
   const TfDims d{B, P, D, H, FF, L, B * P};
   if (int st = tf_check(d, "transformer_forward")) return st;
   if (B == 0) return MPA_OK;
@@ -728,7 +737,7 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
   MPA_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, "transformer_forward: dropout must be in [0, 1)");
   hipStream_t s = mpa::as_stream(stream);
   const TfLayout w = tf_carve(ws, d);
-  const Drop drop{seed, dropout_p, 1.0f / (1.0f - dropout_p)};
+  const Drop drop{seed, dropout_p, 1.0f / (1.0f - dropout_p), reinterpret_cast<const unsigned long long*>(seed_dev)};
   const int M = (int)d.M, Di = (int)D, FFi = (int)FF;
   const float eps = 1e-5f;
   const dim3 rows((M + 3) / 4);
@@ -736,9 +745,8 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
     const float* const* pp = params + l * P_PER_LAYER;
     const TfWs& t = w.layer[l];
     const unsigned site0 = (unsigned)(l * S_PER_LAYER);
-    if (l == 0 && hipMemcpyAsync(t.x_in, tokens, sizeof(float) * d.M * D, hipMemcpyDeviceToDevice, s) != hipSuccess)
-      return mpa::check_launch("transformer_forward(copy)");
-    hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, t.x_in, pp[P_G1], pp[P_BE1], M, Di, eps, t.stats1, t.h1);
+    hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, l == 0 ? tokens : t.x_in, pp[P_G1], pp[P_BE1], M, Di, eps,
+                       t.stats1, t.h1, l == 0 ? t.x_in : (float*)nullptr);
     GemmArgs g = gemm_args(t.h1, pp[P_WQKV], pp[P_BQKV], t.qkv, M, 3 * Di, Di);
     launch_gemm<PRO_NONE, EPI_NONE>(g, s);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, valid, (int)P, Di, (int)H,
@@ -748,7 +756,8 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
     g.drop = drop;
     g.epi_site = site0 + S_SA_OUT;
     launch_gemm<PRO_NONE, EPI_DROP_RESID>(g, s);
-    hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, t.x_mid, pp[P_G2], pp[P_BE2], M, Di, eps, t.stats2, t.h2);
+    hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, t.x_mid, pp[P_G2], pp[P_BE2], M, Di, eps, t.stats2, t.h2,
+                       (float*)nullptr);
     g = gemm_args(t.h2, pp[P_W1], pp[P_B1], t.f, M, FFi, Di);
     g.drop = drop;
     g.epi_site = site0 + S_FFN;
@@ -761,21 +770,22 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
     launch_gemm<PRO_NONE, EPI_DROP_RESID>(g, s);
   }
   const float* const* fin = params + L * P_PER_LAYER;
-  hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, w.x_final, fin[0], fin[1], M, Di, eps, w.stats_f, out);
+  hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, w.x_final, fin[0], fin[1], M, Di, eps, w.stats_f, out,
+                     (float*)nullptr);
   return mpa::check_launch("transformer_forward");
 }
 
 extern "C" int mpa_transformer_backward(const float* grad_out, const float* valid, const float* const* params,
                                         int64_t B, int64_t P, int64_t D, int64_t H, int64_t FF, int64_t L,
-                                        float dropout_p, uint64_t seed, float* ws, float* grad_tokens,
-                                        float* const* grad_params, void* stream) {
+                                        float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* ws,
+                                        float* grad_tokens, float* const* grad_params, void* stream) {
   const TfDims d{B, P, D, H, FF, L, B * P};
   if (int st = tf_check(d, "transformer_backward")) return st;
   if (B == 0) return MPA_OK;
   MPA_REQUIRE(grad_out && valid && params && ws && grad_tokens && grad_params, "transformer_backward: null pointer");
   hipStream_t s = mpa::as_stream(stream);
   const TfLayout w = tf_carve(ws, d);
-  const Drop drop{seed, dropout_p, 1.0f / (1.0f - dropout_p)};
+  const Drop drop{seed, dropout_p, 1.0f / (1.0f - dropout_p), reinterpret_cast<const unsigned long long*>(seed_dev)};
   const int M = (int)d.M, Di = (int)D, FFi = (int)FF;
   const dim3 rows((M + 3) / 4);
   const unsigned lnblocks = (unsigned)((M + 3) / 4);

@@ -11,12 +11,12 @@ per-step scalars live in device memory.  On one GPU the graph holds zero_grad + 
 Adam; with data parallelism it holds zero_grad + forward + backward, the gradient all-reduce and Adam
 run eagerly behind it.
 
-Status: bit-identical to eager launches for the configurations in tests/test_model_gpu.py.  At the
-full benchmark size the SECOND replay returns a wrong bias gradient for one transformer Linear layer —
-a PyTorch-ROCm library GEMM (hipBLASLt kernel with a bias-gradient epilogue), not one of this
-repository's kernels; the first replay is exact, i.e. that library path depends on scratch memory
-being zero.  Until the transformer runs on our own kernels graph mode stays opt-in; the step is
-GPU-bound, so eager launches cost nothing measurable (9.25 vs 9.12 ms).
+Status: bit-identical to eager launches (tests/test_model_gpu.py) and stable at the full benchmark size.  Two
+things make that true: the library issues no hipMemsetAsync / hipMemcpyAsync (as graph NODES they returned stale
+data on replay — what an earlier revision of this note blamed on a library GEMM), and everything that must differ
+between replays is read from device memory that the host refreshes before each replay: the optimiser's step
+scalars and the dropout seeds (`advance_seed`).  The step is GPU-bound, so the replay is only ~2 % faster than
+eager launches (4.63 vs 4.71 ms); eager stays the default of bench.py.
 """
 from __future__ import annotations
 
@@ -61,19 +61,22 @@ class Trainer:
     def _tensor_items(self, data_dict):
         return {k: v for k, v in data_dict.items() if isinstance(v, torch.Tensor)}
 
-    def _fwd_bwd(self, batch):
+    def _fwd_bwd(self, batch, loss_out=None):
         self.optimizer.zero_grad()
         with self.sink:  # HIP backward kernels write straight into the flat gradient buffer
             loss = self.model.training_step(batch, 0)
+            if loss_out is not None:  # graph mode: the loss is copied out before backward recycles memory
+                loss_out.copy_(loss.detach())
             loss.backward()
-        return loss.detach()
+        return loss.detach() if loss_out is None else loss_out
 
     def _capture(self, data_dict):
         self._static_batch = {k: v.clone() for k, v in self._tensor_items(data_dict).items()}
+        self._loss_buf = torch.zeros((), dtype=torch.float32, device=self.flat.flat_param.device)
         self._graph = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread may touch the HIP runtime while we capture
         with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-            self._static_loss = self._fwd_bwd(self._static_batch)
+            self._static_loss = self._fwd_bwd(self._static_batch, self._loss_buf)
             if self.world == 1:
                 self.optimizer.step_dev()
 
@@ -95,6 +98,9 @@ class Trainer:
             if v.data_ptr() != self._static_batch[k].data_ptr():
                 self._static_batch[k].copy_(v, non_blocking=True)
         self.optimizer.prepare_hyper()
+        for mod in self.model.modules():  # fresh dropout masks: the captured kernels read their seed from memory
+            if hasattr(mod, "advance_seed"):
+                mod.advance_seed()
         self._graph.replay()
         if self.world > 1:
             dist.all_reduce(self.flat.flat_grad, group=self.group)

@@ -23,7 +23,7 @@ _LAYER_PARAMS = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_att
 
 class _TransformerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tokens, valid, heads, dropout_p, seed, *params):
+    def forward(ctx, tokens, valid, heads, dropout_p, seed, seed_dev, *params):
         B, P, D = tokens.shape
         L = (len(params) - 2) // len(_LAYER_PARAMS)
         FF = params[4].shape[0]
@@ -37,13 +37,15 @@ class _TransformerFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             tok = _lib.KernelTimer.start(f"transformer_forward[{B}x{P}x{D}]")
             st = lib.mpa_transformer_forward(_lib.ptr(tokens), _lib.ptr(valid), _lib.ptr_array(params), B, P, D,
-                                             heads, FF, L, float(dropout_p), int(seed), _lib.ptr(ws),
+                                             heads, FF, L, float(dropout_p), int(seed),
+                                             None if seed_dev is None else _lib.ptr(seed_dev), _lib.ptr(ws),
                                              _lib.ptr(out), _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_transformer_forward")
         ctx.meta = (heads, FF, L, float(dropout_p), int(seed))
         ctx.params = params  # the Parameter objects themselves (GradSink writes into their .grad)
         GradSink.note_use(params)
+        ctx.seed_dev = seed_dev
         ctx.save_for_backward(valid, ws)
         return out
 
@@ -61,13 +63,14 @@ class _TransformerFn(torch.autograd.Function):
             tok = _lib.KernelTimer.start(f"transformer_backward[{B}x{P}x{D}]")
             st = _lib.lib().mpa_transformer_backward(
                 _lib.ptr(grad_out), _lib.ptr(valid), _lib.ptr_array(params), B, P, D, heads, FF, L, dropout_p,
-                seed, _lib.ptr(ws), _lib.ptr(grad_tokens), _lib.ptr_array(grads), _lib.current_stream(dev))
+                seed, None if ctx.seed_dev is None else _lib.ptr(ctx.seed_dev), _lib.ptr(ws), _lib.ptr(grad_tokens),
+                _lib.ptr_array(grads), _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_transformer_backward")
         if direct:
             GradSink.delivered(params)
-            return (grad_tokens, None, None, None, None, *([None] * len(params)))
-        return (grad_tokens, None, None, None, None, *grads)
+            return (grad_tokens, None, None, None, None, None, *([None] * len(params)))
+        return (grad_tokens, None, None, None, None, None, *grads)
 
 
 class TransformerEncoder(nn.Module):
@@ -82,9 +85,17 @@ class TransformerEncoder(nn.Module):
         self.out_fc = nn.Linear(d_model, out_dim) if out_dim is not None else nn.Identity()
         self.num_heads, self.norm_first = num_heads, norm_first
         self._calls = 0
+        self._seed_dev = None
         # shapes csrc/transformer.hip is built for (every shipped config: 256 / 8 heads / 1024 / pre-LN)
         self.native = (norm_first and d_model % 64 == 0 and ffn_dim % 64 == 0 and d_model % num_heads == 0
                        and d_model // num_heads <= 64 and num_layers <= 16)
+
+    def advance_seed(self):
+        """New dropout seed for the next forward (a counter hashed with torch's seed), written to device memory."""
+        self._calls += 1
+        seed = (torch.initial_seed() * 0x9E3779B1 + self._calls * 0x85EBCA77) & 0x7FFFFFFFFFFFFFFF
+        if self._seed_dev is not None:
+            self._seed_dev.fill_(seed)
 
     def _dropout_p(self):
         """The (single) dropout probability of the stack; 0 in eval mode."""
@@ -119,8 +130,13 @@ class TransformerEncoder(nn.Module):
         valid = (torch.ones(B * P, device=tokens.device) if valid_masks is None
                  else valid_masks.reshape(-1).float())
         p = self._dropout_p()
-        self._calls += 1
-        seed = (torch.initial_seed() * 0x9E3779B1 + self._calls * 0x85EBCA77) & 0xFFFFFFFFFFFFFFFF
-        out = _TransformerFn.apply(tokens.float().contiguous(), valid.contiguous(), self.num_heads, p, seed,
+        seed_dev = None
+        if p > 0.0:  # the seed lives in device memory so that a captured step draws fresh masks on every replay
+            if self._seed_dev is None or self._seed_dev.device != tokens.device:
+                self._seed_dev = torch.zeros(1, dtype=torch.int64, device=tokens.device)
+            if not torch.cuda.is_current_stream_capturing():
+                self.advance_seed()  # (during capture / replays the Trainer calls advance_seed() between replays)
+            seed_dev = self._seed_dev
+        out = _TransformerFn.apply(tokens.float().contiguous(), valid.contiguous(), self.num_heads, p, 0, seed_dev,
                                    *self._params())
         return self.out_fc(out)

@@ -160,7 +160,7 @@ def test_transformer_dropout_matches_oracle_with_same_masks(golden, cuda_device)
     assert not torch.allclose(ref, on.transformer_encoder(tok_ref, valid, sd, "", layers, heads))  # masks bite
     enc.to(cuda_device).train()
     tok = T(z["tokens"]).to(cuda_device).requires_grad_()
-    out = _TransformerFn.apply(tok, valid.reshape(-1).float().to(cuda_device), heads, p_drop, seed, *enc._params())
+    out = _TransformerFn.apply(tok, valid.reshape(-1).float().to(cuda_device), heads, p_drop, seed, None, *enc._params())
     (out * w.to(cuda_device)).sum().backward()
     assert _rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
     assert _rel(tok.grad.cpu().numpy(), tok_ref.grad.numpy()) < 1e-3

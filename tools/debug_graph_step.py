@@ -9,7 +9,7 @@ torch.manual_seed(0)
 model = build_model(cfg).to(dev)
 tr = Trainer(model, cfg, use_graph=True)
 batch = synthetic.make_batch(32, 20, 1000, seed=1234, device=dev); batch.pop("num_parts")
-for i in range(8):
+for i in range(int(os.environ.get("STEPS", "8"))):
     l = tr.train_step(batch); torch.cuda.synchronize()
     g = tr.flat.flat_grad; p = tr.flat.flat_param
     print(i, "graph" if tr._graph is not None else "eager", float(l), "grad norm", float(g.norm()), "finite", bool(torch.isfinite(g).all()),
