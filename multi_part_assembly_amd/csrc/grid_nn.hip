@@ -10,8 +10,8 @@
 //   2. grid_count / grid_scan / grid_scatter : counting sort (global-memory histogram) of each shape,
 //                      role TARGET : by fine cell -> (x, y, z, original index) records + cell start offsets;
 //                                    cells are x-fastest, so a row of cells is one contiguous run of records;
-//                      role QUERY  : by SUPER-cell (2x2x2 fine cells) + a prefix of 128-query batches.
-//   3. grid_search : one wave per (super-cell, batch of <= 128 queries, 2 per lane).  All queries of the wave
+//                      role QUERY  : by SUPER-cell (2x2x2 fine cells) + a prefix of 64-query batches.
+//   3. grid_search : one wave per (super-cell, batch of <= 64 queries, 1 per lane).  All queries of the wave
 //                    lie inside one known box (the super-cell), so the candidate set is wave-uniform:
 //                      seed  — the super-cell grown by one fine cell per side;
 //                      sweep — with B = the largest best-distance in the wave, every cell row (y, z) whose
@@ -35,7 +35,8 @@ namespace {
 constexpr int kMaxCells = 32768;
 constexpr int kMaxAxis = 64;
 constexpr int kStartStride = kMaxCells + 8;   // ints per (sample, shape, role) slot
-constexpr int kBatch = 128;                   // queries per search wave (2 per lane)
+constexpr int kWorkStride = kMaxCells / 8 + 20000 / 64 + 64;  // search work items per slot (<= nsuper + points/batch)
+constexpr int kBatch = 64;                    // queries per search wave (1 per lane)
 
 struct __attribute__((aligned(16))) GridParams {
   float ox, oy, oz, h;
@@ -43,6 +44,8 @@ struct __attribute__((aligned(16))) GridParams {
   int gx, gy, gz;
   int sgx, sgy, sgz, ncells;
   int nsuper, nvalid, pad0, pad1;
+  int tb[2][6];  // per shape: cell bounding box of its valid points (x0, x1, y0, y1, z0, z1), inclusive
+  int pad2[4];
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -66,44 +69,56 @@ __global__ __launch_bounds__(1024) void grid_params_kernel(const float* __restri
                                                           const float* __restrict__ S1,
                                                           const float* __restrict__ S2, int P, int N,
                                                           GridParams* __restrict__ params) {
-  __shared__ float red[6][1024];
+  __shared__ float red[12][1024];
   const int b = blockIdx.x;
   const float* vb = valids + (long long)b * P;
-  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
-  float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  // per shape c: lo[3c + k], hi[3c + k]
+  float lo[6], hi[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    lo[k] = __builtin_inff();
+    hi[k] = -__builtin_inff();
+  }
   int nvalid = 0;
   for (int p = 0; p < P; ++p) {
     if (vb[p] == 0.0f) continue;
     nvalid += N;
-    for (int n = threadIdx.x; n < 2 * N; n += 1024) {
-      const float* cloud = (n < N ? S1 : S2) + 3LL * b * P * N;
-      const float* q = cloud + 3LL * (p * N + (n < N ? n : n - N));
+    for (int n = threadIdx.x; n < N; n += 1024) {
+      const float* q1 = S1 + 3LL * b * P * N + 3LL * (p * N + n);
+      const float* q2 = S2 + 3LL * b * P * N + 3LL * (p * N + n);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        lo[k] = __builtin_fminf(lo[k], q[k]);
-        hi[k] = __builtin_fmaxf(hi[k], q[k]);
+        lo[k] = __builtin_fminf(lo[k], q1[k]);
+        hi[k] = __builtin_fmaxf(hi[k], q1[k]);
+        lo[3 + k] = __builtin_fminf(lo[3 + k], q2[k]);
+        hi[3 + k] = __builtin_fmaxf(hi[3 + k], q2[k]);
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < 6; ++k) {
     red[k][threadIdx.x] = lo[k];
-    red[3 + k][threadIdx.x] = hi[k];
+    red[6 + k][threadIdx.x] = hi[k];
   }
   __syncthreads();
   for (int s = 512; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < 6; ++k) {
         red[k][threadIdx.x] = __builtin_fminf(red[k][threadIdx.x], red[k][threadIdx.x + s]);
-        red[3 + k][threadIdx.x] = __builtin_fmaxf(red[3 + k][threadIdx.x], red[3 + k][threadIdx.x + s]);
+        red[6 + k][threadIdx.x] = __builtin_fmaxf(red[6 + k][threadIdx.x], red[6 + k][threadIdx.x + s]);
       }
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     GridParams g;
-    float ex = red[3][0] - red[0][0], ey = red[4][0] - red[1][0], ez = red[5][0] - red[2][0];
+    // union box of both shapes
+    const float ulo[3] = {__builtin_fminf(red[0][0], red[3][0]), __builtin_fminf(red[1][0], red[4][0]),
+                          __builtin_fminf(red[2][0], red[5][0])};
+    const float uhi[3] = {__builtin_fmaxf(red[6][0], red[9][0]), __builtin_fmaxf(red[7][0], red[10][0]),
+                          __builtin_fmaxf(red[8][0], red[11][0])};
+    float ex = uhi[0] - ulo[0], ey = uhi[1] - ulo[1], ez = uhi[2] - ulo[2];
     const float emax = __builtin_fmaxf(__builtin_fmaxf(ex, ey), __builtin_fmaxf(ez, 1e-12f));
     if (!(emax < 1e30f) || nvalid == 0) {  // non-finite coordinates or nothing to index: one cell
       g.ox = g.oy = g.oz = 0.0f;
@@ -127,9 +142,9 @@ __global__ __launch_bounds__(1024) void grid_params_kernel(const float* __restri
         if (g.gx * g.gy * g.gz <= kMaxCells) break;
         h *= 1.1f;
       }
-      g.ox = red[0][0];
-      g.oy = red[1][0];
-      g.oz = red[2][0];
+      g.ox = ulo[0];
+      g.oy = ulo[1];
+      g.oz = ulo[2];
       g.h = h;
       g.inv_h = 1.0f / h;
     }
@@ -140,6 +155,18 @@ __global__ __launch_bounds__(1024) void grid_params_kernel(const float* __restri
     g.nsuper = g.sgx * g.sgy * g.sgz;
     g.nvalid = nvalid;
     g.pad0 = g.pad1 = 0;
+    g.pad2[0] = g.pad2[1] = g.pad2[2] = g.pad2[3] = 0;
+    for (int c = 0; c < 2; ++c) {  // where each shape's points can be found, in cells (binning is monotone)
+      if (nvalid == 0 || g.inv_h == 0.0f) {
+        g.tb[c][0] = g.tb[c][2] = g.tb[c][4] = 0;
+        g.tb[c][1] = g.gx - 1;
+        g.tb[c][3] = g.gy - 1;
+        g.tb[c][5] = g.gz - 1;
+      } else {
+        cell_of(g, red[3 * c][0], red[3 * c + 1][0], red[3 * c + 2][0], g.tb[c][0], g.tb[c][2], g.tb[c][4]);
+        cell_of(g, red[6 + 3 * c][0], red[6 + 3 * c + 1][0], red[6 + 3 * c + 2][0], g.tb[c][1], g.tb[c][3], g.tb[c][5]);
+      }
+    }
     params[b] = g;
   }
 }
@@ -164,7 +191,7 @@ __global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict
 // and for QUERY slots the exclusive prefix of ceil(count / kBatch) (search work list).
 __global__ __launch_bounds__(1024) void grid_scan_kernel(const GridParams* __restrict__ params,
                                                          int* __restrict__ starts, int* __restrict__ cursor,
-                                                         int* __restrict__ batches) {
+                                                         int* __restrict__ batches, int* __restrict__ worklist) {
   __shared__ int wsum[16][2];
   const int slot = blockIdx.x, role = slot & 1, b = slot >> 2;
   const GridParams g = params[b];
@@ -172,6 +199,7 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(const GridParams* __res
   int* st = starts + (long long)slot * kStartStride;
   int* cu = cursor + (long long)slot * kStartStride;
   int* ba = batches + (long long)slot * kStartStride;
+  int* wl = worklist + (long long)slot * kWorkStride;
   constexpr int PER = kMaxCells / 1024;  // 32 keys per thread
   const int base = threadIdx.x * PER;
   int sum = 0, bsum = 0;
@@ -204,7 +232,10 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(const GridParams* __res
       const int v = st[base + k];
       st[base + k] = run;
       cu[base + k] = run;
-      if (role == 1) ba[base + k] = brun;
+      if (role == 1) {
+        ba[base + k] = brun;
+        for (int i = 0; i < (v + kBatch - 1) / kBatch; ++i) wl[brun + i] = base + k;  // work item -> super-cell
+      }
       run += v;
       brun += (v + kBatch - 1) / kBatch;
     }
@@ -245,23 +276,23 @@ __global__ void grid_zero_kernel(int4* __restrict__ p, long long n4) {
 }
 
 // ---- 3. search ----------------------------------------------------------------------------------------------------
-constexpr int kQ = 2;  // queries per lane
-
+// One query per lane: a super-cell holds a few dozen queries, rarely more than 64, and a packed two-query
+// `v_pk_*_f32` costs two issue slots anyway — so a second query slot per lane would mostly double the VALU time
+// of the scan for nothing.  (Super-cells with more than 64 queries simply appear as several work items.)
 struct LaneState {
-  f32x2 X, Y, Z;
-  float best[kQ];
-  int bidx[kQ];
+  float X, Y, Z;
+  float best;
+  int bidx;
 };
+
+__device__ __forceinline__ float dist_exact_s(float dx, float dy, float dz) { return (dx * dx + dy * dy) + dz * dz; }
 
 // lexicographic update with one candidate given as scalars
 __device__ __forceinline__ void consider(LaneState& s, float tx, float ty, float tz, int tidx) {
-  const f32x2 d = dist_exact_v(s.X - tx, s.Y - ty, s.Z - tz);
-#pragma unroll
-  for (int e = 0; e < kQ; ++e) {
-    if (d[e] < s.best[e] || (d[e] == s.best[e] && tidx < s.bidx[e])) {
-      s.best[e] = d[e];
-      s.bidx[e] = tidx;
-    }
+  const float d = dist_exact_s(s.X - tx, s.Y - ty, s.Z - tz);
+  if (d < s.best || (d == s.best && tidx < s.bidx)) {
+    s.best = d;
+    s.bidx = tidx;
   }
 }
 
@@ -280,23 +311,17 @@ __device__ __forceinline__ void scan_records(LaneState& s, const float4* __restr
     const int jn = j0 + T < end ? j0 + T : j0;
 #pragma unroll
     for (int t = 0; t < T; ++t) nx[t] = rec[jn + t];
-    f32x2 v[T];
+    float d[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) v[t] = dist_exact_v(s.X - cur[t].x, s.Y - cur[t].y, s.Z - cur[t].z);
+    for (int t = 0; t < T; ++t) d[t] = dist_exact_s(s.X - cur[t].x, s.Y - cur[t].y, s.Z - cur[t].z);
+    const float cmin = min8(d);
+    if (cmin <= s.best) {  // rare: an improvement, or a tie that may carry a lower index
 #pragma unroll
-    for (int e = 0; e < kQ; ++e) {
-      float d[T];
-#pragma unroll
-      for (int t = 0; t < T; ++t) d[t] = v[t][e];
-      const float cmin = min8(d);
-      if (cmin <= s.best[e]) {  // rare: an improvement, or a tie that may carry a lower index
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const int ti = __float_as_int(cur[t].w);
-          if (d[t] < s.best[e] || (d[t] == s.best[e] && ti < s.bidx[e])) {
-            s.best[e] = d[t];
-            s.bidx[e] = ti;
-          }
+      for (int t = 0; t < T; ++t) {
+        const int ti = __float_as_int(cur[t].w);
+        if (d[t] < s.best || (d[t] == s.best && ti < s.bidx)) {
+          s.best = d[t];
+          s.bidx = ti;
         }
       }
     }
@@ -320,8 +345,8 @@ __device__ __forceinline__ float gap(float a0, float a1, float b0, float b1) {
 __global__ __launch_bounds__(64) void grid_search_kernel(
     const float* __restrict__ valids, const float* __restrict__ S1, const float* __restrict__ S2, int P,
     int N, const GridParams* __restrict__ params, const float4* __restrict__ records,
-    const int* __restrict__ starts, const int* __restrict__ batches, int rec_stride,
-    float* __restrict__ dist1, float* __restrict__ dist2, int* __restrict__ idx1, int* __restrict__ idx2) {
+    const int* __restrict__ starts, const int* __restrict__ batches, const int* __restrict__ worklist,
+    int rec_stride, float* __restrict__ dist1, float* __restrict__ dist2, int* __restrict__ idx1, int* __restrict__ idx2) {
   const int b = blockIdx.y >> 1, dir = blockIdx.y & 1;
   const int qc = dir, tc = 1 - dir;  // query / target shape
   const GridParams g = params[b];
@@ -336,50 +361,51 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
   const int* bst = batches + (long long)qslot * kStartStride;
   const int total_work = bst[g.nsuper];
   for (int work = blockIdx.x; work < total_work; work += gridDim.x) {  // persistent walk over the work list
-  // binary search: super-cell sc with bst[sc] <= work < bst[sc+1]
-  int lo = 0, hi = g.nsuper;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (bst[mid] <= work) lo = mid;
-    else hi = mid;
-  }
-  const int sc = lo;
+  const int sc = worklist[(long long)qslot * kWorkStride + work];  // super-cell with bst[sc] <= work < bst[sc+1]
   const int* qst = starts + (long long)qslot * kStartStride;
   const int qb = qst[sc] + (work - bst[sc]) * kBatch, q_end = qst[sc + 1];
   const int sx = sc % g.sgx, sy = (sc / g.sgx) % g.sgy, sz = sc / (g.sgx * g.sgy);
   const int lane = threadIdx.x;
 
   LaneState s;
-  int qflat[kQ];
-  bool has[kQ];
-#pragma unroll
-  for (int e = 0; e < kQ; ++e) {
-    const int qi = qb + e * 64 + lane;
-    has[e] = qi < q_end;
-    const float4 r = qrec[has[e] ? qi : q_end - 1];
-    s.X[e] = r.x;
-    s.Y[e] = r.y;
-    s.Z[e] = r.z;
-    qflat[e] = __float_as_int(r.w);
-    s.best[e] = 1e32f;
-    s.bidx[e] = 0x7fffffff;
-  }
+  const int qi = qb + lane;
+  const bool has = qi < q_end;
+  const float4 qr = qrec[has ? qi : q_end - 1];
+  s.X = qr.x;
+  s.Y = qr.y;
+  s.Z = qr.z;
+  const int qflat = __float_as_int(qr.w);
+  s.best = 1e32f;
+  s.bidx = 0x7fffffff;
   // seed: the super-cell grown by one fine cell per side
   const int x0 = clampi(2 * sx - 1, 0, g.gx - 1), x1 = clampi(2 * sx + 2, 0, g.gx - 1);
   const int y0 = clampi(2 * sy - 1, 0, g.gy - 1), y1 = clampi(2 * sy + 2, 0, g.gy - 1);
   const int z0 = clampi(2 * sz - 1, 0, g.gz - 1), z1 = clampi(2 * sz + 2, 0, g.gz - 1);
-  for (int z = z0; z <= z1; ++z)
-    for (int y = y0; y <= y1; ++y) {
-      const int row = (z * g.gy + y) * g.gx;
-      scan_records(s, trec, tst[row + x0], tst[row + x1 + 1]);
+  // the target shape's own cell bounding box: rows and cells outside it are empty, and a query far from a compact
+  // target would otherwise walk hundreds of empty rows (two dependent loads each) before reaching it
+  const int tx0 = g.tb[tc][0], tx1 = g.tb[tc][1], ty0 = g.tb[tc][2], ty1 = g.tb[tc][3], tz0 = g.tb[tc][4],
+            tz1 = g.tb[tc][5];
+  if (x0 <= tx1 && x1 >= tx0 && y0 <= ty1 && y1 >= ty0 && z0 <= tz1 && z1 >= tz0) {
+    // all (begin, end) pairs of the <= 16 seed rows are requested before the first scan waits on one
+    int rb[16], re[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int z = z0 + (i >> 2), y = y0 + (i & 3);
+      const bool ok = z <= z1 && y <= y1;
+      const int row = ((ok ? z : z0) * g.gy + (ok ? y : y0)) * g.gx;
+      rb[i] = tst[row + x0];
+      re[i] = ok ? tst[row + x1 + 1] : rb[i];
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) scan_records(s, trec, rb[i], re[i]);
+  }
   // sweep: every cell whose box can hold a point closer than the worst best-distance of this wave.  The queries
   // lie in the super-cell box (inflated by the binning slack).
   const float slack = 1e-3f * g.h;
   const float bx0 = g.ox + (float)(2 * sx) * g.h - slack, bx1 = g.ox + (float)(2 * sx + 2) * g.h + slack;
   const float by0 = g.oy + (float)(2 * sy) * g.h - slack, by1 = g.oy + (float)(2 * sy + 2) * g.h + slack;
   const float bz0 = g.oz + (float)(2 * sz) * g.h - slack, bz1 = g.oz + (float)(2 * sz + 2) * g.h + slack;
-  float bound = wave_max(__builtin_fmaxf(s.best[0], s.best[1])) * 1.00001f;
+  float bound = wave_max(s.best) * 1.00001f;
   // Rows (y, z) are visited nearest-first, as square rings around the super-cell's own 2x2 rows, so the bound
   // tightens early; a ring whose nearest row is already farther than the bound ends the sweep.
   const int yc0 = 2 * sy, yc1 = 2 * sy + 1, zc0 = 2 * sz, zc1 = 2 * sz + 1;
@@ -390,14 +416,14 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
       if (ring_gap * ring_gap >= bound) break;
     }
     const int zlo = zc0 - r, zhi = zc1 + r, ylo = yc0 - r, yhi = yc1 + r;
-    for (int z = zlo < 0 ? 0 : zlo; z <= (zhi > g.gz - 1 ? g.gz - 1 : zhi); ++z) {
+    for (int z = zlo < tz0 ? tz0 : zlo; z <= (zhi > tz1 ? tz1 : zhi); ++z) {
       const float cz0 = g.oz + (float)z * g.h - slack, cz1 = g.oz + (float)(z + 1) * g.h + slack;
       const float dz = gap(bz0, bz1, cz0, cz1);
       if (dz * dz >= bound) continue;
       const bool edge_z = z == zlo || z == zhi;
       const int ystep = (edge_z || r == 0) ? 1 : (yhi - ylo);  // interior z: only the two frame columns
       for (int y = ylo; y <= yhi; y += ystep) {
-        if (y < 0 || y > g.gy - 1) continue;
+        if (y < ty0 || y > ty1) continue;
         const float cy0 = g.oy + (float)y * g.h - slack, cy1 = g.oy + (float)(y + 1) * g.h + slack;
         const float dy = gap(by0, by1, cy0, cy1);
         const float rem = bound - dz * dz - dy * dy;
@@ -410,6 +436,9 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
           xa = 0;
           xb = g.gx - 1;
         }
+        xa = xa < tx0 ? tx0 : xa;
+        xb = xb > tx1 ? tx1 : xb;
+        if (xa > xb) continue;
         const bool seeded = z >= z0 && z <= z1 && y >= y0 && y <= y1;
         const int row = (z * g.gy + y) * g.gx;
         if (seeded) {  // skip the part already scanned
@@ -418,7 +447,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
         } else {
           scan_records(s, trec, tst[row + xa], tst[row + xb + 1]);
         }
-        bound = wave_max(__builtin_fmaxf(s.best[0], s.best[1])) * 1.00001f;
+        bound = wave_max(s.best) * 1.00001f;
       }
     }
   }
@@ -427,12 +456,9 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     const float* t = tcloud + 3LL * p * N;
     consider(s, t[0], t[1], t[2], p * N);
   }
-#pragma unroll
-  for (int e = 0; e < kQ; ++e) {
-    if (has[e]) {
-      dout[qflat[e]] = s.best[e];
-      iout[qflat[e]] = s.bidx[e] == 0x7fffffff ? -1 : s.bidx[e];
-    }
+  if (has) {
+    dout[qflat] = s.best;
+    iout[qflat] = s.bidx == 0x7fffffff ? -1 : s.bidx;
   }
   }  // work loop
 }
@@ -463,7 +489,9 @@ int64_t grid_workspace_floats(int64_t B, int64_t P, int64_t N) {
   const int64_t rec = (P * N + 8) * 4;  // float4 records (+ sentinels) per slot
   return 4 * B * rec + B * (int64_t)(sizeof(GridParams) / 4) + 2 * B * P * N;  // + 2 distance arrays
 }
-int64_t grid_workspace_ints(int64_t B) { return 3 * 4 * B * (int64_t)kStartStride; }  // starts, cursor, batches
+int64_t grid_workspace_ints(int64_t B) {  // starts, cursor, batches, work list
+  return 3 * 4 * B * (int64_t)kStartStride + 4 * B * (int64_t)kWorkStride;
+}
 
 int launch_grid_shape_search(const float* valids, const float* S1, const float* S2, int64_t B, int64_t P,
                              int64_t N, int tiles, float* fws, int32_t* iws, int32_t* idx1, int32_t* idx2,
@@ -476,18 +504,19 @@ int launch_grid_shape_search(const float* valids, const float* S1, const float* 
   int* starts = iws;
   int* cursor = iws + 4 * B * (int64_t)kStartStride;
   int* batches = cursor + 4 * B * (int64_t)kStartStride;
+  int* worklist = batches + 4 * B * (int64_t)kStartStride;
   hipLaunchKernelGGL(grid_zero_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<int4*>(starts),
                      (long long)(B * (int64_t)kStartStride));  // 4*B*kStartStride ints = B*kStartStride int4
   hipLaunchKernelGGL(grid_params_kernel, dim3((unsigned)B), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N, params);
   hipLaunchKernelGGL(grid_count_kernel, dim3((unsigned)P, (unsigned)(4 * B)), dim3(256), 0, s, valids, S1, S2, (int)P,
                      (int)N, params, starts);
-  hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, params, starts, cursor, batches);
+  hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, params, starts, cursor, batches, worklist);
   hipLaunchKernelGGL(grid_scatter_kernel, dim3((unsigned)P, (unsigned)(4 * B)), dim3(256), 0, s, valids, S1, S2, (int)P,
                      (int)N, params, cursor, records, rec_stride);
-  // persistent waves: 128 per (sample, direction) walk that pair's work list of (super-cell, 128-query batch) items
+  // persistent waves: 128 per (sample, direction) walk that pair's work list of (super-cell, 64-query batch) items
   if (before_search != nullptr) (void)hipEventRecord(before_search, s);
   hipLaunchKernelGGL(grid_search_kernel, dim3(128, (unsigned)(2 * B)), dim3(64), 0, s, valids, S1, S2, (int)P,
-                     (int)N, params, records, starts, batches, rec_stride, dist1, dist2, idx1, idx2);
+                     (int)N, params, records, starts, batches, worklist, rec_stride, dist1, dist2, idx1, idx2);
   if (after_search != nullptr) (void)hipEventRecord(after_search, s);
   hipLaunchKernelGGL(grid_part_sum_kernel, dim3((unsigned)(B * P), 2), dim3(256), 0, s, valids, dist1, dist2, (int)N,
                      tiles, tile_sums);
