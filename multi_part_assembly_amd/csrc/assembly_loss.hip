@@ -534,7 +534,7 @@ extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const floa
     hipLaunchKernelGGL((assembly_nn_kernel<2, mpa::kChunkMin, false>), grid, dim3(kThreads), 0, s, valids,
                        w.R1, w.R2, (int)B, (int)P, (int)N, w.tiles, remap, w.ip1, w.ip2, w.part_tiles);
   mark(2);
-  if (use_grid_search())
+  if (use_grid_search() && P <= 64)  // (the search keeps one padded-part representative per lane)
     mpa::launch_grid_shape_search(valids, w.S1, w.S2, B, P, N, w.tiles, w.grid_f, w.grid_i, w.is1, w.is2,
                                   w.shape_tiles, events ? reinterpret_cast<hipEvent_t>(events[5]) : nullptr,
                                   events ? reinterpret_cast<hipEvent_t>(events[6]) : nullptr, s);

@@ -333,6 +333,11 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
   return v;
 }
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
 
 // squared distance between the intervals [a0, a1] and [b0, b1] on one axis
 __device__ __forceinline__ float gap(float a0, float a1, float b0, float b1) {
@@ -340,13 +345,78 @@ __device__ __forceinline__ float gap(float a0, float a1, float b0, float b1) {
   return g;
 }
 
-// grid = (max batches per (sample, dir), 2*B), block 64.  blockIdx.y = b*2 + dir; dir 0: shape 1 queries
+// A batch of up to 64 record ranges, one per lane ([rb, re); empty for idle lanes), scanned by the whole wave.
+// Walking the ranges one after the other costs two dependent memory latencies per range for a handful of records
+// each.  Instead every lane copies ITS range into one LDS candidate list (vector loads, all ranges in flight at
+// once), and then all lanes scan that list with broadcast LDS reads: two latencies per BATCH.  Long lists are
+// processed in windows of the LDS buffer; single long ranges go to the scalar scan, whose long runs amortise the
+// latency by themselves.
+constexpr int kCand = 512;      // candidate records per LDS window (8 KB per wave)
+constexpr int kLongRange = 48;  // ranges longer than this are scanned directly
+
+__device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restrict__ trec, int rb, int re,
+                                           float4* __restrict__ cand) {
+  const int lane = threadIdx.x;
+  int len = re > rb ? re - rb : 0;
+  // long ranges are contiguous runs that the scalar scan handles at full speed; they would only unbalance the copy
+  unsigned long long big = __ballot(len > kLongRange);
+  while (big) {
+    const int l = __builtin_ctzll(big);
+    big &= big - 1;
+    scan_records(s, trec, __builtin_amdgcn_readlane(rb, l), __builtin_amdgcn_readlane(re, l));
+  }
+  if (len > kLongRange) len = 0;
+  int incl = len;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  const int total = __shfl(incl, 63, 64), off0 = incl - len;
+  constexpr int T = kScanChunk, kCap = kCand - T;
+  for (int w0 = 0; w0 < total; w0 += kCap) {  // windows of the concatenated list that fit the LDS buffer
+    const int wn = total - w0 < kCap ? total - w0 : kCap;
+    const int lo = off0 > w0 ? off0 : w0, hi = off0 + len < w0 + wn ? off0 + len : w0 + wn;
+    const int cnt = hi > lo ? hi - lo : 0, maxc = wave_max_i(cnt);
+    __syncthreads();  // the previous window's readers are done with `cand` (one wave per block: a cheap fence)
+    for (int j = 0; j < maxc; ++j)
+      if (j < cnt) cand[lo - w0 + j] = trec[rb + (lo - off0) + j];
+    if (lane < T) {  // pad the last chunk of 8 with records that can never win
+      const float inf = __builtin_inff();
+      cand[wn + lane] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
+    }
+    __syncthreads();
+    for (int j0 = 0; j0 < wn; j0 += T) {
+      float4 cur[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) cur[t] = cand[j0 + t];  // same address in every lane: broadcast reads
+      float d[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) d[t] = dist_exact_s(s.X - cur[t].x, s.Y - cur[t].y, s.Z - cur[t].z);
+      const float cmin = min8(d);
+      if (cmin <= s.best) {  // rare: an improvement, or a tie that may carry a lower index
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const int ti = __float_as_int(cur[t].w);
+          if (d[t] < s.best || (d[t] == s.best && ti < s.bidx)) {
+            s.best = d[t];
+            s.bidx = ti;
+          }
+        }
+      }
+    }
+  }
+}
+
+// grid = (128 persistent waves per (sample, dir), 2*B), block 64.  blockIdx.y = b*2 + dir; dir 0: shape 1 queries
 // against shape 2 targets.
 __global__ __launch_bounds__(64) void grid_search_kernel(
     const float* __restrict__ valids, const float* __restrict__ S1, const float* __restrict__ S2, int P,
     int N, const GridParams* __restrict__ params, const float4* __restrict__ records,
     const int* __restrict__ starts, const int* __restrict__ batches, const int* __restrict__ worklist,
-    int rec_stride, float* __restrict__ dist1, float* __restrict__ dist2, int* __restrict__ idx1, int* __restrict__ idx2) {
+    int rec_stride, float* __restrict__ dist1, float* __restrict__ dist2, int* __restrict__ idx1,
+    int* __restrict__ idx2) {
+  __shared__ float4 cand[kCand];
   const int b = blockIdx.y >> 1, dir = blockIdx.y & 1;
   const int qc = dir, tc = 1 - dir;  // query / target shape
   const GridParams g = params[b];
@@ -354,112 +424,143 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
   const float4* qrec = records + (long long)qslot * rec_stride;
   const float4* trec = records + (long long)tslot * rec_stride;
   const int* tst = starts + (long long)tslot * kStartStride;
+  const int* qst = starts + (long long)qslot * kStartStride;
   const float* tcloud = (tc == 0 ? S1 : S2) + 3LL * b * P * N;
   const float* vb = valids + (long long)b * P;
   float* dout = (dir == 0 ? dist1 : dist2) + (long long)b * P * N;
   int* iout = (dir == 0 ? idx1 : idx2) + (long long)b * P * N;
   const int* bst = batches + (long long)qslot * kStartStride;
   const int total_work = bst[g.nsuper];
-  for (int work = blockIdx.x; work < total_work; work += gridDim.x) {  // persistent walk over the work list
-  const int sc = worklist[(long long)qslot * kWorkStride + work];  // super-cell with bst[sc] <= work < bst[sc+1]
-  const int* qst = starts + (long long)qslot * kStartStride;
-  const int qb = qst[sc] + (work - bst[sc]) * kBatch, q_end = qst[sc + 1];
-  const int sx = sc % g.sgx, sy = (sc / g.sgx) % g.sgy, sz = sc / (g.sgx * g.sgy);
   const int lane = threadIdx.x;
-
-  LaneState s;
-  const int qi = qb + lane;
-  const bool has = qi < q_end;
-  const float4 qr = qrec[has ? qi : q_end - 1];
-  s.X = qr.x;
-  s.Y = qr.y;
-  s.Z = qr.z;
-  const int qflat = __float_as_int(qr.w);
-  s.best = 1e32f;
-  s.bidx = 0x7fffffff;
-  // seed: the super-cell grown by one fine cell per side
-  const int x0 = clampi(2 * sx - 1, 0, g.gx - 1), x1 = clampi(2 * sx + 2, 0, g.gx - 1);
-  const int y0 = clampi(2 * sy - 1, 0, g.gy - 1), y1 = clampi(2 * sy + 2, 0, g.gy - 1);
-  const int z0 = clampi(2 * sz - 1, 0, g.gz - 1), z1 = clampi(2 * sz + 2, 0, g.gz - 1);
   // the target shape's own cell bounding box: rows and cells outside it are empty, and a query far from a compact
-  // target would otherwise walk hundreds of empty rows (two dependent loads each) before reaching it
+  // target would otherwise walk hundreds of empty rows before reaching it
   const int tx0 = g.tb[tc][0], tx1 = g.tb[tc][1], ty0 = g.tb[tc][2], ty1 = g.tb[tc][3], tz0 = g.tb[tc][4],
             tz1 = g.tb[tc][5];
-  if (x0 <= tx1 && x1 >= tx0 && y0 <= ty1 && y1 >= ty0 && z0 <= tz1 && z1 >= tz0) {
-    // all (begin, end) pairs of the <= 16 seed rows are requested before the first scan waits on one
-    int rb[16], re[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int z = z0 + (i >> 2), y = y0 + (i & 3);
-      const bool ok = z <= z1 && y <= y1;
-      const int row = ((ok ? z : z0) * g.gy + (ok ? y : y0)) * g.gx;
-      rb[i] = tst[row + x0];
-      re[i] = ok ? tst[row + x1 + 1] : rb[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) scan_records(s, trec, rb[i], re[i]);
-  }
-  // sweep: every cell whose box can hold a point closer than the worst best-distance of this wave.  The queries
-  // lie in the super-cell box (inflated by the binning slack).
   const float slack = 1e-3f * g.h;
-  const float bx0 = g.ox + (float)(2 * sx) * g.h - slack, bx1 = g.ox + (float)(2 * sx + 2) * g.h + slack;
-  const float by0 = g.oy + (float)(2 * sy) * g.h - slack, by1 = g.oy + (float)(2 * sy + 2) * g.h + slack;
-  const float bz0 = g.oz + (float)(2 * sz) * g.h - slack, bz1 = g.oz + (float)(2 * sz + 2) * g.h + slack;
-  float bound = wave_max(s.best) * 1.00001f;
-  // Rows (y, z) are visited nearest-first, as square rings around the super-cell's own 2x2 rows, so the bound
-  // tightens early; a ring whose nearest row is already farther than the bound ends the sweep.
-  const int yc0 = 2 * sy, yc1 = 2 * sy + 1, zc0 = 2 * sz, zc1 = 2 * sz + 1;
-  const int rmax = max(max(yc0, g.gy - 1 - yc1), max(zc0, g.gz - 1 - zc1));
-  for (int r = 0; r <= rmax; ++r) {
-    if (r >= 2) {
-      const float ring_gap = (float)(r - 1) * g.h - 2.0f * slack;
-      if (ring_gap * ring_gap >= bound) break;
+  // padded parts: one representative target each (index p*N), the same for every work item; lane p holds part p's
+  float px = 0.0f, py = 0.0f, pz = 0.0f;
+  bool pad = false;
+  if (lane < P && vb[lane] == 0.0f) {
+    pad = true;
+    const float* t = tcloud + 3LL * lane * N;
+    px = t[0];
+    py = t[1];
+    pz = t[2];
+  }
+  const unsigned long long padmask = __ballot(pad);
+
+  for (int work = blockIdx.x; work < total_work; work += gridDim.x) {  // persistent walk over the work list
+    const int sc = worklist[(long long)qslot * kWorkStride + work];  // super-cell with bst[sc] <= work < bst[sc+1]
+    const int qb = qst[sc] + (work - bst[sc]) * kBatch, q_end = qst[sc + 1];
+    const int sx = sc % g.sgx, sy = (sc / g.sgx) % g.sgy, sz = sc / (g.sgx * g.sgy);
+    LaneState s;
+    const int qi = qb + lane;
+    const bool has = qi < q_end;
+    const float4 qr = qrec[has ? qi : q_end - 1];
+    s.X = qr.x;
+    s.Y = qr.y;
+    s.Z = qr.z;
+    const int qflat = __float_as_int(qr.w);
+    s.best = 1e32f;
+    s.bidx = 0x7fffffff;
+    // the queries lie in the super-cell box (inflated by the binning slack)
+    const float bx0 = g.ox + (float)(2 * sx) * g.h - slack, bx1 = g.ox + (float)(2 * sx + 2) * g.h + slack;
+    const float by0 = g.oy + (float)(2 * sy) * g.h - slack, by1 = g.oy + (float)(2 * sy + 2) * g.h + slack;
+    const float bz0 = g.oz + (float)(2 * sz) * g.h - slack, bz1 = g.oz + (float)(2 * sz + 2) * g.h + slack;
+    // seed: the super-cell grown by one fine cell per side (16 rows, lane = row), clipped to the target box
+    const int x0 = clampi(2 * sx - 1, 0, g.gx - 1), x1 = clampi(2 * sx + 2, 0, g.gx - 1);
+    const int y0 = clampi(2 * sy - 1, 0, g.gy - 1), y1 = clampi(2 * sy + 2, 0, g.gy - 1);
+    const int z0 = clampi(2 * sz - 1, 0, g.gz - 1), z1 = clampi(2 * sz + 2, 0, g.gz - 1);
+    {
+      const int z = z0 + (lane >> 2), y = y0 + (lane & 3);
+      const int xa = x0 < tx0 ? tx0 : x0, xb = x1 > tx1 ? tx1 : x1;
+      const bool ok = lane < 16 && z <= z1 && y <= y1 && z >= tz0 && z <= tz1 && y >= ty0 && y <= ty1 && xa <= xb;
+      const int row = (z * g.gy + y) * g.gx;
+      const int rb = ok ? tst[row + xa] : 0, re = ok ? tst[row + xb + 1] : 0;
+      scan_batch(s, trec, rb, re, cand);
     }
-    const int zlo = zc0 - r, zhi = zc1 + r, ylo = yc0 - r, yhi = yc1 + r;
-    for (int z = zlo < tz0 ? tz0 : zlo; z <= (zhi > tz1 ? tz1 : zhi); ++z) {
-      const float cz0 = g.oz + (float)z * g.h - slack, cz1 = g.oz + (float)(z + 1) * g.h + slack;
-      const float dz = gap(bz0, bz1, cz0, cz1);
-      if (dz * dz >= bound) continue;
-      const bool edge_z = z == zlo || z == zhi;
-      const int ystep = (edge_z || r == 0) ? 1 : (yhi - ylo);  // interior z: only the two frame columns
-      for (int y = ylo; y <= yhi; y += ystep) {
-        if (y < ty0 || y > ty1) continue;
-        const float cy0 = g.oy + (float)y * g.h - slack, cy1 = g.oy + (float)(y + 1) * g.h + slack;
-        const float dy = gap(by0, by1, cy0, cy1);
-        const float rem = bound - dz * dz - dy * dy;
-        if (!(rem > 0.0f)) continue;
-        // cells x with gap_x(x)^2 < rem: an interval around the super-cell
-        const float reach = __builtin_sqrtf(rem) + slack;
-        int xa = clampi((int)__builtin_floorf((bx0 - reach - g.ox) * g.inv_h), 0, g.gx - 1);
-        int xb = clampi((int)__builtin_floorf((bx1 + reach - g.ox) * g.inv_h), 0, g.gx - 1);
-        if (bound > 1e31f) {  // nothing found yet: the whole row
-          xa = 0;
-          xb = g.gx - 1;
+    // sweep: every cell whose box can hold a point closer than the worst best-distance of this wave.  Rows (y, z)
+    // are visited nearest-first, as square rings around the super-cell's own 2x2 rows (lane = row of the ring, 64
+    // rows per batch), so the bound tightens early; a ring whose nearest row is already farther than the bound
+    // ends the sweep.  Rings 0 and 1 overlap the seed: only the cells left and right of it are new there.
+    float bound = wave_max(s.best) * 1.00001f;
+    const int yc0 = 2 * sy, yc1 = 2 * sy + 1, zc0 = 2 * sz, zc1 = 2 * sz + 1;
+    const int rmax = max(max(yc0, g.gy - 1 - yc1), max(zc0, g.gz - 1 - zc1));
+    for (int r = 0; r <= rmax; ++r) {
+      if (r >= 2) {
+        const float ring_gap = (float)(r - 1) * g.h - 2.0f * slack;
+        if (ring_gap * ring_gap >= bound) break;
+      }
+      const int zlo = zc0 - r, zhi = zc1 + r, ylo = yc0 - r, yhi = yc1 + r;
+      const int W = yhi - ylo + 1, H = zhi - zlo + 1;
+      const int nrows = r == 0 ? W * H : 2 * W + 2 * (H - 2);
+      const int sides = r <= 1 ? 2 : 1;  // seeded rows: left part and right part are separate ranges
+      for (int side = 0; side < sides; ++side) {
+        for (int i0 = 0; i0 < nrows; i0 += 64) {
+          const int i = i0 + lane;
+          int z, y;
+          if (r == 0) {
+            z = zlo + i / W;
+            y = ylo + i % W;
+          } else if (i < W) {
+            z = zlo;
+            y = ylo + i;
+          } else if (i < 2 * W) {
+            z = zhi;
+            y = ylo + i - W;
+          } else {
+            z = zlo + 1 + ((i - 2 * W) >> 1);
+            y = ((i - 2 * W) & 1) ? yhi : ylo;
+          }
+          int rb = 0, re = 0;
+          if (i < nrows && z >= tz0 && z <= tz1 && y >= ty0 && y <= ty1) {
+            const float cz0 = g.oz + (float)z * g.h - slack, cz1 = g.oz + (float)(z + 1) * g.h + slack;
+            const float cy0 = g.oy + (float)y * g.h - slack, cy1 = g.oy + (float)(y + 1) * g.h + slack;
+            const float dz = gap(bz0, bz1, cz0, cz1), dy = gap(by0, by1, cy0, cy1);
+            const float rem = bound - dz * dz - dy * dy;
+            if (rem > 0.0f) {
+              // cells x with gap_x(x)^2 < rem: an interval around the super-cell
+              const float reach = __builtin_sqrtf(rem) + slack;
+              int xa = clampi((int)__builtin_floorf((bx0 - reach - g.ox) * g.inv_h), 0, g.gx - 1);
+              int xb = clampi((int)__builtin_floorf((bx1 + reach - g.ox) * g.inv_h), 0, g.gx - 1);
+              if (bound > 1e31f) {  // nothing found yet: the whole row
+                xa = 0;
+                xb = g.gx - 1;
+              }
+              xa = xa < tx0 ? tx0 : xa;
+              xb = xb > tx1 ? tx1 : xb;
+              const bool seeded = r <= 1 && z >= z0 && z <= z1 && y >= y0 && y <= y1;
+              if (seeded) {  // the seed covered [x0, x1] of this row
+                if (side == 0) xb = xb < x0 - 1 ? xb : x0 - 1;
+                else xa = xa > x1 + 1 ? xa : x1 + 1;
+              } else if (side == 1) {
+                xa = 1;
+                xb = 0;
+              }
+              if (xa <= xb) {
+                const int row = (z * g.gy + y) * g.gx;
+                rb = tst[row + xa];
+                re = tst[row + xb + 1];
+              }
+            }
+          }
+          scan_batch(s, trec, rb, re, cand);
         }
-        xa = xa < tx0 ? tx0 : xa;
-        xb = xb > tx1 ? tx1 : xb;
-        if (xa > xb) continue;
-        const bool seeded = z >= z0 && z <= z1 && y >= y0 && y <= y1;
-        const int row = (z * g.gy + y) * g.gx;
-        if (seeded) {  // skip the part already scanned
-          if (xa < x0) scan_records(s, trec, tst[row + xa], tst[row + x0]);
-          if (xb > x1) scan_records(s, trec, tst[row + x1 + 1], tst[row + xb + 1]);
-        } else {
-          scan_records(s, trec, tst[row + xa], tst[row + xb + 1]);
-        }
-        bound = wave_max(s.best) * 1.00001f;
+      }
+      bound = wave_max(s.best) * 1.00001f;
+    }
+    {  // padded parts' representatives, in part order (uniform loop over the set bits)
+      unsigned long long m = padmask;
+      while (m) {
+        const int p = __builtin_ctzll(m);
+        m &= m - 1;
+        consider(s, __shfl(px, p, 64), __shfl(py, p, 64), __shfl(pz, p, 64), p * N);
       }
     }
-  }
-  for (int p = 0; p < P; ++p) {  // padded parts: one representative each (index p*N)
-    if (vb[p] != 0.0f) continue;
-    const float* t = tcloud + 3LL * p * N;
-    consider(s, t[0], t[1], t[2], p * N);
-  }
-  if (has) {
-    dout[qflat] = s.best;
-    iout[qflat] = s.bidx == 0x7fffffff ? -1 : s.bidx;
-  }
+    if (has) {
+      dout[qflat] = s.best;
+      iout[qflat] = s.bidx == 0x7fffffff ? -1 : s.bidx;
+    }
   }  // work loop
 }
 
