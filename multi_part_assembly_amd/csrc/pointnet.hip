@@ -1092,6 +1092,7 @@ __global__ __launch_bounds__(64 * kSlices) void pn_wgrad_reduce_kernel(const flo
 struct Dims {
   int64_t M, N, F, rows;
   int splits, tiles1;  // row splits of the MFMA kernels; 256-row tiles of the first-layer kernel
+  int splits_top;      // row splits of the two last-layer GEMMs (MFMA-bound: more, shorter blocks even out the tail)
   int C[6];            // channel widths: C[0] = 3 ... C[5] = F
 };
 
@@ -1103,7 +1104,8 @@ Dims make_dims(int64_t M, int64_t N, int64_t F) {
   d.rows = M * N;
   d.tiles1 = (int)((N + kT - 1) / kT);
   const int T = (int)((N + 31) / 32);
-  d.splits = T >= 16 ? 2 : 1;  // >= 8 tiles (2 per wave) per block
+  d.splits = T >= 32 ? 4 : (T >= 16 ? 2 : 1);  // row splits per part: enough blocks for an even last round
+  d.splits_top = T >= 32 ? 8 : d.splits;
   d.C[0] = 3;
   d.C[1] = 64;
   d.C[2] = 64;
@@ -1155,13 +1157,14 @@ PnWs carve(float* base, const Dims& d) {
   for (int l = 1; l <= 5; ++l) w.bn[l] = take(4LL * d.C[l]);
   for (int l = 1; l <= 5; ++l) w.coef[l] = take(4LL * d.C[l]);
   const int64_t maxc = d.F > 128 ? d.F : 128;
-  const int64_t blocks = d.M * (d.tiles1 > d.splits ? d.tiles1 : d.splits);
+  const int64_t smax = d.splits_top > d.splits ? d.splits_top : d.splits;
+  const int64_t blocks = d.M * (d.tiles1 > smax ? d.tiles1 : smax);
   w.partial = take(blocks * maxc * 2);
   w.dwpart = take((int64_t)kWG * (128 * 128 + 128));
   w.count = take(4);
   w.coop.ticket = reinterpret_cast<unsigned*>(take(4));
   w.coop.stage = reinterpret_cast<double*>(take(2 * 2 * maxc * ((blocks + kEB - 1) / kEB)));
-  w.topv = take(d.M * d.splits * d.F * 4);
+  w.topv = take(d.M * d.splits_top * d.F * 4);
   w.ybest = take(d.M * d.F);
   w.eval = take(d.M * d.F);
   w.q = take(129 * 128);
@@ -1179,7 +1182,7 @@ PnIws carve_int(int32_t* base, const Dims& d) {
     return r;
   };
   w.argmax = take(d.M * d.F);
-  w.topn = take(d.M * d.splits * d.F * 4);
+  w.topn = take(d.M * d.splits_top * d.F * 4);
   w.erow = take(d.M * d.F);
   w.ech = take(d.M * d.F);
   w.tptr = take(d.M * ((d.N + 31) / 32 + 1));
@@ -1242,11 +1245,11 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
       hipLaunchKernelGGL(pn_fwd_first_kernel, dim3((unsigned)d.tiles1, (unsigned)M), dim3(kT), 0, s, points,
                          w.Wt1, valids, (int)N, w.Y[1], w.partial);
     } else {
-      splits = d.splits;
-      const unsigned gx = (unsigned)(M * d.splits);
+      splits = l == 5 ? d.splits_top : d.splits;
+      const unsigned gx = (unsigned)(M * splits);
 #define MPA_FWD(CI, PN, TP, IN, YO, TV, TN)                                                                          \
   hipLaunchKernelGGL((pn_fwd_mfma_kernel<CI, PN, TP>), dim3(gx, (unsigned)(d.C[l] / (64 * PN))), dim3(kT), 0, s, IN, \
-                     w.bn[l - 1], conv_w[l - 1], d.C[l], valids, (int)N, d.splits, YO, w.partial, TV, TN)
+                     w.bn[l - 1], conv_w[l - 1], d.C[l], valids, (int)N, splits, YO, w.partial, TV, TN)
       if (l == 5) {
         if (F == 256) MPA_FWD(128, 4, true, w.Y[4], (float*)nullptr, w.topv, iw.topn);
         else if (F == 128) MPA_FWD(128, 2, true, w.Y[4], (float*)nullptr, w.topv, iw.topn);
@@ -1268,7 +1271,7 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
                          running_mean[l - 1], running_var[l - 1], eps, w.bn[l]);
   }
   hipLaunchKernelGGL(pn_top_finalize_kernel, dim3((unsigned)((M * F + 255) / 256)), dim3(256), 0, s, w.topv, iw.topn,
-                     w.bn[5], valids, w.Y[4], w.bn[4], conv_w[4], (int)M, (int)N, (int)F, d.C[4], d.splits, feat,
+                     w.bn[5], valids, w.Y[4], w.bn[4], conv_w[4], (int)M, (int)N, (int)F, d.C[4], d.splits_top, feat,
                      iw.argmax, w.ybest);
   return mpa::check_launch("pointnet_forward");
 }
@@ -1296,12 +1299,12 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
                      grad_feat, w.coef[5], valids, (int)N, (int)F, iw.erow, iw.ech, w.eval, iw.tptr);
   hipLaunchKernelGGL(pn_top_q_kernel, dim3((unsigned)(C4 + 1)), dim3((unsigned)C4), 0, s, conv_w[4], w.coef[5], (int)F,
                      C4, w.q);
-  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 2, 2, true>), dim3((unsigned)(M * d.splits), (unsigned)(C4 / 128)),
+  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 2, 2, true>), dim3((unsigned)(M * d.splits_top), (unsigned)(C4 / 128)),
                      dim3(kT), 0, s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w.q, C4,
-                     w.Y[4], w.bn[4], valids, (int)N, d.splits, w.dZ[4], w.partial, iw.erow, iw.ech, w.eval, iw.tptr,
+                     w.Y[4], w.bn[4], valids, (int)N, d.splits_top, w.dZ[4], w.partial, iw.erow, iw.ech, w.eval, iw.tptr,
                      conv_w[4], (int)F);
-  hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(C4 / 64), (unsigned)((M * d.splits + kEB - 1) / kEB)),
-                     dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, d.splits, C4, w.count, bn_w[3], w.bn[4],
+  hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(C4 / 64), (unsigned)((M * d.splits_top + kEB - 1) / kEB)),
+                     dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, d.splits_top, C4, w.count, bn_w[3], w.bn[4],
                      w.coef[4], grad_bn_w[3], grad_bn_b[3], w.coop);
   auto reduce_dw = [&](int elems, float* dst) {
     hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * kSlices), 0, s, w.dwpart,
