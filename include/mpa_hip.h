@@ -157,7 +157,7 @@ int mpa_assembly_loss_backward(const float* grad_losses, const float* part_pcs, 
  *                                (boolean-mask compaction + scatter; here: mask in, zeros out)
  * 5 x [1x1 conv (no bias) -> BatchNorm1d -> ReLU (none after the last)], widths 3-64-64-64-128-F,
  * max over the N points of every part.  F must be 64, 128 or 256 (the shipped configs use 128 / 256),
- * N <= 8192 points per part (the reference samples 1000).
+ * N <= 32768 points per part (the reference samples 1000 per part and feeds P*N = 20000 to B-Global's shape encoder).
  *
  * points [M,N,3]; valids [M] (1/0): padded parts are skipped everywhere (they do not enter the
  * BatchNorm statistics) and get feat = 0.  conv_w[l] = [C_l, C_{l-1}] row-major (the Conv1d weight

@@ -61,3 +61,58 @@ def pn_transformer_everyday():
     return Config(exp=Config(batch_size=32, num_epochs=400, num_workers=8, gpus=[0]),
                   data=breaking_bad_everyday(), optimizer=opt, model=pn_transformer_model(),
                   loss=geometric_loss())
+
+
+def partnet_chair():
+    """configs/_base_/datasets/partnet/partnet_chair.py:5-16."""
+    return Config(dataset="partnet", data_keys=("part_ids", "match_ids", "contact_points"), num_pc_points=1000,
+                  num_part_category=57, min_num_part=2, max_num_part=20)
+
+
+def dgl_model():
+    """configs/_base_/models/dgl.py:5-18."""
+    return Config(name="dgl", rot_type="quat", pc_feat_dim=128, encoder="pointnet", gnn_iter=3, merge_node=True)
+
+
+def rgl_net_model():
+    """configs/_base_/models/rgl_net.py:5-14."""
+    return Config(name="rgl_net", rot_type="quat", pc_feat_dim=128, encoder="pointnet", gnn_iter=3, merge_node=True)
+
+
+def global_model():
+    """configs/_base_/models/global.py:5-11."""
+    return Config(name="global", rot_type="quat", pc_feat_dim=128, encoder="pointnet")
+
+
+def _exp(epochs):
+    return Config(batch_size=32, num_epochs=epochs, num_workers=8, gpus=[0])
+
+
+def dgl_everyday():
+    """configs/dgl/dgl-32x1-cosine_200e-everyday.py: no equivalent parts in geometric data -> merge_node off."""
+    model = dgl_model()
+    model.merge_node = False
+    data = breaking_bad_everyday()
+    data.data_keys = ("part_ids", "valid_matrix")
+    return Config(exp=_exp(200), data=data, optimizer=adam_cosine(), model=model, loss=geometric_loss())
+
+
+def rgl_net_everyday():
+    """configs/rgl_net/rgl_net-32x1-cosine_200e-everyday.py (merge_node stays on: the second relation net is used
+    at odd iterations even though geometric data never merges nodes)."""
+    model = rgl_net_model()
+    data = breaking_bad_everyday()
+    data.data_keys = ("part_ids", "valid_matrix")
+    return Config(exp=_exp(200), data=data, optimizer=adam_cosine(), model=model, loss=geometric_loss())
+
+
+def global_everyday():
+    """configs/global/global-32x1-cosine_200e-everyday.py."""
+    return Config(exp=_exp(200), data=breaking_bad_everyday(), optimizer=adam_cosine(), model=global_model(),
+                  loss=geometric_loss())
+
+
+def global_partnet_chair():
+    """configs/global/global-32x1-cosine_200e-partnet_chair.py (semantic data: matching + min-of-N)."""
+    return Config(exp=_exp(200), data=partnet_chair(), optimizer=adam_cosine(), model=global_model(),
+                  loss=semantic_loss())

@@ -720,9 +720,9 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
   const float4 tc = TOP ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : reinterpret_cast<const float4*>(coef + 2 * K)[c4];
   const int TB = (N + RB - 1) / RB;
   const int t_begin = (int)((long long)sp * TB / splits), t_end = (int)((long long)(sp + 1) * TB / splits);
-  // TOP: the part's CSR (<= 256 entries, <= 257 tile offsets) lives in LDS so that the per-tile sparse chain has
+  // TOP: the part's CSR (<= 256 entries, <= 1025 tile offsets) lives in LDS so that the per-tile sparse chain has
   // a single level of global loads (the W5 rows), issued before the tile's main MFMA chain
-  constexpr int kMaxF = 256, kMaxT1 = 260, kSP = 6;
+  constexpr int kMaxF = 256, kMaxT1 = 1032, kSP = 6;  // tile offsets: N <= 32768 points per part
   __shared__ int s_row[TOP ? kMaxF : 1], s_ch[TOP ? kMaxF : 1], s_ptr[TOP ? kMaxT1 : 1];
   __shared__ float s_val[TOP ? kMaxF : 1];
   if constexpr (TOP) {
@@ -1193,7 +1193,7 @@ PnIws carve_int(int32_t* base, const Dims& d) {
 int check_dims(int64_t M, int64_t N, int64_t F, const char* who) {
   MPA_REQUIRE(M >= 0 && N >= 1 && F >= 64, "%s: bad sizes", who);
   MPA_REQUIRE(F == 64 || F == 128 || F == 256, "%s: feat_dim must be 64, 128 or 256", who);
-  MPA_REQUIRE(M <= 32767 && N <= 8192, "%s: at most 32767 parts of at most 8192 points", who);
+  MPA_REQUIRE(M <= 32767 && N <= 32768, "%s: at most 32767 parts of at most 32768 points", who);
   return MPA_OK;
 }
 

@@ -1,0 +1,286 @@
+"""Graph-network callers of the hot path: DGL (dynamic graph learning) and RGL-NET (DGL + bidirectional GRU) —
+mirrors of the reference models (multi_part_assembly/models/dgl/network.py:14-297, dgl/modules.py:5-86,
+rgl_net/network.py:12-162, rgl_net/modules.py:5-30, modules/rnn.py:6-46) with the same sub-module names, hence
+the same state_dict keys (`edge_mlps.{i}.conv1.weight`, `node_mlps.{i}.bn3.running_mean`, `pose_predictors.{i}.*`,
+`relation_predictor_dense.mlp1.*`, `pose_extractor.*`, `grus.{i}.rnn.weight_ih_l0`, ...).
+
+What runs where: the part encoder (PointNet: csrc/pointnet.hip), every loss evaluation of the `gnn_iter` stacked
+predictions (fused assembly loss: csrc/assembly_loss.hip, grid_nn.hip) and the optimiser are the HIP hot path; the
+graph network itself — P x P edge MLPs over <= 20 parts, relation gating, the GRU — is ~1e10 FLOP per iteration on
+tiny tensors and stays on PyTorch-ROCm library ops, as SURVEY.md §8 row a19 scopes it.
+
+Differences from the reference, none of them numerical beyond fp32 re-association:
+  * the edge MLP's first 1x1 conv is applied to the two halves of the pair feature separately
+    (W [f_i ; f_j] = W_a f_i + W_b f_j), so the [B, P, P, 2F] pair tensor is never materialised;
+  * part features are extracted with the mask-in / zeros-out PointNet entry (no boolean-mask sync);
+  * the GRU runs on the padded batch and the padded steps are masked instead of packing sequences through a
+    `lengths.cpu()` round trip (modules/rnn.py:28) — see `_MaskedBiGRU`.
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .base_model import BaseModel
+from .encoder import build_encoder
+from .regressor import StocasticPoseRegressor
+
+
+class _PairMLP(nn.Module):
+    """conv1 (cin -> 512) - bn - relu - conv2 (512 -> 512) - bn - relu - conv3 (512 -> F) - bn [- relu]; the three
+    1x1 Conv1d + BatchNorm1d of dgl/modules.py:5-58 (`MLP3` / `MLP4`, identical there) and rgl_net/modules.py:5-30."""
+
+    def __init__(self, in_dim, feat_len, final_relu=True):
+        super().__init__()
+        self.conv1 = nn.Conv1d(in_dim, 512, 1)
+        self.conv2 = nn.Conv1d(512, 512, 1)
+        self.conv3 = nn.Conv1d(512, feat_len, 1)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.bn2 = nn.BatchNorm1d(512)
+        self.bn3 = nn.BatchNorm1d(feat_len)
+        self.final_relu = final_relu
+
+    def _tail(self, h):
+        """h [R, 512, L]: output of conv1 -> [R, L, F]."""
+        h = torch.relu(self.bn1(h))
+        h = torch.relu(self.bn2(self.conv2(h)))
+        h = self.bn3(self.conv3(h))
+        if self.final_relu:
+            h = torch.relu(h)
+        return h.transpose(1, 2)
+
+    def forward(self, x):
+        """x [R, L, cin] -> [R, L, F]."""
+        return self._tail(self.conv1(x.transpose(1, 2)))
+
+    def forward_pairs(self, a, b):
+        """Rows = (sample, part i), positions = part j, input [a_i ; b_j]: a, b [B, P, F] -> [B*P, P, F_out]
+        without building the pair tensor."""
+        B, P, F = a.shape
+        w = self.conv1.weight[:, :, 0]                         # [512, 2F]
+        pa = a @ w[:, :F].t() + self.conv1.bias                # [B, P, 512]  (depends on i)
+        pb = b @ w[:, F:].t()                                  # [B, P, 512]  (depends on j)
+        h = pa[:, :, None, :] + pb[:, None, :, :]              # [B, P_i, P_j, 512]
+        return self._tail(h.reshape(B * P, P, 512).transpose(1, 2))
+
+
+class RelationNet(nn.Module):
+    """Pair of pose features -> relation weight in (0, 1) (dgl/modules.py:61-73)."""
+
+    def __init__(self):
+        super().__init__()
+        self.mlp1 = nn.Linear(128 + 128, 256)
+        self.mlp2 = nn.Linear(256, 512)
+        self.mlp3 = nn.Linear(512, 1)
+
+    def forward(self, x):
+        return torch.sigmoid(self.mlp3(torch.relu(self.mlp2(torch.relu(self.mlp1(x))))))
+
+
+class PoseEncoder(nn.Module):
+    """Pose vector -> 128-d feature (dgl/modules.py:76-86)."""
+
+    def __init__(self, pose_dim):
+        super().__init__()
+        self.mlp1 = nn.Linear(pose_dim, 256)
+        self.mlp2 = nn.Linear(256, 128)
+
+    def forward(self, x):
+        return torch.relu(self.mlp2(torch.relu(self.mlp1(x))))
+
+
+def _clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+class DGLModel(BaseModel):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.iter = cfg.model.gnn_iter
+        self.merge_node = cfg.model.merge_node
+        zero_pose = torch.zeros(1, 1, self.pose_dim)
+        zero_pose[..., 0] = 1.0  # identity quaternion, zero translation (base_model.py:31-34)
+        self.zero_pose = zero_pose
+        self.encoder = build_encoder(cfg.model.encoder, feat_dim=self.pc_feat_dim, global_feat=True)
+        self.edge_mlps = _clones(_PairMLP(2 * self.pc_feat_dim, self.pc_feat_dim), self.iter)
+        self.node_mlps = self._init_node_mlps()
+        dim = self.pc_feat_dim + self.pose_dim
+        if self.semantic:
+            dim += self.max_num_part
+        if self.use_part_label:
+            dim += cfg.data.num_part_category
+        self.pose_predictors = _clones(
+            StocasticPoseRegressor(feat_dim=dim, noise_dim=cfg.loss.noise_dim, rot_type=self.rot_type), self.iter)
+        self.relation_predictor_dense = RelationNet()
+        if self.merge_node:
+            self.relation_predictor = RelationNet()
+        self.pose_extractor = PoseEncoder(self.pose_dim)
+
+    def _init_node_mlps(self):
+        return _clones(_PairMLP(2 * self.pc_feat_dim, self.pc_feat_dim), self.iter)
+
+    # ---- pieces of one GNN iteration -----------------------------------------------------------------------
+    def _extract_part_feats(self, part_pcs, part_valids):
+        B, P, N, _ = part_pcs.shape
+        if hasattr(self.encoder, "forward_parts"):
+            return self.encoder.forward_parts(part_pcs.reshape(B * P, N, 3), part_valids.reshape(-1)).view(B, P, -1)
+        valid = (part_valids == 1).reshape(-1)
+        slots = torch.nonzero(valid, as_tuple=False).squeeze(1)
+        feats = self.encoder(part_pcs.reshape(B * P, N, 3).index_select(0, slots))
+        return feats.new_zeros(B * P, self.pc_feat_dim).index_copy(0, slots, feats).view(B, P, -1)
+
+    def _gather_same_class(self, data_dict):
+        """Index groups of geometrically equivalent parts per sample (dgl/network.py:75-88); host-side, once per
+        step, semantic datasets only."""
+        class_list = data_dict.get("class_list", None)
+        if self.merge_node and self.semantic and class_list is None:
+            valids, ids = data_dict["part_valids"].cpu().numpy(), data_dict["part_ids"].cpu().numpy()
+            class_list = []
+            for v, i in zip(valids, ids):
+                real = i[v == 1]
+                class_list.append([np.where(real == lbl)[0] for lbl in np.unique(real)])
+        return class_list
+
+    @staticmethod
+    def _merge_nodes(part_feats, pose_feats, class_list):
+        """Equivalent parts share the channel-wise max of their features (dgl/network.py:101-119)."""
+        part_out, pose_out = part_feats.clone(), pose_feats.clone()
+        for b, groups in enumerate(class_list):
+            for idx in groups:
+                if len(idx) > 1:
+                    part_out[b, idx] = part_feats[b, idx].max(dim=-2, keepdim=True)[0]
+                    pose_out[b, idx] = pose_feats[b, idx].max(dim=-2, keepdim=True)[0]
+        return part_out, pose_out
+
+    def _update_relation(self, pose_feats, iter_ind):
+        """relation[b, i, j] = net([pose_j ; pose_i]) (dgl/network.py:121-133)."""
+        B, P, C = pose_feats.shape
+        pair = torch.cat([pose_feats[:, None].expand(B, P, P, C), pose_feats[:, :, None].expand(B, P, P, C)], dim=-1)
+        net = self.relation_predictor if (self.merge_node and iter_ind % 2 == 1) else self.relation_predictor_dense
+        return net(pair.reshape(B, P * P, 2 * C)).view(B, P, P)
+
+    def _message_passing(self, part_feats, relation, iter_ind):
+        """Relation-weighted mean of the edge features (dgl/network.py:135-152)."""
+        B, P, _ = part_feats.shape
+        edge = self.edge_mlps[iter_ind].forward_pairs(part_feats, part_feats).view(B, P, P, -1)
+        msg = (edge * relation[..., None]).sum(dim=2)
+        return msg / (relation.sum(dim=-1, keepdim=True) + 1e-6)
+
+    def _node_update(self, part_feats, messages, data_dict, iter_ind):
+        return self.node_mlps[iter_ind](torch.cat([messages, part_feats], dim=-1))
+
+    def forward(self, data_dict):
+        part_feats = data_dict.get("part_feats", None)
+        if part_feats is None:
+            part_feats = self._extract_part_feats(data_dict["part_pcs"], data_dict["part_valids"])
+        local_feats = part_feats
+        valid_matrix = data_dict["valid_matrix"]
+        part_label = data_dict["part_label"].type_as(part_feats)
+        instance_label = data_dict["instance_label"].type_as(part_feats)
+        B, P = instance_label.shape[:2]
+        pred_pose = self.zero_pose.to(part_feats).expand(B, P, -1)
+        class_list = self._gather_same_class(data_dict)
+        rots, transs = [], []
+        for it in range(self.iter):
+            if it == 0:
+                feats_in, relation = part_feats, valid_matrix  # fully connected start
+            else:
+                pose_feats = self.pose_extractor(pred_pose)
+                feats_in = part_feats
+                if self.merge_node and self.semantic and it % 2 == 1:
+                    feats_in, pose_feats = self._merge_nodes(part_feats, pose_feats, class_list)
+                relation = self._update_relation(pose_feats, it) * valid_matrix
+            messages = self._message_passing(feats_in, relation, it)
+            part_feats = self._node_update(part_feats, messages.type_as(part_feats), data_dict, it)
+            rot, trans = self.pose_predictors[it](torch.cat([part_feats, part_label, instance_label, pred_pose], dim=-1))
+            pred_pose = torch.cat([rot, trans], dim=-1)
+            rots.append(rot)
+            transs.append(trans)
+        if self.training:
+            rot, trans = self._wrap_rotation(torch.stack(rots, dim=0)), torch.stack(transs, dim=0)
+        else:
+            rot, trans = self._wrap_rotation(rots[-1]), transs[-1]
+        return {"rot": rot, "trans": trans, "part_feats": local_feats, "class_list": class_list}
+
+    def _loss_function(self, data_dict, out_dict={}, optimizer_idx=-1):
+        """Loss of every iteration's prediction, summed (dgl/network.py:245-297); `part_feats` / `class_list` are
+        reused across MoN samples."""
+        pred = self.forward({k: data_dict[k] for k in ("part_pcs", "part_valids", "part_label", "instance_label",
+                                                      "part_ids", "valid_matrix")}
+                            | {"part_feats": out_dict.get("part_feats", None),
+                               "class_list": out_dict.get("class_list", None)})
+        keep = {"part_feats": pred["part_feats"], "class_list": pred["class_list"]}
+        if not self.training:
+            loss_dict, out = self._calc_loss(pred, data_dict)
+            out.update(keep)
+            return loss_dict, out
+        total, out = None, {}
+        for i in range(self.iter):
+            loss_dict, out = self._calc_loss({"rot": pred["rot"][i], "trans": pred["trans"][i]}, data_dict)
+            if total is None:
+                total = {k: 0.0 for k in loss_dict}
+            for k, v in loss_dict.items():
+                total[k] = total[k] + v
+                total[f"{k}_{i}"] = v
+        out.update(keep)
+        return total, out
+
+
+class _MaskedBiGRU(nn.Module):
+    """`RNNWrapper(nn.GRU(bidirectional))` of the reference (modules/rnn.py:6-46) with the same `.rnn` sub-module
+    (state_dict keys) but without `pack_padded_sequence`: the reference packs by `valids.sum(1).cpu()` — a device
+    sync per iteration.  Valid parts come first in every sample, so the forward direction over the padded batch
+    already equals the packed run on the valid steps; the reverse direction is run on the per-sample REVERSED valid
+    prefix (a gather built on the device).  Padded steps output zeros, as `pad_packed_sequence` does."""
+
+    def __init__(self, rnn, batch_first=True):
+        super().__init__()
+        assert batch_first and rnn.bidirectional and rnn.num_layers == 1
+        self.rnn = rnn
+        self.batch_first = batch_first
+
+    def forward(self, x, hidden=None, valids=None):
+        if valids is None:
+            return self.rnn(x, hidden)
+        B, T, _ = x.shape
+        H = self.rnn.hidden_size
+        lengths = valids.sum(dim=1).long()                                    # [B], stays on the device
+        steps = torch.arange(T, device=x.device)[None].expand(B, T)
+        rev_idx = torch.where(steps < lengths[:, None], lengths[:, None] - 1 - steps, steps)
+        x_rev = torch.gather(x, 1, rev_idx[..., None].expand_as(x))
+        w = self.rnn
+        fwd = torch._VF.gru(x, hidden[0:1].contiguous(), [w.weight_ih_l0, w.weight_hh_l0, w.bias_ih_l0, w.bias_hh_l0],
+                            True, 1, 0.0, self.training, False, True)[0]
+        bwd = torch._VF.gru(x_rev, hidden[1:2].contiguous(),
+                            [w.weight_ih_l0_reverse, w.weight_hh_l0_reverse, w.bias_ih_l0_reverse,
+                             w.bias_hh_l0_reverse], True, 1, 0.0, self.training, False, True)[0]
+        bwd = torch.gather(bwd, 1, rev_idx[..., None].expand(B, T, H))       # back to part order
+        out = torch.cat([fwd, bwd], dim=-1) * (steps < lengths[:, None])[..., None].to(x.dtype)
+        return out, None
+
+
+class RGLNet(DGLModel):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        gru = nn.GRU(input_size=2 * self.pc_feat_dim, hidden_size=2 * self.pc_feat_dim, num_layers=1, batch_first=True,
+                     dropout=0, bidirectional=True)
+        self.grus = _clones(_MaskedBiGRU(gru), self.iter)
+
+    def _init_node_mlps(self):
+        # consumes the GRU's 4F outputs; no ReLU after the last BatchNorm (rgl_net/modules.py:24-28)
+        return _clones(_PairMLP(4 * self.pc_feat_dim, self.pc_feat_dim, final_relu=False), self.iter)
+
+    def _init_gru_hidden(self, B):
+        """Same random draws, in the same order, as rgl_net/network.py:50-57 (CPU generator)."""
+        rand_vec = torch.randn((1, B, self.pc_feat_dim)).repeat(2, 1, 1)
+        zero_vec = torch.randn((2, B, self.pc_feat_dim))
+        return torch.cat([rand_vec, zero_vec], dim=-1)
+
+    def _node_update(self, part_feats, messages, data_dict, iter_ind):
+        hidden = self._init_gru_hidden(part_feats.shape[0]).type_as(messages)
+        gru_out, _ = self.grus[iter_ind](torch.cat([part_feats, messages], dim=-1), hidden,
+                                         valids=data_dict["part_valids"])
+        return self.node_mlps[iter_ind](gru_out)

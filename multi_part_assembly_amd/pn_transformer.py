@@ -68,7 +68,16 @@ class PNTransformer(BaseModel):
 
 
 def build_model(cfg):
-    """Registry of reference models/__init__.py:10-26 restricted to what is built so far."""
+    """Registry of reference models/__init__.py:10-26 (the LSTM / identity baselines are out of scope)."""
     if cfg.model.name == "pn_transformer":
         return PNTransformer(cfg)
+    if cfg.model.name == "global":
+        from .global_model import GlobalModel
+        return GlobalModel(cfg)
+    if cfg.model.name == "dgl":
+        from .gnn import DGLModel
+        return DGLModel(cfg)
+    if cfg.model.name == "rgl_net":
+        from .gnn import RGLNet
+        return RGLNet(cfg)
     raise NotImplementedError(f"Model {cfg.model.name} not supported")

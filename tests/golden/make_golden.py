@@ -326,6 +326,88 @@ def gen_pn_transformer_step():
     save("pn_transformer_step", **out)
 
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_cfg(rel_dir, module_name):
+    sys.path.insert(0, os.path.join(shim.REFERENCE_ROOT, rel_dir))
+    return importlib.import_module(module_name).get_cfg_defaults()
+
+
+def _model_step(name, cfg, data, seed, extra=None):
+    """One training-mode `forward_pass` + backward of a reference model built by `build_model(cfg)`.  The weights
+    come from `param_fill.fill_parameters` (rebuilt from the names by the test, not stored); recorded: data, every
+    loss term, parameter gradients and the buffers after the step (compact form for large tensors).
+    `torch.manual_seed(seed + 1)` right before the pass fixes the draws the models make on the CPU generator
+    (MoN noise, randperm of the matcher, GRU init)."""
+    from multi_part_assembly.models import build_model
+    import param_fill
+
+    torch.manual_seed(seed)
+    model = build_model(cfg)
+    param_fill.fill_parameters(model, seed)
+    zero_dropout(model)
+    out = {f"data.{k}": npy(v) for k, v in data.items()}
+    out["seed"] = np.array([seed])
+    out["names"] = np.array(sorted(model.state_dict().keys()))
+    out.update(extra or {})
+    model.train()
+    torch.manual_seed(seed + 1)
+    loss_dict = model.forward_pass({k: v.clone() for k, v in data.items()}, mode="val", optimizer_idx=-1)
+    loss_dict["loss"].backward()
+    for k, v in loss_dict.items():
+        if torch.is_tensor(v):
+            out[f"loss.{k}"] = npy(v)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            out.update(param_fill.compact("grad.", k, npy(p.grad)))
+    for k, v in model.state_dict().items():
+        if "running_" in k:
+            out.update(param_fill.compact("sd1.", k, npy(v)))
+    save(name, **out)
+
+
+def gen_dgl_step():
+    """DGL on geometric data (configs/dgl/dgl-32x1-cosine_200e-everyday.py), widths shrunk."""
+    cfg = _load_cfg("configs/dgl", "dgl-32x1-cosine_200e-everyday")
+    cfg.model.pc_feat_dim = 64
+    cfg.data.max_num_part = 5
+    g = torch.Generator().manual_seed(1008)
+    data = synthetic_batch(g, 3, 5, 64, [2, 4, 5])
+    _model_step("dgl_step", cfg, data, 1008, {"cfg": np.array([64, 3])})
+
+
+def gen_rgl_net_step():
+    """RGL-NET on geometric data (configs/rgl_net/rgl_net-32x1-cosine_200e-everyday.py), widths shrunk."""
+    cfg = _load_cfg("configs/rgl_net", "rgl_net-32x1-cosine_200e-everyday")
+    cfg.model.pc_feat_dim = 64
+    cfg.data.max_num_part = 5
+    g = torch.Generator().manual_seed(1009)
+    data = synthetic_batch(g, 3, 5, 64, [2, 4, 5])
+    _model_step("rgl_net_step", cfg, data, 1009, {"cfg": np.array([64, 3])})
+
+
+def gen_global_semantic_step():
+    """B-Global on semantic data (configs/global/global-32x1-cosine_200e-partnet_chair.py): Hungarian matching
+    inside groups of identical parts + min-of-5 sampling with 32 noise channels (BASELINE.json configs[0])."""
+    cfg = _load_cfg("configs/global", "global-32x1-cosine_200e-partnet_chair")
+    cfg.model.pc_feat_dim = 64
+    cfg.data.max_num_part = 5
+    g = torch.Generator().manual_seed(1010)
+    B, P, N = 2, 5, 128
+    data = synthetic_batch(g, B, P, N, [4, 5])
+    match_ids = torch.tensor([[0, 1, 1, 0, 0], [1, 1, 2, 2, 2]])
+    # geometrically equivalent parts share one point cloud (what makes the matching meaningful)
+    for b in range(B):
+        for gid in range(1, int(match_ids[b].max()) + 1):
+            members = torch.nonzero(match_ids[b] == gid).flatten().tolist()
+            for m in members[1:]:
+                data["part_pcs"][b, m] = data["part_pcs"][b, members[0]]
+    data["match_ids"] = match_ids
+    data["instance_label"] = torch.eye(P)[None].repeat(B, 1, 1) * data["part_valids"][..., None]
+    _model_step("global_semantic_step", cfg, data, 1010, {"cfg": np.array([64])})
+
+
 # --------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -343,6 +425,9 @@ def main():
         "dgcnn": lambda: gen_encoder("dgcnn", 128, 3, 96, 1005),
         "transformer": gen_transformer,
         "pn_transformer_step": gen_pn_transformer_step,
+        "dgl_step": gen_dgl_step,
+        "rgl_net_step": gen_rgl_net_step,
+        "global_semantic_step": gen_global_semantic_step,
     }
     for name, fn in todo.items():
         if not only or name in only:

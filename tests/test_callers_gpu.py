@@ -1,0 +1,64 @@
+"""GPU parity of the hot path's other callers: one training-mode forward_pass +
+backward of DGL, RGL-NET (geometric data, 3 GNN iterations, loss summed over the iterations) and B-Global
+(semantic data: Hungarian matching inside groups of identical parts, min-of-5 sampling, 32 noise channels) against
+fixtures captured from the reference's own `build_model(cfg)` (tests/golden/make_golden.py).  Weights are rebuilt
+from the parameter names by `param_fill` on both sides; the draws on the CPU generator (noise, randperm, GRU
+initial state) are reproduced by seeding it identically."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import param_fill  # noqa: E402
+
+from multi_part_assembly_amd import config  # noqa: E402
+from multi_part_assembly_amd.pn_transformer import build_model  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "dgl_step": config.dgl_everyday,
+    "rgl_net_step": config.rgl_net_everyday,
+    "global_semantic_step": config.global_partnet_chair,
+}
+# Gradient tolerance.  The GNN callers stack 3 iterations of 512-wide BatchNorm + ReLU MLPs whose statistics come
+# from 15-75 positions at the fixture's size: measured on this implementation alone, a 1e-6 relative perturbation
+# of the input moves individual parameter gradients by up to 4 % (tools/debug_callers.py) while every loss term
+# moves by 1e-5.  So the losses (all iterations) are held to 2e-4 and the gradients to 8 % — a wiring error (wrong
+# pair order, missing relation gate, detached pose) shows up as an O(1) mismatch.
+GRAD_REL = {"dgl_step": 8e-2, "rgl_net_step": 8e-2, "global_semantic_step": 2e-3}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_caller_step_matches_reference(golden, cuda_device, name):
+    z = golden(name)
+    cfg = CASES[name]()
+    cfg.model.pc_feat_dim = int(z["cfg"][0])
+    cfg.data.max_num_part = 5
+    seed = int(z["seed"][0])
+    torch.manual_seed(seed)
+    model = build_model(cfg)
+    assert sorted(model.state_dict().keys()) == [str(n) for n in z["names"]]  # same state_dict keys as upstream
+    param_fill.fill_parameters(model, seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.to(cuda_device).train()
+    data = {k[5:]: torch.from_numpy(z[k].copy()).to(cuda_device) for k in z if k.startswith("data.")}
+    torch.manual_seed(seed + 1)
+    res = model.forward_pass(data, mode="train")
+    res["loss"].backward()
+    for k in z:
+        if k.startswith("loss."):
+            np.testing.assert_allclose(float(res[k[5:]]), float(z[k]), rtol=2e-4, atol=1e-6, err_msg=k)
+    record = dict(z)
+    for k, p in model.named_parameters():
+        if ("grad." + k) in record or ("grad." + k + "#sample") in record:
+            assert p.grad is not None, k
+            param_fill.compare(record, "grad.", k, p.grad.cpu().numpy(), rel=GRAD_REL[name], floor=1e-4)
+    for k, v in model.state_dict().items():
+        if "running_" in k:
+            param_fill.compare(record, "sd1.", k, v.cpu().numpy(), rel=1e-4)
