@@ -181,6 +181,31 @@ int mpa_pointnet_backward(const float* grad_feat, const float* points, const flo
                           float* const* grad_bn_w, float* const* grad_bn_b, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * DGCNN building blocks — replace
+ *   knn / get_graph_feature : multi_part_assembly/models/modules/encoder/dgcnn.py:8-38
+ *   one EdgeConv stage      : dgcnn.py:76-100 (Conv2d 1x1 over [x_j - x_i ; x_i], BatchNorm2d, LeakyReLU 0.2, max_k)
+ * x [n*N, C] point-major features of n clouds of N points (C = 3, 64 or 128).  mpa_knn writes, per point, the
+ * indices (inside its cloud, best first, the point itself included) of its k = 20 nearest neighbours in feature
+ * space, scored as the reference does (-|x_j|^2 + 2 x_i.x_j - |x_i|^2); equal scores keep the lower index first.
+ *
+ * Edge aggregation: the 1x1 convolution is linear in the edge feature, W [x_j - x_i ; x_i] = U_j + V_i with
+ * [U | V] = X [Wa ; Wb - Wa]^T computed by the caller as ONE GEMM per point (uv [n*N, 2*CO]); the kernels gather
+ * the k neighbour rows of U, apply BatchNorm2d (training != 0: statistics over all n*N*k edges, running statistics
+ * updated with `momentum`; else the running statistics) + LeakyReLU(0.2) and take the max over the neighbours:
+ * out [n*N, CO].  CO a multiple of 64 (<= 1024), k <= 32, N <= 65535.  `ws` (mpa_edge_aggregate_workspace bytes,
+ * 256-byte aligned) carries the selected edges to backward, which overwrites grad_uv [n*N, 2*CO] (fp32 atomic
+ * scatter over neighbours, like the reference's gather backward), grad_gamma and grad_beta [CO].
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_knn(const float* x, int64_t n, int64_t N, int64_t C, int64_t K, int32_t* idx, void* stream);
+int mpa_edge_aggregate_workspace(int64_t n, int64_t N, int64_t CO, int64_t* bytes);
+int mpa_edge_aggregate_forward(const float* uv, const int32_t* idx, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int training, float momentum, float eps,
+                               int64_t n, int64_t N, int64_t CO, int64_t K, void* ws, float* out, void* stream);
+int mpa_edge_aggregate_backward(const float* grad_out, const float* uv, const int32_t* idx, const float* gamma,
+                                int64_t n, int64_t N, int64_t CO, int64_t K, void* ws, float* grad_uv,
+                                float* grad_gamma, float* grad_beta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Part-relation transformer encoder — replaces
  *   TransformerEncoder.forward : multi_part_assembly/models/pn_transformer/transformer.py:63-79
  *   (nn.TransformerEncoder of pre-LN nn.TransformerEncoderLayer, ReLU FFN, batch_first,

@@ -42,6 +42,10 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_pointnet_workspace": (_INT, [_I64, _I64, _I64, _P, _P]),
     "mpa_pointnet_forward": (_INT, [_P] * 7 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
     "mpa_pointnet_backward": (_INT, [_P] * 5 + [_I64, _I64, _I64] + [_P] * 6),
+    "mpa_knn": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P]),
+    "mpa_edge_aggregate_workspace": (_INT, [_I64, _I64, _I64, _P]),
+    "mpa_edge_aggregate_forward": (_INT, [_P] * 6 + [_INT, _F32, _F32, _I64, _I64, _I64, _I64, _P, _P, _P]),
+    "mpa_edge_aggregate_backward": (_INT, [_P] * 4 + [_I64] * 4 + [_P] * 5),
     "mpa_transformer_workspace": (_INT, [_I64] * 6 + [_P]),
     "mpa_transformer_forward": (_INT, [_P, _P, _P] + [_I64] * 6 + [_F32, _U64, _P, _P, _P, _P]),
     "mpa_transformer_backward": (_INT, [_P, _P, _P] + [_I64] * 6 + [_F32, _U64, _P, _P, _P, _P, _P]),

@@ -1,0 +1,87 @@
+// Cooperative fixed-order column reduction shared by the PointNet and DGCNN kernels (BatchNorm statistics and
+// BatchNorm-backward coefficients are sums over per-block partial tables).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace mpa {
+
+constexpr int kSlices = 16;  // row slices per block of the reduction kernels (64 channels x 16 = 1024 threads)
+
+// Sum per-block (sum0, sum1) partial tables over their rows for 64 channels — cooperatively: a single CU
+// streaming the M*splits x 64 x 2 table takes ~25-50 us, so the table is cut into groups of kEB rows, one
+// block (64 channels x 16 slices) per group and channel panel (grid = (C/64, G)).  Every block leaves its
+// fp64 group sums in `stage`, takes a ticket, and the LAST block of the panel adds the G group sums in fixed
+// order: deterministic, one launch.  Returns true in that block only (totals valid for threads < 64).
+constexpr int kEB = 64;  // table rows per block
+
+struct CoopWs {
+  double* stage;       // [G][C][2]
+  unsigned* ticket;    // [C/64], zero between launches
+};
+
+// row(e, ok, x, y): the two addends of table row e (ok = false: skip the row)
+template <typename Row>
+__device__ __forceinline__ bool coop_colsum(int total, int C, int c, const CoopWs ws, Row row, double& s0,
+                                            double& s1) {
+  __shared__ double sm[kSlices][64][2];
+  __shared__ bool last;
+  const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int g = blockIdx.y, G = gridDim.y;
+  constexpr int U = kEB / kSlices;
+  double x[U], y[U];
+  bool ok[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {  // independent loads
+    const int e = g * kEB + slice + u * kSlices;
+    row(e < total ? e : total - 1, ok[u], x[u], y[u]);
+    ok[u] = ok[u] && e < total;
+  }
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (ok[u]) {
+      a += x[u];
+      b += y[u];
+    }
+  }
+  sm[slice][cl][0] = a;
+  sm[slice][cl][1] = b;
+  __syncthreads();
+  if (slice == 0) {
+    a = b = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSlices; ++k) {
+      a += sm[k][cl][0];
+      b += sm[k][cl][1];
+    }
+    ws.stage[((long long)g * C + c) * 2] = a;
+    ws.stage[((long long)g * C + c) * 2 + 1] = b;
+    __threadfence();  // release: the group sums are visible device-wide before the ticket is taken
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(ws.ticket + blockIdx.x, 1u) == (unsigned)(G - 1);
+  __syncthreads();
+  if (!last) return false;
+  __threadfence();  // acquire
+  a = b = 0.0;
+  for (int gg = slice; gg < G; gg += kSlices) {
+    a += ws.stage[((long long)gg * C + c) * 2];
+    b += ws.stage[((long long)gg * C + c) * 2 + 1];
+  }
+  sm[slice][cl][0] = a;
+  sm[slice][cl][1] = b;
+  __syncthreads();
+  s0 = s1 = 0.0;
+  if (slice == 0) {
+#pragma unroll
+    for (int k = 0; k < kSlices; ++k) {
+      s0 += sm[k][cl][0];
+      s1 += sm[k][cl][1];
+    }
+  }
+  if (threadIdx.x == 0) ws.ticket[blockIdx.x] = 0u;  // ready for the next launch
+  return true;
+}
+
+}  // namespace mpa

@@ -26,11 +26,15 @@
 //     parts summed by a second deterministic stage).  The 3-channel first layer uses scalar-operand
 //     VALU panels (weights through the scalar cache), K = 3 being far too thin for a matrix core.
 #include "common.h"
+#include "coop_reduce.h"
 
 namespace {
 
 constexpr int kT = 256;      // threads per block (4 waves)
-constexpr int kSlices = 16;  // m-slices in the per-channel reduction kernels (64 channels x 16 = 1024 thr)
+using mpa::CoopWs;
+using mpa::coop_colsum;
+using mpa::kEB;
+using mpa::kSlices;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -70,82 +74,6 @@ __global__ void pn_count_kernel(const float* __restrict__ valids, int M, int N, 
   for (int m = threadIdx.x; m < M; m += 64) s += valids[m] != 0.0f ? 1.0f : 0.0f;
   s = wave_sum(s);
   if (threadIdx.x == 0) count[0] = s * (float)N;
-}
-
-// Sum the per-block (sum0, sum1) partials of 64 channels over all valid parts — cooperatively: a single CU
-// streaming the M*splits x 64 x 2 table takes ~25-50 us, so the table is cut into groups of kEB rows, one
-// block (64 channels x 16 slices) per group and channel panel (grid = (C/64, G)).  Every block leaves its
-// fp64 group sums in `stage`, takes a ticket, and the LAST block of the panel adds the G group sums in fixed
-// order: deterministic, one launch.  Returns true in that block only (totals valid for threads < 64).
-constexpr int kEB = 64;  // table rows per block
-
-struct CoopWs {
-  double* stage;       // [G][C][2]
-  unsigned* ticket;    // [C/64], zero between launches
-};
-
-// row(e, ok, x, y): the two addends of table row e (ok = false: skip the row)
-template <typename Row>
-__device__ __forceinline__ bool coop_colsum(int total, int C, int c, const CoopWs ws, Row row, double& s0,
-                                            double& s1) {
-  __shared__ double sm[kSlices][64][2];
-  __shared__ bool last;
-  const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int g = blockIdx.y, G = gridDim.y;
-  constexpr int U = kEB / kSlices;
-  double x[U], y[U];
-  bool ok[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {  // independent loads
-    const int e = g * kEB + slice + u * kSlices;
-    row(e < total ? e : total - 1, ok[u], x[u], y[u]);
-    ok[u] = ok[u] && e < total;
-  }
-  double a = 0.0, b = 0.0;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    if (ok[u]) {
-      a += x[u];
-      b += y[u];
-    }
-  }
-  sm[slice][cl][0] = a;
-  sm[slice][cl][1] = b;
-  __syncthreads();
-  if (slice == 0) {
-    a = b = 0.0;
-#pragma unroll
-    for (int k = 0; k < kSlices; ++k) {
-      a += sm[k][cl][0];
-      b += sm[k][cl][1];
-    }
-    ws.stage[((long long)g * C + c) * 2] = a;
-    ws.stage[((long long)g * C + c) * 2 + 1] = b;
-    __threadfence();  // release: the group sums are visible device-wide before the ticket is taken
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(ws.ticket + blockIdx.x, 1u) == (unsigned)(G - 1);
-  __syncthreads();
-  if (!last) return false;
-  __threadfence();  // acquire
-  a = b = 0.0;
-  for (int gg = slice; gg < G; gg += kSlices) {
-    a += ws.stage[((long long)gg * C + c) * 2];
-    b += ws.stage[((long long)gg * C + c) * 2 + 1];
-  }
-  sm[slice][cl][0] = a;
-  sm[slice][cl][1] = b;
-  __syncthreads();
-  s0 = s1 = 0.0;
-  if (slice == 0) {
-#pragma unroll
-    for (int k = 0; k < kSlices; ++k) {
-      s0 += sm[k][cl][0];
-      s1 += sm[k][cl][1];
-    }
-  }
-  if (threadIdx.x == 0) ws.ticket[blockIdx.x] = 0u;  // ready for the next launch
-  return true;
 }
 
 // the (sum0, sum1) partial tables written by the forward / input-gradient kernels; rows of padded parts hold

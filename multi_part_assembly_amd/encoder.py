@@ -118,30 +118,70 @@ class PointNet(nn.Module):
         return self.forward_parts(x, torch.ones(x.shape[0], device=x.device))
 
 
-def knn(x, k):
-    """Indices [n, N, k] of the k nearest points (self included) in feature space; x [n, C, N].
+def knn_indices(x, n, N, k=20):
+    """x [n*N, C] point-major features -> int32 [n*N, k] neighbour indices inside each cloud (csrc/dgcnn.hip)."""
+    R, C = x.shape
+    idx = torch.empty((R, k), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        tok = _lib.KernelTimer.start(f"knn[{n}x{N}x{C}]")
+        st = _lib.lib().mpa_knn(_lib.ptr(x), n, N, C, k, _lib.ptr(idx), _lib.current_stream(x.device))
+        _lib.KernelTimer.stop(tok)
+    _lib.check(st, "mpa_knn")
+    return idx
 
-    Same Gram-form scores as the reference (dgcnn.py:8-15) so the neighbour SETS agree; the order
-    inside k is irrelevant downstream (max over k)."""
-    inner = torch.matmul(x.transpose(2, 1), x)
-    sq = (x * x).sum(dim=1, keepdim=True)
-    score = -sq - (-2 * inner) - sq.transpose(2, 1)
-    return score.topk(k=k, dim=-1)[1]
 
+class _EdgeAggFn(torch.autograd.Function):
+    """BatchNorm2d + LeakyReLU(0.2) + max over the k neighbours of the edge values U_j + V_i (csrc/dgcnn.hip)."""
 
-def get_graph_feature(x, k=20):
-    """Edge features [x_j - x_i ; x_i] for the kNN graph: x [n, C, N] -> [n, 2C, N, k]."""
-    n, C, N = x.shape
-    idx = knn(x, k)
-    pts = x.transpose(2, 1)                                            # [n, N, C]
-    nbr = torch.gather(pts[:, None].expand(n, N, N, C), 2, idx[..., None].expand(n, N, k, C))
-    ctr = pts[:, :, None].expand(n, N, k, C)
-    return torch.cat((nbr - ctr, ctr), dim=3).permute(0, 3, 1, 2).contiguous()
+    @staticmethod
+    def forward(ctx, uv, idx, gamma, beta, running, training, momentum, eps, n, N):
+        R, CO2 = uv.shape
+        CO, K = CO2 // 2, idx.shape[1]
+        dev = uv.device
+        lib = _lib.lib()
+        nbytes = ctypes.c_int64()
+        _lib.check(lib.mpa_edge_aggregate_workspace(n, N, CO, ctypes.byref(nbytes)), "mpa_edge_aggregate_workspace")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        out = torch.empty((R, CO), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"edge_aggregate_forward[{n}x{N}x{CO}]")
+            st = lib.mpa_edge_aggregate_forward(_lib.ptr(uv), _lib.ptr(idx), _lib.ptr(gamma), _lib.ptr(beta),
+                                                _lib.ptr(running[0]), _lib.ptr(running[1]), int(training),
+                                                float(momentum), float(eps), n, N, CO, K, _lib.ptr(ws), _lib.ptr(out),
+                                                _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_edge_aggregate_forward")
+        ctx.dims = (n, N, CO, K, bool(training))
+        ctx.save_for_backward(uv, idx, gamma, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        uv, idx, gamma, ws = ctx.saved_tensors
+        n, N, CO, K, training = ctx.dims
+        if not training:
+            raise RuntimeError("EdgeConv: backward is implemented for training-mode BatchNorm only")
+        dev = uv.device
+        guv = torch.empty_like(uv)
+        ggamma, gbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"edge_aggregate_backward[{n}x{N}x{CO}]")
+            st = _lib.lib().mpa_edge_aggregate_backward(
+                _lib.ptr(grad_out.contiguous()), _lib.ptr(uv), _lib.ptr(idx), _lib.ptr(gamma), n, N, CO, K, _lib.ptr(ws),
+                _lib.ptr(guv), _lib.ptr(ggamma), _lib.ptr(gbeta), _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_edge_aggregate_backward")
+        return (guv, None, ggamma, gbeta, None, None, None, None, None, None)
 
 
 class DGCNN(nn.Module):
     """4 EdgeConv stages (k=20, widths 64-64-128-256, LeakyReLU 0.2, max over k), concat 512 ->
-    1x1 conv -> [max ; mean] over N -> Linear."""
+    1x1 conv -> [max ; mean] over N -> Linear.
+
+    The sub-modules hold the parameters under the reference's names; the computation is point-major and never
+    builds an edge tensor: per stage one kNN kernel, ONE library GEMM per point (X -> [U | V], the 1x1 convolution
+    being linear in the edge feature) and the fused gather + BatchNorm2d + LeakyReLU + max kernels of csrc/dgcnn.hip.
+    The tail (512 -> F convolution, BatchNorm1d, pooling, Linear) is plain library ops."""
 
     def __init__(self, feat_dim, global_feat=True):
         super().__init__()
@@ -158,16 +198,40 @@ class DGCNN(nn.Module):
         if global_feat:
             self.out_fc = nn.Linear(feat_dim * 2, feat_dim)
 
+    def _edge_stage(self, h, conv, n, N):
+        """h [n*N, C] -> [n*N, CO]."""
+        bn = conv[1]
+        C = h.shape[1]
+        w = conv[0].weight[:, :, 0, 0]                               # [CO, 2C] acting on [x_j - x_i ; x_i]
+        w_stack = torch.cat([w[:, :C], w[:, C:] - w[:, :C]], dim=0)   # [2CO, C]: U = X Wa^T, V = X (Wb - Wa)^T
+        idx = knn_indices(h.detach().contiguous(), n, N)
+        if self.training:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+        return _EdgeAggFn.apply(h @ w_stack.t(), idx, bn.weight, bn.bias, (bn.running_mean, bn.running_var),
+                                self.training, bn.momentum, bn.eps, n, N)
+
     def forward(self, x):
-        h = x.transpose(2, 1).contiguous()
+        """x [n, N, 3] -> [n, feat_dim] (global feature) or [n, N, feat_dim]."""
+        if not x.is_cuda:
+            raise RuntimeError("DGCNN: only CUDA (HIP) tensors are supported — no CPU fallback")
+        n, N, _ = x.shape
+        h = x.reshape(n * N, 3).float()
         stages = []
         for conv in (self.conv1, self.conv2, self.conv3, self.conv4):
-            h = conv(get_graph_feature(h)).max(dim=-1)[0]
+            h = self._edge_stage(h, conv, n, N)
             stages.append(h)
-        h = self.conv5(torch.cat(stages, dim=1))
+        y = torch.cat(stages, dim=1) @ self.conv5[0].weight[:, :, 0].t()          # [n*N, F]
+        bn = self.bn5
+        y = F.leaky_relu(F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, self.training,
+                                      bn.momentum, bn.eps), 0.2)
+        if self.training:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+        y = y.view(n, N, -1)
         if not self.global_feat:
-            return h.transpose(2, 1).contiguous()
-        return self.out_fc(torch.cat((h.max(dim=-1)[0], h.mean(dim=-1)), dim=1))
+            return y
+        return self.out_fc(torch.cat((y.max(dim=1)[0], y.mean(dim=1)), dim=1))
 
 
 def build_encoder(arch, feat_dim, global_feat=True, **kwargs):
