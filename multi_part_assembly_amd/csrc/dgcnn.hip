@@ -80,19 +80,21 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ x, i
         dot = __builtin_fmaf(xq[4 * c4 + 3], t.w, dot);
       }
       const float s = (-tnorm[r] + 2.0f * dot) - nq;  // dgcnn.py:11-13: -xx - (-2 x^T x) - xx^T
-      if (s > bs[K - 1]) {  // insert, keeping the list sorted (descending; earlier index first among equals)
+      // insert, keeping the list sorted (descending; earlier index first among equals).  64 independent query
+      // streams share a wave, so some lane inserts at almost every candidate: the insertion is branch-free
+      // (a bubble of selects), and skipped only when no lane of the wave needs it.
+      if (__any(s > bs[K - 1])) {
         float cs = s;
         int cj = j0 + r;
 #pragma unroll
         for (int t = 0; t < K; ++t) {
-          if (cs > bs[t]) {
-            const float ts = bs[t];
-            const int tj = bj[t];
-            bs[t] = cs;
-            bj[t] = cj;
-            cs = ts;
-            cj = tj;
-          }
+          const bool g = cs > bs[t];
+          const float ts = bs[t];
+          const int tj = bj[t];
+          bs[t] = g ? cs : ts;
+          bj[t] = g ? cj : tj;
+          cs = g ? ts : cs;
+          cj = g ? tj : cj;
         }
       }
     }
