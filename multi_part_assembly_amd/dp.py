@@ -38,6 +38,7 @@ class BucketedGradReducer:
             self.buckets.append({"slice": flat.flat_grad[start:end], "count": size, "ready": 0})
             first += size
         self.pending = []
+        self._seen = set()
         self._owner = {}
         idx = 0
         for b, bucket in enumerate(self.buckets):
@@ -49,6 +50,12 @@ class BucketedGradReducer:
                 idx += 1
 
     def _on_grad(self, param):
+        """Gradient of `param` is final for this step.  Idempotent per step: a parameter whose gradient a HIP
+        backward kernel wrote directly is announced by the GradSink, and — depending on the torch version — also by
+        autograd's post-accumulate hook, which fires even when the Function returned None for that input."""
+        if id(param) in self._seen:
+            return
+        self._seen.add(id(param))
         bucket = self.buckets[self._owner[param]]
         bucket["ready"] += 1
         if bucket["ready"] == bucket["count"]:
@@ -67,6 +74,7 @@ class BucketedGradReducer:
             for work in self.pending:
                 work.wait()
             self.pending.clear()
+        self._seen.clear()
         return 1.0 / self.world
 
 
