@@ -142,6 +142,24 @@ class BaseModel(nn.Module):
 
     def loss_function(self, data_dict, optimizer_idx=-1):
         """Min-of-N over `sample_iter` stochastic predictions, per sample (base_model.py:348-387)."""
+        if self.sample_iter == 1:
+            # one prediction: stack the terms once and weight / average them with a handful of launches instead of
+            # five per term (the step is ~200 launches, these would be ~40 of them)
+            sample_loss, _ = self._loss_function(data_dict, {}, optimizer_idx=optimizer_idx)
+            keys = list(sample_loss)
+            terms = torch.stack([sample_loss[k] for k in keys], dim=0)                       # [K, B]
+            cache = getattr(self, "_loss_weight_cache", None)
+            if cache is None or cache[0] != keys or cache[1].device != terms.device:
+                w = [float(self.cfg.loss[f"{k}_w"]) if k.endswith("_loss") else 0.0 for k in keys]
+                cache = (keys, torch.tensor(w, dtype=terms.dtype, device=terms.device))
+                self._loss_weight_cache = cache
+            total = (terms * cache[1][:, None]).sum(dim=0)                                   # [B]
+            means = torch.cat([terms, total[None]], dim=0).mean(dim=1)                       # [K + 1]
+            result = {k: means[i] for i, k in enumerate(keys)}
+            result["loss"] = means[len(keys)]
+            if not self.training:
+                result["batch_size"] = total.shape[0]
+            return result
         samples, out_dict = None, {}
         for _ in range(self.sample_iter):
             sample_loss, out_dict = self._loss_function(data_dict, out_dict, optimizer_idx=optimizer_idx)

@@ -104,9 +104,8 @@ class PointNet(nn.Module):
         convs = [getattr(self, f"conv{i}") for i in range(1, 6)]
         bns = [getattr(self, f"bn{i}") for i in range(1, 6)]
         if self.training:
-            with torch.no_grad():
-                for bn in bns:
-                    bn.num_batches_tracked += 1
+            with torch.no_grad():  # one multi-tensor launch for the five counters
+                torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
         running = ([bn.running_mean for bn in bns], [bn.running_var for bn in bns])
         return _PointNetFn.apply(
             part_pcs.detach().float().contiguous(), valids.detach().float().contiguous(), self.training,
