@@ -6,8 +6,8 @@ Kept: the subclass contract (`forward(data_dict) -> {'rot': Rotation3D, 'trans':
 _calc_loss / _match_parts / _linear_sum_assignment / configure_optimizers`, the loss-term names and
 the weighting by `cfg.loss.<term>_w`.  Dropped: everything that needs a pl.Trainer (per-step
 `.item()` logging through `self.trainer.profiler`, base_model.py:137-146 — which also removes one
-device sync per loss term per step), wandb visualisation and the eval-only metrics (SURVEY.md §8
-row N2, next).
+device sync per loss term per step) and wandb visualisation.  The eval-time metrics (`_calc_metrics`,
+SURVEY.md §8 row N2) are in eval_utils.py.
 """
 from __future__ import annotations
 
@@ -17,6 +17,7 @@ import torch.nn as nn
 from scipy.optimize import linear_sum_assignment
 
 from .chamfer import chamfer_distance
+from .eval_utils import calc_connectivity_acc, calc_part_acc, rot_metrics, trans_metrics
 from .loss import (geometric_assembly_loss, rot_cosine_loss, rot_points_cd_loss,
                    rot_points_l2_loss, shape_cd_loss, trans_l2_loss)
 from .rotation import Rotation3D
@@ -118,6 +119,8 @@ class BaseModel(nn.Module):
                 loss_dict["rot_loss"] = terms["rot_loss"]
             if self.cfg.loss.use_rot_pt_l2_loss:
                 loss_dict["rot_pt_l2_loss"] = terms["rot_pt_l2_loss"]
+            if not self.training:
+                loss_dict.update(self._calc_metrics(data_dict, out_dict, new_trans, new_rot))
             out_dict = {"pred_trans": pred_trans, "pred_rot": pred_rot,
                         "pred_trans_pts": pts[0] if pts else None, "gt_trans_pts": pts[1] if pts else None}
             return loss_dict, out_dict
@@ -133,9 +136,34 @@ class BaseModel(nn.Module):
             loss_dict["rot_loss"] = rot_cosine_loss(pred_rot, new_rot, valids)
         if self.cfg.loss.use_rot_pt_l2_loss:
             loss_dict["rot_pt_l2_loss"] = rot_points_l2_loss(part_pcs, pred_rot, new_rot, valids)
+        if not self.training:
+            loss_dict.update(self._calc_metrics(data_dict, out_dict, new_trans, new_rot))
         out_dict = {"pred_trans": pred_trans, "pred_rot": pred_rot, "gt_trans_pts": gt_pts,
                     "pred_trans_pts": pred_pts}
         return loss_dict, out_dict
+
+    @torch.no_grad()
+    def _calc_metrics(self, data_dict, out_dict, gt_trans, gt_rot):
+        """Evaluation-time metrics (base_model.py:316-339): part accuracy always; connectivity accuracy for the
+        semantic datasets that annotate contacts; translation / rotation MSE, RMSE, MAE for geometric data."""
+        part_pcs, valids = data_dict["part_pcs"], data_dict["part_valids"]
+        pred_trans, pred_rot = out_dict["trans"], out_dict["rot"]
+        metrics = {"part_acc": calc_part_acc(part_pcs, pred_trans, gt_trans, pred_rot, gt_rot, valids)}
+        if self.semantic and "contact_points" in data_dict:
+            metrics["connectivity_acc"] = calc_connectivity_acc(pred_trans, pred_rot, data_dict["contact_points"])
+        if not self.semantic:
+            for m in ("mse", "rmse", "mae"):
+                metrics[f"trans_{m}"] = trans_metrics(pred_trans, gt_trans, valids, metric=m)
+                metrics[f"rot_{m}"] = rot_metrics(pred_rot, gt_rot, valids, metric=m)
+        return metrics
+
+    @staticmethod
+    def aggregate_eval(outputs, prefix="val"):
+        """Batch-size-weighted average of the per-batch dictionaries `validation_step` returns — what the
+        reference's `validation_epoch_end` logs (base_model.py:69-84)."""
+        sizes = torch.tensor([float(o["batch_size"]) for o in outputs], device=outputs[0]["loss"].device)
+        keys = [k for k in outputs[0] if k != "batch_size"]
+        return {f"{prefix}/{k}": (torch.stack([o[k] for o in outputs]) * sizes).sum() / sizes.sum() for k in keys}
 
     def _loss_function(self, data_dict, out_dict={}, optimizer_idx=-1):
         raise NotImplementedError

@@ -54,6 +54,13 @@ class Rotation3D:
     def to_quat(self):
         return self.convert("quat").rot
 
+    def to_euler(self, order="zyx", to_degree=True):
+        """Euler angles [..., 3] (reference rotation.py:201-204; only its default convention is provided)."""
+        if order != "zyx" or not to_degree:
+            raise NotImplementedError("only the 'zyx' / degree convention of the evaluation metrics is provided")
+        from .eval_utils import quat_to_euler_zyx_deg
+        return quat_to_euler_zyx_deg(self.to_quat())
+
     # --- tensor-like surface ------------------------------------------------------------------
     shape = property(lambda self: self._rot.shape)
     device = property(lambda self: self._rot.device)

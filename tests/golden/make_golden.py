@@ -408,6 +408,73 @@ def gen_global_semantic_step():
     _model_step("global_semantic_step", cfg, data, 1010, {"cfg": np.array([64])})
 
 
+def gen_eval_metrics(U):
+    """utils/eval_utils.py: part accuracy, translation / rotation metrics, connectivity accuracy; plus the
+    evaluation-mode forward_pass of PNTransformer (eval-mode SCD, metrics merged into the loss dict)."""
+    from multi_part_assembly.utils import eval_utils as E
+    from multi_part_assembly.utils import Rotation3D
+
+    g = torch.Generator().manual_seed(1011)
+    B, P, N = 3, 5, 64
+    data = synthetic_batch(g, B, P, N, [2, 4, 5])
+    valids = data["part_valids"]
+    gt_t, gt_q = data["part_trans"], data["part_quat"]
+    # predictions: exact for some parts, slightly off for others, far off for the rest
+    scale = torch.tensor([0.0, 0.003, 0.02, 0.3, 1.0])[None, :, None]
+    pr_t = gt_t + scale * torch.randn(B, P, 3, generator=g) * valids[..., None]
+    pr_q = torch.nn.functional.normalize(gt_q + scale * torch.randn(B, P, 4, generator=g), dim=-1) * valids[..., None]
+    r_gt, r_pr = Rotation3D(gt_q.clone(), rot_type="quat"), Rotation3D(pr_q.clone(), rot_type="quat")
+    out = {"pcs": npy(data["part_pcs"]), "valids": npy(valids), "gt_t": npy(gt_t), "gt_q": npy(gt_q),
+           "pr_t": npy(pr_t), "pr_q": npy(pr_q)}
+    out["part_acc"] = npy(E.calc_part_acc(data["part_pcs"], pr_t, gt_t, r_pr, r_gt, valids))
+    for m in ("mse", "rmse", "mae"):
+        out[f"trans_{m}"] = npy(E.trans_metrics(pr_t, gt_t, valids, m))
+        out[f"rot_{m}"] = npy(E.rot_metrics(r_pr, r_gt, valids, m))
+    out["euler_pr"] = npy(r_pr.to_euler(to_degree=True))
+    contact = torch.zeros(B, P, P, 4)
+    for b, k in enumerate([2, 4, 5]):
+        for i in range(k - 1):  # a chain of contacts; the contact point sits between the two GT centroids
+            mid = 0.5 * (gt_t[b, i] + gt_t[b, i + 1])
+            for a, c in ((i, i + 1), (i + 1, i)):
+                contact[b, a, c, 0] = 1.0
+                # the contact point in part a's own frame: under the GT pose of a it lands on `mid`
+                conj = gt_q[b, a] * torch.tensor([1.0, -1.0, -1.0, -1.0])
+                contact[b, a, c, 1:] = U.qrot(conj, mid - gt_t[b, a]) + 0.004 * torch.randn(3, generator=g)
+    out["contact_points"] = npy(contact)
+    out["connectivity_acc_pred"] = npy(E.calc_connectivity_acc(pr_t, r_pr, contact))
+    out["connectivity_acc_zero"] = npy(E.calc_connectivity_acc(torch.zeros_like(pr_t), Rotation3D(
+        torch.tensor([1.0, 0, 0, 0]).repeat(B, P, 1), rot_type="quat"), contact))
+    save("eval_metrics", **out)
+
+
+def gen_pn_transformer_eval():
+    """Evaluation-mode `forward_pass` of PNTransformer on the weights / data of the training-step fixture."""
+    from multi_part_assembly.models import build_model
+
+    sys.path.insert(0, os.path.join(shim.REFERENCE_ROOT, "configs/pn_transformer/pn_transformer"))
+    cfg = importlib.import_module("pn_transformer-32x1-cosine_400e-everyday").get_cfg_defaults()
+    cfg.model.pc_feat_dim = 64
+    cfg.model.transformer_feat_dim = 128
+    cfg.model.transformer_heads = 4
+    cfg.model.transformer_layers = 2
+    cfg.data.max_num_part = 5
+    import param_fill
+    torch.manual_seed(1012)
+    model = build_model(cfg)
+    param_fill.fill_parameters(model, 1012)
+    g = torch.Generator().manual_seed(1012)
+    data = synthetic_batch(g, 3, 5, 64, [2, 4, 5])
+    model.eval()
+    with torch.no_grad():
+        res = model.forward_pass({k: v.clone() for k, v in data.items()}, mode="val", optimizer_idx=-1)
+    out = {f"data.{k}": npy(v) for k, v in data.items()}
+    out["seed"] = np.array([1012])
+    out["cfg"] = np.array([64, 4, 128, 2])
+    for k, v in res.items():
+        out[f"res.{k}"] = npy(v) if torch.is_tensor(v) else np.array(v)
+    save("pn_transformer_eval", **out)
+
+
 # --------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -428,6 +495,8 @@ def main():
         "dgl_step": gen_dgl_step,
         "rgl_net_step": gen_rgl_net_step,
         "global_semantic_step": gen_global_semantic_step,
+        "eval_metrics": lambda: gen_eval_metrics(U),
+        "pn_transformer_eval": gen_pn_transformer_eval,
     }
     for name, fn in todo.items():
         if not only or name in only:
