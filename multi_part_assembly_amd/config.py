@@ -116,3 +116,18 @@ def global_partnet_chair():
     """configs/global/global-32x1-cosine_200e-partnet_chair.py (semantic data: matching + min-of-N)."""
     return Config(exp=_exp(200), data=partnet_chair(), optimizer=adam_cosine(), model=global_model(),
                   loss=semantic_loss())
+
+
+def pn_transformer_refine_model():
+    """configs/_base_/models/pn_transformer/pn_transformer_refine.py:5-19."""
+    return Config(name="pn_transformer_refine", rot_type="quat", pc_feat_dim=128, encoder="pointnet",
+                  transformer_pos_enc=(128, 128), transformer_feat_dim=512, transformer_heads=8,
+                  transformer_layers=2, transformer_pre_ln=True, pose_pc_feat=True, refine_steps=3)
+
+
+def pn_transformer_refine_everyday():
+    """configs/pn_transformer/pn_transformer_refine/pn_transformer_refine-32x1-cosine_400e-everyday.py."""
+    opt = adam_cosine()
+    opt.warmup_ratio = 0.05
+    return Config(exp=_exp(400), data=breaking_bad_everyday(), optimizer=opt, model=pn_transformer_refine_model(),
+                  loss=geometric_loss())

@@ -387,6 +387,19 @@ def gen_rgl_net_step():
     _model_step("rgl_net_step", cfg, data, 1009, {"cfg": np.array([64, 3])})
 
 
+def gen_pn_refine_step():
+    """PNTransformerRefine on geometric data (3 refinement rounds, loss summed over the rounds), widths shrunk."""
+    cfg = _load_cfg("configs/pn_transformer/pn_transformer_refine", "pn_transformer_refine-32x1-cosine_400e-everyday")
+    cfg.model.pc_feat_dim = 64
+    cfg.model.transformer_pos_enc = (64, 64)
+    cfg.model.transformer_feat_dim = 128
+    cfg.model.transformer_heads = 4
+    cfg.data.max_num_part = 5
+    g = torch.Generator().manual_seed(1013)
+    data = synthetic_batch(g, 3, 5, 64, [2, 4, 5])
+    _model_step("pn_refine_step", cfg, data, 1013, {"cfg": np.array([64, 4, 128])})
+
+
 def gen_global_semantic_step():
     """B-Global on semantic data (configs/global/global-32x1-cosine_200e-partnet_chair.py): Hungarian matching
     inside groups of identical parts + min-of-5 sampling with 32 noise channels (BASELINE.json configs[0])."""
@@ -495,6 +508,7 @@ def main():
         "dgl_step": gen_dgl_step,
         "rgl_net_step": gen_rgl_net_step,
         "global_semantic_step": gen_global_semantic_step,
+        "pn_refine_step": gen_pn_refine_step,
         "eval_metrics": lambda: gen_eval_metrics(U),
         "pn_transformer_eval": gen_pn_transformer_eval,
     }

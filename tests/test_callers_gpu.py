@@ -23,13 +23,14 @@ CASES = {
     "dgl_step": config.dgl_everyday,
     "rgl_net_step": config.rgl_net_everyday,
     "global_semantic_step": config.global_partnet_chair,
+    "pn_refine_step": config.pn_transformer_refine_everyday,
 }
 # Gradient tolerance.  The GNN callers stack 3 iterations of 512-wide BatchNorm + ReLU MLPs whose statistics come
 # from 15-75 positions at the fixture's size: measured on this implementation alone, a 1e-6 relative perturbation
 # of the input moves individual parameter gradients by up to 4 % (tools/debug_callers.py) while every loss term
 # moves by 1e-5.  So the losses (all iterations) are held to 2e-4 and the gradients to 8 % — a wiring error (wrong
 # pair order, missing relation gate, detached pose) shows up as an O(1) mismatch.
-GRAD_REL = {"dgl_step": 8e-2, "rgl_net_step": 8e-2, "global_semantic_step": 2e-3}
+GRAD_REL = {"dgl_step": 8e-2, "rgl_net_step": 8e-2, "global_semantic_step": 2e-3, "pn_refine_step": 2e-3}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -37,6 +38,9 @@ def test_caller_step_matches_reference(golden, cuda_device, name):
     z = golden(name)
     cfg = CASES[name]()
     cfg.model.pc_feat_dim = int(z["cfg"][0])
+    if name == "pn_refine_step":
+        cfg.model.transformer_pos_enc = (64, 64)
+        cfg.model.transformer_heads, cfg.model.transformer_feat_dim = int(z["cfg"][1]), int(z["cfg"][2])
     cfg.data.max_num_part = 5
     seed = int(z["seed"][0])
     torch.manual_seed(seed)
@@ -46,6 +50,8 @@ def test_caller_step_matches_reference(golden, cuda_device, name):
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
     model.to(cuda_device).train()
     data = {k[5:]: torch.from_numpy(z[k].copy()).to(cuda_device) for k in z if k.startswith("data.")}
     torch.manual_seed(seed + 1)
