@@ -7,10 +7,12 @@
 //   1. grid_params : bounding box of BOTH shapes' valid points -> one uniform grid per sample, <= 32768
 //                    cells (~1.5 points of each shape per cell), <= 64 cells per axis.  Covering the union
 //                    means no query is ever outside the grid.
-//   2. grid_count / grid_scan / grid_scatter : counting sort (global-memory histogram) of each shape,
+//   2. grid_sort   : counting sort of each shape, one 1024-thread block per (sample, shape) with both histograms
+//                    in LDS (count, scan, scatter in one launch),
 //                      role TARGET : by fine cell -> (x, y, z, original index) records + cell start offsets;
 //                                    cells are x-fastest, so a row of cells is one contiguous run of records;
-//                      role QUERY  : by SUPER-cell (2x2x2 fine cells) + a prefix of 64-query batches.
+//                      role QUERY  : by SUPER-cell (2x2x2 fine cells) + a prefix of 64-query batches and the
+//                                    work list (work item -> super-cell).
 //   3. grid_search : one wave per (super-cell, batch of <= 64 queries, 1 per lane).  All queries of the wave
 //                    lie inside one known box (the super-cell), so the candidate set is wave-uniform:
 //                      seed  — the super-cell grown by one fine cell per side;
@@ -172,39 +174,22 @@ __global__ __launch_bounds__(1024) void grid_params_kernel(const float* __restri
 }
 
 // ---- 2. counting sort.  slot = (b*2 + shape)*2 + role; role 0 = TARGET (fine cells), 1 = QUERY (super-cells) ------
-// count: grid = (P, 4*B), 256 threads; histogram in starts[slot][key] (zeroed by the caller).
-__global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict__ valids,
-                                                         const float* __restrict__ S1,
-                                                         const float* __restrict__ S2, int P, int N,
-                                                         const GridParams* __restrict__ params,
-                                                         int* __restrict__ starts) {
-  const int slot = blockIdx.y, role = slot & 1, c = (slot >> 1) & 1, b = slot >> 2, p = blockIdx.x;
-  if (valids[(long long)b * P + p] == 0.0f) return;
-  const GridParams g = params[b];
-  const float* cloud = (c == 0 ? S1 : S2) + 3LL * ((long long)b * P + p) * N;
-  int* cnt = starts + (long long)slot * kStartStride;
-  for (int n = threadIdx.x; n < N; n += 256)
-    atomicAdd(&cnt[key_of(g, role, cloud[3 * n], cloud[3 * n + 1], cloud[3 * n + 2])], 1);
-}
+// One block of 1024 threads per (sample, shape) does the whole sort of that shape's <= 20 000 points with its two
+// histograms (<= 32768 fine cells, <= 4096 super-cells: 144 KB) in LDS: count with LDS atomics, exclusive scan in
+// place (the starts go to global memory for the search kernel, together with the work list of the QUERY role),
+// scatter with the scanned array as cursor.  The order of the records inside a cell depends on the atomics; the
+// search result does not (lexicographic updates).
+constexpr int kMaxSuper = kMaxCells / 8;
 
-// scan: one block of 1024 threads per slot: counts -> exclusive starts (in place, nkeys+1 entries), a cursor copy,
-// and for QUERY slots the exclusive prefix of ceil(count / kBatch) (search work list).
-__global__ __launch_bounds__(1024) void grid_scan_kernel(const GridParams* __restrict__ params,
-                                                         int* __restrict__ starts, int* __restrict__ cursor,
-                                                         int* __restrict__ batches, int* __restrict__ worklist) {
-  __shared__ int wsum[16][2];
-  const int slot = blockIdx.x, role = slot & 1, b = slot >> 2;
-  const GridParams g = params[b];
-  const int nkeys = role == 0 ? g.ncells : g.nsuper;
-  int* st = starts + (long long)slot * kStartStride;
-  int* cu = cursor + (long long)slot * kStartStride;
-  int* ba = batches + (long long)slot * kStartStride;
-  int* wl = worklist + (long long)slot * kWorkStride;
-  constexpr int PER = kMaxCells / 1024;  // 32 keys per thread
+// exclusive scan of cnt[0..nkeys) in place, 1024 threads, PER consecutive keys per thread; returns through st_out
+// (nkeys + 1 entries).  WORK: also the prefix of ceil(count / kBatch) (ba_out) and the work list (wl_out).
+template <int PER, bool WORK>
+__device__ __forceinline__ void block_scan(int* __restrict__ cnt, int nkeys, int* __restrict__ st_out,
+                                           int* __restrict__ ba_out, int* __restrict__ wl_out, int (*wsum)[2]) {
   const int base = threadIdx.x * PER;
   int sum = 0, bsum = 0;
   for (int k = 0; k < PER; ++k) {
-    const int v = base + k < nkeys ? st[base + k] : 0;
+    const int v = base + k < nkeys ? cnt[base + k] : 0;
     sum += v;
     bsum += (v + kBatch - 1) / kBatch;
   }
@@ -217,6 +202,7 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(const GridParams* __res
       bincl += u;
     }
   }
+  __syncthreads();  // wsum may still be read by the previous scan
   if ((threadIdx.x & 63) == 63) {
     wsum[threadIdx.x >> 6][0] = incl;
     wsum[threadIdx.x >> 6][1] = bincl;
@@ -229,50 +215,74 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(const GridParams* __res
   }
   for (int k = 0; k < PER; ++k) {
     if (base + k < nkeys) {
-      const int v = st[base + k];
-      st[base + k] = run;
-      cu[base + k] = run;
-      if (role == 1) {
-        ba[base + k] = brun;
-        for (int i = 0; i < (v + kBatch - 1) / kBatch; ++i) wl[brun + i] = base + k;  // work item -> super-cell
+      const int v = cnt[base + k];
+      cnt[base + k] = run;  // becomes the scatter cursor
+      st_out[base + k] = run;
+      if (WORK) {
+        ba_out[base + k] = brun;
+        for (int i = 0; i < (v + kBatch - 1) / kBatch; ++i) wl_out[brun + i] = base + k;  // work item -> super-cell
       }
       run += v;
       brun += (v + kBatch - 1) / kBatch;
     }
   }
   if (threadIdx.x == 1023) {
-    st[nkeys] = run;
-    if (role == 1) ba[nkeys] = brun;
+    st_out[nkeys] = run;
+    if (WORK) ba_out[nkeys] = brun;
   }
 }
 
-// scatter: grid = (P, 4*B); records float4 (x, y, z, bits(flat index p*N+n)).
-__global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restrict__ valids,
-                                                           const float* __restrict__ S1,
-                                                           const float* __restrict__ S2, int P, int N,
-                                                           const GridParams* __restrict__ params,
-                                                           int* __restrict__ cursor,
-                                                           float4* __restrict__ records, int rec_stride) {
-  const int slot = blockIdx.y, role = slot & 1, c = (slot >> 1) & 1, b = slot >> 2, p = blockIdx.x;
+// grid = 2*B (blockIdx.x = b*2 + shape), block 1024.
+__global__ __launch_bounds__(1024) void grid_sort_kernel(const float* __restrict__ valids,
+                                                         const float* __restrict__ S1,
+                                                         const float* __restrict__ S2, int P, int N,
+                                                         const GridParams* __restrict__ params,
+                                                         int* __restrict__ starts, int* __restrict__ batches,
+                                                         int* __restrict__ worklist, float4* __restrict__ records,
+                                                         int rec_stride) {
+  __shared__ int cnt_t[kMaxCells];
+  __shared__ int cnt_q[kMaxSuper];
+  __shared__ int wsum[16][2];
+  const int b = blockIdx.x >> 1, c = blockIdx.x & 1;
   const GridParams g = params[b];
-  float4* out = records + (long long)slot * rec_stride;
-  if (role == 0 && p == 0 && threadIdx.x < 8) {  // sentinels: chunked reads may run past the last record
+  const int slot_t = (b * 2 + c) * 2 + 0, slot_q = slot_t + 1;
+  const float* vb = valids + (long long)b * P;
+  const float* shape = (c == 0 ? S1 : S2) + 3LL * b * P * N;
+  for (int i = threadIdx.x; i < g.ncells; i += 1024) cnt_t[i] = 0;
+  for (int i = threadIdx.x; i < g.nsuper; i += 1024) cnt_q[i] = 0;
+  __syncthreads();
+  for (int p = 0; p < P; ++p) {
+    if (vb[p] == 0.0f) continue;
+    const float* cloud = shape + 3LL * p * N;
+    for (int n = threadIdx.x; n < N; n += 1024) {
+      const float x = cloud[3 * n], y = cloud[3 * n + 1], z = cloud[3 * n + 2];
+      atomicAdd(&cnt_t[key_of(g, 0, x, y, z)], 1);
+      atomicAdd(&cnt_q[key_of(g, 1, x, y, z)], 1);
+    }
+  }
+  __syncthreads();
+  block_scan<kMaxCells / 1024, false>(cnt_t, g.ncells, starts + (long long)slot_t * kStartStride, nullptr, nullptr,
+                                      wsum);
+  block_scan<kMaxSuper / 1024, true>(cnt_q, g.nsuper, starts + (long long)slot_q * kStartStride,
+                                     batches + (long long)slot_q * kStartStride,
+                                     worklist + (long long)slot_q * kWorkStride, wsum);
+  __syncthreads();
+  float4* out_t = records + (long long)slot_t * rec_stride;
+  float4* out_q = records + (long long)slot_q * rec_stride;
+  if (threadIdx.x < 8) {  // sentinels: chunked reads may run past the last record
     const float inf = __builtin_inff();
-    out[g.nvalid + threadIdx.x] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
+    out_t[g.nvalid + threadIdx.x] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
   }
-  if (valids[(long long)b * P + p] == 0.0f) return;
-  const float* cloud = (c == 0 ? S1 : S2) + 3LL * ((long long)b * P + p) * N;
-  int* cu = cursor + (long long)slot * kStartStride;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const float x = cloud[3 * n], y = cloud[3 * n + 1], z = cloud[3 * n + 2];
-    const int pos = atomicAdd(&cu[key_of(g, role, x, y, z)], 1);
-    out[pos] = make_float4(x, y, z, __int_as_float(p * N + n));
+  for (int p = 0; p < P; ++p) {
+    if (vb[p] == 0.0f) continue;
+    const float* cloud = shape + 3LL * p * N;
+    for (int n = threadIdx.x; n < N; n += 1024) {
+      const float x = cloud[3 * n], y = cloud[3 * n + 1], z = cloud[3 * n + 2];
+      const float4 rec = make_float4(x, y, z, __int_as_float(p * N + n));
+      out_t[atomicAdd(&cnt_t[key_of(g, 0, x, y, z)], 1)] = rec;
+      out_q[atomicAdd(&cnt_q[key_of(g, 1, x, y, z)], 1)] = rec;
+    }
   }
-}
-
-__global__ void grid_zero_kernel(int4* __restrict__ p, long long n4) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
-    p[i] = make_int4(0, 0, 0, 0);
 }
 
 // ---- 3. search ----------------------------------------------------------------------------------------------------
@@ -590,8 +600,8 @@ int64_t grid_workspace_floats(int64_t B, int64_t P, int64_t N) {
   const int64_t rec = (P * N + 8) * 4;  // float4 records (+ sentinels) per slot
   return 4 * B * rec + B * (int64_t)(sizeof(GridParams) / 4) + 2 * B * P * N;  // + 2 distance arrays
 }
-int64_t grid_workspace_ints(int64_t B) {  // starts, cursor, batches, work list
-  return 3 * 4 * B * (int64_t)kStartStride + 4 * B * (int64_t)kWorkStride;
+int64_t grid_workspace_ints(int64_t B) {  // starts, batches, work list
+  return 2 * 4 * B * (int64_t)kStartStride + 4 * B * (int64_t)kWorkStride;
 }
 
 int launch_grid_shape_search(const float* valids, const float* S1, const float* S2, int64_t B, int64_t P,
@@ -603,17 +613,11 @@ int launch_grid_shape_search(const float* valids, const float* S1, const float* 
   float* dist1 = reinterpret_cast<float*>(params + B);
   float* dist2 = dist1 + B * P * N;
   int* starts = iws;
-  int* cursor = iws + 4 * B * (int64_t)kStartStride;
-  int* batches = cursor + 4 * B * (int64_t)kStartStride;
+  int* batches = iws + 4 * B * (int64_t)kStartStride;
   int* worklist = batches + 4 * B * (int64_t)kStartStride;
-  hipLaunchKernelGGL(grid_zero_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<int4*>(starts),
-                     (long long)(B * (int64_t)kStartStride));  // 4*B*kStartStride ints = B*kStartStride int4
   hipLaunchKernelGGL(grid_params_kernel, dim3((unsigned)B), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N, params);
-  hipLaunchKernelGGL(grid_count_kernel, dim3((unsigned)P, (unsigned)(4 * B)), dim3(256), 0, s, valids, S1, S2, (int)P,
-                     (int)N, params, starts);
-  hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, params, starts, cursor, batches, worklist);
-  hipLaunchKernelGGL(grid_scatter_kernel, dim3((unsigned)P, (unsigned)(4 * B)), dim3(256), 0, s, valids, S1, S2, (int)P,
-                     (int)N, params, cursor, records, rec_stride);
+  hipLaunchKernelGGL(grid_sort_kernel, dim3((unsigned)(2 * B)), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N, params,
+                     starts, batches, worklist, records, rec_stride);
   // persistent waves: 128 per (sample, direction) walk that pair's work list of (super-cell, 64-query batch) items
   if (before_search != nullptr) (void)hipEventRecord(before_search, s);
   hipLaunchKernelGGL(grid_search_kernel, dim3(128, (unsigned)(2 * B)), dim3(64), 0, s, valids, S1, S2, (int)P,
