@@ -19,11 +19,14 @@
 //                      sweep — with B = the largest best-distance in the wave, every cell row (y, z) whose
 //                              box distance to the super-cell box is below B is visited over exactly the
 //                              x-interval of cells that are closer than B; B shrinks as the sweep goes.
-//                    Every cell that intersects ANY lane's search ball is visited, so the search is exact;
-//                    the walk reuses the scalar-operand scan (records in SGPRs via the scalar cache, 8 per
-//                    chunk, one compare per chunk).  Candidates are not visited in index order, so the update
-//                    rule is lexicographic: smaller d, then smaller original index — exactly the answer of the
-//                    strict-`<` in-order scan.  The <= P padded parts' representatives are checked last.
+//                    Every cell that intersects ANY lane's search ball is visited, so the search is exact.
+//                    The rows of the seed / of a ring are mapped to LANES: every lane copies its row's record
+//                    range into one LDS candidate list (all rows in flight at once) and the wave scans the list
+//                    with broadcast reads; long single ranges use the scalar-operand scan (records in SGPRs via
+//                    the scalar cache, 8 per chunk, one compare per chunk).  Candidates are not visited in index
+//                    order, so the update rule is lexicographic: smaller d, then smaller original index — exactly
+//                    the answer of the strict-`<` in-order scan.  The <= P padded parts' representatives are
+//                    checked last.
 //
 // Rounding safety: a record may be binned one ulp across a cell face; cell-box distances are therefore
 // shrunk by 1e-3 of a cell before they are compared with B, and B is inflated by 1e-5.
@@ -389,8 +392,13 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
     const int lo = off0 > w0 ? off0 : w0, hi = off0 + len < w0 + wn ? off0 + len : w0 + wn;
     const int cnt = hi > lo ? hi - lo : 0, maxc = wave_max_i(cnt);
     __syncthreads();  // the previous window's readers are done with `cand` (one wave per block: a cheap fence)
-    for (int j = 0; j < maxc; ++j)
-      if (j < cnt) cand[lo - w0 + j] = trec[rb + (lo - off0) + j];
+    for (int j = 0; j < maxc; j += 2) {  // two records per lane in flight (more would cost occupancy)
+      float4 t0, t1;
+      if (j < cnt) t0 = trec[rb + (lo - off0) + j];
+      if (j + 1 < cnt) t1 = trec[rb + (lo - off0) + j + 1];
+      if (j < cnt) cand[lo - w0 + j] = t0;
+      if (j + 1 < cnt) cand[lo - w0 + j + 1] = t1;
+    }
     if (lane < T) {  // pad the last chunk of 8 with records that can never win
       const float inf = __builtin_inff();
       cand[wn + lane] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
