@@ -1020,7 +1020,8 @@ __global__ __launch_bounds__(64 * kSlices) void pn_wgrad_reduce_kernel(const flo
 struct Dims {
   int64_t M, N, F, rows;
   int splits, tiles1;  // row splits of the MFMA kernels; 256-row tiles of the first-layer kernel
-  int splits_top;      // row splits of the two last-layer GEMMs (MFMA-bound: more, shorter blocks even out the tail)
+  int splits_top;      // row splits of the last layer's forward GEMM (MFMA-bound: shorter blocks even out the tail)
+  int splits_dtop;     // row splits of the last layer's input-gradient GEMM
   int C[6];            // channel widths: C[0] = 3 ... C[5] = F
 };
 
@@ -1034,6 +1035,7 @@ Dims make_dims(int64_t M, int64_t N, int64_t F) {
   const int T = (int)((N + 31) / 32);
   d.splits = T >= 32 ? 4 : (T >= 16 ? 2 : 1);  // row splits per part: enough blocks for an even last round
   d.splits_top = T >= 32 ? 8 : d.splits;
+  d.splits_dtop = d.splits;  // (a sweep over 2..16 moved the step by < 1 %: the kernels are not tail-bound)
   d.C[0] = 3;
   d.C[1] = 64;
   d.C[2] = 64;
@@ -1085,7 +1087,8 @@ PnWs carve(float* base, const Dims& d) {
   for (int l = 1; l <= 5; ++l) w.bn[l] = take(4LL * d.C[l]);
   for (int l = 1; l <= 5; ++l) w.coef[l] = take(4LL * d.C[l]);
   const int64_t maxc = d.F > 128 ? d.F : 128;
-  const int64_t smax = d.splits_top > d.splits ? d.splits_top : d.splits;
+  int64_t smax = d.splits_top > d.splits ? d.splits_top : d.splits;
+  smax = d.splits_dtop > smax ? d.splits_dtop : smax;
   const int64_t blocks = d.M * (d.tiles1 > smax ? d.tiles1 : smax);
   w.partial = take(blocks * maxc * 2);
   w.dwpart = take((int64_t)kWG * (128 * 128 + 128));
@@ -1227,12 +1230,12 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
                      grad_feat, w.coef[5], valids, (int)N, (int)F, iw.erow, iw.ech, w.eval, iw.tptr);
   hipLaunchKernelGGL(pn_top_q_kernel, dim3((unsigned)(C4 + 1)), dim3((unsigned)C4), 0, s, conv_w[4], w.coef[5], (int)F,
                      C4, w.q);
-  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 2, 2, true>), dim3((unsigned)(M * d.splits_top), (unsigned)(C4 / 128)),
+  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 2, 2, true>), dim3((unsigned)(M * d.splits_dtop), (unsigned)(C4 / 128)),
                      dim3(kT), 0, s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w.q, C4,
-                     w.Y[4], w.bn[4], valids, (int)N, d.splits_top, w.dZ[4], w.partial, iw.erow, iw.ech, w.eval, iw.tptr,
+                     w.Y[4], w.bn[4], valids, (int)N, d.splits_dtop, w.dZ[4], w.partial, iw.erow, iw.ech, w.eval, iw.tptr,
                      conv_w[4], (int)F);
-  hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(C4 / 64), (unsigned)((M * d.splits_top + kEB - 1) / kEB)),
-                     dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, d.splits_top, C4, w.count, bn_w[3], w.bn[4],
+  hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(C4 / 64), (unsigned)((M * d.splits_dtop + kEB - 1) / kEB)),
+                     dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, d.splits_dtop, C4, w.count, bn_w[3], w.bn[4],
                      w.coef[4], grad_bn_w[3], grad_bn_b[3], w.coop);
   auto reduce_dw = [&](int elems, float* dst) {
     hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * kSlices), 0, s, w.dwpart,
