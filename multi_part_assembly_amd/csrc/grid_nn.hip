@@ -11,7 +11,7 @@
 //                    in LDS (count, scan, scatter in one launch),
 //                      role TARGET : by fine cell -> (x, y, z, original index) records + cell start offsets;
 //                                    cells are x-fastest, so a row of cells is one contiguous run of records;
-//                      role QUERY  : by SUPER-cell (2x2x2 fine cells) + a prefix of 64-query batches and the
+//                      role QUERY  : by SUPER-cell (kS^3 fine cells) + a prefix of 64-query batches and the
 //                                    work list (work item -> super-cell).
 //   3. grid_search : one wave per (super-cell, batch of <= 64 queries, 1 per lane).  All queries of the wave
 //                    lie inside one known box (the super-cell), so the candidate set is wave-uniform:
@@ -40,7 +40,11 @@ namespace {
 constexpr int kMaxCells = 32768;
 constexpr int kMaxAxis = 64;
 constexpr int kStartStride = kMaxCells + 8;   // ints per (sample, shape, role) slot
-constexpr int kWorkStride = kMaxCells / 8 + 20000 / 64 + 64;  // search work items per slot (<= nsuper + points/batch)
+constexpr int kS = 2;                         // super-cell edge in fine cells (the query bins of the search): 2 is best
+                                              // while predictions are far from the ground truth (a wave's search radius is
+                                              // its worst query's), 3 once they are close (0.62 vs 0.74 ms loss forward)
+constexpr int kMaxSuper = 4096;               // super-cells per sample (<= 22^3 would need more: see grid_params)
+constexpr int kWorkStride = kMaxSuper + 20000 / 64 + 64;  // search work items per slot (<= nsuper + points/batch)
 constexpr int kBatch = 64;                    // queries per search wave (1 per lane)
 
 struct __attribute__((aligned(16))) GridParams {
@@ -66,7 +70,7 @@ __device__ __forceinline__ int key_of(const GridParams& g, int role, float x, fl
   int ix, iy, iz;
   cell_of(g, x, y, z, ix, iy, iz);
   if (role == 0) return (iz * g.gy + iy) * g.gx + ix;
-  return ((iz >> 1) * g.sgy + (iy >> 1)) * g.sgx + (ix >> 1);
+  return ((iz / kS) * g.sgy + (iy / kS)) * g.sgx + (ix / kS);
 }
 
 // ---- 1. grid parameters: one block per sample, 1024 threads -----------------------------------------------------
@@ -140,11 +144,11 @@ __global__ __launch_bounds__(1024) void grid_params_kernel(const float* __restri
       float h = cbrtf(ex * ey * ez / want);
       h = __builtin_fmaxf(h, emax / (float)kMaxAxis);
       for (int it = 0; it < 64; ++it) {
-        // even cell counts: every super-cell is a full 2x2x2 block, so nsuper = ncells / 8 <= kMaxCells / 8
-        g.gx = (clampi((int)__builtin_ceilf(ex / h), 1, kMaxAxis) + 1) & ~1;
-        g.gy = (clampi((int)__builtin_ceilf(ey / h), 1, kMaxAxis) + 1) & ~1;
-        g.gz = (clampi((int)__builtin_ceilf(ez / h), 1, kMaxAxis) + 1) & ~1;
-        if (g.gx * g.gy * g.gz <= kMaxCells) break;
+        g.gx = clampi((int)__builtin_ceilf(ex / h), 1, kMaxAxis);
+        g.gy = clampi((int)__builtin_ceilf(ey / h), 1, kMaxAxis);
+        g.gz = clampi((int)__builtin_ceilf(ez / h), 1, kMaxAxis);
+        const int ns = ((g.gx + kS - 1) / kS) * ((g.gy + kS - 1) / kS) * ((g.gz + kS - 1) / kS);
+        if (g.gx * g.gy * g.gz <= kMaxCells && ns <= kMaxSuper) break;
         h *= 1.1f;
       }
       g.ox = ulo[0];
@@ -153,9 +157,9 @@ __global__ __launch_bounds__(1024) void grid_params_kernel(const float* __restri
       g.h = h;
       g.inv_h = 1.0f / h;
     }
-    g.sgx = (g.gx + 1) >> 1;
-    g.sgy = (g.gy + 1) >> 1;
-    g.sgz = (g.gz + 1) >> 1;
+    g.sgx = (g.gx + kS - 1) / kS;
+    g.sgy = (g.gy + kS - 1) / kS;
+    g.sgz = (g.gz + kS - 1) / kS;
     g.ncells = g.gx * g.gy * g.gz;
     g.nsuper = g.sgx * g.sgy * g.sgz;
     g.nvalid = nvalid;
@@ -182,7 +186,6 @@ __global__ __launch_bounds__(1024) void grid_params_kernel(const float* __restri
 // place (the starts go to global memory for the search kernel, together with the work list of the QUERY role),
 // scatter with the scanned array as cursor.  The order of the records inside a cell depends on the atomics; the
 // search result does not (lexicographic updates).
-constexpr int kMaxSuper = kMaxCells / 8;
 
 // exclusive scan of cnt[0..nkeys) in place, 1024 threads, PER consecutive keys per thread; returns through st_out
 // (nkeys + 1 entries).  WORK: also the prefix of ceil(count / kBatch) (ba_out) and the work list (wl_out).
@@ -482,27 +485,29 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     s.best = 1e32f;
     s.bidx = 0x7fffffff;
     // the queries lie in the super-cell box (inflated by the binning slack)
-    const float bx0 = g.ox + (float)(2 * sx) * g.h - slack, bx1 = g.ox + (float)(2 * sx + 2) * g.h + slack;
-    const float by0 = g.oy + (float)(2 * sy) * g.h - slack, by1 = g.oy + (float)(2 * sy + 2) * g.h + slack;
-    const float bz0 = g.oz + (float)(2 * sz) * g.h - slack, bz1 = g.oz + (float)(2 * sz + 2) * g.h + slack;
-    // seed: the super-cell grown by one fine cell per side (16 rows, lane = row), clipped to the target box
-    const int x0 = clampi(2 * sx - 1, 0, g.gx - 1), x1 = clampi(2 * sx + 2, 0, g.gx - 1);
-    const int y0 = clampi(2 * sy - 1, 0, g.gy - 1), y1 = clampi(2 * sy + 2, 0, g.gy - 1);
-    const int z0 = clampi(2 * sz - 1, 0, g.gz - 1), z1 = clampi(2 * sz + 2, 0, g.gz - 1);
+    const float bx0 = g.ox + (float)(kS * sx) * g.h - slack, bx1 = g.ox + (float)(kS * sx + kS) * g.h + slack;
+    const float by0 = g.oy + (float)(kS * sy) * g.h - slack, by1 = g.oy + (float)(kS * sy + kS) * g.h + slack;
+    const float bz0 = g.oz + (float)(kS * sz) * g.h - slack, bz1 = g.oz + (float)(kS * sz + kS) * g.h + slack;
+    // seed: the super-cell grown by one fine cell per side ((kS+2)^2 rows, lane = row), clipped to the target box
+    const int x0 = clampi(kS * sx - 1, 0, g.gx - 1), x1 = clampi(kS * sx + kS, 0, g.gx - 1);
+    const int y0 = clampi(kS * sy - 1, 0, g.gy - 1), y1 = clampi(kS * sy + kS, 0, g.gy - 1);
+    const int z0 = clampi(kS * sz - 1, 0, g.gz - 1), z1 = clampi(kS * sz + kS, 0, g.gz - 1);
     {
-      const int z = z0 + (lane >> 2), y = y0 + (lane & 3);
+      constexpr int kSeedW = kS + 2;  // rows per axis of the seed region
+      static_assert(kSeedW * kSeedW <= 64, "one lane per seed row");
+      const int z = z0 + lane / kSeedW, y = y0 + lane % kSeedW;
       const int xa = x0 < tx0 ? tx0 : x0, xb = x1 > tx1 ? tx1 : x1;
-      const bool ok = lane < 16 && z <= z1 && y <= y1 && z >= tz0 && z <= tz1 && y >= ty0 && y <= ty1 && xa <= xb;
+      const bool ok = lane < kSeedW * kSeedW && z <= z1 && y <= y1 && z >= tz0 && z <= tz1 && y >= ty0 && y <= ty1 && xa <= xb;
       const int row = (z * g.gy + y) * g.gx;
       const int rb = ok ? tst[row + xa] : 0, re = ok ? tst[row + xb + 1] : 0;
       scan_batch(s, trec, rb, re, cand);
     }
     // sweep: every cell whose box can hold a point closer than the worst best-distance of this wave.  Rows (y, z)
-    // are visited nearest-first, as square rings around the super-cell's own 2x2 rows (lane = row of the ring, 64
+    // are visited nearest-first, as square rings around the super-cell's own kS x kS rows (lane = row of the ring, 64
     // rows per batch), so the bound tightens early; a ring whose nearest row is already farther than the bound
     // ends the sweep.  Rings 0 and 1 overlap the seed: only the cells left and right of it are new there.
     float bound = wave_max(s.best) * 1.00001f;
-    const int yc0 = 2 * sy, yc1 = 2 * sy + 1, zc0 = 2 * sz, zc1 = 2 * sz + 1;
+    const int yc0 = kS * sy, yc1 = kS * sy + kS - 1, zc0 = kS * sz, zc1 = kS * sz + kS - 1;
     const int rmax = max(max(yc0, g.gy - 1 - yc1), max(zc0, g.gz - 1 - zc1));
     for (int r = 0; r <= rmax; ++r) {
       if (r >= 2) {
