@@ -67,24 +67,48 @@ __global__ void pn_transpose_kernel(const float* __restrict__ w, float* __restri
   if (i < cout * cin) wt[(i % cin) * cout + i / cin] = w[i];
 }
 
-__global__ void pn_count_kernel(const float* __restrict__ valids, int M, int N, float* __restrict__ count,
-                                unsigned* __restrict__ ticket) {
+// number of valid points (BatchNorm's sample count), the compact list of valid parts (vlist[0] = how many, part
+// ids from vlist[4] on, ascending) that the persistent backward kernels walk, and the reset of the tickets.
+// one block of 1024 threads.
+__global__ __launch_bounds__(1024) void pn_count_kernel(const float* __restrict__ valids, int M, int N,
+                                                        float* __restrict__ count, unsigned* __restrict__ ticket,
+                                                        int* __restrict__ vlist) {
+  __shared__ int wcnt[16];
   if (threadIdx.x < 4) ticket[threadIdx.x] = 0u;  // the cooperative reductions' counters (reset after every use)
-  float s = 0.0f;
-  for (int m = threadIdx.x; m < M; m += 64) s += valids[m] != 0.0f ? 1.0f : 0.0f;
-  s = wave_sum(s);
-  if (threadIdx.x == 0) count[0] = s * (float)N;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int base = 0;
+  for (int m0 = 0; m0 < M; m0 += 1024) {
+    const int m = m0 + threadIdx.x;
+    const bool ok = m < M && valids[m] != 0.0f;
+    const unsigned long long b = __ballot(ok);
+    if (lane == 0) wcnt[wave] = __popcll(b);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int c = wcnt[k];
+      before += k < wave ? c : 0;
+      total += c;
+    }
+    if (ok) vlist[4 + base + before + __popcll(b & ((1ull << lane) - 1ull))] = m;
+    base += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    count[0] = (float)base * (float)N;
+    vlist[0] = base;
+  }
 }
 
 // the (sum0, sum1) partial tables written by the forward / input-gradient kernels; rows of padded parts hold
-// garbage and are skipped
+// garbage and are skipped (valids == nullptr: one row per persistent block, all of them meaningful)
 __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial,
                                                 const float* __restrict__ valids, int M, int splits, int C,
                                                 int c, const CoopWs ws, double& s0, double& s1) {
   return coop_colsum(M * splits, C, c, ws,
                      [&](int e, bool& ok, double& x, double& y) {
                        const float2 v = *reinterpret_cast<const float2*>(partial + ((long long)e * C + c) * 2);
-                       ok = valids[e / splits] != 0.0f;
+                       ok = valids == nullptr || valids[e / splits] != 0.0f;
                        x = (double)v.x;
                        y = (double)v.y;
                      },
@@ -833,8 +857,8 @@ enum { WG_NORMAL = 0, WG_FIRST = 1, WG_GRAM = 2 };
 template <int COUT, int CIN, int MODE, int LDY = COUT>
 __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
     const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
-    const float* __restrict__ y_prev, const float* __restrict__ bn_prev, const float* __restrict__ valids, int M,
-    int N, float* __restrict__ dwpart, int co0) {
+    const float* __restrict__ y_prev, const float* __restrict__ bn_prev, const int* __restrict__ vlist, int N,
+    float* __restrict__ dwpart, int co0) {
   constexpr int CINP = MODE == WG_FIRST ? 32 : CIN;       // width of the B panel
   constexpr int CT = COUT / 32, IT = CINP / 32, NTILE = CT * IT, TPW = (NTILE + 3) / 4;
   constexpr int RB = 64;
@@ -845,7 +869,7 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
   constexpr int NLI = MODE == WG_FIRST ? 1 : RB * QI / kT;     // float4 per thread: Yprev
   __shared__ __attribute__((aligned(16))) float buf[2][STAGE];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int TB = (N + RB - 1) / RB, U = M * TB;
+  const int TB = (N + RB - 1) / RB, U = vlist[0] * TB;
   // staging roles and per-column tables
   const int co4 = threadIdx.x % QO, ro0 = threadIdx.x / QO;
   const int ci4 = threadIdx.x % QI, ri0 = threadIdx.x / QI;
@@ -864,8 +888,8 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
   }
   float4 ry[NLO], rz[NLO], rp[NLI];
   float rpt = 0.0f;
-  auto fetch = [&](int u) {
-    const int m = u / TB, n0 = (u % TB) * RB;
+  auto fetch = [&](int u, int m) {
+    const int n0 = (u % TB) * RB;
     const long long row0 = (long long)m * N + n0;
     if constexpr (MODE != WG_GRAM) {
 #pragma unroll
@@ -923,22 +947,21 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
       }
     }
   };
-  auto advance = [&](int u) {  // next unit of this block that belongs to a real part
-    while (u < U && valids[u / TB] == 0.0f) u += kWG;
-    return u;
-  };
+  // units u, u + kWG, ... of the valid parts; part ids are looked up two iterations ahead of their use
+  auto part_of = [&](int uu) { return uu < U ? vlist[4 + uu / TB] : 0; };
   f32x16 acc[TPW];
 #pragma unroll
   for (int i = 0; i < TPW; ++i) acc[i] = f32x16{0};
   float bsum = 0.0f;
-  int u = advance(blockIdx.x), k = 0;
-  if (u < U) fetch(u);
+  int u = blockIdx.x, un = u + kWG, k = 0;
+  int m = part_of(u), mn = part_of(un);
+  if (u < U) fetch(u, m);
   while (u < U) {
     float* cur = buf[k];
     stash(u, cur);
     __syncthreads();  // also orders the reuse of this buffer (its readers passed the previous barrier)
-    const int un = advance(u + kWG);
-    if (un < U) fetch(un);  // in flight during the MFMAs below
+    const int unn = un + kWG, mnn = part_of(unn);
+    if (un < U) fetch(un, mn);  // in flight during the MFMAs below
     const float* pa = cur + h * (MODE == WG_GRAM ? CINP : COUT) + j;
     const float* pb = cur + RB * DYW + h * CINP + j;
     constexpr int AW = MODE == WG_GRAM ? CINP : COUT;  // row stride of the A-operand panel
@@ -956,6 +979,9 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
       }
     }
     u = un;
+    m = mn;
+    un = unn;
+    mn = mnn;
     k ^= 1;
   }
   constexpr int ELEMS = MODE == WG_FIRST ? COUT * 3 : COUT * CIN + (MODE == WG_GRAM ? CIN : 0);
@@ -978,6 +1004,214 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
   if constexpr (MODE == WG_GRAM) {
     bsum += __shfl_xor(bsum, 32, 64);
     if (h == 0) out[COUT * CIN + wave * 32 + j] = bsum;
+  }
+}
+
+// ---- fused input + weight gradient (64 -> 64 and 64 -> 128 layers) -------------------------------------------------
+// Both gradients of a layer consume the same dY = alpha*dZ + gammap*Y + betap tile, and the weight gradient's other
+// operand relu(bn_prev(Yprev)) is the tensor the input gradient's epilogue masks with: one kernel reads Y, dZ and
+// Yprev ONCE (separate kernels read each of them twice).  2*kWF persistent blocks of NTH threads (two per CU: what
+// the double-buffered panels and 256 registers per lane allow) take RB-row units of the valid parts round-robin;
+// all threads stage the dY [RB x K] and raw Yprev [RB x 64] panels one unit ahead; the first half of the waves then
+// runs the input-gradient MFMA chain (weights register-resident, dZprev = (dY W) masked by bn_prev(Yprev) > 0,
+// BatchNorm-backward sums), the second half the weight-gradient chain (output tiles accumulate across the block's
+// units) — the same MFMA count per unit on either side.  Per block: one (sum, sum) row of `partial` and one
+// partial dW, reduced in fixed order by pn_bwd_coef_kernel / pn_wgrad_reduce_kernel.
+// Measured (352 valid parts x 1000 points): 106 us for 64 -> 64 (separate kernels: 174), 153 us for 64 -> 128 (293);
+// the fp32 MFMA floor of the two GEMMs is 37 / 74 us, the HBM floor 58 / 86 us.
+constexpr int kWF = 256;
+template <int K, int NT, int PANELS, int NTH>
+__global__ __launch_bounds__(NTH, 2) void pn_bwd_fused_kernel(
+    const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
+    const float* __restrict__ w, const float* __restrict__ y_prev, const float* __restrict__ bn_prev,
+    const int* __restrict__ vlist, int N, float* __restrict__ dz_prev, float* __restrict__ partial,
+    float* __restrict__ dwpart) {
+  constexpr int CIN = 64, KH = K / 2, LDY = K + 4, LDP = CIN + 4, QK = K / 4, QC = CIN / 4;
+  constexpr int ND = NTH / 128;  // waves of each kind
+  constexpr int RT = ND / PANELS, RB = 32 * RT, CW = 32 * NT;
+  constexpr int NLY = RB * QK / NTH, NLP = RB * QC / NTH;  // float4 per thread and unit: Y / dZ, Yprev
+  constexpr int IT = CIN / 32, NTILE = (K / 32) * IT, TPW = NTILE / ND;
+  static_assert(CW * PANELS == CIN && NTILE % ND == 0 && RT >= 1, "tile shapes");
+  __shared__ __attribute__((aligned(16))) float bufY[2][RB * LDY];
+  __shared__ __attribute__((aligned(16))) float bufP[2][RB * LDP];
+  __shared__ float red[ND][CW][2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const bool dwave = wave < ND;
+  const int wv = wave % ND, panel = wv % PANELS, rt = wv / PANELS, d0 = panel * CW;
+  const int TB = (N + RB - 1) / RB, U = vlist[0] * TB, G = gridDim.x;
+  // staging roles and their per-column tables
+  const int c4 = threadIdx.x % QK, rl0 = threadIdx.x / QK, p4 = threadIdx.x % QC, rp0 = threadIdx.x / QC;
+  const float4 ta = reinterpret_cast<const float4*>(coef)[c4];
+  const float4 tb = reinterpret_cast<const float4*>(coef + K)[c4];
+  const float4 tc = reinterpret_cast<const float4*>(coef + 2 * K)[c4];
+  // input-gradient waves: B fragments (lane-half h, step s <-> k = h*KH + s) and the epilogue's channel tables
+  // (the two kinds of waves keep their loop-carried registers in the same array R: weights here, accumulators there)
+  constexpr int NR = NT * KH / 16 > TPW ? NT * KH / 16 : TPW;
+  f32x16 R[NR];
+  float scp[NT], shp[NT], mnp[NT], isp[NT];
+  if (dwave) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int s = 0; s < KH; ++s)
+        R[(t * KH + s) / 16][(t * KH + s) % 16] = w[(long long)(h * KH + s) * CIN + d0 + 32 * t + j];
+      const int ci = d0 + 32 * t + j;
+      scp[t] = bn_prev[ci];
+      shp[t] = bn_prev[CIN + ci];
+      mnp[t] = bn_prev[2 * CIN + ci];
+      isp[t] = bn_prev[3 * CIN + ci];
+    }
+  }
+  // weight-gradient waves: scale / shift of their B-operand channels
+  float scw[IT], shw[IT];
+#pragma unroll
+  for (int u = 0; u < IT; ++u) {
+    scw[u] = bn_prev[32 * u + j];
+    shw[u] = bn_prev[CIN + 32 * u + j];
+  }
+  float4 ry[NLY], rz[NLY], rp[NLP];
+  auto fetch = [&](int u, int m) {
+    const int n0 = (u % TB) * RB;
+    const long long row0 = (long long)m * N + n0;
+#pragma unroll
+    for (int i = 0; i < NLY; ++i) {
+      const bool ok = n0 + rl0 + i * (NTH / QK) < N;
+      const long long o = row0 * QK + i * NTH + threadIdx.x;
+      ry[i] = ok ? reinterpret_cast<const float4*>(y)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      rz[i] = ok ? reinterpret_cast<const float4*>(dz)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int i = 0; i < NLP; ++i) {
+      const bool ok = n0 + rp0 + i * (NTH / QC) < N;
+      rp[i] = ok ? reinterpret_cast<const float4*>(y_prev)[row0 * QC + i * NTH + threadIdx.x]
+                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+  };
+  auto stash = [&](int u, float* dy, float* dp) {  // rows past the part's end: dY = 0 (their Yprev is never used)
+    const int n0 = (u % TB) * RB;
+#pragma unroll
+    for (int i = 0; i < NLY; ++i) {
+      const int rl = rl0 + i * (NTH / QK);
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (n0 + rl < N) {
+        v.x = __builtin_fmaf(ta.x, rz[i].x, __builtin_fmaf(tb.x, ry[i].x, tc.x));
+        v.y = __builtin_fmaf(ta.y, rz[i].y, __builtin_fmaf(tb.y, ry[i].y, tc.y));
+        v.z = __builtin_fmaf(ta.z, rz[i].z, __builtin_fmaf(tb.z, ry[i].z, tc.z));
+        v.w = __builtin_fmaf(ta.w, rz[i].w, __builtin_fmaf(tb.w, ry[i].w, tc.w));
+      }
+      *reinterpret_cast<float4*>(dy + rl * LDY + 4 * c4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NLP; ++i)
+      *reinterpret_cast<float4*>(dp + (rp0 + i * (NTH / QC)) * LDP + 4 * p4) = rp[i];
+  };
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.0f;
+  if (!dwave) {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) R[i] = f32x16{0};
+  }
+  // units u, u + G, ... of the valid parts; the part id of a unit is looked up two iterations before its rows are
+  // requested, so no load latency sits between the barrier and the next unit's requests
+  auto part_of = [&](int uu) { return uu < U ? vlist[4 + uu / TB] : 0; };
+  int u = blockIdx.x, un = u + G, kb = 0;
+  int m = part_of(u), mn = part_of(un);
+  if (u < U) fetch(u, m);
+  while (u < U) {
+    float* cy = bufY[kb];
+    float* cp = bufP[kb];
+    stash(u, cy, cp);
+    __syncthreads();  // also orders the reuse of these buffers (their readers passed the previous barrier)
+    const int unn = un + G, mnn = part_of(unn);
+    if (un < U) fetch(un, mn);  // in flight during the MFMA chains below
+    if (dwave) {
+      const int r0 = (u % TB) * RB + rt * 32;
+      const float4* frag = reinterpret_cast<const float4*>(cy + (rt * 32 + j) * LDY + h * KH);
+      f32x16 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+#pragma unroll
+      for (int v = 0; v < KH / 4; ++v) {
+        const float4 a = frag[v];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, R[(t * KH + 4 * v + 0) / 16][(t * KH + 4 * v + 0) % 16], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, R[(t * KH + 4 * v + 1) / 16][(t * KH + 4 * v + 1) % 16], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, R[(t * KH + 4 * v + 2) / 16][(t * KH + 4 * v + 2) % 16], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, R[(t * KH + 4 * v + 3) / 16][(t * KH + 4 * v + 3) % 16], acc[t], 0, 0, 0);
+        }
+      }
+      const bool full = r0 + 32 <= N;  // wave-uniform: only a part's last tile is ragged
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = rt * 32 + acc_row(r, h), gn = r0 + acc_row(r, h);
+        const bool ok = full || gn < N;
+        const long long o = ((long long)m * N + gn) * CIN + d0 + j;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float ypv = cp[rl * LDP + d0 + 32 * t + j];
+          const float zz = __builtin_fmaf(ypv, scp[t], shp[t]);
+          const float d = (ok && zz > 0.0f) ? acc[t][r] : 0.0f;
+          if (ok) dz_prev[o + 32 * t] = d;
+          s1[t] += d;
+          s2[t] = __builtin_fmaf(d, (ypv - mnp[t]) * isp[t], s2[t]);
+        }
+      }
+    } else {
+      const float* pa = cy + h * LDY + j;
+      const float* pb = cp + h * LDP + j;
+#pragma unroll 4
+      for (int s = 0; s < RB / 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          const int q = wv + ND * i, ct = q / IT, it = q % IT;
+          const float a = pa[2 * s * LDY + ct * 32];
+          const float b = __builtin_fmaxf(__builtin_fmaf(pb[2 * s * LDP + it * 32], scw[it], shw[it]), 0.0f);
+          R[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, R[i], 0, 0, 0);
+        }
+      }
+    }
+    u = un;
+    m = mn;
+    un = unn;
+    mn = mnn;
+    kb ^= 1;
+  }
+  if (dwave) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s1[t] += __shfl_xor(s1[t], 32, 64);
+      s2[t] += __shfl_xor(s2[t], 32, 64);
+    }
+    if (h == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        red[wv][32 * t + j][0] = s1[t];
+        red[wv][32 * t + j][1] = s2[t];
+      }
+    }
+  } else {
+    float* out = dwpart + (long long)blockIdx.x * (K * CIN);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int q = wv + ND * i, ct = q / IT, it = q % IT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(ct * 32 + acc_row(r, h)) * CIN + it * 32 + j] = R[i][r];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < CIN) {  // thread -> (panel, channel); the RT waves of the panel in fixed order
+    const int pn = threadIdx.x / CW, ch = threadIdx.x % CW;
+    float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      t0 += red[q * PANELS + pn][ch][0];
+      t1 += red[q * PANELS + pn][ch][1];
+    }
+    const long long o = ((long long)blockIdx.x * CIN + threadIdx.x) * 2;
+    partial[o] = t0;
+    partial[o + 1] = t1;
   }
 }
 
@@ -1069,6 +1303,7 @@ struct PnIws {
   int* erow;    // [M][F] CSR rows
   int* ech;     // [M][F] CSR channels
   int* tptr;    // [M][T+1] CSR tile offsets
+  int* vlist;   // [4 + M] number of valid parts, then (from [4]) their ids
   int64_t total;
 };
 
@@ -1089,7 +1324,8 @@ PnWs carve(float* base, const Dims& d) {
   const int64_t maxc = d.F > 128 ? d.F : 128;
   int64_t smax = d.splits_top > d.splits ? d.splits_top : d.splits;
   smax = d.splits_dtop > smax ? d.splits_dtop : smax;
-  const int64_t blocks = d.M * (d.tiles1 > smax ? d.tiles1 : smax);
+  int64_t blocks = d.M * (d.tiles1 > smax ? d.tiles1 : smax);
+  if (blocks < 2 * kWF) blocks = 2 * kWF;  // the fused backward kernel leaves one row per persistent block
   w.partial = take(blocks * maxc * 2);
   w.dwpart = take((int64_t)kWG * (128 * 128 + 128));
   w.count = take(4);
@@ -1117,6 +1353,7 @@ PnIws carve_int(int32_t* base, const Dims& d) {
   w.erow = take(d.M * d.F);
   w.ech = take(d.M * d.F);
   w.tptr = take(d.M * ((d.N + 31) / 32 + 1));
+  w.vlist = take(d.M + 4);
   w.total = p - base;
   return w;
 }
@@ -1126,20 +1363,6 @@ int check_dims(int64_t M, int64_t N, int64_t F, const char* who) {
   MPA_REQUIRE(F == 64 || F == 128 || F == 256, "%s: feat_dim must be 64, 128 or 256", who);
   MPA_REQUIRE(M <= 32767 && N <= 32768, "%s: at most 32767 parts of at most 32768 points", who);
   return MPA_OK;
-}
-
-void launch_dgrad(int K, const float* y, const float* dz, const float* coef, const float* w, int cin,
-                  const float* y_prev, const float* bn_prev, const float* valids, const Dims& d, float* dz_prev,
-                  float* partial, hipStream_t s) {
-  const unsigned gx = (unsigned)(d.M * d.splits);
-#define MPA_DGRAD(KK, NT, PN)                                                                                      \
-  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<KK, NT, PN, false>), dim3(gx, cin / (32 * NT * PN)), dim3(kT), 0, s, y, \
-                     dz, coef, w, cin, y_prev, bn_prev, valids, (int)d.N, d.splits, dz_prev, partial,              \
-                     (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, (const int*)nullptr,         \
-                     (const float*)nullptr, 0)
-  if (K == 64) MPA_DGRAD(64, 2, 1);   // 64 -> 64: one 64-channel panel, 128-row block tiles
-  else MPA_DGRAD(128, 1, 2);          // 128 -> 64: two 32-channel panels, 64-row block tiles
-#undef MPA_DGRAD
 }
 
 }  // namespace
@@ -1168,7 +1391,8 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
   const PnWs w = carve(float_ws, d);
   const PnIws iw = carve_int(int_ws, d);
   hipLaunchKernelGGL(pn_transpose_kernel, dim3(1), dim3(192), 0, s, conv_w[0], w.Wt1, 64, 3);
-  hipLaunchKernelGGL(pn_count_kernel, dim3(1), dim3(64), 0, s, valids, (int)M, (int)N, w.count, w.coop.ticket);
+  hipLaunchKernelGGL(pn_count_kernel, dim3(1), dim3(1024), 0, s, valids, (int)M, (int)N, w.count, w.coop.ticket,
+                     iw.vlist);
   for (int l = 1; l <= 5; ++l) {
     int splits;
     if (l == 1) {
@@ -1237,36 +1461,32 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(C4 / 64), (unsigned)((M * d.splits_dtop + kEB - 1) / kEB)),
                      dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, d.splits_dtop, C4, w.count, bn_w[3], w.bn[4],
                      w.coef[4], grad_bn_w[3], grad_bn_b[3], w.coop);
-  auto reduce_dw = [&](int elems, float* dst) {
+  auto reduce_dw = [&](int blocks, int elems, float* dst) {
     hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * kSlices), 0, s, w.dwpart,
-                       (const float*)nullptr, kWG, elems, dst);
+                       (const float*)nullptr, blocks, elems, dst);
   };
   hipLaunchKernelGGL((pn_wgrad_mfma_kernel<128, 128, WG_GRAM>), dim3(kWG), dim3(kT), 0, s, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, w.Y[4], w.bn[4], valids, (int)M, (int)N, w.dwpart, 0);
-  reduce_dw(C4 * C4 + C4, w.gram);
+                     (const float*)nullptr, (const float*)nullptr, w.Y[4], w.bn[4], iw.vlist, (int)N, w.dwpart, 0);
+  reduce_dw(kWG, C4 * C4 + C4, w.gram);
   hipLaunchKernelGGL(pn_top_wgrad_kernel, dim3((unsigned)F), dim3(1024), 0, s, grad_feat, iw.argmax, valids, w.Y[4],
                      w.bn[4], conv_w[4], w.coef[5], w.gram, (int)M, (int)N, (int)F, grad_conv_w[4]);
-  for (int l = 4; l >= 1; --l) {
+  // ---- layers 4..2: fused input + weight gradient, then the next layer's BatchNorm-backward coefficients
+  for (int l = 4; l >= 2; --l) {
     const int cout = d.C[l], cin = d.C[l - 1];
-    if (l == 1)
-      hipLaunchKernelGGL((pn_wgrad_mfma_kernel<64, 4, WG_FIRST>), dim3(kWG), dim3(kT), 0, s, w.Y[1], w.dZ[1], w.coef[1],
-                         points, (const float*)nullptr, valids, (int)M, (int)N, w.dwpart, 0);
-    else if (l == 4)  // two 64-channel slices of the 128 outputs
-      for (int half = 0; half < 2; ++half) {
-        hipLaunchKernelGGL((pn_wgrad_mfma_kernel<64, 64, WG_NORMAL, 128>), dim3(kWG), dim3(kT), 0, s, w.Y[4], w.dZ[4],
-                           w.coef[4], w.Y[3], w.bn[3], valids, (int)M, (int)N, w.dwpart, 64 * half);
-        reduce_dw(64 * cin, grad_conv_w[3] + (long long)half * 64 * cin);
-      }
-    else
-      hipLaunchKernelGGL((pn_wgrad_mfma_kernel<64, 64, WG_NORMAL>), dim3(kWG), dim3(kT), 0, s, w.Y[l], w.dZ[l],
-                         w.coef[l], w.Y[l - 1], w.bn[l - 1], valids, (int)M, (int)N, w.dwpart, 0);
-    if (l != 4) reduce_dw(cout * cin, grad_conv_w[l - 1]);
-    if (l == 1) break;
-    launch_dgrad(cout, w.Y[l], w.dZ[l], w.coef[l], conv_w[l - 1], cin, w.Y[l - 1], w.bn[l - 1], valids, d,
-                 w.dZ[l - 1], w.partial, s);
-    hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(cin / 64), (unsigned)((M * d.splits + kEB - 1) / kEB)),
-                       dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, d.splits, cin, w.count, bn_w[l - 2],
+#define MPA_FUSED(KK, NT, PN, TH)                                                                                      \
+  hipLaunchKernelGGL((pn_bwd_fused_kernel<KK, NT, PN, TH>), dim3(nb), dim3(TH), 0, s, w.Y[l], w.dZ[l], w.coef[l],      \
+                     conv_w[l - 1], w.Y[l - 1], w.bn[l - 1], iw.vlist, (int)N, w.dZ[l - 1], w.partial, w.dwpart)
+    const int nb = 2 * kWF;                      // two 4-wave blocks per CU
+    if (cout == 64) MPA_FUSED(64, 2, 1, 256);    // 64 -> 64: one 64-channel panel, 64-row units
+    else MPA_FUSED(128, 1, 2, 256);              // 64 -> 128: two 32-channel panels, 32-row units
+#undef MPA_FUSED
+    reduce_dw(nb, cout * cin, grad_conv_w[l - 1]);
+    hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(cin / 64), (unsigned)((nb + kEB - 1) / kEB)),
+                       dim3(64 * kSlices), 0, s, w.partial, (const float*)nullptr, nb, 1, cin, w.count, bn_w[l - 2],
                        w.bn[l - 1], w.coef[l - 1], grad_bn_w[l - 2], grad_bn_b[l - 2], w.coop);
   }
+  hipLaunchKernelGGL((pn_wgrad_mfma_kernel<64, 4, WG_FIRST>), dim3(kWG), dim3(kT), 0, s, w.Y[1], w.dZ[1], w.coef[1],
+                     points, (const float*)nullptr, iw.vlist, (int)N, w.dwpart, 0);
+  reduce_dw(kWG, d.C[1] * 3, grad_conv_w[0]);
   return mpa::check_launch("pointnet_backward");
 }
