@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kT) void pn_fwd_first_kernel(const float* __restric
 template <int CIN, int PANELS, bool TOP>
 __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ bn_prev, const float* __restrict__ w, int cout,
-    const float* __restrict__ valids, int N, int splits, float* __restrict__ y_out,
+    const int* __restrict__ vlist, int N, int splits, float* __restrict__ y_out,
     float* __restrict__ partial, float* __restrict__ topv, int* __restrict__ topn) {
   constexpr int KH = CIN / 2;           // K values per lane-half
   constexpr int LD = CIN + 4;           // padded LDS row: conflict-free ds_read_b128 across rows
@@ -467,8 +467,6 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
   constexpr int NLD = RB * Q4 / kT;     // float4 per thread and tile
   __shared__ __attribute__((aligned(16))) float buf[2][RB * LD];
   __shared__ float red[kT / 64][64][2];
-  const int m = blockIdx.x / splits, sp = blockIdx.x % splits;
-  if (valids[m] == 0.0f) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int panel = wave % PANELS, rt = wave / PANELS;
   const int cb = blockIdx.y * 64 * PANELS, c0 = cb + panel * 64;
@@ -491,8 +489,8 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
   const float4 sc = reinterpret_cast<const float4*>(bn_prev)[c4];
   const float4 sh = reinterpret_cast<const float4*>(bn_prev + CIN)[c4];
   const int TB = (N + RB - 1) / RB;
-  const int t_begin = (int)((long long)sp * TB / splits), t_end = (int)((long long)(sp + 1) * TB / splits);
   float4 raw[NLD];
+  int m = 0;
   auto fetch = [&](int tile) {
     const float4* src = reinterpret_cast<const float4*>(in + ((long long)m * N + (long long)tile * RB) * CIN);
 #pragma unroll
@@ -515,6 +513,17 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
       *reinterpret_cast<float4*>(dst + rl * LD + 4 * c4) = v;
     }
   };
+  // persistent: the block keeps its weight panel and walks the (valid part, row split) units u, u + gridDim.x, ...
+  const int U = vlist[0] * splits;
+  int mnext = blockIdx.x < U ? vlist[4 + blockIdx.x / splits] : 0;
+  for (int unit = blockIdx.x; unit < U; unit += gridDim.x) {
+  m = mnext;
+  {
+    const int un = unit + gridDim.x;
+    mnext = un < U ? vlist[4 + un / splits] : 0;  // needed one unit from now
+  }
+  const int sp = unit % splits, ob = m * splits + sp;  // ob: the unit's row in the per-unit output tables
+  const int t_begin = (int)((long long)sp * TB / splits), t_end = (int)((long long)(sp + 1) * TB / splits);
   float s_[2] = {0.0f, 0.0f}, ss_[2] = {0.0f, 0.0f};
   Top2 hi[2] = {top2_empty(), top2_empty()}, lo[2] = {top2_empty(), top2_empty()};
   if (t_begin < t_end) fetch(t_begin);
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
       t0 += red[q * PANELS + pn][ch][0];
       t1 += red[q * PANELS + pn][ch][1];
     }
-    const long long o = ((long long)blockIdx.x * cout + cb + threadIdx.x) * 2;
+    const long long o = ((long long)ob * cout + cb + threadIdx.x) * 2;
     partial[o] = t0;
     partial[o + 1] = t1;
   }
@@ -606,11 +615,13 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
         a = top2_merge(a, tsm[q * PANELS + pn][ch][0]);
         b = top2_merge(b, tsm[q * PANELS + pn][ch][1]);
       }
-      const long long o = ((long long)blockIdx.x * cout + cb + threadIdx.x) * 4;
+      const long long o = ((long long)ob * cout + cb + threadIdx.x) * 4;
       *reinterpret_cast<float4*>(topv + o) = make_float4(a.v1, a.v2, b.v1, b.v2);
       *reinterpret_cast<int4*>(topn + o) = make_int4(a.n1, a.n2, b.n1, b.n2);
     }
   }
+  __syncthreads();  // the reduction scratch is free again before the next unit reaches it
+  }  // unit
 }
 
 // ---- MFMA input gradient -----------------------------------------------------------------------------------------
@@ -631,7 +642,7 @@ template <int K, int NT, int PANELS, bool TOP>
 __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
     const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
     const float* __restrict__ w, int cin, const float* __restrict__ y_prev, const float* __restrict__ bn_prev,
-    const float* __restrict__ valids, int N, int splits, float* __restrict__ dz_prev,
+    const int* __restrict__ vlist, int N, int splits, float* __restrict__ dz_prev,
     float* __restrict__ partial, const int* __restrict__ erow, const int* __restrict__ ech,
     const float* __restrict__ eval, const int* __restrict__ tptr, const float* __restrict__ w5, int F) {
   constexpr int KH = K / 2;            // K values per lane-half
@@ -643,8 +654,6 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
   constexpr int CW = 32 * NT;          // output channels per wave
   __shared__ __attribute__((aligned(16))) float buf[2][RB * LD];
   __shared__ float red[kT / 64][CW][2];
-  const int m = blockIdx.x / splits, sp = blockIdx.x % splits;
-  if (valids[m] == 0.0f) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int panel = wave % PANELS, rt = wave / PANELS;
   const int db = blockIdx.y * CW * PANELS, d0 = db + panel * CW;
@@ -671,22 +680,12 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
   const float4 tb = reinterpret_cast<const float4*>(TOP ? bn_prev + K : coef + K)[c4];
   const float4 tc = TOP ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : reinterpret_cast<const float4*>(coef + 2 * K)[c4];
   const int TB = (N + RB - 1) / RB;
-  const int t_begin = (int)((long long)sp * TB / splits), t_end = (int)((long long)(sp + 1) * TB / splits);
+  int m = 0;
   // TOP: the part's CSR (<= 256 entries, <= 1025 tile offsets) lives in LDS so that the per-tile sparse chain has
   // a single level of global loads (the W5 rows), issued before the tile's main MFMA chain
   constexpr int kMaxF = 256, kMaxT1 = 1032, kSP = 6;  // tile offsets: N <= 32768 points per part
   __shared__ int s_row[TOP ? kMaxF : 1], s_ch[TOP ? kMaxF : 1], s_ptr[TOP ? kMaxT1 : 1];
   __shared__ float s_val[TOP ? kMaxF : 1];
-  if constexpr (TOP) {
-    const int T1 = (N + 31) / 32 + 1;
-    for (int i = threadIdx.x; i < F; i += kT) {
-      s_row[i] = erow[(long long)m * F + i];  // slots past the part's entry count hold garbage, never addressed
-      s_ch[i] = ech[(long long)m * F + i];
-      s_val[i] = eval[(long long)m * F + i];
-    }
-    for (int i = threadIdx.x; i < T1 && i < kMaxT1; i += kT) s_ptr[i] = tptr[(long long)m * T1 + i];
-    // visible after the first barrier of the tile loop
-  }
   float4 ry[NLD], rz[TOP ? 1 : NLD];
   auto fetch = [&](int tile) {
     const long long base = ((long long)m * N + (long long)tile * RB) * Q4;
@@ -724,6 +723,27 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
       *reinterpret_cast<float4*>(dst + rl * LD + 4 * c4) = v;
     }
   };
+  // persistent: the block keeps its weight slab and walks the (valid part, row split) units u, u + gridDim.x, ...
+  const int U = vlist[0] * splits;
+  int mnext = blockIdx.x < U ? vlist[4 + blockIdx.x / splits] : 0;
+  for (int unit = blockIdx.x; unit < U; unit += gridDim.x) {
+  m = mnext;
+  {
+    const int un = unit + gridDim.x;
+    mnext = un < U ? vlist[4 + un / splits] : 0;  // needed one unit from now
+  }
+  const int sp = unit % splits, ob = m * splits + sp;  // ob: the unit's row of `partial`
+  const int t_begin = (int)((long long)sp * TB / splits), t_end = (int)((long long)(sp + 1) * TB / splits);
+  if constexpr (TOP) {
+    const int T1 = (N + 31) / 32 + 1;
+    for (int i = threadIdx.x; i < F; i += kT) {
+      s_row[i] = erow[(long long)m * F + i];  // slots past the part's entry count hold garbage, never addressed
+      s_ch[i] = ech[(long long)m * F + i];
+      s_val[i] = eval[(long long)m * F + i];
+    }
+    for (int i = threadIdx.x; i < T1 && i < kMaxT1; i += kT) s_ptr[i] = tptr[(long long)m * T1 + i];
+    // visible after the first barrier of the tile loop
+  }
   float s1[NT], s2[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.0f;
@@ -831,10 +851,12 @@ __global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
       t0 += red[q * PANELS + pn][ch][0];
       t1 += red[q * PANELS + pn][ch][1];
     }
-    const long long o = ((long long)blockIdx.x * cin + db + threadIdx.x) * 2;
+    const long long o = ((long long)ob * cin + db + threadIdx.x) * 2;
     partial[o] = t0;
     partial[o + 1] = t1;
   }
+  __syncthreads();  // LDS (CSR copy, reduction scratch) is free again before the next unit rewrites it
+  }  // unit
 }
 
 // ---- MFMA weight gradient --------------------------------------------------------------------------------------
@@ -1358,6 +1380,16 @@ PnIws carve_int(int32_t* base, const Dims& d) {
   return w;
 }
 
+constexpr int kCUs = 256;  // MI355X
+
+// resident blocks per CU of a persistent kernel (registers and LDS decide; asked once per kernel)
+template <typename Kern>
+int blocks_per_cu(Kern kern, int threads) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, 0) != hipSuccess || n < 1) n = 1;
+  return n;
+}
+
 int check_dims(int64_t M, int64_t N, int64_t F, const char* who) {
   MPA_REQUIRE(M >= 0 && N >= 1 && F >= 64, "%s: bad sizes", who);
   MPA_REQUIRE(F == 64 || F == 128 || F == 256, "%s: feat_dim must be 64, 128 or 256", who);
@@ -1401,18 +1433,22 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
                          w.Wt1, valids, (int)N, w.Y[1], w.partial);
     } else {
       splits = l == 5 ? d.splits_top : d.splits;
-      const unsigned gx = (unsigned)(M * splits);
 #define MPA_FWD(CI, PN, TP, IN, YO, TV, TN)                                                                          \
-  hipLaunchKernelGGL((pn_fwd_mfma_kernel<CI, PN, TP>), dim3(gx, (unsigned)(d.C[l] / (64 * PN))), dim3(kT), 0, s, IN, \
-                     w.bn[l - 1], conv_w[l - 1], d.C[l], valids, (int)N, splits, YO, w.partial, TV, TN)
+  {                                                                                                                  \
+    static const int occ = blocks_per_cu(pn_fwd_mfma_kernel<CI, PN, TP>, kT);                                        \
+    const long long units = (long long)M * splits, cap = (long long)kCUs * occ;                                      \
+    hipLaunchKernelGGL((pn_fwd_mfma_kernel<CI, PN, TP>),                                                             \
+                       dim3((unsigned)(units < cap ? units : cap), (unsigned)(d.C[l] / (64 * PN))), dim3(kT), 0, s,  \
+                       IN, w.bn[l - 1], conv_w[l - 1], d.C[l], iw.vlist, (int)N, splits, YO, w.partial, TV, TN);     \
+  }
       if (l == 5) {
-        if (F == 256) MPA_FWD(128, 4, true, w.Y[4], (float*)nullptr, w.topv, iw.topn);
-        else if (F == 128) MPA_FWD(128, 2, true, w.Y[4], (float*)nullptr, w.topv, iw.topn);
-        else MPA_FWD(128, 1, true, w.Y[4], (float*)nullptr, w.topv, iw.topn);
+        if (F == 256) MPA_FWD(128, 4, true, w.Y[4], (float*)nullptr, w.topv, iw.topn)
+        else if (F == 128) MPA_FWD(128, 2, true, w.Y[4], (float*)nullptr, w.topv, iw.topn)
+        else MPA_FWD(128, 1, true, w.Y[4], (float*)nullptr, w.topv, iw.topn)
       } else if (d.C[l] == 128) {
-        MPA_FWD(64, 2, false, w.Y[l - 1], w.Y[l], (float*)nullptr, (int*)nullptr);
+        MPA_FWD(64, 2, false, w.Y[l - 1], w.Y[l], (float*)nullptr, (int*)nullptr)
       } else {
-        MPA_FWD(64, 1, false, w.Y[l - 1], w.Y[l], (float*)nullptr, (int*)nullptr);
+        MPA_FWD(64, 1, false, w.Y[l - 1], w.Y[l], (float*)nullptr, (int*)nullptr)
       }
 #undef MPA_FWD
     }
@@ -1454,10 +1490,14 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
                      grad_feat, w.coef[5], valids, (int)N, (int)F, iw.erow, iw.ech, w.eval, iw.tptr);
   hipLaunchKernelGGL(pn_top_q_kernel, dim3((unsigned)(C4 + 1)), dim3((unsigned)C4), 0, s, conv_w[4], w.coef[5], (int)F,
                      C4, w.q);
-  hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 2, 2, true>), dim3((unsigned)(M * d.splits_dtop), (unsigned)(C4 / 128)),
-                     dim3(kT), 0, s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w.q, C4,
-                     w.Y[4], w.bn[4], valids, (int)N, d.splits_dtop, w.dZ[4], w.partial, iw.erow, iw.ech, w.eval, iw.tptr,
-                     conv_w[4], (int)F);
+  {
+    static const int occ = blocks_per_cu(pn_dgrad_mfma_kernel<128, 2, 2, true>, kT);
+    const long long units = (long long)M * d.splits_dtop, cap = (long long)kCUs * occ;
+    hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 2, 2, true>), dim3((unsigned)(units < cap ? units : cap), (unsigned)(C4 / 128)),
+                       dim3(kT), 0, s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w.q, C4,
+                       w.Y[4], w.bn[4], iw.vlist, (int)N, d.splits_dtop, w.dZ[4], w.partial, iw.erow, iw.ech, w.eval,
+                       iw.tptr, conv_w[4], (int)F);
+  }
   hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(C4 / 64), (unsigned)((M * d.splits_dtop + kEB - 1) / kEB)),
                      dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, d.splits_dtop, C4, w.count, bn_w[3], w.bn[4],
                      w.coef[4], grad_bn_w[3], grad_bn_b[3], w.coop);
