@@ -455,7 +455,7 @@ __global__ __launch_bounds__(kT) void pn_fwd_first_kernel(const float* __restric
 // BatchNorm statistics fall out of the accumulator layout (fixed-order reduction, no atomics).
 // TOP (last layer): Y is not stored; the block leaves the per-channel top-2 records of its rows instead.
 template <int CIN, int PANELS, bool TOP>
-__global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
+__global__ __launch_bounds__(kT, 2) void pn_fwd_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ bn_prev, const float* __restrict__ w, int cout,
     const int* __restrict__ vlist, int N, int splits, float* __restrict__ y_out,
     float* __restrict__ partial, float* __restrict__ topv, int* __restrict__ topn) {
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(kT) void pn_fwd_mfma_kernel(
 // one-hot row selector as A operand and the W5 row of the entry's channel as B operand.
 // grid = (M*splits, cin / (32*NT*PANELS)), block 256.
 template <int K, int NT, int PANELS, bool TOP>
-__global__ __launch_bounds__(kT) void pn_dgrad_mfma_kernel(
+__global__ __launch_bounds__(kT, 2) void pn_dgrad_mfma_kernel(
     const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
     const float* __restrict__ w, int cin, const float* __restrict__ y_prev, const float* __restrict__ bn_prev,
     const int* __restrict__ vlist, int N, int splits, float* __restrict__ dz_prev,
@@ -1491,9 +1491,9 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   hipLaunchKernelGGL(pn_top_q_kernel, dim3((unsigned)(C4 + 1)), dim3((unsigned)C4), 0, s, conv_w[4], w.coef[5], (int)F,
                      C4, w.q);
   {
-    static const int occ = blocks_per_cu(pn_dgrad_mfma_kernel<128, 2, 2, true>, kT);
+    static const int occ = blocks_per_cu(pn_dgrad_mfma_kernel<128, 1, 4, true>, kT);
     const long long units = (long long)M * d.splits_dtop, cap = (long long)kCUs * occ;
-    hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 2, 2, true>), dim3((unsigned)(units < cap ? units : cap), (unsigned)(C4 / 128)),
+    hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 1, 4, true>), dim3((unsigned)(units < cap ? units : cap), (unsigned)(C4 / 128)),
                        dim3(kT), 0, s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w.q, C4,
                        w.Y[4], w.bn[4], iw.vlist, (int)N, d.splits_dtop, w.dZ[4], w.partial, iw.erow, iw.ech, w.eval,
                        iw.tptr, conv_w[4], (int)F);
