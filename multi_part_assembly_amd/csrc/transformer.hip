@@ -257,22 +257,38 @@ struct WgradArgs {
   int M, N, K;
   Drop drop;           // WP_DROP on dY
   unsigned site;
+  int pro;             // WPro
 };
 
-// grid = (N/32 * K/32), block = 16 waves that split the M rows (640 tokens -> 40 rows = 20 MFMA k-steps each);
-// ONE 32 x 32 output tile per block, again so that the ~0.3 GFLOP spread over every CU (64..256 blocks).  Lane
-// (j, h) reads, per step, dY[row 2s+h][n0+j] and X[row 2s+h][k0+j] (128 B per half-wave each), all issued before
-// the first MFMA.  The 16 partial tiles are summed by a fixed-order tree through LDS
-// (deterministic), the bias gradient likewise.
-constexpr int kWT = 1024, kWW = kWT / 64;
+// Up to kGroup independent weight gradients share one launch (the four of a transformer layer's backward: each
+// alone is a ~10 us latency-bound kernel); blocks [first[i], first[i+1]) work on problem i.
+constexpr int kGroup = 4;
+struct WgradGroup {
+  WgradArgs p[kGroup];
+  int first[kGroup + 1];
+};
 
-template <int APRO>
-__global__ __launch_bounds__(kWT) void wgrad_kernel(const WgradArgs g) {
-  __shared__ float sm[kWW / 2][16][64];
+// grid = (N/32 * K/32) blocks per problem, block = 4 waves that split the M rows (640 tokens -> 160 rows = 80 MFMA
+// k-steps each); ONE 32 x 32 output tile per block: a layer's four problems are 768 small blocks, all resident at
+// once (3 per CU), so that one wave's loads overlap the other waves' MFMA chains on the same SIMD — a CU that runs
+// a whole 16-wave block in lockstep instead alternates between waiting for loads and queueing on the MFMA pipe.
+// Lane (j, h) reads, per step, dY[row 2s+h][n0+j] and X[row 2s+h][k0+j] (128 B per half-wave each), twenty steps'
+// loads in flight at a time.  The 4 partial tiles are summed in fixed order through LDS (deterministic), the bias
+// gradient likewise.
+constexpr int kWT = 256, kWW = kWT / 64;
+
+__global__ __launch_bounds__(kWT) void wgrad_kernel(const WgradGroup G) {
+  __shared__ float sm[kWW - 1][16][64];
   __shared__ float sb[kWW][32];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < kGroup; ++i) pi += (int)blockIdx.x >= G.first[i] ? 1 : 0;  // first[] is non-decreasing
+  const WgradArgs& g = G.p[pi];
+  const int blk = (int)blockIdx.x - G.first[pi];
+  const bool dropped = g.pro == WP_DROP;  // block-uniform
   const int kg = g.K / 32;
-  const int n0 = (blockIdx.x / kg) * 32, k0 = (blockIdx.x % kg) * 32;
+  const int n0 = (blk / kg) * 32, k0 = (blk % kg) * 32;
   const int per = ((g.M + kWW - 1) / kWW + 1) & ~1;  // rows per wave, even
   const int mb = wave * per, me = mb + per < g.M ? mb + per : g.M, ns = per / 2;
   f32x16 acc = {0};
@@ -290,12 +306,12 @@ __global__ __launch_bounds__(kWT) void wgrad_kernel(const WgradArgs g) {
     if (s >= ns) return;
     const int row = mb + 2 * s + h;
     float a = f.a, b = f.b;
-    if constexpr (APRO == WP_DROP) a *= drop_scale(g.drop, g.site, (unsigned long long)row * g.N + n0 + j);
+    if (dropped) a *= drop_scale(g.drop, g.site, (unsigned long long)row * g.N + n0 + j);
     if (row >= me) a = b = 0.0f;
     bsum += a;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
   };
-  constexpr int U = 20;  // 640 tokens -> 20 steps per wave: every load of the wave is in flight at once
+  constexpr int U = 20;
   for (int s0 = 0; s0 < ns; s0 += U) {
     Frag f[U];
 #pragma unroll
@@ -306,22 +322,19 @@ __global__ __launch_bounds__(kWT) void wgrad_kernel(const WgradArgs g) {
   }
   bsum += __shfl_xor(bsum, 32, 64);
   if (h == 0) sb[wave][j] = bsum;
-  // fixed-order tree: waves [half, 2*half) hand their tile to waves [0, half)
-  for (int half = kWW / 2; half >= 1; half >>= 1) {
-    if (wave >= half && wave < 2 * half) {
+  if (wave > 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sm[wave - half][r][lane] = acc[r];
-    }
-    __syncthreads();
-    if (wave < half) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += sm[wave][r][lane];
-    }
-    __syncthreads();
+    for (int r = 0; r < 16; ++r) sm[wave - 1][r][lane] = acc[r];
   }
+  __syncthreads();
   if (wave == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) g.dW[(long long)(n0 + acc_row(r, h)) * g.K + k0 + j] = acc[r];
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[r];
+#pragma unroll
+      for (int wv = 0; wv < kWW - 1; ++wv) v += sm[wv][r][lane];  // fixed order
+      g.dW[(long long)(n0 + acc_row(r, h)) * g.K + k0 + j] = v;
+    }
   } else if (wave == 1 && g.db != nullptr && k0 == 0 && lane < 32) {
     float s = 0.0f;
 #pragma unroll
@@ -624,10 +637,21 @@ void launch_gemm(const GemmArgs& g, hipStream_t s) {
   }
 }
 
-template <int APRO>
-void launch_wgrad(const WgradArgs& g, hipStream_t s) {
-  hipLaunchKernelGGL((wgrad_kernel<APRO>), dim3((g.N / 32) * (g.K / 32)), dim3(kWT), 0, s, g);
+// one launch for n <= kGroup weight gradients
+void launch_wgrad_group(const WgradArgs* list, int n, hipStream_t s) {
+  WgradGroup G{};
+  int blocks = 0;
+  for (int i = 0; i < kGroup; ++i) {
+    G.first[i] = blocks;
+    if (i < n) {
+      G.p[i] = list[i];
+      blocks += (list[i].N / 32) * (list[i].K / 32);
+    }
+  }
+  G.first[kGroup] = blocks;
+  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)blocks), dim3(kWT), 0, s, G);
 }
+
 
 GemmArgs gemm_args(const float* A, const float* W, const float* bias, float* C, int M, int N, int K) {
   GemmArgs g{};
@@ -652,6 +676,7 @@ WgradArgs wgrad_args(const float* dY, const float* X, float* dW, float* db, int 
   g.N = N;
   g.K = K;
   g.drop = Drop{0, 0.0f, 1.0f, nullptr};
+  g.pro = WP_NONE;
   return g;
 }
 
@@ -807,17 +832,19 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     const unsigned site0 = (unsigned)(l * S_PER_LAYER);
     // ---- FFN: x_out = x_mid + drop(f . W2^T + b2),  f = drop(relu(LN2(x_mid) . W1^T + b1));  the dropout mask of
     // the incoming gradient is regenerated inside the consumers (no masked copy is materialised)
-    WgradArgs wa = wgrad_args(g, t.f, gp[P_W2], gp[P_B2], M, Di, FFi);
-    wa.drop = drop;
-    wa.site = site0 + S_FFN_OUT;
-    launch_wgrad<WP_DROP>(wa, s);
+    // (the layer's four weight gradients are off the critical path and all their operands stay intact until the
+    // layer's last LayerNorm backward: they go out as ONE launch just before it)
+    WgradArgs wl[4];
+    wl[0] = wgrad_args(g, t.f, gp[P_W2], gp[P_B2], M, Di, FFi);
+    wl[0].drop = drop;
+    wl[0].site = site0 + S_FFN_OUT;
+    wl[0].pro = WP_DROP;
     GemmArgs ga = gemm_args(g, pp[P_W2], nullptr, w.dz, M, FFi, Di);  // W2 is [D, FF] = [K, N]
     ga.resid = t.f;
     ga.drop = drop;
     ga.pro_site = site0 + S_FFN_OUT;
     launch_gemm<PRO_DROP, EPI_RELU_MASK, true>(ga, s);  // dz = d(pre-activation)
-    wa = wgrad_args(w.dz, t.h2, gp[P_W1], gp[P_B1], M, FFi, Di);
-    launch_wgrad<WP_NONE>(wa, s);
+    wl[1] = wgrad_args(w.dz, t.h2, gp[P_W1], gp[P_B1], M, FFi, Di);
     launch_gemm<PRO_NONE, EPI_NONE, true>(gemm_args(w.dz, pp[P_W1], nullptr, spare2, M, Di, FFi), s);  // d LN2 output
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, spare2, t.x_mid, t.stats2, pp[P_G2], g,
                        M, Di, spare, w.lnpart);  // spare = d x_mid
@@ -825,19 +852,19 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     float* g_mid = spare;
     spare = g;
     // ---- attention block: x_mid = x_in + drop(o . Wo^T + bo)
-    wa = wgrad_args(g_mid, t.o, gp[P_WO], gp[P_BO], M, Di, Di);
-    wa.drop = drop;
-    wa.site = site0 + S_SA_OUT;
-    launch_wgrad<WP_DROP>(wa, s);
+    wl[2] = wgrad_args(g_mid, t.o, gp[P_WO], gp[P_BO], M, Di, Di);
+    wl[2].drop = drop;
+    wl[2].site = site0 + S_SA_OUT;
+    wl[2].pro = WP_DROP;
     ga = gemm_args(g_mid, pp[P_WO], nullptr, spare2, M, Di, Di);
     ga.drop = drop;
     ga.pro_site = site0 + S_SA_OUT;
     launch_gemm<PRO_DROP, EPI_NONE, true>(ga, s);  // d o
     hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
                        (int)H, drop, site0 + S_ATTN, w.dqkv);
-    wa = wgrad_args(w.dqkv, t.h1, gp[P_WQKV], gp[P_BQKV], M, 3 * Di, Di);
-    launch_wgrad<WP_NONE>(wa, s);
+    wl[3] = wgrad_args(w.dqkv, t.h1, gp[P_WQKV], gp[P_BQKV], M, 3 * Di, Di);
     launch_gemm<PRO_NONE, EPI_NONE, true>(gemm_args(w.dqkv, pp[P_WQKV], nullptr, spare2, M, Di, 3 * Di), s);  // d LN1 out
+    launch_wgrad_group(wl, 4, s);  // before the kernel below overwrites g's buffer
     float* g_in = l == 0 ? grad_tokens : spare;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, spare2, t.x_in, t.stats1, pp[P_G1], g_mid,
                        M, Di, g_in, w.lnpart);
@@ -893,11 +920,12 @@ extern "C" int mpa_pose_head_backward(const float* grad_rot, const float* grad_t
                      params[4], params[6], h2, Mi, 128, dqt, d2);  // d2 = gradient at fc2's pre-activation
   hipLaunchKernelGGL(head_wgrad_kernel, dim3(2), dim3(1024), 0, s, dqt, h2, Mi, 128, grad_params[4], grad_params[5],
                      grad_params[6], grad_params[7]);
-  launch_wgrad<WP_NONE>(wgrad_args(d2, h1, grad_params[2], grad_params[3], Mi, 128, 256), s);
   GemmArgs ga = gemm_args(d2, params[2], nullptr, d1, Mi, 256, 128);  // fc2.weight is [128, 256] = [K, N]
   ga.resid = h1;
   launch_gemm<PRO_NONE, EPI_LEAKY_MASK, true>(ga, s);
-  launch_wgrad<WP_NONE>(wgrad_args(d1, x, grad_params[0], grad_params[1], Mi, 256, (int)F), s);
   launch_gemm<PRO_NONE, EPI_NONE, true>(gemm_args(d1, params[0], nullptr, grad_x, Mi, (int)F, 256), s);
+  const WgradArgs wl[2] = {wgrad_args(d2, h1, grad_params[2], grad_params[3], Mi, 128, 256),
+                           wgrad_args(d1, x, grad_params[0], grad_params[1], Mi, 256, (int)F)};
+  launch_wgrad_group(wl, 2, s);  // both weight gradients in one launch, off the path to grad_x
   return mpa::check_launch("pose_head_backward");
 }

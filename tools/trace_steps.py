@@ -8,6 +8,7 @@ ap.add_argument("trace")
 ap.add_argument("--marker", default="adam_kernel")
 ap.add_argument("--last", type=int, default=3)
 ap.add_argument("--top", type=int, default=40)
+ap.add_argument("--seq", default=None, help="also list, in launch order, the last step's kernels whose name contains this")
 a = ap.parse_args()
 rows = list(csv.DictReader(open(a.trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -29,3 +30,11 @@ print(f"steps={n} wall/step={(t1 - t0) / n / 1e6:.3f} ms  kernel-busy/step={busy
 print(f"{'ms/step':>9} {'calls/step':>10} {'avg us':>9}  kernel")
 for name, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[: a.top]:
     print(f"{d / n / 1e6:9.3f} {c / n:10.1f} {d / c / 1e3:9.1f}  {name[:120]}")
+if a.seq:
+    last = rows[marks[-2] + 1: marks[-1] + 1]
+    print(f"-- last step, launch order, kernels matching {a.seq!r} (start offset us, duration us, grid, block)")
+    for r in last:
+        if a.seq in r["Kernel_Name"]:
+            print(f"{(int(r['Start_Timestamp']) - int(last[0]['Start_Timestamp'])) / 1e3:10.1f} "
+                  f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f}  "
+                  f"{r.get('Grid_Size_X', r.get('Grid_Size', '?'))} {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?'))}  {r['Kernel_Name'][:60]}")
