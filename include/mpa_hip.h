@@ -271,6 +271,15 @@ int mpa_adam_step_dev(float* param, const float* grad, float* exp_avg, float* ex
                       const float* hyper, float beta1, float beta2, float eps, float weight_decay,
                       int decoupled_weight_decay, void* stream);
 
+/* ---- batch producer (device side) -------------------------------------------------------------------------
+ * Replaces the per-part numpy work of GeometryPartDataset.__getitem__ (multi_part_assembly/datasets/
+ * geometry_data.py:74-107,133-146) for a whole batch: raw [M,N,3] float64 sampled points (M = B*max_num_part
+ * slots), rot [M,9] float64 row-major rotation matrices, perm [M,N] int32 point orders, valids [M] ->
+ * part_pcs [M,N,3] float32 = ((rot @ (p - centroid))[perm]) and part_trans [M,3] float32 = centroid; padded
+ * slots are zero-filled.  float64 arithmetic like the reference, fixed summation order. */
+int mpa_part_batch_transform(const double* raw, const double* rot, const int32_t* perm, const float* valids,
+                             int64_t M, int64_t N, float* part_pcs, float* part_trans, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,251 @@
+"""Batch producers: the `data_dict` contract at the entry of the hot path.
+
+Mirrors `GeometryPartDataset` (multi_part_assembly/datasets/geometry_data.py:11-207) and
+`PartNetPartDataset` (multi_part_assembly/datasets/partnet_data.py:7-243) plus torch's default collate:
+the same keys, shapes and dtypes, batched `[B, ...]` and already on the device.
+
+* Breaking-Bad-style geometry data: the per-part numpy work of `__getitem__` (centroid, recentre, random
+  rotation, point shuffle, zero padding, float32 cast) runs for the whole batch in ONE HIP launch
+  (`mpa_part_batch_transform`, csrc/batch.hip) on the raw sampled points; the host only draws the random
+  rotations and point orders — with the reference's own RNG calls, in its order, so a seeded run reproduces
+  the reference's batches — and converts the 3x3 matrices to scalar-first quaternions with scipy exactly as
+  the reference does.  Mesh loading + surface sampling (`trimesh`, geometry_data.py:109-131) is a pluggable
+  `sampler`; this image has no trimesh, so the default sampler raises.
+* PartNet-style semantic data: the on-disk format is plain numpy (`{category}.{split}.npy` id lists,
+  `shape_data/{id}_level3.npy` pickled dicts, `contact_points/pairs_with_contact_points_{id}_level3.npy`);
+  the label derivations (`instance_label`, `match_ids`, one-hot `part_label`) are host integer logic.
+"""
+from __future__ import annotations
+
+import os
+import random
+from typing import Callable, Iterable, Sequence
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation as R
+
+from . import _lib
+
+
+def _no_sampler(folder):
+    raise RuntimeError(
+        "GeometryBatchProducer: no mesh sampler configured (trimesh is not available in this image); pass "
+        "`sampler=folder -> float64 [p, N, 3]` or call produce() with already sampled part clouds")
+
+
+def _to_device(arr: np.ndarray, device) -> torch.Tensor:
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    if device is not None and torch.device(device).type == "cuda":
+        return t.pin_memory().to(device, non_blocking=True)
+    return t
+
+
+class GeometryBatchProducer:
+    """`GeometryPartDataset` + default collate, one HIP launch per batch for the per-part transforms."""
+
+    def __init__(self, num_points=1000, min_num_part=2, max_num_part=20, rot_range=-1, data_keys=("part_ids",),
+                 device="cuda", sampler: Callable | None = None, data_list: Sequence[str] = ()):
+        self.num_points = num_points
+        self.min_num_part = min_num_part
+        self.max_num_part = max_num_part
+        self.rot_range = rot_range
+        self.data_keys = tuple(data_keys)
+        for key in self.data_keys:  # geometry_data.py:189-201
+            if key not in ("part_ids", "valid_matrix"):
+                raise ValueError(f"ERROR: unknown data {key}")
+        self.device = torch.device(device)
+        self.sampler = sampler or _no_sampler
+        self.data_list = list(data_list)
+
+    def __len__(self):
+        return len(self.data_list)
+
+    # -- host randomness, in the reference's call order (geometry_data.py:80-100) --------------------------
+    def _draw_rotation(self):
+        if self.rot_range > 0.0:
+            rot_euler = (np.random.rand(3) - 0.5) * 2.0 * self.rot_range
+            rot_mat = R.from_euler("xyz", rot_euler, degrees=True).as_matrix()
+        else:
+            rot_mat = R.random().as_matrix()
+        quat = R.from_matrix(rot_mat.T).as_quat()[[3, 0, 1, 2]]  # scalar-first, the inverse rotation
+        return rot_mat, quat
+
+    def _draw_order(self, n):
+        order = np.arange(n)
+        random.shuffle(order)
+        return order
+
+    def produce(self, items: Iterable[np.ndarray], data_ids: Sequence[int] | None = None) -> dict:
+        """items: per sample a float64 array [p, N, 3] of sampled part points (what `_get_pcs` returns).
+        Returns the collated `data_dict` on `self.device`."""
+        items = [np.asarray(x, dtype=np.float64) for x in items]
+        B, P, N = len(items), self.max_num_part, self.num_points
+        raw = np.zeros((B, P, N, 3), dtype=np.float64)
+        rot = np.zeros((B, P, 9), dtype=np.float64)
+        perm = np.zeros((B, P, N), dtype=np.int32)
+        quat = np.zeros((B, P, 4), dtype=np.float32)
+        valids = np.zeros((B, P), dtype=np.float32)
+        for b, pcs in enumerate(items):
+            p = pcs.shape[0]
+            if not self.min_num_part <= p <= self.max_num_part or pcs.shape[1:] != (N, 3):
+                raise ValueError(f"sample {b}: expected [{self.min_num_part}..{P}, {N}, 3], got {pcs.shape}")
+            raw[b, :p] = pcs
+            valids[b, :p] = 1.0
+            for i in range(p):  # per part: rotation first, then the point order — as __getitem__ does
+                rot_mat, q = self._draw_rotation()
+                rot[b, i] = rot_mat.reshape(9)
+                quat[b, i] = q
+                perm[b, i] = self._draw_order(N)
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("GeometryBatchProducer: the transform runs on the HIP device only")
+        with torch.cuda.device(dev):
+            d_raw, d_rot, d_perm, d_val = (_to_device(a, dev) for a in (raw, rot, perm, valids))
+            part_pcs = torch.empty((B, P, N, 3), dtype=torch.float32, device=dev)
+            part_trans = torch.empty((B, P, 3), dtype=torch.float32, device=dev)
+            st = _lib.lib().mpa_part_batch_transform(_lib.ptr(d_raw), _lib.ptr(d_rot), _lib.ptr(d_perm),
+                                                     _lib.ptr(d_val), B * P, N, _lib.ptr(part_pcs),
+                                                     _lib.ptr(part_trans), _lib.current_stream(dev))
+        _lib.check(st, "mpa_part_batch_transform")
+        out = {
+            "part_pcs": part_pcs,
+            "part_quat": _to_device(quat, dev),
+            "part_trans": part_trans,
+            "part_valids": d_val,
+            "data_id": torch.as_tensor(list(range(B)) if data_ids is None else list(data_ids), dtype=torch.int64),
+            # zero-width labels keep the semantic models' concatenations valid (geometry_data.py:181-187)
+            "instance_label": torch.zeros((B, P, 0), dtype=torch.float32, device=dev),
+            "part_label": torch.zeros((B, P, 0), dtype=torch.float32, device=dev),
+        }
+        num_parts = valids.sum(1).astype(np.int64)
+        if "part_ids" in self.data_keys:
+            ids = np.zeros((B, P), dtype=np.float32)
+            for b, p in enumerate(num_parts):
+                ids[b, :p] = np.arange(p)
+            out["part_ids"] = _to_device(ids, dev)
+        if "valid_matrix" in self.data_keys:
+            out["valid_matrix"] = d_val[:, :, None] * d_val[:, None, :]
+        return out
+
+    def batch(self, indices: Sequence[int]) -> dict:
+        """Sample the fracture folders `data_list[i]` with the configured sampler and produce the batch."""
+        return self.produce([self.sampler(self.data_list[i]) for i in indices], data_ids=indices)
+
+
+# ---- PartNet ---------------------------------------------------------------------------------------------------
+def instance_labels(geo_part_ids: np.ndarray, max_num_part: int) -> np.ndarray:
+    """One-hot rank of every part among the geometrically equivalent parts before it (partnet_data.py:160-170):
+    `[0,4,4,4,1]` -> ranks `[0,0,1,2,0]`."""
+    ids = np.asarray(geo_part_ids).astype(np.int64)
+    p = ids.shape[0]
+    same_before = (ids[None, :] == ids[:, None]) & (np.arange(p)[None, :] < np.arange(p)[:, None])
+    out = np.zeros((max_num_part, max_num_part), dtype=np.float32)
+    out[np.arange(p), same_before.sum(1)] = 1.0
+    return out
+
+
+def match_ids(geo_part_ids: np.ndarray, max_num_part: int) -> np.ndarray:
+    """Groups of >= 2 equivalent parts numbered 1, 2, ... in increasing id order; everything else (unique ids,
+    id 0, padding) is 0 (partnet_data.py:194-208)."""
+    ids = np.zeros(max_num_part, dtype=np.float32)
+    ids[: len(geo_part_ids)] = geo_part_ids
+    out = np.zeros_like(ids)
+    values, counts = np.unique(ids[ids >= 1], return_counts=True)  # ascending, like the reference's range(1, max+1)
+    for label, v in enumerate(values[counts >= 2], start=1):
+        out[ids == v] = label
+    return out
+
+
+class PartNetBatchProducer:
+    """`PartNetPartDataset` + default collate; reads the reference's on-disk format."""
+
+    LEVEL = 3  # fixed in the paper (partnet_data.py:33)
+
+    def __init__(self, data_dir, data_fn, data_keys, num_part_category=20, min_num_part=2, max_num_part=20,
+                 shuffle_parts=False, overfit=-1, device="cuda"):
+        self.data_dir = data_dir
+        self.num_part_category = num_part_category
+        self.min_num_part = min_num_part
+        self.max_num_part = max_num_part
+        self.shuffle_parts = shuffle_parts
+        self.data_keys = tuple(data_keys)
+        self.device = torch.device(device)
+        self.shape_ids = [s for s in np.load(os.path.join(data_dir, data_fn))
+                          if min_num_part <= self._load(s)["part_pcs"].shape[0] <= max_num_part]
+        if overfit > 0:
+            self.shape_ids = self.shape_ids[:overfit]
+
+    def __len__(self):
+        return len(self.shape_ids)
+
+    def _load(self, shape_id) -> dict:
+        fn = os.path.join(self.data_dir, "shape_data", f"{shape_id}_level{self.LEVEL}.npy")
+        return np.load(fn, allow_pickle=True).item()
+
+    def _pad(self, data) -> np.ndarray:
+        data = np.asarray(data)
+        out = np.zeros((self.max_num_part,) + data.shape[1:], dtype=np.float32)
+        out[: data.shape[0]] = data
+        return out
+
+    def item(self, index) -> dict:
+        """One sample as host arrays — the dict `PartNetPartDataset.__getitem__` returns."""
+        shape_id = self.shape_ids[index]
+        cur = self._load(shape_id)
+        p = cur["part_pcs"].shape[0]
+        if self.shuffle_parts:
+            order = np.random.permutation(p)
+            cur = {k: np.array(v)[order] for k, v in cur.items()}
+        P = self.max_num_part
+        pose = self._pad(cur["part_poses"])
+        valids = np.zeros(P, dtype=np.float32)
+        valids[:p] = 1.0
+        geo = np.asarray(cur["geo_part_ids"])
+        d = {
+            "part_pcs": self._pad(cur["part_pcs"]),
+            "part_trans": pose[:, :3],
+            "part_quat": pose[:, 3:],
+            "part_valids": valids,
+            "data_id": index,
+            "shape_id": int(shape_id),
+            "instance_label": instance_labels(geo, P),
+        }
+        if "part_label" in self.data_keys:  # labels in the files start from 1
+            one_hot = np.zeros((p, self.num_part_category), dtype=np.float32)
+            one_hot[np.arange(p), np.asarray(cur["part_ids"]) - 1] = 1.0
+            d["part_label"] = self._pad(one_hot)
+        else:
+            d["part_label"] = np.zeros((P, 0), dtype=np.float32)
+        for key in self.data_keys:
+            if key == "part_label":
+                continue
+            if key == "part_ids":
+                d[key] = self._pad(geo)
+            elif key == "match_ids":
+                d[key] = match_ids(geo, P)
+            elif key == "contact_points":
+                fn = os.path.join(self.data_dir, "contact_points",
+                                  f"pairs_with_contact_points_{shape_id}_level{self.LEVEL}.npy")
+                out = np.zeros((P, P, 4), dtype=np.float32)
+                out[:p, :p] = np.load(fn, allow_pickle=True)
+                d[key] = out
+            elif key == "sym":
+                d[key] = self._pad(cur["sym"])
+            elif key == "valid_matrix":
+                d[key] = valids[:, None] * valids[None, :]
+            else:
+                raise ValueError(f"ERROR: unknown data {key}")
+        return d
+
+    def batch(self, indices: Sequence[int]) -> dict:
+        """Default collate of `item(i)` for i in indices, moved to the device."""
+        items = [self.item(i) for i in indices]
+        out = {}
+        for k in items[0]:
+            vals = [it[k] for it in items]
+            if isinstance(vals[0], np.ndarray):
+                out[k] = _to_device(np.stack(vals), self.device)
+            else:
+                out[k] = torch.as_tensor(vals, dtype=torch.int64)
+        return out

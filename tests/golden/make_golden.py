@@ -489,6 +489,75 @@ def gen_pn_transformer_eval():
 
 
 # --------------------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------------------
+# batch producers: the reference datasets' __getitem__ on seeded synthetic inputs
+def build_partnet_mini(root):
+    """A tiny dataset in the reference's PartNet on-disk format (written by this script, committed as data)."""
+    g = np.random.default_rng(2024)
+    (root / "shape_data").mkdir(parents=True, exist_ok=True)
+    (root / "contact_points").mkdir(parents=True, exist_ok=True)
+    specs = {101: [0, 4, 4, 4, 1, 2, 3], 102: [0, 1, 1, 2, 3, 4, 4, 4], 103: [3, 3, 1, 1], 104: list(range(9)),
+             105: [2, 5]}
+    np.save(root / "Chair.train.npy", np.array(list(specs), dtype=np.int64))
+    for sid, geo in specs.items():
+        p = len(geo)
+        quat = g.normal(size=(p, 4))
+        quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+        data = {
+            "part_pcs": g.normal(size=(p, 32, 3)).astype(np.float32) * 0.1,
+            "part_poses": np.concatenate([g.uniform(-0.5, 0.5, size=(p, 3)), quat], 1).astype(np.float32),
+            "part_ids": g.integers(1, 6, size=p),
+            "geo_part_ids": np.array(geo, dtype=np.int64),
+            "sym": g.integers(0, 2, size=(p, 3)).astype(np.float32),
+            "bbox": g.uniform(0.05, 0.3, size=(p, 3)).astype(np.float32),
+        }
+        np.save(root / "shape_data" / f"{sid}_level3.npy", data, allow_pickle=True)
+        contact = np.zeros((p, p, 4), dtype=np.float32)
+        contact[..., 0] = g.integers(0, 2, size=(p, p))
+        contact[..., 1:] = g.uniform(-0.3, 0.3, size=(p, p, 3)) * contact[..., :1]
+        np.save(root / "contact_points" / f"pairs_with_contact_points_{sid}_level3.npy", contact)
+
+
+def gen_batch_producer():
+    import random
+
+    from multi_part_assembly.datasets.geometry_data import GeometryPartDataset
+    from multi_part_assembly.datasets.partnet_data import PartNetPartDataset
+
+    out = {}
+    # geometry: __getitem__ with the mesh sampler replaced by seeded synthetic part clouds
+    N, P = 64, 6
+    g = np.random.default_rng(7)
+    parts = [2, 5, 4]
+    raws = [g.normal(size=(p, N, 3)) * g.uniform(0.02, 0.3, size=(p, 1, 3)) + g.uniform(-0.4, 0.4, size=(p, 1, 3))
+            for p in parts]
+    for tag, rot_range in (("free", -1), ("range", 30.0)):
+        ds = object.__new__(GeometryPartDataset)
+        ds.num_points, ds.min_num_part, ds.max_num_part = N, 2, P
+        ds.shuffle_parts, ds.rot_range = False, rot_range
+        ds.data_list = [f"item{i}" for i in range(len(parts))]
+        ds.data_keys = ("part_ids", "valid_matrix")
+        ds._get_pcs = lambda folder: raws[int(folder[4:])].copy()
+        np.random.seed(77)
+        random.seed(77)
+        items = [ds[i] for i in range(len(parts))]
+        for k in items[0]:
+            out[f"geo.{tag}.{k}"] = np.stack([np.asarray(it[k]) for it in items])
+    for i, r in enumerate(raws):
+        out[f"geo.raw{i}"] = r
+    # PartNet: the reference loader on the mini dataset
+    root = HERE / "partnet_mini"
+    build_partnet_mini(root)
+    keys = ("part_label", "part_ids", "match_ids", "contact_points", "sym", "valid_matrix")
+    ds = PartNetPartDataset(str(root), "Chair.train.npy", keys, num_part_category=5, min_num_part=2, max_num_part=8)
+    out["partnet.shape_ids"] = np.array(ds.shape_ids)
+    for i in range(len(ds)):
+        for k, v in ds[i].items():
+            out[f"partnet.{i}.{k}"] = np.asarray(v)
+    save("batch_producer", **out)
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -511,6 +580,7 @@ def main():
         "pn_refine_step": gen_pn_refine_step,
         "eval_metrics": lambda: gen_eval_metrics(U),
         "pn_transformer_eval": gen_pn_transformer_eval,
+        "batch_producer": gen_batch_producer,
     }
     for name, fn in todo.items():
         if not only or name in only:
