@@ -287,8 +287,24 @@ __global__ __launch_bounds__(kWT) void wgrad_kernel(const WgradGroup G) {
   const WgradArgs& g = G.p[pi];
   const int blk = (int)blockIdx.x - G.first[pi];
   const bool dropped = g.pro == WP_DROP;  // block-uniform
-  const int kg = g.K / 32;
-  const int n0 = (blk / kg) * 32, k0 = (blk % kg) * 32;
+  // tile of this block.  Blocks go to the 8 XCDs round-robin and every XCD has its own L2: the blocks of one XCD
+  // take a contiguous eighth of the tiles along the LARGER operand's dimension, so that operand is pulled into
+  // exactly one L2 (plain row-major tile order makes all 8 L2s fetch both operands in full: measured 42 MB of
+  // fetches per layer for ~6 MB of operands).
+  const int tn = g.N / 32, tk = g.K / 32;
+  int nt, kt;
+  const bool big_k = tk >= tn;
+  const int tbig = big_k ? tk : tn;
+  if (tbig % 8 == 0 && G.first[pi] % 8 == 0) {
+    const int xcd = blk & 7, slot = blk >> 3, per_xcd = tbig / 8;
+    const int big = xcd * per_xcd + slot % per_xcd, small = slot / per_xcd;
+    nt = big_k ? small : big;
+    kt = big_k ? big : small;
+  } else {
+    nt = blk / tk;
+    kt = blk % tk;
+  }
+  const int n0 = nt * 32, k0 = kt * 32;
   const int per = ((g.M + kWW - 1) / kWW + 1) & ~1;  // rows per wave, even
   const int mb = wave * per, me = mb + per < g.M ? mb + per : g.M, ns = per / 2;
   f32x16 acc = {0};
@@ -454,11 +470,16 @@ __global__ __launch_bounds__(kAT) void attn_bwd_kernel(const float* __restrict__
 // ---- LayerNorm backward -----------------------------------------------------------------------------------------------------
 // dx[row] = resid[row] + rstd * (dh*gamma - mean(dh*gamma) - xhat * mean(dh*gamma*xhat));  one wave per row.
 // Per-block partial sums of dgamma = sum dh*xhat and dbeta = sum dh go to part[block][2][D].
+// dx_drop (nullable): also writes dx with the dropout mask of `site` applied — dx is the gradient at the output of a
+// residual branch that ended in dropout, and BOTH consumers of the masked gradient (the branch's weight gradient
+// and its input-gradient GEMM) would otherwise regenerate the mask once per output tile (a 64-bit hash per
+// element and tile: 14 of the 32 us of a layer's weight-gradient launch).
 __global__ __launch_bounds__(kT) void ln_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x,
                                                     const float* __restrict__ stats,
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ resid, int M, int D,
-                                                    float* __restrict__ dx, float* __restrict__ part) {
+                                                    float* __restrict__ dx, float* __restrict__ part,
+                                                    const Drop drop, unsigned site, float* __restrict__ dx_drop) {
   extern __shared__ float sm[];  // [4 waves][2][D]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * (kT / 64) + wave;
@@ -476,7 +497,9 @@ __global__ __launch_bounds__(kT) void ln_bwd_kernel(const float* __restrict__ dh
     s2 = wave_sum(s2) / (float)D;
     for (int k = lane; k < D; k += 64) {
       const float xh = (x[o + k] - mean) * rstd, g = dh[o + k];
-      dx[o + k] = (resid ? resid[o + k] : 0.0f) + rstd * (g * gamma[k] - s1 - xh * s2);
+      const float v = (resid ? resid[o + k] : 0.0f) + rstd * (g * gamma[k] - s1 - xh * s2);
+      dx[o + k] = v;
+      if (dx_drop != nullptr) dx_drop[o + k] = v * drop_scale(drop, site, (unsigned long long)(o + k));
       mine[k] = g * xh;
       mine[D + k] = g;
     }
@@ -696,7 +719,7 @@ struct TfLayout {
   TfWs layer[16];
   float *x_final, *stats_f;
   // backward scratch
-  float *g_a, *g_b, *g_c, *dz, *dqkv, *lnpart;
+  float *g_a, *g_b, *g_c, *gd_out, *gd_mid, *dz, *dqkv, *lnpart;
   int64_t total;
 };
 
@@ -725,6 +748,8 @@ TfLayout tf_carve(float* base, const TfDims& d) {
   w.g_a = take(d.M * d.D);
   w.g_b = take(d.M * d.D);
   w.g_c = take(d.M * d.D);
+  w.gd_out = take(d.M * d.D);  // dropout-masked copies of the gradients at the two residual branches' outputs
+  w.gd_mid = take(d.M * d.D);
   w.dz = take(d.M * d.FF);
   w.dqkv = take(d.M * 3 * d.D);
   w.lnpart = take(((d.M + 3) / 4) * 2 * d.D);
@@ -819,8 +844,11 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
   const float* const* fin = params + L * P_PER_LAYER;
   float* const* gfin = grad_params + L * P_PER_LAYER;
   // final LayerNorm backward -> g_a = d x_final
+  // every LayerNorm backward below also leaves the dropout-masked copy its consumers need (see ln_bwd_kernel)
+  const bool dr = dropout_p > 0.0f;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, grad_out, w.x_final, w.stats_f, fin[0],
-                     (const float*)nullptr, M, Di, w.g_a, w.lnpart);
+                     (const float*)nullptr, M, Di, w.g_a, w.lnpart, drop, (unsigned)((L - 1) * S_PER_LAYER + S_FFN_OUT),
+                     dr ? w.gd_out : (float*)nullptr);
   hipLaunchKernelGGL(ln_reduce_kernel, red, dim3(1024), 0, s, w.lnpart, (int)lnblocks, Di, gfin[0], gfin[1]);
   float* g = w.g_a;      // gradient w.r.t. the current layer's output
   float* spare = w.g_b;  // rotating buffers
@@ -835,31 +863,24 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     // (the layer's four weight gradients are off the critical path and all their operands stay intact until the
     // layer's last LayerNorm backward: they go out as ONE launch just before it)
     WgradArgs wl[4];
-    wl[0] = wgrad_args(g, t.f, gp[P_W2], gp[P_B2], M, Di, FFi);
-    wl[0].drop = drop;
-    wl[0].site = site0 + S_FFN_OUT;
-    wl[0].pro = WP_DROP;
-    GemmArgs ga = gemm_args(g, pp[P_W2], nullptr, w.dz, M, FFi, Di);  // W2 is [D, FF] = [K, N]
+    const float* gdo = dr ? w.gd_out : g;  // drop-masked g (site S_FFN_OUT of this layer)
+    wl[0] = wgrad_args(gdo, t.f, gp[P_W2], gp[P_B2], M, Di, FFi);
+    GemmArgs ga = gemm_args(gdo, pp[P_W2], nullptr, w.dz, M, FFi, Di);  // W2 is [D, FF] = [K, N]
     ga.resid = t.f;
-    ga.drop = drop;
-    ga.pro_site = site0 + S_FFN_OUT;
-    launch_gemm<PRO_DROP, EPI_RELU_MASK, true>(ga, s);  // dz = d(pre-activation)
+    ga.drop = drop;  // the epilogue's keep-scale of the hidden layer's dropout (f > 0 <=> kept and active)
+    launch_gemm<PRO_NONE, EPI_RELU_MASK, true>(ga, s);  // dz = d(pre-activation)
     wl[1] = wgrad_args(w.dz, t.h2, gp[P_W1], gp[P_B1], M, FFi, Di);
     launch_gemm<PRO_NONE, EPI_NONE, true>(gemm_args(w.dz, pp[P_W1], nullptr, spare2, M, Di, FFi), s);  // d LN2 output
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, spare2, t.x_mid, t.stats2, pp[P_G2], g,
-                       M, Di, spare, w.lnpart);  // spare = d x_mid
+                       M, Di, spare, w.lnpart, drop, site0 + S_SA_OUT,
+                       dr ? w.gd_mid : (float*)nullptr);  // spare = d x_mid
     hipLaunchKernelGGL(ln_reduce_kernel, red, dim3(1024), 0, s, w.lnpart, (int)lnblocks, Di, gp[P_G2], gp[P_BE2]);
     float* g_mid = spare;
     spare = g;
     // ---- attention block: x_mid = x_in + drop(o . Wo^T + bo)
-    wl[2] = wgrad_args(g_mid, t.o, gp[P_WO], gp[P_BO], M, Di, Di);
-    wl[2].drop = drop;
-    wl[2].site = site0 + S_SA_OUT;
-    wl[2].pro = WP_DROP;
-    ga = gemm_args(g_mid, pp[P_WO], nullptr, spare2, M, Di, Di);
-    ga.drop = drop;
-    ga.pro_site = site0 + S_SA_OUT;
-    launch_gemm<PRO_DROP, EPI_NONE, true>(ga, s);  // d o
+    const float* gdm = dr ? w.gd_mid : g_mid;  // drop-masked g_mid (site S_SA_OUT)
+    wl[2] = wgrad_args(gdm, t.o, gp[P_WO], gp[P_BO], M, Di, Di);
+    launch_gemm<PRO_NONE, EPI_NONE, true>(gemm_args(gdm, pp[P_WO], nullptr, spare2, M, Di, Di), s);  // d o
     hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
                        (int)H, drop, site0 + S_ATTN, w.dqkv);
     wl[3] = wgrad_args(w.dqkv, t.h1, gp[P_WQKV], gp[P_BQKV], M, 3 * Di, Di);
@@ -867,7 +888,8 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     launch_wgrad_group(wl, 4, s);  // before the kernel below overwrites g's buffer
     float* g_in = l == 0 ? grad_tokens : spare;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, spare2, t.x_in, t.stats1, pp[P_G1], g_mid,
-                       M, Di, g_in, w.lnpart);
+                       M, Di, g_in, w.lnpart, drop, (unsigned)((l - 1) * S_PER_LAYER + S_FFN_OUT),
+                       dr && l > 0 ? w.gd_out : (float*)nullptr);  // (the grouped launch above has read gd_out)
     hipLaunchKernelGGL(ln_reduce_kernel, red, dim3(1024), 0, s, w.lnpart, (int)lnblocks, Di, gp[P_G1], gp[P_BE1]);
     if (l > 0) {  // next layer down: its output gradient is g_in; g_mid's buffer is free again
       g = spare;

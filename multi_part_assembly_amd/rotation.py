@@ -15,6 +15,17 @@ _TENSOR_METHODS = ("reshape", "view", "squeeze", "unsqueeze", "flatten", "unflat
                    "permute", "contiguous", "to", "cuda", "type", "type_as", "detach", "clone")
 
 
+_IDENT = {}
+
+
+def _identity_quat(device):
+    """(1, 0, 0, 0) on `device`, created once (the constructor runs several times per training step)."""
+    key = (device.type, device.index)
+    if key not in _IDENT:
+        _IDENT[key] = torch.tensor([1.0, 0.0, 0.0, 0.0], device=device)
+    return _IDENT[key]
+
+
 class Rotation3D:
     ROT_TYPE = ["quat"]
 
@@ -28,9 +39,7 @@ class Rotation3D:
         rot = rot.float()
         with torch.no_grad():
             keep = rot.norm(p=2, dim=-1, keepdim=True) > 0.5
-            ident = torch.zeros_like(rot)
-            ident[..., 0] = 1.0
-        self._rot = torch.where(keep, rot, ident)
+        self._rot = torch.where(keep, rot, _identity_quat(rot.device))  # [4] broadcasts over the batch
         self._rot_type = rot_type
 
     # --- value access -----------------------------------------------------------------------
