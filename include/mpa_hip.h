@@ -271,6 +271,27 @@ int mpa_adam_step_dev(float* param, const float* grad, float* exp_avg, float* ex
                       const float* hyper, float beta1, float beta2, float eps, float weight_decay,
                       int decoupled_weight_decay, void* stream);
 
+/* ---- GT <-> prediction matching of equivalent parts (semantic datasets) --------------------------------------
+ * Replaces BaseModel._linear_sum_assignment / _match_parts (multi_part_assembly/models/modules/base_model.py:
+ * 150-238: p x p Chamfer cost matrix on n = 100 sub-sampled points, scipy.optimize.linear_sum_assignment on the
+ * host, GT poses permuted inside every group) with device code for all groups of a batch, no host round trip.
+ *
+ * mpa_linear_sum_assignment: `problems` square cost matrices cost [problems, ld, ld] (float32, the top-left
+ *   sizes[i] x sizes[i] block of each is the problem, ld <= 64) -> col4row [problems, ld] (column assigned to each
+ *   row, -1 past the size).  scipy's shortest-augmenting-path algorithm (rectangular_lsap.cpp, scipy 1.15.3)
+ *   step by step in float64: same assignment as scipy, ties included.
+ * mpa_match_parts: match_ids [B,P] int32 (0 = unique or padded, g >= 1 = group g; G = number of group slots
+ *   considered, groups with id > G are left unmatched), sample_idx [B,G,n] int32 point indices (the reference
+ *   draws torch.randperm(N)[:n] per group), poses as [B,P,3] / [B,P,4] (w,x,y,z).  Writes new_trans / new_quat
+ *   (the GT poses after rearrangement), perm [B,P] (source slot of every slot), and leaves the cost matrices
+ *   [B,G,P,P] and assignments [B,G,P] in the two workspaces. */
+int mpa_linear_sum_assignment(const float* cost, const int32_t* sizes, int64_t problems, int64_t ld,
+                              int32_t* col4row, void* stream);
+int mpa_match_parts(const float* part_pcs, const float* pred_trans, const float* pred_quat, const float* gt_trans,
+                    const float* gt_quat, const int32_t* match_ids, const int32_t* sample_idx, int64_t B, int64_t P,
+                    int64_t N, int64_t G, int64_t n, float* cost_ws, int32_t* col4row_ws, float* new_trans,
+                    float* new_quat, int32_t* perm, void* stream);
+
 /* ---- batch producer (device side) -------------------------------------------------------------------------
  * Replaces the per-part numpy work of GeometryPartDataset.__getitem__ (multi_part_assembly/datasets/
  * geometry_data.py:74-107,133-146) for a whole batch: raw [M,N,3] float64 sampled points (M = B*max_num_part

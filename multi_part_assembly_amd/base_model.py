@@ -14,10 +14,10 @@ from __future__ import annotations
 import numpy as np
 import torch
 import torch.nn as nn
-from scipy.optimize import linear_sum_assignment
 
 from .chamfer import chamfer_distance
 from .eval_utils import calc_connectivity_acc, calc_part_acc, rot_metrics, trans_metrics
+from .matching import SUBSAMPLE, match_parts
 from .loss import (geometric_assembly_loss, rot_cosine_loss, rot_points_cd_loss,
                    rot_points_l2_loss, shape_cd_loss, trans_l2_loss)
 from .rotation import Rotation3D
@@ -64,9 +64,12 @@ class BaseModel(nn.Module):
     @torch.no_grad()
     def _linear_sum_assignment(self, pts, trans1, rot1, trans2, rot2):
         """Hungarian match between two pose sets of one equivalence group (base_model.py:150-179):
-        100 sub-sampled points, p x p Chamfer cost matrix on the GPU, scipy on the host."""
+        100 sub-sampled points, p x p Chamfer cost matrix on the GPU, scipy on the host.  Kept with the
+        reference's signature as the per-group cross-check of the batched device path `_match_parts` uses."""
+        from scipy.optimize import linear_sum_assignment
+
         p, N, _ = pts.shape
-        n = 100
+        n = min(SUBSAMPLE, N)
         sample_idx = torch.randperm(N)[:n].to(pts.device).long()
         pts = pts[:, sample_idx]
         pts1 = transform_pc(trans1, rot1, pts, self.rot_type)
@@ -79,24 +82,25 @@ class BaseModel(nn.Module):
         return (torch.from_numpy(rind).type_as(sample_idx), torch.from_numpy(cind).type_as(sample_idx))
 
     @torch.no_grad()
-    def _match_parts(self, part_pcs, pred_trans, pred_rot, gt_trans, gt_rot, match_ids):
-        """Permute the GT poses inside every group of geometrically equivalent parts so that they
-        line up with the predictions at minimum Chamfer cost (base_model.py:181-238)."""
-        match_ids = match_ids.long()
-        ids_host = match_ids.cpu().numpy()  # one sync instead of one .item() per sample
-        new_trans = gt_trans.detach().clone()
-        gt_q, pred_q = gt_rot.rot, pred_rot.rot
-        new_q = gt_q.detach().clone()
-        for b in range(part_pcs.shape[0]):
+    def _match_parts(self, part_pcs, pred_trans, pred_rot, gt_trans, gt_rot, match_ids, ids_host=None):
+        """Permute the GT poses inside every group of geometrically equivalent parts so that they line up with
+        the predictions at minimum Chamfer cost (base_model.py:181-238).  All groups of the batch are matched on
+        the device in one call (`matching.match_parts`: cost matrices, scipy's assignment algorithm, permutation);
+        the host only draws the point sub-samples — `torch.randperm(N)[:100]` per existing group, in the
+        reference's order, so a seeded run consumes the CPU generator exactly as the reference does.  `ids_host`
+        (numpy [B,P]) spares the one device-to-host copy of `match_ids` when the loader still has it."""
+        B, P, N, _ = part_pcs.shape
+        if ids_host is None:
+            ids_host = match_ids.long().cpu().numpy()
+        n = min(SUBSAMPLE, N)
+        G = max(1, int(ids_host.max()))
+        idx = torch.zeros((B, G, n), dtype=torch.int32)
+        for b in range(B):
             for group in range(1, int(ids_host[b].max()) + 1):
-                members = np.nonzero(ids_host[b] == group)[0].tolist()
-                if not members:
-                    continue
-                _, matched = self._linear_sum_assignment(
-                    part_pcs[b, members], pred_trans[b, members], pred_q[b, members],
-                    gt_trans[b, members], new_q[b, members])
-                new_trans[b, members] = gt_trans[b, members][matched]
-                new_q[b, members] = gt_q[b, members][matched]
+                if (ids_host[b] == group).any():
+                    idx[b, group - 1] = torch.randperm(N)[:n].to(torch.int32)
+        idx = idx.pin_memory().to(part_pcs.device, non_blocking=True)
+        new_trans, new_q = match_parts(part_pcs, pred_trans, pred_rot.rot, gt_trans, gt_rot.rot, match_ids, idx)
         return new_trans, Rotation3D(new_q, rot_type=self.rot_type)
 
     # ---- loss assembly ------------------------------------------------------------------------------
@@ -106,8 +110,10 @@ class BaseModel(nn.Module):
         part_pcs, valids = data_dict["part_pcs"], data_dict["part_valids"]
         gt_trans, gt_rot = data_dict["part_trans"], data_dict["part_rot"]
         if self.semantic:
+            if "_match_ids_host" not in data_dict:  # one copy per batch, shared by the min-of-N samples
+                data_dict["_match_ids_host"] = data_dict["match_ids"].long().cpu().numpy()
             new_trans, new_rot = self._match_parts(part_pcs, pred_trans, pred_rot, gt_trans, gt_rot,
-                                                   data_dict["match_ids"])
+                                                   data_dict["match_ids"], data_dict["_match_ids_host"])
         else:
             new_trans, new_rot = gt_trans.detach(), gt_rot.detach()
         if self.fused_loss and not self.semantic:

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(1024) void pn_top_wgrad_kernel(
     const float* __restrict__ y4, const float* __restrict__ bn4, const float* __restrict__ w5,
     const float* __restrict__ coef, const float* __restrict__ gram, int M, int N, int F,
     float* __restrict__ dw5) {
-  constexpr int C4 = 128, S = 8, U = 8;
+  constexpr int C4 = 128, S = 8, U = 20;  // 640 slots -> 4 rounds of two dependent load levels per thread
   __shared__ float sm[S][C4];
   const int c = blockIdx.x, ci = threadIdx.x & (C4 - 1), slice = threadIdx.x >> 7;
   const float sc = bn4[ci], sh = bn4[C4 + ci];
@@ -378,6 +378,7 @@ __global__ __launch_bounds__(1024) void pn_top_wgrad_kernel(
       g[u] = gfeat[(long long)mm * F + c];
       yv[u] = y4[((long long)mm * N + (arg >= 0 ? arg : 0)) * C4 + ci];
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (ok[u]) acc = __builtin_fmaf(g[u], __builtin_fmaxf(__builtin_fmaf(yv[u], sc, sh), 0.0f), acc);
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(1024) void pn_top_wgrad_kernel(
 #pragma unroll
   for (int k = 0; k < S; ++k) sparse += sm[k][ci];
   float wg = 0.0f;
-#pragma unroll 8
+#pragma unroll 32
   for (int k = 0; k < C4; ++k) wg = __builtin_fmaf(w5[(long long)c * C4 + k], gram[k * C4 + ci], wg);
   dw5[(long long)c * C4 + ci] = coef[c] * sparse + coef[F + c] * wg + coef[2 * F + c] * gram[C4 * C4 + ci];
 }

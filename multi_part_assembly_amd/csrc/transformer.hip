@@ -614,19 +614,32 @@ __global__ __launch_bounds__(1024) void head_wgrad_kernel(const float* __restric
   __shared__ float sm[16][8][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, k = blockIdx.x * 64 + lane;
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-  for (int row = wave; row < M; row += 16) {
-    const float x = k < K ? hfeat[(long long)row * K + k] : 0.0f;
-    const float4 d0 = *reinterpret_cast<const float4*>(dqt + 8 * row);
-    const float4 d1 = *reinterpret_cast<const float4*>(dqt + 8 * row + 4);
-    a[0] = __builtin_fmaf(d0.x, x, a[0]);
-    a[1] = __builtin_fmaf(d0.y, x, a[1]);
-    a[2] = __builtin_fmaf(d0.z, x, a[2]);
-    a[3] = __builtin_fmaf(d0.w, x, a[3]);
-    a[4] = __builtin_fmaf(d1.x, x, a[4]);
-    a[5] = __builtin_fmaf(d1.y, x, a[5]);
-    a[6] = __builtin_fmaf(d1.z, x, a[6]);
-    if (lane < 7) a[7] += dqt[8 * row + lane];  // bias gradients, lane = output
+  constexpr int U = 20;  // 640 tokens -> 40 rows per wave: two batches of loads, each fully in flight
+  for (int r0 = wave; r0 < M; r0 += 16 * U) {
+    float xs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = r0 + 16 * u;
+      xs[u] = (row < M && k < K) ? hfeat[(long long)row * K + k] : 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = r0 + 16 * u;
+      if (row < M) {  // wave-uniform; the dqt row arrives through the scalar cache
+        const float x = xs[u];
+        const float4 d0 = *reinterpret_cast<const float4*>(dqt + 8 * row);
+        const float4 d1 = *reinterpret_cast<const float4*>(dqt + 8 * row + 4);
+        a[0] = __builtin_fmaf(d0.x, x, a[0]);
+        a[1] = __builtin_fmaf(d0.y, x, a[1]);
+        a[2] = __builtin_fmaf(d0.z, x, a[2]);
+        a[3] = __builtin_fmaf(d0.w, x, a[3]);
+        a[4] = __builtin_fmaf(d1.x, x, a[4]);
+        a[5] = __builtin_fmaf(d1.y, x, a[5]);
+        a[6] = __builtin_fmaf(d1.z, x, a[6]);
+        if (lane < 7) a[7] += dqt[8 * row + lane];  // bias gradients, lane = output
+      }
+    }
   }
 #pragma unroll
   for (int c = 0; c < 8; ++c) sm[wave][c][lane] = a[c];
