@@ -284,6 +284,34 @@ def test_transformer_and_pose_head_full_size_match_library_ops(cuda_device):
     assert torch.equal(f1, f2) and torch.equal(gx1, gx2) and all(torch.equal(g1[k], g2[k]) for k in g1)
 
 
+def test_pose_head_odd_input_width_matches_library_ops(cuda_device):
+    """Input widths that are not multiples of 64 (semantic models append P labels and 32 noise channels; the
+    refinement model appends the 7-d pose) run on the HIP head through zero-padded panels."""
+    torch.manual_seed(5)
+    for width, noise in ((180, 0), (128 + 20, 32), (263, 0)):
+        head = StocasticPoseRegressor(feat_dim=width, noise_dim=noise).to(cuda_device).train()
+        x = torch.randn(7, 5, width, device=cuda_device)
+        w_r, w_t = torch.randn(7, 5, 4, device=cuda_device), torch.randn(7, 5, 3, device=cuda_device)
+
+        def run(native):
+            head.native = native
+            for p in head.parameters():
+                p.grad = None
+            torch.manual_seed(9)  # same noise channels on both paths
+            xi = x.clone().requires_grad_()
+            rot, trans = head(xi)
+            ((rot * w_r).sum() + (trans * w_t).sum()).backward()
+            return rot.detach(), trans.detach(), xi.grad.clone(), {k: p.grad.clone() for k, p in head.named_parameters()}
+
+        r1, t1, gx1, g1 = run(True)
+        r0, t0, gx0, g0 = run(False)
+        assert head.pad == (-(width + noise)) % 64 and head.pad != 0
+        assert _rel(r1.cpu().numpy(), r0.cpu().numpy()) < 1e-4 and _rel(t1.cpu().numpy(), t0.cpu().numpy()) < 1e-4
+        assert gx1.shape == x.shape and _rel(gx1.cpu().numpy(), gx0.cpu().numpy()) < 1e-3
+        for k in g0:
+            assert g1[k].shape == g0[k].shape and _rel(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 1e-3, k
+
+
 def test_grad_sink_direct_writes_equal_autograd_accumulation(cuda_device):
     """GradSink: backward kernels writing straight into the flat gradient buffer give bit-identical gradients
     to autograd's AccumulateGrad path, and a parameter used twice in one step falls back to accumulation."""
