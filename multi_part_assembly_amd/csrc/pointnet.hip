@@ -452,7 +452,8 @@ __global__ __launch_bounds__(kT) void pn_fwd_first_kernel(const float* __restric
 // contiguous RB*CIN-float run of the point-major input — is fetched by all 256 threads with coalesced 16-byte
 // loads ONE TILE AHEAD (registers), gets the previous layer's BatchNorm + ReLU on its way into a double-buffered
 // LDS panel, and is read back as MFMA fragments: the input crosses HBM/L2 once per block and the global latency
-// hides behind the previous tile's MFMA chain.  grid = (M*splits, cout / (64*PANELS)), block 256.
+// hides behind the previous tile's MFMA chain.  Persistent: grid = (min(M*splits, resident blocks), cout /
+// (64*PANELS)), block 256; a block keeps its weight panel and walks (valid part, split) units from `vlist`.
 // BatchNorm statistics fall out of the accumulator layout (fixed-order reduction, no atomics).
 // TOP (last layer): Y is not stored; the block leaves the per-channel top-2 records of its rows instead.
 template <int CIN, int PANELS, bool TOP>
@@ -638,7 +639,8 @@ __global__ __launch_bounds__(kT, 2) void pn_fwd_mfma_kernel(
 // staged like the forward operand, w = Q (symmetric 128 x 128, c0 behind it) and S the sparse arg-max gradient:
 // per tile a short extra MFMA chain over the part's CSR entries (erow, ech, eval; tptr = tile offsets) with the
 // one-hot row selector as A operand and the W5 row of the entry's channel as B operand.
-// grid = (M*splits, cin / (32*NT*PANELS)), block 256.
+// Persistent like the forward GEMM: grid = (min(M*splits, resident blocks), cin / (32*NT*PANELS)), block 256.
+// Only the TOP form is instantiated: layers 2-4 run pn_bwd_fused_kernel, which also produces the weight gradient.
 template <int K, int NT, int PANELS, bool TOP>
 __global__ __launch_bounds__(kT, 2) void pn_dgrad_mfma_kernel(
     const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(kT, 2) void pn_dgrad_mfma_kernel(
 //   WG_GRAM  : dY := A (COUT == CIN): the Gram matrix A^T A plus, in row COUT, the column sums of A — what the
 //              weight gradient of the never-stored last layer needs (pn_top_wgrad_kernel).
 constexpr int kWG = 512;  // persistent blocks (2 per CU)
-enum { WG_NORMAL = 0, WG_FIRST = 1, WG_GRAM = 2 };
+enum { WG_NORMAL = 0, WG_FIRST = 1, WG_GRAM = 2 };  // (WG_NORMAL: layers 2-4, now inside pn_bwd_fused_kernel)
 
 // LDY / co0: the block handles the COUT output channels starting at column co0 of a layer that is LDY wide
 // (the 64 -> 128 layer runs as two 64-channel slices, which keeps the double-buffered panels at 64 KB).

@@ -86,8 +86,7 @@ __global__ __launch_bounds__(kT) void ln_fwd_kernel(const float* __restrict__ x,
   }
 }
 
-// ---- GEMM  C[M,N] = epi(pro(A)[M,K] . W[N,K]^T + bias) ---------------------------------------------------------------
-enum Pro { PRO_NONE = 0, PRO_DROP = 2 };
+// ---- GEMM  C[M,N] = epi(A[M,K] . W[N,K]^T + bias) ---------------------------------------------------------------------
 enum Epi { EPI_NONE = 0, EPI_RELU_DROP = 1, EPI_DROP_RESID = 2, EPI_LEAKY = 3, EPI_RELU_MASK = 4, EPI_LEAKY_MASK = 5 };
 
 struct GemmArgs {
@@ -98,7 +97,7 @@ struct GemmArgs {
   int M, N, K;
   const float* resid;  // EPI_DROP_RESID: [M, N];  EPI_*_MASK: the saved activations [M, N]
   Drop drop;
-  unsigned pro_site, epi_site;
+  unsigned epi_site;
 };
 
 // grid = (ceil(M/32), N/32), block = 8 waves: the block owns ONE 32 x 32 MFMA tile and the waves split K.
@@ -124,7 +123,7 @@ __host__ __device__ inline int gemm_phase(int K) {
 // NPH > 0: K is exactly NPH phases and ALL global loads of the block are issued up front (NPH * 16 B * 2 per
 // thread in registers), so the block pays the L2/HBM latency once instead of once per phase; with NPH >= 3 the LDS
 // panels are double-buffered (one barrier per phase).  NPH == 0: any K, loads one phase ahead.
-template <int PRO, int EPI, bool WT, int NPH>
+template <int EPI, bool WT, int NPH>
 __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
   constexpr int kBuf = NPH >= 3 ? 2 : 1, kPanel = 2 * 32 * kLD;
   __shared__ __attribute__((aligned(16))) float lds[kBuf * kPanel];  // A panel | W panel; later the 8 partial tiles
@@ -159,16 +158,7 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
       const int idx = threadIdx.x + kGT * i;
       if (idx < cnt) {
         const int row = idx / q4, c4 = idx % q4;
-        float4 a = st.a[i];
-        if constexpr (PRO == PRO_DROP) {
-          const int ar = r0 + row < g.M ? r0 + row : g.M - 1;
-          const unsigned long long e = (unsigned long long)ar * g.K + ph * kp + 4 * c4;
-          a.x *= drop_scale(g.drop, g.pro_site, e);
-          a.y *= drop_scale(g.drop, g.pro_site, e + 1);
-          a.z *= drop_scale(g.drop, g.pro_site, e + 2);
-          a.w *= drop_scale(g.drop, g.pro_site, e + 3);
-        }
-        *reinterpret_cast<float4*>(la + buf * kPanel + row * ld + 4 * c4) = a;
+        *reinterpret_cast<float4*>(la + buf * kPanel + row * ld + 4 * c4) = st.a[i];
         if constexpr (WT) *reinterpret_cast<float4*>(lw + buf * kPanel + (idx >> 3) * 32 + 4 * (idx & 7)) = st.w[i];
         else *reinterpret_cast<float4*>(lw + buf * kPanel + row * ld + 4 * c4) = st.w[i];
       }
@@ -246,18 +236,13 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
   }
 }
 
-// ---- weight gradient  dW[N,K] = pro(dY)[M,N]^T . X[M,K],  db[N] = column sums of pro(dY) -----------------------------
-enum WPro { WP_NONE = 0, WP_DROP = 2 };
-
+// ---- weight gradient  dW[N,K] = dY[M,N]^T . X[M,K],  db[N] = column sums of dY ---------------------------------------
 struct WgradArgs {
   const float* dY;     // [M, N]
   const float* X;      // [M, K]
   float* dW;           // [N, K]
   float* db;           // [N] or null
   int M, N, K;
-  Drop drop;           // WP_DROP on dY
-  unsigned site;
-  int pro;             // WPro
 };
 
 // Up to kGroup independent weight gradients share one launch (the four of a transformer layer's backward: each
@@ -286,7 +271,6 @@ __global__ __launch_bounds__(kWT) void wgrad_kernel(const WgradGroup G) {
   for (int i = 1; i < kGroup; ++i) pi += (int)blockIdx.x >= G.first[i] ? 1 : 0;  // first[] is non-decreasing
   const WgradArgs& g = G.p[pi];
   const int blk = (int)blockIdx.x - G.first[pi];
-  const bool dropped = g.pro == WP_DROP;  // block-uniform
   // tile of this block.  Blocks go to the 8 XCDs round-robin and every XCD has its own L2: the blocks of one XCD
   // take a contiguous eighth of the tiles along the LARGER operand's dimension, so that operand is pulled into
   // exactly one L2 (plain row-major tile order makes all 8 L2s fetch both operands in full: measured 42 MB of
@@ -322,7 +306,6 @@ __global__ __launch_bounds__(kWT) void wgrad_kernel(const WgradGroup G) {
     if (s >= ns) return;
     const int row = mb + 2 * s + h;
     float a = f.a, b = f.b;
-    if (dropped) a *= drop_scale(g.drop, g.site, (unsigned long long)row * g.N + n0 + j);
     if (row >= me) a = b = 0.0f;
     bsum += a;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
@@ -660,16 +643,16 @@ __global__ __launch_bounds__(1024) void head_wgrad_kernel(const float* __restric
 }
 
 // ---- host helpers ---------------------------------------------------------------------------------------------------------------
-template <int PRO, int EPI, bool WT = false>
+template <int EPI, bool WT = false>
 void launch_gemm(const GemmArgs& g, hipStream_t s) {
   const dim3 grid((g.M + 31) / 32, g.N / 32), block(kGT);
   const int kp = gemm_phase(g.K);
   switch (kp == kKP || g.K <= kKP ? g.K / kp : 0) {  // full-size phases only
-    case 1: hipLaunchKernelGGL((gemm_kernel<PRO, EPI, WT, 1>), grid, block, 0, s, g); break;
-    case 2: hipLaunchKernelGGL((gemm_kernel<PRO, EPI, WT, 2>), grid, block, 0, s, g); break;
-    case 6: hipLaunchKernelGGL((gemm_kernel<PRO, EPI, WT, 6>), grid, block, 0, s, g); break;
-    case 8: hipLaunchKernelGGL((gemm_kernel<PRO, EPI, WT, 8>), grid, block, 0, s, g); break;
-    default: hipLaunchKernelGGL((gemm_kernel<PRO, EPI, WT, 0>), grid, block, 0, s, g); break;
+    case 1: hipLaunchKernelGGL((gemm_kernel<EPI, WT, 1>), grid, block, 0, s, g); break;
+    case 2: hipLaunchKernelGGL((gemm_kernel<EPI, WT, 2>), grid, block, 0, s, g); break;
+    case 6: hipLaunchKernelGGL((gemm_kernel<EPI, WT, 6>), grid, block, 0, s, g); break;
+    case 8: hipLaunchKernelGGL((gemm_kernel<EPI, WT, 8>), grid, block, 0, s, g); break;
+    default: hipLaunchKernelGGL((gemm_kernel<EPI, WT, 0>), grid, block, 0, s, g); break;
   }
 }
 
@@ -711,8 +694,6 @@ WgradArgs wgrad_args(const float* dY, const float* X, float* dW, float* db, int 
   g.M = M;
   g.N = N;
   g.K = K;
-  g.drop = Drop{0, 0.0f, 1.0f, nullptr};
-  g.pro = WP_NONE;
   return g;
 }
 
@@ -811,26 +792,26 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
     hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, l == 0 ? tokens : t.x_in, pp[P_G1], pp[P_BE1], M, Di, eps,
                        t.stats1, t.h1, l == 0 ? t.x_in : (float*)nullptr);
     GemmArgs g = gemm_args(t.h1, pp[P_WQKV], pp[P_BQKV], t.qkv, M, 3 * Di, Di);
-    launch_gemm<PRO_NONE, EPI_NONE>(g, s);
+    launch_gemm<EPI_NONE>(g, s);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, valid, (int)P, Di, (int)H,
                        drop, site0 + S_ATTN, t.probs, t.o);
     g = gemm_args(t.o, pp[P_WO], pp[P_BO], t.x_mid, M, Di, Di);
     g.resid = t.x_in;
     g.drop = drop;
     g.epi_site = site0 + S_SA_OUT;
-    launch_gemm<PRO_NONE, EPI_DROP_RESID>(g, s);
+    launch_gemm<EPI_DROP_RESID>(g, s);
     hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, t.x_mid, pp[P_G2], pp[P_BE2], M, Di, eps, t.stats2, t.h2,
                        (float*)nullptr);
     g = gemm_args(t.h2, pp[P_W1], pp[P_B1], t.f, M, FFi, Di);
     g.drop = drop;
     g.epi_site = site0 + S_FFN;
-    launch_gemm<PRO_NONE, EPI_RELU_DROP>(g, s);
+    launch_gemm<EPI_RELU_DROP>(g, s);
     float* x_out = l + 1 < L ? w.layer[l + 1].x_in : w.x_final;
     g = gemm_args(t.f, pp[P_W2], pp[P_B2], x_out, M, Di, FFi);
     g.resid = t.x_mid;
     g.drop = drop;
     g.epi_site = site0 + S_FFN_OUT;
-    launch_gemm<PRO_NONE, EPI_DROP_RESID>(g, s);
+    launch_gemm<EPI_DROP_RESID>(g, s);
   }
   const float* const* fin = params + L * P_PER_LAYER;
   hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, w.x_final, fin[0], fin[1], M, Di, eps, w.stats_f, out,
@@ -881,9 +862,9 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     GemmArgs ga = gemm_args(gdo, pp[P_W2], nullptr, w.dz, M, FFi, Di);  // W2 is [D, FF] = [K, N]
     ga.resid = t.f;
     ga.drop = drop;  // the epilogue's keep-scale of the hidden layer's dropout (f > 0 <=> kept and active)
-    launch_gemm<PRO_NONE, EPI_RELU_MASK, true>(ga, s);  // dz = d(pre-activation)
+    launch_gemm<EPI_RELU_MASK, true>(ga, s);  // dz = d(pre-activation)
     wl[1] = wgrad_args(w.dz, t.h2, gp[P_W1], gp[P_B1], M, FFi, Di);
-    launch_gemm<PRO_NONE, EPI_NONE, true>(gemm_args(w.dz, pp[P_W1], nullptr, spare2, M, Di, FFi), s);  // d LN2 output
+    launch_gemm<EPI_NONE, true>(gemm_args(w.dz, pp[P_W1], nullptr, spare2, M, Di, FFi), s);  // d LN2 output
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, spare2, t.x_mid, t.stats2, pp[P_G2], g,
                        M, Di, spare, w.lnpart, drop, site0 + S_SA_OUT,
                        dr ? w.gd_mid : (float*)nullptr);  // spare = d x_mid
@@ -893,11 +874,11 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     // ---- attention block: x_mid = x_in + drop(o . Wo^T + bo)
     const float* gdm = dr ? w.gd_mid : g_mid;  // drop-masked g_mid (site S_SA_OUT)
     wl[2] = wgrad_args(gdm, t.o, gp[P_WO], gp[P_BO], M, Di, Di);
-    launch_gemm<PRO_NONE, EPI_NONE, true>(gemm_args(gdm, pp[P_WO], nullptr, spare2, M, Di, Di), s);  // d o
+    launch_gemm<EPI_NONE, true>(gemm_args(gdm, pp[P_WO], nullptr, spare2, M, Di, Di), s);  // d o
     hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
                        (int)H, drop, site0 + S_ATTN, w.dqkv);
     wl[3] = wgrad_args(w.dqkv, t.h1, gp[P_WQKV], gp[P_BQKV], M, 3 * Di, Di);
-    launch_gemm<PRO_NONE, EPI_NONE, true>(gemm_args(w.dqkv, pp[P_WQKV], nullptr, spare2, M, Di, 3 * Di), s);  // d LN1 out
+    launch_gemm<EPI_NONE, true>(gemm_args(w.dqkv, pp[P_WQKV], nullptr, spare2, M, Di, 3 * Di), s);  // d LN1 out
     launch_wgrad_group(wl, 4, s);  // before the kernel below overwrites g's buffer
     float* g_in = l == 0 ? grad_tokens : spare;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, spare2, t.x_in, t.stats1, pp[P_G1], g_mid,
@@ -930,8 +911,8 @@ extern "C" int mpa_pose_head_forward(const float* x, const float* const* params,
   float* h1 = ws;
   float* h2 = h1 + M * 256;
   float* rot_raw = h2 + M * 128;
-  launch_gemm<PRO_NONE, EPI_LEAKY>(gemm_args(x, params[0], params[1], h1, (int)M, 256, (int)F), s);
-  launch_gemm<PRO_NONE, EPI_LEAKY>(gemm_args(h1, params[2], params[3], h2, (int)M, 128, 256), s);
+  launch_gemm<EPI_LEAKY>(gemm_args(x, params[0], params[1], h1, (int)M, 256, (int)F), s);
+  launch_gemm<EPI_LEAKY>(gemm_args(h1, params[2], params[3], h2, (int)M, 128, 256), s);
   hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(kT), 0, s, h2, params[4], params[5],
                      params[6], params[7], (int)M, 128, rot_raw, rot, trans);
   return mpa::check_launch("pose_head_forward");
@@ -957,8 +938,8 @@ extern "C" int mpa_pose_head_backward(const float* grad_rot, const float* grad_t
                      grad_params[6], grad_params[7]);
   GemmArgs ga = gemm_args(d2, params[2], nullptr, d1, Mi, 256, 128);  // fc2.weight is [128, 256] = [K, N]
   ga.resid = h1;
-  launch_gemm<PRO_NONE, EPI_LEAKY_MASK, true>(ga, s);
-  launch_gemm<PRO_NONE, EPI_NONE, true>(gemm_args(d1, params[0], nullptr, grad_x, Mi, (int)F, 256), s);
+  launch_gemm<EPI_LEAKY_MASK, true>(ga, s);
+  launch_gemm<EPI_NONE, true>(gemm_args(d1, params[0], nullptr, grad_x, Mi, (int)F, 256), s);
   const WgradArgs wl[2] = {wgrad_args(d2, h1, grad_params[2], grad_params[3], Mi, 128, 256),
                            wgrad_args(d1, x, grad_params[0], grad_params[1], Mi, 256, (int)F)};
   launch_wgrad_group(wl, 2, s);  // both weight gradients in one launch, off the path to grad_x
