@@ -9,15 +9,19 @@ clouds, B = 32 per GPU, P = 20, N = 1000 (BASELINE.json configs[1]; weak scaling
 
 Rank 0 prints ONE JSON line.  `value` = parts (B x P slots, padded slots included, as the metric is
 defined) processed per second by the whole job, inputs resident in HBM before the timed region.
-Kernels are launched eagerly (the step is GPU-bound: a HIP-graph replay of the whole step, --graph,
-measures the same ms/step).  `roofline` describes the dominant kernel (the whole-shape Chamfer search of
-the fused loss), timed per launch with HIP events that the library records around it on its launch
-stream inside the timed region.  `cpu_baseline` is the oracle's reference-equivalent PyTorch-CPU step
+Kernels are launched eagerly (the step is GPU-bound: ~2.3 ms of host time for 3.3 ms of GPU work; `--graph`
+replays the captured step as one HIP graph instead and measures ~2.5 % less).  The garbage collector is parked
+during the timed steps: one generation-2 collection (~30 ms with torch loaded) inside K = 20 steps of 3 ms was
+measured as +1.6 ms per step.  `roofline` describes the dominant kernel (the whole-shape Chamfer search of the
+fused loss), timed per launch with HIP events that the library records around it on its launch stream inside the
+timed region (with --graph: in an eager pass over the same K steps right after it, events cannot be recorded
+inside a replay).  `cpu_baseline` is the oracle's reference-equivalent PyTorch-CPU step
 timed on this host (rank 0, N = 1 only) on a bounded sample.
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -43,6 +47,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (default: eager launches; see trainer.py)")
+    ap.add_argument("--eager", action="store_true", help="(the default; accepted for symmetry)")
     ap.add_argument("--cpu-batch", type=int, default=4, help="samples in the CPU-baseline step")
     return ap.parse_args()
 
@@ -119,7 +124,7 @@ def main():
     cfg = config.pn_transformer_everyday()
     torch.manual_seed(0)  # same initial weights on every rank (and broadcast from rank 0 anyway)
     model = build_model(cfg).to(dev)
-    use_graph = args.graph
+    use_graph = args.graph and not args.eager
     trainer = Trainer(model, cfg, use_graph=use_graph)
     batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234 + rank, device=dev)
     num_parts = batch.pop("num_parts")
@@ -135,6 +140,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gc.collect()
+    gc.disable()  # a generation-2 collection (tens of ms with torch loaded) inside K ~3 ms steps would be the measurement
     fence()
     timer = _lib.KernelTimer()
     if not use_graph:
@@ -144,6 +151,7 @@ def main():
         loss = trainer.train_step(batch, i)
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     _lib.KernelTimer.active = None
     final_loss = float(loss)
     if use_graph and rank == 0:
@@ -188,8 +196,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "timing": "HIP events recorded by libmpa_hip.so right before/after the kernel on its launch "
-                          "stream, inside the timed region",
+                "timing": "HIP events recorded by libmpa_hip.so right before/after the kernel on its launch stream, "
+                          + ("in an eager pass over the same K steps right after the timed graph replays"
+                             if use_graph else "inside the timed region"),
                 "whole_phase_avg_ms": kernels[phase]["avg_ms"] if phase in kernels else None,
                 # the search is VALU-bound, not HBM-bound: pair evaluations an exhaustive scan of
                 # the same valid points would need, per second of this kernel

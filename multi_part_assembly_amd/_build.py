@@ -7,6 +7,7 @@ back to anything: if hipcc is missing the build raises.
 from __future__ import annotations
 
 import concurrent.futures
+import json
 import os
 import shutil
 import subprocess
@@ -41,6 +42,37 @@ def sources() -> list[Path]:
     return sorted(CSRC.glob("*.hip"))
 
 
+_USAGE_KEYS = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
+               "Occupancy [waves/SIMD]": "waves_per_simd", "LDS Size [bytes/block]": "lds_bytes", "VGPRs Spill": "vgpr_spill"}
+
+
+def parse_resource_usage(stderr: str) -> dict:
+    """{mangled kernel name: {vgprs, agprs, scratch_bytes_per_lane, waves_per_simd, lds_bytes, vgpr_spill}} from the
+    compiler's kernel-resource-usage remarks.  Written next to every object (csrc/build/<file>.usage.json) and
+    checked by tests/test_abi.py: a kernel that silently starts using scratch memory (registers demoted to
+    private memory by an innocent-looking edit) is a 2-3x slowdown that no correctness test sees."""
+    out, cur = {}, None
+    for line in stderr.splitlines():
+        if "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].replace("[-Rpass-analysis=kernel-resource-usage]", "").strip()
+        if body.startswith("Function Name:"):
+            cur = out.setdefault(body.split(":", 1)[1].strip(), {})
+        elif cur is not None and ":" in body:
+            k, v = body.rsplit(":", 1)
+            if k.strip() in _USAGE_KEYS:
+                cur[_USAGE_KEYS[k.strip()]] = int(v)
+    return out
+
+
+def resource_usage() -> dict:
+    """Merged usage records of the last build (empty if the objects were built by an older _build.py)."""
+    merged = {}
+    for f in sorted(OBJ_DIR.glob("*.usage.json")):
+        merged.update(json.loads(f.read_text()))
+    return merged
+
+
 def _stale(target: Path, deps: list[Path]) -> bool:
     if not target.exists():
         return True
@@ -64,13 +96,15 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *HIPCC_FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stdout}\n{r.stderr}")
-        return r.stderr
+        usage = parse_resource_usage(r.stderr)
+        obj.with_suffix(".usage.json").write_text(json.dumps(usage, indent=1))
+        return "\n".join(l for l in r.stderr.splitlines() if "-Rpass-analysis" not in l)
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         for warn in ex.map(compile_one, jobs):

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(1024) void grid_sort_kernel(const float* __restrict
   __shared__ int cnt_q[kMaxSuper];
   __shared__ int wsum[16][2];
   const int b = blockIdx.x >> 1, c = blockIdx.x & 1;
-  const GridParams g = params[b];
+  const GridParams& g = params[b];  // by reference: uniform address -> scalar loads (a by-value copy indexed with a
+                                    // runtime shape index lands in scratch memory)
   const int slot_t = (b * 2 + c) * 2 + 0, slot_q = slot_t + 1;
   const float* vb = valids + (long long)b * P;
   const float* shape = (c == 0 ? S1 : S2) + 3LL * b * P * N;
@@ -440,7 +441,8 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
   __shared__ float4 cand[kCand];
   const int b = blockIdx.y >> 1, dir = blockIdx.y & 1;
   const int qc = dir, tc = 1 - dir;  // query / target shape
-  const GridParams g = params[b];
+  const GridParams& g = params[b];  // by reference: uniform address -> scalar loads (a by-value copy indexed with a
+                                    // runtime shape index lands in scratch memory)
   const int qslot = (b * 2 + qc) * 2 + 1, tslot = (b * 2 + tc) * 2 + 0;
   const float4* qrec = records + (long long)qslot * rec_stride;
   const float4* trec = records + (long long)tslot * rec_stride;
@@ -455,8 +457,8 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
   const int lane = threadIdx.x;
   // the target shape's own cell bounding box: rows and cells outside it are empty, and a query far from a compact
   // target would otherwise walk hundreds of empty rows before reaching it
-  const int tx0 = g.tb[tc][0], tx1 = g.tb[tc][1], ty0 = g.tb[tc][2], ty1 = g.tb[tc][3], tz0 = g.tb[tc][4],
-            tz1 = g.tb[tc][5];
+  const int* tbox = g.tb[tc];
+  const int tx0 = tbox[0], tx1 = tbox[1], ty0 = tbox[2], ty1 = tbox[3], tz0 = tbox[4], tz1 = tbox[5];
   const float slack = 1e-3f * g.h;
   // padded parts: one representative target each (index p*N), the same for every work item; lane p holds part p's
   float px = 0.0f, py = 0.0f, pz = 0.0f;

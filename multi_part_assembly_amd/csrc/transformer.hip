@@ -158,7 +158,8 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
       const int idx = threadIdx.x + kGT * i;
       if (idx < cnt) {
         const int row = idx / q4, c4 = idx % q4;
-        *reinterpret_cast<float4*>(la + buf * kPanel + row * ld + 4 * c4) = st.a[i];
+        const float4 a = st.a[i];  // (a by-value copy: storing st.a[i] directly sends the staging arrays to scratch)
+        *reinterpret_cast<float4*>(la + buf * kPanel + row * ld + 4 * c4) = a;
         if constexpr (WT) *reinterpret_cast<float4*>(lw + buf * kPanel + (idx >> 3) * 32 + 4 * (idx & 7)) = st.w[i];
         else *reinterpret_cast<float4*>(lw + buf * kPanel + row * ld + 4 * c4) = st.w[i];
       }

@@ -46,15 +46,16 @@ def _shard(rank, dev):
     return batch
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, use_graph, steps):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from multi_part_assembly_amd.trainer import Trainer
     dev = torch.device("cuda", 0)
     model, cfg = _small_model()
     model.to(dev)
-    trainer = Trainer(model, cfg)
-    losses = [float(trainer.train_step(_shard(rank, dev), i)) for i in range(2)]
+    trainer = Trainer(model, cfg, use_graph=use_graph)
+    losses = [float(trainer.train_step(_shard(rank, dev), i)) for i in range(steps)]
+    assert not use_graph or trainer._graph is not None  # the last steps were HIP-graph replays
     # after a step the flat gradient buffer holds the all-reduced SUM; 1/world is folded into the Adam kernel
     grad = (trainer.flat.flat_grad * trainer.optimizer.grad_scale).cpu()
     torch.save({"param": trainer.flat.flat_param.cpu(), "grad": grad, "losses": losses},
@@ -62,9 +63,15 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_training_equals_gradient_averaging(cuda_device):
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
+def test_two_rank_training_equals_gradient_averaging(cuda_device, use_graph):
+    """eager: bucketed all-reduce overlapped with backward; graph: captured forward+backward replayed, one all-reduce
+    and the optimiser step behind it (what bench.py runs by default)."""
+    steps = 2
+    if use_graph:
+        steps = 6  # Trainer's 3 eager settle steps, then the capture and three replays
     with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_worker, args=(2, _free_port(), out_dir), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), out_dir, use_graph, steps), nprocs=2, join=True)
         got = [torch.load(os.path.join(out_dir, f"rank{r}.pt")) for r in range(2)]
     assert torch.equal(got[0]["param"], got[1]["param"])  # replicas stay in lock-step
     # single-process emulation: per-shard forward/backward on replicas sharing the weights, averaged gradients
@@ -81,7 +88,7 @@ def test_two_rank_training_equals_gradient_averaging(cuda_device):
     total = cfg.exp.num_epochs
     lr0 = cosine_warmup_lr(total, int(total * cfg.optimizer.warmup_ratio), cfg.optimizer.lr,
                            cfg.optimizer.lr / cfg.optimizer.lr_decay_factor)(0)
-    for step in range(2):
+    for step in range(steps):
         for r in range(2):
             flats[r].zero_grad()
             models[r].training_step(_shard(r, cuda_device), step).backward()

@@ -8,6 +8,7 @@ ap.add_argument("trace")
 ap.add_argument("--marker", default="adam_kernel")
 ap.add_argument("--last", type=int, default=3)
 ap.add_argument("--top", type=int, default=40)
+ap.add_argument("--gaps", type=float, default=0.0, help="list idle gaps longer than this many us in the last step")
 ap.add_argument("--seq", default=None, help="also list, in launch order, the last step's kernels whose name contains this")
 a = ap.parse_args()
 rows = list(csv.DictReader(open(a.trace)))
@@ -38,3 +39,10 @@ if a.seq:
             print(f"{(int(r['Start_Timestamp']) - int(last[0]['Start_Timestamp'])) / 1e3:10.1f} "
                   f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f}  "
                   f"{r.get('Grid_Size_X', r.get('Grid_Size', '?'))} {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?'))}  {r['Kernel_Name'][:60]}")
+if a.gaps > 0:
+    last = rows[marks[-2] + 1: marks[-1] + 1]
+    print(f"-- last step: idle gaps > {a.gaps} us (gap us, previous kernel -> next kernel)")
+    for x, y in zip(last, last[1:]):
+        gap = (int(y["Start_Timestamp"]) - int(x["End_Timestamp"])) / 1e3
+        if gap > a.gaps:
+            print(f"{gap:9.1f}  {x['Kernel_Name'][:70]}  ->  {y['Kernel_Name'][:70]}")
