@@ -193,11 +193,12 @@ int mpa_pointnet_backward(const float* grad_feat, const float* points, const flo
  * the k neighbour rows of U, apply BatchNorm2d (training != 0: statistics over all n*N*k edges, running statistics
  * updated with `momentum`; else the running statistics) + LeakyReLU(0.2) and take the max over the neighbours:
  * out [n*N, CO].  CO a multiple of 64 (<= 1024), k <= 32, N <= 65535.  `ws` (mpa_edge_aggregate_workspace bytes,
- * 256-byte aligned) carries the selected edges to backward, which overwrites grad_uv [n*N, 2*CO] (fp32 atomic
- * scatter over neighbours, like the reference's gather backward), grad_gamma and grad_beta [CO].
+ * 256-byte aligned) carries the selected edges to backward, which overwrites grad_uv [n*N, 2*CO], grad_gamma and
+ * grad_beta [CO]: the kNN graph of every part is transposed in the workspace and the neighbour sums are gathered in
+ * a fixed order (no atomics, bit-reproducible) for N <= 16384; larger parts use an fp32 atomic scatter.
  * ---------------------------------------------------------------------------------------------- */
 int mpa_knn(const float* x, int64_t n, int64_t N, int64_t C, int64_t K, int32_t* idx, void* stream);
-int mpa_edge_aggregate_workspace(int64_t n, int64_t N, int64_t CO, int64_t* bytes);
+int mpa_edge_aggregate_workspace(int64_t n, int64_t N, int64_t CO, int64_t K, int64_t* bytes);
 int mpa_edge_aggregate_forward(const float* uv, const int32_t* idx, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, int training, float momentum, float eps,
                                int64_t n, int64_t N, int64_t CO, int64_t K, void* ws, float* out, void* stream);

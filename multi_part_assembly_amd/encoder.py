@@ -139,7 +139,7 @@ class _EdgeAggFn(torch.autograd.Function):
         dev = uv.device
         lib = _lib.lib()
         nbytes = ctypes.c_int64()
-        _lib.check(lib.mpa_edge_aggregate_workspace(n, N, CO, ctypes.byref(nbytes)), "mpa_edge_aggregate_workspace")
+        _lib.check(lib.mpa_edge_aggregate_workspace(n, N, CO, K, ctypes.byref(nbytes)), "mpa_edge_aggregate_workspace")
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
         out = torch.empty((R, CO), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
