@@ -123,6 +123,13 @@ def test_edge_aggregate_matches_edge_tensor_formulation(cuda_device):
     want = [ref.detach(), xr.grad, w.grad, gamma.grad, beta.grad, rm2, rv2]
     for a, b, name in zip(got, want, ("out", "dx", "dw", "dgamma", "dbeta", "running_mean", "running_var")):
         assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-4, name
+    # the backward gathers over the transposed kNN graph in a fixed order: same call, bit-identical gradients
+    w.grad = gamma.grad = beta.grad = None
+    xs2 = x.clone().requires_grad_()
+    rm3, rv3 = torch.zeros(CO, device=cuda_device), torch.ones(CO, device=cuda_device)
+    out2 = _EdgeAggFn.apply(xs2.reshape(n * N, C) @ w_stack.t(), idx, gamma, beta, (rm3, rv3), True, 0.1, 1e-5, n, N)
+    (out2 * wout).sum().backward()
+    assert torch.equal(out2, got[0]) and torch.equal(xs2.grad, got[1]) and torch.equal(gamma.grad, got[3])
 
 
 def test_pointnet_masked_parts_equal_compacted(cuda_device):
