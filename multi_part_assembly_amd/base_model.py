@@ -18,7 +18,7 @@ import torch.nn as nn
 from .chamfer import chamfer_distance
 from .eval_utils import calc_connectivity_acc, calc_part_acc, rot_metrics, trans_metrics
 from .matching import SUBSAMPLE, match_parts
-from .loss import (geometric_assembly_loss, rot_cosine_loss, rot_points_cd_loss,
+from .loss import (LossTerms, geometric_assembly_loss, rot_cosine_loss, rot_points_cd_loss,
                    rot_points_l2_loss, shape_cd_loss, trans_l2_loss)
 from .rotation import Rotation3D
 from .transforms import transform_pc
@@ -120,11 +120,13 @@ class BaseModel(nn.Module):
             # one fused forward/backward pair instead of the per-function composition below
             terms, pts = geometric_assembly_loss(part_pcs, pred_trans, pred_rot, new_trans, new_rot,
                                                  valids, training=self.training, ret_pts=self.keep_pts)
-            loss_dict = {k: terms[k] for k in ("trans_loss", "rot_pt_cd_loss", "transform_pt_cd_loss")}
+            loss_dict = LossTerms((k, terms[k]) for k in ("trans_loss", "rot_pt_cd_loss", "transform_pt_cd_loss"))
             if self.cfg.loss.use_rot_loss:
                 loss_dict["rot_loss"] = terms["rot_loss"]
             if self.cfg.loss.use_rot_pt_l2_loss:
                 loss_dict["rot_pt_l2_loss"] = terms["rot_pt_l2_loss"]
+            if self.training and tuple(loss_dict) == terms.stacked[0]:
+                loss_dict.stacked = terms.stacked  # every row is used, in order: no select / re-stack
             if not self.training:
                 loss_dict.update(self._calc_metrics(data_dict, out_dict, new_trans, new_rot))
             out_dict = {"pred_trans": pred_trans, "pred_rot": pred_rot,
@@ -181,7 +183,11 @@ class BaseModel(nn.Module):
             # five per term (the step is ~200 launches, these would be ~40 of them)
             sample_loss, _ = self._loss_function(data_dict, {}, optimizer_idx=optimizer_idx)
             keys = list(sample_loss)
-            terms = torch.stack([sample_loss[k] for k in keys], dim=0)                       # [K, B]
+            stacked = getattr(sample_loss, "stacked", None)
+            if stacked is not None and list(stacked[0]) == keys:
+                terms = stacked[1]                                                            # [K, B] as computed
+            else:
+                terms = torch.stack([sample_loss[k] for k in keys], dim=0)                   # [K, B]
             cache = getattr(self, "_loss_weight_cache", None)
             if cache is None or cache[0] != keys or cache[1].device != terms.device:
                 w = [float(self.cfg.loss[f"{k}_w"]) if k.endswith("_loss") else 0.0 for k in keys]

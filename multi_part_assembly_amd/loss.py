@@ -105,6 +105,14 @@ def repulsion_cd_loss(part_pcs, valids, thre):
 LOSS_TERMS = ("trans_loss", "rot_pt_cd_loss", "transform_pt_cd_loss", "rot_loss", "rot_pt_l2_loss")
 
 
+class LossTerms(dict):
+    """{term name: [B]} that also carries the [K, B] tensor the terms are rows of (`stacked = (names, tensor)`):
+    `BaseModel.loss_function` weights that tensor directly — selecting five rows and stacking them again costs
+    ~15 small launches per step in autograd (five zero-filled [K, B] gradients, copies and adds)."""
+
+    stacked = None
+
+
 class _AssemblyLoss(torch.autograd.Function):
     """All five geometric loss terms in 5 launches forward / 1 launch backward (csrc/assembly_loss.hip)."""
 
@@ -172,5 +180,6 @@ def geometric_assembly_loss(part_pcs, pred_trans, pred_rot, gt_trans, gt_rot, va
         f(part_pcs), f(valids), _quat(pred_rot).to(torch.float32).contiguous(),
         pred_trans.to(torch.float32).contiguous(), f(_quat(gt_rot)), f(gt_trans), bool(training),
         bool(ret_pts))
-    terms = {name: losses[i] for i, name in enumerate(LOSS_TERMS)}
+    terms = LossTerms((name, losses[i]) for i, name in enumerate(LOSS_TERMS))
+    terms.stacked = (LOSS_TERMS, losses)
     return terms, ((pts[2], pts[3]) if ret_pts else None)
