@@ -107,6 +107,11 @@ int mpa_pose_apply_backward(const float* grad_out, const float* pc, const float*
                             const float* mask, float fill, int64_t num_parts, int64_t num_points,
                             float* grad_quat, float* grad_trans, float* grad_pc, void* stream);
 
+/* Rotation3D's constructor rule (multi_part_assembly/utils/rotation.py:115-126): quaternions [count, 4] whose
+ * norm is <= 0.5 (zero padding) are replaced by the identity (1,0,0,0); keep [count] receives 1 where the input
+ * was kept (the gradient gate).  One launch instead of norm + compare + where. */
+int mpa_quat_sanitize(const float* quat, int64_t count, float* out, float* keep, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused geometric-assembly loss — replaces, for the geometric datasets, the loss half of
  *   BaseModel._calc_loss : multi_part_assembly/models/modules/base_model.py:240-314

@@ -144,7 +144,29 @@ __global__ __launch_bounds__(kThreads) void pose_grad_kernel(
   }
 }
 
+// Rotation3D's constructor rule (utils/rotation.py:115-126 upstream): quaternions of norm <= 0.5 (zero padding) become
+// the identity.  One launch instead of norm + compare + where; keep [count] (0/1) gates the gradient.
+__global__ void quat_sanitize_kernel(const float* __restrict__ q, long long count, float* __restrict__ out,
+                                     float* __restrict__ keep) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float4 v = reinterpret_cast<const float4*>(q)[i];
+  // torch.norm(p=2): sqrt of the sum of squares
+  const bool ok = __builtin_sqrtf(((v.x * v.x + v.y * v.y) + v.z * v.z) + v.w * v.w) > 0.5f;
+  reinterpret_cast<float4*>(out)[i] = ok ? v : make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+  keep[i] = ok ? 1.0f : 0.0f;
+}
+
 }  // namespace
+
+extern "C" int mpa_quat_sanitize(const float* quat, int64_t count, float* out, float* keep, void* stream) {
+  MPA_REQUIRE(count >= 0, "quat_sanitize: negative size");
+  if (count == 0) return MPA_OK;
+  MPA_REQUIRE(quat && out && keep, "quat_sanitize: null pointer");
+  hipLaunchKernelGGL(quat_sanitize_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, mpa::as_stream(stream),
+                     quat, (long long)count, out, keep);
+  return mpa::check_launch("quat_sanitize");
+}
 
 extern "C" int mpa_pose_apply_forward(const float* pc, const float* quat, const float* trans,
                                       const float* mask, float fill, int64_t num_parts,

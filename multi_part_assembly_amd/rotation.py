@@ -26,6 +26,28 @@ def _identity_quat(device):
     return _IDENT[key]
 
 
+class _SanitizeFn(torch.autograd.Function):
+    """Quaternions with norm <= 0.5 -> identity (the constructor rule); the gradient passes where the input was kept."""
+
+    @staticmethod
+    def forward(ctx, rot):
+        from . import _lib
+        q = rot.contiguous()
+        out = torch.empty_like(q)
+        keep = torch.empty(q.shape[:-1] + (1,), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            st = _lib.lib().mpa_quat_sanitize(_lib.ptr(q), q.numel() // 4, _lib.ptr(out), _lib.ptr(keep),
+                                              _lib.current_stream(q.device))
+        _lib.check(st, "mpa_quat_sanitize")
+        ctx.save_for_backward(keep)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (keep,) = ctx.saved_tensors
+        return grad * keep
+
+
 class Rotation3D:
     ROT_TYPE = ["quat"]
 
@@ -37,9 +59,12 @@ class Rotation3D:
         assert isinstance(rot, torch.Tensor), "rotation must be a tensor"
         assert rot.shape[-1] == 4, "wrong quaternion shape"
         rot = rot.float()
-        with torch.no_grad():
-            keep = rot.norm(p=2, dim=-1, keepdim=True) > 0.5
-        self._rot = torch.where(keep, rot, _identity_quat(rot.device))  # [4] broadcasts over the batch
+        if rot.is_cuda:  # one HIP launch (csrc/pose.hip) instead of norm + compare + where
+            self._rot = _SanitizeFn.apply(rot)
+        else:
+            with torch.no_grad():
+                keep = rot.norm(p=2, dim=-1, keepdim=True) > 0.5
+            self._rot = torch.where(keep, rot, _identity_quat(rot.device))  # [4] broadcasts over the batch
         self._rot_type = rot_type
 
     # --- value access -----------------------------------------------------------------------

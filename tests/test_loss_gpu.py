@@ -206,3 +206,23 @@ def test_grid_pruned_search_handles_duplicates_and_flat_clouds(cuda_device, monk
     valid = v.bool()
     assert torch.equal(b1[valid], g1[valid]) and torch.equal(b2[valid], g2[valid])
     np.testing.assert_allclose(lg.cpu().numpy(), lb.cpu().numpy(), rtol=2e-6, atol=1e-9)
+
+
+def test_rotation3d_constructor_rule_on_device(cuda_device):
+    """Quaternions of norm <= 0.5 (zero padding) become the identity, gradients pass only where the input was kept
+    (rotation.py:115-126 upstream): the one-launch HIP path against the tensor-op composition on the CPU."""
+    from multi_part_assembly_amd.rotation import Rotation3D
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn(4, 7, 4, generator=g)
+    q[0, 0] = 0.0
+    q[1, 2] = torch.tensor([0.3, 0.0, 0.4, 0.0])    # norm exactly 0.5 -> identity
+    q[2, 3] = torch.tensor([0.3, 0.0, 0.4, 1e-3])   # just above
+    w = torch.randn(4, 7, 4, generator=g)
+    a = q.clone().requires_grad_()
+    b = q.clone().to(cuda_device).requires_grad_()
+    (Rotation3D(a).rot * w).sum().backward()
+    rb = Rotation3D(b).rot
+    (rb * w.to(cuda_device)).sum().backward()
+    assert torch.equal(rb.detach().cpu(), Rotation3D(q).rot)
+    assert torch.equal(b.grad.cpu(), a.grad)
+    assert torch.equal(rb[0, 0].cpu(), torch.tensor([1.0, 0, 0, 0])) and b.grad[0, 0].abs().sum() == 0
