@@ -210,8 +210,9 @@ __global__ __launch_bounds__(64 * kSlices) void pn_bwd_top_kernel(
 // ---- top-2 extrema records (last layer) --------------------------------------------------------------------------
 // The last layer has no ReLU and feeds a max over the points, so its output tensor is never stored: BatchNorm being
 // a per-channel monotone map, max_n z[n] is the image of max_n y[n] (scale > 0) or min_n y[n] (scale < 0).  The
-// forward GEMM keeps, per (part, channel), the two largest y and the two largest -y with their point indices
-// (order: value descending, index ascending).  Two, because z = fma(y, scale, shift) can round two distinct y to
+// sign of scale = gamma * invstd is gamma's, known before the statistics are: the forward GEMM keeps, per (part,
+// channel), the two largest sign(gamma) * y with their point indices (order: value descending, index ascending;
+// gamma == 0 maps every point to `shift` and is handled in the finalize kernel).  Two, because z = fma(y, scale, shift) can round two distinct y to
 // the SAME z, and the reference's arg-max then is the lower index of the two — decided once scale/shift are known.
 struct Top2 {
   float v1, v2;
@@ -255,7 +256,8 @@ __device__ __forceinline__ Top2 top2_shfl_xor(const Top2 t, int mask) {
 }
 
 // BatchNorm of the last layer + max over the points of each part from the per-block top-2 records.
-// topv/topn [M*splits][F][4] = (hi.v1, hi.v2, lo.v1, lo.v2) / indices, lo tracking -y.  One thread per (m, c).
+// topv/topn [M*splits][F][2] = the two largest s*y (s = the sign of the channel's gamma) and their indices.
+// One thread per (m, c).
 __global__ void pn_top_finalize_kernel(const float* __restrict__ topv, const int* __restrict__ topn,
                                        const float* __restrict__ bn, const float* __restrict__ valids,
                                        const float* __restrict__ y4, const float* __restrict__ bn4,
@@ -271,19 +273,17 @@ __global__ void pn_top_finalize_kernel(const float* __restrict__ topv, const int
     ybest[i] = 0.0f;
     return;
   }
-  Top2 hi = top2_empty(), lo = top2_empty();
+  Top2 t = top2_empty();
   for (int sp = 0; sp < splits; ++sp) {
-    const long long o = (((long long)m * splits + sp) * F + c) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(topv + o);
-    const int4 n = *reinterpret_cast<const int4*>(topn + o);
-    hi = top2_merge(hi, Top2{v.x, v.y, n.x, n.y});
-    lo = top2_merge(lo, Top2{v.z, v.w, n.z, n.w});
+    const long long o = (((long long)m * splits + sp) * F + c) * 2;
+    const float2 v = *reinterpret_cast<const float2*>(topv + o);
+    const int2 n = *reinterpret_cast<const int2*>(topn + o);
+    t = top2_merge(t, Top2{v.x, v.y, n.x, n.y});
   }
   const float scale = bn[c], shift = bn[F + c];
   float z, y;
   int arg;
-  if (scale != 0.0f) {
-    const Top2 t = scale > 0.0f ? hi : lo;
+  if (scale != 0.0f) {  // scale = gamma * invstd has gamma's sign: the records hold the extrema of sign(gamma) * y
     const float sg = scale > 0.0f ? 1.0f : -1.0f;
     const float y1 = sg * t.v1, y2 = sg * t.v2;
     const float z1 = __builtin_fmaf(y1, scale, shift), z2 = __builtin_fmaf(y2, scale, shift);
@@ -460,7 +460,8 @@ template <int CIN, int PANELS, bool TOP>
 __global__ __launch_bounds__(kT, 2) void pn_fwd_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ bn_prev, const float* __restrict__ w, int cout,
     const int* __restrict__ vlist, int N, int splits, float* __restrict__ y_out,
-    float* __restrict__ partial, float* __restrict__ topv, int* __restrict__ topn) {
+    float* __restrict__ partial, float* __restrict__ topv, int* __restrict__ topn,
+    const float* __restrict__ gamma_top) {
   constexpr int KH = CIN / 2;           // K values per lane-half
   constexpr int LD = CIN + 4;           // padded LDS row: conflict-free ds_read_b128 across rows
   constexpr int Q4 = CIN / 4;           // float4 per row
@@ -515,6 +516,12 @@ __global__ __launch_bounds__(kT, 2) void pn_fwd_mfma_kernel(
       *reinterpret_cast<float4*>(dst + rl * LD + 4 * c4) = v;
     }
   };
+  // TOP: BatchNorm's scale has gamma's sign, so only the extrema of sign(gamma) * y can become the part's maximum
+  float sgn[2] = {1.0f, 1.0f};
+  if constexpr (TOP) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) sgn[t] = gamma_top[c0 + 32 * t + j] < 0.0f ? -1.0f : 1.0f;
+  }
   // persistent: the block keeps its weight panel and walks the (valid part, row split) units u, u + gridDim.x, ...
   const int U = vlist[0] * splits;
   int mnext = blockIdx.x < U ? vlist[4 + blockIdx.x / splits] : 0;
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(kT, 2) void pn_fwd_mfma_kernel(
   const int sp = unit % splits, ob = m * splits + sp;  // ob: the unit's row in the per-unit output tables
   const int t_begin = (int)((long long)sp * TB / splits), t_end = (int)((long long)(sp + 1) * TB / splits);
   float s_[2] = {0.0f, 0.0f}, ss_[2] = {0.0f, 0.0f};
-  Top2 hi[2] = {top2_empty(), top2_empty()}, lo[2] = {top2_empty(), top2_empty()};
+  Top2 hi[2] = {top2_empty(), top2_empty()};
   if (t_begin < t_end) fetch(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
     float* cur = buf[(tile - t_begin) & 1];
@@ -555,10 +562,8 @@ __global__ __launch_bounds__(kT, 2) void pn_fwd_mfma_kernel(
       if constexpr (TOP) {  // rows past the part's end (all-zero operand rows) must not enter the extrema
         const float ninf = -__builtin_inff();
         const bool ok = gn < N;
-        top2_push(hi[0], ok ? acc0[r] : ninf, gn);
-        top2_push(lo[0], ok ? -acc0[r] : ninf, gn);
-        top2_push(hi[1], ok ? acc1[r] : ninf, gn);
-        top2_push(lo[1], ok ? -acc1[r] : ninf, gn);
+        top2_push(hi[0], ok ? sgn[0] * acc0[r] : ninf, gn);
+        top2_push(hi[1], ok ? sgn[1] * acc1[r] : ninf, gn);
       } else if (gn < N) {
         float* dst = y_out + ((long long)m * N + gn) * cout + c0 + j;
         dst[0] = acc0[r];
@@ -595,31 +600,28 @@ __global__ __launch_bounds__(kT, 2) void pn_fwd_mfma_kernel(
     partial[o + 1] = t1;
   }
   if constexpr (TOP) {
-    __shared__ Top2 tsm[kT / 64][64][2];
+    __shared__ Top2 tsm[kT / 64][64];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {  // lanes l and l+32 hold the same channel
       hi[t] = top2_merge(hi[t], top2_shfl_xor(hi[t], 32));
-      lo[t] = top2_merge(lo[t], top2_shfl_xor(lo[t], 32));
     }
     if (h == 0) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        tsm[wave][32 * t + j][0] = hi[t];
-        tsm[wave][32 * t + j][1] = lo[t];
+        tsm[wave][32 * t + j] = hi[t];
       }
     }
     __syncthreads();
     if (threadIdx.x < 64 * PANELS) {
       const int pn = threadIdx.x >> 6, ch = threadIdx.x & 63;
-      Top2 a = tsm[pn][ch][0], b = tsm[pn][ch][1];
+      Top2 a = tsm[pn][ch];
 #pragma unroll
       for (int q = 1; q < RT; ++q) {
-        a = top2_merge(a, tsm[q * PANELS + pn][ch][0]);
-        b = top2_merge(b, tsm[q * PANELS + pn][ch][1]);
+        a = top2_merge(a, tsm[q * PANELS + pn][ch]);
       }
-      const long long o = ((long long)ob * cout + cb + threadIdx.x) * 4;
-      *reinterpret_cast<float4*>(topv + o) = make_float4(a.v1, a.v2, b.v1, b.v2);
-      *reinterpret_cast<int4*>(topn + o) = make_int4(a.n1, a.n2, b.n1, b.n2);
+      const long long o = ((long long)ob * cout + cb + threadIdx.x) * 2;
+      *reinterpret_cast<float2*>(topv + o) = make_float2(a.v1, a.v2);
+      *reinterpret_cast<int2*>(topn + o) = make_int2(a.n1, a.n2);
     }
   }
   __syncthreads();  // the reduction scratch is free again before the next unit reaches it
@@ -1314,7 +1316,7 @@ struct PnWs {
   float* dwpart;  // [kWG][cout*cin] per-block partial weight gradients (last layer: Gram matrix + column sums)
   float* count;
   CoopWs coop;    // fp64 group sums + tickets of the cooperative reductions
-  float* topv;    // [M*splits][F][4] top-2 records of the last layer (values)
+  float* topv;    // [M*splits][F][2] top-2 records of the last layer (values)
   float* ybest;   // [M][F] pre-BatchNorm value at the arg-max
   float* eval;    // [M][F] CSR values alpha*grad_feat
   float* q;       // [129][128] Q then c0
@@ -1324,7 +1326,7 @@ struct PnWs {
 
 struct PnIws {
   int* argmax;  // [M][F]
-  int* topn;    // [M*splits][F][4]
+  int* topn;    // [M*splits][F][2]
   int* erow;    // [M][F] CSR rows
   int* ech;     // [M][F] CSR channels
   int* tptr;    // [M][T+1] CSR tile offsets
@@ -1356,7 +1358,7 @@ PnWs carve(float* base, const Dims& d) {
   w.count = take(4);
   w.coop.ticket = reinterpret_cast<unsigned*>(take(4));
   w.coop.stage = reinterpret_cast<double*>(take(2 * 2 * maxc * ((blocks + kEB - 1) / kEB)));
-  w.topv = take(d.M * d.splits_top * d.F * 4);
+  w.topv = take(d.M * d.splits_top * d.F * 2);
   w.ybest = take(d.M * d.F);
   w.eval = take(d.M * d.F);
   w.q = take(129 * 128);
@@ -1374,7 +1376,7 @@ PnIws carve_int(int32_t* base, const Dims& d) {
     return r;
   };
   w.argmax = take(d.M * d.F);
-  w.topn = take(d.M * d.splits_top * d.F * 4);
+  w.topn = take(d.M * d.splits_top * d.F * 2);
   w.erow = take(d.M * d.F);
   w.ech = take(d.M * d.F);
   w.tptr = take(d.M * ((d.N + 31) / 32 + 1));
@@ -1442,7 +1444,8 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
     const long long units = (long long)M * splits, cap = (long long)kCUs * occ;                                      \
     hipLaunchKernelGGL((pn_fwd_mfma_kernel<CI, PN, TP>),                                                             \
                        dim3((unsigned)(units < cap ? units : cap), (unsigned)(d.C[l] / (64 * PN))), dim3(kT), 0, s,  \
-                       IN, w.bn[l - 1], conv_w[l - 1], d.C[l], iw.vlist, (int)N, splits, YO, w.partial, TV, TN);     \
+                       IN, w.bn[l - 1], conv_w[l - 1], d.C[l], iw.vlist, (int)N, splits, YO, w.partial, TV, TN,      \
+                       TP ? bn_w[4] : (const float*)nullptr);                                                         \
   }
       if (l == 5) {
         if (F == 256) MPA_FWD(128, 4, true, w.Y[4], (float*)nullptr, w.topv, iw.topn)
