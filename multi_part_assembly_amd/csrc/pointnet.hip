@@ -887,7 +887,11 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
     const float* __restrict__ y_prev, const float* __restrict__ bn_prev, const int* __restrict__ vlist, int N,
     float* __restrict__ dwpart, int co0) {
   constexpr int CINP = MODE == WG_FIRST ? 32 : CIN;       // width of the B panel
-  constexpr int CT = COUT / 32, IT = CINP / 32, NTILE = CT * IT, TPW = (NTILE + 3) / 4;
+  constexpr int CT = COUT / 32, IT = CINP / 32, NTILE = CT * IT;
+  // GRAM: the matrix is symmetric — only the 10 tiles on or above the diagonal of the 4 x 4 tile grid are computed
+  // (3, 3, 2, 2 per wave instead of 4 each) and mirrored on output
+  constexpr bool SYM = MODE == WG_GRAM && CT == 4 && IT == 4;
+  constexpr int TPW = SYM ? 3 : (NTILE + 3) / 4;
   constexpr int RB = 64;
   constexpr int DYW = MODE == WG_GRAM ? 0 : COUT;         // the dY panel does not exist in GRAM mode
   constexpr int STAGE = RB * (DYW + CINP);
@@ -897,6 +901,15 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
   __shared__ __attribute__((aligned(16))) float buf[2][STAGE];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int TB = (N + RB - 1) / RB, U = vlist[0] * TB;
+  // output tile (row-of-tiles ct, column-of-tiles it) number i of this wave; -1: none
+  auto tile_ct = [&](int i) {
+    if constexpr (SYM) return i == 0 ? 0 : (i == 1 ? (wave == 3 ? 2 : 1) : (wave == 0 ? 2 : (wave == 1 ? 3 : -1)));
+    else return wave + 4 * i < NTILE ? (wave + 4 * i) / IT : -1;
+  };
+  auto tile_it = [&](int i) {
+    if constexpr (SYM) return i == 0 ? wave : (i == 1 ? (wave == 3 ? 2 : wave + 1) : 3);
+    else return (wave + 4 * i) % IT;
+  };
   // staging roles and per-column tables
   const int co4 = threadIdx.x % QO, ro0 = threadIdx.x / QO;
   const int ci4 = threadIdx.x % QI, ri0 = threadIdx.x / QI;
@@ -996,10 +1009,10 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
     for (int s = 0; s < RB / 2; ++s) {
 #pragma unroll
       for (int i = 0; i < TPW; ++i) {
-        const int q = wave + 4 * i;
-        if (q < NTILE) {
-          const float a = pa[2 * s * AW + (q / IT) * 32];
-          const float b = pb[2 * s * CINP + (q % IT) * 32];
+        const int tct = tile_ct(i), tit = tile_it(i);
+        if (tct >= 0) {
+          const float a = pa[2 * s * AW + tct * 32];
+          const float b = pb[2 * s * CINP + tit * 32];
           if (MODE == WG_GRAM && i == 0) bsum += b;  // tile row 0: its B operand covers columns 32*wave + j
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
         }
@@ -1015,15 +1028,16 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
   float* out = dwpart + (long long)blockIdx.x * ELEMS;
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
-    const int q = wave + 4 * i;
-    if (q < NTILE) {
+    const int tct = tile_ct(i), tit = tile_it(i);
+    if (tct >= 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = (q / IT) * 32 + acc_row(r, h), ci = (q % IT) * 32 + j;
+        const int co = tct * 32 + acc_row(r, h), ci = tit * 32 + j;
         if constexpr (MODE == WG_FIRST) {
           if (j < 3) out[co * 3 + j] = acc[i][r];
         } else {
           out[co * CIN + ci] = acc[i][r];
+          if (SYM && tct != tit) out[ci * CIN + co] = acc[i][r];  // the mirrored tile
         }
       }
     }
