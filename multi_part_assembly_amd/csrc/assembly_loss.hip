@@ -226,7 +226,11 @@ __global__ __launch_bounds__(kThreads) void assembly_nn_kernel(
   const int bid = xcd_remap(blockIdx.x, remap ? P * tiles : -1, B);
   const int m = bid / tiles, tile = bid % tiles, dir = blockIdx.y;
   if (valids[m] == 0.0f) return;
-  const int b = m / P, wave = threadIdx.x >> 6;
+  const int b = m / P;
+  // readfirstlane: the wave index as a scalar, so that this wave's target range — and every target address — is
+  // provably wave-uniform and the scan's loads go through the scalar cache (the compiler emits per-lane vector
+  // loads of the same address otherwise)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const float* qa = (dir == 0 ? C1 : C2) + 3LL * m * N;
   const float* tb = (dir == 0 ? C2 : C1) + (SHAPE ? 3LL * b * P * N : 3LL * m * N);
   const float* vb = SHAPE ? valids + (long long)b * P : nullptr;
