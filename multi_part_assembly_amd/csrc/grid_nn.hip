@@ -369,18 +369,88 @@ __device__ __forceinline__ float gap(float a0, float a1, float b0, float b1) {
 // processed in windows of the LDS buffer; single long ranges go to the scalar scan, whose long runs amortise the
 // latency by themselves.
 constexpr int kCand = 512;      // candidate records per LDS window (8 KB per wave)
-constexpr int kLongRange = 48;  // ranges longer than this are scanned directly
+constexpr int kLongRange = 32;  // ranges longer than this are fetched by the whole wave, one range at a time
+
+// every lane scans the wn candidate records staged in LDS (padded to a multiple of 8 with sentinels)
+__device__ __forceinline__ void scan_cand(LaneState& s, const float4* __restrict__ cand, int wn) {
+  constexpr int T = kScanChunk;
+  for (int j0 = 0; j0 < wn; j0 += T) {
+    float4 cur[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) cur[t] = cand[j0 + t];  // same address in every lane: broadcast reads
+    float d[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) d[t] = dist_exact_s(s.X - cur[t].x, s.Y - cur[t].y, s.Z - cur[t].z);
+    const float cmin = min8(d);
+    if (cmin <= s.best) {  // rare: an improvement, or a tie that may carry a lower index
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int ti = __float_as_int(cur[t].w);
+        if (d[t] < s.best || (d[t] == s.best && ti < s.bidx)) {
+          s.best = d[t];
+          s.bidx = ti;
+        }
+      }
+    }
+  }
+}
+
+// One long contiguous range [begin, end) of the target records (wave-uniform): ALL lanes fetch it together — 64
+// records per memory round trip and instruction, several in flight — into the LDS window, then scan it.  (A lane
+// copying its own long range alone moves 2 records per round trip; the scalar-operand scan moves 8.)
+__device__ __forceinline__ void scan_range_coop(LaneState& s, const float4* __restrict__ trec, int begin, int end,
+                                                float4* __restrict__ cand) {
+  constexpr int T = kScanChunk, kCap = kCand - T;
+  const int lane = threadIdx.x;
+  for (int w0 = begin; w0 < end; w0 += kCap) {
+    const int wn = end - w0 < kCap ? end - w0 : kCap;
+    __syncthreads();  // the previous readers are done with `cand`
+    constexpr int U = 4;
+    for (int j0 = lane; j0 < wn; j0 += 64 * U) {
+      float4 t[U];  // (unconditional loads of a clamped position: conditional ones send the array to scratch)
+#pragma unroll
+      for (int u = 0; u < U; ++u) t[u] = trec[w0 + (j0 + 64 * u < wn ? j0 + 64 * u : wn - 1)];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (j0 + 64 * u < wn) cand[j0 + 64 * u] = t[u];
+    }
+    if (lane < T) {
+      const float inf = __builtin_inff();
+      cand[wn + lane] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
+    }
+    __syncthreads();
+    scan_cand(s, cand, wn);
+  }
+}
+
+#ifdef MPA_GRID_STATS  // instrumented build for tools/probe_grid_stats.py only (never in libmpa_hip.so)
+__device__ unsigned long long g_grid_stats[8];  // items, active lanes, scan_batch calls, candidates, long-range candidates
+#define MPA_STAT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_grid_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define MPA_STAT(i, v) do { } while (0)
+#endif
 
 __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restrict__ trec, int rb, int re,
-                                           float4* __restrict__ cand) {
+                                           float4* __restrict__ cand, int* __restrict__ sidx) {
   const int lane = threadIdx.x;
   int len = re > rb ? re - rb : 0;
-  // long ranges are contiguous runs that the scalar scan handles at full speed; they would only unbalance the copy
+#ifdef MPA_GRID_STATS
+  {
+    int tot = len;
+    for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    int lng = len > kLongRange ? len : 0;
+    for (int off = 32; off >= 1; off >>= 1) lng += __shfl_xor(lng, off, 64);
+    MPA_STAT(2, 1);
+    MPA_STAT(3, tot);
+    MPA_STAT(4, lng);
+  }
+#endif
+  // long ranges are fetched by the whole wave, one after the other; in the gather below they would unbalance the copy
   unsigned long long big = __ballot(len > kLongRange);
   while (big) {
     const int l = __builtin_ctzll(big);
     big &= big - 1;
-    scan_records(s, trec, __builtin_amdgcn_readlane(rb, l), __builtin_amdgcn_readlane(re, l));
+    scan_range_coop(s, trec, __builtin_amdgcn_readlane(rb, l), __builtin_amdgcn_readlane(re, l), cand);
   }
   if (len > kLongRange) len = 0;
   int incl = len;
@@ -394,39 +464,28 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
   for (int w0 = 0; w0 < total; w0 += kCap) {  // windows of the concatenated list that fit the LDS buffer
     const int wn = total - w0 < kCap ? total - w0 : kCap;
     const int lo = off0 > w0 ? off0 : w0, hi = off0 + len < w0 + wn ? off0 + len : w0 + wn;
-    const int cnt = hi > lo ? hi - lo : 0, maxc = wave_max_i(cnt);
-    __syncthreads();  // the previous window's readers are done with `cand` (one wave per block: a cheap fence)
-    for (int j = 0; j < maxc; j += 2) {  // two records per lane in flight (more would cost occupancy)
-      float4 t0, t1;
-      if (j < cnt) t0 = trec[rb + (lo - off0) + j];
-      if (j + 1 < cnt) t1 = trec[rb + (lo - off0) + j + 1];
-      if (j < cnt) cand[lo - w0 + j] = t0;
-      if (j + 1 < cnt) cand[lo - w0 + j + 1] = t1;
+    const int cnt = hi > lo ? hi - lo : 0;
+    __syncthreads();  // the previous window's readers are done with `cand` / `sidx` (one wave per block: cheap)
+    // balanced gather: every lane first lists the record indices of its own (short) range in LDS, then the wave
+    // fetches the concatenated list position by position — 64 records per instruction, several in flight — instead
+    // of each lane walking its own range two records per memory round trip
+    for (int k = 0; k < cnt; ++k) sidx[lo - w0 + k] = rb + (lo - off0) + k;
+    __syncthreads();
+    constexpr int U = 4;
+    for (int j0 = lane; j0 < wn; j0 += 64 * U) {
+      float4 t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) t[u] = trec[sidx[j0 + 64 * u < wn ? j0 + 64 * u : wn - 1]];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (j0 + 64 * u < wn) cand[j0 + 64 * u] = t[u];
     }
     if (lane < T) {  // pad the last chunk of 8 with records that can never win
       const float inf = __builtin_inff();
       cand[wn + lane] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
     }
     __syncthreads();
-    for (int j0 = 0; j0 < wn; j0 += T) {
-      float4 cur[T];
-#pragma unroll
-      for (int t = 0; t < T; ++t) cur[t] = cand[j0 + t];  // same address in every lane: broadcast reads
-      float d[T];
-#pragma unroll
-      for (int t = 0; t < T; ++t) d[t] = dist_exact_s(s.X - cur[t].x, s.Y - cur[t].y, s.Z - cur[t].z);
-      const float cmin = min8(d);
-      if (cmin <= s.best) {  // rare: an improvement, or a tie that may carry a lower index
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const int ti = __float_as_int(cur[t].w);
-          if (d[t] < s.best || (d[t] == s.best && ti < s.bidx)) {
-            s.best = d[t];
-            s.bidx = ti;
-          }
-        }
-      }
-    }
+    scan_cand(s, cand, wn);
   }
 }
 
@@ -439,6 +498,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     int rec_stride, float* __restrict__ dist1, float* __restrict__ dist2, int* __restrict__ idx1,
     int* __restrict__ idx2) {
   __shared__ float4 cand[kCand];
+  __shared__ int sidx[kCand];  // record index of every position of the current window
   const int b = blockIdx.y >> 1, dir = blockIdx.y & 1;
   const int qc = dir, tc = 1 - dir;  // query / target shape
   const GridParams& g = params[b];  // by reference: uniform address -> scalar loads (a by-value copy indexed with a
@@ -479,6 +539,8 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     LaneState s;
     const int qi = qb + lane;
     const bool has = qi < q_end;
+    MPA_STAT(0, 1);
+    MPA_STAT(1, __popcll(__ballot(has)));
     const float4 qr = qrec[has ? qi : q_end - 1];
     s.X = qr.x;
     s.Y = qr.y;
@@ -502,7 +564,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
       const bool ok = lane < kSeedW * kSeedW && z <= z1 && y <= y1 && z >= tz0 && z <= tz1 && y >= ty0 && y <= ty1 && xa <= xb;
       const int row = (z * g.gy + y) * g.gx;
       const int rb = ok ? tst[row + xa] : 0, re = ok ? tst[row + xb + 1] : 0;
-      scan_batch(s, trec, rb, re, cand);
+      scan_batch(s, trec, rb, re, cand, sidx);
     }
     // sweep: every cell whose box can hold a point closer than the worst best-distance of this wave.  Rows (y, z)
     // are visited nearest-first, as square rings around the super-cell's own kS x kS rows (lane = row of the ring, 64
@@ -569,7 +631,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
               }
             }
           }
-          scan_batch(s, trec, rb, re, cand);
+          scan_batch(s, trec, rb, re, cand, sidx);
         }
       }
       bound = wave_max(s.best) * 1.00001f;
@@ -644,3 +706,14 @@ int launch_grid_shape_search(const float* valids, const float* S1, const float* 
 }
 
 }  // namespace mpa
+
+#ifdef MPA_GRID_STATS
+extern "C" int mpa_debug_grid_stats(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mpa::g_grid_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mpa::g_grid_stats), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
