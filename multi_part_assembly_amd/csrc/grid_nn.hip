@@ -567,74 +567,81 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
       scan_batch(s, trec, rb, re, cand, sidx);
     }
     // sweep: every cell whose box can hold a point closer than the worst best-distance of this wave.  Rows (y, z)
-    // are visited nearest-first, as square rings around the super-cell's own kS x kS rows (lane = row of the ring, 64
-    // rows per batch), so the bound tightens early; a ring whose nearest row is already farther than the bound
-    // ends the sweep.  Rings 0 and 1 overlap the seed: only the cells left and right of it are new there.
+    // are visited nearest-first, as square rings around the super-cell's own kS x kS rows (lane = row of a ring), so
+    // the bound tightens early; a ring whose nearest row is already farther than the bound ends the sweep.  Rings 0
+    // and 1 overlap the seed: only the cells left and right of it are new there (two ranges per row).  Every batch
+    // costs two dependent memory round trips (row offsets, then records), so both flanks of a seeded ring share one
+    // batch.
     float bound = wave_max(s.best) * 1.00001f;
     const int yc0 = kS * sy, yc1 = kS * sy + kS - 1, zc0 = kS * sz, zc1 = kS * sz + kS - 1;
     const int rmax = max(max(yc0, g.gy - 1 - yc1), max(zc0, g.gz - 1 - zc1));
-    for (int r = 0; r <= rmax; ++r) {
-      if (r >= 2) {
-        const float ring_gap = (float)(r - 1) * g.h - 2.0f * slack;
-        if (ring_gap * ring_gap >= bound) break;
-      }
+    auto ring_rows = [&](int r) { return r == 0 ? kS * kS : 2 * (kS + 2 * r) + 2 * (kS + 2 * r - 2); };
+    // record range of row i of ring r (side: which flank of the seed, rings 0 and 1 only); empty if out of reach
+    auto row_range = [&](int r, int side, int i, bool live, int& rb, int& re) {
+      rb = re = 0;
       const int zlo = zc0 - r, zhi = zc1 + r, ylo = yc0 - r, yhi = yc1 + r;
-      const int W = yhi - ylo + 1, H = zhi - zlo + 1;
-      const int nrows = r == 0 ? W * H : 2 * W + 2 * (H - 2);
-      const int sides = r <= 1 ? 2 : 1;  // seeded rows: left part and right part are separate ranges
-      for (int side = 0; side < sides; ++side) {
-        for (int i0 = 0; i0 < nrows; i0 += 64) {
-          const int i = i0 + lane;
-          int z, y;
-          if (r == 0) {
-            z = zlo + i / W;
-            y = ylo + i % W;
-          } else if (i < W) {
-            z = zlo;
-            y = ylo + i;
-          } else if (i < 2 * W) {
-            z = zhi;
-            y = ylo + i - W;
-          } else {
-            z = zlo + 1 + ((i - 2 * W) >> 1);
-            y = ((i - 2 * W) & 1) ? yhi : ylo;
-          }
-          int rb = 0, re = 0;
-          if (i < nrows && z >= tz0 && z <= tz1 && y >= ty0 && y <= ty1) {
-            const float cz0 = g.oz + (float)z * g.h - slack, cz1 = g.oz + (float)(z + 1) * g.h + slack;
-            const float cy0 = g.oy + (float)y * g.h - slack, cy1 = g.oy + (float)(y + 1) * g.h + slack;
-            const float dz = gap(bz0, bz1, cz0, cz1), dy = gap(by0, by1, cy0, cy1);
-            const float rem = bound - dz * dz - dy * dy;
-            if (rem > 0.0f) {
-              // cells x with gap_x(x)^2 < rem: an interval around the super-cell
-              const float reach = __builtin_sqrtf(rem) + slack;
-              int xa = clampi((int)__builtin_floorf((bx0 - reach - g.ox) * g.inv_h), 0, g.gx - 1);
-              int xb = clampi((int)__builtin_floorf((bx1 + reach - g.ox) * g.inv_h), 0, g.gx - 1);
-              if (bound > 1e31f) {  // nothing found yet: the whole row
-                xa = 0;
-                xb = g.gx - 1;
-              }
-              xa = xa < tx0 ? tx0 : xa;
-              xb = xb > tx1 ? tx1 : xb;
-              const bool seeded = r <= 1 && z >= z0 && z <= z1 && y >= y0 && y <= y1;
-              if (seeded) {  // the seed covered [x0, x1] of this row
-                if (side == 0) xb = xb < x0 - 1 ? xb : x0 - 1;
-                else xa = xa > x1 + 1 ? xa : x1 + 1;
-              } else if (side == 1) {
-                xa = 1;
-                xb = 0;
-              }
-              if (xa <= xb) {
-                const int row = (z * g.gy + y) * g.gx;
-                rb = tst[row + xa];
-                re = tst[row + xb + 1];
-              }
-            }
-          }
-          scan_batch(s, trec, rb, re, cand, sidx);
-        }
+      const int W = yhi - ylo + 1;
+      int z, y;
+      if (r == 0) {
+        z = zlo + i / W;
+        y = ylo + i % W;
+      } else if (i < W) {
+        z = zlo;
+        y = ylo + i;
+      } else if (i < 2 * W) {
+        z = zhi;
+        y = ylo + i - W;
+      } else {
+        z = zlo + 1 + ((i - 2 * W) >> 1);
+        y = ((i - 2 * W) & 1) ? yhi : ylo;
       }
-      bound = wave_max(s.best) * 1.00001f;
+      if (!live || z < tz0 || z > tz1 || y < ty0 || y > ty1) return;
+      const float cz0 = g.oz + (float)z * g.h - slack, cz1 = g.oz + (float)(z + 1) * g.h + slack;
+      const float cy0 = g.oy + (float)y * g.h - slack, cy1 = g.oy + (float)(y + 1) * g.h + slack;
+      const float dz = gap(bz0, bz1, cz0, cz1), dy = gap(by0, by1, cy0, cy1);
+      const float rem = bound - dz * dz - dy * dy;
+      if (rem <= 0.0f) return;
+      // cells x with gap_x(x)^2 < rem: an interval around the super-cell
+      const float reach = __builtin_sqrtf(rem) + slack;
+      int xa = clampi((int)__builtin_floorf((bx0 - reach - g.ox) * g.inv_h), 0, g.gx - 1);
+      int xb = clampi((int)__builtin_floorf((bx1 + reach - g.ox) * g.inv_h), 0, g.gx - 1);
+      if (bound > 1e31f) {  // nothing found yet: the whole row
+        xa = 0;
+        xb = g.gx - 1;
+      }
+      xa = xa < tx0 ? tx0 : xa;
+      xb = xb > tx1 ? tx1 : xb;
+      const bool seeded = r <= 1 && z >= z0 && z <= z1 && y >= y0 && y <= y1;
+      if (seeded) {  // the seed covered [x0, x1] of this row
+        if (side == 0) xb = xb < x0 - 1 ? xb : x0 - 1;
+        else xa = xa > x1 + 1 ? xa : x1 + 1;
+      } else if (side == 1) {
+        return;
+      }
+      if (xa <= xb) {
+        const int row = (z * g.gy + y) * g.gx;
+        rb = tst[row + xa];
+        re = tst[row + xb + 1];
+      }
+    };
+    for (int r = 0; r <= 1 && r <= rmax; ++r) {  // rings 0 and 1: both flanks of every row in one batch
+      static_assert(2 * (2 * (kS + 2) + 2 * kS) <= 64, "both flanks of ring 1 fit one batch");
+      int rb, re;
+      row_range(r, lane & 1, lane >> 1, lane < 2 * ring_rows(r), rb, re);
+      scan_batch(s, trec, rb, re, cand, sidx);
+      bound = wave_max(s.best) * 1.00001f;  // (ring 1 must see the bound ring 0 found: without one, rows are whole)
+    }
+    for (int r = 2; r <= rmax; ++r) {
+      const float ring_gap = (float)(r - 1) * g.h - 2.0f * slack;
+      if (ring_gap * ring_gap >= bound) break;
+      const int nrows = ring_rows(r);
+      for (int i0 = 0; i0 < nrows; i0 += 64) {
+        int rb, re;
+        row_range(r, 0, i0 + lane, i0 + lane < nrows, rb, re);
+        scan_batch(s, trec, rb, re, cand, sidx);
+      }
+      bound = wave_max(s.best) * 1.00001f;  // (two rings per batch were tried: the staler bound costs what the saved
+                                            // round trips gain)
     }
     {  // padded parts' representatives, in part order (uniform loop over the set bits)
       unsigned long long m = padmask;
