@@ -540,7 +540,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     const int qi = qb + lane;
     const bool has = qi < q_end;
     MPA_STAT(0, 1);
-    MPA_STAT(1, __popcll(__ballot(has)));
+    { const int nact = __popcll(__ballot(has)); MPA_STAT(1, nact); }
     const float4 qr = qrec[has ? qi : q_end - 1];
     s.X = qr.x;
     s.Y = qr.y;
