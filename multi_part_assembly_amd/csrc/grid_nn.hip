@@ -300,6 +300,8 @@ struct LaneState {
   float X, Y, Z;
   float best;
   int bidx;
+  bool dual;  // wave-uniform: <= 32 queries in this work item, so lanes l and l + 32 hold the SAME query and each half
+              // scans every other candidate (the halves are merged, lexicographically, wherever the best is used)
 };
 
 __device__ __forceinline__ float dist_exact_s(float dx, float dy, float dz) { return (dx * dx + dy * dy) + dz * dz; }
@@ -374,10 +376,12 @@ constexpr int kLongRange = 32;  // ranges longer than this are fetched by the wh
 // every lane scans the wn candidate records staged in LDS (padded to a multiple of 8 with sentinels)
 __device__ __forceinline__ void scan_cand(LaneState& s, const float4* __restrict__ cand, int wn) {
   constexpr int T = kScanChunk;
-  for (int j0 = 0; j0 < wn; j0 += T) {
+  // dual: this half of the wave takes candidates sub, sub + 2, ... (two LDS addresses per read instead of one)
+  const int step = s.dual ? 2 : 1, sub = s.dual ? (int)(threadIdx.x >> 5) : 0;
+  for (int j0 = 0; j0 < wn; j0 += T * step) {
     float4 cur[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) cur[t] = cand[j0 + t];  // same address in every lane: broadcast reads
+    for (int t = 0; t < T; ++t) cur[t] = cand[j0 + t * step + sub];
     float d[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) d[t] = dist_exact_s(s.X - cur[t].x, s.Y - cur[t].y, s.Z - cur[t].z);
@@ -395,12 +399,23 @@ __device__ __forceinline__ void scan_cand(LaneState& s, const float4* __restrict
   }
 }
 
+// dual mode: both halves end up with the better (distance, index) of the two
+__device__ __forceinline__ void merge_halves(LaneState& s) {
+  if (!s.dual) return;
+  const float ob = __shfl_xor(s.best, 32, 64);
+  const int oi = __shfl_xor(s.bidx, 32, 64);
+  if (ob < s.best || (ob == s.best && oi < s.bidx)) {
+    s.best = ob;
+    s.bidx = oi;
+  }
+}
+
 // One long contiguous range [begin, end) of the target records (wave-uniform): ALL lanes fetch it together — 64
 // records per memory round trip and instruction, several in flight — into the LDS window, then scan it.  (A lane
 // copying its own long range alone moves 2 records per round trip; the scalar-operand scan moves 8.)
 __device__ __forceinline__ void scan_range_coop(LaneState& s, const float4* __restrict__ trec, int begin, int end,
                                                 float4* __restrict__ cand) {
-  constexpr int T = kScanChunk, kCap = kCand - T;
+  constexpr int T = 2 * kScanChunk, kCap = kCand - T;  // (2x: the dual scan reads up to 16 records past the end)
   const int lane = threadIdx.x;
   for (int w0 = begin; w0 < end; w0 += kCap) {
     const int wn = end - w0 < kCap ? end - w0 : kCap;
@@ -460,7 +475,7 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
     if (lane >= off) incl += t;
   }
   const int total = __shfl(incl, 63, 64), off0 = incl - len;
-  constexpr int T = kScanChunk, kCap = kCand - T;
+  constexpr int T = 2 * kScanChunk, kCap = kCand - T;  // (2x: the dual scan reads up to 16 records past the end)
   for (int w0 = 0; w0 < total; w0 += kCap) {  // windows of the concatenated list that fit the LDS buffer
     const int wn = total - w0 < kCap ? total - w0 : kCap;
     const int lo = off0 > w0 ? off0 : w0, hi = off0 + len < w0 + wn ? off0 + len : w0 + wn;
@@ -537,7 +552,8 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     const int qb = qst[sc] + (work - bst[sc]) * kBatch, q_end = qst[sc + 1];
     const int sx = sc % g.sgx, sy = (sc / g.sgx) % g.sgy, sz = sc / (g.sgx * g.sgy);
     LaneState s;
-    const int qi = qb + lane;
+    s.dual = q_end - qb <= 32;
+    const int qi = qb + (s.dual ? (lane & 31) : lane);
     const bool has = qi < q_end;
     MPA_STAT(0, 1);
     { const int nact = __popcll(__ballot(has)); MPA_STAT(1, nact); }
@@ -572,6 +588,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     // and 1 overlap the seed: only the cells left and right of it are new there (two ranges per row).  Every batch
     // costs two dependent memory round trips (row offsets, then records), so both flanks of a seeded ring share one
     // batch.
+    merge_halves(s);
     float bound = wave_max(s.best) * 1.00001f;
     const int yc0 = kS * sy, yc1 = kS * sy + kS - 1, zc0 = kS * sz, zc1 = kS * sz + kS - 1;
     const int rmax = max(max(yc0, g.gy - 1 - yc1), max(zc0, g.gz - 1 - zc1));
@@ -629,6 +646,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
       int rb, re;
       row_range(r, lane & 1, lane >> 1, lane < 2 * ring_rows(r), rb, re);
       scan_batch(s, trec, rb, re, cand, sidx);
+      merge_halves(s);
       bound = wave_max(s.best) * 1.00001f;  // (ring 1 must see the bound ring 0 found: without one, rows are whole)
     }
     for (int r = 2; r <= rmax; ++r) {
@@ -640,6 +658,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
         row_range(r, 0, i0 + lane, i0 + lane < nrows, rb, re);
         scan_batch(s, trec, rb, re, cand, sidx);
       }
+      merge_halves(s);
       bound = wave_max(s.best) * 1.00001f;  // (two rings per batch were tried: the staler bound costs what the saved
                                             // round trips gain)
     }
@@ -651,7 +670,8 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
         consider(s, __shfl(px, p, 64), __shfl(py, p, 64), __shfl(pz, p, 64), p * N);
       }
     }
-    if (has) {
+    if (has && !(s.dual && lane >= 32)) {  // (both halves hold the merged result; the padded parts' representatives
+                                           // were considered by both)
       dout[qflat] = s.best;
       iout[qflat] = s.bidx == 0x7fffffff ? -1 : s.bidx;
     }
