@@ -300,8 +300,9 @@ struct LaneState {
   float X, Y, Z;
   float best;
   int bidx;
-  bool dual;  // wave-uniform: <= 32 queries in this work item, so lanes l and l + 32 hold the SAME query and each half
-              // scans every other candidate (the halves are merged, lexicographically, wherever the best is used)
+  int split;  // wave-uniform, 1 / 2 / 4: with <= 32 (16) queries in the work item, 2 (4) groups of lanes hold the SAME
+              // queries and each group scans every 2nd (4th) candidate; the groups are merged, lexicographically,
+              // wherever the best is used
 };
 
 __device__ __forceinline__ float dist_exact_s(float dx, float dy, float dz) { return (dx * dx + dy * dy) + dz * dz; }
@@ -376,8 +377,8 @@ constexpr int kLongRange = 32;  // ranges longer than this are fetched by the wh
 // every lane scans the wn candidate records staged in LDS (padded to a multiple of 8 with sentinels)
 __device__ __forceinline__ void scan_cand(LaneState& s, const float4* __restrict__ cand, int wn) {
   constexpr int T = kScanChunk;
-  // dual: this half of the wave takes candidates sub, sub + 2, ... (two LDS addresses per read instead of one)
-  const int step = s.dual ? 2 : 1, sub = s.dual ? (int)(threadIdx.x >> 5) : 0;
+  // split > 1: this group of lanes takes candidates sub, sub + split, ... (split LDS addresses per read, not one)
+  const int step = s.split, sub = (int)threadIdx.x / (64 / s.split);
   for (int j0 = 0; j0 < wn; j0 += T * step) {
     float4 cur[T];
 #pragma unroll
@@ -399,14 +400,15 @@ __device__ __forceinline__ void scan_cand(LaneState& s, const float4* __restrict
   }
 }
 
-// dual mode: both halves end up with the better (distance, index) of the two
+// split mode: every group ends up with the best (distance, index) of all groups
 __device__ __forceinline__ void merge_halves(LaneState& s) {
-  if (!s.dual) return;
-  const float ob = __shfl_xor(s.best, 32, 64);
-  const int oi = __shfl_xor(s.bidx, 32, 64);
-  if (ob < s.best || (ob == s.best && oi < s.bidx)) {
-    s.best = ob;
-    s.bidx = oi;
+  for (int m = 32; m >= 64 / s.split && m >= 16; m >>= 1) {  // split 2: lanes l ^ 32; split 4: also l ^ 16
+    const float ob = __shfl_xor(s.best, m, 64);
+    const int oi = __shfl_xor(s.bidx, m, 64);
+    if (ob < s.best || (ob == s.best && oi < s.bidx)) {
+      s.best = ob;
+      s.bidx = oi;
+    }
   }
 }
 
@@ -415,7 +417,7 @@ __device__ __forceinline__ void merge_halves(LaneState& s) {
 // copying its own long range alone moves 2 records per round trip; the scalar-operand scan moves 8.)
 __device__ __forceinline__ void scan_range_coop(LaneState& s, const float4* __restrict__ trec, int begin, int end,
                                                 float4* __restrict__ cand) {
-  constexpr int T = 2 * kScanChunk, kCap = kCand - T;  // (2x: the dual scan reads up to 16 records past the end)
+  constexpr int T = 4 * kScanChunk, kCap = kCand - T;  // (4x: a split scan reads up to 32 records past the end)
   const int lane = threadIdx.x;
   for (int w0 = begin; w0 < end; w0 += kCap) {
     const int wn = end - w0 < kCap ? end - w0 : kCap;
@@ -475,7 +477,7 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
     if (lane >= off) incl += t;
   }
   const int total = __shfl(incl, 63, 64), off0 = incl - len;
-  constexpr int T = 2 * kScanChunk, kCap = kCand - T;  // (2x: the dual scan reads up to 16 records past the end)
+  constexpr int T = 4 * kScanChunk, kCap = kCand - T;  // (4x: a split scan reads up to 32 records past the end)
   for (int w0 = 0; w0 < total; w0 += kCap) {  // windows of the concatenated list that fit the LDS buffer
     const int wn = total - w0 < kCap ? total - w0 : kCap;
     const int lo = off0 > w0 ? off0 : w0, hi = off0 + len < w0 + wn ? off0 + len : w0 + wn;
@@ -552,8 +554,8 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     const int qb = qst[sc] + (work - bst[sc]) * kBatch, q_end = qst[sc + 1];
     const int sx = sc % g.sgx, sy = (sc / g.sgx) % g.sgy, sz = sc / (g.sgx * g.sgy);
     LaneState s;
-    s.dual = q_end - qb <= 32;
-    const int qi = qb + (s.dual ? (lane & 31) : lane);
+    s.split = q_end - qb <= 16 ? 4 : (q_end - qb <= 32 ? 2 : 1);
+    const int qi = qb + (lane & (64 / s.split - 1));
     const bool has = qi < q_end;
     MPA_STAT(0, 1);
     { const int nact = __popcll(__ballot(has)); MPA_STAT(1, nact); }
@@ -670,8 +672,8 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
         consider(s, __shfl(px, p, 64), __shfl(py, p, 64), __shfl(pz, p, 64), p * N);
       }
     }
-    if (has && !(s.dual && lane >= 32)) {  // (both halves hold the merged result; the padded parts' representatives
-                                           // were considered by both)
+    if (has && lane < 64 / s.split) {  // (every group holds the merged result; the padded parts' representatives
+                                       // were considered by all of them)
       dout[qflat] = s.best;
       iout[qflat] = s.bidx == 0x7fffffff ? -1 : s.bidx;
     }
