@@ -7,8 +7,11 @@ import numpy as np
 import pytest
 import torch
 
+from pathlib import Path
+
 from multi_part_assembly_amd import datasets
-from tests.conftest import GOLDEN
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
 
 PARTS = [2, 5, 4]
 PARTNET_KEYS = ("part_label", "part_ids", "match_ids", "contact_points", "sym", "valid_matrix")
