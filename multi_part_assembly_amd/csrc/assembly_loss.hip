@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void assembly_backward_kernel(
     const long long qoff = ((long long)b * P + pp) * N;
     for (int k = threadIdx.x; k < N; k += kThreads) {
       const int j = is2[qoff + k];
-      if (j / N != p) continue;
+      if (j < p * N || j >= (p + 1) * N) continue;  // not a point of this part (a range test, not an integer division)
       const long long o = 3LL * (qoff + k), jt = sbase + 3LL * j;
       const float gx = -c_s * (S2[o] - S1[jt]), gy = -c_s * (S2[o + 1] - S1[jt + 1]),
                   gz = -c_s * (S2[o + 2] - S1[jt + 2]);
