@@ -376,8 +376,14 @@ __global__ __launch_bounds__(kThreads) void assembly_backward_kernel(
   for (int pp = 0; pp < P; ++pp) {
     if (vb[pp] == 0.0f) continue;
     const long long qoff = ((long long)b * P + pp) * N;
-    for (int k = threadIdx.x; k < N; k += kThreads) {
-      const int j = is2[qoff + k];
+    constexpr int U = 4;  // index loads of U strides in flight (the scan is a chain of L2 latencies otherwise)
+    for (int k0 = threadIdx.x; k0 < N; k0 += U * kThreads) {
+      int jj[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) jj[u] = k0 + u * kThreads < N ? is2[qoff + k0 + u * kThreads] : -1;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * kThreads, j = jj[u];
       if (j < p * N || j >= (p + 1) * N) continue;  // not a point of this part (a range test, not an integer division)
       const long long o = 3LL * (qoff + k), jt = sbase + 3LL * j;
       const float gx = -c_s * (S2[o] - S1[jt]), gy = -c_s * (S2[o + 1] - S1[jt + 1]),
@@ -389,6 +395,7 @@ __global__ __launch_bounds__(kThreads) void assembly_backward_kernel(
         pz = pcs[jt + 2];
       }
       accumulate(acc, w, ux, uy, uz, px, py, pz, gx, gy, gz, true);
+      }
     }
   }
 
