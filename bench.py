@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: one full training step (forward + losses + backward + gradient
-all-reduce + fused Adam) of PNTransformer + PointNet on synthetic Breaking-Bad-"everyday"-like part
-clouds, B = 32 per GPU, P = 20, N = 1000 (BASELINE.json configs[1]; weak scaling over GPUs).
+"""Benchmark of the hot path: one full training step (forward + losses + backward + gradient all-reduce + fused
+Adam) on synthetic part clouds, B = 32 per GPU, P = 20, N = 1000 (weak scaling over GPUs).
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N --steps K --warmup W] [--config c1|c2|c3|c4|c5]
 
-Rank 0 prints ONE JSON line.  `value` = parts (B x P slots, padded slots included, as the metric is
-defined) processed per second by the whole job, inputs resident in HBM before the timed region.
-Kernels are launched eagerly (the step is GPU-bound: ~2.3 ms of host time for 3.3 ms of GPU work; `--graph`
-replays the captured step as one HIP graph instead and measures ~2.5 % less).  The garbage collector is parked
-during the timed steps: one generation-2 collection (~30 ms with torch loaded) inside K = 20 steps of 3 ms was
-measured as +1.6 ms per step.  `roofline` describes the dominant kernel (the whole-shape Chamfer search of the
-fused loss), timed per launch with HIP events that the library records around it on its launch stream inside the
-timed region (with --graph: in an eager pass over the same K steps right after it, events cannot be recorded
-inside a replay).  `cpu_baseline` is the oracle's reference-equivalent PyTorch-CPU step
-timed on this host (rank 0, N = 1 only) on a bounded sample.
+With --gpus N > 1 and no torch.distributed environment the script re-launches itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU over
+RCCL); launched by the driver under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE from the env.
+
+Workloads (BASELINE.json configs[0..4]):
+    c2 (default) pn_transformer + PointNet, Breaking-Bad-everyday-like clouds       — the configuration `metric` is quoted on
+    c4           = c2 per GPU (the 8-GPU line is `--gpus 8` of the same workload)
+    c3           DGL (3 GNN iterations) + DGCNN encoder, everyday-like clouds        — kNN / EdgeConv kernel stress
+    c5           RGL-NET + DGCNN, artifact-like clouds (12-20 small parts per shape)
+    c1           B-Global + PointNet, semantic flags on (matching, min-of-5), P = 2, B = 4 — plumbing case
+
+Rank 0 prints ONE JSON line.  `value` = parts (B x P slots, padded slots included, as the metric is defined)
+processed per second by the whole job, inputs resident in HBM before the timed region.  Kernels are launched
+eagerly (`--graph` replays the captured step as one HIP graph).  The garbage collector is parked during the timed
+steps (a generation-2 collection inside K steps of 3 ms was measured as +1.6 ms per step).
+
+`roofline` describes the dominant kernel of the workload — c1/c2/c4: the whole-shape Chamfer search of the fused
+loss; c3/c5: the kNN graph kernel of the DGCNN encoder — timed per launch with HIP events that the library records
+around it on its launch stream inside the timed region.  It carries the mandated HBM comparison (algorithmic bytes of
+SURVEY.md §8d per launch / time / 8 TB/s) AND the bound that actually binds (`binding`), plus a per-kernel table
+(`kernel_table`) with MFMA / VALU / HBM fractions of the other large kernels.  `cpu_baseline` is the oracle's
+reference-equivalent PyTorch-CPU step timed on this host (rank 0, N = 1, c2 only) on a bounded sample.
 """
 from __future__ import annotations
 
@@ -24,6 +33,8 @@ import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -31,12 +42,10 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import torch
-import torch.distributed as dist
-
 BATCH, PARTS, POINTS = 32, 20, 1000
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_LANE_OPS = 78.6e12  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (non-packed fp32 VALU issue)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_LANE_OPS = 78.6e12   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (non-packed fp32 VALU issue)
+MFMA_F32_PEAK = 157.3e12       # 256 CU x 4 SIMD x 64 FLOP/cycle x 2.4 GHz (v_mfma_f32_32x32x2_f32, dense)
 
 
 def parse_args():
@@ -44,6 +53,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (default: eager launches; see trainer.py)")
@@ -52,59 +62,172 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(cpu_batch):
-    """Reference-equivalent CPU training step (oracle/nets.py + oracle/chamfer_ref.c), bounded sample:
-    the same workload at B = cpu_batch instead of 32 (cost is linear in B), 1 warm-up + 2 timed steps."""
-    from multi_part_assembly_amd import config
+def relaunch_distributed(args):
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start one rank per GPU ourselves."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+# ---- workloads ----------------------------------------------------------------------------------------------------
+def workload(name, rank, dev):
+    """-> (cfg, batch, description, B, P)."""
+    from multi_part_assembly_amd import config, synthetic
+    if name in ("c2", "c4"):
+        cfg = config.pn_transformer_everyday()
+        batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234 + rank, device=dev)
+        desc = ("pn_transformer + PointNet encoder, Breaking-Bad-everyday-like synthetic clouds, B=32 per GPU, P=20, "
+                "N=1000, geometric loss, Adam (BASELINE.json configs[1]; configs[3] = the same workload on 8 GPUs)")
+        return cfg, batch, desc, BATCH, PARTS
+    if name == "c3":
+        cfg = config.dgl_dgcnn_everyday()
+        batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234 + rank, device=dev)
+        desc = ("DGL (3 GNN iterations, merge_node off) + DGCNN encoder, everyday-like synthetic clouds, B=32 per "
+                "GPU, P=20, N=1000, geometric loss summed over the iterations, Adam (BASELINE.json configs[2])")
+        return cfg, batch, desc, BATCH, PARTS
+    if name == "c5":
+        cfg = config.rgl_net_dgcnn_artifact()
+        batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="artifact", seed=1234 + rank, device=dev)
+        desc = ("RGL-NET (bi-GRU, 3 iterations) + DGCNN encoder, artifact-like synthetic clouds (12-20 small parts), "
+                "B=32 per GPU, P=20, N=1000, Chamfer in fp32 as the reference forces it (BASELINE.json configs[4])")
+        return cfg, batch, desc, BATCH, PARTS
+    cfg = config.global_partnet_chair()
+    cfg.data.max_num_part = 2
+    batch = synthetic.make_semantic_batch(4, 2, POINTS, seed=1234 + rank, device=dev,
+                                          num_part_category=cfg.data.num_part_category)
+    desc = ("B-Global + PointNet, semantic flags on (identical-part matching, min-of-5 sampling, 32 noise channels), "
+            "P=2, B=4, N=1000 (BASELINE.json configs[0]: the reference's CPU-runnable plumbing case)")
+    return cfg, batch, desc, 4, 2
+
+
+# ---- CPU baseline ---------------------------------------------------------------------------------------------------
+def cpu_model_name():
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cpu_batch, dev):
+    """Reference-equivalent CPU training step (oracle/nets.py + oracle/chamfer_ref.c) on a bounded sample of the c2
+    workload: the SAME synthetic generator and seed as the GPU run (synthetic.make_batch, seed 1234) at B = cpu_batch
+    instead of 32 (cost is linear in B), all cores: 3 warm-up + 5 timed steps; one thread: 1 warm-up + 2 timed steps at
+    B = 2."""
+    import torch
+    from multi_part_assembly_amd import config, synthetic
     from multi_part_assembly_amd.pn_transformer import build_model
     from oracle import nets as on
 
     cores = len(os.sched_getaffinity(0))
-    threads = max(1, min(64, cores))
-    torch.set_num_threads(threads)
-    os.environ["OMP_NUM_THREADS"] = str(threads)
     cfg = config.pn_transformer_everyday()
     torch.manual_seed(0)
     model = build_model(cfg)
-    sd = {k: v.clone() for k, v in model.state_dict().items()}
-    params = {k: sd[k].requires_grad_() for k, _ in model.named_parameters()}
-    g = torch.Generator().manual_seed(1234)
-    B, P, N = cpu_batch, PARTS, POINTS
-    num_parts = torch.randint(2, P + 1, (B,), generator=g).tolist()
-    valids = torch.zeros(B, P)
-    for b, k in enumerate(num_parts):
-        valids[b, :k] = 1
-    pcs = (torch.rand(B, P, N, 3, generator=g) - 0.5) * 0.3 * valids[..., None, None]
-    quat = torch.nn.functional.normalize(torch.randn(B, P, 4, generator=g), dim=-1) * valids[..., None]
-    batch = {"part_pcs": pcs, "part_quat": quat, "part_valids": valids,
-             "part_trans": (torch.rand(B, P, 3, generator=g) * 0.8 - 0.4) * valids[..., None]}
-    state = {}
+    P, N = PARTS, POINTS
 
-    def step():
-        for p in params.values():
-            p.grad = None
-        stats = {}
-        losses, _ = on.pn_transformer_loss(sd, batch, cfg.model.transformer_layers,
-                                           cfg.model.transformer_heads, training=True, stats_out=stats)
-        losses["loss"].backward()
-        on.adam_step(params, {k: p.grad for k, p in params.items()}, state, lr=cfg.optimizer.lr)
-        for k, v in stats.items():
-            sd[k] = v
+    def run(B, threads, warm, timed):
+        torch.set_num_threads(threads)
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        params = {k: sd[k].requires_grad_() for k, _ in model.named_parameters()}
+        full = synthetic.make_batch(B, P, N, preset="everyday", seed=1234, device=dev)
+        batch = {k: v.cpu() for k, v in full.items() if hasattr(v, "cpu")}
+        state = {}
 
-    step()
-    t0 = time.perf_counter()
-    timed = 2
-    for _ in range(timed):
-        step()
-    dt = (time.perf_counter() - t0) / timed
-    return {"value": B * P / dt, "unit": "parts/s", "cores": threads, "kind": "port",
-            "sample": f"full train step (fwd+loss+bwd+Adam) of the same model at B={B} (vs 32), P={P}, "
-                      f"N={N}; {timed} timed steps after 1 warm-up; {dt:.2f} s/step; torch CPU ops + "
-                      f"OpenMP C Chamfer on {threads} threads of {cores} visible"}
+        def step():
+            for p in params.values():
+                p.grad = None
+            stats = {}
+            losses, _ = on.pn_transformer_loss(sd, batch, cfg.model.transformer_layers,
+                                               cfg.model.transformer_heads, training=True, stats_out=stats)
+            losses["loss"].backward()
+            on.adam_step(params, {k: p.grad for k, p in params.items()}, state, lr=cfg.optimizer.lr)
+            for k, v in stats.items():
+                sd[k] = v
+
+        for _ in range(warm):
+            step()
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            step()
+        dt = (time.perf_counter() - t0) / timed
+        return B * P / dt, dt
+
+    threads = max(1, min(64, cores))
+    v_all, dt_all = run(cpu_batch, threads, 3, 5)
+    v_one, dt_one = run(2, 1, 1, 2)
+    return {"value": v_all, "unit": "parts/s", "cores": threads, "kind": "port",
+            "one_thread_value": v_one, "cpu": cpu_model_name(), "visible_cores": cores,
+            "sample": f"full train step (fwd+loss+bwd+Adam) of the c2 model on synthetic.make_batch(seed=1234) at "
+                      f"B={cpu_batch} (vs 32), P={P}, N={N}: 3 warm-up + 5 timed steps, {dt_all:.2f} s/step on "
+                      f"{threads} threads; one thread: B=2, 1 warm-up + 2 timed, {dt_one:.2f} s/step; torch CPU ops + "
+                      f"OpenMP C Chamfer (oracle/), cost linear in B"}
+
+
+# ---- roofline bookkeeping -------------------------------------------------------------------------------------------
+def _find(kernels, prefix):
+    return [(k, v) for k, v in kernels.items() if k.startswith(prefix)]
+
+
+def kernel_table(kernels, num_parts, cfg, B, P):
+    """Per-kernel fractions of the bound that binds each of the large kernels (algorithmic work / measured time)."""
+    nv = sum(num_parts)
+    N = POINTS
+    F = cfg.model.pc_feat_dim
+    rows = {}
+
+    def add(prefix, name, **kw):
+        hit = _find(kernels, prefix)
+        if not hit:
+            return
+        ms = sum(v["total_ms"] for _, v in hit) / max(1, hit[0][1]["launches"])  # per step
+        rec = {"ms_per_step": ms}
+        secs = ms * 1e-3
+        if "flops" in kw:
+            rec.update(bound="mfma_f32", flops=kw["flops"], achieved_tflops=kw["flops"] / secs / 1e12,
+                       frac=kw["flops"] / secs / MFMA_F32_PEAK)
+        if "lane_ops" in kw:
+            rec.update(bound="valu", lane_ops=kw["lane_ops"], frac=kw["lane_ops"] / secs / VALU_PEAK_LANE_OPS)
+        if "bytes" in kw:
+            rec.update(hbm_bytes=kw["bytes"], hbm_frac=kw["bytes"] / secs / 1e9 / HBM_PEAK_GBS)
+        rows[name] = rec
+
+    if cfg.model.encoder == "pointnet":
+        fwd = 2.0 * nv * N * (3 * 64 + 64 * 64 + 64 * 64 + 64 * 128 + 128 * F)
+        add("pointnet_forward", "pointnet_forward", flops=fwd)
+        add("pointnet_backward", "pointnet_backward", flops=2.0 * fwd)
+    else:
+        gemm = 2.0 * nv * N * (3 * 128 + 64 * 128 + 64 * 256 + 128 * 512 + 512 * F)
+        add("dgcnn_forward", "dgcnn_forward", flops=gemm + 2.0 * nv * N * N * (3 + 64 + 64 + 128))
+        add("dgcnn_backward", "dgcnn_backward", flops=2.0 * gemm)
+    if "transformer_layers" in cfg.model:
+        D, FF, L, H = F, cfg.model.transformer_feat_dim, cfg.model.transformer_layers, cfg.model.transformer_heads
+        M = B * P
+        tf = L * (2.0 * M * D * 3 * D + 2.0 * M * D * D + 4.0 * M * D * FF + 4.0 * B * H * P * P * (D // H))
+        add("transformer_forward", "transformer_forward", flops=tf)
+        add("transformer_backward", "transformer_backward", flops=2.0 * tf)
+    # per-part Chamfer: 2 directions x N^2 pairs per valid part, 8.6 VALU lane-slots per pair (DESIGN.md §4)
+    add("assembly_part_chamfer", "assembly_part_chamfer", lane_ops=8.6 * 2.0 * nv * N * N, bytes=24.0 * 2 * nv * N)
+    return rows
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        relaunch_distributed(args)
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -113,20 +236,20 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from multi_part_assembly_amd import _lib, config, synthetic
+    from multi_part_assembly_amd import _lib
     from multi_part_assembly_amd.pn_transformer import build_model
     from multi_part_assembly_amd.trainer import Trainer
 
-    cfg = config.pn_transformer_everyday()
+    cfg, batch, desc, B, P = workload(args.config, rank, dev)
     torch.manual_seed(0)  # same initial weights on every rank (and broadcast from rank 0 anyway)
     model = build_model(cfg).to(dev)
     use_graph = args.graph and not args.eager
     trainer = Trainer(model, cfg, use_graph=use_graph)
-    batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234 + rank, device=dev)
     num_parts = batch.pop("num_parts")
     valid_parts = int(sum(num_parts))
 
@@ -170,57 +293,103 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(1, args.steps)
-        value = world * BATCH * PARTS * args.steps / elapsed
+        value = world * B * P * args.steps / elapsed
         kernels = timer.summary()
-        dom = f"grid_search_kernel[{BATCH}x{PARTS}x{POINTS}]"
-        phase = f"assembly_shape_chamfer[{BATCH}x{PARTS}x{POINTS}]"
+        N = POINTS
+        timing = ("HIP events recorded by libmpa_hip.so right before/after the kernel on its launch stream, "
+                  + ("in an eager pass over the same K steps right after the timed graph replays"
+                     if use_graph else "inside the timed region"))
         roofline = None
-        if dom in kernels:
-            k = kernels[dom]
-            # algorithmic traffic of the whole-shape search kernel: every valid point of both
-            # shapes is read once as a 16 B query record and once as a 16 B target record and produces a 4 B
-            # distance and a 4 B index -> 40 B per valid point and shape; padded slots cost nothing.
-            alg_bytes = 2.0 * 40.0 * valid_parts * POINTS
-            brute_pairs = 2.0 * POINTS * POINTS * sum(n * n for n in num_parts)
-            secs = k["avg_ms"] * 1e-3
-            achieved = alg_bytes / secs / 1e9
-            traffic, traffic_src = None, None
-            pmc = sorted((ROOT / "profiles").glob("r*_pmc_dominant_kernel.json"))
-            if pmc:  # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes
-                rec = json.loads(pmc[-1].read_text())
-                traffic, traffic_src = rec["traffic_bytes_per_launch"], f"profiles/{pmc[-1].name}: {rec['correction']}"
-            roofline = {
-                "kernel": "mpa::grid_search_kernel (exact grid-pruned whole-shape Chamfer search of the fused "
-                          "loss, both directions)",
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "timing": "HIP events recorded by libmpa_hip.so right before/after the kernel on its launch stream, "
-                          + ("in an eager pass over the same K steps right after the timed graph replays"
-                             if use_graph else "inside the timed region"),
-                "whole_phase_avg_ms": kernels[phase]["avg_ms"] if phase in kernels else None,
-                # the search is VALU-bound, not HBM-bound: pair evaluations an exhaustive scan of
-                # the same valid points would need, per second of this kernel
-                "equivalent_brute_force_pair_evals_per_s": brute_pairs / secs,
-            }
+        if cfg.model.encoder == "dgcnn":
+            # kNN graph of the first EdgeConv stage (C = 3): SURVEY.md §8d — n*N*(4C read + 20*8 index write)
+            hit = _find(kernels, "dgcnn_knn[")
+            if hit:
+                per_layer = {}
+                for name, k in hit:
+                    C = int(name.split("C=")[1].rstrip("]"))
+                    secs = k["avg_ms"] * 1e-3
+                    alg = float(valid_parts) * N * (4 * C + 20 * 8)
+                    pairs = float(valid_parts) * N * N
+                    per_layer[f"C={C}"] = {
+                        "avg_launch_ms": k["avg_ms"], "launches": k["launches"], "algorithmic_bytes": alg,
+                        "hbm_GBps": alg / secs / 1e9, "hbm_frac": alg / secs / 1e9 / HBM_PEAK_GBS,
+                        "score_flops": pairs * (2 * C + 1), "score_tflops": pairs * (2 * C + 1) / secs / 1e12,
+                        "pairs_per_s": pairs / secs}
+                name, k = max(hit, key=lambda kv: kv[1]["total_ms"])
+                C = int(name.split("C=")[1].rstrip("]"))
+                secs = k["avg_ms"] * 1e-3
+                alg = float(valid_parts) * N * (4 * C + 20 * 8)
+                pairs = float(valid_parts) * N * N
+                roofline = {
+                    "kernel": f"mpa::dg_knn_kernel (k = 20 nearest neighbours in {C}-d feature space, {valid_parts} "
+                              f"clouds of {N} points)",
+                    "bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                    "avg_launch_ms": k["avg_ms"], "launches": k["launches"], "algorithmic_bytes_per_launch": alg,
+                    "binding": {"bound": "mfma_f32" if C >= 64 else "valu",
+                                "note": "exhaustive exact top-20: N candidate scores per query (2C+1 FLOP each) + "
+                                        "the top-k selection; HBM is not what binds it (SURVEY.md §7 hard part 1)",
+                                "score_flops_per_launch": pairs * (2 * C + 1),
+                                "frac": (pairs * (2 * C + 1) / secs / MFMA_F32_PEAK) if C >= 64 else
+                                        (pairs * 12.0 / secs / VALU_PEAK_LANE_OPS)},
+                    "per_layer": per_layer, "timing": timing}
+        else:
+            dom = _find(kernels, "grid_search_kernel[")
+            phase = _find(kernels, "assembly_shape_chamfer[")
+            if dom:
+                k = dom[0][1]
+                # 24 B per point of both clouds (12 B xyz read, 4 B distance, 8 B index written);
+                # padded parts cost nothing here (one representative point each), so valid points only.
+                alg_bytes = 2.0 * 24.0 * valid_parts * N
+                brute_pairs = 2.0 * N * N * sum(n * n for n in num_parts)
+                secs = k["avg_ms"] * 1e-3
+                achieved = alg_bytes / secs / 1e9
+                traffic, traffic_src = None, None
+                pmc = sorted((ROOT / "profiles").glob("r*_pmc_dominant_kernel.json"))
+                if pmc:  # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes
+                    rec = json.loads(pmc[-1].read_text())
+                    traffic, traffic_src = rec["traffic_bytes_per_launch"], f"profiles/{pmc[-1].name}: {rec['correction']}"
+                roofline = {
+                    "kernel": "mpa::grid_search_kernel (exact grid-pruned whole-shape Chamfer search of the fused "
+                              "loss, both directions)",
+                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "binding": {"bound": "latency",
+                                "note": "exact pruned search: short dependent candidate-list round trips, neither HBM "
+                                        "nor VALU throughput binds it (DESIGN.md §4); an exhaustive scan of the same "
+                                        "points would be VALU-bound",
+                                "equivalent_brute_force_pair_evals_per_s": brute_pairs / secs,
+                                "valu_frac_if_brute_force": 8.6 * brute_pairs / secs / VALU_PEAK_LANE_OPS},
+                    "oracle_note": "quaternion algebra of the loss restated from pytorch3d (un-vendored): parity "
+                                   "unpinned at that boundary",
+                    "timing": timing,
+                    "whole_phase_avg_ms": phase[0][1]["avg_ms"] if phase else None,
+                }
+        rccl = None
+        if distributed:
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                rccl = "unknown"
         line = {
             "metric": "train-step parts/sec (BxP) at N=1000 pts",
             "value": value, "unit": "parts/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "pn_transformer + PointNet encoder, Breaking-Bad-everyday-like "
-                                   "synthetic clouds, B=32 per GPU, P=20, N=1000, geometric loss, Adam "
-                                   "(BASELINE.json configs[1])",
-                       "per_gpu_batch": BATCH, "max_parts": PARTS, "points_per_part": POINTS,
+            "config": {"workload": desc, "name": args.config,
+                       "per_gpu_batch": B, "max_parts": P, "points_per_part": POINTS,
                        "valid_parts_rank0": valid_parts, "parallelism": f"dp{world}",
+                       "rccl_ranks": world if distributed else 0, "rccl_version": rccl,
                        "launch": "hip-graph replay" if use_graph else "eager"},
             "final_loss": final_loss,
             "kernels": kernels,
             "roofline": roofline,
+            "kernel_table": kernel_table(kernels, num_parts, cfg, B, P),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+        if world == 1 and not args.no_cpu_baseline and args.config in ("c2", "c4"):
+            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, dev)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

@@ -25,7 +25,7 @@ extern "C" {
 #define MPA_ELAUNCH (-2) /* hipGetLastError() reported a launch failure */
 
 /* ABI version of this header; bumped whenever a signature changes. */
-#define MPA_ABI_VERSION 1
+#define MPA_ABI_VERSION 2
 int mpa_abi_version(void);
 
 /* Thread-local, NUL-terminated description of the last failure on this thread ("" if none). */
@@ -266,16 +266,33 @@ int mpa_pose_head_backward(const float* grad_rot, const float* grad_trans, const
  * gradients, first and second moments).  `step` is the 1-based step count (bias correction),
  * `grad_scale` multiplies the gradient first (1/world_size of the data-parallel mean),
  * `decoupled_weight_decay` selects AdamW (p *= 1 - lr*wd) over Adam's L2 form (g += wd*p).
+ * `decay_mask` (nullable = decay everything): [numel] 1/0 per element; the reference's AdamW parameter groups
+ * exempt biases and normalisation weights (multi_part_assembly/utils/utils.py:90-125 filter_wd_parameters).
  * ---------------------------------------------------------------------------------------------- */
 int mpa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
                   float lr, float beta1, float beta2, float eps, float weight_decay,
-                  int decoupled_weight_decay, int64_t step, float grad_scale, void* stream);
+                  int decoupled_weight_decay, int64_t step, float grad_scale, const float* decay_mask,
+                  void* stream);
 
-/* Graph-capturable twin: `hyper` is a DEVICE buffer {lr, 1-beta1^step, sqrt(1-beta2^step), grad_scale}
- * that the host refreshes between replays of a captured step (the launch arguments stay constant). */
+/* Graph-capturable twin: `hyper` is an 8-float DEVICE buffer
+ *   [0] lr  [1] 1-beta1^step  [2] sqrt(1-beta2^step)  [3] grad_scale  [4] step count (int32 bits)
+ *   [5] clip coefficient (1 = no clipping; written by mpa_grad_clip_coef)  [6] clipped norm (info)  [7] unused.
+ * Every call first ADVANCES the step count on the device and recomputes [1], [2] from it, then applies the update:
+ * the launch arguments stay constant across replays of a captured step and the host uploads nothing per step (it
+ * writes [0] / [3] only when the schedule or the world size changes, [4] when a checkpoint is loaded). */
 int mpa_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
-                      const float* hyper, float beta1, float beta2, float eps, float weight_decay,
-                      int decoupled_weight_decay, void* stream);
+                      float* hyper, float beta1, float beta2, float eps, float weight_decay,
+                      int decoupled_weight_decay, const float* decay_mask, void* stream);
+
+/* Global-norm gradient clipping — replaces Lightning's `gradient_clip_val` (scripts/train.py:90 passes
+ * cfg.optimizer.clip_grad; algorithm "norm" = torch.nn.utils.clip_grad_norm_): coef[0] = min(1, max_norm /
+ * (|scale * grad|_2 + 1e-6)), coef[1] = that norm; `scale` = *grad_scale_dev if non-NULL else grad_scale (the
+ * 1/world of the data-parallel mean that the optimiser applies later).  Point `coef` at hyper + 5 of
+ * mpa_adam_step_dev to fold the clipping into the update.  Deterministic two-stage sum in double; `ws` =
+ * mpa_grad_clip_workspace bytes. */
+int mpa_grad_clip_workspace(int64_t* bytes);
+int mpa_grad_clip_coef(const float* grad, int64_t numel, float max_norm, const float* grad_scale_dev,
+                       float grad_scale, void* ws, float* coef, void* stream);
 
 /* ---- GT <-> prediction matching of equivalent parts (semantic datasets) --------------------------------------
  * Replaces BaseModel._linear_sum_assignment / _match_parts (multi_part_assembly/models/modules/base_model.py:

@@ -56,11 +56,13 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_pose_head_workspace": (_INT, [_I64, _I64, _P]),
     "mpa_pose_head_forward": (_INT, [_P, _P, _I64, _I64, _P, _P, _P, _P]),
     "mpa_pose_head_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
-    "mpa_adam_step": (_INT, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _INT, _I64, _F32, _P]),
-    "mpa_adam_step_dev": (_INT, [_P, _P, _P, _P, _I64, _P, _F32, _F32, _F32, _F32, _INT, _P]),
+    "mpa_adam_step": (_INT, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _INT, _I64, _F32, _P, _P]),
+    "mpa_adam_step_dev": (_INT, [_P, _P, _P, _P, _I64, _P, _F32, _F32, _F32, _F32, _INT, _P, _P]),
+    "mpa_grad_clip_workspace": (_INT, [_P]),
+    "mpa_grad_clip_coef": (_INT, [_P, _I64, _F32, _P, _F32, _P, _P, _P]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

@@ -230,7 +230,11 @@ class BaseModel(nn.Module):
         from .optim import FusedAdam, cosine_warmup_lr
 
         opt_cfg = self.cfg.optimizer
-        optimizer = FusedAdam(self.parameters(), lr=opt_cfg.lr, weight_decay=opt_cfg.weight_decay)
+        optimizer = FusedAdam(self.parameters(), lr=opt_cfg.lr, weight_decay=opt_cfg.weight_decay,
+                              clip_grad=opt_cfg.get("clip_grad", None))
+        if opt_cfg.weight_decay > 0:  # AdamW parameter groups: biases and normalisation weights are not decayed
+            from .optim import decay_mask_for
+            optimizer.decay_mask = decay_mask_for(self, optimizer.flat)
         schedule = None
         if opt_cfg.lr_scheduler:
             assert opt_cfg.lr_scheduler == "cosine"

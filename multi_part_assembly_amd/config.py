@@ -106,6 +106,22 @@ def rgl_net_everyday():
     return Config(exp=_exp(200), data=data, optimizer=adam_cosine(), model=model, loss=geometric_loss())
 
 
+def dgl_dgcnn_everyday():
+    """BASELINE.json configs[2]: DGL with the DGCNN part encoder (`cfg.model.encoder = 'dgcnn'`, allowed by
+    models/modules/encoder/__init__.py:6-21; no shipped config file sets it)."""
+    cfg = dgl_everyday()
+    cfg.model.encoder = "dgcnn"
+    return cfg
+
+
+def rgl_net_dgcnn_artifact():
+    """BASELINE.json configs[4]: RGL-NET with the DGCNN part encoder on the Breaking-Bad artifact subset
+    (configs/_base_/datasets/breaking_bad/artifact.py: same keys as everyday, other data list)."""
+    cfg = rgl_net_everyday()
+    cfg.model.encoder = "dgcnn"
+    return cfg
+
+
 def global_everyday():
     """configs/global/global-32x1-cosine_200e-everyday.py."""
     return Config(exp=_exp(200), data=breaking_bad_everyday(), optimizer=adam_cosine(), model=global_model(),

@@ -351,23 +351,28 @@ __global__ __launch_bounds__(kThreads) void assembly_backward_kernel(
       const long long o = base + 3LL * n;
       const float px = pcs[o], py = pcs[o + 1], pz = pcs[o + 2];
       const float ax = R1[o], ay = R1[o + 1], az = R1[o + 2];
-      const long long j = base + 3LL * ip1[(long long)m * N + n];
-      float gx = c_cd * (ax - R2[j]) + c_l2 * (ax - R2[o]);
-      float gy = c_cd * (ay - R2[j + 1]) + c_l2 * (ay - R2[o + 1]);
-      float gz = c_cd * (az - R2[j + 2]) + c_l2 * (az - R2[o + 2]);
+      // a stored index of -1 (no candidate below 1e32: NaN / inf poses of a diverged step) contributes nothing,
+      // like chamfer_kernel.cu:199-208 for idx = -1 — and must not be used as an address
+      const int i1 = ip1[(long long)m * N + n], i2 = is1[(long long)m * N + n];
+      const float k_cd = i1 >= 0 ? c_cd : 0.0f, k_s = i2 >= 0 ? c_s : 0.0f;
+      const long long j = base + 3LL * (i1 >= 0 ? i1 : 0);
+      float gx = k_cd * (ax - R2[j]) + c_l2 * (ax - R2[o]);
+      float gy = k_cd * (ay - R2[j + 1]) + c_l2 * (ay - R2[o + 1]);
+      float gz = k_cd * (az - R2[j + 2]) + c_l2 * (az - R2[o + 2]);
       accumulate(acc, w, ux, uy, uz, px, py, pz, gx, gy, gz, false);
-      const long long js = sbase + 3LL * is1[(long long)m * N + n];
-      gx = c_s * (S1[o] - S2[js]);
-      gy = c_s * (S1[o + 1] - S2[js + 1]);
-      gz = c_s * (S1[o + 2] - S2[js + 2]);
+      const long long js = sbase + 3LL * (i2 >= 0 ? i2 : 0);
+      gx = k_s * (S1[o] - S2[js]);
+      gy = k_s * (S1[o + 1] - S2[js + 1]);
+      gz = k_s * (S1[o + 2] - S2[js + 2]);
       accumulate(acc, w, ux, uy, uz, px, py, pz, gx, gy, gz, true);
     }
     // B. this part's points as matched TARGETS of its GT copy (part-CD dir 2)
     for (int k = threadIdx.x; k < N; k += kThreads) {
-      const int jn = ip2[(long long)m * N + k];
+      const int jraw = ip2[(long long)m * N + k], jn = jraw >= 0 ? jraw : 0;
+      const float k_cd = jraw >= 0 ? c_cd : 0.0f;
       const long long o = base + 3LL * k, j = base + 3LL * jn;
-      const float gx = -c_cd * (R2[o] - R1[j]), gy = -c_cd * (R2[o + 1] - R1[j + 1]),
-                  gz = -c_cd * (R2[o + 2] - R1[j + 2]);
+      const float gx = -k_cd * (R2[o] - R1[j]), gy = -k_cd * (R2[o + 1] - R1[j + 1]),
+                  gz = -k_cd * (R2[o + 2] - R1[j + 2]);
       accumulate(acc, w, ux, uy, uz, pcs[j], pcs[j + 1], pcs[j + 2], gx, gy, gz, false);
     }
   }

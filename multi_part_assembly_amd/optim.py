@@ -55,65 +55,106 @@ class FlatBuffers:
         self.flat_grad.zero_()
 
 
+def decay_mask_for(model, flat: "FlatBuffers"):
+    """1/0 per element of the flat parameter buffer: the reference's AdamW parameter groups (utils/utils.py:90-125
+    `filter_wd_parameters`) exempt every bias and the weights of normalisation layers from weight decay."""
+    import torch.nn as nn
+    norm_types = (nn.LayerNorm, nn.GroupNorm, nn.modules.batchnorm._BatchNorm, nn.modules.instancenorm._InstanceNorm)
+    no_decay = set()
+    for m in model.modules():
+        if isinstance(m, norm_types) and getattr(m, "weight", None) is not None:
+            no_decay.add(id(m.weight))
+        if getattr(m, "bias", None) is not None and isinstance(m.bias, torch.Tensor):
+            no_decay.add(id(m.bias))
+    mask = torch.zeros_like(flat.flat_param)
+    for p, off in zip(flat.params, flat.offsets):
+        if id(p) not in no_decay:
+            mask[off:off + p.numel()] = 1.0
+    return mask
+
+
 class FusedAdam:
+    """One-kernel Adam / AdamW over FlatBuffers.  `step()` = `prepare_hyper()` + `step_dev()`: the step count and
+    the bias corrections live in DEVICE memory and are advanced by the library on the stream (csrc/adam.hip), so
+    neither eager steps nor HIP-graph replays upload per-step scalars from the host — a host that runs steps ahead
+    of the GPU cannot corrupt a queued update.  Learning rate and grad_scale are written with `fill_` (the value
+    travels as a kernel argument) only when they change.
+
+    `decay_mask`: optional flat 1/0 tensor (see `decay_mask_for`).  `clip_grad`: global-norm clipping of the
+    (mean) gradient, the reference's `gradient_clip_val` (scripts/train.py:90)."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 decoupled_weight_decay=None):
+                 decoupled_weight_decay=None, decay_mask=None, clip_grad=None):
         self.flat = params if isinstance(params, FlatBuffers) else FlatBuffers(params)
         self.params = self.flat.params
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         # the reference switches to AdamW as soon as weight_decay > 0 (base_model.py:394-404)
         self.decoupled = (weight_decay > 0) if decoupled_weight_decay is None else decoupled_weight_decay
+        self.decay_mask = decay_mask
+        self.clip_grad = clip_grad if clip_grad else None
         self.step_count = 0
         self.grad_scale = 1.0
         self.numel = self.flat.numel
         self.flat_param, self.flat_grad = self.flat.flat_param, self.flat.flat_grad
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self._hyper_dev, self._uploaded = None, (None, None)
 
     def zero_grad(self):
         self.flat.zero_grad()
 
-    def step(self, lr=None):
-        if lr is not None:
-            self.lr = lr
-        dev = self.flat_param.device
-        if dev.type != "cuda":
-            raise RuntimeError("FusedAdam.step: parameters must live on the GPU (HIP kernel only)")
-        self.step_count += 1
-        with torch.cuda.device(dev):
-            st = _lib.lib().mpa_adam_step(
-                _lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
-                _lib.ptr(self.exp_avg_sq), self.numel, float(self.lr), float(self.betas[0]),
-                float(self.betas[1]), float(self.eps), float(self.weight_decay), int(self.decoupled),
-                self.step_count, float(self.grad_scale), _lib.current_stream(dev))
-        _lib.check(st, "mpa_adam_step")
+    # ---- device-resident hyper-parameters -----------------------------------------------------------------
+    def _ensure_hyper(self):
+        if self._hyper_dev is None:
+            dev = self.flat_param.device
+            if dev.type != "cuda":
+                raise RuntimeError("FusedAdam.step: parameters must live on the GPU (HIP kernel only)")
+            self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
+            self._hyper_dev[5] = 1.0  # clip coefficient: no clipping
+            self._set_device_step(self.step_count)
+            if self.clip_grad is not None:
+                nbytes = __import__("ctypes").c_int64()
+                _lib.check(_lib.lib().mpa_grad_clip_workspace(__import__("ctypes").byref(nbytes)),
+                           "mpa_grad_clip_workspace")
+                self._clip_ws = torch.empty(nbytes.value // 8, dtype=torch.float64, device=dev)
 
-    # ---- graph-capturable form: hyper-parameters live in a 4-float device buffer -----------------------
-    def _hyper_values(self, step):
-        # same arithmetic as mpa_adam_step: betas rounded to fp32 first, powers and sqrt in double
-        b1, b2 = (float(torch.tensor(b, dtype=torch.float32)) for b in self.betas)
-        return [float(self.lr), 1.0 - b1 ** step, math.sqrt(1.0 - b2 ** step), float(self.grad_scale)]
+    def _set_device_step(self, step):
+        self._hyper_dev[4:5].view(torch.int32).fill_(int(step))
 
     def prepare_hyper(self):
-        """Advance the step count and upload {lr, bias corrections, grad_scale} for the next captured or
-        eager `step_dev` launch (async copy from pinned memory on the current stream)."""
-        if not hasattr(self, "_hyper_dev"):
-            self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=self.flat_param.device)
-            self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        """Host-side bookkeeping in front of `step_dev`: advances the host mirror of the step count and rewrites
+        lr / grad_scale on the device when they changed (fill_: no host staging buffer involved)."""
+        self._ensure_hyper()
         self.step_count += 1
-        self._hyper_host.copy_(torch.tensor(self._hyper_values(self.step_count)))
-        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        if self._uploaded != (float(self.lr), float(self.grad_scale)):
+            self._hyper_dev[0:1].fill_(float(self.lr))
+            self._hyper_dev[3:4].fill_(float(self.grad_scale))
+            self._uploaded = (float(self.lr), float(self.grad_scale))
 
     def step_dev(self):
-        """The Adam launch with device-resident hyper-parameters (safe to capture in a HIP graph)."""
+        """[clip coefficient +] step-count advance + Adam update, all on the stream (safe to capture in a HIP
+        graph: every launch argument is constant across replays)."""
         dev = self.flat_param.device
+        lib = _lib.lib()
         with torch.cuda.device(dev):
-            st = _lib.lib().mpa_adam_step_dev(
+            stream = _lib.current_stream(dev)
+            if self.clip_grad is not None:
+                st = lib.mpa_grad_clip_coef(_lib.ptr(self.flat_grad), self.numel, float(self.clip_grad),
+                                            self._hyper_dev.data_ptr() + 12, 1.0, _lib.ptr(self._clip_ws),
+                                            self._hyper_dev.data_ptr() + 20, stream)
+                _lib.check(st, "mpa_grad_clip_coef")
+            st = lib.mpa_adam_step_dev(
                 _lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
                 _lib.ptr(self.exp_avg_sq), self.numel, _lib.ptr(self._hyper_dev), float(self.betas[0]),
                 float(self.betas[1]), float(self.eps), float(self.weight_decay), int(self.decoupled),
-                _lib.current_stream(dev))
+                _lib.ptr(self.decay_mask), stream)
         _lib.check(st, "mpa_adam_step_dev")
+
+    def step(self, lr=None):
+        if lr is not None:
+            self.lr = lr
+        self.prepare_hyper()
+        self.step_dev()
 
     def state_dict(self):
         return {"step": self.step_count, "lr": self.lr, "exp_avg": self.exp_avg.clone(),
@@ -123,6 +164,8 @@ class FusedAdam:
         self.step_count, self.lr = state["step"], state["lr"]
         self.exp_avg.copy_(state["exp_avg"])
         self.exp_avg_sq.copy_(state["exp_avg_sq"])
+        if self._hyper_dev is not None:
+            self._set_device_step(self.step_count)
 
 
 def cosine_warmup_lr(total_epochs, warmup_epochs, max_lr, min_lr):

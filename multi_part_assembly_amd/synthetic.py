@@ -58,3 +58,18 @@ def make_batch(batch_size, max_parts=20, num_points=1000, preset="everyday", see
         "valid_matrix": v[:, :, None] * v[:, None, :],
         "num_parts": num_parts,
     }
+
+
+def make_semantic_batch(batch_size, max_parts=2, num_points=1000, seed=1234, device="cuda", num_part_category=57):
+    """Semantic-dataset (PartNet-like) stand-in for the plumbing configuration (P = 2, B = 4,
+    `match_ids = [1, 1]`): every shape has `max_parts` geometrically identical parts (one cloud, different poses), so
+    the GT <-> prediction matching has a real group to permute; `instance_label` is the one-hot part slot
+    (partnet_data.py:163-208), `part_label` zero-width (not in the shipped `data_keys`)."""
+    batch = make_batch(batch_size, max_parts, num_points, preset="everyday", seed=seed, device=device,
+                       num_parts=[max_parts] * batch_size)
+    dev = batch["part_pcs"].device
+    B, P = batch_size, max_parts
+    batch["part_pcs"] = batch["part_pcs"][:, :1].expand(B, P, num_points, 3).contiguous()
+    batch["match_ids"] = torch.ones(B, P, dtype=torch.int64, device=dev)
+    batch["instance_label"] = torch.eye(P, device=dev)[None].repeat(B, 1, 1)
+    return batch

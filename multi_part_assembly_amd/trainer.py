@@ -15,8 +15,8 @@ Status: bit-identical to eager launches (tests/test_model_gpu.py) and stable at 
 things make that true: the library issues no hipMemsetAsync / hipMemcpyAsync (as graph NODES they returned stale
 data on replay — what an earlier revision of this note blamed on a library GEMM), and everything that must differ
 between replays is read from device memory that the host refreshes before each replay: the optimiser's step
-scalars and the dropout seeds (`advance_seed`).  The step is GPU-bound, so the replay is only ~2 % faster than
-eager launches (4.63 vs 4.71 ms); eager stays the default of bench.py.
+scalars (csrc/adam.hip keeps the step count on the device) and the dropout seeds (`advance_seed`).  The step is
+GPU-bound, so the replay is only ~2 % faster than eager launches; eager stays the default of bench.py.
 """
 from __future__ import annotations
 
@@ -25,7 +25,7 @@ import torch.distributed as dist
 
 from .gradsink import GradSink
 from .dp import BucketedGradReducer, broadcast_from_rank0, bucket_sizes_for, ordered_parameters
-from .optim import FlatBuffers, FusedAdam, cosine_warmup_lr
+from .optim import FlatBuffers, FusedAdam, cosine_warmup_lr, decay_mask_for
 
 
 class Trainer:
@@ -36,7 +36,11 @@ class Trainer:
         cfg = cfg if cfg is not None else model.cfg
         opt = cfg.optimizer
         self.flat = FlatBuffers(ordered_parameters(model))
-        self.optimizer = FusedAdam(self.flat, lr=opt.lr, weight_decay=opt.weight_decay)
+        # weight decay > 0 -> AdamW with biases / normalisation weights exempt (base_model.py:394-404); clip_grad ->
+        # global-norm clipping of the averaged gradient (scripts/train.py:90 gradient_clip_val)
+        self.optimizer = FusedAdam(self.flat, lr=opt.lr, weight_decay=opt.weight_decay,
+                                   decay_mask=decay_mask_for(model, self.flat) if opt.weight_decay > 0 else None,
+                                   clip_grad=opt.get("clip_grad", None))
         self.schedule = None
         if opt.lr_scheduler:
             total = cfg.exp.num_epochs

@@ -74,6 +74,8 @@ class _TransformerFn(torch.autograd.Function):
 
 
 class TransformerEncoder(nn.Module):
+    _instances = 0
+
     def __init__(self, d_model, num_heads, ffn_dim, num_layers, norm_first=True, dropout=0.1,
                  out_dim=None):
         super().__init__()
@@ -86,6 +88,9 @@ class TransformerEncoder(nn.Module):
         self.num_heads, self.norm_first = num_heads, norm_first
         self._calls = 0
         self._seed_dev = None
+        TransformerEncoder._instances += 1
+        self._instance = TransformerEncoder._instances  # mixed into the seed: sibling modules draw different masks
+        self._warned = False
         # shapes csrc/transformer.hip is built for (every shipped config: 256 / 8 heads / 1024 / pre-LN)
         self.native = (norm_first and d_model % 64 == 0 and ffn_dim % 64 == 0 and d_model % num_heads == 0
                        and d_model // num_heads <= 64 and num_layers <= 16)
@@ -93,7 +98,8 @@ class TransformerEncoder(nn.Module):
     def advance_seed(self):
         """New dropout seed for the next forward (a counter hashed with torch's seed), written to device memory."""
         self._calls += 1
-        seed = (torch.initial_seed() * 0x9E3779B1 + self._calls * 0x85EBCA77) & 0x7FFFFFFFFFFFFFFF
+        seed = (torch.initial_seed() * 0x9E3779B1 + self._calls * 0x85EBCA77
+                + self._instance * 0xC2B2AE3D27D4EB4F) & 0x7FFFFFFFFFFFFFFF
         if self._seed_dev is not None:
             self._seed_dev.fill_(seed)
 
@@ -123,7 +129,12 @@ class TransformerEncoder(nn.Module):
         if valid_masks is not None:
             assert valid_masks.shape == tokens.shape[:2]
         if not self.native or tokens.shape[1] > 64:
-            # configurations outside the HIP kernels' instantiation (post-LN, odd widths): library ops
+            # configurations outside the HIP kernels' instantiation (post-LN, odd widths): library ops — said aloud
+            if not self._warned:
+                import warnings
+                warnings.warn("TransformerEncoder: configuration outside csrc/transformer.hip (needs pre-LN, widths "
+                              "multiple of 64, head dim <= 64, <= 64 tokens, <= 16 layers); running on library ops")
+                self._warned = True
             pad = None if valid_masks is None else ~valid_masks
             return self.out_fc(self.transformer_encoder(tokens, src_key_padding_mask=pad))
         B, P, _ = tokens.shape
@@ -134,9 +145,15 @@ class TransformerEncoder(nn.Module):
         if p > 0.0:  # the seed lives in device memory so that a captured step draws fresh masks on every replay
             if self._seed_dev is None or self._seed_dev.device != tokens.device:
                 self._seed_dev = torch.zeros(1, dtype=torch.int64, device=tokens.device)
-            if not torch.cuda.is_current_stream_capturing():
+            capturing = torch.cuda.is_current_stream_capturing()
+            if not capturing:
                 self.advance_seed()  # (during capture / replays the Trainer calls advance_seed() between replays)
-            seed_dev = self._seed_dev
+                self._salt = 0
+            # per-call snapshot: a second forward of this module before the first one's backward (gradient
+            # accumulation, a caller that reuses the module) must not change the masks the first backward regenerates.
+            # Inside a captured step the k-th call of the module reads seed + k * odd constant at replay time.
+            seed_dev = self._seed_dev + (getattr(self, "_salt", 0) * 0x632BE59BD9B4E019 & 0x3FFFFFFFFFFFFFFF)
+            self._salt = getattr(self, "_salt", 0) + 1 if capturing else 0
         out = _TransformerFn.apply(tokens.float().contiguous(), valid.contiguous(), self.num_heads, p, 0, seed_dev,
                                    *self._params())
         return self.out_fc(out)

@@ -387,6 +387,53 @@ def gen_rgl_net_step():
     _model_step("rgl_net_step", cfg, data, 1009, {"cfg": np.array([64, 3])})
 
 
+def gen_dgl_dgcnn_step():
+    """BASELINE.json configs[2]: DGL with `cfg.model.encoder = 'dgcnn'` (models/dgl/network.py:90-99 feeding
+    encoder/dgcnn.py:41-109), geometric data.  N = 64 points per part: k = 20 neighbours of 64."""
+    cfg = _load_cfg("configs/dgl", "dgl-32x1-cosine_200e-everyday")
+    cfg.model.encoder = "dgcnn"
+    cfg.model.pc_feat_dim = 64
+    cfg.data.max_num_part = 5
+    g = torch.Generator().manual_seed(1014)
+    data = synthetic_batch(g, 3, 5, 64, [2, 4, 5])
+    _model_step("dgl_dgcnn_step", cfg, data, 1014, {"cfg": np.array([64, 3])})
+
+
+def gen_rgl_net_dgcnn_artifact_step():
+    """BASELINE.json configs[4]: RGL-NET with the DGCNN encoder on "artifact"-like data (many small parts: every
+    sample has 4-5 of 5 parts, part extents a third of the everyday stand-in)."""
+    cfg = _load_cfg("configs/rgl_net", "rgl_net-32x1-cosine_200e-everyday")
+    cfg.model.encoder = "dgcnn"
+    cfg.model.pc_feat_dim = 64
+    cfg.data.max_num_part = 5
+    g = torch.Generator().manual_seed(1015)
+    data = synthetic_batch(g, 3, 5, 64, [4, 5, 5])
+    data["part_pcs"] = data["part_pcs"] * 0.33
+    _model_step("rgl_net_dgcnn_artifact_step", cfg, data, 1015, {"cfg": np.array([64, 3])})
+
+
+def gen_lr_schedule():
+    """utils/lr.py:26-125 CosineAnnealingWarmupRestarts exactly as base_model.py:407-425 builds it (cycle_mult and
+    gamma 1, stepped once per epoch): the learning rate of every epoch for the shipped schedules."""
+    from multi_part_assembly.utils.lr import CosineAnnealingWarmupRestarts
+
+    out = {}
+    for tag, (total, ratio, lr, decay) in {"pn400": (400, 0.05, 1e-3, 100.0), "dgl200": (200, 0.0, 1e-3, 100.0),
+                                           "short": (10, 0.2, 5e-4, 10.0)}.items():
+        p = nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=lr)
+        sched = CosineAnnealingWarmupRestarts(opt, total, max_lr=lr, min_lr=lr / decay,
+                                              warmup_steps=int(total * ratio))
+        lrs = []
+        for _ in range(total + 5):  # a few epochs past the restart
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sched.step()
+        out[f"{tag}.cfg"] = np.array([total, ratio, lr, decay])
+        out[f"{tag}.lr"] = np.array(lrs, dtype=np.float64)
+    save("lr_schedule", **out)
+
+
 def gen_pn_refine_step():
     """PNTransformerRefine on geometric data (3 refinement rounds, loss summed over the rounds), widths shrunk."""
     cfg = _load_cfg("configs/pn_transformer/pn_transformer_refine", "pn_transformer_refine-32x1-cosine_400e-everyday")
@@ -578,6 +625,9 @@ def main():
         "rgl_net_step": gen_rgl_net_step,
         "global_semantic_step": gen_global_semantic_step,
         "pn_refine_step": gen_pn_refine_step,
+        "dgl_dgcnn_step": gen_dgl_dgcnn_step,
+        "rgl_net_dgcnn_artifact_step": gen_rgl_net_dgcnn_artifact_step,
+        "lr_schedule": gen_lr_schedule,
         "eval_metrics": lambda: gen_eval_metrics(U),
         "pn_transformer_eval": gen_pn_transformer_eval,
         "batch_producer": gen_batch_producer,

@@ -113,3 +113,14 @@ def test_cosine_schedule_restates_reference_quirks():
     assert lr(399) > 1e-5 and abs(lr(400) - lr(0 + 400 % 400 or 400)) >= 0
     no_warm = cosine_warmup_lr(200, 0, 1e-3, 1e-5)
     assert abs(no_warm(1) - (1e-5 + (1e-3 - 1e-5) * (1 + np.cos(np.pi / 200)) / 2)) < 1e-12
+
+
+def test_cosine_schedule_matches_reference_scheduler(golden):
+    """Every epoch's learning rate of the reference's CosineAnnealingWarmupRestarts (utils/lr.py:26-125, driven as
+    base_model.py:407-425 does) for the shipped schedules and a short one, restart included."""
+    z = golden("lr_schedule")
+    for tag in ("pn400", "dgl200", "short"):
+        total, ratio, lr, decay = z[tag + ".cfg"]
+        fn = cosine_warmup_lr(int(total), int(total * ratio), float(lr), float(lr / decay))
+        mine = np.array([fn(e) for e in range(len(z[tag + ".lr"]))])
+        np.testing.assert_allclose(mine, z[tag + ".lr"], rtol=1e-12, atol=0, err_msg=tag)

@@ -1,5 +1,6 @@
-"""Data-parallel training step on the GPU with world_size 2: two processes share the one GPU of the test box and
-talk over gloo (RCCL refuses two ranks on one device; the code under test — Trainer, the flat-buffer bucket reducer
+"""Data-parallel training step on the GPU with world_size 2: over RCCL with one rank per GPU when the box has two
+GPUs, and — always — with two processes sharing one GPU and talking over gloo (RCCL refuses two ranks on one device;
+the code under test — Trainer, the flat-buffer bucket reducer
 and the GradSink hand-off from the HIP backward kernels to the buckets — is backend-agnostic).  Each rank trains
 on its own shard; the result must equal a single-process emulation that averages the two shards' gradients
 (reference semantics: DDP, per-rank BatchNorm statistics, scripts/train.py:85,141)."""
@@ -46,11 +47,16 @@ def _shard(rank, dev):
     return batch
 
 
-def _worker(rank, world, port, out_dir, use_graph, steps):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, port, out_dir, use_graph, steps, backend="gloo"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from multi_part_assembly_amd.trainer import Trainer
-    dev = torch.device("cuda", 0)
+    if backend == "nccl":  # RCCL: one rank per GPU (scripts/train.py:81-95 `strategy='ddp'`)
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     model, cfg = _small_model()
     model.to(dev)
     trainer = Trainer(model, cfg, use_graph=use_graph)
@@ -63,15 +69,19 @@ def _worker(rank, world, port, out_dir, use_graph, steps):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
-def test_two_rank_training_equals_gradient_averaging(cuda_device, use_graph):
+def test_two_rank_training_equals_gradient_averaging(cuda_device, use_graph, backend):
     """eager: bucketed all-reduce overlapped with backward; graph: captured forward+backward replayed, one all-reduce
-    and the optimiser step behind it (what bench.py runs by default)."""
+    and the optimiser step behind it.  backend "gloo": both ranks on the one GPU of the test box; "nccl": RCCL with
+    one rank per GPU — needs two GPUs, skipped on a one-GPU box."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL with two ranks needs two GPUs")
     steps = 2
     if use_graph:
         steps = 6  # Trainer's 3 eager settle steps, then the capture and three replays
     with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_worker, args=(2, _free_port(), out_dir, use_graph, steps), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), out_dir, use_graph, steps, backend), nprocs=2, join=True)
         got = [torch.load(os.path.join(out_dir, f"rank{r}.pt")) for r in range(2)]
     assert torch.equal(got[0]["param"], got[1]["param"])  # replicas stay in lock-step
     # single-process emulation: per-shard forward/backward on replicas sharing the weights, averaged gradients

@@ -409,6 +409,38 @@ def test_fused_adam_matches_torch_adam(cuda_device):
             np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
 
 
+def test_fused_adamw_param_groups_and_clipping_match_torch(cuda_device):
+    """weight_decay > 0: AdamW with biases and normalisation weights exempt (utils/utils.py:90-125, base_model.py:
+    394-404); clip_grad: Lightning's gradient_clip_val = torch.nn.utils.clip_grad_norm_ (scripts/train.py:90)."""
+    from multi_part_assembly_amd.optim import FlatBuffers, decay_mask_for
+    torch.manual_seed(3)
+
+    def net():
+        torch.manual_seed(4)
+        return torch.nn.Sequential(torch.nn.Linear(7, 9), torch.nn.LayerNorm(9), torch.nn.Linear(9, 5),
+                                   torch.nn.BatchNorm1d(5)).to(cuda_device)
+
+    mine, theirs = net(), net()
+    flat = FlatBuffers(list(mine.parameters()))
+    mask = decay_mask_for(mine, flat)
+    assert 0 < float(mask.sum()) < flat.numel
+    opt = FusedAdam(flat, lr=1e-2, weight_decay=0.1, decay_mask=mask, clip_grad=0.05)
+    no_decay = [theirs[0].bias, theirs[1].weight, theirs[1].bias, theirs[2].bias, theirs[3].weight, theirs[3].bias]
+    decay = [theirs[0].weight, theirs[2].weight]
+    topt = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": 0.1}], lr=1e-2)
+    for step in range(4):
+        x = torch.randn(16, 7, device=cuda_device) * (3.0 if step % 2 else 0.01)  # clipped and unclipped steps
+        opt.zero_grad()
+        topt.zero_grad()
+        mine(x).square().sum().backward()
+        theirs(x).square().sum().backward()
+        torch.nn.utils.clip_grad_norm_(theirs.parameters(), 0.05)
+        opt.step()  # no host sync between the steps: the step count lives on the device
+        topt.step()
+    for a, b in zip(mine.parameters(), theirs.parameters()):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
 def test_trainer_step_matches_oracle_step(golden, cuda_device):
     """Full optimiser step: loss and gradients equal the oracle's (CPU autograd), and the parameter
     update is exactly Adam's first step on those gradients."""
@@ -468,6 +500,23 @@ def test_graph_replay_equals_eager_steps(golden, cuda_device):
         lg = graph.train_step(batch)
         assert float(lg) == float(le)
     assert graph._graph is not None  # steps 2.. were replays
+    _same_trajectory(graph.flat.flat_param, eager.flat.flat_param)
+
+
+def test_graph_replays_without_host_sync(golden, cuda_device):
+    """Replays queued back to back with NO host synchronisation between them (the step is GPU-bound, so the host
+    runs steps ahead): Adam's step count and bias corrections are advanced on the device, so each queued update
+    sees its own step — the trajectory equals eager steps, bit for bit."""
+    eager, batch = _fresh_trainer(golden, cuda_device)
+    graph, _ = _fresh_trainer(golden, cuda_device, use_graph=True, graph_warmup=1)
+    for _ in range(2):  # settle + capture
+        graph.train_step(batch)
+    torch.cuda.synchronize()
+    for _ in range(8):
+        graph.train_step(batch)  # nothing reads a result back inside this loop
+    torch.cuda.synchronize()
+    for _ in range(10):
+        eager.train_step(batch)
     _same_trajectory(graph.flat.flat_param, eager.flat.flat_param)
 
 
