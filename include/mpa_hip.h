@@ -212,6 +212,51 @@ int mpa_edge_aggregate_backward(const float* grad_out, const float* uv, const in
                                 float* grad_gamma, float* grad_beta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * DGCNN part encoder, whole forward / backward — replaces
+ *   DGCNN.forward        : multi_part_assembly/models/modules/encoder/dgcnn.py:73-109 (global_feat = True)
+ *   _extract_part_feats  : multi_part_assembly/models/dgl/network.py:90-99 (boolean-mask compaction + scatter; here:
+ *                          mask in, zeros out, the valid parts are counted and compacted on the device)
+ * 4 x [kNN (k = 20) -> Conv2d 1x1 over [x_j - x_i ; x_i] -> BatchNorm2d -> LeakyReLU 0.2 -> max_k], widths
+ * 3-64-64-128-256, concatenation (512) -> Conv1d 1x1 -> BatchNorm1d -> LeakyReLU 0.2 -> [max ; mean] over the N
+ * points -> Linear(2F -> F).  20 <= N <= 1024 points per part, F = 64, 128 or 256.
+ *
+ * points [M,N,3]; valids [M] (1/0): padded parts are skipped everywhere (they do not enter the BatchNorm statistics)
+ * and get feat = 0.  conv_w[l]: the Conv2d / Conv1d weights with their trailing 1s dropped, [64,6] [64,128] [128,128]
+ * [256,256] [F,512]; bn_w / bn_b / running_mean / running_var [C_l], l = 0..4 — HOST arrays of 5 DEVICE pointers;
+ * fc_w [F,2F], fc_b [F].  training != 0: batch statistics (over all edges of the valid parts), running statistics
+ * updated in place; else running statistics.  feat [M,F].
+ * kNN indices: arithmetic and tie rule pinned as for mpa_knn_exact below (index-exact against oracle/knn_ref.c).
+ * `ws` (mpa_dgcnn_workspace bytes, 256-byte aligned) carries everything backward needs and must stay untouched until
+ * then.  `events` (nullable): host array of 8 hipEvent_t, [2l] / [2l+1] recorded on `stream` right before / after the
+ * kNN kernels of stage l — lets a benchmark time them inside its timed region.
+ * backward (training mode): grad_feat [M,F] -> grad_conv_w[l], grad_bn_w[l], grad_bn_b[l] (host arrays of 5 device
+ * pointers), grad_fc_w, grad_fc_b (all overwritten) and, if non-NULL, grad_points [M,N,3] (through the edge features;
+ * the neighbour choice itself is not differentiable).  Deterministic: no cross-wave atomics on floats.
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_dgcnn_workspace(int64_t M, int64_t N, int64_t F, int64_t* bytes);
+int mpa_dgcnn_forward(const float* points, const float* valids, const float* const* conv_w,
+                      const float* const* bn_w, const float* const* bn_b, float* const* running_mean,
+                      float* const* running_var, const float* fc_w, const float* fc_b, int training, float momentum,
+                      float eps, int64_t M, int64_t N, int64_t F, void* ws, float* feat, void* const* events,
+                      void* stream);
+int mpa_dgcnn_backward(const float* grad_feat, const float* const* conv_w, const float* const* bn_w,
+                       const float* fc_w, int64_t M, int64_t N, int64_t F, void* ws, float* const* grad_conv_w,
+                       float* const* grad_bn_w, float* const* grad_bn_b, float* grad_fc_w, float* grad_fc_b,
+                       float* grad_points, void* stream);
+
+/* kNN graph with the pinned arithmetic, as used inside mpa_dgcnn_forward — replaces `knn`
+ * (multi_part_assembly/models/modules/encoder/dgcnn.py:8-15) for n clouds of N points (20 <= N <= 1024), k = 20.
+ * x [n*N, ld] row-major point features, the first C columns are used (C = 3: ld = 4 with a zero pad column; C = 64 /
+ * 128: any ld >= C, a multiple of 4).  idx [n*N, 20] int32, best first.
+ *   C = 3:    dot = fma(x2,y2, fma(x1,y1, x0*y0)), |x|^2 = (x0*x0 + x1*x1) + x2*x2 — the reference's CPU arithmetic,
+ *             bit for bit (torch matmul + torch.sum on the fixture cloud);
+ *   C >= 64:  dot = fmaf chain over k in the order 0, C/2, 1, C/2+1, ... (the matrix-core chain), |x|^2 likewise;
+ *   score = (-|x_j|^2 + 2 dot) - |x_i|^2, every operation rounded to fp32; neighbours = the 20 best by (score
+ *   descending, index ascending).  `ws`: n*N + 4 floats of scratch (a device-side header + the row norms). */
+int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, int64_t C, float* ws, int32_t* idx,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Part-relation transformer encoder — replaces
  *   TransformerEncoder.forward : multi_part_assembly/models/pn_transformer/transformer.py:63-79
  *   (nn.TransformerEncoder of pre-LN nn.TransformerEncoderLayer, ReLU FFN, batch_first,

@@ -50,6 +50,10 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_edge_aggregate_workspace": (_INT, [_I64, _I64, _I64, _I64, _P]),
     "mpa_edge_aggregate_forward": (_INT, [_P] * 6 + [_INT, _F32, _F32, _I64, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_edge_aggregate_backward": (_INT, [_P] * 4 + [_I64] * 4 + [_P] * 5),
+    "mpa_dgcnn_workspace": (_INT, [_I64, _I64, _I64, _P]),
+    "mpa_dgcnn_forward": (_INT, [_P] * 9 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "mpa_dgcnn_backward": (_INT, [_P] * 4 + [_I64, _I64, _I64] + [_P] * 8),
+    "mpa_knn_exact": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_transformer_workspace": (_INT, [_I64] * 6 + [_P]),
     "mpa_transformer_forward": (_INT, [_P, _P, _P] + [_I64] * 6 + [_F32, _U64, _P, _P, _P, _P]),
     "mpa_transformer_backward": (_INT, [_P, _P, _P] + [_I64] * 6 + [_F32, _U64, _P, _P, _P, _P, _P]),

@@ -1,0 +1,236 @@
+// Exact-fp32 matrix-core GEMMs over the point rows of the DGCNN encoder (gfx950, v_mfma_f32_32x32x2_f32).
+//
+// The reference's EdgeConv stages are 1x1 Conv2d over [n, 2C, N, k] edge tensors and a 1x1 Conv1d over the 512-wide
+// concatenation (multi_part_assembly/models/modules/encoder/dgcnn.py:57-71,76-100); here they are plain GEMMs over
+// R = (valid parts) x N point rows (csrc/dgcnn_enc.hip explains the algebra).  R is only known on the device (the
+// number of valid parts is counted there, no host sync), so every kernel takes `hdr` (hdr[1] = R) and is launched
+// for the worst case: tiles past R exit at once.
+//
+//   gemm_nt :  C[r, n] (+)= sum_k A[r, k] * W[n, k]        forward GEMMs and input gradients (W pre-transposed)
+//   gemm_tn :  P[chunk][n, k] = sum_{r in chunk} Y[r, n] * X[r, k]   weight gradients, fixed-order second stage
+//
+// Block = 256 threads (4 waves, 2 x 2), block tile 128 rows x BN columns, K walked in chunks of 32 through a
+// double-buffered LDS panel (global loads of chunk c+1 in flight during the MFMA chain of chunk c); a wave owns a
+// 64 x (BN/2) tile = 2 x (BN/64) accumulators of 32x32.  The MFMA K index is split as "lanes 0-31 take the first half
+// of the chunk, lanes 32-63 the second", so a lane's operand fragments are contiguous 16-float runs of an LDS row
+// (ds_read_b128, rows padded by 4 floats: conflict-free).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace dg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// MFMA 32x32 accumulator layout: lane l holds column (l & 31) and, in register r, row acc_row(r, l >> 5).
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+constexpr int kGT = 256;   // threads per GEMM block
+constexpr int kKC = 32;    // K chunk
+constexpr int kLD = kKC + 4;
+
+// ---- C[r, n] (+)= A[r, :] . W[n, :] -----------------------------------------------------------------------------------
+// A [R, K] row-major with leading dimension lda (a column slice of a wider buffer is fine), W [Nout, K] row-major,
+// C [R, Nout] with leading dimension ldc.  K % 32 == 0, Nout % BN == 0.  grid = (ceil(Rmax / 128), Nout / BN).
+template <int BN, bool ACCUM>
+__global__ __launch_bounds__(kGT, 2) void gemm_nt_kernel(const float* __restrict__ A, int lda,
+                                                         const float* __restrict__ W, int K,
+                                                         float* __restrict__ C, int ldc, const int* __restrict__ hdr) {
+  constexpr int BM = 128;
+  constexpr int WN = BN / 2;        // columns per wave
+  constexpr int TN = WN / 32;       // 32-wide column tiles per wave (1 or 2)
+  constexpr int A4 = BM * kKC / 4 / kGT;  // float4 per thread and chunk (A panel) = 4
+  constexpr int B4 = BN * kKC / 4 / kGT;  // (W panel) = 4 or 2
+  __shared__ __attribute__((aligned(16))) float As[2][BM * kLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * kLD];
+  const int R = hdr[1];
+  const long long r0 = (long long)blockIdx.x * BM;
+  if (r0 >= R) return;
+  const int n0 = blockIdx.y * BN;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;  // wave tile: rows wr*64.., columns wc*WN..
+  const int c4 = threadIdx.x & 7, rl = threadIdx.x >> 3;  // staging role: float4 column c4 of rows rl + 32 i
+  // staged operands as named registers (an indexed float4 array here ends up in scratch memory)
+  static_assert(A4 == 4 && (B4 == 4 || B4 == 2), "staging layout");
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2 = {}, rb3 = {};
+  const float* ap_[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    long long r = r0 + rl + 32 * i;  // rows past R: any valid row will do, their results are never stored
+    ap_[i] = A + (r < R ? r : (long long)R - 1) * lda + 4 * c4;
+  }
+  const float* wp_ = W + (long long)(n0 + rl) * K + 4 * c4;
+#define DG_NT_FETCH(kc)                                                        \
+  ra0 = *reinterpret_cast<const float4*>(ap_[0] + (kc));                       \
+  ra1 = *reinterpret_cast<const float4*>(ap_[1] + (kc));                       \
+  ra2 = *reinterpret_cast<const float4*>(ap_[2] + (kc));                       \
+  ra3 = *reinterpret_cast<const float4*>(ap_[3] + (kc));                       \
+  rb0 = *reinterpret_cast<const float4*>(wp_ + (kc));                          \
+  rb1 = *reinterpret_cast<const float4*>(wp_ + 32LL * K + (kc));               \
+  if constexpr (B4 == 4) {                                                     \
+    rb2 = *reinterpret_cast<const float4*>(wp_ + 64LL * K + (kc));             \
+    rb3 = *reinterpret_cast<const float4*>(wp_ + 96LL * K + (kc));             \
+  }
+#define DG_NT_STASH(buf)                                                       \
+  *reinterpret_cast<float4*>(&As[buf][(rl + 0) * kLD + 4 * c4]) = ra0;         \
+  *reinterpret_cast<float4*>(&As[buf][(rl + 32) * kLD + 4 * c4]) = ra1;        \
+  *reinterpret_cast<float4*>(&As[buf][(rl + 64) * kLD + 4 * c4]) = ra2;        \
+  *reinterpret_cast<float4*>(&As[buf][(rl + 96) * kLD + 4 * c4]) = ra3;        \
+  *reinterpret_cast<float4*>(&Bs[buf][(rl + 0) * kLD + 4 * c4]) = rb0;         \
+  *reinterpret_cast<float4*>(&Bs[buf][(rl + 32) * kLD + 4 * c4]) = rb1;        \
+  if constexpr (B4 == 4) {                                                     \
+    *reinterpret_cast<float4*>(&Bs[buf][(rl + 64) * kLD + 4 * c4]) = rb2;      \
+    *reinterpret_cast<float4*>(&Bs[buf][(rl + 96) * kLD + 4 * c4]) = rb3;      \
+  }
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x16{0};
+  DG_NT_FETCH(0)
+  const int chunks = K / kKC;
+  for (int c = 0; c < chunks; ++c) {
+    const int buf = c & 1;
+    DG_NT_STASH(buf)
+    __syncthreads();  // also orders the reuse of this buffer: its readers of two chunks ago passed the last barrier
+    if (c + 1 < chunks) {
+      DG_NT_FETCH((c + 1) * kKC)
+    }
+    const float* ap = &As[buf][(wr * 64 + j) * kLD + h * 16];
+    const float* bp = &Bs[buf][(wc * WN + j) * kLD + h * 16];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float4 fa[2], fb[TN];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const float4*>(ap + a * 32 * kLD + 4 * v);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const float4*>(bp + b * 32 * kLD + 4 * v);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long row = r0 + wr * 64 + a * 32 + acc_row(r, h);
+      if (row < R) {
+        float* dst = C + row * ldc + n0 + wc * WN + j;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          if constexpr (ACCUM) dst[32 * b] += acc[a][b][r];
+          else dst[32 * b] = acc[a][b][r];
+        }
+      }
+    }
+#undef DG_NT_FETCH
+#undef DG_NT_STASH
+}
+
+// ---- P[chunk][n, k] = sum over the chunk's rows of Y[r, n] * X[r, k] ----------------------------------------------------
+// Y [R, Nout] (ldy), X [R, K] (ldx).  Block tile 128 (n) x BK (k) outputs, the rows of chunk blockIdx.z in steps of
+// 32 through LDS; the MFMA reduction index is the row.  grid = (Nout / 128 rounded up, K / BK, row chunks);
+// part [chunks][Nout][K].  Chunks entirely past R write zeros (the second stage adds all chunks in order).
+template <int BK>
+__global__ __launch_bounds__(kGT, 2) void gemm_tn_kernel(const float* __restrict__ Y, int ldy, int Nout,
+                                                         const float* __restrict__ X, int ldx, int K,
+                                                         float* __restrict__ part, int rows_per_chunk,
+                                                         const int* __restrict__ hdr) {
+  constexpr int BNT = 128;
+  constexpr int RC = 32;            // rows per LDS step
+  constexpr int WK = BK / 2;        // k columns per wave
+  constexpr int TK = WK / 32;       // 1 or 2
+  constexpr int Y4 = RC * BNT / 4 / kGT;  // 4
+  constexpr int X4 = RC * BK / 4 / kGT;   // 2 or 4
+  __shared__ __attribute__((aligned(16))) float Ys[2][RC * BNT];
+  __shared__ __attribute__((aligned(16))) float Xs[2][RC * BK];
+  const int R = hdr[1];
+  const int n0 = blockIdx.x * BNT, k0 = blockIdx.y * BK;
+  const long long rb = (long long)blockIdx.z * rows_per_chunk;
+  long long re = rb + rows_per_chunk;
+  if (re > R) re = R;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int wn = wave >> 1, wk = wave & 1;  // wave tile: n rows wn*64.., k columns wk*WK..
+  float4 ry[Y4], rx[X4];
+  auto fetch = [&](long long r) {
+#pragma unroll
+    for (int i = 0; i < Y4; ++i) {
+      const int e = threadIdx.x + i * kGT, row = e / (BNT / 4), c4 = e % (BNT / 4);
+      const bool ok = r + row < re && n0 + 4 * c4 < Nout;  // clamped address + select: no conditional load
+      const float4 t = *reinterpret_cast<const float4*>(Y + (ok ? (r + row) * ldy + n0 + 4 * c4 : 0));
+      ry[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < X4; ++i) {
+      const int e = threadIdx.x + i * kGT, row = e / (BK / 4), c4 = e % (BK / 4);
+      const bool ok = r + row < re;
+      const float4 t = *reinterpret_cast<const float4*>(X + (ok ? (r + row) * ldx + k0 + 4 * c4 : 0));
+      rx[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < Y4; ++i) reinterpret_cast<float4*>(Ys[buf])[threadIdx.x + i * kGT] = ry[i];
+#pragma unroll
+    for (int i = 0; i < X4; ++i) reinterpret_cast<float4*>(Xs[buf])[threadIdx.x + i * kGT] = rx[i];
+  };
+  f32x16 acc[2][TK];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < TK; ++b) acc[a][b] = f32x16{0};
+  if (rb < re) {
+    fetch(rb);
+    int it = 0;
+    for (long long r = rb; r < re; r += RC, ++it) {
+      const int buf = it & 1;
+      stash(buf);
+      __syncthreads();
+      if (r + RC < re) fetch(r + RC);
+      const float* yp = &Ys[buf][h * BNT + wn * 64 + j];
+      const float* xp = &Xs[buf][h * BK + wk * WK + j];
+#pragma unroll
+      for (int s = 0; s < RC / 2; ++s) {  // MFMA step s reduces rows 2s (lanes 0-31) and 2s+1 (lanes 32-63)
+        float fy[2], fx[TK];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fy[a] = yp[2 * s * BNT + 32 * a];
+#pragma unroll
+        for (int b = 0; b < TK; ++b) fx[b] = xp[2 * s * BK + 32 * b];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < TK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fy[a], fx[b], acc[a][b], 0, 0, 0);
+      }
+    }
+  }
+  float* out = part + (long long)blockIdx.z * Nout * K;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * 64 + a * 32 + acc_row(r, h);
+      if (n < Nout) {
+#pragma unroll
+        for (int b = 0; b < TK; ++b) out[(long long)n * K + k0 + wk * WK + 32 * b + j] = acc[a][b][r];
+      }
+    }
+}
+
+// second stage of the weight gradient: out[e] = sum_chunk part[chunk][e] in chunk order (deterministic)
+__global__ void gemm_tn_reduce_kernel(const float* __restrict__ part, int chunks, long long elems,
+                                      float* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= elems) return;
+  float s = 0.0f;
+  for (int c = 0; c < chunks; ++c) s += part[(long long)c * elems + e];
+  out[e] = s;
+}
+
+}  // namespace dg

@@ -44,9 +44,15 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ x, i
   float xq[CP];
 #pragma unroll
   for (int c = 0; c < CP; ++c) xq[c] = c < C ? xp[(long long)qi * C + c] : 0.0f;
+  // |x|^2: C = 3 follows the reference's CPU arithmetic (torch.sum(x**2): rounded squares added in order, no FMA —
+  // bit-equal to torch on the fixture cloud, see csrc/dg_knn.h); wider features use the fmaf chain of the dot product
   float nq = 0.0f;
+  if constexpr (C == 3) {
+    nq = (xq[0] * xq[0] + xq[1] * xq[1]) + xq[2] * xq[2];
+  } else {
 #pragma unroll
-  for (int c = 0; c < C; ++c) nq = __builtin_fmaf(xq[c], xq[c], nq);
+    for (int c = 0; c < C; ++c) nq = __builtin_fmaf(xq[c], xq[c], nq);
+  }
   float bs[K];
   int bj[K];
 #pragma unroll
@@ -63,8 +69,13 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ x, i
     __syncthreads();
     if (threadIdx.x < kTile) {
       float s = 0.0f;
+      const float* tr = tile[threadIdx.x];
+      if constexpr (C == 3) {
+        s = (tr[0] * tr[0] + tr[1] * tr[1]) + tr[2] * tr[2];
+      } else {
 #pragma unroll
-      for (int c = 0; c < C; ++c) s = __builtin_fmaf(tile[threadIdx.x][c], tile[threadIdx.x][c], s);
+        for (int c = 0; c < C; ++c) s = __builtin_fmaf(tr[c], tr[c], s);
+      }
       tnorm[threadIdx.x] = s;
     }
     __syncthreads();
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ x, i
         int cj = j0 + r;
 #pragma unroll
         for (int t = 0; t < K; ++t) {
-          const bool g = cs > bs[t];
+          const bool g = s > bs[t];  // the NEW score against every slot: everything behind the insertion point shifts
           const float ts = bs[t];
           const int tj = bj[t];
           bs[t] = g ? cs : ts;

@@ -1,0 +1,1059 @@
+// DGCNN part encoder — whole forward and backward (training-mode BatchNorm) as hand-written gfx950 kernels.
+//
+// Replaces the torch module of the reference (multi_part_assembly/models/modules/encoder/dgcnn.py:41-109):
+//   4 x [kNN graph (k = 20) in feature space -> edge features [x_j - x_i ; x_i] -> Conv2d 1x1 -> BatchNorm2d ->
+//        LeakyReLU(0.2) -> max over the k neighbours]   widths 3-64-64-128-256
+//   concat 512 -> Conv1d 1x1 -> BatchNorm1d -> LeakyReLU(0.2) -> [max ; mean] over the N points -> Linear(2F -> F)
+// and the valid-part compaction around it (models/dgl/network.py:90-99): the kernels take ALL part slots plus the
+// validity mask, count and compact the valid parts on the device (no host sync) and write zeros for padded slots.
+//
+// The reference materialises per stage an [n, N, N] score matrix, the gathered neighbours and the [n, 2C, N, 20] edge
+// tensor (13 GB at C = 128, n = 640).  None of them exists here:
+//   * kNN: Gram tiles on the matrix cores, top-20 kept in registers (dg_knn.h; index-exact, arithmetic pinned);
+//   * the 1x1 convolution is linear in the edge feature:  W [x_j - x_i ; x_i] = Wa x_j + (Wb - Wa) x_i = U_j + V_i, so
+//     ONE exact-fp32 MFMA GEMM per POINT (X -> [U | V], dg_gemm.h) replaces the GEMM per EDGE (20x fewer FLOPs);
+//   * BatchNorm + LeakyReLU is a monotone per-channel map whose direction is the sign of gamma, so
+//     max_j act(bn(U_j + V_i)) = act(bn(ext_j U_j + V_i)) with ext = max (gamma >= 0) or min: the aggregation kernel
+//     keeps a 32-channel slice of the part's U in LDS (128 KB), gathers the 20 neighbour rows from there (LDS, not
+//     L2), and leaves the selected edge value, its slot, the neighbour sum (for backward) and the BatchNorm sums
+//     sum(e), sum(e^2) over all 20 edges — computed from sum_j U_j, sum_j U_j^2 and V_i without forming the edges.
+// Backward: BatchNorm backward is the affine map  de = alpha*dz + gammap*e + betap  with dz nonzero only on the selected
+// edge of every (point, channel):
+//   dV_i = alpha dz_i + gammap (sum_j U_j + k V_i) + k betap                      (neighbour sum saved by forward)
+//   dU_j = gammap (deg_j U_j + sum_{i: j in nn(i)} V_i) + deg_j betap  +  sum_{i: sel_i = j} alpha dz_i
+// The middle sum is gathered over the TRANSPOSED kNN graph from an LDS-resident slice of V; the last one is scattered
+// into an LDS accumulator by ONE wave per channel group in ascending point order (LDS executes a wave's operations in
+// order), so the whole backward is free of cross-wave atomics and bit-reproducible.
+#include "common.h"
+#include "coop_reduce.h"
+#include "dg_gemm.h"
+#include "dg_knn.h"
+
+namespace {
+
+using namespace dg;
+using mpa::CoopWs;
+using mpa::coop_colsum;
+using mpa::kEB;
+using mpa::kSlices;
+
+constexpr int kCat = 512;                     // 64 + 64 + 128 + 256
+constexpr int kCinP[4] = {4, 64, 64, 128};    // input width of stage l (3 padded to 4)
+constexpr int kCin[4] = {3, 64, 64, 128};
+constexpr int kCO[4] = {64, 64, 128, 256};
+constexpr int kOff[4] = {0, 64, 128, 256};    // column of stage l's output inside the concatenation
+constexpr int kTile = 128;                    // rows per block of the row-tiled elementwise kernels
+constexpr int kTnChunks = 128;                // row chunks of the weight-gradient GEMMs
+constexpr float kSlope = 0.2f;
+
+// ---- bookkeeping --------------------------------------------------------------------------------------------------------
+// hdr[0] = number of valid parts nv, hdr[1] = nv * N; vlist[v] = part slot of the v-th valid part; rank[m] = v or -1.
+__global__ void dg_prepare_kernel(const float* __restrict__ valids, int M, int N, int* __restrict__ hdr,
+                                  int* __restrict__ vlist, int* __restrict__ rank, unsigned* __restrict__ tickets,
+                                  int ntickets) {
+  const int lane = threadIdx.x;
+  int base = 0;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    const int m = m0 + lane;
+    const bool flag = m < M && valids[m] != 0.0f;
+    const unsigned long long mask = __ballot(flag);
+    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+    if (flag) {
+      vlist[pos] = m;
+      rank[m] = pos;
+    } else if (m < M) {
+      rank[m] = -1;
+    }
+    base += __popcll(mask);
+  }
+  if (lane == 0) {
+    hdr[0] = base;
+    hdr[1] = base * N;
+  }
+  for (int t = lane; t < ntickets; t += 64) tickets[t] = 0u;
+}
+
+__global__ void dg_gather_points_kernel(const float* __restrict__ points, const int* __restrict__ vlist, int N,
+                                        float4* __restrict__ x0, const int* __restrict__ hdr) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= hdr[1]) return;
+  const int v = (int)(r / N), p = (int)(r % N);
+  const float* s = points + ((long long)vlist[v] * N + p) * 3;
+  x0[r] = make_float4(s[0], s[1], s[2], 0.0f);
+}
+
+// conv weight w [CO][2C] -> stacked ws [2CO][CP] = [Wa ; Wb - Wa] (U = X Wa^T, V = X (Wb - Wa)^T) and its
+// transpose wst [CP][2CO] (operand of the input-gradient GEMM); CP = C padded (3 -> 4).
+__global__ void dg_wstack_kernel(const float* __restrict__ w, int CO, int C, int CP, float* __restrict__ ws,
+                                 float* __restrict__ wst) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * CO * CP) return;
+  const int o = e / CP, c = e % CP;
+  float val = 0.0f;
+  if (c < C) val = o < CO ? w[o * 2 * C + c] : w[(o - CO) * 2 * C + C + c] - w[(o - CO) * 2 * C + c];
+  ws[e] = val;
+  wst[c * 2 * CO + o] = val;
+}
+
+__global__ void dg_transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * cols) return;
+  wt[(e % cols) * rows + e / cols] = w[e];
+}
+
+// d(conv weight) from d(stacked weight) ds [2CO][CP]:  dWa = dS_top - dS_bottom, dWb = dS_bottom
+__global__ void dg_wunstack_kernel(const float* __restrict__ ds, int CO, int C, int CP, float* __restrict__ dw) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= CO * 2 * C) return;
+  const int o = e / (2 * C), c = e % (2 * C);
+  dw[e] = c < C ? ds[o * CP + c] - ds[(CO + o) * CP + c] : ds[(CO + o) * CP + (c - C)];
+}
+
+// ---- first stage: K = 3 is far too thin for a matrix core ------------------------------------------------------------------
+// uv [R][128] = x0 [R][4] . ws [128][4]^T; thread = (row, 4 outputs).  grid = ceil(Rmax / 8), block 256.
+__global__ __launch_bounds__(256) void dg_first_uv_kernel(const float4* __restrict__ x0, const float* __restrict__ ws,
+                                                          float* __restrict__ uv, const int* __restrict__ hdr) {
+  const long long r = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (r >= hdr[1]) return;
+  const int o4 = threadIdx.x & 31;
+  const float4 x = x0[r];
+  float out[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float4 w = reinterpret_cast<const float4*>(ws)[4 * o4 + u];
+    out[u] = (x.x * w.x + x.y * w.y) + x.z * w.z;
+  }
+  reinterpret_cast<float4*>(uv + r * 128)[o4] = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// d(ws1) partials: part [tiles][128][4] = sum over the tile's rows of duv[r][o] * x0[r][k].  grid = tiles of 1024 rows,
+// block 512 = 4 row groups x 128 outputs, groups merged in fixed order.
+constexpr int kFirstTile = 1024;
+__global__ __launch_bounds__(512) void dg_first_wgrad_kernel(const float* __restrict__ duv, const float4* __restrict__ x0,
+                                                             float* __restrict__ part, const int* __restrict__ hdr) {
+  __shared__ float4 red[4][128];
+  const int R = hdr[1];
+  const int g = threadIdx.x >> 7, o = threadIdx.x & 127;
+  const long long r0 = (long long)blockIdx.x * kFirstTile + g * (kFirstTile / 4);
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+  for (int i = 0; i < kFirstTile / 4 && r0 + i < R; ++i) {
+    const float4 x = x0[r0 + i];
+    const float gv = duv[(r0 + i) * 128 + o];
+    a0 = __builtin_fmaf(gv, x.x, a0);
+    a1 = __builtin_fmaf(gv, x.y, a1);
+    a2 = __builtin_fmaf(gv, x.z, a2);
+  }
+  red[g][o] = make_float4(a0, a1, a2, 0.0f);
+  __syncthreads();
+  if (g == 0) {
+    float4 t = red[0][o];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      t.x += red[k][o].x;
+      t.y += red[k][o].y;
+      t.z += red[k][o].z;
+    }
+    reinterpret_cast<float4*>(part)[(long long)blockIdx.x * 128 + o] = t;
+  }
+}
+
+// optional gradient w.r.t. the input points: gp [M][N][3] (pre-zeroed), rows of valid parts only
+__global__ void dg_first_dgrad_kernel(const float* __restrict__ duv, const float* __restrict__ ws,
+                                      const int* __restrict__ vlist, int N, float* __restrict__ gp,
+                                      const int* __restrict__ hdr) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= hdr[1]) return;
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+  for (int o = 0; o < 128; ++o) {
+    const float g = duv[r * 128 + o];
+    a0 = __builtin_fmaf(g, ws[4 * o], a0);
+    a1 = __builtin_fmaf(g, ws[4 * o + 1], a1);
+    a2 = __builtin_fmaf(g, ws[4 * o + 2], a2);
+  }
+  const int v = (int)(r / N), p = (int)(r % N);
+  float* d = gp + ((long long)vlist[v] * N + p) * 3;
+  d[0] = a0;
+  d[1] = a1;
+  d[2] = a2;
+}
+
+// ---- edge aggregation, forward ------------------------------------------------------------------------------------------------
+// grid = (CO / 32, M parts), block 512.  LDS: the part's U slice [N][32].  Lane = (point slot q = lane / 16, channel
+// pair cp = lane % 16): a wave gathers for 4 points at once with ds_read_b64, 8 waves -> 32 points per pass.
+constexpr int kAT = 512;
+
+__global__ __launch_bounds__(kAT) void dg_agg_fwd_kernel(const float* __restrict__ uv, int CO,
+                                                         const unsigned short* __restrict__ idx,
+                                                         const float* __restrict__ gamma, int N,
+                                                         float* __restrict__ esel, unsigned char* __restrict__ ssel,
+                                                         float* __restrict__ s1out, float* __restrict__ partial,
+                                                         const int* __restrict__ hdr) {
+  __shared__ __attribute__((aligned(16))) float Us[kMaxN * 32];
+  __shared__ float red[32][16][4];
+  const int v = blockIdx.y;
+  if (v >= hdr[0]) return;
+  const int c0 = blockIdx.x * 32;
+  const float* up = uv + (long long)v * N * 2 * CO;
+  for (int e = threadIdx.x; e < N * 8; e += kAT) {
+    const int row = e >> 3, c4 = e & 7;
+    *reinterpret_cast<float4*>(&Us[row * 32 + 4 * c4]) =
+        *reinterpret_cast<const float4*>(up + (long long)row * 2 * CO + c0 + 4 * c4);
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cp = lane & 15, q = lane >> 4;
+  const float gx = gamma[c0 + 2 * cp] < 0.0f ? -1.0f : 1.0f, gy = gamma[c0 + 2 * cp + 1] < 0.0f ? -1.0f : 1.0f;
+  float a1x = 0.0f, a1y = 0.0f, a2x = 0.0f, a2y = 0.0f;
+  // the neighbour list (5 x 8 bytes) and V of the NEXT point are requested before the current point's 20 LDS gathers:
+  // without that every pass of the loop is one exposed L2 round trip
+  unsigned wv[10], wn[10];
+  float2 vv, vn = make_float2(0.0f, 0.0f);
+  auto request = [&](int i, unsigned (&w)[10], float2& vout) {
+    const int ic = i < N ? i : N - 1;
+    const uint2* ip = reinterpret_cast<const uint2*>(idx + ((long long)v * N + ic) * kNbr);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const uint2 t = ip[u];
+      w[2 * u] = t.x;
+      w[2 * u + 1] = t.y;
+    }
+    vout = *reinterpret_cast<const float2*>(up + (long long)ic * 2 * CO + CO + c0 + 2 * cp);
+  };
+  request(wave * 4 + q, wn, vn);
+  for (int i = wave * 4 + q; i < N; i += 32) {
+    const long long row = (long long)v * N + i;
+#pragma unroll
+    for (int u = 0; u < 10; ++u) wv[u] = wn[u];
+    vv = vn;
+    request(i + 32, wn, vn);
+    float bx = -__builtin_inff(), by = -__builtin_inff(), sux = 0.0f, suy = 0.0f, sqx = 0.0f, sqy = 0.0f;
+    int ax = 0, ay = 0;
+#pragma unroll
+    for (int t = 0; t < kNbr; ++t) {
+      const int j = (wv[t >> 1] >> (16 * (t & 1))) & 0xffff;
+      const float2 u = *reinterpret_cast<const float2*>(&Us[j * 32 + 2 * cp]);
+      const float sx = gx * u.x, sy = gy * u.y;
+      if (sx > bx) {
+        bx = sx;
+        ax = t;
+      }
+      if (sy > by) {
+        by = sy;
+        ay = t;
+      }
+      sux += u.x;
+      suy += u.y;
+      sqx = __builtin_fmaf(u.x, u.x, sqx);
+      sqy = __builtin_fmaf(u.y, u.y, sqy);
+    }
+    const long long o = row * CO + c0 + 2 * cp;
+    *reinterpret_cast<float2*>(esel + o) = make_float2(gx * bx + vv.x, gy * by + vv.y);
+    *reinterpret_cast<uchar2*>(ssel + o) = make_uchar2((unsigned char)ax, (unsigned char)ay);
+    *reinterpret_cast<float2*>(s1out + o) = make_float2(sux, suy);
+    // BatchNorm sums over the 20 edges e = U_j + V_i:  sum e = S + k V,  sum e^2 = Q + 2 V S + k V^2
+    a1x += sux + (float)kNbr * vv.x;
+    a1y += suy + (float)kNbr * vv.y;
+    a2x += sqx + 2.0f * vv.x * sux + (float)kNbr * vv.x * vv.x;
+    a2y += sqy + 2.0f * vv.y * suy + (float)kNbr * vv.y * vv.y;
+  }
+  red[wave * 4 + q][cp][0] = a1x;
+  red[wave * 4 + q][cp][1] = a1y;
+  red[wave * 4 + q][cp][2] = a2x;
+  red[wave * 4 + q][cp][3] = a2y;
+  __syncthreads();
+  if (threadIdx.x < 32) {  // thread = channel of the slice; the 32 point slots in fixed order
+    const int c = threadIdx.x;
+    float s = 0.0f, ss = 0.0f;
+    for (int k = 0; k < 32; ++k) {
+      s += red[k][c >> 1][c & 1];
+      ss += red[k][c >> 1][2 + (c & 1)];
+    }
+    float* d = partial + ((long long)v * CO + c0 + c) * 2;
+    d[0] = s;
+    d[1] = ss;
+  }
+}
+
+// ---- BatchNorm statistics from a partial table [rows][C][2] -> bn [4][C] (scale, shift, mean, invstd) ------------------------
+// rows_are_parts != 0: table row e belongs to valid part e (valid iff e < nv); else to the row tile e (valid iff
+// e * kTile < nv * N).  count = nv * N * kmul.  grid = (C / 64, ceil(rows / kEB)), block 1024.
+__device__ __forceinline__ int dg_valid_rows(const int* hdr, int rows_are_parts) {
+  return rows_are_parts ? hdr[0] : (hdr[1] + kTile - 1) / kTile;
+}
+
+__global__ __launch_bounds__(64 * kSlices) void dg_bn_finalize_kernel(
+    const float* __restrict__ partial, int rows, int C, int rows_are_parts, int kmul, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+    float eps, float* __restrict__ bn, const CoopWs cw, const int* __restrict__ hdr) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int vrows = dg_valid_rows(hdr, rows_are_parts);
+  double s, ss;
+  const bool last = coop_colsum(rows, C, c, cw,
+                                [&](int e, bool& ok, double& x, double& y) {
+                                  ok = e < vrows;
+                                  const float2 t = ok ? *reinterpret_cast<const float2*>(partial + ((long long)e * C + c) * 2)
+                                                      : make_float2(0.0f, 0.0f);
+                                  x = (double)t.x;
+                                  y = (double)t.y;
+                                },
+                                s, ss);
+  if (!last || threadIdx.x >= 64) return;
+  const double count = (double)hdr[1] * (double)kmul;
+  const double mean = count > 0.0 ? s / count : 0.0;
+  double var = count > 0.0 ? ss / count - mean * mean : 0.0;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / __builtin_sqrt(var + (double)eps));
+  const float scale = gamma[c] * invstd;
+  bn[c] = scale;
+  bn[C + c] = beta[c] - (float)mean * scale;
+  bn[2 * C + c] = (float)mean;
+  bn[3 * C + c] = invstd;
+  if (running_mean != nullptr && count > 0.0) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void dg_bn_from_running_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                          float eps, float* __restrict__ bn) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / __builtin_sqrtf(running_var[c] + eps);
+  const float scale = gamma[c] * invstd;
+  bn[c] = scale;
+  bn[C + c] = beta[c] - running_mean[c] * scale;
+  bn[2 * C + c] = running_mean[c];
+  bn[3 * C + c] = invstd;
+}
+
+// backward coefficients coef [3][C] (alpha, gammap, betap) of  dY = alpha*dZ + gammap*Y + betap  from the two column
+// sums (sum dz, sum dz*xhat), and dgamma / dbeta.  Same table conventions as dg_bn_finalize_kernel.
+__global__ __launch_bounds__(64 * kSlices) void dg_bwd_coef_kernel(
+    const float* __restrict__ partial, int rows, int C, int kmul, const float* __restrict__ gamma,
+    const float* __restrict__ bn, float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    const CoopWs cw, const int* __restrict__ hdr) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int vrows = dg_valid_rows(hdr, 0);
+  double s1, s2;
+  const bool last = coop_colsum(rows, C, c, cw,
+                                [&](int e, bool& ok, double& x, double& y) {
+                                  ok = e < vrows;
+                                  const float2 t = ok ? *reinterpret_cast<const float2*>(partial + ((long long)e * C + c) * 2)
+                                                      : make_float2(0.0f, 0.0f);
+                                  x = (double)t.x;
+                                  y = (double)t.y;
+                                },
+                                s1, s2);
+  if (!last || threadIdx.x >= 64) return;
+  const double count = (double)hdr[1] * (double)kmul;
+  const float mean = bn[2 * C + c], invstd = bn[3 * C + c];
+  const float alpha = gamma[c] * invstd;
+  const float gammap = count > 0.0 ? (float)(-(double)alpha * s2 / count * (double)invstd) : 0.0f;
+  coef[c] = alpha;
+  coef[C + c] = gammap;
+  coef[2 * C + c] = count > 0.0 ? (float)(-(double)alpha * s1 / count - (double)gammap * (double)mean) : 0.0f;
+  dgamma[c] = (float)s2;
+  dbeta[c] = (float)s1;
+}
+
+// H[r][off + c] = LeakyReLU(bn(esel[r][c]));  one thread per float4.
+__global__ void dg_apply_kernel(const float* __restrict__ esel, int CO, const float* __restrict__ bn,
+                                float* __restrict__ hcat, int off, const int* __restrict__ hdr) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q4 = CO / 4;
+  const long long r = e / q4;
+  if (r >= hdr[1]) return;
+  const int c = 4 * (int)(e % q4);
+  const float4 x = *reinterpret_cast<const float4*>(esel + r * CO + c);
+  const float4 sc = *reinterpret_cast<const float4*>(bn + c), sh = *reinterpret_cast<const float4*>(bn + CO + c);
+  float4 z = make_float4(__builtin_fmaf(x.x, sc.x, sh.x), __builtin_fmaf(x.y, sc.y, sh.y),
+                         __builtin_fmaf(x.z, sc.z, sh.z), __builtin_fmaf(x.w, sc.w, sh.w));
+  z.x = z.x > 0.0f ? z.x : kSlope * z.x;
+  z.y = z.y > 0.0f ? z.y : kSlope * z.y;
+  z.z = z.z > 0.0f ? z.z : kSlope * z.z;
+  z.w = z.w > 0.0f ? z.w : kSlope * z.w;
+  *reinterpret_cast<float4*>(hcat + r * kCat + off + c) = z;
+}
+
+// ---- tail: column statistics of y5, pooling, linear ----------------------------------------------------------------------------
+// partial [tiles][F][2] = (sum y, sum y^2) over the tile's rows.  grid = ceil(Rmax / kTile), block = F.
+__global__ void dg_colstats_kernel(const float* __restrict__ y, int F, float* __restrict__ partial,
+                                   const int* __restrict__ hdr) {
+  const int R = hdr[1];
+  const long long r0 = (long long)blockIdx.x * kTile;
+  if (r0 >= R) return;
+  const int c = threadIdx.x;
+  float s = 0.0f, ss = 0.0f;
+  const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
+  for (int i = 0; i < rows; ++i) {
+    const float t = y[(r0 + i) * F + c];
+    s += t;
+    ss = __builtin_fmaf(t, t, ss);
+  }
+  float* d = partial + ((long long)blockIdx.x * F + c) * 2;
+  d[0] = s;
+  d[1] = ss;
+}
+
+// pooled [nv][2F] = [max_n a ; mean_n a] with a = LeakyReLU(bn(y)); arg [nv][F] = row of the (first) maximum.
+// grid = M parts, block 1024 = (1024 / F) row groups x F channels; groups merged in fixed order.
+__global__ __launch_bounds__(1024) void dg_pool_kernel(const float* __restrict__ y, int F, int N,
+                                                      const float* __restrict__ bn, float* __restrict__ pooled,
+                                                      int* __restrict__ arg, const int* __restrict__ hdr) {
+  __shared__ float smax[1024], ssum[1024];
+  __shared__ int sarg[1024];
+  const int v = blockIdx.x;
+  if (v >= hdr[0]) return;
+  const int G = 1024 / F, g = threadIdx.x / F, c = threadIdx.x % F;
+  const float scale = bn[c], shift = bn[F + c];
+  const float* yp = y + (long long)v * N * F;
+  float best = -__builtin_inff(), sum = 0.0f;
+  int at = 0;
+  for (int n = g; n < N; n += G) {
+    const float z = __builtin_fmaf(yp[(long long)n * F + c], scale, shift);
+    const float a = z > 0.0f ? z : kSlope * z;
+    sum += a;
+    if (a > best) {
+      best = a;
+      at = n;
+    }
+  }
+  smax[threadIdx.x] = best;
+  ssum[threadIdx.x] = sum;
+  sarg[threadIdx.x] = at;
+  __syncthreads();
+  if (g == 0) {
+    for (int k = 1; k < G; ++k) {
+      const float b2 = smax[k * F + c];
+      const int a2 = sarg[k * F + c];
+      if (b2 > best || (b2 == best && a2 < at)) {
+        best = b2;
+        at = a2;
+      }
+      sum += ssum[k * F + c];
+    }
+    pooled[(long long)v * 2 * F + c] = best;
+    pooled[(long long)v * 2 * F + F + c] = sum / (float)N;
+    arg[(long long)v * F + c] = at;
+  }
+}
+
+// feat [M][F] = pooled[rank[m]] . W^T + b (zeros for padded parts).  grid = M, block = F.
+__global__ void dg_fc_kernel(const float* __restrict__ pooled, const int* __restrict__ rank, int F,
+                             const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ feat) {
+  __shared__ float row[512];
+  const int m = blockIdx.x, f = threadIdx.x, v = rank[m];
+  if (v < 0) {
+    feat[(long long)m * F + f] = 0.0f;
+    return;
+  }
+  for (int k = f; k < 2 * F; k += F) row[k] = pooled[(long long)v * 2 * F + k];
+  __syncthreads();
+  float acc = 0.0f;
+  const float4* wr = reinterpret_cast<const float4*>(w + (long long)f * 2 * F);
+  for (int k4 = 0; k4 < F / 2; ++k4) {
+    const float4 t = wr[k4];
+    acc = __builtin_fmaf(row[4 * k4], t.x, acc);
+    acc = __builtin_fmaf(row[4 * k4 + 1], t.y, acc);
+    acc = __builtin_fmaf(row[4 * k4 + 2], t.z, acc);
+    acc = __builtin_fmaf(row[4 * k4 + 3], t.w, acc);
+  }
+  feat[(long long)m * F + f] = acc + b[f];
+}
+
+// dpooled [nv][2F] = gfeat[vlist[v]] . W.  grid = M (v < nv), block = 2F.
+__global__ void dg_fc_bwd_in_kernel(const float* __restrict__ gfeat, const int* __restrict__ vlist, int F,
+                                    const float* __restrict__ w, float* __restrict__ dpooled,
+                                    const int* __restrict__ hdr) {
+  __shared__ float g[256];
+  const int v = blockIdx.x;
+  if (v >= hdr[0]) return;
+  const int k = threadIdx.x;
+  if (k < F) g[k] = gfeat[(long long)vlist[v] * F + k];
+  __syncthreads();
+  float acc = 0.0f;
+  for (int f = 0; f < F; ++f) acc = __builtin_fmaf(g[f], w[(long long)f * 2 * F + k], acc);
+  dpooled[(long long)v * 2 * F + k] = acc;
+}
+
+// dW [F][2F], db [F]: block f, 1024 threads = (1024 / 2F) part groups x 2F columns; groups merged in fixed order.
+__global__ __launch_bounds__(1024) void dg_fc_bwd_w_kernel(const float* __restrict__ gfeat, const int* __restrict__ vlist,
+                                                           int F, const float* __restrict__ pooled,
+                                                           float* __restrict__ dw, float* __restrict__ db,
+                                                           const int* __restrict__ hdr) {
+  __shared__ float red[1024], redb[8];
+  const int f = blockIdx.x, W = 2 * F, G = 1024 / W, g = threadIdx.x / W, k = threadIdx.x % W, nv = hdr[0];
+  float acc = 0.0f, sb = 0.0f;
+  for (int v = g; v < nv; v += G) {
+    const float gv = gfeat[(long long)vlist[v] * F + f];
+    acc = __builtin_fmaf(gv, pooled[(long long)v * W + k], acc);
+    sb += gv;
+  }
+  red[threadIdx.x] = acc;
+  if (k == 0) redb[g] = sb;
+  __syncthreads();
+  if (g == 0) {
+    for (int q = 1; q < G; ++q) acc += red[q * W + k];
+    dw[(long long)f * W + k] = acc;
+    if (k == 0) {
+      for (int q = 1; q < G; ++q) sb += redb[q];
+      db[f] = sb;
+    }
+  }
+}
+
+// gradient reaching a = LeakyReLU(bn(y5)) from the pooling: dmean / N everywhere + dmax at the arg-max row
+__device__ __forceinline__ float dg_tail_dz(float y, float scale, float shift, float dmax, float dmean_n, bool is_arg) {
+  const float z = __builtin_fmaf(y, scale, shift);
+  return (z > 0.0f ? 1.0f : kSlope) * (dmean_n + (is_arg ? dmax : 0.0f));
+}
+
+// partial [tiles][F][2] = (sum dz, sum dz*xhat).  grid = ceil(Rmax / kTile), block = F.
+__global__ void dg_tail_bwd_sums_kernel(const float* __restrict__ y, int F, int N, const float* __restrict__ bn,
+                                        const float* __restrict__ dpooled, const int* __restrict__ arg,
+                                        float* __restrict__ partial, const int* __restrict__ hdr) {
+  const int R = hdr[1];
+  const long long r0 = (long long)blockIdx.x * kTile;
+  if (r0 >= R) return;
+  const int c = threadIdx.x;
+  const float scale = bn[c], shift = bn[F + c], mean = bn[2 * F + c], invstd = bn[3 * F + c];
+  const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int i = 0; i < rows; ++i) {
+    const long long r = r0 + i;
+    const int v = (int)(r / N), p = (int)(r % N);
+    const float t = y[r * F + c];
+    const float dz = dg_tail_dz(t, scale, shift, dpooled[(long long)v * 2 * F + c],
+                                dpooled[(long long)v * 2 * F + F + c] / (float)N, arg[(long long)v * F + c] == p);
+    s1 += dz;
+    s2 = __builtin_fmaf(dz, (t - mean) * invstd, s2);
+  }
+  float* d = partial + ((long long)blockIdx.x * F + c) * 2;
+  d[0] = s1;
+  d[1] = s2;
+}
+
+// y5 <- dY5 = alpha*dz + gammap*y + betap, in place.  grid = ceil(Rmax / kTile), block = F.
+__global__ void dg_tail_bwd_apply_kernel(float* __restrict__ y, int F, int N, const float* __restrict__ bn,
+                                         const float* __restrict__ coef, const float* __restrict__ dpooled,
+                                         const int* __restrict__ arg, const int* __restrict__ hdr) {
+  const int R = hdr[1];
+  const long long r0 = (long long)blockIdx.x * kTile;
+  if (r0 >= R) return;
+  const int c = threadIdx.x;
+  const float scale = bn[c], shift = bn[F + c];
+  const float alpha = coef[c], gammap = coef[F + c], betap = coef[2 * F + c];
+  const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
+  for (int i = 0; i < rows; ++i) {
+    const long long r = r0 + i;
+    const int v = (int)(r / N), p = (int)(r % N);
+    const float t = y[r * F + c];
+    const float dz = dg_tail_dz(t, scale, shift, dpooled[(long long)v * 2 * F + c],
+                                dpooled[(long long)v * 2 * F + F + c] / (float)N, arg[(long long)v * F + c] == p);
+    y[r * F + c] = __builtin_fmaf(alpha, dz, __builtin_fmaf(gammap, t, betap));
+  }
+}
+
+// ---- edge aggregation, backward ----------------------------------------------------------------------------------------------
+// dz = dH * LeakyReLU'(z) (z > 0 <=> H > 0), the two BatchNorm-backward sums over the selected edges, and the target
+// point of every (point, channel)'s selected edge: jsel = idx[row][ssel].  grid = ceil(Rmax / kTile), block = CO.
+__global__ void dg_agg_bwd_sums_kernel(const float* __restrict__ hcat, const float* __restrict__ dhcat, int off, int CO,
+                                       const float* __restrict__ esel, const unsigned char* __restrict__ ssel,
+                                       const unsigned short* __restrict__ idx, const float* __restrict__ bn,
+                                       float* __restrict__ dz, unsigned short* __restrict__ jsel,
+                                       float* __restrict__ partial, const int* __restrict__ hdr) {
+  const int R = hdr[1];
+  const long long r0 = (long long)blockIdx.x * kTile;
+  if (r0 >= R) return;
+  const int c = threadIdx.x;
+  const float mean = bn[2 * CO + c], invstd = bn[3 * CO + c];
+  const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int i = 0; i < rows; ++i) {
+    const long long r = r0 + i, o = r * CO + c;
+    const float h = hcat[r * kCat + off + c];
+    const float d = dhcat[r * kCat + off + c] * (h > 0.0f ? 1.0f : kSlope);
+    dz[o] = d;
+    jsel[o] = idx[r * kNbr + ssel[o]];
+    s1 += d;
+    s2 = __builtin_fmaf(d, (esel[o] - mean) * invstd, s2);
+  }
+  float* p = partial + ((long long)blockIdx.x * CO + c) * 2;
+  p[0] = s1;
+  p[1] = s2;
+}
+
+// Transposed kNN graph of every part: rptr [M][N + 1], rlist [R][20] = source points of the in-edges of every point,
+// ascending (fixed summation order downstream).  grid = M parts, block 1024.
+__global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* __restrict__ idx, int N,
+                                                          int* __restrict__ rptr, unsigned short* __restrict__ rlist,
+                                                          const int* __restrict__ hdr) {
+  __shared__ int cnt[kMaxN];
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int v = blockIdx.x;
+  if (v >= hdr[0]) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int E = N * kNbr;
+  const unsigned short* id = idx + (long long)v * E;
+  int* rp = rptr + (long long)v * (N + 1);
+  unsigned short* rl = rlist + (long long)v * E;
+  for (int j = t; j < N; j += 1024) cnt[j] = 0;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int e = t; e < E; e += 1024) atomicAdd(&cnt[id[e]], 1);  // integer counts: order-independent
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {  // exclusive prefix sum, 1024 rows at a time
+    const int j = base + t, val = j < N ? cnt[j] : 0;
+    int inc = val;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (j < N) {
+      rp[j] = before + inc - val;
+      cnt[j] = before + inc - val;  // becomes the row's fill cursor
+    }
+    __syncthreads();
+    if (t == 1023) carry = before + inc;
+    __syncthreads();
+  }
+  if (t == 0) rp[N] = carry;
+  for (int e = t; e < E; e += 1024) {
+    const int pos = atomicAdd(&cnt[id[e]], 1);
+    rl[pos] = (unsigned short)(e / kNbr);
+  }
+  __syncthreads();
+  for (int j = t; j < N; j += 1024) {  // ascending order inside every row
+    const int b = rp[j], e = cnt[j];
+    for (int a = b + 1; a < e; ++a) {
+      const unsigned short key = rl[a];
+      int q = a - 1;
+      while (q >= b && rl[q] > key) {
+        rl[q + 1] = rl[q];
+        --q;
+      }
+      rl[q + 1] = key;
+    }
+  }
+}
+
+// d(uv) [R][2CO].  grid = (CO / 32, M), block 512; LDS buffer [N][32]: first the part's V slice (gather over the
+// in-edges), then the accumulator of the selected-edge scatter.
+__global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict__ uv, int CO,
+                                                         const int* __restrict__ rptr,
+                                                         const unsigned short* __restrict__ rlist,
+                                                         const float* __restrict__ dz,
+                                                         const unsigned short* __restrict__ jsel,
+                                                         const float* __restrict__ s1in, const float* __restrict__ coef,
+                                                         int N, float* __restrict__ guv, const int* __restrict__ hdr) {
+  __shared__ __attribute__((aligned(16))) float buf[kMaxN * 32];
+  __shared__ int rps[kMaxN + 1];
+  const int v = blockIdx.y;
+  if (v >= hdr[0]) return;
+  const int c0 = blockIdx.x * 32;
+  const float* up = uv + (long long)v * N * 2 * CO;
+  float* gp = guv + (long long)v * N * 2 * CO;
+  for (int e = threadIdx.x; e < N * 8; e += kAT) {
+    const int row = e >> 3, c4 = e & 7;
+    *reinterpret_cast<float4*>(&buf[row * 32 + 4 * c4]) =
+        *reinterpret_cast<const float4*>(up + (long long)row * 2 * CO + CO + c0 + 4 * c4);
+  }
+  for (int e = threadIdx.x; e <= N; e += kAT) rps[e] = rptr[(long long)v * (N + 1) + e];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cp = lane & 15, q = lane >> 4;
+  const float2 alpha = *reinterpret_cast<const float2*>(coef + c0 + 2 * cp);
+  const float2 gammap = *reinterpret_cast<const float2*>(coef + CO + c0 + 2 * cp);
+  const float2 betap = *reinterpret_cast<const float2*>(coef + 2 * CO + c0 + 2 * cp);
+  const unsigned short* rl = rlist + (long long)v * N * kNbr;
+  {
+    // In-edge lists: the first kHead sources of the NEXT point are requested (as independent loads, the offsets come
+    // from LDS) before the current point's LDS gathers; only hubs with more in-edges than that pay a further round trip.
+    constexpr int kHead = 24;
+    unsigned short cur[kHead], nxt[kHead];
+    const int last = N * kNbr - 1;
+    auto request = [&](int b, unsigned short (&w)[kHead]) {
+#pragma unroll
+      for (int u = 0; u < kHead; ++u) w[u] = rl[b + u < last ? b + u : last];
+    };
+    int j = wave * 4 + q;
+    int b = j < N ? rps[j] : 0, e = j < N ? rps[j + 1] : 0;
+    request(b, nxt);
+    for (; j < N; j += 32) {
+#pragma unroll
+      for (int u = 0; u < kHead; ++u) cur[u] = nxt[u];
+      const int jn = j + 32;
+      const int bn = jn < N ? rps[jn] : 0, en = jn < N ? rps[jn + 1] : 0;
+      request(bn, nxt);
+      const long long row = (long long)v * N + j, o = row * CO + c0 + 2 * cp;
+      const float2 u = *reinterpret_cast<const float2*>(up + (long long)j * 2 * CO + c0 + 2 * cp);
+      const float2 d = *reinterpret_cast<const float2*>(dz + o);
+      const float2 s1 = *reinterpret_cast<const float2*>(s1in + o);
+      float svx = 0.0f, svy = 0.0f;
+#pragma unroll
+      for (int k = 0; k < kHead; ++k) {  // ascending sources: fixed summation order
+        const float2 t = *reinterpret_cast<const float2*>(&buf[(int)cur[k] * 32 + 2 * cp]);
+        const bool ok = b + k < e;
+        svx += ok ? t.x : 0.0f;
+        svy += ok ? t.y : 0.0f;
+      }
+      for (int a = b + kHead; a < e; ++a) {
+        const float2 t = *reinterpret_cast<const float2*>(&buf[(int)rl[a] * 32 + 2 * cp]);
+        svx += t.x;
+        svy += t.y;
+      }
+      const float deg = (float)(e - b);
+      const float2 vv = *reinterpret_cast<const float2*>(&buf[j * 32 + 2 * cp]);
+      float2 du, dv;
+      du.x = __builtin_fmaf(gammap.x, __builtin_fmaf(deg, u.x, svx), deg * betap.x);
+      du.y = __builtin_fmaf(gammap.y, __builtin_fmaf(deg, u.y, svy), deg * betap.y);
+      dv.x = __builtin_fmaf(alpha.x, d.x, __builtin_fmaf(gammap.x, s1.x + (float)kNbr * vv.x, (float)kNbr * betap.x));
+      dv.y = __builtin_fmaf(alpha.y, d.y, __builtin_fmaf(gammap.y, s1.y + (float)kNbr * vv.y, (float)kNbr * betap.y));
+      *reinterpret_cast<float2*>(gp + (long long)j * 2 * CO + c0 + 2 * cp) = du;
+      *reinterpret_cast<float2*>(gp + (long long)j * 2 * CO + CO + c0 + 2 * cp) = dv;
+      b = bn;
+      e = en;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * 8; e += kAT) *reinterpret_cast<float4*>(&buf[4 * e]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  {
+    // selected-edge scatter: wave w owns channels 4w .. 4w+3 of the slice; lane = (point slot pt, channel ch); the 16
+    // point slots of a pass are applied one after the other, so every (target, channel) sees its addends in ascending
+    // source order — LDS executes one wave's operations in program order.  The next pass's operands are requested
+    // before the current pass's adds.
+    const int pt = lane >> 2, ch = lane & 3, c = c0 + 4 * wave + ch;
+    const float al = coef[c];
+    auto request = [&](int i, float& val, int& tgt) {
+      const int ic = i < N ? i : N - 1;
+      const long long o = ((long long)v * N + ic) * CO + c;
+      val = al * dz[o];
+      tgt = jsel[o];
+    };
+    float vn;
+    int tn;
+    request(pt, vn, tn);
+    for (int i0 = 0; i0 < N; i0 += 16) {
+      const int i = i0 + pt;
+      const float val = vn;
+      const int tgt = tn;
+      request(i + 16, vn, tn);
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        // hardware ds_add_f32 (no compare-and-swap loop): one wave owns the address, so this is an ordered RMW
+        if (pt == p && i < N) unsafeAtomicAdd(&buf[tgt * 32 + 4 * wave + ch], val);
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * 8; e += kAT) {
+    const int row = e >> 3, c4 = e & 7;
+    float4* d = reinterpret_cast<float4*>(gp + (long long)row * 2 * CO + c0 + 4 * c4);
+    const float4 a = *reinterpret_cast<const float4*>(&buf[4 * e]);
+    float4 t = *d;
+    t.x += a.x;
+    t.y += a.y;
+    t.z += a.z;
+    t.w += a.w;
+    *d = t;
+  }
+}
+
+// ---- workspace ----------------------------------------------------------------------------------------------------------------
+struct Ws {
+  int *hdr, *vlist, *rank, *arg5, *rptr;
+  unsigned* tickets;
+  float4* x0;
+  float *hcat, *uv[4], *esel[4], *s1[4], *y5, *norm, *bn[5], *coef, *partial, *wstk[4], *wstt[4], *w5t, *pooled,
+      *dpooled, *tnpart, *dhcat, *duv, *dz, *gstk;
+  unsigned short *idx[4], *jsel, *rlist;
+  unsigned char* ssel[4];
+  double* stage;
+  int64_t total;
+};
+
+Ws dg_carve(char* base, int64_t M, int64_t N, int64_t F) {
+  Ws w;
+  char* p = base;
+  auto take = [&](int64_t bytes) {
+    char* r = p;
+    p += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  const int64_t R = M * N, tiles = (R + kTile - 1) / kTile;
+  w.hdr = reinterpret_cast<int*>(take(64));
+  w.vlist = reinterpret_cast<int*>(take(4 * M));
+  w.rank = reinterpret_cast<int*>(take(4 * M));
+  w.tickets = reinterpret_cast<unsigned*>(take(64));
+  w.x0 = reinterpret_cast<float4*>(take(16 * R));
+  w.hcat = reinterpret_cast<float*>(take(4 * R * kCat));
+  for (int l = 0; l < 4; ++l) {
+    w.uv[l] = reinterpret_cast<float*>(take(4 * R * 2 * kCO[l]));
+    w.esel[l] = reinterpret_cast<float*>(take(4 * R * kCO[l]));
+    w.s1[l] = reinterpret_cast<float*>(take(4 * R * kCO[l]));
+    w.ssel[l] = reinterpret_cast<unsigned char*>(take(R * kCO[l]));
+    w.idx[l] = reinterpret_cast<unsigned short*>(take(2 * R * kNbr));
+    w.bn[l] = reinterpret_cast<float*>(take(4 * 4 * kCO[l]));
+    w.wstk[l] = reinterpret_cast<float*>(take(4 * 2 * kCO[l] * kCinP[l]));
+    w.wstt[l] = reinterpret_cast<float*>(take(4 * 2 * kCO[l] * kCinP[l]));
+  }
+  w.y5 = reinterpret_cast<float*>(take(4 * R * F));
+  w.norm = reinterpret_cast<float*>(take(4 * R));
+  w.bn[4] = reinterpret_cast<float*>(take(4 * 4 * F));
+  w.coef = reinterpret_cast<float*>(take(4 * 3 * kCat));
+  const int64_t prow = tiles > M ? tiles : M;  // partial table rows: row tiles or parts
+  w.partial = reinterpret_cast<float*>(take(4 * prow * kCat * 2));
+  w.w5t = reinterpret_cast<float*>(take(4 * kCat * F));
+  w.pooled = reinterpret_cast<float*>(take(4 * M * 2 * F));
+  w.dpooled = reinterpret_cast<float*>(take(4 * M * 2 * F));
+  w.arg5 = reinterpret_cast<int*>(take(4 * M * F));
+  int64_t tn = (int64_t)kTnChunks * kCat * 128;  // largest weight gradient: 512 x 128 (or F x 512)
+  if ((int64_t)kTnChunks * F * kCat > tn) tn = (int64_t)kTnChunks * F * kCat;
+  const int64_t first = ((R + kFirstTile - 1) / kFirstTile) * 128 * 4;  // first-stage weight-gradient partials
+  if (first > tn) tn = first;
+  w.tnpart = reinterpret_cast<float*>(take(4 * tn));
+  w.dhcat = reinterpret_cast<float*>(take(4 * R * kCat));
+  w.duv = reinterpret_cast<float*>(take(4 * R * 2 * kCO[3]));
+  w.dz = reinterpret_cast<float*>(take(4 * R * kCO[3]));
+  w.jsel = reinterpret_cast<unsigned short*>(take(2 * R * kCO[3]));
+  w.gstk = reinterpret_cast<float*>(take(4 * kCat * 128));
+  w.rptr = reinterpret_cast<int*>(take(4 * M * (N + 1)));
+  w.rlist = reinterpret_cast<unsigned short*>(take(2 * R * kNbr));
+  w.stage = reinterpret_cast<double*>(take(8 * 2 * kCat * ((prow + kEB - 1) / kEB)));
+  w.total = p - base;
+  return w;
+}
+
+int dg_check(int64_t M, int64_t N, int64_t F, const char* who) {
+  MPA_REQUIRE(M >= 0 && M <= 65535, "%s: 0 <= parts <= 65535", who);
+  MPA_REQUIRE(N >= kNbr && N <= kMaxN, "%s: %d <= points per part <= %d", who, kNbr, kMaxN);
+  MPA_REQUIRE(F == 64 || F == 128 || F == 256, "%s: feat_dim must be 64, 128 or 256", who);
+  return MPA_OK;
+}
+
+template <typename Kern, typename... Args>
+void launch(Kern kern, dim3 grid, dim3 block, hipStream_t s, Args... args) {
+  hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
+}
+
+// C (+)= A . W^T on the matrix cores (see dg_gemm.h); Nout a multiple of 64
+void gemm_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, int Nout, bool accum, int64_t Rmax,
+             const int* hdr, hipStream_t s) {
+  const unsigned gx = (unsigned)((Rmax + 127) / 128);
+  if (Nout % 128 == 0) {
+    if (accum) launch(gemm_nt_kernel<128, true>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+    else launch(gemm_nt_kernel<128, false>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+  } else {
+    if (accum) launch(gemm_nt_kernel<64, true>, dim3(gx, Nout / 64), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+    else launch(gemm_nt_kernel<64, false>, dim3(gx, Nout / 64), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+  }
+}
+
+// out [Nout][K] = Y^T . X over the valid rows (two deterministic stages); K a multiple of 64
+void gemm_tn(const float* Y, int ldy, int Nout, const float* X, int ldx, int K, float* part, float* out, int64_t Rmax,
+             const int* hdr, hipStream_t s) {
+  const int rows_per_chunk = (int)(((Rmax + kTnChunks - 1) / kTnChunks + 31) / 32 * 32);
+  const dim3 grid((unsigned)((Nout + 127) / 128), (unsigned)(K % 128 == 0 ? K / 128 : K / 64), kTnChunks);
+  if (K % 128 == 0) launch(gemm_tn_kernel<128>, grid, dim3(kGT), s, Y, ldy, Nout, X, ldx, K, part, rows_per_chunk, hdr);
+  else launch(gemm_tn_kernel<64>, grid, dim3(kGT), s, Y, ldy, Nout, X, ldx, K, part, rows_per_chunk, hdr);
+  const long long elems = (long long)Nout * K;
+  launch(gemm_tn_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), s, (const float*)part, kTnChunks, elems,
+         out);
+}
+
+void record(void* const* events, int i, hipStream_t s) {
+  if (events != nullptr && events[i] != nullptr) hipEventRecord(static_cast<hipEvent_t>(events[i]), s);
+}
+
+}  // namespace
+
+extern "C" int mpa_dgcnn_workspace(int64_t M, int64_t N, int64_t F, int64_t* bytes) {
+  if (int st = dg_check(M, N, F, "dgcnn_workspace")) return st;
+  MPA_REQUIRE(bytes != nullptr, "dgcnn_workspace: null pointer");
+  *bytes = dg_carve(nullptr, M, N, F).total;
+  return MPA_OK;
+}
+
+extern "C" int mpa_dgcnn_forward(const float* points, const float* valids, const float* const* conv_w,
+                                 const float* const* bn_w, const float* const* bn_b, float* const* running_mean,
+                                 float* const* running_var, const float* fc_w, const float* fc_b, int training,
+                                 float momentum, float eps, int64_t M, int64_t N, int64_t F, void* ws, float* feat,
+                                 void* const* events, void* stream) {
+  if (int st = dg_check(M, N, F, "dgcnn_forward")) return st;
+  if (M == 0) return MPA_OK;
+  MPA_REQUIRE(points && valids && conv_w && bn_w && bn_b && running_mean && running_var && fc_w && fc_b && ws && feat,
+              "dgcnn_forward: null pointer");
+  MPA_REQUIRE((uintptr_t)ws % 256 == 0, "dgcnn_forward: workspace must be 256-byte aligned");
+  hipStream_t s = mpa::as_stream(stream);
+  const Ws w = dg_carve(static_cast<char*>(ws), M, N, F);
+  const int64_t R = M * N, tiles = (R + kTile - 1) / kTile;
+  const CoopWs cw{w.stage, w.tickets};
+  launch(dg_prepare_kernel, dim3(1), dim3(64), s, valids, (int)M, (int)N, w.hdr, w.vlist, w.rank, w.tickets, 16);
+  launch(dg_gather_points_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), s, points, (const int*)w.vlist, (int)N,
+         w.x0, (const int*)w.hdr);
+  for (int l = 0; l < 4; ++l) {
+    const int CO = kCO[l], C = kCin[l], CP = kCinP[l];
+    launch(dg_wstack_kernel, dim3((unsigned)((2 * CO * CP + 255) / 256)), dim3(256), s, conv_w[l], CO, C, CP, w.wstk[l],
+           w.wstt[l]);
+    // kNN graph in the stage's input space
+    record(events, 2 * l, s);
+    if (l == 0) {
+      launch(knn3_kernel<unsigned short>, dim3((unsigned)((N + 255) / 256), (unsigned)M), dim3(256), s,
+             reinterpret_cast<const float*>(w.x0), (int)N, w.idx[0], (const int*)w.hdr);
+    } else {
+      const float* x = w.hcat + kOff[l - 1];
+      const dim3 g((unsigned)((N + 127) / 128), (unsigned)M);
+      if (C == 64) {
+        launch(rownorm_kernel<64>, dim3((unsigned)((R + 255) / 256)), dim3(256), s, x, kCat, w.norm, (const int*)w.hdr);
+        launch(knn_mfma_kernel<64, unsigned short>, g, dim3(256), s, x, kCat, (const float*)w.norm, (int)N, w.idx[l],
+               (const int*)w.hdr);
+      } else {
+        launch(rownorm_kernel<128>, dim3((unsigned)((R + 255) / 256)), dim3(256), s, x, kCat, w.norm, (const int*)w.hdr);
+        launch(knn_mfma_kernel<128, unsigned short>, g, dim3(256), s, x, kCat, (const float*)w.norm, (int)N, w.idx[l],
+               (const int*)w.hdr);
+      }
+    }
+    record(events, 2 * l + 1, s);
+    // [U | V] = X . [Wa ; Wb - Wa]^T
+    if (l == 0) {
+      launch(dg_first_uv_kernel, dim3((unsigned)((R + 7) / 8)), dim3(256), s, (const float4*)w.x0,
+             (const float*)w.wstk[0], w.uv[0], (const int*)w.hdr);
+    } else {
+      gemm_nt(w.hcat + kOff[l - 1], kCat, w.wstk[l], C, w.uv[l], 2 * CO, 2 * CO, false, R, w.hdr, s);
+    }
+    launch(dg_agg_fwd_kernel, dim3((unsigned)(CO / 32), (unsigned)M), dim3(kAT), s, (const float*)w.uv[l], CO,
+           (const unsigned short*)w.idx[l], bn_w[l], (int)N, w.esel[l], w.ssel[l], w.s1[l], w.partial,
+           (const int*)w.hdr);
+    if (training) {
+      launch(dg_bn_finalize_kernel, dim3((unsigned)(CO / 64), (unsigned)((M + kEB - 1) / kEB)), dim3(64 * kSlices), s,
+             (const float*)w.partial, (int)M, CO, 1, kNbr, bn_w[l], bn_b[l], running_mean[l], running_var[l], momentum,
+             eps, w.bn[l], cw, (const int*)w.hdr);
+    } else {
+      launch(dg_bn_from_running_kernel, dim3((unsigned)(CO / 64)), dim3(64), s, CO, bn_w[l], bn_b[l],
+             (const float*)running_mean[l], (const float*)running_var[l], eps, w.bn[l]);
+    }
+    launch(dg_apply_kernel, dim3((unsigned)((R * (CO / 4) + 255) / 256)), dim3(256), s, (const float*)w.esel[l], CO,
+           (const float*)w.bn[l], w.hcat, kOff[l], (const int*)w.hdr);
+  }
+  // tail: 512 -> F convolution, BatchNorm1d, LeakyReLU, [max ; mean] over the points, Linear
+  gemm_nt(w.hcat, kCat, conv_w[4], kCat, w.y5, (int)F, (int)F, false, R, w.hdr, s);
+  if (training) {
+    launch(dg_colstats_kernel, dim3((unsigned)tiles), dim3((unsigned)F), s, (const float*)w.y5, (int)F, w.partial,
+           (const int*)w.hdr);
+    launch(dg_bn_finalize_kernel, dim3((unsigned)(F / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
+           (const float*)w.partial, (int)tiles, (int)F, 0, 1, bn_w[4], bn_b[4], running_mean[4], running_var[4], momentum,
+           eps, w.bn[4], cw, (const int*)w.hdr);
+  } else {
+    launch(dg_bn_from_running_kernel, dim3((unsigned)(F / 64)), dim3(64), s, (int)F, bn_w[4], bn_b[4],
+           (const float*)running_mean[4], (const float*)running_var[4], eps, w.bn[4]);
+  }
+  launch(dg_pool_kernel, dim3((unsigned)M), dim3(1024), s, (const float*)w.y5, (int)F, (int)N, (const float*)w.bn[4],
+         w.pooled, w.arg5, (const int*)w.hdr);
+  launch(dg_fc_kernel, dim3((unsigned)M), dim3((unsigned)F), s, (const float*)w.pooled, (const int*)w.rank, (int)F, fc_w,
+         fc_b, feat);
+  return mpa::check_launch("dgcnn_forward");
+}
+
+extern "C" int mpa_dgcnn_backward(const float* grad_feat, const float* const* conv_w, const float* const* bn_w,
+                                  const float* fc_w, int64_t M, int64_t N, int64_t F, void* ws,
+                                  float* const* grad_conv_w, float* const* grad_bn_w, float* const* grad_bn_b,
+                                  float* grad_fc_w, float* grad_fc_b, float* grad_points, void* stream) {
+  if (int st = dg_check(M, N, F, "dgcnn_backward")) return st;
+  if (M == 0) return MPA_OK;
+  MPA_REQUIRE(grad_feat && conv_w && bn_w && fc_w && ws && grad_conv_w && grad_bn_w && grad_bn_b && grad_fc_w &&
+                  grad_fc_b,
+              "dgcnn_backward: null pointer");
+  hipStream_t s = mpa::as_stream(stream);
+  const Ws w = dg_carve(static_cast<char*>(ws), M, N, F);
+  const int64_t R = M * N, tiles = (R + kTile - 1) / kTile;
+  const CoopWs cw{w.stage, w.tickets};
+  const int* hdr = w.hdr;
+  // Linear and pooling
+  launch(dg_fc_bwd_in_kernel, dim3((unsigned)M), dim3((unsigned)(2 * F)), s, grad_feat, (const int*)w.vlist, (int)F,
+         fc_w, w.dpooled, hdr);
+  launch(dg_fc_bwd_w_kernel, dim3((unsigned)F), dim3(1024), s, grad_feat, (const int*)w.vlist, (int)F,
+         (const float*)w.pooled, grad_fc_w, grad_fc_b, hdr);
+  // BatchNorm1d backward of the tail; y5 becomes dY5
+  launch(dg_tail_bwd_sums_kernel, dim3((unsigned)tiles), dim3((unsigned)F), s, (const float*)w.y5, (int)F, (int)N,
+         (const float*)w.bn[4], (const float*)w.dpooled, (const int*)w.arg5, w.partial, hdr);
+  launch(dg_bwd_coef_kernel, dim3((unsigned)(F / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
+         (const float*)w.partial, (int)tiles, (int)F, 1, bn_w[4], (const float*)w.bn[4], w.coef, grad_bn_w[4],
+         grad_bn_b[4], cw, hdr);
+  launch(dg_tail_bwd_apply_kernel, dim3((unsigned)tiles), dim3((unsigned)F), s, w.y5, (int)F, (int)N,
+         (const float*)w.bn[4], (const float*)w.coef, (const float*)w.dpooled, (const int*)w.arg5, hdr);
+  gemm_tn(w.y5, (int)F, (int)F, w.hcat, kCat, kCat, w.tnpart, grad_conv_w[4], R, hdr, s);
+  launch(dg_transpose_kernel, dim3((unsigned)((F * kCat + 255) / 256)), dim3(256), s, conv_w[4], (int)F, kCat, w.w5t);
+  gemm_nt(w.y5, (int)F, w.w5t, (int)F, w.dhcat, kCat, kCat, false, R, hdr, s);
+  if (grad_points != nullptr) mpa::zero_words_async(grad_points, M * N * 3, s);
+  for (int l = 3; l >= 0; --l) {
+    const int CO = kCO[l], C = kCin[l], CP = kCinP[l];
+    launch(dg_agg_bwd_sums_kernel, dim3((unsigned)tiles), dim3((unsigned)CO), s, (const float*)w.hcat,
+           (const float*)w.dhcat, kOff[l], CO, (const float*)w.esel[l], (const unsigned char*)w.ssel[l],
+           (const unsigned short*)w.idx[l], (const float*)w.bn[l], w.dz, w.jsel, w.partial, hdr);
+    launch(dg_bwd_coef_kernel, dim3((unsigned)(CO / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
+           (const float*)w.partial, (int)tiles, CO, kNbr, bn_w[l], (const float*)w.bn[l], w.coef, grad_bn_w[l],
+           grad_bn_b[l], cw, hdr);
+    launch(dg_reverse_kernel, dim3((unsigned)M), dim3(1024), s, (const unsigned short*)w.idx[l], (int)N, w.rptr, w.rlist,
+           hdr);
+    launch(dg_agg_bwd_kernel, dim3((unsigned)(CO / 32), (unsigned)M), dim3(kAT), s, (const float*)w.uv[l], CO,
+           (const int*)w.rptr, (const unsigned short*)w.rlist, (const float*)w.dz, (const unsigned short*)w.jsel,
+           (const float*)w.s1[l], (const float*)w.coef, (int)N, w.duv, hdr);
+    if (l == 0) {
+      const int t1 = (int)((R + kFirstTile - 1) / kFirstTile);
+      launch(dg_first_wgrad_kernel, dim3((unsigned)t1), dim3(512), s, (const float*)w.duv, (const float4*)w.x0, w.tnpart,
+             hdr);
+      launch(gemm_tn_reduce_kernel, dim3(2), dim3(256), s, (const float*)w.tnpart, t1, (long long)(128 * 4), w.gstk);
+      if (grad_points != nullptr)
+        launch(dg_first_dgrad_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), s, (const float*)w.duv,
+               (const float*)w.wstk[0], (const int*)w.vlist, (int)N, grad_points, hdr);
+    } else {
+      gemm_tn(w.duv, 2 * CO, 2 * CO, w.hcat + kOff[l - 1], kCat, C, w.tnpart, w.gstk, R, hdr, s);
+      gemm_nt(w.duv, 2 * CO, w.wstt[l], 2 * CO, w.dhcat + kOff[l - 1], kCat, C, true, R, hdr, s);
+    }
+    launch(dg_wunstack_kernel, dim3((unsigned)((CO * 2 * C + 255) / 256)), dim3(256), s, (const float*)w.gstk, CO, C, CP,
+           grad_conv_w[l]);
+  }
+  return mpa::check_launch("dgcnn_backward");
+}
+
+namespace {
+__global__ void dg_set_hdr_kernel(int* hdr, int n, int N) {
+  hdr[0] = n;
+  hdr[1] = n * N;
+}
+}  // namespace
+
+extern "C" int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, int64_t C, float* ws, int32_t* idx,
+                             void* stream) {
+  MPA_REQUIRE(n >= 0 && n <= 65535 && N >= kNbr && N <= kMaxN, "knn_exact: %d <= N <= %d, n <= 65535", kNbr, kMaxN);
+  MPA_REQUIRE(C == 3 || C == 64 || C == 128, "knn_exact: feature width must be 3, 64 or 128");
+  MPA_REQUIRE(ld % 4 == 0 && ld >= (C == 3 ? 4 : C), "knn_exact: bad leading dimension");
+  MPA_REQUIRE(C != 3 || ld == 4, "knn_exact: C = 3 takes [n*N, 4] rows (x, y, z, 0)");
+  if (n == 0) return MPA_OK;
+  MPA_REQUIRE(x && idx && ws, "knn_exact: null pointer");
+  hipStream_t s = mpa::as_stream(stream);
+  int* hdr = reinterpret_cast<int*>(ws);  // {n, n*N}: every cloud is valid here
+  float* norm = ws + 4;
+  const int64_t R = n * N;
+  launch(dg_set_hdr_kernel, dim3(1), dim3(1), s, hdr, (int)n, (int)N);
+  if (C == 3) {
+    launch(knn3_kernel<int>, dim3((unsigned)((N + 255) / 256), (unsigned)n), dim3(256), s, x, (int)N, idx,
+           (const int*)hdr);
+  } else if (C == 64) {
+    launch(rownorm_kernel<64>, dim3((unsigned)((R + 255) / 256)), dim3(256), s, x, (int)ld, norm, (const int*)hdr);
+    launch(knn_mfma_kernel<64, int>, dim3((unsigned)((N + 127) / 128), (unsigned)n), dim3(256), s, x, (int)ld,
+           (const float*)norm, (int)N, idx, (const int*)hdr);
+  } else {
+    launch(rownorm_kernel<128>, dim3((unsigned)((R + 255) / 256)), dim3(256), s, x, (int)ld, norm, (const int*)hdr);
+    launch(knn_mfma_kernel<128, int>, dim3((unsigned)((N + 127) / 128), (unsigned)n), dim3(256), s, x, (int)ld,
+           (const float*)norm, (int)N, idx, (const int*)hdr);
+  }
+  return mpa::check_launch("knn_exact");
+}

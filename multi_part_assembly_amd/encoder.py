@@ -117,6 +117,19 @@ class PointNet(nn.Module):
         return self.forward_parts(x, torch.ones(x.shape[0], device=x.device))
 
 
+def knn_exact(x, n, N, C=None):
+    """Index-exact kNN graph (mpa_knn_exact, csrc/dg_knn.h): x [n*N, ld] row-major (C = 3: ld = 4, zero pad column)
+    -> int32 [n*N, 20], best first, (score descending, index ascending)."""
+    R, ld = x.shape
+    C = (3 if ld == 4 else ld) if C is None else C
+    idx = torch.empty((R, 20), dtype=torch.int32, device=x.device)
+    ws = torch.empty(R + 4, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = _lib.lib().mpa_knn_exact(_lib.ptr(x), ld, n, N, C, _lib.ptr(ws), _lib.ptr(idx), _lib.current_stream(x.device))
+    _lib.check(st, "mpa_knn_exact")
+    return idx
+
+
 def knn_indices(x, n, N, k=20):
     """x [n*N, C] point-major features -> int32 [n*N, k] neighbour indices inside each cloud (csrc/dgcnn.hip)."""
     R, C = x.shape
@@ -173,14 +186,80 @@ class _EdgeAggFn(torch.autograd.Function):
         return (guv, None, ggamma, gbeta, None, None, None, None, None, None)
 
 
+class _DGCNNFn(torch.autograd.Function):
+    """Whole DGCNN encoder forward/backward on the HIP library (csrc/dgcnn_enc.hip)."""
+
+    @staticmethod
+    def forward(ctx, points, valids, training, momentum, eps, running, want_point_grad, *params):
+        conv_w, bn_w, bn_b, fc_w, fc_b = params[0:5], params[5:10], params[10:15], params[15], params[16]
+        run_mean, run_var = running
+        M, N, _ = points.shape
+        F_ = fc_w.shape[0]
+        dev = points.device
+        L = _lib.lib()
+        nbytes = ctypes.c_int64()
+        _lib.check(L.mpa_dgcnn_workspace(M, N, F_, ctypes.byref(nbytes)), "mpa_dgcnn_workspace")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        feat = torch.empty((M, F_), dtype=torch.float32, device=dev)
+        pts = points.detach()
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"dgcnn_forward[{M}x{N}x{F_}]")
+            evs = _lib.KernelTimer.phase_events(8)
+            ev_arr = None if evs is None else (ctypes.c_void_p * 8)(*[e.cuda_event for e in evs])
+            st = L.mpa_dgcnn_forward(
+                _lib.ptr(pts), _lib.ptr(valids), _lib.ptr_array(conv_w), _lib.ptr_array(bn_w), _lib.ptr_array(bn_b),
+                _lib.ptr_array(run_mean), _lib.ptr_array(run_var), _lib.ptr(fc_w), _lib.ptr(fc_b), int(training),
+                float(momentum), float(eps), M, N, F_, _lib.ptr(ws), _lib.ptr(feat), ev_arr, _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+            if evs is not None:
+                for l, C in enumerate((3, 64, 64, 128)):
+                    _lib.KernelTimer.add_phases([f"dgcnn_knn[{M}x{N} stage {l + 1} C={C}]"], evs[2 * l:2 * l + 2])
+        _lib.check(st, "mpa_dgcnn_forward")
+        ctx.training = bool(training)
+        ctx.want_point_grad = bool(want_point_grad)
+        ctx.params = params
+        ctx.save_for_backward(pts, ws)
+        return feat
+
+    @staticmethod
+    def backward(ctx, grad_feat):
+        if not ctx.training:
+            raise RuntimeError("DGCNN: backward is implemented for training-mode BatchNorm only")
+        pts, ws = ctx.saved_tensors
+        params = ctx.params
+        conv_w, bn_w, fc_w = params[0:5], params[5:10], params[15]
+        M, N, _ = pts.shape
+        F_ = fc_w.shape[0]
+        dev = pts.device
+        grads = [torch.empty_like(p) for p in params]
+        gpts = torch.empty_like(pts) if ctx.want_point_grad else None
+        grad_feat = grad_feat.contiguous()
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"dgcnn_backward[{M}x{N}x{F_}]")
+            st = _lib.lib().mpa_dgcnn_backward(
+                _lib.ptr(grad_feat), _lib.ptr_array(conv_w), _lib.ptr_array(bn_w), _lib.ptr(fc_w), M, N, F_,
+                _lib.ptr(ws), _lib.ptr_array(grads[0:5]), _lib.ptr_array(grads[5:10]), _lib.ptr_array(grads[10:15]),
+                _lib.ptr(grads[15]), _lib.ptr(grads[16]), _lib.ptr(gpts), _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_dgcnn_backward")
+        return (gpts, None, None, None, None, None, None, *grads)
+
+
 class DGCNN(nn.Module):
     """4 EdgeConv stages (k=20, widths 64-64-128-256, LeakyReLU 0.2, max over k), concat 512 ->
     1x1 conv -> [max ; mean] over N -> Linear.
 
-    The sub-modules hold the parameters under the reference's names; the computation is point-major and never
-    builds an edge tensor: per stage one kNN kernel, ONE library GEMM per point (X -> [U | V], the 1x1 convolution
-    being linear in the edge feature) and the fused gather + BatchNorm2d + LeakyReLU + max kernels of csrc/dgcnn.hip.
-    The tail (512 -> F convolution, BatchNorm1d, pooling, Linear) is plain library ops."""
+    The sub-modules hold the parameters under the reference's names (state_dict keys as upstream, every BatchNorm
+    under `bnK` and `convK.1`); the computation is ONE library call forward and one backward (csrc/dgcnn_enc.hip:
+    index-exact kNN on the matrix cores, one exact-fp32 MFMA GEMM per point instead of per edge, LDS-resident
+    gather / BatchNorm2d / LeakyReLU / max, HIP tail).  `forward_parts` is the sync-free entry of the assembly
+    models: all part slots plus the validity mask, zeros out for padded parts.
+
+    Outside the kernels' instantiation (per-point features, more than 1024 points per cloud, feat_dim not in
+    {64, 128, 256}) the stage-by-stage composition of mpa_knn / mpa_edge_aggregate_* with library GEMMs is used and
+    says so once."""
+
+    MAX_POINTS = 1024
 
     def __init__(self, feat_dim, global_feat=True):
         super().__init__()
@@ -194,8 +273,45 @@ class DGCNN(nn.Module):
         self.conv4 = nn.Sequential(nn.Conv2d(256, 256, kernel_size=1, bias=False), self.bn4, act())
         self.conv5 = nn.Sequential(nn.Conv1d(512, feat_dim, kernel_size=1, bias=False), self.bn5, act())
         self.global_feat = global_feat
+        self.feat_dim = feat_dim
         if global_feat:
             self.out_fc = nn.Linear(feat_dim * 2, feat_dim)
+        self._warned = False
+
+    def _fused_ok(self, N):
+        return self.global_feat and self.feat_dim in (64, 128, 256) and 20 <= N <= self.MAX_POINTS
+
+    def forward_parts(self, part_pcs, valids):
+        """part_pcs [M, N, 3], valids [M] (1/0) -> [M, feat_dim]; rows of padded parts are zero."""
+        if not part_pcs.is_cuda:
+            raise RuntimeError("DGCNN: only CUDA (HIP) tensors are supported — no CPU fallback")
+        M, N, _ = part_pcs.shape
+        if not self._fused_ok(N):
+            return self._composed_parts(part_pcs, valids)
+        bns = [self.bn1, self.bn2, self.bn3, self.bn4, self.bn5]
+        convs = [self.conv1[0], self.conv2[0], self.conv3[0], self.conv4[0], self.conv5[0]]
+        if self.training:
+            with torch.no_grad():
+                torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+        running = ([bn.running_mean for bn in bns], [bn.running_var for bn in bns])
+        return _DGCNNFn.apply(
+            part_pcs.float().contiguous(), valids.detach().float().contiguous(), self.training, bns[0].momentum,
+            bns[0].eps, running, part_pcs.requires_grad, *[c.weight for c in convs], *[b.weight for b in bns],
+            *[b.bias for b in bns], self.out_fc.weight, self.out_fc.bias)
+
+    def forward(self, x):
+        """x [n, N, 3] -> [n, feat_dim] (global feature) or [n, N, feat_dim]; the reference's signature."""
+        if not x.is_cuda:
+            raise RuntimeError("DGCNN: only CUDA (HIP) tensors are supported — no CPU fallback")
+        if self._fused_ok(x.shape[1]):
+            return self.forward_parts(x, torch.ones(x.shape[0], device=x.device))
+        return self._composed(x)
+
+    # ---- stage-by-stage composition (sizes outside csrc/dgcnn_enc.hip) -------------------------------------------
+    def _composed_parts(self, part_pcs, valids):
+        slots = torch.nonzero(valids.reshape(-1) == 1, as_tuple=False).squeeze(1)  # (device sync)
+        feats = self._composed(part_pcs.index_select(0, slots))
+        return feats.new_zeros(part_pcs.shape[0], self.feat_dim).index_copy(0, slots, feats)
 
     def _edge_stage(self, h, conv, n, N):
         """h [n*N, C] -> [n*N, CO]."""
@@ -210,10 +326,12 @@ class DGCNN(nn.Module):
         return _EdgeAggFn.apply(h @ w_stack.t(), idx, bn.weight, bn.bias, (bn.running_mean, bn.running_var),
                                 self.training, bn.momentum, bn.eps, n, N)
 
-    def forward(self, x):
-        """x [n, N, 3] -> [n, feat_dim] (global feature) or [n, N, feat_dim]."""
-        if not x.is_cuda:
-            raise RuntimeError("DGCNN: only CUDA (HIP) tensors are supported — no CPU fallback")
+    def _composed(self, x):
+        if not self._warned:
+            import warnings
+            warnings.warn("DGCNN: configuration outside csrc/dgcnn_enc.hip (global feature, 20..1024 points per cloud, "
+                          "feat_dim 64/128/256); composing the per-stage kernels with library GEMMs")
+            self._warned = True
         n, N, _ = x.shape
         h = x.reshape(n * N, 3).float()
         stages = []

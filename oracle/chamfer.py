@@ -14,7 +14,7 @@ _lib = None
 
 def build(force: bool = False) -> Path:
     """(Re)build liboracle.so with the committed Makefile."""
-    src_m = max(p.stat().st_mtime for p in [_DIR / "chamfer_ref.c", _DIR / "Makefile"])
+    src_m = max(p.stat().st_mtime for p in [_DIR / "chamfer_ref.c", _DIR / "knn_ref.c", _DIR / "Makefile"])
     if force or not _SO.exists() or _SO.stat().st_mtime < src_m:
         subprocess.run(["make", "-C", str(_DIR), "-B", "liboracle.so"], check=True,
                        capture_output=True)

@@ -45,14 +45,22 @@ def test_encoder_matches_reference(golden, cuda_device, name, feat):
     out = enc(x)
     (out * T(z["w"]).to(cuda_device)).sum().backward()
     assert _rel(out.detach().cpu().numpy(), z["feat_train"]) < 1e-4
-    # DGCNN (library-op path for now): rocBLAS evaluates the Gram-form kNN scores in a different
-    # summation order than the CPU, so a few near-tie neighbours differ (SURVEY.md §7 hard part 3)
-    # and the input gradient — a sum over neighbour edges — moves by ~1e-2 at isolated points.
+    # DGCNN: the first stage's kNN graph is index-exact; the later stages' graphs are built in 64/128-d feature
+    # space where the reference's BLAS summation order is undefined, so an isolated near-tie neighbour can differ
+    # (the forward max hides it: 1e-4 holds) and moves the gradient of the few edges it touches: the worst entry is
+    # held to 3e-2, and all but a few percent of the entries to 2e-3.
     gtol = 1e-3 if name == "pointnet" else 3e-2
+
+    def close(a, b, who):
+        assert _rel(a, b) < gtol, who
+        if name == "dgcnn":
+            bad = (np.abs(a - b) > 2e-3 * np.abs(b).max()).mean()
+            assert bad < 0.05, (who, float(bad))
+
     if name == "dgcnn":  # the HIP PointNet does not differentiate w.r.t. its input points (data)
-        assert _rel(x.grad.cpu().numpy(), z["grad_x"]) < gtol
+        close(x.grad.cpu().numpy(), z["grad_x"], "grad_x")
     for k, p in enc.named_parameters():
-        assert _rel(p.grad.cpu().numpy(), z["grad." + k]) < gtol, k
+        close(p.grad.cpu().numpy(), z["grad." + k], k)
     for k, v in enc.state_dict().items():  # running statistics after the training-mode forward
         np.testing.assert_allclose(v.cpu().numpy(), z["sd1." + k], rtol=1e-4, atol=1e-5, err_msg=k)
     enc.eval()
@@ -84,7 +92,7 @@ def test_knn_kernel_selects_the_k_best(golden, cuda_device, C):
         got = knn_indices(xr.reshape(-1, 3).to(cuda_device).contiguous(), xr.shape[0], xr.shape[1], k).cpu()
         got = got.view(xr.shape[0], xr.shape[1], k).long().sort(-1)[0]
         want = torch.from_numpy(z["knn_idx_layer1"]).long().sort(-1)[0]
-        assert (got != want).any(-1).float().mean() < 0.01                    # near-ties at the 20th place only
+        assert torch.equal(got, want)                                         # same arithmetic as the reference's CPU path
 
 
 def test_edge_aggregate_matches_edge_tensor_formulation(cuda_device):
@@ -415,30 +423,31 @@ def test_fused_adamw_param_groups_and_clipping_match_torch(cuda_device):
     from multi_part_assembly_amd.optim import FlatBuffers, decay_mask_for
     torch.manual_seed(3)
 
-    def net():
+    def net():  # every parameter has a non-degenerate gradient (no shift fed into a following normalisation)
         torch.manual_seed(4)
-        return torch.nn.Sequential(torch.nn.Linear(7, 9), torch.nn.LayerNorm(9), torch.nn.Linear(9, 5),
-                                   torch.nn.BatchNorm1d(5)).to(cuda_device)
+        return torch.nn.Sequential(torch.nn.BatchNorm1d(7), torch.nn.Linear(7, 9), torch.nn.LayerNorm(9),
+                                   torch.nn.Linear(9, 5)).to(cuda_device)
 
     mine, theirs = net(), net()
     flat = FlatBuffers(list(mine.parameters()))
     mask = decay_mask_for(mine, flat)
     assert 0 < float(mask.sum()) < flat.numel
     opt = FusedAdam(flat, lr=1e-2, weight_decay=0.1, decay_mask=mask, clip_grad=0.05)
-    no_decay = [theirs[0].bias, theirs[1].weight, theirs[1].bias, theirs[2].bias, theirs[3].weight, theirs[3].bias]
-    decay = [theirs[0].weight, theirs[2].weight]
+    no_decay = [theirs[0].weight, theirs[0].bias, theirs[1].bias, theirs[2].weight, theirs[2].bias, theirs[3].bias]
+    decay = [theirs[1].weight, theirs[3].weight]
     topt = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": 0.1}], lr=1e-2)
     for step in range(4):
-        x = torch.randn(16, 7, device=cuda_device) * (3.0 if step % 2 else 0.01)  # clipped and unclipped steps
+        x = torch.randn(16, 7, device=cuda_device)
         opt.zero_grad()
         topt.zero_grad()
-        mine(x).square().sum().backward()
-        theirs(x).square().sum().backward()
+        k = 30.0 if step % 2 else 1e-3  # clipped and unclipped steps
+        (mine(x).square().sum() * k).backward()
+        (theirs(x).square().sum() * k).backward()
         torch.nn.utils.clip_grad_norm_(theirs.parameters(), 0.05)
         opt.step()  # no host sync between the steps: the step count lives on the device
         topt.step()
     for a, b in zip(mine.parameters(), theirs.parameters()):
-        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
 def test_trainer_step_matches_oracle_step(golden, cuda_device):

@@ -186,3 +186,29 @@ def test_full_pn_transformer_step_matches_reference(golden):
         if t.requires_grad:
             scale = np.abs(z["grad." + k]).max() + 1e-12
             assert np.abs(t.grad.numpy() - z["grad." + k]).max() / scale < 2e-3, (k, scale)
+
+
+def test_knn_oracle_reproduces_reference_topk(golden):
+    """oracle/knn_ref.c (mode 0: the reference's CPU arithmetic for the 3-d first stage) returns the reference's own
+    `knn` output on the fixture cloud — the same 20 indices per point IN THE SAME ORDER (dgcnn.py:8-15)."""
+    from oracle.knn import knn_exact
+    z = golden("dgcnn")
+    got = knn_exact(z["x"])
+    np.testing.assert_array_equal(got, z["knn_idx_layer1"].astype(np.int32))
+
+
+def test_knn_oracle_wide_features_are_the_true_neighbours():
+    """mode 1 (64 / 128-d features, matrix-core chain order): against float64 scores — sorted, self first, and no
+    selected neighbour worse than the true 20th best beyond fp32 rounding."""
+    from oracle.knn import knn_exact
+    rng = np.random.default_rng(5)
+    for C in (64, 128):
+        x = rng.normal(size=(2, 150, C)).astype(np.float32)
+        idx = knn_exact(x).astype(np.int64)
+        xd = x.astype(np.float64)
+        score = -((xd[:, :, None] - xd[:, None]) ** 2).sum(-1)
+        mine = np.take_along_axis(score, idx, 2)
+        kth = -np.sort(-score, axis=-1)[..., 19:20]
+        tol = 1e-5 * (xd ** 2).sum(-1).max()
+        assert (mine >= kth - tol).all() and (np.diff(mine, axis=-1) <= tol).all()
+        assert (idx[..., 0] == np.arange(150)[None]).all()
