@@ -182,6 +182,24 @@ __global__ void dg_first_dgrad_kernel(const float* __restrict__ duv, const float
 // pair cp = lane % 16): a wave gathers for 4 points at once with ds_read_b64, 8 waves -> 32 points per pass.
 constexpr int kAT = 512;
 
+// Copy a 32-channel column slice (row stride `ld` floats, N rows) between global memory and an LDS panel [N][32] with
+// four independent 16-byte requests in flight per thread (a plain loop exposes one L2 round trip per pass).
+__device__ __forceinline__ void dg_load_slice(const float* __restrict__ src, int ld, int N, float* __restrict__ dst) {
+  for (int e0 = threadIdx.x; e0 < N * 8; e0 += 4 * kAT) {
+    float4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * kAT, ec = e < N * 8 ? e : N * 8 - 1;
+      t[u] = *reinterpret_cast<const float4*>(src + (long long)(ec >> 3) * ld + 4 * (ec & 7));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * kAT;
+      if (e < N * 8) *reinterpret_cast<float4*>(&dst[4 * e]) = t[u];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kAT) void dg_agg_fwd_kernel(const float* __restrict__ uv, int CO,
                                                          const unsigned short* __restrict__ idx,
                                                          const float* __restrict__ gamma, int N,
@@ -194,11 +212,7 @@ __global__ __launch_bounds__(kAT) void dg_agg_fwd_kernel(const float* __restrict
   if (v >= hdr[0]) return;
   const int c0 = blockIdx.x * 32;
   const float* up = uv + (long long)v * N * 2 * CO;
-  for (int e = threadIdx.x; e < N * 8; e += kAT) {
-    const int row = e >> 3, c4 = e & 7;
-    *reinterpret_cast<float4*>(&Us[row * 32 + 4 * c4]) =
-        *reinterpret_cast<const float4*>(up + (long long)row * 2 * CO + c0 + 4 * c4);
-  }
+  dg_load_slice(up + c0, 2 * CO, N, Us);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cp = lane & 15, q = lane >> 4;
   const float gx = gamma[c0 + 2 * cp] < 0.0f ? -1.0f : 1.0f, gy = gamma[c0 + 2 * cp + 1] < 0.0f ? -1.0f : 1.0f;
@@ -585,11 +599,14 @@ __global__ void dg_agg_bwd_sums_kernel(const float* __restrict__ hcat, const flo
 }
 
 // Transposed kNN graph of every part: rptr [M][N + 1], rlist [R][20] = source points of the in-edges of every point,
-// ascending (fixed summation order downstream).  grid = M parts, block 1024.
+// ascending (fixed summation order downstream).  grid = M parts, block 1024; the part's whole list (N * 20 sources,
+// 40 KB) is built and sorted in LDS and written out once, coalesced.
 __global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* __restrict__ idx, int N,
                                                           int* __restrict__ rptr, unsigned short* __restrict__ rlist,
                                                           const int* __restrict__ hdr) {
   __shared__ int cnt[kMaxN];
+  __shared__ int beg[kMaxN + 1];
+  __shared__ unsigned short lst[kMaxN * kNbr];
   __shared__ int wsum[16];
   __shared__ int carry;
   const int v = blockIdx.x;
@@ -597,8 +614,6 @@ __global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int E = N * kNbr;
   const unsigned short* id = idx + (long long)v * E;
-  int* rp = rptr + (long long)v * (N + 1);
-  unsigned short* rl = rlist + (long long)v * E;
   for (int j = t; j < N; j += 1024) cnt[j] = 0;
   if (t == 0) carry = 0;
   __syncthreads();
@@ -617,31 +632,36 @@ __global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* 
     int before = carry;
     for (int w = 0; w < wave; ++w) before += wsum[w];
     if (j < N) {
-      rp[j] = before + inc - val;
+      beg[j] = before + inc - val;
       cnt[j] = before + inc - val;  // becomes the row's fill cursor
     }
     __syncthreads();
     if (t == 1023) carry = before + inc;
     __syncthreads();
   }
-  if (t == 0) rp[N] = carry;
+  if (t == 0) beg[N] = carry;
   for (int e = t; e < E; e += 1024) {
     const int pos = atomicAdd(&cnt[id[e]], 1);
-    rl[pos] = (unsigned short)(e / kNbr);
+    lst[pos] = (unsigned short)(e / kNbr);
   }
   __syncthreads();
-  for (int j = t; j < N; j += 1024) {  // ascending order inside every row
-    const int b = rp[j], e = cnt[j];
+  for (int j = t; j < N; j += 1024) {  // ascending order inside every row (insertion sort in LDS: ~20 entries)
+    const int b = beg[j], e = cnt[j];
     for (int a = b + 1; a < e; ++a) {
-      const unsigned short key = rl[a];
+      const unsigned short key = lst[a];
       int q = a - 1;
-      while (q >= b && rl[q] > key) {
-        rl[q + 1] = rl[q];
+      while (q >= b && lst[q] > key) {
+        lst[q + 1] = lst[q];
         --q;
       }
-      rl[q + 1] = key;
+      lst[q + 1] = key;
     }
   }
+  __syncthreads();
+  int* rp = rptr + (long long)v * (N + 1);
+  unsigned short* rl = rlist + (long long)v * E;
+  for (int j = t; j <= N; j += 1024) rp[j] = beg[j];
+  for (int e = t; e < E; e += 1024) rl[e] = lst[e];
 }
 
 // d(uv) [R][2CO].  grid = (CO / 32, M), block 512; LDS buffer [N][32]: first the part's V slice (gather over the
@@ -660,11 +680,7 @@ __global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict
   const int c0 = blockIdx.x * 32;
   const float* up = uv + (long long)v * N * 2 * CO;
   float* gp = guv + (long long)v * N * 2 * CO;
-  for (int e = threadIdx.x; e < N * 8; e += kAT) {
-    const int row = e >> 3, c4 = e & 7;
-    *reinterpret_cast<float4*>(&buf[row * 32 + 4 * c4]) =
-        *reinterpret_cast<const float4*>(up + (long long)row * 2 * CO + CO + c0 + 4 * c4);
-  }
+  dg_load_slice(up + CO + c0, 2 * CO, N, buf);
   for (int e = threadIdx.x; e <= N; e += kAT) rps[e] = rptr[(long long)v * (N + 1) + e];
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cp = lane & 15, q = lane >> 4;
@@ -753,16 +769,22 @@ __global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < N * 8; e += kAT) {
-    const int row = e >> 3, c4 = e & 7;
-    float4* d = reinterpret_cast<float4*>(gp + (long long)row * 2 * CO + c0 + 4 * c4);
-    const float4 a = *reinterpret_cast<const float4*>(&buf[4 * e]);
-    float4 t = *d;
-    t.x += a.x;
-    t.y += a.y;
-    t.z += a.z;
-    t.w += a.w;
-    *d = t;
+  for (int e0 = threadIdx.x; e0 < N * 8; e0 += 4 * kAT) {
+    float4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * kAT, ec = e < N * 8 ? e : N * 8 - 1;
+      t[u] = *reinterpret_cast<const float4*>(gp + (long long)(ec >> 3) * 2 * CO + c0 + 4 * (ec & 7));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * kAT;
+      if (e < N * 8) {
+        const float4 a = *reinterpret_cast<const float4*>(&buf[4 * e]);
+        *reinterpret_cast<float4*>(gp + (long long)(e >> 3) * 2 * CO + c0 + 4 * (e & 7)) =
+            make_float4(t[u].x + a.x, t[u].y + a.y, t[u].z + a.z, t[u].w + a.w);
+      }
+    }
   }
 }
 
