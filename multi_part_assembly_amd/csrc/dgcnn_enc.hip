@@ -21,9 +21,9 @@
 // edge of every (point, channel):
 //   dV_i = alpha dz_i + gammap (sum_j U_j + k V_i) + k betap                      (neighbour sum saved by forward)
 //   dU_j = gammap (deg_j U_j + sum_{i: j in nn(i)} V_i) + deg_j betap  +  sum_{i: sel_i = j} alpha dz_i
-// The middle sum is gathered over the TRANSPOSED kNN graph from an LDS-resident slice of V; the last one is scattered
-// into an LDS accumulator by ONE wave per channel group in ascending point order (LDS executes a wave's operations in
-// order), so the whole backward is free of cross-wave atomics and bit-reproducible.
+// Both sums run over the TRANSPOSED kNN graph (built per stage in LDS, in-edges sorted by source) from LDS-resident
+// 16-channel panels of V, alpha*dz and the selected slots: an in-edge (i -> j, slot t) contributes alpha dz_i[c] exactly
+// for the channels whose selected slot at i is t.  No atomics anywhere, fixed summation order: bit-reproducible.
 #include "common.h"
 #include "coop_reduce.h"
 #include "dg_gemm.h"
@@ -570,13 +570,12 @@ __global__ void dg_tail_bwd_apply_kernel(float* __restrict__ y, int F, int N, co
 }
 
 // ---- edge aggregation, backward ----------------------------------------------------------------------------------------------
-// dz = dH * LeakyReLU'(z) (z > 0 <=> H > 0), the two BatchNorm-backward sums over the selected edges, and the target
-// point of every (point, channel)'s selected edge: jsel = idx[row][ssel].  grid = ceil(Rmax / kTile), block = CO.
+// dz = dH * LeakyReLU'(z) (z > 0 <=> H > 0) and the two BatchNorm-backward sums over the selected edges.
+// grid = ceil(Rmax / kTile), block = CO.
 __global__ void dg_agg_bwd_sums_kernel(const float* __restrict__ hcat, const float* __restrict__ dhcat, int off, int CO,
-                                       const float* __restrict__ esel, const unsigned char* __restrict__ ssel,
-                                       const unsigned short* __restrict__ idx, const float* __restrict__ bn,
-                                       float* __restrict__ dz, unsigned short* __restrict__ jsel,
-                                       float* __restrict__ partial, const int* __restrict__ hdr) {
+                                       const float* __restrict__ esel, const float* __restrict__ bn,
+                                       float* __restrict__ dz, float* __restrict__ partial,
+                                       const int* __restrict__ hdr) {
   const int R = hdr[1];
   const long long r0 = (long long)blockIdx.x * kTile;
   if (r0 >= R) return;
@@ -589,7 +588,6 @@ __global__ void dg_agg_bwd_sums_kernel(const float* __restrict__ hcat, const flo
     const float h = hcat[r * kCat + off + c];
     const float d = dhcat[r * kCat + off + c] * (h > 0.0f ? 1.0f : kSlope);
     dz[o] = d;
-    jsel[o] = idx[r * kNbr + ssel[o]];
     s1 += d;
     s2 = __builtin_fmaf(d, (esel[o] - mean) * invstd, s2);
   }
@@ -598,8 +596,8 @@ __global__ void dg_agg_bwd_sums_kernel(const float* __restrict__ hcat, const flo
   p[1] = s2;
 }
 
-// Transposed kNN graph of every part: rptr [M][N + 1], rlist [R][20] = source points of the in-edges of every point,
-// ascending (fixed summation order downstream).  grid = M parts, block 1024; the part's whole list (N * 20 sources,
+// Transposed kNN graph of every part: rptr [M][N + 1], rlist [R][20] = the in-edges of every point as
+// (source point * 32 + neighbour slot of the target in the source's list), ascending (fixed summation order downstream).  grid = M parts, block 1024; the part's whole list (N * 20 sources,
 // 40 KB) is built and sorted in LDS and written out once, coalesced.
 __global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* __restrict__ idx, int N,
                                                           int* __restrict__ rptr, unsigned short* __restrict__ rlist,
@@ -642,7 +640,7 @@ __global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* 
   if (t == 0) beg[N] = carry;
   for (int e = t; e < E; e += 1024) {
     const int pos = atomicAdd(&cnt[id[e]], 1);
-    lst[pos] = (unsigned short)(e / kNbr);
+    lst[pos] = (unsigned short)((e / kNbr) * 32 + e % kNbr);  // source point and its neighbour slot
   }
   __syncthreads();
   for (int j = t; j < N; j += 1024) {  // ascending order inside every row (insertion sort in LDS: ~20 entries)
@@ -664,126 +662,155 @@ __global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* 
   for (int e = t; e < E; e += 1024) rl[e] = lst[e];
 }
 
-// d(uv) [R][2CO].  grid = (CO / 32, M), block 512; LDS buffer [N][32]: first the part's V slice (gather over the
-// in-edges), then the accumulator of the selected-edge scatter.
+// d(uv) [R][2CO] in ONE pass over the transposed graph.  grid = (CO / 16, M), block 512.  LDS panels of a 16-channel
+// slice of the part: V, W = alpha * dz and the selected slots (rows 0..N-1, row N = neutral: zeros / slot 255), the
+// in-edge offsets, and per wave a scratch run of in-edge entries.  Lane = (point of 16, channel quad): for every
+// in-edge (source i, slot t) of its point j it adds V_i to the neighbour sum and W_i[c] to the selected-edge sum of the
+// channels whose selected slot at i is t — i.e. whose selected neighbour is j.  No atomics, no second pass:
+//   dU_j = gammap (deg_j U_j + sum V_i) + deg_j betap + sum_sel W_i,   dV_j = W_j + gammap (S1_j + k V_j) + k betap
+// with every sum taken in ascending source order (bit-reproducible).
+constexpr int kBS = 16;          // channels per slice
+constexpr int kRun = 512;        // scratch entries per wave (16 points x ~20 in-edges, with room for hubs)
 __global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict__ uv, int CO,
                                                          const int* __restrict__ rptr,
                                                          const unsigned short* __restrict__ rlist,
                                                          const float* __restrict__ dz,
-                                                         const unsigned short* __restrict__ jsel,
+                                                         const unsigned char* __restrict__ ssel,
                                                          const float* __restrict__ s1in, const float* __restrict__ coef,
                                                          int N, float* __restrict__ guv, const int* __restrict__ hdr) {
-  __shared__ __attribute__((aligned(16))) float buf[kMaxN * 32];
-  __shared__ int rps[kMaxN + 1];
+  __shared__ __attribute__((aligned(16))) float Vp[(kMaxN + 1) * kBS];
+  __shared__ __attribute__((aligned(16))) float Wp[(kMaxN + 1) * kBS];
+  __shared__ __attribute__((aligned(16))) unsigned char Sp[(kMaxN + 1) * kBS];
+  __shared__ int rps[kMaxN + 2];
+  __shared__ unsigned short scr[kAT / 64][kRun];
   const int v = blockIdx.y;
   if (v >= hdr[0]) return;
-  const int c0 = blockIdx.x * 32;
+  const int c0 = blockIdx.x * kBS;
   const float* up = uv + (long long)v * N * 2 * CO;
   float* gp = guv + (long long)v * N * 2 * CO;
-  dg_load_slice(up + CO + c0, 2 * CO, N, buf);
-  for (int e = threadIdx.x; e <= N; e += kAT) rps[e] = rptr[(long long)v * (N + 1) + e];
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cp = lane & 15, q = lane >> 4;
-  const float2 alpha = *reinterpret_cast<const float2*>(coef + c0 + 2 * cp);
-  const float2 gammap = *reinterpret_cast<const float2*>(coef + CO + c0 + 2 * cp);
-  const float2 betap = *reinterpret_cast<const float2*>(coef + 2 * CO + c0 + 2 * cp);
-  const unsigned short* rl = rlist + (long long)v * N * kNbr;
-  {
-    // In-edge lists: the first kHead sources of the NEXT point are requested (as independent loads, the offsets come
-    // from LDS) before the current point's LDS gathers; only hubs with more in-edges than that pay a further round trip.
-    constexpr int kHead = 24;
-    unsigned short cur[kHead], nxt[kHead];
-    const int last = N * kNbr - 1;
-    auto request = [&](int b, unsigned short (&w)[kHead]) {
-#pragma unroll
-      for (int u = 0; u < kHead; ++u) w[u] = rl[b + u < last ? b + u : last];
-    };
-    int j = wave * 4 + q;
-    int b = j < N ? rps[j] : 0, e = j < N ? rps[j + 1] : 0;
-    request(b, nxt);
-    for (; j < N; j += 32) {
-#pragma unroll
-      for (int u = 0; u < kHead; ++u) cur[u] = nxt[u];
-      const int jn = j + 32;
-      const int bn = jn < N ? rps[jn] : 0, en = jn < N ? rps[jn + 1] : 0;
-      request(bn, nxt);
-      const long long row = (long long)v * N + j, o = row * CO + c0 + 2 * cp;
-      const float2 u = *reinterpret_cast<const float2*>(up + (long long)j * 2 * CO + c0 + 2 * cp);
-      const float2 d = *reinterpret_cast<const float2*>(dz + o);
-      const float2 s1 = *reinterpret_cast<const float2*>(s1in + o);
-      float svx = 0.0f, svy = 0.0f;
-#pragma unroll
-      for (int k = 0; k < kHead; ++k) {  // ascending sources: fixed summation order
-        const float2 t = *reinterpret_cast<const float2*>(&buf[(int)cur[k] * 32 + 2 * cp]);
-        const bool ok = b + k < e;
-        svx += ok ? t.x : 0.0f;
-        svy += ok ? t.y : 0.0f;
-      }
-      for (int a = b + kHead; a < e; ++a) {
-        const float2 t = *reinterpret_cast<const float2*>(&buf[(int)rl[a] * 32 + 2 * cp]);
-        svx += t.x;
-        svy += t.y;
-      }
-      const float deg = (float)(e - b);
-      const float2 vv = *reinterpret_cast<const float2*>(&buf[j * 32 + 2 * cp]);
-      float2 du, dv;
-      du.x = __builtin_fmaf(gammap.x, __builtin_fmaf(deg, u.x, svx), deg * betap.x);
-      du.y = __builtin_fmaf(gammap.y, __builtin_fmaf(deg, u.y, svy), deg * betap.y);
-      dv.x = __builtin_fmaf(alpha.x, d.x, __builtin_fmaf(gammap.x, s1.x + (float)kNbr * vv.x, (float)kNbr * betap.x));
-      dv.y = __builtin_fmaf(alpha.y, d.y, __builtin_fmaf(gammap.y, s1.y + (float)kNbr * vv.y, (float)kNbr * betap.y));
-      *reinterpret_cast<float2*>(gp + (long long)j * 2 * CO + c0 + 2 * cp) = du;
-      *reinterpret_cast<float2*>(gp + (long long)j * 2 * CO + CO + c0 + 2 * cp) = dv;
-      b = bn;
-      e = en;
-    }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < N * 8; e += kAT) *reinterpret_cast<float4*>(&buf[4 * e]) = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  {
-    // selected-edge scatter: wave w owns channels 4w .. 4w+3 of the slice; lane = (point slot pt, channel ch); the 16
-    // point slots of a pass are applied one after the other, so every (target, channel) sees its addends in ascending
-    // source order — LDS executes one wave's operations in program order.  The next pass's operands are requested
-    // before the current pass's adds.
-    const int pt = lane >> 2, ch = lane & 3, c = c0 + 4 * wave + ch;
-    const float al = coef[c];
-    auto request = [&](int i, float& val, int& tgt) {
-      const int ic = i < N ? i : N - 1;
-      const long long o = ((long long)v * N + ic) * CO + c;
-      val = al * dz[o];
-      tgt = jsel[o];
-    };
-    float vn;
-    int tn;
-    request(pt, vn, tn);
-    for (int i0 = 0; i0 < N; i0 += 16) {
-      const int i = i0 + pt;
-      const float val = vn;
-      const int tgt = tn;
-      request(i + 16, vn, tn);
-#pragma unroll
-      for (int p = 0; p < 16; ++p) {
-        // hardware ds_add_f32 (no compare-and-swap loop): one wave owns the address, so this is an ordered RMW
-        if (pt == p && i < N) unsafeAtomicAdd(&buf[tgt * 32 + 4 * wave + ch], val);
-      }
-    }
-  }
-  __syncthreads();
-  for (int e0 = threadIdx.x; e0 < N * 8; e0 += 4 * kAT) {
-    float4 t[4];
+  const float* dzp = dz + (long long)v * N * CO;
+  const unsigned char* sp = ssel + (long long)v * N * CO;
+  // panels: four requests in flight per thread
+  for (int e0 = threadIdx.x; e0 < N * 4; e0 += 4 * kAT) {
+    float4 tv[4], tw[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * kAT, ec = e < N * 8 ? e : N * 8 - 1;
-      t[u] = *reinterpret_cast<const float4*>(gp + (long long)(ec >> 3) * 2 * CO + c0 + 4 * (ec & 7));
+      const int e = e0 + u * kAT, ec = e < N * 4 ? e : N * 4 - 1;
+      tv[u] = *reinterpret_cast<const float4*>(up + (long long)(ec >> 2) * 2 * CO + CO + c0 + 4 * (ec & 3));
+      tw[u] = *reinterpret_cast<const float4*>(dzp + (long long)(ec >> 2) * CO + c0 + 4 * (ec & 3));
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = e0 + u * kAT;
-      if (e < N * 8) {
-        const float4 a = *reinterpret_cast<const float4*>(&buf[4 * e]);
-        *reinterpret_cast<float4*>(gp + (long long)(e >> 3) * 2 * CO + c0 + 4 * (e & 7)) =
-            make_float4(t[u].x + a.x, t[u].y + a.y, t[u].z + a.z, t[u].w + a.w);
+      if (e < N * 4) {
+        const float4 al = *reinterpret_cast<const float4*>(coef + c0 + 4 * (e & 3));
+        *reinterpret_cast<float4*>(&Vp[4 * e]) = tv[u];
+        *reinterpret_cast<float4*>(&Wp[4 * e]) = make_float4(al.x * tw[u].x, al.y * tw[u].y, al.z * tw[u].z, al.w * tw[u].w);
       }
+    }
+  }
+  for (int r = threadIdx.x; r < N; r += kAT)
+    *reinterpret_cast<uint4*>(&Sp[r * kBS]) = *reinterpret_cast<const uint4*>(sp + (long long)r * CO + c0);
+  if (threadIdx.x < kBS) {
+    Vp[N * kBS + threadIdx.x] = 0.0f;
+    Wp[N * kBS + threadIdx.x] = 0.0f;
+    Sp[N * kBS + threadIdx.x] = 255;
+  }
+  for (int e = threadIdx.x; e <= N; e += kAT) rps[e] = rptr[(long long)v * (N + 1) + e];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cq = lane & 3, q = lane >> 2;
+  const float4 gammap = *reinterpret_cast<const float4*>(coef + CO + c0 + 4 * cq);
+  const float4 betap = *reinterpret_cast<const float4*>(coef + 2 * CO + c0 + 4 * cq);
+  const unsigned short* rl = rlist + (long long)v * N * kNbr;
+  unsigned short* sc = scr[wave];
+  const int last = N * kNbr - 1;
+  const unsigned short kNeutral = (unsigned short)(N * 32 + 31);
+  // the in-edge lists of a wave pass's 16 consecutive points are ONE contiguous run of rlist: requested a pass ahead
+  // with coalesced loads, copied to the wave's scratch, read from there by every lane
+  unsigned short pre[kRun / 64];
+  float4 un, sn;
+  auto request = [&](int j0) {  // j0: first point of the pass (wave-uniform)
+    const int base = rps[j0 < N ? j0 : N];
+#pragma unroll
+    for (int u = 0; u < kRun / 64; ++u) pre[u] = rl[base + 64 * u + lane < last ? base + 64 * u + lane : last];
+    const int jc = j0 + q < N ? j0 + q : N - 1;
+    un = *reinterpret_cast<const float4*>(up + (long long)jc * 2 * CO + c0 + 4 * cq);
+    sn = *reinterpret_cast<const float4*>(s1in + ((long long)v * N + jc) * CO + c0 + 4 * cq);
+  };
+  request(wave * 16);
+  for (int j0 = wave * 16; j0 < N; j0 += 128) {
+    const int j = j0 + q;
+    const int base = rps[j0];
+    const int b = j < N ? rps[j] : base, e = j < N ? rps[j + 1] : base;
+#pragma unroll
+    for (int u = 0; u < kRun / 64; ++u) sc[64 * u + lane] = pre[u];
+    const float4 u4 = un, s4 = sn;
+    request(j0 + 128);
+    __builtin_amdgcn_wave_barrier();  // the scratch is private to the wave; LDS keeps a wave's accesses in order
+    int kmax = e - b;
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+      const int t = __shfl_xor(kmax, o, 64);
+      kmax = t > kmax ? t : kmax;
+    }
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
+    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f), sd = make_float4(0.f, 0.f, 0.f, 0.f);
+    // four in-edges per pass of the loop: their scratch reads, then their twelve panel reads, are issued together —
+    // one in-edge at a time is two dependent LDS round trips per pass with two waves per SIMD to hide them
+    const bool hub = __any(e - base > kRun);  // a point whose in-edges reach past the staged run (rare)
+    for (int k = 0; k < kmax; k += 4) {  // ascending sources: fixed summation order
+      unsigned ent[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int off = b + k + u - base;
+        ent[u] = sc[off < kRun ? off : kRun - 1];
+      }
+      if (__builtin_expect(hub, 0)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int a = b + k + u;
+          if (a < e && a - base >= kRun) ent[u] = rl[a];
+        }
+      }
+      float4 tv[4], tw[4];
+      unsigned ts[4], slot[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned en = b + k + u < e ? ent[u] : (unsigned)kNeutral;
+        const int src = en >> 5;
+        slot[u] = en & 31u;
+        tv[u] = *reinterpret_cast<const float4*>(&Vp[src * kBS + 4 * cq]);
+        tw[u] = *reinterpret_cast<const float4*>(&Wp[src * kBS + 4 * cq]);
+        ts[u] = *reinterpret_cast<const unsigned*>(&Sp[src * kBS + 4 * cq]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sv.x += tv[u].x;
+        sv.y += tv[u].y;
+        sv.z += tv[u].z;
+        sv.w += tv[u].w;
+        sd.x += (ts[u] & 0xffu) == slot[u] ? tw[u].x : 0.0f;
+        sd.y += ((ts[u] >> 8) & 0xffu) == slot[u] ? tw[u].y : 0.0f;
+        sd.z += ((ts[u] >> 16) & 0xffu) == slot[u] ? tw[u].z : 0.0f;
+        sd.w += (ts[u] >> 24) == slot[u] ? tw[u].w : 0.0f;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (j < N) {
+      const float deg = (float)(e - b), kf = (float)kNbr;
+      const float4 vv = *reinterpret_cast<const float4*>(&Vp[j * kBS + 4 * cq]);
+      const float4 wj = *reinterpret_cast<const float4*>(&Wp[j * kBS + 4 * cq]);
+      float4 du, dv;
+      du.x = __builtin_fmaf(gammap.x, __builtin_fmaf(deg, u4.x, sv.x), deg * betap.x) + sd.x;
+      du.y = __builtin_fmaf(gammap.y, __builtin_fmaf(deg, u4.y, sv.y), deg * betap.y) + sd.y;
+      du.z = __builtin_fmaf(gammap.z, __builtin_fmaf(deg, u4.z, sv.z), deg * betap.z) + sd.z;
+      du.w = __builtin_fmaf(gammap.w, __builtin_fmaf(deg, u4.w, sv.w), deg * betap.w) + sd.w;
+      dv.x = wj.x + __builtin_fmaf(gammap.x, s4.x + kf * vv.x, kf * betap.x);
+      dv.y = wj.y + __builtin_fmaf(gammap.y, s4.y + kf * vv.y, kf * betap.y);
+      dv.z = wj.z + __builtin_fmaf(gammap.z, s4.z + kf * vv.z, kf * betap.z);
+      dv.w = wj.w + __builtin_fmaf(gammap.w, s4.w + kf * vv.w, kf * betap.w);
+      *reinterpret_cast<float4*>(gp + (long long)j * 2 * CO + c0 + 4 * cq) = du;
+      *reinterpret_cast<float4*>(gp + (long long)j * 2 * CO + CO + c0 + 4 * cq) = dv;
     }
   }
 }
@@ -795,7 +822,7 @@ struct Ws {
   float4* x0;
   float *hcat, *uv[4], *esel[4], *s1[4], *y5, *norm, *bn[5], *coef, *partial, *wstk[4], *wstt[4], *w5t, *pooled,
       *dpooled, *tnpart, *dhcat, *duv, *dz, *gstk;
-  unsigned short *idx[4], *jsel, *rlist;
+  unsigned short *idx[4], *rlist;
   unsigned char* ssel[4];
   double* stage;
   int64_t total;
@@ -844,7 +871,6 @@ Ws dg_carve(char* base, int64_t M, int64_t N, int64_t F) {
   w.dhcat = reinterpret_cast<float*>(take(4 * R * kCat));
   w.duv = reinterpret_cast<float*>(take(4 * R * 2 * kCO[3]));
   w.dz = reinterpret_cast<float*>(take(4 * R * kCO[3]));
-  w.jsel = reinterpret_cast<unsigned short*>(take(2 * R * kCO[3]));
   w.gstk = reinterpret_cast<float*>(take(4 * kCat * 128));
   w.rptr = reinterpret_cast<int*>(take(4 * M * (N + 1)));
   w.rlist = reinterpret_cast<unsigned short*>(take(2 * R * kNbr));
@@ -1017,15 +1043,14 @@ extern "C" int mpa_dgcnn_backward(const float* grad_feat, const float* const* co
   for (int l = 3; l >= 0; --l) {
     const int CO = kCO[l], C = kCin[l], CP = kCinP[l];
     launch(dg_agg_bwd_sums_kernel, dim3((unsigned)tiles), dim3((unsigned)CO), s, (const float*)w.hcat,
-           (const float*)w.dhcat, kOff[l], CO, (const float*)w.esel[l], (const unsigned char*)w.ssel[l],
-           (const unsigned short*)w.idx[l], (const float*)w.bn[l], w.dz, w.jsel, w.partial, hdr);
+           (const float*)w.dhcat, kOff[l], CO, (const float*)w.esel[l], (const float*)w.bn[l], w.dz, w.partial, hdr);
     launch(dg_bwd_coef_kernel, dim3((unsigned)(CO / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
            (const float*)w.partial, (int)tiles, CO, kNbr, bn_w[l], (const float*)w.bn[l], w.coef, grad_bn_w[l],
            grad_bn_b[l], cw, hdr);
     launch(dg_reverse_kernel, dim3((unsigned)M), dim3(1024), s, (const unsigned short*)w.idx[l], (int)N, w.rptr, w.rlist,
            hdr);
-    launch(dg_agg_bwd_kernel, dim3((unsigned)(CO / 32), (unsigned)M), dim3(kAT), s, (const float*)w.uv[l], CO,
-           (const int*)w.rptr, (const unsigned short*)w.rlist, (const float*)w.dz, (const unsigned short*)w.jsel,
+    launch(dg_agg_bwd_kernel, dim3((unsigned)(CO / kBS), (unsigned)M), dim3(kAT), s, (const float*)w.uv[l], CO,
+           (const int*)w.rptr, (const unsigned short*)w.rlist, (const float*)w.dz, (const unsigned char*)w.ssel[l],
            (const float*)w.s1[l], (const float*)w.coef, (int)N, w.duv, hdr);
     if (l == 0) {
       const int t1 = (int)((R + kFirstTile - 1) / kFirstTile);

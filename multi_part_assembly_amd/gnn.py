@@ -103,7 +103,9 @@ class DGLModel(BaseModel):
         self.merge_node = cfg.model.merge_node
         zero_pose = torch.zeros(1, 1, self.pose_dim)
         zero_pose[..., 0] = 1.0  # identity quaternion, zero translation (base_model.py:31-34)
-        self.zero_pose = zero_pose
+        # a plain attribute upstream; a non-persistent buffer here (same state_dict keys) so that it lives on the
+        # module's device: a host-to-device copy inside forward cannot be captured into a HIP graph
+        self.register_buffer("zero_pose", zero_pose, persistent=False)
         self.encoder = build_encoder(cfg.model.encoder, feat_dim=self.pc_feat_dim, global_feat=True)
         self.edge_mlps = _clones(_PairMLP(2 * self.pc_feat_dim, self.pc_feat_dim), self.iter)
         self.node_mlps = self._init_node_mlps()

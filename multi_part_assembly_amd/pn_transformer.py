@@ -102,7 +102,7 @@ class PNTransformerRefine(PNTransformer):
         super().__init__(cfg)
         zero_pose = torch.zeros(1, 1, self.pose_dim)
         zero_pose[..., 0] = 1.0
-        self.zero_pose = zero_pose
+        self.register_buffer("zero_pose", zero_pose, persistent=False)  # on the module's device: graph-capturable
         self.corr_pos_enc = PosEncoder([self.pose_dim, *cfg.model.transformer_pos_enc])
 
     def _init_corr_module(self):
