@@ -320,11 +320,18 @@ def main():
                 secs = k["avg_ms"] * 1e-3
                 alg = float(valid_parts) * N * (4 * C + 20 * 8)
                 pairs = float(valid_parts) * N * N
+                traffic, traffic_src = None, None
+                pmc = sorted((ROOT / "profiles").glob("r*_pmc_knn_kernel.json"))
+                if pmc:  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes
+                    rec = json.loads(pmc[-1].read_text())
+                    if str(C) in rec.get("per_width", {}):
+                        traffic = rec["per_width"][str(C)]["traffic_bytes_per_launch"]
+                        traffic_src = f"profiles/{pmc[-1].name}: {rec['correction']}"
                 roofline = {
-                    "kernel": f"mpa::dg_knn_kernel (k = 20 nearest neighbours in {C}-d feature space, {valid_parts} "
-                              f"clouds of {N} points)",
+                    "kernel": f"dg::knn_mfma_kernel (k = 20 nearest neighbours in {C}-d feature space, {valid_parts} "
+                              f"clouds of {N} points; timed with its row-norm pre-pass)",
                     "bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                    "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": k["avg_ms"], "launches": k["launches"], "algorithmic_bytes_per_launch": alg,
                     "binding": {"bound": "mfma_f32" if C >= 64 else "valu",
                                 "note": "exhaustive exact top-20: N candidate scores per query (2C+1 FLOP each) + "
