@@ -257,6 +257,29 @@ int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, int64_t C, f
                   void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * One MLP layer of the graph networks — replaces the Conv1d(k=1) + BatchNorm1d + ReLU layers of
+ *   MLP3 / MLP4 / MLP5   : multi_part_assembly/models/dgl/modules.py:5-58, models/rgl_net/modules.py:5-30
+ * and the Linear + ReLU layers of
+ *   RelationNet          : multi_part_assembly/models/dgl/modules.py:61-73
+ * which DGL / RGL-NET run over the B*P*P part pairs (edge MLP, relation weights) and the B*P parts (node MLP) in every
+ * GNN iteration (models/dgl/network.py:121-152).
+ * x [R, K] row-major (leading dimension ldx >= K), w [N, K] (the Conv1d weight with its trailing 1 dropped / the Linear
+ * weight), bias [N] or NULL; gamma == NULL: out = act(x w^T + bias); else out = act(BatchNorm(x w^T + bias)) with
+ * batch statistics over the R rows (training != 0; running statistics updated in place) or the running statistics.
+ * act = ReLU if relu != 0.  K and N multiples of 64.  out [R, N].  `ws` (mpa_mlp_layer_workspace bytes, 256-byte
+ * aligned) carries the pre-normalisation values and the statistics to backward, which takes the forward's `out`
+ * (for the ReLU mask) and overwrites grad_x [R, K] (if non-NULL), grad_w [N, K], grad_b [N] (if non-NULL),
+ * grad_gamma / grad_beta [N] (BatchNorm layers).  Exact-fp32 matrix-core GEMMs, fixed-order reductions: deterministic.
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_mlp_layer_workspace(int64_t R, int64_t K, int64_t N, int64_t* bytes);
+int mpa_mlp_layer_forward(const float* x, int64_t ldx, const float* w, const float* bias, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, int training, float momentum,
+                          float eps, int relu, int64_t R, int64_t K, int64_t N, void* ws, float* out, void* stream);
+int mpa_mlp_layer_backward(const float* grad_out, const float* x, int64_t ldx, const float* w, const float* gamma,
+                           const float* out, int relu, int64_t R, int64_t K, int64_t N, void* ws, float* grad_x,
+                           float* grad_w, float* grad_b, float* grad_gamma, float* grad_beta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Part-relation transformer encoder — replaces
  *   TransformerEncoder.forward : multi_part_assembly/models/pn_transformer/transformer.py:63-79
  *   (nn.TransformerEncoder of pre-LN nn.TransformerEncoderLayer, ReLU FFN, batch_first,

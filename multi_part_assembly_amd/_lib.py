@@ -54,6 +54,9 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_dgcnn_forward": (_INT, [_P] * 9 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
     "mpa_dgcnn_backward": (_INT, [_P] * 4 + [_I64, _I64, _I64] + [_P] * 8),
     "mpa_knn_exact": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P, _P]),
+    "mpa_mlp_layer_workspace": (_INT, [_I64, _I64, _I64, _P]),
+    "mpa_mlp_layer_forward": (_INT, [_P, _I64, _P, _P, _P, _P, _P, _P, _INT, _F32, _F32, _INT, _I64, _I64, _I64, _P, _P, _P]),
+    "mpa_mlp_layer_backward": (_INT, [_P, _P, _I64, _P, _P, _P, _INT, _I64, _I64, _I64] + [_P] * 7),
     "mpa_transformer_workspace": (_INT, [_I64] * 6 + [_P]),
     "mpa_transformer_forward": (_INT, [_P, _P, _P] + [_I64] * 6 + [_F32, _U64, _P, _P, _P, _P]),
     "mpa_transformer_backward": (_INT, [_P, _P, _P] + [_I64] * 6 + [_F32, _U64, _P, _P, _P, _P, _P]),

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kGT, 2) void gemm_tn_kernel(const float* __restrict
 }
 
 // second stage of the weight gradient: out[e] = sum_chunk part[chunk][e] in chunk order (deterministic)
-__global__ void gemm_tn_reduce_kernel(const float* __restrict__ part, int chunks, long long elems,
+static __global__ void gemm_tn_reduce_kernel(const float* __restrict__ part, int chunks, long long elems,
                                       float* __restrict__ out) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= elems) return;

@@ -1,0 +1,364 @@
+// One layer of the graph networks' MLPs — Linear (+ bias) [-> BatchNorm1d (training or running statistics)] [-> ReLU]
+// over R rows, forward and backward — for gfx950.
+//
+// Replaces the Conv1d(k=1) + BatchNorm1d + ReLU layers of the reference's MLP3 / MLP4 / MLP5 and the Linear + ReLU
+// layers of RelationNet (multi_part_assembly/models/dgl/modules.py:5-73, models/rgl_net/modules.py:5-30): the P x P edge
+// MLP runs them over B*P*P = 12 800 pair rows three times per training step (dgl/network.py:135-152), the node MLP
+// over B*P rows.  The GEMMs are the exact-fp32 matrix-core kernels of dg_gemm.h (weights [Nout, K] as PyTorch stores
+// them); BatchNorm statistics are fixed-order two-stage sums in double; the backward is the affine map
+//   dY = alpha * dz + gammap * Y + betap,  dz = dOut * [out > 0]
+// followed by dW = dY^T X (row-chunked, fixed order), db = column sums of dY, dX = dY W.  No atomics: bit-reproducible.
+// Padded pairs are rows like any other (the reference's BatchNorm sees them too, dgl/network.py:139-144).
+#include "common.h"
+#include "coop_reduce.h"
+#include "dg_gemm.h"
+
+namespace {
+
+using namespace dg;
+using mpa::CoopWs;
+using mpa::coop_colsum;
+using mpa::kEB;
+using mpa::kSlices;
+
+constexpr int kRT = 16;          // rows per block of the row-tiled kernels
+constexpr int kChunks = 64;      // most row chunks of the weight-gradient GEMM (fewer for few rows: >= 256 rows each)
+
+__global__ void ml_set_hdr_kernel(int* hdr, int R, unsigned* tickets) {
+  hdr[0] = 1;
+  hdr[1] = R;
+  for (int t = threadIdx.x; t < 64; t += blockDim.x) tickets[t] = 0u;
+}
+
+// y[r][c] += bias[c] (in place) and the per-tile column sums (sum y, sum y^2).  grid = tiles, block = 256 (channels in
+// chunks of 256).
+__global__ __launch_bounds__(256) void ml_bias_stats_kernel(float* __restrict__ y, const float* __restrict__ bias, int R,
+                                                            int C, float* __restrict__ partial) {
+  const long long r0 = (long long)blockIdx.x * kRT;
+  const int rows = R - r0 < kRT ? (int)(R - r0) : kRT;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float b = bias != nullptr ? bias[c] : 0.0f;
+    float s = 0.0f, ss = 0.0f;
+    for (int i = 0; i < rows; ++i) {
+      const float t = y[(r0 + i) * C + c] + b;
+      y[(r0 + i) * C + c] = t;
+      s += t;
+      ss = __builtin_fmaf(t, t, ss);
+    }
+    float* d = partial + ((long long)blockIdx.x * C + c) * 2;
+    d[0] = s;
+    d[1] = ss;
+  }
+}
+
+__global__ __launch_bounds__(64 * kSlices) void ml_bn_finalize_kernel(
+    const float* __restrict__ partial, int rows, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+    float eps, float* __restrict__ bn, const CoopWs cw) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s, ss;
+  const bool last = coop_colsum(rows, C, c, cw,
+                                [&](int e, bool& ok, double& x, double& y) {
+                                  const float2 t = *reinterpret_cast<const float2*>(partial + ((long long)e * C + c) * 2);
+                                  ok = true;
+                                  x = (double)t.x;
+                                  y = (double)t.y;
+                                },
+                                s, ss);
+  if (!last || threadIdx.x >= 64) return;
+  const double mean = s / count;
+  double var = ss / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / __builtin_sqrt(var + (double)eps));
+  const float scale = gamma[c] * invstd;
+  bn[c] = scale;
+  bn[C + c] = beta[c] - (float)mean * scale;
+  bn[2 * C + c] = (float)mean;
+  bn[3 * C + c] = invstd;
+  if (running_mean != nullptr) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void ml_bn_from_running_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                          float eps, float* __restrict__ bn) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / __builtin_sqrtf(running_var[c] + eps);
+  const float scale = gamma[c] * invstd;
+  bn[c] = scale;
+  bn[C + c] = beta[c] - running_mean[c] * scale;
+  bn[2 * C + c] = running_mean[c];
+  bn[3 * C + c] = invstd;
+}
+
+// out = act(y * scale + shift) (bn != NULL) or act(y + bias) (bn == NULL); one thread per float4.
+__global__ void ml_apply_kernel(const float* __restrict__ y, const float* __restrict__ bn, const float* __restrict__ bias,
+                                long long total4, int C, int relu, float* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total4) return;
+  const int c = 4 * (int)(e % (C / 4));
+  const float4 x = reinterpret_cast<const float4*>(y)[e];
+  float4 z;
+  if (bn != nullptr) {
+    const float4 sc = *reinterpret_cast<const float4*>(bn + c), sh = *reinterpret_cast<const float4*>(bn + C + c);
+    z = make_float4(__builtin_fmaf(x.x, sc.x, sh.x), __builtin_fmaf(x.y, sc.y, sh.y), __builtin_fmaf(x.z, sc.z, sh.z),
+                    __builtin_fmaf(x.w, sc.w, sh.w));
+  } else if (bias != nullptr) {
+    const float4 b = *reinterpret_cast<const float4*>(bias + c);
+    z = make_float4(x.x + b.x, x.y + b.y, x.z + b.z, x.w + b.w);
+  } else {
+    z = x;
+  }
+  if (relu) {
+    z.x = z.x > 0.0f ? z.x : 0.0f;
+    z.y = z.y > 0.0f ? z.y : 0.0f;
+    z.z = z.z > 0.0f ? z.z : 0.0f;
+    z.w = z.w > 0.0f ? z.w : 0.0f;
+  }
+  reinterpret_cast<float4*>(out)[e] = z;
+}
+
+// backward, BatchNorm layers: per-tile sums of dz and dz * xhat with dz = g * [out > 0] (relu) or g.
+__global__ __launch_bounds__(256) void ml_bwd_sums_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                          const float* __restrict__ y, const float* __restrict__ bn, int R,
+                                                          int C, int relu, float* __restrict__ partial) {
+  const long long r0 = (long long)blockIdx.x * kRT;
+  const int rows = R - r0 < kRT ? (int)(R - r0) : kRT;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mean = bn[2 * C + c], invstd = bn[3 * C + c];
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int i = 0; i < rows; ++i) {
+      const long long o = (r0 + i) * C + c;
+      const float d = relu ? (out[o] > 0.0f ? g[o] : 0.0f) : g[o];
+      s1 += d;
+      s2 = __builtin_fmaf(d, (y[o] - mean) * invstd, s2);
+    }
+    float* p = partial + ((long long)blockIdx.x * C + c) * 2;
+    p[0] = s1;
+    p[1] = s2;
+  }
+}
+
+__global__ __launch_bounds__(64 * kSlices) void ml_bwd_coef_kernel(const float* __restrict__ partial, int rows, int C,
+                                                                   double count, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ bn, float* __restrict__ coef,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                   const CoopWs cw) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s1, s2;
+  const bool last = coop_colsum(rows, C, c, cw,
+                                [&](int e, bool& ok, double& x, double& y) {
+                                  const float2 t = *reinterpret_cast<const float2*>(partial + ((long long)e * C + c) * 2);
+                                  ok = true;
+                                  x = (double)t.x;
+                                  y = (double)t.y;
+                                },
+                                s1, s2);
+  if (!last || threadIdx.x >= 64) return;
+  const float mean = bn[2 * C + c], invstd = bn[3 * C + c];
+  const float alpha = gamma[c] * invstd;
+  const float gammap = (float)(-(double)alpha * s2 / count * (double)invstd);
+  coef[c] = alpha;
+  coef[C + c] = gammap;
+  coef[2 * C + c] = (float)(-(double)alpha * s1 / count - (double)gammap * (double)mean);
+  dgamma[c] = (float)s2;
+  dbeta[c] = (float)s1;
+}
+
+// dY = alpha * dz + gammap * y + betap (coef != NULL) or dz (coef == NULL); also the per-tile column sums of dY (the
+// bias gradient).  grid = tiles, block 256.
+__global__ __launch_bounds__(256) void ml_bwd_dy_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                        const float* __restrict__ y, const float* __restrict__ coef, int R,
+                                                        int C, int relu, float* __restrict__ dy,
+                                                        float* __restrict__ partial) {
+  const long long r0 = (long long)blockIdx.x * kRT;
+  const int rows = R - r0 < kRT ? (int)(R - r0) : kRT;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float alpha = 1.0f, gammap = 0.0f, betap = 0.0f;
+    if (coef != nullptr) {
+      alpha = coef[c];
+      gammap = coef[C + c];
+      betap = coef[2 * C + c];
+    }
+    float s = 0.0f;
+    for (int i = 0; i < rows; ++i) {
+      const long long o = (r0 + i) * C + c;
+      const float d = relu ? (out[o] > 0.0f ? g[o] : 0.0f) : g[o];
+      const float v = coef != nullptr ? __builtin_fmaf(alpha, d, __builtin_fmaf(gammap, y[o], betap)) : d;
+      dy[o] = v;
+      s += v;
+    }
+    partial[(long long)blockIdx.x * C + c] = s;
+  }
+}
+
+// column sums of a per-tile table [tiles][C]: block = 64 channels x 16 tile slices, slices merged in fixed order
+__global__ __launch_bounds__(1024) void ml_colsum_kernel(const float* __restrict__ partial, int tiles, int C,
+                                                         float* __restrict__ out) {
+  __shared__ double sm[16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  double s = 0.0;
+  for (int t = slice; t < tiles; t += 16) s += (double)partial[(long long)t * C + c];
+  sm[slice][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (slice == 0) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a += sm[k][threadIdx.x];
+    out[c] = (float)a;
+  }
+}
+
+__global__ void ml_transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * cols) return;
+  wt[(e % cols) * rows + e / cols] = w[e];
+}
+
+struct MlWs {
+  int* hdr;
+  unsigned* tickets;
+  float *ypre, *bn, *coef, *partial, *wt, *tnpart, *dy;
+  double* stage;
+  int64_t total;
+};
+
+MlWs ml_carve(char* base, int64_t R, int64_t K, int64_t N) {
+  MlWs w;
+  char* p = base;
+  auto take = [&](int64_t bytes) {
+    char* r = p;
+    p += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  const int64_t tiles = (R + kRT - 1) / kRT;
+  w.hdr = reinterpret_cast<int*>(take(64));
+  w.tickets = reinterpret_cast<unsigned*>(take(256));
+  w.ypre = reinterpret_cast<float*>(take(4 * R * N));
+  w.bn = reinterpret_cast<float*>(take(4 * 4 * N));
+  w.coef = reinterpret_cast<float*>(take(4 * 3 * N));
+  w.partial = reinterpret_cast<float*>(take(4 * tiles * N * 2));
+  w.wt = reinterpret_cast<float*>(take(4 * K * N));
+  w.tnpart = reinterpret_cast<float*>(take(4 * (int64_t)kChunks * N * K));
+  w.dy = reinterpret_cast<float*>(take(4 * R * N));
+  w.stage = reinterpret_cast<double*>(take(8 * 2 * N * ((tiles + kEB - 1) / kEB)));
+  w.total = p - base;
+  return w;
+}
+
+int ml_check(int64_t R, int64_t K, int64_t N, const char* who) {
+  MPA_REQUIRE(R >= 1 && R <= (1 << 24), "%s: 1 <= rows <= 2^24", who);
+  MPA_REQUIRE(K >= 64 && K % 64 == 0 && K <= 4096, "%s: input width must be a multiple of 64 (<= 4096)", who);
+  MPA_REQUIRE(N >= 64 && N % 64 == 0 && N <= 4096, "%s: output width must be a multiple of 64 (<= 4096)", who);
+  return MPA_OK;
+}
+
+template <typename Kern, typename... Args>
+void launch(Kern kern, dim3 grid, dim3 block, hipStream_t s, Args... args) {
+  hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
+}
+
+void ml_gemm_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, int Nout, int64_t R, const int* hdr,
+                hipStream_t s) {
+  const unsigned gx = (unsigned)((R + 127) / 128);
+  if (Nout % 128 == 0) launch(gemm_nt_kernel<128, false>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+  else launch(gemm_nt_kernel<64, false>, dim3(gx, Nout / 64), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+}
+
+}  // namespace
+
+extern "C" int mpa_mlp_layer_workspace(int64_t R, int64_t K, int64_t N, int64_t* bytes) {
+  if (int st = ml_check(R, K, N, "mlp_layer_workspace")) return st;
+  MPA_REQUIRE(bytes != nullptr, "mlp_layer_workspace: null pointer");
+  *bytes = ml_carve(nullptr, R, K, N).total;
+  return MPA_OK;
+}
+
+extern "C" int mpa_mlp_layer_forward(const float* x, int64_t ldx, const float* w, const float* bias, const float* gamma,
+                                     const float* beta, float* running_mean, float* running_var, int training,
+                                     float momentum, float eps, int relu, int64_t R, int64_t K, int64_t N, void* ws,
+                                     float* out, void* stream) {
+  if (int st = ml_check(R, K, N, "mlp_layer_forward")) return st;
+  MPA_REQUIRE(x && w && ws && out && ldx >= K && ldx % 4 == 0, "mlp_layer_forward: bad pointer / leading dimension");
+  MPA_REQUIRE(gamma == nullptr || (beta && running_mean && running_var), "mlp_layer_forward: incomplete BatchNorm");
+  MPA_REQUIRE((uintptr_t)ws % 256 == 0, "mlp_layer_forward: workspace must be 256-byte aligned");
+  hipStream_t s = mpa::as_stream(stream);
+  const MlWs m = ml_carve(static_cast<char*>(ws), R, K, N);
+  const int tiles = (int)((R + kRT - 1) / kRT);
+  const long long total4 = R * N / 4;
+  launch(ml_set_hdr_kernel, dim3(1), dim3(64), s, m.hdr, (int)R, m.tickets);
+  if (gamma == nullptr) {
+    ml_gemm_nt(x, (int)ldx, w, (int)K, out, (int)N, (int)N, R, m.hdr, s);
+    launch(ml_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), s, (const float*)out, (const float*)nullptr,
+           bias, total4, (int)N, relu, out);
+    return mpa::check_launch("mlp_layer_forward");
+  }
+  const CoopWs cw{m.stage, m.tickets};
+  ml_gemm_nt(x, (int)ldx, w, (int)K, m.ypre, (int)N, (int)N, R, m.hdr, s);
+  if (training) {
+    launch(ml_bias_stats_kernel, dim3((unsigned)tiles), dim3(256), s, m.ypre, bias, (int)R, (int)N, m.partial);
+    launch(ml_bn_finalize_kernel, dim3((unsigned)(N / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
+           (const float*)m.partial, tiles, (int)N, (double)R, gamma, beta, running_mean, running_var, momentum, eps, m.bn,
+           cw);
+  } else {
+    if (bias != nullptr)
+      launch(ml_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), s, (const float*)m.ypre,
+             (const float*)nullptr, bias, total4, (int)N, 0, m.ypre);
+    launch(ml_bn_from_running_kernel, dim3((unsigned)(N / 64)), dim3(64), s, (int)N, gamma, beta,
+           (const float*)running_mean, (const float*)running_var, eps, m.bn);
+  }
+  launch(ml_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), s, (const float*)m.ypre, (const float*)m.bn,
+         (const float*)nullptr, total4, (int)N, relu, out);
+  return mpa::check_launch("mlp_layer_forward");
+}
+
+extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int64_t ldx, const float* w,
+                                      const float* gamma, const float* out, int relu, int64_t R, int64_t K, int64_t N,
+                                      void* ws, float* grad_x, float* grad_w, float* grad_b, float* grad_gamma,
+                                      float* grad_beta, void* stream) {
+  if (int st = ml_check(R, K, N, "mlp_layer_backward")) return st;
+  MPA_REQUIRE(grad_out && x && w && out && ws && grad_w, "mlp_layer_backward: null pointer");
+  MPA_REQUIRE(gamma == nullptr || (grad_gamma && grad_beta), "mlp_layer_backward: BatchNorm gradients missing");
+  hipStream_t s = mpa::as_stream(stream);
+  const MlWs m = ml_carve(static_cast<char*>(ws), R, K, N);
+  const int tiles = (int)((R + kRT - 1) / kRT);
+  const CoopWs cw{m.stage, m.tickets};
+  if (gamma != nullptr) {
+    launch(ml_bwd_sums_kernel, dim3((unsigned)tiles), dim3(256), s, grad_out, out, (const float*)m.ypre,
+           (const float*)m.bn, (int)R, (int)N, relu, m.partial);
+    launch(ml_bwd_coef_kernel, dim3((unsigned)(N / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
+           (const float*)m.partial, tiles, (int)N, (double)R, gamma, (const float*)m.bn, m.coef, grad_gamma, grad_beta, cw);
+  }
+  launch(ml_bwd_dy_kernel, dim3((unsigned)tiles), dim3(256), s, grad_out, out, (const float*)m.ypre,
+         gamma != nullptr ? (const float*)m.coef : (const float*)nullptr, (int)R, (int)N, relu, m.dy, m.partial);
+  if (grad_b != nullptr)
+    launch(ml_colsum_kernel, dim3((unsigned)(N / 64)), dim3(1024), s, (const float*)m.partial, tiles, (int)N, grad_b);
+  // dW [N][K] = dY^T X
+  {
+    // enough chunks for ~512 blocks in the launch, each at least 64 rows
+    const int out_tiles = (int)(((N + 127) / 128) * (K % 128 == 0 ? K / 128 : K / 64));
+    int chunks = (512 + out_tiles - 1) / out_tiles;
+    if (chunks > (int)(R / 64)) chunks = (int)(R / 64);
+    chunks = chunks < 1 ? 1 : (chunks > kChunks ? kChunks : chunks);
+    const int rows_per_chunk = (int)(((R + chunks - 1) / chunks + 31) / 32 * 32);
+    const dim3 grid((unsigned)((N + 127) / 128), (unsigned)(K % 128 == 0 ? K / 128 : K / 64), (unsigned)chunks);
+    if (K % 128 == 0)
+      launch(gemm_tn_kernel<128>, grid, dim3(kGT), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
+             rows_per_chunk, (const int*)m.hdr);
+    else
+      launch(gemm_tn_kernel<64>, grid, dim3(kGT), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
+             rows_per_chunk, (const int*)m.hdr);
+    const long long elems = (long long)N * K;
+    launch(gemm_tn_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), s, (const float*)m.tnpart, chunks,
+           elems, grad_w);
+  }
+  if (grad_x != nullptr) {  // dX [R][K] = dY [R][N] . W [N][K]
+    launch(ml_transpose_kernel, dim3((unsigned)((N * K + 255) / 256)), dim3(256), s, w, (int)N, (int)K, m.wt);
+    ml_gemm_nt(m.dy, (int)N, m.wt, (int)N, grad_x, (int)K, (int)K, R, m.hdr, s);
+  }
+  return mpa::check_launch("mlp_layer_backward");
+}

@@ -4,14 +4,13 @@ rgl_net/network.py:12-162, rgl_net/modules.py:5-30, modules/rnn.py:6-46) with th
 the same state_dict keys (`edge_mlps.{i}.conv1.weight`, `node_mlps.{i}.bn3.running_mean`, `pose_predictors.{i}.*`,
 `relation_predictor_dense.mlp1.*`, `pose_extractor.*`, `grus.{i}.rnn.weight_ih_l0`, ...).
 
-What runs where: the part encoder (PointNet: csrc/pointnet.hip), every loss evaluation of the `gnn_iter` stacked
-predictions (fused assembly loss: csrc/assembly_loss.hip, grid_nn.hip) and the optimiser are the HIP hot path; the
-graph network itself — P x P edge MLPs over <= 20 parts, relation gating, the GRU — is ~1e10 FLOP per iteration on
-tiny tensors and stays on PyTorch-ROCm library ops, as SURVEY.md §8 row a19 scopes it.
+What runs where: the part encoder (PointNet: csrc/pointnet.hip, DGCNN: csrc/dgcnn_enc.hip), every loss evaluation of
+the `gnn_iter` stacked predictions (fused assembly loss: csrc/assembly_loss.hip, grid_nn.hip), the optimiser, and the
+bulk of the graph network — the P x P edge MLPs, the node MLPs and the wide layers of the relation nets (Conv1d /
+Linear + BatchNorm1d + ReLU layers: csrc/mlp.hip, exact-fp32 MFMA) and the pose heads — are the HIP hot path; the small
+rest (7-wide pose encoder, 512 -> 1 relation head, relation-weighted mean, the GRU) stays on PyTorch-ROCm library ops.
 
 Differences from the reference, none of them numerical beyond fp32 re-association:
-  * the edge MLP's first 1x1 conv is applied to the two halves of the pair feature separately
-    (W [f_i ; f_j] = W_a f_i + W_b f_j), so the [B, P, P, 2F] pair tensor is never materialised;
   * part features are extracted with the mask-in / zeros-out PointNet entry (no boolean-mask sync);
   * the GRU runs on the padded batch and the padded steps are masked instead of packing sequences through a
     `lengths.cpu()` round trip (modules/rnn.py:28) — see `_MaskedBiGRU`.
@@ -26,6 +25,7 @@ import torch.nn as nn
 
 from .base_model import BaseModel
 from .encoder import build_encoder
+from .mlp import mlp_layer, supported as mlp_supported
 from .regressor import StocasticPoseRegressor
 
 
@@ -43,8 +43,22 @@ class _PairMLP(nn.Module):
         self.bn3 = nn.BatchNorm1d(feat_len)
         self.final_relu = final_relu
 
+    def _rows(self, x):
+        """x [rows, cin] -> [rows, F]: the three Conv1d(k=1) + BatchNorm1d (+ ReLU) layers on the HIP library
+        (csrc/mlp.hip: exact-fp32 MFMA GEMMs, fixed-order BatchNorm statistics over all rows — BatchNorm1d over the
+        (batch, position) axes of the reference's [R, C, L] layout is exactly that)."""
+        h = mlp_layer(x, self.conv1.weight, self.conv1.bias, self.bn1, relu=True, training=self.training)
+        h = mlp_layer(h, self.conv2.weight, self.conv2.bias, self.bn2, relu=True, training=self.training)
+        return mlp_layer(h, self.conv3.weight, self.conv3.bias, self.bn3, relu=self.final_relu, training=self.training)
+
+    MIN_ROWS = 4096  # below that the layers are launch-latency bound and the library's small-GEMM kernels do as well
+
+    def _hip_ok(self, x, cin, rows):
+        return (x.is_cuda and rows >= self.MIN_ROWS and mlp_supported(cin, 512)
+                and mlp_supported(512, self.conv3.out_channels))
+
     def _tail(self, h):
-        """h [R, 512, L]: output of conv1 -> [R, L, F]."""
+        """h [R, 512, L]: output of conv1 -> [R, L, F] (library ops: widths outside csrc/mlp.hip)."""
         h = torch.relu(self.bn1(h))
         h = torch.relu(self.bn2(self.conv2(h)))
         h = self.bn3(self.conv3(h))
@@ -54,12 +68,18 @@ class _PairMLP(nn.Module):
 
     def forward(self, x):
         """x [R, L, cin] -> [R, L, F]."""
+        R, L, cin = x.shape
+        if self._hip_ok(x, cin, R * L):
+            return self._rows(x.reshape(R * L, cin)).view(R, L, -1)
         return self._tail(self.conv1(x.transpose(1, 2)))
 
     def forward_pairs(self, a, b):
-        """Rows = (sample, part i), positions = part j, input [a_i ; b_j]: a, b [B, P, F] -> [B*P, P, F_out]
-        without building the pair tensor."""
+        """Rows = (sample, part i), positions = part j, input [a_i ; b_j]: a, b [B, P, F] -> [B*P, P, F_out]."""
         B, P, F = a.shape
+        if self._hip_ok(a, 2 * F, B * P * P):
+            pair = torch.cat([a[:, :, None, :].expand(B, P, P, F), b[:, None, :, :].expand(B, P, P, F)], dim=-1)
+            return self._rows(pair.reshape(B * P * P, 2 * F)).view(B * P, P, -1)
+        # library ops: the first conv applied to the two halves separately, the pair tensor is never materialised
         w = self.conv1.weight[:, :, 0]                         # [512, 2F]
         pa = a @ w[:, :F].t() + self.conv1.bias                # [B, P, 512]  (depends on i)
         pb = b @ w[:, F:].t()                                  # [B, P, 512]  (depends on j)
@@ -77,6 +97,12 @@ class RelationNet(nn.Module):
         self.mlp3 = nn.Linear(512, 1)
 
     def forward(self, x):
+        """x [B, P*P, 256] -> [B, P*P, 1]; the two wide layers on csrc/mlp.hip, the 512 -> 1 head on library ops."""
+        if x.is_cuda and x.numel() // x.shape[-1] >= _PairMLP.MIN_ROWS:
+            lead = x.shape[:-1]
+            h = mlp_layer(x.reshape(-1, x.shape[-1]), self.mlp1.weight, self.mlp1.bias, None, relu=True)
+            h = mlp_layer(h, self.mlp2.weight, self.mlp2.bias, None, relu=True)
+            return torch.sigmoid(self.mlp3(h)).view(*lead, 1)
         return torch.sigmoid(self.mlp3(torch.relu(self.mlp2(torch.relu(self.mlp1(x))))))
 
 

@@ -1,0 +1,83 @@
+"""One MLP layer (Linear / Conv1d k=1 [+ BatchNorm1d] [+ ReLU]) over rows on the HIP library (csrc/mlp.hip) — the building
+block of the graph networks' edge / node MLPs and relation nets (reference models/dgl/modules.py:5-73,
+models/rgl_net/modules.py:5-30).  The torch modules keep holding the parameters (same state_dict keys); this only
+replaces what `conv(x)`, `bn(.)`, `relu(.)` compute."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class _MLPLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, running, training, momentum, eps, relu):
+        R, K = x.shape
+        N = w.shape[0]
+        dev = x.device
+        L = _lib.lib()
+        nbytes = ctypes.c_int64()
+        _lib.check(L.mpa_mlp_layer_workspace(R, K, N, ctypes.byref(nbytes)), "mpa_mlp_layer_workspace")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        out = torch.empty((R, N), dtype=torch.float32, device=dev)
+        rm, rv = running if running is not None else (None, None)
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"mlp_layer_forward[{R}x{K}x{N}]")
+            st = L.mpa_mlp_layer_forward(_lib.ptr(x), x.stride(0), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(gamma),
+                                         _lib.ptr(beta), _lib.ptr(rm), _lib.ptr(rv), int(training), float(momentum),
+                                         float(eps), int(relu), R, K, N, _lib.ptr(ws), _lib.ptr(out),
+                                         _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_mlp_layer_forward")
+        ctx.meta = (bool(relu), bool(training), bias is not None, gamma is not None)
+        ctx.save_for_backward(x, w, gamma, out, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w, gamma, out, ws = ctx.saved_tensors
+        relu, training, has_bias, has_bn = ctx.meta
+        if has_bn and not training:
+            raise RuntimeError("MLP layer: backward is implemented for training-mode BatchNorm only")
+        R, K = x.shape
+        N = w.shape[0]
+        dev = x.device
+        gx = torch.empty((R, K), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
+        gg = torch.empty(N, dtype=torch.float32, device=dev) if has_bn else None
+        gbe = torch.empty(N, dtype=torch.float32, device=dev) if has_bn else None
+        grad_out = grad_out.contiguous()
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"mlp_layer_backward[{R}x{K}x{N}]")
+            st = _lib.lib().mpa_mlp_layer_backward(
+                _lib.ptr(grad_out), _lib.ptr(x), x.stride(0), _lib.ptr(w), _lib.ptr(gamma), _lib.ptr(out), int(relu), R, K,
+                N, _lib.ptr(ws), _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(gg), _lib.ptr(gbe),
+                _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_mlp_layer_backward")
+        return gx, gw, gb, gg, gbe, None, None, None, None, None
+
+
+def supported(in_dim, out_dim):
+    return in_dim % 64 == 0 and out_dim % 64 == 0 and 64 <= in_dim <= 4096 and 64 <= out_dim <= 4096
+
+
+def mlp_layer(x, weight, bias=None, bn=None, relu=True, training=True):
+    """x [R, K] (CUDA, fp32, rows contiguous) -> [R, N] = act(bn(x W^T + b)).  `weight` [N, K] or a Conv1d weight
+    [N, K, 1]; `bn`: an nn.BatchNorm1d (its running statistics are updated in training mode) or None."""
+    if not x.is_cuda:
+        raise RuntimeError("mlp_layer: only CUDA (HIP) tensors are supported — no CPU fallback")
+    w = weight.reshape(weight.shape[0], -1)
+    x = x.float()
+    if x.stride(1) != 1 or x.stride(0) % 4 != 0:
+        x = x.contiguous()
+    if bn is None:
+        return _MLPLayerFn.apply(x, w, bias, None, None, None, training, 0.0, 0.0, relu)
+    if training:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+    return _MLPLayerFn.apply(x, w, bias, bn.weight, bn.bias, (bn.running_mean, bn.running_var), training,
+                             bn.momentum, bn.eps, relu)

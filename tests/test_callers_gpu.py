@@ -72,3 +72,68 @@ def test_caller_step_matches_reference(golden, cuda_device, name):
     for k, v in model.state_dict().items():
         if "running_" in k:
             param_fill.compare(record, "sd1.", k, v.cpu().numpy(), rel=1e-4)
+
+
+@pytest.mark.parametrize("final_relu,rows,L,cin,feat", [(True, 7, 5, 128, 64), (False, 640, 1, 512, 128), (True, 40, 20, 256, 128)])
+def test_pair_mlp_hip_layers_match_library_ops(cuda_device, final_relu, rows, L, cin, feat):
+    """The Conv1d(k=1) + BatchNorm1d + ReLU layers of MLP3 / MLP4 / MLP5 on csrc/mlp.hip against the same module on
+    torch's library ops (reference models/dgl/modules.py:5-58, rgl_net/modules.py:5-30): outputs, every gradient,
+    running statistics; and evaluation mode."""
+    import copy
+    from multi_part_assembly_amd.gnn import _PairMLP
+    torch.manual_seed(rows)
+    mine = _PairMLP(cin, feat, final_relu=final_relu).to(cuda_device).train()
+    mine.MIN_ROWS = 1  # force the HIP layers at these small sizes
+    with torch.no_grad():
+        for bn in (mine.bn1, mine.bn2, mine.bn3):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.1)
+    ref = copy.deepcopy(mine)
+    x = torch.randn(rows, L, cin, device=cuda_device)
+    w = torch.randn(rows, L, feat, device=cuda_device)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    out = mine(xa)
+    (out * w).sum().backward()
+    want = ref._tail(ref.conv1(xb.transpose(1, 2)))
+    (want * w).sum().backward()
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    assert rel(out.detach(), want.detach()) < 1e-4
+
+    def close(a, b, who):  # three stacked BatchNorm backwards in fp32: worst entry 2e-2, all but 1 % of entries 2e-3
+        assert rel(a, b) < 2e-2, who
+        assert float(((a - b).abs() > 2e-3 * b.abs().max()).float().mean()) < 0.01, who
+
+    close(xa.grad, xb.grad, "x")
+    for (k, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        if "conv" in k and "bias" in k:   # a bias in front of a BatchNorm: its gradient is zero up to rounding
+            assert float(p.grad.abs().max()) < 1e-3 * float(w.abs().sum())
+        else:
+            close(p.grad, q.grad, k)
+    for (k, a), (_, b) in zip(mine.named_buffers(), ref.named_buffers()):
+        if "running" in k:
+            assert rel(a, b) < 1e-4, k
+    mine.eval()
+    ref.eval()
+    with torch.no_grad():
+        assert rel(mine(x), ref._tail(ref.conv1(x.transpose(1, 2)))) < 1e-4
+
+
+def test_relation_net_hip_layers_match_library_ops(cuda_device):
+    import copy
+    from multi_part_assembly_amd.gnn import RelationNet
+    torch.manual_seed(3)
+    from multi_part_assembly_amd.gnn import _PairMLP
+    mine = RelationNet().to(cuda_device)
+    ref = copy.deepcopy(mine)
+    x = torch.randn(8, 25 * 25, 256, device=cuda_device)  # 5000 pair rows: above _PairMLP.MIN_ROWS
+    assert x.shape[0] * x.shape[1] >= _PairMLP.MIN_ROWS
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    out = mine(xa)
+    out.square().sum().backward()
+    want = torch.sigmoid(ref.mlp3(torch.relu(ref.mlp2(torch.relu(ref.mlp1(xb))))))
+    want.square().sum().backward()
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    assert rel(out.detach(), want.detach()) < 1e-5
+    assert rel(xa.grad, xb.grad) < 1e-4
+    for (k, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel(p.grad, q.grad) < 1e-4, k
