@@ -596,11 +596,13 @@ __global__ void dg_agg_bwd_sums_kernel(const float* __restrict__ hcat, const flo
   p[1] = s2;
 }
 
-// Transposed kNN graph of every part: rptr [M][N + 1], rlist [R][20] = the in-edges of every point as
-// (source point * 32 + neighbour slot of the target in the source's list), ascending (fixed summation order downstream).  grid = M parts, block 1024; the part's whole list (N * 20 sources,
+// Transposed kNN graph of every part, points in the order of descending in-degree: order [M][N] (rank -> point),
+// rptr [M][N + 1] (rank -> offset), rlist [R][20] = the in-edges of every point as (source point * 32 + neighbour slot
+// of the target in the source's list), ascending (fixed summation order downstream).  grid = M parts, block 1024; the part's whole list (N * 20 sources,
 // 40 KB) is built and sorted in LDS and written out once, coalesced.
 __global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* __restrict__ idx, int N,
-                                                          int* __restrict__ rptr, unsigned short* __restrict__ rlist,
+                                                          int* __restrict__ rptr, int* __restrict__ order,
+                                                          unsigned short* __restrict__ rlist,
                                                           const int* __restrict__ hdr) {
   __shared__ int cnt[kMaxN];
   __shared__ int beg[kMaxN + 1];
@@ -656,10 +658,54 @@ __global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* 
     }
   }
   __syncthreads();
+  // Points in the order of DESCENDING in-degree (ties: ascending index): the backward gathers 16 points per wave pass
+  // and a pass takes as many rounds as its longest list — with the points in index order that is ~35 rounds for a
+  // mean of 20 in-edges; in degree order the lists of a pass are equally long.  Bitonic sort of (511 - degree) << 10 |
+  // point in LDS (1024 keys, one per thread), then the lists are written out in that order.
+  __shared__ unsigned key[kMaxN];
+  {
+    const int deg = t < N ? cnt[t] - beg[t] : 0;
+    key[t] = t < N ? ((unsigned)(511 - (deg > 511 ? 511 : deg)) << 10) | (unsigned)t : 0xffffffffu;
+  }
+  __syncthreads();
+  for (int k = 2; k <= kMaxN; k <<= 1) {
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      const int partner = t ^ jj;
+      if (partner > t) {
+        const unsigned a = key[t], b = key[partner];
+        const bool up = (t & k) == 0;
+        if ((a > b) == up) {
+          key[t] = b;
+          key[partner] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // rank r -> point order[r]; offsets of the lists in rank order (exclusive scan of the degrees in rank order)
+  const int pj = t < N ? (int)(key[t] & 1023u) : 0;
+  const int dg_ = t < N ? cnt[pj] - beg[pj] : 0;
+  int inc = dg_;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += wsum[w];
+  const int start = before + inc - dg_;
   int* rp = rptr + (long long)v * (N + 1);
+  int* ord = order + (long long)v * N;
   unsigned short* rl = rlist + (long long)v * E;
-  for (int j = t; j <= N; j += 1024) rp[j] = beg[j];
-  for (int e = t; e < E; e += 1024) rl[e] = lst[e];
+  if (t < N) {
+    rp[t] = start;
+    ord[t] = pj;
+    const int src0 = beg[pj];
+    for (int a = 0; a < dg_; ++a) rl[start + a] = lst[src0 + a];
+  }
+  if (t == N - 1) rp[N] = start + dg_;
 }
 
 // d(uv) [R][2CO] in ONE pass over the transposed graph.  grid = (CO / 16, M), block 512.  LDS panels of a 16-channel
@@ -672,7 +718,7 @@ __global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* 
 constexpr int kBS = 16;          // channels per slice
 constexpr int kRun = 512;        // scratch entries per wave (16 points x ~20 in-edges, with room for hubs)
 __global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict__ uv, int CO,
-                                                         const int* __restrict__ rptr,
+                                                         const int* __restrict__ rptr, const int* __restrict__ order,
                                                          const unsigned short* __restrict__ rlist,
                                                          const float* __restrict__ dz,
                                                          const unsigned char* __restrict__ ssel,
@@ -729,19 +775,23 @@ __global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict
   // with coalesced loads, copied to the wave's scratch, read from there by every lane
   unsigned short pre[kRun / 64];
   float4 un, sn;
-  auto request = [&](int j0) {  // j0: first point of the pass (wave-uniform)
-    const int base = rps[j0 < N ? j0 : N];
+  // A pass = 16 consecutive RANKS of the degree order (equally long lists); the passes are dealt to the waves round
+  // robin so that every wave gets long and short ones.
+  const int* ord = order + (long long)v * N;
+  int jn = 0;
+  auto request = [&](int r0) {  // r0: first rank of the pass (wave-uniform)
+    const int base = rps[r0 < N ? r0 : N];
 #pragma unroll
     for (int u = 0; u < kRun / 64; ++u) pre[u] = rl[base + 64 * u + lane < last ? base + 64 * u + lane : last];
-    const int jc = j0 + q < N ? j0 + q : N - 1;
-    un = *reinterpret_cast<const float4*>(up + (long long)jc * 2 * CO + c0 + 4 * cq);
-    sn = *reinterpret_cast<const float4*>(s1in + ((long long)v * N + jc) * CO + c0 + 4 * cq);
+    jn = ord[r0 + q < N ? r0 + q : N - 1];
+    un = *reinterpret_cast<const float4*>(up + (long long)jn * 2 * CO + c0 + 4 * cq);
+    sn = *reinterpret_cast<const float4*>(s1in + ((long long)v * N + jn) * CO + c0 + 4 * cq);
   };
   request(wave * 16);
   for (int j0 = wave * 16; j0 < N; j0 += 128) {
-    const int j = j0 + q;
+    const int rk = j0 + q, j = jn;
     const int base = rps[j0];
-    const int b = j < N ? rps[j] : base, e = j < N ? rps[j + 1] : base;
+    const int b = rk < N ? rps[rk] : base, e = rk < N ? rps[rk + 1] : base;
 #pragma unroll
     for (int u = 0; u < kRun / 64; ++u) sc[64 * u + lane] = pre[u];
     const float4 u4 = un, s4 = sn;
@@ -796,7 +846,7 @@ __global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (j < N) {
+    if (rk < N) {
       const float deg = (float)(e - b), kf = (float)kNbr;
       const float4 vv = *reinterpret_cast<const float4*>(&Vp[j * kBS + 4 * cq]);
       const float4 wj = *reinterpret_cast<const float4*>(&Wp[j * kBS + 4 * cq]);
@@ -817,7 +867,7 @@ __global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict
 
 // ---- workspace ----------------------------------------------------------------------------------------------------------------
 struct Ws {
-  int *hdr, *vlist, *rank, *arg5, *rptr;
+  int *hdr, *vlist, *rank, *arg5, *rptr, *order;
   unsigned* tickets;
   float4* x0;
   float *hcat, *uv[4], *esel[4], *s1[4], *y5, *norm, *bn[5], *coef, *partial, *wstk[4], *wstt[4], *w5t, *pooled,
@@ -873,6 +923,7 @@ Ws dg_carve(char* base, int64_t M, int64_t N, int64_t F) {
   w.dz = reinterpret_cast<float*>(take(4 * R * kCO[3]));
   w.gstk = reinterpret_cast<float*>(take(4 * kCat * 128));
   w.rptr = reinterpret_cast<int*>(take(4 * M * (N + 1)));
+  w.order = reinterpret_cast<int*>(take(4 * M * N));
   w.rlist = reinterpret_cast<unsigned short*>(take(2 * R * kNbr));
   w.stage = reinterpret_cast<double*>(take(8 * 2 * kCat * ((prow + kEB - 1) / kEB)));
   w.total = p - base;
@@ -1047,11 +1098,11 @@ extern "C" int mpa_dgcnn_backward(const float* grad_feat, const float* const* co
     launch(dg_bwd_coef_kernel, dim3((unsigned)(CO / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
            (const float*)w.partial, (int)tiles, CO, kNbr, bn_w[l], (const float*)w.bn[l], w.coef, grad_bn_w[l],
            grad_bn_b[l], cw, hdr);
-    launch(dg_reverse_kernel, dim3((unsigned)M), dim3(1024), s, (const unsigned short*)w.idx[l], (int)N, w.rptr, w.rlist,
-           hdr);
+    launch(dg_reverse_kernel, dim3((unsigned)M), dim3(1024), s, (const unsigned short*)w.idx[l], (int)N, w.rptr, w.order,
+           w.rlist, hdr);
     launch(dg_agg_bwd_kernel, dim3((unsigned)(CO / kBS), (unsigned)M), dim3(kAT), s, (const float*)w.uv[l], CO,
-           (const int*)w.rptr, (const unsigned short*)w.rlist, (const float*)w.dz, (const unsigned char*)w.ssel[l],
-           (const float*)w.s1[l], (const float*)w.coef, (int)N, w.duv, hdr);
+           (const int*)w.rptr, (const int*)w.order, (const unsigned short*)w.rlist, (const float*)w.dz,
+           (const unsigned char*)w.ssel[l], (const float*)w.s1[l], (const float*)w.coef, (int)N, w.duv, hdr);
     if (l == 0) {
       const int t1 = (int)((R + kFirstTile - 1) / kFirstTile);
       launch(dg_first_wgrad_kernel, dim3((unsigned)t1), dim3(512), s, (const float*)w.duv, (const float4*)w.x0, w.tnpart,
