@@ -178,8 +178,8 @@ __global__ void dg_first_dgrad_kernel(const float* __restrict__ duv, const float
 }
 
 // ---- edge aggregation, forward ------------------------------------------------------------------------------------------------
-// grid = (CO / 32, M parts), block 512.  LDS: the part's U slice [N][32].  Lane = (point slot q = lane / 16, channel
-// pair cp = lane % 16): a wave gathers for 4 points at once with ds_read_b64, 8 waves -> 32 points per pass.
+// grid = (CO / 32, M parts), block 512.  LDS: the part's U slice [N][32].  Lane = (point slot q = lane / 8, channel
+// quad cq = lane % 8): a wave gathers for 8 points at once with ds_read_b128, 8 waves -> 64 points per pass.
 constexpr int kAT = 512;
 
 // Copy a 32-channel column slice (row stride `ld` floats, N rows) between global memory and an LDS panel [N][32] with
@@ -207,21 +207,24 @@ __global__ __launch_bounds__(kAT) void dg_agg_fwd_kernel(const float* __restrict
                                                          float* __restrict__ s1out, float* __restrict__ partial,
                                                          const int* __restrict__ hdr) {
   __shared__ __attribute__((aligned(16))) float Us[kMaxN * 32];
-  __shared__ float red[32][16][4];
+  __shared__ float red[64][32][2];
   const int v = blockIdx.y;
   if (v >= hdr[0]) return;
   const int c0 = blockIdx.x * 32;
   const float* up = uv + (long long)v * N * 2 * CO;
   dg_load_slice(up + c0, 2 * CO, N, Us);
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cp = lane & 15, q = lane >> 4;
-  const float gx = gamma[c0 + 2 * cp] < 0.0f ? -1.0f : 1.0f, gy = gamma[c0 + 2 * cp + 1] < 0.0f ? -1.0f : 1.0f;
-  float a1x = 0.0f, a1y = 0.0f, a2x = 0.0f, a2y = 0.0f;
-  // the neighbour list (5 x 8 bytes) and V of the NEXT point are requested before the current point's 20 LDS gathers:
-  // without that every pass of the loop is one exposed L2 round trip
+  // lane = (point slot q of 8, channel quad cq of 8): one ds_read_b128 per neighbour feeds four channels, so the index
+  // unpacking and address arithmetic are paid once per four channels (the kernel is bound by VALU issue)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cq = lane & 7, q = lane >> 3;
+  float sg[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sg[k] = gamma[c0 + 4 * cq + k] < 0.0f ? -1.0f : 1.0f;
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  // the neighbour list (5 x 8 bytes) and V of the NEXT point are requested before the current point's 20 LDS gathers
   unsigned wv[10], wn[10];
-  float2 vv, vn = make_float2(0.0f, 0.0f);
-  auto request = [&](int i, unsigned (&w)[10], float2& vout) {
+  float4 vv, vn = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto request = [&](int i, unsigned (&w)[10], float4& vout) {
     const int ic = i < N ? i : N - 1;
     const uint2* ip = reinterpret_cast<const uint2*>(idx + ((long long)v * N + ic) * kNbr);
 #pragma unroll
@@ -230,56 +233,61 @@ __global__ __launch_bounds__(kAT) void dg_agg_fwd_kernel(const float* __restrict
       w[2 * u] = t.x;
       w[2 * u + 1] = t.y;
     }
-    vout = *reinterpret_cast<const float2*>(up + (long long)ic * 2 * CO + CO + c0 + 2 * cp);
+    vout = *reinterpret_cast<const float4*>(up + (long long)ic * 2 * CO + CO + c0 + 4 * cq);
   };
-  request(wave * 4 + q, wn, vn);
-  for (int i = wave * 4 + q; i < N; i += 32) {
+  request(wave * 8 + q, wn, vn);
+  for (int i = wave * 8 + q; i < N; i += 64) {
     const long long row = (long long)v * N + i;
 #pragma unroll
     for (int u = 0; u < 10; ++u) wv[u] = wn[u];
     vv = vn;
-    request(i + 32, wn, vn);
-    float bx = -__builtin_inff(), by = -__builtin_inff(), sux = 0.0f, suy = 0.0f, sqx = 0.0f, sqy = 0.0f;
-    int ax = 0, ay = 0;
+    request(i + 64, wn, vn);
+    float best[4], su[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+    int at[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) best[k] = -__builtin_inff();
 #pragma unroll
     for (int t = 0; t < kNbr; ++t) {
       const int j = (wv[t >> 1] >> (16 * (t & 1))) & 0xffff;
-      const float2 u = *reinterpret_cast<const float2*>(&Us[j * 32 + 2 * cp]);
-      const float sx = gx * u.x, sy = gy * u.y;
-      if (sx > bx) {
-        bx = sx;
-        ax = t;
+      const float4 u4 = *reinterpret_cast<const float4*>(&Us[j * 32 + 4 * cq]);
+      const float u[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float sx = sg[k] * u[k];
+        if (sx > best[k]) {
+          best[k] = sx;
+          at[k] = t;
+        }
+        su[k] += u[k];
+        sq[k] = __builtin_fmaf(u[k], u[k], sq[k]);
       }
-      if (sy > by) {
-        by = sy;
-        ay = t;
-      }
-      sux += u.x;
-      suy += u.y;
-      sqx = __builtin_fmaf(u.x, u.x, sqx);
-      sqy = __builtin_fmaf(u.y, u.y, sqy);
     }
-    const long long o = row * CO + c0 + 2 * cp;
-    *reinterpret_cast<float2*>(esel + o) = make_float2(gx * bx + vv.x, gy * by + vv.y);
-    *reinterpret_cast<uchar2*>(ssel + o) = make_uchar2((unsigned char)ax, (unsigned char)ay);
-    *reinterpret_cast<float2*>(s1out + o) = make_float2(sux, suy);
+    const float vk[4] = {vv.x, vv.y, vv.z, vv.w};
+    const long long o = row * CO + c0 + 4 * cq;
+    *reinterpret_cast<float4*>(esel + o) = make_float4(sg[0] * best[0] + vk[0], sg[1] * best[1] + vk[1],
+                                                       sg[2] * best[2] + vk[2], sg[3] * best[3] + vk[3]);
+    *reinterpret_cast<uchar4*>(ssel + o) =
+        make_uchar4((unsigned char)at[0], (unsigned char)at[1], (unsigned char)at[2], (unsigned char)at[3]);
+    *reinterpret_cast<float4*>(s1out + o) = make_float4(su[0], su[1], su[2], su[3]);
     // BatchNorm sums over the 20 edges e = U_j + V_i:  sum e = S + k V,  sum e^2 = Q + 2 V S + k V^2
-    a1x += sux + (float)kNbr * vv.x;
-    a1y += suy + (float)kNbr * vv.y;
-    a2x += sqx + 2.0f * vv.x * sux + (float)kNbr * vv.x * vv.x;
-    a2y += sqy + 2.0f * vv.y * suy + (float)kNbr * vv.y * vv.y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a1[k] += su[k] + (float)kNbr * vk[k];
+      a2[k] += sq[k] + 2.0f * vk[k] * su[k] + (float)kNbr * vk[k] * vk[k];
+    }
   }
-  red[wave * 4 + q][cp][0] = a1x;
-  red[wave * 4 + q][cp][1] = a1y;
-  red[wave * 4 + q][cp][2] = a2x;
-  red[wave * 4 + q][cp][3] = a2y;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[wave * 8 + q][4 * cq + k][0] = a1[k];
+    red[wave * 8 + q][4 * cq + k][1] = a2[k];
+  }
   __syncthreads();
-  if (threadIdx.x < 32) {  // thread = channel of the slice; the 32 point slots in fixed order
+  if (threadIdx.x < 32) {  // thread = channel of the slice; the 64 point slots in fixed order
     const int c = threadIdx.x;
     float s = 0.0f, ss = 0.0f;
-    for (int k = 0; k < 32; ++k) {
-      s += red[k][c >> 1][c & 1];
-      ss += red[k][c >> 1][2 + (c & 1)];
+    for (int k = 0; k < 64; ++k) {
+      s += red[k][c][0];
+      ss += red[k][c][1];
     }
     float* d = partial + ((long long)v * CO + c0 + c) * 2;
     d[0] = s;
