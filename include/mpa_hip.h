@@ -280,6 +280,25 @@ int mpa_mlp_layer_backward(const float* grad_out, const float* x, int64_t ldx, c
                            float* grad_w, float* grad_b, float* grad_gamma, float* grad_beta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Recurrent half of a single-layer (bi)directional GRU — replaces the per-step library launches behind
+ *   RNNWrapper(nn.GRU(batch_first, bidirectional)) : multi_part_assembly/models/modules/rnn.py:6-46
+ *   RGLNet.forward                                 : multi_part_assembly/models/rgl_net/network.py:118-127
+ * The input projections gi[d][b][t] = W_ih x + b_ih [D,B,T,3H] (gate order r, z, n as torch.nn.GRU) are one GEMM done by
+ * the caller; this runs the T sequential steps of D directions in ONE launch:
+ *   r = sigmoid(gi_r + W_hr h + b_hr), z = sigmoid(gi_z + W_hz h + b_hz), n = tanh(gi_n + r (W_hn h + b_hn)),
+ *   h' = (1 - z) n + z h,   out [D,B,T,H] = h' of every step.
+ * h0 [D,B,H], whh [D,3H,H], bhh [D,3H].  H = 128, 256 or 512, B <= 64, D = 1 or 2.  `ws` (mpa_gru_workspace floats)
+ * carries the gates to backward.  backward: grad_out [D,B,T,H] -> grad_gi [D,B,T,3H], grad_whh, grad_bhh (overwritten);
+ * deterministic (partials summed in block order, no float atomics).  Sequences of different lengths: run the padded
+ * batch (valid steps first) and mask the outputs — the reverse direction on the per-sample reversed valid prefix.
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_gru_workspace(int64_t D, int64_t B, int64_t T, int64_t H, int64_t* float_elems);
+int mpa_gru_forward(const float* gi, const float* h0, const float* whh, const float* bhh, int64_t D, int64_t B, int64_t T,
+                    int64_t H, float* ws, float* out, void* stream);
+int mpa_gru_backward(const float* grad_out, const float* h0, const float* whh, const float* out, int64_t D, int64_t B,
+                     int64_t T, int64_t H, float* ws, float* grad_gi, float* grad_whh, float* grad_bhh, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Part-relation transformer encoder — replaces
  *   TransformerEncoder.forward : multi_part_assembly/models/pn_transformer/transformer.py:63-79
  *   (nn.TransformerEncoder of pre-LN nn.TransformerEncoderLayer, ReLU FFN, batch_first,

@@ -57,6 +57,9 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_mlp_layer_workspace": (_INT, [_I64, _I64, _I64, _P]),
     "mpa_mlp_layer_forward": (_INT, [_P, _I64, _P, _P, _P, _P, _P, _P, _INT, _F32, _F32, _INT, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_mlp_layer_backward": (_INT, [_P, _P, _I64, _P, _P, _P, _INT, _I64, _I64, _I64] + [_P] * 7),
+    "mpa_gru_workspace": (_INT, [_I64, _I64, _I64, _I64, _P]),
+    "mpa_gru_forward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P]),
+    "mpa_gru_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
     "mpa_transformer_workspace": (_INT, [_I64] * 6 + [_P]),
     "mpa_transformer_forward": (_INT, [_P, _P, _P] + [_I64] * 6 + [_F32, _U64, _P, _P, _P, _P]),
     "mpa_transformer_backward": (_INT, [_P, _P, _P] + [_I64] * 6 + [_F32, _U64, _P, _P, _P, _P, _P]),

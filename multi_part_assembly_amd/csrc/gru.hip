@@ -1,0 +1,274 @@
+// Recurrent half of a (bi)directional single-layer GRU over short sequences — forward and backward through time — for
+// gfx950: replaces the per-step cuDNN/MIOpen launches behind
+//   RNNWrapper(nn.GRU(bidirectional))   multi_part_assembly/models/modules/rnn.py:6-46
+//   RGLNet.forward                      multi_part_assembly/models/rgl_net/network.py:50-68,118-127
+// (B = 32 shapes, T = P = 20 parts, hidden 2F = 256, three GRUs per training step, two directions each: MIOpen runs it
+// as ~2500 tiny launches per step, which makes the whole RGL-NET step host-bound).
+//
+// The input projections  gi[t] = W_ih x_t + b_ih  of all steps are ONE GEMM outside (library op, autograd handles it);
+// this file does what is sequential:
+//   r = sigmoid(gi_r + W_hr h + b_hr),  z = sigmoid(gi_z + W_hz h + b_hz),  n = tanh(gi_n + r * (W_hn h + b_hn)),
+//   h' = (1 - z) * n + z * h                                                     (torch.nn.GRU's equations and gate order)
+// ONE launch per pass for both directions: grid = (H / 16, directions).  A block owns 16 hidden units — its 48 rows of
+// W_hh stay in LDS for the whole sequence — and the blocks of a direction meet at a grid barrier after every step (the
+// new hidden state goes through global memory).  Backward through time keeps its 48 x H slice of dW_hh in registers,
+// hands the partial dL/dh_{t-1} of its rows to the other blocks through global memory and sums the partials in block
+// order: no atomics on floats, bit-reproducible.  All blocks must be co-resident (2 * H/16 <= 256 CUs).
+#include "common.h"
+
+namespace {
+
+constexpr int kU = 16;       // hidden units per block
+constexpr int kGT = 256;     // threads per block
+constexpr int kMaxH = 512;
+constexpr int kMaxB = 64;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// all blocks of one direction: arrive, then wait until `target` arrivals in total (monotone counter, zeroed per launch)
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(counter, 1u);
+    while (atomicAdd(counter, 0u) < target) __builtin_amdgcn_s_sleep(1);
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+// gi [D][B][T][3H], h0 [D][B][H], whh [D][3H][H], bhh [D][3H] -> out [D][B][T][H]; saved [D][B][T][4][H] = r, z, n, hn.
+template <int H>
+__global__ __launch_bounds__(kGT) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ h0,
+                                                      const float* __restrict__ whh, const float* __restrict__ bhh,
+                                                      int B, int T, float* __restrict__ out,
+                                                      float* __restrict__ saved, unsigned* __restrict__ counters) {
+  extern __shared__ float smem[];
+  constexpr int LD = H + 1;              // padded rows: the 16 units / 4 samples of a wave read the same column of
+  float* W = smem;                       // different rows in one instruction  ([3 * kU][LD]: rows r(u0..), z(..), n(..))
+  float* hp = smem + 3 * kU * LD;        // [B][LD] previous hidden state
+  const int d = blockIdx.y, u0 = blockIdx.x * kU, nblk = gridDim.x;
+  const float* wd = whh + (long long)d * 3 * H * H;
+  for (int e = threadIdx.x; e < 3 * kU * H; e += kGT) {
+    const int row = e / H, k = e % H, gate = row / kU, u = row % kU;
+    W[row * LD + k] = wd[(long long)(gate * H + u0 + u) * H + k];
+  }
+  const float* gid = gi + (long long)d * B * T * 3 * H;
+  float* od = out + (long long)d * B * T * H;
+  float* sd = saved + (long long)d * B * T * 4 * H;
+  unsigned* ctr = counters + d;
+  for (int t = 0; t < T; ++t) {
+    // previous hidden state of ALL units (written by all blocks of this direction in the previous step)
+    for (int e = threadIdx.x; e < B * H; e += kGT) {
+      const int b = e / H, k = e % H;
+      hp[b * LD + k] = t == 0 ? h0[((long long)d * B + b) * H + k] : od[((long long)b * T + (t - 1)) * H + k];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < B * kU; e += kGT) {  // (sample, own unit)
+      const int b = e / kU, u = e % kU;
+      const float* hb = hp + b * LD;
+      const float *wr = W + (0 * kU + u) * LD, *wz = W + (1 * kU + u) * LD, *wn = W + (2 * kU + u) * LD;
+      float ar = 0.0f, az = 0.0f, an = 0.0f;
+#pragma unroll 8
+      for (int k = 0; k < H; ++k) {
+        const float h = hb[k];
+        ar = __builtin_fmaf(h, wr[k], ar);
+        az = __builtin_fmaf(h, wz[k], az);
+        an = __builtin_fmaf(h, wn[k], an);
+      }
+      const int c = u0 + u;
+      const float* g = gid + ((long long)b * T + t) * 3 * H;
+      const float* bh = bhh + (long long)d * 3 * H;
+      const float r = sigmoidf_(g[c] + ar + bh[c]);
+      const float z = sigmoidf_(g[H + c] + az + bh[H + c]);
+      const float hn = an + bh[2 * H + c];
+      const float n = tanhf(g[2 * H + c] + r * hn);
+      const float hnew = (1.0f - z) * n + z * hb[c];
+      od[((long long)b * T + t) * H + c] = hnew;
+      float* sv = sd + ((long long)b * T + t) * 4 * H;
+      sv[c] = r;
+      sv[H + c] = z;
+      sv[2 * H + c] = n;
+      sv[3 * H + c] = hn;
+    }
+    grid_barrier(ctr, (unsigned)(nblk * (t + 1)));
+  }
+}
+
+// backward through time.  gout [D][B][T][H] -> dgi [D][B][T][3H], dwhh [D][3H][H], dbhh [D][3H];
+// part [D][2][nblk][B][H]: per-step partial dL/dh_{t-1} of every block's rows (double-buffered by step parity).
+template <int H>
+__global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ h0,
+                                                      const float* __restrict__ whh, const float* __restrict__ out,
+                                                      const float* __restrict__ saved, int B, int T,
+                                                      float* __restrict__ dgi, float* __restrict__ dwhh,
+                                                      float* __restrict__ dbhh, float* __restrict__ part,
+                                                      unsigned* __restrict__ counters) {
+  extern __shared__ float smem[];
+  float* W = smem;                        // [3 * kU][H]
+  float* hp = smem + 3 * kU * H;          // [B][H] h_{t-1}
+  float* dg = hp + B * H;                 // [B][3 * kU] gate gradients of the own rows at this step (r, z, n-hidden)
+  float* dhc = dg + B * 3 * kU;           // [B][kU] carried dL/dh of the own units
+  const int d = blockIdx.y, u0 = blockIdx.x * kU, nblk = gridDim.x, blk = blockIdx.x;
+  const float* wd = whh + (long long)d * 3 * H * H;
+  for (int e = threadIdx.x; e < 3 * kU * H; e += kGT) {
+    const int row = e / H, k = e % H, gate = row / kU, u = row % kU;
+    W[e] = wd[(long long)(gate * H + u0 + u) * H + k];
+  }
+  for (int e = threadIdx.x; e < B * kU; e += kGT) dhc[e] = 0.0f;
+  const float* god = gout + (long long)d * B * T * H;
+  const float* od = out + (long long)d * B * T * H;
+  const float* sd = saved + (long long)d * B * T * 4 * H;
+  float* dgid = dgi + (long long)d * B * T * 3 * H;
+  float* pd = part + (long long)d * 2 * nblk * B * H;
+  unsigned* ctr = counters + 2 + d;
+  // own slice of dW_hh: 3 * kU rows x H columns spread over the threads (row-major, 48 * H / 256 per thread)
+  constexpr int per = 3 * kU * H / kGT;
+  float dw[per];
+#pragma unroll
+  for (int i = 0; i < per; ++i) dw[i] = 0.0f;
+  float db_acc = 0.0f;  // threads 0 .. 3*kU-1: bias gradient of row threadIdx.x
+  __syncthreads();
+  for (int t = T - 1; t >= 0; --t) {
+    for (int e = threadIdx.x; e < B * H; e += kGT) {
+      const int b = e / H, k = e % H;
+      hp[e] = t == 0 ? h0[((long long)d * B + b) * H + k] : od[((long long)b * T + (t - 1)) * H + k];
+    }
+    __syncthreads();
+    // gate gradients of the own units
+    for (int e = threadIdx.x; e < B * kU; e += kGT) {
+      const int b = e / kU, u = e % kU, c = u0 + u;
+      float dh = god[((long long)b * T + t) * H + c] + dhc[e];
+      if (t < T - 1) {  // + what the other rows sent back through W_hh in step t + 1 (fixed block order)
+        const float* pp = pd + (long long)((t + 1) & 1) * nblk * B * H;
+        for (int k = 0; k < nblk; ++k) dh += pp[((long long)k * B + b) * H + c];
+      }
+      const float* sv = sd + ((long long)b * T + t) * 4 * H;
+      const float r = sv[c], z = sv[H + c], n = sv[2 * H + c], hn = sv[3 * H + c];
+      const float hprev = hp[b * H + c];
+      const float dn = dh * (1.0f - z), dz = dh * (hprev - n);
+      const float dn_pre = dn * (1.0f - n * n);
+      const float dr_pre = dn_pre * hn * r * (1.0f - r);
+      const float dz_pre = dz * z * (1.0f - z);
+      dhc[e] = dh * z;  // the direct path to h_{t-1}
+      float* go = dgid + ((long long)b * T + t) * 3 * H;
+      go[c] = dr_pre;
+      go[H + c] = dz_pre;
+      go[2 * H + c] = dn_pre;
+      dg[b * 3 * kU + u] = dr_pre;
+      dg[b * 3 * kU + kU + u] = dz_pre;
+      dg[b * 3 * kU + 2 * kU + u] = dn_pre * r;  // gradient w.r.t. (W_hn h + b_hn)
+    }
+    __syncthreads();
+    // dW_hh[row][k] += sum_b dg[b][row] * h_{t-1}[b][k];  db_hh[row] += sum_b dg[b][row]
+#pragma unroll
+    for (int i = 0; i < per; ++i) {
+      const int e = threadIdx.x + i * kGT, row = e / H, k = e % H;
+      float a = dw[i];
+      for (int b = 0; b < B; ++b) a = __builtin_fmaf(dg[b * 3 * kU + row], hp[b * H + k], a);
+      dw[i] = a;
+    }
+    if (threadIdx.x < 3 * kU) {
+      float a = db_acc;
+      for (int b = 0; b < B; ++b) a += dg[b * 3 * kU + threadIdx.x];
+      db_acc = a;
+    }
+    // partial dL/dh_{t-1}[b][k] = sum over the own rows of dg[b][row] * W[row][k]
+    float* po = pd + (long long)(t & 1) * nblk * B * H + (long long)blk * B * H;
+    for (int e = threadIdx.x; e < B * H; e += kGT) {
+      const int b = e / H, k = e % H;
+      float a = 0.0f;
+#pragma unroll 8
+      for (int row = 0; row < 3 * kU; ++row) a = __builtin_fmaf(dg[b * 3 * kU + row], W[row * H + k], a);
+      po[e] = a;
+    }
+    grid_barrier(ctr, (unsigned)(nblk * (T - t)));
+  }
+  float* dwd = dwhh + (long long)d * 3 * H * H;
+#pragma unroll
+  for (int i = 0; i < per; ++i) {
+    const int e = threadIdx.x + i * kGT, row = e / H, k = e % H, gate = row / kU, u = row % kU;
+    dwd[(long long)(gate * H + u0 + u) * H + k] = dw[i];
+  }
+  if (threadIdx.x < 3 * kU) {
+    const int gate = threadIdx.x / kU, u = threadIdx.x % kU;
+    dbhh[(long long)d * 3 * H + gate * H + u0 + u] = db_acc;
+  }
+}
+
+__global__ void gru_zero_counters_kernel(unsigned* c, int first, int count) {
+  if ((int)threadIdx.x < count) c[first + threadIdx.x] = 0u;
+}
+
+int gru_check(int64_t D, int64_t B, int64_t T, int64_t H, const char* who) {
+  MPA_REQUIRE(D == 1 || D == 2, "%s: 1 or 2 directions", who);
+  MPA_REQUIRE(B >= 1 && B <= kMaxB && T >= 1 && T <= 4096, "%s: 1 <= batch <= %d, 1 <= steps <= 4096", who, kMaxB);
+  MPA_REQUIRE(H == 128 || H == 256 || H == 512, "%s: hidden size must be 128, 256 or 512", who);
+  return MPA_OK;
+}
+
+}  // namespace
+
+extern "C" int mpa_gru_workspace(int64_t D, int64_t B, int64_t T, int64_t H, int64_t* float_elems) {
+  if (int st = gru_check(D, B, T, H, "gru_workspace")) return st;
+  MPA_REQUIRE(float_elems != nullptr, "gru_workspace: null pointer");
+  // saved gates [D][B][T][4][H] | backward partials [D][2][H/16][B][H] | 4 barrier counters (as floats)
+  *float_elems = D * B * T * 4 * H + D * 2 * (H / kU) * B * H + 64;
+  return MPA_OK;
+}
+
+extern "C" int mpa_gru_forward(const float* gi, const float* h0, const float* whh, const float* bhh, int64_t D, int64_t B,
+                               int64_t T, int64_t H, float* ws, float* out, void* stream) {
+  if (int st = gru_check(D, B, T, H, "gru_forward")) return st;
+  MPA_REQUIRE(gi && h0 && whh && bhh && ws && out, "gru_forward: null pointer");
+  hipStream_t s = mpa::as_stream(stream);
+  float* saved = ws;
+  unsigned* counters = reinterpret_cast<unsigned*>(ws + D * B * T * 4 * H + D * 2 * (H / kU) * B * H);
+  const size_t smem = sizeof(float) * (3 * kU * (H + 1) + B * (H + 1));
+  MPA_REQUIRE(smem <= 160 * 1024, "gru_forward: batch x hidden size does not fit the 160 KB of LDS");
+  hipLaunchKernelGGL(gru_zero_counters_kernel, dim3(1), dim3(64), 0, s, counters, 0, 2);
+  const dim3 grid((unsigned)(H / kU), (unsigned)D);
+#define MPA_GRU_FWD(HH)                                                                                               \
+  {                                                                                                                   \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          160 * 1024);                                                                                \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(gru_fwd_kernel<HH>, grid, dim3(kGT), smem, s, gi, h0, whh, bhh, (int)B, (int)T, out, saved,     \
+                       counters);                                                                                     \
+  }
+  if (H == 128) MPA_GRU_FWD(128) else if (H == 256) MPA_GRU_FWD(256) else MPA_GRU_FWD(512)
+#undef MPA_GRU_FWD
+  return mpa::check_launch("gru_forward");
+}
+
+extern "C" int mpa_gru_backward(const float* grad_out, const float* h0, const float* whh, const float* out, int64_t D,
+                                int64_t B, int64_t T, int64_t H, float* ws, float* grad_gi, float* grad_whh,
+                                float* grad_bhh, void* stream) {
+  if (int st = gru_check(D, B, T, H, "gru_backward")) return st;
+  MPA_REQUIRE(grad_out && h0 && whh && out && ws && grad_gi && grad_whh && grad_bhh, "gru_backward: null pointer");
+  hipStream_t s = mpa::as_stream(stream);
+  const float* saved = ws;
+  float* part = ws + D * B * T * 4 * H;
+  unsigned* counters = reinterpret_cast<unsigned*>(ws + D * B * T * 4 * H + D * 2 * (H / kU) * B * H);
+  const size_t smem = sizeof(float) * (3 * kU * H + B * H + B * 3 * kU + B * kU);
+  MPA_REQUIRE(smem <= 160 * 1024, "gru_backward: batch x hidden size does not fit the 160 KB of LDS");
+  hipLaunchKernelGGL(gru_zero_counters_kernel, dim3(1), dim3(64), 0, s, counters, 2, 2);
+  const dim3 grid((unsigned)(H / kU), (unsigned)D);
+#define MPA_GRU_BWD(HH)                                                                                               \
+  {                                                                                                                   \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          160 * 1024);                                                                                \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(gru_bwd_kernel<HH>, grid, dim3(kGT), smem, s, grad_out, h0, whh, out, saved, (int)B, (int)T,    \
+                       grad_gi, grad_whh, grad_bhh, part, counters);                                                  \
+  }
+  if (H == 128) MPA_GRU_BWD(128) else if (H == 256) MPA_GRU_BWD(256) else MPA_GRU_BWD(512)
+#undef MPA_GRU_BWD
+  return mpa::check_launch("gru_backward");
+}

@@ -25,6 +25,7 @@ import torch.nn as nn
 
 from .base_model import BaseModel
 from .encoder import build_encoder
+from .gru import gru_recurrent, supported as gru_supported
 from .mlp import mlp_layer, supported as mlp_supported
 from .regressor import StocasticPoseRegressor
 
@@ -280,11 +281,20 @@ class _MaskedBiGRU(nn.Module):
         rev_idx = torch.where(steps < lengths[:, None], lengths[:, None] - 1 - steps, steps)
         x_rev = torch.gather(x, 1, rev_idx[..., None].expand_as(x))
         w = self.rnn
-        fwd = torch._VF.gru(x, hidden[0:1].contiguous(), [w.weight_ih_l0, w.weight_hh_l0, w.bias_ih_l0, w.bias_hh_l0],
-                            True, 1, 0.0, self.training, False, True)[0]
-        bwd = torch._VF.gru(x_rev, hidden[1:2].contiguous(),
-                            [w.weight_ih_l0_reverse, w.weight_hh_l0_reverse, w.bias_ih_l0_reverse,
-                             w.bias_hh_l0_reverse], True, 1, 0.0, self.training, False, True)[0]
+        if x.is_cuda and gru_supported(H, B):
+            # both directions' T steps in ONE launch (csrc/gru.hip); the two input projections are plain GEMMs
+            gi = torch.stack([torch.nn.functional.linear(x, w.weight_ih_l0, w.bias_ih_l0),
+                              torch.nn.functional.linear(x_rev, w.weight_ih_l0_reverse, w.bias_ih_l0_reverse)])
+            hs = gru_recurrent(gi, hidden[0:2], torch.stack([w.weight_hh_l0, w.weight_hh_l0_reverse]),
+                               torch.stack([w.bias_hh_l0, w.bias_hh_l0_reverse]))
+            fwd, bwd = hs[0], hs[1]
+        else:
+            fwd = torch._VF.gru(x, hidden[0:1].contiguous(),
+                                [w.weight_ih_l0, w.weight_hh_l0, w.bias_ih_l0, w.bias_hh_l0],
+                                True, 1, 0.0, self.training, False, True)[0]
+            bwd = torch._VF.gru(x_rev, hidden[1:2].contiguous(),
+                                [w.weight_ih_l0_reverse, w.weight_hh_l0_reverse, w.bias_ih_l0_reverse,
+                                 w.bias_hh_l0_reverse], True, 1, 0.0, self.training, False, True)[0]
         bwd = torch.gather(bwd, 1, rev_idx[..., None].expand(B, T, H))       # back to part order
         out = torch.cat([fwd, bwd], dim=-1) * (steps < lengths[:, None])[..., None].to(x.dtype)
         return out, None

@@ -137,3 +137,44 @@ def test_relation_net_hip_layers_match_library_ops(cuda_device):
     assert rel(xa.grad, xb.grad) < 1e-4
     for (k, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
         assert rel(p.grad, q.grad) < 1e-4, k
+
+
+@pytest.mark.parametrize("H,B,T", [(256, 32, 20), (128, 3, 5), (256, 7, 33)])
+def test_gru_recurrent_matches_torch_gru(cuda_device, H, B, T):
+    """csrc/gru.hip (all steps of both directions in one launch, grid barrier per step) against torch.nn.GRU run per
+    direction: hidden states of every step and the gradients of inputs, both weight sets and biases; and the masked
+    bidirectional wrapper of RGL-NET (reference modules/rnn.py:6-46) with the HIP path against its library path."""
+    import copy
+    from multi_part_assembly_amd.gnn import _MaskedBiGRU
+    torch.manual_seed(H + B)
+    gru = torch.nn.GRU(input_size=H, hidden_size=H, num_layers=1, batch_first=True, bidirectional=True).to(cuda_device)
+    mine = _MaskedBiGRU(gru)
+    ref = _MaskedBiGRU(copy.deepcopy(gru))
+    x = torch.randn(B, T, H, device=cuda_device)
+    h0 = torch.randn(2, B, H, device=cuda_device)
+    lengths = torch.randint(1, T + 1, (B,))
+    lengths[0] = T
+    valids = (torch.arange(T)[None] < lengths[:, None]).float().to(cuda_device)
+    w = torch.randn(B, T, 2 * H, device=cuda_device)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    out, _ = mine(xa, h0, valids=valids)
+    (out * w).sum().backward()
+    import multi_part_assembly_amd.gnn as G
+    keep = G.gru_supported
+    G.gru_supported = lambda *a: False  # library path of the same wrapper
+    try:
+        want, _ = ref(xb, h0, valids=valids)
+        (want * w).sum().backward()
+    finally:
+        G.gru_supported = keep
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    assert rel(out.detach(), want.detach()) < 1e-5
+    assert rel(xa.grad, xb.grad) < 1e-4
+    for (k, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel(p.grad, q.grad) < 1e-4, k
+    # bit-reproducible backward
+    g1 = [p.grad.clone() for p in mine.parameters()]
+    mine.zero_grad()
+    out2, _ = mine(x.clone().requires_grad_(), h0, valids=valids)
+    (out2 * w).sum().backward()
+    assert all(torch.equal(a, p.grad) for a, p in zip(g1, mine.parameters()))
