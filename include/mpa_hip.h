@@ -287,7 +287,7 @@ int mpa_mlp_layer_backward(const float* grad_out, const float* x, int64_t ldx, c
  * the caller; this runs the T sequential steps of D directions in ONE launch:
  *   r = sigmoid(gi_r + W_hr h + b_hr), z = sigmoid(gi_z + W_hz h + b_hz), n = tanh(gi_n + r (W_hn h + b_hn)),
  *   h' = (1 - z) n + z h,   out [D,B,T,H] = h' of every step.
- * h0 [D,B,H], whh [D,3H,H], bhh [D,3H].  H = 128, 256 or 512, B <= 64, D = 1 or 2.  `ws` (mpa_gru_workspace floats)
+ * h0 [D,B,H], whh [D,3H,H], bhh [D,3H].  H = 128 or 256, B <= 64, D = 1 or 2.  `ws` (mpa_gru_workspace floats)
  * carries the gates to backward.  backward: grad_out [D,B,T,H] -> grad_gi [D,B,T,3H], grad_whh, grad_bhh (overwritten);
  * deterministic (partials summed in block order, no float atomics).  Sequences of different lengths: run the padded
  * batch (valid steps first) and mask the outputs — the reverse direction on the per-sample reversed valid prefix.

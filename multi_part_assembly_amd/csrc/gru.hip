@@ -122,13 +122,25 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
   float* dgid = dgi + (long long)d * B * T * 3 * H;
   float* pd = part + (long long)d * 2 * nblk * B * H;
   unsigned* ctr = counters + 2 + d;
-  // own slice of dW_hh: 3 * kU rows x H columns spread over the threads (row-major, 48 * H / 256 per thread)
-  constexpr int per = 3 * kU * H / kGT;
-  float dw[per];
+  // own slice of dW_hh (3 * kU rows x H columns) and of W_hh, column-wise in registers: thread -> column(s) k0 + 256 c of
+  // the rows rbase .. rbase + RPT - 1, so that per sample one h value and RPT/4 broadcast 16-byte reads of the gate
+  // gradients feed RPT FMAs (a row-major spread cost two LDS reads per FMA)
+  constexpr int CPT = H >= kGT ? H / kGT : 1;          // columns per thread
+  constexpr int RG = H >= kGT ? 1 : kGT / H;           // row groups (H < 256: the threads split the rows)
+  constexpr int RPT = 3 * kU / RG;                     // rows per thread
+  const int k0 = threadIdx.x % H, rbase = (threadIdx.x / H) * RPT;
+  float dw[RPT][CPT], wreg[RPT][CPT];
 #pragma unroll
-  for (int i = 0; i < per; ++i) dw[i] = 0.0f;
+  for (int r = 0; r < RPT; ++r)
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) dw[r][c] = 0.0f;
   float db_acc = 0.0f;  // threads 0 .. 3*kU-1: bias gradient of row threadIdx.x
+  __shared__ float red[kGT];
   __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) wreg[r][c] = W[(rbase + r) * H + k0 + kGT * c];
   for (int t = T - 1; t >= 0; --t) {
     for (int e = threadIdx.x; e < B * H; e += kGT) {
       const int b = e / H, k = e % H;
@@ -161,34 +173,64 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
     }
     __syncthreads();
     // dW_hh[row][k] += sum_b dg[b][row] * h_{t-1}[b][k];  db_hh[row] += sum_b dg[b][row]
+    for (int b = 0; b < B; ++b) {
+      float hk[CPT];
 #pragma unroll
-    for (int i = 0; i < per; ++i) {
-      const int e = threadIdx.x + i * kGT, row = e / H, k = e % H;
-      float a = dw[i];
-      for (int b = 0; b < B; ++b) a = __builtin_fmaf(dg[b * 3 * kU + row], hp[b * H + k], a);
-      dw[i] = a;
+      for (int c = 0; c < CPT; ++c) hk[c] = hp[b * H + k0 + kGT * c];
+#pragma unroll
+      for (int r4 = 0; r4 < RPT / 4; ++r4) {
+        const float4 g4 = *reinterpret_cast<const float4*>(&dg[b * 3 * kU + rbase + 4 * r4]);
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int c = 0; c < CPT; ++c) dw[4 * r4 + u][c] = __builtin_fmaf(gv[u], hk[c], dw[4 * r4 + u][c]);
+      }
     }
     if (threadIdx.x < 3 * kU) {
       float a = db_acc;
       for (int b = 0; b < B; ++b) a += dg[b * 3 * kU + threadIdx.x];
       db_acc = a;
     }
-    // partial dL/dh_{t-1}[b][k] = sum over the own rows of dg[b][row] * W[row][k]
+    // partial dL/dh_{t-1}[b][k] = sum over the rows of dg[b][row] * W[row][k]: the thread's rows of its column(s);
+    // H < 256: the row groups of a column are added in group order through LDS (fixed order)
     float* po = pd + (long long)(t & 1) * nblk * B * H + (long long)blk * B * H;
-    for (int e = threadIdx.x; e < B * H; e += kGT) {
-      const int b = e / H, k = e % H;
-      float a = 0.0f;
-#pragma unroll 8
-      for (int row = 0; row < 3 * kU; ++row) a = __builtin_fmaf(dg[b * 3 * kU + row], W[row * H + k], a);
-      po[e] = a;
+    for (int b = 0; b < B; ++b) {
+      float a[CPT];
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) a[c] = 0.0f;
+#pragma unroll
+      for (int r4 = 0; r4 < RPT / 4; ++r4) {
+        const float4 g4 = *reinterpret_cast<const float4*>(&dg[b * 3 * kU + rbase + 4 * r4]);
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int c = 0; c < CPT; ++c) a[c] = __builtin_fmaf(gv[u], wreg[4 * r4 + u][c], a[c]);
+      }
+      if constexpr (RG == 1) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) po[(long long)b * H + k0 + kGT * c] = a[c];
+      } else {
+        red[threadIdx.x] = a[0];
+        __syncthreads();
+        if (threadIdx.x < H) {
+          float sum = 0.0f;
+#pragma unroll
+          for (int g = 0; g < RG; ++g) sum += red[g * H + threadIdx.x];
+          po[(long long)b * H + threadIdx.x] = sum;
+        }
+        __syncthreads();
+      }
     }
     grid_barrier(ctr, (unsigned)(nblk * (T - t)));
   }
   float* dwd = dwhh + (long long)d * 3 * H * H;
 #pragma unroll
-  for (int i = 0; i < per; ++i) {
-    const int e = threadIdx.x + i * kGT, row = e / H, k = e % H, gate = row / kU, u = row % kU;
-    dwd[(long long)(gate * H + u0 + u) * H + k] = dw[i];
+  for (int r = 0; r < RPT; ++r) {
+    const int row = rbase + r, gate = row / kU, u = row % kU;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) dwd[(long long)(gate * H + u0 + u) * H + k0 + kGT * c] = dw[r][c];
   }
   if (threadIdx.x < 3 * kU) {
     const int gate = threadIdx.x / kU, u = threadIdx.x % kU;
@@ -203,7 +245,7 @@ __global__ void gru_zero_counters_kernel(unsigned* c, int first, int count) {
 int gru_check(int64_t D, int64_t B, int64_t T, int64_t H, const char* who) {
   MPA_REQUIRE(D == 1 || D == 2, "%s: 1 or 2 directions", who);
   MPA_REQUIRE(B >= 1 && B <= kMaxB && T >= 1 && T <= 4096, "%s: 1 <= batch <= %d, 1 <= steps <= 4096", who, kMaxB);
-  MPA_REQUIRE(H == 128 || H == 256 || H == 512, "%s: hidden size must be 128, 256 or 512", who);
+  MPA_REQUIRE(H == 128 || H == 256, "%s: hidden size must be 128 or 256 (2 x pc_feat_dim of the shipped configs)", who);
   return MPA_OK;
 }
 
@@ -230,16 +272,17 @@ extern "C" int mpa_gru_forward(const float* gi, const float* h0, const float* wh
   const dim3 grid((unsigned)(H / kU), (unsigned)D);
 #define MPA_GRU_FWD(HH)                                                                                               \
   {                                                                                                                   \
-    static bool attr = false;                                                                                         \
-    if (!attr) {                                                                                                      \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          160 * 1024);                                                                                \
-      attr = true;                                                                                                    \
+    static size_t allowed = 64 * 1024; /* dynamic LDS above 64 KB must be requested (exactly: static LDS counts too) */ \
+    if (smem > allowed) {                                                                                             \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)smem) != hipSuccess)                                                               \
+        return mpa::fail(MPA_EINVAL, "gru: cannot reserve %zu bytes of LDS", smem);                                   \
+      allowed = smem;                                                                                                 \
     }                                                                                                                 \
     hipLaunchKernelGGL(gru_fwd_kernel<HH>, grid, dim3(kGT), smem, s, gi, h0, whh, bhh, (int)B, (int)T, out, saved,     \
                        counters);                                                                                     \
   }
-  if (H == 128) MPA_GRU_FWD(128) else if (H == 256) MPA_GRU_FWD(256) else MPA_GRU_FWD(512)
+  if (H == 128) MPA_GRU_FWD(128) else MPA_GRU_FWD(256)
 #undef MPA_GRU_FWD
   return mpa::check_launch("gru_forward");
 }
@@ -259,16 +302,17 @@ extern "C" int mpa_gru_backward(const float* grad_out, const float* h0, const fl
   const dim3 grid((unsigned)(H / kU), (unsigned)D);
 #define MPA_GRU_BWD(HH)                                                                                               \
   {                                                                                                                   \
-    static bool attr = false;                                                                                         \
-    if (!attr) {                                                                                                      \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          160 * 1024);                                                                                \
-      attr = true;                                                                                                    \
+    static size_t allowed = 64 * 1024; /* dynamic LDS above 64 KB must be requested (exactly: static LDS counts too) */ \
+    if (smem > allowed) {                                                                                             \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)smem) != hipSuccess)                                                               \
+        return mpa::fail(MPA_EINVAL, "gru: cannot reserve %zu bytes of LDS", smem);                                   \
+      allowed = smem;                                                                                                 \
     }                                                                                                                 \
     hipLaunchKernelGGL(gru_bwd_kernel<HH>, grid, dim3(kGT), smem, s, grad_out, h0, whh, out, saved, (int)B, (int)T,    \
                        grad_gi, grad_whh, grad_bhh, part, counters);                                                  \
   }
-  if (H == 128) MPA_GRU_BWD(128) else if (H == 256) MPA_GRU_BWD(256) else MPA_GRU_BWD(512)
+  if (H == 128) MPA_GRU_BWD(128) else MPA_GRU_BWD(256)
 #undef MPA_GRU_BWD
   return mpa::check_launch("gru_backward");
 }

@@ -50,7 +50,7 @@ class _GRURecurrentFn(torch.autograd.Function):
 
 
 def supported(hidden, batch):
-    return hidden in (128, 256, 512) and batch <= 64 and (48 * hidden + batch * hidden + batch * 64) * 4 <= 160 * 1024
+    return hidden in (128, 256) and batch <= 64 and (48 * hidden + batch * hidden + batch * 64) * 4 <= 160 * 1024
 
 
 def gru_recurrent(gi, h0, whh, bhh):

@@ -176,3 +176,33 @@ def test_fused_dgcnn_masked_parts_equal_compacted(cuda_device):
     for (k, a), (_, b) in zip(enc.named_buffers(), ref.named_buffers()):
         if "running" in k:
             assert _rel(a, b) < 1e-5, k
+
+
+@pytest.mark.parametrize("M,N,valid", [(4, 20, [1, 1, 1, 1]), (3, 1024, [1, 0, 1]), (5, 64, [0, 0, 0, 0, 0]), (6, 333, [0, 0, 1, 0, 0, 0])])
+def test_fused_dgcnn_edge_sizes(cuda_device, M, N, valid):
+    """Smallest and largest supported cloud (k = 20 of 20 points; 1024 points), a batch with NO valid part (features
+    and every gradient are zero, nothing is read out of range) and a single valid part between padded ones."""
+    import copy
+    enc = _fresh(64, 21, cuda_device).train()
+    ref = copy.deepcopy(enc)
+    g = torch.Generator().manual_seed(M * N)
+    v = torch.tensor(valid, dtype=torch.float32)
+    pcs = (torch.randn(M, N, 3, generator=g) * 0.2 * v[:, None, None]).to(cuda_device)
+    w = torch.randn(M, 64, generator=g).to(cuda_device)
+    vd = v.to(cuda_device)
+    out = enc.forward_parts(pcs, vd)
+    (out * w).sum().backward()
+    keep = vd.bool()
+    assert torch.equal(out[~keep], torch.zeros_like(out[~keep]))
+    assert torch.isfinite(out).all()
+    if int(v.sum()) == 0:
+        for p in enc.parameters():
+            assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) == 0.0
+        return
+    want = _reference_dgcnn(pcs[keep], ref)
+    (want * w[keep]).sum().backward()
+    assert _rel(out[keep].detach(), want.detach()) < 1e-4
+    for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        if int(v.sum()) * N > 64:  # (one 20-point cloud: the statistics of 20 rows make the gradients ill-conditioned)
+            assert _rel(p.grad, q.grad) < 5e-3, k
+        assert torch.isfinite(p.grad).all()
