@@ -2,7 +2,7 @@
 """Benchmark of the hot path: one full training step (forward + losses + backward + gradient all-reduce + fused
 Adam) on synthetic part clouds, B = 32 per GPU, P = 20, N = 1000 (weak scaling over GPUs).
 
-    python bench.py [--gpus N --steps K --warmup W] [--config c1|c2|c3|c4|c5]
+    python bench.py [--gpus N --steps K --warmup W] [--config c1|c2|c3|c4|c5 | global_partnet|pn_transformer|dgl_dgcnn|rgl_net_dgcnn]
 
 With --gpus N > 1 and no torch.distributed environment the script re-launches itself under
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU over
@@ -48,18 +48,24 @@ VALU_PEAK_LANE_OPS = 78.6e12   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (non-packe
 MFMA_F32_PEAK = 157.3e12       # 256 CU x 4 SIMD x 64 FLOP/cycle x 2.4 GHz (v_mfma_f32_32x32x2_f32, dense)
 
 
+CONFIG_ALIASES = {"global_partnet": "c1", "pn_transformer": "c2", "dgl_dgcnn": "c3", "pn_transformer_dp8": "c4",
+                  "rgl_net_dgcnn": "c5"}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"] + sorted(CONFIG_ALIASES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (default: eager launches; see trainer.py)")
     ap.add_argument("--eager", action="store_true", help="(the default; accepted for symmetry)")
     ap.add_argument("--cpu-batch", type=int, default=4, help="samples in the CPU-baseline step")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.config = CONFIG_ALIASES.get(args.config, args.config)
+    return args
 
 
 def relaunch_distributed(args):

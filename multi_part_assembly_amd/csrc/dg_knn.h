@@ -85,8 +85,32 @@ struct Queue {
   int cnt;
   float thr;
 };
-// a queue of QN slots takes 16 candidates per round: flush as soon as fewer than 16 slots are left
-#define DG_QUEUE_FULL(q, QN) __any((q).cnt > (QN) - 16)
+// a queue of QN slots takes R candidates per round: flush as soon as fewer than R slots are left
+#define DG_QUEUE_FULL_R(q, QN, R) __any((q).cnt > (QN) - (R))
+#define DG_QUEUE_FULL(q, QN) DG_QUEUE_FULL_R(q, QN, 16)
+// Tuning knobs (tools/probes/knn_time.hip builds variants).  The queues are what limits the blocks per CU: 20 slots
+// checked every 8 candidates flush as full as 32 slots checked every 16, and leave room for a third block.
+#ifndef DG_QN64   // queue slots per lane, C = 64 Gram kernel
+#define DG_QN64 20
+#endif
+#ifndef DG_QN128
+#define DG_QN128 24
+#endif
+#ifndef DG_GPC64  // candidate groups (of 4) between two queue checks
+#define DG_GPC64 2
+#endif
+#ifndef DG_GPC128
+#define DG_GPC128 4
+#endif
+#ifndef DG_BPC64  // blocks per CU the C = 64 kernel is compiled for
+#define DG_BPC64 3
+#endif
+#ifndef DG_QN3    // C = 3 kernel: queue slots and candidates per check
+#define DG_QN3 16
+#endif
+#ifndef DG_CPC3
+#define DG_CPC3 4
+#endif
 
 __device__ __forceinline__ void queue_push(Queue& q, float s, int idx) {
   if (s > q.thr) {
@@ -133,8 +157,9 @@ template <typename IdxT>
 __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x4, int N, IdxT* __restrict__ idx,
                                                    const int* __restrict__ hdr) {
   __shared__ __attribute__((aligned(16))) float4 pts[kMaxN];  // x, y, z, |p|^2
-  __shared__ float qs_[4][kQ * 64];
-  __shared__ unsigned short qj_[4][kQ * 64];
+  constexpr int QN = DG_QN3, CPC = DG_CPC3;
+  __shared__ float qs_[4][QN * 64];
+  __shared__ unsigned short qj_[4][QN * 64];
   const int v = blockIdx.y;
   if (v >= hdr[0]) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -150,9 +175,9 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x4,
   Best b;
   best_init(b);
   Queue q{qs_[wave], qj_[wave], lane, 0, -__builtin_inff()};
-  for (int j0 = 0; j0 < N; j0 += 16) {
+  for (int j0 = 0; j0 < N; j0 += CPC) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < CPC; ++u) {
       const int j = j0 + u;
       if (j < N) {  // wave-uniform
         const float4 t = pts[j];
@@ -160,7 +185,7 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x4,
         queue_push(q, (-t.w + 2.0f * dot) - me.w, j);
       }
     }
-    if (DG_QUEUE_FULL(q, kQ)) queue_flush<false>(q, b);
+    if (DG_QUEUE_FULL_R(q, QN, CPC)) queue_flush<false>(q, b);
   }
   queue_flush<false>(q, b);
   if (qi < N) {
@@ -214,18 +239,19 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
 // MODE (timing probes only, tools/probes/knn_time.hip): 0 = the real kernel; 1 = Gram tiles only (scores summed, no
 // selection); 2 = gate + queue pushes but no list maintenance (the queue is simply emptied when full).
 template <int C, typename IdxT, int MODE = 0>
-__global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restrict__ x, int ld,
+__global__ __launch_bounds__(256, C > 64 ? 2 : DG_BPC64) void knn_mfma_kernel(const float* __restrict__ x, int ld,
                                                           const float* __restrict__ norm, int N,
                                                           IdxT* __restrict__ idx, const int* __restrict__ hdr) {
   constexpr int KH = C / 2, LD = C + 4, T4 = 32 * C / 4 / 256;  // float4 per thread and candidate tile
-  constexpr int QN = C > 64 ? 24 : kQ;  // two blocks per CU must fit in the 160 KB of LDS
+  constexpr int QN = C > 64 ? DG_QN128 : DG_QN64;  // the blocks of a CU must fit in its 160 KB of LDS
+  constexpr int GPC = C > 64 ? DG_GPC128 : DG_GPC64;
   __shared__ __attribute__((aligned(16))) float tile[2][32 * LD];
   __shared__ __attribute__((aligned(16))) float tnorm[2][32];
   __shared__ float qs_[4][QN * 64];
   __shared__ unsigned short qj_[4][QN * 64];
   const int v = blockIdx.y;
   if (v >= hdr[0]) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const float* xp = x + (long long)v * N * ld;
   const float* np_ = norm + (long long)v * N;
   const int q0 = blockIdx.x * 128 + wave * 32;
@@ -256,12 +282,12 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
       const int row = t * 32 + rl + RS * i;
       raw[i] = row < N ? *reinterpret_cast<const float4*>(xp + (long long)row * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (threadIdx.x < 32) rn = t * 32 + threadIdx.x < N ? np_[t * 32 + threadIdx.x] : 0.0f;
+    if (wave == 0 && lane < 32) rn = t * 32 + lane < N ? np_[t * 32 + lane] : 0.0f;
   };
   auto stash = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < T4; ++i) *reinterpret_cast<float4*>(&tile[buf][(rl + RS * i) * LD + 4 * c4]) = raw[i];
-    if (threadIdx.x < 32) tnorm[buf][threadIdx.x] = rn;
+    if (wave == 0 && lane < 32) tnorm[buf][lane] = rn;
   };
   const int tiles = (N + 31) / 32;
   fetch(0);
@@ -293,31 +319,40 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float* __restric
         else queue_push(q, s, cand);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: hoisting all 16 scores costs 30+ registers
-    }
-    if constexpr (MODE == 2) {
-      if (DG_QUEUE_FULL(q, QN)) {
-        q.thr = q.qs[8 * 64 + lane];  // some plausible gate
-        q.cnt = 0;
+      if ((g4 + 1) % GPC == 0) {
+        if constexpr (MODE == 2) {
+          if (DG_QUEUE_FULL_R(q, QN, 4 * GPC)) {
+            q.thr = q.qs[8 * 64 + lane];  // some plausible gate
+            q.cnt = 0;
+          }
+        } else if constexpr (MODE == 0) {
+          if (DG_QUEUE_FULL_R(q, QN, 4 * GPC)) queue_flush<(C <= 64)>(q, b);  // C = 128: the shared gate does not fit in 256 registers
+        }
       }
-    } else if (DG_QUEUE_FULL(q, QN)) {
-      queue_flush<(C <= 64)>(q, b);  // C = 128: the shared gate does not fit in 256 registers
     }
   }
   queue_flush<(C <= 64)>(q, b);
-  // merge the two halves of every query: lanes 32-63 hand their lists to lanes 0-31 through the queue memory
-  if (h == 1) {
+  // merge the two halves of every query: lanes 32-63 hand their lists to lanes 0-31 through the queue memory.  The
+  // lane's coordinates are derived afresh (mbcnt) so that nothing but the lists has to stay in registers across the
+  // tile loop — the C = 64 kernel sits right at the 168-register limit of three blocks per CU.
+  const int l2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int j2 = l2 & 31;
+  float* qs2 = qs_[wave];
+  unsigned short* qj2 = qj_[wave];
+  if (l2 >= 32) {
 #pragma unroll
     for (int t = 0; t < kNbr; ++t) {
-      q.qs[t * 64 + j] = b.s[t];
-      q.qj[t * 64 + j] = (unsigned short)b.j[t];
+      qs2[t * 64 + j2] = b.s[t];
+      qj2[t * 64 + j2] = (unsigned short)b.j[t];
     }
   }
   __builtin_amdgcn_wave_barrier();
-  if (h == 0) {
+  if (l2 < 32) {
 #pragma unroll 1
-    for (int t = 0; t < kNbr; ++t) best_insert<true>(b, q.qs[t * 64 + j], q.qj[t * 64 + j]);
-    if (q0 + j < N) {
-      IdxT* out = idx + ((long long)v * N + q0 + j) * kNbr;
+    for (int t = 0; t < kNbr; ++t) best_insert<true>(b, qs2[t * 64 + j2], qj2[t * 64 + j2]);
+    const int qi = blockIdx.x * 128 + wave * 32 + j2;
+    if (qi < N) {
+      IdxT* out = idx + ((long long)blockIdx.y * N + qi) * kNbr;
 #pragma unroll
       for (int t = 0; t < kNbr; ++t) out[t] = (IdxT)b.j[t];
     }

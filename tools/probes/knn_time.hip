@@ -34,7 +34,28 @@ void all(int n, int N) {
          run<C, 1>(x, norm, idx, hdr, n, N), run<C, 2>(x, norm, idx, hdr, n, N));
 }
 
+void knn3(int n, int N) {
+  std::vector<float> h((size_t)n * N * 4);
+  srand(2);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (i & 3) == 3 ? 0.f : (float)rand() / RAND_MAX - 0.5f;
+  float* x; unsigned short* idx; int* hdr;
+  hipMalloc(&x, h.size() * 4); hipMalloc(&idx, (size_t)n * N * 20 * 2); hipMalloc(&hdr, 64);
+  hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  int hh[2] = {n, n * N}; hipMemcpy(hdr, hh, 8, hipMemcpyHostToDevice);
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  const dim3 g((N + 255) / 256, n);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((dg::knn3_kernel<unsigned short>), g, dim3(256), 0, 0, x, N, idx, hdr);
+  hipEventRecord(a, 0);
+  for (int w = 0; w < 5; ++w) hipLaunchKernelGGL((dg::knn3_kernel<unsigned short>), g, dim3(256), 0, 0, x, N, idx, hdr);
+  hipEventRecord(b, 0);
+  hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  printf("C=3 n=%d N=%d: full %.3f ms\n", n, N, ms / 5);
+}
+
 int main() {
+  knn3(352, 1000);
   all<64>(352, 1000);
   all<128>(352, 1000);
   return 0;
