@@ -223,14 +223,45 @@ __global__ __launch_bounds__(kGT, 2) void gemm_tn_kernel(const float* __restrict
     }
 }
 
-// second stage of the weight gradient: out[e] = sum_chunk part[chunk][e] in chunk order (deterministic)
-static __global__ void gemm_tn_reduce_kernel(const float* __restrict__ part, int chunks, long long elems,
-                                      float* __restrict__ out) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= elems) return;
-  float s = 0.0f;
-  for (int c = 0; c < chunks; ++c) s += part[(long long)c * elems + e];
-  out[e] = s;
+// second stage of the weight gradient: out[e] = sum_chunk part[chunk][e], in a FIXED order (deterministic): a block of
+// 256 threads owns EPB consecutive elements; 256 / EPB slices of the chunk range are summed side by side (eight
+// independent partial sums each, so the loads pipeline) and combined in slice order.
+template <int EPB>
+static __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, int chunks,
+                                                                    long long elems, float* __restrict__ out) {
+  constexpr int SL = 256 / EPB;
+  __shared__ float red[SL][EPB];
+  const int el = threadIdx.x % EPB, sl = threadIdx.x / EPB;
+  const long long e = (long long)blockIdx.x * EPB + el;
+  const int per = (chunks + SL - 1) / SL;
+  const int c0 = sl * per, c1 = c0 + per < chunks ? c0 + per : chunks;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (e < elems) {
+    const float* p = part + e;
+    int c = c0;
+    for (; c + 8 <= c1; c += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += p[(long long)(c + u) * elems];
+    }
+    for (; c < c1; ++c) a[0] += p[(long long)c * elems];
+  }
+  red[sl][el] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (sl == 0 && e < elems) {
+    float t = red[0][el];
+#pragma unroll
+    for (int q = 1; q < SL; ++q) t += red[q][el];
+    out[e] = t;
+  }
+}
+
+// few elements and many chunks (the 128 x 4 first-layer gradient: thousands of row tiles) -> more slices per element
+static inline void launch_tn_reduce(const float* part, int chunks, long long elems, float* out, hipStream_t s) {
+  if (elems <= 4096)
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel<8>, dim3((unsigned)((elems + 7) / 8)), dim3(256), 0, s, part, chunks, elems, out);
+  else
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel<32>, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, s, part, chunks, elems,
+                       out);
 }
 
 }  // namespace dg

@@ -963,16 +963,18 @@ void gemm_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, 
   }
 }
 
-// out [Nout][K] = Y^T . X over the valid rows (two deterministic stages); K a multiple of 64
+// out [Nout][K] = Y^T . X over the valid rows (two deterministic stages); K a multiple of 64.  The rows are cut into
+// as many chunks as it takes to put 512 blocks on the chip (two per CU): a 128 x 64 gradient has ONE output tile.
 void gemm_tn(const float* Y, int ldy, int Nout, const float* X, int ldx, int K, float* part, float* out, int64_t Rmax,
              const int* hdr, hipStream_t s) {
-  const int rows_per_chunk = (int)(((Rmax + kTnChunks - 1) / kTnChunks + 31) / 32 * 32);
-  const dim3 grid((unsigned)((Nout + 127) / 128), (unsigned)(K % 128 == 0 ? K / 128 : K / 64), kTnChunks);
+  const unsigned tn = (unsigned)((Nout + 127) / 128), tk = (unsigned)(K % 128 == 0 ? K / 128 : K / 64);
+  const int chunks = tn * tk >= 4 ? kTnChunks : (int)(4 * kTnChunks / (tn * tk));
+  const int rows_per_chunk = (int)(((Rmax + chunks - 1) / chunks + 31) / 32 * 32);
+  const dim3 grid(tn, tk, (unsigned)chunks);
   if (K % 128 == 0) launch(gemm_tn_kernel<128>, grid, dim3(kGT), s, Y, ldy, Nout, X, ldx, K, part, rows_per_chunk, hdr);
   else launch(gemm_tn_kernel<64>, grid, dim3(kGT), s, Y, ldy, Nout, X, ldx, K, part, rows_per_chunk, hdr);
   const long long elems = (long long)Nout * K;
-  launch(gemm_tn_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), s, (const float*)part, kTnChunks, elems,
-         out);
+  launch_tn_reduce(part, chunks, elems, out, s);
 }
 
 void record(void* const* events, int i, hipStream_t s) {
@@ -1115,7 +1117,7 @@ extern "C" int mpa_dgcnn_backward(const float* grad_feat, const float* const* co
       const int t1 = (int)((R + kFirstTile - 1) / kFirstTile);
       launch(dg_first_wgrad_kernel, dim3((unsigned)t1), dim3(512), s, (const float*)w.duv, (const float4*)w.x0, w.tnpart,
              hdr);
-      launch(gemm_tn_reduce_kernel, dim3(2), dim3(256), s, (const float*)w.tnpart, t1, (long long)(128 * 4), w.gstk);
+      launch_tn_reduce(w.tnpart, t1, (long long)(128 * 4), w.gstk, s);
       if (grad_points != nullptr)
         launch(dg_first_dgrad_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), s, (const float*)w.duv,
                (const float*)w.wstk[0], (const int*)w.vlist, (int)N, grad_points, hdr);

@@ -353,8 +353,7 @@ extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int
       launch(gemm_tn_kernel<64>, grid, dim3(kGT), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
              rows_per_chunk, (const int*)m.hdr);
     const long long elems = (long long)N * K;
-    launch(gemm_tn_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), s, (const float*)m.tnpart, chunks,
-           elems, grad_w);
+    dg::launch_tn_reduce(m.tnpart, chunks, elems, grad_w, s);
   }
   if (grad_x != nullptr) {  // dX [R][K] = dY [R][N] . W [N][K]
     launch(ml_transpose_kernel, dim3((unsigned)((N * K + 255) / 256)), dim3(256), s, w, (int)N, (int)K, m.wt);

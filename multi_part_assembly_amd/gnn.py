@@ -52,7 +52,8 @@ class _PairMLP(nn.Module):
         h = mlp_layer(h, self.conv2.weight, self.conv2.bias, self.bn2, relu=True, training=self.training)
         return mlp_layer(h, self.conv3.weight, self.conv3.bias, self.bn3, relu=self.final_relu, training=self.training)
 
-    MIN_ROWS = 4096  # below that the layers are launch-latency bound and the library's small-GEMM kernels do as well
+    MIN_ROWS = 1  # (a knob for A/B runs: tools/probe_node_mlp.py — the HIP layers win from the 640-row node MLP up, and
+                  # unlike the library's split-K weight gradients they are deterministic)
 
     def _hip_ok(self, x, cin, rows):
         return (x.is_cuda and rows >= self.MIN_ROWS and mlp_supported(cin, 512)

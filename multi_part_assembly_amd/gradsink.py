@@ -46,7 +46,7 @@ class GradSink:
         """-> (buffers, direct): the tensors the backward kernels must overwrite with d loss / d param."""
         sink = GradSink.active
         if sink is not None and all(
-                sink.uses.get(id(p)) == 1 and p.grad is not None and p.grad.is_contiguous()
+                sink.uses.get(id(p)) == 1 and p.is_leaf and p.grad is not None and p.grad.is_contiguous()
                 and p.grad.dtype == torch.float32 and p.grad.device == p.device for p in params):
             return [p.grad for p in params], True
         return [torch.empty_like(p) for p in params], False

@@ -178,3 +178,28 @@ def test_gru_recurrent_matches_torch_gru(cuda_device, H, B, T):
     out2, _ = mine(x.clone().requires_grad_(), h0, valids=valids)
     (out2 * w).sum().backward()
     assert all(torch.equal(a, p.grad) for a, p in zip(g1, mine.parameters()))
+
+
+def test_dgl_dgcnn_graph_replay_equals_eager_steps(cuda_device):
+    """BASELINE.json configs[2] as ONE HIP graph (bench.py --config c3 --graph): DGL draws no random numbers in
+    training, every kernel on its path is deterministic (no atomics: fixed-order statistics, the transposed kNN graph
+    in the encoder's backward), and the device-side valid-part count keeps the launch shapes static — so the replayed
+    graph must walk the eager trajectory to the last bit, with a different batch (other part counts) every step."""
+    from multi_part_assembly_amd import synthetic
+    from multi_part_assembly_amd.trainer import Trainer
+
+    def fresh(use_graph):
+        cfg = config.dgl_dgcnn_everyday()
+        torch.manual_seed(3)
+        model = build_model(cfg).to(cuda_device)
+        return Trainer(model, cfg, use_graph=use_graph, graph_warmup=1)
+
+    eager, graph = fresh(False), fresh(True)
+    for step in range(4):
+        batch = synthetic.make_batch(3, 20, 256, preset="everyday", seed=50 + step, device=cuda_device)
+        batch.pop("num_parts")
+        le = eager.train_step(dict(batch))
+        lg = graph.train_step(dict(batch))
+        assert float(lg) == float(le), (step, float(lg), float(le))
+    assert graph._graph is not None
+    assert torch.equal(graph.flat.flat_param, eager.flat.flat_param)
