@@ -312,14 +312,17 @@ class RGLNet(DGLModel):
         # consumes the GRU's 4F outputs; no ReLU after the last BatchNorm (rgl_net/modules.py:24-28)
         return _clones(_PairMLP(4 * self.pc_feat_dim, self.pc_feat_dim, final_relu=False), self.iter)
 
-    def _init_gru_hidden(self, B):
-        """Same random draws, in the same order, as rgl_net/network.py:50-57 (CPU generator)."""
-        rand_vec = torch.randn((1, B, self.pc_feat_dim)).repeat(2, 1, 1)
-        zero_vec = torch.randn((2, B, self.pc_feat_dim))
+    def _init_gru_hidden(self, B, device=None):
+        """Same random draws, in the same order, as rgl_net/network.py:50-57 (CPU generator).  While a HIP graph is
+        being captured the draws come from the device generator instead (a host-to-device copy cannot be a graph
+        node; torch advances the captured generator's offset on every replay)."""
+        where = device if device is not None and device.type == "cuda" and torch.cuda.is_current_stream_capturing() else None
+        rand_vec = torch.randn((1, B, self.pc_feat_dim), device=where).repeat(2, 1, 1)
+        zero_vec = torch.randn((2, B, self.pc_feat_dim), device=where)
         return torch.cat([rand_vec, zero_vec], dim=-1)
 
     def _node_update(self, part_feats, messages, data_dict, iter_ind):
-        hidden = self._init_gru_hidden(part_feats.shape[0]).type_as(messages)
+        hidden = self._init_gru_hidden(part_feats.shape[0], messages.device).type_as(messages)
         gru_out, _ = self.grus[iter_ind](torch.cat([part_feats, messages], dim=-1), hidden,
                                          valids=data_dict["part_valids"])
         return self.node_mlps[iter_ind](gru_out)

@@ -203,3 +203,23 @@ def test_dgl_dgcnn_graph_replay_equals_eager_steps(cuda_device):
         assert float(lg) == float(le), (step, float(lg), float(le))
     assert graph._graph is not None
     assert torch.equal(graph.flat.flat_param, eager.flat.flat_param)
+
+
+def test_rgl_net_step_captures_as_one_graph(cuda_device):
+    """BASELINE.json configs[4] in graph mode (bench.py --config c5 --graph): the GRU's random initial state is the
+    only host-side draw on RGL-NET's path; under capture it comes from the device generator (gnn.py), so the step has
+    no host-to-device copy left and replays with fresh noise — the replays must train (finite, moving loss) and draw
+    different initial states each time."""
+    from multi_part_assembly_amd import synthetic
+    from multi_part_assembly_amd.trainer import Trainer
+
+    cfg = config.rgl_net_dgcnn_artifact()
+    torch.manual_seed(5)
+    model = build_model(cfg).to(cuda_device)
+    tr = Trainer(model, cfg, use_graph=True, graph_warmup=1)
+    batch = synthetic.make_batch(3, 20, 256, preset="artifact", seed=9, device=cuda_device)
+    batch.pop("num_parts")
+    losses = [float(tr.train_step(dict(batch))) for _ in range(5)]
+    assert tr._graph is not None
+    assert all(np.isfinite(losses)), losses
+    assert len(set(losses[1:])) == 4, losses  # same batch, new noise + updated weights: no replay repeats a value
