@@ -63,6 +63,10 @@ def parse_args():
                     help="replay the step as one HIP graph (default: eager launches; see trainer.py)")
     ap.add_argument("--eager", action="store_true", help="(the default; accepted for symmetry)")
     ap.add_argument("--cpu-batch", type=int, default=4, help="samples in the CPU-baseline step")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: the separately named PERFORMANCE VARIANT of the PointNet encoder (csrc/pointnet_bf16.hip: "
+                         "bf16 activations and matrix-core GEMMs, fp32 statistics; transformer, pose head, losses and "
+                         "optimiser stay fp32) - a second line beside the fp32 parity run, never the default")
     args = ap.parse_args()
     args.config = CONFIG_ALIASES.get(args.config, args.config)
     return args
@@ -206,12 +210,22 @@ def kernel_table(kernels, num_parts, cfg, B, P):
             rec.update(bound="valu", lane_ops=kw["lane_ops"], frac=kw["lane_ops"] / secs / VALU_PEAK_LANE_OPS)
         if "bytes" in kw:
             rec.update(hbm_bytes=kw["bytes"], hbm_frac=kw["bytes"] / secs / 1e9 / HBM_PEAK_GBS)
+        if kw.get("bf16"):  # bf16 matrix cores (2.5 PFLOP/s dense): the variant is bound by the bf16 activations it moves
+            rec.update(bound="hbm", frac=rec["hbm_frac"], mfma_bf16_frac=kw["flops"] / secs / 2.5e15)
         rows[name] = rec
 
     if cfg.model.encoder == "pointnet":
         fwd = 2.0 * nv * N * (3 * 64 + 64 * 64 + 64 * 64 + 64 * 128 + 128 * F)
-        add("pointnet_forward", "pointnet_forward", flops=fwd)
-        add("pointnet_backward", "pointnet_backward", flops=2.0 * fwd)
+        add("pointnet_forward[", "pointnet_forward", flops=fwd)
+        add("pointnet_backward[", "pointnet_backward", flops=2.0 * fwd)
+        # the bf16 variant is bound by HBM: bytes of the bf16 activations it must move (written once forward; read by
+        # the next layer, by both gradient kernels of its own layer and by the gradient kernels of the next)
+        rows_b = 2.0 * nv * N
+        add("pointnet_forward_bf16", "pointnet_forward_bf16", flops=fwd, bf16=True,
+            bytes=rows_b * (2 * (64 * 3) + 2 * 128 + 2 * F) + 12.0 * nv * N)
+        add("pointnet_backward_bf16", "pointnet_backward_bf16", flops=2.0 * fwd, bf16=True,
+            bytes=rows_b * (2 * F + 2112))  # per layer: both gradient kernels read (G, y) of the layer and y of the
+        # one below, the input-gradient kernel writes G of the one below
     else:
         gemm = 2.0 * nv * N * (3 * 128 + 64 * 128 + 64 * 256 + 128 * 512 + 512 * F)
         add("dgcnn_forward", "dgcnn_forward", flops=gemm + 2.0 * nv * N * N * (3 + 64 + 64 + 128))
@@ -254,6 +268,13 @@ def main():
     cfg, batch, desc, B, P = workload(args.config, rank, dev)
     torch.manual_seed(0)  # same initial weights on every rank (and broadcast from rank 0 anyway)
     model = build_model(cfg).to(dev)
+    if args.dtype == "bf16":
+        from multi_part_assembly_amd.encoder import PointNet
+        nets = [m for m in model.modules() if isinstance(m, PointNet)]
+        if not nets:
+            sys.exit("bench.py: --dtype bf16 needs a PointNet encoder (configs c1, c2, c4)")
+        for m in nets:
+            m.precision = "bf16"
     use_graph = args.graph and not args.eager
     trainer = Trainer(model, cfg, use_graph=use_graph)
     num_parts = batch.pop("num_parts")
@@ -390,12 +411,15 @@ def main():
             "metric": "train-step parts/sec (BxP) at N=1000 pts",
             "value": value, "unit": "parts/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": desc, "name": args.config,
                        "per_gpu_batch": B, "max_parts": P, "points_per_part": POINTS,
                        "valid_parts_rank0": valid_parts, "parallelism": f"dp{world}",
                        "rccl_ranks": world if distributed else 0, "rccl_version": rccl,
-                       "launch": "hip-graph replay" if use_graph else "eager"},
+                       "launch": "hip-graph replay" if use_graph else "eager",
+                       **({"precision_note": "performance variant: PointNet encoder with bf16 stored activations and "
+                           "v_mfma_f32_32x32x16_bf16 GEMMs, fp32 BatchNorm statistics and gradients; everything else "
+                           "fp32; parity is claimed for the f32 line only"} if args.dtype == "bf16" else {})},
             "final_loss": final_loss,
             "kernels": kernels,
             "roofline": roofline,

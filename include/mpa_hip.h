@@ -185,6 +185,23 @@ int mpa_pointnet_backward(const float* grad_feat, const float* points, const flo
                           int64_t F, float* float_ws, const int32_t* int_ws, float* const* grad_conv_w,
                           float* const* grad_bn_w, float* const* grad_bn_b, void* stream);
 
+/* bf16 PERFORMANCE VARIANT of the PointNet encoder (csrc/pointnet_bf16.hip) — separately named, never the default,
+ * outside every parity claim (the reference's own precision switch: AMP runs the encoder's convolutions in half
+ * precision and keeps the Chamfer loss in fp32, multi_part_assembly/utils/chamfer/chamfer.py:14).  Same arguments
+ * and masking as mpa_pointnet_forward / _backward above; the convolution outputs are STORED in bf16, the GEMMs are
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation, BatchNorm statistics / affine / every reduction and all returned
+ * gradients are fp32 and deterministic.  One workspace (`bytes` from mpa_pointnet_workspace_bf16, 256-byte aligned)
+ * that must stay untouched between forward and backward. */
+int mpa_pointnet_workspace_bf16(int64_t M, int64_t N, int64_t F, int64_t* bytes);
+int mpa_pointnet_forward_bf16(const float* points, const float* valids, const float* const* conv_w,
+                              const float* const* bn_w, const float* const* bn_b, float* const* running_mean,
+                              float* const* running_var, int training, float momentum, float eps, int64_t M,
+                              int64_t N, int64_t F, void* ws, float* feat, void* stream);
+int mpa_pointnet_backward_bf16(const float* grad_feat, const float* points, const float* valids,
+                               const float* const* conv_w, const float* const* bn_w, int64_t M, int64_t N, int64_t F,
+                               void* ws, float* const* grad_conv_w, float* const* grad_bn_w, float* const* grad_bn_b,
+                               void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * DGCNN building blocks — replace
  *   knn / get_graph_feature : multi_part_assembly/models/modules/encoder/dgcnn.py:8-38

@@ -46,6 +46,9 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_pointnet_workspace": (_INT, [_I64, _I64, _I64, _P, _P]),
     "mpa_pointnet_forward": (_INT, [_P] * 7 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
     "mpa_pointnet_backward": (_INT, [_P] * 5 + [_I64, _I64, _I64] + [_P] * 6),
+    "mpa_pointnet_workspace_bf16": (_INT, [_I64, _I64, _I64, _P]),
+    "mpa_pointnet_forward_bf16": (_INT, [_P] * 7 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P]),
+    "mpa_pointnet_backward_bf16": (_INT, [_P] * 5 + [_I64, _I64, _I64] + [_P] * 5),
     "mpa_knn": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P]),
     "mpa_edge_aggregate_workspace": (_INT, [_I64, _I64, _I64, _I64, _P]),
     "mpa_edge_aggregate_forward": (_INT, [_P] * 6 + [_INT, _F32, _F32, _I64, _I64, _I64, _I64, _P, _P, _P]),

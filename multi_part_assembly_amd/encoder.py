@@ -75,6 +75,62 @@ class _PointNetFn(torch.autograd.Function):
         return (None, None, None, None, None, None, *grads)
 
 
+class _PointNetBF16Fn(torch.autograd.Function):
+    """The bf16 performance variant of the PointNet encoder (csrc/pointnet_bf16.hip): same interface as _PointNetFn."""
+
+    @staticmethod
+    def forward(ctx, points, valids, training, momentum, eps, running, *params):
+        conv_w, bn_w, bn_b = params[0:5], params[5:10], params[10:15]
+        run_mean, run_var = running
+        M, N, _ = points.shape
+        F_ = conv_w[4].shape[0]
+        dev = points.device
+        L = _lib.lib()
+        nb = ctypes.c_int64()
+        _lib.check(L.mpa_pointnet_workspace_bf16(M, N, F_, ctypes.byref(nb)), "mpa_pointnet_workspace_bf16")
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+        feat = torch.empty((M, F_), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"pointnet_forward_bf16[{M}x{N}x{F_}]")
+            st = L.mpa_pointnet_forward_bf16(
+                _lib.ptr(points), _lib.ptr(valids), _lib.ptr_array(conv_w), _lib.ptr_array(bn_w),
+                _lib.ptr_array(bn_b), _lib.ptr_array(run_mean), _lib.ptr_array(run_var), int(training),
+                float(momentum), float(eps), M, N, F_, _lib.ptr(ws), _lib.ptr(feat), _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_pointnet_forward_bf16")
+        ctx.training = bool(training)
+        ctx.params = params
+        GradSink.note_use(params)
+        ctx.save_for_backward(points, valids, ws)
+        return feat
+
+    @staticmethod
+    def backward(ctx, grad_feat):
+        if not ctx.training:
+            raise RuntimeError("PointNet (bf16): backward is implemented for training-mode BatchNorm only")
+        points, valids, ws = ctx.saved_tensors
+        params = ctx.params
+        conv_w, bn_w = params[0:5], params[5:10]
+        M, N, _ = points.shape
+        F_ = conv_w[4].shape[0]
+        dev = points.device
+        grads, direct = GradSink.outputs(params)
+        g_conv, g_bnw, g_bnb = grads[0:5], grads[5:10], grads[10:15]
+        grad_feat = grad_feat.contiguous()
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"pointnet_backward_bf16[{M}x{N}x{F_}]")
+            st = _lib.lib().mpa_pointnet_backward_bf16(
+                _lib.ptr(grad_feat), _lib.ptr(points), _lib.ptr(valids), _lib.ptr_array(conv_w),
+                _lib.ptr_array(bn_w), M, N, F_, _lib.ptr(ws), _lib.ptr_array(g_conv), _lib.ptr_array(g_bnw),
+                _lib.ptr_array(g_bnb), _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_pointnet_backward_bf16")
+        if direct:
+            GradSink.delivered(params)
+            return (None,) * (6 + len(params))
+        return (None, None, None, None, None, None, *grads)
+
+
 class PointNet(nn.Module):
     """Shared MLP 3-64-64-64-128-F (1x1 conv, no bias, BN, ReLU except after the last) + max over N.
 
@@ -96,6 +152,9 @@ class PointNet(nn.Module):
         for i in range(5):
             setattr(self, f"bn{i + 1}", nn.BatchNorm1d(dims[i + 1]))
         self.global_feat = global_feat
+        # "fp32": the parity path (csrc/pointnet.hip).  "bf16": the separately named performance variant
+        # (csrc/pointnet_bf16.hip, bench.py --dtype bf16) — bf16 activations and matrix-core GEMMs, fp32 statistics.
+        self.precision = "fp32"
 
     def forward_parts(self, part_pcs, valids):
         """part_pcs [M, N, 3], valids [M] (1/0) -> [M, feat_dim]; rows of padded parts are zero."""
@@ -107,7 +166,10 @@ class PointNet(nn.Module):
             with torch.no_grad():  # one multi-tensor launch for the five counters
                 torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
         running = ([bn.running_mean for bn in bns], [bn.running_var for bn in bns])
-        return _PointNetFn.apply(
+        if self.precision not in ("fp32", "bf16"):
+            raise ValueError(f"PointNet.precision must be 'fp32' or 'bf16', not {self.precision!r}")
+        fn = _PointNetFn if self.precision == "fp32" else _PointNetBF16Fn
+        return fn.apply(
             part_pcs.detach().float().contiguous(), valids.detach().float().contiguous(), self.training,
             bns[0].momentum, bns[0].eps, running, *[c.weight for c in convs], *[b.weight for b in bns],
             *[b.bias for b in bns])
