@@ -174,12 +174,15 @@ __global__ __launch_bounds__(kT) void pb_first_fwd_kernel(const float* __restric
 // grid = row tiles, block 256 = 2 x 2 waves, a wave owns 64 rows x CT/2 columns.  The whole K = CI panel of
 // both operands sits in LDS (bf16, rows padded by 16 bytes); the output tile goes back through LDS (aliasing the
 // panels) for 16-byte row-segment stores and the column statistics.
-template <int CI, int CT>
+// POOL (last layer, N >= 128: a tile touches at most two parts): the tile's per-column extrema and their rows go to
+// `pool` ([tiles][2][CO] records {max, min, row of max, row of min}, rows counted inside the part) — pb_pool_merge_kernel
+// picks by the sign of the BatchNorm scale once the statistics are final, so y5 is never read back for the pooling.
+template <int CI, int CT, bool POOL>
 __global__ __launch_bounds__(kT) void pb_fwd_kernel(const unsigned short* __restrict__ yin,
                                                     const float* __restrict__ coef_in,  // a [CI] | b [CI]
                                                     const unsigned short* __restrict__ Wb, int CO,
                                                     unsigned short* __restrict__ yout, float* __restrict__ part,
-                                                    const int* __restrict__ hdr) {
+                                                    const int* __restrict__ hdr, int N, float4* __restrict__ pool) {
   constexpr int LDK = CI + kPad, LDC = CT + kPad, TB = CT / 64;
   constexpr int kB = CT * LDK > kRows * LDC ? CT * LDK : kRows * LDC;  // the W panel, later the output tile
   __shared__ __attribute__((aligned(16))) unsigned short As[kRows * LDK];
@@ -189,22 +192,29 @@ __global__ __launch_bounds__(kT) void pb_fwd_kernel(const unsigned short* __rest
   const int r0 = blockIdx.x * kRows;
   if (r0 >= R) return;
   constexpr int G = CI / 8;
-  // A panel: affine + ReLU in fp32, rounded to bf16 — loaded ONCE, all CO / CT column tiles are computed from it
+  // A panel: affine + ReLU in fp32, rounded to bf16 — loaded ONCE, all CO / CT column tiles are computed from it.
+  // All loads are issued before the first value is used (clamped addresses, rows past the end are zeroed afterwards).
+  {
+    constexpr int NI = kRows * G / kT;
+    uint4 raw[NI];
 #pragma unroll
-  for (int i = 0; i < kRows * G / kT; ++i) {
-    const int idx = threadIdx.x + kT * i, row = idx / G, g = idx % G;
-    float f[8];
-    uint4 u = make_uint4(0u, 0u, 0u, 0u);
-    if (r0 + row < R) {
-      unpack8(*reinterpret_cast<const uint4*>(&yin[(long long)(r0 + row) * CI + 8 * g]), f);
-      float a[8], b[8];
+    for (int i = 0; i < NI; ++i) {
+      const int idx = threadIdx.x + kT * i, row = idx / G, g = idx % G;
+      const int rr = r0 + row < R ? r0 + row : R - 1;
+      raw[i] = *reinterpret_cast<const uint4*>(&yin[(long long)rr * CI + 8 * g]);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int idx = threadIdx.x + kT * i, row = idx / G, g = idx % G;
+      float f[8], a[8], b[8];
+      unpack8(raw[i], f);
       load8f(coef_in + 8 * g, a);
       load8f(coef_in + CI + 8 * g, b);
+      const bool ok = r0 + row < R;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = __builtin_fmaxf(__builtin_fmaf(a[e], f[e], b[e]), 0.0f);
-      u = pack8(f);
+      for (int e = 0; e < 8; ++e) f[e] = ok ? __builtin_fmaxf(__builtin_fmaf(a[e], f[e], b[e]), 0.0f) : 0.0f;
+      *reinterpret_cast<uint4*>(&As[row * LDK + 8 * g]) = pack8(f);
     }
-    *reinterpret_cast<uint4*>(&As[row * LDK + 8 * g]) = u;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
@@ -252,16 +262,80 @@ __global__ __launch_bounds__(kT) void pb_fwd_kernel(const unsigned short* __rest
         *reinterpret_cast<uint4*>(&yout[(long long)(r0 + row) * CO + n0 + 8 * g]) = *reinterpret_cast<const uint4*>(&Cs[row * LDC + 8 * g]);
     }
     tile_col_stats<CT>(Cs, LDC, red, part + (long long)blockIdx.x * 2 * CO + n0, CO);
+    if constexpr (POOL) {
+      constexpr int SLP = kT / CT, RPS = kRows / SLP;
+      __shared__ float4 pm[SLP][2][CT];
+      const int c = threadIdx.x % CT, sl = threadIdx.x / CT;
+      const int v0 = r0 / N, bnd = (v0 + 1) * N - r0;  // tile-local row where the next part starts
+      const int lim = R - r0 < kRows ? R - r0 : kRows;
+      float mxa = -__builtin_inff(), mna = __builtin_inff(), mxb = -__builtin_inff(), mnb = __builtin_inff();
+      int xa = 0, na = 0, xb = 0, nb = 0;
+      for (int i0 = sl * RPS; i0 < (sl + 1) * RPS; i0 += 8) {  // ascending rows, strict compares: lowest row on ties
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = unpack1(Cs[(i0 + u) * LDC + c]);  // eight LDS reads in flight
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u;
+          const float v = v8[u];
+          const bool ina = i < bnd && i < lim, inb = i >= bnd && i < lim;
+          const int rpa = r0 + i - v0 * N, rpb = i - bnd;
+          if (ina && v > mxa) { mxa = v; xa = rpa; }
+          if (ina && v < mna) { mna = v; na = rpa; }
+          if (inb && v > mxb) { mxb = v; xb = rpb; }
+          if (inb && v < mnb) { mnb = v; nb = rpb; }
+        }
+      }
+      pm[sl][0][c] = make_float4(mxa, mna, __int_as_float(xa), __int_as_float(na));
+      pm[sl][1][c] = make_float4(mxb, mnb, __int_as_float(xb), __int_as_float(nb));
+      __syncthreads();
+      if (threadIdx.x < 2 * CT) {
+        const int slot = threadIdx.x / CT;
+        float4 best = pm[0][slot][c];
+#pragma unroll
+        for (int k = 1; k < SLP; ++k) {
+          const float4 o = pm[k][slot][c];
+          if (o.x > best.x) { best.x = o.x; best.z = o.z; }
+          if (o.y < best.y) { best.y = o.y; best.w = o.w; }
+        }
+        pool[((long long)blockIdx.x * 2 + slot) * CO + n0 + c] = best;
+      }
+    }
     __syncthreads();  // before the next W panel overwrites the tile
   }
 }
 
-constexpr int kRS = 32;  // slices of the partial tables in the reduction kernels (512 threads = 16 channels x 32 slices)
+// feat = a ext + b from the per-tile extrema of pb_fwd_kernel<.., POOL>; grid = part slots, block F.
+__global__ void pb_pool_merge_kernel(const float4* __restrict__ pool, const float* __restrict__ coef, int N, int F,
+                                     const int* __restrict__ rank, float* __restrict__ feat, int* __restrict__ arg) {
+  const int m = blockIdx.x, c = threadIdx.x, v = rank[m];
+  if (v < 0) {
+    feat[(long long)m * F + c] = 0.0f;
+    return;
+  }
+  const float a = coef[c], b = coef[F + c];
+  const int t0 = (int)(((long long)v * N) / kRows), t1 = (int)((((long long)v + 1) * N - 1) / kRows);
+  float best = a >= 0.0f ? -__builtin_inff() : __builtin_inff();
+  int row = 0;
+  for (int t = t0; t <= t1; ++t) {  // ascending tiles, strict compares: lowest row on ties
+    const int slot = v - (int)(((long long)t * kRows) / N);
+    const float4 r = pool[((long long)t * 2 + slot) * F + c];
+    if (a >= 0.0f) {
+      if (r.x > best) { best = r.x; row = __float_as_int(r.z); }
+    } else {
+      if (r.y < best) { best = r.y; row = __float_as_int(r.w); }
+    }
+  }
+  feat[(long long)m * F + c] = __builtin_fmaf(a, best, b);
+  arg[(long long)v * F + c] = row;
+}
+
+constexpr int kRS = 64;  // slices of the partial tables in the reduction kernels (1024 threads = 16 channels x 64 slices)
 // slice `sl` of kRS of the per-tile partials of channel c: part[t][c] and part[t][C + c], eight loads in flight
 __device__ __forceinline__ void sum_partials(const float* __restrict__ part, int C, int c, int sl, int tiles, double& s,
                                              double& q) {
   int t = sl;
-  for (; t + kRS * 7 < tiles; t += kRS * 8) {
+  for (; t + kRS * 7 < tiles; t += kRS * 8) {  // 16 loads in flight
     float a[8], b[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -281,24 +355,32 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ part, int
 }
 
 // ---- BatchNorm finalisation: partial sums -> coef = a | b | mean | rstd; running statistics --------------------------------
-// grid = C / 16, block 512: 16 channels x 32 slices of the tile range; double accumulation, fixed order.
-__global__ __launch_bounds__(512) void pb_finalize_kernel(const float* __restrict__ part, int C, const int* __restrict__ hdr,
+// grid = C / 16, block 1024: 16 channels x 64 slices of the tile range; double accumulation, fixed order.
+__global__ __launch_bounds__(1024) void pb_finalize_kernel(const float* __restrict__ part, int C, const int* __restrict__ hdr,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ rmean, float* __restrict__ rvar,
                                                          int training, float momentum, float eps,
                                                          float* __restrict__ coef) {
-  __shared__ double red[2][kRS][16];
+  __shared__ double red[2][kRS / 4][16];
   const int R = hdr[1];
   const int tiles = (R + kRows - 1) / kRows;
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
   double s = 0.0, q = 0.0;
   if (training) sum_partials(part, C, c, sl, tiles, s, q);
-  red[0][sl][cl] = s;
-  red[1][sl][cl] = q;
+  // a wave holds 4 slices of the 16 channels: fold them with two butterflies, then the 16 waves meet in LDS
+  s += __shfl_xor(s, 16, 64);
+  q += __shfl_xor(q, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  q += __shfl_xor(q, 32, 64);
+  if ((threadIdx.x & 63) < 16) {
+    red[0][threadIdx.x >> 6][cl] = s;
+    red[1][threadIdx.x >> 6][cl] = q;
+  }
   __syncthreads();
   if (threadIdx.x < 16) {
     double ts = 0.0, tq = 0.0;
-    for (int k = 0; k < kRS; ++k) {
+#pragma unroll 4
+    for (int k = 0; k < kRS / 4; ++k) {
       ts += red[0][k][cl];
       tq += red[1][k][cl];
     }
@@ -431,23 +513,31 @@ __global__ void pb_top_mark_kernel(const float* __restrict__ grad_feat, const in
 
 // s1, s2 from the partial table -> dgamma, dbeta and the coefficients a | P | Q.  The table has one row per row tile
 // (layers 4..1: written by the input-gradient kernel) or per valid part (last layer: pb_top_mark_kernel).
-// grid = C / 16, block 512.
-__global__ __launch_bounds__(512) void pb_bwd_coef_kernel(const float* __restrict__ part, int C, const int* __restrict__ hdr,
+// grid = C / 16, block 1024.
+__global__ __launch_bounds__(1024) void pb_bwd_coef_kernel(const float* __restrict__ part, int C, const int* __restrict__ hdr,
                                                            int per_part, const float* __restrict__ coef,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ bc) {
-  __shared__ double red[2][kRS][16];
+  __shared__ double red[2][kRS / 4][16];
   const int R = hdr[1];
   const int tiles = per_part ? hdr[0] : (R + kRows - 1) / kRows;
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
   double s = 0.0, q = 0.0;
   sum_partials(part, C, c, sl, tiles, s, q);
-  red[0][sl][cl] = s;
-  red[1][sl][cl] = q;
+  // a wave holds 4 slices of the 16 channels: fold them with two butterflies, then the 16 waves meet in LDS
+  s += __shfl_xor(s, 16, 64);
+  q += __shfl_xor(q, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  q += __shfl_xor(q, 32, 64);
+  if ((threadIdx.x & 63) < 16) {
+    red[0][threadIdx.x >> 6][cl] = s;
+    red[1][threadIdx.x >> 6][cl] = q;
+  }
   __syncthreads();
   if (threadIdx.x < 16) {
     double t1 = 0.0, t2 = 0.0;
-    for (int k = 0; k < kRS; ++k) {
+#pragma unroll 4
+    for (int k = 0; k < kRS / 4; ++k) {
       t1 += red[0][k][cl];
       t2 += red[1][k][cl];
     }
@@ -541,21 +631,57 @@ __global__ __launch_bounds__(kT) void pb_dgrad_kernel(const unsigned short* __re
 #pragma unroll 1
   for (int ph = 0; ph < NPH; ++ph) {
     if (ph > 0) __syncthreads();
-#pragma unroll 2
-    for (int i = 0; i < kRows * GK / kT; ++i) {
-      const int idx = threadIdx.x + kT * i, row = idx / GK, g = idx % GK;
-      uint4 u = make_uint4(0u, 0u, 0u, 0u);
-      if (r0 + row < R) {
-        float d[8];
-        dy8<TOP, CO>(G, y, top, bcs, (long long)(r0 + row), ph * KP + 8 * g, d);
-        u = pack8(d);
-      }
-      *reinterpret_cast<uint4*>(&As[row * LDK + 8 * g]) = u;
-    }
+    {  // every load of the phase is issued before the first value is used
+      constexpr int NA_ = kRows * GK / kT, NB_ = CI * GK / kT;
+      uint4 ry[NA_], rg[TOP ? 1 : NA_], rw[NB_];
 #pragma unroll
-    for (int i = 0; i < CI * GK / kT; ++i) {
-      const int idx = threadIdx.x + kT * i, row = idx / GK, g = idx % GK;
-      *reinterpret_cast<uint4*>(&Bs[row * LDK + 8 * g]) = *reinterpret_cast<const uint4*>(&Wt[(long long)row * CO + ph * KP + 8 * g]);
+      for (int i = 0; i < NA_; ++i) {
+        const int idx = threadIdx.x + kT * i, row = idx / GK, g = idx % GK;
+        const long long rr = r0 + row < R ? r0 + row : R - 1;
+        ry[i] = *reinterpret_cast<const uint4*>(&y[rr * CO + ph * KP + 8 * g]);
+        if constexpr (!TOP) rg[i] = *reinterpret_cast<const uint4*>(&G[rr * CO + ph * KP + 8 * g]);
+      }
+#pragma unroll
+      for (int i = 0; i < NB_; ++i) {
+        const int idx = threadIdx.x + kT * i, row = idx / GK, g = idx % GK;
+        rw[i] = *reinterpret_cast<const uint4*>(&Wt[(long long)row * CO + ph * KP + 8 * g]);
+      }
+#pragma unroll
+      for (int i = 0; i < NA_; ++i) {
+        const int idx = threadIdx.x + kT * i, row = idx / GK, g = idx % GK, c8 = ph * KP + 8 * g;
+        const bool ok = r0 + row < R;
+        float fy[8], fg[8], d[8];
+        unpack8(ry[i], fy);
+        if constexpr (TOP) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fg[e] = 0.0f;  // the few arg-max positions are patched below
+        } else {
+          unpack8(rg[i], fg);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          d[e] = ok ? __builtin_fmaf(bcs[c8 + e], fg[e], __builtin_fmaf(bcs[2 * CO + c8 + e], fy[e], bcs[CO + c8 + e])) : 0.0f;
+        *reinterpret_cast<uint4*>(&As[row * LDK + 8 * g]) = pack8(d);
+      }
+#pragma unroll
+      for (int i = 0; i < NB_; ++i) {
+        const int idx = threadIdx.x + kT * i, row = idx / GK, g = idx % GK;
+        *reinterpret_cast<uint4*>(&Bs[row * LDK + 8 * g]) = rw[i];
+      }
+      if constexpr (TOP) {
+        // one item in ~N / 8 holds an arg-max of its 8 channels: those are recomputed with the pooled gradient (the
+        // thread rewrites its own LDS slot; a rolled loop keeps the common path free of this code's registers)
+#pragma unroll 1
+        for (int i = 0; i < NA_; ++i) {
+          const int idx = threadIdx.x + kT * i, row = idx / GK, g = idx % GK, c8 = ph * KP + 8 * g;
+          if (r0 + row >= R) continue;
+          const long long rr = r0 + row;
+          if (!((top.bitmap[rr] >> (c8 >> 3)) & 1u)) continue;
+          float d[8];
+          dy8<true, CO>(G, y, top, bcs, rr, c8, d);
+          *reinterpret_cast<uint4*>(&As[row * LDK + 8 * g]) = pack8(d);
+        }
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -593,25 +719,35 @@ __global__ __launch_bounds__(kT) void pb_dgrad_kernel(const unsigned short* __re
   load8f(coef_prev + 3 * CI + 8 * g, pr);
 #pragma unroll
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.0f;
-#pragma unroll 2
-  for (int i = 0; i < kRows / RS; ++i) {
-    const int row = rb + RS * i;
-    if (r0 + row < R) {
-      float fy[8], o[8];
-      unpack8(*reinterpret_cast<const uint4*>(&yprev[(long long)(r0 + row) * CI + 8 * g]), fy);
-      const float4 c0 = *reinterpret_cast<const float4*>(&Cs[row * LDC + 8 * g]);
-      const float4 c1 = *reinterpret_cast<const float4*>(&Cs[row * LDC + 8 * g + 4]);
-      const float d[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  {
+    constexpr int NE = kRows / RS;
+    uint4 ryp[NE];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(pa[e], fy[e], pb_[e]) > 0.0f ? d[e] : 0.0f;
-      const uint4 u = pack8(o);
-      *reinterpret_cast<uint4*>(&gprev[(long long)(r0 + row) * CI + 8 * g]) = u;
-      float rq[8];
-      unpack8(u, rq);  // the sums see the stored (rounded) values
+    for (int i = 0; i < NE; ++i) {
+      const int row = rb + RS * i;
+      const long long rr = r0 + row < R ? r0 + row : R - 1;
+      ryp[i] = *reinterpret_cast<const uint4*>(&yprev[rr * CI + 8 * g]);
+    }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        s1[e] += rq[e];
-        s2[e] += rq[e] * ((fy[e] - pm[e]) * pr[e]);
+    for (int i = 0; i < NE; ++i) {
+      const int row = rb + RS * i;
+      if (r0 + row < R) {
+        float fy[8], o[8];
+        unpack8(ryp[i], fy);
+        const float4 c0 = *reinterpret_cast<const float4*>(&Cs[row * LDC + 8 * g]);
+        const float4 c1 = *reinterpret_cast<const float4*>(&Cs[row * LDC + 8 * g + 4]);
+        const float d[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(pa[e], fy[e], pb_[e]) > 0.0f ? d[e] : 0.0f;
+        const uint4 u = pack8(o);
+        *reinterpret_cast<uint4*>(&gprev[(long long)(r0 + row) * CI + 8 * g]) = u;
+        float rq[8];
+        unpack8(u, rq);  // the sums see the stored (rounded) values
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s1[e] += rq[e];
+          s2[e] += rq[e] * ((fy[e] - pm[e]) * pr[e]);
+        }
       }
     }
   }
@@ -821,6 +957,7 @@ struct Ws {
   unsigned short* g[5];  // g[l]: gradient w.r.t. the BatchNorm output of layer l + 1, l < 4 (the last layer's is never stored)
   float* part;
   float* partw;
+  float4* pool;      // [tiles][2][F] extrema records of the last layer's tiles
   unsigned* bitmap;  // one word per row (backward of the last layer)
 };
 
@@ -856,6 +993,7 @@ Ws carve(void* base, int64_t M, int64_t N, int64_t F, int64_t* total) {
   if (tiles * 192 > pw) pw = tiles * 192;
   w.partw = reinterpret_cast<float*>(take(p, 4 * pw));
   w.bitmap = reinterpret_cast<unsigned*>(take(p, 4 * R));
+  w.pool = reinterpret_cast<float4*>(take(p, 16 * tiles * 2 * F));
   if (total) *total = p - static_cast<char*>(base);
   return w;
 }
@@ -905,7 +1043,7 @@ extern "C" int mpa_pointnet_forward_bf16(const float* points, const float* valid
            w.wb[l], w.wt[l]);
   launch(pb_first_fwd_kernel, dim3(tiles), dim3(kT), s, points, (const int*)w.vlist, (int)N, conv_w[0], w.y[0], w.part, hdr);
   auto finalize = [&](int l) {
-    launch(pb_finalize_kernel, dim3((unsigned)(C[l + 1] / 16)), dim3(512), s, (const float*)w.part, C[l + 1], hdr, bn_w[l],
+    launch(pb_finalize_kernel, dim3((unsigned)(C[l + 1] / 16)), dim3(1024), s, (const float*)w.part, C[l + 1], hdr, bn_w[l],
            bn_b[l], running_mean[l], running_var[l], training, momentum, eps, w.coef[l]);
   };
   finalize(0);
@@ -914,18 +1052,28 @@ extern "C" int mpa_pointnet_forward_bf16(const float* points, const float* valid
     const unsigned short* yin = w.y[l - 1];
     const float* cin = w.coef[l - 1];
     const unsigned short* wb = w.wb[l];
+    const bool fuse_pool = l == 4 && N >= kRows;  // (shorter parts: a tile could touch three of them)
+    float4* none = nullptr;
     if (CI == 64 && CO == 64)
-      launch(pb_fwd_kernel<64, 64>, dim3(tiles), dim3(kT), s, yin, cin, wb, CO, w.y[l], w.part, hdr);
+      launch(pb_fwd_kernel<64, 64, false>, dim3(tiles), dim3(kT), s, yin, cin, wb, CO, w.y[l], w.part, hdr, (int)N, none);
     else if (CI == 64)
-      launch(pb_fwd_kernel<64, 128>, dim3(tiles), dim3(kT), s, yin, cin, wb, CO, w.y[l], w.part, hdr);
+      launch(pb_fwd_kernel<64, 128, false>, dim3(tiles), dim3(kT), s, yin, cin, wb, CO, w.y[l], w.part, hdr, (int)N, none);
+    else if (CO == 64 && fuse_pool)
+      launch(pb_fwd_kernel<128, 64, true>, dim3(tiles), dim3(kT), s, yin, cin, wb, CO, w.y[l], w.part, hdr, (int)N, w.pool);
     else if (CO == 64)
-      launch(pb_fwd_kernel<128, 64>, dim3(tiles), dim3(kT), s, yin, cin, wb, CO, w.y[l], w.part, hdr);
+      launch(pb_fwd_kernel<128, 64, false>, dim3(tiles), dim3(kT), s, yin, cin, wb, CO, w.y[l], w.part, hdr, (int)N, none);
+    else if (fuse_pool)
+      launch(pb_fwd_kernel<128, 128, true>, dim3(tiles), dim3(kT), s, yin, cin, wb, CO, w.y[l], w.part, hdr, (int)N, w.pool);
     else
-      launch(pb_fwd_kernel<128, 128>, dim3(tiles), dim3(kT), s, yin, cin, wb, CO, w.y[l], w.part, hdr);
+      launch(pb_fwd_kernel<128, 128, false>, dim3(tiles), dim3(kT), s, yin, cin, wb, CO, w.y[l], w.part, hdr, (int)N, none);
     finalize(l);
   }
-  launch(pb_pool_kernel, dim3((unsigned)M), dim3(kT), s, (const unsigned short*)w.y[4], (const float*)w.coef[4], (int)N,
-         (int)F, (const int*)w.rank, feat, w.arg);
+  if (N >= kRows)
+    launch(pb_pool_merge_kernel, dim3((unsigned)M), dim3((unsigned)F), s, (const float4*)w.pool, (const float*)w.coef[4],
+           (int)N, (int)F, (const int*)w.rank, feat, w.arg);
+  else
+    launch(pb_pool_kernel, dim3((unsigned)M), dim3(kT), s, (const unsigned short*)w.y[4], (const float*)w.coef[4], (int)N,
+           (int)F, (const int*)w.rank, feat, w.arg);
   return mpa::check_launch("pointnet_forward_bf16");
 }
 
@@ -949,7 +1097,7 @@ extern "C" int mpa_pointnet_backward_bf16(const float* grad_feat, const float* p
   mpa::zero_words_async(w.bitmap, R, s);
   launch(pb_top_mark_kernel, dim3((unsigned)M), dim3((unsigned)F), s, grad_feat, (const int*)w.vlist, (const int*)w.arg,
          (const unsigned short*)w.y[4], (const float*)w.coef[4], (int)N, (int)F, hdr, w.part, w.bitmap);
-  launch(pb_bwd_coef_kernel, dim3((unsigned)(F / 16)), dim3(512), s, (const float*)w.part, (int)F, hdr, 1,
+  launch(pb_bwd_coef_kernel, dim3((unsigned)(F / 16)), dim3(1024), s, (const float*)w.part, (int)F, hdr, 1,
          (const float*)w.coef[4], grad_bn_w[4], grad_bn_b[4], w.bc[4]);
 #define PB_BWD(CI, CO, TOP, l)                                                                                            \
   {                                                                                                                       \
@@ -960,7 +1108,7 @@ extern "C" int mpa_pointnet_backward_bf16(const float* grad_feat, const float* p
     launch(pb_dgrad_kernel<CI, CO, TOP>, dim3(tiles), dim3(kT), s, (const unsigned short*)(TOP ? nullptr : w.g[l]),        \
            (const unsigned short*)w.y[l], TOP ? top : none, (const float*)w.bc[l], (const unsigned short*)w.wt[l],         \
            (const unsigned short*)w.y[l - 1], (const float*)w.coef[l - 1], w.g[l - 1], w.part, hdr);                       \
-    launch(pb_bwd_coef_kernel, dim3((unsigned)(CI / 16)), dim3(512), s, (const float*)w.part, CI, hdr, 0,                  \
+    launch(pb_bwd_coef_kernel, dim3((unsigned)(CI / 16)), dim3(1024), s, (const float*)w.part, CI, hdr, 0,                 \
            (const float*)w.coef[l - 1], grad_bn_w[l - 1], grad_bn_b[l - 1], w.bc[l - 1]);                                  \
   }
   if (F == 256) PB_BWD(128, 256, true, 4)
