@@ -98,6 +98,14 @@ struct GemmArgs {
   const float* resid;  // EPI_DROP_RESID: [M, N];  EPI_*_MASK: the saved activations [M, N]
   Drop drop;
   unsigned epi_site;
+  // LNF (LayerNorm fused into the operand load, K = 256 only): A is the un-normalised x; the block normalises its 32
+  // rows in registers; the blocks of column 0 also write what the standalone LayerNorm kernel would have written
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  float* ln_stats;   // [M][2] mean, rstd
+  float* ln_h;       // [M, K] the normalised rows (the weight gradient's operand)
+  float* ln_xcopy;   // nullable: x itself (the first layer keeps its input)
 };
 
 // grid = (ceil(M/32), N/32), block = 8 waves: the block owns ONE 32 x 32 MFMA tile and the waves split K.
@@ -123,8 +131,9 @@ __host__ __device__ inline int gemm_phase(int K) {
 // NPH > 0: K is exactly NPH phases and ALL global loads of the block are issued up front (NPH * 16 B * 2 per
 // thread in registers), so the block pays the L2/HBM latency once instead of once per phase; with NPH >= 3 the LDS
 // panels are double-buffered (one barrier per phase).  NPH == 0: any K, loads one phase ahead.
-template <int EPI, bool WT, int NPH>
+template <int EPI, bool WT, int NPH, bool LNF = false>
 __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
+  static_assert(!LNF || (NPH == 2 && !WT), "the fused LayerNorm needs the whole K = 2 x 128 row in registers");
   constexpr int kBuf = NPH >= 3 ? 2 : 1, kPanel = 2 * 32 * kLD;
   __shared__ __attribute__((aligned(16))) float lds[kBuf * kPanel];  // A panel | W panel; later the 8 partial tiles
   float* la = lds;
@@ -185,6 +194,56 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
     Stage st[NPH];
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) fetch(ph, st[ph]);
+    if constexpr (LNF) {
+      // thread t holds, per phase, columns 4 (t % 32) .. + 3 of rows t / 32 and 16 + t / 32: a row lives in one half-wave
+      const int c4 = threadIdx.x & 31;
+      float4 gm[NPH], bt[NPH];
+#pragma unroll
+      for (int ph = 0; ph < NPH; ++ph) {
+        gm[ph] = *reinterpret_cast<const float4*>(g.ln_gamma + ph * kKP + 4 * c4);
+        bt[ph] = *reinterpret_cast<const float4*>(g.ln_beta + ph * kKP + 4 * c4);
+      }
+#pragma unroll
+      for (int i = 0; i < kFI; ++i) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) sum += (st[ph].a[i].x + st[ph].a[i].y) + (st[ph].a[i].z + st[ph].a[i].w);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = sum / (float)(NPH * kKP);
+        float var = 0.0f;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+          const float dx = st[ph].a[i].x - mean, dy = st[ph].a[i].y - mean, dz = st[ph].a[i].z - mean,
+                      dw = st[ph].a[i].w - mean;
+          var += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) var += __shfl_xor(var, off, 64);
+        const float rstd = 1.0f / __builtin_sqrtf(var / (float)(NPH * kKP) + g.ln_eps);
+        const int row = r0 + (threadIdx.x >> 5) + 16 * i;
+        const bool save = blockIdx.y == 0 && row < g.M;
+        if (save && c4 == 0) {
+          g.ln_stats[2 * row] = mean;
+          g.ln_stats[2 * row + 1] = rstd;
+        }
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+          const float4 x = st[ph].a[i];
+          float4 hn;
+          hn.x = (x.x - mean) * rstd * gm[ph].x + bt[ph].x;
+          hn.y = (x.y - mean) * rstd * gm[ph].y + bt[ph].y;
+          hn.z = (x.z - mean) * rstd * gm[ph].z + bt[ph].z;
+          hn.w = (x.w - mean) * rstd * gm[ph].w + bt[ph].w;
+          st[ph].a[i] = hn;
+          if (save) {
+            const long long o = (long long)row * g.K + ph * kKP + 4 * c4;
+            *reinterpret_cast<float4*>(g.ln_h + o) = hn;
+            if (g.ln_xcopy != nullptr) *reinterpret_cast<float4*>(g.ln_xcopy + o) = x;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
       stash(ph, st[ph], ph % kBuf);
@@ -663,6 +722,13 @@ void launch_gemm(const GemmArgs& g, hipStream_t s) {
   }
 }
 
+// C = epi(LayerNorm(x) . W^T + bias) for K = 2 x kKP: the LayerNorm rides in the GEMM's operand load (g.ln_* set)
+template <int EPI>
+void launch_gemm_ln(const GemmArgs& g, hipStream_t s) {
+  const dim3 grid((g.M + 31) / 32, g.N / 32), block(kGT);
+  hipLaunchKernelGGL((gemm_kernel<EPI, false, 2, true>), grid, block, 0, s, g);
+}
+
 // one launch for n <= kGroup weight gradients
 void launch_wgrad_group(const WgradArgs* list, int n, hipStream_t s) {
   WgradGroup G{};
@@ -792,14 +858,27 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
   const int M = (int)d.M, Di = (int)D, FFi = (int)FF;
   const float eps = 1e-5f;
   const dim3 rows((M + 3) / 4);
+  const bool fuse_ln = Di == 2 * kKP;  // D = 256: a block's 32 rows fit its registers, LayerNorm rides in the next GEMM
   for (int l = 0; l < L; ++l) {  // layer l + 1 finds its input already in its own x_in slot
     const float* const* pp = params + l * P_PER_LAYER;
     const TfWs& t = w.layer[l];
     const unsigned site0 = (unsigned)(l * S_PER_LAYER);
-    hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, l == 0 ? tokens : t.x_in, pp[P_G1], pp[P_BE1], M, Di, eps,
-                       t.stats1, t.h1, l == 0 ? t.x_in : (float*)nullptr);
-    GemmArgs g = gemm_args(t.h1, pp[P_WQKV], pp[P_BQKV], t.qkv, M, 3 * Di, Di);
-    launch_gemm<EPI_NONE>(g, s);
+    GemmArgs g;
+    if (fuse_ln) {  // LN1 inside the qkv GEMM
+      g = gemm_args(l == 0 ? tokens : t.x_in, pp[P_WQKV], pp[P_BQKV], t.qkv, M, 3 * Di, Di);
+      g.ln_gamma = pp[P_G1];
+      g.ln_beta = pp[P_BE1];
+      g.ln_eps = eps;
+      g.ln_stats = t.stats1;
+      g.ln_h = t.h1;
+      g.ln_xcopy = l == 0 ? t.x_in : (float*)nullptr;
+      launch_gemm_ln<EPI_NONE>(g, s);
+    } else {
+      hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, l == 0 ? tokens : t.x_in, pp[P_G1], pp[P_BE1], M, Di, eps,
+                         t.stats1, t.h1, l == 0 ? t.x_in : (float*)nullptr);
+      g = gemm_args(t.h1, pp[P_WQKV], pp[P_BQKV], t.qkv, M, 3 * Di, Di);
+      launch_gemm<EPI_NONE>(g, s);
+    }
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, valid, (int)P, Di, (int)H,
                        drop, site0 + S_ATTN, t.probs, t.o);
     g = gemm_args(t.o, pp[P_WO], pp[P_BO], t.x_mid, M, Di, Di);
@@ -807,12 +886,24 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
     g.drop = drop;
     g.epi_site = site0 + S_SA_OUT;
     launch_gemm<EPI_DROP_RESID>(g, s);
-    hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, t.x_mid, pp[P_G2], pp[P_BE2], M, Di, eps, t.stats2, t.h2,
-                       (float*)nullptr);
-    g = gemm_args(t.h2, pp[P_W1], pp[P_B1], t.f, M, FFi, Di);
-    g.drop = drop;
-    g.epi_site = site0 + S_FFN;
-    launch_gemm<EPI_RELU_DROP>(g, s);
+    if (fuse_ln) {  // LN2 inside the first FFN GEMM
+      g = gemm_args(t.x_mid, pp[P_W1], pp[P_B1], t.f, M, FFi, Di);
+      g.ln_gamma = pp[P_G2];
+      g.ln_beta = pp[P_BE2];
+      g.ln_eps = eps;
+      g.ln_stats = t.stats2;
+      g.ln_h = t.h2;
+      g.drop = drop;
+      g.epi_site = site0 + S_FFN;
+      launch_gemm_ln<EPI_RELU_DROP>(g, s);
+    } else {
+      hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, t.x_mid, pp[P_G2], pp[P_BE2], M, Di, eps, t.stats2, t.h2,
+                         (float*)nullptr);
+      g = gemm_args(t.h2, pp[P_W1], pp[P_B1], t.f, M, FFi, Di);
+      g.drop = drop;
+      g.epi_site = site0 + S_FFN;
+      launch_gemm<EPI_RELU_DROP>(g, s);
+    }
     float* x_out = l + 1 < L ? w.layer[l + 1].x_in : w.x_final;
     g = gemm_args(t.f, pp[P_W2], pp[P_B2], x_out, M, Di, FFi);
     g.resid = t.x_mid;
