@@ -5,7 +5,7 @@
 //
 // Per sample (both transformed shapes, <= 20 000 valid points each):
 //   1. grid_params : bounding box of BOTH shapes' valid points -> one uniform grid per sample, <= 32768
-//                    cells (~0.8 points of each shape per cell: finer beats coarser, 1.29 -> 1.06 ms on clumpy artifact-like shapes), <= 64 cells per axis.  Covering the union
+//                    cells (~0.6 points of each shape per cell: finer beats coarser, most of all on clumpy artifact-like shapes), <= 64 cells per axis.  Covering the union
 //                    means no query is ever outside the grid.
 //   2. grid_sort   : counting sort of each shape, one 1024-thread block per (sample, shape) with both histograms
 //                    in LDS (count, scan, scatter in one launch),
@@ -40,14 +40,20 @@ namespace {
 constexpr int kMaxCells = 32768;
 constexpr int kMaxAxis = 64;
 constexpr int kStartStride = kMaxCells + 8;   // ints per (sample, shape, role) slot
-constexpr int kS = 2;                         // super-cell edge in fine cells (the query bins of the search): 2 is best
+#ifndef MPA_GRID_KS
+#define MPA_GRID_KS 2
+#endif
+#ifndef MPA_GRID_WAVES
+#define MPA_GRID_WAVES 512
+#endif
+constexpr int kS = MPA_GRID_KS;                         // super-cell edge in fine cells (the query bins of the search): 2 is best
                                               // while predictions are far from the ground truth (a wave's search radius is
                                               // its worst query's), 3 once they are close (0.62 vs 0.74 ms loss forward)
 constexpr int kMaxSuper = 4096;               // super-cells per sample (<= 22^3 would need more: see grid_params)
 constexpr int kWorkStride = kMaxSuper + 20000 / 64 + 64;  // search work items per slot (<= nsuper + points/batch)
 constexpr int kBatch = 64;                    // queries per search wave (1 per lane)
 #ifndef MPA_GRID_DENSITY
-#define MPA_GRID_DENSITY 0.8f
+#define MPA_GRID_DENSITY 0.6f
 #endif
 constexpr float kPointsPerCell = MPA_GRID_DENSITY;  // target points of one shape per fine cell (tools/variant_bench.sh)
 
@@ -375,7 +381,13 @@ __device__ __forceinline__ float gap(float a0, float a1, float b0, float b1) {
 // once), and then all lanes scan that list with broadcast LDS reads: two latencies per BATCH.  Long lists are
 // processed in windows of the LDS buffer; single long ranges go to the scalar scan, whose long runs amortise the
 // latency by themselves.
-constexpr int kCand = 512;      // candidate records per LDS window (8 KB per wave)
+#ifndef MPA_GRID_CAND
+#define MPA_GRID_CAND 128
+#endif
+constexpr int kCand = MPA_GRID_CAND;  // candidate records per LDS window (2.5 KB per wave: the window is what limits the
+                                      // waves per CU, and this latency-bound search wants all of them — 512 -> 128 records
+                                      // together with 512 instead of 128 persistent waves per (sample, direction) took
+                                      // the kernel from 0.44 to 0.28 ms; tools/variant_bench.sh)
 constexpr int kLongRange = 32;  // ranges longer than this are fetched by the whole wave, one range at a time
 
 // every lane scans the wn candidate records staged in LDS (padded to a multiple of 8 with sentinels)
@@ -510,7 +522,7 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
   }
 }
 
-// grid = (128 persistent waves per (sample, dir), 2*B), block 64.  blockIdx.y = b*2 + dir; dir 0: shape 1 queries
+// grid = (512 persistent waves per (sample, dir), 2*B), block 64.  blockIdx.y = b*2 + dir; dir 0: shape 1 queries
 // against shape 2 targets.
 __global__ __launch_bounds__(64) void grid_search_kernel(
     const float* __restrict__ valids, const float* __restrict__ S1, const float* __restrict__ S2, int P,
@@ -730,7 +742,7 @@ int launch_grid_shape_search(const float* valids, const float* S1, const float* 
                      starts, batches, worklist, records, rec_stride);
   // persistent waves: 128 per (sample, direction) walk that pair's work list of (super-cell, 64-query batch) items
   if (before_search != nullptr) (void)hipEventRecord(before_search, s);
-  hipLaunchKernelGGL(grid_search_kernel, dim3(128, (unsigned)(2 * B)), dim3(64), 0, s, valids, S1, S2, (int)P,
+  hipLaunchKernelGGL(grid_search_kernel, dim3(MPA_GRID_WAVES, (unsigned)(2 * B)), dim3(64), 0, s, valids, S1, S2, (int)P,
                      (int)N, params, records, starts, batches, worklist, rec_stride, dist1, dist2, idx1, idx2);
   if (after_search != nullptr) (void)hipEventRecord(after_search, s);
   hipLaunchKernelGGL(grid_part_sum_kernel, dim3((unsigned)(B * P), 2), dim3(256), 0, s, valids, dist1, dist2, (int)N,
