@@ -876,7 +876,10 @@ __global__ __launch_bounds__(kT, 2) void pn_dgrad_mfma_kernel(
 //   WG_FIRST : A = the raw input points (3 columns, zero-padded to one 32-wide tile) — first layer.
 //   WG_GRAM  : dY := A (COUT == CIN): the Gram matrix A^T A plus, in row COUT, the column sums of A — what the
 //              weight gradient of the never-stored last layer needs (pn_top_wgrad_kernel).
-constexpr int kWG = 512;  // persistent blocks (2 per CU)
+#ifndef MPA_PN_WG
+#define MPA_PN_WG 512
+#endif
+constexpr int kWG = MPA_PN_WG;  // persistent blocks (2 per CU)
 enum { WG_NORMAL = 0, WG_FIRST = 1, WG_GRAM = 2 };  // (WG_NORMAL: layers 2-4, now inside pn_bwd_fused_kernel)
 
 // LDY / co0: the block handles the COUT output channels starting at column co0 of a layer that is LDY wide
@@ -1060,7 +1063,10 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
 // partial dW, reduced in fixed order by pn_bwd_coef_kernel / pn_wgrad_reduce_kernel.
 // Measured (352 valid parts x 1000 points): 106 us for 64 -> 64 (separate kernels: 174), 153 us for 64 -> 128 (293);
 // the fp32 MFMA floor of the two GEMMs is 37 / 74 us, the HBM floor 58 / 86 us.
-constexpr int kWF = 256;
+#ifndef MPA_PN_WF
+#define MPA_PN_WF 256
+#endif
+constexpr int kWF = MPA_PN_WF;
 template <int K, int NT, int PANELS, int NTH>
 __global__ __launch_bounds__(NTH, 2) void pn_bwd_fused_kernel(
     const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
@@ -1400,6 +1406,9 @@ PnIws carve_int(int32_t* base, const Dims& d) {
 }
 
 constexpr int kCUs = 256;  // MI355X
+#ifndef MPA_PN_OVERSUB
+#define MPA_PN_OVERSUB 1
+#endif
 
 // resident blocks per CU of a persistent kernel (registers and LDS decide; asked once per kernel)
 template <typename Kern>
@@ -1455,7 +1464,7 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
 #define MPA_FWD(CI, PN, TP, IN, YO, TV, TN)                                                                          \
   {                                                                                                                  \
     static const int occ = blocks_per_cu(pn_fwd_mfma_kernel<CI, PN, TP>, kT);                                        \
-    const long long units = (long long)M * splits, cap = (long long)kCUs * occ;                                      \
+    const long long units = (long long)M * splits, cap = (long long)kCUs * occ * MPA_PN_OVERSUB;                     \
     hipLaunchKernelGGL((pn_fwd_mfma_kernel<CI, PN, TP>),                                                             \
                        dim3((unsigned)(units < cap ? units : cap), (unsigned)(d.C[l] / (64 * PN))), dim3(kT), 0, s,  \
                        IN, w.bn[l - 1], conv_w[l - 1], d.C[l], iw.vlist, (int)N, splits, YO, w.partial, TV, TN,      \
@@ -1512,7 +1521,7 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
                      C4, w.q);
   {
     static const int occ = blocks_per_cu(pn_dgrad_mfma_kernel<128, 1, 4, true>, kT);
-    const long long units = (long long)M * d.splits_dtop, cap = (long long)kCUs * occ;
+    const long long units = (long long)M * d.splits_dtop, cap = (long long)kCUs * occ * MPA_PN_OVERSUB;
     hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 1, 4, true>), dim3((unsigned)(units < cap ? units : cap), (unsigned)(C4 / 128)),
                        dim3(kT), 0, s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w.q, C4,
                        w.Y[4], w.bn[4], iw.vlist, (int)N, d.splits_dtop, w.dZ[4], w.partial, iw.erow, iw.ech, w.eval,
