@@ -150,6 +150,25 @@ __device__ __forceinline__ void queue_flush(Queue& q, Best& b) {
   }
 }
 
+// Block -> (cloud, query block).  Workgroups go to the 8 XCDs round-robin and every XCD has its own L2; the query blocks
+// of one cloud all stream the same candidate rows, so they are given to ONE XCD: linear block id L runs on XCD L % 8 and
+// takes cloud (L / 8 / Q) * 8 + L % 8, query block (L / 8) % Q.  grid.y must be a multiple of 8 (DG_KNN_GRID_Y).
+#ifndef DG_KNN_XCD
+#define DG_KNN_XCD 1
+#endif
+#define DG_KNN_GRID_Y(n) ((unsigned)(((n) + 7) / 8 * 8))
+__device__ __forceinline__ void knn_block(int& v, int& qb) {
+#if DG_KNN_XCD
+  const int Q = (int)gridDim.x, L = (int)blockIdx.y * Q + (int)blockIdx.x;
+  const int xcd = L & 7, k = L >> 3;
+  v = (k / Q) * 8 + xcd;
+  qb = k % Q;
+#else
+  v = (int)blockIdx.y;
+  qb = (int)blockIdx.x;
+#endif
+}
+
 // ---- C = 3 -------------------------------------------------------------------------------------------------------------
 // x4 [R][4] (xyz0), idx [R][20] u16.  grid = (ceil(N / 256), parts), block 256: lane = query; the part's points
 // (+ their norms) sit in LDS and are read as broadcasts.
@@ -160,7 +179,8 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x4,
   constexpr int QN = DG_QN3, CPC = DG_CPC3;
   __shared__ float qs_[4][QN * 64];
   __shared__ unsigned short qj_[4][QN * 64];
-  const int v = blockIdx.y;
+  int v, qb;
+  knn_block(v, qb);
   if (v >= hdr[0]) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float4* xp = reinterpret_cast<const float4*>(x4) + (long long)v * N;
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x4,
     pts[p] = t;
   }
   __syncthreads();
-  const int qi = blockIdx.x * 256 + threadIdx.x, qc = qi < N ? qi : N - 1;
+  const int qi = qb * 256 + threadIdx.x, qc = qi < N ? qi : N - 1;
   const float4 me = pts[qc];
   Best b;
   best_init(b);
@@ -249,12 +269,13 @@ __global__ __launch_bounds__(256, C > 64 ? 2 : DG_BPC64) void knn_mfma_kernel(co
   __shared__ __attribute__((aligned(16))) float tnorm[2][32];
   __shared__ float qs_[4][QN * 64];
   __shared__ unsigned short qj_[4][QN * 64];
-  const int v = blockIdx.y;
+  int v, qb;
+  knn_block(v, qb);
   if (v >= hdr[0]) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const float* xp = x + (long long)v * N * ld;
   const float* np_ = norm + (long long)v * N;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = qb * 128 + wave * 32;
   const int qrow = q0 + j < N ? q0 + j : N - 1;
   float bq[KH];
   {
@@ -350,9 +371,9 @@ __global__ __launch_bounds__(256, C > 64 ? 2 : DG_BPC64) void knn_mfma_kernel(co
   if (l2 < 32) {
 #pragma unroll 1
     for (int t = 0; t < kNbr; ++t) best_insert<true>(b, qs2[t * 64 + j2], qj2[t * 64 + j2]);
-    const int qi = blockIdx.x * 128 + wave * 32 + j2;
+    const int qi = qb * 128 + wave * 32 + j2;
     if (qi < N) {
-      IdxT* out = idx + ((long long)blockIdx.y * N + qi) * kNbr;
+      IdxT* out = idx + ((long long)v * N + qi) * kNbr;
 #pragma unroll
       for (int t = 0; t < kNbr; ++t) out[t] = (IdxT)b.j[t];
     }

@@ -939,7 +939,7 @@ Ws dg_carve(char* base, int64_t M, int64_t N, int64_t F) {
 }
 
 int dg_check(int64_t M, int64_t N, int64_t F, const char* who) {
-  MPA_REQUIRE(M >= 0 && M <= 65535, "%s: 0 <= parts <= 65535", who);
+  MPA_REQUIRE(M >= 0 && M <= 65528, "%s: 0 <= parts <= 65528", who);
   MPA_REQUIRE(N >= kNbr && N <= kMaxN, "%s: %d <= points per part <= %d", who, kNbr, kMaxN);
   MPA_REQUIRE(F == 64 || F == 128 || F == 256, "%s: feat_dim must be 64, 128 or 256", who);
   return MPA_OK;
@@ -1014,11 +1014,11 @@ extern "C" int mpa_dgcnn_forward(const float* points, const float* valids, const
     // kNN graph in the stage's input space
     record(events, 2 * l, s);
     if (l == 0) {
-      launch(knn3_kernel<unsigned short>, dim3((unsigned)((N + 255) / 256), (unsigned)M), dim3(256), s,
+      launch(knn3_kernel<unsigned short>, dim3((unsigned)((N + 255) / 256), DG_KNN_GRID_Y(M)), dim3(256), s,
              reinterpret_cast<const float*>(w.x0), (int)N, w.idx[0], (const int*)w.hdr);
     } else {
       const float* x = w.hcat + kOff[l - 1];
-      const dim3 g((unsigned)((N + 127) / 128), (unsigned)M);
+      const dim3 g((unsigned)((N + 127) / 128), DG_KNN_GRID_Y(M));
       if (C == 64) {
         launch(rownorm_kernel<64>, dim3((unsigned)((R + 255) / 256)), dim3(256), s, x, kCat, w.norm, (const int*)w.hdr);
         launch(knn_mfma_kernel<64, unsigned short>, g, dim3(256), s, x, kCat, (const float*)w.norm, (int)N, w.idx[l],
@@ -1140,7 +1140,7 @@ __global__ void dg_set_hdr_kernel(int* hdr, int n, int N) {
 
 extern "C" int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, int64_t C, float* ws, int32_t* idx,
                              void* stream) {
-  MPA_REQUIRE(n >= 0 && n <= 65535 && N >= kNbr && N <= kMaxN, "knn_exact: %d <= N <= %d, n <= 65535", kNbr, kMaxN);
+  MPA_REQUIRE(n >= 0 && n <= 65528 && N >= kNbr && N <= kMaxN, "knn_exact: %d <= N <= %d, n <= 65528", kNbr, kMaxN);
   MPA_REQUIRE(C == 3 || C == 64 || C == 128, "knn_exact: feature width must be 3, 64 or 128");
   MPA_REQUIRE(ld % 4 == 0 && ld >= (C == 3 ? 4 : C), "knn_exact: bad leading dimension");
   MPA_REQUIRE(C != 3 || ld == 4, "knn_exact: C = 3 takes [n*N, 4] rows (x, y, z, 0)");
@@ -1152,15 +1152,15 @@ extern "C" int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, i
   const int64_t R = n * N;
   launch(dg_set_hdr_kernel, dim3(1), dim3(1), s, hdr, (int)n, (int)N);
   if (C == 3) {
-    launch(knn3_kernel<int>, dim3((unsigned)((N + 255) / 256), (unsigned)n), dim3(256), s, x, (int)N, idx,
+    launch(knn3_kernel<int>, dim3((unsigned)((N + 255) / 256), DG_KNN_GRID_Y(n)), dim3(256), s, x, (int)N, idx,
            (const int*)hdr);
   } else if (C == 64) {
     launch(rownorm_kernel<64>, dim3((unsigned)((R + 255) / 256)), dim3(256), s, x, (int)ld, norm, (const int*)hdr);
-    launch(knn_mfma_kernel<64, int>, dim3((unsigned)((N + 127) / 128), (unsigned)n), dim3(256), s, x, (int)ld,
+    launch(knn_mfma_kernel<64, int>, dim3((unsigned)((N + 127) / 128), DG_KNN_GRID_Y(n)), dim3(256), s, x, (int)ld,
            (const float*)norm, (int)N, idx, (const int*)hdr);
   } else {
     launch(rownorm_kernel<128>, dim3((unsigned)((R + 255) / 256)), dim3(256), s, x, (int)ld, norm, (const int*)hdr);
-    launch(knn_mfma_kernel<128, int>, dim3((unsigned)((N + 127) / 128), (unsigned)n), dim3(256), s, x, (int)ld,
+    launch(knn_mfma_kernel<128, int>, dim3((unsigned)((N + 127) / 128), DG_KNN_GRID_Y(n)), dim3(256), s, x, (int)ld,
            (const float*)norm, (int)N, idx, (const int*)hdr);
   }
   return mpa::check_launch("knn_exact");

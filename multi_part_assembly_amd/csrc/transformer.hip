@@ -320,7 +320,10 @@ struct WgradGroup {
 // Lane (j, h) reads, per step, dY[row 2s+h][n0+j] and X[row 2s+h][k0+j] (128 B per half-wave each), twenty steps'
 // loads in flight at a time.  The 4 partial tiles are summed in fixed order through LDS (deterministic), the bias
 // gradient likewise.
-constexpr int kWT = 256, kWW = kWT / 64;
+#ifndef MPA_TF_WT
+#define MPA_TF_WT 256
+#endif
+constexpr int kWT = MPA_TF_WT, kWW = kWT / 64;
 
 __global__ __launch_bounds__(kWT) void wgrad_kernel(const WgradGroup G) {
   __shared__ float sm[kWW - 1][16][64];
