@@ -43,6 +43,9 @@ constexpr int kStartStride = kMaxCells + 8;   // ints per (sample, shape, role) 
 #ifndef MPA_GRID_KS
 #define MPA_GRID_KS 2
 #endif
+#ifndef MPA_GRID_XCD
+#define MPA_GRID_XCD 0
+#endif
 #ifndef MPA_GRID_WAVES
 #define MPA_GRID_WAVES 512
 #endif
@@ -536,7 +539,17 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     int* __restrict__ idx2) {
   __shared__ float4 cand[kCand];
   __shared__ int sidx[kCand];  // record index of every position of the current window
-  const int b = blockIdx.y >> 1, dir = blockIdx.y & 1;
+  // block -> (sample, direction, wave).  MPA_GRID_XCD: all waves of a (sample, direction) on ONE XCD (workgroups go
+  // to the XCDs round-robin): its records are then pulled into one L2 instead of eight
+  int pair = (int)blockIdx.y, wid = (int)blockIdx.x;
+#if MPA_GRID_XCD
+  if ((gridDim.y & 7) == 0) {
+    const int W = (int)gridDim.x, L = (int)blockIdx.y * W + (int)blockIdx.x, xcd = L & 7, k = L >> 3;
+    pair = (k / W) * 8 + xcd;
+    wid = k % W;
+  }
+#endif
+  const int b = pair >> 1, dir = pair & 1;
   const int qc = dir, tc = 1 - dir;  // query / target shape
   const GridParams& g = params[b];  // by reference: uniform address -> scalar loads (a by-value copy indexed with a
                                     // runtime shape index lands in scratch memory)
@@ -569,7 +582,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
   }
   const unsigned long long padmask = __ballot(pad);
 
-  for (int work = blockIdx.x; work < total_work; work += gridDim.x) {  // persistent walk over the work list
+  for (int work = wid; work < total_work; work += gridDim.x) {  // persistent walk over the work list
     const int sc = worklist[(long long)qslot * kWorkStride + work];  // super-cell with bst[sc] <= work < bst[sc+1]
     const int qb = qst[sc] + (work - bst[sc]) * kBatch, q_end = qst[sc + 1];
     const int sx = sc % g.sgx, sy = (sc / g.sgx) % g.sgy, sz = sc / (g.sgx * g.sgy);
