@@ -144,12 +144,20 @@ class KernelTimer:
 
     active: "KernelTimer | None" = None
 
-    def __init__(self):
+    def __init__(self, only=None):
+        """`only`: name prefixes to time (None: every instrumented launch).  bench.py times just the roofline kernel
+        inside its timed region — two event records per step instead of ~60 — and the rest in a second pass."""
         self.events: dict[str, list] = {}
+        self.only = None if only is None else tuple(only)
+
+    @classmethod
+    def wants(cls, name: str) -> bool:
+        a = cls.active
+        return a is not None and (a.only is None or name.startswith(a.only))
 
     @classmethod
     def start(cls, name: str):
-        if cls.active is None:
+        if not cls.wants(name):
             return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
@@ -164,13 +172,20 @@ class KernelTimer:
         cls.active.events.setdefault(token[0], []).append((token[1], end))
 
     @classmethod
-    def phase_events(cls, count: int):
-        """`count` timing events for a library call that records its own phase boundaries, or None."""
-        if cls.active is None:
+    def phase_events(cls, names):
+        """Timing events for a library call that records its own phase boundaries: phase i runs from event i to event
+        i + 1 and is called names[i].  Returns a list of len(names) + 1 events with None where no wanted phase touches
+        the boundary (the library skips null entries), or None when nothing is wanted."""
+        want = [cls.wants(n) for n in names]
+        if not any(want):
             return None
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(count)]
-        for e in evs:
-            e.record()  # materialise the hipEvent_t handle; the library re-records it at the right place
+        evs = []
+        for i in range(len(names) + 1):
+            need = (i < len(names) and want[i]) or (i > 0 and want[i - 1])
+            ev = torch.cuda.Event(enable_timing=True) if need else None
+            if ev is not None:
+                ev.record()  # materialise the hipEvent_t handle; the library re-records it at the right place
+            evs.append(ev)
         return evs
 
     @classmethod
@@ -178,7 +193,15 @@ class KernelTimer:
         if evs is None or cls.active is None:
             return
         for i, name in enumerate(names):
-            cls.active.events.setdefault(name, []).append((evs[i], evs[i + 1]))
+            if evs[i] is not None and evs[i + 1] is not None and cls.wants(name):
+                cls.active.events.setdefault(name, []).append((evs[i], evs[i + 1]))
+
+    @staticmethod
+    def handles(evs):
+        """ctypes array of the hipEvent_t handles (null where the event is None), or None."""
+        if evs is None:
+            return None
+        return (ctypes.c_void_p * len(evs))(*[None if e is None else e.cuda_event for e in evs])
 
     def summary(self) -> dict[str, dict]:
         """name -> {launches, avg_ms, total_ms}; call after torch.cuda.synchronize()."""

@@ -518,7 +518,8 @@ extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const floa
                                                float* float_ws, int32_t* int_ws, float* losses,
                                                void* const* events, void* stream) {
   auto mark = [&](int k) {
-    if (events != nullptr) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(events[k]), mpa::as_stream(stream));
+    if (events != nullptr && events[k] != nullptr)  // (entries may be null: time only some of the phases)
+      (void)hipEventRecord(reinterpret_cast<hipEvent_t>(events[k]), mpa::as_stream(stream));
   };
   MPA_REQUIRE(B >= 0 && P >= 0 && N >= 0, "assembly_loss_forward: negative size");
   if (B == 0) return MPA_OK;

@@ -266,16 +266,20 @@ class _DGCNNFn(torch.autograd.Function):
         pts = points.detach()
         with torch.cuda.device(dev):
             tok = _lib.KernelTimer.start(f"dgcnn_forward[{M}x{N}x{F_}]")
-            evs = _lib.KernelTimer.phase_events(8)
-            ev_arr = None if evs is None else (ctypes.c_void_p * 8)(*[e.cuda_event for e in evs])
+            # library-recorded events [2l] / [2l + 1] right around the kNN kernels of stage l
+            knn_names = [f"dgcnn_knn[{M}x{N} stage {l + 1} C={C}]" for l, C in enumerate((3, 64, 64, 128))]
+            pairs = [_lib.KernelTimer.phase_events([n]) for n in knn_names]
+            flat = None
+            if any(p is not None for p in pairs):
+                flat = [e for p in pairs for e in (p if p is not None else [None, None])]
             st = L.mpa_dgcnn_forward(
                 _lib.ptr(pts), _lib.ptr(valids), _lib.ptr_array(conv_w), _lib.ptr_array(bn_w), _lib.ptr_array(bn_b),
                 _lib.ptr_array(run_mean), _lib.ptr_array(run_var), _lib.ptr(fc_w), _lib.ptr(fc_b), int(training),
-                float(momentum), float(eps), M, N, F_, _lib.ptr(ws), _lib.ptr(feat), ev_arr, _lib.current_stream(dev))
+                float(momentum), float(eps), M, N, F_, _lib.ptr(ws), _lib.ptr(feat), _lib.KernelTimer.handles(flat),
+                _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
-            if evs is not None:
-                for l, C in enumerate((3, 64, 64, 128)):
-                    _lib.KernelTimer.add_phases([f"dgcnn_knn[{M}x{N} stage {l + 1} C={C}]"], evs[2 * l:2 * l + 2])
+            for n, p in zip(knn_names, pairs):
+                _lib.KernelTimer.add_phases([n], p)
         _lib.check(st, "mpa_dgcnn_forward")
         ctx.training = bool(training)
         ctx.want_point_grad = bool(want_point_grad)

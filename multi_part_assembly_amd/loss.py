@@ -128,17 +128,22 @@ class _AssemblyLoss(torch.autograd.Function):
         iws = torch.empty(ni.value, dtype=torch.int32, device=dev)
         losses = torch.empty((5, B), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            evs = _lib.KernelTimer.phase_events(7)
-            ev_arr = None if evs is None else (ctypes.c_void_p * 7)(*[e.cuda_event for e in evs])
+            # library-recorded events: [0..4] bound the four phases, [5] / [6] sit right around the grid search kernel
+            tag = f"[{B}x{P}x{N}]"
+            names = [k + tag for k in ("assembly_pose", "assembly_part_chamfer", "assembly_shape_chamfer",
+                                       "assembly_finalize")]
+            evs = _lib.KernelTimer.phase_events(names)
+            gs = _lib.KernelTimer.phase_events(["grid_search_kernel" + tag])
+            both = None
+            if evs is not None or gs is not None:
+                both = (evs if evs is not None else [None] * 5) + (gs if gs is not None else [None] * 2)
             st = L.mpa_assembly_loss_forward_timed(
                 _lib.ptr(part_pcs), _lib.ptr(valids), _lib.ptr(quat_pred), _lib.ptr(trans_pred),
                 _lib.ptr(quat_gt), _lib.ptr(trans_gt), B, P, N, int(training), int(fill_pads),
-                _lib.ptr(fws), _lib.ptr(iws), _lib.ptr(losses), ev_arr, _lib.current_stream(dev))
-            _lib.KernelTimer.add_phases(
-                [f"{k}[{B}x{P}x{N}]" for k in ("assembly_pose", "assembly_part_chamfer",
-                                                "assembly_shape_chamfer", "assembly_finalize")], evs)
-            if evs is not None:
-                _lib.KernelTimer.add_phases([f"grid_search_kernel[{B}x{P}x{N}]"], evs[5:7])
+                _lib.ptr(fws), _lib.ptr(iws), _lib.ptr(losses), _lib.KernelTimer.handles(both),
+                _lib.current_stream(dev))
+            _lib.KernelTimer.add_phases(names, evs)
+            _lib.KernelTimer.add_phases(["grid_search_kernel" + tag], gs)
         _lib.check(st, "mpa_assembly_loss_forward")
         ctx.save_for_backward(part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, fws, iws)
         ctx.training = int(training)
