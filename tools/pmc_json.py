@@ -1,0 +1,54 @@
+"""Build the per-kernel HBM-traffic records bench.py reads (`profiles/rNN_pmc_dominant_kernel.json`,
+`profiles/rNN_pmc_knn_kernel.json`) out of the FETCH_SIZE / WRITE_SIZE summaries of tools/gpu_full_pass.sh.
+    python tools/pmc_json.py profiles r02
+FETCH_SIZE is doubled (gfx950 reports half of wide coalesced reads: MI355X_MICROARCH.md, HBM section); both counters are in KB."""
+import json
+import re
+import sys
+from pathlib import Path
+
+
+def per_kernel(path, pattern):
+    """avg/launch (KB) of the first line of a pmc_summary file whose kernel name matches `pattern`."""
+    for line in Path(path).read_text().splitlines():
+        m = re.match(r"\s*(\w+)\s+avg/launch\s+([\d.]+)\s+launches\s+(\d+)\s+(.*)", line)
+        if m and re.search(pattern, m.group(4)):
+            return float(m.group(2))
+    return None
+
+
+def main():
+    prof, rnd = Path(sys.argv[1]), sys.argv[2]
+    note = ("FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
+            "WRITE_SIZE as reported")
+    f = per_kernel(prof / f"{rnd}_c2_pmc_fetch_size.txt", r"grid_search_kernel")
+    w = per_kernel(prof / f"{rnd}_c2_pmc_write_size.txt", r"grid_search_kernel")
+    if f is not None and w is not None:
+        rec = {"kernel": "grid_search_kernel",
+               "command": "python bench.py --config c2 --no-cpu-baseline --steps 4 --warmup 2 (rocprofv3 --pmc FETCH_SIZE "
+                          "and --pmc WRITE_SIZE, separate passes; tools/gpu_full_pass.sh)",
+               "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
+               "correction": note + " (scattered 4-byte result stores count a full 64-byte line each)",
+               "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0}
+        (prof / f"{rnd}_pmc_dominant_kernel.json").write_text(json.dumps(rec, indent=1))
+        print(rec)
+    widths = {}
+    for C in (128, 64):
+        f = per_kernel(prof / f"{rnd}_c3_pmc_fetch_size.txt", rf"knn_mfma_kernel<{C},")
+        w = per_kernel(prof / f"{rnd}_c3_pmc_write_size.txt", rf"knn_mfma_kernel<{C},")
+        if f is not None and w is not None:
+            widths[str(C)] = {"fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
+                              "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0}
+    if widths:
+        rec = {"kernel": "dg::knn_mfma_kernel",
+               "command": "python bench.py --config c3 --no-cpu-baseline --steps 4 --warmup 2 (rocprofv3 --pmc FETCH_SIZE "
+                          "and --pmc WRITE_SIZE, separate passes; tools/gpu_full_pass.sh)",
+               "correction": note, "per_width": widths,
+               "note": "the query blocks of a cloud run on one XCD (dg_knn.h: knn_block), so one L2 streams the cloud's "
+                       "features; the index lists are written once"}
+        (prof / f"{rnd}_pmc_knn_kernel.json").write_text(json.dumps(rec, indent=1))
+        print(rec)
+
+
+if __name__ == "__main__":
+    main()
