@@ -43,8 +43,8 @@ constexpr int kStartStride = kMaxCells + 8;   // ints per (sample, shape, role) 
 #ifndef MPA_GRID_KS
 #define MPA_GRID_KS 2
 #endif
-#ifndef MPA_GRID_XCD
-#define MPA_GRID_XCD 0
+#ifndef MPA_GRID_XCD  // 1: XCD-aware, work-proportional wave table (grid_assign_kernel); 0: waves x of pair y
+#define MPA_GRID_XCD 1
 #endif
 #ifndef MPA_GRID_WAVES
 #define MPA_GRID_WAVES 512
@@ -529,6 +529,68 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
   }
 }
 
+// ---- 2b. waves -> (sample, direction) with XCD locality ---------------------------------------------------------------
+// Workgroups go to the 8 XCDs round-robin (linear id L runs on XCD L % 8) and every XCD has its own L2.  All waves
+// that search one (sample, direction) pair therefore get ids of ONE residue class, so the pair's records are pulled
+// into one L2 instead of eight — but samples differ 10x in size, so the pairs are dealt to the XCDs by descending
+// work (snake order) and every pair gets a share of its XCD's wave slots proportional to its work.
+// The plan (per XCD: its pairs and the prefix of their wave slots) is tiny; every search wave looks its slot up itself.
+constexpr int kMaxPairs = 1024;            // 2 * B (larger batches fall back to the plain mapping)
+constexpr int kPlanCap = kMaxPairs / 8;    // pairs per XCD
+struct XcdPlan {
+  int cnt[8];
+  int lst[8][kPlanCap];
+  int first[8][kPlanCap + 1];
+};
+// one block of 1024 threads
+__global__ __launch_bounds__(1024) void grid_assign_kernel(const GridParams* __restrict__ params,
+                                                           const int* __restrict__ batches, int npairs, int nwaves,
+                                                           XcdPlan* __restrict__ plan) {
+  __shared__ int work[kMaxPairs];
+  __shared__ int lst[8][kPlanCap], cnt[8];
+  const int t = threadIdx.x;
+  for (int p = t; p < npairs; p += 1024) {
+    const int b = p >> 1, dir = p & 1, qslot = (b * 2 + dir) * 2 + 1;
+    work[p] = batches[(long long)qslot * kStartStride + params[b].nsuper];
+  }
+  if (t < 8) cnt[t] = 0;
+  __syncthreads();
+  for (int p = t; p < npairs; p += 1024) {  // rank by descending work (ties: lower pair first), snake over the XCDs
+    int r = 0;
+    for (int q = 0; q < npairs; ++q) r += work[q] > work[p] || (work[q] == work[p] && q < p);
+    const int cyc = r >> 3, pos = r & 7, xcd = (cyc & 1) ? 7 - pos : pos;
+    lst[xcd][cyc] = p;
+    atomicAdd(&cnt[xcd], 1);  // (integer count: order-free)
+  }
+  __syncthreads();
+  const int per = nwaves / 8;  // wave slots of one XCD
+  if (t < 8) {  // proportional shares, at least one wave for every pair that has work
+    long long rem_work = 0;
+    int busy = 0;
+    for (int i = 0; i < cnt[t]; ++i) {
+      rem_work += work[lst[t][i]];
+      busy += work[lst[t][i]] > 0;
+    }
+    int rem = per, at = 0;
+    plan->cnt[t] = cnt[t];
+    for (int i = 0; i < cnt[t]; ++i) {
+      const int w = work[lst[t][i]];
+      plan->lst[t][i] = lst[t][i];
+      plan->first[t][i] = at;
+      if (w > 0) {
+        int n = (int)(((long long)rem * w + rem_work / 2) / rem_work);
+        const int keep = busy - 1;  // one slot for each pair still to come
+        n = n < 1 ? 1 : (n > rem - keep ? rem - keep : n);
+        at += n;
+        rem -= n;
+        rem_work -= w;
+        --busy;
+      }
+    }
+    plan->first[t][cnt[t]] = at;
+  }
+}
+
 // grid = (512 persistent waves per (sample, dir), 2*B), block 64.  blockIdx.y = b*2 + dir; dir 0: shape 1 queries
 // against shape 2 targets.
 __global__ __launch_bounds__(64) void grid_search_kernel(
@@ -536,19 +598,25 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     int N, const GridParams* __restrict__ params, const float4* __restrict__ records,
     const int* __restrict__ starts, const int* __restrict__ batches, const int* __restrict__ worklist,
     int rec_stride, float* __restrict__ dist1, float* __restrict__ dist2, int* __restrict__ idx1,
-    int* __restrict__ idx2) {
+    int* __restrict__ idx2, const XcdPlan* __restrict__ plan) {
   __shared__ float4 cand[kCand];
   __shared__ int sidx[kCand];  // record index of every position of the current window
-  // block -> (sample, direction, wave).  MPA_GRID_XCD: all waves of a (sample, direction) on ONE XCD (workgroups go
-  // to the XCDs round-robin): its records are then pulled into one L2 instead of eight
-  int pair = (int)blockIdx.y, wid = (int)blockIdx.x;
-#if MPA_GRID_XCD
-  if ((gridDim.y & 7) == 0) {
-    const int W = (int)gridDim.x, L = (int)blockIdx.y * W + (int)blockIdx.x, xcd = L & 7, k = L >> 3;
-    pair = (k / W) * 8 + xcd;
-    wid = k % W;
+  // block -> (sample, direction, wave): from the XCD-aware plan (grid_assign_kernel) or, without one, waves
+  // blockIdx.x of pair blockIdx.y
+  int pair = (int)blockIdx.y, wid = (int)blockIdx.x, wstride = (int)gridDim.x;
+  if (plan != nullptr) {
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, n = plan->cnt[xcd];
+    pair = -1;
+    for (int i = 0; i < n; ++i) {  // (wave-uniform scalar loads; <= 2B / 8 entries)
+      const int f0 = plan->first[xcd][i], f1 = plan->first[xcd][i + 1];
+      if (slot >= f0 && slot < f1) {
+        pair = plan->lst[xcd][i];
+        wid = slot - f0;
+        wstride = f1 - f0;
+      }
+    }
+    if (pair < 0) return;
   }
-#endif
   const int b = pair >> 1, dir = pair & 1;
   const int qc = dir, tc = 1 - dir;  // query / target shape
   const GridParams& g = params[b];  // by reference: uniform address -> scalar loads (a by-value copy indexed with a
@@ -582,7 +650,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
   }
   const unsigned long long padmask = __ballot(pad);
 
-  for (int work = wid; work < total_work; work += gridDim.x) {  // persistent walk over the work list
+  for (int work = wid; work < total_work; work += wstride) {  // persistent walk over the work list
     const int sc = worklist[(long long)qslot * kWorkStride + work];  // super-cell with bst[sc] <= work < bst[sc+1]
     const int qb = qst[sc] + (work - bst[sc]) * kBatch, q_end = qst[sc + 1];
     const int sx = sc % g.sgx, sy = (sc / g.sgx) % g.sgy, sz = sc / (g.sgx * g.sgy);
@@ -739,8 +807,8 @@ int64_t grid_workspace_floats(int64_t B, int64_t P, int64_t N) {
   const int64_t rec = (P * N + 8) * 4;  // float4 records (+ sentinels) per slot
   return 4 * B * rec + B * (int64_t)(sizeof(GridParams) / 4) + 2 * B * P * N;  // + 2 distance arrays
 }
-int64_t grid_workspace_ints(int64_t B) {  // starts, batches, work list
-  return 2 * 4 * B * (int64_t)kStartStride + 4 * B * (int64_t)kWorkStride;
+int64_t grid_workspace_ints(int64_t B) {  // starts, batches, work list, wave table
+  return 2 * 4 * B * (int64_t)kStartStride + 4 * B * (int64_t)kWorkStride + (int64_t)(sizeof(XcdPlan) / 4);
 }
 
 int launch_grid_shape_search(const float* valids, const float* S1, const float* S2, int64_t B, int64_t P,
@@ -757,10 +825,21 @@ int launch_grid_shape_search(const float* valids, const float* S1, const float* 
   hipLaunchKernelGGL(grid_params_kernel, dim3((unsigned)B), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N, params);
   hipLaunchKernelGGL(grid_sort_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N, params,
                      starts, batches, worklist, records, rec_stride);
-  // persistent waves: 128 per (sample, direction) walk that pair's work list of (super-cell, 64-query batch) items
+  // persistent waves (512 per (sample, direction) on average) walk a pair's work list of (super-cell, 64-query batch) items
+  XcdPlan* plan = reinterpret_cast<XcdPlan*>(worklist + 4 * B * (int64_t)kWorkStride);
+  const bool xcd_table = MPA_GRID_XCD && 2 * B >= 8 && 2 * B <= kMaxPairs;
+  const int nwaves = (int)(MPA_GRID_WAVES * 2 * B);
+  if (xcd_table)
+    hipLaunchKernelGGL(grid_assign_kernel, dim3(1), dim3(1024), 0, s, (const GridParams*)params, (const int*)batches,
+                       (int)(2 * B), nwaves, plan);
   if (before_search != nullptr) (void)hipEventRecord(before_search, s);
-  hipLaunchKernelGGL(grid_search_kernel, dim3(MPA_GRID_WAVES, (unsigned)(2 * B)), dim3(64), 0, s, valids, S1, S2, (int)P,
-                     (int)N, params, records, starts, batches, worklist, rec_stride, dist1, dist2, idx1, idx2);
+  if (xcd_table)
+    hipLaunchKernelGGL(grid_search_kernel, dim3((unsigned)nwaves), dim3(64), 0, s, valids, S1, S2, (int)P, (int)N, params,
+                       records, starts, batches, worklist, rec_stride, dist1, dist2, idx1, idx2, (const XcdPlan*)plan);
+  else
+    hipLaunchKernelGGL(grid_search_kernel, dim3(MPA_GRID_WAVES, (unsigned)(2 * B)), dim3(64), 0, s, valids, S1, S2, (int)P,
+                       (int)N, params, records, starts, batches, worklist, rec_stride, dist1, dist2, idx1, idx2,
+                       (const XcdPlan*)nullptr);
   if (after_search != nullptr) (void)hipEventRecord(after_search, s);
   hipLaunchKernelGGL(grid_part_sum_kernel, dim3((unsigned)(B * P), 2), dim3(256), 0, s, valids, dist1, dist2, (int)N,
                      tiles, tile_sums);
