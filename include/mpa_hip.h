@@ -25,7 +25,7 @@ extern "C" {
 #define MPA_ELAUNCH (-2) /* hipGetLastError() reported a launch failure */
 
 /* ABI version of this header; bumped whenever a signature changes. */
-#define MPA_ABI_VERSION 2
+#define MPA_ABI_VERSION 3
 int mpa_abi_version(void);
 
 /* Thread-local, NUL-terminated description of the last failure on this thread ("" if none). */
