@@ -141,7 +141,8 @@ int mpa_assembly_loss_forward(const float* part_pcs, const float* valids, const 
 /* Profiling twin: identical launches; `events` (may be NULL) is a host array of 7 hipEvent_t recorded on
  * `stream`: [0] start, [1] after pose kernel, [2] after per-part Chamfer, [3] after the whole-shape Chamfer
  * phase, [4] after finalize, [5]/[6] right before/after the grid search kernel itself — so a benchmark can
- * time the dominant kernel inside its timed region. */
+ * time the dominant kernel inside its timed region.  Individual entries may be NULL (e.g. only [5] and [6] set: two
+ * records per call instead of seven). */
 int mpa_assembly_loss_forward_timed(const float* part_pcs, const float* valids, const float* quat_pred,
                                     const float* trans_pred, const float* quat_gt, const float* trans_gt,
                                     int64_t B, int64_t P, int64_t N, int training, int fill_pad_points,
