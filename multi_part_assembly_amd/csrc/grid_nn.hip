@@ -47,7 +47,7 @@ constexpr int kStartStride = kMaxCells + 8;   // ints per (sample, shape, role) 
 #define MPA_GRID_XCD 1
 #endif
 #ifndef MPA_GRID_WAVES
-#define MPA_GRID_WAVES 512
+#define MPA_GRID_WAVES 768
 #endif
 constexpr int kS = MPA_GRID_KS;                         // super-cell edge in fine cells (the query bins of the search): 2 is best
                                               // while predictions are far from the ground truth (a wave's search radius is
@@ -393,7 +393,7 @@ __device__ __forceinline__ float gap(float a0, float a1, float b0, float b1) {
 #endif
 constexpr int kCand = MPA_GRID_CAND;  // candidate records per LDS window (2.5 KB per wave: the window is what limits the
                                       // waves per CU, and this latency-bound search wants all of them — 512 -> 128 records
-                                      // together with 512 instead of 128 persistent waves per (sample, direction) took
+                                      // together with 768 instead of 128 persistent waves per (sample, direction) took
                                       // the kernel from 0.44 to 0.28 ms; tools/variant_bench.sh)
 constexpr int kLongRange = 32;  // ranges longer than this are fetched by the whole wave, one range at a time
 
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(1024) void grid_assign_kernel(const GridParams* __r
   }
 }
 
-// grid = (512 persistent waves per (sample, dir), 2*B), block 64.  blockIdx.y = b*2 + dir; dir 0: shape 1 queries
+// grid = (768 persistent waves per (sample, dir) on average), block 64.  blockIdx.y = b*2 + dir; dir 0: shape 1 queries
 // against shape 2 targets.
 __global__ __launch_bounds__(64) void grid_search_kernel(
     const float* __restrict__ valids, const float* __restrict__ S1, const float* __restrict__ S2, int P,
@@ -825,7 +825,7 @@ int launch_grid_shape_search(const float* valids, const float* S1, const float* 
   hipLaunchKernelGGL(grid_params_kernel, dim3((unsigned)B), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N, params);
   hipLaunchKernelGGL(grid_sort_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N, params,
                      starts, batches, worklist, records, rec_stride);
-  // persistent waves (512 per (sample, direction) on average) walk a pair's work list of (super-cell, 64-query batch) items
+  // persistent waves (768 per (sample, direction) on average) walk a pair's work list of (super-cell, 64-query batch) items
   XcdPlan* plan = reinterpret_cast<XcdPlan*>(worklist + 4 * B * (int64_t)kWorkStride);
   const bool xcd_table = MPA_GRID_XCD && 2 * B >= 8 && 2 * B <= kMaxPairs;
   const int nwaves = (int)(MPA_GRID_WAVES * 2 * B);
