@@ -28,6 +28,7 @@ __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8
 constexpr int kGT = 256;   // threads per GEMM block
 constexpr int kKC = 32;    // K chunk
 constexpr int kLD = kKC + 4;
+#define DG_GEMM_GRID_X(rows) ((unsigned)((((rows) + 127) / 128 + 7) / 8 * 8))  // row tiles, rounded up to the XCD count
 
 // ---- C[r, n] (+)= A[r, :] . W[n, :] -----------------------------------------------------------------------------------
 // A [R, K] row-major with leading dimension lda (a column slice of a wider buffer is fine), W [Nout, K] row-major,
@@ -44,9 +45,18 @@ __global__ __launch_bounds__(kGT, 2) void gemm_nt_kernel(const float* __restrict
   __shared__ __attribute__((aligned(16))) float As[2][BM * kLD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * kLD];
   const int R = hdr[1];
-  const long long r0 = (long long)blockIdx.x * BM;
+  // block -> (row tile, column tile).  The column tiles of one row tile all read the same A rows; workgroups go to the
+  // 8 XCDs round-robin, so they are given consecutive slots of ONE XCD (linear id L: XCD L % 8, row tile
+  // (L / 8 / gy) * 8 + L % 8, column tile (L / 8) % gy): the A tile is fetched from HBM once instead of gy times.
+  // gridDim.x is a multiple of 8 (DG_GEMM_GRID_X); tiles past R exit.
+  long long r0;
+  int n0;
+  {
+    const int gy = (int)gridDim.y, L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, xcd = L & 7, k = L >> 3;
+    r0 = (long long)((k / gy) * 8 + xcd) * BM;
+    n0 = (k % gy) * BN;
+  }
   if (r0 >= R) return;
-  const int n0 = blockIdx.y * BN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;  // wave tile: rows wr*64.., columns wc*WN..
   const int c4 = threadIdx.x & 7, rl = threadIdx.x >> 3;  // staging role: float4 column c4 of rows rl + 32 i

@@ -953,7 +953,7 @@ void launch(Kern kern, dim3 grid, dim3 block, hipStream_t s, Args... args) {
 // C (+)= A . W^T on the matrix cores (see dg_gemm.h); Nout a multiple of 64
 void gemm_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, int Nout, bool accum, int64_t Rmax,
              const int* hdr, hipStream_t s) {
-  const unsigned gx = (unsigned)((Rmax + 127) / 128);
+  const unsigned gx = DG_GEMM_GRID_X(Rmax);
   if (Nout % 128 == 0) {
     if (accum) launch(gemm_nt_kernel<128, true>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
     else launch(gemm_nt_kernel<128, false>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);

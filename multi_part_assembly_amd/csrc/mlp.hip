@@ -264,7 +264,7 @@ void launch(Kern kern, dim3 grid, dim3 block, hipStream_t s, Args... args) {
 
 void ml_gemm_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, int Nout, int64_t R, const int* hdr,
                 hipStream_t s) {
-  const unsigned gx = (unsigned)((R + 127) / 128);
+  const unsigned gx = DG_GEMM_GRID_X(R);
   if (Nout % 128 == 0) launch(gemm_nt_kernel<128, false>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
   else launch(gemm_nt_kernel<64, false>, dim3(gx, Nout / 64), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
 }
