@@ -9,16 +9,20 @@
 // this file does what is sequential:
 //   r = sigmoid(gi_r + W_hr h + b_hr),  z = sigmoid(gi_z + W_hz h + b_hz),  n = tanh(gi_n + r * (W_hn h + b_hn)),
 //   h' = (1 - z) * n + z * h                                                     (torch.nn.GRU's equations and gate order)
-// ONE launch per pass for both directions: grid = (H / 16, directions).  A block owns 16 hidden units — its 48 rows of
+// ONE launch per pass for both directions: grid = (H / 8, directions).  A block owns 8 hidden units (A/B: 16 units per
+// block 0.33 + 0.73 ms forward + backward, 8 units 0.28 + 0.56, 4 units 0.38 + 0.70) — its 24 rows of
 // W_hh stay in LDS for the whole sequence — and the blocks of a direction meet at a grid barrier after every step (the
-// new hidden state goes through global memory).  Backward through time keeps its 48 x H slice of dW_hh in registers,
+// new hidden state goes through global memory).  Backward through time keeps its 24 x H slice of dW_hh in registers,
 // hands the partial dL/dh_{t-1} of its rows to the other blocks through global memory and sums the partials in block
-// order: no atomics on floats, bit-reproducible.  All blocks must be co-resident (2 * H/16 <= 256 CUs).
+// order: no atomics on floats, bit-reproducible.  All blocks must be co-resident (2 * H/8 <= 256 CUs).
 #include "common.h"
 
 namespace {
 
-constexpr int kU = 16;       // hidden units per block
+#ifndef MPA_GRU_U
+#define MPA_GRU_U 8
+#endif
+constexpr int kU = MPA_GRU_U;  // hidden units per block
 constexpr int kGT = 256;     // threads per block
 constexpr int kMaxH = 512;
 constexpr int kMaxB = 64;
