@@ -233,6 +233,29 @@ def test_grid_pruned_search_is_bit_identical_to_brute_force(cuda_device, monkeyp
     np.testing.assert_allclose(lg.cpu().numpy(), lb.cpu().numpy(), rtol=2e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("B", [1, 3, 5, 13])
+def test_grid_search_wave_plan_covers_every_batch_size(cuda_device, monkeypatch, B):
+    """The search waves get their (sample, direction) from an XCD-aware plan (grid_assign_kernel: pairs dealt to the 8
+    XCDs by descending work, wave shares proportional to work) when there are at least 8 pairs, and from the plain
+    block mapping below that: batch sizes on both sides of the switch, pair counts that are no multiple of 8, very
+    uneven samples and a sample with no valid part at all must give the brute-force arg-mins."""
+    from multi_part_assembly_amd import synthetic
+
+    counts = [20, 1, 0, 7, 20, 2, 13, 0, 5, 20, 1, 9, 3][:B]
+    batch = synthetic.make_batch(B, 20, 500, seed=23 + B, device=cuda_device, num_parts=[max(c, 1) for c in counts])
+    for b, c in enumerate(counts):
+        if c == 0:  # no valid part in this sample
+            batch["part_valids"][b] = 0
+    g = torch.Generator().manual_seed(B)
+    qp = torch.nn.functional.normalize(torch.randn(B, 20, 4, generator=g), dim=-1).to(cuda_device)
+    tp = (torch.randn(B, 20, 3, generator=g) * 0.4).to(cuda_device)
+    lb, b1, b2 = _raw_assembly_forward(batch, qp, tp, "brute", monkeypatch)
+    lg, g1, g2 = _raw_assembly_forward(batch, qp, tp, "grid", monkeypatch)
+    valid = batch["part_valids"].bool()
+    assert torch.equal(b1[valid], g1[valid]) and torch.equal(b2[valid], g2[valid])
+    np.testing.assert_allclose(lg.cpu().numpy(), lb.cpu().numpy(), rtol=2e-6, atol=1e-9)
+
+
 def test_grid_pruned_search_handles_duplicates_and_flat_clouds(cuda_device, monkeypatch):
     """Degenerate geometry: every part is the same flat (z = 0) lattice patch, so there are exact distance
     ties everywhere and the grid is one cell thick — indices must still match the in-order scan."""
