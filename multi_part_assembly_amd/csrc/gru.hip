@@ -22,6 +22,9 @@ namespace {
 #ifndef MPA_GRU_U
 #define MPA_GRU_U 8
 #endif
+#ifndef MPA_GRU_SPLIT_FENCE
+#define MPA_GRU_SPLIT_FENCE 1
+#endif
 constexpr int kU = MPA_GRU_U;  // hidden units per block
 constexpr int kGT = 256;     // threads per block
 constexpr int kMaxH = 512;
@@ -33,10 +36,19 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target) {
   __syncthreads();
   if (threadIdx.x == 0) {
+#if MPA_GRU_SPLIT_FENCE
+    // release (write back this XCD's L2) before arriving, acquire (invalidate) after the last arrival: half the cache
+    // maintenance of two full fences
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
     __threadfence();
     atomicAdd(counter, 1u);
     while (atomicAdd(counter, 0u) < target) __builtin_amdgcn_s_sleep(1);
     __threadfence();
+#endif
   }
   __syncthreads();
 }
