@@ -57,13 +57,14 @@ __device__ __forceinline__ bool coop_colsum(int total, int C, int c, const CoopW
     }
     ws.stage[((long long)g * C + c) * 2] = a;
     ws.stage[((long long)g * C + c) * 2 + 1] = b;
-    __threadfence();  // release: the group sums are visible device-wide before the ticket is taken
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the group sums are visible device-wide before the ticket is
+                                                        // taken (release only: no invalidate needed on this side)
   }
   __syncthreads();
   if (threadIdx.x == 0) last = atomicAdd(ws.ticket + blockIdx.x, 1u) == (unsigned)(G - 1);
   __syncthreads();
   if (!last) return false;
-  __threadfence();  // acquire
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (acquire only)
   a = b = 0.0;
   for (int gg = slice; gg < G; gg += kSlices) {
     a += ws.stage[((long long)gg * C + c) * 2];
