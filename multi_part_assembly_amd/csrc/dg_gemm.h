@@ -9,8 +9,9 @@
 //   gemm_nt :  C[r, n] (+)= sum_k A[r, k] * W[n, k]        forward GEMMs and input gradients (W pre-transposed)
 //   gemm_tn :  P[chunk][n, k] = sum_{r in chunk} Y[r, n] * X[r, k]   weight gradients, fixed-order second stage
 //
-// Block = 256 threads (4 waves, 2 x 2), block tile 128 rows x BN columns, K walked in chunks of 32 through a
-// double-buffered LDS panel (global loads of chunk c+1 in flight during the MFMA chain of chunk c); a wave owns a
+// Block = 256 threads (4 waves, 2 x 2), block tile 128 rows x BN columns, K walked in chunks of 32 through an LDS
+// panel pair (global loads of chunk c+1 in flight — in registers — during the MFMA chain of chunk c; ONE panel per
+// operand and three blocks per CU measured slightly faster than two panels and two blocks); a wave owns a
 // 64 x (BN/2) tile = 2 x (BN/64) accumulators of 32x32.  The MFMA K index is split as "lanes 0-31 take the first half
 // of the chunk, lanes 32-63 the second", so a lane's operand fragments are contiguous 16-float runs of an LDS row
 // (ds_read_b128, rows padded by 4 floats: conflict-free).
@@ -33,8 +34,11 @@ constexpr int kLD = kKC + 4;
 // ---- C[r, n] (+)= A[r, :] . W[n, :] -----------------------------------------------------------------------------------
 // A [R, K] row-major with leading dimension lda (a column slice of a wider buffer is fine), W [Nout, K] row-major,
 // C [R, Nout] with leading dimension ldc.  K % 32 == 0, Nout % BN == 0.  grid = (ceil(Rmax / 128), Nout / BN).
+#ifndef DG_NT_BUFS  // A/B knob: LDS panels per operand (2: double-buffered, 2 blocks per CU; 1: single, 3 blocks)
+#define DG_NT_BUFS 1
+#endif
 template <int BN, bool ACCUM>
-__global__ __launch_bounds__(kGT, 2) void gemm_nt_kernel(const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(kGT, DG_NT_BUFS == 2 ? 2 : 3) void gemm_nt_kernel(const float* __restrict__ A, int lda,
                                                          const float* __restrict__ W, int K,
                                                          float* __restrict__ C, int ldc, const int* __restrict__ hdr) {
   constexpr int BM = 128;
@@ -42,8 +46,8 @@ __global__ __launch_bounds__(kGT, 2) void gemm_nt_kernel(const float* __restrict
   constexpr int TN = WN / 32;       // 32-wide column tiles per wave (1 or 2)
   constexpr int A4 = BM * kKC / 4 / kGT;  // float4 per thread and chunk (A panel) = 4
   constexpr int B4 = BN * kKC / 4 / kGT;  // (W panel) = 4 or 2
-  __shared__ __attribute__((aligned(16))) float As[2][BM * kLD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * kLD];
+  __shared__ __attribute__((aligned(16))) float As[DG_NT_BUFS][BM * kLD];
+  __shared__ __attribute__((aligned(16))) float Bs[DG_NT_BUFS][BN * kLD];
   const int R = hdr[1];
   // block -> (row tile, column tile).  The column tiles of one row tile all read the same A rows; workgroups go to the
   // 8 XCDs round-robin, so they are given consecutive slots of ONE XCD (linear id L: XCD L % 8, row tile
@@ -100,7 +104,8 @@ __global__ __launch_bounds__(kGT, 2) void gemm_nt_kernel(const float* __restrict
   DG_NT_FETCH(0)
   const int chunks = K / kKC;
   for (int c = 0; c < chunks; ++c) {
-    const int buf = c & 1;
+    const int buf = DG_NT_BUFS == 2 ? (c & 1) : 0;
+    if (DG_NT_BUFS == 1 && c > 0) __syncthreads();  // single panel: its readers of the previous chunk must be done
     DG_NT_STASH(buf)
     __syncthreads();  // also orders the reuse of this buffer: its readers of two chunks ago passed the last barrier
     if (c + 1 < chunks) {
