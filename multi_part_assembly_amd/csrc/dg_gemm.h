@@ -153,8 +153,11 @@ __global__ __launch_bounds__(kGT, DG_NT_BUFS == 2 ? 2 : 3) void gemm_nt_kernel(c
 // Y [R, Nout] (ldy), X [R, K] (ldx).  Block tile 128 (n) x BK (k) outputs, the rows of chunk blockIdx.z in steps of
 // 32 through LDS; the MFMA reduction index is the row.  grid = (Nout / 128 rounded up, K / BK, row chunks);
 // part [chunks][Nout][K].  Chunks entirely past R write zeros (the second stage adds all chunks in order).
+#ifndef DG_TN_BUFS  // A/B knob like DG_NT_BUFS
+#define DG_TN_BUFS 2
+#endif
 template <int BK>
-__global__ __launch_bounds__(kGT, 2) void gemm_tn_kernel(const float* __restrict__ Y, int ldy, int Nout,
+__global__ __launch_bounds__(kGT, DG_TN_BUFS == 2 ? 2 : 3) void gemm_tn_kernel(const float* __restrict__ Y, int ldy, int Nout,
                                                          const float* __restrict__ X, int ldx, int K,
                                                          float* __restrict__ part, int rows_per_chunk,
                                                          const int* __restrict__ hdr) {
@@ -164,8 +167,8 @@ __global__ __launch_bounds__(kGT, 2) void gemm_tn_kernel(const float* __restrict
   constexpr int TK = WK / 32;       // 1 or 2
   constexpr int Y4 = RC * BNT / 4 / kGT;  // 4
   constexpr int X4 = RC * BK / 4 / kGT;   // 2 or 4
-  __shared__ __attribute__((aligned(16))) float Ys[2][RC * BNT];
-  __shared__ __attribute__((aligned(16))) float Xs[2][RC * BK];
+  __shared__ __attribute__((aligned(16))) float Ys[DG_TN_BUFS][RC * BNT];
+  __shared__ __attribute__((aligned(16))) float Xs[DG_TN_BUFS][RC * BK];
   const int R = hdr[1];
   const int n0 = blockIdx.x * BNT, k0 = blockIdx.y * BK;
   const long long rb = (long long)blockIdx.z * rows_per_chunk;
@@ -205,7 +208,8 @@ __global__ __launch_bounds__(kGT, 2) void gemm_tn_kernel(const float* __restrict
     fetch(rb);
     int it = 0;
     for (long long r = rb; r < re; r += RC, ++it) {
-      const int buf = it & 1;
+      const int buf = DG_TN_BUFS == 2 ? (it & 1) : 0;
+      if (DG_TN_BUFS == 1 && it > 0) __syncthreads();  // single panel: the previous step's readers must be done
       stash(buf);
       __syncthreads();
       if (r + RC < re) fetch(r + RC);

@@ -43,7 +43,10 @@ constexpr int kCin[4] = {3, 64, 64, 128};
 constexpr int kCO[4] = {64, 64, 128, 256};
 constexpr int kOff[4] = {0, 64, 128, 256};    // column of stage l's output inside the concatenation
 constexpr int kTile = 128;                    // rows per block of the row-tiled elementwise kernels
-constexpr int kTnChunks = 128;                // row chunks of the weight-gradient GEMMs
+#ifndef DG_TN_CHUNKS
+#define DG_TN_CHUNKS 128
+#endif
+constexpr int kTnChunks = DG_TN_CHUNKS;       // row chunks of the weight-gradient GEMMs
 constexpr float kSlope = 0.2f;
 
 // ---- bookkeeping --------------------------------------------------------------------------------------------------------
