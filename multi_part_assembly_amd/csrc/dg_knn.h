@@ -29,7 +29,6 @@
 namespace dg {
 
 constexpr int kNbr = 20;   // neighbours per point (the reference's k)
-constexpr int kQ = 32;     // queue slots per lane (24 where LDS is short: the C = 128 Gram kernel)
 constexpr int kMaxN = 1024;
 
 struct Best {

@@ -15,7 +15,7 @@
 //     one for the weight gradient per layer, both forming dy_l on the fly.
 // Rows of padded parts never enter: the valid parts are counted and compacted on the device (hdr = {parts, rows}).
 //
-// Tolerances against the fp32 path are those of bf16 (8 mantissa bits): tests/test_model_gpu.py holds features to a few
+// Tolerances against the fp32 path are those of bf16 (8 mantissa bits): tests/test_pointnet_bf16_gpu.py holds features to a few
 // 1e-2 of their scale and gradients to a cosine similarity; parity claims are made for the fp32 path only.
 #include "common.h"
 #include "dg_gemm.h"
