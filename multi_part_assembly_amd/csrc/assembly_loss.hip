@@ -323,6 +323,23 @@ __device__ __forceinline__ void accumulate(PoseGrad& a, float w, float ux, float
   }
 }
 
+// closed-form terms of pose component k (0..3 quaternion, 4..6 translation) of part m: translation L2, quaternion cosine
+__device__ __forceinline__ float pose_closed_form(const float* __restrict__ go, const float* __restrict__ valids,
+                                                  const float* __restrict__ q1, const float* __restrict__ t1,
+                                                  const float* __restrict__ q2, const float* __restrict__ t2, int B,
+                                                  int P, int m, int k) {
+  const int b = m / P;
+  const float* vb = valids + (long long)b * P;
+  if (vb[m % P] == 0.0f) return 0.0f;
+  float nv = 0.0f;
+  for (int i = 0; i < P; ++i) nv += vb[i];
+  if (k >= 4) return (go[0 * B + b] / nv) * 2.0f * (t1[3 * m + (k - 4)] - t2[3 * m + (k - 4)]);
+  const float dot = q1[4 * m] * q2[4 * m] + q1[4 * m + 1] * q2[4 * m + 1] + q1[4 * m + 2] * q2[4 * m + 2] +
+                    q1[4 * m + 3] * q2[4 * m + 3];
+  const float sgn = dot > 0.0f ? 1.0f : (dot < 0.0f ? -1.0f : 0.0f);
+  return (go[3 * B + b] / nv) * (-sgn) * q2[4 * m + k];
+}
+
 // grid = B*P blocks.  go [5][B] = d(total)/d(loss term).  Writes gq [B*P][4], gt [B*P][3] (pred pose).
 __global__ __launch_bounds__(kThreads) void assembly_backward_kernel(
     const float* __restrict__ go, const float* __restrict__ pcs, const float* __restrict__ valids,
@@ -330,9 +347,14 @@ __global__ __launch_bounds__(kThreads) void assembly_backward_kernel(
     const float* __restrict__ t2, const float* __restrict__ R1, const float* __restrict__ R2,
     const float* __restrict__ S1, const float* __restrict__ S2, const int* __restrict__ ip1,
     const int* __restrict__ ip2, const int* __restrict__ is1, const int* __restrict__ is2, int B,
-    int P, int N, int training, float* __restrict__ gq, float* __restrict__ gt) {
+    int P, int N, int training, float* __restrict__ gq, float* __restrict__ gt, float* __restrict__ psum) {
+  // gridDim.y = S slices of the point range per part (the scans below are chains of L2 latencies: one 4-wave block
+  // per part leaves the chip at ~5 waves per CU); S > 1: the 7 partial sums of a slice go to psum[(m * S + s) * 8 + k]
+  // and assembly_backward_finish_kernel adds them in slice order.
   __shared__ float red[kThreads / 64][7];
   const int m = blockIdx.x, b = m / P, p = m % P;
+  const int S = (int)gridDim.y, sl = (int)blockIdx.y;
+  const int n_lo = (int)((long long)sl * N / S), n_hi = (int)((long long)(sl + 1) * N / S);
   const float* vb = valids + (long long)b * P;
   float nv = 0.0f;
   for (int k = 0; k < P; ++k) nv += vb[k];
@@ -347,7 +369,7 @@ __global__ __launch_bounds__(kThreads) void assembly_backward_kernel(
 
   if (valid) {
     // A. this part's own points as QUERIES (part-CD dir 1, point-wise L2, shape-CD dir 1)
-    for (int n = threadIdx.x; n < N; n += kThreads) {
+    for (int n = n_lo + threadIdx.x; n < n_hi; n += kThreads) {
       const long long o = base + 3LL * n;
       const float px = pcs[o], py = pcs[o + 1], pz = pcs[o + 2];
       const float ax = R1[o], ay = R1[o + 1], az = R1[o + 2];
@@ -367,7 +389,7 @@ __global__ __launch_bounds__(kThreads) void assembly_backward_kernel(
       accumulate(acc, w, ux, uy, uz, px, py, pz, gx, gy, gz, true);
     }
     // B. this part's points as matched TARGETS of its GT copy (part-CD dir 2)
-    for (int k = threadIdx.x; k < N; k += kThreads) {
+    for (int k = n_lo + threadIdx.x; k < n_hi; k += kThreads) {
       const int jraw = ip2[(long long)m * N + k], jn = jraw >= 0 ? jraw : 0;
       const float k_cd = jraw >= 0 ? c_cd : 0.0f;
       const long long o = base + 3LL * k, j = base + 3LL * jn;
@@ -382,10 +404,10 @@ __global__ __launch_bounds__(kThreads) void assembly_backward_kernel(
     if (vb[pp] == 0.0f) continue;
     const long long qoff = ((long long)b * P + pp) * N;
     constexpr int U = 4;  // index loads of U strides in flight (the scan is a chain of L2 latencies otherwise)
-    for (int k0 = threadIdx.x; k0 < N; k0 += U * kThreads) {
+    for (int k0 = n_lo + threadIdx.x; k0 < n_hi; k0 += U * kThreads) {
       int jj[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) jj[u] = k0 + u * kThreads < N ? is2[qoff + k0 + u * kThreads] : -1;
+      for (int u = 0; u < U; ++u) jj[u] = k0 + u * kThreads < n_hi ? is2[qoff + k0 + u * kThreads] : -1;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
       const int k = k0 + u * kThreads, j = jj[u];
@@ -417,19 +439,31 @@ __global__ __launch_bounds__(kThreads) void assembly_backward_kernel(
 #pragma unroll
     for (int v = 0; v < kThreads / 64; ++v) s += red[v][threadIdx.x];
     const int k = threadIdx.x;
-    if (valid) {  // closed-form terms: translation L2 and quaternion cosine
-      if (k >= 4) {
-        s += (go[0 * B + b] / nv) * 2.0f * (t1[3 * m + (k - 4)] - t2[3 * m + (k - 4)]);
-      } else {
-        const float dot = q1[4 * m] * q2[4 * m] + q1[4 * m + 1] * q2[4 * m + 1] +
-                          q1[4 * m + 2] * q2[4 * m + 2] + q1[4 * m + 3] * q2[4 * m + 3];
-        const float sgn = dot > 0.0f ? 1.0f : (dot < 0.0f ? -1.0f : 0.0f);
-        s += (go[3 * B + b] / nv) * (-sgn) * q2[4 * m + k];
-      }
+    if (S > 1) {
+      psum[((long long)m * S + sl) * 8 + k] = s;
+      return;
     }
+    s += pose_closed_form(go, valids, q1, t1, q2, t2, B, P, m, k);
     if (k < 4) gq[4 * m + k] = s;
     else gt[3 * m + (k - 4)] = s;
   }
+}
+
+// S > 1: one thread per (part, pose component)
+__global__ void assembly_backward_finish_kernel(const float* __restrict__ go, const float* __restrict__ valids,
+                                                const float* __restrict__ q1, const float* __restrict__ t1,
+                                                const float* __restrict__ q2, const float* __restrict__ t2,
+                                                const float* __restrict__ psum, int B, int P, int S,
+                                                float* __restrict__ gq, float* __restrict__ gt) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * P * 8) return;
+  const int m = e >> 3, k = e & 7;
+  if (k == 7) return;
+  float s = 0.0f;
+  for (int q = 0; q < S; ++q) s += psum[((long long)m * S + q) * 8 + k];  // slice order: deterministic
+  s += pose_closed_form(go, valids, q1, t1, q2, t2, B, P, m, k);
+  if (k < 4) gq[4 * m + k] = s;
+  else gt[3 * m + (k - 4)] = s;
 }
 
 }  // namespace
@@ -582,9 +616,15 @@ extern "C" int mpa_assembly_loss_backward(const float* grad_losses, const float*
                   float_ws && int_ws && grad_quat && grad_trans, "assembly_loss_backward: null pointer");
   const Workspace w = carve(const_cast<float*>(float_ws), const_cast<int32_t*>(int_ws), B, P, N,
                             pick_q(B, P, N));
-  hipLaunchKernelGGL(assembly_backward_kernel, dim3((unsigned)(B * P)), dim3(kThreads), 0,
+  // four slices of the point range per part when the (forward-only) tile-sum area is big enough for their partials
+  const int S = w.tiles >= 8 ? 4 : 1;
+  hipLaunchKernelGGL(assembly_backward_kernel, dim3((unsigned)(B * P), (unsigned)S), dim3(kThreads), 0,
                      mpa::as_stream(stream), grad_losses, part_pcs, valids, quat_pred, trans_pred,
                      quat_gt, trans_gt, w.R1, w.R2, w.S1, w.S2, w.ip1, w.ip2, w.is1, w.is2, (int)B,
-                     (int)P, (int)N, training, grad_quat, grad_trans);
+                     (int)P, (int)N, training, grad_quat, grad_trans, w.part_tiles);
+  if (S > 1)
+    hipLaunchKernelGGL(assembly_backward_finish_kernel, dim3((unsigned)((B * P * 8 + 255) / 256)), dim3(256), 0,
+                       mpa::as_stream(stream), grad_losses, valids, quat_pred, trans_pred, quat_gt, trans_gt,
+                       (const float*)w.part_tiles, (int)B, (int)P, S, grad_quat, grad_trans);
   return mpa::check_launch("assembly_loss_backward");
 }
