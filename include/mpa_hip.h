@@ -257,6 +257,19 @@ int mpa_dgcnn_forward(const float* points, const float* valids, const float* con
                       float* const* running_var, const float* fc_w, const float* fc_b, int training, float momentum,
                       float eps, int64_t M, int64_t N, int64_t F, void* ws, float* feat, void* const* events,
                       void* stream);
+/* The same forward with caller-supplied kNN graphs, and the read-out of the graphs a forward built.  `graphs`: HOST array
+ * of 4 DEVICE pointers, one per EdgeConv stage; a non-NULL entry [nv*N, 20] int32 (indices inside each cloud, rows of
+ * the nv VALID parts in order) replaces that stage's search, a NULL entry is searched as usual.  The reference rebuilds
+ * every graph from the features (dgcnn.py:84-96); this entry point exists so that a parity test can hold the graphs
+ * fixed to the reference's own `knn` outputs and attribute what remains of a difference.  mpa_dgcnn_export_graph copies
+ * stage `stage`'s (0..3) lists out of a forward's workspace: idx [M*N, 20] int32, rows past the valid parts = -1. */
+int mpa_dgcnn_forward_graphs(const float* points, const float* valids, const float* const* conv_w,
+                             const float* const* bn_w, const float* const* bn_b, float* const* running_mean,
+                             float* const* running_var, const float* fc_w, const float* fc_b, int training,
+                             float momentum, float eps, int64_t M, int64_t N, int64_t F, void* ws, float* feat,
+                             const int32_t* const* graphs, void* stream);
+int mpa_dgcnn_export_graph(const void* ws, int64_t M, int64_t N, int64_t F, int64_t stage, int32_t* idx,
+                           void* stream);
 int mpa_dgcnn_backward(const float* grad_feat, const float* const* conv_w, const float* const* bn_w,
                        const float* fc_w, int64_t M, int64_t N, int64_t F, void* ws, float* const* grad_conv_w,
                        float* const* grad_bn_w, float* const* grad_bn_b, float* grad_fc_w, float* grad_fc_b,

@@ -55,6 +55,8 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_edge_aggregate_backward": (_INT, [_P] * 4 + [_I64] * 4 + [_P] * 5),
     "mpa_dgcnn_workspace": (_INT, [_I64, _I64, _I64, _P]),
     "mpa_dgcnn_forward": (_INT, [_P] * 9 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "mpa_dgcnn_forward_graphs": (_INT, [_P] * 9 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "mpa_dgcnn_export_graph": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P]),
     "mpa_dgcnn_backward": (_INT, [_P] * 4 + [_I64, _I64, _I64] + [_P] * 8),
     "mpa_knn_exact": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_mlp_layer_workspace": (_INT, [_I64, _I64, _I64, _P]),

@@ -993,11 +993,24 @@ extern "C" int mpa_dgcnn_workspace(int64_t M, int64_t N, int64_t F, int64_t* byt
   return MPA_OK;
 }
 
-extern "C" int mpa_dgcnn_forward(const float* points, const float* valids, const float* const* conv_w,
-                                 const float* const* bn_w, const float* const* bn_b, float* const* running_mean,
-                                 float* const* running_var, const float* fc_w, const float* fc_b, int training,
-                                 float momentum, float eps, int64_t M, int64_t N, int64_t F, void* ws, float* feat,
-                                 void* const* events, void* stream) {
+namespace {
+// caller-supplied graph of the COMPACTED valid parts -> the workspace's u16 lists (rows past the valid parts untouched)
+__global__ void dg_import_graph_kernel(const int32_t* __restrict__ src, unsigned short* __restrict__ dst,
+                                       const int* __restrict__ hdr) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (long long)hdr[1] * kNbr) dst[i] = (unsigned short)src[i];
+}
+__global__ void dg_export_graph_kernel(const unsigned short* __restrict__ src, int32_t* __restrict__ dst,
+                                       const int* __restrict__ hdr, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) dst[i] = i < (long long)hdr[1] * kNbr ? (int32_t)src[i] : -1;
+}
+
+int dgcnn_forward_impl(const float* points, const float* valids, const float* const* conv_w,
+                       const float* const* bn_w, const float* const* bn_b, float* const* running_mean,
+                       float* const* running_var, const float* fc_w, const float* fc_b, int training,
+                       float momentum, float eps, int64_t M, int64_t N, int64_t F, void* ws, float* feat,
+                       void* const* events, const int32_t* const* graphs, void* stream) {
   if (int st = dg_check(M, N, F, "dgcnn_forward")) return st;
   if (M == 0) return MPA_OK;
   MPA_REQUIRE(points && valids && conv_w && bn_w && bn_b && running_mean && running_var && fc_w && fc_b && ws && feat,
@@ -1016,7 +1029,10 @@ extern "C" int mpa_dgcnn_forward(const float* points, const float* valids, const
            w.wstt[l]);
     // kNN graph in the stage's input space
     record(events, 2 * l, s);
-    if (l == 0) {
+    if (graphs != nullptr && graphs[l] != nullptr) {
+      launch(dg_import_graph_kernel, dim3((unsigned)((R * kNbr + 255) / 256)), dim3(256), s, graphs[l], w.idx[l],
+             (const int*)w.hdr);
+    } else if (l == 0) {
       launch(knn3_kernel<unsigned short>, dim3((unsigned)((N + 255) / 256), DG_KNN_GRID_Y(M)), dim3(256), s,
              reinterpret_cast<const float*>(w.x0), (int)N, w.idx[0], (const int*)w.hdr);
     } else {
@@ -1071,6 +1087,39 @@ extern "C" int mpa_dgcnn_forward(const float* points, const float* valids, const
   launch(dg_fc_kernel, dim3((unsigned)M), dim3((unsigned)F), s, (const float*)w.pooled, (const int*)w.rank, (int)F, fc_w,
          fc_b, feat);
   return mpa::check_launch("dgcnn_forward");
+}
+}  // namespace
+
+extern "C" int mpa_dgcnn_forward(const float* points, const float* valids, const float* const* conv_w,
+                                 const float* const* bn_w, const float* const* bn_b, float* const* running_mean,
+                                 float* const* running_var, const float* fc_w, const float* fc_b, int training,
+                                 float momentum, float eps, int64_t M, int64_t N, int64_t F, void* ws, float* feat,
+                                 void* const* events, void* stream) {
+  return dgcnn_forward_impl(points, valids, conv_w, bn_w, bn_b, running_mean, running_var, fc_w, fc_b, training, momentum,
+                            eps, M, N, F, ws, feat, events, nullptr, stream);
+}
+
+extern "C" int mpa_dgcnn_forward_graphs(const float* points, const float* valids, const float* const* conv_w,
+                                        const float* const* bn_w, const float* const* bn_b, float* const* running_mean,
+                                        float* const* running_var, const float* fc_w, const float* fc_b, int training,
+                                        float momentum, float eps, int64_t M, int64_t N, int64_t F, void* ws,
+                                        float* feat, const int32_t* const* graphs, void* stream) {
+  MPA_REQUIRE(graphs != nullptr, "dgcnn_forward_graphs: null pointer");
+  return dgcnn_forward_impl(points, valids, conv_w, bn_w, bn_b, running_mean, running_var, fc_w, fc_b, training, momentum,
+                            eps, M, N, F, ws, feat, nullptr, graphs, stream);
+}
+
+extern "C" int mpa_dgcnn_export_graph(const void* ws, int64_t M, int64_t N, int64_t F, int64_t stage, int32_t* idx,
+                                      void* stream) {
+  if (int st = dg_check(M, N, F, "dgcnn_export_graph")) return st;
+  MPA_REQUIRE(stage >= 0 && stage < 4, "dgcnn_export_graph: stage must be 0..3");
+  if (M == 0) return MPA_OK;
+  MPA_REQUIRE(ws && idx, "dgcnn_export_graph: null pointer");
+  const Ws w = dg_carve(static_cast<char*>(const_cast<void*>(ws)), M, N, F);
+  const long long total = (long long)M * N * kNbr;
+  launch(dg_export_graph_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), mpa::as_stream(stream),
+         (const unsigned short*)w.idx[stage], idx, (const int*)w.hdr, total);
+  return mpa::check_launch("dgcnn_export_graph");
 }
 
 extern "C" int mpa_dgcnn_backward(const float* grad_feat, const float* const* conv_w, const float* const* bn_w,

@@ -252,7 +252,7 @@ class _DGCNNFn(torch.autograd.Function):
     """Whole DGCNN encoder forward/backward on the HIP library (csrc/dgcnn_enc.hip)."""
 
     @staticmethod
-    def forward(ctx, points, valids, training, momentum, eps, running, want_point_grad, *params):
+    def forward(ctx, points, valids, training, momentum, eps, running, want_point_grad, hooks, *params):
         conv_w, bn_w, bn_b, fc_w, fc_b = params[0:5], params[5:10], params[10:15], params[15], params[16]
         run_mean, run_var = running
         M, N, _ = points.shape
@@ -272,12 +272,30 @@ class _DGCNNFn(torch.autograd.Function):
             flat = None
             if any(p is not None for p in pairs):
                 flat = [e for p in pairs for e in (p if p is not None else [None, None])]
-            st = L.mpa_dgcnn_forward(
-                _lib.ptr(pts), _lib.ptr(valids), _lib.ptr_array(conv_w), _lib.ptr_array(bn_w), _lib.ptr_array(bn_b),
-                _lib.ptr_array(run_mean), _lib.ptr_array(run_var), _lib.ptr(fc_w), _lib.ptr(fc_b), int(training),
-                float(momentum), float(eps), M, N, F_, _lib.ptr(ws), _lib.ptr(feat), _lib.KernelTimer.handles(flat),
-                _lib.current_stream(dev))
+            graphs = hooks.get("graphs") if hooks else None
+            if graphs is not None:  # parity tests: hold some stages' kNN graphs fixed (mpa_dgcnn_forward_graphs)
+                graphs = [None if g is None else g.to(device=dev, dtype=torch.int32).contiguous() for g in graphs]
+                gp = (ctypes.c_void_p * 4)(*[None if g is None else g.data_ptr() for g in graphs])
+                st = L.mpa_dgcnn_forward_graphs(
+                    _lib.ptr(pts), _lib.ptr(valids), _lib.ptr_array(conv_w), _lib.ptr_array(bn_w),
+                    _lib.ptr_array(bn_b), _lib.ptr_array(run_mean), _lib.ptr_array(run_var), _lib.ptr(fc_w),
+                    _lib.ptr(fc_b), int(training), float(momentum), float(eps), M, N, F_, _lib.ptr(ws), _lib.ptr(feat),
+                    gp, _lib.current_stream(dev))
+            else:
+                st = L.mpa_dgcnn_forward(
+                    _lib.ptr(pts), _lib.ptr(valids), _lib.ptr_array(conv_w), _lib.ptr_array(bn_w),
+                    _lib.ptr_array(bn_b), _lib.ptr_array(run_mean), _lib.ptr_array(run_var), _lib.ptr(fc_w),
+                    _lib.ptr(fc_b), int(training), float(momentum), float(eps), M, N, F_, _lib.ptr(ws), _lib.ptr(feat),
+                    _lib.KernelTimer.handles(flat), _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
+            if hooks is not None and hooks.get("export"):
+                out = []
+                for l in range(4):
+                    g = torch.empty((M * N, 20), dtype=torch.int32, device=dev)
+                    _lib.check(L.mpa_dgcnn_export_graph(_lib.ptr(ws), M, N, F_, l, _lib.ptr(g),
+                                                        _lib.current_stream(dev)), "mpa_dgcnn_export_graph")
+                    out.append(g)
+                hooks["exported"] = out
             for n, p in zip(knn_names, pairs):
                 _lib.KernelTimer.add_phases([n], p)
         _lib.check(st, "mpa_dgcnn_forward")
@@ -308,7 +326,7 @@ class _DGCNNFn(torch.autograd.Function):
                 _lib.ptr(grads[15]), _lib.ptr(grads[16]), _lib.ptr(gpts), _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_dgcnn_backward")
-        return (gpts, None, None, None, None, None, None, *grads)
+        return (gpts, None, None, None, None, None, None, None, *grads)
 
 
 class DGCNN(nn.Module):
@@ -343,6 +361,9 @@ class DGCNN(nn.Module):
         if global_feat:
             self.out_fc = nn.Linear(feat_dim * 2, feat_dim)
         self._warned = False
+        # parity-test hooks (None in production): {"graphs": [4 x (None | int32 [nv*N, 20])]} holds stages' kNN graphs
+        # fixed; {"export": True} leaves the graphs the forward built under "exported" ([M*N, 20] int32 per stage)
+        self.graph_hooks = None
 
     def _fused_ok(self, N):
         return self.global_feat and self.feat_dim in (64, 128, 256) and 20 <= N <= self.MAX_POINTS
@@ -362,7 +383,7 @@ class DGCNN(nn.Module):
         running = ([bn.running_mean for bn in bns], [bn.running_var for bn in bns])
         return _DGCNNFn.apply(
             part_pcs.float().contiguous(), valids.detach().float().contiguous(), self.training, bns[0].momentum,
-            bns[0].eps, running, part_pcs.requires_grad, *[c.weight for c in convs], *[b.weight for b in bns],
+            bns[0].eps, running, part_pcs.requires_grad, self.graph_hooks, *[c.weight for c in convs], *[b.weight for b in bns],
             *[b.bias for b in bns], self.out_fc.weight, self.out_fc.bias)
 
     def forward(self, x):

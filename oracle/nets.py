@@ -50,22 +50,23 @@ def knn_indices(x, k):
     return (-xx - inner - xx.transpose(2, 1)).topk(k=k, dim=-1)[1]
 
 
-def graph_feature(x, k=20):
-    """dgcnn.py:18-38: [n, C, N] -> [n, 2C, N, k] = [x_j - x_i ; x_i]."""
+def graph_feature(x, k=20, idx=None):
+    """dgcnn.py:18-38: [n, C, N] -> [n, 2C, N, k] = [x_j - x_i ; x_i].  `idx` [n, N, k] (tests only): a given graph
+    instead of the search — lets a float64 evaluation run on the float32 reference's graphs."""
     n, C, N = x.shape
-    idx = knn_indices(x, k) + torch.arange(n).view(-1, 1, 1) * N
+    idx = (knn_indices(x, k) if idx is None else idx.long()) + torch.arange(n).view(-1, 1, 1) * N
     pts = x.transpose(2, 1).contiguous()
     nbr = pts.view(n * N, C)[idx.view(-1)].view(n, N, k, C)
     ctr = pts.view(n, N, 1, C).repeat(1, 1, k, 1)
     return torch.cat((nbr - ctr, ctr), dim=3).permute(0, 3, 1, 2).contiguous()
 
 
-def dgcnn(x, sd, prefix="", training=True, stats_out=None):
-    """dgcnn.py:77-109 (global_feat=True): x [n, N, 3] -> [n, F]."""
+def dgcnn(x, sd, prefix="", training=True, stats_out=None, graphs=None):
+    """dgcnn.py:77-109 (global_feat=True): x [n, N, 3] -> [n, F].  `graphs`: optional list of 4 index tensors."""
     h = x.transpose(2, 1).contiguous()
     stages = []
     for i in range(1, 5):
-        e = F.conv2d(graph_feature(h), sd[f"{prefix}conv{i}.0.weight"])
+        e = F.conv2d(graph_feature(h, idx=None if graphs is None else graphs[i - 1]), sd[f"{prefix}conv{i}.0.weight"])
         e = F.leaky_relu(_bn(e, sd, f"{prefix}bn{i}", training, stats_out), 0.2)
         h = e.max(dim=-1)[0]
         stages.append(h)

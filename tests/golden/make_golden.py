@@ -16,6 +16,9 @@ Fixture -> reference entry points exercised
   losses.npz        utils/loss.py:7-202                 every loss on the geometric path + input grads
   pointnet.npz      models/modules/encoder/pointnet.py:6-41
   dgcnn.npz         models/modules/encoder/dgcnn.py:8-109
+  dgcnn_graphs.npz  models/modules/encoder/dgcnn.py:8-15,84-96  the inputs of all four EdgeConv stages and the
+                    reference's own `knn(x, 20)` output for each, on the dgcnn.npz cloud (3 x 96 points) and
+                    on a 2 x 1000-point cloud (the benchmark's points per part)
   transformer.npz   models/pn_transformer/transformer.py:37-79, models/modules/regressor.py:30-84
   pn_transformer_step.npz  models/pn_transformer/network.py:70-139 + models/modules/base_model.py
                     forward_pass/loss_function/_calc_loss on a seeded synthetic batch (+ all grads)
@@ -223,6 +226,50 @@ def gen_encoder(name, feat_dim, n, N, seed):
     save(name, **out)
 
 
+def gen_dgcnn_graphs():
+    """The kNN graph of EVERY EdgeConv stage as the reference builds it (dgcnn.py:8-15 called from :84-96): `knn` is
+    wrapped while the reference's DGCNN runs a training-mode forward, and each call's input [n, C, N] (stored
+    point-major [n, N, C]) and index output [n, N, 20] are recorded.  Case `a` repeats gen_encoder('dgcnn', 128, 3, 96,
+    1005) draw for draw (same weights and cloud as dgcnn.npz); case `b` is a 2 x 1000-point cloud."""
+    from multi_part_assembly.models import build_encoder
+    from multi_part_assembly.models.modules.encoder import dgcnn as D
+
+    out = {}
+    for tag, (feat_dim, n, N, seed) in {"a": (128, 3, 96, 1005), "b": (128, 2, 1000, 1016)}.items():
+        g = torch.Generator().manual_seed(seed)
+        torch.manual_seed(seed)
+        enc = build_encoder("dgcnn", feat_dim=feat_dim, global_feat=True)
+        randomize_norm_params(enc, g)
+        x = torch.randn(n, N, 3, generator=g) * 0.3
+        calls = []
+        real_knn = D.knn
+
+        def spy(xx, k, _real=real_knn, _calls=calls):
+            idx = _real(xx, k)
+            _calls.append((npy(xx.transpose(2, 1).contiguous()), npy(idx)))
+            return idx
+
+        D.knn = spy
+        try:
+            enc.train()
+            with torch.no_grad():
+                feat = enc(x)
+        finally:
+            D.knn = real_knn
+        assert len(calls) == 4 and [c[0].shape[-1] for c in calls] == [3, 64, 64, 128]
+        out[f"{tag}.feat_train"] = npy(feat)
+        for l, (xin, idx) in enumerate(calls):
+            out[f"{tag}.stage{l + 1}.x"] = xin.astype(np.float32)
+            out[f"{tag}.stage{l + 1}.idx"] = idx.astype(np.int16)
+        if tag == "a":  # the same cloud and graph as dgcnn.npz
+            ref = np.load(HERE / "dgcnn.npz")
+            assert np.array_equal(ref["x"], calls[0][0]) and np.array_equal(ref["knn_idx_layer1"], calls[0][1])
+            assert np.array_equal(ref["feat_train"], out["a.feat_train"])
+        if tag == "b":  # the parameters of case b are not in any other fixture
+            out.update(state_arrays(enc, "b.sd0."))
+    save("dgcnn_graphs", **out)
+
+
 def gen_transformer():
     from multi_part_assembly.models.pn_transformer.transformer import TransformerEncoder
     from multi_part_assembly.models.modules.regressor import StocasticPoseRegressor
@@ -364,6 +411,23 @@ def _model_step(name, cfg, data, seed, extra=None):
     for k, v in model.state_dict().items():
         if "running_" in k:
             out.update(param_fill.compact("sd1.", k, npy(v)))
+    # the same step once more in float64 (same weights, data and CPU-generator draws, all cast up): the anchor that
+    # tells a test how far the float32 reference itself sits from the exact gradients of its own graph
+    torch.manual_seed(seed)
+    model64 = build_model(cfg)
+    param_fill.fill_parameters(model64, seed)
+    zero_dropout(model64)
+    model64.double().train()
+    torch.manual_seed(seed + 1)  # the draws inside forward are float32 `.type_as(...)` upstream: the same values
+    loss64 = model64.forward_pass({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in data.items()},
+                                  mode="val", optimizer_idx=-1)
+    loss64["loss"].backward()
+    for k, v in loss64.items():
+        if torch.is_tensor(v):
+            out[f"loss64.{k}"] = npy(v).astype(np.float64)
+    for k, p in model64.named_parameters():
+        if p.grad is not None:
+            out.update(param_fill.compact("grad64.", k, npy(p.grad)))
     save(name, **out)
 
 
@@ -619,6 +683,7 @@ def main():
         "losses": lambda: gen_losses(U),
         "pointnet": lambda: gen_encoder("pointnet", 256, 5, 128, 1004),
         "dgcnn": lambda: gen_encoder("dgcnn", 128, 3, 96, 1005),
+        "dgcnn_graphs": gen_dgcnn_graphs,
         "transformer": gen_transformer,
         "pn_transformer_step": gen_pn_transformer_step,
         "dgl_step": gen_dgl_step,

@@ -58,3 +58,29 @@ def compare(record, prefix, name, array, rel, floor=0.0):
     norms = record[key + "#norms"]
     mine = np.array([np.abs(a).sum(), np.sqrt((a.astype(np.float64) ** 2).sum())])
     assert np.all(np.abs(mine - norms) / np.maximum(np.abs(norms), floor * a.size ** 0.5 + 1e-12) < rel), (key, "norms", mine, norms)
+
+
+def anchored_errors(record, name, array, floor=0.0):
+    """(err_mine, err_ref32, outliers): max-abs distance of `array`, and of the float32 reference gradient recorded under
+    "grad." + name, from the float64 evaluation of the same step recorded under "grad64." + name — both relative to
+    max(|float64 gradient|, floor), on the recorded entries (the full tensor or its strided sample); `outliers` = the
+    number of recorded entries of `array` further than 1e-2 from float64 (an isolated ReLU / arg-max flip shows up as one
+    or two entries, a wiring error as most of them) and the number of recorded entries."""
+    a = np.asarray(array, dtype=np.float64).reshape(-1)
+    if "grad64." + name in record:
+        t, r = record["grad64." + name], record["grad." + name]
+    else:
+        idx = np.linspace(0, a.size - 1, SAMPLE).astype(np.int64)
+        a, t, r = a[idx], record[f"grad64.{name}#sample"], record[f"grad.{name}#sample"]
+    t = t.astype(np.float64)
+    scale = max(np.abs(t).max(), floor, 1e-12)
+    e = np.abs(a - t) / scale
+    return float(e.max()), float(np.abs(r.astype(np.float64) - t).max() / scale), (int((e > 1e-2).sum()), int(e.size))
+
+
+def grad64_scale(record, name):
+    """Largest |float64 gradient| recorded for parameter `name` (0.0 if there is no record)."""
+    for key in ("grad64." + name, f"grad64.{name}#sample"):
+        if key in record:
+            return float(np.abs(record[key]).max())
+    return 0.0

@@ -29,16 +29,26 @@ CASES = {
     "rgl_net_dgcnn_artifact_step": config.rgl_net_dgcnn_artifact,
 }
 # Gradient tolerance.  The GNN callers stack 3 iterations of 512-wide BatchNorm + ReLU MLPs whose statistics come
-# from 15-75 positions at the fixture's size: measured on this implementation alone, a 1e-6 relative perturbation
-# of the input moves individual parameter gradients by up to 4 % (tools/debug_callers.py) while every loss term
-# moves by 1e-5.  So the losses (all iterations) are held to 2e-4 and the gradients to 8 % — a wiring error (wrong
-# pair order, missing relation gate, detached pose) shows up as an O(1) mismatch.
-GRAD_REL = {"dgl_step": 8e-2, "rgl_net_step": 8e-2, "global_semantic_step": 2e-3, "pn_refine_step": 2e-3,
-            "dgl_dgcnn_step": 8e-2, "rgl_net_dgcnn_artifact_step": 8e-2}
+# from 15-75 positions at the fixture's size, so the float32 REFERENCE itself is up to 4.4 % (DGL), 1.7 % (DGL + DGCNN,
+# RGL-NET) away from the float64 evaluation of its own step (the `grad64.*` records of the fixtures; B-Global and the
+# refine transformer: 1e-5).  The bar is therefore anchored at float64, per parameter tensor (errors relative to the
+# tensor's largest float64 entry):
+#   (a) |hip - fp64| <= 2 |ref_fp32 - fp64| + 1e-4, or
+#   (b) |hip - fp64| <= GRAD_REL (1e-2 for the graph networks, 2e-3 else), or
+#   (c) an ISOLATED flip: at most 2 recorded entries of the tensor (and at most FLIP_TENSORS tensors of the model)
+#       exceed 1e-2, none exceeds 5e-2.  One ReLU whose pre-activation rounds to the other side of zero moves one
+#       channel's BatchNorm-bias gradient by 1/rows of its value — 2.8 % of the largest entry with the fixture's 75
+#       pair rows — exactly as it moved the float32 reference's own DGCNN input gradient (tests/test_dgcnn_gpu.py);
+#       tools/debug_anchor.py lists the entries: 1 of 512 in the one tensor where it happens (RGL-NET + DGCNN).
+# A bias in front of a BatchNorm has a structurally zero gradient: there the bar is absolute, 1e-5 of the layer's
+# weight-gradient scale (the float32 reference leaves 5e-7 there).
+GRAD_REL = {"dgl_step": 1e-2, "rgl_net_step": 1e-2, "global_semantic_step": 2e-3, "pn_refine_step": 2e-3,
+            "dgl_dgcnn_step": 1e-2, "rgl_net_dgcnn_artifact_step": 1e-2}
+FLIP_TENSORS = 3
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_caller_step_matches_reference(golden, cuda_device, name):
+def test_caller_step_matches_reference(golden, cuda_device, capsys, name):
     z = golden(name)
     cfg = CASES[name]()
     cfg.model.pc_feat_dim = int(z["cfg"][0])
@@ -65,10 +75,28 @@ def test_caller_step_matches_reference(golden, cuda_device, name):
         if k.startswith("loss."):
             np.testing.assert_allclose(float(res[k[5:]]), float(z[k]), rtol=2e-4, atol=1e-6, err_msg=k)
     record = dict(z)
+    rows, flips = [], []
     for k, p in model.named_parameters():
         if ("grad." + k) in record or ("grad." + k + "#sample") in record:
             assert p.grad is not None, k
-            param_fill.compare(record, "grad.", k, p.grad.cpu().numpy(), rel=GRAD_REL[name], floor=1e-4)
+            g = p.grad.cpu().numpy()
+            wscale = param_fill.grad64_scale(record, k[:-len("bias")] + "weight") if k.endswith(".bias") else 0.0
+            if wscale > 0 and param_fill.grad64_scale(record, k) < 1e-9 * wscale:  # structurally zero gradient
+                assert np.abs(g).max() <= 1e-5 * wscale, (k, float(np.abs(g).max()), wscale)
+                continue
+            mine, ref32, (outliers, n) = param_fill.anchored_errors(record, k, g, floor=1e-4)
+            rows.append((mine, ref32, k))
+            if mine <= 2.0 * ref32 + 1e-4 or mine <= GRAD_REL[name]:
+                continue
+            assert outliers <= 2 and mine <= 5e-2, (k, mine, ref32, outliers, n)
+            flips.append((k, mine, ref32, outliers, n))
+    worst = max(rows)
+    with capsys.disabled():
+        med = sorted(r[0] for r in rows)[len(rows) // 2]
+        print(f"\n  {name}: {len(rows)} gradient tensors vs float64: worst {worst[0]:.2e} ({worst[2]}; the float32 "
+              f"reference there: {worst[1]:.2e}), median {med:.2e}; float32 reference worst {max(r[1] for r in rows):.2e}"
+              f"; isolated flips: {flips}", end="")
+    assert len(flips) <= FLIP_TENSORS, flips
     for k, v in model.state_dict().items():
         if "running_" in k:
             param_fill.compare(record, "sd1.", k, v.cpu().numpy(), rel=1e-4)
@@ -89,26 +117,36 @@ def test_pair_mlp_hip_layers_match_library_ops(cuda_device, final_relu, rows, L,
             bn.weight.uniform_(0.5, 1.5)
             bn.bias.normal_(0, 0.1)
     ref = copy.deepcopy(mine)
+    ref64 = copy.deepcopy(mine).double()
     x = torch.randn(rows, L, cin, device=cuda_device)
     w = torch.randn(rows, L, feat, device=cuda_device)
-    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    xa, xb, xc = x.clone().requires_grad_(), x.clone().requires_grad_(), x.double().requires_grad_()
     out = mine(xa)
     (out * w).sum().backward()
     want = ref._tail(ref.conv1(xb.transpose(1, 2)))
     (want * w).sum().backward()
-    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    want64 = ref64._tail(ref64.conv1(xc.transpose(1, 2)))
+    (want64 * w.double()).sum().backward()
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / (b.abs().max() + 1e-12))
     assert rel(out.detach(), want.detach()) < 1e-4
+    assert rel(out.detach(), want64.detach()) < 1e-5
 
-    def close(a, b, who):  # three stacked BatchNorm backwards in fp32: worst entry 2e-2, all but 1 % of entries 2e-3
-        assert rel(a, b) < 2e-2, who
-        assert float(((a - b).abs() > 2e-3 * b.abs().max()).float().mean()) < 0.01, who
+    def close(a, lib32, f64, who):
+        """Three stacked BatchNorm backwards over few rows: anchored at the float64 evaluation of the same module — within
+        2e-4 of it, or no further from it than twice the float32 library result is; a ReLU on the rounding edge may move
+        isolated entries (at most 0.5 % of them beyond 2e-3, none beyond 3e-2)."""
+        mine_e, lib_e = rel(a, f64), rel(lib32, f64)
+        if mine_e < 2e-4 or mine_e <= 2.0 * lib_e:
+            return
+        far = ((a.double() - f64).abs() > 2e-3 * f64.abs().max()).float().mean()
+        assert mine_e < 3e-2 and float(far) <= 0.005, (who, mine_e, lib_e, float(far))
 
-    close(xa.grad, xb.grad, "x")
-    for (k, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+    close(xa.grad, xb.grad, xc.grad, "x")
+    for (k, p), (_, q), (_, r) in zip(mine.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
         if "conv" in k and "bias" in k:   # a bias in front of a BatchNorm: its gradient is zero up to rounding
             assert float(p.grad.abs().max()) < 1e-3 * float(w.abs().sum())
         else:
-            close(p.grad, q.grad, k)
+            close(p.grad, q.grad, r.grad, k)
     for (k, a), (_, b) in zip(mine.named_buffers(), ref.named_buffers()):
         if "running" in k:
             assert rel(a, b) < 1e-4, k

@@ -44,6 +44,97 @@ def test_knn_is_index_exact_against_oracle(golden, cuda_device, C):
         assert torch.equal(got, T(z["knn_idx_layer1"]).long())  # the reference's topk output itself, order included
 
 
+def test_knn_matches_reference_graphs_of_every_stage(golden, cuda_device, capsys):
+    """mpa_knn_exact on the reference's own stage inputs (dgcnn_graphs.npz: recorded while the reference's DGCNN ran,
+    dgcnn.py:8-15,84-96; C = 3, 64, 64, 128; the dgcnn.npz cloud and a 2 x 1000-point cloud): index for index the C
+    oracle's lists, and the REFERENCE's neighbour sets — a differing pick only as a proven float64 near-tie."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from knn_check import compare_with_reference_graph
+    from oracle.knn import knn_exact as oracle_knn
+    z = golden("dgcnn_graphs")
+    for tag in "ab":
+        for l in (1, 2, 3, 4):
+            x, ref = z[f"{tag}.stage{l}.x"], z[f"{tag}.stage{l}.idx"]
+            got = _hip_knn(T(x.copy()), x.shape[-1]).numpy()
+            assert np.array_equal(got, oracle_knn(x).astype(np.int64)), (tag, l)
+            st = compare_with_reference_graph(x, got, ref)
+            with capsys.disabled():
+                print(f"\n  HIP knn vs reference, case {tag} stage {l} (C={x.shape[-1]}): {st}", end="")
+            assert st["set_mismatch_rows"] <= 0.001 * st["rows"] and st["in_order_equal"] > 0.999
+
+
+def test_encoder_builds_the_reference_graphs(golden, cuda_device, capsys):
+    """The graphs the one-call encoder builds INSIDE its forward (from its own stage outputs, which differ from the
+    reference's by fp32 rounding) on the 2 x 1000-point fixture cloud with the fixture's weights, read back through
+    mpa_dgcnn_export_graph, against the reference's graphs of all four stages; and the features against the
+    reference's.  Near-tie bound 1e-5 here: the inputs themselves differ at the 1e-6 level."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from knn_check import compare_with_reference_graph
+    z = golden("dgcnn_graphs")
+    enc = DGCNN(128)
+    enc.load_state_dict({k[len("b.sd0."):]: T(v.copy()) for k, v in z.items() if k.startswith("b.sd0.")}, strict=True)
+    enc.to(cuda_device).train()
+    enc.graph_hooks = {"export": True}
+    x = T(z["b.stage1.x"].copy()).to(cuda_device)
+    with torch.no_grad():
+        feat = enc(x)
+    assert _rel(feat.cpu(), T(z["b.feat_train"])) < 1e-4
+    n, N, _ = x.shape
+    for l in (1, 2, 3, 4):
+        got = enc.graph_hooks["exported"][l - 1].cpu().view(n, N, 20).numpy()
+        st = compare_with_reference_graph(z[f"b.stage{l}.x"], got, z[f"b.stage{l}.idx"], gap=1e-5)
+        with capsys.disabled():
+            print(f"\n  encoder-internal graph vs reference, stage {l}: {st}", end="")
+        assert st["set_mismatch_rows"] <= 0.002 * st["rows"]
+
+
+def test_encoder_gradients_with_reference_graphs(golden, cuda_device, capsys):
+    """test_encoder_matches_reference[dgcnn] (tests/test_model_gpu.py) with the kNN graphs of all four stages held to
+    the REFERENCE's (mpa_dgcnn_forward_graphs), anchored at the float64 evaluation of the same network on the same
+    graphs (oracle.nets.dgcnn in double).  The float32 reference fixture is itself 2.8e-2 (grad_x) and 2.4e-3
+    (conv1.weight) away from float64 — a near-tie of the max over the 20 neighbours resolved the other way in float32
+    — so the free-running 3e-2 bar of test_model_gpu measured the REFERENCE's rounding, not this build's.  Here every
+    gradient must be within 2e-4 of float64 or twice as close to float64 as the float32 reference is."""
+    from oracle import nets as on
+    z, zg = golden("dgcnn"), golden("dgcnn_graphs")
+    n, N, _ = z["x"].shape
+    graphs = [T(zg[f"a.stage{l}.idx"].astype(np.int64)) for l in (1, 2, 3, 4)]
+    sd64 = {}
+    for k, v in z.items():
+        if k.startswith("sd0."):
+            t = T(v.copy())
+            if t.is_floating_point():
+                t = t.double()
+                if "running" not in k:
+                    t.requires_grad_()
+            sd64[k[4:]] = t
+    x64 = T(z["x"]).double().requires_grad_()
+    f64 = on.dgcnn(x64, sd64, "", True, {}, graphs=graphs)
+    (f64 * T(z["w"]).double()).sum().backward()
+
+    enc = DGCNN(128)
+    enc.load_state_dict({k[4:]: T(v.copy()) for k, v in z.items() if k.startswith("sd0.")}, strict=True)
+    enc.to(cuda_device).train()
+    enc.graph_hooks = {"graphs": [g.int().view(n * N, 20) for g in graphs]}
+    x = T(z["x"].copy()).to(cuda_device).requires_grad_()
+    out = enc(x)
+    (out * T(z["w"]).to(cuda_device)).sum().backward()
+    assert _rel(out.detach().cpu().double(), f64.detach()) < 1e-5
+    assert _rel(out.detach().cpu(), T(z["feat_train"])) < 1e-4
+    rows = [("grad_x", _rel(x.grad.cpu().double(), x64.grad), _rel(T(z["grad_x"]).double(), x64.grad))]
+    for k, p in enc.named_parameters():
+        rows.append((k, _rel(p.grad.cpu().double(), sd64[k].grad), _rel(T(z["grad." + k]).double(), sd64[k].grad)))
+    with capsys.disabled():
+        for k, mine, ref32 in rows:
+            print(f"\n  dgcnn {k}: hip vs float64 {mine:.2e}; float32 reference vs float64 {ref32:.2e}", end="")
+    for k, mine, ref32 in rows:
+        assert mine < 2e-4 or mine < 0.5 * ref32, (k, mine, ref32)
+
+
 @pytest.mark.parametrize("C", [3, 64])
 def test_knn_ties_resolve_to_the_lower_index(cuda_device, C):
     """Duplicated points and lattice coordinates: many exactly equal scores; (score, index) order must hold."""

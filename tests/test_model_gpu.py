@@ -45,16 +45,18 @@ def test_encoder_matches_reference(golden, cuda_device, name, feat):
     out = enc(x)
     (out * T(z["w"]).to(cuda_device)).sum().backward()
     assert _rel(out.detach().cpu().numpy(), z["feat_train"]) < 1e-4
-    # DGCNN: the first stage's kNN graph is index-exact; the later stages' graphs are built in 64/128-d feature
-    # space where the reference's BLAS summation order is undefined, so an isolated near-tie neighbour can differ
-    # (the forward max hides it: 1e-4 holds) and moves the gradient of the few edges it touches: the worst entry is
-    # held to 3e-2, and all but a few percent of the entries to 2e-3.
-    gtol = 1e-3 if name == "pointnet" else 3e-2
+    # DGCNN: the fixture's float32 reference gradients are THEMSELVES 2.8e-2 (grad_x) and 2.4e-3 (conv1.weight) away from
+    # the float64 evaluation of the same network on the same graphs — one near-tie of the max over the 20 neighbours
+    # resolved the other way in the reference's float32 run — while this build is within 5e-6 of float64 on every tensor
+    # (tests/test_dgcnn_gpu.py::test_encoder_gradients_with_reference_graphs).  So those two tensors are compared with
+    # the reference's own deviation as the bar, every other tensor at 2e-4.
+    ref_dev = {"grad_x": 3e-2, "conv1.0.weight": 3e-3}
 
     def close(a, b, who):
-        assert _rel(a, b) < gtol, who
-        if name == "dgcnn":
-            bad = (np.abs(a - b) > 2e-3 * np.abs(b).max()).mean()
+        tol = 1e-3 if name == "pointnet" else ref_dev.get(who, 2e-4)
+        assert _rel(a, b) < tol, (who, _rel(a, b))
+        if name == "dgcnn" and who in ref_dev:  # ... and the deviation is isolated: the bulk of the entries agree
+            bad = (np.abs(a - b) > 2e-4 * np.abs(b).max()).mean()
             assert bad < 0.05, (who, float(bad))
 
     if name == "dgcnn":  # the HIP PointNet does not differentiate w.r.t. its input points (data)
