@@ -25,7 +25,7 @@ extern "C" {
 #define MPA_ELAUNCH (-2) /* hipGetLastError() reported a launch failure */
 
 /* ABI version of this header; bumped whenever a signature changes. */
-#define MPA_ABI_VERSION 3
+#define MPA_ABI_VERSION 4
 int mpa_abi_version(void);
 
 /* Thread-local, NUL-terminated description of the last failure on this thread ("" if none). */
@@ -277,14 +277,19 @@ int mpa_dgcnn_backward(const float* grad_feat, const float* const* conv_w, const
 
 /* kNN graph with the pinned arithmetic, as used inside mpa_dgcnn_forward — replaces `knn`
  * (multi_part_assembly/models/modules/encoder/dgcnn.py:8-15) for n clouds of N points (20 <= N <= 1024), k = 20.
- * x [n*N, ld] row-major point features, the first C columns are used (C = 3: ld = 4 with a zero pad column; C = 64 /
- * 128: any ld >= C, a multiple of 4).  idx [n*N, 20] int32, best first.
+ * x [n*N, ld] row-major point features (16-byte aligned), the first C columns are used (C = 3: ld = 4 with a zero pad
+ * column; C = 64 / 128: any ld >= C, a multiple of 4).  idx [n*N, 20] int32, best first.
  *   C = 3:    dot = fma(x2,y2, fma(x1,y1, x0*y0)), |x|^2 = (x0*x0 + x1*x1) + x2*x2 — the reference's CPU arithmetic,
  *             bit for bit (torch matmul + torch.sum on the fixture cloud);
  *   C >= 64:  dot = fmaf chain over k in the order 0, C/2, 1, C/2+1, ... (the matrix-core chain), |x|^2 likewise;
  *   score = (-|x_j|^2 + 2 dot) - |x_i|^2, every operation rounded to fp32; neighbours = the 20 best by (score
- *   descending, index ascending).  `ws`: n*N + 4 floats of scratch (a device-side header + the row norms). */
-int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, int64_t C, float* ws, int32_t* idx,
+ *   descending, index ascending).  On the reference's own stage inputs this selects exactly the reference's neighbour
+ *   sets (tests/golden/dgcnn_graphs.npz).
+ * C >= 64 runs as a shortlist search (csrc/dg_knn_fast.h): bf16 matrix-core Gram tiles with a proven error bound select
+ * ~21 of the N candidates per point, only those get the pinned fp32 score — same indices as the exhaustive scan, bit for
+ * bit.  `ws`: mpa_knn_exact_workspace(n, N) bytes of scratch, 256-byte aligned. */
+int mpa_knn_exact_workspace(int64_t n, int64_t N, int64_t* bytes);
+int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, int64_t C, void* ws, int32_t* idx,
                   void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -58,6 +58,7 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_dgcnn_forward_graphs": (_INT, [_P] * 9 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
     "mpa_dgcnn_export_graph": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P]),
     "mpa_dgcnn_backward": (_INT, [_P] * 4 + [_I64, _I64, _I64] + [_P] * 8),
+    "mpa_knn_exact_workspace": (_INT, [_I64, _I64, _P]),
     "mpa_knn_exact": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_mlp_layer_workspace": (_INT, [_I64, _I64, _I64, _P]),
     "mpa_mlp_layer_forward": (_INT, [_P, _I64, _P, _P, _P, _P, _P, _P, _INT, _F32, _F32, _INT, _I64, _I64, _I64, _P, _P, _P]),
@@ -77,7 +78,7 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_grad_clip_coef": (_INT, [_P, _I64, _F32, _P, _F32, _P, _P, _P]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

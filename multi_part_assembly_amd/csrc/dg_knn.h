@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
 template <int C, typename IdxT, int MODE = 0>
 __global__ __launch_bounds__(256, C > 64 ? 2 : DG_BPC64) void knn_mfma_kernel(const float* __restrict__ x, int ld,
                                                           const float* __restrict__ norm, int N,
-                                                          IdxT* __restrict__ idx, const int* __restrict__ hdr) {
+                                                          IdxT* __restrict__ idx, const int* __restrict__ hdr,
+                                                          const int* __restrict__ flags = nullptr) {
   constexpr int KH = C / 2, LD = C + 4, T4 = 32 * C / 4 / 256;  // float4 per thread and candidate tile
   constexpr int QN = C > 64 ? DG_QN128 : DG_QN64;  // the blocks of a CU must fit in its 160 KB of LDS
   constexpr int GPC = C > 64 ? DG_GPC128 : DG_GPC64;
@@ -271,6 +272,8 @@ __global__ __launch_bounds__(256, C > 64 ? 2 : DG_BPC64) void knn_mfma_kernel(co
   int v, qb;
   knn_block(v, qb);
   if (v >= hdr[0]) return;
+  // as the safety net of the shortlist search (dg_knn_fast.h): only the 128-query blocks it flagged are recomputed
+  if (flags != nullptr && flags[v * (int)gridDim.x + qb] == 0) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const float* xp = x + (long long)v * N * ld;
   const float* np_ = norm + (long long)v * N;

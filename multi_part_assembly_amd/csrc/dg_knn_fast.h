@@ -1,0 +1,432 @@
+// k-nearest-neighbour graph in 64 / 128-d feature space at the bf16 matrix-core rate, with the pinned result — gfx950.
+//
+// dg_knn.h computes every candidate score exactly (fp32 MFMA chain, 1/16 of the bf16 rate) and keeps a sorted list of
+// 20 per lane: 0.87 / 1.46 ms per stage at 353 x 1000 points.  Here the exact arithmetic is spent only on a SHORTLIST:
+//
+//   split   x = hi + lo + r, hi = bf16(x), lo = bf16(x - hi)  (|r| <= 2^-16 |x|), row norms n_j in the pinned chain order
+//   BOUND   (knn_bound_kernel)   Gram tiles  a^ = hi.hi + hi.lo + lo.hi  on v_mfma_f32_32x32x16_bf16 (3 products: 16/3 of
+//           the fp32-MFMA rate).  |score(i,j) - (2 a^ - n_j - n_i)| <= kappa (n_i + n_j)  [derivation below], so
+//               lower(i,j) = 2 a^ - (1 + kappa) n_j - (1 + kappa) n_i  <=  score(i,j)  <=  upper(i,j) = 2 a^ - (1 - kappa)(n_j + n_i).
+//           No list: every lane keeps the running MAXIMUM of `lower` per accumulator slot — 32 disjoint candidate groups
+//           per query (16 slots x 2 lane halves).  The 20th largest of the 32 group maxima, tau_i, is a lower bound of
+//           the true 20th best score T_i (20 distinct candidates reach it).  2 VALU operations per candidate.
+//   COLLECT (knn_collect_kernel) the same Gram tiles again; a candidate survives iff upper(i,j) >= tau_i.  Every true
+//           neighbour survives (upper >= score >= T_i >= tau_i), ties included; typically 30-35 of 1000 do.  Survivor
+//           indices go to a per-lane list in LDS, then to HBM.
+//   RERANK  (knn_rerank_kernel)  the pinned score — fmaf chain in the matrix-core order, exactly dg_knn.h's / the
+//           oracle's arithmetic — of the survivors only, and the 20 best by (score descending, index ascending).
+//   A query whose survivor list overflows (mass ties: duplicated points, lattices) flags its 128-query block; the
+//   exhaustive kernel of dg_knn.h then recomputes exactly the flagged blocks (it exits at once elsewhere).
+// Result: bit-identical indices to dg_knn.h on every input (tests/test_dgcnn_gpu.py: index-exact against oracle/knn_ref.c
+// and against the reference's own graphs).
+//
+// kappa.  With |x - hi| <= 2^-8 |x| (bf16 keeps 8 significant bits, round to nearest even), |lo| <= 2^-8 (1 + 2^-8) |x|,
+// |r| <= 2^-16 |x|:  x.y - (hi.hi + hi.lo + lo.hi) = lo.lo + (hi + lo).r_y + r_x.y, at most 3.02 * 2^-16 sum_k |x_k y_k|.
+// The bf16 products are exact in fp32; their 3C-term accumulation inside the matrix core is charged 2^-23 per term (twice
+// round-to-nearest, the internal order is not documented): 3C * 2^-23 * 1.01 sum_k |x_k y_k|.  The pinned fp32 chain is
+// within C * 2^-24 sum_k |x_k y_k| of the true dot product.  sum_k |x_k y_k| <= sqrt(N_i N_j) <= (N_i + N_j) / 2 with
+// N = |x|^2 <= n (1 + C 2^-24).  Forming the score rounds twice: <= 5.02 * 2^-24 (n_i + n_j).  Together, per unit of
+// (n_i + n_j):  C = 64: 7.3e-5, C = 128: 9.9e-5; the fp32 evaluation of lower / upper themselves adds 3 * 2^-24 and the
+// scaled norms one rounding each.  kappa = 8.5e-5 (C = 64), 1.15e-4 (C = 128) covers all of it with > 10 % to spare.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "dg_knn.h"
+
+namespace dg {
+
+typedef __bf16 kf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 kf_bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int C>
+struct KnnFast {
+  static constexpr float kappa = C > 64 ? 1.15e-4f : 8.5e-5f;
+};
+
+constexpr int kKfCap = 24;     // survivor slots per (query, lane half); the expected load is ~10.5 (an overflow — about
+                               // one list in 10^4 — only costs the exhaustive recomputation of its 128-query block)
+constexpr int kKfQB = 256;     // queries per block of the bound / collect kernels (4 waves x 2 sets of 32)
+
+__device__ __forceinline__ float next_float(float x) { return -prev_float(-x); }
+
+// ---- split: x -> (hi | lo) bf16 rows, scaled norms ----------------------------------------------------------------------
+// x [R][ld] (first C columns), norm [R] (rownorm_kernel), xs [R][2C] bf16 = hi(0..C-1) | lo(0..C-1), nl / nu [R].
+// One thread per 4 elements.  grid = ceil(Rmax * C / 4 / 256).
+template <int C>
+__global__ __launch_bounds__(256) void knn_split_kernel(const float* __restrict__ x, int ld, const float* __restrict__ norm,
+                                                        unsigned short* __restrict__ xs, float* __restrict__ nl,
+                                                        float* __restrict__ nu, const int* __restrict__ hdr) {
+  const long long R = hdr[1];
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long r = t / (C / 4);
+  if (r >= R) return;
+  const int c4 = (int)(t % (C / 4));
+  const float4 v = *reinterpret_cast<const float4*>(x + r * ld + 4 * c4);
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  kf_bf16x4 hi, lo;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    hi[u] = (__bf16)f[u];
+    lo[u] = (__bf16)(f[u] - (float)hi[u]);
+  }
+  unsigned short* row = xs + r * (2 * C);
+  *reinterpret_cast<kf_bf16x4*>(row + 4 * c4) = hi;
+  *reinterpret_cast<kf_bf16x4*>(row + C + 4 * c4) = lo;
+  if (c4 == 0) {
+    const float n = norm[r], k = KnnFast<C>::kappa;
+    nl[r] = next_float(__builtin_fmaf(n, k, n));
+    nu[r] = prev_float(__builtin_fmaf(n, -k, n));
+  }
+}
+
+// ---- shared Gram-tile machinery of the bound / collect kernels ------------------------------------------------------------
+// Block = WAVES waves handling 256 queries; a wave owns SETS sets of 32 queries (B operands hi / lo, register-resident:
+// SETS * C / 2 VGPRs); candidate tiles of 32 rows (hi | lo, 4C bytes per row) go through a double-buffered LDS panel
+// shared by the waves.  Accumulator layout as in dg_knn.h: lane (j, h) holds, for query j of a set, the candidates
+// acc_row(r, h).  (C = 128 with two sets per wave needs more than 256 registers: it runs 8 waves x 1 set.)
+template <int C>
+struct KfTile {
+  static constexpr int ROWB = 4 * C + 16;          // LDS row stride in bytes (odd multiple of 16: conflict-free b128 reads)
+  static constexpr int KS = C / 16;                // MFMA k-steps
+};
+
+// a < b as sorted pairs: sort two registers descending
+#define KF_CEX(x0, x1)                                  \
+  do {                                                  \
+    const float lo_ = __builtin_fminf(x0, x1);          \
+    x0 = __builtin_fmaxf(x0, x1);                       \
+    x1 = lo_;                                           \
+  } while (0)
+
+// Batcher's odd-even merge sort of 2^k register keys, descending (fully unrolled: constant indices only)
+template <int NKEYS>
+__device__ __forceinline__ void kf_sort_desc(float* a) {
+#pragma unroll
+  for (int p = 1; p < NKEYS; p <<= 1)
+#pragma unroll
+    for (int k = p; k >= 1; k >>= 1)
+#pragma unroll
+      for (int jj = k % p; jj + k < NKEYS; jj += 2 * k)
+#pragma unroll
+        for (int i = 0; i < k; ++i)
+          if (i + jj + k < NKEYS && (i + jj) / (2 * p) == (i + jj + k) / (2 * p)) KF_CEX(a[i + jj], a[i + jj + k]);
+}
+
+// MODE (timing probes only, tools/probes/knn_fast.hip): 0 = the real kernel; 1 = no per-candidate epilogue; 2 = no staging
+// after the first tile (no loads, no barriers); 3 = both.
+template <int C, bool COLLECT, int SETS, int WAVES, int MODE = 0>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void knn_gram_kernel(
+    const unsigned short* __restrict__ xs, const float* __restrict__ nsc, const float* __restrict__ nl,
+    const float* __restrict__ nu, int N, float* __restrict__ theta, unsigned short* __restrict__ surv,
+    unsigned char* __restrict__ scnt, int* __restrict__ flags, const int* __restrict__ hdr) {
+  using TL = KfTile<C>;
+  static_assert(SETS * WAVES * 32 == kKfQB, "a block handles 256 queries");
+  constexpr int KS = TL::KS, ROWB = TL::ROWB, NT = 64 * WAVES;
+  constexpr int CPR = 4 * C / 16;            // 16-byte chunks per row
+  constexpr int CH = 32 * CPR / NT;          // chunks per thread and tile
+  static_assert(CH >= 1 && 32 * CPR % NT == 0, "staging layout");
+  __shared__ __attribute__((aligned(16))) unsigned char tile[2][32 * ROWB];
+  __shared__ __attribute__((aligned(16))) float tn[2][32];
+  __shared__ unsigned short lst[COLLECT ? WAVES * SETS * kKfCap * 64 : 1];
+  int v, qb;
+  knn_block(v, qb);
+  if (v >= hdr[0]) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const unsigned short* xp = xs + (long long)v * N * (2 * C);
+  const float* np_ = nsc + (long long)v * N;   // the scaled candidate norms this pass uses (nl: bound, nu: collect)
+  const int q0 = qb * kKfQB + wave * (32 * SETS);
+  // query operands: hi / lo fragments of the k-steps
+  kf_bf16x8 bh[SETS][KS], bl[SETS][KS];
+  float thr[SETS];
+#pragma unroll
+  for (int s = 0; s < SETS; ++s) {
+    const int qrow = q0 + 32 * s + j < N ? q0 + 32 * s + j : N - 1;
+    const unsigned short* src = xp + (long long)qrow * (2 * C) + 8 * h;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      bh[s][kk] = *reinterpret_cast<const kf_bf16x8*>(src + 16 * kk);
+      bl[s][kk] = *reinterpret_cast<const kf_bf16x8*>(src + C + 16 * kk);
+    }
+    // (a threshold of -inf would let the -inf scores of the rows past N through: clamp)
+    thr[s] = COLLECT ? __builtin_fmaxf(theta[(long long)v * N + qrow], -3.0e38f) : 0.0f;
+  }
+  // bound pass: the two largest `lower` values per accumulator slot (= per candidate group)
+  float g1[SETS][16], g2[SETS][16];
+  int cnt[SETS];
+#pragma unroll
+  for (int s = 0; s < SETS; ++s) {
+    cnt[s] = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g1[s][r] = g2[s][r] = (MODE & 1) ? 0.0f : -__builtin_inff();
+  }
+  unsigned short* mylst = lst + (COLLECT ? wave * SETS * kKfCap * 64 : 0);
+  // staged chunks as named registers (an indexed uint4 array ends up in scratch memory and every load is waited for at once)
+  static_assert(CH == 1 || CH == 2 || CH == 4, "staging layout");
+  uint4 raw0, raw1 = {}, raw2 = {}, raw3 = {};
+  float rn = 0.0f;
+  // rows past N: any valid row (unconditional loads: a select makes the compiler wait for the load right away); their
+  // scaled norm is +inf: lower = -inf (bound pass), upper = -inf (collect pass): never selected
+#define KF_SRC(t, i) \
+  (xp + (long long)((t) * 32 + (threadIdx.x + NT * (i)) / CPR < N ? (t) * 32 + (threadIdx.x + NT * (i)) / CPR : N - 1) * (2 * C) + \
+   8 * ((threadIdx.x + NT * (i)) % CPR))
+#define KF_FETCH(t)                                                                   \
+  do {                                                                                \
+    raw0 = *reinterpret_cast<const uint4*>(KF_SRC(t, 0));                             \
+    if constexpr (CH > 1) raw1 = *reinterpret_cast<const uint4*>(KF_SRC(t, 1));       \
+    if constexpr (CH > 2) {                                                           \
+      raw2 = *reinterpret_cast<const uint4*>(KF_SRC(t, 2));                           \
+      raw3 = *reinterpret_cast<const uint4*>(KF_SRC(t, 3));                           \
+    }                                                                                 \
+    if (wave == 0 && lane < 32) {                                                     \
+      const int row_ = (t) * 32 + lane;                                               \
+      const float nv_ = np_[row_ < N ? row_ : N - 1];                                 \
+      rn = row_ < N ? nv_ : __builtin_inff();                                         \
+    }                                                                                 \
+  } while (0)
+#define KF_DST(buf, i) (&tile[buf][((threadIdx.x + NT * (i)) / CPR) * ROWB + 16 * ((threadIdx.x + NT * (i)) % CPR)])
+#define KF_STASH(buf)                                                                 \
+  do {                                                                                \
+    *reinterpret_cast<uint4*>(KF_DST(buf, 0)) = raw0;                                 \
+    if constexpr (CH > 1) *reinterpret_cast<uint4*>(KF_DST(buf, 1)) = raw1;           \
+    if constexpr (CH > 2) {                                                           \
+      *reinterpret_cast<uint4*>(KF_DST(buf, 2)) = raw2;                               \
+      *reinterpret_cast<uint4*>(KF_DST(buf, 3)) = raw3;                               \
+    }                                                                                 \
+    if (wave == 0 && lane < 32) tn[buf][lane] = rn;                                   \
+  } while (0)
+  const int tiles = (N + 31) / 32;
+  KF_FETCH(0);
+  for (int t = 0; t < tiles; ++t) {
+    const int buf = (MODE & 2) ? 0 : (t & 1);
+    if (!(MODE & 2) || t == 0) {
+      KF_STASH(buf);
+      __syncthreads();
+      if (t + 1 < tiles) KF_FETCH(t + 1);
+    }
+    const unsigned char* arow = &tile[buf][j * ROWB + 16 * h];
+    f32x16 acc[SETS];
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) acc[s] = f32x16{0};
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const kf_bf16x8 ah = *reinterpret_cast<const kf_bf16x8*>(arow + 32 * kk);
+      const kf_bf16x8 al = *reinterpret_cast<const kf_bf16x8*>(arow + 2 * C + 32 * kk);
+#pragma unroll
+      for (int s = 0; s < SETS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s][kk], acc[s], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < SETS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s][kk], acc[s], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < SETS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s][kk], acc[s], 0, 0, 0);
+    }
+    if constexpr ((MODE & 1) != 0) {
+#pragma unroll
+      for (int s = 0; s < SETS; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g1[s][r] += acc[s][r];
+      continue;
+    }
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 n4 = *reinterpret_cast<const float4*>(&tn[buf][8 * g4 + 4 * h]);
+      const float cn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int s = 0; s < SETS; ++s) {
+          const float b = __builtin_fmaf(2.0f, acc[s][4 * g4 + u], -cn[u]);
+          if constexpr (!COLLECT) {
+            const float m = __builtin_fminf(b, g1[s][4 * g4 + u]);
+            g1[s][4 * g4 + u] = __builtin_fmaxf(b, g1[s][4 * g4 + u]);
+            g2[s][4 * g4 + u] = __builtin_fmaxf(m, g2[s][4 * g4 + u]);
+          } else {
+            if (b >= thr[s]) {
+              const int slot = cnt[s] < kKfCap ? cnt[s] : kKfCap - 1;  // clamped: an overflowing list is recomputed anyway
+              mylst[(s * kKfCap + slot) * 64 + lane] = (unsigned short)(t * 32 + 8 * g4 + 4 * h + u);
+              ++cnt[s];
+            }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (!COLLECT) {
+    // tau' = the 20th largest of the query's 64 recorded values (top two of 32 disjoint candidate groups: 64 distinct
+    // candidates): sort the lane's 32 (descending), fetch the partner half's, and take max over i of min(a_i, b_{20-i})
+    // (i-th largest of either list, i = 0..20, rank 0 = +inf).
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
+      float a[32];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        a[r] = g1[s][r];
+        a[16 + r] = g2[s][r];
+      }
+      kf_sort_desc<32>(a);
+      float o[20];
+#pragma unroll
+      for (int r = 0; r < 20; ++r) o[r] = __shfl_xor(a[r], 32, 64);
+      float kth = __builtin_fmaxf(a[19], o[19]);  // i = 20 (all from a) and i = 0 (all from o)
+#pragma unroll
+      for (int i = 1; i <= 19; ++i) kth = __builtin_fmaxf(kth, __builtin_fminf(a[i - 1], o[20 - i - 1]));
+      const int qi = q0 + 32 * s + j;
+      if (h == 0 && qi < N) {
+        // survive iff upper' = 2 a^ - nu_j >= tau' - nl_i + nu_i; every step rounded towards "keep more"
+        const long long row = (long long)v * N + qi;
+        const float d = next_float(nl[row] - nu[row]);
+        theta[row] = prev_float(kth - d);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
+      const int qi = q0 + 32 * s + j;
+      if (qi < N) {
+        const long long row = (long long)v * N + qi;
+        const int n = cnt[s] < kKfCap ? cnt[s] : kKfCap;
+        unsigned short* dst = surv + (row * 2 + h) * kKfCap;
+        for (int e = 0; e < n; ++e) dst[e] = mylst[(s * kKfCap + e) * 64 + lane];
+        scnt[row * 2 + h] = (unsigned char)n;
+        if (cnt[s] > kKfCap) flags[v * ((N + 127) / 128) + qi / 128] = 1;
+      }
+    }
+  }
+}
+
+// ---- rerank: pinned scores of the survivors, 20 best ------------------------------------------------------------------------
+// x [R][ld] fp32, norm [R]; surv / scnt from the collect pass; idx [R][20].  A block takes 16 consecutive queries of a
+// cloud and flattens their (query, survivor) PAIRS (~340) over its 64 QUADS of lanes.  The survivor rows are scattered:
+// with one row per lane a gather costs one vector-cache tag lookup per lane and instruction (0.30 / 0.56 ms measured),
+// and staging coalesced fetches through an LDS panel costs the occupancy that hides the latency (0.33 / 0.42 ms).  So
+// a quad owns a pair: its four lanes fetch one 64-byte run of the row per instruction (16 lookups per KB) and the pinned
+// chain walks THROUGH the quad — every lane applies its 4 + 4 columns to the running sum, a DPP quad broadcast hands
+// lane t's result to the next step (4x the fmaf instructions of a chain per lane, but no LDS, 40 registers, full
+// occupancy).  Every pair parks its order-preserving score bits; the quad then counts the pairs of its query that beat
+// it (score, then lower index; a quarter of them per lane) — its rank — and ranks below 20 write the output, best
+// first.  grid = (ceil(N / 16), DG_KNN_GRID_Y(parts)), block 256.
+constexpr int kRrQ = 16;  // queries per block
+__device__ __forceinline__ unsigned kf_ordered(float s) {  // monotone map float -> unsigned
+  const unsigned u = __float_as_uint(s);
+  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+template <int T>
+__device__ __forceinline__ float kf_quad_bcast(float x) {  // lane T of every quad -> the whole quad
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), T * 0x55, 0xf, 0xf, true));
+}
+__device__ __forceinline__ int kf_quad_sum(int x) {
+  x += __builtin_amdgcn_mov_dpp(x, 0xb1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_mov_dpp(x, 0x4e, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+  return x;
+}
+template <int C, typename IdxT>
+__global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict__ x, int ld, const float* __restrict__ norm,
+                                                         int N, const unsigned short* __restrict__ surv,
+                                                         const unsigned char* __restrict__ scnt, IdxT* __restrict__ idx,
+                                                         const int* __restrict__ hdr) {
+  constexpr int KH = C / 2, MAXS = 2 * kKfCap, SL = KH / 16;  // slices of 16 + 16 chain positions
+  __shared__ __attribute__((aligned(16))) float qrow[kRrQ][C + 4];
+  __shared__ float qnorm[kRrQ];
+  __shared__ int qoff[kRrQ + 1], qcnt[kRrQ];
+  __shared__ unsigned pq[kRrQ * MAXS];                 // pair -> query << 16 | survivor index
+  __shared__ unsigned skey[kRrQ * MAXS];               // pair -> ordered score bits
+  int v, qblk;
+  knn_block(v, qblk);  // all query blocks of a cloud on one XCD: its L2 holds the cloud's rows for every gather
+  if (v >= hdr[0]) return;
+  const float* xp = x + (long long)v * N * ld;
+  const float* np_ = norm + (long long)v * N;
+  const int qbase = qblk * kRrQ;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  for (int c = threadIdx.x; c < kRrQ * C / 4; c += 256) {
+    const int q = c / (C / 4), w = c % (C / 4);
+    const int qi = qbase + q < N ? qbase + q : N - 1;
+    *reinterpret_cast<float4*>(&qrow[q][4 * w]) = *reinterpret_cast<const float4*>(xp + (long long)qi * ld + 4 * w);
+  }
+  if (wave == 0) {  // survivor counts of the 16 queries and their exclusive prefix sums
+    const int q = lane & 15, qi = qbase + q;
+    const long long row = (long long)v * N + (qi < N ? qi : N - 1);
+    const int c = (lane < kRrQ && qi < N) ? scnt[row * 2] + scnt[row * 2 + 1] : 0;
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < kRrQ; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane < kRrQ) {
+      qcnt[q] = c;
+      qoff[q] = incl - c;
+      qnorm[q] = np_[qi < N ? qi : N - 1];
+      if (lane == kRrQ - 1) qoff[kRrQ] = incl;
+    }
+  }
+  __syncthreads();
+  {  // pair table: a quarter wave (16 lanes) per query
+    const int q = threadIdx.x >> 4, e0 = threadIdx.x & 15;
+    const int qi = qbase + q;
+    if (qi < N) {
+      const long long row = (long long)v * N + qi;
+      const int c0 = scnt[row * 2], cnt = qcnt[q], off = qoff[q];
+      for (int e = e0; e < cnt; e += 16) {
+        const unsigned cj = e < c0 ? surv[(row * 2) * kKfCap + e] : surv[(row * 2 + 1) * kKfCap + (e - c0)];
+        pq[off + e] = ((unsigned)q << 16) | cj;
+      }
+    }
+  }
+  __syncthreads();
+  const int total = qoff[kRrQ];
+  const int quad = threadIdx.x >> 2, ql = threadIdx.x & 3;
+  for (int p0 = 0; p0 < total; p0 += 64) {  // 64 pairs per round, one per quad
+    const int p = p0 + quad;
+    const bool live = p < total;
+    const unsigned rec = pq[live ? p : total - 1];
+    const int q = (int)(rec >> 16), cj = (int)(rec & 0xffffu);
+    const float* row_lo = xp + (long long)cj * ld + 4 * ql;
+    float4 a[SL], c[SL];
+#pragma unroll
+    for (int r = 0; r < SL; ++r) {
+      a[r] = *reinterpret_cast<const float4*>(row_lo + 16 * r);
+      c[r] = *reinterpret_cast<const float4*>(row_lo + KH + 16 * r);
+    }
+    const float cn = np_[cj];
+    float acc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < SL; ++r) {
+      const float4 pp = *reinterpret_cast<const float4*>(&qrow[q][16 * r + 4 * ql]);
+      const float4 rr = *reinterpret_cast<const float4*>(&qrow[q][KH + 16 * r + 4 * ql]);
+      auto step = [&](float in) {  // chain order s, C/2+s, s+1, C/2+s+1, ... over this lane's 4 + 4 columns
+        in = __builtin_fmaf(a[r].x, pp.x, in);
+        in = __builtin_fmaf(c[r].x, rr.x, in);
+        in = __builtin_fmaf(a[r].y, pp.y, in);
+        in = __builtin_fmaf(c[r].y, rr.y, in);
+        in = __builtin_fmaf(a[r].z, pp.z, in);
+        in = __builtin_fmaf(c[r].z, rr.z, in);
+        in = __builtin_fmaf(a[r].w, pp.w, in);
+        in = __builtin_fmaf(c[r].w, rr.w, in);
+        return in;
+      };
+      acc = kf_quad_bcast<0>(step(acc));
+      acc = kf_quad_bcast<1>(step(acc));
+      acc = kf_quad_bcast<2>(step(acc));
+      acc = kf_quad_bcast<3>(step(acc));
+    }
+    if (live && ql == 0) skey[p] = kf_ordered((-cn + 2.0f * acc) - qnorm[q]);
+  }
+  __syncthreads();
+  for (int p0 = 0; p0 < total; p0 += 64) {
+    const int p = p0 + quad;
+    if (p >= total) break;
+    const unsigned rec = pq[p];
+    const int q = (int)(rec >> 16);
+    const int off = qoff[q], cnt = qcnt[q];
+    const unsigned ms = skey[p], mj = rec & 0xffffu;
+    int rank = 0;
+    for (int m = ql; m < cnt; m += 4) {
+      const unsigned os = skey[off + m], oj = pq[off + m] & 0xffffu;
+      rank += (os > ms || (os == ms && oj < mj)) ? 1 : 0;
+    }
+    rank = kf_quad_sum(rank);
+    // (cnt < 20 cannot happen for a non-overflowing query; flagged blocks are recomputed by the exhaustive kernel)
+    if (ql == 0 && cnt >= kNbr && rank < kNbr) idx[((long long)v * N + qbase + q) * kNbr + rank] = (IdxT)mj;
+  }
+}
+
+}  // namespace dg

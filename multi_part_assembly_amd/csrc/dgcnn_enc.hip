@@ -28,6 +28,7 @@
 #include "coop_reduce.h"
 #include "dg_gemm.h"
 #include "dg_knn.h"
+#include "dg_knn_fast.h"
 
 namespace {
 
@@ -877,6 +878,55 @@ __global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict
 }
 
 // ---- workspace ----------------------------------------------------------------------------------------------------------------
+// scratch of the shortlist kNN search (dg_knn_fast.h) for clouds of N points, R rows in total, width <= 128
+struct KnnWs {
+  unsigned short *xs, *surv;
+  float *nl, *nu, *theta;
+  unsigned char* scnt;
+  int* flags;
+};
+
+template <typename Take>
+KnnWs knn_carve(Take&& take, int64_t M, int64_t N) {
+  KnnWs k;
+  const int64_t R = M * N;
+  k.xs = reinterpret_cast<unsigned short*>(take(2 * R * 2 * 128));
+  k.surv = reinterpret_cast<unsigned short*>(take(2 * R * 2 * kKfCap));
+  k.nl = reinterpret_cast<float*>(take(4 * R));
+  k.nu = reinterpret_cast<float*>(take(4 * R));
+  k.theta = reinterpret_cast<float*>(take(4 * R));
+  k.scnt = reinterpret_cast<unsigned char*>(take(2 * R));
+  k.flags = reinterpret_cast<int*>(take(4 * (M + 8) * ((N + 127) / 128)));
+  return k;
+}
+
+// kNN graph of n (<= M: launch bound) clouds in C = 64 / 128-d feature space: row norms, bf16 split, bound pass, collect
+// pass, exact rerank of the survivors, and the exhaustive search of the (rare) flagged 128-query blocks.  Bit-identical
+// to knn_mfma_kernel alone (which is what this build ran before; 0.93 / 1.55 ms vs 0.55 / 0.85 ms at 353 x 1000).
+template <int C, typename IdxT>
+void knn_wide(const float* x, int ld, float* norm, const KnnWs& k, int64_t M, int64_t N, IdxT* idx, const int* hdr,
+              hipStream_t s) {
+  const int64_t R = M * N;
+  constexpr int SETS = 1, WAVES = 8;
+  const dim3 ggram((unsigned)((N + kKfQB - 1) / kKfQB), DG_KNN_GRID_Y(M));
+  const int64_t nflags = (M + 8) * ((N + 127) / 128);
+  hipLaunchKernelGGL(rownorm_kernel<C>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, x, ld, norm, hdr);
+  hipLaunchKernelGGL(knn_split_kernel<C>, dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, x, ld,
+                     (const float*)norm, k.xs, k.nl, k.nu, hdr);
+  hipLaunchKernelGGL((knn_gram_kernel<C, false, SETS, WAVES>), ggram, dim3(64 * WAVES), 0, s, (const unsigned short*)k.xs,
+                     (const float*)k.nl, (const float*)k.nl, (const float*)k.nu, (int)N, k.theta, k.surv, k.scnt, k.flags,
+                     hdr);
+  mpa::zero_words_async(k.flags, nflags, s);
+  hipLaunchKernelGGL((knn_gram_kernel<C, true, SETS, WAVES>), ggram, dim3(64 * WAVES), 0, s, (const unsigned short*)k.xs,
+                     (const float*)k.nu, (const float*)k.nl, (const float*)k.nu, (int)N, k.theta, k.surv, k.scnt, k.flags,
+                     hdr);
+  hipLaunchKernelGGL((knn_rerank_kernel<C, IdxT>), dim3((unsigned)((N + kRrQ - 1) / kRrQ), DG_KNN_GRID_Y(M)), dim3(256), 0,
+                     s, x, ld, (const float*)norm, (int)N, (const unsigned short*)k.surv, (const unsigned char*)k.scnt, idx,
+                     hdr);
+  hipLaunchKernelGGL((knn_mfma_kernel<C, IdxT>), dim3((unsigned)((N + 127) / 128), DG_KNN_GRID_Y(M)), dim3(256), 0, s, x,
+                     ld, (const float*)norm, (int)N, idx, hdr, (const int*)k.flags);
+}
+
 struct Ws {
   int *hdr, *vlist, *rank, *arg5, *rptr, *order;
   unsigned* tickets;
@@ -886,6 +936,7 @@ struct Ws {
   unsigned short *idx[4], *rlist;
   unsigned char* ssel[4];
   double* stage;
+  KnnWs knn;
   int64_t total;
 };
 
@@ -937,6 +988,7 @@ Ws dg_carve(char* base, int64_t M, int64_t N, int64_t F) {
   w.order = reinterpret_cast<int*>(take(4 * M * N));
   w.rlist = reinterpret_cast<unsigned short*>(take(2 * R * kNbr));
   w.stage = reinterpret_cast<double*>(take(8 * 2 * kCat * ((prow + kEB - 1) / kEB)));
+  w.knn = knn_carve(take, M, N);
   w.total = p - base;
   return w;
 }
@@ -1037,16 +1089,8 @@ int dgcnn_forward_impl(const float* points, const float* valids, const float* co
              reinterpret_cast<const float*>(w.x0), (int)N, w.idx[0], (const int*)w.hdr);
     } else {
       const float* x = w.hcat + kOff[l - 1];
-      const dim3 g((unsigned)((N + 127) / 128), DG_KNN_GRID_Y(M));
-      if (C == 64) {
-        launch(rownorm_kernel<64>, dim3((unsigned)((R + 255) / 256)), dim3(256), s, x, kCat, w.norm, (const int*)w.hdr);
-        launch(knn_mfma_kernel<64, unsigned short>, g, dim3(256), s, x, kCat, (const float*)w.norm, (int)N, w.idx[l],
-               (const int*)w.hdr);
-      } else {
-        launch(rownorm_kernel<128>, dim3((unsigned)((R + 255) / 256)), dim3(256), s, x, kCat, w.norm, (const int*)w.hdr);
-        launch(knn_mfma_kernel<128, unsigned short>, g, dim3(256), s, x, kCat, (const float*)w.norm, (int)N, w.idx[l],
-               (const int*)w.hdr);
-      }
+      if (C == 64) knn_wide<64, unsigned short>(x, kCat, w.norm, w.knn, M, N, w.idx[l], (const int*)w.hdr, s);
+      else knn_wide<128, unsigned short>(x, kCat, w.norm, w.knn, M, N, w.idx[l], (const int*)w.hdr, s);
     }
     record(events, 2 * l + 1, s);
     // [U | V] = X . [Wa ; Wb - Wa]^T
@@ -1190,7 +1234,37 @@ __global__ void dg_set_hdr_kernel(int* hdr, int n, int N) {
 }
 }  // namespace
 
-extern "C" int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, int64_t C, float* ws, int32_t* idx,
+namespace {
+struct KnnExactWs {
+  int* hdr;
+  float* norm;
+  KnnWs knn;
+  int64_t total;
+};
+KnnExactWs knn_exact_carve(char* base, int64_t n, int64_t N) {
+  KnnExactWs w;
+  char* p = base;
+  auto take = [&](int64_t bytes) {
+    char* r = p;
+    p += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  w.hdr = reinterpret_cast<int*>(take(64));
+  w.norm = reinterpret_cast<float*>(take(4 * n * N));
+  w.knn = knn_carve(take, n, N);
+  w.total = p - base;
+  return w;
+}
+}  // namespace
+
+extern "C" int mpa_knn_exact_workspace(int64_t n, int64_t N, int64_t* bytes) {
+  MPA_REQUIRE(n >= 0 && n <= 65528 && N >= kNbr && N <= kMaxN, "knn_exact_workspace: %d <= N <= %d, n <= 65528", kNbr, kMaxN);
+  MPA_REQUIRE(bytes != nullptr, "knn_exact_workspace: null pointer");
+  *bytes = knn_exact_carve(nullptr, n, N).total;
+  return MPA_OK;
+}
+
+extern "C" int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, int64_t C, void* ws, int32_t* idx,
                              void* stream) {
   MPA_REQUIRE(n >= 0 && n <= 65528 && N >= kNbr && N <= kMaxN, "knn_exact: %d <= N <= %d, n <= 65528", kNbr, kMaxN);
   MPA_REQUIRE(C == 3 || C == 64 || C == 128, "knn_exact: feature width must be 3, 64 or 128");
@@ -1198,22 +1272,17 @@ extern "C" int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, i
   MPA_REQUIRE(C != 3 || ld == 4, "knn_exact: C = 3 takes [n*N, 4] rows (x, y, z, 0)");
   if (n == 0) return MPA_OK;
   MPA_REQUIRE(x && idx && ws, "knn_exact: null pointer");
+  MPA_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)x % 16 == 0, "knn_exact: workspace 256-byte, x 16-byte aligned");
   hipStream_t s = mpa::as_stream(stream);
-  int* hdr = reinterpret_cast<int*>(ws);  // {n, n*N}: every cloud is valid here
-  float* norm = ws + 4;
-  const int64_t R = n * N;
-  launch(dg_set_hdr_kernel, dim3(1), dim3(1), s, hdr, (int)n, (int)N);
+  const KnnExactWs w = knn_exact_carve(static_cast<char*>(ws), n, N);  // hdr = {n, n*N}: every cloud is valid here
+  launch(dg_set_hdr_kernel, dim3(1), dim3(1), s, w.hdr, (int)n, (int)N);
   if (C == 3) {
     launch(knn3_kernel<int>, dim3((unsigned)((N + 255) / 256), DG_KNN_GRID_Y(n)), dim3(256), s, x, (int)N, idx,
-           (const int*)hdr);
+           (const int*)w.hdr);
   } else if (C == 64) {
-    launch(rownorm_kernel<64>, dim3((unsigned)((R + 255) / 256)), dim3(256), s, x, (int)ld, norm, (const int*)hdr);
-    launch(knn_mfma_kernel<64, int>, dim3((unsigned)((N + 127) / 128), DG_KNN_GRID_Y(n)), dim3(256), s, x, (int)ld,
-           (const float*)norm, (int)N, idx, (const int*)hdr);
+    knn_wide<64, int>(x, (int)ld, w.norm, w.knn, n, N, idx, (const int*)w.hdr, s);
   } else {
-    launch(rownorm_kernel<128>, dim3((unsigned)((R + 255) / 256)), dim3(256), s, x, (int)ld, norm, (const int*)hdr);
-    launch(knn_mfma_kernel<128, int>, dim3((unsigned)((N + 127) / 128), DG_KNN_GRID_Y(n)), dim3(256), s, x, (int)ld,
-           (const float*)norm, (int)N, idx, (const int*)hdr);
+    knn_wide<128, int>(x, (int)ld, w.norm, w.knn, n, N, idx, (const int*)w.hdr, s);
   }
   return mpa::check_launch("knn_exact");
 }

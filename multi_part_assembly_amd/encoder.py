@@ -185,7 +185,9 @@ def knn_exact(x, n, N, C=None):
     R, ld = x.shape
     C = (3 if ld == 4 else ld) if C is None else C
     idx = torch.empty((R, 20), dtype=torch.int32, device=x.device)
-    ws = torch.empty(R + 4, dtype=torch.float32, device=x.device)
+    nbytes = ctypes.c_int64()
+    _lib.check(_lib.lib().mpa_knn_exact_workspace(n, N, ctypes.byref(nbytes)), "mpa_knn_exact_workspace")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         st = _lib.lib().mpa_knn_exact(_lib.ptr(x), ld, n, N, C, _lib.ptr(ws), _lib.ptr(idx), _lib.current_stream(x.device))
     _lib.check(st, "mpa_knn_exact")
