@@ -25,7 +25,11 @@ loss; c3/c5: the kNN graph kernel of the DGCNN encoder — timed per launch with
 around it on its launch stream inside the timed region.  It carries the mandated HBM comparison (algorithmic bytes of
 SURVEY.md §8d per launch / time / 8 TB/s) AND the bound that actually binds (`binding`), plus a per-kernel table
 (`kernel_table`) with MFMA / VALU / HBM fractions of the other large kernels.  `cpu_baseline` is the oracle's
-reference-equivalent PyTorch-CPU step timed on this host (rank 0, N = 1, c2 only) on a bounded sample.
+reference-equivalent PyTorch-CPU step of the SAME workload timed on this host (rank 0, N = 1) on a bounded sample: c1 at
+full size, c2 / c4 at B = 4, c3 at B = 2 (scaled linearly in B, labelled), on all physical cores and on one thread.
+With several ranks the line carries `collectives`: bytes of each gradient bucket, its stand-alone all-reduce time, the step
+time without any collective, and the fraction of the collective time that backward hid (`overlap_frac`).
+`--self-check N` appends N more timed steps and reports whether the K-step mean holds over them.
 """
 from __future__ import annotations
 
@@ -46,6 +50,7 @@ BATCH, PARTS, POINTS = 32, 20, 1000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_LANE_OPS = 78.6e12   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (non-packed fp32 VALU issue)
 MFMA_F32_PEAK = 157.3e12       # 256 CU x 4 SIMD x 64 FLOP/cycle x 2.4 GHz (v_mfma_f32_32x32x2_f32, dense)
+MFMA_BF16_PEAK = 2.5e15        # dense bf16 (MI355X_MICROARCH.md; 1.75-1.9e15 sustained: tools/probes/mfma_rate.hip)
 
 
 CONFIG_ALIASES = {"global_partnet": "c1", "pn_transformer": "c2", "dgl_dgcnn": "c3", "pn_transformer_dp8": "c4",
@@ -62,7 +67,10 @@ def parse_args():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (default: eager launches; see trainer.py)")
     ap.add_argument("--eager", action="store_true", help="(the default; accepted for symmetry)")
-    ap.add_argument("--cpu-batch", type=int, default=4, help="samples in the CPU-baseline step")
+    ap.add_argument("--cpu-batch", type=int, default=0,
+                    help="samples in the CPU-baseline step (0: the workload's default: c1 4 = full size, c2/c4 4, c3 2)")
+    ap.add_argument("--self-check", type=int, default=0, metavar="N",
+                    help="after the K timed steps, time N more (same protocol) and report the ratio of the two means")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16: the separately named PERFORMANCE VARIANT of the PointNet encoder (csrc/pointnet_bf16.hip: "
                          "bf16 activations and matrix-core GEMMs, fp32 statistics; transformer, pose head, losses and "
@@ -129,39 +137,80 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(cpu_batch, dev):
-    """Reference-equivalent CPU training step (oracle/nets.py + oracle/chamfer_ref.c) on a bounded sample of the c2
-    workload: the SAME synthetic generator and seed as the GPU run (synthetic.make_batch, seed 1234) at B = cpu_batch
-    instead of 32 (cost is linear in B), all cores: 3 warm-up + 5 timed steps; one thread: 1 warm-up + 2 timed steps at
-    B = 2."""
+def physical_cores():
+    """Distinct (package, core) pairs among the CPUs this process may run on; falls back to the visible count."""
+    allowed = os.sched_getaffinity(0)
+    try:
+        seen, cur = set(), {}
+        for line in Path("/proc/cpuinfo").read_text().splitlines() + [""]:
+            if not line.strip():
+                if "processor" in cur and int(cur["processor"]) in allowed:
+                    seen.add((cur.get("physical id", "0"), cur.get("core id", cur["processor"])))
+                cur = {}
+            elif ":" in line:
+                k, v = line.split(":", 1)
+                cur[k.strip()] = v.strip()
+        if seen:
+            return len(seen)
+    except (OSError, ValueError):
+        pass
+    return len(allowed)
+
+
+def cpu_baseline(name, cpu_batch, dev):
+    """Reference-equivalent CPU training step (oracle/nets.py, oracle/callers.py + oracle/chamfer_ref.c) on a bounded
+    sample of the workload `name`: the SAME synthetic generator and seed as the GPU run at B = cpu_batch (cost is linear
+    in B; c1 runs at its full size), on all physical cores and on one thread, forward + losses + backward + Adam."""
     import torch
     from multi_part_assembly_amd import config, synthetic
     from multi_part_assembly_amd.pn_transformer import build_model
+    from oracle import callers as oc
     from oracle import nets as on
 
-    cores = len(os.sched_getaffinity(0))
-    cfg = config.pn_transformer_everyday()
+    visible = len(os.sched_getaffinity(0))
+    cores = physical_cores()
+    P, N = PARTS, POINTS
+    if name in ("c2", "c4"):
+        cfg, full_B, B_all, B_one, label = config.pn_transformer_everyday(), BATCH, cpu_batch or 4, 2, "c2"
+        make = lambda B: synthetic.make_batch(B, P, N, preset="everyday", seed=1234, device=dev)
+    elif name == "c3":
+        cfg, full_B, B_all, B_one, label = config.dgl_dgcnn_everyday(), BATCH, cpu_batch or 2, 1, "c3"
+        make = lambda B: synthetic.make_batch(B, P, N, preset="everyday", seed=1234, device=dev)
+    elif name == "c1":
+        cfg = config.global_partnet_chair()
+        cfg.data.max_num_part = 2
+        P, full_B, B_all, B_one, label = 2, 4, cpu_batch or 4, 4, "c1"
+        make = lambda B: synthetic.make_semantic_batch(B, 2, N, seed=1234, device=dev,
+                                                       num_part_category=cfg.data.num_part_category)
+    else:
+        return None
     torch.manual_seed(0)
     model = build_model(cfg)
-    P, N = PARTS, POINTS
+    loss_cfg = {k: cfg.loss[k] for k in cfg.loss}
 
     def run(B, threads, warm, timed):
         torch.set_num_threads(threads)
         os.environ["OMP_NUM_THREADS"] = str(threads)
         sd = {k: v.clone() for k, v in model.state_dict().items()}
         params = {k: sd[k].requires_grad_() for k, _ in model.named_parameters()}
-        full = synthetic.make_batch(B, P, N, preset="everyday", seed=1234, device=dev)
-        batch = {k: v.cpu() for k, v in full.items() if hasattr(v, "cpu")}
+        batch = {k: v.cpu() for k, v in make(B).items() if hasattr(v, "cpu")}
         state = {}
 
         def step():
             for p in params.values():
                 p.grad = None
             stats = {}
-            losses, _ = on.pn_transformer_loss(sd, batch, cfg.model.transformer_layers,
-                                               cfg.model.transformer_heads, training=True, stats_out=stats)
+            if label == "c2":
+                losses, _ = on.pn_transformer_loss(sd, batch, cfg.model.transformer_layers,
+                                                   cfg.model.transformer_heads, training=True, stats_out=stats)
+            elif label == "c3":
+                losses = oc.dgl_loss(sd, batch, cfg.model.gnn_iter, cfg.model.encoder, True, stats)
+            else:
+                losses = oc.global_loss(sd, batch, loss_cfg, cfg.loss.sample_iter, cfg.loss.noise_dim, cfg.model.encoder,
+                                        True, stats)
             losses["loss"].backward()
-            on.adam_step(params, {k: p.grad for k, p in params.items()}, state, lr=cfg.optimizer.lr)
+            live = {k: p for k, p in params.items() if p.grad is not None}
+            on.adam_step(live, {k: p.grad for k, p in live.items()}, state, lr=cfg.optimizer.lr)
             for k, v in stats.items():
                 sd[k] = v
 
@@ -173,15 +222,23 @@ def cpu_baseline(cpu_batch, dev):
         dt = (time.perf_counter() - t0) / timed
         return B * P / dt, dt
 
-    threads = max(1, min(64, cores))
-    v_all, dt_all = run(cpu_batch, threads, 3, 5)
-    v_one, dt_one = run(2, 1, 1, 2)
-    return {"value": v_all, "unit": "parts/s", "cores": threads, "kind": "port",
-            "one_thread_value": v_one, "cpu": cpu_model_name(), "visible_cores": cores,
-            "sample": f"full train step (fwd+loss+bwd+Adam) of the c2 model on synthetic.make_batch(seed=1234) at "
-                      f"B={cpu_batch} (vs 32), P={P}, N={N}: 3 warm-up + 5 timed steps, {dt_all:.2f} s/step on "
-                      f"{threads} threads; one thread: B=2, 1 warm-up + 2 timed, {dt_one:.2f} s/step; torch CPU ops + "
-                      f"OpenMP C Chamfer (oracle/), cost linear in B"}
+    heavy = label == "c3"  # ~8 s per step: 1 warm-up + 1 timed per thread count keeps the default run within minutes
+    # torch's CPU ops do not scale to 128 threads at these sizes (c2: 57 parts/s on 128 threads, 100 on 64): the baseline
+    # is the BEST of {all physical cores, 64, 16} threads, and every measured point is reported
+    by_threads = {}
+    for threads in sorted({cores, min(64, cores), min(16, cores)}, reverse=True):
+        by_threads[threads] = run(B_all, threads, 1 if heavy else 2, 1 if heavy else 4)
+    best = max(by_threads, key=lambda t: by_threads[t][0])
+    v_all, dt_all = by_threads[best]
+    v_one, dt_one = run(B_one, 1, 0 if heavy else 1, 1 if heavy else 2)
+    scaled = "" if B_all == full_B else f" (vs {full_B}: cost linear in B)"
+    return {"value": v_all, "unit": "parts/s", "cores": best, "kind": "port", "physical_cores": cores,
+            "by_threads": {str(t): v for t, (v, _) in by_threads.items()},
+            "one_thread_value": v_one, "cpu": cpu_model_name(), "visible_cores": visible,
+            "sample": f"full train step (fwd+loss+bwd+Adam) of the {label} model on the bench's own generator (seed 1234) "
+                      f"at B={B_all}{scaled}, P={P}, N={N}: {dt_all:.2f} s/step on {best} threads, the best of "
+                      f"{sorted(by_threads, reverse=True)} ({cores} physical cores, {visible} hardware threads visible); "
+                      f"one thread: B={B_one}, {dt_one:.2f} s/step; torch CPU ops + OpenMP C Chamfer (oracle/)"}
 
 
 # ---- roofline bookkeeping -------------------------------------------------------------------------------------------
@@ -307,6 +364,30 @@ def main():
     gc.enable()
     _lib.KernelTimer.active = None
     final_loss = float(loss)
+    self_check = None
+    if args.self_check > 0:  # does the K-step mean hold over a longer run?  (same fences, same batch)
+        gc.collect()
+        gc.disable()
+        fence()
+        t1 = time.perf_counter()
+        for i in range(args.self_check):
+            trainer.train_step(batch, i)
+        fence()
+        long_ms = 1e3 * (time.perf_counter() - t1) / args.self_check
+        gc.enable()
+        short_ms = 1e3 * elapsed / max(1, args.steps)
+        self_check = {"steps": args.self_check, "ms_per_step": long_ms, "ratio_to_timed_mean": long_ms / short_ms,
+                      "holds": abs(long_ms / short_ms - 1.0) < 0.05}
+    collectives = None
+    if distributed:
+        from multi_part_assembly_amd.dp import measure_collectives
+        collectives = measure_collectives(trainer, batch, steps=min(args.steps, 10), fence=fence)
+        if collectives is not None and collectives["local_ms_per_step"] is not None:
+            dp_ms = 1e3 * elapsed / max(1, args.steps)
+            hidden = sum(collectives["allreduce_ms"]) - max(0.0, dp_ms - collectives["local_ms_per_step"])
+            collectives["exposed_ms"] = max(0.0, dp_ms - collectives["local_ms_per_step"])
+            collectives["overlap_frac"] = (max(0.0, min(1.0, hidden / sum(collectives["allreduce_ms"])))
+                                           if sum(collectives["allreduce_ms"]) > 0 else None)
     timer = _lib.KernelTimer()
     if rank == 0 and not distributed:  # (with several ranks the backward hooks of this pass would start collectives)
         # per-phase timing pass (not timed): the same K steps launched eagerly with every entry point instrumented
@@ -362,17 +443,24 @@ def main():
                         traffic = rec["per_width"][str(C)]["traffic_bytes_per_launch"]
                         traffic_src = f"profiles/{pmc[-1].name}: {rec['correction']}"
                 roofline = {
-                    "kernel": f"dg::knn_mfma_kernel (k = 20 nearest neighbours in {C}-d feature space, {valid_parts} "
-                              f"clouds of {N} points; timed with its row-norm pre-pass)",
+                    "kernel": (f"dg::knn_wide (rownorm + split + knn_gram_kernel bound / collect + knn_rerank_kernel: k = 20 "
+                               f"nearest neighbours in {C}-d feature space, {valid_parts} clouds of {N} points)"
+                               if C >= 64 else f"dg::knn3_kernel (k = 20 nearest neighbours of {valid_parts} clouds of {N} "
+                               f"points in 3-d)"),
                     "bound": "hbm", "achieved": alg / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": k["avg_ms"], "launches": k["launches"], "algorithmic_bytes_per_launch": alg,
-                    "binding": {"bound": "mfma_f32" if C >= 64 else "valu",
-                                "note": "exhaustive exact top-20: N candidate scores per query (2C+1 FLOP each) + "
-                                        "the top-k selection; HBM is not what binds it (SURVEY.md §7 hard part 1)",
-                                "score_flops_per_launch": pairs * (2 * C + 1),
-                                "frac": (pairs * (2 * C + 1) / secs / MFMA_F32_PEAK) if C >= 64 else
-                                        (pairs * 12.0 / secs / VALU_PEAK_LANE_OPS)},
+                    "binding": {"bound": "mfma_bf16" if C >= 64 else "valu",
+                                "note": "exact top-20 as a shortlist search (csrc/dg_knn_fast.h): two passes of 3-product "
+                                        "split-bf16 Gram tiles (bound + collect: 12 C FLOP per pair) on the bf16 matrix "
+                                        "cores, then the pinned fp32 chain for ~21 survivors per query; HBM is not what "
+                                        "binds it (SURVEY.md §7 hard part 1)" if C >= 64 else
+                                        "exhaustive exact top-20 on the VALU (12 lane-slots per pair)",
+                                "gram_flops_per_launch": pairs * 12.0 * C if C >= 64 else None,
+                                "frac": (pairs * 12.0 * C / secs / MFMA_BF16_PEAK) if C >= 64 else
+                                        (pairs * 12.0 / secs / VALU_PEAK_LANE_OPS),
+                                "frac_of_fp32_mfma_if_exhaustive": (pairs * (2 * C + 1) / secs / MFMA_F32_PEAK)
+                                if C >= 64 else None},
                     "per_layer": per_layer, "timing": timing}
         else:
             dom = _find(kernels, "grid_search_kernel[")
@@ -432,8 +520,12 @@ def main():
             "roofline": roofline,
             "kernel_table": kernel_table(kernels, num_parts, cfg, B, P),
         }
-        if world == 1 and not args.no_cpu_baseline and args.config in ("c2", "c4"):
-            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, dev)
+        if world == 1 and not args.no_cpu_baseline and args.config in ("c1", "c2", "c3", "c4"):
+            line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, dev)
+        if self_check is not None:
+            line["self_check"] = self_check
+        if collectives is not None:
+            line["collectives"] = collectives
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

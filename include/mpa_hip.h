@@ -204,32 +204,6 @@ int mpa_pointnet_backward_bf16(const float* grad_feat, const float* points, cons
                                void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * DGCNN building blocks — replace
- *   knn / get_graph_feature : multi_part_assembly/models/modules/encoder/dgcnn.py:8-38
- *   one EdgeConv stage      : dgcnn.py:76-100 (Conv2d 1x1 over [x_j - x_i ; x_i], BatchNorm2d, LeakyReLU 0.2, max_k)
- * x [n*N, C] point-major features of n clouds of N points (C = 3, 64 or 128).  mpa_knn writes, per point, the
- * indices (inside its cloud, best first, the point itself included) of its k = 20 nearest neighbours in feature
- * space, scored as the reference does (-|x_j|^2 + 2 x_i.x_j - |x_i|^2); equal scores keep the lower index first.
- *
- * Edge aggregation: the 1x1 convolution is linear in the edge feature, W [x_j - x_i ; x_i] = U_j + V_i with
- * [U | V] = X [Wa ; Wb - Wa]^T computed by the caller as ONE GEMM per point (uv [n*N, 2*CO]); the kernels gather
- * the k neighbour rows of U, apply BatchNorm2d (training != 0: statistics over all n*N*k edges, running statistics
- * updated with `momentum`; else the running statistics) + LeakyReLU(0.2) and take the max over the neighbours:
- * out [n*N, CO].  CO a multiple of 64 (<= 1024), k <= 32, N <= 65535.  `ws` (mpa_edge_aggregate_workspace bytes,
- * 256-byte aligned) carries the selected edges to backward, which overwrites grad_uv [n*N, 2*CO], grad_gamma and
- * grad_beta [CO]: the kNN graph of every part is transposed in the workspace and the neighbour sums are gathered in
- * a fixed order (no atomics, bit-reproducible) for N <= 16384; larger parts use an fp32 atomic scatter.
- * ---------------------------------------------------------------------------------------------- */
-int mpa_knn(const float* x, int64_t n, int64_t N, int64_t C, int64_t K, int32_t* idx, void* stream);
-int mpa_edge_aggregate_workspace(int64_t n, int64_t N, int64_t CO, int64_t K, int64_t* bytes);
-int mpa_edge_aggregate_forward(const float* uv, const int32_t* idx, const float* gamma, const float* beta,
-                               float* running_mean, float* running_var, int training, float momentum, float eps,
-                               int64_t n, int64_t N, int64_t CO, int64_t K, void* ws, float* out, void* stream);
-int mpa_edge_aggregate_backward(const float* grad_out, const float* uv, const int32_t* idx, const float* gamma,
-                                int64_t n, int64_t N, int64_t CO, int64_t K, void* ws, float* grad_uv,
-                                float* grad_gamma, float* grad_beta, void* stream);
-
-/* ------------------------------------------------------------------------------------------------
  * DGCNN part encoder, whole forward / backward — replaces
  *   DGCNN.forward        : multi_part_assembly/models/modules/encoder/dgcnn.py:73-109 (global_feat = True)
  *   _extract_part_feats  : multi_part_assembly/models/dgl/network.py:90-99 (boolean-mask compaction + scatter; here:
@@ -329,6 +303,9 @@ int mpa_mlp_layer_backward(const float* grad_out, const float* x, int64_t ldx, c
  * batch (valid steps first) and mask the outputs — the reverse direction on the per-sample reversed valid prefix.
  * ---------------------------------------------------------------------------------------------- */
 int mpa_gru_workspace(int64_t D, int64_t B, int64_t T, int64_t H, int64_t* float_elems);
+/* *ok = 1 iff the shapes are instantiated AND the current device can hold the whole grid of both kernels at once (their
+ * per-step barrier spins on it; forward / backward return an error instead of hanging when it cannot). */
+int mpa_gru_resident(int64_t D, int64_t B, int64_t H, int* ok);
 int mpa_gru_forward(const float* gi, const float* h0, const float* whh, const float* bhh, int64_t D, int64_t B, int64_t T,
                     int64_t H, float* ws, float* out, void* stream);
 int mpa_gru_backward(const float* grad_out, const float* h0, const float* whh, const float* out, int64_t D, int64_t B,

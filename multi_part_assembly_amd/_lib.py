@@ -49,10 +49,6 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_pointnet_workspace_bf16": (_INT, [_I64, _I64, _I64, _P]),
     "mpa_pointnet_forward_bf16": (_INT, [_P] * 7 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_pointnet_backward_bf16": (_INT, [_P] * 5 + [_I64, _I64, _I64] + [_P] * 5),
-    "mpa_knn": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P]),
-    "mpa_edge_aggregate_workspace": (_INT, [_I64, _I64, _I64, _I64, _P]),
-    "mpa_edge_aggregate_forward": (_INT, [_P] * 6 + [_INT, _F32, _F32, _I64, _I64, _I64, _I64, _P, _P, _P]),
-    "mpa_edge_aggregate_backward": (_INT, [_P] * 4 + [_I64] * 4 + [_P] * 5),
     "mpa_dgcnn_workspace": (_INT, [_I64, _I64, _I64, _P]),
     "mpa_dgcnn_forward": (_INT, [_P] * 9 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
     "mpa_dgcnn_forward_graphs": (_INT, [_P] * 9 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
@@ -64,6 +60,7 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_mlp_layer_forward": (_INT, [_P, _I64, _P, _P, _P, _P, _P, _P, _INT, _F32, _F32, _INT, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_mlp_layer_backward": (_INT, [_P, _P, _I64, _P, _P, _P, _INT, _I64, _I64, _I64] + [_P] * 7),
     "mpa_gru_workspace": (_INT, [_I64, _I64, _I64, _I64, _P]),
+    "mpa_gru_resident": (_INT, [_I64, _I64, _I64, _P]),
     "mpa_gru_forward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_gru_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
     "mpa_transformer_workspace": (_INT, [_I64] * 6 + [_P]),

@@ -267,6 +267,42 @@ int gru_check(int64_t D, int64_t B, int64_t T, int64_t H, const char* who) {
 
 }  // namespace
 
+namespace {
+// The step barrier spins until every block of the grid has arrived: all H/8 x D blocks must be RESIDENT at once (a block
+// that was never dispatched would hang the kernel without a diagnostic — e.g. on a partitioned device with fewer CUs,
+// or with an LDS footprint that leaves one block per CU).  Checked against the occupancy the runtime reports.
+template <typename Kern>
+int gru_resident(Kern kern, size_t smem, int blocks, const char* who) {
+  if (smem > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+          hipSuccess)
+    return mpa::fail(MPA_EINVAL, "%s: cannot reserve %zu bytes of LDS", who, smem);
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kGT, smem) != hipSuccess)
+    return mpa::fail(MPA_EINVAL, "%s: cannot query the device's occupancy", who);
+  if ((long long)per_cu * cus < blocks)
+    return mpa::fail(MPA_EINVAL, "%s: the grid barrier needs all %d blocks resident, this device holds %d x %d", who, blocks,
+                     per_cu, cus);
+  return MPA_OK;
+}
+}  // namespace
+
+extern "C" int mpa_gru_resident(int64_t D, int64_t B, int64_t H, int* ok) {
+  MPA_REQUIRE(ok != nullptr, "gru_resident: null pointer");
+  *ok = 0;
+  if (!((H == 128 || H == 256) && B >= 1 && B <= 64 && (D == 1 || D == 2))) return MPA_OK;
+  const size_t fwd = sizeof(float) * (3 * kU * (H + 1) + B * (H + 1)), bwd = sizeof(float) * (3 * kU * H + B * H + B * 3 * kU + B * kU);
+  if (fwd > 160 * 1024 || bwd > 160 * 1024) return MPA_OK;
+  const int blocks = (int)(H / kU * D);
+  int st = H == 128 ? gru_resident(gru_fwd_kernel<128>, fwd, blocks, "gru") : gru_resident(gru_fwd_kernel<256>, fwd, blocks, "gru");
+  if (st == MPA_OK)
+    st = H == 128 ? gru_resident(gru_bwd_kernel<128>, bwd, blocks, "gru") : gru_resident(gru_bwd_kernel<256>, bwd, blocks, "gru");
+  *ok = st == MPA_OK;
+  return MPA_OK;
+}
+
 extern "C" int mpa_gru_workspace(int64_t D, int64_t B, int64_t T, int64_t H, int64_t* float_elems) {
   if (int st = gru_check(D, B, T, H, "gru_workspace")) return st;
   MPA_REQUIRE(float_elems != nullptr, "gru_workspace: null pointer");
@@ -288,12 +324,10 @@ extern "C" int mpa_gru_forward(const float* gi, const float* h0, const float* wh
   const dim3 grid((unsigned)(H / kU), (unsigned)D);
 #define MPA_GRU_FWD(HH)                                                                                               \
   {                                                                                                                   \
-    static size_t allowed = 64 * 1024; /* dynamic LDS above 64 KB must be requested (exactly: static LDS counts too) */ \
-    if (smem > allowed) {                                                                                             \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)smem) != hipSuccess)                                                               \
-        return mpa::fail(MPA_EINVAL, "gru: cannot reserve %zu bytes of LDS", smem);                                   \
-      allowed = smem;                                                                                                 \
+    static size_t checked = 0; /* LDS request + co-residency of the whole grid, once per footprint */                  \
+    if (smem != checked) {                                                                                            \
+      if (int st = gru_resident(gru_fwd_kernel<HH>, smem, (int)(grid.x * grid.y), "gru_forward")) return st;          \
+      checked = smem;                                                                                                 \
     }                                                                                                                 \
     hipLaunchKernelGGL(gru_fwd_kernel<HH>, grid, dim3(kGT), smem, s, gi, h0, whh, bhh, (int)B, (int)T, out, saved,     \
                        counters);                                                                                     \
@@ -318,12 +352,10 @@ extern "C" int mpa_gru_backward(const float* grad_out, const float* h0, const fl
   const dim3 grid((unsigned)(H / kU), (unsigned)D);
 #define MPA_GRU_BWD(HH)                                                                                               \
   {                                                                                                                   \
-    static size_t allowed = 64 * 1024; /* dynamic LDS above 64 KB must be requested (exactly: static LDS counts too) */ \
-    if (smem > allowed) {                                                                                             \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_kernel<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)smem) != hipSuccess)                                                               \
-        return mpa::fail(MPA_EINVAL, "gru: cannot reserve %zu bytes of LDS", smem);                                   \
-      allowed = smem;                                                                                                 \
+    static size_t checked = 0;                                                                                        \
+    if (smem != checked) {                                                                                            \
+      if (int st = gru_resident(gru_bwd_kernel<HH>, smem, (int)(grid.x * grid.y), "gru_backward")) return st;         \
+      checked = smem;                                                                                                 \
     }                                                                                                                 \
     hipLaunchKernelGGL(gru_bwd_kernel<HH>, grid, dim3(kGT), smem, s, grad_out, h0, whh, out, saved, (int)B, (int)T,    \
                        grad_gi, grad_whh, grad_bhh, part, counters);                                                  \

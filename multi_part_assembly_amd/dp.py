@@ -38,6 +38,7 @@ class BucketedGradReducer:
             self.buckets.append({"slice": flat.flat_grad[start:end], "count": size, "ready": 0})
             first += size
         self.pending = []
+        self.enabled = True  # False: hooks and finish() issue no collective (bench.py: the step time without them)
         self._seen = set()
         self._owner = {}
         idx = 0
@@ -53,7 +54,7 @@ class BucketedGradReducer:
         """Gradient of `param` is final for this step.  Idempotent per step: a parameter whose gradient a HIP
         backward kernel wrote directly is announced by the GradSink, and — depending on the torch version — also by
         autograd's post-accumulate hook, which fires even when the Function returned None for that input."""
-        if id(param) in self._seen:
+        if id(param) in self._seen or not self.enabled:
             return
         self._seen.add(id(param))
         bucket = self.buckets[self._owner[param]]
@@ -65,7 +66,7 @@ class BucketedGradReducer:
     def finish(self):
         """Issue collectives for buckets whose hooks did not all fire (parameters unused in this
         step), wait for everything, reset.  Returns the scale (1/world) still to be applied."""
-        if self.world > 1:
+        if self.world > 1 and self.enabled:
             for bucket in self.buckets:
                 if bucket["ready"] != bucket["count"]:
                     self.pending.append(dist.all_reduce(bucket["slice"], op=dist.ReduceOp.SUM,
@@ -74,6 +75,8 @@ class BucketedGradReducer:
             for work in self.pending:
                 work.wait()
             self.pending.clear()
+        for bucket in self.buckets:
+            bucket["ready"] = 0
         self._seen.clear()
         return 1.0 / self.world
 
@@ -99,3 +102,58 @@ def ordered_parameters(model):
     enc = {id(p) for p in model.encoder.parameters()} if hasattr(model, "encoder") else set()
     rest = [p for p in model.parameters() if id(p) not in enc and p.requires_grad]
     return rest + [p for p in model.parameters() if id(p) in enc and p.requires_grad]
+
+
+def measure_collectives(trainer, batch, steps=10, fence=None, reps=10):
+    """Where a data-parallel step's time goes (bench.py, after its timed region; every rank must call this): per
+    gradient bucket its size and the time of its all-reduce ALONE (nothing else running: `reps` back-to-back calls
+    between fences), and the step time with the collectives switched off.  Together with the measured data-parallel
+    step time: exposed = dp - local, overlap = 1 - exposed / sum(all-reduce).  The replicas diverge during the
+    collective-free steps — call this last."""
+    import time
+
+    reducer = trainer.reducer
+    if reducer is None or not dist.is_initialized():
+        return None
+    on_gpu = trainer.flat.flat_grad.is_cuda
+
+    def sync():
+        if fence is not None:
+            fence()
+        else:
+            if on_gpu:
+                torch.cuda.synchronize()
+            dist.barrier(group=reducer.group)
+            if on_gpu:
+                torch.cuda.synchronize()
+
+    bucket_bytes, allreduce_ms = [], []
+    for bucket in reducer.buckets:
+        bucket_bytes.append(int(bucket["slice"].numel() * bucket["slice"].element_size()))
+        scratch = torch.zeros_like(bucket["slice"])
+        dist.all_reduce(scratch, group=reducer.group)  # warm-up (connection setup on the first call)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(scratch, group=reducer.group)
+        sync()
+        allreduce_ms.append(1e3 * (time.perf_counter() - t0) / reps)
+    local_ms = float("nan")
+    if reducer.enabled:  # (graph mode issues its collectives itself: no collective-free variant of its step)
+        reducer.enabled = False
+        try:
+            trainer.train_step(batch, 0)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                trainer.train_step(batch, i)
+            sync()
+            local_ms = 1e3 * (time.perf_counter() - t0) / steps
+        finally:
+            reducer.enabled = True
+    # max over ranks, like the step time itself
+    vals = torch.tensor(allreduce_ms + [local_ms], dtype=torch.float64, device=trainer.flat.flat_grad.device)
+    dist.all_reduce(vals, op=dist.ReduceOp.MAX, group=reducer.group)
+    vals = vals.tolist()
+    return {"world": reducer.world, "bucket_bytes": bucket_bytes, "allreduce_ms": vals[:-1],
+            "local_ms_per_step": vals[-1] if vals[-1] == vals[-1] else None, "algorithm_note": "ring all-reduce moves 2 (n-1)/n of the bucket per link"}

@@ -13,7 +13,18 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .gradsink import GradSink
+from .gradsink import DeferredBackward, GradSink
+
+
+def _deliver(params, returned, skip):
+    """A parked backward ran outside autograd: add the gradients it RETURNED (the non-direct path; with a GradSink they
+    were written in place and the entries are None) to the parameters' .grad."""
+    for p, g in zip(params, returned[skip:]):
+        if g is not None:
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
 
 
 class _PointNetFn(torch.autograd.Function):
@@ -52,7 +63,15 @@ class _PointNetFn(torch.autograd.Function):
     def backward(ctx, grad_feat):
         if not ctx.training:
             raise RuntimeError("PointNet: backward is implemented for training-mode BatchNorm only")
-        points, valids, fws, iws = ctx.saved_tensors
+        if DeferredBackward.active is not None:  # graph-mode data parallelism: run later, behind the first all-reduce
+            saved = ctx.saved_tensors  # (autograd releases them when its own pass is over)
+            DeferredBackward.park(lambda g: _deliver(ctx.params, _PointNetFn._run_backward(ctx, g, saved), 6), grad_feat)
+            return (None,) * (6 + len(ctx.params))
+        return _PointNetFn._run_backward(ctx, grad_feat, ctx.saved_tensors)
+
+    @staticmethod
+    def _run_backward(ctx, grad_feat, saved):
+        points, valids, fws, iws = saved
         params = ctx.params
         conv_w, bn_w = params[0:5], params[5:10]
         M, N, _ = points.shape
@@ -108,7 +127,15 @@ class _PointNetBF16Fn(torch.autograd.Function):
     def backward(ctx, grad_feat):
         if not ctx.training:
             raise RuntimeError("PointNet (bf16): backward is implemented for training-mode BatchNorm only")
-        points, valids, ws = ctx.saved_tensors
+        if DeferredBackward.active is not None:
+            saved = ctx.saved_tensors
+            DeferredBackward.park(lambda g: _deliver(ctx.params, _PointNetBF16Fn._run_backward(ctx, g, saved), 6), grad_feat)
+            return (None,) * (6 + len(ctx.params))
+        return _PointNetBF16Fn._run_backward(ctx, grad_feat, ctx.saved_tensors)
+
+    @staticmethod
+    def _run_backward(ctx, grad_feat, saved):
+        points, valids, ws = saved
         params = ctx.params
         conv_w, bn_w = params[0:5], params[5:10]
         M, N, _ = points.shape
@@ -194,62 +221,6 @@ def knn_exact(x, n, N, C=None):
     return idx
 
 
-def knn_indices(x, n, N, k=20):
-    """x [n*N, C] point-major features -> int32 [n*N, k] neighbour indices inside each cloud (csrc/dgcnn.hip)."""
-    R, C = x.shape
-    idx = torch.empty((R, k), dtype=torch.int32, device=x.device)
-    with torch.cuda.device(x.device):
-        tok = _lib.KernelTimer.start(f"knn[{n}x{N}x{C}]")
-        st = _lib.lib().mpa_knn(_lib.ptr(x), n, N, C, k, _lib.ptr(idx), _lib.current_stream(x.device))
-        _lib.KernelTimer.stop(tok)
-    _lib.check(st, "mpa_knn")
-    return idx
-
-
-class _EdgeAggFn(torch.autograd.Function):
-    """BatchNorm2d + LeakyReLU(0.2) + max over the k neighbours of the edge values U_j + V_i (csrc/dgcnn.hip)."""
-
-    @staticmethod
-    def forward(ctx, uv, idx, gamma, beta, running, training, momentum, eps, n, N):
-        R, CO2 = uv.shape
-        CO, K = CO2 // 2, idx.shape[1]
-        dev = uv.device
-        lib = _lib.lib()
-        nbytes = ctypes.c_int64()
-        _lib.check(lib.mpa_edge_aggregate_workspace(n, N, CO, K, ctypes.byref(nbytes)), "mpa_edge_aggregate_workspace")
-        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-        out = torch.empty((R, CO), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            tok = _lib.KernelTimer.start(f"edge_aggregate_forward[{n}x{N}x{CO}]")
-            st = lib.mpa_edge_aggregate_forward(_lib.ptr(uv), _lib.ptr(idx), _lib.ptr(gamma), _lib.ptr(beta),
-                                                _lib.ptr(running[0]), _lib.ptr(running[1]), int(training),
-                                                float(momentum), float(eps), n, N, CO, K, _lib.ptr(ws), _lib.ptr(out),
-                                                _lib.current_stream(dev))
-            _lib.KernelTimer.stop(tok)
-        _lib.check(st, "mpa_edge_aggregate_forward")
-        ctx.dims = (n, N, CO, K, bool(training))
-        ctx.save_for_backward(uv, idx, gamma, ws)
-        return out
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        uv, idx, gamma, ws = ctx.saved_tensors
-        n, N, CO, K, training = ctx.dims
-        if not training:
-            raise RuntimeError("EdgeConv: backward is implemented for training-mode BatchNorm only")
-        dev = uv.device
-        guv = torch.empty_like(uv)
-        ggamma, gbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        with torch.cuda.device(dev):
-            tok = _lib.KernelTimer.start(f"edge_aggregate_backward[{n}x{N}x{CO}]")
-            st = _lib.lib().mpa_edge_aggregate_backward(
-                _lib.ptr(grad_out.contiguous()), _lib.ptr(uv), _lib.ptr(idx), _lib.ptr(gamma), n, N, CO, K, _lib.ptr(ws),
-                _lib.ptr(guv), _lib.ptr(ggamma), _lib.ptr(gbeta), _lib.current_stream(dev))
-            _lib.KernelTimer.stop(tok)
-        _lib.check(st, "mpa_edge_aggregate_backward")
-        return (guv, None, ggamma, gbeta, None, None, None, None, None, None)
-
-
 class _DGCNNFn(torch.autograd.Function):
     """Whole DGCNN encoder forward/backward on the HIP library (csrc/dgcnn_enc.hip)."""
 
@@ -311,7 +282,20 @@ class _DGCNNFn(torch.autograd.Function):
     def backward(ctx, grad_feat):
         if not ctx.training:
             raise RuntimeError("DGCNN: backward is implemented for training-mode BatchNorm only")
-        pts, ws = ctx.saved_tensors
+        if DeferredBackward.active is not None and not ctx.want_point_grad:
+            saved = ctx.saved_tensors
+            DeferredBackward.park(lambda g: _deliver(ctx.params, _DGCNNFn._run_backward(ctx, g, saved), 8), grad_feat)
+            return (None,) * (8 + len(ctx.params))
+        return _DGCNNFn._run_backward(ctx, grad_feat, ctx.saved_tensors)
+
+    @staticmethod
+    def _run_backward(ctx, grad_feat, saved):
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("DGCNN: the backward pass overwrites its saved workspace (y5 becomes dY5, dhcat is "
+                               "accumulated in place): a second backward over the same forward is not supported — "
+                               "run the forward again")
+        ctx.consumed = True
+        pts, ws = saved
         params = ctx.params
         conv_w, bn_w, fc_w = params[0:5], params[5:10], params[15]
         M, N, _ = pts.shape
@@ -341,9 +325,9 @@ class DGCNN(nn.Module):
     gather / BatchNorm2d / LeakyReLU / max, HIP tail).  `forward_parts` is the sync-free entry of the assembly
     models: all part slots plus the validity mask, zeros out for padded parts.
 
-    Outside the kernels' instantiation (per-point features, more than 1024 points per cloud, feat_dim not in
-    {64, 128, 256}) the stage-by-stage composition of mpa_knn / mpa_edge_aggregate_* with library GEMMs is used and
-    says so once."""
+    Outside the kernels' instantiation (per-point features, fewer than 20 or more than 1024 points per cloud, feat_dim
+    not in {64, 128, 256}) the module raises: there is no second, slower path (every shipped configuration — 1000
+    points per part, global feature — is inside)."""
 
     MAX_POINTS = 1024
 
@@ -362,7 +346,6 @@ class DGCNN(nn.Module):
         self.feat_dim = feat_dim
         if global_feat:
             self.out_fc = nn.Linear(feat_dim * 2, feat_dim)
-        self._warned = False
         # parity-test hooks (None in production): {"graphs": [4 x (None | int32 [nv*N, 20])]} holds stages' kNN graphs
         # fixed; {"export": True} leaves the graphs the forward built under "exported" ([M*N, 20] int32 per stage)
         self.graph_hooks = None
@@ -376,7 +359,9 @@ class DGCNN(nn.Module):
             raise RuntimeError("DGCNN: only CUDA (HIP) tensors are supported — no CPU fallback")
         M, N, _ = part_pcs.shape
         if not self._fused_ok(N):
-            return self._composed_parts(part_pcs, valids)
+            raise NotImplementedError(
+                f"DGCNN: csrc/dgcnn_enc.hip is built for the global feature, 20..{self.MAX_POINTS} points per cloud and "
+                f"feat_dim 64 / 128 / 256 (got N = {N}, feat_dim = {self.feat_dim}, global_feat = {self.global_feat})")
         bns = [self.bn1, self.bn2, self.bn3, self.bn4, self.bn5]
         convs = [self.conv1[0], self.conv2[0], self.conv3[0], self.conv4[0], self.conv5[0]]
         if self.training:
@@ -392,52 +377,7 @@ class DGCNN(nn.Module):
         """x [n, N, 3] -> [n, feat_dim] (global feature) or [n, N, feat_dim]; the reference's signature."""
         if not x.is_cuda:
             raise RuntimeError("DGCNN: only CUDA (HIP) tensors are supported — no CPU fallback")
-        if self._fused_ok(x.shape[1]):
-            return self.forward_parts(x, torch.ones(x.shape[0], device=x.device))
-        return self._composed(x)
-
-    # ---- stage-by-stage composition (sizes outside csrc/dgcnn_enc.hip) -------------------------------------------
-    def _composed_parts(self, part_pcs, valids):
-        slots = torch.nonzero(valids.reshape(-1) == 1, as_tuple=False).squeeze(1)  # (device sync)
-        feats = self._composed(part_pcs.index_select(0, slots))
-        return feats.new_zeros(part_pcs.shape[0], self.feat_dim).index_copy(0, slots, feats)
-
-    def _edge_stage(self, h, conv, n, N):
-        """h [n*N, C] -> [n*N, CO]."""
-        bn = conv[1]
-        C = h.shape[1]
-        w = conv[0].weight[:, :, 0, 0]                               # [CO, 2C] acting on [x_j - x_i ; x_i]
-        w_stack = torch.cat([w[:, :C], w[:, C:] - w[:, :C]], dim=0)   # [2CO, C]: U = X Wa^T, V = X (Wb - Wa)^T
-        idx = knn_indices(h.detach().contiguous(), n, N)
-        if self.training:
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
-        return _EdgeAggFn.apply(h @ w_stack.t(), idx, bn.weight, bn.bias, (bn.running_mean, bn.running_var),
-                                self.training, bn.momentum, bn.eps, n, N)
-
-    def _composed(self, x):
-        if not self._warned:
-            import warnings
-            warnings.warn("DGCNN: configuration outside csrc/dgcnn_enc.hip (global feature, 20..1024 points per cloud, "
-                          "feat_dim 64/128/256); composing the per-stage kernels with library GEMMs")
-            self._warned = True
-        n, N, _ = x.shape
-        h = x.reshape(n * N, 3).float()
-        stages = []
-        for conv in (self.conv1, self.conv2, self.conv3, self.conv4):
-            h = self._edge_stage(h, conv, n, N)
-            stages.append(h)
-        y = torch.cat(stages, dim=1) @ self.conv5[0].weight[:, :, 0].t()          # [n*N, F]
-        bn = self.bn5
-        y = F.leaky_relu(F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, self.training,
-                                      bn.momentum, bn.eps), 0.2)
-        if self.training:
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
-        y = y.view(n, N, -1)
-        if not self.global_feat:
-            return y
-        return self.out_fc(torch.cat((y.max(dim=1)[0], y.mean(dim=1)), dim=1))
+        return self.forward_parts(x, torch.ones(x.shape[0], device=x.device))
 
 
 def build_encoder(arch, feat_dim, global_feat=True, **kwargs):

@@ -30,12 +30,7 @@ class GlobalModel(BaseModel):
 
     def _extract_part_feats(self, part_pcs, part_valids):
         B, P, N, _ = part_pcs.shape
-        if hasattr(self.encoder, "forward_parts"):
-            return self.encoder.forward_parts(part_pcs.reshape(B * P, N, 3), part_valids.reshape(-1)).view(B, P, -1)
-        valid = (part_valids == 1).reshape(-1)
-        slots = torch.nonzero(valid, as_tuple=False).squeeze(1)
-        feats = self.encoder(part_pcs.reshape(B * P, N, 3).index_select(0, slots))
-        return feats.new_zeros(B * P, self.pc_feat_dim).index_copy(0, slots, feats).view(B, P, -1)
+        return self.encoder.forward_parts(part_pcs.reshape(B * P, N, 3), part_valids.reshape(-1)).view(B, P, -1)
 
     def forward(self, data_dict):
         feats = data_dict.get("pre_pose_feats", None)

@@ -7,8 +7,10 @@ the same state_dict keys (`edge_mlps.{i}.conv1.weight`, `node_mlps.{i}.bn3.runni
 What runs where: the part encoder (PointNet: csrc/pointnet.hip, DGCNN: csrc/dgcnn_enc.hip), every loss evaluation of
 the `gnn_iter` stacked predictions (fused assembly loss: csrc/assembly_loss.hip, grid_nn.hip), the optimiser, and the
 bulk of the graph network — the P x P edge MLPs, the node MLPs and the wide layers of the relation nets (Conv1d /
-Linear + BatchNorm1d + ReLU layers: csrc/mlp.hip, exact-fp32 MFMA) and the pose heads — are the HIP hot path; the small
-rest (7-wide pose encoder, 512 -> 1 relation head, relation-weighted mean, the GRU) stays on PyTorch-ROCm library ops.
+Linear + BatchNorm1d + ReLU layers: csrc/mlp.hip, exact-fp32 MFMA), the recurrence of RGL-NET's bidirectional GRU
+(csrc/gru.hip: all steps of both directions in one launch) and the pose heads — are the HIP hot path; the small rest
+(7-wide pose encoder, 512 -> 1 relation head, relation-weighted mean, the GRU's input projection) stays on PyTorch-ROCm
+library ops.
 
 Differences from the reference, none of them numerical beyond fp32 re-association:
   * part features are extracted with the mask-in / zeros-out PointNet entry (no boolean-mask sync);
@@ -100,7 +102,8 @@ class RelationNet(nn.Module):
 
     def forward(self, x):
         """x [B, P*P, 256] -> [B, P*P, 1]; the two wide layers on csrc/mlp.hip, the 512 -> 1 head on library ops."""
-        if x.is_cuda and x.numel() // x.shape[-1] >= _PairMLP.MIN_ROWS:
+        if (x.is_cuda and x.numel() // x.shape[-1] >= _PairMLP.MIN_ROWS and mlp_supported(x.shape[-1], 256)
+                and mlp_supported(256, 512)):
             lead = x.shape[:-1]
             h = mlp_layer(x.reshape(-1, x.shape[-1]), self.mlp1.weight, self.mlp1.bias, None, relu=True)
             h = mlp_layer(h, self.mlp2.weight, self.mlp2.bias, None, relu=True)
@@ -155,12 +158,7 @@ class DGLModel(BaseModel):
     # ---- pieces of one GNN iteration -----------------------------------------------------------------------
     def _extract_part_feats(self, part_pcs, part_valids):
         B, P, N, _ = part_pcs.shape
-        if hasattr(self.encoder, "forward_parts"):
-            return self.encoder.forward_parts(part_pcs.reshape(B * P, N, 3), part_valids.reshape(-1)).view(B, P, -1)
-        valid = (part_valids == 1).reshape(-1)
-        slots = torch.nonzero(valid, as_tuple=False).squeeze(1)
-        feats = self.encoder(part_pcs.reshape(B * P, N, 3).index_select(0, slots))
-        return feats.new_zeros(B * P, self.pc_feat_dim).index_copy(0, slots, feats).view(B, P, -1)
+        return self.encoder.forward_parts(part_pcs.reshape(B * P, N, 3), part_valids.reshape(-1)).view(B, P, -1)
 
     def _gather_same_class(self, data_dict):
         """Index groups of geometrically equivalent parts per sample (dgl/network.py:75-88); host-side, once per

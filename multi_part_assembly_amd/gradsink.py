@@ -57,3 +57,25 @@ class GradSink:
         if sink is not None and sink.on_ready is not None:
             for p in params:
                 sink.on_ready(p)
+
+
+class DeferredBackward:
+    """Lets the Trainer cut the backward pass in front of the part encoder (graph-mode data parallelism).
+
+    While `DeferredBackward.active` is a list, an encoder Function whose only gradients are parameter gradients (its
+    input points are data) does not run its backward kernels when autograd reaches it: it parks (run, grad_output) here
+    and returns.  `run_all()` then executes the parked backward calls — the Trainer captures that into a SECOND HIP graph,
+    so the all-reduce of the first gradient bucket (everything but the encoder) can be launched between the two graphs
+    and overlaps the encoder's backward, exactly like the eager path's bucket hooks."""
+    active: "list | None" = None
+
+    @staticmethod
+    def park(run, grad):
+        DeferredBackward.active.append((run, grad))
+
+    @staticmethod
+    def run_all():
+        items, DeferredBackward.active = DeferredBackward.active or [], None
+        for run, grad in items:
+            run(grad)
+        return len(items)

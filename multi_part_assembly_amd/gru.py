@@ -49,8 +49,21 @@ class _GRURecurrentFn(torch.autograd.Function):
         return ggi, None, gw, gb
 
 
-def supported(hidden, batch):
-    return hidden in (128, 256) and batch <= 64 and (48 * hidden + batch * hidden + batch * 64) * 4 <= 160 * 1024
+_RESIDENT: dict = {}
+
+
+def supported(hidden, batch, directions=2):
+    """Shapes csrc/gru.hip is built for AND a device that can hold the kernels' whole grid at once (their per-step
+    barrier needs every block resident: mpa_gru_resident asks the runtime's occupancy calculator; a partitioned or
+    smaller device answers no and the caller keeps the library GRU)."""
+    if not (hidden in (128, 256) and batch <= 64 and (48 * hidden + batch * hidden + batch * 64) * 4 <= 160 * 1024):
+        return False
+    key = (hidden, batch, directions, torch.cuda.current_device())
+    if key not in _RESIDENT:
+        ok = ctypes.c_int(0)
+        _lib.check(_lib.lib().mpa_gru_resident(directions, batch, hidden, ctypes.byref(ok)), "mpa_gru_resident")
+        _RESIDENT[key] = bool(ok.value)
+    return _RESIDENT[key]
 
 
 def gru_recurrent(gi, h0, whh, bhh):

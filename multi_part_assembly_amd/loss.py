@@ -154,6 +154,10 @@ class _AssemblyLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_losses, _grad_pts):
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("assembly loss: the backward pass reuses the forward's tile-sum area as scratch: a second "
+                               "backward over the same forward (retain_graph=True) is not supported — run the forward again")
+        ctx.consumed = True
         part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, fws, iws = ctx.saved_tensors
         B, P, N, _ = part_pcs.shape
         dev = part_pcs.device

@@ -37,6 +37,10 @@ class _MLPLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("MLP layer: the backward pass overwrites its saved workspace: a second backward over the "
+                               "same forward (retain_graph=True) is not supported — run the forward again")
+        ctx.consumed = True
         x, w, gamma, out, ws = ctx.saved_tensors
         relu, training, has_bias, has_bn = ctx.meta
         if has_bn and not training:

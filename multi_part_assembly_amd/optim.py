@@ -92,7 +92,8 @@ class FusedAdam:
         self.decoupled = (weight_decay > 0) if decoupled_weight_decay is None else decoupled_weight_decay
         self.decay_mask = decay_mask
         self.clip_grad = clip_grad if clip_grad else None
-        self.step_count = 0
+        self._clip_ws = None
+        self._step_count = 0
         self.grad_scale = 1.0
         self.numel = self.flat.numel
         self.flat_param, self.flat_grad = self.flat.flat_param, self.flat.flat_grad
@@ -111,12 +112,26 @@ class FusedAdam:
                 raise RuntimeError("FusedAdam.step: parameters must live on the GPU (HIP kernel only)")
             self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
             self._hyper_dev[5] = 1.0  # clip coefficient: no clipping
-            self._set_device_step(self.step_count)
-            if self.clip_grad is not None:
-                nbytes = __import__("ctypes").c_int64()
-                _lib.check(_lib.lib().mpa_grad_clip_workspace(__import__("ctypes").byref(nbytes)),
-                           "mpa_grad_clip_workspace")
-                self._clip_ws = torch.empty(nbytes.value // 8, dtype=torch.float64, device=dev)
+            self._set_device_step(self._step_count)
+
+    @property
+    def step_count(self):
+        return self._step_count
+
+    @step_count.setter
+    def step_count(self, value):
+        """The device keeps its own copy (bias corrections are computed there): assigning re-synchronises it."""
+        self._step_count = int(value)
+        if self._hyper_dev is not None:
+            self._set_device_step(self._step_count)
+
+    def _ensure_clip_ws(self):
+        """Allocated on first use, so `clip_grad` may be assigned after construction or after the first step."""
+        if self._clip_ws is None:
+            import ctypes
+            nbytes = ctypes.c_int64()
+            _lib.check(_lib.lib().mpa_grad_clip_workspace(ctypes.byref(nbytes)), "mpa_grad_clip_workspace")
+            self._clip_ws = torch.empty(nbytes.value // 8, dtype=torch.float64, device=self.flat_param.device)
 
     def _set_device_step(self, step):
         self._hyper_dev[4:5].view(torch.int32).fill_(int(step))
@@ -125,7 +140,7 @@ class FusedAdam:
         """Host-side bookkeeping in front of `step_dev`: advances the host mirror of the step count and rewrites
         lr / grad_scale on the device when they changed (fill_: no host staging buffer involved)."""
         self._ensure_hyper()
-        self.step_count += 1
+        self._step_count += 1  # (the device advances its own counter inside step_dev)
         if self._uploaded != (float(self.lr), float(self.grad_scale)):
             self._hyper_dev[0:1].fill_(float(self.lr))
             self._hyper_dev[3:4].fill_(float(self.grad_scale))
@@ -138,7 +153,8 @@ class FusedAdam:
         lib = _lib.lib()
         with torch.cuda.device(dev):
             stream = _lib.current_stream(dev)
-            if self.clip_grad is not None:
+            if self.clip_grad:
+                self._ensure_clip_ws()
                 st = lib.mpa_grad_clip_coef(_lib.ptr(self.flat_grad), self.numel, float(self.clip_grad),
                                             self._hyper_dev.data_ptr() + 12, 1.0, _lib.ptr(self._clip_ws),
                                             self._hyper_dev.data_ptr() + 20, stream)
@@ -161,11 +177,9 @@ class FusedAdam:
                 "exp_avg_sq": self.exp_avg_sq.clone()}
 
     def load_state_dict(self, state):
-        self.step_count, self.lr = state["step"], state["lr"]
+        self.step_count, self.lr = state["step"], state["lr"]  # (the setter re-synchronises the device counter)
         self.exp_avg.copy_(state["exp_avg"])
         self.exp_avg_sq.copy_(state["exp_avg_sq"])
-        if self._hyper_dev is not None:
-            self._set_device_step(self.step_count)
 
 
 def cosine_warmup_lr(total_epochs, warmup_epochs, max_lr, min_lr):

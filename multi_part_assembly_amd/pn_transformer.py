@@ -42,14 +42,9 @@ class PNTransformer(BaseModel):
     def _extract_part_feats(self, part_pcs, part_valids):
         """[B, P, N, 3] -> [B, P, C]; padded slots get zeros (network.py:59-68)."""
         B, P, N, _ = part_pcs.shape
-        if hasattr(self.encoder, "forward_parts"):  # HIP PointNet: mask in, zeros out, no host sync
-            feats = self.encoder.forward_parts(part_pcs.reshape(B * P, N, 3), part_valids.reshape(-1))
-            return feats.view(B, P, self.pc_feat_dim)
-        valid = (part_valids == 1).reshape(-1)
-        slots = torch.nonzero(valid, as_tuple=False).squeeze(1)          # [n] flat part indices
-        feats = self.encoder(part_pcs.reshape(B * P, N, 3).index_select(0, slots))
-        out = feats.new_zeros(B * P, self.pc_feat_dim)
-        return out.index_copy(0, slots, feats).view(B, P, self.pc_feat_dim)
+        # mask in, zeros out: the valid parts are counted and compacted on the device, no host sync
+        feats = self.encoder.forward_parts(part_pcs.reshape(B * P, N, 3), part_valids.reshape(-1))
+        return feats.view(B, P, self.pc_feat_dim)
 
     def forward(self, data_dict):
         feats = data_dict.get("pre_pose_feats", None)
@@ -172,6 +167,12 @@ class PNTransformerRefine(PNTransformer):
 
 def build_model(cfg):
     """Registry of reference models/__init__.py:10-26 (the LSTM / identity baselines are out of scope)."""
+    model = _build_model(cfg)
+    TransformerEncoder.assign_dropout_salts(model)  # sibling encoders draw different masks, reproducibly
+    return model
+
+
+def _build_model(cfg):
     if cfg.model.name == "pn_transformer":
         return PNTransformer(cfg)
     if cfg.model.name == "pn_transformer_refine":

@@ -8,8 +8,11 @@ With `use_graph=True` the whole step (several hundred launches, most of them tin
 into a HIP graph and replayed: the launch shapes are static by construction (all B*P part slots +
 masks, no compaction), the batch is copied into static input tensors, and the optimiser's
 per-step scalars live in device memory.  On one GPU the graph holds zero_grad + forward + backward +
-Adam; with data parallelism it holds zero_grad + forward + backward, the gradient all-reduce and Adam
-run eagerly behind it.
+Adam.  With data parallelism the step is TWO graphs cut in front of the part encoder's backward
+(`DeferredBackward`): graph A = zero_grad + forward + backward of everything but the encoder, then the
+all-reduce of the first gradient bucket is launched (asynchronously, on the collective's stream), graph B =
+the encoder's backward runs under it, then the second bucket's all-reduce and Adam — the same two-bucket
+overlap as the eager path's hooks.
 
 Status: bit-identical to eager launches (tests/test_model_gpu.py) and stable at the full benchmark size.  Two
 things make that true: the library issues no hipMemsetAsync / hipMemcpyAsync (as graph NODES they returned stale
@@ -23,7 +26,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-from .gradsink import GradSink
+from .gradsink import DeferredBackward, GradSink
 from .dp import BucketedGradReducer, broadcast_from_rank0, bucket_sizes_for, ordered_parameters
 from .optim import FlatBuffers, FusedAdam, cosine_warmup_lr, decay_mask_for
 
@@ -50,10 +53,13 @@ class Trainer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         broadcast_from_rank0(self.flat, model, process_group)
         self.group = process_group
-        # graph mode replaces the backward-overlapped bucket hooks by one all-reduce after the replay
-        self.reducer = None if use_graph else BucketedGradReducer(
-            self.flat, bucket_sizes_for(model, self.flat), process_group)
-        self.sink = GradSink(on_ready=self.reducer._on_grad if self.reducer is not None and self.world > 1 else None)
+        # eager: bucket hooks fire during backward; graph mode: the same two buckets, reduced between / behind the two
+        # graphs (the reducer only provides the bucket slices there: its hooks are switched off)
+        self.reducer = BucketedGradReducer(self.flat, bucket_sizes_for(model, self.flat), process_group)
+        if use_graph:
+            self.reducer.enabled = False
+        self._graph_b = None
+        self.sink = GradSink(on_ready=self.reducer._on_grad if not use_graph and self.world > 1 else None)
         self.set_epoch(0)
 
     def set_epoch(self, epoch):
@@ -78,11 +84,41 @@ class Trainer:
         self._static_batch = {k: v.clone() for k, v in self._tensor_items(data_dict).items()}
         self._loss_buf = torch.zeros((), dtype=torch.float32, device=self.flat.flat_param.device)
         self._graph = torch.cuda.CUDAGraph()
-        # thread_local: RCCL's watchdog thread may touch the HIP runtime while we capture
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-            self._static_loss = self._fwd_bwd(self._static_batch, self._loss_buf)
-            if self.world == 1:
+        if self.world == 1:
+            # thread_local: RCCL's watchdog thread may touch the HIP runtime while we capture
+            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+                self._static_loss = self._fwd_bwd(self._static_batch, self._loss_buf)
                 self.optimizer.step_dev()
+            return
+        # data parallel: graph A stops in front of the encoder's backward, graph B is the encoder's backward
+        self.sink.__enter__()  # one sink (one set of use counts) across both graphs
+        try:
+            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+                self.optimizer.zero_grad()
+                DeferredBackward.active = []
+                loss = self.model.training_step(self._static_batch, 0)
+                self._loss_buf.copy_(loss.detach())
+                loss.backward()
+            self._static_loss = self._loss_buf
+            parked = DeferredBackward.active
+            if parked:
+                self._graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph_b, pool=self._graph.pool(), capture_error_mode="thread_local"):
+                    DeferredBackward.run_all()
+        finally:
+            DeferredBackward.active = None
+            self.sink.__exit__(None, None, None)
+
+    def _reduce_buckets_around(self, run_second_half):
+        """bucket 0 (everything but the encoder) is reduced WHILE `run_second_half` (the encoder's backward) runs; the
+        encoder's bucket behind it."""
+        buckets = self.reducer.buckets
+        first = dist.all_reduce(buckets[0]["slice"], group=self.group, async_op=True) if len(buckets) > 1 else None
+        run_second_half()
+        last = dist.all_reduce(buckets[-1]["slice"], group=self.group, async_op=True)
+        if first is not None:
+            first.wait()
+        last.wait()
 
     def _graph_step(self, data_dict):
         self.model.train()
@@ -107,7 +143,10 @@ class Trainer:
                 mod.advance_seed()
         self._graph.replay()
         if self.world > 1:
-            dist.all_reduce(self.flat.flat_grad, group=self.group)
+            if self._graph_b is not None:
+                self._reduce_buckets_around(self._graph_b.replay)
+            else:  # nothing was deferred (an encoder outside the fused kernels): one all-reduce behind the replay
+                dist.all_reduce(self.flat.flat_grad, group=self.group)
             self.optimizer.step_dev()
         return self._static_loss
 

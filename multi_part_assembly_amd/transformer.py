@@ -74,7 +74,6 @@ class _TransformerFn(torch.autograd.Function):
 
 
 class TransformerEncoder(nn.Module):
-    _instances = 0
 
     def __init__(self, d_model, num_heads, ffn_dim, num_layers, norm_first=True, dropout=0.1,
                  out_dim=None):
@@ -88,12 +87,23 @@ class TransformerEncoder(nn.Module):
         self.num_heads, self.norm_first = num_heads, norm_first
         self._calls = 0
         self._seed_dev = None
-        TransformerEncoder._instances += 1
-        self._instance = TransformerEncoder._instances  # mixed into the seed: sibling modules draw different masks
+        # Mixed into the dropout seed so that sibling encoders of one model draw different masks.  The owning model
+        # numbers its encoders in module order (`assign_dropout_salts`): a position INSIDE the model, stable from run to
+        # run and independent of how many encoders the process built before (a class-level counter was not).
+        self._instance = 1
         self._warned = False
         # shapes csrc/transformer.hip is built for (every shipped config: 256 / 8 heads / 1024 / pre-LN)
         self.native = (norm_first and d_model % 64 == 0 and ffn_dim % 64 == 0 and d_model % num_heads == 0
                        and d_model // num_heads <= 64 and num_layers <= 16)
+
+    @staticmethod
+    def assign_dropout_salts(model):
+        """Number the TransformerEncoder modules of `model` 1, 2, ... in `model.modules()` order."""
+        k = 0
+        for m in model.modules():
+            if isinstance(m, TransformerEncoder):
+                k += 1
+                m._instance = k
 
     def advance_seed(self):
         """New dropout seed for the next forward (a counter hashed with torch's seed), written to device memory."""

@@ -41,12 +41,47 @@ def test_bench_line_has_the_contract_keys(cuda_device):
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
 
 
-def test_bench_variants_are_labelled(cuda_device):
-    d = _run("--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dtype", "bf16")
-    assert d["dtype"] == "bf16" and "precision_note" in d["config"] and "cpu_baseline" not in d
-    d = _run("--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--config", "dgl_dgcnn")
-    assert d["config"]["name"] == "c3" and "knn" in d["roofline"]["kernel"]
-    assert d["roofline"]["launches"] == 2
+def _committed_ms(tag):
+    """ms_per_step of the newest committed bench line profiles/rNN_<tag>_bench_line.json."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_bench_line.json")))
+    assert files, f"no committed bench line for {tag}"
+    with open(files[-1]) as f:
+        return json.loads(f.read().strip().splitlines()[-1])["ms_per_step"], os.path.basename(files[-1])
+
+
+@pytest.mark.parametrize("tag,flags", [("c3", ("--config", "c3")), ("c5", ("--config", "c5")),
+                                       ("c2_bf16", ("--dtype", "bf16"))])
+def test_other_configs_hold_their_committed_step_time(cuda_device, capsys, tag, flags):
+    """BASELINE.json configs[2] / configs[4] and the bf16 variant line, 10 timed steps each under the driver's own GPU
+    test run: the JSON line is printed (so the run's log witnesses the number) and the step time must be within 25 % of
+    the builder-run line committed under profiles/."""
+    d = _run("--steps", "10", "--warmup", "3", "--no-cpu-baseline", *flags)
+    want, src = _committed_ms(tag)
+    with capsys.disabled():
+        slim = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "dtype")}
+        slim["config"] = d["config"]["name"]
+        slim["roofline"] = {k: d["roofline"][k] for k in ("kernel", "avg_launch_ms", "frac")} if d["roofline"] else None
+        print(f"\n  BENCH {tag}: {json.dumps(slim)}  (committed: {want:.3f} ms in profiles/{src})", end="")
+    assert d["ms_per_step"] < 1.25 * want, (d["ms_per_step"], want, src)
+    if tag == "c2_bf16":
+        assert d["dtype"] == "bf16" and "precision_note" in d["config"] and "cpu_baseline" not in d
+    else:
+        assert d["config"]["name"] == tag and "knn" in d["roofline"]["kernel"] and d["roofline"]["launches"] == 10
+        assert d["roofline"]["binding"]["bound"] == "mfma_bf16"
+
+
+def test_plumbing_config_with_its_cpu_baseline_and_self_check(cuda_device, capsys):
+    """configs[0] (B-Global, semantic flags, P = 2, B = 4) with its full-size CPU baseline on all physical cores, and the
+    `--self-check` leg: the mean of 40 further timed steps stays within 15 % of the 10-step mean."""
+    d = _run("--config", "c1", "--steps", "10", "--warmup", "3", "--self-check", "40")
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "B=4," in c["sample"]
+    sc = d["self_check"]
+    assert sc["steps"] == 40 and abs(sc["ratio_to_timed_mean"] - 1.0) < 0.15, sc
+    with capsys.disabled():
+        print(f"\n  BENCH c1: {d['ms_per_step']:.3f} ms/step, {d['value']:.0f} parts/s; CPU {c['value']:.1f} parts/s on "
+              f"{c['cores']} cores; self-check {sc}", end="")
 
 
 def test_kernel_timer_scope(cuda_device):

@@ -56,7 +56,24 @@ def _worker(rank, world, port, out_dir):
         results.append((flat.flat_grad * scale).clone())
         with torch.no_grad():
             flat.flat_param -= 0.1 * flat.flat_grad * scale
-    torch.save({"grads": results, "param": flat.flat_param.clone(),
+    # the collective break-down bench.py reports with several ranks (dp.measure_collectives), on a stand-in trainer
+    from multi_part_assembly_amd.dp import measure_collectives
+
+    class ToyTrainer:
+        pass
+
+    tr = ToyTrainer()
+    tr.reducer, tr.flat = reducer, flat
+
+    def train_step(batch, i):
+        flat.zero_grad()
+        model(batch).backward()
+        reducer.finish()
+
+    tr.train_step = train_step
+    coll = measure_collectives(tr, _shard(rank), steps=2, reps=2)
+    assert reducer.enabled
+    torch.save({"grads": results, "param": flat.flat_param.clone(), "collectives": coll,
                 "offsets": flat.offsets}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
@@ -70,6 +87,15 @@ def test_two_rank_gloo_matches_single_process_emulation(tmp_path):
     assert torch.equal(outs[0]["param"], outs[1]["param"])
     for a, b in zip(outs[0]["grads"], outs[1]["grads"]):
         assert torch.equal(a, b)
+
+    # the multi-rank bench fields: two buckets (head: 2 + 5 unused + 16 = 23 floats ... in FlatBuffers' padded layout),
+    # a stand-alone all-reduce time per bucket and the collective-free step time, identical on both ranks (MAX-reduced)
+    for o in outs:
+        c = o["collectives"]
+        assert c["world"] == 2 and len(c["bucket_bytes"]) == 2 == len(c["allreduce_ms"])
+        assert sum(c["bucket_bytes"]) == outs[0]["grads"][0].numel() * 4
+        assert all(t > 0 for t in c["allreduce_ms"]) and c["local_ms_per_step"] > 0
+    assert outs[0]["collectives"] == outs[1]["collectives"]
 
     # single-process emulation: rank-0 init, per-shard BN statistics, mean of shard gradients
     torch.manual_seed(0)

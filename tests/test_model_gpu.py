@@ -72,13 +72,17 @@ def test_encoder_matches_reference(golden, cuda_device, name, feat):
 
 @pytest.mark.parametrize("C", [3, 64, 128])
 def test_knn_kernel_selects_the_k_best(golden, cuda_device, C):
-    """mpa_knn against fp64 scores of the reference's formula (dgcnn.py:8-15): 20 distinct neighbours per point,
-    best first, self included, and none of them worse than the true 20th best by more than rounding."""
-    from multi_part_assembly_amd.encoder import knn_indices
+    """mpa_knn_exact against fp64 scores of the reference's formula (dgcnn.py:8-15): 20 distinct neighbours per point,
+    best first, self included, and none of them worse than the true 20th best by more than rounding — a property
+    check that does not go through the C oracle (tests/test_dgcnn_gpu.py holds the index-exact comparisons)."""
+    from multi_part_assembly_amd.encoder import knn_exact
     g = torch.Generator().manual_seed(C)
     n, N, k = 3, 300, 20
     x = torch.randn(n, N, C, generator=g) * (0.3 if C == 3 else 1.0)
-    idx = knn_indices(x.reshape(n * N, C).to(cuda_device).contiguous(), n, N, k).cpu().view(n, N, k).long()
+    rows = x.reshape(n * N, C)
+    if C == 3:
+        rows = torch.cat([rows, torch.zeros(n * N, 1)], dim=1)
+    idx = knn_exact(rows.to(cuda_device).contiguous(), n, N, C).cpu().view(n, N, k).long()
     xd = x.double()
     score = -((xd[:, :, None, :] - xd[:, None, :, :]) ** 2).sum(-1)            # [n, N, N]
     mine = torch.gather(score, 2, idx)
@@ -88,58 +92,14 @@ def test_knn_kernel_selects_the_k_best(golden, cuda_device, C):
     assert (mine[..., :-1] >= mine[..., 1:] - tol).all()                        # best first
     assert (idx.sort(-1)[0].diff(dim=-1) > 0).all()                            # distinct
     assert (idx[..., 0] == torch.arange(N)[None]).all()                        # the point itself comes first
-    if C == 3:  # the reference's own index sets on its fixture cloud (first EdgeConv layer)
-        z = golden("dgcnn")
-        xr = T(z["x"])
-        got = knn_indices(xr.reshape(-1, 3).to(cuda_device).contiguous(), xr.shape[0], xr.shape[1], k).cpu()
-        got = got.view(xr.shape[0], xr.shape[1], k).long().sort(-1)[0]
-        want = torch.from_numpy(z["knn_idx_layer1"]).long().sort(-1)[0]
-        assert torch.equal(got, want)                                         # same arithmetic as the reference's CPU path
 
 
-def test_edge_aggregate_matches_edge_tensor_formulation(cuda_device):
-    """The fused EdgeConv aggregation (U_j + V_i, BatchNorm2d over all edges, LeakyReLU, max_k) against the
-    reference's formulation on materialised edge tensors (dgcnn.py:18-38,76-80) written with torch ops."""
-    import torch.nn.functional as Fn
-    from multi_part_assembly_amd.encoder import _EdgeAggFn, knn_indices
-    torch.manual_seed(9)
-    n, N, C, CO, k = 3, 200, 64, 128, 20
-    x = torch.randn(n, N, C, device=cuda_device)
-    w = (torch.randn(CO, 2 * C, device=cuda_device) / (2 * C) ** 0.5).requires_grad_()
-    gamma = (torch.rand(CO, device=cuda_device) + 0.5)
-    gamma[::5] *= -1.0                                                         # negative scales take the min branch
-    gamma.requires_grad_()
-    beta = (0.1 * torch.randn(CO, device=cuda_device)).requires_grad_()
-    wout = torch.randn(n * N, CO, device=cuda_device)
-    idx = knn_indices(x.reshape(n * N, C).contiguous(), n, N, k)
-    rm, rv = torch.zeros(CO, device=cuda_device), torch.ones(CO, device=cuda_device)
-
-    xs = x.clone().requires_grad_()
-    w_stack = torch.cat([w[:, :C], w[:, C:] - w[:, :C]], dim=0)
-    out = _EdgeAggFn.apply(xs.reshape(n * N, C) @ w_stack.t(), idx, gamma, beta, (rm, rv), True, 0.1, 1e-5, n, N)
-    (out * wout).sum().backward()
-    got = [out.detach(), xs.grad.clone(), w.grad.clone(), gamma.grad.clone(), beta.grad.clone(), rm.clone(), rv.clone()]
-
-    w.grad = gamma.grad = beta.grad = None
-    xr = x.clone().requires_grad_()
-    rm2, rv2 = torch.zeros(CO, device=cuda_device), torch.ones(CO, device=cuda_device)
-    nbr = torch.gather(xr[:, None].expand(n, N, N, C), 2, idx.view(n, N, k, 1).long().expand(n, N, k, C))
-    ctr = xr[:, :, None].expand(n, N, k, C)
-    edge = torch.cat((nbr - ctr, ctr), dim=3).permute(0, 3, 1, 2)              # [n, 2C, N, k]
-    e = Fn.conv2d(edge, w[:, :, None, None])
-    e = Fn.leaky_relu(Fn.batch_norm(e, rm2, rv2, gamma, beta, True, 0.1, 1e-5), 0.2)
-    ref = e.max(dim=-1)[0].permute(0, 2, 1).reshape(n * N, CO)
-    (ref * wout).sum().backward()
-    want = [ref.detach(), xr.grad, w.grad, gamma.grad, beta.grad, rm2, rv2]
-    for a, b, name in zip(got, want, ("out", "dx", "dw", "dgamma", "dbeta", "running_mean", "running_var")):
-        assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-4, name
-    # the backward gathers over the transposed kNN graph in a fixed order: same call, bit-identical gradients
-    w.grad = gamma.grad = beta.grad = None
-    xs2 = x.clone().requires_grad_()
-    rm3, rv3 = torch.zeros(CO, device=cuda_device), torch.ones(CO, device=cuda_device)
-    out2 = _EdgeAggFn.apply(xs2.reshape(n * N, C) @ w_stack.t(), idx, gamma, beta, (rm3, rv3), True, 0.1, 1e-5, n, N)
-    (out2 * wout).sum().backward()
-    assert torch.equal(out2, got[0]) and torch.equal(xs2.grad, got[1]) and torch.equal(gamma.grad, got[3])
+def test_dgcnn_outside_the_fused_range_raises(cuda_device):
+    """There is no second DGCNN path: sizes the one-call encoder is not built for are refused, loudly."""
+    enc = build_encoder("dgcnn", 128).to(cuda_device)
+    for N in (19, 1025):
+        with pytest.raises(NotImplementedError):
+            enc(torch.zeros(2, N, 3, device=cuda_device))
 
 
 def test_pointnet_masked_parts_equal_compacted(cuda_device):
