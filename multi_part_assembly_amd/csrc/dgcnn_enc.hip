@@ -27,6 +27,17 @@
 #include "common.h"
 #include "coop_reduce.h"
 #include "dg_gemm.h"
+#include "dg_gemm_split.h"
+#ifndef DG_GEMM_SPLIT  // 1: fp32-grade GEMMs on the bf16 matrix cores (dg_gemm_split.h); 0: v_mfma_f32_32x32x2_f32 (dg_gemm.h)
+#define DG_GEMM_SPLIT 1
+#endif
+#if DG_GEMM_SPLIT
+#define DG_NT_KERNEL gemm_nt_split_kernel
+#define DG_TN_KERNEL gemm_tn_split_kernel
+#else
+#define DG_NT_KERNEL gemm_nt_kernel
+#define DG_TN_KERNEL gemm_tn_kernel
+#endif
 #include "dg_knn.h"
 #include "dg_knn_fast.h"
 
@@ -1010,11 +1021,11 @@ void gemm_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, 
              const int* hdr, hipStream_t s) {
   const unsigned gx = DG_GEMM_GRID_X(Rmax);
   if (Nout % 128 == 0) {
-    if (accum) launch(gemm_nt_kernel<128, true>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
-    else launch(gemm_nt_kernel<128, false>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+    if (accum) launch(DG_NT_KERNEL<128, true>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+    else launch(DG_NT_KERNEL<128, false>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
   } else {
-    if (accum) launch(gemm_nt_kernel<64, true>, dim3(gx, Nout / 64), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
-    else launch(gemm_nt_kernel<64, false>, dim3(gx, Nout / 64), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+    if (accum) launch(DG_NT_KERNEL<64, true>, dim3(gx, Nout / 64), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+    else launch(DG_NT_KERNEL<64, false>, dim3(gx, Nout / 64), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
   }
 }
 
@@ -1026,8 +1037,8 @@ void gemm_tn(const float* Y, int ldy, int Nout, const float* X, int ldx, int K, 
   const int chunks = tn * tk >= 4 ? kTnChunks : (int)(4 * kTnChunks / (tn * tk));
   const int rows_per_chunk = (int)(((Rmax + chunks - 1) / chunks + 31) / 32 * 32);
   const dim3 grid(tn, tk, (unsigned)chunks);
-  if (K % 128 == 0) launch(gemm_tn_kernel<128>, grid, dim3(kGT), s, Y, ldy, Nout, X, ldx, K, part, rows_per_chunk, hdr);
-  else launch(gemm_tn_kernel<64>, grid, dim3(kGT), s, Y, ldy, Nout, X, ldx, K, part, rows_per_chunk, hdr);
+  if (K % 128 == 0) launch(DG_TN_KERNEL<128>, grid, dim3(kGT), s, Y, ldy, Nout, X, ldx, K, part, rows_per_chunk, hdr);
+  else launch(DG_TN_KERNEL<64>, grid, dim3(kGT), s, Y, ldy, Nout, X, ldx, K, part, rows_per_chunk, hdr);
   const long long elems = (long long)Nout * K;
   launch_tn_reduce(part, chunks, elems, out, s);
 }

@@ -12,6 +12,17 @@
 #include "common.h"
 #include "coop_reduce.h"
 #include "dg_gemm.h"
+#include "dg_gemm_split.h"
+#ifndef DG_GEMM_SPLIT  // 1: fp32-grade GEMMs on the bf16 matrix cores (dg_gemm_split.h); 0: v_mfma_f32_32x32x2_f32 (dg_gemm.h)
+#define DG_GEMM_SPLIT 1
+#endif
+#if DG_GEMM_SPLIT
+#define DG_NT_KERNEL gemm_nt_split_kernel
+#define DG_TN_KERNEL gemm_tn_split_kernel
+#else
+#define DG_NT_KERNEL gemm_nt_kernel
+#define DG_TN_KERNEL gemm_tn_kernel
+#endif
 
 namespace {
 
@@ -265,8 +276,8 @@ void launch(Kern kern, dim3 grid, dim3 block, hipStream_t s, Args... args) {
 void ml_gemm_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, int Nout, int64_t R, const int* hdr,
                 hipStream_t s) {
   const unsigned gx = DG_GEMM_GRID_X(R);
-  if (Nout % 128 == 0) launch(gemm_nt_kernel<128, false>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
-  else launch(gemm_nt_kernel<64, false>, dim3(gx, Nout / 64), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+  if (Nout % 128 == 0) launch(DG_NT_KERNEL<128, false>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+  else launch(DG_NT_KERNEL<64, false>, dim3(gx, Nout / 64), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
 }
 
 }  // namespace
@@ -347,10 +358,10 @@ extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int
     const int rows_per_chunk = (int)(((R + chunks - 1) / chunks + 31) / 32 * 32);
     const dim3 grid((unsigned)((N + 127) / 128), (unsigned)(K % 128 == 0 ? K / 128 : K / 64), (unsigned)chunks);
     if (K % 128 == 0)
-      launch(gemm_tn_kernel<128>, grid, dim3(kGT), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
+      launch(DG_TN_KERNEL<128>, grid, dim3(kGT), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
              rows_per_chunk, (const int*)m.hdr);
     else
-      launch(gemm_tn_kernel<64>, grid, dim3(kGT), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
+      launch(DG_TN_KERNEL<64>, grid, dim3(kGT), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
              rows_per_chunk, (const int*)m.hdr);
     const long long elems = (long long)N * K;
     dg::launch_tn_reduce(m.tnpart, chunks, elems, grad_w, s);
