@@ -15,8 +15,8 @@
 //           indices go to a per-lane list in LDS, then to HBM.
 //   RERANK  (knn_rerank_kernel)  the pinned score — fmaf chain in the matrix-core order, exactly dg_knn.h's / the
 //           oracle's arithmetic — of the survivors only, and the 20 best by (score descending, index ascending).
-//   A query whose survivor list overflows (mass ties: duplicated points, lattices) flags its 128-query block; the
-//   exhaustive kernel of dg_knn.h then recomputes exactly the flagged blocks (it exits at once elsewhere).
+//   A query whose survivor list overflows (mass ties: duplicated points, lattices; about one list in 10^4 on random
+//   data) is marked; the rerank kernel scores ALL N candidates of such a query with the pinned chain instead.
 // Result: bit-identical indices to dg_knn.h on every input (tests/test_dgcnn_gpu.py: index-exact against oracle/knn_ref.c
 // and against the reference's own graphs).
 //
@@ -44,9 +44,11 @@ struct KnnFast {
   static constexpr float kappa = C > 64 ? 1.15e-4f : 8.5e-5f;
 };
 
-constexpr int kKfCap = 24;     // survivor slots per (query, lane half); the expected load is ~10.5 (an overflow — about
-                               // one list in 10^4 — only costs the exhaustive recomputation of its 128-query block)
+constexpr int kKfCap = 32;     // survivor slots per (query, lane half): the expected load is ~10.5, the largest of 2.5 M lists
+                               // of the benchmark's features 27; a list that overflows costs its query an exhaustive scan
+                               // in the rerank kernel (~0.2 ms for the launch: one block's tail)
 constexpr int kKfQB = 256;     // queries per block of the bound / collect kernels (4 waves x 2 sets of 32)
+constexpr int kKfOverflow = 255;  // survivor count of a list that overflowed: the rerank kernel scans that query exhaustively
 
 __device__ __forceinline__ float next_float(float x) { return -prev_float(-x); }
 
@@ -119,7 +121,7 @@ template <int C, bool COLLECT, int SETS, int WAVES, int MODE = 0>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void knn_gram_kernel(
     const unsigned short* __restrict__ xs, const float* __restrict__ nsc, const float* __restrict__ nl,
     const float* __restrict__ nu, int N, float* __restrict__ theta, unsigned short* __restrict__ surv,
-    unsigned char* __restrict__ scnt, int* __restrict__ flags, const int* __restrict__ hdr) {
+    unsigned char* __restrict__ scnt, const int* __restrict__ hdr) {
   using TL = KfTile<C>;
   static_assert(SETS * WAVES * 32 == kKfQB, "a block handles 256 queries");
   constexpr int KS = TL::KS, ROWB = TL::ROWB, NT = 64 * WAVES;
@@ -286,8 +288,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void knn_gram_kerne
         const int n = cnt[s] < kKfCap ? cnt[s] : kKfCap;
         unsigned short* dst = surv + (row * 2 + h) * kKfCap;
         for (int e = 0; e < n; ++e) dst[e] = mylst[(s * kKfCap + e) * 64 + lane];
-        scnt[row * 2 + h] = (unsigned char)n;
-        if (cnt[s] > kKfCap) flags[v * ((N + 127) / 128) + qi / 128] = 1;
+        scnt[row * 2 + h] = cnt[s] > kKfCap ? (unsigned char)kKfOverflow : (unsigned char)n;
       }
     }
   }
@@ -326,9 +327,9 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
   constexpr int KH = C / 2, MAXS = 2 * kKfCap, SL = KH / 16;  // slices of 16 + 16 chain positions
   __shared__ __attribute__((aligned(16))) float qrow[kRrQ][C + 4];
   __shared__ float qnorm[kRrQ];
-  __shared__ int qoff[kRrQ + 1], qcnt[kRrQ];
+  __shared__ int qoff[kRrQ + 1], qcnt[kRrQ], qover[kRrQ];
   __shared__ unsigned pq[kRrQ * MAXS];                 // pair -> query << 16 | survivor index
-  __shared__ unsigned skey[kRrQ * MAXS];               // pair -> ordered score bits
+  __shared__ unsigned skey[kRrQ * MAXS > kMaxN ? kRrQ * MAXS : kMaxN];  // pair -> ordered score bits (or: all N candidates of one query)
   int v, qblk;
   knn_block(v, qblk);  // all query blocks of a cloud on one XCD: its L2 holds the cloud's rows for every gather
   if (v >= hdr[0]) return;
@@ -341,10 +342,15 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
     const int qi = qbase + q < N ? qbase + q : N - 1;
     *reinterpret_cast<float4*>(&qrow[q][4 * w]) = *reinterpret_cast<const float4*>(xp + (long long)qi * ld + 4 * w);
   }
-  if (wave == 0) {  // survivor counts of the 16 queries and their exclusive prefix sums
+  if (wave == 0) {  // survivor counts of the 16 queries (an overflowed list: none, the query is scanned below) and their prefix sums
     const int q = lane & 15, qi = qbase + q;
     const long long row = (long long)v * N + (qi < N ? qi : N - 1);
-    const int c = (lane < kRrQ && qi < N) ? scnt[row * 2] + scnt[row * 2 + 1] : 0;
+    int c = 0, over = 0;
+    if (lane < kRrQ && qi < N) {
+      const int a = scnt[row * 2], b = scnt[row * 2 + 1];
+      over = a == kKfOverflow || b == kKfOverflow;
+      c = over ? 0 : a + b;
+    }
     int incl = c;
 #pragma unroll
     for (int d = 1; d < kRrQ; d <<= 1) {
@@ -353,6 +359,7 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
     }
     if (lane < kRrQ) {
       qcnt[q] = c;
+      qover[q] = over;
       qoff[q] = incl - c;
       qnorm[q] = np_[qi < N ? qi : N - 1];
       if (lane == kRrQ - 1) qoff[kRrQ] = incl;
@@ -424,8 +431,50 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
       rank += (os > ms || (os == ms && oj < mj)) ? 1 : 0;
     }
     rank = kf_quad_sum(rank);
-    // (cnt < 20 cannot happen for a non-overflowing query; flagged blocks are recomputed by the exhaustive kernel)
     if (ql == 0 && cnt >= kNbr && rank < kNbr) idx[((long long)v * N + qbase + q) * kNbr + rank] = (IdxT)mj;
+  }
+  // ---- queries whose survivor list overflowed: every candidate gets the pinned score (block-uniform loop; rare) ----------
+  for (int q = 0; q < kRrQ; ++q) {
+    if (!qover[q]) continue;
+    __syncthreads();  // skey is reused
+    for (int cj = quad; cj < N; cj += 64) {
+      const float* row_lo = xp + (long long)cj * ld + 4 * ql;
+      float acc = 0.0f;
+#pragma unroll 1  // (a rare path: keep its registers out of the kernel's budget)
+      for (int r = 0; r < SL; ++r) {
+        const float4 a = *reinterpret_cast<const float4*>(row_lo + 16 * r);
+        const float4 c = *reinterpret_cast<const float4*>(row_lo + KH + 16 * r);
+        const float4 pp = *reinterpret_cast<const float4*>(&qrow[q][16 * r + 4 * ql]);
+        const float4 rr = *reinterpret_cast<const float4*>(&qrow[q][KH + 16 * r + 4 * ql]);
+        auto step = [&](float in) {
+          in = __builtin_fmaf(a.x, pp.x, in);
+          in = __builtin_fmaf(c.x, rr.x, in);
+          in = __builtin_fmaf(a.y, pp.y, in);
+          in = __builtin_fmaf(c.y, rr.y, in);
+          in = __builtin_fmaf(a.z, pp.z, in);
+          in = __builtin_fmaf(c.z, rr.z, in);
+          in = __builtin_fmaf(a.w, pp.w, in);
+          in = __builtin_fmaf(c.w, rr.w, in);
+          return in;
+        };
+        acc = kf_quad_bcast<0>(step(acc));
+        acc = kf_quad_bcast<1>(step(acc));
+        acc = kf_quad_bcast<2>(step(acc));
+        acc = kf_quad_bcast<3>(step(acc));
+      }
+      if (ql == 0) skey[cj] = kf_ordered((-np_[cj] + 2.0f * acc) - qnorm[q]);
+    }
+    __syncthreads();
+    for (int cj = quad; cj < N; cj += 64) {
+      const unsigned ms = skey[cj];
+      int rank = 0;
+      for (int m = ql; m < N; m += 4) {
+        const unsigned os = skey[m];
+        rank += (os > ms || (os == ms && m < cj)) ? 1 : 0;
+      }
+      rank = kf_quad_sum(rank);
+      if (ql == 0 && rank < kNbr) idx[((long long)v * N + qbase + q) * kNbr + rank] = (IdxT)cj;
+    }
   }
 }
 

@@ -38,6 +38,9 @@
 #define DG_NT_KERNEL gemm_nt_kernel
 #define DG_TN_KERNEL gemm_tn_kernel
 #endif
+#include <cstdio>
+#include <vector>
+
 #include "dg_knn.h"
 #include "dg_knn_fast.h"
 
@@ -894,7 +897,6 @@ struct KnnWs {
   unsigned short *xs, *surv;
   float *nl, *nu, *theta;
   unsigned char* scnt;
-  int* flags;
 };
 
 template <typename Take>
@@ -907,35 +909,51 @@ KnnWs knn_carve(Take&& take, int64_t M, int64_t N) {
   k.nu = reinterpret_cast<float*>(take(4 * R));
   k.theta = reinterpret_cast<float*>(take(4 * R));
   k.scnt = reinterpret_cast<unsigned char*>(take(2 * R));
-  k.flags = reinterpret_cast<int*>(take(4 * (M + 8) * ((N + 127) / 128)));
   return k;
 }
 
 // kNN graph of n (<= M: launch bound) clouds in C = 64 / 128-d feature space: row norms, bf16 split, bound pass, collect
-// pass, exact rerank of the survivors, and the exhaustive search of the (rare) flagged 128-query blocks.  Bit-identical
-// to knn_mfma_kernel alone (which is what this build ran before; 0.93 / 1.55 ms vs 0.55 / 0.85 ms at 353 x 1000).
+// pass, exact rerank of the survivors (all candidates for the rare query whose survivor list overflowed).  Bit-identical
+// to the exhaustive knn_mfma_kernel of dg_knn.h (which is what this build ran before; 0.93 / 1.55 ms vs 0.55 / 0.85 ms
+// at 353 x 1000; tools/probes/knn_fast.hip compares the two index for index).
 template <int C, typename IdxT>
 void knn_wide(const float* x, int ld, float* norm, const KnnWs& k, int64_t M, int64_t N, IdxT* idx, const int* hdr,
               hipStream_t s) {
   const int64_t R = M * N;
   constexpr int SETS = 1, WAVES = 8;
   const dim3 ggram((unsigned)((N + kKfQB - 1) / kKfQB), DG_KNN_GRID_Y(M));
-  const int64_t nflags = (M + 8) * ((N + 127) / 128);
   hipLaunchKernelGGL(rownorm_kernel<C>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, x, ld, norm, hdr);
   hipLaunchKernelGGL(knn_split_kernel<C>, dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, x, ld,
                      (const float*)norm, k.xs, k.nl, k.nu, hdr);
   hipLaunchKernelGGL((knn_gram_kernel<C, false, SETS, WAVES>), ggram, dim3(64 * WAVES), 0, s, (const unsigned short*)k.xs,
-                     (const float*)k.nl, (const float*)k.nl, (const float*)k.nu, (int)N, k.theta, k.surv, k.scnt, k.flags,
-                     hdr);
-  mpa::zero_words_async(k.flags, nflags, s);
+                     (const float*)k.nl, (const float*)k.nl, (const float*)k.nu, (int)N, k.theta, k.surv, k.scnt, hdr);
   hipLaunchKernelGGL((knn_gram_kernel<C, true, SETS, WAVES>), ggram, dim3(64 * WAVES), 0, s, (const unsigned short*)k.xs,
-                     (const float*)k.nu, (const float*)k.nl, (const float*)k.nu, (int)N, k.theta, k.surv, k.scnt, k.flags,
-                     hdr);
+                     (const float*)k.nu, (const float*)k.nl, (const float*)k.nu, (int)N, k.theta, k.surv, k.scnt, hdr);
   hipLaunchKernelGGL((knn_rerank_kernel<C, IdxT>), dim3((unsigned)((N + kRrQ - 1) / kRrQ), DG_KNN_GRID_Y(M)), dim3(256), 0,
                      s, x, ld, (const float*)norm, (int)N, (const unsigned short*)k.surv, (const unsigned char*)k.scnt, idx,
                      hdr);
-  hipLaunchKernelGGL((knn_mfma_kernel<C, IdxT>), dim3((unsigned)((N + 127) / 128), DG_KNN_GRID_Y(M)), dim3(256), 0, s, x,
-                     ld, (const float*)norm, (int)N, idx, hdr, (const int*)k.flags);
+#ifdef MPA_KNN_STATS  // instrumentation build (tools/build_variant.sh ... -DMPA_KNN_STATS=1): survivor statistics of this search
+  {
+    hipStreamSynchronize(s);
+    std::vector<unsigned char> h((size_t)(2 * R));
+    int hh[2] = {0, 0};
+    hipMemcpy(hh, hdr, 8, hipMemcpyDeviceToHost);
+    hipMemcpy(h.data(), k.scnt, h.size(), hipMemcpyDeviceToHost);
+    long long rows = hh[1], over = 0, total = 0, hist[8] = {0};
+    int mx = 0;
+    for (long long r = 0; r < rows; ++r) {
+      const int a = h[2 * r], b = h[2 * r + 1];
+      if (a == kKfOverflow || b == kKfOverflow) { ++over; continue; }
+      total += a + b;
+      mx = a + b > mx ? a + b : mx;
+      ++hist[(a > b ? a : b) / 4 < 7 ? (a > b ? a : b) / 4 : 7];
+    }
+    fprintf(stderr, "[knn stats] C=%d rows=%lld overflow queries=%lld mean survivors=%.2f max=%d | larger half-list histogram (bins of 4):",
+            C, rows, over, (double)total / (double)(rows - over > 0 ? rows - over : 1), mx);
+    for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", hist[i]);
+    fprintf(stderr, "\n");
+  }
+#endif
 }
 
 struct Ws {

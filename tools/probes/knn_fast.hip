@@ -54,15 +54,14 @@ void run(int n, int N, int mode) {
   TIME("rownorm", 5, hipLaunchKernelGGL((dg::rownorm_kernel<C>), dim3((R + 255) / 256), dim3(256), 0, 0, x, C, norm, hdr));
   TIME("exhaustive exact (old)", 3, hipLaunchKernelGGL((dg::knn_mfma_kernel<C, unsigned short>), gold, dim3(256), 0, 0, x, C, norm, N, idx_ref, hdr));
   TIME("split", 5, hipLaunchKernelGGL((dg::knn_split_kernel<C>), dim3((R * (C / 4) + 255) / 256), dim3(256), 0, 0, x, C, norm, xs, nl, nu, hdr));
-  TIME("bound", 5, hipLaunchKernelGGL((dg::knn_gram_kernel<C, false, S, W>), gnew, dim3(64 * W), 0, 0, xs, nl, nl, nu, N, theta, surv, scnt, flags, hdr));
+  TIME("bound", 5, hipLaunchKernelGGL((dg::knn_gram_kernel<C, false, S, W>), gnew, dim3(64 * W), 0, 0, xs, nl, nl, nu, N, theta, surv, scnt, hdr));
   if (mode == 0 && n > 100) {
-    TIME("bound, no epilogue", 5, hipLaunchKernelGGL((dg::knn_gram_kernel<C, false, S, W, 1>), gnew, dim3(64 * W), 0, 0, xs, nl, nl, nu, N, theta, surv, scnt, flags, hdr));
-    TIME("bound, no staging", 5, hipLaunchKernelGGL((dg::knn_gram_kernel<C, false, S, W, 2>), gnew, dim3(64 * W), 0, 0, xs, nl, nl, nu, N, theta, surv, scnt, flags, hdr));
-    TIME("bound, MFMA only", 5, hipLaunchKernelGGL((dg::knn_gram_kernel<C, false, S, W, 3>), gnew, dim3(64 * W), 0, 0, xs, nl, nl, nu, N, theta, surv, scnt, flags, hdr));
-    TIME("bound", 5, hipLaunchKernelGGL((dg::knn_gram_kernel<C, false, S, W>), gnew, dim3(64 * W), 0, 0, xs, nl, nl, nu, N, theta, surv, scnt, flags, hdr));
+    TIME("bound, no epilogue", 5, hipLaunchKernelGGL((dg::knn_gram_kernel<C, false, S, W, 1>), gnew, dim3(64 * W), 0, 0, xs, nl, nl, nu, N, theta, surv, scnt, hdr));
+    TIME("bound, no staging", 5, hipLaunchKernelGGL((dg::knn_gram_kernel<C, false, S, W, 2>), gnew, dim3(64 * W), 0, 0, xs, nl, nl, nu, N, theta, surv, scnt, hdr));
+    TIME("bound, MFMA only", 5, hipLaunchKernelGGL((dg::knn_gram_kernel<C, false, S, W, 3>), gnew, dim3(64 * W), 0, 0, xs, nl, nl, nu, N, theta, surv, scnt, hdr));
+    TIME("bound", 5, hipLaunchKernelGGL((dg::knn_gram_kernel<C, false, S, W>), gnew, dim3(64 * W), 0, 0, xs, nl, nl, nu, N, theta, surv, scnt, hdr));
   }
-  hipMemset(flags, 0, (size_t)(n + 8) * Q128 * 4);
-  TIME("collect", 5, hipLaunchKernelGGL((dg::knn_gram_kernel<C, true, S, W>), gnew, dim3(64 * W), 0, 0, xs, nu, nl, nu, N, theta, surv, scnt, flags, hdr));
+  TIME("collect", 5, hipLaunchKernelGGL((dg::knn_gram_kernel<C, true, S, W>), gnew, dim3(64 * W), 0, 0, xs, nu, nl, nu, N, theta, surv, scnt, hdr));
   TIME("rerank", 5, hipLaunchKernelGGL((dg::knn_rerank_kernel<C, unsigned short>), grr, dim3(256), 0, 0, x, C, norm, N, surv, scnt, idx_new, hdr));
   std::vector<unsigned short> a(R * 20), b(R * 20);
   std::vector<unsigned char> cnt(R * 2);
@@ -71,17 +70,14 @@ void run(int n, int N, int mode) {
   hipMemcpy(b.data(), idx_new, R * 40, hipMemcpyDeviceToHost);
   hipMemcpy(cnt.data(), scnt, R * 2, hipMemcpyDeviceToHost);
   hipMemcpy(fl.data(), flags, fl.size() * 4, hipMemcpyDeviceToHost);
-  size_t bad_rows = 0, flagged_rows = 0, total = 0; int mx = 0; size_t nflag = 0;
-  for (auto f : fl) nflag += f != 0;
+  size_t bad_rows = 0, over = 0, total = 0; int mx = 0;
   for (size_t r = 0; r < R; ++r) {
-    const int c = cnt[2 * r] + cnt[2 * r + 1];
-    total += c; if (c > mx) mx = c;
-    const bool flagged = fl[(r / N) * Q128 + (r % N) / 128] != 0;
-    if (flagged) { ++flagged_rows; continue; }
+    if (cnt[2 * r] == dg::kKfOverflow || cnt[2 * r + 1] == dg::kKfOverflow) ++over;
+    else { const int c = cnt[2 * r] + cnt[2 * r + 1]; total += c; if (c > mx) mx = c; }
     if (memcmp(&a[r * 20], &b[r * 20], 40) != 0) ++bad_rows;
   }
-  printf("  survivors per query: mean %.2f max %d | flagged 128-query blocks %zu of %zu (%zu rows) | MISMATCHED rows (unflagged): %zu of %zu\n",
-         (double)total / R, mx, nflag, fl.size(), flagged_rows, bad_rows, R);
+  printf("  survivors per query: mean %.2f max %d | queries scanned exhaustively (list overflow): %zu | MISMATCHED rows: %zu of %zu\n",
+         (double)total / (R - over ? R - over : 1), mx, over, bad_rows, R);
   hipFree(x); hipFree(norm); hipFree(nl); hipFree(nu); hipFree(theta); hipFree(xs); hipFree(surv); hipFree(scnt);
   hipFree(idx_ref); hipFree(idx_new); hipFree(hdr); hipFree(flags);
 }
