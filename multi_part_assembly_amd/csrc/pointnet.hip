@@ -628,6 +628,145 @@ __global__ __launch_bounds__(kT, 2) void pn_fwd_mfma_kernel(
   }  // unit
 }
 
+// ---- last layer forward on the bf16 matrix cores, fp32-grade --------------------------------------------------------------
+// The 128 -> F layer is the one forward GEMM the matrix cores bind (2.3e10 FLOP against 181 MB of input).  Its operands
+// are split into three bf16 terms each, x = h + m + l (exact), and the six products of order <= 2 run on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (csrc/dg_gemm_split.h has the error analysis: the dropped terms are
+// one fp32 rounding of the product) — 192 instead of 512 matrix-core cycles per 16 k-values.  A block of NW = F / 32
+// waves walks 32-row tiles of its (valid part, split) units like pn_fwd_mfma_kernel; wave w owns output channels
+// 32w .. 32w+31 with its split weight slab register-resident (96 VGPRs) and ALL 32 rows of the tile, so the BatchNorm
+// sums and the top-2 records of a channel live in one wave (no cross-wave reduction).  The tile is fetched one tile
+// ahead, gets the previous layer's BatchNorm + ReLU and the split on its way into a double-buffered LDS panel of three
+// bf16 planes (rows of 3 x 256 + 16 bytes: conflict-free 16-byte fragment reads).
+typedef __bf16 pn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pn_bf16x4 __attribute__((ext_vector_type(4)));
+template <int CIN, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void pn_fwd_split_kernel(
+    const float* __restrict__ in, const float* __restrict__ bn_prev, const float* __restrict__ w, int cout,
+    const int* __restrict__ vlist, int N, int splits, float* __restrict__ partial, float* __restrict__ topv,
+    int* __restrict__ topn, const float* __restrict__ gamma_top) {
+  constexpr int NT = 64 * NW, KS = CIN / 16, Q4 = CIN / 4;
+  constexpr int ROWB = 3 * CIN * 2 + 16;  // LDS row: h | m | l planes of CIN bf16 each + pad (an odd multiple of 16)
+  constexpr int NLD = 32 * Q4 / NT;       // float4 per thread and tile
+  static_assert(32 * Q4 % NT == 0 && NT % Q4 == 0, "staging layout");
+  __shared__ __attribute__((aligned(16))) unsigned char buf[2][32 * ROWB];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int c0 = 32 * wave;
+  // split weight slab: lane (j, h) holds, per k-step, W[c0 + j][16 ks + 8 h .. + 7] as h / m / l
+  pn_bf16x8 bh[KS], bm[KS], bl[KS];
+  {
+    const float* src = w + (long long)(c0 + j) * CIN + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 q0 = *reinterpret_cast<const float4*>(src + 16 * ks), q1 = *reinterpret_cast<const float4*>(src + 16 * ks + 4);
+      const float f[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        bh[ks][u] = (__bf16)f[u];
+        const float r1 = f[u] - (float)bh[ks][u];
+        bm[ks][u] = (__bf16)r1;
+        bl[ks][u] = (__bf16)(r1 - (float)bm[ks][u]);
+      }
+    }
+  }
+  const int c4 = threadIdx.x % Q4, rl0 = threadIdx.x / Q4;
+  const float4 sc = reinterpret_cast<const float4*>(bn_prev)[c4];
+  const float4 sh = reinterpret_cast<const float4*>(bn_prev + CIN)[c4];
+  const int TB = (N + 31) / 32;
+  float4 raw[NLD];
+  int m = 0;
+  auto fetch = [&](int tile) {
+    const float4* src = reinterpret_cast<const float4*>(in + ((long long)m * N + (long long)tile * 32) * CIN);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int rl = rl0 + i * (NT / Q4);
+      const int rr = tile * 32 + rl < N ? rl : N - 1 - tile * 32;  // rows past the part's end: any row of the part
+      raw[i] = src[rr * Q4 + c4];
+    }
+  };
+  auto stash = [&](int tile, unsigned char* dst) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int rl = rl0 + i * (NT / Q4);
+      const float4 r = raw[i];
+      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (tile * 32 + rl < N) {  // rows past the part's end enter the MFMA as zeros
+        v[0] = __builtin_fmaxf(__builtin_fmaf(r.x, sc.x, sh.x), 0.0f);
+        v[1] = __builtin_fmaxf(__builtin_fmaf(r.y, sc.y, sh.y), 0.0f);
+        v[2] = __builtin_fmaxf(__builtin_fmaf(r.z, sc.z, sh.z), 0.0f);
+        v[3] = __builtin_fmaxf(__builtin_fmaf(r.w, sc.w, sh.w), 0.0f);
+      }
+      pn_bf16x4 ph, pm, pl;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ph[u] = (__bf16)v[u];
+        const float r1 = v[u] - (float)ph[u];
+        pm[u] = (__bf16)r1;
+        pl[u] = (__bf16)(r1 - (float)pm[u]);
+      }
+      unsigned char* p = dst + rl * ROWB + 8 * c4;
+      *reinterpret_cast<pn_bf16x4*>(p) = ph;
+      *reinterpret_cast<pn_bf16x4*>(p + 2 * CIN) = pm;
+      *reinterpret_cast<pn_bf16x4*>(p + 4 * CIN) = pl;
+    }
+  };
+  const float sgn = gamma_top[c0 + j] < 0.0f ? -1.0f : 1.0f;  // only the extrema of sign(gamma) * y can become the maximum
+  const int U = vlist[0] * splits;
+  int mnext = blockIdx.x < U ? vlist[4 + blockIdx.x / splits] : 0;
+  for (int unit = blockIdx.x; unit < U; unit += gridDim.x) {
+    m = mnext;
+    {
+      const int un = unit + gridDim.x;
+      mnext = un < U ? vlist[4 + un / splits] : 0;
+    }
+    const int sp = unit % splits, ob = m * splits + sp;
+    const int t_begin = (int)((long long)sp * TB / splits), t_end = (int)((long long)(sp + 1) * TB / splits);
+    float s_ = 0.0f, ss_ = 0.0f;
+    Top2 hi = top2_empty();
+    if (t_begin < t_end) fetch(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      unsigned char* cur = buf[(tile - t_begin) & 1];
+      stash(tile, cur);
+      __syncthreads();  // also orders this buffer's reuse: its previous readers finished before the last barrier
+      if (tile + 1 < t_end) fetch(tile + 1);
+      const unsigned char* arow = cur + j * ROWB + 16 * h;
+      f32x16 acc = {0};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const pn_bf16x8 ah = *reinterpret_cast<const pn_bf16x8*>(arow + 32 * ks);
+        const pn_bf16x8 am = *reinterpret_cast<const pn_bf16x8*>(arow + 2 * CIN + 32 * ks);
+        const pn_bf16x8 al = *reinterpret_cast<const pn_bf16x8*>(arow + 4 * CIN + 32 * ks);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc, 0, 0, 0);
+      }
+      const int r0 = tile * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gn = r0 + acc_row(r, h);
+        top2_push(hi, gn < N ? sgn * acc[r] : -__builtin_inff(), gn);  // rows past the end must not enter the extrema
+        s_ += acc[r];  // zero operand rows give exactly 0: no mask needed for the statistics
+        ss_ = __builtin_fmaf(acc[r], acc[r], ss_);
+      }
+    }
+    // lanes l and l + 32 hold the same channel (rows 4h .. of every 8): combine, lane half 0 writes the unit's records
+    s_ += __shfl_xor(s_, 32, 64);
+    ss_ += __shfl_xor(ss_, 32, 64);
+    hi = top2_merge(hi, top2_shfl_xor(hi, 32));
+    if (h == 0) {
+      const long long o = ((long long)ob * cout + c0 + j) * 2;
+      partial[o] = s_;
+      partial[o + 1] = ss_;
+      *reinterpret_cast<float2*>(topv + o) = make_float2(hi.v1, hi.v2);
+      *reinterpret_cast<int2*>(topn + o) = make_int2(hi.n1, hi.n2);
+    }
+    __syncthreads();  // every wave is done with the last tile's panel before the next unit's first stash
+  }
+}
+
 // ---- MFMA input gradient -----------------------------------------------------------------------------------------
 // dA[rows x cin] = dY[rows x K] . W[K x cin] with dY = alpha*dZ + gammap*Y + betap built on the fly,
 // then the ReLU mask and the BatchNorm-backward column sums of layer l-1:
@@ -1470,7 +1609,22 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
                        IN, w.bn[l - 1], conv_w[l - 1], d.C[l], iw.vlist, (int)N, splits, YO, w.partial, TV, TN,      \
                        TP ? bn_w[4] : (const float*)nullptr);                                                         \
   }
-      if (l == 5) {
+#ifndef MPA_PN_SPLIT  // 1: last layer on the bf16 matrix cores (pn_fwd_split_kernel); 0: v_mfma_f32_32x32x2_f32
+#define MPA_PN_SPLIT 1
+#endif
+#define MPA_FWD_SPLIT(NWV)                                                                                           \
+  {                                                                                                                  \
+    static const int occ = blocks_per_cu(pn_fwd_split_kernel<128, NWV>, 64 * NWV);                                   \
+    const long long units = (long long)M * splits, cap = (long long)kCUs * occ * MPA_PN_OVERSUB;                     \
+    hipLaunchKernelGGL((pn_fwd_split_kernel<128, NWV>), dim3((unsigned)(units < cap ? units : cap)), dim3(64 * NWV), \
+                       0, s, w.Y[4], w.bn[4], conv_w[4], d.C[5], iw.vlist, (int)N, splits, w.partial, w.topv,        \
+                       iw.topn, bn_w[4]);                                                                            \
+  }
+      if (l == 5 && MPA_PN_SPLIT) {
+        if (F == 256) MPA_FWD_SPLIT(8)
+        else if (F == 128) MPA_FWD_SPLIT(4)
+        else MPA_FWD_SPLIT(2)
+      } else if (l == 5) {
         if (F == 256) MPA_FWD(128, 4, true, w.Y[4], (float*)nullptr, w.topv, iw.topn)
         else if (F == 128) MPA_FWD(128, 2, true, w.Y[4], (float*)nullptr, w.topv, iw.topn)
         else MPA_FWD(128, 1, true, w.Y[4], (float*)nullptr, w.topv, iw.topn)
@@ -1480,6 +1634,7 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
         MPA_FWD(64, 1, false, w.Y[l - 1], w.Y[l], (float*)nullptr, (int*)nullptr)
       }
 #undef MPA_FWD
+#undef MPA_FWD_SPLIT
     }
     const dim3 cg((unsigned)(d.C[l] / 64));
     if (training)
