@@ -1003,6 +1003,242 @@ __global__ __launch_bounds__(kT, 2) void pn_dgrad_mfma_kernel(
   }  // unit
 }
 
+// The same input gradient of the never-stored last layer (dA = A Q + c0 + S W5, TOP form above) with the dense product
+// A Q on the bf16 matrix cores, fp32-grade: both operands split into three bf16 terms, six products (see
+// pn_fwd_split_kernel); the sparse S W5 steps stay exact-fp32 MFMAs on the same accumulator.
+template <int K>
+__global__ __launch_bounds__(kT, 2) void pn_dgrad_split_kernel(
+    const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
+    const float* __restrict__ w, int cin, const float* __restrict__ y_prev, const float* __restrict__ bn_prev,
+    const int* __restrict__ vlist, int N, int splits, float* __restrict__ dz_prev,
+    float* __restrict__ partial, const int* __restrict__ erow, const int* __restrict__ ech,
+    const float* __restrict__ eval, const int* __restrict__ tptr, const float* __restrict__ w5, int F) {
+  constexpr int NT = 1, PANELS = 4;    // a wave owns 32 output channels, the four waves share one 32-row tile
+  constexpr bool TOP = true;
+  constexpr int KS = K / 16;           // bf16 MFMA k-steps
+  constexpr int ROWB = 3 * K * 2 + 16; // LDS row: h | m | l planes of K bf16 each + pad (an odd multiple of 16 bytes)
+  constexpr int Q4 = K / 4;
+  constexpr int RT = 4 / PANELS;       // 32-row sub-tiles per block tile
+  constexpr int RB = 32 * RT;          // rows per block tile
+  constexpr int NLD = RB * Q4 / kT;    // float4 per thread, tensor and tile
+  constexpr int CW = 32 * NT;          // output channels per wave
+  __shared__ __attribute__((aligned(16))) unsigned char buf[2][RB * ROWB];
+  __shared__ float red[kT / 64][CW][2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int panel = wave % PANELS, rt = wave / PANELS;
+  const int db = blockIdx.y * CW * PANELS, d0 = db + panel * CW;
+  // B fragments, split: lane (j, h) holds, per k-step, Q[k = 16 ks + 8 h .. + 7][d0 + j] as h / m / l
+  pn_bf16x8 bh[KS], bm[KS], bl[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float f = w[(long long)(16 * ks + 8 * h + u) * cin + d0 + j];
+      bh[ks][u] = (__bf16)f;
+      const float r1 = f - (float)bh[ks][u];
+      bm[ks][u] = (__bf16)r1;
+      bl[ks][u] = (__bf16)(r1 - (float)bm[ks][u]);
+    }
+  float scp[NT], shp[NT], mnp[NT], isp[NT], c0v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ci = d0 + 32 * t + j;
+    scp[t] = bn_prev[ci];
+    shp[t] = bn_prev[cin + ci];
+    mnp[t] = bn_prev[2 * cin + ci];
+    isp[t] = bn_prev[3 * cin + ci];
+    c0v[t] = TOP ? w[(long long)K * cin + ci] : 0.0f;
+  }
+  // staging role of this thread: float4 column c4 of rows rl0, rl0 + kT/Q4, ...; its per-column tables.
+  // TOP: the staged operand is relu(bn_prev(Yprev)), tables = scale, shift; else alpha, gammap, betap.
+  const int c4 = threadIdx.x % Q4, rl0 = threadIdx.x / Q4;
+  const float4 ta = reinterpret_cast<const float4*>(TOP ? bn_prev : coef)[c4];
+  const float4 tb = reinterpret_cast<const float4*>(TOP ? bn_prev + K : coef + K)[c4];
+  const float4 tc = TOP ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : reinterpret_cast<const float4*>(coef + 2 * K)[c4];
+  const int TB = (N + RB - 1) / RB;
+  int m = 0;
+  // TOP: the part's CSR (<= 256 entries, <= 1025 tile offsets) lives in LDS so that the per-tile sparse chain has
+  // a single level of global loads (the W5 rows), issued before the tile's main MFMA chain
+  constexpr int kMaxF = 256, kMaxT1 = 1032, kSP = 6;  // tile offsets: N <= 32768 points per part
+  __shared__ int s_row[TOP ? kMaxF : 1], s_ch[TOP ? kMaxF : 1], s_ptr[TOP ? kMaxT1 : 1];
+  __shared__ float s_val[TOP ? kMaxF : 1];
+  float4 ry[NLD], rz[TOP ? 1 : NLD];
+  auto fetch = [&](int tile) {
+    const long long base = ((long long)m * N + (long long)tile * RB) * Q4;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int rl = rl0 + i * (kT / Q4);
+      const bool ok = tile * RB + rl < N;
+      const long long o = base + i * kT + threadIdx.x;
+      if constexpr (TOP) {
+        ry[i] = ok ? reinterpret_cast<const float4*>(y_prev)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      } else {
+        ry[i] = ok ? reinterpret_cast<const float4*>(y)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        rz[i] = ok ? reinterpret_cast<const float4*>(dz)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+    }
+  };
+  auto stash = [&](int tile, unsigned char* dst) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int rl = rl0 + i * (kT / Q4);
+      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (tile * RB + rl < N) {  // rows past the part's end enter the MFMA as zeros
+        v[0] = __builtin_fmaxf(__builtin_fmaf(ry[i].x, ta.x, tb.x), 0.0f);
+        v[1] = __builtin_fmaxf(__builtin_fmaf(ry[i].y, ta.y, tb.y), 0.0f);
+        v[2] = __builtin_fmaxf(__builtin_fmaf(ry[i].z, ta.z, tb.z), 0.0f);
+        v[3] = __builtin_fmaxf(__builtin_fmaf(ry[i].w, ta.w, tb.w), 0.0f);
+      }
+      pn_bf16x4 ph, pm, pl;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ph[u] = (__bf16)v[u];
+        const float r1 = v[u] - (float)ph[u];
+        pm[u] = (__bf16)r1;
+        pl[u] = (__bf16)(r1 - (float)pm[u]);
+      }
+      unsigned char* p = dst + rl * ROWB + 8 * c4;
+      *reinterpret_cast<pn_bf16x4*>(p) = ph;
+      *reinterpret_cast<pn_bf16x4*>(p + 2 * K) = pm;
+      *reinterpret_cast<pn_bf16x4*>(p + 4 * K) = pl;
+    }
+  };
+  // persistent: the block keeps its weight slab and walks the (valid part, row split) units u, u + gridDim.x, ...
+  const int U = vlist[0] * splits;
+  int mnext = blockIdx.x < U ? vlist[4 + blockIdx.x / splits] : 0;
+  for (int unit = blockIdx.x; unit < U; unit += gridDim.x) {
+  m = mnext;
+  {
+    const int un = unit + gridDim.x;
+    mnext = un < U ? vlist[4 + un / splits] : 0;  // needed one unit from now
+  }
+  const int sp = unit % splits, ob = m * splits + sp;  // ob: the unit's row of `partial`
+  const int t_begin = (int)((long long)sp * TB / splits), t_end = (int)((long long)(sp + 1) * TB / splits);
+  if constexpr (TOP) {
+    const int T1 = (N + 31) / 32 + 1;
+    for (int i = threadIdx.x; i < F; i += kT) {
+      s_row[i] = erow[(long long)m * F + i];  // slots past the part's entry count hold garbage, never addressed
+      s_ch[i] = ech[(long long)m * F + i];
+      s_val[i] = eval[(long long)m * F + i];
+    }
+    for (int i = threadIdx.x; i < T1 && i < kMaxT1; i += kT) s_ptr[i] = tptr[(long long)m * T1 + i];
+    // visible after the first barrier of the tile loop
+  }
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.0f;
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    unsigned char* cur = buf[(tile - t_begin) & 1];
+    stash(tile, cur);
+    __syncthreads();  // also orders this buffer's reuse: its previous readers finished before the last barrier
+    if (tile + 1 < t_end) fetch(tile + 1);  // in flight during the MFMA chain below
+    const int r0 = tile * RB + rt * 32;
+    // Yprev of the epilogue (row of register r, columns d0 + 32t + j); rows past the end read row N-1, unused
+    float yp[NT][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gn = r0 + acc_row(r, h);
+      const long long o = ((long long)m * N + (gn < N ? gn : N - 1)) * cin + d0 + j;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) yp[t][r] = y_prev[o + 32 * t];
+    }
+    float sa[TOP ? kSP : 1], sbv[TOP ? kSP : 1][NT];  // TOP: the first kSP sparse steps (2 entries each)
+    int pb = 0, pe = 0;
+    if constexpr (TOP) {
+      const int st = r0 >> 5;  // this wave's 32-row tile
+      pb = s_ptr[st];
+      pe = s_ptr[st + 1];
+#pragma unroll
+      for (int q = 0; q < kSP; ++q) {
+        const int ee = pb + 2 * q + h;
+        const bool okk = ee < pe;
+        const int es = okk ? ee : 0;
+        sa[q] = (okk && s_row[es] - r0 == j) ? s_val[es] : 0.0f;
+        const float* wrow = w5 + (long long)(okk ? s_ch[es] : 0) * cin + d0 + j;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sbv[q][t] = wrow[32 * t];
+      }
+    }
+    const unsigned char* arow = cur + (rt * 32 + j) * ROWB + 16 * h;
+    f32x16 acc[NT];
+    acc[0] = f32x16{0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const pn_bf16x8 ah = *reinterpret_cast<const pn_bf16x8*>(arow + 32 * ks);
+      const pn_bf16x8 am = *reinterpret_cast<const pn_bf16x8*>(arow + 2 * K + 32 * ks);
+      const pn_bf16x8 al = *reinterpret_cast<const pn_bf16x8*>(arow + 4 * K + 32 * ks);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[ks], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[ks], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[ks], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc[0], 0, 0, 0);
+    }
+    if constexpr (TOP) {  // + S W5: the entries whose arg-max row lies in this tile, two per MFMA
+#pragma unroll
+      for (int q = 0; q < kSP; ++q) {
+        if (pb + 2 * q < pe) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[q], sbv[q][t], acc[t], 0, 0, 0);
+        }
+      }
+      for (int e = pb + 2 * kSP; e < pe; e += 2) {  // unusually crowded tile
+        const int ee = e + h;
+        const bool okk = ee < pe;
+        const int es = okk ? ee : 0;
+        const float a = (okk && s_row[es] - r0 == j) ? s_val[es] : 0.0f;
+        const float* wrow = w5 + (long long)(okk ? s_ch[es] : 0) * cin + d0 + j;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[32 * t], acc[t], 0, 0, 0);
+      }
+    }
+    const bool full = r0 + 32 <= N;  // wave-uniform: only a part's last tile is ragged
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gn = r0 + acc_row(r, h);
+      const bool ok = full || gn < N;
+      const long long o = ((long long)m * N + gn) * cin + d0 + j;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float zz = __builtin_fmaf(yp[t][r], scp[t], shp[t]);
+        const float d = (ok && zz > 0.0f) ? acc[t][r] + c0v[t] : 0.0f;
+        if (ok) dz_prev[o + 32 * t] = d;
+        s1[t] += d;
+        s2[t] = __builtin_fmaf(d, (yp[t][r] - mnp[t]) * isp[t], s2[t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    s1[t] += __shfl_xor(s1[t], 32, 64);
+    s2[t] += __shfl_xor(s2[t], 32, 64);
+  }
+  if (h == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      red[wave][32 * t + j][0] = s1[t];
+      red[wave][32 * t + j][1] = s2[t];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < CW * PANELS) {  // thread -> (panel, channel); the RT waves of the panel in fixed order
+    const int pn = threadIdx.x / CW, ch = threadIdx.x % CW;
+    float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+      t0 += red[q * PANELS + pn][ch][0];
+      t1 += red[q * PANELS + pn][ch][1];
+    }
+    const long long o = ((long long)ob * cin + db + threadIdx.x) * 2;
+    partial[o] = t0;
+    partial[o + 1] = t1;
+  }
+  __syncthreads();  // LDS (CSR copy, reduction scratch) is free again before the next unit rewrites it
+  }  // unit
+}
+
 // ---- MFMA weight gradient --------------------------------------------------------------------------------------
 // dW[co][ci] = sum over all valid rows of dY[r,co] * A[r,ci]   (a GEMM whose K dimension is the point rows), with
 // dY = alpha*dZ + gammap*Y + betap and A = relu(bn_prev(Yprev)) built on the fly.
@@ -1675,9 +1911,14 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   hipLaunchKernelGGL(pn_top_q_kernel, dim3((unsigned)(C4 + 1)), dim3((unsigned)C4), 0, s, conv_w[4], w.coef[5], (int)F,
                      C4, w.q);
   {
-    static const int occ = blocks_per_cu(pn_dgrad_mfma_kernel<128, 1, 4, true>, kT);
+#if MPA_PN_SPLIT
+#define MPA_DGRAD_TOP pn_dgrad_split_kernel<128>
+#else
+#define MPA_DGRAD_TOP pn_dgrad_mfma_kernel<128, 1, 4, true>
+#endif
+    static const int occ = blocks_per_cu(MPA_DGRAD_TOP, kT);
     const long long units = (long long)M * d.splits_dtop, cap = (long long)kCUs * occ * MPA_PN_OVERSUB;
-    hipLaunchKernelGGL((pn_dgrad_mfma_kernel<128, 1, 4, true>), dim3((unsigned)(units < cap ? units : cap), (unsigned)(C4 / 128)),
+    hipLaunchKernelGGL((MPA_DGRAD_TOP), dim3((unsigned)(units < cap ? units : cap), (unsigned)(C4 / 128)),
                        dim3(kT), 0, s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w.q, C4,
                        w.Y[4], w.bn[4], iw.vlist, (int)N, d.splits_dtop, w.dZ[4], w.partial, iw.erow, iw.ech, w.eval,
                        iw.tptr, conv_w[4], (int)F);
