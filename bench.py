@@ -443,7 +443,7 @@ def main():
                         traffic = rec["per_width"][str(C)]["traffic_bytes_per_launch"]
                         traffic_src = f"profiles/{pmc[-1].name}: {rec['correction']}"
                 roofline = {
-                    "kernel": (f"dg::knn_wide (rownorm + split + knn_gram_kernel bound / collect + knn_rerank_kernel: k = 20 "
+                    "kernel": (f"dg::knn_wide (rownorm_kernel + knn_split_kernel + knn_gram_kernel bound / collect + knn_rerank_kernel: k = 20 "
                                f"nearest neighbours in {C}-d feature space, {valid_parts} clouds of {N} points)"
                                if C >= 64 else f"dg::knn3_kernel (k = 20 nearest neighbours of {valid_parts} clouds of {N} "
                                f"points in 3-d)"),

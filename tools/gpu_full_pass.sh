@@ -18,5 +18,5 @@ python $R/tools/trace_steps.py $(find /tmp/prof -name "*kernel_trace.csv" | head
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc
   timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc -o pm -- python $R/bench.py --config $CFG --no-cpu-baseline --steps 4 --warmup 2 > /dev/null 2>&1
-  python $R/tools/pmc_summary.py $(find /tmp/pmc -name "*counter_collection.csv" | head -1) --top 40 > $O/pmc_$c.txt
+  python $R/tools/pmc_summary.py $(find /tmp/pmc -name "*counter_collection.csv" | head -1) --top 400 > $O/pmc_$c.txt
 done

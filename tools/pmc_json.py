@@ -33,22 +33,29 @@ def main():
         (prof / f"{rnd}_pmc_dominant_kernel.json").write_text(json.dumps(rec, indent=1))
         print(rec)
     widths = {}
-    for C in (128, 64):
-        f = per_kernel(prof / f"{rnd}_c3_pmc_fetch_size.txt", rf"knn_mfma_kernel<{C},")
-        w = per_kernel(prof / f"{rnd}_c3_pmc_write_size.txt", rf"knn_mfma_kernel<{C},")
-        if f is not None and w is not None:
-            widths[str(C)] = {"fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
-                              "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0}
+    # the wide kNN stages are a pipeline of kernels now (csrc/dg_knn_fast.h): sum them per feature width
+    pipeline = {C: [rf"rownorm_kernel<{C}>", rf"knn_split_kernel<{C}>", rf"knn_gram_kernel<{C}, false", rf"knn_gram_kernel<{C}, true",
+                    rf"knn_rerank_kernel<{C},"] for C in (128, 64)}
+    for C, pats in pipeline.items():
+        fs = [per_kernel(prof / f"{rnd}_c3_pmc_fetch_size.txt", pat) for pat in pats]
+        ws = [per_kernel(prof / f"{rnd}_c3_pmc_write_size.txt", pat) for pat in pats]
+        missing = [pat for pat, a, b in zip(pats, fs, ws) if a is None or b is None]
+        fs = [0.0 if v is None else v for v in fs]  # a kernel below the summary's cut-off moved (almost) nothing
+        ws = [0.0 if v is None else v for v in ws]
+        if len(missing) < len(pats):
+            widths[str(C)] = {"fetch_size_kb_per_launch": sum(fs), "write_size_kb_per_launch": sum(ws),
+                              "per_kernel_fetch_kb": dict(zip(pats, fs)), "per_kernel_write_kb": dict(zip(pats, ws)),
+                              "below_the_summary_cutoff": missing,
+                              "traffic_bytes_per_launch": (2.0 * sum(fs) + sum(ws)) * 1024.0}
     if widths:
-        rec = {"kernel": "dg::knn_mfma_kernel",
+        rec = {"kernel": "dg::knn_wide = rownorm + knn_split + knn_gram (bound) + knn_gram (collect) + knn_rerank",
                "command": "python bench.py --config c3 --no-cpu-baseline --steps 4 --warmup 2 (rocprofv3 --pmc FETCH_SIZE "
                           "and --pmc WRITE_SIZE, separate passes; tools/gpu_full_pass.sh)",
                "correction": note, "per_width": widths,
-               "note": "the query blocks of a cloud run on one XCD (dg_knn.h: knn_block), so one L2 streams the cloud's "
-                       "features; the index lists are written once"}
+               "note": "sum over the five kernels of one search; the query blocks of a cloud run on one XCD (dg_knn.h: "
+                       "knn_block), so one L2 streams the cloud's split features in both Gram passes"}
         (prof / f"{rnd}_pmc_knn_kernel.json").write_text(json.dumps(rec, indent=1))
         print(rec)
-
 
 if __name__ == "__main__":
     main()
