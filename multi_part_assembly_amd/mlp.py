@@ -9,13 +9,15 @@ import ctypes
 import torch
 
 from . import _lib
+from .gradsink import GradSink
 
 
 class _MLPLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, gamma, beta, running, training, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, gamma, beta, running, training, momentum, eps, relu):
         R, K = x.shape
-        N = w.shape[0]
+        N = weight.shape[0]
+        w = weight.reshape(N, -1)  # a Conv1d weight [N, K, 1] or a Linear weight [N, K]: the same bytes
         dev = x.device
         L = _lib.lib()
         nbytes = ctypes.c_int64()
@@ -32,6 +34,10 @@ class _MLPLayerFn(torch.autograd.Function):
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_mlp_layer_forward")
         ctx.meta = (bool(relu), bool(training), bias is not None, gamma is not None)
+        # the parameters themselves (not views of them): with a GradSink active their gradients are written straight
+        # into the flat gradient buffer instead of going through one AccumulateGrad `add` launch per parameter
+        ctx.params = [p for p in (weight, bias, gamma, beta) if p is not None]
+        GradSink.note_use(ctx.params)
         ctx.save_for_backward(x, w, gamma, out, ws)
         return out
 
@@ -49,10 +55,12 @@ class _MLPLayerFn(torch.autograd.Function):
         N = w.shape[0]
         dev = x.device
         gx = torch.empty((R, K), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
-        gw = torch.empty_like(w)
-        gb = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
-        gg = torch.empty(N, dtype=torch.float32, device=dev) if has_bn else None
-        gbe = torch.empty(N, dtype=torch.float32, device=dev) if has_bn else None
+        bufs, direct = GradSink.outputs(ctx.params)
+        it = iter(bufs)
+        gw = next(it)
+        gb = next(it) if has_bias else None
+        gg = next(it) if has_bn else None
+        gbe = next(it) if has_bn else None
         grad_out = grad_out.contiguous()
         with torch.cuda.device(dev):
             tok = _lib.KernelTimer.start(f"mlp_layer_backward[{R}x{K}x{N}]")
@@ -62,6 +70,9 @@ class _MLPLayerFn(torch.autograd.Function):
                 _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_mlp_layer_backward")
+        if direct:
+            GradSink.delivered(ctx.params)
+            return gx, None, None, None, None, None, None, None, None, None
         return gx, gw, gb, gg, gbe, None, None, None, None, None
 
 
@@ -74,14 +85,13 @@ def mlp_layer(x, weight, bias=None, bn=None, relu=True, training=True):
     [N, K, 1]; `bn`: an nn.BatchNorm1d (its running statistics are updated in training mode) or None."""
     if not x.is_cuda:
         raise RuntimeError("mlp_layer: only CUDA (HIP) tensors are supported — no CPU fallback")
-    w = weight.reshape(weight.shape[0], -1)
     x = x.float()
     if x.stride(1) != 1 or x.stride(0) % 4 != 0:
         x = x.contiguous()
     if bn is None:
-        return _MLPLayerFn.apply(x, w, bias, None, None, None, training, 0.0, 0.0, relu)
+        return _MLPLayerFn.apply(x, weight, bias, None, None, None, training, 0.0, 0.0, relu)
     if training:
         with torch.no_grad():
             bn.num_batches_tracked += 1
-    return _MLPLayerFn.apply(x, w, bias, bn.weight, bn.bias, (bn.running_mean, bn.running_var), training,
+    return _MLPLayerFn.apply(x, weight, bias, bn.weight, bn.bias, (bn.running_mean, bn.running_var), training,
                              bn.momentum, bn.eps, relu)
