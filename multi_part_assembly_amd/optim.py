@@ -93,6 +93,7 @@ class FusedAdam:
         self.decay_mask = decay_mask
         self.clip_grad = clip_grad if clip_grad else None
         self._clip_ws = None
+        self._clip_written = False  # the device-side clip coefficient holds a value other than 1
         self._step_count = 0
         self.grad_scale = 1.0
         self.numel = self.flat.numel
@@ -153,8 +154,12 @@ class FusedAdam:
         lib = _lib.lib()
         with torch.cuda.device(dev):
             stream = _lib.current_stream(dev)
+            if not self.clip_grad and self._clip_written:  # clipping was switched off: back to "no clipping"
+                self._hyper_dev[5:6].fill_(1.0)
+                self._clip_written = False
             if self.clip_grad:
                 self._ensure_clip_ws()
+                self._clip_written = True
                 st = lib.mpa_grad_clip_coef(_lib.ptr(self.flat_grad), self.numel, float(self.clip_grad),
                                             self._hyper_dev.data_ptr() + 12, 1.0, _lib.ptr(self._clip_ws),
                                             self._hyper_dev.data_ptr() + 20, stream)

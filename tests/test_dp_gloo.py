@@ -150,3 +150,18 @@ def test_cosine_schedule_matches_reference_scheduler(golden):
         fn = cosine_warmup_lr(int(total), int(total * ratio), float(lr), float(lr / decay))
         mine = np.array([fn(e) for e in range(len(z[tag + ".lr"]))])
         np.testing.assert_allclose(mine, z[tag + ".lr"], rtol=1e-12, atol=0, err_msg=tag)
+
+
+def test_dropout_salts_are_positions_inside_the_model():
+    """The dropout seed of a TransformerEncoder mixes in the encoder's index inside ITS model (module order), not a
+    process-global construction counter: a model built second in a process draws the same masks as one built first."""
+    from multi_part_assembly_amd import config
+    from multi_part_assembly_amd.pn_transformer import build_model
+    from multi_part_assembly_amd.transformer import TransformerEncoder
+
+    def salts(model):
+        return [m._instance for m in model.modules() if isinstance(m, TransformerEncoder)]
+
+    first = build_model(config.pn_transformer_refine_everyday())
+    second = build_model(config.pn_transformer_refine_everyday())
+    assert salts(first) == salts(second) == list(range(1, len(salts(first)) + 1)) and len(salts(first)) >= 1

@@ -516,3 +516,59 @@ def test_graph_trainer_data_parallel_path(golden, cuda_device):
         _same_trajectory(dp.flat.flat_param, ref.flat.flat_param)
     finally:
         dist.destroy_process_group()
+
+
+# ---- regressions for the round-2 advisor findings ---------------------------------------------------------------------------
+def test_second_backward_over_a_consumed_workspace_raises(cuda_device):
+    """The DGCNN / MLP-layer / assembly-loss backward passes overwrite their saved workspaces; a second backward over the
+    same forward must raise instead of returning gradients computed from clobbered buffers."""
+    from multi_part_assembly_amd.mlp import mlp_layer
+    enc = build_encoder("dgcnn", 64).to(cuda_device).train()
+    x = (torch.randn(2, 64, 3, device=cuda_device) * 0.2).requires_grad_()
+    out = enc(x)
+    out.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        out.sum().backward()
+    lin = torch.nn.Linear(64, 64).to(cuda_device)
+    y = mlp_layer(torch.randn(128, 64, device=cuda_device, requires_grad=True), lin.weight, lin.bias, None, relu=True)
+    y.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        y.sum().backward()
+
+
+def test_optimizer_clip_and_step_count_can_be_assigned_late(cuda_device):
+    """`clip_grad` set after the first step allocates its workspace on first use; assigning `step_count` re-synchronises
+    the device-side counter (bias corrections follow the host mirror)."""
+    torch.manual_seed(0)
+    p = torch.nn.Parameter(torch.randn(1000, device=cuda_device))
+    q = torch.nn.Parameter(p.detach().clone())
+    mine, ref = FusedAdam([p], lr=1e-2), torch.optim.Adam([q], lr=1e-2)
+    for step in range(3):
+        g = torch.randn(1000, device=cuda_device) * 10
+        p.grad.copy_(g) if p.grad is not None else setattr(p, "grad", g.clone())
+        q.grad = g.clone()
+        if step == 1:
+            mine.clip_grad = 1.0  # assigned after the first step
+        if step >= 1:
+            torch.nn.utils.clip_grad_norm_([q], 1.0)
+        mine.step()
+        ref.step()
+    np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+    mine.step_count = 10  # e.g. a resumed run
+    ref.state[q]["step"].fill_(10)
+    g = torch.randn(1000, device=cuda_device)
+    p.grad.copy_(g)
+    q.grad = g.clone()
+    mine.clip_grad = None
+    mine.step()
+    ref.step()
+    assert mine.step_count == 11
+    np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_gru_reports_grid_residency(cuda_device):
+    """csrc/gru.hip's step barrier needs its whole grid resident: `supported()` asks the runtime's occupancy calculator
+    (mpa_gru_resident) and is true for the shipped shapes on a whole MI355X, false for shapes the kernels are not built for."""
+    from multi_part_assembly_amd.gru import supported
+    assert supported(256, 32) and supported(128, 3)
+    assert not supported(192, 32) and not supported(256, 65)
