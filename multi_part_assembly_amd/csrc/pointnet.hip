@@ -1426,6 +1426,138 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
   }
 }
 
+// ---- Gram matrix of the last hidden layer on the bf16 matrix cores, fp32-grade ---------------------------------------------
+// G = A^T A and the column sums of A = relu(bn_prev(Yprev)) over all valid rows (WG_GRAM above; what the weight gradient of
+// the never-stored last layer needs), with the split products of pn_fwd_split_kernel.  The MFMA reduction index is the
+// point row, so the operand is TRANSPOSED while it is staged: a thread's float4 (one row, four channels) becomes 3 x 4
+// two-byte stores into the channel rows [channel][h | m | l planes of 64 rows] of the panel (rows of 384 + 16 bytes; the
+// eight 8-row groups of a plane are XOR-swizzled by (channel >> 2) & 7 so that an instruction's stores spread over the
+// banks while a fragment — 8 consecutive rows — stays one aligned 16-byte read).  Same units, persistent blocks, symmetric
+// tile assignment (3, 3, 2, 2 tiles per wave, mirrored on output) and output layout as pn_wgrad_mfma_kernel<.., WG_GRAM>.
+template <int CIN>
+__global__ __launch_bounds__(kT, 2) void pn_gram_split_kernel(const float* __restrict__ y_prev,
+                                                              const float* __restrict__ bn_prev,
+                                                              const int* __restrict__ vlist, int N,
+                                                              float* __restrict__ dwpart) {
+  static_assert(CIN == 128, "the symmetric tile assignment is written for a 4 x 4 tile grid");
+  constexpr int RB = 64, QI = CIN / 4, NLI = RB * QI / kT, ROWB = 3 * RB * 2 + 16, KS = RB / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char pan[CIN * ROWB];
+  __shared__ float csum[kT / QI][CIN];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int TB = (N + RB - 1) / RB, U = vlist[0] * TB;
+  auto tile_ct = [&](int i) { return i == 0 ? 0 : (i == 1 ? (wave == 3 ? 2 : 1) : (wave == 0 ? 2 : (wave == 1 ? 3 : -1))); };
+  auto tile_it = [&](int i) { return i == 0 ? wave : (i == 1 ? (wave == 3 ? 2 : wave + 1) : 3); };
+  const int ci4 = threadIdx.x % QI, ri0 = threadIdx.x / QI;
+  const float4 sc = reinterpret_cast<const float4*>(bn_prev)[ci4];
+  const float4 sh = reinterpret_cast<const float4*>(bn_prev + CIN)[ci4];
+  float4 rp[NLI];
+  auto fetch = [&](int u, int m) {
+    const int n0 = (u % TB) * RB;
+    const long long row0 = (long long)m * N + n0;
+#pragma unroll
+    for (int i = 0; i < NLI; ++i) {
+      const int rl = ri0 + i * (kT / QI);
+      const long long rr = n0 + rl < N ? row0 + rl : (long long)m * N + N - 1;  // clamped: the value is dropped below
+      rp[i] = reinterpret_cast<const float4*>(y_prev)[rr * QI + ci4];
+    }
+  };
+  float4 colsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // this thread's four channels over its rows of all units
+  auto stash = [&](int u) {
+    const int n0 = (u % TB) * RB;
+#pragma unroll
+    for (int i = 0; i < NLI; ++i) {
+      const int rl = ri0 + i * (kT / QI);
+      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (n0 + rl < N) {  // rows past the part's end are staged as zeros
+        v[0] = __builtin_fmaxf(__builtin_fmaf(rp[i].x, sc.x, sh.x), 0.0f);
+        v[1] = __builtin_fmaxf(__builtin_fmaf(rp[i].y, sc.y, sh.y), 0.0f);
+        v[2] = __builtin_fmaxf(__builtin_fmaf(rp[i].z, sc.z, sh.z), 0.0f);
+        v[3] = __builtin_fmaxf(__builtin_fmaf(rp[i].w, sc.w, sh.w), 0.0f);
+      }
+      colsum.x += v[0];
+      colsum.y += v[1];
+      colsum.z += v[2];
+      colsum.w += v[3];
+      const int slot = 16 * ((rl >> 3) ^ (ci4 & 7)) + 2 * (rl & 7);  // (channel >> 2) & 7 == ci4 & 7
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 bh = (__bf16)v[e];
+        const float r1 = v[e] - (float)bh;
+        const __bf16 bm = (__bf16)r1;
+        const __bf16 bl = (__bf16)(r1 - (float)bm);
+        unsigned char* p = pan + (4 * ci4 + e) * ROWB + slot;
+        *reinterpret_cast<__bf16*>(p) = bh;
+        *reinterpret_cast<__bf16*>(p + 2 * RB) = bm;
+        *reinterpret_cast<__bf16*>(p + 4 * RB) = bl;
+      }
+    }
+  };
+  auto frag = [&](int ch, int ks, pn_bf16x8& fh, pn_bf16x8& fm, pn_bf16x8& fl) {  // rows 16 ks + 8 h .. + 7 of channel ch
+    const unsigned char* p = pan + ch * ROWB + 16 * ((2 * ks + h) ^ ((ch >> 2) & 7));
+    fh = *reinterpret_cast<const pn_bf16x8*>(p);
+    fm = *reinterpret_cast<const pn_bf16x8*>(p + 2 * RB);
+    fl = *reinterpret_cast<const pn_bf16x8*>(p + 4 * RB);
+  };
+  auto part_of = [&](int uu) { return uu < U ? vlist[4 + uu / TB] : 0; };
+  f32x16 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) acc[i] = f32x16{0};
+  int u = blockIdx.x, un = u + kWG;
+  int m = part_of(u), mn = part_of(un);
+  if (u < U) fetch(u, m);
+  while (u < U) {
+    stash(u);
+    __syncthreads();
+    const int unn = un + kWG, mnn = part_of(unn);
+    if (un < U) fetch(un, mn);  // in flight during the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int tct = tile_ct(i), tit = tile_it(i);
+        if (tct >= 0) {  // wave-uniform
+          pn_bf16x8 ah, am, al, bh, bm, bl;
+          frag(tct * 32 + j, ks, ah, am, al);
+          frag(tit * 32 + j, ks, bh, bm, bl);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // single panel: the fragment reads are done before the next unit is staged
+    u = un;
+    m = mn;
+    un = unn;
+    mn = mnn;
+  }
+  float* out = dwpart + (long long)blockIdx.x * (CIN * CIN + CIN);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int tct = tile_ct(i), tit = tile_it(i);
+    if (tct >= 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = tct * 32 + acc_row(r, h), ci = tit * 32 + j;
+        out[co * CIN + ci] = acc[i][r];
+        if (tct != tit) out[ci * CIN + co] = acc[i][r];  // the mirrored tile
+      }
+    }
+  }
+  // column sums: the kT / QI threads that share four channels, in a fixed order
+  *reinterpret_cast<float4*>(&csum[ri0][4 * ci4]) = colsum;
+  __syncthreads();
+  if (threadIdx.x < CIN) {
+    float t = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kT / QI; ++q) t += csum[q][threadIdx.x];
+    out[CIN * CIN + threadIdx.x] = t;
+  }
+}
+
 // ---- fused input + weight gradient (64 -> 64 and 64 -> 128 layers) -------------------------------------------------
 // Both gradients of a layer consume the same dY = alpha*dZ + gammap*Y + betap tile, and the weight gradient's other
 // operand relu(bn_prev(Yprev)) is the tensor the input gradient's epilogue masks with: one kernel reads Y, dZ and
@@ -1930,8 +2062,15 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
     hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * kSlices), 0, s, w.dwpart,
                        (const float*)nullptr, blocks, elems, dst);
   };
+#ifndef MPA_PN_GRAM_SPLIT
+#define MPA_PN_GRAM_SPLIT MPA_PN_SPLIT
+#endif
+#if MPA_PN_GRAM_SPLIT
+  hipLaunchKernelGGL((pn_gram_split_kernel<128>), dim3(kWG), dim3(kT), 0, s, w.Y[4], w.bn[4], iw.vlist, (int)N, w.dwpart);
+#else
   hipLaunchKernelGGL((pn_wgrad_mfma_kernel<128, 128, WG_GRAM>), dim3(kWG), dim3(kT), 0, s, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, w.Y[4], w.bn[4], iw.vlist, (int)N, w.dwpart, 0);
+#endif
   reduce_dw(kWG, C4 * C4 + C4, w.gram);
   hipLaunchKernelGGL(pn_top_wgrad_kernel, dim3((unsigned)F), dim3(1024), 0, s, grad_feat, iw.argmax, valids, w.Y[4],
                      w.bn[4], conv_w[4], w.coef[5], w.gram, (int)M, (int)N, (int)F, grad_conv_w[4]);
