@@ -10,7 +10,11 @@ the same keys, shapes and dtypes, batched `[B, ...]` and already on the device.
   rotations and point orders — with the reference's own RNG calls, in its order, so a seeded run reproduces
   the reference's batches — and converts the 3x3 matrices to scalar-first quaternions with scipy exactly as
   the reference does.  Mesh loading + surface sampling (`trimesh`, geometry_data.py:109-131) is a pluggable
-  `sampler`; this image has no trimesh, so the default sampler raises.
+  `sampler`: `ObjSurfaceSampler` reads the fracture folders' Wavefront .obj meshes itself and samples them with the
+  algorithm trimesh publishes for `trimesh.sample.sample_surface` (area-weighted face pick, folded uniform barycentric
+  coordinates, numpy's global RNG in the same call order).  trimesh is a third-party dependency that is neither vendored
+  by the reference nor present in this image, so that piece is PARITY UNPINNED (its statistical properties are tested);
+  without a sampler the producer raises.
 * PartNet-style semantic data: the on-disk format is plain numpy (`{category}.{split}.npy` id lists,
   `shape_data/{id}_level3.npy` pickled dicts, `contact_points/pairs_with_contact_points_{id}_level3.npy`);
   the label derivations (`instance_label`, `match_ids`, one-hot `part_label`) are host integer logic.
@@ -32,6 +36,66 @@ def _no_sampler(folder):
     raise RuntimeError(
         "GeometryBatchProducer: no mesh sampler configured (trimesh is not available in this image); pass "
         "`sampler=folder -> float64 [p, N, 3]` or call produce() with already sampled part clouds")
+
+
+def load_obj(path):
+    """Wavefront .obj -> (vertices float64 [V, 3], triangles int64 [F, 3]); polygons are fan-triangulated, texture /
+    normal indices (`v/vt/vn`) and negative (relative) indices are understood, everything else is ignored."""
+    verts, faces = [], []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("v "):
+                verts.append([float(t) for t in line.split()[1:4]])
+            elif line.startswith("f "):
+                idx = []
+                for tok in line.split()[1:]:
+                    i = int(tok.split("/")[0])
+                    idx.append(i - 1 if i > 0 else len(verts) + i)
+                for k in range(1, len(idx) - 1):
+                    faces.append([idx[0], idx[k], idx[k + 1]])
+    return np.asarray(verts, dtype=np.float64).reshape(-1, 3), np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+
+
+def sample_surface(vertices, faces, count):
+    """`trimesh.sample.sample_surface(mesh, count)[0]` restated from trimesh's published algorithm (trimesh is not in this
+    image: parity unpinned): faces are picked with probability proportional to their area by inverting the cumulative
+    area with `np.random.random(count)`, and a point inside the picked triangle is `origin + a * e1 + b * e2` with (a, b)
+    = `np.random.random((count, 2, 1))`, reflected into the triangle where a + b > 1.  Uses numpy's GLOBAL generator,
+    like trimesh, so that `np.random.seed` in the caller governs it."""
+    tri = vertices[faces]                                   # [F, 3, 3]
+    area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    weight_cum = np.cumsum(area)
+    face_pick = np.random.random(count) * weight_cum[-1]
+    face_index = np.searchsorted(weight_cum, face_pick)
+    origins = tri[face_index, 0]
+    vectors = tri[face_index, 1:] - origins[:, None, :]     # [count, 2, 3]
+    lengths = np.random.random((count, 2, 1))
+    outside = lengths.sum(axis=1).reshape(-1) > 1.0
+    lengths[outside] -= 1.0
+    lengths = np.abs(lengths)
+    return (vectors * lengths).sum(axis=1) + origins
+
+
+class ObjSurfaceSampler:
+    """`GeometryPartDataset._get_pcs` (geometry_data.py:109-131): the sorted mesh files of a fracture folder (shuffled
+    with `random.shuffle` if `shuffle_parts`), `num_points` surface samples each -> float64 [p, num_points, 3]."""
+
+    def __init__(self, data_dir, num_points=1000, min_num_part=2, max_num_part=20, shuffle_parts=False):
+        self.data_dir, self.num_points = data_dir, num_points
+        self.min_num_part, self.max_num_part, self.shuffle_parts = min_num_part, max_num_part, shuffle_parts
+
+    def __call__(self, data_folder):
+        folder = os.path.join(self.data_dir, data_folder)
+        mesh_files = sorted(os.listdir(folder))
+        if not self.min_num_part <= len(mesh_files) <= self.max_num_part:
+            raise ValueError(f"{folder}: {len(mesh_files)} parts outside [{self.min_num_part}, {self.max_num_part}]")
+        if self.shuffle_parts:
+            random.shuffle(mesh_files)
+        pcs = []
+        for name in mesh_files:
+            v, f = load_obj(os.path.join(folder, name))
+            pcs.append(sample_surface(v, f, self.num_points))
+        return np.stack(pcs, axis=0)
 
 
 def _to_device(arr: np.ndarray, device) -> torch.Tensor:
