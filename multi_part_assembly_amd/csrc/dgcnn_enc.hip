@@ -196,41 +196,49 @@ __global__ void dg_first_dgrad_kernel(const float* __restrict__ duv, const float
 }
 
 // ---- edge aggregation, forward ------------------------------------------------------------------------------------------------
-// grid = (CO / 32, M parts), block 512.  LDS: the part's U slice [N][32].  Lane = (point slot q = lane / 8, channel
-// quad cq = lane % 8): a wave gathers for 8 points at once with ds_read_b128, 8 waves -> 64 points per pass.
-constexpr int kAT = 512;
+// grid = (CO / 32, M parts), block AT = 1024 (512: the A/B baseline).  LDS (dynamic): the part's U slice [N][32] and the
+// BatchNorm partial sums of the block's point slots.  Lane = (point slot q = lane / 8, channel quad cq = lane % 8): a wave
+// gathers for 8 points at once with ds_read_b128, 16 waves -> 128 points per pass.
+#ifndef MPA_AGG_FWD_AT
+#define MPA_AGG_FWD_AT 1024
+#endif
+constexpr size_t agg_fwd_lds(int AT, int N) { return (size_t)N * 32 * sizeof(float) + (size_t)(AT / 8) * 32 * 2 * sizeof(float); }
 
 // Copy a 32-channel column slice (row stride `ld` floats, N rows) between global memory and an LDS panel [N][32] with
 // four independent 16-byte requests in flight per thread (a plain loop exposes one L2 round trip per pass).
+template <int AT>
 __device__ __forceinline__ void dg_load_slice(const float* __restrict__ src, int ld, int N, float* __restrict__ dst) {
-  for (int e0 = threadIdx.x; e0 < N * 8; e0 += 4 * kAT) {
+  for (int e0 = threadIdx.x; e0 < N * 8; e0 += 4 * AT) {
     float4 t[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * kAT, ec = e < N * 8 ? e : N * 8 - 1;
+      const int e = e0 + u * AT, ec = e < N * 8 ? e : N * 8 - 1;
       t[u] = *reinterpret_cast<const float4*>(src + (long long)(ec >> 3) * ld + 4 * (ec & 7));
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * kAT;
+      const int e = e0 + u * AT;
       if (e < N * 8) *reinterpret_cast<float4*>(&dst[4 * e]) = t[u];
     }
   }
 }
 
-__global__ __launch_bounds__(kAT) void dg_agg_fwd_kernel(const float* __restrict__ uv, int CO,
-                                                         const unsigned short* __restrict__ idx,
-                                                         const float* __restrict__ gamma, int N,
-                                                         float* __restrict__ esel, unsigned char* __restrict__ ssel,
-                                                         float* __restrict__ s1out, float* __restrict__ partial,
-                                                         const int* __restrict__ hdr) {
-  __shared__ __attribute__((aligned(16))) float Us[kMaxN * 32];
-  __shared__ float red[64][32][2];
+template <int AT>
+__global__ __launch_bounds__(AT) void dg_agg_fwd_kernel(const float* __restrict__ uv, int CO,
+                                                        const unsigned short* __restrict__ idx,
+                                                        const float* __restrict__ gamma, int N,
+                                                        float* __restrict__ esel, unsigned char* __restrict__ ssel,
+                                                        float* __restrict__ s1out, float* __restrict__ partial,
+                                                        const int* __restrict__ hdr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char agg_lds[];
+  constexpr int kSlots = AT / 8;  // points in flight per pass of the block
+  float* Us = reinterpret_cast<float*>(agg_lds);                                    // [N][32]
+  float(*red)[32][2] = reinterpret_cast<float(*)[32][2]>(Us + (size_t)N * 32);      // [kSlots][32][2]
   const int v = blockIdx.y;
   if (v >= hdr[0]) return;
   const int c0 = blockIdx.x * 32;
   const float* up = uv + (long long)v * N * 2 * CO;
-  dg_load_slice(up + c0, 2 * CO, N, Us);
+  dg_load_slice<AT>(up + c0, 2 * CO, N, Us);
   __syncthreads();
   // lane = (point slot q of 8, channel quad cq of 8): one ds_read_b128 per neighbour feeds four channels, so the index
   // unpacking and address arithmetic are paid once per four channels (the kernel is bound by VALU issue)
@@ -254,12 +262,12 @@ __global__ __launch_bounds__(kAT) void dg_agg_fwd_kernel(const float* __restrict
     vout = *reinterpret_cast<const float4*>(up + (long long)ic * 2 * CO + CO + c0 + 4 * cq);
   };
   request(wave * 8 + q, wn, vn);
-  for (int i = wave * 8 + q; i < N; i += 64) {
+  for (int i = wave * 8 + q; i < N; i += kSlots) {
     const long long row = (long long)v * N + i;
 #pragma unroll
     for (int u = 0; u < 10; ++u) wv[u] = wn[u];
     vv = vn;
-    request(i + 64, wn, vn);
+    request(i + kSlots, wn, vn);
     float best[4], su[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
     int at[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -300,10 +308,10 @@ __global__ __launch_bounds__(kAT) void dg_agg_fwd_kernel(const float* __restrict
     red[wave * 8 + q][4 * cq + k][1] = a2[k];
   }
   __syncthreads();
-  if (threadIdx.x < 32) {  // thread = channel of the slice; the 64 point slots in fixed order
+  if (threadIdx.x < 32) {  // thread = channel of the slice; the point slots in fixed order
     const int c = threadIdx.x;
     float s = 0.0f, ss = 0.0f;
-    for (int k = 0; k < 64; ++k) {
+    for (int k = 0; k < kSlots; ++k) {
       s += red[k][c][0];
       ss += red[k][c][1];
     }
@@ -743,18 +751,26 @@ __global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* 
 // with every sum taken in ascending source order (bit-reproducible).
 constexpr int kBS = 16;          // channels per slice
 constexpr int kRun = 512;        // scratch entries per wave (16 points x ~20 in-edges, with room for hubs)
-__global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict__ uv, int CO,
-                                                         const int* __restrict__ rptr, const int* __restrict__ order,
-                                                         const unsigned short* __restrict__ rlist,
-                                                         const float* __restrict__ dz,
-                                                         const unsigned char* __restrict__ ssel,
-                                                         const float* __restrict__ s1in, const float* __restrict__ coef,
-                                                         int N, float* __restrict__ guv, const int* __restrict__ hdr) {
-  __shared__ __attribute__((aligned(16))) float Vp[(kMaxN + 1) * kBS];
-  __shared__ __attribute__((aligned(16))) float Wp[(kMaxN + 1) * kBS];
-  __shared__ __attribute__((aligned(16))) unsigned char Sp[(kMaxN + 1) * kBS];
-  __shared__ int rps[kMaxN + 2];
-  __shared__ unsigned short scr[kAT / 64][kRun];
+// LDS of a block of AT threads for parts of N points (dynamic: the 16-wave variant needs all 160 KB at N = 1000)
+constexpr size_t agg_bwd_lds(int AT, int N) {
+  return (size_t)(N + 1) * kBS * (2 * sizeof(float) + 1) + (size_t)(AT / 64) * kRun * 2 + (size_t)(N + 2) * 2;
+}
+// AT = 1024 (16 waves, four per SIMD: the loop is two dependent LDS round trips per four in-edges, and 59 % of the wave
+// cycles of the 8-wave variant were waits) whenever its panels fit; AT = 512 otherwise.
+template <int AT>
+__global__ __launch_bounds__(AT) void dg_agg_bwd_kernel(const float* __restrict__ uv, int CO,
+                                                        const int* __restrict__ rptr, const int* __restrict__ order,
+                                                        const unsigned short* __restrict__ rlist,
+                                                        const float* __restrict__ dz,
+                                                        const unsigned char* __restrict__ ssel,
+                                                        const float* __restrict__ s1in, const float* __restrict__ coef,
+                                                        int N, float* __restrict__ guv, const int* __restrict__ hdr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char agg_lds[];
+  float* Vp = reinterpret_cast<float*>(agg_lds);                                   // [(N + 1)][kBS]
+  float* Wp = Vp + (N + 1) * kBS;                                                  // [(N + 1)][kBS]
+  unsigned char* Sp = reinterpret_cast<unsigned char*>(Wp + (N + 1) * kBS);       // [(N + 1)][kBS]
+  unsigned short* scr_all = reinterpret_cast<unsigned short*>(Sp + (N + 1) * kBS);  // [AT / 64][kRun]
+  unsigned short* rps = scr_all + (AT / 64) * kRun;                                // [N + 2]: offsets < 20 N <= 20480
   const int v = blockIdx.y;
   if (v >= hdr[0]) return;
   const int c0 = blockIdx.x * kBS;
@@ -763,17 +779,17 @@ __global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict
   const float* dzp = dz + (long long)v * N * CO;
   const unsigned char* sp = ssel + (long long)v * N * CO;
   // panels: four requests in flight per thread
-  for (int e0 = threadIdx.x; e0 < N * 4; e0 += 4 * kAT) {
+  for (int e0 = threadIdx.x; e0 < N * 4; e0 += 4 * AT) {
     float4 tv[4], tw[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * kAT, ec = e < N * 4 ? e : N * 4 - 1;
+      const int e = e0 + u * AT, ec = e < N * 4 ? e : N * 4 - 1;
       tv[u] = *reinterpret_cast<const float4*>(up + (long long)(ec >> 2) * 2 * CO + CO + c0 + 4 * (ec & 3));
       tw[u] = *reinterpret_cast<const float4*>(dzp + (long long)(ec >> 2) * CO + c0 + 4 * (ec & 3));
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * kAT;
+      const int e = e0 + u * AT;
       if (e < N * 4) {
         const float4 al = *reinterpret_cast<const float4*>(coef + c0 + 4 * (e & 3));
         *reinterpret_cast<float4*>(&Vp[4 * e]) = tv[u];
@@ -781,20 +797,20 @@ __global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict
       }
     }
   }
-  for (int r = threadIdx.x; r < N; r += kAT)
+  for (int r = threadIdx.x; r < N; r += AT)
     *reinterpret_cast<uint4*>(&Sp[r * kBS]) = *reinterpret_cast<const uint4*>(sp + (long long)r * CO + c0);
   if (threadIdx.x < kBS) {
     Vp[N * kBS + threadIdx.x] = 0.0f;
     Wp[N * kBS + threadIdx.x] = 0.0f;
     Sp[N * kBS + threadIdx.x] = 255;
   }
-  for (int e = threadIdx.x; e <= N; e += kAT) rps[e] = rptr[(long long)v * (N + 1) + e];
+  for (int e = threadIdx.x; e <= N; e += AT) rps[e] = (unsigned short)rptr[(long long)v * (N + 1) + e];
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cq = lane & 3, q = lane >> 2;
   const float4 gammap = *reinterpret_cast<const float4*>(coef + CO + c0 + 4 * cq);
   const float4 betap = *reinterpret_cast<const float4*>(coef + 2 * CO + c0 + 4 * cq);
   const unsigned short* rl = rlist + (long long)v * N * kNbr;
-  unsigned short* sc = scr[wave];
+  unsigned short* sc = scr_all + wave * kRun;
   const int last = N * kNbr - 1;
   const unsigned short kNeutral = (unsigned short)(N * 32 + 31);
   // the in-edge lists of a wave pass's 16 consecutive points are ONE contiguous run of rlist: requested a pass ahead
@@ -814,14 +830,14 @@ __global__ __launch_bounds__(kAT) void dg_agg_bwd_kernel(const float* __restrict
     sn = *reinterpret_cast<const float4*>(s1in + ((long long)v * N + jn) * CO + c0 + 4 * cq);
   };
   request(wave * 16);
-  for (int j0 = wave * 16; j0 < N; j0 += 128) {
+  for (int j0 = wave * 16; j0 < N; j0 += AT / 4) {
     const int rk = j0 + q, j = jn;
     const int base = rps[j0];
     const int b = rk < N ? rps[rk] : base, e = rk < N ? rps[rk + 1] : base;
 #pragma unroll
     for (int u = 0; u < kRun / 64; ++u) sc[64 * u + lane] = pre[u];
     const float4 u4 = un, s4 = sn;
-    request(j0 + 128);
+    request(j0 + AT / 4);
     __builtin_amdgcn_wave_barrier();  // the scratch is private to the wave; LDS keeps a wave's accesses in order
     int kmax = e - b;
 #pragma unroll
@@ -1034,6 +1050,29 @@ void launch(Kern kern, dim3 grid, dim3 block, hipStream_t s, Args... args) {
   hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
 }
 
+// the transposed-graph pass with as many waves as its LDS panels leave room for (see dg_agg_bwd_kernel)
+#ifndef MPA_AGG_BWD_AT
+#define MPA_AGG_BWD_AT 1024
+#endif
+template <int AT, typename... Args>
+void launch_agg_bwd_as(dim3 grid, hipStream_t s, int N, Args... args) {
+  static bool reserved = false;  // the opt-in to more than 64 KB of dynamic LDS is per kernel, once
+  if (!reserved) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(dg_agg_bwd_kernel<AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)(agg_bwd_lds(AT, kMaxN) < 160 * 1024 ? agg_bwd_lds(AT, kMaxN) : 160 * 1024));
+    reserved = true;
+  }
+  hipLaunchKernelGGL(dg_agg_bwd_kernel<AT>, grid, dim3(AT), agg_bwd_lds(AT, N), s, args...);
+}
+inline void launch_agg_bwd(dim3 grid, hipStream_t s, const float* uv, int CO, const int* rptr, const int* order,
+                    const unsigned short* rlist, const float* dz, const unsigned char* ssel, const float* s1,
+                    const float* coef, int N, float* guv, const int* hdr) {
+  if (agg_bwd_lds(MPA_AGG_BWD_AT, N) <= 160 * 1024)
+    launch_agg_bwd_as<MPA_AGG_BWD_AT>(grid, s, N, uv, CO, rptr, order, rlist, dz, ssel, s1, coef, N, guv, hdr);
+  else
+    launch_agg_bwd_as<512>(grid, s, N, uv, CO, rptr, order, rlist, dz, ssel, s1, coef, N, guv, hdr);
+}
+
 // C (+)= A . W^T on the matrix cores (see dg_gemm.h); Nout a multiple of 64
 void gemm_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, int Nout, bool accum, int64_t Rmax,
              const int* hdr, hipStream_t s) {
@@ -1129,9 +1168,18 @@ int dgcnn_forward_impl(const float* points, const float* valids, const float* co
     } else {
       gemm_nt(w.hcat + kOff[l - 1], kCat, w.wstk[l], C, w.uv[l], 2 * CO, 2 * CO, false, R, w.hdr, s);
     }
-    launch(dg_agg_fwd_kernel, dim3((unsigned)(CO / 32), (unsigned)M), dim3(kAT), s, (const float*)w.uv[l], CO,
-           (const unsigned short*)w.idx[l], bn_w[l], (int)N, w.esel[l], w.ssel[l], w.s1[l], w.partial,
-           (const int*)w.hdr);
+    {
+      static bool reserved = false;  // opt-in to more than 64 KB of dynamic LDS, once
+      if (!reserved) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dg_agg_fwd_kernel<MPA_AGG_FWD_AT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)agg_fwd_lds(MPA_AGG_FWD_AT, kMaxN));
+        reserved = true;
+      }
+      hipLaunchKernelGGL(dg_agg_fwd_kernel<MPA_AGG_FWD_AT>, dim3((unsigned)(CO / 32), (unsigned)M), dim3(MPA_AGG_FWD_AT),
+                         agg_fwd_lds(MPA_AGG_FWD_AT, (int)N), s, (const float*)w.uv[l], CO,
+                         (const unsigned short*)w.idx[l], bn_w[l], (int)N, w.esel[l], w.ssel[l], w.s1[l], w.partial,
+                         (const int*)w.hdr);
+    }
     if (training) {
       launch(dg_bn_finalize_kernel, dim3((unsigned)(CO / 64), (unsigned)((M + kEB - 1) / kEB)), dim3(64 * kSlices), s,
              (const float*)w.partial, (int)M, CO, 1, kNbr, bn_w[l], bn_b[l], running_mean[l], running_var[l], momentum,
@@ -1235,9 +1283,9 @@ extern "C" int mpa_dgcnn_backward(const float* grad_feat, const float* const* co
            grad_bn_b[l], cw, hdr);
     launch(dg_reverse_kernel, dim3((unsigned)M), dim3(1024), s, (const unsigned short*)w.idx[l], (int)N, w.rptr, w.order,
            w.rlist, hdr);
-    launch(dg_agg_bwd_kernel, dim3((unsigned)(CO / kBS), (unsigned)M), dim3(kAT), s, (const float*)w.uv[l], CO,
-           (const int*)w.rptr, (const int*)w.order, (const unsigned short*)w.rlist, (const float*)w.dz,
-           (const unsigned char*)w.ssel[l], (const float*)w.s1[l], (const float*)w.coef, (int)N, w.duv, hdr);
+    launch_agg_bwd(dim3((unsigned)(CO / kBS), (unsigned)M), s, (const float*)w.uv[l], CO, (const int*)w.rptr,
+                   (const int*)w.order, (const unsigned short*)w.rlist, (const float*)w.dz,
+                   (const unsigned char*)w.ssel[l], (const float*)w.s1[l], (const float*)w.coef, (int)N, w.duv, hdr);
     if (l == 0) {
       const int t1 = (int)((R + kFirstTile - 1) / kFirstTile);
       launch(dg_first_wgrad_kernel, dim3((unsigned)t1), dim3(512), s, (const float*)w.duv, (const float4*)w.x0, w.tnpart,

@@ -31,7 +31,7 @@ print(f"steps={n} wall/step={(t1 - t0) / n / 1e6:.3f} ms  kernel-busy/step={busy
 print(f"{'ms/step':>9} {'calls/step':>10} {'avg us':>9}  kernel")
 for name, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[: a.top]:
     print(f"{d / n / 1e6:9.3f} {c / n:10.1f} {d / c / 1e3:9.1f}  {name[:120]}")
-if a.seq:
+if a.seq is not None:
     last = rows[marks[-2] + 1: marks[-1] + 1]
     print(f"-- last step, launch order, kernels matching {a.seq!r} (start offset us, duration us, grid, block)")
     for r in last:
