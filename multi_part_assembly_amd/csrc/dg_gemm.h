@@ -171,8 +171,10 @@ __global__ __launch_bounds__(kGT, DG_TN_BUFS == 2 ? 2 : 3) void gemm_tn_kernel(c
   __shared__ __attribute__((aligned(16))) float Xs[DG_TN_BUFS][RC * BK];
   const int R = hdr[1];
   const int n0 = blockIdx.x * BNT, k0 = blockIdx.y * BK;
-  const long long rb = (long long)blockIdx.z * rows_per_chunk;
-  long long re = rb + rows_per_chunk;
+  // rows_per_chunk == 0: the valid rows (known on the device only) are dealt evenly to the grid's chunks
+  const int rpc = rows_per_chunk > 0 ? rows_per_chunk : (int)((((long long)R + gridDim.z - 1) / gridDim.z + 31) / 32 * 32);
+  const long long rb = (long long)blockIdx.z * rpc;
+  long long re = rb + rpc;
   if (re > R) re = R;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int wn = wave >> 1, wk = wave & 1;  // wave tile: n rows wn*64.., k columns wk*WK..

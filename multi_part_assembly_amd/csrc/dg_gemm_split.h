@@ -4,9 +4,8 @@
 // v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The dropped terms (ml, lm, ll) are below 2^-23 |x||y| per
 // element — the size of ONE fp32 rounding of the product — so the result differs from an fp32 GEMM by no more than a
 // different summation order does (tests hold the encoder to 1e-4 / 2e-4 of float64 as before).  Six bf16 MFMAs of K = 16
-// take 6 x 32 = 192 cycles per SIMD where the eight v_mfma_f32_32x32x2_f32 of the same 16 k-values take 512: the
-// large GEMMs of the DGCNN encoder and of the graph networks' MLP layers move from the fp32-MFMA bound (100 TFLOP/s
-// measured = 64 % of its peak) to the HBM / LDS bound.  Same tiles, grids and calling conventions as dg_gemm.h.
+// take 6 x 32 = 192 cycles per SIMD where the eight v_mfma_f32_32x32x2_f32 of the same 16 k-values take 512.
+// Same tiles, grids and calling conventions as dg_gemm.h.
 //
 //   gemm_nt_split :  C[r, n] (+)= sum_k A[r, k] * W[n, k]
 //   gemm_tn_split :  P[chunk][n, k] = sum_{r in chunk} Y[r, n] * X[r, k]
@@ -14,6 +13,13 @@
 // LDS panels hold the three bf16 planes of a 32-wide k chunk side by side: row = [h(32) | m(32) | l(32)] bf16 = 192
 // bytes + 16 of padding (208 = 13 x 16: the 16-byte fragment reads of 16 consecutive rows fall on 16 different bank
 // quads).  The split is computed while the operands are staged (13 VALU operations per pair of elements).
+//
+// Block = kGsT threads.  tools/probes/gemm_split.hip takes the kernels apart at the encoder's shapes: the three phases of
+// a K step — global loads, split + LDS stores, MFMAs — cost about 100 + 145 + 200 us of a 470 us weight gradient and
+// add up rather than overlap, with four waves per block (two blocks per CU) or eight (DG_GS_WAVES: 64 x 32 wave tiles,
+// four waves per SIMD), with one K step of loads in flight or two: the time is the same within 3 %.  The loads of the
+// big shapes move 1.4 GB at ~4.6 TB/s when they run alone; the MFMAs alone run at 240 TFLOP/s fp32-equivalent (the
+// bf16 pipe's sustained 1.85 PFLOP/s over six products).  Four waves are the default.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -25,7 +31,23 @@ namespace dg {
 typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 gs_bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGsRow = 208;  // bytes per LDS row: 3 planes x 32 bf16 + 16 pad
+#ifndef DG_GS_WAVES  // A/B knob: waves per block (4: the 2 x 2 arrangement of dg_gemm.h; 8: 2 x 4 / 4 x 2)
+#define DG_GS_WAVES 4
+#endif
+constexpr int kGsT = 64 * DG_GS_WAVES;  // threads per block
+constexpr int kGsRow = 208;             // bytes per LDS row: 3 planes x 32 bf16 + 16 pad
+
+// probe knobs (tools/probes/gemm_split.hip): which of the three phases of a K step the kernels execute
+#ifdef GS_PROBE_NO_STASH
+#define GS_STASH_ON (hdr[0] == -12345)
+#else
+#define GS_STASH_ON true
+#endif
+#ifdef GS_PROBE_NO_LOAD
+#define GS_LOAD_ON (hdr[0] == -12345)
+#else
+#define GS_LOAD_ON true
+#endif
 
 struct Split4 {
   gs_bf16x4 h, m, l;
@@ -62,6 +84,9 @@ __device__ __forceinline__ Frag3 gs_frag(const unsigned char* panel, int row, in
   f.l = *reinterpret_cast<const gs_bf16x8*>(p + 128);
   return f;
 }
+#ifdef GS_PROBE_NO_MMA  // probe knob: staging without the matrix products
+#define GS_MMA6(acc, a, b) acc[0] += (float)(a).h[0] * (float)(b).l[0];
+#else
 #define GS_MMA6(acc, a, b)                                                          \
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16((a).h, (b).h, acc, 0, 0, 0);        \
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16((a).h, (b).m, acc, 0, 0, 0);        \
@@ -69,15 +94,42 @@ __device__ __forceinline__ Frag3 gs_frag(const unsigned char* panel, int row, in
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16((a).m, (b).m, acc, 0, 0, 0);        \
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16((a).h, (b).l, acc, 0, 0, 0);        \
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16((a).l, (b).h, acc, 0, 0, 0);
+#endif
+
+// 4 x 4 transpose of bf16 values inside a lane quad: lane t holds (row t; columns 0..3) and receives (column t; rows
+// 0..3) — two exchange stages (lane ^ 1, lane ^ 2), each one DPP move and one byte permute / select per dword.
+//   sel1 = lane odd ? 0x03020706 : 0x05040100,  low = (lane & 2) == 0
+__device__ __forceinline__ uint2 gs_quad_transpose(const gs_bf16x4 x, unsigned sel1, bool low) {
+  const uint2 w = __builtin_bit_cast(uint2, x);
+  const unsigned p0 = (unsigned)__builtin_amdgcn_mov_dpp((int)w.x, 0xb1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+  const unsigned p1 = (unsigned)__builtin_amdgcn_mov_dpp((int)w.y, 0xb1, 0xf, 0xf, true);
+  const unsigned a0 = __builtin_amdgcn_perm(p0, w.x, sel1);  // column (lane & 1), rows of the lane pair
+  const unsigned a1 = __builtin_amdgcn_perm(p1, w.y, sel1);  // column 2 + (lane & 1)
+  const unsigned send = low ? a1 : a0;
+  const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4e, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+  return low ? make_uint2(a0, recv) : make_uint2(recv, a1);
+}
+
+// waves of a block as WR x WC over a 128 x BN tile: wave tiles of 64 x (BN / 2) with four waves, 64 x 32 or 32 x 32
+// with eight
+template <int BN>
+struct GsWaves {
+  static constexpr int WC = DG_GS_WAVES == 4 ? 2 : (BN == 128 ? 4 : 2), WR = DG_GS_WAVES / WC;
+  static constexpr int TM = 128 / WR / 32, TN = BN / WC / 32;  // 32 x 32 accumulators per wave
+  static_assert(TM >= 1 && TN >= 1, "wave tile");
+};
 
 // ---- C[r, n] (+)= A[r, :] . W[n, :] -----------------------------------------------------------------------------------
-// Arguments, tiles and the XCD-aware block -> tile mapping exactly as gemm_nt_kernel (dg_gemm.h).
+// Arguments, tiles and the XCD-aware block -> tile mapping exactly as gemm_nt_kernel (dg_gemm.h); block = kGsT threads.
 template <int BN, bool ACCUM>
-__global__ __launch_bounds__(kGT, 2) void gemm_nt_split_kernel(const float* __restrict__ A, int lda,
-                                                               const float* __restrict__ W, int K, float* __restrict__ C,
-                                                               int ldc, const int* __restrict__ hdr) {
-  constexpr int BM = 128, WN = BN / 2, TN = WN / 32;
-  constexpr int B4 = BN * kKC / 4 / kGT;  // float4 per thread and chunk of the W panel: 4 or 2
+__global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_nt_split_kernel(const float* __restrict__ A, int lda,
+                                                            const float* __restrict__ W, int K, float* __restrict__ C,
+                                                            int ldc, const int* __restrict__ hdr) {
+  constexpr int BM = 128;
+  using WV = GsWaves<BN>;
+  constexpr int TM = WV::TM, TN = WV::TN;
+  constexpr int RS = kGsT / 8;                 // panel rows staged per pass of the block (8 threads per 32-float row)
+  constexpr int A4 = BM / RS, B4 = BN / RS;    // float4 per thread and chunk
   __shared__ __attribute__((aligned(16))) unsigned char As[BM * kGsRow];
   __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * kGsRow];
   const int R = hdr[1];
@@ -90,62 +142,48 @@ __global__ __launch_bounds__(kGT, 2) void gemm_nt_split_kernel(const float* __re
   }
   if (r0 >= R) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WV::WC, wc = wave % WV::WC;
   const int c4 = threadIdx.x & 7, rl = threadIdx.x >> 3;
-  static_assert(B4 == 4 || B4 == 2, "staging layout");
-  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2 = {}, rb3 = {};
-  const float* ap_[4];
+  float4 ra[A4], rb[B4];
+  const float* ap_[A4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    long long r = r0 + rl + 32 * i;
+  for (int i = 0; i < A4; ++i) {
+    const long long r = r0 + rl + RS * i;
     ap_[i] = A + (r < R ? r : (long long)R - 1) * lda + 4 * c4;
   }
   const float* wp_ = W + (long long)(n0 + rl) * K + 4 * c4;
-#define GS_NT_FETCH(kc)                                                        \
-  ra0 = *reinterpret_cast<const float4*>(ap_[0] + (kc));                       \
-  ra1 = *reinterpret_cast<const float4*>(ap_[1] + (kc));                       \
-  ra2 = *reinterpret_cast<const float4*>(ap_[2] + (kc));                       \
-  ra3 = *reinterpret_cast<const float4*>(ap_[3] + (kc));                       \
-  rb0 = *reinterpret_cast<const float4*>(wp_ + (kc));                          \
-  rb1 = *reinterpret_cast<const float4*>(wp_ + 32LL * K + (kc));               \
-  if constexpr (B4 == 4) {                                                     \
-    rb2 = *reinterpret_cast<const float4*>(wp_ + 64LL * K + (kc));             \
-    rb3 = *reinterpret_cast<const float4*>(wp_ + 96LL * K + (kc));             \
-  }
-#define GS_NT_STASH()                                                          \
-  gs_stash(As, rl + 0, c4, ra0);                                               \
-  gs_stash(As, rl + 32, c4, ra1);                                              \
-  gs_stash(As, rl + 64, c4, ra2);                                              \
-  gs_stash(As, rl + 96, c4, ra3);                                              \
-  gs_stash(Bs, rl + 0, c4, rb0);                                               \
-  gs_stash(Bs, rl + 32, c4, rb1);                                              \
-  if constexpr (B4 == 4) {                                                     \
-    gs_stash(Bs, rl + 64, c4, rb2);                                            \
-    gs_stash(Bs, rl + 96, c4, rb3);                                            \
-  }
-  f32x16 acc[2][TN];
+  auto fetch = [&](int kc) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int i = 0; i < A4; ++i) ra[i] = *reinterpret_cast<const float4*>(ap_[i] + kc);
+#pragma unroll
+    for (int i = 0; i < B4; ++i) rb[i] = *reinterpret_cast<const float4*>(wp_ + (long long)(RS * i) * K + kc);
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x16{0};
-  GS_NT_FETCH(0)
+  fetch(0);
   const int chunks = K / kKC;
   for (int c = 0; c < chunks; ++c) {
     if (c > 0) __syncthreads();  // the previous chunk's fragment reads are done
-    GS_NT_STASH()
-    __syncthreads();
-    if (c + 1 < chunks) {
-      GS_NT_FETCH((c + 1) * kKC)
+    if (GS_STASH_ON) {
+#pragma unroll
+      for (int i = 0; i < A4; ++i) gs_stash(As, rl + RS * i, c4, ra[i]);
+#pragma unroll
+      for (int i = 0; i < B4; ++i) gs_stash(Bs, rl + RS * i, c4, rb[i]);
     }
+    __syncthreads();
+    if (c + 1 < chunks && GS_LOAD_ON) fetch((c + 1) * kKC);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      Frag3 fa[2], fb[TN];
+      Frag3 fa[TM], fb[TN];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) fa[a] = gs_frag(As, wr * 64 + a * 32 + j, s, h);
+      for (int a = 0; a < TM; ++a) fa[a] = gs_frag(As, wr * (32 * TM) + a * 32 + j, s, h);
 #pragma unroll
-      for (int b = 0; b < TN; ++b) fb[b] = gs_frag(Bs, wc * WN + b * 32 + j, s, h);
+      for (int b = 0; b < TN; ++b) fb[b] = gs_frag(Bs, wc * (32 * TN) + b * 32 + j, s, h);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
           GS_MMA6(acc[a][b], fa[a], fb[b])
@@ -153,12 +191,12 @@ __global__ __launch_bounds__(kGT, 2) void gemm_nt_split_kernel(const float* __re
     }
   }
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const long long row = r0 + wr * 64 + a * 32 + acc_row(r, h);
+      const long long row = r0 + wr * (32 * TM) + a * 32 + acc_row(r, h);
       if (row < R) {
-        float* dst = C + row * ldc + n0 + wc * WN + j;
+        float* dst = C + row * ldc + n0 + wc * (32 * TN) + j;
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
           if constexpr (ACCUM) dst[32 * b] += acc[a][b][r];
@@ -166,62 +204,72 @@ __global__ __launch_bounds__(kGT, 2) void gemm_nt_split_kernel(const float* __re
         }
       }
     }
-#undef GS_NT_FETCH
-#undef GS_NT_STASH
 }
 
 // ---- P[chunk][n, k] = sum over the chunk's rows of Y[r, n] * X[r, k] ----------------------------------------------------
-// Arguments and grid as gemm_tn_kernel.  The MFMA reduction index is the point row, so both operands are TRANSPOSED while
-// they are staged: a thread's float4 (one row, four columns) becomes 3 x 4 two-byte stores into the rows [column][row] of
-// the panels.  The four 8-row groups of a panel row are XOR-swizzled by (column >> 4) & 3: the stores of an instruction
-// fall on 16 different banks (2-way) instead of 4, and a fragment (8 consecutive rows = one aligned 16-byte group) stays
-// contiguous and in order.
+// Arguments and grid as gemm_tn_kernel; block = kGsT threads.  The MFMA reduction index is the point row, so both operands
+// are TRANSPOSED while they are staged into the rows [column][row] of the panels.  The four lanes of a quad load four
+// consecutive rows of the same four columns, transpose the 4 x 4 block of every bf16 plane in registers
+// (gs_quad_transpose) and store 8 bytes (one column, four rows) each: 3 ds_write_b64 per float4 where element-wise
+// stores take 12 ds_write_b16.  A 16-lane store group is 8 columns x 2 row groups = 32 different banks.  The four 8-row
+// groups of a panel row are XOR-swizzled by (column >> 4) & 3 (a fragment = 8 consecutive rows = one aligned 16-byte
+// group).
 template <int BK>
-__global__ __launch_bounds__(kGT, 2) void gemm_tn_split_kernel(const float* __restrict__ Y, int ldy, int Nout,
-                                                               const float* __restrict__ X, int ldx, int K,
-                                                               float* __restrict__ part, int rows_per_chunk,
-                                                               const int* __restrict__ hdr) {
+__global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_tn_split_kernel(const float* __restrict__ Y, int ldy, int Nout,
+                                                            const float* __restrict__ X, int ldx, int K,
+                                                            float* __restrict__ part, int rows_per_chunk,
+                                                            const int* __restrict__ hdr) {
   constexpr int BNT = 128, RC = 32;
-  constexpr int WK = BK / 2, TK = WK / 32;
-  constexpr int Y4 = RC * BNT / 4 / kGT;  // 4
-  constexpr int X4 = RC * BK / 4 / kGT;   // 2 or 4
+  // waves as WNW x WKW over the 128 x BK tile of the gradient
+  constexpr int WKW = DG_GS_WAVES == 4 ? 2 : (BK == 128 ? 4 : 2), WNW = DG_GS_WAVES / WKW;
+  constexpr int TNn = BNT / WNW / 32, TK = BK / WKW / 32;
+  constexpr int YC = BNT / 4, XC = BK / 4;           // column quads per row
+  constexpr int YS = 2 * (kGsT / 8) / YC, XS = 2 * (kGsT / 8) / XC;  // 4-row groups staged per pass of the block
+  constexpr int Y4 = 8 / YS, X4 = 8 / XS;            // float4 per thread and step
+  static_assert(YS >= 1 && XS >= 1 && YS <= 8 && XS <= 8, "staging layout");
   __shared__ __attribute__((aligned(16))) unsigned char Ys[BNT * kGsRow];
   __shared__ __attribute__((aligned(16))) unsigned char Xs[BK * kGsRow];
   const int R = hdr[1];
   const int n0 = blockIdx.x * BNT, k0 = blockIdx.y * BK;
-  const long long rb = (long long)blockIdx.z * rows_per_chunk;
-  long long re = rb + rows_per_chunk;
+  // rows_per_chunk == 0: the valid rows (known on the device only) are dealt evenly to the grid's chunks
+  const int rpc = rows_per_chunk > 0 ? rows_per_chunk : (int)((((long long)R + gridDim.z - 1) / gridDim.z + 31) / 32 * 32);
+  const long long rb = (long long)blockIdx.z * rpc;
+  long long re = rb + rpc;
   if (re > R) re = R;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int wn = wave >> 1, wk = wave & 1;
+  const int wn = wave / WKW, wk = wave % WKW;
   float4 ry[Y4], rx[X4];
+  // thread -> (row 4 g + qt, column quad c4):  qt = tid & 3, g = (tid >> 2 & 1) + 2 ((tid >> 3) / C) + S i,  c4 = (tid >> 3) % C
+  const int qt = threadIdx.x & 3, t8 = threadIdx.x >> 3;
+  const int yc4 = t8 % YC, yg = ((threadIdx.x >> 2) & 1) + 2 * (t8 / YC);
+  const int xc4 = t8 % XC, xg = ((threadIdx.x >> 2) & 1) + 2 * (t8 / XC);
+  const unsigned sel1 = (qt & 1) ? 0x03020706u : 0x05040100u;
+  const bool qlow = (qt & 2) == 0;
+  const bool ycol_ok = n0 + 4 * yc4 < Nout;
+  const float* ybase = Y + (ycol_ok ? n0 + 4 * yc4 : 0);
+  const float* xbase = X + k0 + 4 * xc4;
+  // loads are unconditional (rows clamped to the chunk's last one); what lies past the chunk is zeroed when it is staged
   auto fetch = [&](long long r) {
 #pragma unroll
     for (int i = 0; i < Y4; ++i) {
-      const int e = threadIdx.x + i * kGT, row = e / (BNT / 4), c4 = e % (BNT / 4);
-      const bool ok = r + row < re && n0 + 4 * c4 < Nout;
-      const float4 t = *reinterpret_cast<const float4*>(Y + (ok ? (r + row) * ldy + n0 + 4 * c4 : 0));
-      ry[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+      const long long row = r + 4 * (yg + YS * i) + qt;
+      ry[i] = *reinterpret_cast<const float4*>(ybase + (row < re ? row : re - 1) * ldy);
     }
 #pragma unroll
     for (int i = 0; i < X4; ++i) {
-      const int e = threadIdx.x + i * kGT, row = e / (BK / 4), c4 = e % (BK / 4);
-      const bool ok = r + row < re;
-      const float4 t = *reinterpret_cast<const float4*>(X + (ok ? (r + row) * ldx + k0 + 4 * c4 : 0));
-      rx[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+      const long long row = r + 4 * (xg + XS * i) + qt;
+      rx[i] = *reinterpret_cast<const float4*>(xbase + (row < re ? row : re - 1) * ldx);
     }
   };
-  // element (row r of the step, column col) -> byte offset of its h plane entry
-  auto slot = [](int col, int r) { return col * kGsRow + 16 * ((r >> 3) ^ ((col >> 4) & 3)) + 2 * (r & 7); };
-  auto put = [&](unsigned char* panel, int col0, int r, const float4 v) {
+  // the quad's 4 x 4 block (rows 4 g .. 4 g + 3, columns 4 c4 .. 4 c4 + 3): this lane stores column 4 c4 + qt
+  auto put = [&](unsigned char* panel, int c4, int g, const float4 v0, bool ok) {
+    const float4 v = make_float4(ok ? v0.x : 0.f, ok ? v0.y : 0.f, ok ? v0.z : 0.f, ok ? v0.w : 0.f);
     const Split4 s = gs_split(v);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      unsigned char* p = panel + slot(col0 + u, r);
-      *reinterpret_cast<__bf16*>(p) = s.h[u];
-      *reinterpret_cast<__bf16*>(p + 64) = s.m[u];
-      *reinterpret_cast<__bf16*>(p + 128) = s.l[u];
-    }
+    const int col = 4 * c4 + qt;
+    unsigned char* p = panel + col * kGsRow + 16 * ((g >> 1) ^ ((col >> 4) & 3)) + 8 * (g & 1);
+    *reinterpret_cast<uint2*>(p) = gs_quad_transpose(s.h, sel1, qlow);
+    *reinterpret_cast<uint2*>(p + 64) = gs_quad_transpose(s.m, sel1, qlow);
+    *reinterpret_cast<uint2*>(p + 128) = gs_quad_transpose(s.l, sel1, qlow);
   };
   auto frag = [&](const unsigned char* panel, int col, int s) {  // rows 16 s + 8 h .. + 7 of column `col`
     const unsigned char* p = panel + col * kGsRow + 16 * ((2 * s + h) ^ ((col >> 4) & 3));
@@ -231,36 +279,38 @@ __global__ __launch_bounds__(kGT, 2) void gemm_tn_split_kernel(const float* __re
     f.l = *reinterpret_cast<const gs_bf16x8*>(p + 128);
     return f;
   };
-  f32x16 acc[2][TK];
+  f32x16 acc[TNn][TK];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TNn; ++a)
 #pragma unroll
     for (int b = 0; b < TK; ++b) acc[a][b] = f32x16{0};
   if (rb < re) {
     fetch(rb);
     for (long long r = rb; r < re; r += RC) {
       if (r > rb) __syncthreads();  // the previous step's fragment reads are done
+      if (GS_STASH_ON) {
 #pragma unroll
-      for (int i = 0; i < Y4; ++i) {
-        const int e = threadIdx.x + i * kGT;
-        put(Ys, 4 * (e % (BNT / 4)), e / (BNT / 4), ry[i]);
-      }
+        for (int i = 0; i < Y4; ++i) {
+          const int g = yg + YS * i;
+          put(Ys, yc4, g, ry[i], ycol_ok && r + 4 * g + qt < re);
+        }
 #pragma unroll
-      for (int i = 0; i < X4; ++i) {
-        const int e = threadIdx.x + i * kGT;
-        put(Xs, 4 * (e % (BK / 4)), e / (BK / 4), rx[i]);
+        for (int i = 0; i < X4; ++i) {
+          const int g = xg + XS * i;
+          put(Xs, xc4, g, rx[i], r + 4 * g + qt < re);
+        }
       }
       __syncthreads();
-      if (r + RC < re) fetch(r + RC);
+      if (r + RC < re && GS_LOAD_ON) fetch(r + RC);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        Frag3 fy[2], fx[TK];
+        Frag3 fy[TNn], fx[TK];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) fy[a] = frag(Ys, wn * 64 + 32 * a + j, s);
+        for (int a = 0; a < TNn; ++a) fy[a] = frag(Ys, wn * (32 * TNn) + 32 * a + j, s);
 #pragma unroll
-        for (int b = 0; b < TK; ++b) fx[b] = frag(Xs, wk * WK + 32 * b + j, s);
+        for (int b = 0; b < TK; ++b) fx[b] = frag(Xs, wk * (32 * TK) + 32 * b + j, s);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TNn; ++a)
 #pragma unroll
           for (int b = 0; b < TK; ++b) {
             GS_MMA6(acc[a][b], fy[a], fx[b])
@@ -270,13 +320,13 @@ __global__ __launch_bounds__(kGT, 2) void gemm_tn_split_kernel(const float* __re
   }
   float* out = part + (long long)blockIdx.z * Nout * K;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TNn; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = n0 + wn * 64 + a * 32 + acc_row(r, h);
+      const int n = n0 + wn * (32 * TNn) + a * 32 + acc_row(r, h);
       if (n < Nout) {
 #pragma unroll
-        for (int b = 0; b < TK; ++b) out[(long long)n * K + k0 + wk * WK + 32 * b + j] = acc[a][b][r];
+        for (int b = 0; b < TK; ++b) out[(long long)n * K + k0 + wk * (32 * TK) + 32 * b + j] = acc[a][b][r];
       }
     }
 }

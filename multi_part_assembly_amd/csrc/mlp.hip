@@ -19,9 +19,11 @@
 #if DG_GEMM_SPLIT
 #define DG_NT_KERNEL gemm_nt_split_kernel
 #define DG_TN_KERNEL gemm_tn_split_kernel
+#define DG_GEMM_THREADS kGsT
 #else
 #define DG_NT_KERNEL gemm_nt_kernel
 #define DG_TN_KERNEL gemm_tn_kernel
+#define DG_GEMM_THREADS kGT
 #endif
 
 namespace {
@@ -276,8 +278,8 @@ void launch(Kern kern, dim3 grid, dim3 block, hipStream_t s, Args... args) {
 void ml_gemm_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, int Nout, int64_t R, const int* hdr,
                 hipStream_t s) {
   const unsigned gx = DG_GEMM_GRID_X(R);
-  if (Nout % 128 == 0) launch(DG_NT_KERNEL<128, false>, dim3(gx, Nout / 128), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
-  else launch(DG_NT_KERNEL<64, false>, dim3(gx, Nout / 64), dim3(kGT), s, A, lda, W, K, C, ldc, hdr);
+  if (Nout % 128 == 0) launch(DG_NT_KERNEL<128, false>, dim3(gx, Nout / 128), dim3(DG_GEMM_THREADS), s, A, lda, W, K, C, ldc, hdr);
+  else launch(DG_NT_KERNEL<64, false>, dim3(gx, Nout / 64), dim3(DG_GEMM_THREADS), s, A, lda, W, K, C, ldc, hdr);
 }
 
 }  // namespace
@@ -358,10 +360,10 @@ extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int
     const int rows_per_chunk = (int)(((R + chunks - 1) / chunks + 31) / 32 * 32);
     const dim3 grid((unsigned)((N + 127) / 128), (unsigned)(K % 128 == 0 ? K / 128 : K / 64), (unsigned)chunks);
     if (K % 128 == 0)
-      launch(DG_TN_KERNEL<128>, grid, dim3(kGT), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
+      launch(DG_TN_KERNEL<128>, grid, dim3(DG_GEMM_THREADS), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
              rows_per_chunk, (const int*)m.hdr);
     else
-      launch(DG_TN_KERNEL<64>, grid, dim3(kGT), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
+      launch(DG_TN_KERNEL<64>, grid, dim3(DG_GEMM_THREADS), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
              rows_per_chunk, (const int*)m.hdr);
     const long long elems = (long long)N * K;
     dg::launch_tn_reduce(m.tnpart, chunks, elems, grad_w, s);
