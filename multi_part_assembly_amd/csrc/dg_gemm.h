@@ -160,7 +160,7 @@ template <int BK>
 __global__ __launch_bounds__(kGT, DG_TN_BUFS == 2 ? 2 : 3) void gemm_tn_kernel(const float* __restrict__ Y, int ldy, int Nout,
                                                          const float* __restrict__ X, int ldx, int K,
                                                          float* __restrict__ part, int rows_per_chunk,
-                                                         const int* __restrict__ hdr) {
+                                                         const int* __restrict__ hdr, int rows) {
   constexpr int BNT = 128;
   constexpr int RC = 32;            // rows per LDS step
   constexpr int WK = BK / 2;        // k columns per wave
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kGT, DG_TN_BUFS == 2 ? 2 : 3) void gemm_tn_kernel(c
   constexpr int X4 = RC * BK / 4 / kGT;   // 2 or 4
   __shared__ __attribute__((aligned(16))) float Ys[DG_TN_BUFS][RC * BNT];
   __shared__ __attribute__((aligned(16))) float Xs[DG_TN_BUFS][RC * BK];
-  const int R = hdr[1];
+  const int R = hdr != nullptr ? hdr[1] : rows;
   const int n0 = blockIdx.x * BNT, k0 = blockIdx.y * BK;
   // rows_per_chunk == 0: the valid rows (known on the device only) are dealt evenly to the grid's chunks
   const int rpc = rows_per_chunk > 0 ? rows_per_chunk : (int)((((long long)R + gridDim.z - 1) / gridDim.z + 31) / 32 * 32);
@@ -248,12 +248,12 @@ __global__ __launch_bounds__(kGT, DG_TN_BUFS == 2 ? 2 : 3) void gemm_tn_kernel(c
 // 256 threads owns EPB consecutive elements; 256 / EPB slices of the chunk range are summed side by side (eight
 // independent partial sums each, so the loads pipeline) and combined in slice order.
 template <int EPB>
-static __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, int chunks,
-                                                                    long long elems, float* __restrict__ out) {
+__device__ __forceinline__ void tn_reduce_block(const float* __restrict__ part, int chunks, long long elems,
+                                                float* __restrict__ out, int block) {
   constexpr int SL = 256 / EPB;
   __shared__ float red[SL][EPB];
   const int el = threadIdx.x % EPB, sl = threadIdx.x / EPB;
-  const long long e = (long long)blockIdx.x * EPB + el;
+  const long long e = (long long)block * EPB + el;
   const int per = (chunks + SL - 1) / SL;
   const int c0 = sl * per, c1 = c0 + per < chunks ? c0 + per : chunks;
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -274,6 +274,21 @@ static __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float*
     for (int q = 1; q < SL; ++q) t += red[q][el];
     out[e] = t;
   }
+}
+template <int EPB>
+static __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, int chunks,
+                                                                    long long elems, float* __restrict__ out) {
+  tn_reduce_block<EPB>(part, chunks, elems, out, (int)blockIdx.x);
+}
+// two tables in one launch: blocks [0, blocks_a) reduce table a, the others table b (an MLP layer's weight gradient and
+// the per-tile column sums of its bias gradient)
+static __global__ __launch_bounds__(256) void gemm_tn_reduce2_kernel(const float* __restrict__ pa, int chunks_a,
+                                                                     long long elems_a, float* __restrict__ out_a,
+                                                                     int blocks_a, const float* __restrict__ pb,
+                                                                     int chunks_b, long long elems_b,
+                                                                     float* __restrict__ out_b) {
+  if ((int)blockIdx.x < blocks_a) tn_reduce_block<32>(pa, chunks_a, elems_a, out_a, (int)blockIdx.x);
+  else tn_reduce_block<32>(pb, chunks_b, elems_b, out_b, (int)blockIdx.x - blocks_a);
 }
 
 // few elements and many chunks (the 128 x 4 first-layer gradient: thousands of row tiles) -> more slices per element

@@ -119,12 +119,28 @@ struct GsWaves {
   static_assert(TM >= 1 && TN >= 1, "wave tile");
 };
 
+// Optional work of the output pass of gemm_nt_split_kernel (the MLP layers of csrc/mlp.hip):
+//   EPI 0: none.   EPI 1: C += bias[n], and stats[(row tile)][n] = (sum, sum of squares) of the tile's valid rows of C —
+//   the BatchNorm statistics pass of a layer.   EPI 2: C = relu?(C + bias[n]) — a layer without BatchNorm.
+struct GsEpi {
+  const float* bias = nullptr;  // [Nout] or NULL
+  float* stats = nullptr;       // [ceil(R / 128)][ldstats][2]
+  int ldstats = 0;
+  int relu = 0;
+  int rows = 0;                 // the row count R when `hdr` is NULL (callers that know it on the host)
+  unsigned* zero = nullptr;     // 64 words cleared by the first block (the tickets of the layer's cooperative reductions)
+};
+
 // ---- C[r, n] (+)= A[r, :] . W[n, :] -----------------------------------------------------------------------------------
 // Arguments, tiles and the XCD-aware block -> tile mapping exactly as gemm_nt_kernel (dg_gemm.h); block = kGsT threads.
-template <int BN, bool ACCUM>
+// WT: the second operand is given TRANSPOSED, Wt [K][Nout] with leading dimension ldwt (the
+// input-gradient GEMM dX = dY . W reads the layer's weight as it is stored): its panel is staged through the 4 x 4
+// quad transpose of gemm_tn_split_kernel.
+template <int BN, bool ACCUM, int EPI = 0, bool WT = false>
 __global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_nt_split_kernel(const float* __restrict__ A, int lda,
                                                             const float* __restrict__ W, int K, float* __restrict__ C,
-                                                            int ldc, const int* __restrict__ hdr) {
+                                                            int ldc, const int* __restrict__ hdr, const GsEpi epi,
+                                                            int ldwt) {
   constexpr int BM = 128;
   using WV = GsWaves<BN>;
   constexpr int TM = WV::TM, TN = WV::TN;
@@ -132,7 +148,8 @@ __global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_nt_split_
   constexpr int A4 = BM / RS, B4 = BN / RS;    // float4 per thread and chunk
   __shared__ __attribute__((aligned(16))) unsigned char As[BM * kGsRow];
   __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * kGsRow];
-  const int R = hdr[1];
+  const int R = hdr != nullptr ? hdr[1] : epi.rows;
+  if (EPI != 0 && epi.zero != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) epi.zero[threadIdx.x] = 0u;
   long long r0;
   int n0;
   {
@@ -151,12 +168,33 @@ __global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_nt_split_
     const long long r = r0 + rl + RS * i;
     ap_[i] = A + (r < R ? r : (long long)R - 1) * lda + 4 * c4;
   }
-  const float* wp_ = W + (long long)(n0 + rl) * K + 4 * c4;
+  // W panel.  Plain: thread = (output column rl + RS i, k quad c4).  WT: thread = (k row 4 g + qt of the chunk, output
+  // column quad wc4) with g = (tid >> 2 & 1) + 2 ((tid >> 3) / (BN / 4)) + WS i — the mapping of gemm_tn_split_kernel.
+  constexpr int WC4 = BN / 4, WS = 2 * (kGsT / 8) / WC4;
+  static_assert(!WT || 8 / WS == B4, "transposed W panel: float4 per thread");
+  const int qt = threadIdx.x & 3, wc4 = (threadIdx.x >> 3) % WC4, wg = ((threadIdx.x >> 2) & 1) + 2 * ((threadIdx.x >> 3) / WC4);
+  const unsigned sel1 = (qt & 1) ? 0x03020706u : 0x05040100u;
+  const bool qlow = (qt & 2) == 0;
+  const float* wp_ = WT ? W + (long long)(4 * wg + qt) * ldwt + n0 + 4 * wc4 : W + (long long)(n0 + rl) * K + 4 * c4;
   auto fetch = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < A4; ++i) ra[i] = *reinterpret_cast<const float4*>(ap_[i] + kc);
 #pragma unroll
-    for (int i = 0; i < B4; ++i) rb[i] = *reinterpret_cast<const float4*>(wp_ + (long long)(RS * i) * K + kc);
+    for (int i = 0; i < B4; ++i) {
+      if constexpr (WT) rb[i] = *reinterpret_cast<const float4*>(wp_ + (long long)(kc + 4 * WS * i) * ldwt);
+      else rb[i] = *reinterpret_cast<const float4*>(wp_ + (long long)(RS * i) * K + kc);
+    }
+  };
+  auto stash_w = [&](int i) {
+    if constexpr (WT) {  // the quad's 4 k rows x 4 columns -> this lane: column 4 wc4 + qt, k = 4 g .. 4 g + 3
+      const Split4 sp = gs_split(rb[i]);
+      unsigned char* p = Bs + (4 * wc4 + qt) * kGsRow + 8 * (wg + WS * i);
+      *reinterpret_cast<uint2*>(p) = gs_quad_transpose(sp.h, sel1, qlow);
+      *reinterpret_cast<uint2*>(p + 64) = gs_quad_transpose(sp.m, sel1, qlow);
+      *reinterpret_cast<uint2*>(p + 128) = gs_quad_transpose(sp.l, sel1, qlow);
+    } else {
+      gs_stash(Bs, rl + RS * i, c4, rb[i]);
+    }
   };
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -171,7 +209,7 @@ __global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_nt_split_
 #pragma unroll
       for (int i = 0; i < A4; ++i) gs_stash(As, rl + RS * i, c4, ra[i]);
 #pragma unroll
-      for (int i = 0; i < B4; ++i) gs_stash(Bs, rl + RS * i, c4, rb[i]);
+      for (int i = 0; i < B4; ++i) stash_w(i);
     }
     __syncthreads();
     if (c + 1 < chunks && GS_LOAD_ON) fetch((c + 1) * kKC);
@@ -190,6 +228,12 @@ __global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_nt_split_
         }
     }
   }
+  float bcol[TN], cs[TN], css[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    bcol[b] = (EPI != 0 && epi.bias != nullptr) ? epi.bias[n0 + wc * (32 * TN) + 32 * b + j] : 0.0f;
+    cs[b] = css[b] = 0.0f;
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -199,11 +243,44 @@ __global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_nt_split_
         float* dst = C + row * ldc + n0 + wc * (32 * TN) + j;
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-          if constexpr (ACCUM) dst[32 * b] += acc[a][b][r];
-          else dst[32 * b] = acc[a][b][r];
+          float v = acc[a][b][r];
+          if constexpr (EPI != 0) v += bcol[b];
+          if constexpr (EPI == 2) v = epi.relu ? __builtin_fmaxf(v, 0.0f) : v;
+          if constexpr (ACCUM) dst[32 * b] += v;
+          else dst[32 * b] = v;
+          if constexpr (EPI == 1) {
+            cs[b] += v;
+            css[b] = __builtin_fmaf(v, v, css[b]);
+          }
         }
       }
     }
+  if constexpr (EPI == 1) {
+    // column sums of the tile: lane halves by shuffle, the WR wave rows through LDS in fixed order
+    float(*red)[BN][2] = reinterpret_cast<float(*)[BN][2]>(As);  // [WR][BN][2]; the panels are free after the barrier
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      cs[b] += __shfl_xor(cs[b], 32, 64);
+      css[b] += __shfl_xor(css[b], 32, 64);
+      if (h == 0) {
+        red[wr][wc * (32 * TN) + 32 * b + j][0] = cs[b];
+        red[wr][wc * (32 * TN) + 32 * b + j][1] = css[b];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < BN) {
+      float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+      for (int q = 0; q < WV::WR; ++q) {
+        t0 += red[q][threadIdx.x][0];
+        t1 += red[q][threadIdx.x][1];
+      }
+      float* d = epi.stats + ((r0 / BM) * epi.ldstats + n0 + threadIdx.x) * 2;
+      d[0] = t0;
+      d[1] = t1;
+    }
+  }
 }
 
 // ---- P[chunk][n, k] = sum over the chunk's rows of Y[r, n] * X[r, k] ----------------------------------------------------
@@ -218,7 +295,7 @@ template <int BK>
 __global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_tn_split_kernel(const float* __restrict__ Y, int ldy, int Nout,
                                                             const float* __restrict__ X, int ldx, int K,
                                                             float* __restrict__ part, int rows_per_chunk,
-                                                            const int* __restrict__ hdr) {
+                                                            const int* __restrict__ hdr, int rows) {
   constexpr int BNT = 128, RC = 32;
   // waves as WNW x WKW over the 128 x BK tile of the gradient
   constexpr int WKW = DG_GS_WAVES == 4 ? 2 : (BK == 128 ? 4 : 2), WNW = DG_GS_WAVES / WKW;
@@ -229,7 +306,7 @@ __global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_tn_split_
   static_assert(YS >= 1 && XS >= 1 && YS <= 8 && XS <= 8, "staging layout");
   __shared__ __attribute__((aligned(16))) unsigned char Ys[BNT * kGsRow];
   __shared__ __attribute__((aligned(16))) unsigned char Xs[BK * kGsRow];
-  const int R = hdr[1];
+  const int R = hdr != nullptr ? hdr[1] : rows;  // `rows`: the row count for callers that know it on the host
   const int n0 = blockIdx.x * BNT, k0 = blockIdx.y * BK;
   // rows_per_chunk == 0: the valid rows (known on the device only) are dealt evenly to the grid's chunks
   const int rpc = rows_per_chunk > 0 ? rows_per_chunk : (int)((((long long)R + gridDim.z - 1) / gridDim.z + 31) / 32 * 32);

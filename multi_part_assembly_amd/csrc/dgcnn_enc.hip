@@ -35,10 +35,12 @@
 #define DG_NT_KERNEL gemm_nt_split_kernel
 #define DG_TN_KERNEL gemm_tn_split_kernel
 #define DG_GEMM_THREADS kGsT
+#define DG_NT_TAIL , GsEpi{}, 0
 #else
 #define DG_NT_KERNEL gemm_nt_kernel
 #define DG_TN_KERNEL gemm_tn_kernel
 #define DG_GEMM_THREADS kGT
+#define DG_NT_TAIL
 #endif
 #include <cstdio>
 #include <vector>
@@ -1080,11 +1082,11 @@ void gemm_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, 
              const int* hdr, hipStream_t s) {
   const unsigned gx = DG_GEMM_GRID_X(Rmax);
   if (Nout % 128 == 0) {
-    if (accum) launch(DG_NT_KERNEL<128, true>, dim3(gx, Nout / 128), dim3(DG_GEMM_THREADS), s, A, lda, W, K, C, ldc, hdr);
-    else launch(DG_NT_KERNEL<128, false>, dim3(gx, Nout / 128), dim3(DG_GEMM_THREADS), s, A, lda, W, K, C, ldc, hdr);
+    if (accum) launch(DG_NT_KERNEL<128, true>, dim3(gx, Nout / 128), dim3(DG_GEMM_THREADS), s, A, lda, W, K, C, ldc, hdr DG_NT_TAIL);
+    else launch(DG_NT_KERNEL<128, false>, dim3(gx, Nout / 128), dim3(DG_GEMM_THREADS), s, A, lda, W, K, C, ldc, hdr DG_NT_TAIL);
   } else {
-    if (accum) launch(DG_NT_KERNEL<64, true>, dim3(gx, Nout / 64), dim3(DG_GEMM_THREADS), s, A, lda, W, K, C, ldc, hdr);
-    else launch(DG_NT_KERNEL<64, false>, dim3(gx, Nout / 64), dim3(DG_GEMM_THREADS), s, A, lda, W, K, C, ldc, hdr);
+    if (accum) launch(DG_NT_KERNEL<64, true>, dim3(gx, Nout / 64), dim3(DG_GEMM_THREADS), s, A, lda, W, K, C, ldc, hdr DG_NT_TAIL);
+    else launch(DG_NT_KERNEL<64, false>, dim3(gx, Nout / 64), dim3(DG_GEMM_THREADS), s, A, lda, W, K, C, ldc, hdr DG_NT_TAIL);
   }
 }
 
@@ -1096,8 +1098,8 @@ void gemm_tn(const float* Y, int ldy, int Nout, const float* X, int ldx, int K, 
   const int chunks = tn * tk >= 4 ? kTnChunks : (int)(4 * kTnChunks / (tn * tk));
   const int rows_per_chunk = 0;  // cut the VALID rows (hdr[1], at most Rmax) evenly: every chunk has work
   const dim3 grid(tn, tk, (unsigned)chunks);
-  if (K % 128 == 0) launch(DG_TN_KERNEL<128>, grid, dim3(DG_GEMM_THREADS), s, Y, ldy, Nout, X, ldx, K, part, rows_per_chunk, hdr);
-  else launch(DG_TN_KERNEL<64>, grid, dim3(DG_GEMM_THREADS), s, Y, ldy, Nout, X, ldx, K, part, rows_per_chunk, hdr);
+  if (K % 128 == 0) launch(DG_TN_KERNEL<128>, grid, dim3(DG_GEMM_THREADS), s, Y, ldy, Nout, X, ldx, K, part, rows_per_chunk, hdr, 0);
+  else launch(DG_TN_KERNEL<64>, grid, dim3(DG_GEMM_THREADS), s, Y, ldy, Nout, X, ldx, K, part, rows_per_chunk, hdr, 0);
   const long long elems = (long long)Nout * K;
   launch_tn_reduce(part, chunks, elems, out, s);
 }

@@ -209,23 +209,6 @@ __global__ __launch_bounds__(256) void ml_bwd_dy_kernel(const float* __restrict_
   }
 }
 
-// column sums of a per-tile table [tiles][C]: block = 64 channels x 16 tile slices, slices merged in fixed order
-__global__ __launch_bounds__(1024) void ml_colsum_kernel(const float* __restrict__ partial, int tiles, int C,
-                                                         float* __restrict__ out) {
-  __shared__ double sm[16][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-  double s = 0.0;
-  for (int t = slice; t < tiles; t += 16) s += (double)partial[(long long)t * C + c];
-  sm[slice][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (slice == 0) {
-    double a = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a += sm[k][threadIdx.x];
-    out[c] = (float)a;
-  }
-}
-
 __global__ void ml_transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= rows * cols) return;
@@ -275,12 +258,28 @@ void launch(Kern kern, dim3 grid, dim3 block, hipStream_t s, Args... args) {
   hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
 }
 
+#if DG_GEMM_SPLIT
+// C = A W^T with the output pass of `EPI` (dg_gemm_split.h); WT: W is given as [K][Nout].  The row count travels by value.
+template <int EPI, bool WT>
+void ml_gemm(const float* A, int lda, const float* W, int K, float* C, int ldc, int Nout, int64_t R, GsEpi epi, int ldwt,
+             hipStream_t s) {
+  const unsigned gx = DG_GEMM_GRID_X(R);
+  epi.rows = (int)R;
+  if (Nout % 128 == 0)
+    launch(gemm_nt_split_kernel<128, false, EPI, WT>, dim3(gx, Nout / 128), dim3(kGsT), s, A, lda, W, K, C, ldc,
+           (const int*)nullptr, epi, ldwt);
+  else
+    launch(gemm_nt_split_kernel<64, false, EPI, WT>, dim3(gx, Nout / 64), dim3(kGsT), s, A, lda, W, K, C, ldc,
+           (const int*)nullptr, epi, ldwt);
+}
+#else
 void ml_gemm_nt(const float* A, int lda, const float* W, int K, float* C, int ldc, int Nout, int64_t R, const int* hdr,
                 hipStream_t s) {
   const unsigned gx = DG_GEMM_GRID_X(R);
   if (Nout % 128 == 0) launch(DG_NT_KERNEL<128, false>, dim3(gx, Nout / 128), dim3(DG_GEMM_THREADS), s, A, lda, W, K, C, ldc, hdr);
   else launch(DG_NT_KERNEL<64, false>, dim3(gx, Nout / 64), dim3(DG_GEMM_THREADS), s, A, lda, W, K, C, ldc, hdr);
 }
+#endif
 
 }  // namespace
 
@@ -303,6 +302,32 @@ extern "C" int mpa_mlp_layer_forward(const float* x, int64_t ldx, const float* w
   const MlWs m = ml_carve(static_cast<char*>(ws), R, K, N);
   const int tiles = (int)((R + kRT - 1) / kRT);
   const long long total4 = R * N / 4;
+  const CoopWs cw{m.stage, m.tickets};
+#if DG_GEMM_SPLIT
+  // bias, BatchNorm statistics / activation in the GEMM's output pass: 3 launches with BatchNorm, 1 without
+  GsEpi epi;
+  epi.bias = bias;
+  epi.zero = m.tickets;
+  if (gamma == nullptr) {
+    epi.relu = relu;
+    ml_gemm<2, false>(x, (int)ldx, w, (int)K, out, (int)N, (int)N, R, epi, 0, s);
+    return mpa::check_launch("mlp_layer_forward");
+  }
+  if (training) {
+    const int tiles128 = (int)((R + 127) / 128);
+    epi.stats = m.partial;
+    epi.ldstats = (int)N;
+    ml_gemm<1, false>(x, (int)ldx, w, (int)K, m.ypre, (int)N, (int)N, R, epi, 0, s);
+    launch(ml_bn_finalize_kernel, dim3((unsigned)(N / 64), (unsigned)((tiles128 + kEB - 1) / kEB)), dim3(64 * kSlices), s,
+           (const float*)m.partial, tiles128, (int)N, (double)R, gamma, beta, running_mean, running_var, momentum, eps, m.bn,
+           cw);
+  } else {
+    ml_gemm<2, false>(x, (int)ldx, w, (int)K, m.ypre, (int)N, (int)N, R, epi, 0, s);
+    launch(ml_bn_from_running_kernel, dim3((unsigned)(N / 64)), dim3(64), s, (int)N, gamma, beta,
+           (const float*)running_mean, (const float*)running_var, eps, m.bn);
+  }
+  (void)tiles;
+#else
   launch(ml_set_hdr_kernel, dim3(1), dim3(64), s, m.hdr, (int)R, m.tickets);
   if (gamma == nullptr) {
     ml_gemm_nt(x, (int)ldx, w, (int)K, out, (int)N, (int)N, R, m.hdr, s);
@@ -310,7 +335,6 @@ extern "C" int mpa_mlp_layer_forward(const float* x, int64_t ldx, const float* w
            bias, total4, (int)N, relu, out);
     return mpa::check_launch("mlp_layer_forward");
   }
-  const CoopWs cw{m.stage, m.tickets};
   ml_gemm_nt(x, (int)ldx, w, (int)K, m.ypre, (int)N, (int)N, R, m.hdr, s);
   if (training) {
     launch(ml_bias_stats_kernel, dim3((unsigned)tiles), dim3(256), s, m.ypre, bias, (int)R, (int)N, m.partial);
@@ -324,6 +348,7 @@ extern "C" int mpa_mlp_layer_forward(const float* x, int64_t ldx, const float* w
     launch(ml_bn_from_running_kernel, dim3((unsigned)(N / 64)), dim3(64), s, (int)N, gamma, beta,
            (const float*)running_mean, (const float*)running_var, eps, m.bn);
   }
+#endif
   launch(ml_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), s, (const float*)m.ypre, (const float*)m.bn,
          (const float*)nullptr, total4, (int)N, relu, out);
   return mpa::check_launch("mlp_layer_forward");
@@ -348,9 +373,7 @@ extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int
   }
   launch(ml_bwd_dy_kernel, dim3((unsigned)tiles), dim3(256), s, grad_out, out, (const float*)m.ypre,
          gamma != nullptr ? (const float*)m.coef : (const float*)nullptr, (int)R, (int)N, relu, m.dy, m.partial);
-  if (grad_b != nullptr)
-    launch(ml_colsum_kernel, dim3((unsigned)(N / 64)), dim3(1024), s, (const float*)m.partial, tiles, (int)N, grad_b);
-  // dW [N][K] = dY^T X
+  // dW [N][K] = dY^T X (row chunks, then a fixed-order sum) and db = the column sums of dY's per-tile table
   {
     // enough chunks for ~512 blocks in the launch, each at least 64 rows
     const int out_tiles = (int)(((N + 127) / 128) * (K % 128 == 0 ? K / 128 : K / 64));
@@ -359,18 +382,33 @@ extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int
     chunks = chunks < 1 ? 1 : (chunks > kChunks ? kChunks : chunks);
     const int rows_per_chunk = (int)(((R + chunks - 1) / chunks + 31) / 32 * 32);
     const dim3 grid((unsigned)((N + 127) / 128), (unsigned)(K % 128 == 0 ? K / 128 : K / 64), (unsigned)chunks);
+#if DG_GEMM_SPLIT
+    const int* hdr = nullptr;  // the row count travels by value
+#else
+    const int* hdr = m.hdr;    // (written by the forward call)
+#endif
     if (K % 128 == 0)
       launch(DG_TN_KERNEL<128>, grid, dim3(DG_GEMM_THREADS), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
-             rows_per_chunk, (const int*)m.hdr);
+             rows_per_chunk, hdr, (int)R);
     else
       launch(DG_TN_KERNEL<64>, grid, dim3(DG_GEMM_THREADS), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
-             rows_per_chunk, (const int*)m.hdr);
+             rows_per_chunk, hdr, (int)R);
     const long long elems = (long long)N * K;
-    dg::launch_tn_reduce(m.tnpart, chunks, elems, grad_w, s);
+    if (grad_b != nullptr) {
+      const int blocks_w = (int)((elems + 31) / 32);
+      launch(dg::gemm_tn_reduce2_kernel, dim3((unsigned)(blocks_w + (N + 31) / 32)), dim3(256), s, (const float*)m.tnpart,
+             chunks, elems, grad_w, blocks_w, (const float*)m.partial, tiles, (long long)N, grad_b);
+    } else {
+      dg::launch_tn_reduce(m.tnpart, chunks, elems, grad_w, s);
+    }
   }
   if (grad_x != nullptr) {  // dX [R][K] = dY [R][N] . W [N][K]
+#if DG_GEMM_SPLIT
+    ml_gemm<0, true>(m.dy, (int)N, w, (int)N, grad_x, (int)K, (int)K, R, GsEpi{}, (int)K, s);
+#else
     launch(ml_transpose_kernel, dim3((unsigned)((N * K + 255) / 256)), dim3(256), s, w, (int)N, (int)K, m.wt);
     ml_gemm_nt(m.dy, (int)N, m.wt, (int)N, grad_x, (int)K, (int)K, R, m.hdr, s);
+#endif
   }
   return mpa::check_launch("mlp_layer_backward");
 }

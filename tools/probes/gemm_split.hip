@@ -66,11 +66,11 @@ static void run_tn(int R, int Rmax, int Nout, int K, int ldx, int chunks) {
   const int rpc = ((R + chunks - 1) / chunks + 31) / 32 * 32;  // what the kernels derive from hdr when passed 0
   auto split = [&] {
     hipLaunchKernelGGL(dg::gemm_tn_split_kernel<BK>, grid, dim3(dg::kGsT), 0, 0, (const float*)Y, Nout, Nout, (const float*)X,
-                       ldx, K, part, rpc, (const int*)hdr);
+                       ldx, K, part, rpc, (const int*)hdr, 0);
   };
   auto exact = [&] {
     hipLaunchKernelGGL(dg::gemm_tn_kernel<BK>, grid, dim3(dg::kGT), 0, 0, (const float*)Y, Nout, Nout, (const float*)X, ldx,
-                       K, part, rpc, (const int*)hdr);
+                       K, part, rpc, (const int*)hdr, 0);
   };
   const float t_split = time_ms(split, 10);
   dg::launch_tn_reduce(part, chunks, (long long)Nout * K, o1, 0);
@@ -97,7 +97,7 @@ static void run_nt(int R, int Rmax, int K, int Nout) {
   const unsigned gx = DG_GEMM_GRID_X(Rmax);
   auto split = [&] {
     hipLaunchKernelGGL((dg::gemm_nt_split_kernel<BN, false>), dim3(gx, Nout / BN), dim3(dg::kGsT), 0, 0, (const float*)A, K,
-                       (const float*)W, K, c1, Nout, (const int*)hdr);
+                       (const float*)W, K, c1, Nout, (const int*)hdr, dg::GsEpi{}, 0);
   };
   auto exact = [&] {
     hipLaunchKernelGGL((dg::gemm_nt_kernel<BN, false>), dim3(gx, Nout / BN), dim3(dg::kGT), 0, 0, (const float*)A, K,
