@@ -59,9 +59,9 @@ __global__ __launch_bounds__(kGT) void gru_fwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ whh, const float* __restrict__ bhh,
                                                       int B, int T, float* __restrict__ out,
                                                       float* __restrict__ saved, unsigned* __restrict__ counters) {
-  extern __shared__ float smem[];
-  constexpr int LD = H + 1;              // padded rows: the 16 units / 4 samples of a wave read the same column of
-  float* W = smem;                       // different rows in one instruction  ([3 * kU][LD]: rows r(u0..), z(..), n(..))
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LD = H + 4;              // rows padded by one 16-byte slot: the rows a ds_read_b128 lane group touches
+  float* W = smem;                       // (4 samples, 8 units) start 4 banks apart  ([3 * kU][LD]: rows r(u0..), z(..), n(..))
   float* hp = smem + 3 * kU * LD;        // [B][LD] previous hidden state
   const int d = blockIdx.y, u0 = blockIdx.x * kU, nblk = gridDim.x;
   const float* wd = whh + (long long)d * 3 * H * H;
@@ -75,9 +75,10 @@ __global__ __launch_bounds__(kGT) void gru_fwd_kernel(const float* __restrict__ 
   unsigned* ctr = counters + d;
   for (int t = 0; t < T; ++t) {
     // previous hidden state of ALL units (written by all blocks of this direction in the previous step)
-    for (int e = threadIdx.x; e < B * H; e += kGT) {
-      const int b = e / H, k = e % H;
-      hp[b * LD + k] = t == 0 ? h0[((long long)d * B + b) * H + k] : od[((long long)b * T + (t - 1)) * H + k];
+    for (int e = threadIdx.x; e < B * (H / 4); e += kGT) {
+      const int b = e / (H / 4), k = 4 * (e % (H / 4));
+      const float* src = t == 0 ? h0 + ((long long)d * B + b) * H + k : od + ((long long)b * T + (t - 1)) * H + k;
+      *reinterpret_cast<float4*>(&hp[b * LD + k]) = *reinterpret_cast<const float4*>(src);
     }
     __syncthreads();
     for (int e = threadIdx.x; e < B * kU; e += kGT) {  // (sample, own unit)
@@ -85,12 +86,24 @@ __global__ __launch_bounds__(kGT) void gru_fwd_kernel(const float* __restrict__ 
       const float* hb = hp + b * LD;
       const float *wr = W + (0 * kU + u) * LD, *wz = W + (1 * kU + u) * LD, *wn = W + (2 * kU + u) * LD;
       float ar = 0.0f, az = 0.0f, an = 0.0f;
-#pragma unroll 8
-      for (int k = 0; k < H; ++k) {
-        const float h = hb[k];
-        ar = __builtin_fmaf(h, wr[k], ar);
-        az = __builtin_fmaf(h, wz[k], az);
-        an = __builtin_fmaf(h, wn[k], an);
+#pragma unroll 4
+      for (int k = 0; k < H; k += 4) {  // 16-byte LDS reads; the three chains run over k in ascending order
+        const float4 h4 = *reinterpret_cast<const float4*>(hb + k);
+        const float4 r4 = *reinterpret_cast<const float4*>(wr + k);
+        const float4 z4 = *reinterpret_cast<const float4*>(wz + k);
+        const float4 n4 = *reinterpret_cast<const float4*>(wn + k);
+        ar = __builtin_fmaf(h4.x, r4.x, ar);
+        az = __builtin_fmaf(h4.x, z4.x, az);
+        an = __builtin_fmaf(h4.x, n4.x, an);
+        ar = __builtin_fmaf(h4.y, r4.y, ar);
+        az = __builtin_fmaf(h4.y, z4.y, az);
+        an = __builtin_fmaf(h4.y, n4.y, an);
+        ar = __builtin_fmaf(h4.z, r4.z, ar);
+        az = __builtin_fmaf(h4.z, z4.z, az);
+        an = __builtin_fmaf(h4.z, n4.z, an);
+        ar = __builtin_fmaf(h4.w, r4.w, ar);
+        az = __builtin_fmaf(h4.w, z4.w, az);
+        an = __builtin_fmaf(h4.w, n4.w, an);
       }
       const int c = u0 + u;
       const float* g = gid + ((long long)b * T + t) * 3 * H;
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
                                                       float* __restrict__ dgi, float* __restrict__ dwhh,
                                                       float* __restrict__ dbhh, float* __restrict__ part,
                                                       unsigned* __restrict__ counters) {
-  extern __shared__ float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W = smem;                        // [3 * kU][H]
   float* hp = smem + 3 * kU * H;          // [B][H] h_{t-1}
   float* dg = hp + B * H;                 // [B][3 * kU] gate gradients of the own rows at this step (r, z, n-hidden)
@@ -158,9 +171,10 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < CPT; ++c) wreg[r][c] = W[(rbase + r) * H + k0 + kGT * c];
   for (int t = T - 1; t >= 0; --t) {
-    for (int e = threadIdx.x; e < B * H; e += kGT) {
-      const int b = e / H, k = e % H;
-      hp[e] = t == 0 ? h0[((long long)d * B + b) * H + k] : od[((long long)b * T + (t - 1)) * H + k];
+    for (int e = threadIdx.x; e < B * (H / 4); e += kGT) {
+      const int b = e / (H / 4), k = 4 * (e % (H / 4));
+      const float* src = t == 0 ? h0 + ((long long)d * B + b) * H + k : od + ((long long)b * T + (t - 1)) * H + k;
+      *reinterpret_cast<float4*>(&hp[b * H + k]) = *reinterpret_cast<const float4*>(src);
     }
     __syncthreads();
     // gate gradients of the own units
@@ -169,7 +183,8 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
       float dh = god[((long long)b * T + t) * H + c] + dhc[e];
       if (t < T - 1) {  // + what the other rows sent back through W_hh in step t + 1 (fixed block order)
         const float* pp = pd + (long long)((t + 1) & 1) * nblk * B * H;
-        for (int k = 0; k < nblk; ++k) dh += pp[((long long)k * B + b) * H + c];
+#pragma unroll 8
+        for (int k = 0; k < nblk; ++k) dh += pp[((long long)k * B + b) * H + c];  // (independent loads, ordered adds)
       }
       const float* sv = sd + ((long long)b * T + t) * 4 * H;
       const float r = sv[c], z = sv[H + c], n = sv[2 * H + c], hn = sv[3 * H + c];
@@ -293,7 +308,7 @@ extern "C" int mpa_gru_resident(int64_t D, int64_t B, int64_t H, int* ok) {
   MPA_REQUIRE(ok != nullptr, "gru_resident: null pointer");
   *ok = 0;
   if (!((H == 128 || H == 256) && B >= 1 && B <= 64 && (D == 1 || D == 2))) return MPA_OK;
-  const size_t fwd = sizeof(float) * (3 * kU * (H + 1) + B * (H + 1)), bwd = sizeof(float) * (3 * kU * H + B * H + B * 3 * kU + B * kU);
+  const size_t fwd = sizeof(float) * (3 * kU * (H + 4) + B * (H + 4)), bwd = sizeof(float) * (3 * kU * H + B * H + B * 3 * kU + B * kU);
   if (fwd > 160 * 1024 || bwd > 160 * 1024) return MPA_OK;
   const int blocks = (int)(H / kU * D);
   int st = H == 128 ? gru_resident(gru_fwd_kernel<128>, fwd, blocks, "gru") : gru_resident(gru_fwd_kernel<256>, fwd, blocks, "gru");
@@ -318,7 +333,7 @@ extern "C" int mpa_gru_forward(const float* gi, const float* h0, const float* wh
   hipStream_t s = mpa::as_stream(stream);
   float* saved = ws;
   unsigned* counters = reinterpret_cast<unsigned*>(ws + D * B * T * 4 * H + D * 2 * (H / kU) * B * H);
-  const size_t smem = sizeof(float) * (3 * kU * (H + 1) + B * (H + 1));
+  const size_t smem = sizeof(float) * (3 * kU * (H + 4) + B * (H + 4));
   MPA_REQUIRE(smem <= 160 * 1024, "gru_forward: batch x hidden size does not fit the 160 KB of LDS");
   hipLaunchKernelGGL(gru_zero_counters_kernel, dim3(1), dim3(64), 0, s, counters, 0, 2);
   const dim3 grid((unsigned)(H / kU), (unsigned)D);
