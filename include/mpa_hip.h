@@ -298,13 +298,13 @@ int mpa_mlp_layer_backward(const float* grad_out, const float* x, int64_t ldx, c
  *   r = sigmoid(gi_r + W_hr h + b_hr), z = sigmoid(gi_z + W_hz h + b_hz), n = tanh(gi_n + r (W_hn h + b_hn)),
  *   h' = (1 - z) n + z h,   out [D,B,T,H] = h' of every step.
  * h0 [D,B,H], whh [D,3H,H], bhh [D,3H].  H = 128 or 256, B <= 64, D = 1 or 2.  `ws` (mpa_gru_workspace floats)
- * carries the gates to backward.  backward: grad_out [D,B,T,H] -> grad_gi [D,B,T,3H], grad_whh, grad_bhh (overwritten);
+ * (8-byte aligned) carries the gates to backward and the tagged words the blocks exchange once per step.  backward: grad_out [D,B,T,H] -> grad_gi [D,B,T,3H], grad_whh, grad_bhh (overwritten);
  * deterministic (partials summed in block order, no float atomics).  Sequences of different lengths: run the padded
  * batch (valid steps first) and mask the outputs — the reverse direction on the per-sample reversed valid prefix.
  * ---------------------------------------------------------------------------------------------- */
 int mpa_gru_workspace(int64_t D, int64_t B, int64_t T, int64_t H, int64_t* float_elems);
 /* *ok = 1 iff the shapes are instantiated AND the current device can hold the whole grid of both kernels at once (their
- * per-step barrier spins on it; forward / backward return an error instead of hanging when it cannot). */
+ * blocks poll for each other's per-step words; forward / backward return an error instead of stalling when it cannot). */
 int mpa_gru_resident(int64_t D, int64_t B, int64_t H, int* ok);
 int mpa_gru_forward(const float* gi, const float* h0, const float* whh, const float* bhh, int64_t D, int64_t B, int64_t T,
                     int64_t H, float* ws, float* out, void* stream);

@@ -11,19 +11,17 @@
 //   h' = (1 - z) * n + z * h                                                     (torch.nn.GRU's equations and gate order)
 // ONE launch per pass for both directions: grid = (H / 8, directions).  A block owns 8 hidden units (A/B: 16 units per
 // block 0.33 + 0.73 ms forward + backward, 8 units 0.28 + 0.56, 4 units 0.38 + 0.70) — its 24 rows of
-// W_hh stay in LDS for the whole sequence — and the blocks of a direction meet at a grid barrier after every step (the
-// new hidden state goes through global memory).  Backward through time keeps its 24 x H slice of dW_hh in registers,
-// hands the partial dL/dh_{t-1} of its rows to the other blocks through global memory and sums the partials in block
-// order: no atomics on floats, bit-reproducible.  All blocks must be co-resident (2 * H/8 <= 256 CUs).
+// W_hh stay in LDS for the whole sequence — and the blocks of a direction hand each other the new hidden state once per
+// step as tagged 8-byte words in global memory (tagged_store below: no grid barrier).  Backward through time keeps its
+// 24 x H slice of dW_hh in registers, hands the partial dL/dh_{t-1} of its rows to the other blocks the same way and sums
+// the partials in block order: no atomics on floats, bit-reproducible.  All blocks must be co-resident (2 * H/8 <= 256
+// CUs): a consumer polls for words only a running producer can write.
 #include "common.h"
 
 namespace {
 
 #ifndef MPA_GRU_U
 #define MPA_GRU_U 8
-#endif
-#ifndef MPA_GRU_SPLIT_FENCE
-#define MPA_GRU_SPLIT_FENCE 1
 #endif
 constexpr int kU = MPA_GRU_U;  // hidden units per block
 constexpr int kGT = 256;     // threads per block
@@ -32,25 +30,45 @@ constexpr int kMaxB = 64;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// all blocks of one direction: arrive, then wait until `target` arrivals in total (monotone counter, zeroed per launch)
-__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#if MPA_GRU_SPLIT_FENCE
-    // release (write back this XCD's L2) before arriving, acquire (invalidate) after the last arrival: half the cache
-    // maintenance of two full fences
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#else
-    __threadfence();
-    atomicAdd(counter, 1u);
-    while (atomicAdd(counter, 0u) < target) __builtin_amdgcn_s_sleep(1);
-    __threadfence();
-#endif
+// Exchange between the blocks of a direction, once per step, WITHOUT a grid barrier: every value travels as one
+// naturally aligned 8-byte {value, tag} word written by a single device-scope store (tag = the step's number), and a
+// consumer polls the word itself until the tag is the one it waits for — data and "ready" arrive in the same store, so
+// no fence, no counter and no arrival skew sit between a producer and its consumers (a counter barrier with its release /
+// acquire fences measured ~7 us per step, most of a step's time).  The exchange buffers are zeroed before the launch
+// (tags start at 1); two buffers by step parity suffice: a block can only be one step ahead of the slowest reader of
+// its previous values.  All blocks of the grid must be co-resident (checked by gru_resident).
+typedef unsigned long long tagged_t;
+__device__ __forceinline__ void tagged_store(tagged_t* p, float v, unsigned tag) {
+  __hip_atomic_store(p, ((tagged_t)tag << 32) | (tagged_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ tagged_t tagged_peek(const tagged_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the value of *p once it carries `tag` (first poll result given).  `budget`: polls the thread may still spend in this
+// launch — a producer that never shows up (a grid that is not co-resident after all) exhausts it after a few seconds and
+// the kernel TRAPS: the launch fails loudly instead of hanging the device or returning garbage.
+__device__ __forceinline__ float tagged_wait(const tagged_t* p, tagged_t first, unsigned tag, int& budget) {
+  tagged_t v = first;
+  while ((unsigned)(v >> 32) != tag) {
+    if (--budget < 0) __builtin_trap();
+    __builtin_amdgcn_s_sleep(2);
+    v = tagged_peek(p);
   }
-  __syncthreads();
+  return __uint_as_float((unsigned)v);
+}
+constexpr int kPollBudget = 1 << 22;
+// PF words p[q * stride] (q < n valid): wait for the first one alone (ONE polled word per thread while the producers
+// are still busy: the pollers' traffic delays the very stores they wait for — re-loading whole batches until every tag
+// had arrived was 4x slower), then load the others together, and wait singly for a straggler.
+template <int PF>
+__device__ __forceinline__ void tagged_wait_all(const tagged_t* p, long long stride, int n, unsigned tag, int& budget,
+                                                float (&out)[PF]) {
+  out[0] = tagged_wait(p, tagged_peek(p), tag, budget);
+  tagged_t v[PF];
+#pragma unroll
+  for (int q = 1; q < PF; ++q) v[q] = tagged_peek(p + (q < n ? q : 0) * stride);
+#pragma unroll
+  for (int q = 1; q < PF; ++q) out[q] = q < n ? tagged_wait(p + q * stride, v[q], tag, budget) : 0.0f;
 }
 
 // gi [D][B][T][3H], h0 [D][B][H], whh [D][3H][H], bhh [D][3H] -> out [D][B][T][H]; saved [D][B][T][4][H] = r, z, n, hn.
@@ -58,7 +76,7 @@ template <int H>
 __global__ __launch_bounds__(kGT) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ h0,
                                                       const float* __restrict__ whh, const float* __restrict__ bhh,
                                                       int B, int T, float* __restrict__ out,
-                                                      float* __restrict__ saved, unsigned* __restrict__ counters) {
+                                                      float* __restrict__ saved, tagged_t* __restrict__ xch) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LD = H + 4;              // rows padded by one 16-byte slot: the rows a ds_read_b128 lane group touches
   float* W = smem;                       // (4 samples, 8 units) start 4 banks apart  ([3 * kU][LD]: rows r(u0..), z(..), n(..))
@@ -72,13 +90,28 @@ __global__ __launch_bounds__(kGT) void gru_fwd_kernel(const float* __restrict__ 
   const float* gid = gi + (long long)d * B * T * 3 * H;
   float* od = out + (long long)d * B * T * H;
   float* sd = saved + (long long)d * B * T * 4 * H;
-  unsigned* ctr = counters + d;
+  tagged_t* xd = xch + (long long)d * 2 * B * H;  // [2 (step parity)][B][H]
+  int budget = kPollBudget;
   for (int t = 0; t < T; ++t) {
-    // previous hidden state of ALL units (written by all blocks of this direction in the previous step)
-    for (int e = threadIdx.x; e < B * (H / 4); e += kGT) {
-      const int b = e / (H / 4), k = 4 * (e % (H / 4));
-      const float* src = t == 0 ? h0 + ((long long)d * B + b) * H + k : od + ((long long)b * T + (t - 1)) * H + k;
-      *reinterpret_cast<float4*>(&hp[b * LD + k]) = *reinterpret_cast<const float4*>(src);
+    // previous hidden state of ALL units: h0, or the tagged words the blocks of this direction published in step t - 1
+    if (t == 0) {
+      for (int e = threadIdx.x; e < B * (H / 4); e += kGT) {
+        const int b = e / (H / 4), k = 4 * (e % (H / 4));
+        *reinterpret_cast<float4*>(&hp[b * LD + k]) = *reinterpret_cast<const float4*>(h0 + ((long long)d * B + b) * H + k);
+      }
+    } else {
+      const tagged_t* xr = xd + (long long)((t - 1) & 1) * B * H;
+      constexpr int PF = 32;  // words per thread and batch (B x H = 32 x 256: all of a thread's words at once)
+      for (int e0 = threadIdx.x; e0 < B * H; e0 += PF * kGT) {
+        float hv[PF];
+        const int n = (B * H - e0 + kGT - 1) / kGT;
+        tagged_wait_all<PF>(xr + e0, kGT, n < PF ? n : PF, (unsigned)t, budget, hv);
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+          const int e = e0 + q * kGT;
+          if (e < B * H) hp[(e / H) * LD + e % H] = hv[q];
+        }
+      }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < B * kU; e += kGT) {  // (sample, own unit)
@@ -114,13 +147,14 @@ __global__ __launch_bounds__(kGT) void gru_fwd_kernel(const float* __restrict__ 
       const float n = tanhf(g[2 * H + c] + r * hn);
       const float hnew = (1.0f - z) * n + z * hb[c];
       od[((long long)b * T + t) * H + c] = hnew;
+      tagged_store(xd + (long long)(t & 1) * B * H + b * H + c, hnew, (unsigned)(t + 1));
       float* sv = sd + ((long long)b * T + t) * 4 * H;
       sv[c] = r;
       sv[H + c] = z;
       sv[2 * H + c] = n;
       sv[3 * H + c] = hn;
     }
-    grid_barrier(ctr, (unsigned)(nblk * (t + 1)));
+    __syncthreads();  // hp is rewritten by the next step
   }
 }
 
@@ -131,8 +165,7 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ whh, const float* __restrict__ out,
                                                       const float* __restrict__ saved, int B, int T,
                                                       float* __restrict__ dgi, float* __restrict__ dwhh,
-                                                      float* __restrict__ dbhh, float* __restrict__ part,
-                                                      unsigned* __restrict__ counters) {
+                                                      float* __restrict__ dbhh, tagged_t* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W = smem;                        // [3 * kU][H]
   float* hp = smem + 3 * kU * H;          // [B][H] h_{t-1}
@@ -149,8 +182,8 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
   const float* od = out + (long long)d * B * T * H;
   const float* sd = saved + (long long)d * B * T * 4 * H;
   float* dgid = dgi + (long long)d * B * T * 3 * H;
-  float* pd = part + (long long)d * 2 * nblk * B * H;
-  unsigned* ctr = counters + 2 + d;
+  tagged_t* pd = part + (long long)d * 2 * nblk * B * H;  // tagged words, see tagged_store
+  int budget = kPollBudget;
   // own slice of dW_hh (3 * kU rows x H columns) and of W_hh, column-wise in registers: thread -> column(s) k0 + 256 c of
   // the rows rbase .. rbase + RPT - 1, so that per sample one h value and RPT/4 broadcast 16-byte reads of the gate
   // gradients feed RPT FMAs (a row-major spread cost two LDS reads per FMA)
@@ -182,9 +215,17 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
       const int b = e / kU, u = e % kU, c = u0 + u;
       float dh = god[((long long)b * T + t) * H + c] + dhc[e];
       if (t < T - 1) {  // + what the other rows sent back through W_hh in step t + 1 (fixed block order)
-        const float* pp = pd + (long long)((t + 1) & 1) * nblk * B * H;
-#pragma unroll 8
-        for (int k = 0; k < nblk; ++k) dh += pp[((long long)k * B + b) * H + c];  // (independent loads, ordered adds)
+        const tagged_t* pp = pd + (long long)((t + 1) & 1) * nblk * B * H + (long long)b * H + c;
+        const unsigned tag = (unsigned)(T - (t + 1));
+        constexpr int PF = 32;  // words per batch (all blocks of H = 256 at once); the additions in block order
+        for (int k0 = 0; k0 < nblk; k0 += PF) {
+          float pv[PF];
+          const int n = nblk - k0 < PF ? nblk - k0 : PF;
+          tagged_wait_all<PF>(pp + (long long)k0 * B * H, (long long)B * H, n, tag, budget, pv);
+#pragma unroll
+          for (int q = 0; q < PF; ++q)
+            if (q < n) dh += pv[q];
+        }
       }
       const float* sv = sd + ((long long)b * T + t) * 4 * H;
       const float r = sv[c], z = sv[H + c], n = sv[2 * H + c], hn = sv[3 * H + c];
@@ -225,7 +266,8 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
     }
     // partial dL/dh_{t-1}[b][k] = sum over the rows of dg[b][row] * W[row][k]: the thread's rows of its column(s);
     // H < 256: the row groups of a column are added in group order through LDS (fixed order)
-    float* po = pd + (long long)(t & 1) * nblk * B * H + (long long)blk * B * H;
+    tagged_t* po = pd + (long long)(t & 1) * nblk * B * H + (long long)blk * B * H;
+    const unsigned otag = (unsigned)(T - t);
     for (int b = 0; b < B; ++b) {
       float a[CPT];
 #pragma unroll
@@ -241,7 +283,7 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
       }
       if constexpr (RG == 1) {
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) po[(long long)b * H + k0 + kGT * c] = a[c];
+        for (int c = 0; c < CPT; ++c) tagged_store(po + (long long)b * H + k0 + kGT * c, a[c], otag);
       } else {
         red[threadIdx.x] = a[0];
         __syncthreads();
@@ -249,12 +291,12 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
           float sum = 0.0f;
 #pragma unroll
           for (int g = 0; g < RG; ++g) sum += red[g * H + threadIdx.x];
-          po[(long long)b * H + threadIdx.x] = sum;
+          tagged_store(po + (long long)b * H + threadIdx.x, sum, otag);
         }
         __syncthreads();
       }
     }
-    grid_barrier(ctr, (unsigned)(nblk * (T - t)));
+    __syncthreads();  // hp, dg and dhc are rewritten by the next step
   }
   float* dwd = dwhh + (long long)d * 3 * H * H;
 #pragma unroll
@@ -269,10 +311,6 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
   }
 }
 
-__global__ void gru_zero_counters_kernel(unsigned* c, int first, int count) {
-  if ((int)threadIdx.x < count) c[first + threadIdx.x] = 0u;
-}
-
 int gru_check(int64_t D, int64_t B, int64_t T, int64_t H, const char* who) {
   MPA_REQUIRE(D == 1 || D == 2, "%s: 1 or 2 directions", who);
   MPA_REQUIRE(B >= 1 && B <= kMaxB && T >= 1 && T <= 4096, "%s: 1 <= batch <= %d, 1 <= steps <= 4096", who, kMaxB);
@@ -283,9 +321,10 @@ int gru_check(int64_t D, int64_t B, int64_t T, int64_t H, const char* who) {
 }  // namespace
 
 namespace {
-// The step barrier spins until every block of the grid has arrived: all H/8 x D blocks must be RESIDENT at once (a block
-// that was never dispatched would hang the kernel without a diagnostic — e.g. on a partitioned device with fewer CUs,
-// or with an LDS footprint that leaves one block per CU).  Checked against the occupancy the runtime reports.
+// Every block polls for the words the other blocks of its direction publish in the same step: all H/8 x D blocks must be
+// RESIDENT at once (a block that was never dispatched — e.g. on a partitioned device with fewer CUs, or with an LDS
+// footprint that leaves one block per CU — would stall the others until their poll budget runs out).  Checked against the
+// occupancy the runtime reports.
 template <typename Kern>
 int gru_resident(Kern kern, size_t smem, int blocks, const char* who) {
   if (smem > 64 * 1024 &&
@@ -298,7 +337,7 @@ int gru_resident(Kern kern, size_t smem, int blocks, const char* who) {
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kGT, smem) != hipSuccess)
     return mpa::fail(MPA_EINVAL, "%s: cannot query the device's occupancy", who);
   if ((long long)per_cu * cus < blocks)
-    return mpa::fail(MPA_EINVAL, "%s: the grid barrier needs all %d blocks resident, this device holds %d x %d", who, blocks,
+    return mpa::fail(MPA_EINVAL, "%s: the per-step exchange needs all %d blocks resident, this device holds %d x %d", who, blocks,
                      per_cu, cus);
   return MPA_OK;
 }
@@ -321,8 +360,9 @@ extern "C" int mpa_gru_resident(int64_t D, int64_t B, int64_t H, int* ok) {
 extern "C" int mpa_gru_workspace(int64_t D, int64_t B, int64_t T, int64_t H, int64_t* float_elems) {
   if (int st = gru_check(D, B, T, H, "gru_workspace")) return st;
   MPA_REQUIRE(float_elems != nullptr, "gru_workspace: null pointer");
-  // saved gates [D][B][T][4][H] | backward partials [D][2][H/16][B][H] | 4 barrier counters (as floats)
-  *float_elems = D * B * T * 4 * H + D * 2 * (H / kU) * B * H + 64;
+  // saved gates [D][B][T][4][H] | exchange words [D][2][H/kU][B][H] of 8 bytes (the backward's partials; the forward
+  // uses the first [D][2][B][H] of them) | padding
+  *float_elems = D * B * T * 4 * H + 2 * D * 2 * (H / kU) * B * H + 64;
   return MPA_OK;
 }
 
@@ -332,10 +372,12 @@ extern "C" int mpa_gru_forward(const float* gi, const float* h0, const float* wh
   MPA_REQUIRE(gi && h0 && whh && bhh && ws && out, "gru_forward: null pointer");
   hipStream_t s = mpa::as_stream(stream);
   float* saved = ws;
-  unsigned* counters = reinterpret_cast<unsigned*>(ws + D * B * T * 4 * H + D * 2 * (H / kU) * B * H);
+  tagged_t* xch = reinterpret_cast<tagged_t*>(ws + D * B * T * 4 * H);
+  MPA_REQUIRE((uintptr_t)xch % 8 == 0, "gru_forward: workspace must be 8-byte aligned");
   const size_t smem = sizeof(float) * (3 * kU * (H + 4) + B * (H + 4));
   MPA_REQUIRE(smem <= 160 * 1024, "gru_forward: batch x hidden size does not fit the 160 KB of LDS");
-  hipLaunchKernelGGL(gru_zero_counters_kernel, dim3(1), dim3(64), 0, s, counters, 0, 2);
+  if (hipMemsetAsync(xch, 0, sizeof(tagged_t) * D * 2 * B * H, s) != hipSuccess)
+    return mpa::fail(MPA_ELAUNCH, "gru_forward: cannot clear the exchange words");
   const dim3 grid((unsigned)(H / kU), (unsigned)D);
 #define MPA_GRU_FWD(HH)                                                                                               \
   {                                                                                                                   \
@@ -345,7 +387,7 @@ extern "C" int mpa_gru_forward(const float* gi, const float* h0, const float* wh
       checked = smem;                                                                                                 \
     }                                                                                                                 \
     hipLaunchKernelGGL(gru_fwd_kernel<HH>, grid, dim3(kGT), smem, s, gi, h0, whh, bhh, (int)B, (int)T, out, saved,     \
-                       counters);                                                                                     \
+                       xch);                                                                                          \
   }
   if (H == 128) MPA_GRU_FWD(128) else MPA_GRU_FWD(256)
 #undef MPA_GRU_FWD
@@ -359,11 +401,12 @@ extern "C" int mpa_gru_backward(const float* grad_out, const float* h0, const fl
   MPA_REQUIRE(grad_out && h0 && whh && out && ws && grad_gi && grad_whh && grad_bhh, "gru_backward: null pointer");
   hipStream_t s = mpa::as_stream(stream);
   const float* saved = ws;
-  float* part = ws + D * B * T * 4 * H;
-  unsigned* counters = reinterpret_cast<unsigned*>(ws + D * B * T * 4 * H + D * 2 * (H / kU) * B * H);
+  tagged_t* part = reinterpret_cast<tagged_t*>(ws + D * B * T * 4 * H);
+  MPA_REQUIRE((uintptr_t)part % 8 == 0, "gru_backward: workspace must be 8-byte aligned");
   const size_t smem = sizeof(float) * (3 * kU * H + B * H + B * 3 * kU + B * kU);
   MPA_REQUIRE(smem <= 160 * 1024, "gru_backward: batch x hidden size does not fit the 160 KB of LDS");
-  hipLaunchKernelGGL(gru_zero_counters_kernel, dim3(1), dim3(64), 0, s, counters, 2, 2);
+  if (hipMemsetAsync(part, 0, sizeof(tagged_t) * D * 2 * (H / kU) * B * H, s) != hipSuccess)
+    return mpa::fail(MPA_ELAUNCH, "gru_backward: cannot clear the exchange words");
   const dim3 grid((unsigned)(H / kU), (unsigned)D);
 #define MPA_GRU_BWD(HH)                                                                                               \
   {                                                                                                                   \
@@ -373,7 +416,7 @@ extern "C" int mpa_gru_backward(const float* grad_out, const float* h0, const fl
       checked = smem;                                                                                                 \
     }                                                                                                                 \
     hipLaunchKernelGGL(gru_bwd_kernel<HH>, grid, dim3(kGT), smem, s, grad_out, h0, whh, out, saved, (int)B, (int)T,    \
-                       grad_gi, grad_whh, grad_bhh, part, counters);                                                  \
+                       grad_gi, grad_whh, grad_bhh, part);                                                            \
   }
   if (H == 128) MPA_GRU_BWD(128) else MPA_GRU_BWD(256)
 #undef MPA_GRU_BWD

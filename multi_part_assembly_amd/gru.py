@@ -54,7 +54,7 @@ _RESIDENT: dict = {}
 
 def supported(hidden, batch, directions=2):
     """Shapes csrc/gru.hip is built for AND a device that can hold the kernels' whole grid at once (their per-step
-    barrier needs every block resident: mpa_gru_resident asks the runtime's occupancy calculator; a partitioned or
+    exchange needs every block resident: mpa_gru_resident asks the runtime's occupancy calculator; a partitioned or
     smaller device answers no and the caller keeps the library GRU)."""
     if not (hidden in (128, 256) and batch <= 64 and (48 * hidden + batch * hidden + batch * 64) * 4 <= 160 * 1024):
         return False
