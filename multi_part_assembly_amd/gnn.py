@@ -314,10 +314,18 @@ class RGLNet(DGLModel):
         """Same random draws, in the same order, as rgl_net/network.py:50-57 (CPU generator).  While a HIP graph is
         being captured the draws come from the device generator instead (a host-to-device copy cannot be a graph
         node; torch advances the captured generator's offset on every replay)."""
-        where = device if device is not None and device.type == "cuda" and torch.cuda.is_current_stream_capturing() else None
-        rand_vec = torch.randn((1, B, self.pc_feat_dim), device=where).repeat(2, 1, 1)
-        zero_vec = torch.randn((2, B, self.pc_feat_dim), device=where)
-        return torch.cat([rand_vec, zero_vec], dim=-1)
+        cuda = device is not None and device.type == "cuda"
+        if cuda and torch.cuda.is_current_stream_capturing():
+            rand_vec = torch.randn((1, B, self.pc_feat_dim), device=device).repeat(2, 1, 1)
+            zero_vec = torch.randn((2, B, self.pc_feat_dim), device=device)
+            return torch.cat([rand_vec, zero_vec], dim=-1)
+        # the draws land in pinned memory and travel with an asynchronous copy: a copy from pageable memory makes the
+        # host wait until the stream has drained (three pipeline drains per RGL-NET step, one per GNN iteration)
+        rand_vec = torch.randn((1, B, self.pc_feat_dim), pin_memory=cuda)
+        zero_vec = torch.randn((2, B, self.pc_feat_dim), pin_memory=cuda)
+        if cuda:
+            rand_vec, zero_vec = rand_vec.to(device, non_blocking=True), zero_vec.to(device, non_blocking=True)
+        return torch.cat([rand_vec.repeat(2, 1, 1), zero_vec], dim=-1)
 
     def _node_update(self, part_feats, messages, data_dict, iter_ind):
         hidden = self._init_gru_hidden(part_feats.shape[0], messages.device).type_as(messages)

@@ -105,5 +105,6 @@ class StocasticPoseRegressor(PoseRegressor):
     def forward(self, x):
         if self.noise_dim == 0:
             return super().forward(x)
-        noise = torch.randn(*x.shape[:-1], self.noise_dim).type_as(x)
+        # CPU generator draws as upstream; pinned + asynchronous copy (a pageable copy drains the stream first)
+        noise = torch.randn(*x.shape[:-1], self.noise_dim, pin_memory=x.is_cuda).to(x.device, non_blocking=True).type_as(x)
         return super().forward(torch.cat([x, noise], dim=-1))
