@@ -170,10 +170,21 @@ __global__ __launch_bounds__(kGT, DG_TN_BUFS == 2 ? 2 : 3) void gemm_tn_kernel(c
   __shared__ __attribute__((aligned(16))) float Ys[DG_TN_BUFS][RC * BNT];
   __shared__ __attribute__((aligned(16))) float Xs[DG_TN_BUFS][RC * BK];
   const int R = hdr != nullptr ? hdr[1] : rows;
-  const int n0 = blockIdx.x * BNT, k0 = blockIdx.y * BK;
+  // block -> (n tile, k tile, row chunk).  The tiles of one row chunk read the same rows of Y and X; workgroups go to
+  // the 8 XCDs round-robin (linear id L runs on XCD L % 8) and every XCD has its own L2, so a chunk's tiles are given
+  // consecutive slots of ONE XCD (chunks a multiple of 8): its rows come from HBM once instead of once per tile.
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+  if (gridDim.z % 8 == 0) {
+    const int gx = (int)gridDim.x, tiles = gx * (int)gridDim.y, L = (bz * (int)gridDim.y + by) * gx + bx;
+    const int q = L >> 3, t = q % tiles;
+    bz = (q / tiles) * 8 + (L & 7);
+    bx = t % gx;
+    by = t / gx;
+  }
+  const int n0 = bx * BNT, k0 = by * BK;
   // rows_per_chunk == 0: the valid rows (known on the device only) are dealt evenly to the grid's chunks
   const int rpc = rows_per_chunk > 0 ? rows_per_chunk : (int)((((long long)R + gridDim.z - 1) / gridDim.z + 31) / 32 * 32);
-  const long long rb = (long long)blockIdx.z * rpc;
+  const long long rb = (long long)bz * rpc;
   long long re = rb + rpc;
   if (re > R) re = R;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(kGT, DG_TN_BUFS == 2 ? 2 : 3) void gemm_tn_kernel(c
       }
     }
   }
-  float* out = part + (long long)blockIdx.z * Nout * K;
+  float* out = part + (long long)bz * Nout * K;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll

@@ -43,6 +43,7 @@
 #define DG_NT_TAIL
 #endif
 #include <cstdio>
+#include <type_traits>
 #include <vector>
 
 #include "dg_knn.h"
@@ -238,9 +239,12 @@ __global__ __launch_bounds__(AT) void dg_agg_fwd_kernel(const float* __restrict_
   constexpr int kSlots = AT / 8;  // points in flight per pass of the block
   float* Us = reinterpret_cast<float*>(agg_lds);                                    // [N][32]
   float(*red)[32][2] = reinterpret_cast<float(*)[32][2]>(Us + (size_t)N * 32);      // [kSlots][32][2]
-  const int v = blockIdx.y;
+  // the channel slices of one part run on ONE XCD (dg::knn_block: grid.y is the part count rounded up to 8): they read
+  // the same neighbour lists and neighbouring pieces of the same cache lines, and every XCD has its own L2
+  int v, sl;
+  dg::knn_block(v, sl);
   if (v >= hdr[0]) return;
-  const int c0 = blockIdx.x * 32;
+  const int c0 = sl * 32;
   const float* up = uv + (long long)v * N * 2 * CO;
   dg_load_slice<AT>(up + c0, 2 * CO, N, Us);
   __syncthreads();
@@ -775,9 +779,13 @@ __global__ __launch_bounds__(AT) void dg_agg_bwd_kernel(const float* __restrict_
   unsigned char* Sp = reinterpret_cast<unsigned char*>(Wp + (N + 1) * kBS);       // [(N + 1)][kBS]
   unsigned short* scr_all = reinterpret_cast<unsigned short*>(Sp + (N + 1) * kBS);  // [AT / 64][kRun]
   unsigned short* rps = scr_all + (AT / 64) * kRun;                                // [N + 2]: offsets < 20 N <= 20480
-  const int v = blockIdx.y;
+  // the 16-channel slices of one part run on ONE XCD (dg::knn_block): a slice's rows are 64-byte halves (V, dz) and
+  // 16-byte eighths (selected slots) of cache lines whose other parts the neighbouring slices read — spread over the
+  // eight L2s, every line was fetched from HBM once per slice (1.8 GB per launch measured against 0.77 GB of operands)
+  int v, sl;
+  dg::knn_block(v, sl);
   if (v >= hdr[0]) return;
-  const int c0 = blockIdx.x * kBS;
+  const int c0 = sl * kBS;
   const float* up = uv + (long long)v * N * 2 * CO;
   float* gp = guv + (long long)v * N * 2 * CO;
   const float* dzp = dz + (long long)v * N * CO;
@@ -854,43 +862,50 @@ __global__ __launch_bounds__(AT) void dg_agg_bwd_kernel(const float* __restrict_
     // four in-edges per pass of the loop: their scratch reads, then their twelve panel reads, are issued together —
     // one in-edge at a time is two dependent LDS round trips per pass with two waves per SIMD to hide them
     const bool hub = __any(e - base > kRun);  // a point whose in-edges reach past the staged run (rare)
-    for (int k = 0; k < kmax; k += 4) {  // ascending sources: fixed summation order
-      unsigned ent[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int off = b + k + u - base;
-        ent[u] = sc[off < kRun ? off : kRun - 1];
-      }
-      if (__builtin_expect(hub, 0)) {
+    // Two copies of the loop, chosen per pass: only the hub one loads entries from global memory.  With the load in
+    // the one loop, every iteration carried an `s_waitcnt vmcnt(0)` for it — which also waits for the NEXT pass's
+    // prefetch (request) issued just above, so the prefetch never overlapped the loop it was meant to hide behind.
+    auto scan = [&](auto with_hub) {
+      for (int k = 0; k < kmax; k += 4) {  // ascending sources: fixed summation order
+        unsigned ent[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int a = b + k + u;
-          if (a < e && a - base >= kRun) ent[u] = rl[a];
+          const int off = b + k + u - base;
+          ent[u] = sc[off < kRun ? off : kRun - 1];
+        }
+        if constexpr (decltype(with_hub)::value) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int a = b + k + u;
+            if (a < e && a - base >= kRun) ent[u] = rl[a];
+          }
+        }
+        float4 tv[4], tw[4];
+        unsigned ts[4], slot[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned en = b + k + u < e ? ent[u] : (unsigned)kNeutral;
+          const int src = en >> 5;
+          slot[u] = en & 31u;
+          tv[u] = *reinterpret_cast<const float4*>(&Vp[src * kBS + 4 * cq]);
+          tw[u] = *reinterpret_cast<const float4*>(&Wp[src * kBS + 4 * cq]);
+          ts[u] = *reinterpret_cast<const unsigned*>(&Sp[src * kBS + 4 * cq]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          sv.x += tv[u].x;
+          sv.y += tv[u].y;
+          sv.z += tv[u].z;
+          sv.w += tv[u].w;
+          sd.x += (ts[u] & 0xffu) == slot[u] ? tw[u].x : 0.0f;
+          sd.y += ((ts[u] >> 8) & 0xffu) == slot[u] ? tw[u].y : 0.0f;
+          sd.z += ((ts[u] >> 16) & 0xffu) == slot[u] ? tw[u].z : 0.0f;
+          sd.w += (ts[u] >> 24) == slot[u] ? tw[u].w : 0.0f;
         }
       }
-      float4 tv[4], tw[4];
-      unsigned ts[4], slot[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned en = b + k + u < e ? ent[u] : (unsigned)kNeutral;
-        const int src = en >> 5;
-        slot[u] = en & 31u;
-        tv[u] = *reinterpret_cast<const float4*>(&Vp[src * kBS + 4 * cq]);
-        tw[u] = *reinterpret_cast<const float4*>(&Wp[src * kBS + 4 * cq]);
-        ts[u] = *reinterpret_cast<const unsigned*>(&Sp[src * kBS + 4 * cq]);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        sv.x += tv[u].x;
-        sv.y += tv[u].y;
-        sv.z += tv[u].z;
-        sv.w += tv[u].w;
-        sd.x += (ts[u] & 0xffu) == slot[u] ? tw[u].x : 0.0f;
-        sd.y += ((ts[u] >> 8) & 0xffu) == slot[u] ? tw[u].y : 0.0f;
-        sd.z += ((ts[u] >> 16) & 0xffu) == slot[u] ? tw[u].z : 0.0f;
-        sd.w += (ts[u] >> 24) == slot[u] ? tw[u].w : 0.0f;
-      }
-    }
+    };
+    if (__builtin_expect(hub, 0)) scan(std::true_type{});
+    else scan(std::false_type{});
     __builtin_amdgcn_wave_barrier();
     if (rk < N) {
       const float deg = (float)(e - b), kf = (float)kNbr;
@@ -1179,7 +1194,7 @@ int dgcnn_forward_impl(const float* points, const float* valids, const float* co
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)agg_fwd_lds(MPA_AGG_FWD_AT, kMaxN));
         reserved = true;
       }
-      hipLaunchKernelGGL(dg_agg_fwd_kernel<MPA_AGG_FWD_AT>, dim3((unsigned)(CO / 32), (unsigned)M), dim3(MPA_AGG_FWD_AT),
+      hipLaunchKernelGGL(dg_agg_fwd_kernel<MPA_AGG_FWD_AT>, dim3((unsigned)(CO / 32), DG_KNN_GRID_Y(M)), dim3(MPA_AGG_FWD_AT),
                          agg_fwd_lds(MPA_AGG_FWD_AT, (int)N), s, (const float*)w.uv[l], CO,
                          (const unsigned short*)w.idx[l], bn_w[l], (int)N, w.esel[l], w.ssel[l], w.s1[l], w.partial,
                          (const int*)w.hdr);
@@ -1287,7 +1302,7 @@ extern "C" int mpa_dgcnn_backward(const float* grad_feat, const float* const* co
            grad_bn_b[l], cw, hdr);
     launch(dg_reverse_kernel, dim3((unsigned)M), dim3(1024), s, (const unsigned short*)w.idx[l], (int)N, w.rptr, w.order,
            w.rlist, hdr);
-    launch_agg_bwd(dim3((unsigned)(CO / kBS), (unsigned)M), s, (const float*)w.uv[l], CO, (const int*)w.rptr,
+    launch_agg_bwd(dim3((unsigned)(CO / kBS), DG_KNN_GRID_Y(M)), s, (const float*)w.uv[l], CO, (const int*)w.rptr,
                    (const int*)w.order, (const unsigned short*)w.rlist, (const float*)w.dz,
                    (const unsigned char*)w.ssel[l], (const float*)w.s1[l], (const float*)w.coef, (int)N, w.duv, hdr);
     if (l == 0) {

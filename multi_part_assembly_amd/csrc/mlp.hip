@@ -380,6 +380,7 @@ extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int
     int chunks = (512 + out_tiles - 1) / out_tiles;
     if (chunks > (int)(R / 64)) chunks = (int)(R / 64);
     chunks = chunks < 1 ? 1 : (chunks > kChunks ? kChunks : chunks);
+    if (chunks >= 8) chunks = chunks / 8 * 8;  // (a multiple of 8 gets the kernel's XCD-aware chunk mapping)
     const int rows_per_chunk = (int)(((R + chunks - 1) / chunks + 31) / 32 * 32);
     const dim3 grid((unsigned)((N + 127) / 128), (unsigned)(K % 128 == 0 ? K / 128 : K / 64), (unsigned)chunks);
 #if DG_GEMM_SPLIT
