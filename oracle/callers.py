@@ -51,7 +51,7 @@ def part_features(sd, batch, encoder, prefix, training, stats_out):
     mask = valids == 1
     enc = on.pointnet if encoder == "pointnet" else on.dgcnn
     feats = enc(pcs[mask], sd, prefix, training, stats_out)
-    return torch.zeros(B, P, feats.shape[-1]).index_put((mask,), feats)
+    return torch.zeros(B, P, feats.shape[-1], dtype=feats.dtype).index_put((mask,), feats)
 
 
 def dgl_forward(sd, batch, iters, encoder="dgcnn", training=True, stats_out=None):
@@ -60,7 +60,7 @@ def dgl_forward(sd, batch, iters, encoder="dgcnn", training=True, stats_out=None
     part_feats = part_features(sd, batch, encoder, "encoder.", training, stats_out)
     valid_matrix = batch["valid_matrix"]
     B, P, Fd = part_feats.shape
-    pose = torch.zeros(B, P, 7)
+    pose = torch.zeros(B, P, 7, dtype=part_feats.dtype)
     pose[..., 0] = 1.0
     preds = []
     for it in range(iters):

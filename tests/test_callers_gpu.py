@@ -246,6 +246,69 @@ def test_gru_exchange_is_stable_over_many_launches(cuda_device):
             assert all(torch.equal(a, b) for a, b in zip(first, got))
 
 
+def test_dgl_dgcnn_step_at_the_benchmark_part_size_against_float64(cuda_device, capsys):
+    """BASELINE.json configs[2] at its part size (P = 20 slots, N = 1000 points, everyday-like synthetic shapes; B = 4
+    to bound the CPU time): the training-mode forward_pass + backward of DGL + DGCNN on the HIP path, on the float32 CPU
+    oracle (oracle/callers.py) and on the same oracle in float64.
+
+    At this size the step is NOT well conditioned in float32: the loss goes through ~10^5 discrete choices per sample
+    (nearest neighbours of the Chamfer terms, kNN graphs, max-pool / ReLU selections) on random-init predictions, and the
+    float32 oracle's own parameter gradients sit 5-80 % (largest entry, per tensor) from its float64 evaluation.  A
+    bar "hip == oracle32 to 1e-2" would therefore fail for ANY correct float32 implementation; the bar here is that the
+    HIP path is as close to float64 as the float32 restatement of the reference is: the loss within twice the
+    oracle's own deviation, per tensor |hip - f64| <= 2 |o32 - f64| + 0.25, and the median ratio of the two deviations
+    over all tensors <= 1.2 (measured: 0.88 — the HIP path is the closer of the two)."""
+    from multi_part_assembly_amd import synthetic
+    from oracle import callers as oc
+    import statistics
+    B = 4
+    cfg = config.dgl_dgcnn_everyday()
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    names = [k for k, _ in model.named_parameters()]
+    batch = synthetic.make_batch(B, 20, 1000, preset="everyday", seed=1234, device=cuda_device)
+    batch.pop("num_parts", None)
+    model.to(cuda_device).train()
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    hip = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters() if p.grad is not None}
+    hip_loss = float(loss.detach())
+    threads = torch.get_num_threads()
+    torch.set_num_threads(16)
+
+    def oracle(dt):
+        sd = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        params = {k: sd[k].requires_grad_() for k in names}
+        cb = {k: (v.cpu().to(dt) if v.is_floating_point() else v.cpu()) for k, v in batch.items() if hasattr(v, "cpu")}
+        losses = oc.dgl_loss(sd, cb, cfg.model.gnn_iter, cfg.model.encoder, True, {})
+        losses["loss"].backward()
+        return float(losses["loss"].detach()), {k: p.grad.double() for k, p in params.items() if p.grad is not None}
+
+    try:
+        l32, g32 = oracle(torch.float32)
+        l64, g64 = oracle(torch.float64)
+    finally:
+        torch.set_num_threads(threads)
+    assert abs(hip_loss - l64) <= 2.0 * abs(l32 - l64) + 1e-4 * abs(l64), (hip_loss, l32, l64)
+    ratios, worst = [], (0.0, "")
+    for k, b in g64.items():
+        scale = float(b.abs().max())
+        if scale < 1e-10:  # a bias in front of a BatchNorm: structurally zero
+            continue
+        eh = float((hip[k] - b).abs().max()) / scale
+        eo = float((g32[k] - b).abs().max()) / scale
+        assert eh <= 2.0 * eo + 0.25, (k, eh, eo)
+        ratios.append(eh / max(eo, 1e-12))
+        worst = max(worst, (eh, k))
+    med = statistics.median(ratios)
+    with capsys.disabled():
+        print(f"\n  DGL + DGCNN at P=20, N=1000, B={B}: loss hip {hip_loss:.6f} / oracle32 {l32:.6f} / float64 {l64:.6f}; "
+              f"gradient deviation from float64, hip : oracle32, median ratio over {len(ratios)} tensors {med:.2f} "
+              f"(largest hip deviation {worst[0]:.2f} of max: {worst[1]})", end="")
+    assert med <= 1.2, med
+
+
 def test_dgl_dgcnn_graph_replay_equals_eager_steps(cuda_device):
     """BASELINE.json configs[2] as ONE HIP graph (bench.py --config c3 --graph): DGL draws no random numbers in
     training, every kernel on its path is deterministic (no atomics: fixed-order statistics, the transposed kNN graph
