@@ -145,7 +145,7 @@ def pn_transformer_forward(sd, batch, num_layers, num_heads, training=True, stat
     mask = valids == 1
     enc = pointnet if encoder == "pointnet" else dgcnn
     feats = enc(pcs[mask], sd, "encoder.", training, stats_out)
-    pc_feats = torch.zeros(B, P, feats.shape[-1]).index_put((mask,), feats)
+    pc_feats = torch.zeros(B, P, feats.shape[-1], dtype=feats.dtype).index_put((mask,), feats)
     corr = transformer_encoder(pc_feats, mask, sd, "corr_module.", num_layers, num_heads)
     rot, trans = pose_head(corr, sd, "pose_predictor.")
     return {"pc_feats": pc_feats, "rot": rot, "trans": trans}

@@ -246,25 +246,20 @@ def test_gru_exchange_is_stable_over_many_launches(cuda_device):
             assert all(torch.equal(a, b) for a, b in zip(first, got))
 
 
-def test_dgl_dgcnn_step_at_the_benchmark_part_size_against_float64(cuda_device, capsys):
-    """BASELINE.json configs[2] at its part size (P = 20 slots, N = 1000 points, everyday-like synthetic shapes; B = 4
-    to bound the CPU time): the training-mode forward_pass + backward of DGL + DGCNN on the HIP path, on the float32 CPU
-    oracle (oracle/callers.py) and on the same oracle in float64.
-
-    At this size the step is NOT well conditioned in float32: the loss goes through ~10^5 discrete choices per sample
-    (nearest neighbours of the Chamfer terms, kNN graphs, max-pool / ReLU selections) on random-init predictions, and the
-    float32 oracle's own parameter gradients sit 5-80 % (largest entry, per tensor) from its float64 evaluation.  A
-    bar "hip == oracle32 to 1e-2" would therefore fail for ANY correct float32 implementation; the bar here is that the
-    HIP path is as close to float64 as the float32 restatement of the reference is: the loss within twice the
-    oracle's own deviation, per tensor |hip - f64| <= 2 |o32 - f64| + 0.25, and the median ratio of the two deviations
-    over all tensors <= 1.2 (measured: 0.88 — the HIP path is the closer of the two)."""
+def _against_float64(cuda_device, capsys, cfg, label, oracle_loss, B=4, no_dropout=False, slack=0.25, median_cap=1.2,
+                     abs_cap=None):
+    """One training-mode forward_pass + backward at P = 20, N = 1000 on the HIP path, on the float32 CPU oracle and on the
+    same oracle in float64; returns nothing, asserts that the HIP path is as close to float64 as the float32 oracle."""
     from multi_part_assembly_amd import synthetic
-    from oracle import callers as oc
     import statistics
-    B = 4
-    cfg = config.dgl_dgcnn_everyday()
     torch.manual_seed(0)
     model = build_model(cfg)
+    if no_dropout:
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if isinstance(m, torch.nn.MultiheadAttention):
+                m.dropout = 0.0
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     names = [k for k, _ in model.named_parameters()]
     batch = synthetic.make_batch(B, 20, 1000, preset="everyday", seed=1234, device=cuda_device)
@@ -281,9 +276,9 @@ def test_dgl_dgcnn_step_at_the_benchmark_part_size_against_float64(cuda_device, 
         sd = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
         params = {k: sd[k].requires_grad_() for k in names}
         cb = {k: (v.cpu().to(dt) if v.is_floating_point() else v.cpu()) for k, v in batch.items() if hasattr(v, "cpu")}
-        losses = oc.dgl_loss(sd, cb, cfg.model.gnn_iter, cfg.model.encoder, True, {})
-        losses["loss"].backward()
-        return float(losses["loss"].detach()), {k: p.grad.double() for k, p in params.items() if p.grad is not None}
+        total = oracle_loss(sd, cb)
+        total.backward()
+        return float(total.detach()), {k: p.grad.double() for k, p in params.items() if p.grad is not None}
 
     try:
         l32, g32 = oracle(torch.float32)
@@ -291,22 +286,61 @@ def test_dgl_dgcnn_step_at_the_benchmark_part_size_against_float64(cuda_device, 
     finally:
         torch.set_num_threads(threads)
     assert abs(hip_loss - l64) <= 2.0 * abs(l32 - l64) + 1e-4 * abs(l64), (hip_loss, l32, l64)
-    ratios, worst = [], (0.0, "")
+    ratios, worst, worst_o = [], (0.0, ""), 0.0
     for k, b in g64.items():
         scale = float(b.abs().max())
         if scale < 1e-10:  # a bias in front of a BatchNorm: structurally zero
             continue
         eh = float((hip[k] - b).abs().max()) / scale
         eo = float((g32[k] - b).abs().max()) / scale
-        assert eh <= 2.0 * eo + 0.25, (k, eh, eo)
+        assert eh <= 2.0 * eo + slack, (k, eh, eo)
+        assert abs_cap is None or eh <= abs_cap, (k, eh)
         ratios.append(eh / max(eo, 1e-12))
         worst = max(worst, (eh, k))
+        worst_o = max(worst_o, eo)
     med = statistics.median(ratios)
     with capsys.disabled():
-        print(f"\n  DGL + DGCNN at P=20, N=1000, B={B}: loss hip {hip_loss:.6f} / oracle32 {l32:.6f} / float64 {l64:.6f}; "
+        print(f"\n  {label} at P=20, N=1000, B={B}: loss hip {hip_loss:.6f} / oracle32 {l32:.6f} / float64 {l64:.6f}; "
               f"gradient deviation from float64, hip : oracle32, median ratio over {len(ratios)} tensors {med:.2f} "
-              f"(largest hip deviation {worst[0]:.2f} of max: {worst[1]})", end="")
-    assert med <= 1.2, med
+              f"(largest deviation of a tensor: hip {worst[0]:.2e} [{worst[1]}], oracle32 {worst_o:.2e})", end="")
+    assert median_cap is None or med <= median_cap, med
+
+
+def test_dgl_dgcnn_step_at_the_benchmark_part_size_against_float64(cuda_device, capsys):
+    """BASELINE.json configs[2] at its part size (P = 20 slots, N = 1000 points, everyday-like synthetic shapes; B = 4
+    to bound the CPU time): the training-mode forward_pass + backward of DGL + DGCNN on the HIP path, on the float32 CPU
+    oracle (oracle/callers.py) and on the same oracle in float64.
+
+    At this size the step is NOT well conditioned in float32: the loss goes through ~10^5 discrete choices per sample
+    (nearest neighbours of the Chamfer terms, kNN graphs, max-pool / ReLU selections) on random-init predictions, and the
+    float32 oracle's own parameter gradients sit 5-80 % (largest entry, per tensor) from its float64 evaluation.  A
+    bar "hip == oracle32 to 1e-2" would therefore fail for ANY correct float32 implementation; the bar here is that the
+    HIP path is as close to float64 as the float32 restatement of the reference is: the loss within twice the
+    oracle's own deviation, per tensor |hip - f64| <= 2 |o32 - f64| + 0.25, and the median ratio of the two deviations
+    over all tensors <= 1.2 (measured: 0.88 — the HIP path is the closer of the two)."""
+    from oracle import callers as oc
+    cfg = config.dgl_dgcnn_everyday()
+    _against_float64(cuda_device, capsys, cfg, "DGL + DGCNN",
+                     lambda sd, cb: oc.dgl_loss(sd, cb, cfg.model.gnn_iter, cfg.model.encoder, True, {})["loss"])
+
+
+def test_pn_transformer_step_at_the_benchmark_part_size_against_float64(cuda_device, capsys):
+    """BASELINE.json configs[1] — the configuration the headline metric is quoted on (PNTransformer + PointNet, P = 20,
+    N = 1000; B = 4, dropout off so that all three evaluations see the same network).  This step IS well conditioned (no
+    kNN graph, one max-pool): the float32 oracle sits 2e-5 .. 7e-4 from float64 and the bar is absolute — every parameter
+    gradient of the HIP path within 1e-3 of float64 (largest entry of the tensor; measured 1.2e-4 .. 8.1e-4, the largest on
+    `encoder.conv4.weight` where the float32 oracle is at 7.4e-4), and within 2 x the oracle's deviation + 5e-4.  The
+    transformer and pose-head gradients share a ~2e-4 offset that enters with the rotation gradient (the translation head is
+    at 1e-5): the loss is not scale-invariant in the quaternion, the pose head's normalisation projects the large radial part
+    of d loss / d q away, and what is left carries the float32 rounding of the whole at ~10^3 x its own scale (the fused loss
+    backward itself is within 1e-7 of float64 relative to the largest entry; evaluating the projection in double changes
+    nothing)."""
+    from oracle import nets as on
+    cfg = config.pn_transformer_everyday()
+    _against_float64(cuda_device, capsys, cfg, "PNTransformer + PointNet",
+                     lambda sd, cb: on.pn_transformer_loss(sd, cb, cfg.model.transformer_layers,
+                                                           cfg.model.transformer_heads, training=True, stats_out={})[0]["loss"],
+                     no_dropout=True, slack=5e-4, median_cap=None, abs_cap=1e-3)
 
 
 def test_dgl_dgcnn_graph_replay_equals_eager_steps(cuda_device):
