@@ -211,8 +211,10 @@ constexpr size_t agg_fwd_lds(int AT, int N) { return (size_t)N * 32 * sizeof(flo
 
 // Copy a 32-channel column slice (row stride `ld` floats, N rows) between global memory and an LDS panel [N][32] with
 // four independent 16-byte requests in flight per thread (a plain loop exposes one L2 round trip per pass).
+// `gamma` [32] (or NULL): the panel holds sign(gamma) * value per channel (exact).
 template <int AT>
-__device__ __forceinline__ void dg_load_slice(const float* __restrict__ src, int ld, int N, float* __restrict__ dst) {
+__device__ __forceinline__ void dg_load_slice(const float* __restrict__ src, int ld, int N, float* __restrict__ dst,
+                                              const float* __restrict__ gamma = nullptr) {
   for (int e0 = threadIdx.x; e0 < N * 8; e0 += 4 * AT) {
     float4 t[4];
 #pragma unroll
@@ -223,7 +225,14 @@ __device__ __forceinline__ void dg_load_slice(const float* __restrict__ src, int
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = e0 + u * AT;
-      if (e < N * 8) *reinterpret_cast<float4*>(&dst[4 * e]) = t[u];
+      if (e < N * 8) {
+        if (gamma != nullptr) {
+          const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * (e & 7));
+          t[u] = make_float4(gm.x < 0.0f ? -t[u].x : t[u].x, gm.y < 0.0f ? -t[u].y : t[u].y, gm.z < 0.0f ? -t[u].z : t[u].z,
+                             gm.w < 0.0f ? -t[u].w : t[u].w);
+        }
+        *reinterpret_cast<float4*>(&dst[4 * e]) = t[u];
+      }
     }
   }
 }
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(AT) void dg_agg_fwd_kernel(const float* __restrict_
   if (v >= hdr[0]) return;
   const int c0 = sl * 32;
   const float* up = uv + (long long)v * N * 2 * CO;
-  dg_load_slice<AT>(up + c0, 2 * CO, N, Us);
+  dg_load_slice<AT>(up + c0, 2 * CO, N, Us, gamma + c0);  // the panel holds sign(gamma) * U: the maximum of that is tracked
   __syncthreads();
   // lane = (point slot q of 8, channel quad cq of 8): one ds_read_b128 per neighbour feeds four channels, so the index
   // unpacking and address arithmetic are paid once per four channels (the kernel is bound by VALU issue)
@@ -284,18 +293,19 @@ __global__ __launch_bounds__(AT) void dg_agg_fwd_kernel(const float* __restrict_
     for (int t = 0; t < kNbr; ++t) {
       const int j = (wv[t >> 1] >> (16 * (t & 1))) & 0xffff;
       const float4 u4 = *reinterpret_cast<const float4*>(&Us[j * 32 + 4 * cq]);
-      const float u[4] = {u4.x, u4.y, u4.z, u4.w};
+      const float u[4] = {u4.x, u4.y, u4.z, u4.w};  // sign(gamma) * U_j
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float sx = sg[k] * u[k];
-        if (sx > best[k]) {
-          best[k] = sx;
+        if (u[k] > best[k]) {
+          best[k] = u[k];
           at[k] = t;
         }
         su[k] += u[k];
         sq[k] = __builtin_fmaf(u[k], u[k], sq[k]);
       }
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) su[k] *= sg[k];  // (exact) the sum of the unsigned values
     const float vk[4] = {vv.x, vv.y, vv.z, vv.w};
     const long long o = row * CO + c0 + 4 * cq;
     *reinterpret_cast<float4*>(esel + o) = make_float4(sg[0] * best[0] + vk[0], sg[1] * best[1] + vk[1],
