@@ -652,17 +652,14 @@ __global__ void dg_agg_bwd_sums_kernel(const float* __restrict__ hcat, const flo
 // rptr [M][N + 1] (rank -> offset), rlist [R][20] = the in-edges of every point as (source point * 32 + neighbour slot
 // of the target in the source's list), ascending (fixed summation order downstream).  grid = M parts, block 1024; the part's whole list (N * 20 sources,
 // 40 KB) is built and sorted in LDS and written out once, coalesced.
-__global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* __restrict__ idx, int N,
-                                                          int* __restrict__ rptr, int* __restrict__ order,
-                                                          unsigned short* __restrict__ rlist,
-                                                          const int* __restrict__ hdr) {
+// (a device function: the blocks that run it are part of dg_bwd_head_kernel's grid)
+__device__ __forceinline__ void dg_reverse_part(const unsigned short* __restrict__ idx, int N, int* __restrict__ rptr,
+                                                int* __restrict__ order, unsigned short* __restrict__ rlist, int v) {
   __shared__ int cnt[kMaxN];
   __shared__ int beg[kMaxN + 1];
   __shared__ unsigned short lst[kMaxN * kNbr];
   __shared__ int wsum[16];
   __shared__ int carry;
-  const int v = blockIdx.x;
-  if (v >= hdr[0]) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int E = N * kNbr;
   const unsigned short* id = idx + (long long)v * E;
@@ -758,6 +755,60 @@ __global__ __launch_bounds__(1024) void dg_reverse_kernel(const unsigned short* 
     for (int a = 0; a < dg_; ++a) rl[start + a] = lst[src0 + a];
   }
   if (t == N - 1) rp[N] = start + dg_;
+}
+
+// First launch of the EdgeConv backward: the transposed graphs of ALL FOUR stages (they depend on the forward's
+// neighbour lists only) and the BatchNorm-backward sums of the last stage in ONE grid of 1024-thread blocks.  The graph
+// blocks are latency chains in LDS (count, scan, insertion sorts, a 1024-key bitonic sort: ~80 us a block, 0.33 ms as four
+// launches of one block per part), the sums blocks stream 2 GB: together the CUs hold both kinds and the graph build hides
+// behind the stream.  Blocks [0, 4 M): (stage, part) = (b / M, b % M); blocks [4 M, ...): 128-row tiles of the sums.
+struct DgRevArgs {
+  const unsigned short* idx[4];
+  int* rptr[4];
+  int* order[4];
+  unsigned short* rlist[4];
+};
+__global__ __launch_bounds__(1024) void dg_bwd_head_kernel(const DgRevArgs ra, int M, int N, const float* __restrict__ hcat,
+                                                           const float* __restrict__ dhcat, int off, int CO,
+                                                           const float* __restrict__ esel, const float* __restrict__ bn,
+                                                           float* __restrict__ dz, float* __restrict__ partial,
+                                                           const int* __restrict__ hdr) {
+  const int b = (int)blockIdx.x;
+  if (b < 4 * M) {
+    const int st = b / M, v = b % M;
+    if (v >= hdr[0]) return;
+    dg_reverse_part(ra.idx[st], N, ra.rptr[st], ra.order[st], ra.rlist[st], v);
+    return;
+  }
+  // dz = dH * LeakyReLU'(z) and the two sums of dg_agg_bwd_sums_kernel for tile b - 4 M: thread = (row group, channel)
+  __shared__ float red[1024][2];  // [row group][channel]
+  const int R = hdr[1];
+  const long long r0 = (long long)(b - 4 * M) * kTile;
+  if (r0 >= R) return;
+  const int c = threadIdx.x % CO, g = threadIdx.x / CO, G = 1024 / CO;
+  const float mean = bn[2 * CO + c], invstd = bn[3 * CO + c];
+  const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int i = g; i < rows; i += G) {
+    const long long r = r0 + i, o = r * CO + c;
+    const float h = hcat[r * kCat + off + c];
+    const float d = dhcat[r * kCat + off + c] * (h > 0.0f ? 1.0f : kSlope);
+    dz[o] = d;
+    s1 += d;
+    s2 = __builtin_fmaf(d, (esel[o] - mean) * invstd, s2);
+  }
+  red[g * CO + c][0] = s1;
+  red[g * CO + c][1] = s2;
+  __syncthreads();
+  if (g == 0) {  // the row groups in fixed order
+    for (int q = 1; q < G; ++q) {
+      s1 += red[q * CO + c][0];
+      s2 += red[q * CO + c][1];
+    }
+    float* p = partial + ((long long)(b - 4 * M) * CO + c) * 2;
+    p[0] = s1;
+    p[1] = s2;
+  }
 }
 
 // d(uv) [R][2CO] in ONE pass over the transposed graph.  grid = (CO / 16, M), block 512.  LDS panels of a 16-channel
@@ -1002,12 +1053,12 @@ void knn_wide(const float* x, int ld, float* norm, const KnnWs& k, int64_t M, in
 }
 
 struct Ws {
-  int *hdr, *vlist, *rank, *arg5, *rptr, *order;
+  int *hdr, *vlist, *rank, *arg5, *rptr[4], *order[4];
   unsigned* tickets;
   float4* x0;
   float *hcat, *uv[4], *esel[4], *s1[4], *y5, *norm, *bn[5], *coef, *partial, *wstk[4], *wstt[4], *w5t, *pooled,
       *dpooled, *tnpart, *dhcat, *duv, *dz, *gstk;
-  unsigned short *idx[4], *rlist;
+  unsigned short *idx[4], *rlist[4];
   unsigned char* ssel[4];
   double* stage;
   KnnWs knn;
@@ -1058,9 +1109,11 @@ Ws dg_carve(char* base, int64_t M, int64_t N, int64_t F) {
   w.duv = reinterpret_cast<float*>(take(4 * R * 2 * kCO[3]));
   w.dz = reinterpret_cast<float*>(take(4 * R * kCO[3]));
   w.gstk = reinterpret_cast<float*>(take(4 * kCat * 128));
-  w.rptr = reinterpret_cast<int*>(take(4 * M * (N + 1)));
-  w.order = reinterpret_cast<int*>(take(4 * M * N));
-  w.rlist = reinterpret_cast<unsigned short*>(take(2 * R * kNbr));
+  for (int l = 0; l < 4; ++l) {
+    w.rptr[l] = reinterpret_cast<int*>(take(4 * M * (N + 1)));
+    w.order[l] = reinterpret_cast<int*>(take(4 * M * N));
+  }
+  for (int l = 0; l < 4; ++l) w.rlist[l] = reinterpret_cast<unsigned short*>(take(2 * R * kNbr));
   w.stage = reinterpret_cast<double*>(take(8 * 2 * kCat * ((prow + kEB - 1) / kEB)));
   w.knn = knn_carve(take, M, N);
   w.total = p - base;
@@ -1305,15 +1358,25 @@ extern "C" int mpa_dgcnn_backward(const float* grad_feat, const float* const* co
   if (grad_points != nullptr) mpa::zero_words_async(grad_points, M * N * 3, s);
   for (int l = 3; l >= 0; --l) {
     const int CO = kCO[l], C = kCin[l], CP = kCinP[l];
-    launch(dg_agg_bwd_sums_kernel, dim3((unsigned)tiles), dim3((unsigned)CO), s, (const float*)w.hcat,
-           (const float*)w.dhcat, kOff[l], CO, (const float*)w.esel[l], (const float*)w.bn[l], w.dz, w.partial, hdr);
+    if (l == 3) {  // + the transposed graphs of all four stages (dg_bwd_head_kernel)
+      DgRevArgs ra;
+      for (int q = 0; q < 4; ++q) {
+        ra.idx[q] = w.idx[q];
+        ra.rptr[q] = w.rptr[q];
+        ra.order[q] = w.order[q];
+        ra.rlist[q] = w.rlist[q];
+      }
+      launch(dg_bwd_head_kernel, dim3((unsigned)(4 * M + tiles)), dim3(1024), s, ra, (int)M, (int)N, (const float*)w.hcat,
+             (const float*)w.dhcat, kOff[l], CO, (const float*)w.esel[l], (const float*)w.bn[l], w.dz, w.partial, hdr);
+    } else {
+      launch(dg_agg_bwd_sums_kernel, dim3((unsigned)tiles), dim3((unsigned)CO), s, (const float*)w.hcat,
+             (const float*)w.dhcat, kOff[l], CO, (const float*)w.esel[l], (const float*)w.bn[l], w.dz, w.partial, hdr);
+    }
     launch(dg_bwd_coef_kernel, dim3((unsigned)(CO / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
            (const float*)w.partial, (int)tiles, CO, kNbr, bn_w[l], (const float*)w.bn[l], w.coef, grad_bn_w[l],
            grad_bn_b[l], cw, hdr);
-    launch(dg_reverse_kernel, dim3((unsigned)M), dim3(1024), s, (const unsigned short*)w.idx[l], (int)N, w.rptr, w.order,
-           w.rlist, hdr);
-    launch_agg_bwd(dim3((unsigned)(CO / kBS), DG_KNN_GRID_Y(M)), s, (const float*)w.uv[l], CO, (const int*)w.rptr,
-                   (const int*)w.order, (const unsigned short*)w.rlist, (const float*)w.dz,
+    launch_agg_bwd(dim3((unsigned)(CO / kBS), DG_KNN_GRID_Y(M)), s, (const float*)w.uv[l], CO, (const int*)w.rptr[l],
+                   (const int*)w.order[l], (const unsigned short*)w.rlist[l], (const float*)w.dz,
                    (const unsigned char*)w.ssel[l], (const float*)w.s1[l], (const float*)w.coef, (int)N, w.duv, hdr);
     if (l == 0) {
       const int t1 = (int)((R + kFirstTile - 1) / kFirstTile);
