@@ -9,6 +9,11 @@ namespace mpa {
 // extra workspace the grid-pruned whole-shape search needs (floats / int32s)
 int64_t grid_workspace_floats(int64_t B, int64_t P, int64_t N);
 int64_t grid_workspace_ints(int64_t B);
+// inside that scratch: the per-part bounding boxes [B*P][12] (lo of shape 1, lo of shape 2, hi of shape 1, hi of shape 2)
+// and the one-word ticket of the sort launch — both written by the producer of S1 / S2 BEFORE launch_grid_shape_search
+// (boxes of the valid parts; ticket = 0).
+float* grid_bbox(float* fws, int64_t B, int64_t P, int64_t N);
+unsigned* grid_ticket(int32_t* iws, int64_t B);
 
 // Exact NN of every valid point of S1 in S2 and vice versa (whole shapes of each sample, padded parts as
 // one representative).  Writes idx1/idx2 [B,P,N] (index within the sample, -1 if none) and the per-part

@@ -100,9 +100,12 @@ __global__ __launch_bounds__(kThreads) void assembly_pose_kernel(
     const float* __restrict__ pcs, const float* __restrict__ valids, const float* __restrict__ q1,
     const float* __restrict__ t1, const float* __restrict__ q2, const float* __restrict__ t2, int N,
     int fill_pads, float* __restrict__ R1, float* __restrict__ R2, float* __restrict__ S1,
-    float* __restrict__ S2, float* __restrict__ partial) {
+    float* __restrict__ S2, float* __restrict__ partial, float* __restrict__ bbox,
+    unsigned* __restrict__ ticket) {
   __shared__ float red[kThreads / 64];
+  __shared__ float box[kThreads / 64][12];
   const int m = blockIdx.x;
+  if (m == 0 && threadIdx.x == 0 && ticket != nullptr) *ticket = 0u;  // of the grid sorts' "last block" election
   const Quat qa = load_quat(q1 + 4 * m), qb = load_quat(q2 + 4 * m);
   const float ta0 = t1[3 * m], ta1 = t1[3 * m + 1], ta2 = t1[3 * m + 2];
   const float tb0 = t2[3 * m], tb1 = t2[3 * m + 1], tb2 = t2[3 * m + 2];
@@ -122,6 +125,9 @@ __global__ __launch_bounds__(kThreads) void assembly_pose_kernel(
     return;
   }
   float l2 = 0.0f;
+  // bounding boxes of the part in the two shapes (for the grid of the whole-shape search): lo1, lo2, hi1, hi2
+  const float inf = __builtin_inff();
+  float bb[12] = {inf, inf, inf, inf, inf, inf, -inf, -inf, -inf, -inf, -inf, -inf};
   for (int n = threadIdx.x; n < N; n += kThreads) {
     const long long o = base + 3LL * n;
     const float px = pcs[o], py = pcs[o + 1], pz = pcs[o + 2];
@@ -130,13 +136,42 @@ __global__ __launch_bounds__(kThreads) void assembly_pose_kernel(
     quat_apply(qb, px, py, pz, bx, by, bz);
     R1[o] = ax; R1[o + 1] = ay; R1[o + 2] = az;
     R2[o] = bx; R2[o + 1] = by; R2[o + 2] = bz;
-    S1[o] = ax + ta0; S1[o + 1] = ay + ta1; S1[o + 2] = az + ta2;
-    S2[o] = bx + tb0; S2[o + 1] = by + tb1; S2[o + 2] = bz + tb2;
+    const float s1[3] = {ax + ta0, ay + ta1, az + ta2}, s2[3] = {bx + tb0, by + tb1, bz + tb2};
+    S1[o] = s1[0]; S1[o + 1] = s1[1]; S1[o + 2] = s1[2];
+    S2[o] = s2[0]; S2[o + 1] = s2[1]; S2[o + 2] = s2[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      bb[k] = __builtin_fminf(bb[k], s1[k]);
+      bb[3 + k] = __builtin_fminf(bb[3 + k], s2[k]);
+      bb[6 + k] = __builtin_fmaxf(bb[6 + k], s1[k]);
+      bb[9 + k] = __builtin_fmaxf(bb[9 + k], s2[k]);
+    }
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
     l2 += (dx * dx + dy * dy) + dz * dz;
   }
-  const float s = block_sum(l2, red);
+  if (bbox != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(bb[k], off, 64);
+        bb[k] = k < 6 ? __builtin_fminf(bb[k], o) : __builtin_fmaxf(bb[k], o);
+      }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) box[threadIdx.x >> 6][k] = bb[k];
+    }
+  }
+  const float s = block_sum(l2, red);  // (its barrier also publishes `box`)
   if (threadIdx.x == 0) partial[5 * m + 0] = s;
+  if (bbox != nullptr && threadIdx.x < 12) {
+    float v = box[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kThreads / 64; ++w)
+      v = threadIdx.x < 6 ? __builtin_fminf(v, box[w][threadIdx.x]) : __builtin_fmaxf(v, box[w][threadIdx.x]);
+    bbox[12LL * m + threadIdx.x] = v;
+  }
 }
 
 // ---- NN kernels -------------------------------------------------------------------------------------
@@ -571,7 +606,7 @@ extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const floa
   mark(0);
   hipLaunchKernelGGL(assembly_pose_kernel, dim3(parts), dim3(kThreads), 0, s, part_pcs, valids,
                      quat_pred, trans_pred, quat_gt, trans_gt, (int)N, fill_pad_points, w.R1, w.R2,
-                     w.S1, w.S2, w.partial);
+                     w.S1, w.S2, w.partial, mpa::grid_bbox(w.grid_f, B, P, N), mpa::grid_ticket(w.grid_i, B));
   mark(1);
   const dim3 grid(parts * w.tiles, 2, 1);
   // Steering a sample's blocks to one XCD (L2 affinity) loses more to the static load imbalance between

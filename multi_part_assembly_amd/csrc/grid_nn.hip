@@ -4,7 +4,7 @@
 // query only visits the targets that can matter.
 //
 // Per sample (both transformed shapes, <= 20 000 valid points each):
-//   1. grid_params : bounding box of BOTH shapes' valid points -> one uniform grid per sample, <= 32768
+//   1. grid parameters (grid_params_from_boxes, evaluated by every sort block): bounding box of BOTH shapes' valid points -> one uniform grid per sample, <= 32768
 //                    cells (~0.6 points of each shape per cell: finer beats coarser, most of all on clumpy artifact-like shapes), <= 64 cells per axis.  Covering the union
 //                    means no query is ever outside the grid.
 //   2. grid_sort   : counting sort of each shape, one 1024-thread block per (sample, shape) with both histograms
@@ -43,7 +43,7 @@ constexpr int kStartStride = kMaxCells + 8;   // ints per (sample, shape, role) 
 #ifndef MPA_GRID_KS
 #define MPA_GRID_KS 2
 #endif
-#ifndef MPA_GRID_XCD  // 1: XCD-aware, work-proportional wave table (grid_assign_kernel); 0: waves x of pair y
+#ifndef MPA_GRID_XCD  // 1: XCD-aware, work-proportional wave table (grid_assign_plan); 0: waves x of pair y
 #define MPA_GRID_XCD 1
 #endif
 #ifndef MPA_GRID_WAVES
@@ -52,7 +52,7 @@ constexpr int kStartStride = kMaxCells + 8;   // ints per (sample, shape, role) 
 constexpr int kS = MPA_GRID_KS;                         // super-cell edge in fine cells (the query bins of the search): 2 is best
                                               // while predictions are far from the ground truth (a wave's search radius is
                                               // its worst query's), 3 once they are close (0.62 vs 0.74 ms loss forward)
-constexpr int kMaxSuper = 4096;               // super-cells per sample (<= 22^3 would need more: see grid_params)
+constexpr int kMaxSuper = 4096;               // super-cells per sample (<= 22^3 would need more: see grid_params_from_boxes)
 constexpr int kWorkStride = kMaxSuper + 20000 / 64 + 64;  // search work items per slot (<= nsuper + points/batch)
 constexpr int kBatch = 64;                    // queries per search wave (1 per lane)
 #ifndef MPA_GRID_DENSITY
@@ -86,110 +86,123 @@ __device__ __forceinline__ int key_of(const GridParams& g, int role, float x, fl
   return ((iz / kS) * g.sgy + (iy / kS)) * g.sgx + (ix / kS);
 }
 
-// ---- 1. grid parameters: one block per sample, 1024 threads -----------------------------------------------------
-__global__ __launch_bounds__(1024) void grid_params_kernel(const float* __restrict__ valids,
-                                                          const float* __restrict__ S1,
-                                                          const float* __restrict__ S2, int P, int N,
-                                                          GridParams* __restrict__ params) {
-  __shared__ float red[12][1024];
-  const int b = blockIdx.x;
-  const float* vb = valids + (long long)b * P;
-  // per shape c: lo[3c + k], hi[3c + k]
-  float lo[6], hi[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    lo[k] = __builtin_inff();
-    hi[k] = -__builtin_inff();
+// ---- 1. grid parameters ----------------------------------------------------------------------------------------------
+// From the bounding boxes of a sample's two shapes: lo / hi [6] = shape c's box in [3c .. 3c + 2] (valid parts only).
+// The pose kernel of the loss leaves one box per PART (assembly_loss.hip: 12 floats, lo1 lo2 hi1 hi2); every sort block
+// reduces its sample's boxes and evaluates this itself (a separate one-block-per-sample kernel in front of the sorts
+// was 15 us of an almost empty chip).
+__device__ __forceinline__ void grid_params_from_boxes(const float* lo, const float* hi, int nvalid, GridParams& g) {
+  const float ulo[3] = {__builtin_fminf(lo[0], lo[3]), __builtin_fminf(lo[1], lo[4]), __builtin_fminf(lo[2], lo[5])};
+  const float uhi[3] = {__builtin_fmaxf(hi[0], hi[3]), __builtin_fmaxf(hi[1], hi[4]), __builtin_fmaxf(hi[2], hi[5])};
+  float ex = uhi[0] - ulo[0], ey = uhi[1] - ulo[1], ez = uhi[2] - ulo[2];
+  const float emax = __builtin_fmaxf(__builtin_fmaxf(ex, ey), __builtin_fmaxf(ez, 1e-12f));
+  if (!(emax < 1e30f) || nvalid == 0) {  // non-finite coordinates or nothing to index: one cell
+    g.ox = g.oy = g.oz = 0.0f;
+    g.h = 1.0f;
+    g.inv_h = 0.0f;
+    g.gx = g.gy = g.gz = 2;
+  } else {
+    const float floor_e = emax / (float)kMaxAxis;  // flat clouds: no axis thinner than this
+    ex = __builtin_fmaxf(ex, floor_e);
+    ey = __builtin_fmaxf(ey, floor_e);
+    ez = __builtin_fmaxf(ez, floor_e);
+    float want = (float)nvalid / kPointsPerCell;
+    want = want < 8.0f ? 8.0f : (want > (float)kMaxCells ? (float)kMaxCells : want);
+    float h = cbrtf(ex * ey * ez / want);
+    h = __builtin_fmaxf(h, emax / (float)kMaxAxis);
+    for (int it = 0; it < 64; ++it) {
+      g.gx = clampi((int)__builtin_ceilf(ex / h), 1, kMaxAxis);
+      g.gy = clampi((int)__builtin_ceilf(ey / h), 1, kMaxAxis);
+      g.gz = clampi((int)__builtin_ceilf(ez / h), 1, kMaxAxis);
+      const int ns = ((g.gx + kS - 1) / kS) * ((g.gy + kS - 1) / kS) * ((g.gz + kS - 1) / kS);
+      if (g.gx * g.gy * g.gz <= kMaxCells && ns <= kMaxSuper) break;
+      h *= 1.1f;
+    }
+    g.ox = ulo[0];
+    g.oy = ulo[1];
+    g.oz = ulo[2];
+    g.h = h;
+    g.inv_h = 1.0f / h;
   }
-  int nvalid = 0;
-  for (int p = 0; p < P; ++p) {
-    if (vb[p] == 0.0f) continue;
-    nvalid += N;
-    for (int n = threadIdx.x; n < N; n += 1024) {
-      const float* q1 = S1 + 3LL * b * P * N + 3LL * (p * N + n);
-      const float* q2 = S2 + 3LL * b * P * N + 3LL * (p * N + n);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        lo[k] = __builtin_fminf(lo[k], q1[k]);
-        hi[k] = __builtin_fmaxf(hi[k], q1[k]);
-        lo[3 + k] = __builtin_fminf(lo[3 + k], q2[k]);
-        hi[3 + k] = __builtin_fmaxf(hi[3 + k], q2[k]);
-      }
+  g.sgx = (g.gx + kS - 1) / kS;
+  g.sgy = (g.gy + kS - 1) / kS;
+  g.sgz = (g.gz + kS - 1) / kS;
+  g.ncells = g.gx * g.gy * g.gz;
+  g.nsuper = g.sgx * g.sgy * g.sgz;
+  g.nvalid = nvalid;
+  g.pad0 = g.pad1 = 0;
+  g.pad2[0] = g.pad2[1] = g.pad2[2] = g.pad2[3] = 0;
+  for (int c = 0; c < 2; ++c) {  // where each shape's points can be found, in cells (binning is monotone)
+    if (nvalid == 0 || g.inv_h == 0.0f) {
+      g.tb[c][0] = g.tb[c][2] = g.tb[c][4] = 0;
+      g.tb[c][1] = g.gx - 1;
+      g.tb[c][3] = g.gy - 1;
+      g.tb[c][5] = g.gz - 1;
+    } else {
+      cell_of(g, lo[3 * c], lo[3 * c + 1], lo[3 * c + 2], g.tb[c][0], g.tb[c][2], g.tb[c][4]);
+      cell_of(g, hi[3 * c], hi[3 * c + 1], hi[3 * c + 2], g.tb[c][1], g.tb[c][3], g.tb[c][5]);
     }
   }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    red[k][threadIdx.x] = lo[k];
-    red[6 + k][threadIdx.x] = hi[k];
+}
+
+// ---- 2b. waves -> (sample, direction) with XCD locality ---------------------------------------------------------------
+// Workgroups go to the 8 XCDs round-robin (linear id L runs on XCD L % 8) and every XCD has its own L2.  All waves
+// that search one (sample, direction) pair therefore get ids of ONE residue class, so the pair's records are pulled
+// into one L2 instead of eight — but samples differ 10x in size, so the pairs are dealt to the XCDs by descending
+// work (snake order) and every pair gets a share of its XCD's wave slots proportional to its work.
+// The plan (per XCD: its pairs and the prefix of their wave slots) is tiny; every search wave looks its slot up itself.
+constexpr int kMaxPairs = 1024;            // 2 * B (larger batches fall back to the plain mapping)
+constexpr int kPlanCap = kMaxPairs / 8;    // pairs per XCD
+struct XcdPlan {
+  int cnt[8];
+  int lst[8][kPlanCap];
+  int first[8][kPlanCap + 1];
+};
+// one block of 1024 threads: the LAST sort block of the launch (grid_sort_kernel), once every pair's batch count is there
+__device__ __forceinline__ void grid_assign_plan(const GridParams* __restrict__ params, const int* __restrict__ batches,
+                                                 int npairs, int nwaves, XcdPlan* __restrict__ plan) {
+  __shared__ int work[kMaxPairs];
+  __shared__ int lst[8][kPlanCap], cnt[8];
+  const int t = threadIdx.x;
+  for (int p = t; p < npairs; p += 1024) {
+    const int b = p >> 1, dir = p & 1, qslot = (b * 2 + dir) * 2 + 1;
+    work[p] = batches[(long long)qslot * kStartStride + params[b].nsuper];
+  }
+  if (t < 8) cnt[t] = 0;
+  __syncthreads();
+  for (int p = t; p < npairs; p += 1024) {  // rank by descending work (ties: lower pair first), snake over the XCDs
+    int r = 0;
+    for (int q = 0; q < npairs; ++q) r += work[q] > work[p] || (work[q] == work[p] && q < p);
+    const int cyc = r >> 3, pos = r & 7, xcd = (cyc & 1) ? 7 - pos : pos;
+    lst[xcd][cyc] = p;
+    atomicAdd(&cnt[xcd], 1);  // (integer count: order-free)
   }
   __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        red[k][threadIdx.x] = __builtin_fminf(red[k][threadIdx.x], red[k][threadIdx.x + s]);
-        red[6 + k][threadIdx.x] = __builtin_fmaxf(red[6 + k][threadIdx.x], red[6 + k][threadIdx.x + s]);
+  const int per = nwaves / 8;  // wave slots of one XCD
+  if (t < 8) {  // proportional shares, at least one wave for every pair that has work
+    long long rem_work = 0;
+    int busy = 0;
+    for (int i = 0; i < cnt[t]; ++i) {
+      rem_work += work[lst[t][i]];
+      busy += work[lst[t][i]] > 0;
+    }
+    int rem = per, at = 0;
+    plan->cnt[t] = cnt[t];
+    for (int i = 0; i < cnt[t]; ++i) {
+      const int w = work[lst[t][i]];
+      plan->lst[t][i] = lst[t][i];
+      plan->first[t][i] = at;
+      if (w > 0) {
+        int n = (int)(((long long)rem * w + rem_work / 2) / rem_work);
+        const int keep = busy - 1;  // one slot for each pair still to come
+        n = n < 1 ? 1 : (n > rem - keep ? rem - keep : n);
+        at += n;
+        rem -= n;
+        rem_work -= w;
+        --busy;
       }
     }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    GridParams g;
-    // union box of both shapes
-    const float ulo[3] = {__builtin_fminf(red[0][0], red[3][0]), __builtin_fminf(red[1][0], red[4][0]),
-                          __builtin_fminf(red[2][0], red[5][0])};
-    const float uhi[3] = {__builtin_fmaxf(red[6][0], red[9][0]), __builtin_fmaxf(red[7][0], red[10][0]),
-                          __builtin_fmaxf(red[8][0], red[11][0])};
-    float ex = uhi[0] - ulo[0], ey = uhi[1] - ulo[1], ez = uhi[2] - ulo[2];
-    const float emax = __builtin_fmaxf(__builtin_fmaxf(ex, ey), __builtin_fmaxf(ez, 1e-12f));
-    if (!(emax < 1e30f) || nvalid == 0) {  // non-finite coordinates or nothing to index: one cell
-      g.ox = g.oy = g.oz = 0.0f;
-      g.h = 1.0f;
-      g.inv_h = 0.0f;
-      g.gx = g.gy = g.gz = 2;
-    } else {
-      const float floor_e = emax / (float)kMaxAxis;  // flat clouds: no axis thinner than this
-      ex = __builtin_fmaxf(ex, floor_e);
-      ey = __builtin_fmaxf(ey, floor_e);
-      ez = __builtin_fmaxf(ez, floor_e);
-      float want = (float)nvalid / kPointsPerCell;
-      want = want < 8.0f ? 8.0f : (want > (float)kMaxCells ? (float)kMaxCells : want);
-      float h = cbrtf(ex * ey * ez / want);
-      h = __builtin_fmaxf(h, emax / (float)kMaxAxis);
-      for (int it = 0; it < 64; ++it) {
-        g.gx = clampi((int)__builtin_ceilf(ex / h), 1, kMaxAxis);
-        g.gy = clampi((int)__builtin_ceilf(ey / h), 1, kMaxAxis);
-        g.gz = clampi((int)__builtin_ceilf(ez / h), 1, kMaxAxis);
-        const int ns = ((g.gx + kS - 1) / kS) * ((g.gy + kS - 1) / kS) * ((g.gz + kS - 1) / kS);
-        if (g.gx * g.gy * g.gz <= kMaxCells && ns <= kMaxSuper) break;
-        h *= 1.1f;
-      }
-      g.ox = ulo[0];
-      g.oy = ulo[1];
-      g.oz = ulo[2];
-      g.h = h;
-      g.inv_h = 1.0f / h;
-    }
-    g.sgx = (g.gx + kS - 1) / kS;
-    g.sgy = (g.gy + kS - 1) / kS;
-    g.sgz = (g.gz + kS - 1) / kS;
-    g.ncells = g.gx * g.gy * g.gz;
-    g.nsuper = g.sgx * g.sgy * g.sgz;
-    g.nvalid = nvalid;
-    g.pad0 = g.pad1 = 0;
-    g.pad2[0] = g.pad2[1] = g.pad2[2] = g.pad2[3] = 0;
-    for (int c = 0; c < 2; ++c) {  // where each shape's points can be found, in cells (binning is monotone)
-      if (nvalid == 0 || g.inv_h == 0.0f) {
-        g.tb[c][0] = g.tb[c][2] = g.tb[c][4] = 0;
-        g.tb[c][1] = g.gx - 1;
-        g.tb[c][3] = g.gy - 1;
-        g.tb[c][5] = g.gz - 1;
-      } else {
-        cell_of(g, red[3 * c][0], red[3 * c + 1][0], red[3 * c + 2][0], g.tb[c][0], g.tb[c][2], g.tb[c][4]);
-        cell_of(g, red[6 + 3 * c][0], red[6 + 3 * c + 1][0], red[6 + 3 * c + 2][0], g.tb[c][1], g.tb[c][3], g.tb[c][5]);
-      }
-    }
-    params[b] = g;
+    plan->first[t][cnt[t]] = at;
   }
 }
 
@@ -290,23 +303,75 @@ __device__ __forceinline__ void grid_sort_role(const float* __restrict__ vb, con
   }
 }
 
+// bbox [B*P][12]: per part lo1[3], lo2[3], hi1[3], hi2[3] of its points in the two shapes (valid parts; written by the
+// pose kernel of the loss).  ticket: one word, zero at launch (the pose kernel clears it).  plan != NULL: the block that
+// finishes last builds the search's wave plan (grid_assign_plan).
 __global__ __launch_bounds__(1024) void grid_sort_kernel(const float* __restrict__ valids,
                                                          const float* __restrict__ S1,
                                                          const float* __restrict__ S2, int P, int N,
-                                                         const GridParams* __restrict__ params,
+                                                         const float* __restrict__ bbox, GridParams* __restrict__ params,
                                                          int* __restrict__ starts, int* __restrict__ batches,
                                                          int* __restrict__ worklist, float4* __restrict__ records,
-                                                         int rec_stride) {
+                                                         int rec_stride, unsigned* __restrict__ ticket,
+                                                         XcdPlan* __restrict__ plan, int nwaves) {
   __shared__ int cnt[kMaxCells];
   __shared__ int wsum[16][2];
+  __shared__ GridParams gsm;
+  __shared__ bool last;
   const int role = blockIdx.x & 1, c = (blockIdx.x >> 1) & 1, b = blockIdx.x >> 2;
-  const GridParams& g = params[b];  // by reference: uniform address -> scalar loads (a by-value copy indexed with a
-                                    // runtime shape index lands in scratch memory)
-  const int slot = (b * 2 + c) * 2 + role;
   const float* vb = valids + (long long)b * P;
+  // the sample's grid: boxes of its valid parts (one lane per part, P <= 64), then the closed-form parameters
+  if (threadIdx.x < 64) {
+    const int p = threadIdx.x;
+    const bool on = p < P && vb[p] != 0.0f;
+    float lo[6], hi[6];
+    const float* bp = bbox + ((long long)b * P + (p < P ? p : 0)) * 12;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      lo[k] = on ? bp[k] : __builtin_inff();
+      hi[k] = on ? bp[6 + k] : -__builtin_inff();
+    }
+    int nval = on ? N : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        lo[k] = __builtin_fminf(lo[k], __shfl_xor(lo[k], off, 64));
+        hi[k] = __builtin_fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+      }
+      nval += __shfl_xor(nval, off, 64);
+    }
+    if (threadIdx.x == 0) {
+      GridParams gl;
+      grid_params_from_boxes(lo, hi, nval, gl);
+      gsm = gl;
+      if (role == 0 && c == 0) params[b] = gl;  // for the search kernel
+    }
+  }
+  __syncthreads();
+  // a uniform copy in scalar registers (the binning reads half a dozen fields per point)
+  GridParams g;
+  {
+    const int* src = reinterpret_cast<const int*>(&gsm);
+    int* dst = reinterpret_cast<int*>(&g);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(GridParams) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
+  }
+  const int slot = (b * 2 + c) * 2 + role;
   const float* shape = (c == 0 ? S1 : S2) + 3LL * b * P * N;
   if (role == 0) grid_sort_role<0>(vb, shape, P, N, g, slot, starts, batches, worklist, records, rec_stride, cnt, wsum);
   else grid_sort_role<1>(vb, shape, P, N, g, slot, starts, batches, worklist, records, rec_stride, cnt, wsum);
+  if (plan == nullptr) return;
+  // the last block of the launch plans the search's waves: everybody's batch counts are in global memory by then
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  grid_assign_plan(params, batches, (int)(gridDim.x / 2), nwaves, plan);
 }
 
 // ---- 3. search ----------------------------------------------------------------------------------------------------
@@ -529,68 +594,6 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
   }
 }
 
-// ---- 2b. waves -> (sample, direction) with XCD locality ---------------------------------------------------------------
-// Workgroups go to the 8 XCDs round-robin (linear id L runs on XCD L % 8) and every XCD has its own L2.  All waves
-// that search one (sample, direction) pair therefore get ids of ONE residue class, so the pair's records are pulled
-// into one L2 instead of eight — but samples differ 10x in size, so the pairs are dealt to the XCDs by descending
-// work (snake order) and every pair gets a share of its XCD's wave slots proportional to its work.
-// The plan (per XCD: its pairs and the prefix of their wave slots) is tiny; every search wave looks its slot up itself.
-constexpr int kMaxPairs = 1024;            // 2 * B (larger batches fall back to the plain mapping)
-constexpr int kPlanCap = kMaxPairs / 8;    // pairs per XCD
-struct XcdPlan {
-  int cnt[8];
-  int lst[8][kPlanCap];
-  int first[8][kPlanCap + 1];
-};
-// one block of 1024 threads
-__global__ __launch_bounds__(1024) void grid_assign_kernel(const GridParams* __restrict__ params,
-                                                           const int* __restrict__ batches, int npairs, int nwaves,
-                                                           XcdPlan* __restrict__ plan) {
-  __shared__ int work[kMaxPairs];
-  __shared__ int lst[8][kPlanCap], cnt[8];
-  const int t = threadIdx.x;
-  for (int p = t; p < npairs; p += 1024) {
-    const int b = p >> 1, dir = p & 1, qslot = (b * 2 + dir) * 2 + 1;
-    work[p] = batches[(long long)qslot * kStartStride + params[b].nsuper];
-  }
-  if (t < 8) cnt[t] = 0;
-  __syncthreads();
-  for (int p = t; p < npairs; p += 1024) {  // rank by descending work (ties: lower pair first), snake over the XCDs
-    int r = 0;
-    for (int q = 0; q < npairs; ++q) r += work[q] > work[p] || (work[q] == work[p] && q < p);
-    const int cyc = r >> 3, pos = r & 7, xcd = (cyc & 1) ? 7 - pos : pos;
-    lst[xcd][cyc] = p;
-    atomicAdd(&cnt[xcd], 1);  // (integer count: order-free)
-  }
-  __syncthreads();
-  const int per = nwaves / 8;  // wave slots of one XCD
-  if (t < 8) {  // proportional shares, at least one wave for every pair that has work
-    long long rem_work = 0;
-    int busy = 0;
-    for (int i = 0; i < cnt[t]; ++i) {
-      rem_work += work[lst[t][i]];
-      busy += work[lst[t][i]] > 0;
-    }
-    int rem = per, at = 0;
-    plan->cnt[t] = cnt[t];
-    for (int i = 0; i < cnt[t]; ++i) {
-      const int w = work[lst[t][i]];
-      plan->lst[t][i] = lst[t][i];
-      plan->first[t][i] = at;
-      if (w > 0) {
-        int n = (int)(((long long)rem * w + rem_work / 2) / rem_work);
-        const int keep = busy - 1;  // one slot for each pair still to come
-        n = n < 1 ? 1 : (n > rem - keep ? rem - keep : n);
-        at += n;
-        rem -= n;
-        rem_work -= w;
-        --busy;
-      }
-    }
-    plan->first[t][cnt[t]] = at;
-  }
-}
-
 // grid = (768 persistent waves per (sample, dir) on average), block 64.  blockIdx.y = b*2 + dir; dir 0: shape 1 queries
 // against shape 2 targets.
 __global__ __launch_bounds__(64) void grid_search_kernel(
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     int* __restrict__ idx2, const XcdPlan* __restrict__ plan) {
   __shared__ float4 cand[kCand];
   __shared__ int sidx[kCand];  // record index of every position of the current window
-  // block -> (sample, direction, wave): from the XCD-aware plan (grid_assign_kernel) or, without one, waves
+  // block -> (sample, direction, wave): from the XCD-aware plan (grid_assign_plan) or, without one, waves
   // blockIdx.x of pair blockIdx.y
   int pair = (int)blockIdx.y, wid = (int)blockIdx.x, wstride = (int)gridDim.x;
   if (plan != nullptr) {
@@ -805,10 +808,18 @@ __global__ __launch_bounds__(256) void grid_part_sum_kernel(const float* __restr
 
 int64_t grid_workspace_floats(int64_t B, int64_t P, int64_t N) {
   const int64_t rec = (P * N + 8) * 4;  // float4 records (+ sentinels) per slot
-  return 4 * B * rec + B * (int64_t)(sizeof(GridParams) / 4) + 2 * B * P * N;  // + 2 distance arrays
+  return 4 * B * rec + B * (int64_t)(sizeof(GridParams) / 4) + 2 * B * P * N + 12 * B * P;  // + 2 distance arrays + boxes
 }
-int64_t grid_workspace_ints(int64_t B) {  // starts, batches, work list, wave table
-  return 2 * 4 * B * (int64_t)kStartStride + 4 * B * (int64_t)kWorkStride + (int64_t)(sizeof(XcdPlan) / 4);
+int64_t grid_workspace_ints(int64_t B) {  // starts, batches, work list, wave table, ticket
+  return 2 * 4 * B * (int64_t)kStartStride + 4 * B * (int64_t)kWorkStride + (int64_t)(sizeof(XcdPlan) / 4) + 16;
+}
+float* grid_bbox(float* fws, int64_t B, int64_t P, int64_t N) {
+  const int64_t rec = (P * N + 8) * 4;
+  return fws + 4 * B * rec + B * (int64_t)(sizeof(GridParams) / 4) + 2 * B * P * N;
+}
+unsigned* grid_ticket(int32_t* iws, int64_t B) {
+  return reinterpret_cast<unsigned*>(iws + 2 * 4 * B * (int64_t)kStartStride + 4 * B * (int64_t)kWorkStride +
+                                     (int64_t)(sizeof(XcdPlan) / 4));
 }
 
 int launch_grid_shape_search(const float* valids, const float* S1, const float* S2, int64_t B, int64_t P,
@@ -822,16 +833,13 @@ int launch_grid_shape_search(const float* valids, const float* S1, const float* 
   int* starts = iws;
   int* batches = iws + 4 * B * (int64_t)kStartStride;
   int* worklist = batches + 4 * B * (int64_t)kStartStride;
-  hipLaunchKernelGGL(grid_params_kernel, dim3((unsigned)B), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N, params);
-  hipLaunchKernelGGL(grid_sort_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N, params,
-                     starts, batches, worklist, records, rec_stride);
   // persistent waves (768 per (sample, direction) on average) walk a pair's work list of (super-cell, 64-query batch) items
   XcdPlan* plan = reinterpret_cast<XcdPlan*>(worklist + 4 * B * (int64_t)kWorkStride);
   const bool xcd_table = MPA_GRID_XCD && 2 * B >= 8 && 2 * B <= kMaxPairs;
   const int nwaves = (int)(MPA_GRID_WAVES * 2 * B);
-  if (xcd_table)
-    hipLaunchKernelGGL(grid_assign_kernel, dim3(1), dim3(1024), 0, s, (const GridParams*)params, (const int*)batches,
-                       (int)(2 * B), nwaves, plan);
+  hipLaunchKernelGGL(grid_sort_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N,
+                     (const float*)grid_bbox(fws, B, P, N), params, starts, batches, worklist, records, rec_stride,
+                     grid_ticket(iws, B), xcd_table ? plan : (XcdPlan*)nullptr, nwaves);
   if (before_search != nullptr) (void)hipEventRecord(before_search, s);
   if (xcd_table)
     hipLaunchKernelGGL(grid_search_kernel, dim3((unsigned)nwaves), dim3(64), 0, s, valids, S1, S2, (int)P, (int)N, params,
