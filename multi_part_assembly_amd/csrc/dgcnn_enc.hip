@@ -818,6 +818,12 @@ __global__ __launch_bounds__(1024) void dg_bwd_head_kernel(const DgRevArgs ra, i
 // channels whose selected slot at i is t — i.e. whose selected neighbour is j.  No atomics, no second pass:
 //   dU_j = gammap (deg_j U_j + sum V_i) + deg_j betap + sum_sel W_i,   dV_j = W_j + gammap (S1_j + k V_j) + k betap
 // with every sum taken in ascending source order (bit-reproducible).
+#ifdef MPA_AGG_STATS  // instrumented build for tools/probe_agg_stats.py only (never in libmpa_hip.so)
+__device__ unsigned long long g_agg_stats[8];  // blocks, ticks: panel load, passes (sum over waves / waves), total; wave passes, loop iterations
+#define AGG_TICK() __builtin_readcyclecounter()
+#else
+#define AGG_TICK() 0ull
+#endif
 constexpr int kBS = 16;          // channels per slice
 constexpr int kRun = 512;        // scratch entries per wave (16 points x ~20 in-edges, with room for hubs)
 // LDS of a block of AT threads for parts of N points (dynamic: the 16-wave variant needs all 160 KB at N = 1000)
@@ -846,6 +852,7 @@ __global__ __launch_bounds__(AT) void dg_agg_bwd_kernel(const float* __restrict_
   int v, sl;
   dg::knn_block(v, sl);
   if (v >= hdr[0]) return;
+  const unsigned long long tk0 = AGG_TICK();
   const int c0 = sl * kBS;
   const float* up = uv + (long long)v * N * 2 * CO;
   float* gp = guv + (long long)v * N * 2 * CO;
@@ -879,6 +886,8 @@ __global__ __launch_bounds__(AT) void dg_agg_bwd_kernel(const float* __restrict_
   }
   for (int e = threadIdx.x; e <= N; e += AT) rps[e] = (unsigned short)rptr[(long long)v * (N + 1) + e];
   __syncthreads();
+  const unsigned long long tk1 = AGG_TICK();
+  unsigned long long n_pass = 0, n_iter = 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cq = lane & 3, q = lane >> 2;
   const float4 gammap = *reinterpret_cast<const float4*>(coef + CO + c0 + 4 * cq);
   const float4 betap = *reinterpret_cast<const float4*>(coef + 2 * CO + c0 + 4 * cq);
@@ -967,6 +976,10 @@ __global__ __launch_bounds__(AT) void dg_agg_bwd_kernel(const float* __restrict_
     };
     if (__builtin_expect(hub, 0)) scan(std::true_type{});
     else scan(std::false_type{});
+#ifdef MPA_AGG_STATS
+    ++n_pass;
+    n_iter += (kmax + 3) / 4;
+#endif
     __builtin_amdgcn_wave_barrier();
     if (rk < N) {
       const float deg = (float)(e - b), kf = (float)kNbr;
@@ -985,6 +998,22 @@ __global__ __launch_bounds__(AT) void dg_agg_bwd_kernel(const float* __restrict_
       *reinterpret_cast<float4*>(gp + (long long)j * 2 * CO + CO + c0 + 4 * cq) = dv;
     }
   }
+#ifdef MPA_AGG_STATS
+  {
+    const unsigned long long tk2 = AGG_TICK();
+    if (lane == 0) {
+      atomicAdd(&g_agg_stats[2], tk2 - tk1);  // per wave: time in the passes
+      atomicAdd(&g_agg_stats[4], n_pass);
+      atomicAdd(&g_agg_stats[5], n_iter);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&g_agg_stats[0], 1ull);
+      atomicAdd(&g_agg_stats[1], tk1 - tk0);
+      atomicAdd(&g_agg_stats[3], AGG_TICK() - tk0);
+    }
+  }
+#endif
 }
 
 // ---- workspace ----------------------------------------------------------------------------------------------------------------
@@ -1455,3 +1484,14 @@ extern "C" int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, i
   }
   return mpa::check_launch("knn_exact");
 }
+
+#ifdef MPA_AGG_STATS
+extern "C" int mpa_debug_agg_stats(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_agg_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_agg_stats), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
