@@ -28,6 +28,7 @@ import torch.nn as nn
 from .base_model import BaseModel
 from .encoder import build_encoder
 from .gru import gru_recurrent, supported as gru_supported
+from .loss import LossTerms
 from .mlp import mlp_layer, supported as mlp_supported
 from .regressor import StocasticPoseRegressor
 
@@ -245,15 +246,30 @@ class DGLModel(BaseModel):
             loss_dict, out = self._calc_loss(pred, data_dict)
             out.update(keep)
             return loss_dict, out
-        total, out = None, {}
+        per_iter, out = [], {}
         for i in range(self.iter):
             loss_dict, out = self._calc_loss({"rot": pred["rot"][i], "trans": pred["trans"][i]}, data_dict)
-            if total is None:
-                total = {k: 0.0 for k in loss_dict}
+            per_iter.append(loss_dict)
+        out.update(keep)
+        names = list(per_iter[0])
+        stacks = [getattr(d, "stacked", None) for d in per_iter]
+        if all(st is not None and list(st[0]) == names for st in stacks):
+            # the fused loss hands every iteration's terms over as ONE [K, B] tensor: sum those (iter - 1 launches), and
+            # let `loss_function` weight the [K (iter + 1), B] concatenation directly — summing and re-stacking the
+            # terms one by one was ~100 small launches per step, forward and backward
+            summed = stacks[0][1]
+            for st in stacks[1:]:
+                summed = summed + st[1]
+            full = torch.cat([summed] + [st[1] for st in stacks], dim=0)
+            keys = names + [f"{k}_{i}" for i in range(self.iter) for k in names]
+            total = LossTerms((k, full[j]) for j, k in enumerate(keys))
+            total.stacked = (tuple(keys), full)
+            return total, out
+        total = {k: 0.0 for k in names}
+        for i, loss_dict in enumerate(per_iter):
             for k, v in loss_dict.items():
                 total[k] = total[k] + v
                 total[f"{k}_{i}"] = v
-        out.update(keep)
         return total, out
 
 
