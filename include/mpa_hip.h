@@ -25,7 +25,7 @@ extern "C" {
 #define MPA_ELAUNCH (-2) /* hipGetLastError() reported a launch failure */
 
 /* ABI version of this header; bumped whenever a signature changes. */
-#define MPA_ABI_VERSION 4
+#define MPA_ABI_VERSION 5
 int mpa_abi_version(void);
 
 /* Thread-local, NUL-terminated description of the last failure on this thread ("" if none). */
@@ -290,6 +290,43 @@ int mpa_mlp_layer_backward(const float* grad_out, const float* x, int64_t ldx, c
                            float* grad_w, float* grad_b, float* grad_gamma, float* grad_beta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The small per-iteration pieces of the graph networks between the MLP layers — replace the library element-wise /
+ * reduction / 1-column GEMM launches behind
+ *   PoseEncoder.mlp1 + ReLU (7 -> 256)                  : multi_part_assembly/models/dgl/modules.py:76-86
+ *   RelationNet.mlp3 + sigmoid, times the valid matrix  : models/dgl/modules.py:61-73, models/dgl/network.py:121-133
+ *   the relation-weighted mean of the edge features     : models/dgl/network.py:135-152
+ *   the [part i ; part j] pair rows fed to the edge MLP / relation net : models/dgl/network.py:121-125, 135-141
+ * narrow_linear_relu: out [R, N] = relu(x [R, K] w[N, K]^T + bias), K <= 16; backward takes the forward's `out` (ReLU
+ *   mask) and overwrites grad_x [R, K] (if non-NULL), grad_w [N, K], grad_b [N] (if non-NULL).
+ * relation_head: out [R] = sigmoid(h [R, K] . w [K] + bias[0]) * mask [R] (mask NULL = ones), K a multiple of 4; `ws`
+ *   (mpa_relation_head_workspace floats) carries the sigmoids to backward, which overwrites grad_h [R, K] (if non-NULL),
+ *   grad_w [K], grad_b [1] (if non-NULL).
+ * relation_mean: out [G, C] = sum_j edge [G, P, C] rel [G, P] / (sum_j rel [G, P] + 1e-6), P <= 64; backward overwrites
+ *   grad_edge [G, P, C] and grad_rel [G, P] (each if non-NULL).
+ * pair_rows: out [S, P, P, 2F] = [a [S, P, F] of part i ; b [S, P, F] of part j] for every pair (i, j) (swap != 0: [b of
+ *   part j ; a of part i]) — the input rows of the edge MLP and the relation net; F a multiple of 4; backward overwrites
+ *   grad_a = sum over j of a's F columns and grad_b = sum over i of b's (each if non-NULL).
+ * Fixed-order reductions, no atomics: deterministic.
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_pair_rows_forward(const float* a, const float* b, int64_t S, int64_t P, int64_t F, int swap, float* out,
+                          void* stream);
+int mpa_pair_rows_backward(const float* grad_out, int64_t S, int64_t P, int64_t F, int swap, float* grad_a, float* grad_b,
+                           void* stream);
+int mpa_narrow_linear_relu_forward(const float* x, const float* w, const float* bias, int64_t R, int64_t K, int64_t N,
+                                   float* out, void* stream);
+int mpa_narrow_linear_relu_backward(const float* grad_out, const float* out, const float* x, const float* w, int64_t R,
+                                    int64_t K, int64_t N, float* grad_x, float* grad_w, float* grad_b, void* stream);
+int mpa_relation_head_workspace(int64_t R, int64_t K, int64_t* float_elems);
+int mpa_relation_head_forward(const float* h, const float* w, const float* bias, const float* mask, int64_t R, int64_t K,
+                              float* ws, float* out, void* stream);
+int mpa_relation_head_backward(const float* grad_out, const float* h, const float* w, const float* mask, int64_t R,
+                               int64_t K, float* ws, float* grad_h, float* grad_w, float* grad_b, void* stream);
+int mpa_relation_mean_forward(const float* edge, const float* rel, int64_t G, int64_t P, int64_t C, float* out,
+                              void* stream);
+int mpa_relation_mean_backward(const float* grad_out, const float* edge, const float* rel, const float* out, int64_t G,
+                               int64_t P, int64_t C, float* grad_edge, float* grad_rel, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Recurrent half of a single-layer (bi)directional GRU — replaces the per-step library launches behind
  *   RNNWrapper(nn.GRU(batch_first, bidirectional)) : multi_part_assembly/models/modules/rnn.py:6-46
  *   RGLNet.forward                                 : multi_part_assembly/models/rgl_net/network.py:118-127
@@ -346,11 +383,12 @@ int mpa_transformer_backward(const float* grad_out, const float* valid, const fl
  *   PoseRegressor.forward : multi_part_assembly/models/modules/regressor.py:50-68
  *   (Linear F-256, LeakyReLU 0.2, Linear 256-128, LeakyReLU 0.2, rot_head 128-4 + F.normalize,
  *    trans_head 128-3; regressor.py:33-48)
- * x [M,F] (F multiple of 64; M = B*P tokens).  params: HOST array of 8 DEVICE pointers — fc_layers.0.weight
+ * x [M,F] (1 <= F <= 4096: widths that are not a multiple of 64 — labels / noise appended to the features — are
+ * zero-padded inside the workspace; M = B*P tokens).  params: HOST array of 8 DEVICE pointers — fc_layers.0.weight
  * [256,F], .bias, fc_layers.2.weight [128,256], .bias, rot_head.weight [4,128], .bias, trans_head.weight
  * [3,128], .bias.  rot [M,4] unit quaternions (x / max(|x|, 1e-12)), trans [M,3].
  * ws (mpa_pose_head_workspace floats) carries activations to backward, which overwrites grad_x [M,F] and
- * the 8 grad_params buffers.
+ * the 8 grad_params buffers (fc_layers.0.weight must be unchanged between the two calls).
  * ---------------------------------------------------------------------------------------------- */
 int mpa_pose_head_workspace(int64_t M, int64_t F, int64_t* float_elems);
 int mpa_pose_head_forward(const float* x, const float* const* params, int64_t M, int64_t F, float* ws,

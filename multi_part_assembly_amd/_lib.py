@@ -59,6 +59,15 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_mlp_layer_workspace": (_INT, [_I64, _I64, _I64, _P]),
     "mpa_mlp_layer_forward": (_INT, [_P, _I64, _P, _P, _P, _P, _P, _P, _INT, _F32, _F32, _INT, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_mlp_layer_backward": (_INT, [_P, _P, _I64, _P, _P, _P, _INT, _I64, _I64, _I64] + [_P] * 7),
+    "mpa_pair_rows_forward": (_INT, [_P, _P, _I64, _I64, _I64, _INT, _P, _P]),
+    "mpa_pair_rows_backward": (_INT, [_P, _I64, _I64, _I64, _INT, _P, _P, _P]),
+    "mpa_narrow_linear_relu_forward": (_INT, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
+    "mpa_narrow_linear_relu_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "mpa_relation_head_workspace": (_INT, [_I64, _I64, _P]),
+    "mpa_relation_head_forward": (_INT, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
+    "mpa_relation_head_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
+    "mpa_relation_mean_forward": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P]),
+    "mpa_relation_mean_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_gru_workspace": (_INT, [_I64, _I64, _I64, _I64, _P]),
     "mpa_gru_resident": (_INT, [_I64, _I64, _I64, _P]),
     "mpa_gru_forward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P]),
@@ -75,7 +84,7 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_grad_clip_coef": (_INT, [_P, _I64, _F32, _P, _F32, _P, _P, _P]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

@@ -1003,22 +1003,71 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
 // ---- pose head -------------------------------------------------------------------------------------------------------------------
 // params: fc1.w [256,F], fc1.b, fc2.w [128,256], fc2.b, rot.w [4,128], rot.b, trans.w [3,128], trans.b
 // ws: h1 [M,256] | h2 [M,128] | rot_raw [M,4] | dqt [M,8] | d2 [M,128] | d1 [M,256]
+//     and, when F is not a multiple of the GEMM panels' 64 columns (labels / noise appended to the features), zero-padded
+//     copies of x and fc1.w and the padded gradients of both: x' [M,F'] | w' [256,F'] | dx' [M,F'] | dw' [256,F']
+struct HeadPad {
+  int64_t Fp;  // F rounded up to a multiple of 64
+  float *x, *w, *dx, *dw;
+};
+
+static HeadPad head_pad(float* ws, int64_t M, int64_t F) {
+  HeadPad h;
+  h.Fp = (F + 63) / 64 * 64;
+  h.x = ws + M * (256 + 128 + 4 + 8 + 128 + 256) + 64;
+  h.w = h.x + M * h.Fp;
+  h.dx = h.w + 256 * h.Fp;
+  h.dw = h.dx + M * h.Fp;
+  return h;
+}
+
+// two row-major tables in one launch: dst [rows][ldd] = src [rows][lds] in the first min(lds, ldd) columns, zero beyond
+// (ldd > lds pads, ldd < lds drops the padding columns).  blocks [0, nb0) work on table 0, the rest on table 1.
+struct Pad2 {
+  const float* src[2];
+  float* dst[2];
+  int rows[2];
+};
+__global__ __launch_bounds__(256) void head_pad2_kernel(Pad2 a, int lds, int ldd, int nb0) {
+  const int t = (int)blockIdx.x < nb0 ? 0 : 1;
+  const long long i = ((long long)blockIdx.x - (t ? nb0 : 0)) * 256 + threadIdx.x;
+  if (i >= (long long)a.rows[t] * ldd) return;
+  const long long r = i / ldd;
+  const int c = (int)(i - r * ldd);
+  a.dst[t][i] = c < lds ? a.src[t][r * lds + c] : 0.0f;
+}
+
+static void launch_pad2(const float* s0, float* d0, int64_t rows0, const float* s1, float* d1, int64_t rows1, int64_t lds,
+                        int64_t ldd, hipStream_t s) {
+  Pad2 a;
+  a.src[0] = s0, a.dst[0] = d0, a.rows[0] = (int)rows0;
+  a.src[1] = s1, a.dst[1] = d1, a.rows[1] = (int)rows1;
+  const int nb0 = (int)((rows0 * ldd + 255) / 256), nb1 = (int)((rows1 * ldd + 255) / 256);
+  hipLaunchKernelGGL(head_pad2_kernel, dim3((unsigned)(nb0 + nb1)), dim3(256), 0, s, a, (int)lds, (int)ldd, nb0);
+}
+
 extern "C" int mpa_pose_head_workspace(int64_t M, int64_t F, int64_t* float_elems) {
-  MPA_REQUIRE(M >= 0 && F >= 64 && F % 64 == 0 && float_elems, "pose_head_workspace: need F multiple of 64");
+  MPA_REQUIRE(M >= 0 && F >= 1 && F <= 4096 && float_elems, "pose_head_workspace: need 1 <= F <= 4096");
   *float_elems = M * (256 + 128 + 4 + 8 + 128 + 256) + 64;
+  if (F % 64 != 0) *float_elems += 2 * (M + 256) * ((F + 63) / 64 * 64);
   return MPA_OK;
 }
 
 extern "C" int mpa_pose_head_forward(const float* x, const float* const* params, int64_t M, int64_t F, float* ws,
                                      float* rot, float* trans, void* stream) {
-  MPA_REQUIRE(M >= 0 && F >= 64 && F % 64 == 0, "pose_head_forward: need F multiple of 64");
+  MPA_REQUIRE(M >= 0 && F >= 1 && F <= 4096, "pose_head_forward: need 1 <= F <= 4096");
   if (M == 0) return MPA_OK;
   MPA_REQUIRE(x && params && ws && rot && trans, "pose_head_forward: null pointer");
   hipStream_t s = mpa::as_stream(stream);
   float* h1 = ws;
   float* h2 = h1 + M * 256;
   float* rot_raw = h2 + M * 128;
-  launch_gemm<EPI_LEAKY>(gemm_args(x, params[0], params[1], h1, (int)M, 256, (int)F), s);
+  const float* w1 = params[0];
+  if (F % 64 != 0) {
+    const HeadPad hp = head_pad(ws, M, F);
+    launch_pad2(x, hp.x, M, w1, hp.w, 256, F, hp.Fp, s);
+    x = hp.x, w1 = hp.w, F = hp.Fp;
+  }
+  launch_gemm<EPI_LEAKY>(gemm_args(x, w1, params[1], h1, (int)M, 256, (int)F), s);
   launch_gemm<EPI_LEAKY>(gemm_args(h1, params[2], params[3], h2, (int)M, 128, 256), s);
   hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(kT), 0, s, h2, params[4], params[5],
                      params[6], params[7], (int)M, 128, rot_raw, rot, trans);
@@ -1028,7 +1077,7 @@ extern "C" int mpa_pose_head_forward(const float* x, const float* const* params,
 extern "C" int mpa_pose_head_backward(const float* grad_rot, const float* grad_trans, const float* x,
                                       const float* const* params, int64_t M, int64_t F, float* ws, float* grad_x,
                                       float* const* grad_params, void* stream) {
-  MPA_REQUIRE(M >= 0 && F >= 64 && F % 64 == 0, "pose_head_backward: need F multiple of 64");
+  MPA_REQUIRE(M >= 0 && F >= 1 && F <= 4096, "pose_head_backward: need 1 <= F <= 4096");
   if (M == 0) return MPA_OK;
   MPA_REQUIRE(grad_rot && grad_trans && x && params && ws && grad_x && grad_params, "pose_head_backward: null pointer");
   hipStream_t s = mpa::as_stream(stream);
@@ -1039,6 +1088,13 @@ extern "C" int mpa_pose_head_backward(const float* grad_rot, const float* grad_t
   float* d2 = dqt + M * 8;
   float* d1 = d2 + M * 128;
   const int Mi = (int)M;
+  const bool padded = F % 64 != 0;
+  const HeadPad hp = head_pad(ws, M, F);  // (the forward call left x' and w' there; fc1.w has not changed since)
+  const float* w1 = padded ? hp.w : params[0];
+  const float* xin = padded ? hp.x : x;
+  float* gx = padded ? hp.dx : grad_x;
+  float* gw1 = padded ? hp.dw : grad_params[0];
+  const int Fi = (int)(padded ? hp.Fp : F);
   hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(kT), 0, s, rot_raw, grad_rot, grad_trans,
                      params[4], params[6], h2, Mi, 128, dqt, d2);  // d2 = gradient at fc2's pre-activation
   hipLaunchKernelGGL(head_wgrad_kernel, dim3(2), dim3(1024), 0, s, dqt, h2, Mi, 128, grad_params[4], grad_params[5],
@@ -1046,9 +1102,10 @@ extern "C" int mpa_pose_head_backward(const float* grad_rot, const float* grad_t
   GemmArgs ga = gemm_args(d2, params[2], nullptr, d1, Mi, 256, 128);  // fc2.weight is [128, 256] = [K, N]
   ga.resid = h1;
   launch_gemm<EPI_LEAKY_MASK, true>(ga, s);
-  launch_gemm<EPI_NONE, true>(gemm_args(d1, params[0], nullptr, grad_x, Mi, (int)F, 256), s);
+  launch_gemm<EPI_NONE, true>(gemm_args(d1, w1, nullptr, gx, Mi, Fi, 256), s);
   const WgradArgs wl[2] = {wgrad_args(d2, h1, grad_params[2], grad_params[3], Mi, 128, 256),
-                           wgrad_args(d1, x, grad_params[0], grad_params[1], Mi, 256, (int)F)};
+                           wgrad_args(d1, xin, gw1, grad_params[1], Mi, 256, Fi)};
   launch_wgrad_group(wl, 2, s);  // both weight gradients in one launch, off the path to grad_x
+  if (padded) launch_pad2(gx, grad_x, M, gw1, grad_params[0], 256, hp.Fp, F, s);  // drop the padding columns
   return mpa::check_launch("pose_head_backward");
 }

@@ -8,9 +8,9 @@ What runs where: the part encoder (PointNet: csrc/pointnet.hip, DGCNN: csrc/dgcn
 the `gnn_iter` stacked predictions (fused assembly loss: csrc/assembly_loss.hip, grid_nn.hip), the optimiser, and the
 bulk of the graph network — the P x P edge MLPs, the node MLPs and the wide layers of the relation nets (Conv1d /
 Linear + BatchNorm1d + ReLU layers: csrc/mlp.hip, exact-fp32 MFMA), the recurrence of RGL-NET's bidirectional GRU
-(csrc/gru.hip: all steps of both directions in one launch) and the pose heads — are the HIP hot path; the small rest
-(7-wide pose encoder, 512 -> 1 relation head, relation-weighted mean, the GRU's input projection) stays on PyTorch-ROCm
-library ops.
+(csrc/gru.hip: all steps of both directions in one launch) and the pose heads — are the HIP hot path, as are the small pieces between them (the 7-wide
+first layer of the pose encoder, the 512 -> 1 relation head with its sigmoid and mask, the relation-weighted mean:
+csrc/gnn_glue.hip); the GRU's input projection and the concatenations stay on PyTorch-ROCm library ops.
 
 Differences from the reference, none of them numerical beyond fp32 re-association:
   * part features are extracted with the mask-in / zeros-out PointNet entry (no boolean-mask sync);
@@ -27,6 +27,8 @@ import torch.nn as nn
 
 from .base_model import BaseModel
 from .encoder import build_encoder
+from .gnn_ops import (NARROW_MAX_IN, RELATION_MEAN_MAX_PARTS, narrow_linear_relu, pair_rows, pair_rows_supported,
+                      relation_head, relation_head_supported, relation_mean)
 from .gru import gru_recurrent, supported as gru_supported
 from .loss import LossTerms
 from .mlp import mlp_layer, supported as mlp_supported
@@ -82,7 +84,10 @@ class _PairMLP(nn.Module):
         """Rows = (sample, part i), positions = part j, input [a_i ; b_j]: a, b [B, P, F] -> [B*P, P, F_out]."""
         B, P, F = a.shape
         if self._hip_ok(a, 2 * F, B * P * P):
-            pair = torch.cat([a[:, :, None, :].expand(B, P, P, F), b[:, None, :, :].expand(B, P, P, F)], dim=-1)
+            if pair_rows_supported(F):
+                pair = pair_rows(a, b)  # one launch; its backward sums the two halves over j / over i in one more
+            else:
+                pair = torch.cat([a[:, :, None, :].expand(B, P, P, F), b[:, None, :, :].expand(B, P, P, F)], dim=-1)
             return self._rows(pair.reshape(B * P * P, 2 * F)).view(B * P, P, -1)
         # library ops: the first conv applied to the two halves separately, the pair tensor is never materialised
         w = self.conv1.weight[:, :, 0]                         # [512, 2F]
@@ -101,15 +106,18 @@ class RelationNet(nn.Module):
         self.mlp2 = nn.Linear(256, 512)
         self.mlp3 = nn.Linear(512, 1)
 
-    def forward(self, x):
-        """x [B, P*P, 256] -> [B, P*P, 1]; the two wide layers on csrc/mlp.hip, the 512 -> 1 head on library ops."""
+    def forward(self, x, mask=None):
+        """x [B, P*P, 256] -> [B, P*P, 1] (times `mask` [B, P*P], if given); the two wide layers on csrc/mlp.hip, the
+        512 -> 1 head with its sigmoid and the mask in one launch of csrc/gnn_glue.hip."""
         if (x.is_cuda and x.numel() // x.shape[-1] >= _PairMLP.MIN_ROWS and mlp_supported(x.shape[-1], 256)
-                and mlp_supported(256, 512)):
+                and mlp_supported(256, 512) and relation_head_supported(512)):
             lead = x.shape[:-1]
             h = mlp_layer(x.reshape(-1, x.shape[-1]), self.mlp1.weight, self.mlp1.bias, None, relu=True)
             h = mlp_layer(h, self.mlp2.weight, self.mlp2.bias, None, relu=True)
-            return torch.sigmoid(self.mlp3(h)).view(*lead, 1)
-        return torch.sigmoid(self.mlp3(torch.relu(self.mlp2(torch.relu(self.mlp1(x))))))
+            m = None if mask is None else mask.reshape(-1)
+            return relation_head(h, self.mlp3.weight, self.mlp3.bias, m).view(*lead, 1)
+        out = torch.sigmoid(self.mlp3(torch.relu(self.mlp2(torch.relu(self.mlp1(x))))))
+        return out if mask is None else out * mask.reshape(*out.shape)
 
 
 class PoseEncoder(nn.Module):
@@ -121,6 +129,11 @@ class PoseEncoder(nn.Module):
         self.mlp2 = nn.Linear(256, 128)
 
     def forward(self, x):
+        if x.is_cuda and x.shape[-1] <= NARROW_MAX_IN and mlp_supported(256, 128):
+            # the 7-wide layer in one launch of csrc/gnn_glue.hip, the 256 -> 128 layer on csrc/mlp.hip
+            h = narrow_linear_relu(x, self.mlp1.weight, self.mlp1.bias)
+            lead = h.shape[:-1]
+            return mlp_layer(h.reshape(-1, 256), self.mlp2.weight, self.mlp2.bias, None, relu=True).view(*lead, 128)
         return torch.relu(self.mlp2(torch.relu(self.mlp1(x))))
 
 
@@ -184,17 +197,24 @@ class DGLModel(BaseModel):
                     pose_out[b, idx] = pose_feats[b, idx].max(dim=-2, keepdim=True)[0]
         return part_out, pose_out
 
-    def _update_relation(self, pose_feats, iter_ind):
-        """relation[b, i, j] = net([pose_j ; pose_i]) (dgl/network.py:121-133)."""
+    def _update_relation(self, pose_feats, iter_ind, mask=None):
+        """relation[b, i, j] = net([pose_j ; pose_i]) (dgl/network.py:121-133), times `mask` [B, P, P] if given (the
+        valid matrix the caller multiplies by, dgl/network.py:213)."""
         B, P, C = pose_feats.shape
-        pair = torch.cat([pose_feats[:, None].expand(B, P, P, C), pose_feats[:, :, None].expand(B, P, P, C)], dim=-1)
+        if pose_feats.is_cuda and pair_rows_supported(C):  # row (i, j) = [pose_j ; pose_i]
+            pair = pair_rows(pose_feats, pose_feats, swap=True)
+        else:
+            pair = torch.cat([pose_feats[:, None].expand(B, P, P, C), pose_feats[:, :, None].expand(B, P, P, C)], dim=-1)
         net = self.relation_predictor if (self.merge_node and iter_ind % 2 == 1) else self.relation_predictor_dense
-        return net(pair.reshape(B, P * P, 2 * C)).view(B, P, P)
+        m = None if mask is None else mask.reshape(B, P * P)
+        return net(pair.reshape(B, P * P, 2 * C), m).view(B, P, P)
 
     def _message_passing(self, part_feats, relation, iter_ind):
         """Relation-weighted mean of the edge features (dgl/network.py:135-152)."""
         B, P, _ = part_feats.shape
         edge = self.edge_mlps[iter_ind].forward_pairs(part_feats, part_feats).view(B, P, P, -1)
+        if edge.is_cuda and P <= RELATION_MEAN_MAX_PARTS:
+            return relation_mean(edge, relation.expand(B, P, P))  # one launch of csrc/gnn_glue.hip
         msg = (edge * relation[..., None]).sum(dim=2)
         return msg / (relation.sum(dim=-1, keepdim=True) + 1e-6)
 
@@ -221,7 +241,7 @@ class DGLModel(BaseModel):
                 feats_in = part_feats
                 if self.merge_node and self.semantic and it % 2 == 1:
                     feats_in, pose_feats = self._merge_nodes(part_feats, pose_feats, class_list)
-                relation = self._update_relation(pose_feats, it) * valid_matrix
+                relation = self._update_relation(pose_feats, it, valid_matrix)
             messages = self._message_passing(feats_in, relation, it)
             part_feats = self._node_update(part_feats, messages.type_as(part_feats), data_dict, it)
             rot, trans = self.pose_predictors[it](torch.cat([part_feats, part_label, instance_label, pred_pose], dim=-1))
@@ -232,7 +252,12 @@ class DGLModel(BaseModel):
             rot, trans = self._wrap_rotation(torch.stack(rots, dim=0)), torch.stack(transs, dim=0)
         else:
             rot, trans = self._wrap_rotation(rots[-1]), transs[-1]
-        return {"rot": rot, "trans": trans, "part_feats": local_feats, "class_list": class_list}
+        out = {"rot": rot, "trans": trans, "part_feats": local_feats, "class_list": class_list}
+        if self.training:
+            # the per-iteration predictions as they were produced: the loss reads these, so that autograd does not
+            # scatter each iteration's gradient into a zero-filled stack and add the stacks up again
+            out["_iters"] = [(self._wrap_rotation(r), t) for r, t in zip(rots, transs)]
+        return out
 
     def _loss_function(self, data_dict, out_dict={}, optimizer_idx=-1):
         """Loss of every iteration's prediction, summed (dgl/network.py:245-297); `part_feats` / `class_list` are
@@ -247,8 +272,9 @@ class DGLModel(BaseModel):
             out.update(keep)
             return loss_dict, out
         per_iter, out = [], {}
-        for i in range(self.iter):
-            loss_dict, out = self._calc_loss({"rot": pred["rot"][i], "trans": pred["trans"][i]}, data_dict)
+        iters = pred.get("_iters") or [(pred["rot"][i], pred["trans"][i]) for i in range(self.iter)]
+        for rot, trans in iters:
+            loss_dict, out = self._calc_loss({"rot": rot, "trans": trans}, data_dict)
             per_iter.append(loss_dict)
         out.update(keep)
         names = list(per_iter[0])

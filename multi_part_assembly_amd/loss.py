@@ -150,6 +150,7 @@ class _AssemblyLoss(torch.autograd.Function):
         cloud = B * P * N * 3
         pts = fws[: 4 * cloud].view(4, B, P, N, 3)
         ctx.mark_non_differentiable(pts)
+        ctx.set_materialize_grads(False)   # else every backward zero-fills a [4, B, P, N, 3] "gradient" for pts
         return losses, pts
 
     @staticmethod
@@ -157,6 +158,8 @@ class _AssemblyLoss(torch.autograd.Function):
         if getattr(ctx, "consumed", False):
             raise RuntimeError("assembly loss: the backward pass reuses the forward's tile-sum area as scratch: a second "
                                "backward over the same forward (retain_graph=True) is not supported — run the forward again")
+        if grad_losses is None:
+            return (None,) * 8
         ctx.consumed = True
         part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, fws, iws = ctx.saved_tensors
         B, P, N, _ = part_pcs.shape

@@ -72,7 +72,6 @@ class PoseRegressor(nn.Module):
         self.rot_head = nn.Linear(128, 4)
         self.trans_head = nn.Linear(128, 3)
         self.native = norm_rot  # csrc/transformer.hip normalises the quaternion in its head kernel
-        self.pad = (-feat_dim) % 64  # its GEMM panels are 64 wide: odd widths (labels / noise appended) are zero-padded
 
     def forward(self, x):
         """x [B, C] or [B, P, C] -> (rot [.., 4] unit-normalised, trans [.., 3])."""
@@ -80,11 +79,9 @@ class PoseRegressor(nn.Module):
             raise RuntimeError("PoseRegressor: only CUDA (HIP) tensors are supported — no CPU fallback")
         if self.native:
             lead = x.shape[:-1]
-            x2, w1 = x.reshape(-1, x.shape[-1]).float(), self.fc_layers[0].weight
-            if self.pad:  # zero columns on both operands of the first GEMM; autograd slices the gradients back
-                x2, w1 = F.pad(x2, (0, self.pad)), F.pad(w1, (0, self.pad))
+            # (any input width: the library zero-pads odd widths — labels / noise appended — to its 64-column GEMM panels)
             rot, trans = _PoseHeadFn.apply(
-                x2.contiguous(), w1,
+                x.reshape(-1, x.shape[-1]).float().contiguous(), self.fc_layers[0].weight,
                 self.fc_layers[0].bias, self.fc_layers[2].weight, self.fc_layers[2].bias, self.rot_head.weight,
                 self.rot_head.bias, self.trans_head.weight, self.trans_head.bias)
             return rot.view(*lead, 4), trans.view(*lead, 3)

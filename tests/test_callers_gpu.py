@@ -177,6 +177,131 @@ def test_relation_net_hip_layers_match_library_ops(cuda_device):
         assert rel(p.grad, q.grad) < 1e-4, k
 
 
+def test_relation_net_mask_is_the_callers_product(cuda_device):
+    """`RelationNet(x, mask)` (mask folded into the head's launch) equals `RelationNet(x) * mask` on library ops, value and
+    gradients (reference models/dgl/network.py:213: `relation_matrix * valid_matrix`)."""
+    import copy
+    from multi_part_assembly_amd.gnn import RelationNet
+    torch.manual_seed(5)
+    mine = RelationNet().to(cuda_device)
+    ref = copy.deepcopy(mine).double()
+    x = torch.randn(3, 20 * 20, 256, device=cuda_device)
+    mask = (torch.rand(3, 20 * 20, device=cuda_device) < 0.6).float()
+    xa, xb = x.clone().requires_grad_(), x.double().requires_grad_()
+    w = torch.randn(3, 20 * 20, 1, device=cuda_device)
+    out = mine(xa, mask)
+    (out * w).sum().backward()
+    want = torch.sigmoid(ref.mlp3(torch.relu(ref.mlp2(torch.relu(ref.mlp1(xb)))))) * mask.double()[..., None]
+    (want * w.double()).sum().backward()
+    rel = lambda a, b: float((a.double() - b).abs().max() / (b.abs().max() + 1e-12))
+    assert out.shape == want.shape and rel(out.detach(), want.detach()) < 1e-5
+    assert rel(xa.grad, xb.grad) < 1e-4
+    for (k, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel(p.grad, q.grad) < 1e-4, k
+
+
+@pytest.mark.parametrize("R,K,N", [(640, 7, 256), (5, 1, 3), (33, 16, 700)])
+def test_narrow_linear_relu_matches_library_ops(cuda_device, R, K, N):
+    """csrc/gnn_glue.hip's narrow layer (the pose encoder's 7 -> 256, reference models/dgl/modules.py:76-86) against
+    float64 library ops: output, input / weight / bias gradients; without a bias; bit-reproducible."""
+    from multi_part_assembly_amd.gnn_ops import narrow_linear_relu
+    torch.manual_seed(R + N)
+    lin = torch.nn.Linear(K, N).to(cuda_device)
+    x = torch.randn(R, K, device=cuda_device)
+    w = torch.randn(R, N, device=cuda_device)
+    xa, xb = x.clone().requires_grad_(), x.double().requires_grad_()
+    out = narrow_linear_relu(xa, lin.weight, lin.bias)
+    (out * w).sum().backward()
+    got = [xa.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    wd, bd = lin.weight.detach().double().requires_grad_(), lin.bias.detach().double().requires_grad_()
+    want = torch.relu(xb @ wd.t() + bd)
+    (want * w.double()).sum().backward()
+    rel = lambda a, b: float((a.double() - b).abs().max() / (b.abs().max() + 1e-12))
+    assert rel(out.detach(), want.detach()) < 1e-6
+    for a, b in zip(got, (xb.grad, wd.grad, bd.grad)):
+        assert rel(a, b) < 1e-5
+    lin.zero_grad()
+    xc = x.clone().requires_grad_()
+    (narrow_linear_relu(xc, lin.weight, lin.bias) * w).sum().backward()
+    assert torch.equal(xc.grad, got[0]) and torch.equal(lin.weight.grad, got[1]) and torch.equal(lin.bias.grad, got[2])
+    nb = narrow_linear_relu(x.view(1, R, K), lin.weight)  # leading dimensions, no bias
+    assert nb.shape == (1, R, N) and rel(nb, torch.relu(x.double() @ wd.detach().t())[None]) < 1e-6
+    with pytest.raises(Exception):
+        narrow_linear_relu(torch.randn(4, 17, device=cuda_device), torch.randn(8, 17, device=cuda_device))
+
+
+@pytest.mark.parametrize("B,P,C", [(32, 20, 128), (2, 1, 5), (3, 64, 200)])
+def test_relation_mean_matches_library_ops(cuda_device, B, P, C):
+    """The relation-weighted mean of the edge features (reference models/dgl/network.py:135-152) in one launch against
+    the float64 library formulation; rows without any relation weight (padded parts) give zeros as there."""
+    from multi_part_assembly_amd.gnn_ops import relation_mean
+    torch.manual_seed(B * P)
+    edge = torch.randn(B, P, P, C, device=cuda_device)
+    rel_w = torch.rand(B, P, P, device=cuda_device) * (torch.rand(B, P, P, device=cuda_device) < 0.7)
+    rel_w[0, 0] = 0.0  # a padded part: no neighbours
+    w = torch.randn(B, P, C, device=cuda_device)
+    ea, ra = edge.clone().requires_grad_(), rel_w.clone().requires_grad_()
+    eb, rb = edge.double().requires_grad_(), rel_w.double().requires_grad_()
+    out = relation_mean(ea, ra)
+    (out * w).sum().backward()
+    want = (eb * rb[..., None]).sum(dim=2) / (rb.sum(dim=-1, keepdim=True) + 1e-6)
+    (want * w.double()).sum().backward()
+    rel = lambda a, b: float((a.double() - b).abs().max() / (b.abs().max() + 1e-12))
+    assert rel(out.detach(), want.detach()) < 1e-5
+    assert float(out[0, 0].abs().max()) == 0.0
+    assert rel(ea.grad, eb.grad) < 1e-5
+    assert rel(ra.grad, rb.grad) < 1e-4   # (entries of the empty row are O(1e6): the reference's 1 / 1e-6)
+    out2 = relation_mean(edge.requires_grad_(), rel_w)  # weights that are data (the first iteration's valid matrix)
+    (out2 * w).sum().backward()
+    assert torch.equal(out2.detach(), out.detach()) and torch.equal(edge.grad, ea.grad)
+
+
+@pytest.mark.parametrize("S,P,F,swap", [(32, 20, 128, False), (32, 20, 128, True), (2, 1, 4, False), (3, 7, 36, True)])
+def test_pair_rows_match_library_ops(cuda_device, S, P, F, swap):
+    """[part i ; part j] rows for every pair (reference models/dgl/network.py:121-125 — swapped halves — and 135-141):
+    the same bytes as expand + cat, gradients = the sums over the other index."""
+    from multi_part_assembly_amd.gnn_ops import pair_rows
+    torch.manual_seed(S + P)
+    a, b = torch.randn(S, P, F, device=cuda_device), torch.randn(S, P, F, device=cuda_device)
+    w = torch.randn(S, P, P, 2 * F, device=cuda_device)
+    aa, ba = a.clone().requires_grad_(), b.clone().requires_grad_()
+    ad, bd = a.double().requires_grad_(), b.double().requires_grad_()
+    out = pair_rows(aa, ba, swap=swap)
+    (out * w).sum().backward()
+    halves = [ad[:, :, None].expand(S, P, P, F), bd[:, None].expand(S, P, P, F)]
+    want = torch.cat(halves[::-1] if swap else halves, dim=-1)
+    (want * w.double()).sum().backward()
+    assert torch.equal(out.detach().double(), want.detach())
+    rel = lambda x, y: float((x.double() - y).abs().max() / (y.abs().max() + 1e-12))
+    assert rel(aa.grad, ad.grad) < 1e-5 and rel(ba.grad, bd.grad) < 1e-5
+    same = a.clone().requires_grad_()   # one tensor in both roles (the relation net's input): the two sums add up
+    (pair_rows(same, same, swap=swap) * w).sum().backward()
+    assert rel(same.grad, ad.grad + bd.grad) < 1e-5
+    only_a = a.clone().requires_grad_()  # b is data
+    (pair_rows(only_a, b, swap=swap) * w).sum().backward()
+    assert torch.equal(only_a.grad, aa.grad)
+
+
+def test_pose_encoder_hip_layers_match_library_ops(cuda_device):
+    import copy
+    from multi_part_assembly_amd.gnn import PoseEncoder
+    torch.manual_seed(11)
+    mine = PoseEncoder(7).to(cuda_device)
+    ref = copy.deepcopy(mine).double()
+    x = torch.randn(32, 20, 7, device=cuda_device)
+    xa, xb = x.clone().requires_grad_(), x.double().requires_grad_()
+    w = torch.randn(32, 20, 128, device=cuda_device)
+    out = mine(xa)
+    (out * w).sum().backward()
+    want = torch.relu(ref.mlp2(torch.relu(ref.mlp1(xb))))
+    (want * w.double()).sum().backward()
+    rel = lambda a, b: float((a.double() - b).abs().max() / (b.abs().max() + 1e-12))
+    assert out.shape == want.shape and rel(out.detach(), want.detach()) < 1e-5
+    assert rel(xa.grad, xb.grad) < 1e-4
+    for (k, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel(p.grad, q.grad) < 1e-4, k
+
+
 @pytest.mark.parametrize("H,B,T", [(256, 32, 20), (128, 3, 5), (256, 7, 33)])
 def test_gru_recurrent_matches_torch_gru(cuda_device, H, B, T):
     """csrc/gru.hip (all steps of both directions in one launch, tagged-word exchange per step) against torch.nn.GRU run per
