@@ -398,38 +398,6 @@ __device__ __forceinline__ void consider(LaneState& s, float tx, float ty, float
   }
 }
 
-// records [begin, end) of the target array, 8 per chunk (reads may run past `end`: the extra records are
-// real targets or sentinels, both harmless), scalar loads prefetched one chunk ahead.
-__device__ __forceinline__ void scan_records(LaneState& s, const float4* __restrict__ rec, int begin, int end) {
-  constexpr int T = kScanChunk;
-  if (begin >= end) return;
-  float4 nx[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) nx[t] = rec[begin + t];
-  for (int j0 = begin; j0 < end; j0 += T) {
-    float4 cur[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) cur[t] = nx[t];
-    const int jn = j0 + T < end ? j0 + T : j0;
-#pragma unroll
-    for (int t = 0; t < T; ++t) nx[t] = rec[jn + t];
-    float d[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) d[t] = dist_exact_s(s.X - cur[t].x, s.Y - cur[t].y, s.Z - cur[t].z);
-    const float cmin = min8(d);
-    if (cmin <= s.best) {  // rare: an improvement, or a tie that may carry a lower index
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const int ti = __float_as_int(cur[t].w);
-        if (d[t] < s.best || (d[t] == s.best && ti < s.bidx)) {
-          s.best = d[t];
-          s.bidx = ti;
-        }
-      }
-    }
-  }
-}
-
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
@@ -453,6 +421,12 @@ __device__ __forceinline__ float gap(float a0, float a1, float b0, float b1) {
 // once), and then all lanes scan that list with broadcast LDS reads: two latencies per BATCH.  Long lists are
 // processed in windows of the LDS buffer; single long ranges go to the scalar scan, whose long runs amortise the
 // latency by themselves.
+#ifndef MPA_GRID_GATHER_U
+#define MPA_GRID_GATHER_U 4
+#endif
+#ifndef MPA_GRID_CAND_CHUNK  // candidates per step of the LDS scan: 4 instead of 8 frees 16 registers (94 -> 78: 6 waves per
+#define MPA_GRID_CAND_CHUNK 4  // SIMD instead of 5; 0.279 -> 0.265 ms); 2 costs more LDS instructions than the 7th wave gains
+#endif
 #ifndef MPA_GRID_CAND
 #define MPA_GRID_CAND 128
 #endif
@@ -464,7 +438,7 @@ constexpr int kLongRange = 32;  // ranges longer than this are fetched by the wh
 
 // every lane scans the wn candidate records staged in LDS (padded to a multiple of 8 with sentinels)
 __device__ __forceinline__ void scan_cand(LaneState& s, const float4* __restrict__ cand, int wn) {
-  constexpr int T = kScanChunk;
+  constexpr int T = MPA_GRID_CAND_CHUNK;
   // split > 1: this group of lanes takes candidates sub, sub + split, ... (split LDS addresses per read, not one)
   const int step = s.split, sub = (int)threadIdx.x / (64 / s.split);
   for (int j0 = 0; j0 < wn; j0 += T * step) {
@@ -474,7 +448,9 @@ __device__ __forceinline__ void scan_cand(LaneState& s, const float4* __restrict
     float d[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) d[t] = dist_exact_s(s.X - cur[t].x, s.Y - cur[t].y, s.Z - cur[t].z);
-    const float cmin = min8(d);
+    float cmin = d[0];
+#pragma unroll
+    for (int t = 1; t < T; ++t) cmin = __builtin_fminf(cmin, d[t]);
     if (cmin <= s.best) {  // rare: an improvement, or a tie that may carry a lower index
 #pragma unroll
       for (int t = 0; t < T; ++t) {
@@ -505,12 +481,12 @@ __device__ __forceinline__ void merge_halves(LaneState& s) {
 // copying its own long range alone moves 2 records per round trip; the scalar-operand scan moves 8.)
 __device__ __forceinline__ void scan_range_coop(LaneState& s, const float4* __restrict__ trec, int begin, int end,
                                                 float4* __restrict__ cand) {
-  constexpr int T = 4 * kScanChunk, kCap = kCand - T;  // (4x: a split scan reads up to 32 records past the end)
+  constexpr int T = 4 * MPA_GRID_CAND_CHUNK, kCap = kCand - T;  // (4x: a split-4 scan reads up to that far past the end)
   const int lane = threadIdx.x;
   for (int w0 = begin; w0 < end; w0 += kCap) {
     const int wn = end - w0 < kCap ? end - w0 : kCap;
     __syncthreads();  // the previous readers are done with `cand`
-    constexpr int U = 4;
+    constexpr int U = MPA_GRID_GATHER_U;
     for (int j0 = lane; j0 < wn; j0 += 64 * U) {
       float4 t[U];  // (unconditional loads of a clamped position: conditional ones send the array to scratch)
 #pragma unroll
@@ -565,7 +541,7 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
     if (lane >= off) incl += t;
   }
   const int total = __shfl(incl, 63, 64), off0 = incl - len;
-  constexpr int T = 4 * kScanChunk, kCap = kCand - T;  // (4x: a split scan reads up to 32 records past the end)
+  constexpr int T = 4 * MPA_GRID_CAND_CHUNK, kCap = kCand - T;  // (4x: a split-4 scan reads up to that far past the end)
   for (int w0 = 0; w0 < total; w0 += kCap) {  // windows of the concatenated list that fit the LDS buffer
     const int wn = total - w0 < kCap ? total - w0 : kCap;
     const int lo = off0 > w0 ? off0 : w0, hi = off0 + len < w0 + wn ? off0 + len : w0 + wn;
@@ -576,7 +552,7 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
     // of each lane walking its own range two records per memory round trip
     for (int k = 0; k < cnt; ++k) sidx[lo - w0 + k] = rb + (lo - off0) + k;
     __syncthreads();
-    constexpr int U = 4;
+    constexpr int U = MPA_GRID_GATHER_U;
     for (int j0 = lane; j0 < wn; j0 += 64 * U) {
       float4 t[U];
 #pragma unroll
