@@ -297,7 +297,8 @@ int mpa_mlp_layer_backward(const float* grad_out, const float* x, int64_t ldx, c
  *   the relation-weighted mean of the edge features     : models/dgl/network.py:135-152
  *   the [part i ; part j] pair rows fed to the edge MLP / relation net : models/dgl/network.py:121-125, 135-141
  * narrow_linear_relu: out [R, N] = relu(x [R, K] w[N, K]^T + bias), K <= 16; backward takes the forward's `out` (ReLU
- *   mask) and overwrites grad_x [R, K] (if non-NULL), grad_w [N, K], grad_b [N] (if non-NULL).
+ *   mask) and scratch `ws` (mpa_narrow_linear_relu_workspace floats) and overwrites grad_x [R, K] (if non-NULL),
+ *   grad_w [N, K], grad_b [N] (if non-NULL).
  * relation_head: out [R] = sigmoid(h [R, K] . w [K] + bias[0]) * mask [R] (mask NULL = ones), K a multiple of 4; `ws`
  *   (mpa_relation_head_workspace floats) carries the sigmoids to backward, which overwrites grad_h [R, K] (if non-NULL),
  *   grad_w [K], grad_b [1] (if non-NULL).
@@ -314,8 +315,10 @@ int mpa_pair_rows_backward(const float* grad_out, int64_t S, int64_t P, int64_t 
                            void* stream);
 int mpa_narrow_linear_relu_forward(const float* x, const float* w, const float* bias, int64_t R, int64_t K, int64_t N,
                                    float* out, void* stream);
+int mpa_narrow_linear_relu_workspace(int64_t R, int64_t K, int64_t N, int64_t* float_elems);
 int mpa_narrow_linear_relu_backward(const float* grad_out, const float* out, const float* x, const float* w, int64_t R,
-                                    int64_t K, int64_t N, float* grad_x, float* grad_w, float* grad_b, void* stream);
+                                    int64_t K, int64_t N, float* ws, float* grad_x, float* grad_w, float* grad_b,
+                                    void* stream);
 int mpa_relation_head_workspace(int64_t R, int64_t K, int64_t* float_elems);
 int mpa_relation_head_forward(const float* h, const float* w, const float* bias, const float* mask, int64_t R, int64_t K,
                               float* ws, float* out, void* stream);

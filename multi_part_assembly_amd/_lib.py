@@ -62,7 +62,8 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_pair_rows_forward": (_INT, [_P, _P, _I64, _I64, _I64, _INT, _P, _P]),
     "mpa_pair_rows_backward": (_INT, [_P, _I64, _I64, _I64, _INT, _P, _P, _P]),
     "mpa_narrow_linear_relu_forward": (_INT, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
-    "mpa_narrow_linear_relu_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "mpa_narrow_linear_relu_workspace": (_INT, [_I64, _I64, _I64, _P]),
+    "mpa_narrow_linear_relu_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
     "mpa_relation_head_workspace": (_INT, [_I64, _I64, _P]),
     "mpa_relation_head_forward": (_INT, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "mpa_relation_head_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),

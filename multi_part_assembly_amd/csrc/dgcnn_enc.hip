@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void dg_first_uv_kernel(const float4* __restri
 
 // d(ws1) partials: part [tiles][128][4] = sum over the tile's rows of duv[r][o] * x0[r][k].  grid = tiles of 1024 rows,
 // block 512 = 4 row groups x 128 outputs, groups merged in fixed order.
-constexpr int kFirstTile = 1024;
+constexpr int kFirstTile = 256;  // (1024: 128 us for the 180 MB pass — 350 blocks of 256-row serial loops; 256: ~1400 blocks)
 __global__ __launch_bounds__(512) void dg_first_wgrad_kernel(const float* __restrict__ duv, const float4* __restrict__ x0,
                                                              float* __restrict__ part, const int* __restrict__ hdr) {
   __shared__ float4 red[4][128];
@@ -443,23 +443,42 @@ __global__ void dg_apply_kernel(const float* __restrict__ esel, int CO, const fl
 }
 
 // ---- tail: column statistics of y5, pooling, linear ----------------------------------------------------------------------------
-// partial [tiles][F][2] = (sum y, sum y^2) over the tile's rows.  grid = ceil(Rmax / kTile), block = F.
-__global__ void dg_colstats_kernel(const float* __restrict__ y, int F, float* __restrict__ partial,
-                                   const int* __restrict__ hdr) {
+// The row-tiled passes below run 512 threads per tile of kTile rows: thread = (row group, channel), the 512 / F row groups
+// walk every (512 / F)-th row (F threads per tile left 128 dependent-address row loads to two waves).
+constexpr int kTileT = 512;
+
+// the row groups' (a, b) added in group order by group 0 -> partial[tile][F][2]
+__device__ __forceinline__ void tile_pair_out(float a, float b, int F, int g, int c, float* __restrict__ partial) {
+  __shared__ float red[kTileT][2];
+  red[g * F + c][0] = a;
+  red[g * F + c][1] = b;
+  __syncthreads();
+  if (g == 0) {
+    for (int q = 1; q < kTileT / F; ++q) {
+      a += red[q * F + c][0];
+      b += red[q * F + c][1];
+    }
+    float* d = partial + ((long long)blockIdx.x * F + c) * 2;
+    d[0] = a;
+    d[1] = b;
+  }
+}
+
+// partial [tiles][F][2] = (sum y, sum y^2) over the tile's rows.  grid = ceil(Rmax / kTile), block = kTileT.
+__global__ __launch_bounds__(kTileT) void dg_colstats_kernel(const float* __restrict__ y, int F, float* __restrict__ partial,
+                                                             const int* __restrict__ hdr) {
   const int R = hdr[1];
   const long long r0 = (long long)blockIdx.x * kTile;
   if (r0 >= R) return;
-  const int c = threadIdx.x;
+  const int c = threadIdx.x % F, g = threadIdx.x / F, G = kTileT / F;
   float s = 0.0f, ss = 0.0f;
   const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
-  for (int i = 0; i < rows; ++i) {
+  for (int i = g; i < rows; i += G) {
     const float t = y[(r0 + i) * F + c];
     s += t;
     ss = __builtin_fmaf(t, t, ss);
   }
-  float* d = partial + ((long long)blockIdx.x * F + c) * 2;
-  d[0] = s;
-  d[1] = ss;
+  tile_pair_out(s, ss, F, g, c, partial);
 }
 
 // pooled [nv][2F] = [max_n a ; mean_n a] with a = LeakyReLU(bn(y)); arg [nv][F] = row of the (first) maximum.
@@ -575,18 +594,20 @@ __device__ __forceinline__ float dg_tail_dz(float y, float scale, float shift, f
   return (z > 0.0f ? 1.0f : kSlope) * (dmean_n + (is_arg ? dmax : 0.0f));
 }
 
-// partial [tiles][F][2] = (sum dz, sum dz*xhat).  grid = ceil(Rmax / kTile), block = F.
-__global__ void dg_tail_bwd_sums_kernel(const float* __restrict__ y, int F, int N, const float* __restrict__ bn,
-                                        const float* __restrict__ dpooled, const int* __restrict__ arg,
-                                        float* __restrict__ partial, const int* __restrict__ hdr) {
+// partial [tiles][F][2] = (sum dz, sum dz*xhat).  grid = ceil(Rmax / kTile), block = kTileT.
+__global__ __launch_bounds__(kTileT) void dg_tail_bwd_sums_kernel(const float* __restrict__ y, int F, int N,
+                                                                  const float* __restrict__ bn,
+                                                                  const float* __restrict__ dpooled,
+                                                                  const int* __restrict__ arg, float* __restrict__ partial,
+                                                                  const int* __restrict__ hdr) {
   const int R = hdr[1];
   const long long r0 = (long long)blockIdx.x * kTile;
   if (r0 >= R) return;
-  const int c = threadIdx.x;
+  const int c = threadIdx.x % F, g = threadIdx.x / F, G = kTileT / F;
   const float scale = bn[c], shift = bn[F + c], mean = bn[2 * F + c], invstd = bn[3 * F + c];
   const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
   float s1 = 0.0f, s2 = 0.0f;
-  for (int i = 0; i < rows; ++i) {
+  for (int i = g; i < rows; i += G) {
     const long long r = r0 + i;
     const int v = (int)(r / N), p = (int)(r % N);
     const float t = y[r * F + c];
@@ -595,23 +616,24 @@ __global__ void dg_tail_bwd_sums_kernel(const float* __restrict__ y, int F, int 
     s1 += dz;
     s2 = __builtin_fmaf(dz, (t - mean) * invstd, s2);
   }
-  float* d = partial + ((long long)blockIdx.x * F + c) * 2;
-  d[0] = s1;
-  d[1] = s2;
+  tile_pair_out(s1, s2, F, g, c, partial);
 }
 
-// y5 <- dY5 = alpha*dz + gammap*y + betap, in place.  grid = ceil(Rmax / kTile), block = F.
-__global__ void dg_tail_bwd_apply_kernel(float* __restrict__ y, int F, int N, const float* __restrict__ bn,
-                                         const float* __restrict__ coef, const float* __restrict__ dpooled,
-                                         const int* __restrict__ arg, const int* __restrict__ hdr) {
+// y5 <- dY5 = alpha*dz + gammap*y + betap, in place.  grid = ceil(Rmax / kTile), block = kTileT.
+__global__ __launch_bounds__(kTileT) void dg_tail_bwd_apply_kernel(float* __restrict__ y, int F, int N,
+                                                                   const float* __restrict__ bn,
+                                                                   const float* __restrict__ coef,
+                                                                   const float* __restrict__ dpooled,
+                                                                   const int* __restrict__ arg,
+                                                                   const int* __restrict__ hdr) {
   const int R = hdr[1];
   const long long r0 = (long long)blockIdx.x * kTile;
   if (r0 >= R) return;
-  const int c = threadIdx.x;
+  const int c = threadIdx.x % F, g = threadIdx.x / F, G = kTileT / F;
   const float scale = bn[c], shift = bn[F + c];
   const float alpha = coef[c], gammap = coef[F + c], betap = coef[2 * F + c];
   const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
-  for (int i = 0; i < rows; ++i) {
+  for (int i = g; i < rows; i += G) {
     const long long r = r0 + i;
     const int v = (int)(r / N), p = (int)(r % N);
     const float t = y[r * F + c];
@@ -623,19 +645,23 @@ __global__ void dg_tail_bwd_apply_kernel(float* __restrict__ y, int F, int N, co
 
 // ---- edge aggregation, backward ----------------------------------------------------------------------------------------------
 // dz = dH * LeakyReLU'(z) (z > 0 <=> H > 0) and the two BatchNorm-backward sums over the selected edges.
-// grid = ceil(Rmax / kTile), block = CO.
-__global__ void dg_agg_bwd_sums_kernel(const float* __restrict__ hcat, const float* __restrict__ dhcat, int off, int CO,
-                                       const float* __restrict__ esel, const float* __restrict__ bn,
-                                       float* __restrict__ dz, float* __restrict__ partial,
-                                       const int* __restrict__ hdr) {
+// grid = ceil(Rmax / kTile), block = 512: thread = (row group, channel), the 512 / CO row groups of a tile walk every
+// (512 / CO)-th row and are added in group order (one wave per tile left the loads of 128 rows to a single wave: 167 us
+// per launch where the 270-540 MB of the pass stream in 80-160).
+__global__ __launch_bounds__(512) void dg_agg_bwd_sums_kernel(const float* __restrict__ hcat,
+                                                              const float* __restrict__ dhcat, int off, int CO,
+                                                              const float* __restrict__ esel, const float* __restrict__ bn,
+                                                              float* __restrict__ dz, float* __restrict__ partial,
+                                                              const int* __restrict__ hdr) {
+  __shared__ float red[512][2];  // [row group][channel]
   const int R = hdr[1];
   const long long r0 = (long long)blockIdx.x * kTile;
   if (r0 >= R) return;
-  const int c = threadIdx.x;
+  const int c = threadIdx.x % CO, g = threadIdx.x / CO, G = 512 / CO;
   const float mean = bn[2 * CO + c], invstd = bn[3 * CO + c];
   const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
   float s1 = 0.0f, s2 = 0.0f;
-  for (int i = 0; i < rows; ++i) {
+  for (int i = g; i < rows; i += G) {
     const long long r = r0 + i, o = r * CO + c;
     const float h = hcat[r * kCat + off + c];
     const float d = dhcat[r * kCat + off + c] * (h > 0.0f ? 1.0f : kSlope);
@@ -643,9 +669,18 @@ __global__ void dg_agg_bwd_sums_kernel(const float* __restrict__ hcat, const flo
     s1 += d;
     s2 = __builtin_fmaf(d, (esel[o] - mean) * invstd, s2);
   }
-  float* p = partial + ((long long)blockIdx.x * CO + c) * 2;
-  p[0] = s1;
-  p[1] = s2;
+  red[g * CO + c][0] = s1;
+  red[g * CO + c][1] = s2;
+  __syncthreads();
+  if (g == 0) {
+    for (int q = 1; q < G; ++q) {
+      s1 += red[q * CO + c][0];
+      s2 += red[q * CO + c][1];
+    }
+    float* p = partial + ((long long)blockIdx.x * CO + c) * 2;
+    p[0] = s1;
+    p[1] = s2;
+  }
 }
 
 // Transposed kNN graph of every part, points in the order of descending in-degree: order [M][N] (rank -> point),
@@ -1318,7 +1353,7 @@ int dgcnn_forward_impl(const float* points, const float* valids, const float* co
   // tail: 512 -> F convolution, BatchNorm1d, LeakyReLU, [max ; mean] over the points, Linear
   gemm_nt(w.hcat, kCat, conv_w[4], kCat, w.y5, (int)F, (int)F, false, R, w.hdr, s);
   if (training) {
-    launch(dg_colstats_kernel, dim3((unsigned)tiles), dim3((unsigned)F), s, (const float*)w.y5, (int)F, w.partial,
+    launch(dg_colstats_kernel, dim3((unsigned)tiles), dim3(kTileT), s, (const float*)w.y5, (int)F, w.partial,
            (const int*)w.hdr);
     launch(dg_bn_finalize_kernel, dim3((unsigned)(F / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
            (const float*)w.partial, (int)tiles, (int)F, 0, 1, bn_w[4], bn_b[4], running_mean[4], running_var[4], momentum,
@@ -1387,12 +1422,12 @@ extern "C" int mpa_dgcnn_backward(const float* grad_feat, const float* const* co
   launch(dg_fc_bwd_w_kernel, dim3((unsigned)F), dim3(1024), s, grad_feat, (const int*)w.vlist, (int)F,
          (const float*)w.pooled, grad_fc_w, grad_fc_b, hdr);
   // BatchNorm1d backward of the tail; y5 becomes dY5
-  launch(dg_tail_bwd_sums_kernel, dim3((unsigned)tiles), dim3((unsigned)F), s, (const float*)w.y5, (int)F, (int)N,
+  launch(dg_tail_bwd_sums_kernel, dim3((unsigned)tiles), dim3(kTileT), s, (const float*)w.y5, (int)F, (int)N,
          (const float*)w.bn[4], (const float*)w.dpooled, (const int*)w.arg5, w.partial, hdr);
   launch(dg_bwd_coef_kernel, dim3((unsigned)(F / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
          (const float*)w.partial, (int)tiles, (int)F, 1, bn_w[4], (const float*)w.bn[4], w.coef, grad_bn_w[4],
          grad_bn_b[4], cw, hdr);
-  launch(dg_tail_bwd_apply_kernel, dim3((unsigned)tiles), dim3((unsigned)F), s, w.y5, (int)F, (int)N,
+  launch(dg_tail_bwd_apply_kernel, dim3((unsigned)tiles), dim3(kTileT), s, w.y5, (int)F, (int)N,
          (const float*)w.bn[4], (const float*)w.coef, (const float*)w.dpooled, (const int*)w.arg5, hdr);
   gemm_tn(w.y5, (int)F, (int)F, w.hcat, kCat, kCat, w.tnpart, grad_conv_w[4], R, hdr, s);
   launch(dg_transpose_kernel, dim3((unsigned)((F * kCat + 255) / 256)), dim3(256), s, conv_w[4], (int)F, kCat, w.w5t);
@@ -1411,7 +1446,7 @@ extern "C" int mpa_dgcnn_backward(const float* grad_feat, const float* const* co
       launch(dg_bwd_head_kernel, dim3((unsigned)(4 * M + tiles)), dim3(1024), s, ra, (int)M, (int)N, (const float*)w.hcat,
              (const float*)w.dhcat, kOff[l], CO, (const float*)w.esel[l], (const float*)w.bn[l], w.dz, w.partial, hdr);
     } else {
-      launch(dg_agg_bwd_sums_kernel, dim3((unsigned)tiles), dim3((unsigned)CO), s, (const float*)w.hcat,
+      launch(dg_agg_bwd_sums_kernel, dim3((unsigned)tiles), dim3(512), s, (const float*)w.hcat,
              (const float*)w.dhcat, kOff[l], CO, (const float*)w.esel[l], (const float*)w.bn[l], w.dz, w.partial, hdr);
     }
     launch(dg_bwd_coef_kernel, dim3((unsigned)(CO / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,

@@ -46,13 +46,16 @@ __global__ __launch_bounds__(256) void nl_fwd_kernel(const float* __restrict__ x
 
 // Backward, two kinds of block in one launch (dy = grad_out where out > 0):
 //   blocks [0, R): row r — grad_x[r][k] = sum_n dy[r][n] w[n][k]  (skipped when grad_x is null)
-//   blocks [R, R + ceil(N / 64)): 64 channels — grad_w[n][k] = sum_r dy[r][n] x[r][k], grad_b[n] = sum_r dy[r][n];
-//   8 row groups of 64 lanes each walk every 8th row, the groups' sums are added in group order.
+//   then ceil(N / 64) x ceil(R / 128) blocks: 64 channels x 128 rows — the chunk's part of grad_w[n][k] = sum_r dy[r][n] x[r][k]
+//   and grad_b[n] = sum_r dy[r][n] into part[chunk][n][kMaxK + 1]; 8 row groups of 64 lanes, 16 rows each with all their
+//   loads in flight at once (a block per 64 channels walking ALL rows was a chain of dependent round trips: 63 us at 640
+//   rows), the groups' sums added in group order.  nl_reduce_kernel adds the chunks in order.
+constexpr int kNlRows = 128;
 __global__ __launch_bounds__(512) void nl_bwd_kernel(const float* __restrict__ g, const float* __restrict__ out,
-                                                      const float* __restrict__ x, const float* __restrict__ w, int R,
-                                                      int K, int N, float* __restrict__ grad_x,
-                                                      float* __restrict__ grad_w, float* __restrict__ grad_b) {
+                                                     const float* __restrict__ x, const float* __restrict__ w, int R,
+                                                     int K, int N, float* __restrict__ grad_x, float* __restrict__ part) {
   __shared__ float red[8][64][kMaxK + 1];
+  __shared__ float xs[kNlRows][kMaxK];
   const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
   if ((int)blockIdx.x < R) {
     if (grad_x == nullptr) return;
@@ -68,8 +71,10 @@ __global__ __launch_bounds__(512) void nl_bwd_kernel(const float* __restrict__ g
     }
 #pragma unroll
     for (int k = 0; k < kMaxK; ++k) {
-      const float s = wave_sum(acc[k]);
-      if (lane == 0) red[grp][0][k] = s;
+      if (k < K) {
+        const float s = wave_sum(acc[k]);
+        if (lane == 0) red[grp][0][k] = s;
+      }
     }
     __syncthreads();
     if (tid < K) {
@@ -79,31 +84,57 @@ __global__ __launch_bounds__(512) void nl_bwd_kernel(const float* __restrict__ g
     }
     return;
   }
-  const int n = ((int)blockIdx.x - R) * 64 + lane;
+  const int nb = (N + 63) / 64, bb = (int)blockIdx.x - R, chunk = bb / nb;
+  const int n = (bb - chunk * nb) * 64 + lane;
+  const int t0 = chunk * kNlRows, trows = R - t0 < kNlRows ? R - t0 : kNlRows;
+  for (int e = tid; e < trows * K; e += 512) xs[e / K][e % K] = x[(long long)t0 * K + e];
+  __syncthreads();
   float acc[kMaxK + 1];
 #pragma unroll
   for (int k = 0; k <= kMaxK; ++k) acc[k] = 0.0f;
   if (n < N) {
-    for (long long r = grp; r < R; r += 8) {
-      const float dy = out[r * N + n] > 0.0f ? g[r * N + n] : 0.0f;
+    constexpr int U = kNlRows / 8;
+    float dy[U];
 #pragma unroll
-      for (int k = 0; k < kMaxK; ++k)
-        if (k < K) acc[k] = __builtin_fmaf(dy, x[r * K + k], acc[k]);
-      acc[kMaxK] += dy;
+    for (int u = 0; u < U; ++u) {
+      const int rr = grp + 8 * u;
+      const long long r = t0 + (rr < trows ? rr : 0);  // (clamped: the value is dropped below)
+      dy[u] = out[r * N + n] > 0.0f ? g[r * N + n] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rr = grp + 8 * u;
+      if (rr < trows) {
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k)
+          if (k < K) acc[k] = __builtin_fmaf(dy[u], xs[rr][k], acc[k]);
+        acc[kMaxK] += dy[u];
+      }
     }
   }
 #pragma unroll
   for (int k = 0; k <= kMaxK; ++k) red[grp][lane][k] = acc[k];
   __syncthreads();
   if (n < N) {
-    for (int k = grp; k <= K; k += 8) {  // (k == K: the bias)
-      const int kk = k < K ? k : kMaxK;
+    for (int k = grp; k <= kMaxK; k += 8) {
       float s = 0.0f;
-      for (int q = 0; q < 8; ++q) s += red[q][lane][kk];
-      if (k < K) grad_w[(long long)n * K + k] = s;
-      else if (grad_b != nullptr) grad_b[n] = s;
+      for (int q = 0; q < 8; ++q) s += red[q][lane][k];
+      part[((long long)chunk * N + n) * (kMaxK + 1) + k] = s;
     }
   }
+}
+
+// grad_w[n][k] (k < K) and grad_b[n] (column kMaxK of the table) = the row chunks' partials added in chunk order.
+__global__ __launch_bounds__(256) void nl_reduce_kernel(const float* __restrict__ part, int chunks, int K, int N,
+                                                        float* __restrict__ grad_w, float* __restrict__ grad_b) {
+  const int e = (int)blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * (K + 1)) return;
+  const int n = e / (K + 1), k = e - n * (K + 1);
+  const int col = k < K ? k : kMaxK;
+  float s = 0.0f;
+  for (int c = 0; c < chunks; ++c) s += part[((long long)c * N + n) * (kMaxK + 1) + col];
+  if (k < K) grad_w[(long long)n * K + k] = s;
+  else if (grad_b != nullptr) grad_b[n] = s;
 }
 
 // ---- relation head ------------------------------------------------------------------------------------------------
@@ -132,10 +163,10 @@ __global__ __launch_bounds__(256) void rh_fwd_kernel(const float* __restrict__ h
   }
 }
 
-constexpr int kRhRows = 64;  // rows per block of the backward
+constexpr int kRhRows = 16;  // rows per block of the backward (12 800 pair rows: 800 blocks)
 
 // dz[r] = g[r] mask[r] sig[r] (1 - sig[r]);  grad_h[r][k] = dz[r] w[k];  the block's partial of grad_w[k] = sum_r dz[r] h[r][k]
-// and of grad_b = sum_r dz[r] into part[block][K + 1].  grid = ceil(R / 64), block = 256.
+// and of grad_b = sum_r dz[r] into part[block][K + 1].  grid = ceil(R / 16), block = 256.
 __global__ __launch_bounds__(256) void rh_bwd_kernel(const float* __restrict__ g, const float* __restrict__ h,
                                                      const float* __restrict__ w, const float* __restrict__ mask,
                                                      const float* __restrict__ sig, int R, int K,
@@ -156,11 +187,17 @@ __global__ __launch_bounds__(256) void rh_bwd_kernel(const float* __restrict__ g
   float* prow = part + (long long)blockIdx.x * (K + 1);
   for (int k = threadIdx.x; k < K; k += 256) {
     const float wk = w[k];
+    float hv[kRhRows];
+#pragma unroll
+    for (int i = 0; i < kRhRows; ++i) hv[i] = h[(r0 + (i < rows ? i : rows - 1)) * K + k];  // all loads in flight
     float acc = 0.0f;
-    for (int i = 0; i < rows; ++i) {
-      const float d = dz[i];
-      acc = __builtin_fmaf(d, h[(r0 + i) * K + k], acc);
-      if (grad_h != nullptr) grad_h[(r0 + i) * K + k] = d * wk;
+#pragma unroll
+    for (int i = 0; i < kRhRows; ++i) {
+      if (i < rows) {
+        const float d = dz[i];
+        acc = __builtin_fmaf(d, hv[i], acc);
+        if (grad_h != nullptr) grad_h[(r0 + i) * K + k] = d * wk;
+      }
     }
     prow[k] = acc;
   }
@@ -190,8 +227,10 @@ __global__ __launch_bounds__(256) void rh_reduce_kernel(const float* __restrict_
 // out[g][c] = sum_j edge[g][j][c] rel[g][j] / (sum_j rel[g][j] + 1e-6).  grid = G (rows (sample, part i)), block = 128.
 __global__ __launch_bounds__(128) void rm_fwd_kernel(const float* __restrict__ edge, const float* __restrict__ rel, int P,
                                                      int C, float* __restrict__ out) {
+  __shared__ float rl[64];  // the row's weights (as scalar-cache operands every one is a dependent round trip)
   const long long g = blockIdx.x;
-  const float* rl = rel + g * P;
+  if ((int)threadIdx.x < P) rl[threadIdx.x] = rel[g * P + threadIdx.x];
+  __syncthreads();
   float den = 0.0f;
   for (int j = 0; j < P; ++j) den += rl[j];
   den += 1e-6f;
@@ -207,23 +246,36 @@ __global__ __launch_bounds__(128) void rm_bwd_kernel(const float* __restrict__ g
                                                      const float* __restrict__ rel, const float* __restrict__ out, int P,
                                                      int C, float* __restrict__ grad_edge, float* __restrict__ grad_rel) {
   __shared__ float red[2][64];
+  __shared__ float rl[64];
   const long long g = blockIdx.x;
-  const float* rl = rel + g * P;
+  if ((int)threadIdx.x < P) rl[threadIdx.x] = rel[g * P + threadIdx.x];
+  __syncthreads();
   float den = 0.0f;
   for (int j = 0; j < P; ++j) den += rl[j];
   den += 1e-6f;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int j = 0; j < P; ++j) {
-    const float rj = rl[j];
-    float acc = 0.0f;
-    for (int c = threadIdx.x; c < C; c += 128) {
-      const float gd = go[g * C + c] / den;
-      if (grad_edge != nullptr) grad_edge[(g * P + j) * C + c] = gd * rj;
-      if (grad_rel != nullptr) acc = __builtin_fmaf(gd, edge[(g * P + j) * C + c] - out[g * C + c], acc);
-    }
-    if (grad_rel != nullptr) {
-      acc = wave_sum(acc);
-      if (lane == 0) red[wv][j] = acc;
+  if ((int)threadIdx.x < 64) red[0][threadIdx.x] = red[1][threadIdx.x] = 0.0f;
+  __syncthreads();
+  for (int c0 = 0; c0 < C; c0 += 128) {  // channel chunks of the block's width (one for C <= 128)
+    const int c = c0 + threadIdx.x;
+    const bool on = c < C;
+    const float gd = on ? go[g * C + c] / den : 0.0f, oc = on ? out[g * C + c] : 0.0f;
+    for (int j0 = 0; j0 < P; j0 += 4) {  // four rows' loads in flight
+      float ev[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        ev[u] = (on && grad_rel != nullptr && j0 + u < P) ? edge[(g * P + j0 + u) * C + c] : oc;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j < P) {  // (uniform)
+          if (on && grad_edge != nullptr) grad_edge[(g * P + j) * C + c] = gd * rl[j];
+          if (grad_rel != nullptr) {
+            const float acc = wave_sum(gd * (ev[u] - oc));
+            if (lane == 0) red[wv][j] += acc;  // (chunks in order: fixed summation order)
+          }
+        }
+      }
     }
   }
   if (grad_rel != nullptr) {
@@ -282,15 +334,26 @@ extern "C" int mpa_narrow_linear_relu_forward(const float* x, const float* w, co
   return mpa::check_launch("narrow_linear_relu_forward");
 }
 
-extern "C" int mpa_narrow_linear_relu_backward(const float* grad_out, const float* out, const float* x, const float* w,
-                                               int64_t R, int64_t K, int64_t N, float* grad_x, float* grad_w,
-                                               float* grad_b, void* stream) {
+extern "C" int mpa_narrow_linear_relu_workspace(int64_t R, int64_t K, int64_t N, int64_t* float_elems) {
+  MPA_REQUIRE(float_elems != nullptr, "narrow_linear_relu_workspace: null pointer");
   MPA_REQUIRE(R >= 1 && R <= (1 << 24) && K >= 1 && K <= kMaxK && N >= 1 && N <= (1 << 16),
-              "narrow_linear_relu_backward: R=%lld K=%lld (1..%d) N=%lld out of range", (long long)R, (long long)K, kMaxK,
-              (long long)N);
-  MPA_REQUIRE(grad_out && out && x && w && grad_w, "narrow_linear_relu_backward: null pointer");
-  launch(nl_bwd_kernel, dim3((unsigned)(R + (N + 63) / 64)), dim3(512), mpa::as_stream(stream), grad_out, out, x, w, (int)R,
-         (int)K, (int)N, grad_x, grad_w, grad_b);
+              "narrow_linear_relu: R=%lld K=%lld (1..%d) N=%lld out of range", (long long)R, (long long)K, kMaxK, (long long)N);
+  *float_elems = ((R + kNlRows - 1) / kNlRows) * N * (kMaxK + 1);  // the backward's per-chunk partial sums
+  return MPA_OK;
+}
+
+extern "C" int mpa_narrow_linear_relu_backward(const float* grad_out, const float* out, const float* x, const float* w,
+                                               int64_t R, int64_t K, int64_t N, float* ws, float* grad_x, float* grad_w,
+                                               float* grad_b, void* stream) {
+  int64_t nf;
+  if (int st = mpa_narrow_linear_relu_workspace(R, K, N, &nf)) return st;
+  MPA_REQUIRE(grad_out && out && x && w && ws && grad_w, "narrow_linear_relu_backward: null pointer");
+  hipStream_t s = mpa::as_stream(stream);
+  const int chunks = (int)((R + kNlRows - 1) / kNlRows);
+  launch(nl_bwd_kernel, dim3((unsigned)(R + ((N + 63) / 64) * chunks)), dim3(512), s, grad_out, out, x, w, (int)R, (int)K,
+         (int)N, grad_x, ws);
+  launch(nl_reduce_kernel, dim3((unsigned)((N * (K + 1) + 255) / 256)), dim3(256), s, (const float*)ws, chunks, (int)K, (int)N,
+         grad_w, grad_b);
   return mpa::check_launch("narrow_linear_relu_backward");
 }
 

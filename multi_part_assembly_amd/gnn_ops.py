@@ -44,11 +44,14 @@ class _NarrowLinearReLU(torch.autograd.Function):
         gw = bufs[0]
         gb = bufs[1] if ctx.has_bias else None
         grad_out = grad_out.contiguous()
+        n = ctypes.c_int64()
+        _lib.check(_lib.lib().mpa_narrow_linear_relu_workspace(R, K, N, ctypes.byref(n)), "mpa_narrow_linear_relu_workspace")
+        ws = torch.empty(n.value, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             tok = _lib.KernelTimer.start(f"narrow_linear_relu_backward[{R}x{K}x{N}]")
             st = _lib.lib().mpa_narrow_linear_relu_backward(
-                _lib.ptr(grad_out), _lib.ptr(out), _lib.ptr(x), _lib.ptr(weight), R, K, N, _lib.ptr(gx), _lib.ptr(gw),
-                _lib.ptr(gb), _lib.current_stream(x.device))
+                _lib.ptr(grad_out), _lib.ptr(out), _lib.ptr(x), _lib.ptr(weight), R, K, N, _lib.ptr(ws), _lib.ptr(gx),
+                _lib.ptr(gw), _lib.ptr(gb), _lib.current_stream(x.device))
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_narrow_linear_relu_backward")
         if direct:
