@@ -215,13 +215,17 @@ __device__ __forceinline__ void grid_assign_plan(const GridParams* __restrict__ 
 
 // exclusive scan of cnt[0..nkeys) in place, 1024 threads, PER consecutive keys per thread; returns through st_out
 // (nkeys + 1 entries).  WORK: also the prefix of ceil(count / kBatch) (ba_out) and the work list (wl_out).
+// The histogram lives in LDS with one pad word per 32 keys: the scan below has thread t walk keys 32 t .. 32 t + 31, which
+// unpadded puts all 64 lanes of every access on two banks.
+__device__ __forceinline__ int padk(int k) { return k + (k >> 5); }
+
 template <int PER, bool WORK>
 __device__ __forceinline__ void block_scan(int* __restrict__ cnt, int nkeys, int* __restrict__ st_out,
                                            int* __restrict__ ba_out, int* __restrict__ wl_out, int (*wsum)[2]) {
   const int base = threadIdx.x * PER;
   int sum = 0, bsum = 0;
   for (int k = 0; k < PER; ++k) {
-    const int v = base + k < nkeys ? cnt[base + k] : 0;
+    const int v = base + k < nkeys ? cnt[padk(base + k)] : 0;
     sum += v;
     bsum += (v + kBatch - 1) / kBatch;
   }
@@ -247,9 +251,8 @@ __device__ __forceinline__ void block_scan(int* __restrict__ cnt, int nkeys, int
   }
   for (int k = 0; k < PER; ++k) {
     if (base + k < nkeys) {
-      const int v = cnt[base + k];
-      cnt[base + k] = run;  // becomes the scatter cursor
-      st_out[base + k] = run;
+      const int v = cnt[padk(base + k)];
+      cnt[padk(base + k)] = run;  // becomes the scatter cursor
       if (WORK) {
         ba_out[base + k] = brun;
         for (int i = 0; i < (v + kBatch - 1) / kBatch; ++i) wl_out[brun + i] = base + k;  // work item -> super-cell
@@ -262,23 +265,39 @@ __device__ __forceinline__ void block_scan(int* __restrict__ cnt, int nkeys, int
     st_out[nkeys] = run;
     if (WORK) ba_out[nkeys] = brun;
   }
+  __syncthreads();
+  // the starts, coalesced (written from the loop above every store instruction touched 64 different cache lines)
+  for (int i = threadIdx.x; i < nkeys; i += 1024) st_out[i] = cnt[padk(i)];
 }
 
 // grid = 4*B (blockIdx.x = (b*2 + shape)*2 + role), block 1024: the two roles of a shape are sorted by different
 // blocks (each reads the shape's points itself: 240 KB from L2) — 128 instead of 64 blocks on 256 CUs, and neither
 // waits for the other's scan.
+constexpr int kSortU = 4;
 template <int ROLE>
-__device__ __forceinline__ void grid_sort_role(const float* __restrict__ vb, const float* __restrict__ shape, int P, int N,
+__device__ __forceinline__ void grid_sort_role(const float* __restrict__ vsm, const float* __restrict__ shape, int P, int N,
                                                const GridParams& g, int slot, int* __restrict__ starts,
                                                int* __restrict__ batches, int* __restrict__ worklist,
                                                float4* __restrict__ records, int rec_stride, int* cnt, int (*wsum)[2]) {
   const int nkeys = ROLE == 0 ? g.ncells : g.nsuper;
-  for (int i = threadIdx.x; i < nkeys; i += 1024) cnt[i] = 0;
+  for (int i = threadIdx.x; i < padk(nkeys) + 1; i += 1024) cnt[i] = 0;
   __syncthreads();
-  for (int p = 0; p < P; ++p) {
-    if (vb[p] == 0.0f) continue;
-    const float* cloud = shape + 3LL * p * N;
-    for (int n = threadIdx.x; n < N; n += 1024) atomicAdd(&cnt[key_of(g, ROLE, cloud[3 * n], cloud[3 * n + 1], cloud[3 * n + 2])], 1);
+  // all P * N point slots in one flat loop, kSortU loads per thread in flight (a loop over the parts was one dependent
+  // memory round trip per valid part and pass)
+  const int total = P * N;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 1024 * kSortU) {
+    float x[kSortU], y[kSortU], z[kSortU];
+    bool ok[kSortU];
+#pragma unroll
+    for (int u = 0; u < kSortU; ++u) {
+      const int i = i0 + 1024 * u;
+      ok[u] = i < total && vsm[i / N] != 0.0f;
+      const float* q = shape + 3LL * (ok[u] ? i : 0);
+      x[u] = q[0], y[u] = q[1], z[u] = q[2];
+    }
+#pragma unroll
+    for (int u = 0; u < kSortU; ++u)
+      if (ok[u]) atomicAdd(&cnt[padk(key_of(g, ROLE, x[u], y[u], z[u]))], 1);
   }
   __syncthreads();
   if (ROLE == 0)
@@ -293,13 +312,21 @@ __device__ __forceinline__ void grid_sort_role(const float* __restrict__ vb, con
     const float inf = __builtin_inff();
     out[g.nvalid + threadIdx.x] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
   }
-  for (int p = 0; p < P; ++p) {
-    if (vb[p] == 0.0f) continue;
-    const float* cloud = shape + 3LL * p * N;
-    for (int n = threadIdx.x; n < N; n += 1024) {
-      const float x = cloud[3 * n], y = cloud[3 * n + 1], z = cloud[3 * n + 2];
-      out[atomicAdd(&cnt[key_of(g, ROLE, x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(p * N + n));
+  for (int i0 = threadIdx.x; i0 < total; i0 += 1024 * kSortU) {
+    float x[kSortU], y[kSortU], z[kSortU];
+    bool ok[kSortU];
+#pragma unroll
+    for (int u = 0; u < kSortU; ++u) {
+      const int i = i0 + 1024 * u;
+      ok[u] = i < total && vsm[i / N] != 0.0f;
+      const float* q = shape + 3LL * (ok[u] ? i : 0);
+      x[u] = q[0], y[u] = q[1], z[u] = q[2];
     }
+#pragma unroll
+    for (int u = 0; u < kSortU; ++u)
+      if (ok[u])
+        out[atomicAdd(&cnt[padk(key_of(g, ROLE, x[u], y[u], z[u]))], 1)] =
+            make_float4(x[u], y[u], z[u], __int_as_float(i0 + 1024 * u));  // (the flat slot p * N + n)
   }
 }
 
@@ -314,12 +341,14 @@ __global__ __launch_bounds__(1024) void grid_sort_kernel(const float* __restrict
                                                          int* __restrict__ worklist, float4* __restrict__ records,
                                                          int rec_stride, unsigned* __restrict__ ticket,
                                                          XcdPlan* __restrict__ plan, int nwaves) {
-  __shared__ int cnt[kMaxCells];
+  __shared__ int cnt[kMaxCells + kMaxCells / 32 + 1];
   __shared__ int wsum[16][2];
   __shared__ GridParams gsm;
   __shared__ bool last;
+  __shared__ float vsm[64];  // the sample's valid flags
   const int role = blockIdx.x & 1, c = (blockIdx.x >> 1) & 1, b = blockIdx.x >> 2;
   const float* vb = valids + (long long)b * P;
+  if (threadIdx.x < 64) vsm[threadIdx.x] = (int)threadIdx.x < P ? vb[threadIdx.x] : 0.0f;
   // the sample's grid: boxes of its valid parts (one lane per part, P <= 64), then the closed-form parameters
   if (threadIdx.x < 64) {
     const int p = threadIdx.x;
@@ -359,8 +388,8 @@ __global__ __launch_bounds__(1024) void grid_sort_kernel(const float* __restrict
   }
   const int slot = (b * 2 + c) * 2 + role;
   const float* shape = (c == 0 ? S1 : S2) + 3LL * b * P * N;
-  if (role == 0) grid_sort_role<0>(vb, shape, P, N, g, slot, starts, batches, worklist, records, rec_stride, cnt, wsum);
-  else grid_sort_role<1>(vb, shape, P, N, g, slot, starts, batches, worklist, records, rec_stride, cnt, wsum);
+  if (role == 0) grid_sort_role<0>(vsm, shape, P, N, g, slot, starts, batches, worklist, records, rec_stride, cnt, wsum);
+  else grid_sort_role<1>(vsm, shape, P, N, g, slot, starts, batches, worklist, records, rec_stride, cnt, wsum);
   if (plan == nullptr) return;
   // the last block of the launch plans the search's waves: everybody's batch counts are in global memory by then
   __syncthreads();
