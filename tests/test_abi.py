@@ -45,6 +45,44 @@ def test_argument_validation_needs_no_gpu(built):
     assert L.mpa_pose_apply_forward(None, None, None, None, ctypes.c_float(0), 0, 10, None, None) == 0
 
 
+def test_graph_network_glue_validates_its_arguments(built):
+    """csrc/gnn_glue.hip: shapes outside the kernels' instantiation and null pointers are refused with a message, before
+    anything touches the device; the workspace queries are pure arithmetic."""
+    L = _lib.lib()
+    n = ctypes.c_int64()
+    assert L.mpa_narrow_linear_relu_workspace(640, 7, 256, ctypes.byref(n)) == 0 and n.value == 5 * 256 * 17
+    assert L.mpa_narrow_linear_relu_workspace(640, 17, 256, ctypes.byref(n)) == -1 and b"K=17" in L.mpa_last_error()
+    assert L.mpa_narrow_linear_relu_forward(None, None, None, 640, 17, 256, None, None) == -1
+    assert L.mpa_narrow_linear_relu_forward(None, None, None, 640, 7, 256, None, None) == -1
+    assert b"null" in L.mpa_last_error()
+    assert L.mpa_relation_head_workspace(12800, 512, ctypes.byref(n)) == 0 and n.value == 12800 + 800 * 513
+    assert L.mpa_relation_head_workspace(12800, 510, ctypes.byref(n)) == -1 and b"multiple of 4" in L.mpa_last_error()
+    assert L.mpa_relation_head_forward(None, None, None, None, 12800, 512, None, None, None) == -1
+    assert L.mpa_relation_mean_forward(None, None, 640, 65, 128, None, None) == -1 and b"P=65" in L.mpa_last_error()
+    assert L.mpa_relation_mean_backward(None, None, None, None, 640, 20, 128, None, None, None) == -1
+    assert L.mpa_pair_rows_forward(None, None, 32, 20, 126, 0, None, None) == -1 and b"F=126" in L.mpa_last_error()
+    assert L.mpa_pair_rows_backward(None, 32, 20, 128, 0, None, None, None) == -1 and b"null" in L.mpa_last_error()
+    # the pose head takes any input width now (odd widths are padded inside its workspace)
+    assert L.mpa_pose_head_workspace(640, 135, ctypes.byref(n)) == 0
+    assert n.value == 640 * 780 + 64 + 2 * (640 + 256) * 192
+    assert L.mpa_pose_head_workspace(640, 128, ctypes.byref(n)) == 0 and n.value == 640 * 780 + 64
+    assert L.mpa_pose_head_workspace(640, 0, ctypes.byref(n)) == -1
+
+
+def test_graph_network_glue_wrappers_reject_cpu_tensors():
+    import torch
+    from multi_part_assembly_amd import gnn_ops
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gnn_ops.narrow_linear_relu(torch.zeros(4, 7), torch.zeros(8, 7))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gnn_ops.relation_head(torch.zeros(4, 8), torch.zeros(1, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gnn_ops.relation_mean(torch.zeros(1, 2, 2, 4), torch.zeros(1, 2, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gnn_ops.pair_rows(torch.zeros(1, 2, 4), torch.zeros(1, 2, 4))
+
+
 def test_code_object_targets_gfx950_only(built):
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(built)],
                          capture_output=True, text=True).stdout
