@@ -110,6 +110,9 @@ struct Queue {
 #ifndef DG_CPC3
 #define DG_CPC3 4
 #endif
+#ifndef DG_T3     // C = 3 kernel: threads (= queries) per block.  tools/probes/knn3_time.hip at 353 x 1000 points, (T3, QN3, CPC3):
+#define DG_T3 256 // (256, 16, 4) 0.354 ms, (512, 16, 4) 0.349, (128, 16, 4) 0.466, (64, 16, 4) 0.571, (256, 24, 8) 0.365, (256, 32, 8) 0.458
+#endif
 
 __device__ __forceinline__ void queue_push(Queue& q, float s, int idx) {
   if (s > q.thr) {
@@ -172,24 +175,24 @@ __device__ __forceinline__ void knn_block(int& v, int& qb) {
 // x4 [R][4] (xyz0), idx [R][20] u16.  grid = (ceil(N / 256), parts), block 256: lane = query; the part's points
 // (+ their norms) sit in LDS and are read as broadcasts.
 template <typename IdxT>
-__global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ x4, int N, IdxT* __restrict__ idx,
-                                                   const int* __restrict__ hdr) {
+__global__ __launch_bounds__(DG_T3) void knn3_kernel(const float* __restrict__ x4, int N, IdxT* __restrict__ idx,
+                                                     const int* __restrict__ hdr) {
   __shared__ __attribute__((aligned(16))) float4 pts[kMaxN];  // x, y, z, |p|^2
   constexpr int QN = DG_QN3, CPC = DG_CPC3;
-  __shared__ float qs_[4][QN * 64];
-  __shared__ unsigned short qj_[4][QN * 64];
+  __shared__ float qs_[DG_T3 / 64][QN * 64];
+  __shared__ unsigned short qj_[DG_T3 / 64][QN * 64];
   int v, qb;
   knn_block(v, qb);
   if (v >= hdr[0]) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float4* xp = reinterpret_cast<const float4*>(x4) + (long long)v * N;
-  for (int p = threadIdx.x; p < N; p += 256) {
+  for (int p = threadIdx.x; p < N; p += DG_T3) {
     float4 t = xp[p];
     t.w = (t.x * t.x + t.y * t.y) + t.z * t.z;
     pts[p] = t;
   }
   __syncthreads();
-  const int qi = qb * 256 + threadIdx.x, qc = qi < N ? qi : N - 1;
+  const int qi = qb * DG_T3 + threadIdx.x, qc = qi < N ? qi : N - 1;
   const float4 me = pts[qc];
   Best b;
   best_init(b);
