@@ -1,0 +1,228 @@
+"""Randomised differential checks of the index-exact kernels, for a time budget on the GPU box (dev tool; the fixed cases
+live in tests/).  Every case draws its own sizes, masks and pose regime from the seed:
+
+  loss   grid-pruned whole-shape search vs the brute-force scan of the same library (MPA_SHAPE_SEARCH): arg-mins of both
+         directions bit-equal on the valid parts, the five loss terms within 2e-6;
+  chamfer  the Chamfer operator (three scan variants) vs oracle/chamfer_ref.c: distances and indices bit-equal;
+  knn    mpa_knn_exact (C = 3, 64, 128) vs oracle/knn_ref.c: every neighbour index, in order;
+  glue   the graph-network glue kernels vs float64 library ops.
+
+usage: python tools/fuzz_parity.py [seconds=240] [first_seed=0] [families, e.g. glue,knn]
+       -> one summary line per family, exit 1 on a mismatch
+"""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multi_part_assembly_amd import _lib, chamfer as C, synthetic  # noqa: E402
+from multi_part_assembly_amd.encoder import knn_exact  # noqa: E402
+from multi_part_assembly_amd.gnn_ops import narrow_linear_relu, pair_rows, relation_head, relation_mean  # noqa: E402
+from multi_part_assembly_amd.rotation import Rotation3D  # noqa: E402
+from oracle import chamfer as oc  # noqa: E402
+from oracle.knn import knn_exact as oracle_knn  # noqa: E402
+
+dev = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+only = sys.argv[3].split(",") if len(sys.argv) > 3 else None  # families to run (default: all)
+bad = []
+
+
+def raw_loss(batch, qp, tp, mode):
+    os.environ["MPA_SHAPE_SEARCH"] = mode
+    pcs, v = batch["part_pcs"], batch["part_valids"]
+    qg, tg = Rotation3D(batch["part_quat"]).rot.contiguous(), batch["part_trans"].contiguous()
+    B, P, N, _ = pcs.shape
+    L = _lib.lib()
+    nf, ni = ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(L.mpa_assembly_loss_workspace(B, P, N, ctypes.byref(nf), ctypes.byref(ni)), "ws")
+    fws = torch.full((nf.value,), float("nan"), device=dev)
+    iws = torch.full((ni.value,), 0x7F7F7F7F, dtype=torch.int32, device=dev)
+    losses = torch.empty(5, B, device=dev)
+    _lib.check(L.mpa_assembly_loss_forward(_lib.ptr(pcs), _lib.ptr(v), _lib.ptr(qp), _lib.ptr(tp), _lib.ptr(qg), _lib.ptr(tg),
+                                           B, P, N, 1, 0, _lib.ptr(fws), _lib.ptr(iws), _lib.ptr(losses),
+                                           _lib.current_stream(dev)), "fwd")
+    torch.cuda.synchronize()
+    pn = B * P * N
+    return losses, iws[2 * pn:3 * pn].view(B, P, N).clone(), iws[3 * pn:4 * pn].view(B, P, N).clone()
+
+
+def case_loss(rng):
+    B = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 33]))
+    P = int(rng.integers(1, 21))
+    N = int(rng.choice([16, 33, 64, 100, 255, 256, 500, 777, 1000, 1200]))
+    counts = [int(rng.integers(1, P + 1)) for _ in range(B)]
+    batch = synthetic.make_batch(B, P, N, seed=int(rng.integers(1 << 30)), device=dev, num_parts=counts,
+                                 preset=str(rng.choice(["everyday", "artifact"])))
+    if rng.random() < 0.3:  # valid flags that are not a prefix
+        v = batch["part_valids"]
+        for b in range(B):
+            perm = torch.randperm(P, generator=torch.Generator().manual_seed(int(rng.integers(1 << 30))))
+            v[b] = v[b][perm.to(v.device)]
+        if rng.random() < 0.3:
+            v[int(rng.integers(B))] = 0  # a sample with no valid part
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    spread = float(rng.choice([0.0, 0.02, 0.3, 1.0, 30.0]))
+    qp = torch.nn.functional.normalize(torch.randn(B, P, 4, generator=g), dim=-1).to(dev)
+    tp = (torch.randn(B, P, 3, generator=g) * spread).to(dev)
+    if rng.random() < 0.15:  # duplicated points: exact ties
+        batch["part_pcs"][:, :, 1::2] = batch["part_pcs"][:, :, 0::2][:, :, : batch["part_pcs"][:, :, 1::2].shape[2]]
+    lb, b1, b2 = raw_loss(batch, qp, tp, "brute")
+    lg, g1, g2 = raw_loss(batch, qp, tp, "grid")
+    valid = batch["part_valids"].bool()
+    ok = torch.equal(b1[valid], g1[valid]) and torch.equal(b2[valid], g2[valid])
+    fin = torch.isfinite(lb)
+    ok = ok and bool(torch.equal(fin, torch.isfinite(lg)))
+    ok = ok and bool(((lg[fin] - lb[fin]).abs() <= 2e-6 * lb[fin].abs() + 1e-9).all())
+    return ok, f"B={B} P={P} N={N} spread={spread}"
+
+
+def case_chamfer(rng):
+    B = int(rng.integers(1, 6))
+    n1, n2 = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
+    a = rng.standard_normal((B, n1, 3)).astype(np.float32) * float(rng.choice([1e-3, 1.0, 100.0]))
+    b = rng.standard_normal((B, n2, 3)).astype(np.float32) * float(rng.choice([1e-3, 1.0, 100.0]))
+    if rng.random() < 0.3:
+        b[:, : min(n1, n2)] = a[:, : min(n1, n2)]  # zero distances and ties
+    if rng.random() < 0.2:
+        a = np.round(a * 4) / 4  # lattice: many exact ties
+        b = np.round(b * 4) / 4
+    ref = oc.chamfer_forward(a, b)
+    ok = True
+    for variant in (0, 1, 2):
+        out = C.chamfer_forward(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), variant=variant)
+        ok = ok and all(np.array_equal(g.cpu().numpy(), w) for g, w in zip(out, ref))
+    return ok, f"B={B} n1={n1} n2={n2}"
+
+
+def case_knn(rng):
+    Cw = int(rng.choice([3, 3, 64, 128]))
+    n, N = int(rng.integers(1, 6)), int(rng.integers(20, 1025))
+    x = torch.from_numpy(rng.standard_normal((n, N, Cw)).astype(np.float32)) * (0.3 if Cw == 3 else 1.0)
+    if Cw > 3 and rng.random() < 0.5:
+        x = torch.where(x > 0, x, 0.2 * x)  # activations after a LeakyReLU, as the encoder's stages see them
+    if rng.random() < 0.15:
+        x[:, 1::2] = x[:, 0::2][:, : x[:, 1::2].shape[1]]  # duplicated points
+    rows = x.reshape(n * N, Cw)
+    if Cw == 3:
+        rows = torch.cat([rows, torch.zeros(n * N, 1)], dim=1)
+    got = knn_exact(rows.to(dev).contiguous(), n, N, Cw).cpu().view(n, N, 20).long()
+    want = torch.from_numpy(oracle_knn(x.numpy())).long()
+    return bool(torch.equal(got, want)), f"C={Cw} n={n} N={N}"
+
+
+def case_glue(rng):
+    rel = lambda a, b: float((a.double() - b).abs().max() / (b.abs().max() + 1e-12))
+    fails = []
+
+    def check(name, got, want, tol, lib32=None, scale=None, flips=0):
+        """Within tol (relative to the largest entry) of float64.  For sums that cancel, `scale` is the entry-wise sum of
+        the absolute addends (the error of ANY float32 evaluation is relative to that) or `lib32` the float32 library
+        result (no further from float64 than twice that); `flips`: entries a ReLU on the rounding edge may move."""
+        d = (got.double() - want).abs()
+        lim = tol * want.abs().max() + 1e-12
+        if scale is not None:
+            lim = lim + 1e-5 * scale
+        nbad = int((d > lim).sum())
+        if nbad == 0 or nbad <= flips:
+            return
+        if lib32 is not None and float(d.max()) <= 2.0 * float((lib32.double() - want).abs().max()) + 1e-12:
+            return
+        fails.append(f"{name} {rel(got, want):.1e} ({nbad} entries)")
+
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    R, K, N = int(rng.integers(1, 900)), int(rng.integers(1, 17)), int(rng.integers(1, 400))
+    x = torch.randn(R, K, generator=g).to(dev).requires_grad_()
+    w = torch.randn(N, K, generator=g).to(dev).requires_grad_()
+    b = torch.randn(N, generator=g).to(dev).requires_grad_()
+    go = torch.randn(R, N, generator=g).to(dev)
+    out = narrow_linear_relu(x, w, b)
+    out.backward(go)
+    xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+    want = torch.relu(xd @ wd.t() + bd)
+    want.backward(go.double())
+    x3, w3, b3 = (t.detach().clone().requires_grad_() for t in (x, w, b))
+    torch.relu(x3 @ w3.t() + b3).backward(go)  # float32 library ops: a ReLU on the rounding edge flips there too
+    check("nl out", out.detach(), want.detach(), 1e-5)
+    check("nl gx", x.grad, xd.grad, 1e-4, x3.grad, flips=2 * K)   # (one or two flipped (row, channel) entries)
+    check("nl gw", w.grad, wd.grad, 1e-4, w3.grad, flips=2 * K)
+    check("nl gb", b.grad, bd.grad, 1e-4, b3.grad, flips=2)
+    S, P, F = int(rng.integers(1, 9)), int(rng.integers(1, 25)), 4 * int(rng.integers(1, 40))
+    a = torch.randn(S, P, F, generator=g).to(dev).requires_grad_()
+    c = torch.randn(S, P, F, generator=g).to(dev).requires_grad_()
+    gw = torch.randn(S, P, P, 2 * F, generator=g).to(dev)
+    swap = bool(rng.random() < 0.5)
+    pr = pair_rows(a, c, swap=swap)
+    pr.backward(gw)
+    ad, cd = a.detach().double().requires_grad_(), c.detach().double().requires_grad_()
+    halves = [ad[:, :, None].expand(S, P, P, F), cd[:, None].expand(S, P, P, F)]
+    wantp = torch.cat(halves[::-1] if swap else halves, dim=-1)
+    wantp.backward(gw.double())
+    if not torch.equal(pr.detach().double(), wantp.detach()):
+        fails.append("pr out")
+    check("pr ga", a.grad, ad.grad, 1e-5)
+    check("pr gb", c.grad, cd.grad, 1e-5)
+    Cc = int(rng.integers(1, 300))
+    e = torch.randn(S, P, P, Cc, generator=g).to(dev).requires_grad_()
+    r = (torch.rand(S, P, P, generator=g) * (torch.rand(S, P, P, generator=g) < 0.7)).to(dev).requires_grad_()
+    gm = torch.randn(S, P, Cc, generator=g).to(dev)
+    rm = relation_mean(e, r)
+    rm.backward(gm)
+    ed, rd = e.detach().double().requires_grad_(), r.detach().double().requires_grad_()
+    wantm = (ed * rd[..., None]).sum(dim=2) / (rd.sum(dim=-1, keepdim=True) + 1e-6)
+    wantm.backward(gm.double())
+    e3, r3 = e.detach().clone().requires_grad_(), r.detach().clone().requires_grad_()
+    ((e3 * r3[..., None]).sum(dim=2) / (r3.sum(dim=-1, keepdim=True) + 1e-6)).backward(gm)
+    check("rm out", rm.detach(), wantm.detach(), 1e-5)
+    check("rm ge", e.grad, ed.grad, 1e-5)
+    # (a row with ONE weight: the weight's gradient is the difference of two equal sums — any float32 evaluation is only
+    # accurate relative to the sum of the absolute addends)
+    den = rd.detach().sum(dim=-1, keepdim=True) + 1e-6
+    addends = ((gm.double() / den)[:, :, None, :].abs() * (ed.detach().abs() + wantm.detach().abs()[:, :, None, :])).sum(-1)
+    check("rm gr", r.grad, rd.grad, 1e-4, r3.grad, scale=addends)
+    Rh, Kh = int(rng.integers(1, 3000)), 4 * int(rng.integers(1, 200))
+    h = torch.randn(Rh, Kh, generator=g).to(dev).requires_grad_()
+    wh = (torch.randn(1, Kh, generator=g) * 0.1).to(dev).requires_grad_()
+    bh = torch.randn(1, generator=g).to(dev).requires_grad_()
+    mk = (torch.rand(Rh, generator=g) < 0.6).float().to(dev)
+    gh = torch.randn(Rh, generator=g).to(dev)
+    rh = relation_head(h, wh, bh, mk)
+    rh.backward(gh)
+    hd, whd, bhd = (t.detach().double().requires_grad_() for t in (h, wh, bh))
+    wanth = torch.sigmoid(hd @ whd.t() + bhd).view(-1) * mk.double()
+    wanth.backward(gh.double())
+    check("rh out", rh.detach(), wanth.detach(), 1e-5)
+    check("rh gh", h.grad, hd.grad, 1e-4)
+    dzs = (gh.double() * mk.double() * (torch.sigmoid(hd.detach() @ whd.detach().t() + bhd.detach()).view(-1)
+                                        * (1 - torch.sigmoid(hd.detach() @ whd.detach().t() + bhd.detach()).view(-1)))).abs()
+    check("rh gw", wh.grad, whd.grad, 1e-4, scale=(dzs[:, None] * hd.detach().abs()).sum(0, keepdim=True))
+    check("rh gb", bh.grad, bhd.grad, 1e-4, scale=dzs.sum().view(1))
+    return not fails, f"nl {R}x{K}x{N} pr {S}x{P}x{F} rm C={Cc} rh {Rh}x{Kh}: {fails}"
+
+
+families = [("loss", case_loss), ("chamfer", case_chamfer), ("knn", case_knn), ("glue", case_glue)]
+counts = {k: 0 for k, _ in families}
+t_end = time.time() + budget
+seed = seed0
+while time.time() < t_end:
+    for fam, (name, fn) in enumerate(families):
+        if only is not None and name not in only:
+            continue
+        rng = np.random.default_rng([seed, fam])
+        try:
+            ok, what = fn(rng)
+        except Exception as exc:  # a refused shape is a finding too
+            ok, what = False, f"exception {type(exc).__name__}: {exc}"
+        counts[name] += 1
+        if not ok:
+            bad.append((name, seed, what))
+            print(f"MISMATCH {name} seed {seed}: {what}", flush=True)
+    seed += 1
+for name, _ in families:
+    print(f"{name}: {counts[name]} random cases (seeds {seed0}..{seed - 1}), {sum(1 for b in bad if b[0] == name)} mismatches")
+sys.exit(1 if bad else 0)
