@@ -171,6 +171,8 @@ int mpa_assembly_loss_backward(const float* grad_losses, const float* part_pcs, 
  * arrays of 5 DEVICE pointers each.  training != 0: batch statistics (biased variance) and running
  * statistics updated in place with `momentum` (unbiased variance), else running statistics.
  * feat [M,F].  Workspaces sized by mpa_pointnet_workspace must stay untouched until backward.
+ * A call in which NO part is valid returns zero features, leaves the running statistics untouched and its backward
+ * writes zero gradients (the reference's BatchNorm would refuse the empty batch).
  * ---------------------------------------------------------------------------------------------- */
 int mpa_pointnet_workspace(int64_t M, int64_t N, int64_t F, int64_t* float_elems, int64_t* int_elems);
 int mpa_pointnet_forward(const float* points, const float* valids, const float* const* conv_w,

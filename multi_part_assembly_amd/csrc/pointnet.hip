@@ -126,6 +126,13 @@ __global__ __launch_bounds__(64 * kSlices) void pn_bn_finalize_kernel(
   if (!reduce_partials(partial, valids, M, splits, C, c, cw, s, ss)) return;
   if (threadIdx.x >= 64) return;
   const double n = (double)count[0];
+  if (n == 0.0) {  // no valid part in the whole call (the reference's BatchNorm would refuse an empty batch): a neutral
+    bn[c] = 0.0f;  // map, running statistics untouched — every output row is a padded part's zero row anyway, and the
+    bn[C + c] = beta[c];  // backward pass then produces zero gradients instead of 0 / 0
+    bn[2 * C + c] = 0.0f;
+    bn[3 * C + c] = 0.0f;
+    return;
+  }
   const double mean = s / n;
   double var = ss / n - mean * mean;  // biased: what BatchNorm normalises with
   if (var < 0.0) var = 0.0;
@@ -162,6 +169,10 @@ __device__ __forceinline__ void write_coef(float* __restrict__ coef, int C, int 
                                            const float* __restrict__ bn, double s1, double s2, double n) {
   const float mean = bn[2 * C + c], invstd = bn[3 * C + c];
   const float alpha = gamma * invstd;
+  if (n == 0.0) {  // no valid part: nothing to differentiate
+    coef[c] = coef[C + c] = coef[2 * C + c] = 0.0f;
+    return;
+  }
   const float gammap = (float)(-(double)alpha * s2 / n * (double)invstd);
   coef[c] = alpha;
   coef[C + c] = gammap;

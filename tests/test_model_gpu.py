@@ -261,6 +261,31 @@ def test_transformer_and_pose_head_full_size_match_library_ops(cuda_device):
     assert torch.equal(f1, f2) and torch.equal(gx1, gx2) and all(torch.equal(g1[k], g2[k]) for k in g1)
 
 
+@pytest.mark.parametrize("arch,N", [("pointnet", 333), ("dgcnn", 200)])
+def test_encoders_without_any_valid_part_give_zeros(cuda_device, arch, N):
+    """A call in which every part is padding (found by tools/fuzz_parity.py: PointNet's BatchNorm divided by the zero
+    count and returned NaN gradients): zero features, zero — finite — parameter gradients, running statistics untouched;
+    the reference's BatchNorm would refuse the empty batch (modules/encoder/pointnet.py:45-55 on a [0, 3, N] input)."""
+    from multi_part_assembly_amd.encoder import build_encoder
+    torch.manual_seed(0)
+    enc = build_encoder(arch, 128).to(cuda_device).train()
+    before = {k: v.clone() for k, v in enc.state_dict().items() if "running" in k}
+    pts = torch.randn(3, N, 3, device=cuda_device)
+    out = enc.forward_parts(pts, torch.zeros(3, device=cuda_device))
+    (out + 1.0).square().sum().backward()
+    assert float(out.abs().max()) == 0.0
+    for k, p in enc.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) == 0.0, k
+    for k, v in enc.state_dict().items():
+        if "running" in k:
+            assert torch.equal(v, before[k]), k
+    # and a mixed call still matches the compacted one (the guard does not touch the regular path)
+    v = torch.tensor([0.0, 1.0, 0.0], device=cuda_device)
+    enc.zero_grad()
+    mixed = enc.forward_parts(pts, v)
+    assert float(mixed[0].abs().max()) == 0.0 and float(mixed[1].abs().max()) > 0.0
+
+
 def test_pose_head_odd_input_width_matches_library_ops(cuda_device):
     """Input widths that are not multiples of 64 (semantic models append P labels and 32 noise channels; the
     refinement model appends the 7-d pose) run on the HIP head, which zero-pads its panels inside the workspace."""

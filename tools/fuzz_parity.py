@@ -5,7 +5,9 @@ live in tests/).  Every case draws its own sizes, masks and pose regime from the
          directions bit-equal on the valid parts, the five loss terms within 2e-6;
   chamfer  the Chamfer operator (three scan variants) vs oracle/chamfer_ref.c: distances and indices bit-equal;
   knn    mpa_knn_exact (C = 3, 64, 128) vs oracle/knn_ref.c: every neighbour index, in order;
-  glue   the graph-network glue kernels vs float64 library ops.
+  glue   the graph-network glue kernels vs float64 library ops;
+  repro  bit-reproducibility: forward + backward of every module of the path (both encoders, transformer, pose head, MLP layer,
+         GRU recurrence, fused loss) run twice on the same inputs — outputs and every gradient bit-equal.
 
 usage: python tools/fuzz_parity.py [seconds=240] [first_seed=0] [families, e.g. glue,knn]
        -> one summary line per family, exit 1 on a mismatch
@@ -205,7 +207,113 @@ def case_glue(rng):
     return not fails, f"nl {R}x{K}x{N} pr {S}x{P}x{F} rm C={Cc} rh {Rh}x{Kh}: {fails}"
 
 
-families = [("loss", case_loss), ("chamfer", case_chamfer), ("knn", case_knn), ("glue", case_glue)]
+def case_repro(rng):
+    from multi_part_assembly_amd.encoder import DGCNN, PointNet
+    from multi_part_assembly_amd.gru import gru_recurrent
+    from multi_part_assembly_amd.loss import geometric_assembly_loss
+    from multi_part_assembly_amd.mlp import mlp_layer
+    from multi_part_assembly_amd.regressor import PoseRegressor
+    from multi_part_assembly_amd.transformer import TransformerEncoder
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    fails = []
+
+    def twice(name, module_params, run):
+        res = []
+        for _ in range(2):
+            for p in module_params:
+                p.grad = None
+            outs, leaves = run()
+            res.append([o.detach().clone() for o in outs] + [t.grad.clone() for t in leaves if t.grad is not None]
+                       + [p.grad.clone() for p in module_params if p.grad is not None])
+        if len(res[0]) != len(res[1]) or not all(torch.equal(a, b) for a, b in zip(*res)):
+            fails.append(name)
+
+    which = int(rng.integers(0, 6))
+    if which == 0:
+        M, N, F = int(rng.integers(1, 12)), int(rng.choice([64, 333, 1000])), int(rng.choice([128, 256]))
+        enc = PointNet(F).to(dev).train()
+        pts = torch.randn(M, N, 3, generator=g).to(dev)
+        v = (torch.rand(M, generator=g) < 0.8).float().to(dev)
+        w = torch.randn(M, F, generator=g).to(dev)
+
+        def run():
+            out = enc.forward_parts(pts, v)
+            (out * w).sum().backward()
+            return [out], []
+        twice(f"pointnet {M}x{N}x{F}", list(enc.parameters()), run)
+    elif which == 1:
+        M, N, F = int(rng.integers(1, 8)), int(rng.choice([40, 200, 1000])), int(rng.choice([64, 128]))
+        enc = DGCNN(F).to(dev).train()
+        pts = (torch.randn(M, N, 3, generator=g) * 0.3).to(dev)
+        v = (torch.rand(M, generator=g) < 0.8).float().to(dev)
+        w = torch.randn(M, F, generator=g).to(dev)
+
+        def run():
+            out = enc.forward_parts(pts, v)
+            (out * w).sum().backward()
+            return [out], []
+        twice(f"dgcnn {M}x{N}x{F}", list(enc.parameters()), run)
+    elif which == 2:
+        B, P, D = int(rng.integers(1, 33)), int(rng.integers(2, 21)), int(rng.choice([64, 128, 256]))
+        tf = TransformerEncoder(D, int(rng.choice([4, 8])), 4 * D, int(rng.integers(1, 5)), norm_first=True, dropout=0.0).to(dev).train()
+        head = PoseRegressor(D + int(rng.choice([0, 7, 39]))).to(dev).train()
+        x = torch.randn(B, P, D, generator=g).to(dev).requires_grad_()
+        extra = torch.randn(B, P, head.fc_layers[0].in_features - D, generator=g).to(dev)
+        valid = (torch.arange(P)[None] < torch.randint(1, P + 1, (B, 1), generator=g)).to(dev)
+
+        def run():
+            x.grad = None
+            rot, trans = head(torch.cat([tf(x, valid), extra], dim=-1))
+            (rot.sum() + trans.square().sum()).backward()
+            return [rot, trans], [x]
+        twice(f"transformer + head {B}x{P}x{D}", list(tf.parameters()) + list(head.parameters()), run)
+    elif which == 3:
+        R, K, N = int(rng.integers(1, 3000)), 64 * int(rng.integers(1, 9)), 64 * int(rng.integers(1, 9))
+        lin = torch.nn.Linear(K, N).to(dev)
+        bn = torch.nn.BatchNorm1d(N).to(dev).train() if rng.random() < 0.7 and R > 1 else None
+        x = torch.randn(R, K, generator=g).to(dev).requires_grad_()
+        w = torch.randn(R, N, generator=g).to(dev)
+
+        def run():
+            x.grad = None
+            if bn is not None:
+                bn.running_mean.zero_(), bn.running_var.fill_(1.0), bn.num_batches_tracked.zero_()
+            out = mlp_layer(x, lin.weight, lin.bias, bn, relu=True)
+            (out * w).sum().backward()
+            return [out], [x]
+        twice(f"mlp layer {R}x{K}x{N}", list(lin.parameters()) + (list(bn.parameters()) if bn is not None else []), run)
+    elif which == 4:
+        H, B, T = int(rng.choice([128, 256])), int(rng.integers(1, 41)), int(rng.integers(1, 30))
+        gi = torch.randn(2, B, T, 3 * H, generator=g).to(dev).requires_grad_()
+        h0 = torch.randn(2, B, H, generator=g).to(dev)
+        whh = (torch.randn(2, 3 * H, H, generator=g) * 0.05).to(dev).requires_grad_()
+        bhh = torch.randn(2, 3 * H, generator=g).to(dev).requires_grad_()
+        w = torch.randn(2, B, T, H, generator=g).to(dev)
+
+        def run():
+            gi.grad = whh.grad = bhh.grad = None
+            out = gru_recurrent(gi, h0, whh, bhh)
+            (out * w).sum().backward()
+            return [out], [gi, whh, bhh]
+        twice(f"gru {H}x{B}x{T}", [], run)
+    else:
+        B, P, N = int(rng.integers(1, 17)), int(rng.integers(1, 21)), int(rng.choice([64, 500, 1000]))
+        batch = synthetic.make_batch(B, P, N, seed=int(rng.integers(1 << 30)), device=dev,
+                                     num_parts=[int(rng.integers(1, P + 1)) for _ in range(B)])
+        q = torch.nn.functional.normalize(torch.randn(B, P, 4, generator=g), dim=-1).to(dev).requires_grad_()
+        t = (torch.randn(B, P, 3, generator=g) * 0.4).to(dev).requires_grad_()
+
+        def run():
+            q.grad = t.grad = None
+            terms, _ = geometric_assembly_loss(batch["part_pcs"], t, Rotation3D(q), batch["part_trans"],
+                                               Rotation3D(batch["part_quat"]), batch["part_valids"], training=True)
+            sum(v.sum() for v in terms.values()).backward()
+            return list(terms.values()), [q, t]
+        twice(f"loss {B}x{P}x{N}", [], run)
+    return not fails, str(fails)
+
+
+families = [("loss", case_loss), ("chamfer", case_chamfer), ("knn", case_knn), ("glue", case_glue), ("repro", case_repro)]
 counts = {k: 0 for k, _ in families}
 t_end = time.time() + budget
 seed = seed0
