@@ -9,6 +9,9 @@ live in tests/).  Every case draws its own sizes, masks and pose regime from the
   nets   PointNet (random part counts, masks, point counts, negative / zero BatchNorm weights) and transformer + pose head
          (random widths, depths, masks, odd head widths) vs oracle/nets.py evaluated in float64: features and every
          gradient within 2e-4, or no further from float64 than twice the float32 oracle is;
+  dgcnn  the one-call DGCNN encoder (random part counts, 20-400 points, widths 64 / 128 / 256, negative BatchNorm weights) vs
+         the reference's edge-tensor formulation in float64 on the graphs the encoder itself built (read back): features,
+         input and parameter gradients, same bounds and conditioning check as `nets`;
   repro  bit-reproducibility: forward + backward of every module of the path (both encoders, transformer, pose head, MLP layer,
          GRU recurrence, fused loss) run twice on the same inputs — outputs and every gradient bit-equal.
 
@@ -318,6 +321,85 @@ def case_nets(rng):
     return not fails, what + ": " + str(fails)
 
 
+def case_dgcnn(rng):
+    import copy
+    import torch.nn.functional as Fn
+    from multi_part_assembly_amd.encoder import DGCNN
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12))
+    n, N, feat = int(rng.integers(1, 6)), int(rng.integers(20, 401)), int(rng.choice([64, 128, 256]))
+    enc = DGCNN(feat)
+    with torch.no_grad():
+        for m in enc.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.weight[::5] *= -1.0  # negative scales take the min branch of the aggregation
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    enc = enc.to(dev).train()
+    x = (torch.randn(n, N, 3, generator=g) * 0.2).to(dev)
+    w = torch.randn(n, feat, generator=g).to(dev)
+    xa = x.clone().requires_grad_()
+    enc.graph_hooks = {"export": True}
+    out = enc(xa)
+    (out * w).sum().backward()
+    graphs = [t.clone() for t in enc.graph_hooks["exported"]]
+    enc.graph_hooks = None
+
+    def formulation(ref, xin):  # dgcnn.py:8-109 on materialised edge tensors, graphs given
+        h, stages = xin, []
+        for l, conv in enumerate((ref.conv1, ref.conv2, ref.conv3, ref.conv4)):
+            C = h.shape[-1]
+            idx = graphs[l].view(n, N, 20).long()
+            flat = (idx + torch.arange(n, device=dev).view(-1, 1, 1) * N).view(-1)
+            nbr = h.reshape(n * N, C)[flat].view(n, N, 20, C)
+            ctr = h[:, :, None].expand(n, N, 20, C)
+            edge = torch.cat((nbr - ctr, ctr), dim=3).permute(0, 3, 1, 2)
+            bn = conv[1]
+            e = Fn.leaky_relu(Fn.batch_norm(Fn.conv2d(edge, conv[0].weight), None, None, bn.weight, bn.bias, True, 0.1, bn.eps), 0.2)
+            h = e.max(dim=-1)[0].permute(0, 2, 1)
+            stages.append(h)
+        y = Fn.conv1d(torch.cat(stages, dim=2).permute(0, 2, 1), ref.conv5[0].weight)
+        y = Fn.leaky_relu(Fn.batch_norm(y, None, None, ref.bn5.weight, ref.bn5.bias, True, 0.1, ref.bn5.eps), 0.2)
+        return ref.out_fc(torch.cat((y.max(dim=-1)[0], y.mean(dim=-1)), dim=1))
+
+    def run(dtype, jitter=0.0):
+        ref = copy.deepcopy(enc).to(dtype)
+        ref.zero_grad()
+        xin = x.detach().to(dtype).clone()
+        if jitter:
+            xin = xin * (1.0 + jitter * torch.randn(xin.shape, generator=g).to(dev).to(dtype))
+        xin = xin.requires_grad_()
+        o = formulation(ref, xin)
+        (o * w.to(dtype)).sum().backward()
+        return o.detach(), xin.grad, {k: p.grad for k, p in ref.named_parameters()}
+
+    o32, gx32, p32 = run(torch.float32)
+    o64, gx64, p64 = run(torch.float64)
+    fails = []
+
+    def check(name, hip, a32, a64, tol):
+        e, e32 = rel(hip, a64), rel(a32, a64)
+        if not (e < tol or e <= 2.0 * e32 + 1e-6):
+            fails.append(f"{name} {e:.1e} (float32 formulation {e32:.1e})")
+
+    check("feat", out.detach(), o32, o64, 2e-4)
+    check("grad x", xa.grad, gx32, gx64, 1e-3)
+    for k, p in enc.named_parameters():
+        if p.grad is None or p64[k] is None:
+            if (p.grad is None) != (p64[k] is None):
+                fails.append(f"grad {k}: present on one side only")
+            continue
+        check("grad " + k, p.grad, p32[k], p64[k], 1e-3)
+    if fails:  # a max over the 20 neighbours / a LeakyReLU on the rounding edge?
+        for trial in range(10):
+            _, gj, pj = run(torch.float64, 2e-6 if trial < 5 else 2e-5)
+            if rel(gj, gx64) > 1e-3 or any(rel(pj[k], p64[k]) > 1e-3 for k in p64 if p64[k] is not None):
+                edge.append(f"dgcnn {n}x{N}x{feat}")
+                fails.clear()
+                break
+    return not fails, f"dgcnn {n}x{N}x{feat}: {fails}"
+
+
 def case_repro(rng):
     from multi_part_assembly_amd.encoder import DGCNN, PointNet
     from multi_part_assembly_amd.gru import gru_recurrent
@@ -425,7 +507,7 @@ def case_repro(rng):
 
 
 families = [("loss", case_loss), ("chamfer", case_chamfer), ("knn", case_knn), ("glue", case_glue), ("repro", case_repro),
-            ("nets", case_nets)]
+            ("nets", case_nets), ("dgcnn", case_dgcnn)]
 counts = {k: 0 for k, _ in families}
 t_end = time.time() + budget
 seed = seed0
@@ -445,7 +527,7 @@ while time.time() < t_end:
             print(f"MISMATCH {name} seed {seed}: {what}", flush=True)
     seed += 1
 if edge:
-    print(f"nets: {len(edge)} cases set aside: the float64 oracle's own gradients move by > 1e-3 under a 2e-6 .. 2e-5 relative input change "
+    print(f"nets / dgcnn: {len(edge)} cases set aside: the float64 oracle's own gradients move by > 1e-3 under a 2e-6 .. 2e-5 relative input change "
           f"(a ReLU / max on the rounding edge)")
 for name, _ in families:
     print(f"{name}: {counts[name]} random cases (seeds {seed0}..{seed - 1}), {sum(1 for b in bad if b[0] == name)} mismatches")
