@@ -12,6 +12,10 @@ live in tests/).  Every case draws its own sizes, masks and pose regime from the
   dgcnn  the one-call DGCNN encoder (random part counts, 20-400 points, widths 64 / 128 / 256, negative BatchNorm weights) vs
          the reference's edge-tensor formulation in float64 on the graphs the encoder itself built (read back): features,
          input and parameter gradients, same bounds and conditioning check as `nets`;
+  step   a whole training step (forward, five-term loss, backward) of PNTransformer + PointNet — random batch sizes, part
+         counts, point counts, widths, depths — vs oracle/nets.py (pn_transformer_loss) in float64: loss and every
+         parameter gradient, same bounds and conditioning check;
+  gnn    the same for DGL (three GNN iterations) on either encoder vs oracle/callers.py (dgl_loss);
   repro  bit-reproducibility: forward + backward of every module of the path (both encoders, transformer, pose head, MLP layer,
          GRU recurrence, fused loss) run twice on the same inputs — outputs and every gradient bit-equal.
 
@@ -400,6 +404,89 @@ def case_dgcnn(rng):
     return not fails, f"dgcnn {n}x{N}x{feat}: {fails}"
 
 
+def _whole_step(rng, g, cfg, B, P, N, oracle_total, label):
+    """forward_pass + backward of build_model(cfg) on the HIP path against oracle_total(sd, cpu_batch) -> scalar in float64."""
+    from multi_part_assembly_amd.pn_transformer import build_model
+    rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).abs().max() / (b.double().abs().max() + 1e-12))
+    model = build_model(cfg)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    names = [k for k, _ in model.named_parameters()]
+    batch = synthetic.make_batch(B, P, N, preset="everyday", seed=int(rng.integers(1 << 30)), device=dev,
+                                 num_parts=[int(rng.integers(2, P + 1)) for _ in range(B)])
+    batch.pop("num_parts", None)
+    model.to(dev).train()
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    hip = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters() if p.grad is not None}
+
+    def oracle(dt, jitter=0.0):
+        sd = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        params = {k: sd[k].requires_grad_() for k in names}
+        cb = {k: (v.cpu().to(dt) if v.is_floating_point() else v.cpu()) for k, v in batch.items() if hasattr(v, "cpu")}
+        if jitter:
+            cb["part_pcs"] = cb["part_pcs"] * (1.0 + jitter * torch.randn(cb["part_pcs"].shape, generator=g).to(dt))
+        total = oracle_total(sd, cb)
+        total.backward()
+        return float(total.detach()), {k: p.grad.double() for k, p in params.items() if p.grad is not None}
+
+    l32, g32 = oracle(torch.float32)
+    l64, g64 = oracle(torch.float64)
+    fails = []
+    if abs(float(loss.detach()) - l64) > 2.0 * abs(l32 - l64) + 1e-4 * abs(l64):
+        fails.append(f"loss {float(loss.detach()):.7f} vs {l64:.7f} (float32 oracle {l32:.7f})")
+    for k, b in g64.items():
+        if float(b.abs().max()) < 1e-10:  # a bias in front of a BatchNorm: structurally zero
+            continue
+        if k not in hip:
+            fails.append(f"grad {k} missing")
+            continue
+        e, e32 = rel(hip[k], b), rel(g32[k], b)
+        if not (e < 2e-4 or e <= 2.0 * e32 + 1e-6):
+            fails.append(f"grad {k} {e:.1e} (float32 oracle {e32:.1e})")
+    if fails:  # a nearest neighbour of the Chamfer matching, a kNN graph, a max over the points or a ReLU on the rounding edge?
+        for trial in range(8):
+            _, gj = oracle(torch.float64, 2e-6 if trial < 4 else 2e-5)
+            if any(rel(gj[k], g64[k]) > 1e-3 for k in g64 if float(g64[k].abs().max()) >= 1e-10):
+                edge.append(f"{label} {B}x{P}x{N}")
+                fails.clear()
+                break
+    return not fails, f"{label} B={B} P={P} N={N}: {fails[:6]}"
+
+
+def case_step(rng):
+    from multi_part_assembly_amd import config
+    from oracle import nets as on
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    B, P, N = int(rng.integers(1, 5)), int(rng.integers(2, 9)), int(rng.choice([32, 64, 100, 200]))
+    cfg = config.pn_transformer_everyday()
+    cfg.model.pc_feat_dim = int(rng.choice([128, 256]))
+    cfg.model.transformer_heads = int(rng.choice([4, 8]))
+    cfg.model.transformer_feat_dim = int(rng.choice([256, 512]))
+    cfg.model.transformer_layers = int(rng.integers(1, 4))
+    cfg.data.max_num_part = P
+    return _whole_step(rng, g, cfg, B, P, N,
+                       lambda sd, cb: on.pn_transformer_loss(sd, cb, cfg.model.transformer_layers, cfg.model.transformer_heads)[0]["loss"],
+                       f"pn_transformer D={cfg.model.pc_feat_dim} L={cfg.model.transformer_layers}")
+
+
+def case_gnn(rng):
+    from multi_part_assembly_amd import config
+    from oracle import callers as oc
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    B, P, N = int(rng.integers(1, 4)), int(rng.integers(2, 9)), int(rng.choice([32, 64, 100, 200]))
+    cfg = config.dgl_dgcnn_everyday()
+    cfg.model.encoder = str(rng.choice(["dgcnn", "pointnet"]))
+    cfg.data.max_num_part = P
+    return _whole_step(rng, g, cfg, B, P, N,
+                       lambda sd, cb: oc.dgl_loss(sd, cb, cfg.model.gnn_iter, cfg.model.encoder, True, {})["loss"],
+                       f"dgl + {cfg.model.encoder}")
+
+
 def case_repro(rng):
     from multi_part_assembly_amd.encoder import DGCNN, PointNet
     from multi_part_assembly_amd.gru import gru_recurrent
@@ -507,7 +594,8 @@ def case_repro(rng):
 
 
 families = [("loss", case_loss), ("chamfer", case_chamfer), ("knn", case_knn), ("glue", case_glue), ("repro", case_repro),
-            ("nets", case_nets), ("dgcnn", case_dgcnn)]
+            ("nets", case_nets), ("dgcnn", case_dgcnn), ("step", case_step),
+            ("gnn", case_gnn)]
 counts = {k: 0 for k, _ in families}
 t_end = time.time() + budget
 seed = seed0
@@ -527,7 +615,7 @@ while time.time() < t_end:
             print(f"MISMATCH {name} seed {seed}: {what}", flush=True)
     seed += 1
 if edge:
-    print(f"nets / dgcnn: {len(edge)} cases set aside: the float64 oracle's own gradients move by > 1e-3 under a 2e-6 .. 2e-5 relative input change "
+    print(f"nets / dgcnn / step / gnn: {len(edge)} cases set aside: the float64 oracle's own gradients move by > 1e-3 under a 2e-6 .. 2e-5 relative input change "
           f"(a ReLU / max on the rounding edge)")
 for name, _ in families:
     print(f"{name}: {counts[name]} random cases (seeds {seed0}..{seed - 1}), {sum(1 for b in bad if b[0] == name)} mismatches")
