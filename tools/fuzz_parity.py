@@ -16,6 +16,8 @@ live in tests/).  Every case draws its own sizes, masks and pose regime from the
          counts, point counts, widths, depths — vs oracle/nets.py (pn_transformer_loss) in float64: loss and every
          parameter gradient, same bounds and conditioning check;
   gnn    the same for DGL (three GNN iterations) on either encoder vs oracle/callers.py (dgl_loss);
+  global the same for B-Global on semantic batches (identical-part matching, min-of-N sampling, noise channels) vs
+         oracle/callers.py (global_loss), every evaluation re-seeded so that all three see the same noise;
   repro  bit-reproducibility: forward + backward of every module of the path (both encoders, transformer, pose head, MLP layer,
          GRU recurrence, fused loss) run twice on the same inputs — outputs and every gradient bit-equal.
 
@@ -404,7 +406,7 @@ def case_dgcnn(rng):
     return not fails, f"dgcnn {n}x{N}x{feat}: {fails}"
 
 
-def _whole_step(rng, g, cfg, B, P, N, oracle_total, label):
+def _whole_step(rng, g, cfg, B, P, N, oracle_total, label, make=None, reseed=None):
     """forward_pass + backward of build_model(cfg) on the HIP path against oracle_total(sd, cpu_batch) -> scalar in float64."""
     from multi_part_assembly_amd.pn_transformer import build_model
     rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).abs().max() / (b.double().abs().max() + 1e-12))
@@ -416,10 +418,15 @@ def _whole_step(rng, g, cfg, B, P, N, oracle_total, label):
             m.dropout = 0.0
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     names = [k for k, _ in model.named_parameters()]
-    batch = synthetic.make_batch(B, P, N, preset="everyday", seed=int(rng.integers(1 << 30)), device=dev,
-                                 num_parts=[int(rng.integers(2, P + 1)) for _ in range(B)])
+    if make is None:
+        batch = synthetic.make_batch(B, P, N, preset="everyday", seed=int(rng.integers(1 << 30)), device=dev,
+                                     num_parts=[int(rng.integers(2, P + 1)) for _ in range(B)])
+    else:
+        batch = make()
     batch.pop("num_parts", None)
     model.to(dev).train()
+    if reseed is not None:  # models that draw noise: every evaluation sees the same draws
+        torch.manual_seed(reseed)
     loss = model.training_step(batch, 0)
     loss.backward()
     hip = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters() if p.grad is not None}
@@ -430,6 +437,8 @@ def _whole_step(rng, g, cfg, B, P, N, oracle_total, label):
         cb = {k: (v.cpu().to(dt) if v.is_floating_point() else v.cpu()) for k, v in batch.items() if hasattr(v, "cpu")}
         if jitter:
             cb["part_pcs"] = cb["part_pcs"] * (1.0 + jitter * torch.randn(cb["part_pcs"].shape, generator=g).to(dt))
+        if reseed is not None:
+            torch.manual_seed(reseed)
         total = oracle_total(sd, cb)
         total.backward()
         return float(total.detach()), {k: p.grad.double() for k, p in params.items() if p.grad is not None}
@@ -485,6 +494,22 @@ def case_gnn(rng):
     return _whole_step(rng, g, cfg, B, P, N,
                        lambda sd, cb: oc.dgl_loss(sd, cb, cfg.model.gnn_iter, cfg.model.encoder, True, {})["loss"],
                        f"dgl + {cfg.model.encoder}")
+
+
+def case_global(rng):
+    from multi_part_assembly_amd import config
+    from oracle import callers as oc
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    B, P, N = int(rng.integers(1, 5)), int(rng.integers(2, 7)), int(rng.choice([32, 64, 100, 200]))
+    cfg = config.global_partnet_chair()
+    cfg.data.max_num_part = P
+    loss_cfg = {k: cfg.loss[k] for k in cfg.loss}
+    bseed = int(rng.integers(1 << 30))
+    make = lambda: synthetic.make_semantic_batch(B, P, N, seed=bseed, device=dev, num_part_category=cfg.data.num_part_category)
+    return _whole_step(rng, g, cfg, B, P, N,
+                       lambda sd, cb: oc.global_loss(sd, cb, loss_cfg, cfg.loss.sample_iter, cfg.loss.noise_dim, cfg.model.encoder,
+                                                     True, {})["loss"],
+                       "b-global (semantic: matching, min-of-N sampling, noise)", make=make, reseed=int(rng.integers(1 << 30)))
 
 
 def case_repro(rng):
@@ -595,7 +620,7 @@ def case_repro(rng):
 
 families = [("loss", case_loss), ("chamfer", case_chamfer), ("knn", case_knn), ("glue", case_glue), ("repro", case_repro),
             ("nets", case_nets), ("dgcnn", case_dgcnn), ("step", case_step),
-            ("gnn", case_gnn)]
+            ("gnn", case_gnn), ("global", case_global)]
 counts = {k: 0 for k, _ in families}
 t_end = time.time() + budget
 seed = seed0
@@ -615,7 +640,7 @@ while time.time() < t_end:
             print(f"MISMATCH {name} seed {seed}: {what}", flush=True)
     seed += 1
 if edge:
-    print(f"nets / dgcnn / step / gnn: {len(edge)} cases set aside: the float64 oracle's own gradients move by > 1e-3 under a 2e-6 .. 2e-5 relative input change "
+    print(f"nets / dgcnn / step / gnn / global: {len(edge)} cases set aside: the float64 oracle's own gradients move by > 1e-3 under a 2e-6 .. 2e-5 relative input change "
           f"(a ReLU / max on the rounding edge)")
 for name, _ in families:
     print(f"{name}: {counts[name]} random cases (seeds {seed0}..{seed - 1}), {sum(1 for b in bad if b[0] == name)} mismatches")
