@@ -18,6 +18,9 @@ live in tests/).  Every case draws its own sizes, masks and pose regime from the
   gnn    the same for DGL (three GNN iterations) on either encoder vs oracle/callers.py (dgl_loss);
   global the same for B-Global on semantic batches (identical-part matching, min-of-N sampling, noise channels) vs
          oracle/callers.py (global_loss), every evaluation re-seeded so that all three see the same noise;
+  adam   the fused optimiser vs torch.optim.Adam / AdamW (+ clip_grad_norm_) over 1-7 steps on random tensor sets;
+  graph  four training steps replayed as a HIP graph vs eager launches (PNTransformer or DGL, dropout on): losses and the
+         final parameters bit-equal;
   repro  bit-reproducibility: forward + backward of every module of the path (both encoders, transformer, pose head, MLP layer,
          GRU recurrence, fused loss) run twice on the same inputs — outputs and every gradient bit-equal.
 
@@ -512,6 +515,64 @@ def case_global(rng):
                        "b-global (semantic: matching, min-of-N sampling, noise)", make=make, reseed=int(rng.integers(1 << 30)))
 
 
+def case_adam(rng):
+    """The fused optimiser against torch.optim.Adam / AdamW (+ clip_grad_norm_) over a few steps on random tensor sets."""
+    from multi_part_assembly_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    shapes = [tuple(int(v) for v in rng.integers(1, 40, size=int(rng.integers(1, 4)))) for _ in range(int(rng.integers(1, 9)))]
+    ref_p = [torch.randn(*sh, generator=g).to(dev) for sh in shapes]
+    wd = float(rng.choice([0.0, 0.0, 0.01, 0.1]))
+    lr = float(rng.choice([1e-4, 1e-3, 1e-2]))
+    clip = float(rng.choice([0.0, 0.0, 0.05, 5.0]))
+    mine = [torch.nn.Parameter(p.clone()) for p in ref_p]
+    theirs = [torch.nn.Parameter(p.clone()) for p in ref_p]
+    opt = FusedAdam(mine, lr=lr, weight_decay=wd, clip_grad=clip if clip > 0 else None)
+    topt = (torch.optim.AdamW if wd > 0 else torch.optim.Adam)(theirs, lr=lr, weight_decay=wd)
+    for step in range(int(rng.integers(1, 8))):
+        opt.zero_grad()
+        topt.zero_grad()
+        scale = float(rng.choice([1e-3, 1.0, 30.0]))
+        for a, b in zip(mine, theirs):
+            gr = torch.randn(a.shape, generator=g).to(dev) * scale
+            a.grad.copy_(gr)
+            b.grad = gr.clone()
+        if clip > 0:
+            torch.nn.utils.clip_grad_norm_(theirs, clip)
+        opt.step()
+        topt.step()
+    ok = all(bool(((a.detach() - b.detach()).abs() <= 1e-5 * b.detach().abs() + 1e-6 * lr / 1e-3 + 1e-7).all()) for a, b in zip(mine, theirs))
+    return ok, f"adam {len(shapes)} tensors wd={wd} lr={lr} clip={clip}"
+
+
+def case_graph(rng):
+    """A HIP-graph replay of the whole training step walks the same parameter trajectory, bit for bit, as eager launches."""
+    from multi_part_assembly_amd import config
+    from multi_part_assembly_amd.pn_transformer import build_model
+    from multi_part_assembly_amd.trainer import Trainer
+    B, P, N = int(rng.integers(1, 5)), int(rng.integers(2, 9)), int(rng.choice([32, 64, 100, 200]))
+    which = str(rng.choice(["pn_transformer", "dgl"]))
+    cfg = config.pn_transformer_everyday() if which == "pn_transformer" else config.dgl_dgcnn_everyday()
+    cfg.data.max_num_part = P
+    cfg.optimizer.lr_scheduler = ""
+    if which == "pn_transformer":
+        cfg.model.transformer_layers = int(rng.integers(1, 3))
+    batch = synthetic.make_batch(B, P, N, preset="everyday", seed=int(rng.integers(1 << 30)), device=dev,
+                                 num_parts=[int(rng.integers(2, P + 1)) for _ in range(B)])
+    batch.pop("num_parts", None)
+    seed = int(rng.integers(1 << 30))
+    finals, losses = [], []
+    for use_graph in (False, True):
+        torch.manual_seed(seed)
+        model = build_model(cfg).to(dev)
+        tr = Trainer(model, cfg, use_graph=use_graph, graph_warmup=1)
+        ls = [float(tr.train_step(batch)) for _ in range(4)]
+        torch.cuda.synchronize()
+        finals.append(tr.flat.flat_param.clone())
+        losses.append(ls)
+    ok = torch.equal(finals[0], finals[1]) and losses[0] == losses[1]
+    return bool(ok), f"graph vs eager {which} B={B} P={P} N={N}: losses {losses[0][-1]} / {losses[1][-1]}"
+
+
 def case_repro(rng):
     from multi_part_assembly_amd.encoder import DGCNN, PointNet
     from multi_part_assembly_amd.gru import gru_recurrent
@@ -620,7 +681,8 @@ def case_repro(rng):
 
 families = [("loss", case_loss), ("chamfer", case_chamfer), ("knn", case_knn), ("glue", case_glue), ("repro", case_repro),
             ("nets", case_nets), ("dgcnn", case_dgcnn), ("step", case_step),
-            ("gnn", case_gnn), ("global", case_global)]
+            ("gnn", case_gnn), ("global", case_global),
+            ("adam", case_adam), ("graph", case_graph)]
 counts = {k: 0 for k, _ in families}
 t_end = time.time() + budget
 seed = seed0
