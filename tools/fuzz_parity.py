@@ -44,9 +44,6 @@ from oracle import chamfer as oc  # noqa: E402
 from oracle.knn import knn_exact as oracle_knn  # noqa: E402
 
 dev = torch.device("cuda:0")
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-only = sys.argv[3].split(",") if len(sys.argv) > 3 else None  # families to run (default: all)
 bad = []
 edge = []  # cases at which the float64 oracle itself is discontinuous (a 2e-6 .. 2e-5 relative input change moves its gradients by > 1e-3)
 
@@ -683,27 +680,43 @@ families = [("loss", case_loss), ("chamfer", case_chamfer), ("knn", case_knn), (
             ("nets", case_nets), ("dgcnn", case_dgcnn), ("step", case_step),
             ("gnn", case_gnn), ("global", case_global),
             ("adam", case_adam), ("graph", case_graph)]
-counts = {k: 0 for k, _ in families}
-t_end = time.time() + budget
-seed = seed0
-while time.time() < t_end:
-    for fam, (name, fn) in enumerate(families):
-        if only is not None and name not in only:
-            continue
-        rng = np.random.default_rng([seed, fam])
-        torch.manual_seed(seed * 16 + fam)  # module initialisations draw from the global generator: make a case a function of its seed
-        try:
-            ok, what = fn(rng)
-        except Exception as exc:  # a refused shape is a finding too
-            ok, what = False, f"exception {type(exc).__name__}: {exc}"
-        counts[name] += 1
-        if not ok:
-            bad.append((name, seed, what))
-            print(f"MISMATCH {name} seed {seed}: {what}", flush=True)
-    seed += 1
-if edge:
-    print(f"nets / dgcnn / step / gnn / global: {len(edge)} cases set aside: the float64 oracle's own gradients move by > 1e-3 under a 2e-6 .. 2e-5 relative input change "
-          f"(a ReLU / max on the rounding edge)")
-for name, _ in families:
-    print(f"{name}: {counts[name]} random cases (seeds {seed0}..{seed - 1}), {sum(1 for b in bad if b[0] == name)} mismatches")
-sys.exit(1 if bad else 0)
+
+
+def run_case(name, seed):
+    """One case of family `name`: (ok, description).  A case is a function of (family, seed) only."""
+    fam = [k for k, _ in families].index(name)
+    rng = np.random.default_rng([seed, fam])
+    torch.manual_seed(seed * 16 + fam)  # module initialisations draw from the global generator
+    try:
+        return families[fam][1](rng)
+    except Exception as exc:  # a refused shape is a finding too
+        return False, f"exception {type(exc).__name__}: {exc}"
+
+
+def main(argv):
+    budget = float(argv[1]) if len(argv) > 1 else 240.0
+    seed0 = int(argv[2]) if len(argv) > 2 else 0
+    only = argv[3].split(",") if len(argv) > 3 else None  # families to run (default: all)
+    counts = {k: 0 for k, _ in families}
+    t_end = time.time() + budget
+    seed = seed0
+    while time.time() < t_end:
+        for name, _ in families:
+            if only is not None and name not in only:
+                continue
+            ok, what = run_case(name, seed)
+            counts[name] += 1
+            if not ok:
+                bad.append((name, seed, what))
+                print(f"MISMATCH {name} seed {seed}: {what}", flush=True)
+        seed += 1
+    if edge:
+        print(f"nets / dgcnn / step / gnn / global: {len(edge)} cases set aside: the float64 oracle's own gradients move by > 1e-3 "
+              f"under a 2e-6 .. 2e-5 relative input change (a ReLU / max on the rounding edge)")
+    for name, _ in families:
+        print(f"{name}: {counts[name]} random cases (seeds {seed0}..{seed - 1}), {sum(1 for b in bad if b[0] == name)} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))
