@@ -38,14 +38,15 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // (tags start at 1); two buffers by step parity suffice: a block can only be one step ahead of the slowest reader of
 // its previous values.  All blocks of the grid must be co-resident (checked by gru_resident).
 typedef unsigned long long tagged_t;
+constexpr int kPollBudget = 1 << 22;
 __device__ __forceinline__ void tagged_store(tagged_t* p, float v, unsigned tag) {
   __hip_atomic_store(p, ((tagged_t)tag << 32) | (tagged_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ tagged_t tagged_peek(const tagged_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the value of *p once it carries `tag` (first poll result given).  `budget`: polls the thread may still spend in this
-// launch — a producer that never shows up (a grid that is not co-resident after all) exhausts it after a few seconds and
+// the value of *p once it carries `tag` (first poll result given).  `budget`: polls the thread may still spend on this
+// wait — a producer that never shows up (a grid that is not co-resident after all) exhausts it after a few seconds and
 // the kernel TRAPS: the launch fails loudly instead of hanging the device or returning garbage.
 __device__ __forceinline__ float tagged_wait(const tagged_t* p, tagged_t first, unsigned tag, int& budget) {
   tagged_t v = first;
@@ -54,9 +55,9 @@ __device__ __forceinline__ float tagged_wait(const tagged_t* p, tagged_t first, 
     __builtin_amdgcn_s_sleep(2);
     v = tagged_peek(p);
   }
+  budget = kPollBudget;  // the budget bounds ONE wait (a few seconds), not the launch's total polling
   return __uint_as_float((unsigned)v);
 }
-constexpr int kPollBudget = 1 << 22;
 // PF words p[q * stride] (q < n valid): wait for the first one alone (ONE polled word per thread while the producers
 // are still busy: the pollers' traffic delays the very stores they wait for — re-loading whole batches until every tag
 // had arrived was 4x slower), then load the others together, and wait singly for a straggler.
@@ -376,8 +377,9 @@ extern "C" int mpa_gru_forward(const float* gi, const float* h0, const float* wh
   MPA_REQUIRE((uintptr_t)xch % 8 == 0, "gru_forward: workspace must be 8-byte aligned");
   const size_t smem = sizeof(float) * (3 * kU * (H + 4) + B * (H + 4));
   MPA_REQUIRE(smem <= 160 * 1024, "gru_forward: batch x hidden size does not fit the 160 KB of LDS");
-  if (hipMemsetAsync(xch, 0, sizeof(tagged_t) * D * 2 * B * H, s) != hipSuccess)
-    return mpa::fail(MPA_ELAUNCH, "gru_forward: cannot clear the exchange words");
+  // tags run 1..T in EVERY launch: a word left by the previous launch (or graph replay) already carries the tag a
+  // consumer waits for, so the clear is load-bearing — and it is a kernel, not hipMemsetAsync (common.h).
+  mpa::zero_words_async(xch, 2 * D * 2 * B * H, s);
   const dim3 grid((unsigned)(H / kU), (unsigned)D);
 #define MPA_GRU_FWD(HH)                                                                                               \
   {                                                                                                                   \
@@ -405,8 +407,7 @@ extern "C" int mpa_gru_backward(const float* grad_out, const float* h0, const fl
   MPA_REQUIRE((uintptr_t)part % 8 == 0, "gru_backward: workspace must be 8-byte aligned");
   const size_t smem = sizeof(float) * (3 * kU * H + B * H + B * 3 * kU + B * kU);
   MPA_REQUIRE(smem <= 160 * 1024, "gru_backward: batch x hidden size does not fit the 160 KB of LDS");
-  if (hipMemsetAsync(part, 0, sizeof(tagged_t) * D * 2 * (H / kU) * B * H, s) != hipSuccess)
-    return mpa::fail(MPA_ELAUNCH, "gru_backward: cannot clear the exchange words");
+  mpa::zero_words_async(part, 2 * D * 2 * (H / kU) * B * H, s);  // load-bearing, see gru_forward
   const dim3 grid((unsigned)(H / kU), (unsigned)D);
 #define MPA_GRU_BWD(HH)                                                                                               \
   {                                                                                                                   \

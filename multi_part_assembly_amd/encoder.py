@@ -65,7 +65,7 @@ class _PointNetFn(torch.autograd.Function):
             raise RuntimeError("PointNet: backward is implemented for training-mode BatchNorm only")
         if DeferredBackward.active is not None:  # graph-mode data parallelism: run later, behind the first all-reduce
             saved = ctx.saved_tensors  # (autograd releases them when its own pass is over)
-            DeferredBackward.park(lambda g: _deliver(ctx.params, _PointNetFn._run_backward(ctx, g, saved), 6), grad_feat)
+            DeferredBackward.park(lambda g: _deliver(ctx.params, _PointNetFn._run_backward(ctx, g, saved), 6), grad_feat, ctx.params)
             return (None,) * (6 + len(ctx.params))
         return _PointNetFn._run_backward(ctx, grad_feat, ctx.saved_tensors)
 
@@ -129,7 +129,7 @@ class _PointNetBF16Fn(torch.autograd.Function):
             raise RuntimeError("PointNet (bf16): backward is implemented for training-mode BatchNorm only")
         if DeferredBackward.active is not None:
             saved = ctx.saved_tensors
-            DeferredBackward.park(lambda g: _deliver(ctx.params, _PointNetBF16Fn._run_backward(ctx, g, saved), 6), grad_feat)
+            DeferredBackward.park(lambda g: _deliver(ctx.params, _PointNetBF16Fn._run_backward(ctx, g, saved), 6), grad_feat, ctx.params)
             return (None,) * (6 + len(ctx.params))
         return _PointNetBF16Fn._run_backward(ctx, grad_feat, ctx.saved_tensors)
 
@@ -284,7 +284,7 @@ class _DGCNNFn(torch.autograd.Function):
             raise RuntimeError("DGCNN: backward is implemented for training-mode BatchNorm only")
         if DeferredBackward.active is not None and not ctx.want_point_grad:
             saved = ctx.saved_tensors
-            DeferredBackward.park(lambda g: _deliver(ctx.params, _DGCNNFn._run_backward(ctx, g, saved), 8), grad_feat)
+            DeferredBackward.park(lambda g: _deliver(ctx.params, _DGCNNFn._run_backward(ctx, g, saved), 8), grad_feat, ctx.params)
             return (None,) * (8 + len(ctx.params))
         return _DGCNNFn._run_backward(ctx, grad_feat, ctx.saved_tensors)
 

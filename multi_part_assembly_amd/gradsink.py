@@ -70,12 +70,14 @@ class DeferredBackward:
     active: "list | None" = None
 
     @staticmethod
-    def park(run, grad):
-        DeferredBackward.active.append((run, grad))
+    def park(run, grad, params=()):
+        """`params`: the parameters `run` writes gradients of — the Trainer checks that all of them live in the LAST
+        gradient bucket before it overlaps the first bucket's all-reduce with the parked calls."""
+        DeferredBackward.active.append((run, grad, tuple(params)))
 
     @staticmethod
     def run_all():
         items, DeferredBackward.active = DeferredBackward.active or [], None
-        for run, grad in items:
+        for run, grad, _ in items:
             run(grad)
         return len(items)

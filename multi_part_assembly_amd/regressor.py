@@ -102,6 +102,12 @@ class StocasticPoseRegressor(PoseRegressor):
     def forward(self, x):
         if self.noise_dim == 0:
             return super().forward(x)
-        # CPU generator draws as upstream; pinned + asynchronous copy (a pageable copy drains the stream first)
-        noise = torch.randn(*x.shape[:-1], self.noise_dim, pin_memory=x.is_cuda).to(x.device, non_blocking=True).type_as(x)
+        if x.is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture a host-to-device copy would become a memcpy node replaying ONE draw (or freed
+            # pinned memory) for ever: draw on the device generator, whose offset torch advances on every replay
+            # (same rule as RGLNet._init_gru_hidden)
+            noise = torch.randn(*x.shape[:-1], self.noise_dim, device=x.device, dtype=x.dtype)
+        else:
+            # CPU generator draws as upstream; pinned + asynchronous copy (a pageable copy drains the stream first)
+            noise = torch.randn(*x.shape[:-1], self.noise_dim, pin_memory=x.is_cuda).to(x.device, non_blocking=True).type_as(x)
         return super().forward(torch.cat([x, noise], dim=-1))

@@ -102,6 +102,7 @@ class Trainer:
             self._static_loss = self._loss_buf
             parked = DeferredBackward.active
             if parked:
+                self._check_parked_in_last_bucket(parked)
                 self._graph_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph_b, pool=self._graph.pool(), capture_error_mode="thread_local"):
                     DeferredBackward.run_all()
@@ -109,10 +110,27 @@ class Trainer:
             DeferredBackward.active = None
             self.sink.__exit__(None, None, None)
 
+    def _check_parked_in_last_bucket(self, parked):
+        """The two-graph overlap reduces bucket 0 WHILE the parked backward calls run: every gradient they write must
+        lie in the last bucket (an encoder module living outside `model.encoder` would race with the all-reduce)."""
+        buckets = self.reducer.buckets
+        if len(buckets) < 2:
+            return
+        last = buckets[-1]["slice"]
+        lo, hi = last.data_ptr(), last.data_ptr() + last.numel() * last.element_size()
+        for _, _, params in parked:
+            for p in params:
+                g = p.grad if isinstance(p, torch.Tensor) else None
+                if g is not None and not (lo <= g.data_ptr() < hi):
+                    raise RuntimeError("graph-mode data parallelism: a deferred encoder backward owns a parameter "
+                                       "outside the last gradient bucket (an encoder module outside model.encoder?); "
+                                       "use use_graph=False for this model")
+
     def _reduce_buckets_around(self, run_second_half):
         """bucket 0 (everything but the encoder) is reduced WHILE `run_second_half` (the encoder's backward) runs; the
         encoder's bucket behind it."""
         buckets = self.reducer.buckets
+        assert len(buckets) <= 2, "the two-graph overlap reduces only the first and the last bucket"
         first = dist.all_reduce(buckets[0]["slice"], group=self.group, async_op=True) if len(buckets) > 1 else None
         run_second_half()
         last = dist.all_reduce(buckets[-1]["slice"], group=self.group, async_op=True)

@@ -512,3 +512,53 @@ def test_rgl_net_step_captures_as_one_graph(cuda_device):
     assert tr._graph is not None
     assert all(np.isfinite(losses)), losses
     assert len(set(losses[1:])) == 4, losses  # same batch, new noise + updated weights: no replay repeats a value
+
+
+# ---- HIP-graph replay of the graph networks (round-3 advisor finding: the GRU's tagged exchange words) -------------------
+def _graph_net_trainer(golden, cuda_device, name, **kw):
+    from multi_part_assembly_amd.trainer import Trainer
+    z = golden(name)
+    cfg = CASES[name]()
+    cfg.model.pc_feat_dim = int(z["cfg"][0])
+    cfg.data.max_num_part = 5
+    cfg.optimizer.lr_scheduler = ""
+    seed = int(z["seed"][0])
+    torch.manual_seed(seed)
+    model = build_model(cfg)
+    param_fill.fill_parameters(model, seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.to(cuda_device)
+    data = {k[5:]: torch.from_numpy(z[k].copy()).to(cuda_device) for k in z if k.startswith("data.")}
+    return Trainer(model, cfg, **kw), data
+
+
+@pytest.mark.parametrize("name", ["dgl_step", "rgl_net_step", "rgl_net_dgcnn_artifact_step"])
+def test_graph_replay_equals_eager_steps_of_graph_networks(golden, cuda_device, monkeypatch, name):
+    """Captured-graph replays of DGL / RGL-NET walk the eager trajectory.  RGL-NET's recurrent kernels hand hidden states
+    between blocks as {value, tag} words with tags 1..T in EVERY launch: unless the words are cleared by a graph-safe
+    node before each replay, a consumer can take the PREVIOUS replay's word for the current one.  The GRU's random
+    initial state is pinned to one fixed device tensor on both sides (eager draws it on the CPU generator, capture on
+    the device generator: two different streams by design), everything else is the shipped step."""
+    from multi_part_assembly_amd import gnn
+    fixed = {}
+
+    def fixed_hidden(self, B, device=None):
+        key = (B, self.pc_feat_dim)
+        if key not in fixed:
+            g = torch.Generator().manual_seed(11)
+            fixed[key] = torch.randn((2, B, 2 * self.pc_feat_dim), generator=g).to(device)
+        return fixed[key]
+
+    if hasattr(gnn, "RGLNet"):
+        monkeypatch.setattr(gnn.RGLNet, "_init_gru_hidden", fixed_hidden)
+    eager, batch = _graph_net_trainer(golden, cuda_device, name)
+    graph, _ = _graph_net_trainer(golden, cuda_device, name, use_graph=True, graph_warmup=1)
+    for step in range(6):
+        le = eager.train_step(batch)
+        lg = graph.train_step(batch)
+        assert float(lg) == float(le), (step, float(lg), float(le))
+    assert graph._graph is not None
+    assert torch.equal(graph.flat.flat_param, eager.flat.flat_param), \
+        float((graph.flat.flat_param - eager.flat.flat_param).abs().max())
