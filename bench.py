@@ -66,6 +66,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"] + sorted(CONFIG_ALIASES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-chamfer-standalone", action="store_true",
+                    help="skip the stand-alone timing of the drop-in Chamfer operator (the `chamfer_standalone` object)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (default: eager launches; see trainer.py)")
     ap.add_argument("--eager", action="store_true", help="(the default; accepted for symmetry)")
@@ -300,6 +302,80 @@ def kernel_table(kernels, num_parts, cfg, B, P):
     return rows
 
 
+# ---- the drop-in operator on its own (BASELINE.json metric: "+ Chamfer kernel GB/s") ----------------------------------------
+def chamfer_standalone(dev, reps=20):
+    """mpa_chamfer_forward through the C ABI (multi_part_assembly_amd.chamfer.chamfer_forward, the `chamfer_cuda`
+    replacement) at SURVEY.md §8(d)'s two standalone shapes, timed per call with HIP events on the launch stream:
+    the per-part call [640, 1000, 3]^2 of rot_points_cd_loss and the whole-shape call [32, 20000, 3]^2 of shape_cd_loss
+    with the 1e3 padding fill applied (utils/loss.py:173-199), the latter for an untrained (far) and a trained (close)
+    prediction.  GB/s on §8(d)'s 24 algorithmic bytes per point of both clouds; the exhaustive scan of the same call
+    is timed beside the pruned search."""
+    import torch
+    from multi_part_assembly_amd import _lib, chamfer, synthetic
+    from multi_part_assembly_amd.transforms import pose_apply
+
+    batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234, device=dev)
+    v = batch["part_valids"]
+    pts = batch["part_pcs"]
+    g = torch.Generator(device="cpu").manual_seed(99)
+    q_far = torch.nn.functional.normalize(torch.randn(BATCH, PARTS, 4, generator=g), dim=-1).to(dev)
+    t_far = (torch.rand(BATCH, PARTS, 3, generator=g) * 0.8 - 0.4).to(dev)
+    q_gt = torch.where(v[..., None] > 0, batch["part_quat"], q_far.new_tensor([1.0, 0.0, 0.0, 0.0]))
+    q_near = torch.nn.functional.normalize(q_gt + 0.02 * torch.randn(BATCH, PARTS, 4, generator=g).to(dev), dim=-1)
+    t_near = batch["part_trans"] + 0.01 * torch.randn(BATCH, PARTS, 3, generator=g).to(dev)
+
+    def shape(q, t):  # shape_cd_loss's cloud: padded parts := 1e3, then the pose, flattened to [B, P*N, 3]
+        return pose_apply(pts, q, t, mask=v, fill=1e3).reshape(BATCH, PARTS * POINTS, 3).contiguous()
+
+    gt = shape(q_gt, batch["part_trans"])
+    cases = [
+        ("[640,1000,3]^2 per-part clouds (rot_points_cd_loss: rotated by prediction vs ground truth)",
+         pose_apply(pts, q_far).reshape(BATCH * PARTS, POINTS, 3).contiguous(),
+         pose_apply(pts, q_gt).reshape(BATCH * PARTS, POINTS, 3).contiguous()),
+        ("[32,20000,3]^2 whole shapes, 1e3 padding fill, untrained prediction (random poses)", shape(q_far, t_far), gt),
+        ("[32,20000,3]^2 whole shapes, 1e3 padding fill, trained prediction (poses within 2 % of ground truth)",
+         shape(q_near, t_near), gt),
+    ]
+
+    def timed(a, b, variant, n):
+        for _ in range(3):
+            chamfer.chamfer_forward(a, b, variant=variant)
+        timer = _lib.KernelTimer()
+        _lib.KernelTimer.active = timer
+        try:
+            for _ in range(n):
+                out = chamfer.chamfer_forward(a, b, variant=variant)
+            torch.cuda.synchronize()
+        finally:
+            _lib.KernelTimer.active = None
+        (rec,) = timer.summary().values()
+        return rec["avg_ms"], rec["launches"], out
+
+    rows = []
+    for name, a, b in cases:
+        B_, n1, n2 = a.shape[0], a.shape[1], b.shape[1]
+        ms, launches, out = timed(a, b, None, reps)
+        alg = 24.0 * B_ * (n1 + n2)
+        pairs = 2.0 * B_ * n1 * n2
+        row = {"case": name, "calls": launches, "avg_call_ms": ms, "algorithmic_bytes_per_call": alg,
+               "GBps": alg / (ms * 1e-3) / 1e9, "hbm_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "exhaustive_pair_evals_per_call": pairs}
+        pruned = n1 * n2 >= 9_000_000
+        row["search"] = "grid-pruned exact (sort + search + hand-back scan, 3 launches)" if pruned else "exhaustive scan"
+        if pruned:
+            ms2, _, out2 = timed(a, b, 2, 3)
+            row["exhaustive_scan_ms"] = ms2
+            row["exhaustive_scan_valu_frac"] = 8.6 * pairs / (ms2 * 1e-3) / VALU_PEAK_LANE_OPS
+            row["bit_equal_to_exhaustive_scan"] = all(bool(torch.equal(x, y)) for x, y in zip(out, out2))
+        else:
+            row["valu_frac"] = 8.6 * pairs / (ms * 1e-3) / VALU_PEAK_LANE_OPS
+        rows.append(row)
+    return {"entry": "mpa_chamfer_forward (include/mpa_hip.h) via multi_part_assembly_amd.chamfer.chamfer_forward",
+            "timing": "HIP events on the launch stream around each call (workspace allocation outside the events)",
+            "bytes_rule": "SURVEY.md 8(d): 24 B per point of both clouds (12 B xyz read, 4 B distance + 8 B int64 index written)",
+            "cases": rows}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -524,6 +600,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.config in ("c1", "c2", "c3", "c4"):
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, dev)
+        if world == 1 and not args.no_chamfer_standalone:
+            line["chamfer_standalone"] = chamfer_standalone(dev)
         if self_check is not None:
             line["self_check"] = self_check
         if collectives is not None:

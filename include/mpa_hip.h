@@ -25,7 +25,7 @@ extern "C" {
 #define MPA_ELAUNCH (-2) /* hipGetLastError() reported a launch failure */
 
 /* ABI version of this header; bumped whenever a signature changes. */
-#define MPA_ABI_VERSION 5
+#define MPA_ABI_VERSION 6
 int mpa_abi_version(void);
 
 /* Thread-local, NUL-terminated description of the last failure on this thread ("" if none). */
@@ -48,16 +48,30 @@ const char* mpa_last_error(void);
  *   j attaining it (strict `<` scan in index order, chamfer_kernel.cu:82); a query with no
  *   candidate below 1e32 (n2 == 0, NaN/huge input) gets dist = 1e32f, idx = -1 (:60-61).
  *   dist2/idx2: the same with the roles of the clouds swapped.
+ *
+ * Two searches stand behind the call, with identical results (tests/test_chamfer_gpu.py):
+ *   - the exhaustive scan: n1 * n2 pair evaluations per sample and direction (what the reference does);
+ *   - an exact grid-pruned search (csrc/grid_nn.hip) for large clouds — the whole-shape call of shape_cd_loss,
+ *     [32, 20000, 3] against itself (utils/loss.py:173-199), is 2.56e10 pair evaluations exhaustively and a few
+ *     dozen candidates per query pruned.  It needs scratch memory, which the CALLER provides (the library never
+ *     allocates): `workspace` = mpa_chamfer_workspace() bytes, 16-byte aligned, contents irrelevant before and
+ *     after the call.  With workspace == NULL (or too small) every size is answered by the exhaustive scan.
+ *   The pruned search is chosen when min(n1, n2) >= 512 and n1 * n2 >= 9e6.  Samples that hold a non-finite
+ *   coordinate, or one beyond 1e15 in magnitude, are always answered by the exhaustive scan.
  * ---------------------------------------------------------------------------------------------- */
+int mpa_chamfer_workspace(int64_t batch, int64_t n1, int64_t n2, int64_t* bytes);
 int mpa_chamfer_forward(const float* xyz1, const float* xyz2, int64_t batch, int64_t n1, int64_t n2,
-                        float* dist1, int64_t* idx1, float* dist2, int64_t* idx2, void* stream);
+                        float* dist1, int64_t* idx1, float* dist2, int64_t* idx2, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 
-/* Diagnostic twin of mpa_chamfer_forward that pins the scan variant (all bit-identical in their
- * results): 0 = direct compare/select per pair, 1 = fused-form gate + exact recheck (fastest on
- * tie-free clouds), 2 = exact chunk-minimum scan (the default: insensitive to duplicated points). */
+/* Diagnostic twin of mpa_chamfer_forward that pins the search (all bit-identical in their results):
+ * 0 = direct compare/select per pair, 1 = fused-form gate + exact recheck (fastest on tie-free clouds),
+ * 2 = exact chunk-minimum scan (the exhaustive default: insensitive to duplicated points), 3 = the grid-pruned
+ * search at ANY size (needs the workspace), -1 = by size as mpa_chamfer_forward does. */
 int mpa_chamfer_forward_variant(const float* xyz1, const float* xyz2, int64_t batch, int64_t n1,
                                 int64_t n2, float* dist1, int64_t* idx1, float* dist2,
-                                int64_t* idx2, int variant, void* stream);
+                                int64_t* idx2, int variant, void* workspace, int64_t workspace_bytes,
+                                void* stream);
 
 /*
  * grad_xyz1 [batch, n1, 3] and grad_xyz2 [batch, n2, 3] are OVERWRITTEN (the library zero-fills

@@ -28,8 +28,9 @@ _U64 = _c.c_uint64
 SIGNATURES: dict[str, tuple] = {
     "mpa_abi_version": (_INT, []),
     "mpa_last_error": (_c.c_char_p, []),
-    "mpa_chamfer_forward": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
-    "mpa_chamfer_forward_variant": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _INT, _P]),
+    "mpa_chamfer_workspace": (_INT, [_I64, _I64, _I64, _P]),
+    "mpa_chamfer_forward": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _I64, _P]),
+    "mpa_chamfer_forward_variant": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _INT, _P, _I64, _P]),
     "mpa_chamfer_backward": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_chamfer_forward_f64": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
     "mpa_chamfer_backward_f64": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
@@ -85,7 +86,7 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_grad_clip_coef": (_INT, [_P, _I64, _F32, _P, _F32, _P, _P, _P]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

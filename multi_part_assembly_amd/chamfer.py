@@ -35,11 +35,24 @@ def _check_cloud(name: str, t: torch.Tensor) -> None:
         raise RuntimeError(f"{name}: only float32/float64 are dispatched, got {t.dtype}")
 
 
+def _workspace(B: int, n1: int, n2: int, dev) -> tuple[torch.Tensor | None, int]:
+    """Scratch for the grid-pruned search, sized by the library (the library itself never allocates); torch's caching
+    allocator makes the per-call request free after the first."""
+    import ctypes
+    nbytes = ctypes.c_int64(0)
+    _lib.check(_lib.lib().mpa_chamfer_workspace(B, n1, n2, ctypes.byref(nbytes)), "mpa_chamfer_workspace")
+    if nbytes.value == 0:
+        return None, 0
+    return torch.empty(nbytes.value, dtype=torch.uint8, device=dev), nbytes.value
+
+
 def chamfer_forward(xyz1: torch.Tensor, xyz2: torch.Tensor, variant: int | None = None):
     """`chamfer_cuda.chamfer_forward(xyz1, xyz2) -> [dist1, idx1, dist2, idx2]`.
 
     xyz1 (B, N1, 3), xyz2 (B, N2, 3); dist in the input dtype, idx int64 (chamfer_kernel.cu:129-132).
-    `variant` (0/1, fp32 only) pins the kernel variant for tests and A/B timing.
+    Large fp32 clouds (min(N1, N2) >= 512 and N1 * N2 >= 9e6: the whole-shape call of shape_cd_loss) are answered by
+    the exact grid-pruned search, everything else by the exhaustive scan — same results, bit for bit.
+    `variant` (fp32 only) pins the search for tests and A/B timing: 0 / 1 / 2 exhaustive scan variants, 3 grid-pruned.
     """
     _check_cloud("xyz1", xyz1)
     _check_cloud("xyz2", xyz2)
@@ -58,13 +71,17 @@ def chamfer_forward(xyz1: torch.Tensor, xyz2: torch.Tensor, variant: int | None 
         s = _lib.current_stream(dev)
         args = (_lib.ptr(xyz1), _lib.ptr(xyz2), B, n1, n2, _lib.ptr(dist1), _lib.ptr(idx1),
                 _lib.ptr(dist2), _lib.ptr(idx2))
-        tok = _lib.KernelTimer.start(f"chamfer_forward[{B}x{n1}x{n2}]")
         if xyz1.dtype == torch.float64:
+            tok = _lib.KernelTimer.start(f"chamfer_forward[{B}x{n1}x{n2}]")
             st = L.mpa_chamfer_forward_f64(*args, s)
-        elif variant is None:
-            st = L.mpa_chamfer_forward(*args, s)
         else:
-            st = L.mpa_chamfer_forward_variant(*args, int(variant), s)
+            ws, nbytes = _workspace(B, n1, n2, dev) if variant in (None, 3, -1) else (None, 0)
+            tok = _lib.KernelTimer.start(f"chamfer_forward[{B}x{n1}x{n2}]")
+            if variant is None:
+                st = L.mpa_chamfer_forward(*args, _lib.ptr(ws) if ws is not None else None, nbytes, s)
+            else:
+                st = L.mpa_chamfer_forward_variant(*args, int(variant), _lib.ptr(ws) if ws is not None else None,
+                                                   nbytes, s)
         _lib.KernelTimer.stop(tok)
     _lib.check(st, "mpa_chamfer_forward")
     return [dist1, idx1, dist2, idx2]

@@ -23,4 +23,14 @@ int launch_grid_shape_search(const float* valids, const float* S1, const float* 
                              int64_t N, int tiles, float* fws, int32_t* iws, int32_t* idx1, int32_t* idx2,
                              float* tile_sums, hipEvent_t before_search, hipEvent_t after_search, hipStream_t s);
 
+// ---- the same exact pruned search for two plain clouds per sample (the generic operator, chamfer.hip) -----------------
+// xyz1 [B, n1, 3], xyz2 [B, n2, 3] -> dist / idx of mpa_chamfer_forward's contract, bit for bit, for every sample whose
+// coordinates are finite and <= 1e15 in magnitude; the other samples are left untouched and flagged in (*fallback)[b]
+// (device memory inside `workspace`) for the caller's exhaustive scan.  `workspace`: cloud_grid_workspace_bytes() bytes.
+int64_t cloud_grid_workspace_bytes(int64_t B, int64_t n1, int64_t n2);
+bool cloud_grid_supported(int64_t B, int64_t n1, int64_t n2);
+int launch_cloud_grid_search(const float* xyz1, const float* xyz2, int64_t B, int64_t n1, int64_t n2, float* dist1,
+                             int64_t* idx1, float* dist2, int64_t* idx2, void* workspace, const int** fallback,
+                             hipStream_t s);
+
 }  // namespace mpa

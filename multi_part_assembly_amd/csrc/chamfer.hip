@@ -8,6 +8,7 @@
 // chamfer_core.h (Q queries per lane, targets in SGPRs, no LDS, no barriers), both directions of the
 // bidirectional search run in ONE launch (blockIdx.y = direction), and the arithmetic is pinned so
 // that results are bit-identical to the reference's CPU ground truth.
+#include "assembly_internal.h"
 #include "chamfer_core.h"
 #include "common.h"
 
@@ -45,8 +46,9 @@ template <int Q, int MODE, int THREADS>
 __global__ __launch_bounds__(THREADS) void chamfer_nn_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, int n1, int n2,
     int blocks_per_cloud, float* __restrict__ dist1, long long* __restrict__ idx1,
-    float* __restrict__ dist2, long long* __restrict__ idx2) {
+    float* __restrict__ dist2, long long* __restrict__ idx2, const int* __restrict__ only) {
   const int b = blockIdx.x / blocks_per_cloud;
+  if (only != nullptr && only[b] == 0) return;  // (behind the pruned search: only the samples it handed back)
   const int qbase = (blockIdx.x % blocks_per_cloud) * (THREADS * Q);
   const long long o1 = (long long)b * n1, o2 = (long long)b * n2;
   if (blockIdx.y == 0) {
@@ -124,22 +126,34 @@ __global__ __launch_bounds__(kThreads) void chamfer_grad_kernel(
 
 template <int Q, int MODE, int THREADS>
 void launch_nn(const float* xyz1, const float* xyz2, int64_t batch, int n1, int n2, float* dist1,
-               int64_t* idx1, float* dist2, int64_t* idx2, hipStream_t s) {
+               int64_t* idx1, float* dist2, int64_t* idx2, const int* only, hipStream_t s) {
   const int nmax = n1 > n2 ? n1 : n2;
   const int bpc = (nmax + THREADS * Q - 1) / (THREADS * Q);
   dim3 grid((unsigned)(batch * bpc), 2, 1);
   hipLaunchKernelGGL((chamfer_nn_kernel<Q, MODE, THREADS>), grid, dim3(THREADS), 0, s, xyz1, xyz2,
-                     n1, n2, bpc, dist1, (long long*)idx1, dist2, (long long*)idx2);
+                     n1, n2, bpc, dist1, (long long*)idx1, dist2, (long long*)idx2, only);
 }
 
 template <int MODE>
 void launch_nn_sized(const float* xyz1, const float* xyz2, int64_t batch, int n1, int n2,
-                     float* dist1, int64_t* idx1, float* dist2, int64_t* idx2, hipStream_t s) {
+                     float* dist1, int64_t* idx1, float* dist2, int64_t* idx2, hipStream_t s,
+                     const int* only = nullptr) {
   const int nmax = n1 > n2 ? n1 : n2;
   // 4 queries per lane x 256 lanes for real clouds; 2 x 64 for the <=256-point clouds of part
   // matching (reference base_model.py:163-173 sub-samples to 100 points).
-  if (nmax <= 256) launch_nn<2, MODE, 64>(xyz1, xyz2, batch, n1, n2, dist1, idx1, dist2, idx2, s);
-  else launch_nn<4, MODE, 256>(xyz1, xyz2, batch, n1, n2, dist1, idx1, dist2, idx2, s);
+  if (nmax <= 256) launch_nn<2, MODE, 64>(xyz1, xyz2, batch, n1, n2, dist1, idx1, dist2, idx2, only, s);
+  else launch_nn<4, MODE, 256>(xyz1, xyz2, batch, n1, n2, dist1, idx1, dist2, idx2, only, s);
+}
+
+// Which search answers a call: the exhaustive scan costs n1 * n2 pair evaluations per sample and direction, the
+// grid-pruned one a sort plus a few dozen candidates per query — but three launches and a 1024-thread sort block per
+// (sample, cloud, role) whatever the size.  Crossover measured on MI355X (DESIGN.md "Generic Chamfer: search choice").
+#ifndef MPA_CHAMFER_GRID_MIN_PAIRS
+#define MPA_CHAMFER_GRID_MIN_PAIRS (int64_t)(3000 * 3000)
+#endif
+bool grid_pays(int64_t batch, int64_t n1, int64_t n2) {
+  const int64_t nmin = n1 < n2 ? n1 : n2;
+  return nmin >= 512 && n1 * n2 >= MPA_CHAMFER_GRID_MIN_PAIRS && mpa::cloud_grid_supported(batch, n1, n2);
 }
 
 int check_forward_args(const void* xyz1, const void* xyz2, int64_t batch, int64_t n1, int64_t n2,
@@ -181,25 +195,54 @@ int chamfer_backward_impl(const S* grad_dist1, const S* grad_dist2, const S* xyz
 
 }  // namespace
 
-// variant: 0 = direct, 1 = fused-form gate, 2 = exact chunk-min (default) — see chamfer_core.h.
+// variant: 0 = direct, 1 = fused-form gate, 2 = exact chunk-min, 3 = grid-pruned (needs the workspace), -1 = by size
+// — see chamfer_core.h / grid_nn.hip.
 extern "C" int mpa_chamfer_forward_variant(const float* xyz1, const float* xyz2, int64_t batch,
                                            int64_t n1, int64_t n2, float* dist1, int64_t* idx1,
-                                           float* dist2, int64_t* idx2, int variant, void* stream) {
-  MPA_REQUIRE(variant >= 0 && variant <= 2, "chamfer_forward: unknown variant %d", variant);
+                                           float* dist2, int64_t* idx2, int variant, void* workspace,
+                                           int64_t workspace_bytes, void* stream) {
+  MPA_REQUIRE(variant >= -1 && variant <= 3, "chamfer_forward: unknown variant %d", variant);
   const int st = check_forward_args(xyz1, xyz2, batch, n1, n2, dist1, idx1, dist2, idx2);
   if (st != MPA_OK) return st < 0 ? st : MPA_OK;
   hipStream_t s = mpa::as_stream(stream);
   const int a = (int)n1, b = (int)n2;
-  if (variant == 0) launch_nn_sized<mpa::kDirect>(xyz1, xyz2, batch, a, b, dist1, idx1, dist2, idx2, s);
-  else if (variant == 1) launch_nn_sized<mpa::kFusedGate>(xyz1, xyz2, batch, a, b, dist1, idx1, dist2, idx2, s);
-  else launch_nn_sized<mpa::kChunkMin>(xyz1, xyz2, batch, a, b, dist1, idx1, dist2, idx2, s);
+  if (variant == 3)
+    MPA_REQUIRE(mpa::cloud_grid_supported(batch, n1, n2), "chamfer_forward: the grid-pruned search needs two non-empty clouds");
+  if (variant == -1) variant = grid_pays(batch, n1, n2) && workspace != nullptr ? 3 : 2;
+  if (variant == 3) {
+    MPA_REQUIRE(workspace != nullptr && workspace_bytes >= mpa::cloud_grid_workspace_bytes(batch, n1, n2),
+                "chamfer_forward: the grid-pruned search needs mpa_chamfer_workspace() bytes of workspace");
+    MPA_REQUIRE((uintptr_t)workspace % 16 == 0, "chamfer_forward: workspace must be 16-byte aligned");
+    const int* flagged = nullptr;
+    if (int e = mpa::launch_cloud_grid_search(xyz1, xyz2, batch, n1, n2, dist1, idx1, dist2, idx2, workspace, &flagged, s))
+      return e;
+    // samples the pruned search handed back (non-finite / huge coordinates): the exhaustive scan, for those only
+    launch_nn_sized<mpa::kChunkMin>(xyz1, xyz2, batch, a, b, dist1, idx1, dist2, idx2, s, flagged);
+  } else if (variant == 0) {
+    launch_nn_sized<mpa::kDirect>(xyz1, xyz2, batch, a, b, dist1, idx1, dist2, idx2, s);
+  } else if (variant == 1) {
+    launch_nn_sized<mpa::kFusedGate>(xyz1, xyz2, batch, a, b, dist1, idx1, dist2, idx2, s);
+  } else {
+    launch_nn_sized<mpa::kChunkMin>(xyz1, xyz2, batch, a, b, dist1, idx1, dist2, idx2, s);
+  }
   return mpa::check_launch("chamfer_forward");
+}
+
+extern "C" int mpa_chamfer_workspace(int64_t batch, int64_t n1, int64_t n2, int64_t* bytes) {
+  MPA_REQUIRE(bytes != nullptr, "chamfer_workspace: null pointer");
+  MPA_REQUIRE(batch >= 0 && n1 >= 0 && n2 >= 0, "chamfer_workspace: negative size");
+  *bytes = mpa::cloud_grid_supported(batch, n1, n2) ? mpa::cloud_grid_workspace_bytes(batch, n1, n2) : 0;
+  return MPA_OK;
 }
 
 extern "C" int mpa_chamfer_forward(const float* xyz1, const float* xyz2, int64_t batch, int64_t n1,
                                    int64_t n2, float* dist1, int64_t* idx1, float* dist2,
-                                   int64_t* idx2, void* stream) {
-  return mpa_chamfer_forward_variant(xyz1, xyz2, batch, n1, n2, dist1, idx1, dist2, idx2, 2, stream);
+                                   int64_t* idx2, void* workspace, int64_t workspace_bytes, void* stream) {
+  // without (enough) workspace the exhaustive scan answers every size: same results, n1 * n2 work
+  const bool ws_ok = workspace != nullptr && mpa::cloud_grid_supported(batch, n1, n2) &&
+                     workspace_bytes >= mpa::cloud_grid_workspace_bytes(batch, n1, n2);
+  return mpa_chamfer_forward_variant(xyz1, xyz2, batch, n1, n2, dist1, idx1, dist2, idx2, -1, ws_ok ? workspace : nullptr,
+                                     workspace_bytes, stream);
 }
 
 extern "C" int mpa_chamfer_forward_f64(const double* xyz1, const double* xyz2, int64_t batch,

@@ -74,9 +74,10 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 __device__ __forceinline__ void cell_of(const GridParams& g, float x, float y, float z, int& ix, int& iy,
                                         int& iz) {
-  ix = clampi((int)((x - g.ox) * g.inv_h), 0, g.gx - 1);
-  iy = clampi((int)((y - g.oy) * g.inv_h), 0, g.gy - 1);
-  iz = clampi((int)((z - g.oz) * g.inv_h), 0, g.gz - 1);
+  // (clamped as floats first: the generic operator bins far outliers, and a float -> int conversion must stay in range)
+  ix = clampi((int)__builtin_amdgcn_fmed3f((x - g.ox) * g.inv_h, 0.0f, 1024.0f), 0, g.gx - 1);
+  iy = clampi((int)__builtin_amdgcn_fmed3f((y - g.oy) * g.inv_h, 0.0f, 1024.0f), 0, g.gy - 1);
+  iz = clampi((int)__builtin_amdgcn_fmed3f((z - g.oz) * g.inv_h, 0.0f, 1024.0f), 0, g.gz - 1);
 }
 
 __device__ __forceinline__ int key_of(const GridParams& g, int role, float x, float y, float z) {
@@ -91,7 +92,10 @@ __device__ __forceinline__ int key_of(const GridParams& g, int role, float x, fl
 // The pose kernel of the loss leaves one box per PART (assembly_loss.hip: 12 floats, lo1 lo2 hi1 hi2); every sort block
 // reduces its sample's boxes and evaluates this itself (a separate one-block-per-sample kernel in front of the sorts
 // was 15 us of an almost empty chip).
-__device__ __forceinline__ void grid_params_from_boxes(const float* lo, const float* hi, int nvalid, GridParams& g) {
+// tlo / thi [6]: boxes that hold ALL points of each shape (what tb, the shapes' cell boxes, is taken from) — the same
+// boxes for the fused loss; the generic operator lays the grid over outlier-trimmed boxes and passes the full ones here.
+__device__ __forceinline__ void grid_params_from_boxes(const float* lo, const float* hi, int nvalid, GridParams& g,
+                                                       const float* tlo, const float* thi) {
   const float ulo[3] = {__builtin_fminf(lo[0], lo[3]), __builtin_fminf(lo[1], lo[4]), __builtin_fminf(lo[2], lo[5])};
   const float uhi[3] = {__builtin_fmaxf(hi[0], hi[3]), __builtin_fmaxf(hi[1], hi[4]), __builtin_fmaxf(hi[2], hi[5])};
   float ex = uhi[0] - ulo[0], ey = uhi[1] - ulo[1], ez = uhi[2] - ulo[2];
@@ -139,8 +143,8 @@ __device__ __forceinline__ void grid_params_from_boxes(const float* lo, const fl
       g.tb[c][3] = g.gy - 1;
       g.tb[c][5] = g.gz - 1;
     } else {
-      cell_of(g, lo[3 * c], lo[3 * c + 1], lo[3 * c + 2], g.tb[c][0], g.tb[c][2], g.tb[c][4]);
-      cell_of(g, hi[3 * c], hi[3 * c + 1], hi[3 * c + 2], g.tb[c][1], g.tb[c][3], g.tb[c][5]);
+      cell_of(g, tlo[3 * c], tlo[3 * c + 1], tlo[3 * c + 2], g.tb[c][0], g.tb[c][2], g.tb[c][4]);
+      cell_of(g, thi[3 * c], thi[3 * c + 1], thi[3 * c + 2], g.tb[c][1], g.tb[c][3], g.tb[c][5]);
     }
   }
 }
@@ -274,27 +278,55 @@ __device__ __forceinline__ void block_scan(int* __restrict__ cnt, int nkeys, int
 // blocks (each reads the shape's points itself: 240 KB from L2) — 128 instead of 64 blocks on 256 CUs, and neither
 // waits for the other's scan.
 constexpr int kSortU = 4;
-template <int ROLE>
-__device__ __forceinline__ void grid_sort_role(const float* __restrict__ vsm, const float* __restrict__ shape, int P, int N,
-                                               const GridParams& g, int slot, int* __restrict__ starts,
-                                               int* __restrict__ batches, int* __restrict__ worklist,
+
+// Where a sort block's points come from.  fetch(i, x, y, z): the point in flat slot i (unconditional load of a clamped
+// position: conditional loads send the unrolled arrays to scratch) and whether it takes part.
+struct PartsSource {  // the fused loss: P parts of N points, padded parts out
+  const float* vsm;   // the sample's valid flags (LDS)
+  const float* shape;
+  int N, total;
+  __device__ __forceinline__ bool fetch(int i, float& x, float& y, float& z) const {
+    const bool ok = i < total && vsm[i / N] != 0.0f;
+    const float* q = shape + 3LL * (ok ? i : 0);
+    x = q[0], y = q[1], z = q[2];
+    return ok;
+  }
+};
+// the generic operator: one cloud of `total` points.  As TARGETS, a point equal to its predecessor is dropped: the
+// strict-`<` in-order scan can never prefer it (same distance to every query, higher index), so the answer is unchanged
+// — and the 1e3-filled padded parts of shape_cd_loss (utils/loss.py:173-175: N identical points per padded part) shrink
+// to one record each.  As QUERIES every point takes part.  A sample routed to the exhaustive scan sorts nothing.
+template <bool DEDUPE>
+struct CloudSource {
+  const float* cloud;
+  int total;
+  bool off;
+  __device__ __forceinline__ bool fetch(int i, float& x, float& y, float& z) const {
+    const bool in = i < total && !off;
+    const float* q = cloud + 3LL * (in ? i : 0);
+    x = q[0], y = q[1], z = q[2];
+    if (!DEDUPE) return in;
+    const float* r = cloud + 3LL * (in && i > 0 ? i - 1 : 0);
+    const float px = r[0], py = r[1], pz = r[2];
+    return in && (i == 0 || !(px == x && py == y && pz == z));
+  }
+};
+
+template <int ROLE, bool GENERIC, class Src>
+__device__ __forceinline__ void grid_sort_role(const Src& src, const GridParams& g, int slot, int* __restrict__ starts,
+                                               int* __restrict__ batches, int* __restrict__ worklist, int work_stride,
                                                float4* __restrict__ records, int rec_stride, int* cnt, int (*wsum)[2]) {
   const int nkeys = ROLE == 0 ? g.ncells : g.nsuper;
   for (int i = threadIdx.x; i < padk(nkeys) + 1; i += 1024) cnt[i] = 0;
   __syncthreads();
-  // all P * N point slots in one flat loop, kSortU loads per thread in flight (a loop over the parts was one dependent
+  // all point slots in one flat loop, kSortU loads per thread in flight (a loop over the parts was one dependent
   // memory round trip per valid part and pass)
-  const int total = P * N;
+  const int total = src.total;
   for (int i0 = threadIdx.x; i0 < total; i0 += 1024 * kSortU) {
     float x[kSortU], y[kSortU], z[kSortU];
     bool ok[kSortU];
 #pragma unroll
-    for (int u = 0; u < kSortU; ++u) {
-      const int i = i0 + 1024 * u;
-      ok[u] = i < total && vsm[i / N] != 0.0f;
-      const float* q = shape + 3LL * (ok[u] ? i : 0);
-      x[u] = q[0], y[u] = q[1], z[u] = q[2];
-    }
+    for (int u = 0; u < kSortU; ++u) ok[u] = src.fetch(i0 + 1024 * u, x[u], y[u], z[u]);
 #pragma unroll
     for (int u = 0; u < kSortU; ++u)
       if (ok[u]) atomicAdd(&cnt[padk(key_of(g, ROLE, x[u], y[u], z[u]))], 1);
@@ -304,24 +336,21 @@ __device__ __forceinline__ void grid_sort_role(const float* __restrict__ vsm, co
     block_scan<kMaxCells / 1024, false>(cnt, nkeys, starts + (long long)slot * kStartStride, nullptr, nullptr, wsum);
   else
     block_scan<kMaxSuper / 1024, true>(cnt, nkeys, starts + (long long)slot * kStartStride,
-                                       batches + (long long)slot * kStartStride, worklist + (long long)slot * kWorkStride,
+                                       batches + (long long)slot * kStartStride, worklist + (long long)slot * work_stride,
                                        wsum);
   __syncthreads();
   float4* out = records + (long long)slot * rec_stride;
   if (ROLE == 0 && threadIdx.x < 8) {  // sentinels: chunked reads may run past the last record
     const float inf = __builtin_inff();
-    out[g.nvalid + threadIdx.x] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
+    // (generic: the record count is what the scan left behind the last key — written by this block, in front of a barrier)
+    const int nrec = GENERIC ? starts[(long long)slot * kStartStride + nkeys] : g.nvalid;
+    out[nrec + threadIdx.x] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
   }
   for (int i0 = threadIdx.x; i0 < total; i0 += 1024 * kSortU) {
     float x[kSortU], y[kSortU], z[kSortU];
     bool ok[kSortU];
 #pragma unroll
-    for (int u = 0; u < kSortU; ++u) {
-      const int i = i0 + 1024 * u;
-      ok[u] = i < total && vsm[i / N] != 0.0f;
-      const float* q = shape + 3LL * (ok[u] ? i : 0);
-      x[u] = q[0], y[u] = q[1], z[u] = q[2];
-    }
+    for (int u = 0; u < kSortU; ++u) ok[u] = src.fetch(i0 + 1024 * u, x[u], y[u], z[u]);
 #pragma unroll
     for (int u = 0; u < kSortU; ++u)
       if (ok[u])
@@ -372,7 +401,7 @@ __global__ __launch_bounds__(1024) void grid_sort_kernel(const float* __restrict
     }
     if (threadIdx.x == 0) {
       GridParams gl;
-      grid_params_from_boxes(lo, hi, nval, gl);
+      grid_params_from_boxes(lo, hi, nval, gl, lo, hi);
       gsm = gl;
       if (role == 0 && c == 0) params[b] = gl;  // for the search kernel
     }
@@ -388,10 +417,218 @@ __global__ __launch_bounds__(1024) void grid_sort_kernel(const float* __restrict
   }
   const int slot = (b * 2 + c) * 2 + role;
   const float* shape = (c == 0 ? S1 : S2) + 3LL * b * P * N;
-  if (role == 0) grid_sort_role<0>(vsm, shape, P, N, g, slot, starts, batches, worklist, records, rec_stride, cnt, wsum);
-  else grid_sort_role<1>(vsm, shape, P, N, g, slot, starts, batches, worklist, records, rec_stride, cnt, wsum);
+  const PartsSource src{vsm, shape, N, P * N};
+  if (role == 0) grid_sort_role<0, false>(src, g, slot, starts, batches, worklist, kWorkStride, records, rec_stride, cnt, wsum);
+  else grid_sort_role<1, false>(src, g, slot, starts, batches, worklist, kWorkStride, records, rec_stride, cnt, wsum);
   if (plan == nullptr) return;
   // the last block of the launch plans the search's waves: everybody's batch counts are in global memory by then
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  grid_assign_plan(params, batches, (int)(gridDim.x / 2), nwaves, plan);
+}
+
+// ---- 2c. the generic operator's sort: two plain clouds per sample (chamfer.hip, mpa_chamfer_forward) -------------------
+// Same launch shape and outputs as grid_sort_kernel; the grid comes from the clouds themselves.  A uniform grid over the
+// bounding box dies on outliers — shape_cd_loss hands over clouds whose padded parts sit at (1e3, 1e3, 1e3) while the
+// shape itself spans ~1 — so the grid is laid over an OUTLIER-TRIMMED box (two rounds of 3-sigma clipping of the
+// distinct points, in double) and everything outside is binned into the border cells, which the search treats as
+// unbounded outwards.  The trimming only steers speed: the search is exact for ANY box.
+// Samples holding a non-finite or huge (> 1e15: squares would overflow) coordinate are flagged instead (fallback[b] = 1):
+// they sort nothing here and are answered by the exhaustive scan behind the search.
+struct CloudStats {
+  double sum[3], sq[3];
+  float lo[3], hi[3];
+  int cnt, bad;
+};
+
+// block-wide (1024 threads) reduction of one CloudStats; the result lands in every thread.  Fixed order: all four sort
+// blocks of a sample must arrive at the SAME grid, bit for bit.
+__device__ __forceinline__ void block_reduce_stats(CloudStats& st, CloudStats* sm /* [16] in LDS */, CloudStats* out_sm) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      st.sum[k] += __shfl_xor(st.sum[k], off, 64);
+      st.sq[k] += __shfl_xor(st.sq[k], off, 64);
+      st.lo[k] = __builtin_fminf(st.lo[k], __shfl_xor(st.lo[k], off, 64));
+      st.hi[k] = __builtin_fmaxf(st.hi[k], __shfl_xor(st.hi[k], off, 64));
+    }
+    st.cnt += __shfl_xor(st.cnt, off, 64);
+    st.bad |= __shfl_xor(st.bad, off, 64);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = st;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    CloudStats t = sm[0];
+#pragma unroll 1
+    for (int w = 1; w < 16; ++w) {
+      for (int k = 0; k < 3; ++k) {
+        t.sum[k] += sm[w].sum[k];
+        t.sq[k] += sm[w].sq[k];
+        t.lo[k] = __builtin_fminf(t.lo[k], sm[w].lo[k]);
+        t.hi[k] = __builtin_fmaxf(t.hi[k], sm[w].hi[k]);
+      }
+      t.cnt += sm[w].cnt;
+      t.bad |= sm[w].bad;
+    }
+    *out_sm = t;
+  }
+  __syncthreads();
+  st = *out_sm;
+}
+
+// statistics of the distinct points of one cloud that lie inside [clo, chi] (all three axes)
+__device__ __forceinline__ CloudStats cloud_stats(const float* __restrict__ cloud, int n, const float* clo, const float* chi) {
+  CloudStats st;
+  for (int k = 0; k < 3; ++k) {
+    st.sum[k] = st.sq[k] = 0.0;
+    st.lo[k] = __builtin_inff();
+    st.hi[k] = -__builtin_inff();
+  }
+  st.cnt = st.bad = 0;
+  constexpr int U = 4;  // points per thread in flight (one dependent L2 round trip per iteration otherwise)
+#pragma unroll 1
+  for (int i0 = threadIdx.x; i0 < n; i0 += 1024 * U) {
+    float v[U][3], r[U][3];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + 1024 * u < n ? i0 + 1024 * u : n - 1;
+      const float* q = cloud + 3LL * i;
+      const float* pr = cloud + 3LL * (i > 0 ? i - 1 : 0);
+      v[u][0] = q[0], v[u][1] = q[1], v[u][2] = q[2];
+      r[u][0] = pr[0], r[u][1] = pr[1], r[u][2] = pr[2];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + 1024 * u;
+      const bool dup = i > 0 && r[u][0] == v[u][0] && r[u][1] == v[u][1] && r[u][2] == v[u][2];
+      bool in = i < n && !dup;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (i < n && !(__builtin_fabsf(v[u][k]) <= 1e15f)) st.bad = 1;  // (NaN fails the comparison too)
+        in = in && v[u][k] >= clo[k] && v[u][k] <= chi[k];
+      }
+      if (in) {
+        ++st.cnt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          st.sum[k] += (double)v[u][k];
+          st.sq[k] += (double)v[u][k] * (double)v[u][k];
+          st.lo[k] = __builtin_fminf(st.lo[k], v[u][k]);
+          st.hi[k] = __builtin_fmaxf(st.hi[k], v[u][k]);
+        }
+      }
+    }
+  }
+  return st;
+}
+
+// mean +- 3 sigma of `st`, rounded outwards, into clo / chi; returns whether that interval cuts anything off the box
+__device__ __forceinline__ bool clip_interval(const CloudStats& st, float* clo, float* chi) {
+  bool cuts = false;
+  for (int k = 0; k < 3; ++k) {
+    const double mean = st.sum[k] / (double)st.cnt;
+    double var = st.sq[k] / (double)st.cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double sd = __builtin_sqrt(var), a = mean - 3.0 * sd, b = mean + 3.0 * sd;
+    clo[k] = (float)(a - 1e-6 * __builtin_fabs(a) - 1e-30);
+    chi[k] = (float)(b + 1e-6 * __builtin_fabs(b) + 1e-30);
+    cuts = cuts || clo[k] > st.lo[k] || chi[k] < st.hi[k];
+  }
+  return cuts;
+}
+
+__global__ __launch_bounds__(1024) void cloud_sort_kernel(const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                          int n1, int n2, GridParams* __restrict__ params,
+                                                          int* __restrict__ fallback, int* __restrict__ starts,
+                                                          int* __restrict__ batches, int* __restrict__ worklist,
+                                                          int work_stride, float4* __restrict__ records, int rec_stride,
+                                                          unsigned* __restrict__ ticket, XcdPlan* __restrict__ plan,
+                                                          int nwaves) {
+  __shared__ int cnt[kMaxCells + kMaxCells / 32 + 1];
+  __shared__ int wsum[16][2];
+  __shared__ GridParams gsm;
+  __shared__ bool last;
+  __shared__ CloudStats ssm[17];
+  __shared__ float box[24];  // lo[6] hi[6] (trimmed, what the grid covers) tlo[6] thi[6] (full) — [3 * cloud + axis]
+  __shared__ int nuniq_sm, bad_sm;
+  const int role = blockIdx.x & 1, c = (blockIdx.x >> 1) & 1, b = blockIdx.x >> 2;
+  const float* const cl0 = xyz1 + 3LL * b * n1;
+  const float* const cl1 = xyz2 + 3LL * b * n2;
+  if (threadIdx.x == 0) nuniq_sm = bad_sm = 0;
+  // the sample's grid.  Per cloud: full box + moments of its distinct points; clipped twice at 3 sigma if that cuts anything
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) {
+    const float* cloud = k == 0 ? cl0 : cl1;
+    const int n = k == 0 ? n1 : n2;
+    float clo[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    float chi[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    CloudStats st = cloud_stats(cloud, n, clo, chi);
+    block_reduce_stats(st, ssm, ssm + 16);
+    if (threadIdx.x == 0) {
+      bad_sm |= st.bad;
+      nuniq_sm = st.cnt > nuniq_sm ? st.cnt : nuniq_sm;
+      for (int a = 0; a < 3; ++a) {
+        box[12 + 3 * k + a] = box[3 * k + a] = st.lo[a];
+        box[18 + 3 * k + a] = box[6 + 3 * k + a] = st.hi[a];
+      }
+    }
+    if (!st.bad) {
+#pragma unroll 1
+      for (int round = 0; round < 2 && st.cnt > 0; ++round) {  // (uniform condition: st is the same in every thread)
+        if (!clip_interval(st, clo, chi)) break;
+        st = cloud_stats(cloud, n, clo, chi);
+        block_reduce_stats(st, ssm, ssm + 16);
+      }
+      if (threadIdx.x == 0 && st.cnt > 0) {  // (nothing survived the clipping: cannot happen, but then the full box stays)
+        for (int a = 0; a < 3; ++a) {
+          box[3 * k + a] = st.lo[a];
+          box[6 + 3 * k + a] = st.hi[a];
+        }
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    int bad = bad_sm;
+    // a trimmed box too large for fp32 cell arithmetic (its volume must not overflow): the exhaustive scan as well
+    float e = 0.0f;
+    for (int a = 0; a < 12; ++a) e = __builtin_fmaxf(e, __builtin_fabsf(box[a]));
+    if (!(e < 1e10f)) bad = 1;
+    GridParams gl;
+    grid_params_from_boxes(box, box + 6, bad ? 0 : nuniq_sm, gl, box + 12, box + 18);
+    gl.pad0 = bad;
+    gsm = gl;
+    if (role == 0 && c == 0) {
+      params[b] = gl;
+      fallback[b] = bad;
+    }
+  }
+  __syncthreads();
+  GridParams g;
+  {
+    const int* src = reinterpret_cast<const int*>(&gsm);
+    int* dst = reinterpret_cast<int*>(&g);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(GridParams) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
+  }
+  const float* const cloud_c = c == 0 ? cl0 : cl1;
+  const int n_c = c == 0 ? n1 : n2;
+  const int slot = (b * 2 + c) * 2 + role;
+  if (role == 0) {
+    const CloudSource<true> src{cloud_c, n_c, g.pad0 != 0};
+    grid_sort_role<0, true>(src, g, slot, starts, batches, worklist, work_stride, records, rec_stride, cnt, wsum);
+  } else {
+    const CloudSource<false> src{cloud_c, n_c, g.pad0 != 0};
+    grid_sort_role<1, true>(src, g, slot, starts, batches, worklist, work_stride, records, rec_stride, cnt, wsum);
+  }
+  if (plan == nullptr) return;
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -601,12 +838,18 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
 
 // grid = (768 persistent waves per (sample, dir) on average), block 64.  blockIdx.y = b*2 + dir; dir 0: shape 1 queries
 // against shape 2 targets.
+// GENERIC (the operator of chamfer.hip: two plain clouds [B, P, 3] and [B, N, 3] per sample — P, N are the point counts
+// there, no valid flags, int64 indices out) differs from the fused loss's search in what the pruning may assume:
+//   * points outside the (outlier-trimmed) grid sit in its border cells, so a border cell / row is unbounded outwards;
+//   * the queries of a wave are boxed by their actual coordinates (a wave-wide min / max), not by their super-cell;
+//   * all geometry is relative to the grid origin (the origin may be large against the cell size).
+template <bool GENERIC, typename IdxT>
 __global__ __launch_bounds__(64) void grid_search_kernel(
     const float* __restrict__ valids, const float* __restrict__ S1, const float* __restrict__ S2, int P,
     int N, const GridParams* __restrict__ params, const float4* __restrict__ records,
     const int* __restrict__ starts, const int* __restrict__ batches, const int* __restrict__ worklist,
-    int rec_stride, float* __restrict__ dist1, float* __restrict__ dist2, int* __restrict__ idx1,
-    int* __restrict__ idx2, const XcdPlan* __restrict__ plan) {
+    int work_stride, int rec_stride, float* __restrict__ dist1, float* __restrict__ dist2, IdxT* __restrict__ idx1,
+    IdxT* __restrict__ idx2, const XcdPlan* __restrict__ plan) {
   __shared__ float4 cand[kCand];
   __shared__ int sidx[kCand];  // record index of every position of the current window
   // block -> (sample, direction, wave): from the XCD-aware plan (grid_assign_plan) or, without one, waves
@@ -634,13 +877,14 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
   const float4* trec = records + (long long)tslot * rec_stride;
   const int* tst = starts + (long long)tslot * kStartStride;
   const int* qst = starts + (long long)qslot * kStartStride;
-  const float* tcloud = (tc == 0 ? S1 : S2) + 3LL * b * P * N;
-  const float* vb = valids + (long long)b * P;
-  float* dout = (dir == 0 ? dist1 : dist2) + (long long)b * P * N;
-  int* iout = (dir == 0 ? idx1 : idx2) + (long long)b * P * N;
+  const long long qstride = GENERIC ? (long long)(dir == 0 ? P : N) : (long long)P * N;  // points per sample, query side
+  float* dout = (dir == 0 ? dist1 : dist2) + (long long)b * qstride;
+  IdxT* iout = (dir == 0 ? idx1 : idx2) + (long long)b * qstride;
   const int* bst = batches + (long long)qslot * kStartStride;
   const int total_work = bst[g.nsuper];
   const int lane = threadIdx.x;
+  // origin of the geometry below: absolute coordinates for the fused loss, relative to the grid origin otherwise
+  const float OX = GENERIC ? 0.0f : g.ox, OY = GENERIC ? 0.0f : g.oy, OZ = GENERIC ? 0.0f : g.oz;
   // the target shape's own cell bounding box: rows and cells outside it are empty, and a query far from a compact
   // target would otherwise walk hundreds of empty rows before reaching it
   const int* tbox = g.tb[tc];
@@ -649,17 +893,21 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
   // padded parts: one representative target each (index p*N), the same for every work item; lane p holds part p's
   float px = 0.0f, py = 0.0f, pz = 0.0f;
   bool pad = false;
-  if (lane < P && vb[lane] == 0.0f) {
-    pad = true;
-    const float* t = tcloud + 3LL * lane * N;
-    px = t[0];
-    py = t[1];
-    pz = t[2];
+  if constexpr (!GENERIC) {
+    const float* tcloud = (tc == 0 ? S1 : S2) + 3LL * b * P * N;
+    const float* vb = valids + (long long)b * P;
+    if (lane < P && vb[lane] == 0.0f) {
+      pad = true;
+      const float* t = tcloud + 3LL * lane * N;
+      px = t[0];
+      py = t[1];
+      pz = t[2];
+    }
   }
-  const unsigned long long padmask = __ballot(pad);
+  const unsigned long long padmask = GENERIC ? 0ull : __ballot(pad);
 
   for (int work = wid; work < total_work; work += wstride) {  // persistent walk over the work list
-    const int sc = worklist[(long long)qslot * kWorkStride + work];  // super-cell with bst[sc] <= work < bst[sc+1]
+    const int sc = worklist[(long long)qslot * work_stride + work];  // super-cell with bst[sc] <= work < bst[sc+1]
     const int qb = qst[sc] + (work - bst[sc]) * kBatch, q_end = qst[sc + 1];
     const int sx = sc % g.sgx, sy = (sc / g.sgx) % g.sgy, sz = sc / (g.sgx * g.sgy);
     LaneState s;
@@ -676,9 +924,16 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     s.best = 1e32f;
     s.bidx = 0x7fffffff;
     // the queries lie in the super-cell box (inflated by the binning slack)
-    const float bx0 = g.ox + (float)(kS * sx) * g.h - slack, bx1 = g.ox + (float)(kS * sx + kS) * g.h + slack;
-    const float by0 = g.oy + (float)(kS * sy) * g.h - slack, by1 = g.oy + (float)(kS * sy + kS) * g.h + slack;
-    const float bz0 = g.oz + (float)(kS * sz) * g.h - slack, bz1 = g.oz + (float)(kS * sz + kS) * g.h + slack;
+    float bx0 = OX + (float)(kS * sx) * g.h - slack, bx1 = OX + (float)(kS * sx + kS) * g.h + slack;
+    float by0 = OY + (float)(kS * sy) * g.h - slack, by1 = OY + (float)(kS * sy + kS) * g.h + slack;
+    float bz0 = OZ + (float)(kS * sz) * g.h - slack, bz1 = OZ + (float)(kS * sz + kS) * g.h + slack;
+    if constexpr (GENERIC) {  // ... unless they were binned from outside the grid: box them by their coordinates (idle
+                              // lanes shadow a real query)
+      const float rx = s.X - g.ox, ry = s.Y - g.oy, rz = s.Z - g.oz;
+      bx0 = -wave_max(-rx) - slack, bx1 = wave_max(rx) + slack;
+      by0 = -wave_max(-ry) - slack, by1 = wave_max(ry) + slack;
+      bz0 = -wave_max(-rz) - slack, bz1 = wave_max(rz) + slack;
+    }
     // seed: the super-cell grown by one fine cell per side ((kS+2)^2 rows, lane = row), clipped to the target box
     const int x0 = clampi(kS * sx - 1, 0, g.gx - 1), x1 = clampi(kS * sx + kS, 0, g.gx - 1);
     const int y0 = clampi(kS * sy - 1, 0, g.gy - 1), y1 = clampi(kS * sy + kS, 0, g.gy - 1);
@@ -724,15 +979,27 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
         y = ((i - 2 * W) & 1) ? yhi : ylo;
       }
       if (!live || z < tz0 || z > tz1 || y < ty0 || y > ty1) return;
-      const float cz0 = g.oz + (float)z * g.h - slack, cz1 = g.oz + (float)(z + 1) * g.h + slack;
-      const float cy0 = g.oy + (float)y * g.h - slack, cy1 = g.oy + (float)(y + 1) * g.h + slack;
+      float cz0 = OZ + (float)z * g.h - slack, cz1 = OZ + (float)(z + 1) * g.h + slack;
+      float cy0 = OY + (float)y * g.h - slack, cy1 = OY + (float)(y + 1) * g.h + slack;
+      if constexpr (GENERIC) {  // border rows hold whatever lies beyond them
+        const float inf = __builtin_inff();
+        cz0 = z == 0 ? -inf : cz0, cz1 = z == g.gz - 1 ? inf : cz1;
+        cy0 = y == 0 ? -inf : cy0, cy1 = y == g.gy - 1 ? inf : cy1;
+      }
       const float dz = gap(bz0, bz1, cz0, cz1), dy = gap(by0, by1, cy0, cy1);
       const float rem = bound - dz * dz - dy * dy;
       if (rem <= 0.0f) return;
       // cells x with gap_x(x)^2 < rem: an interval around the super-cell
       const float reach = __builtin_sqrtf(rem) + slack;
-      int xa = clampi((int)__builtin_floorf((bx0 - reach - g.ox) * g.inv_h), 0, g.gx - 1);
-      int xb = clampi((int)__builtin_floorf((bx1 + reach - g.ox) * g.inv_h), 0, g.gx - 1);
+      int xa, xb;
+      if constexpr (GENERIC) {  // (clamped as floats: far queries put these beyond the int range; the border cells, which
+                                // hold everything beyond the grid, are reached exactly when the clamped index says so)
+        xa = clampi((int)__builtin_amdgcn_fmed3f(__builtin_floorf((bx0 - reach) * g.inv_h), -1.0f, 1024.0f), 0, g.gx - 1);
+        xb = clampi((int)__builtin_amdgcn_fmed3f(__builtin_floorf((bx1 + reach) * g.inv_h), -1.0f, 1024.0f), 0, g.gx - 1);
+      } else {
+        xa = clampi((int)__builtin_floorf((bx0 - reach - g.ox) * g.inv_h), 0, g.gx - 1);
+        xb = clampi((int)__builtin_floorf((bx1 + reach - g.ox) * g.inv_h), 0, g.gx - 1);
+      }
       if (bound > 1e31f) {  // nothing found yet: the whole row
         xa = 0;
         xb = g.gx - 1;
@@ -784,7 +1051,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     if (has && lane < 64 / s.split) {  // (every group holds the merged result; the padded parts' representatives
                                        // were considered by all of them)
       dout[qflat] = s.best;
-      iout[qflat] = s.bidx == 0x7fffffff ? -1 : s.bidx;
+      iout[qflat] = s.bidx == 0x7fffffff ? (IdxT)-1 : (IdxT)s.bidx;
     }
   }  // work loop
 }
@@ -847,15 +1114,83 @@ int launch_grid_shape_search(const float* valids, const float* S1, const float* 
                      grid_ticket(iws, B), xcd_table ? plan : (XcdPlan*)nullptr, nwaves);
   if (before_search != nullptr) (void)hipEventRecord(before_search, s);
   if (xcd_table)
-    hipLaunchKernelGGL(grid_search_kernel, dim3((unsigned)nwaves), dim3(64), 0, s, valids, S1, S2, (int)P, (int)N, params,
-                       records, starts, batches, worklist, rec_stride, dist1, dist2, idx1, idx2, (const XcdPlan*)plan);
+    hipLaunchKernelGGL((grid_search_kernel<false, int>), dim3((unsigned)nwaves), dim3(64), 0, s, valids, S1, S2, (int)P,
+                       (int)N, params, records, starts, batches, worklist, kWorkStride, rec_stride, dist1, dist2, idx1, idx2,
+                       (const XcdPlan*)plan);
   else
-    hipLaunchKernelGGL(grid_search_kernel, dim3(MPA_GRID_WAVES, (unsigned)(2 * B)), dim3(64), 0, s, valids, S1, S2, (int)P,
-                       (int)N, params, records, starts, batches, worklist, rec_stride, dist1, dist2, idx1, idx2,
-                       (const XcdPlan*)nullptr);
+    hipLaunchKernelGGL((grid_search_kernel<false, int>), dim3(MPA_GRID_WAVES, (unsigned)(2 * B)), dim3(64), 0, s, valids, S1,
+                       S2, (int)P, (int)N, params, records, starts, batches, worklist, kWorkStride, rec_stride, dist1, dist2,
+                       idx1, idx2, (const XcdPlan*)nullptr);
   if (after_search != nullptr) (void)hipEventRecord(after_search, s);
   hipLaunchKernelGGL(grid_part_sum_kernel, dim3((unsigned)(B * P), 2), dim3(256), 0, s, valids, dist1, dist2, (int)N,
                      tiles, tile_sums);
+  return MPA_OK;
+}
+
+// ---- the generic operator's entry (chamfer.hip) ---------------------------------------------------------------------------
+namespace {
+struct CloudWs {
+  float4* records;
+  GridParams* params;
+  int *starts, *batches, *worklist, *fallback;
+  XcdPlan* plan;
+  unsigned* ticket;
+  int rec_stride, work_stride;
+  int64_t bytes;
+};
+CloudWs cloud_ws(void* base, int64_t B, int64_t n1, int64_t n2) {
+  const int64_t nmax = n1 > n2 ? n1 : n2;
+  CloudWs w;
+  w.rec_stride = (int)(nmax + 8);
+  w.work_stride = (int)(kMaxSuper + nmax / kBatch + 64);
+  char* p = static_cast<char*>(base);
+  auto take = [&p](int64_t bytes) {
+    char* q = p;
+    p += (bytes + 255) / 256 * 256;
+    return q;
+  };
+  w.records = reinterpret_cast<float4*>(take(4 * B * (int64_t)w.rec_stride * 16));
+  w.params = reinterpret_cast<GridParams*>(take(B * (int64_t)sizeof(GridParams)));
+  w.starts = reinterpret_cast<int*>(take(4 * B * (int64_t)kStartStride * 4));
+  w.batches = reinterpret_cast<int*>(take(4 * B * (int64_t)kStartStride * 4));
+  w.worklist = reinterpret_cast<int*>(take(4 * B * (int64_t)w.work_stride * 4));
+  w.plan = reinterpret_cast<XcdPlan*>(take(sizeof(XcdPlan)));
+  w.ticket = reinterpret_cast<unsigned*>(take(64));
+  w.fallback = reinterpret_cast<int*>(take(B * 4));
+  w.bytes = p - static_cast<char*>(base);
+  return w;
+}
+}  // namespace
+
+int64_t cloud_grid_workspace_bytes(int64_t B, int64_t n1, int64_t n2) { return cloud_ws(nullptr, B, n1, n2).bytes; }
+
+bool cloud_grid_supported(int64_t B, int64_t n1, int64_t n2) {
+  // the sort block indexes points with ints and keeps one histogram in LDS; 2^22 points per cloud is far beyond what the
+  // 32768-cell grid prunes well, but stays correct
+  return B >= 1 && n1 >= 1 && n2 >= 1 && n1 <= (1 << 22) && n2 <= (1 << 22) && 4 * B < (1 << 30) / kStartStride;
+}
+
+int launch_cloud_grid_search(const float* xyz1, const float* xyz2, int64_t B, int64_t n1, int64_t n2, float* dist1,
+                             int64_t* idx1, float* dist2, int64_t* idx2, void* workspace, const int** fallback,
+                             hipStream_t s) {
+  const CloudWs w = cloud_ws(workspace, B, n1, n2);
+  const bool xcd_table = MPA_GRID_XCD && 2 * B >= 8 && 2 * B <= kMaxPairs;
+  const int nwaves = (int)(MPA_GRID_WAVES * 2 * B);
+  zero_words_async(w.ticket, 16, s);
+  hipLaunchKernelGGL(cloud_sort_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, xyz1, xyz2, (int)n1, (int)n2, w.params,
+                     w.fallback, w.starts, w.batches, w.worklist, w.work_stride, w.records, w.rec_stride, w.ticket,
+                     xcd_table ? w.plan : (XcdPlan*)nullptr, nwaves);
+  long long* i1 = reinterpret_cast<long long*>(idx1);
+  long long* i2 = reinterpret_cast<long long*>(idx2);
+  if (xcd_table)
+    hipLaunchKernelGGL((grid_search_kernel<true, long long>), dim3((unsigned)nwaves), dim3(64), 0, s, (const float*)nullptr,
+                       xyz1, xyz2, (int)n1, (int)n2, w.params, w.records, w.starts, w.batches, w.worklist, w.work_stride,
+                       w.rec_stride, dist1, dist2, i1, i2, (const XcdPlan*)w.plan);
+  else
+    hipLaunchKernelGGL((grid_search_kernel<true, long long>), dim3(MPA_GRID_WAVES, (unsigned)(2 * B)), dim3(64), 0, s,
+                       (const float*)nullptr, xyz1, xyz2, (int)n1, (int)n2, w.params, w.records, w.starts, w.batches,
+                       w.worklist, w.work_stride, w.rec_stride, dist1, dist2, i1, i2, (const XcdPlan*)nullptr);
+  *fallback = w.fallback;
   return MPA_OK;
 }
 

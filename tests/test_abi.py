@@ -36,12 +36,12 @@ def test_library_loads_and_reports_abi(built):
 def test_argument_validation_needs_no_gpu(built):
     L = _lib.lib()
     # negative sizes are rejected before anything touches the device
-    st = L.mpa_chamfer_forward(None, None, -1, 4, 4, None, None, None, None, None)
+    st = L.mpa_chamfer_forward(None, None, -1, 4, 4, None, None, None, None, None, 0, None)
     assert st == -1 and b"negative" in L.mpa_last_error()
-    st = L.mpa_chamfer_forward(None, None, 2, 4, 4, None, None, None, None, None)
+    st = L.mpa_chamfer_forward(None, None, 2, 4, 4, None, None, None, None, None, 0, None)
     assert st == -1 and b"null" in L.mpa_last_error()
     # empty problems are a no-op success
-    assert L.mpa_chamfer_forward(None, None, 0, 4, 4, None, None, None, None, None) == 0
+    assert L.mpa_chamfer_forward(None, None, 0, 4, 4, None, None, None, None, None, 0, None) == 0
     assert L.mpa_pose_apply_forward(None, None, None, None, ctypes.c_float(0), 0, 10, None, None) == 0
 
 

@@ -147,3 +147,129 @@ def test_full_size_properties(cuda_device):
         z = C.chamfer_forward(a, a)
         assert (z[0] == 0).all()
         assert torch.equal(z[1], torch.arange(n, device=cuda_device).expand(B, n))
+
+
+# ---- the grid-pruned search behind mpa_chamfer_forward (csrc/grid_nn.hip: cloud_sort_kernel + grid_search_kernel<true>) ----
+def _cloud(kind, rng, B, n):
+    """Clouds that stress what the pruning assumes: clumps, flat / degenerate extents, exact duplicates, far outliers and
+    the padded-part fill of shape_cd_loss (utils/loss.py:173-175)."""
+    if kind == "normal":
+        return rng.standard_normal((B, n, 3)).astype(np.float32)
+    if kind == "uniform_offset":  # an origin far larger than the cell size
+        return (rng.random((B, n, 3)) * 0.3 + np.array([500.0, -700.0, 90.0])).astype(np.float32)
+    if kind == "flat":  # a plane: one axis has no extent at all
+        x = rng.random((B, n, 3)).astype(np.float32)
+        x[..., 2] = 0.25
+        return x
+    if kind == "line":
+        t = rng.random((B, n, 1)).astype(np.float32)
+        return (t * np.array([1.0, 2.0, -1.0], np.float32)).astype(np.float32)
+    if kind == "clumps":
+        c = rng.standard_normal((B, 6, 3)).astype(np.float32)
+        pick = rng.integers(0, 6, (B, n))
+        return (np.take_along_axis(c, pick[..., None].repeat(3, -1), 1) + 1e-3 * rng.standard_normal((B, n, 3))).astype(np.float32)
+    if kind == "duplicates":  # every point four times, scattered: ties resolved by the lowest index
+        base = rng.random((B, (n + 3) // 4, 3)).astype(np.float32)
+        x = np.concatenate([base] * 4, 1)[:, :n]
+        return np.stack([x[b][rng.permutation(n)] for b in range(B)])
+    if kind == "one_point":
+        return np.broadcast_to(rng.random((B, 1, 3)).astype(np.float32), (B, n, 3)).copy()
+    if kind == "outliers":  # 5 % of the points up to 1e6 away
+        x = rng.standard_normal((B, n, 3)).astype(np.float32)
+        far = rng.random((B, n)) < 0.05
+        x[far] *= np.float32(10.0) ** rng.integers(1, 7, (int(far.sum()), 1)).astype(np.float32)
+        return x
+    if kind == "padded_fill":  # shape_cd_loss: the last parts are N copies of (1e3, 1e3, 1e3) + t
+        x = (rng.random((B, n, 3)) - 0.5).astype(np.float32)
+        for b in range(B):
+            cut = int(n * rng.uniform(0.1, 0.9))
+            part = max(1, (n - cut) // 4)
+            for s in range(cut, n, part):
+                x[b, s:s + part] = np.float32(1e3) + rng.uniform(-0.5, 0.5, 3).astype(np.float32)
+        return x
+    raise KeyError(kind)
+
+
+KINDS = ["normal", "uniform_offset", "flat", "line", "clumps", "duplicates", "one_point", "outliers", "padded_fill"]
+
+
+@pytest.mark.parametrize("kind2", ["normal", "padded_fill", "outliers"])
+@pytest.mark.parametrize("kind1", KINDS)
+def test_grid_search_matches_oracle(cuda_device, kind1, kind2):
+    """variant 3 forces the pruned search at sizes the oracle finishes in a moment: every output bit-equal to the
+    sequential strict-`<` scan of oracle/chamfer_ref.c."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(f"{kind1}/{kind2}".encode()))
+    for B, n1, n2 in ((3, 700, 900), (2, 1, 1500), (1, 2300, 64)):
+        a, b = _cloud(kind1, rng, B, n1), _cloud(kind2, rng, B, n2)
+        ref = oc.chamfer_forward(a, b)
+        out = C.chamfer_forward(_dev(a, cuda_device), _dev(b, cuda_device), variant=3)
+        for got, want, name in zip(out, ref, ("dist1", "idx1", "dist2", "idx2")):
+            np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"{name} {kind1} {kind2} {(B, n1, n2)}")
+
+
+def test_grid_search_hands_non_finite_samples_to_the_scan(cuda_device):
+    """A sample with a NaN / inf / > 1e15 coordinate is answered by the exhaustive scan (same contract as the scan's own
+    special-value test); its neighbours in the batch still go through the grid."""
+    rng = np.random.default_rng(77)
+    a = rng.standard_normal((5, 600, 3)).astype(np.float32)
+    b = rng.standard_normal((5, 800, 3)).astype(np.float32)
+    a[1, 17, 0] = np.nan
+    b[2, 5, 2] = np.inf
+    b[3, 9, 1] = -3e16
+    a[4, 100] = 9e14  # large but legal: stays on the grid path
+    ref = oc.chamfer_forward(a, b)
+    out = C.chamfer_forward(_dev(a, cuda_device), _dev(b, cuda_device), variant=3)
+    for got, want in zip(out, ref):
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_grid_search_full_size_equals_the_scan(cuda_device):
+    """§8(d)'s whole-shape call, [32, 20000, 3] against itself with the 1e3 padding fill applied: the default dispatch
+    (pruned search) against the exhaustive scan, bit for bit, on shape-like clouds whose prediction is (a) far from and
+    (b) close to the target; plus unequal cloud sizes."""
+    g = torch.Generator().manual_seed(5)
+    B, P, N = 32, 20, 1000
+    parts = torch.randint(2, P + 1, (B,), generator=g)
+    base = (torch.rand(B, P, N, 3, generator=g) - 0.5) * torch.rand(B, P, 1, 3, generator=g) * 0.6
+    off1, off2 = (torch.rand(B, P, 1, 3, generator=g) - 0.5) * 0.8, (torch.rand(B, P, 1, 3, generator=g) - 0.5) * 0.8
+    for close in (False, True):
+        s1 = base + off1
+        s2 = base + (off1 + 0.01 * off2 if close else off2)
+        for b in range(B):
+            s1[b, parts[b]:] = 1e3 + off1[b, parts[b]:]
+            s2[b, parts[b]:] = 1e3
+        x1 = s1.reshape(B, P * N, 3).contiguous().to(cuda_device)
+        x2 = s2.reshape(B, P * N, 3).contiguous().to(cuda_device)
+        fast = C.chamfer_forward(x1, x2)
+        slow = C.chamfer_forward(x1, x2, variant=2)
+        for f, s in zip(fast, slow):
+            assert torch.equal(f, s)
+    y1 = x1[:, :12345].contiguous()
+    fast, slow = C.chamfer_forward(y1, x2), C.chamfer_forward(y1, x2, variant=2)
+    for f, s in zip(fast, slow):
+        assert torch.equal(f, s)
+
+
+def test_chamfer_workspace_contract(cuda_device):
+    """mpa_chamfer_workspace sizes the scratch; without it (or with too little) mpa_chamfer_forward still answers, by the
+    exhaustive scan; variant 3 without workspace is an error, not a silent fallback."""
+    import ctypes
+    from multi_part_assembly_amd import _lib
+    L = _lib.lib()
+    nb = ctypes.c_int64(-1)
+    assert L.mpa_chamfer_workspace(32, 20000, 20000, ctypes.byref(nb)) == 0 and nb.value > 0
+    assert L.mpa_chamfer_workspace(4, 0, 100, ctypes.byref(nb)) == 0 and nb.value == 0
+    a = torch.rand(2, 4000, 3, device=cuda_device)
+    b = torch.rand(2, 4000, 3, device=cuda_device)
+    d1 = torch.empty(2, 4000, device=cuda_device)
+    d2 = torch.empty(2, 4000, device=cuda_device)
+    i1 = torch.empty(2, 4000, dtype=torch.int64, device=cuda_device)
+    i2 = torch.empty(2, 4000, dtype=torch.int64, device=cuda_device)
+    s = _lib.current_stream(cuda_device)
+    args = (a.data_ptr(), b.data_ptr(), 2, 4000, 4000, d1.data_ptr(), i1.data_ptr(), d2.data_ptr(), i2.data_ptr())
+    assert L.mpa_chamfer_forward(*args, None, 0, s) == 0
+    want = C.chamfer_forward(a, b)
+    assert torch.equal(d1, want[0]) and torch.equal(i1, want[1]) and torch.equal(i2, want[3])
+    assert L.mpa_chamfer_forward_variant(*args, 3, None, 0, s) == _lib.lib().mpa_chamfer_forward_variant(*args, 3, None, 0, s) != 0
+    assert b"workspace" in L.mpa_last_error()

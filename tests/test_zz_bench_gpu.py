@@ -43,6 +43,12 @@ def test_bench_line_has_the_contract_keys(cuda_device):
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # the drop-in operator on its own: SURVEY.md 8(d)'s two standalone shapes through the C ABI
+    cs = d["chamfer_standalone"]["cases"]
+    assert len(cs) == 3 and all(x["GBps"] > 0 and x["calls"] == 20 for x in cs)
+    assert cs[0]["algorithmic_bytes_per_call"] == 24.0 * 640 * 2000 and cs[1]["algorithmic_bytes_per_call"] == 24.0 * 32 * 40000
+    assert cs[0]["search"].startswith("exhaustive") and all(x["search"].startswith("grid") for x in cs[1:])
+    assert all(x["bit_equal_to_exhaustive_scan"] is True for x in cs[1:])
 
 
 def _committed_ms(tag):
@@ -60,7 +66,7 @@ def test_other_configs_hold_their_committed_step_time(cuda_device, capsys, tag, 
     """BASELINE.json configs[2] / configs[4] and the bf16 variant line, 10 timed steps each under the driver's own GPU
     test run: the JSON line is printed (so the run's log witnesses the number) next to the builder-run line committed
     under profiles/ and their ratio.  Only the structure of the line is asserted."""
-    d = _run("--steps", "10", "--warmup", "3", "--no-cpu-baseline", *flags)
+    d = _run("--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-chamfer-standalone", *flags)
     want, src = _committed_ms(tag)
     with capsys.disabled():
         slim = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "dtype")}
@@ -79,7 +85,7 @@ def test_other_configs_hold_their_committed_step_time(cuda_device, capsys, tag, 
 def test_plumbing_config_with_its_cpu_baseline_and_self_check(cuda_device, capsys):
     """configs[0] (B-Global, semantic flags, P = 2, B = 4) with its full-size CPU baseline on all physical cores.  The
     step time and CPU rate are printed, not judged."""
-    d = _run("--config", "c1", "--steps", "10", "--warmup", "5")
+    d = _run("--config", "c1", "--steps", "10", "--warmup", "5", "--no-chamfer-standalone")
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "B=4," in c["sample"]
     with capsys.disabled():
@@ -91,7 +97,7 @@ def test_self_check_leg_reports_the_ratio(cuda_device, capsys):
     """`--self-check M` on the headline config (c2, device-bound) after 20 warm-up steps: the leg runs M further steps
     and reports their mean against the K timed ones.  The ratio is printed for the record; only its presence and the
     step count are asserted."""
-    d = _run("--steps", "20", "--warmup", "20", "--self-check", "40", "--no-cpu-baseline")
+    d = _run("--steps", "20", "--warmup", "20", "--self-check", "40", "--no-cpu-baseline", "--no-chamfer-standalone")
     sc = d["self_check"]
     assert sc["steps"] == 40 and sc["ms_per_step"] > 0 and sc["ratio_to_timed_mean"] > 0
     with capsys.disabled():
