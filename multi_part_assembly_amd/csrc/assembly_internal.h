@@ -32,5 +32,9 @@ bool cloud_grid_supported(int64_t B, int64_t n1, int64_t n2);
 int launch_cloud_grid_search(const float* xyz1, const float* xyz2, int64_t B, int64_t n1, int64_t n2, float* dist1,
                              int64_t* idx1, float* dist2, int64_t* idx2, void* workspace, const int** fallback,
                              hipStream_t s);
+// ... and, behind the caller's scan of the flagged samples: points that repeat their predecessor were not searched (neither
+// here nor — same answer — need they be): they take the answer of the first point of their run.
+void launch_cloud_copy_runs(int64_t B, int64_t n1, int64_t n2, float* dist1, int64_t* idx1, float* dist2, int64_t* idx2,
+                            void* workspace, hipStream_t s);
 
 }  // namespace mpa

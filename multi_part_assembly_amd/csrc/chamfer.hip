@@ -218,6 +218,7 @@ extern "C" int mpa_chamfer_forward_variant(const float* xyz1, const float* xyz2,
       return e;
     // samples the pruned search handed back (non-finite / huge coordinates): the exhaustive scan, for those only
     launch_nn_sized<mpa::kChunkMin>(xyz1, xyz2, batch, a, b, dist1, idx1, dist2, idx2, s, flagged);
+    mpa::launch_cloud_copy_runs(batch, n1, n2, dist1, idx1, dist2, idx2, workspace, s);
   } else if (variant == 0) {
     launch_nn_sized<mpa::kDirect>(xyz1, xyz2, batch, a, b, dist1, idx1, dist2, idx2, s);
   } else if (variant == 1) {

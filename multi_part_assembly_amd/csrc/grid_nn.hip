@@ -295,7 +295,10 @@ struct PartsSource {  // the fused loss: P parts of N points, padded parts out
 // the generic operator: one cloud of `total` points.  As TARGETS, a point equal to its predecessor is dropped: the
 // strict-`<` in-order scan can never prefer it (same distance to every query, higher index), so the answer is unchanged
 // — and the 1e3-filled padded parts of shape_cd_loss (utils/loss.py:173-175: N identical points per padded part) shrink
-// to one record each.  As QUERIES every point takes part.  A sample routed to the exhaustive scan sorts nothing.
+// to one record each.  As QUERIES the same points are dropped — a point equal to its predecessor has its predecessor's
+// answer, copied behind the search (cloud_copy_runs_kernel) from the head of its run: the far-away padded points are the
+// most expensive queries a grid can get (everything is "near" from 1e3 away), and there are thousands of copies of each.
+// A sample routed to the exhaustive scan sorts nothing.
 template <bool DEDUPE>
 struct CloudSource {
   const float* cloud;
@@ -493,7 +496,7 @@ __device__ __forceinline__ CloudStats cloud_stats(const float* __restrict__ clou
     st.hi[k] = -__builtin_inff();
   }
   st.cnt = st.bad = 0;
-  constexpr int U = 4;  // points per thread in flight (one dependent L2 round trip per iteration otherwise)
+  constexpr int U = 8;  // points per thread in flight (one dependent memory round trip per iteration otherwise)
 #pragma unroll 1
   for (int i0 = threadIdx.x; i0 < n; i0 += 1024 * U) {
     float v[U][3], r[U][3];
@@ -545,64 +548,114 @@ __device__ __forceinline__ bool clip_interval(const CloudStats& st, float* clo, 
   return cuts;
 }
 
+// What the sort needs to know about one cloud of one sample: written by cloud_stats_kernel, [b * 2 + cloud].
+struct __attribute__((aligned(16))) CloudBox {
+  float lo[3], hi[3];    // trimmed box of its distinct points (what the grid should cover)
+  float tlo[3], thi[3];  // box of all its points
+  int cnt, bad, pad0, pad1;
+};
+
+// grid = (2, B), block 1024: one block per (cloud, sample) — the box of the cloud (moments of its distinct points, up to
+// two rounds of 3-sigma clipping if that cuts anything off) and the head of every point's run of identical points
+// (itself for a point that differs from its predecessor).
+__global__ __launch_bounds__(1024) void cloud_stats_kernel(const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                           int n1, int n2, int hstride, CloudBox* __restrict__ boxes,
+                                                           int* __restrict__ heads) {
+  __shared__ CloudStats ssm[17];
+  __shared__ int wave_head[2][16];
+  const int c = blockIdx.x, b = blockIdx.y, n = c == 0 ? n1 : n2;
+  const float* const cloud = (c == 0 ? xyz1 + 3LL * b * n1 : xyz2 + 3LL * b * n2);
+  float clo[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  float chi[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  CloudStats st = cloud_stats(cloud, n, clo, chi);
+  block_reduce_stats(st, ssm, ssm + 16);
+  CloudBox out;
+  for (int a = 0; a < 3; ++a) {
+    out.tlo[a] = out.lo[a] = st.lo[a];
+    out.thi[a] = out.hi[a] = st.hi[a];
+  }
+  out.cnt = st.cnt;
+  out.bad = st.bad;
+  out.pad0 = out.pad1 = 0;
+  if (!st.bad) {
+#pragma unroll 1
+    for (int round = 0; round < 2 && st.cnt > 0; ++round) {  // (uniform condition: st is the same in every thread)
+      if (!clip_interval(st, clo, chi)) break;
+      st = cloud_stats(cloud, n, clo, chi);
+      block_reduce_stats(st, ssm, ssm + 16);
+    }
+    if (st.cnt > 0) {  // (nothing survived the clipping: cannot happen, but then the full box stays)
+      for (int a = 0; a < 3; ++a) {
+        out.lo[a] = st.lo[a];
+        out.hi[a] = st.hi[a];
+      }
+    }
+  }
+  if (threadIdx.x == 0) boxes[b * 2 + c] = out;
+  // run heads: tiles of 1024 consecutive points, the last head of a tile carried into the next (one barrier per tile:
+  // the per-wave results are double-buffered, and every thread derives the carry itself)
+  int* hd = heads + (long long)(b * 2 + c) * hstride;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int carry = 0, buf = 0;
+  constexpr int HU = 4;  // tiles whose points are loaded together (one memory round trip per HU tiles)
+  for (int g0 = 0; g0 < n; g0 += 1024 * HU) {
+    bool uq[HU];
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+      const int i = g0 + 1024 * u + (int)threadIdx.x;
+      const float* q = cloud + 3LL * (i < n ? i : 0);
+      const float* r = cloud + 3LL * (i < n && i > 0 ? i - 1 : 0);
+      uq[u] = i < n && (i == 0 || !(r[0] == q[0] && r[1] == q[1] && r[2] == q[2]));
+    }
+#pragma unroll
+    for (int u = 0; u < HU; ++u, buf ^= 1) {
+      const int t0 = g0 + 1024 * u, i = t0 + (int)threadIdx.x;
+      if (t0 >= n) break;  // (uniform)
+      const unsigned long long below = __ballot(uq[u]) & (~0ull >> (63 - lane));
+      int h = below ? t0 + w * 64 + 63 - __builtin_clzll(below) : -1;
+      if (lane == 63) wave_head[buf][w] = h;
+      __syncthreads();
+      int next = carry;
+      for (int ww = 0; ww < 16; ++ww) {
+        const int v = wave_head[buf][ww];
+        if (ww < w && h < 0 && v >= 0) next = v;  // (ascending: the last hit below this wave wins)
+        carry = v >= 0 ? v : carry;
+      }
+      if (h < 0) h = next;
+      if (i < n) hd[i] = h;
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void cloud_sort_kernel(const float* __restrict__ xyz1, const float* __restrict__ xyz2,
-                                                          int n1, int n2, GridParams* __restrict__ params,
-                                                          int* __restrict__ fallback, int* __restrict__ starts,
-                                                          int* __restrict__ batches, int* __restrict__ worklist,
-                                                          int work_stride, float4* __restrict__ records, int rec_stride,
+                                                          int n1, int n2, const CloudBox* __restrict__ boxes,
+                                                          GridParams* __restrict__ params, int* __restrict__ fallback,
+                                                          int* __restrict__ starts, int* __restrict__ batches,
+                                                          int* __restrict__ worklist, int work_stride,
+                                                          float4* __restrict__ records, int rec_stride,
                                                           unsigned* __restrict__ ticket, XcdPlan* __restrict__ plan,
                                                           int nwaves) {
   __shared__ int cnt[kMaxCells + kMaxCells / 32 + 1];
   __shared__ int wsum[16][2];
   __shared__ GridParams gsm;
   __shared__ bool last;
-  __shared__ CloudStats ssm[17];
-  __shared__ float box[24];  // lo[6] hi[6] (trimmed, what the grid covers) tlo[6] thi[6] (full) — [3 * cloud + axis]
-  __shared__ int nuniq_sm, bad_sm;
   const int role = blockIdx.x & 1, c = (blockIdx.x >> 1) & 1, b = blockIdx.x >> 2;
   const float* const cl0 = xyz1 + 3LL * b * n1;
   const float* const cl1 = xyz2 + 3LL * b * n2;
-  if (threadIdx.x == 0) nuniq_sm = bad_sm = 0;
-  // the sample's grid.  Per cloud: full box + moments of its distinct points; clipped twice at 3 sigma if that cuts anything
-#pragma unroll 1
-  for (int k = 0; k < 2; ++k) {
-    const float* cloud = k == 0 ? cl0 : cl1;
-    const int n = k == 0 ? n1 : n2;
-    float clo[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    float chi[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
-    CloudStats st = cloud_stats(cloud, n, clo, chi);
-    block_reduce_stats(st, ssm, ssm + 16);
-    if (threadIdx.x == 0) {
-      bad_sm |= st.bad;
-      nuniq_sm = st.cnt > nuniq_sm ? st.cnt : nuniq_sm;
-      for (int a = 0; a < 3; ++a) {
-        box[12 + 3 * k + a] = box[3 * k + a] = st.lo[a];
-        box[18 + 3 * k + a] = box[6 + 3 * k + a] = st.hi[a];
-      }
+  if (threadIdx.x == 0) {  // the sample's grid, from the boxes of its two clouds
+    const CloudBox b0 = boxes[b * 2], b1 = boxes[b * 2 + 1];
+    float box[24];  // lo[6] hi[6] (trimmed: what the grid covers) tlo[6] thi[6] (full) — [3 * cloud + axis]
+    for (int a = 0; a < 3; ++a) {
+      box[a] = b0.lo[a], box[3 + a] = b1.lo[a], box[6 + a] = b0.hi[a], box[9 + a] = b1.hi[a];
+      box[12 + a] = b0.tlo[a], box[15 + a] = b1.tlo[a], box[18 + a] = b0.thi[a], box[21 + a] = b1.thi[a];
     }
-    if (!st.bad) {
-#pragma unroll 1
-      for (int round = 0; round < 2 && st.cnt > 0; ++round) {  // (uniform condition: st is the same in every thread)
-        if (!clip_interval(st, clo, chi)) break;
-        st = cloud_stats(cloud, n, clo, chi);
-        block_reduce_stats(st, ssm, ssm + 16);
-      }
-      if (threadIdx.x == 0 && st.cnt > 0) {  // (nothing survived the clipping: cannot happen, but then the full box stays)
-        for (int a = 0; a < 3; ++a) {
-          box[3 * k + a] = st.lo[a];
-          box[6 + 3 * k + a] = st.hi[a];
-        }
-      }
-    }
-  }
-  if (threadIdx.x == 0) {
-    int bad = bad_sm;
+    int bad = b0.bad | b1.bad;
     // a trimmed box too large for fp32 cell arithmetic (its volume must not overflow): the exhaustive scan as well
     float e = 0.0f;
     for (int a = 0; a < 12; ++a) e = __builtin_fmaxf(e, __builtin_fabsf(box[a]));
     if (!(e < 1e10f)) bad = 1;
     GridParams gl;
-    grid_params_from_boxes(box, box + 6, bad ? 0 : nuniq_sm, gl, box + 12, box + 18);
+    grid_params_from_boxes(box, box + 6, bad ? 0 : (b0.cnt > b1.cnt ? b0.cnt : b1.cnt), gl, box + 12, box + 18);
     gl.pad0 = bad;
     gsm = gl;
     if (role == 0 && c == 0) {
@@ -621,13 +674,11 @@ __global__ __launch_bounds__(1024) void cloud_sort_kernel(const float* __restric
   const float* const cloud_c = c == 0 ? cl0 : cl1;
   const int n_c = c == 0 ? n1 : n2;
   const int slot = (b * 2 + c) * 2 + role;
-  if (role == 0) {
-    const CloudSource<true> src{cloud_c, n_c, g.pad0 != 0};
+  const CloudSource<true> src{cloud_c, n_c, g.pad0 != 0};
+  if (role == 0)
     grid_sort_role<0, true>(src, g, slot, starts, batches, worklist, work_stride, records, rec_stride, cnt, wsum);
-  } else {
-    const CloudSource<false> src{cloud_c, n_c, g.pad0 != 0};
+  else
     grid_sort_role<1, true>(src, g, slot, starts, batches, worklist, work_stride, records, rec_stride, cnt, wsum);
-  }
   if (plan == nullptr) return;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -638,6 +689,21 @@ __global__ __launch_bounds__(1024) void cloud_sort_kernel(const float* __restric
   if (!last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   grid_assign_plan(params, batches, (int)(gridDim.x / 2), nwaves, plan);
+}
+
+// behind the search (and the hand-back scan): every point that repeats its predecessor takes the answer of its run's head
+__global__ __launch_bounds__(256) void cloud_copy_runs_kernel(const int* __restrict__ heads, int n1, int n2, int hstride,
+                                                              float* __restrict__ dist1, float* __restrict__ dist2,
+                                                              long long* __restrict__ idx1, long long* __restrict__ idx2) {
+  const int b = blockIdx.y >> 1, c = blockIdx.y & 1, n = c == 0 ? n1 : n2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int h = heads[(long long)(b * 2 + c) * hstride + i];
+  if (h == i) return;
+  float* d = (c == 0 ? dist1 : dist2) + (long long)b * n;
+  long long* ix = (c == 0 ? idx1 : idx2) + (long long)b * n;
+  d[i] = d[h];
+  ix[i] = ix[h];
 }
 
 // ---- 3. search ----------------------------------------------------------------------------------------------------
@@ -843,6 +909,8 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
 //   * points outside the (outlier-trimmed) grid sit in its border cells, so a border cell / row is unbounded outwards;
 //   * the queries of a wave are boxed by their actual coordinates (a wave-wide min / max), not by their super-cell;
 //   * all geometry is relative to the grid origin (the origin may be large against the cell size).
+// (GENERIC compiles to 84 VGPRs = 5 waves per SIMD against the fused loss's 78 = 6; forcing 6 costs a spill and measured
+// the same: 0.526 vs 0.529 ms per [32, 20000, 3]^2 call)
 template <bool GENERIC, typename IdxT>
 __global__ __launch_bounds__(64) void grid_search_kernel(
     const float* __restrict__ valids, const float* __restrict__ S1, const float* __restrict__ S2, int P,
@@ -956,6 +1024,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     // batch.
     merge_halves(s);
     float bound = wave_max(s.best) * 1.00001f;
+    MPA_STAT(6, bound > 1e31f ? 1 : 0);
     const int yc0 = kS * sy, yc1 = kS * sy + kS - 1, zc0 = kS * sz, zc1 = kS * sz + kS - 1;
     const int rmax = max(max(yc0, g.gy - 1 - yc1), max(zc0, g.gz - 1 - zc1));
     auto ring_rows = [&](int r) { return r == 0 ? kS * kS : 2 * (kS + 2 * r) + 2 * (kS + 2 * r - 2); };
@@ -1034,6 +1103,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
       for (int i0 = 0; i0 < nrows; i0 += 64) {
         int rb, re;
         row_range(r, 0, i0 + lane, i0 + lane < nrows, rb, re);
+        MPA_STAT(5, 1);
         scan_batch(s, trec, rb, re, cand, sidx);
       }
       merge_halves(s);
@@ -1132,7 +1202,8 @@ namespace {
 struct CloudWs {
   float4* records;
   GridParams* params;
-  int *starts, *batches, *worklist, *fallback;
+  int *starts, *batches, *worklist, *fallback, *heads;
+  CloudBox* boxes;
   XcdPlan* plan;
   unsigned* ticket;
   int rec_stride, work_stride;
@@ -1157,6 +1228,8 @@ CloudWs cloud_ws(void* base, int64_t B, int64_t n1, int64_t n2) {
   w.plan = reinterpret_cast<XcdPlan*>(take(sizeof(XcdPlan)));
   w.ticket = reinterpret_cast<unsigned*>(take(64));
   w.fallback = reinterpret_cast<int*>(take(B * 4));
+  w.heads = reinterpret_cast<int*>(take(2 * B * nmax * 4));
+  w.boxes = reinterpret_cast<CloudBox*>(take(2 * B * (int64_t)sizeof(CloudBox)));
   w.bytes = p - static_cast<char*>(base);
   return w;
 }
@@ -1177,9 +1250,11 @@ int launch_cloud_grid_search(const float* xyz1, const float* xyz2, int64_t B, in
   const bool xcd_table = MPA_GRID_XCD && 2 * B >= 8 && 2 * B <= kMaxPairs;
   const int nwaves = (int)(MPA_GRID_WAVES * 2 * B);
   zero_words_async(w.ticket, 16, s);
-  hipLaunchKernelGGL(cloud_sort_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, xyz1, xyz2, (int)n1, (int)n2, w.params,
-                     w.fallback, w.starts, w.batches, w.worklist, w.work_stride, w.records, w.rec_stride, w.ticket,
-                     xcd_table ? w.plan : (XcdPlan*)nullptr, nwaves);
+  hipLaunchKernelGGL(cloud_stats_kernel, dim3(2, (unsigned)B), dim3(1024), 0, s, xyz1, xyz2, (int)n1, (int)n2,
+                     w.rec_stride - 8, w.boxes, w.heads);
+  hipLaunchKernelGGL(cloud_sort_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, xyz1, xyz2, (int)n1, (int)n2,
+                     (const CloudBox*)w.boxes, w.params, w.fallback, w.starts, w.batches, w.worklist, w.work_stride,
+                     w.records, w.rec_stride, w.ticket, xcd_table ? w.plan : (XcdPlan*)nullptr, nwaves);
   long long* i1 = reinterpret_cast<long long*>(idx1);
   long long* i2 = reinterpret_cast<long long*>(idx2);
   if (xcd_table)
@@ -1192,6 +1267,15 @@ int launch_cloud_grid_search(const float* xyz1, const float* xyz2, int64_t B, in
                        w.worklist, w.work_stride, w.rec_stride, dist1, dist2, i1, i2, (const XcdPlan*)nullptr);
   *fallback = w.fallback;
   return MPA_OK;
+}
+
+void launch_cloud_copy_runs(int64_t B, int64_t n1, int64_t n2, float* dist1, int64_t* idx1, float* dist2, int64_t* idx2,
+                            void* workspace, hipStream_t s) {
+  const CloudWs w = cloud_ws(workspace, B, n1, n2);
+  const int64_t nmax = n1 > n2 ? n1 : n2;
+  hipLaunchKernelGGL(cloud_copy_runs_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)(2 * B)), dim3(256), 0, s,
+                     (const int*)w.heads, (int)n1, (int)n2, (int)nmax, dist1, dist2, reinterpret_cast<long long*>(idx1),
+                     reinterpret_cast<long long*>(idx2));
 }
 
 }  // namespace mpa
