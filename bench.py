@@ -100,9 +100,13 @@ def relaunch_distributed(args):
 
 
 # ---- workloads ----------------------------------------------------------------------------------------------------
-def workload(name, rank, dev):
-    """-> (cfg, batch, description, B, P)."""
+N_BATCHES = 4  # distinct synthetic batches rotated through the warm-up and timed steps (batch k: seed 1234 + rank + 1000 k)
+
+
+def workload(name, rank, dev, k=0):
+    """-> (cfg, batch k of this rank, description, B, P)."""
     from multi_part_assembly_amd import config, synthetic
+    rank = rank + 1000 * k
     if name in ("c2", "c4"):
         cfg = config.pn_transformer_everyday()
         batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234 + rank, device=dev)
@@ -250,9 +254,9 @@ def _find(kernels, prefix):
     return [(k, v) for k, v in kernels.items() if k.startswith(prefix)]
 
 
-def kernel_table(kernels, num_parts, cfg, B, P):
-    """Per-kernel fractions of the bound that binds each of the large kernels (algorithmic work / measured time)."""
-    nv = sum(num_parts)
+def kernel_table(kernels, nv, cfg, B, P):
+    """Per-kernel fractions of the bound that binds each of the large kernels (algorithmic work / measured time);
+    nv = valid parts per step (mean over the rotated batches)."""
     N = POINTS
     F = cfg.model.pc_feat_dim
     rows = {}
@@ -401,6 +405,7 @@ def main():
     from multi_part_assembly_amd.trainer import Trainer
 
     cfg, batch, desc, B, P = workload(args.config, rank, dev)
+    batches = [batch] + [workload(args.config, rank, dev, k)[1] for k in range(1, N_BATCHES)]
     torch.manual_seed(0)  # same initial weights on every rank (and broadcast from rank 0 anyway)
     model = build_model(cfg).to(dev)
     if args.dtype == "bf16":
@@ -412,12 +417,16 @@ def main():
             m.precision = "bf16"
     use_graph = args.graph and not args.eager
     trainer = Trainer(model, cfg, use_graph=use_graph)
-    num_parts = batch.pop("num_parts")
-    valid_parts = int(sum(num_parts))
+    parts_of = [bt.pop("num_parts") for bt in batches]
+    num_parts = parts_of[0]
+    valid_per_batch = [int(sum(n)) for n in parts_of]
+    # units of the roofline kernels PER LAUNCH, averaged over the launches of the timed region (batch i % N_BATCHES in step i)
+    used = [valid_per_batch[i % N_BATCHES] for i in range(max(1, args.steps))]
+    valid_parts = sum(used) / len(used)
 
     # untimed: W warm-up steps (+ the eager settle steps and the capture itself in graph mode)
     for i in range(args.warmup + (trainer.graph_warmup + 1 if use_graph else 0)):
-        trainer.train_step(batch, i)
+        trainer.train_step(batches[i % N_BATCHES], i)
 
     def fence():
         torch.cuda.synchronize()
@@ -431,12 +440,12 @@ def main():
     # Inside the timed region only the roofline kernel is bracketed by HIP events (recorded by the library right around
     # it: two records per step); the per-phase table of every entry point (~60 records per step, 0.1 ms of gaps in a
     # 2.7 ms step) is taken in a second, untimed pass over the same K steps.
-    roof_timer = _lib.KernelTimer(only=("grid_search_kernel", "dgcnn_knn"))
+    roof_timer = _lib.KernelTimer(only=("grid_search_kernel", "dgcnn_knn") + (("chamfer_forward[",) if args.config == "c1" else ()))
     if not use_graph:
         _lib.KernelTimer.active = roof_timer
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = trainer.train_step(batch, i)
+        loss = trainer.train_step(batches[i % N_BATCHES], i)
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -449,7 +458,7 @@ def main():
         fence()
         t1 = time.perf_counter()
         for i in range(args.self_check):
-            trainer.train_step(batch, i)
+            trainer.train_step(batches[i % N_BATCHES], i)
         fence()
         long_ms = 1e3 * (time.perf_counter() - t1) / args.self_check
         gc.enable()
@@ -471,7 +480,7 @@ def main():
         # per-phase timing pass (not timed): the same K steps launched eagerly with every entry point instrumented
         _lib.KernelTimer.active = timer
         for i in range(args.steps):
-            trainer._fwd_bwd(batch)
+            trainer._fwd_bwd(batches[i % N_BATCHES])
             trainer.optimizer.prepare_hyper()
             trainer.optimizer.step_dev()
         torch.cuda.synchronize()
@@ -514,10 +523,12 @@ def main():
                 alg = float(valid_parts) * N * (4 * C + 20 * 8)
                 pairs = float(valid_parts) * N * N
                 traffic, traffic_src = None, None
-                pmc = sorted((ROOT / "profiles").glob("r*_pmc_knn_kernel.json"))
-                if pmc:  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes
-                    rec = json.loads(pmc[-1].read_text())
-                    if str(C) in rec.get("per_width", {}):
+                pmc = sorted((ROOT / "profiles").glob("r*_pmc_knn_kernel_c5.json" if args.config == "c5"
+                                                     else "r*_pmc_knn_kernel.json"))
+                if pmc:  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes OF THIS WORKLOAD (same
+                    rec = json.loads(pmc[-1].read_text())  # clouds per launch), else null
+                    same = rec.get("clouds_per_launch") is not None and abs(rec["clouds_per_launch"] - valid_parts) < 0.5
+                    if same and str(C) in rec.get("per_width", {}):
                         traffic = rec["per_width"][str(C)]["traffic_bytes_per_launch"]
                         traffic_src = f"profiles/{pmc[-1].name}: {rec['correction']}"
                 roofline = {
@@ -548,14 +559,17 @@ def main():
                 # 24 B per point of both clouds (12 B xyz read, 4 B distance, 8 B index written);
                 # padded parts cost nothing here (one representative point each), so valid points only.
                 alg_bytes = 2.0 * 24.0 * valid_parts * N
-                brute_pairs = 2.0 * N * N * sum(n * n for n in num_parts)
+                brute_pairs = 2.0 * N * N * sum(sum(n * n for n in parts_of[i % N_BATCHES])
+                                                for i in range(max(1, args.steps))) / max(1, args.steps)
                 secs = k["avg_ms"] * 1e-3
                 achieved = alg_bytes / secs / 1e9
                 traffic, traffic_src = None, None
                 pmc = sorted((ROOT / "profiles").glob("r*_pmc_dominant_kernel.json"))
-                if pmc:  # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes
+                if pmc:  # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes of c2
                     rec = json.loads(pmc[-1].read_text())
-                    traffic, traffic_src = rec["traffic_bytes_per_launch"], f"profiles/{pmc[-1].name}: {rec['correction']}"
+                    if (args.config in ("c2", "c4") and rec.get("clouds_per_launch") is not None
+                            and abs(rec["clouds_per_launch"] - valid_parts) < 0.5):
+                        traffic, traffic_src = rec["traffic_bytes_per_launch"], f"profiles/{pmc[-1].name}: {rec['correction']}"
                 roofline = {
                     "kernel": "mpa::grid_search_kernel (exact grid-pruned whole-shape Chamfer search of the fused "
                               "loss, both directions)",
@@ -574,6 +588,27 @@ def main():
                     "timing": timing,
                     "whole_phase_avg_ms": phase[0][1]["avg_ms"] if phase else None,
                 }
+            elif args.config == "c1":
+                # plumbing case (P = 2: no grid phase): the loss runs the drop-in operator itself, 5 min-of-N samples x
+                # (whole-shape call [B, P*N, 3]^2 + per-part call) per step; the whole-shape call dominates
+                hit = _find(kernels, f"chamfer_forward[{B}x{P * N}x{P * N}]")
+                if hit:
+                    k = hit[0][1]
+                    secs = k["avg_ms"] * 1e-3
+                    alg_bytes = 24.0 * B * 2 * P * N
+                    pairs = 2.0 * B * (P * N) ** 2
+                    roofline = {
+                        "kernel": f"chamfer_nn_kernel behind mpa_chamfer_forward, whole-shape call [{B}, {P * N}, 3]^2 of "
+                                  "shape_cd_loss (exhaustive scan: below the grid-pruned search's size threshold)",
+                        "bound": "hbm", "achieved": alg_bytes / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg_bytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                        "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
+                        "algorithmic_bytes_per_launch": alg_bytes,
+                        "binding": {"bound": "valu", "pair_evals_per_launch": pairs,
+                                    "frac": 8.6 * pairs / secs / VALU_PEAK_LANE_OPS,
+                                    "note": "4 samples x 2 directions x 2000 queries = 63 waves of work on 1024 SIMDs: the "
+                                            "call is far too small to fill the chip (launch-latency territory)"},
+                        "timing": timing}
         rccl = None
         if distributed:
             try:
@@ -587,7 +622,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": desc, "name": args.config,
                        "per_gpu_batch": B, "max_parts": P, "points_per_part": POINTS,
-                       "valid_parts_rank0": valid_parts, "parallelism": f"dp{world}",
+                       "valid_parts_rank0": valid_parts, "valid_parts_per_batch_rank0": valid_per_batch,
+                       "batches": f"{N_BATCHES} distinct synthetic batches (seeds 1234 + rank + 1000 k), batch i % {N_BATCHES} "
+                                  "in step i of warm-up and timed region alike",
+                       "parallelism": f"dp{world}",
                        "rccl_ranks": world if distributed else 0, "rccl_version": rccl,
                        "launch": "hip-graph replay" if use_graph else "eager",
                        **({"precision_note": "performance variant: PointNet encoder with bf16 stored activations and "
@@ -596,7 +634,7 @@ def main():
             "final_loss": final_loss,
             "kernels": kernels,
             "roofline": roofline,
-            "kernel_table": kernel_table(kernels, num_parts, cfg, B, P),
+            "kernel_table": kernel_table(kernels, valid_parts, cfg, B, P),
         }
         if world == 1 and not args.no_cpu_baseline and args.config in ("c1", "c2", "c3", "c4"):
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, dev)

@@ -31,6 +31,7 @@ def test_bench_line_has_the_contract_keys(cuda_device):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
+    assert len(d["config"]["valid_parts_per_batch_rank0"]) == 4  # distinct batches rotated through the timed loop
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
@@ -88,6 +89,8 @@ def test_plumbing_config_with_its_cpu_baseline_and_self_check(cuda_device, capsy
     d = _run("--config", "c1", "--steps", "10", "--warmup", "5", "--no-chamfer-standalone")
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "B=4," in c["sample"]
+    r = d["roofline"]  # the drop-in operator's whole-shape call: 5 min-of-N samples per step
+    assert "mpa_chamfer_forward" in r["kernel"] and r["launches"] == 50 and r["algorithmic_bytes_per_launch"] == 24.0 * 4 * 4000
     with capsys.disabled():
         print(f"\n  BENCH c1: {d['ms_per_step']:.3f} ms/step, {d['value']:.0f} parts/s; CPU {c['value']:.1f} parts/s on "
               f"{c['cores']} cores", end="")

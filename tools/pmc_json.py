@@ -17,6 +17,14 @@ def per_kernel(path, pattern):
     return None
 
 
+def clouds_of(prof, rnd, cfg):
+    """valid parts per launch (mean over the rotated batches) of the bench line committed beside the counter passes."""
+    f = prof / f"{rnd}_{cfg}_bench_line.json"
+    if not f.exists():
+        return None
+    return json.loads(f.read_text().strip().splitlines()[-1])["config"].get("valid_parts_rank0")
+
+
 def main():
     prof, rnd = Path(sys.argv[1]), sys.argv[2]
     note = ("FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
@@ -27,35 +35,44 @@ def main():
         rec = {"kernel": "grid_search_kernel",
                "command": "python bench.py --config c2 --no-cpu-baseline --steps 4 --warmup 2 (rocprofv3 --pmc FETCH_SIZE "
                           "and --pmc WRITE_SIZE, separate passes; tools/gpu_full_pass.sh)",
+               "config": "c2", "clouds_per_launch": clouds_of(prof, rnd, "c2"),
                "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
                "correction": note + " (scattered 4-byte result stores count a full 64-byte line each)",
                "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0}
         (prof / f"{rnd}_pmc_dominant_kernel.json").write_text(json.dumps(rec, indent=1))
         print(rec)
-    widths = {}
-    # the wide kNN stages are a pipeline of kernels now (csrc/dg_knn_fast.h): sum them per feature width
-    pipeline = {C: [rf"rownorm_kernel<{C}>", rf"knn_split_kernel<{C}>", rf"knn_gram_kernel<{C}, false", rf"knn_gram_kernel<{C}, true",
-                    rf"knn_rerank_kernel<{C},"] for C in (128, 64)}
-    for C, pats in pipeline.items():
-        fs = [per_kernel(prof / f"{rnd}_c3_pmc_fetch_size.txt", pat) for pat in pats]
-        ws = [per_kernel(prof / f"{rnd}_c3_pmc_write_size.txt", pat) for pat in pats]
-        missing = [pat for pat, a, b in zip(pats, fs, ws) if a is None or b is None]
-        fs = [0.0 if v is None else v for v in fs]  # a kernel below the summary's cut-off moved (almost) nothing
-        ws = [0.0 if v is None else v for v in ws]
-        if len(missing) < len(pats):
+    # the wide kNN stages are a pipeline of kernels (csrc/dg_knn_fast.h): sum them per feature width; one record per
+    # workload (c3: everyday-like, c5: artifact-like clouds — different cloud counts per launch)
+    for cfg, out in (("c3", f"{rnd}_pmc_knn_kernel.json"), ("c5", f"{rnd}_pmc_knn_kernel_c5.json")):
+        ff, wf = prof / f"{rnd}_{cfg}_pmc_fetch_size.txt", prof / f"{rnd}_{cfg}_pmc_write_size.txt"
+        if not (ff.exists() and wf.exists()):
+            continue
+        names = [ln.split()[-1] for ln in ff.read_text().splitlines() if "knn" in ln or "rownorm" in ln]
+        widths = {}
+        for C in (128, 64):
+            pats = sorted({re.escape(n.split("(")[0]) for n in names if re.search(rf"<{C}[,>]", n)})
+            if not pats:
+                continue
+            fs = [per_kernel(ff, pat) for pat in pats]
+            ws = [per_kernel(wf, pat) for pat in pats]
+            missing = [pat for pat, a, b in zip(pats, fs, ws) if a is None or b is None]
+            fs = [0.0 if v is None else v for v in fs]  # a kernel below the summary's cut-off moved (almost) nothing
+            ws = [0.0 if v is None else v for v in ws]
             widths[str(C)] = {"fetch_size_kb_per_launch": sum(fs), "write_size_kb_per_launch": sum(ws),
                               "per_kernel_fetch_kb": dict(zip(pats, fs)), "per_kernel_write_kb": dict(zip(pats, ws)),
                               "below_the_summary_cutoff": missing,
                               "traffic_bytes_per_launch": (2.0 * sum(fs) + sum(ws)) * 1024.0}
-    if widths:
-        rec = {"kernel": "dg::knn_wide = rownorm + knn_split + knn_gram (bound) + knn_gram (collect) + knn_rerank",
-               "command": "python bench.py --config c3 --no-cpu-baseline --steps 4 --warmup 2 (rocprofv3 --pmc FETCH_SIZE "
-                          "and --pmc WRITE_SIZE, separate passes; tools/gpu_full_pass.sh)",
-               "correction": note, "per_width": widths,
-               "note": "sum over the five kernels of one search; the query blocks of a cloud run on one XCD (dg_knn.h: "
-                       "knn_block), so one L2 streams the cloud's split features in both Gram passes"}
-        (prof / f"{rnd}_pmc_knn_kernel.json").write_text(json.dumps(rec, indent=1))
-        print(rec)
+        if widths:
+            rec = {"kernel": "dg::knn_wide = every kernel of one wide kNN search (names in per_kernel_*)",
+                   "config": cfg, "clouds_per_launch": clouds_of(prof, rnd, cfg),
+                   "command": f"python bench.py --config {cfg} --no-cpu-baseline --steps 4 --warmup 2 (rocprofv3 --pmc "
+                              "FETCH_SIZE and --pmc WRITE_SIZE, separate passes; tools/gpu_full_pass.sh)",
+                   "correction": note, "per_width": widths,
+                   "note": "sum over the kernels of one search; the query blocks of a cloud run on one XCD (dg_knn.h: "
+                           "knn_block), so one L2 streams the cloud's split features in both Gram passes"}
+            (prof / out).write_text(json.dumps(rec, indent=1))
+            print(rec)
+
 
 if __name__ == "__main__":
     main()
