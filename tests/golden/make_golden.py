@@ -418,6 +418,23 @@ def _model_step(name, cfg, data, seed, extra=None):
     param_fill.fill_parameters(model64, seed)
     zero_dropout(model64)
     model64.double().train()
+    # per BatchNorm module and channel: the smallest and the largest |output| of the float64 pass — the pre-activation of
+    # the ReLU behind it.  A test that excuses an isolated ReLU flip of a float32 implementation must show that this
+    # very channel has a pre-activation at the rounding level of zero (tests/test_callers_gpu.py, clause (c)).
+    preact = {}
+
+    def watch(mod_name):
+        def hook(_m, _inp, outp):
+            z = outp.detach().abs().transpose(0, 1).reshape(outp.shape[1], -1)
+            lo, hi = z.min(dim=1).values, z.max(dim=1).values
+            if mod_name in preact:
+                lo, hi = torch.minimum(lo, preact[mod_name][0]), torch.maximum(hi, preact[mod_name][1])
+            preact[mod_name] = (lo, hi)
+        return hook
+
+    for mod_name, mod in model64.named_modules():
+        if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            mod.register_forward_hook(watch(mod_name))
     torch.manual_seed(seed + 1)  # the draws inside forward are float32 `.type_as(...)` upstream: the same values
     loss64 = model64.forward_pass({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in data.items()},
                                   mode="val", optimizer_idx=-1)
@@ -428,6 +445,8 @@ def _model_step(name, cfg, data, seed, extra=None):
     for k, p in model64.named_parameters():
         if p.grad is not None:
             out.update(param_fill.compact("grad64.", k, npy(p.grad)))
+    for mod_name, (lo, hi) in preact.items():
+        out[f"preact64.{mod_name}"] = np.stack([npy(lo), npy(hi)]).astype(np.float64)
     save(name, **out)
 
 
