@@ -78,21 +78,6 @@ def anchored_errors(record, name, array, floor=0.0):
     return float(e.max()), float(np.abs(r.astype(np.float64) - t).max() / scale), (int((e > 1e-2).sum()), int(e.size))
 
 
-def anchored_outlier_entries(record, name, array, level=1e-2):
-    """Flat indices (into the full tensor) of the recorded entries of `array` further than `level` from float64, relative
-    to the tensor's largest float64 entry — the entries clause (c) of tests/test_callers_gpu.py must account for."""
-    a = np.asarray(array, dtype=np.float64).reshape(-1)
-    idx = np.arange(a.size)
-    if "grad64." + name in record:
-        t = record["grad64." + name]
-    else:
-        idx = np.linspace(0, a.size - 1, SAMPLE).astype(np.int64)
-        a, t = a[idx], record[f"grad64.{name}#sample"]
-    t = t.astype(np.float64).reshape(-1)
-    e = np.abs(a - t) / max(np.abs(t).max(), 1e-12)
-    return [int(i) for i in idx[e > level]]
-
-
 def grad64_scale(record, name):
     """Largest |float64 gradient| recorded for parameter `name` (0.0 if there is no record)."""
     for key in ("grad64." + name, f"grad64.{name}#sample"):

@@ -35,15 +35,17 @@ CASES = {
 # tensor's largest float64 entry):
 #   (a) |hip - fp64| <= 2 |ref_fp32 - fp64| + 1e-4, or
 #   (b) |hip - fp64| <= GRAD_REL (1e-2 for the graph networks, 2e-3 else), or
-#   (c) an ISOLATED ReLU flip, SHOWN to be one: at most 2 recorded entries of the tensor (and at most FLIP_TENSORS
-#       tensors of the model) exceed 1e-2, none exceeds 5e-2, the tensor is the bias / weight of a BatchNorm, and for
-#       every such entry (= channel) the float64 evaluation of the reference has a pre-activation of that very channel
-#       within FLIP_PREACT of zero (relative to the channel's largest pre-activation; the `preact64.*` records of the
-#       fixtures, written by make_golden.py's hooks on the float64 model).  One ReLU whose pre-activation rounds to the
-#       other side of zero moves one channel's BatchNorm-bias gradient by 1/rows of its value — 2.8 % of the largest
-#       entry with the fixture's 75 pair rows — exactly as it moved the float32 reference's own DGCNN input gradient
-#       (tests/test_dgcnn_gpu.py).  The test prints tensor, channel and the float64 pre-activation of every entry it
-#       excuses this way.
+#   (c) downstream of a ReLU flip that is SHOWN to be possible: the float64 evaluation of the reference has, in the SAME
+#       MLP (`edge_mlps.0.`, `node_mlps.1.`, ...), a BatchNorm output — the pre-activation of a ReLU — within FLIP_PREACT
+#       of zero relative to its channel's largest value (the `preact64.*` records of the fixtures, written by
+#       make_golden.py's hooks on the float64 model: per module and channel the smallest and largest |output|).  A
+#       float32 evaluation with another summation order can land on the other side of zero there; the unit's upstream
+#       gradient then appears or vanishes in every parameter gradient of that MLP at and below the site (measured with
+#       tools/debug_flip.py on RGL-NET + DGCNN: the site is edge_mlps.0.bn3 channel 1, |z64| = 3e-6 of its scale; its
+#       own bias gradient moves 1.05e-2, conv3.weight's row 1 by 1.6e-2, conv2.weight by up to 1.26e-2 in 2 entries,
+#       everything else of the MLP < 7e-3).  Under this clause a tensor may deviate by at most 5e-2, at most 2 of its
+#       recorded entries by more than 1e-2 unless it is the site's own layer, at most FLIP_TENSORS tensors per model.
+#       The test prints the site(s) and every tensor it excuses.
 # A bias in front of a BatchNorm has a structurally zero gradient: there the bar is absolute, 1e-5 of the layer's
 # weight-gradient scale (the float32 reference leaves 5e-7 there).
 GRAD_REL = {"dgl_step": 1e-2, "rgl_net_step": 1e-2, "global_semantic_step": 2e-3, "pn_refine_step": 2e-3,
@@ -80,7 +82,13 @@ def test_caller_step_matches_reference(golden, cuda_device, capsys, name):
         if k.startswith("loss."):
             np.testing.assert_allclose(float(res[k[5:]]), float(z[k]), rtol=2e-4, atol=1e-6, err_msg=k)
     record = dict(z)
-    rows, flips = [], []
+    rows, flips, used_sites = [], [], set()
+    # ReLU sites where a float32 evaluation may flip: float64 pre-activations at the rounding level of zero
+    sites = []
+    for key, v in record.items():
+        if key.startswith("preact64."):
+            lo, hi = v
+            sites += [(key[len("preact64."):], int(ch), float(lo[ch]), float(hi[ch])) for ch in np.nonzero(lo <= FLIP_PREACT * hi)[0]]
     for k, p in model.named_parameters():
         if ("grad." + k) in record or ("grad." + k + "#sample") in record:
             assert p.grad is not None, k
@@ -93,20 +101,20 @@ def test_caller_step_matches_reference(golden, cuda_device, capsys, name):
             rows.append((mine, ref32, k))
             if mine <= 2.0 * ref32 + 1e-4 or mine <= GRAD_REL[name]:
                 continue
-            assert outliers <= 2 and mine <= 5e-2, (k, mine, ref32, outliers, n)
-            module = k.rsplit(".", 1)[0]
-            assert ("preact64." + module) in record and g.ndim == 1, f"{k}: clause (c) is for BatchNorm parameters only"
-            lo, hi = record["preact64." + module]
-            entries = param_fill.anchored_outlier_entries(record, k, g)
-            for ch in entries:  # the channel's float64 pre-activation closest to zero: at the float32 rounding level?
-                assert lo[ch] <= FLIP_PREACT * hi[ch], (k, ch, float(lo[ch]), float(hi[ch]))
-            flips.append((k, f"{mine:.2e}", [(ch, f"|z64|min {lo[ch]:.2e} of scale {hi[ch]:.2e}") for ch in entries]))
+            mlp = ".".join(k.split(".")[:2]) + "."
+            near = [(m, ch, lo, hi) for (m, ch, lo, hi) in sites if m.startswith(mlp)]
+            assert near, (k, mine, ref32, "no float64 pre-activation at the rounding level of zero in this MLP", sites)
+            own_layer = any(m.rsplit(".", 1)[0] == k.rsplit(".", 2)[0] and m[-1] == k.rsplit(".", 1)[0][-1] for m, *_ in near)
+            assert mine <= 5e-2 and (outliers <= 2 or own_layer), (k, mine, ref32, outliers, n, near)
+            flips.append((k, f"{mine:.2e}", f"{outliers} of {n} entries > 1e-2"))
+            used_sites.update(near)
     worst = max(rows)
     with capsys.disabled():
         med = sorted(r[0] for r in rows)[len(rows) // 2]
         print(f"\n  {name}: {len(rows)} gradient tensors vs float64: worst {worst[0]:.2e} ({worst[2]}; the float32 "
               f"reference there: {worst[1]:.2e}), median {med:.2e}; float32 reference worst {max(r[1] for r in rows):.2e}"
-              f"; isolated flips: {flips}", end="")
+              f"; clause (c): {len(sites)} float64 pre-activations within {FLIP_PREACT:g} of zero in the model, used "
+              f"(module, channel, |z64|, channel scale): {sorted(used_sites)}; tensors excused: {flips}", end="")
     assert len(flips) <= FLIP_TENSORS, flips
     for k, v in model.state_dict().items():
         if "running_" in k:
@@ -382,7 +390,7 @@ def test_gru_exchange_is_stable_over_many_launches(cuda_device):
             assert all(torch.equal(a, b) for a, b in zip(first, got))
 
 
-def _against_float64(cuda_device, capsys, cfg, label, oracle_loss, B=4, no_dropout=False, slack=0.25, median_cap=1.2,
+def _against_float64(cuda_device, capsys, cfg, label, oracle_loss, B=4, no_dropout=False, slack=0.17, median_cap=1.2,
                      abs_cap=None):
     """One training-mode forward_pass + backward at P = 20, N = 1000 on the HIP path, on the float32 CPU oracle and on the
     same oracle in float64; returns nothing, asserts that the HIP path is as close to float64 as the float32 oracle."""
@@ -456,8 +464,10 @@ def test_dgl_dgcnn_step_at_the_benchmark_part_size_against_float64(cuda_device, 
     float32 oracle's own parameter gradients sit 5-80 % (largest entry, per tensor) from its float64 evaluation.  A
     bar "hip == oracle32 to 1e-2" would therefore fail for ANY correct float32 implementation; the bar here is that the
     HIP path is as close to float64 as the float32 restatement of the reference is: the loss within twice the
-    oracle's own deviation, per tensor |hip - f64| <= 2 |o32 - f64| + 0.25, and the median ratio of the two deviations
-    over all tensors <= 1.2 (measured: 0.88 — the HIP path is the closer of the two)."""
+    oracle's own deviation, per tensor |hip - f64| <= 2 |o32 - f64| + 0.17, and the median ratio of the two deviations
+    over all tensors <= 1.2 (measured: 0.88 — the HIP path is the closer of the two).  The additive term is the measured
+    need + 50 %: 3 of the 105 tensors sit beyond twice the oracle's deviation, the farthest by 0.113
+    (pose_predictors.1.fc_layers.0.weight); the test prints both numbers on every run."""
     from oracle import callers as oc
     cfg = config.dgl_dgcnn_everyday()
     _against_float64(cuda_device, capsys, cfg, "DGL + DGCNN",
@@ -469,7 +479,8 @@ def test_pn_transformer_step_at_the_benchmark_part_size_against_float64(cuda_dev
     N = 1000; B = 4, dropout off so that all three evaluations see the same network).  This step IS well conditioned (no
     kNN graph, one max-pool): the float32 oracle sits 2e-5 .. 7e-4 from float64 and the bar is absolute — every parameter
     gradient of the HIP path within 1e-3 of float64 (largest entry of the tensor; measured 1.2e-4 .. 8.1e-4, the largest on
-    `encoder.conv4.weight` where the float32 oracle is at 7.4e-4), and within 2 x the oracle's deviation + 5e-4.  The
+    `encoder.conv4.weight` where the float32 oracle is at 7.4e-4), and within 2 x the oracle's deviation + 4e-4 (measured
+    need 2.6e-4 on encoder.conv5.weight, + 50 %; 61 of 73 tensors sit beyond twice the oracle's tiny deviation).  The
     transformer and pose-head gradients share a ~2e-4 offset that enters with d loss / d rot at the pose head's output (2e-4
     there for the HIP path, 2e-5 for the float32 oracle; the translation gradient: 3e-5 for both).  It is not arithmetic:
     fed the SAME predicted poses, the fused loss backward is within 1e-7 of float64 per term, like the oracle — except the
@@ -481,7 +492,7 @@ def test_pn_transformer_step_at_the_benchmark_part_size_against_float64(cuda_dev
     _against_float64(cuda_device, capsys, cfg, "PNTransformer + PointNet",
                      lambda sd, cb: on.pn_transformer_loss(sd, cb, cfg.model.transformer_layers,
                                                            cfg.model.transformer_heads, training=True, stats_out={})[0]["loss"],
-                     no_dropout=True, slack=5e-4, median_cap=None, abs_cap=1e-3)
+                     no_dropout=True, slack=4e-4, median_cap=None, abs_cap=1e-3)
 
 
 def test_dgl_dgcnn_graph_replay_equals_eager_steps(cuda_device):
