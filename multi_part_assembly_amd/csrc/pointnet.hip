@@ -409,6 +409,18 @@ __global__ __launch_bounds__(1024) void pn_top_wgrad_kernel(
 // ---- first layer (3 -> 64): scalar-operand VALU panel ------------------------------------------------------
 // lane = point; the 3x64 transposed weights are wave-uniform (scalar cache).  grid = (ceil(N/256), M).
 // partial [M*tiles][64][2].
+// STORE = false (the shipped path): only the BatchNorm sums leave the kernel.  Y1 — 256 bytes per point, 3 FMAs per
+// value from a 12-byte point — is never written: the three kernels that consume it (layer 2 forward, layer 2's fused
+// backward, layer 1's weight gradient) recompute their tile from the points with first_layer_y below, the SAME
+// operation sequence, so every consumer sees the bits the statistics were taken from.  Saves one write and three reads
+// of the [rows x 64] tensor per step (4 x 94 MB at 366 valid parts).
+__device__ __forceinline__ float first_layer_y(float a0, float a1, float a2, float w0, float w1, float w2) {
+  float v = a0 * w0;
+  v = __builtin_fmaf(a1, w1, v);
+  return __builtin_fmaf(a2, w2, v);
+}
+
+template <bool STORE>
 __global__ __launch_bounds__(kT) void pn_fwd_first_kernel(const float* __restrict__ pts,
                                                           const float* __restrict__ wt,
                                                           const float* __restrict__ valids, int N,
@@ -424,18 +436,13 @@ __global__ __launch_bounds__(kT) void pn_fwd_first_kernel(const float* __restric
   const int rows_here = N - n0 < 64 ? (N - n0 < 0 ? 0 : N - n0) : 64;
   const float a0 = pts[row * 3 + 0], a1 = pts[row * 3 + 1], a2 = pts[row * 3 + 2];
 #pragma unroll
-  for (int c = 0; c < 64; ++c) {
-    float v = a0 * wt[c];
-    v = __builtin_fmaf(a1, wt[64 + c], v);
-    v = __builtin_fmaf(a2, wt[128 + c], v);
-    tile[wave][lane][c] = v;
-  }
+  for (int c = 0; c < 64; ++c) tile[wave][lane][c] = first_layer_y(a0, a1, a2, wt[c], wt[64 + c], wt[128 + c]);
   __builtin_amdgcn_wave_barrier();
   float s = 0.0f, ss = 0.0f;
   float* dst = y_out + ((long long)m * N + n0) * 64 + lane;
   for (int i = 0; i < rows_here; ++i) {
     const float v = tile[wave][i][lane];
-    dst[(long long)i * 64] = v;
+    if constexpr (STORE) dst[(long long)i * 64] = v;
     s += v;
     ss = __builtin_fmaf(v, v, ss);
   }
@@ -467,12 +474,15 @@ __global__ __launch_bounds__(kT) void pn_fwd_first_kernel(const float* __restric
 // (64*PANELS)), block 256; a block keeps its weight panel and walks (valid part, split) units from `vlist`.
 // BatchNorm statistics fall out of the accumulator layout (fixed-order reduction, no atomics).
 // TOP (last layer): Y is not stored; the block leaves the per-channel top-2 records of its rows instead.
-template <int CIN, int PANELS, bool TOP>
+// FIRST (layer 2): `in` holds the raw points [rows][3] and the layer's input Y1 is recomputed from them on the way
+// into the panel (wt1 [3][64], see pn_fwd_first_kernel).
+template <int CIN, int PANELS, bool TOP, bool FIRST = false>
 __global__ __launch_bounds__(kT, 2) void pn_fwd_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ bn_prev, const float* __restrict__ w, int cout,
     const int* __restrict__ vlist, int N, int splits, float* __restrict__ y_out,
     float* __restrict__ partial, float* __restrict__ topv, int* __restrict__ topn,
-    const float* __restrict__ gamma_top) {
+    const float* __restrict__ gamma_top, const float* __restrict__ wt1 = nullptr) {
+  static_assert(!FIRST || CIN == 64, "the recomputed input is the 64-channel first layer");
   constexpr int KH = CIN / 2;           // K values per lane-half
   constexpr int LD = CIN + 4;           // padded LDS row: conflict-free ds_read_b128 across rows
   constexpr int Q4 = CIN / 4;           // float4 per row
@@ -503,9 +513,25 @@ __global__ __launch_bounds__(kT, 2) void pn_fwd_mfma_kernel(
   const float4 sc = reinterpret_cast<const float4*>(bn_prev)[c4];
   const float4 sh = reinterpret_cast<const float4*>(bn_prev + CIN)[c4];
   const int TB = (N + RB - 1) / RB;
-  float4 raw[NLD];
+  float4 raw[NLD];  // (FIRST: x, y, z of the row's point in .x .y .z)
+  float4 w1a = {}, w1b = {}, w1c = {};  // FIRST: the first layer's weights of this thread's 4 channels
+  if constexpr (FIRST) {
+    w1a = reinterpret_cast<const float4*>(wt1)[c4];
+    w1b = reinterpret_cast<const float4*>(wt1 + 64)[c4];
+    w1c = reinterpret_cast<const float4*>(wt1 + 128)[c4];
+  }
   int m = 0;
   auto fetch = [&](int tile) {
+    if constexpr (FIRST) {
+      const float* src = in + ((long long)m * N + (long long)tile * RB) * 3;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int rl = rl0 + i * (kT / Q4);
+        const float* p = src + 3 * (tile * RB + rl < N ? rl : 0);
+        raw[i] = make_float4(p[0], p[1], p[2], 0.0f);
+      }
+      return;
+    }
     const float4* src = reinterpret_cast<const float4*>(in + ((long long)m * N + (long long)tile * RB) * CIN);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -518,6 +544,11 @@ __global__ __launch_bounds__(kT, 2) void pn_fwd_mfma_kernel(
     for (int i = 0; i < NLD; ++i) {
       const int rl = rl0 + i * (kT / Q4);
       float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if constexpr (FIRST) {
+        const float a0 = raw[i].x, a1 = raw[i].y, a2 = raw[i].z;
+        raw[i] = make_float4(first_layer_y(a0, a1, a2, w1a.x, w1b.x, w1c.x), first_layer_y(a0, a1, a2, w1a.y, w1b.y, w1c.y),
+                             first_layer_y(a0, a1, a2, w1a.z, w1b.z, w1c.z), first_layer_y(a0, a1, a2, w1a.w, w1b.w, w1c.w));
+      }
       if (tile * RB + rl < N) {  // rows past the part's end enter the MFMA as zeros
         v.x = __builtin_fmaxf(__builtin_fmaf(raw[i].x, sc.x, sh.x), 0.0f);
         v.y = __builtin_fmaxf(__builtin_fmaf(raw[i].y, sc.y, sh.y), 0.0f);
@@ -1274,7 +1305,8 @@ template <int COUT, int CIN, int MODE, int LDY = COUT>
 __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
     const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
     const float* __restrict__ y_prev, const float* __restrict__ bn_prev, const int* __restrict__ vlist, int N,
-    float* __restrict__ dwpart, int co0) {
+    float* __restrict__ dwpart, int co0, const float* __restrict__ wt1 = nullptr) {
+  // WG_FIRST: `y` is not read — the layer's own output Y1 is recomputed from the points in y_prev (wt1 [3][64])
   constexpr int CINP = MODE == WG_FIRST ? 32 : CIN;       // width of the B panel
   constexpr int CT = COUT / 32, IT = CINP / 32, NTILE = CT * IT;
   // GRAM: the matrix is symmetric — only the 10 tiles on or above the diagonal of the 4 x 4 tile grid are computed
@@ -1317,6 +1349,12 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
   }
   float4 ry[NLO], rz[NLO], rp[NLI];
   float rpt = 0.0f;
+  float4 w1a = {}, w1b = {}, w1c = {};
+  if constexpr (MODE == WG_FIRST) {
+    w1a = reinterpret_cast<const float4*>(wt1)[co4];
+    w1b = reinterpret_cast<const float4*>(wt1 + 64)[co4];
+    w1c = reinterpret_cast<const float4*>(wt1 + 128)[co4];
+  }
   auto fetch = [&](int u, int m) {
     const int n0 = (u % TB) * RB;
     const long long row0 = (long long)m * N + n0;
@@ -1326,7 +1364,12 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
         const int rl = ro0 + i * (kT / QO);
         const bool ok = n0 + rl < N;
         const long long o = ((row0 + rl) * LDY + co0) / 4 + co4;
-        ry[i] = ok ? reinterpret_cast<const float4*>(y)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if constexpr (MODE == WG_FIRST) {
+          const float* p = y_prev + (row0 + (ok ? rl : 0)) * 3;
+          ry[i] = make_float4(p[0], p[1], p[2], 0.0f);
+        } else {
+          ry[i] = ok ? reinterpret_cast<const float4*>(y)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
         rz[i] = ok ? reinterpret_cast<const float4*>(dz)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
     }
@@ -1349,6 +1392,11 @@ __global__ __launch_bounds__(kT) void pn_wgrad_mfma_kernel(
       for (int i = 0; i < NLO; ++i) {
         const int rl = ro0 + i * (kT / QO);
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if constexpr (MODE == WG_FIRST) {
+          const float a0 = ry[i].x, a1 = ry[i].y, a2 = ry[i].z;
+          ry[i] = make_float4(first_layer_y(a0, a1, a2, w1a.x, w1b.x, w1c.x), first_layer_y(a0, a1, a2, w1a.y, w1b.y, w1c.y),
+                              first_layer_y(a0, a1, a2, w1a.z, w1b.z, w1c.z), first_layer_y(a0, a1, a2, w1a.w, w1b.w, w1c.w));
+        }
         if (n0 + rl < N) {
           v.x = __builtin_fmaf(al.x, rz[i].x, __builtin_fmaf(gp.x, ry[i].x, bp.x));
           v.y = __builtin_fmaf(al.y, rz[i].y, __builtin_fmaf(gp.y, ry[i].y, bp.y));
@@ -1585,12 +1633,13 @@ __global__ __launch_bounds__(kT, 2) void pn_gram_split_kernel(const float* __res
 #define MPA_PN_WF 256
 #endif
 constexpr int kWF = MPA_PN_WF;
-template <int K, int NT, int PANELS, int NTH>
+// FIRST (layer 2): `y_prev` holds the raw points [rows][3]; the Y1 panel is recomputed from them (wt1 [3][64]).
+template <int K, int NT, int PANELS, int NTH, bool FIRST = false>
 __global__ __launch_bounds__(NTH, 2) void pn_bwd_fused_kernel(
     const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ coef,
     const float* __restrict__ w, const float* __restrict__ y_prev, const float* __restrict__ bn_prev,
     const int* __restrict__ vlist, int N, float* __restrict__ dz_prev, float* __restrict__ partial,
-    float* __restrict__ dwpart) {
+    float* __restrict__ dwpart, const float* __restrict__ wt1 = nullptr) {
   constexpr int CIN = 64, KH = K / 2, LDY = K + 4, LDP = CIN + 4, QK = K / 4, QC = CIN / 4;
   constexpr int ND = NTH / 128;  // waves of each kind
   constexpr int RT = ND / PANELS, RB = 32 * RT, CW = 32 * NT;
@@ -1635,6 +1684,12 @@ __global__ __launch_bounds__(NTH, 2) void pn_bwd_fused_kernel(
     shw[u] = bn_prev[CIN + 32 * u + j];
   }
   float4 ry[NLY], rz[NLY], rp[NLP];
+  // FIRST: the first layer's weights sit in LDS and are read where they are used (12 more live registers per lane would
+  // spill: the kernel runs at the 256-register limit of two blocks per CU)
+  __shared__ __attribute__((aligned(16))) float w1s[FIRST ? 192 : 4];
+  if constexpr (FIRST) {
+    if (threadIdx.x < 192) w1s[threadIdx.x] = wt1[threadIdx.x];  // (published by the first barrier of the unit loop)
+  }
   auto fetch = [&](int u, int m) {
     const int n0 = (u % TB) * RB;
     const long long row0 = (long long)m * N + n0;
@@ -1648,8 +1703,13 @@ __global__ __launch_bounds__(NTH, 2) void pn_bwd_fused_kernel(
 #pragma unroll
     for (int i = 0; i < NLP; ++i) {
       const bool ok = n0 + rp0 + i * (NTH / QC) < N;
-      rp[i] = ok ? reinterpret_cast<const float4*>(y_prev)[row0 * QC + i * NTH + threadIdx.x]
-                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if constexpr (FIRST) {
+        const float* p = y_prev + (row0 + (ok ? rp0 + i * (NTH / QC) : 0)) * 3;
+        rp[i] = make_float4(p[0], p[1], p[2], 0.0f);
+      } else {
+        rp[i] = ok ? reinterpret_cast<const float4*>(y_prev)[row0 * QC + i * NTH + threadIdx.x]
+                   : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
     }
   };
   auto stash = [&](int u, float* dy, float* dp) {  // rows past the part's end: dY = 0 (their Yprev is never used)
@@ -1667,8 +1727,16 @@ __global__ __launch_bounds__(NTH, 2) void pn_bwd_fused_kernel(
       *reinterpret_cast<float4*>(dy + rl * LDY + 4 * c4) = v;
     }
 #pragma unroll
-    for (int i = 0; i < NLP; ++i)
+    for (int i = 0; i < NLP; ++i) {
+      if constexpr (FIRST) {
+        const float4 w1a = reinterpret_cast<const float4*>(w1s)[p4], w1b = reinterpret_cast<const float4*>(w1s + 64)[p4],
+                     w1c = reinterpret_cast<const float4*>(w1s + 128)[p4];
+        const float a0 = rp[i].x, a1 = rp[i].y, a2 = rp[i].z;
+        rp[i] = make_float4(first_layer_y(a0, a1, a2, w1a.x, w1b.x, w1c.x), first_layer_y(a0, a1, a2, w1a.y, w1b.y, w1c.y),
+                            first_layer_y(a0, a1, a2, w1a.z, w1b.z, w1c.z), first_layer_y(a0, a1, a2, w1a.w, w1b.w, w1c.w));
+      }
       *reinterpret_cast<float4*>(dp + (rp0 + i * (NTH / QC)) * LDP + 4 * p4) = rp[i];
+    }
   };
   float s1[NT], s2[NT];
 #pragma unroll
@@ -1880,7 +1948,8 @@ PnWs carve(float* base, const Dims& d) {
     p += (n + 3) / 4 * 4;  // keep 16-byte alignment for float4 accesses
     return r;
   };
-  for (int l = 1; l <= 4; ++l) w.Y[l] = take(d.rows * d.C[l]);
+  w.Y[1] = nullptr;  // never stored: recomputed from the points by its consumers (pn_fwd_first_kernel)
+  for (int l = 2; l <= 4; ++l) w.Y[l] = take(d.rows * d.C[l]);
   w.Y[5] = nullptr;
   for (int l = 1; l <= 4; ++l) w.dZ[l] = take(d.rows * d.C[l]);
   w.Wt1 = take(192);
@@ -1975,19 +2044,20 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
     int splits;
     if (l == 1) {
       splits = d.tiles1;
-      hipLaunchKernelGGL(pn_fwd_first_kernel, dim3((unsigned)d.tiles1, (unsigned)M), dim3(kT), 0, s, points,
-                         w.Wt1, valids, (int)N, w.Y[1], w.partial);
+      hipLaunchKernelGGL(pn_fwd_first_kernel<false>, dim3((unsigned)d.tiles1, (unsigned)M), dim3(kT), 0, s, points,
+                         w.Wt1, valids, (int)N, (float*)nullptr, w.partial);
     } else {
       splits = l == 5 ? d.splits_top : d.splits;
-#define MPA_FWD(CI, PN, TP, IN, YO, TV, TN)                                                                          \
+#define MPA_FWD_(CI, PN, TP, FI, IN, YO, TV, TN)                                                                     \
   {                                                                                                                  \
-    static const int occ = blocks_per_cu(pn_fwd_mfma_kernel<CI, PN, TP>, kT);                                        \
+    static const int occ = blocks_per_cu(pn_fwd_mfma_kernel<CI, PN, TP, FI>, kT);                                    \
     const long long units = (long long)M * splits, cap = (long long)kCUs * occ * MPA_PN_OVERSUB;                     \
-    hipLaunchKernelGGL((pn_fwd_mfma_kernel<CI, PN, TP>),                                                             \
+    hipLaunchKernelGGL((pn_fwd_mfma_kernel<CI, PN, TP, FI>),                                                         \
                        dim3((unsigned)(units < cap ? units : cap), (unsigned)(d.C[l] / (64 * PN))), dim3(kT), 0, s,  \
                        IN, w.bn[l - 1], conv_w[l - 1], d.C[l], iw.vlist, (int)N, splits, YO, w.partial, TV, TN,      \
-                       TP ? bn_w[4] : (const float*)nullptr);                                                         \
+                       TP ? bn_w[4] : (const float*)nullptr, (const float*)w.Wt1);                                    \
   }
+#define MPA_FWD(CI, PN, TP, IN, YO, TV, TN) MPA_FWD_(CI, PN, TP, false, IN, YO, TV, TN)
 #ifndef MPA_PN_SPLIT  // 1: last layer on the bf16 matrix cores (pn_fwd_split_kernel); 0: v_mfma_f32_32x32x2_f32
 #define MPA_PN_SPLIT 1
 #endif
@@ -2009,10 +2079,13 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
         else MPA_FWD(128, 1, true, w.Y[4], (float*)nullptr, w.topv, iw.topn)
       } else if (d.C[l] == 128) {
         MPA_FWD(64, 2, false, w.Y[l - 1], w.Y[l], (float*)nullptr, (int*)nullptr)
+      } else if (l == 2) {  // its input, the first layer's output, is recomputed from the points
+        MPA_FWD_(64, 1, false, true, points, w.Y[l], (float*)nullptr, (int*)nullptr)
       } else {
         MPA_FWD(64, 1, false, w.Y[l - 1], w.Y[l], (float*)nullptr, (int*)nullptr)
       }
 #undef MPA_FWD
+#undef MPA_FWD_
 #undef MPA_FWD_SPLIT
     }
     const dim3 cg((unsigned)(d.C[l] / 64));
@@ -2088,20 +2161,22 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   // ---- layers 4..2: fused input + weight gradient, then the next layer's BatchNorm-backward coefficients
   for (int l = 4; l >= 2; --l) {
     const int cout = d.C[l], cin = d.C[l - 1];
-#define MPA_FUSED(KK, NT, PN, TH)                                                                                      \
-  hipLaunchKernelGGL((pn_bwd_fused_kernel<KK, NT, PN, TH>), dim3(nb), dim3(TH), 0, s, w.Y[l], w.dZ[l], w.coef[l],      \
-                     conv_w[l - 1], w.Y[l - 1], w.bn[l - 1], iw.vlist, (int)N, w.dZ[l - 1], w.partial, w.dwpart)
+#define MPA_FUSED(KK, NT, PN, TH, FI, YP)                                                                              \
+  hipLaunchKernelGGL((pn_bwd_fused_kernel<KK, NT, PN, TH, FI>), dim3(nb), dim3(TH), 0, s, w.Y[l], w.dZ[l], w.coef[l],  \
+                     conv_w[l - 1], YP, w.bn[l - 1], iw.vlist, (int)N, w.dZ[l - 1], w.partial, w.dwpart,               \
+                     (const float*)w.Wt1)
     const int nb = 2 * kWF;                      // two 4-wave blocks per CU
-    if (cout == 64) MPA_FUSED(64, 2, 1, 256);    // 64 -> 64: one 64-channel panel, 64-row units
-    else MPA_FUSED(128, 1, 2, 256);              // 64 -> 128: two 32-channel panels, 32-row units
+    if (l == 2) MPA_FUSED(64, 2, 1, 256, true, points);          // (Yprev = the first layer's output: recomputed)
+    else if (cout == 64) MPA_FUSED(64, 2, 1, 256, false, w.Y[l - 1]);  // 64 -> 64: one 64-channel panel, 64-row units
+    else MPA_FUSED(128, 1, 2, 256, false, w.Y[l - 1]);                 // 64 -> 128: two 32-channel panels, 32-row units
 #undef MPA_FUSED
     reduce_dw(nb, cout * cin, grad_conv_w[l - 1]);
     hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(cin / 64), (unsigned)((nb + kEB - 1) / kEB)),
                        dim3(64 * kSlices), 0, s, w.partial, (const float*)nullptr, nb, 1, cin, w.count, bn_w[l - 2],
                        w.bn[l - 1], w.coef[l - 1], grad_bn_w[l - 2], grad_bn_b[l - 2], w.coop);
   }
-  hipLaunchKernelGGL((pn_wgrad_mfma_kernel<64, 4, WG_FIRST>), dim3(kWG), dim3(kT), 0, s, w.Y[1], w.dZ[1], w.coef[1],
-                     points, (const float*)nullptr, iw.vlist, (int)N, w.dwpart, 0);
+  hipLaunchKernelGGL((pn_wgrad_mfma_kernel<64, 4, WG_FIRST>), dim3(kWG), dim3(kT), 0, s, (const float*)nullptr, w.dZ[1],
+                     w.coef[1], points, (const float*)nullptr, iw.vlist, (int)N, w.dwpart, 0, (const float*)w.Wt1);
   reduce_dw(kWG, d.C[1] * 3, grad_conv_w[0]);
   return mpa::check_launch("pointnet_backward");
 }
