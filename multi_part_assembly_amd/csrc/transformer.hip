@@ -513,6 +513,207 @@ __global__ __launch_bounds__(kAT) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---- attention on the matrix cores: one wave per (sample, head), P <= 32 tokens, head dim 32 * NT -------------------------
+// q k^T and attn . v are the two dense contractions of the layer (reference: nn.MultiheadAttention inside
+// models/pn_transformer/transformer.py:23-33); they run on v_mfma_f32_32x32x2_f32 over ONE 32-padded token tile, with
+// everything between them in registers and NO LDS:
+//   T = K (q scale)^T — computed TRANSPOSED: the accumulator lane (i = query, half h) then holds T[j][i] for the 16 keys
+//   j = acc_row(r, h), so the softmax over the keys is a reduction over the lane's own 16 registers plus one exchange with
+//   lane i + 32;
+//   O = S V with S = dropout(softmax): the MFMA's reduction index k = key, enumerated as (step t, half h) <-> j =
+//   acc_row(t, h) — so the A operand of step t IS accumulator register t of the first product (no data movement), and the
+//   B operand is the V row of that key, loaded straight from global memory (coalesced over the head dimension).
+// Rows / keys >= P of the padded tile are zeros / masked; padded keys (valid == 0) are masked as in the reference.
+template <int NT>
+__global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ valid,
+                                                           int P, int D, int H, Drop drop, unsigned site,
+                                                           float* __restrict__ probs, float* __restrict__ out) {
+  constexpr int DH = 32 * NT, KH = DH / 2;
+  const int b = blockIdx.x / H, hd = blockIdx.x % H, lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+  const float scale = 1.0f / __builtin_sqrtf((float)DH);
+  // lane (c, h): columns h * KH .. of row c of K (A operand) and of the scaled Q (B operand)
+  float ka[KH], qb[KH];
+  {
+    const float* row = qkv + (long long)(b * P + (c < P ? c : 0)) * 3 * D + hd * DH + h * KH;
+#pragma unroll
+    for (int v = 0; v < KH / 4; ++v) {
+      const float4 q4 = *reinterpret_cast<const float4*>(row + 4 * v);
+      const float4 k4 = *reinterpret_cast<const float4*>(row + D + 4 * v);
+      const float on = c < P ? 1.0f : 0.0f;
+      qb[4 * v + 0] = q4.x * scale * on, qb[4 * v + 1] = q4.y * scale * on;  // torch scales q before the product
+      qb[4 * v + 2] = q4.z * scale * on, qb[4 * v + 3] = q4.w * scale * on;
+      ka[4 * v + 0] = k4.x * on, ka[4 * v + 1] = k4.y * on, ka[4 * v + 2] = k4.z * on, ka[4 * v + 3] = k4.w * on;
+    }
+  }
+  // everything else the wave will need is requested NOW, in one memory round trip with the operands above: the key mask
+  // and the V rows of the second product (loaded where they are used, each was one more dependent round trip of a
+  // kernel that is nothing but latency)
+  float kv[16], vb[NT][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = acc_row(r, h);
+    kv[r] = j < P ? valid[b * P + j] : 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      vb[nt][r] = j < P ? qkv[(long long)(b * P + j) * 3 * D + 2 * D + hd * DH + 32 * nt + c] : 0.0f;
+  }
+  f32x16 acc = {0};
+#pragma unroll
+  for (int s2 = 0; s2 < KH; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s2], qb[s2], acc, 0, 0, 0);
+  // mask + softmax over the keys of query c
+  float t[16], m = -__builtin_inff();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    t[r] = kv[r] != 0.0f ? acc[r] : -__builtin_inff();
+    m = __builtin_fmaxf(m, t[r]);
+  }
+  m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+  float z = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    t[r] = __expf(t[r] - m);
+    z += t[r];
+  }
+  z += __shfl_xor(z, 32, 64);
+  const float inv = 1.0f / z;
+  const long long prow = ((long long)(b * H + hd) * P + c) * P;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = acc_row(r, h);
+    const bool in = c < P && j < P;
+    const float pj = t[r] * inv;
+    if (in) probs[prow + j] = pj;
+    t[r] = in ? pj * drop_scale(drop, site, (unsigned long long)(prow + j)) : 0.0f;
+  }
+  // O[i][d] = sum_j S[i][j] V[j][d]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    f32x16 o = {0};
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) o = __builtin_amdgcn_mfma_f32_32x32x2f32(t[tt], vb[nt][tt], o, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = acc_row(r, h);
+      if (i < P) out[(long long)(b * P + i) * D + hd * DH + 32 * nt + c] = o[r];
+    }
+  }
+}
+
+// Backward of the same.  dP = dO V^T is taken in BOTH orientations (two chains over the head dimension): lane = query i
+// (softmax backward needs a row's keys together) and lane = key j (dK and dV reduce over the queries).  With
+// dS = P (dP m - <dP m, P>_row):  dQ = scale dS K,  dK = scale dS^T Q,  dV = (P m)^T dO — three chains over the token
+// index whose A operands are accumulator registers again; a row's inner product travels from the query orientation to the
+// key orientation with one cross-lane read per register.
+template <int NT>
+__global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
+                                                           const float* __restrict__ dout, int P, int D, int H, Drop drop,
+                                                           unsigned site, float* __restrict__ dqkv) {
+  constexpr int DH = 32 * NT, KH = DH / 2;
+  const int b = blockIdx.x / H, hd = blockIdx.x % H, lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+  const float scale = 1.0f / __builtin_sqrtf((float)DH);
+  float va[KH], ga[KH];  // lane (c, h): columns h * KH .. of row c of V and of dO
+  {
+    const long long tok = b * P + (c < P ? c : 0);
+    const float* vrow = qkv + tok * 3 * D + 2 * D + hd * DH + h * KH;
+    const float* grow = dout + tok * D + hd * DH + h * KH;
+    const float on = c < P ? 1.0f : 0.0f;
+#pragma unroll
+    for (int v = 0; v < KH / 4; ++v) {
+      const float4 v4 = *reinterpret_cast<const float4*>(vrow + 4 * v);
+      const float4 g4 = *reinterpret_cast<const float4*>(grow + 4 * v);
+      va[4 * v + 0] = v4.x * on, va[4 * v + 1] = v4.y * on, va[4 * v + 2] = v4.z * on, va[4 * v + 3] = v4.w * on;
+      ga[4 * v + 0] = g4.x * on, ga[4 * v + 1] = g4.y * on, ga[4 * v + 2] = g4.z * on, ga[4 * v + 3] = g4.w * on;
+    }
+  }
+  // every other operand is requested now, in the same memory round trip (see the forward kernel): the probabilities in
+  // both orientations and, for the first 32 columns of the head, the K / Q / dO rows of the three token-index chains
+  const long long pbase = (long long)(b * H + hd) * P * P;
+  const long long row0 = (long long)b * P;
+  float pa_[16], pb_[16], kb0[16], qb0[16], gb0[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int x = acc_row(r, h);
+    const bool in = c < P && x < P;
+    pa_[r] = in ? probs[pbase + (long long)c * P + x] : 0.0f;
+    pb_[r] = in ? probs[pbase + (long long)x * P + c] : 0.0f;
+    const long long tok = row0 + (x < P ? x : 0);
+    const float on = x < P ? 1.0f : 0.0f;
+    qb0[r] = qkv[tok * 3 * D + hd * DH + c] * on;
+    kb0[r] = qkv[tok * 3 * D + D + hd * DH + c] * on;
+    gb0[r] = dout[tok * D + hd * DH + c] * on;
+  }
+  f32x16 ga_acc = {0}, gb_acc = {0};  // lane = query: dP[i][j], j = acc_row(r, h);  lane = key: dP[i][j], i = acc_row(r, h)
+#pragma unroll
+  for (int s2 = 0; s2 < KH; ++s2) {
+    ga_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s2], ga[s2], ga_acc, 0, 0, 0);
+    gb_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s2], va[s2], gb_acc, 0, 0, 0);
+  }
+  // query orientation: dS[c][j] and the row's inner product
+  float dsa[16], rowdot = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = acc_row(r, h);
+    const bool in = c < P && j < P;
+    const long long e = pbase + (long long)(in ? c : 0) * P + (in ? j : 0);
+    const float pa = pa_[r];
+    const float dp = in ? ga_acc[r] * drop_scale(drop, site, (unsigned long long)e) : 0.0f;
+    rowdot = __builtin_fmaf(dp, pa, rowdot);
+    dsa[r] = dp;
+    ga_acc[r] = pa;
+  }
+  rowdot += __shfl_xor(rowdot, 32, 64);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dsa[r] = ga_acc[r] * (dsa[r] - rowdot);
+  // key orientation: dS[i][c] and (P m)[i][c]
+  float dsb[16], pdb[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = acc_row(r, h);
+    const bool in = i < P && c < P;
+    const long long e = pbase + (long long)(in ? i : 0) * P + (in ? c : 0);
+    const float pb = pb_[r];
+    const float mk = in ? drop_scale(drop, site, (unsigned long long)e) : 0.0f;
+    const float rd = __shfl(rowdot, i, 64);  // (lane i holds query i's inner product, both halves)
+    dsb[r] = pb * (gb_acc[r] * mk - rd);
+    pdb[r] = pb * mk;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = hd * DH + 32 * nt + c;
+    float kb[16], qb[16], gb[16];
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) {
+      if (nt == 0) {
+        qb[tt] = qb0[tt], kb[tt] = kb0[tt], gb[tt] = gb0[tt];
+      } else {
+        const int x = acc_row(tt, h);
+        const long long tok = row0 + (x < P ? x : 0);
+        const float on = x < P ? 1.0f : 0.0f;
+        qb[tt] = qkv[tok * 3 * D + col] * on;
+        kb[tt] = qkv[tok * 3 * D + D + col] * on;
+        gb[tt] = dout[tok * D + col] * on;
+      }
+    }
+    f32x16 dq = {0}, dk = {0}, dv = {0};
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) {
+      dq = __builtin_amdgcn_mfma_f32_32x32x2f32(dsa[tt], kb[tt], dq, 0, 0, 0);  // dQ[i] = sum_j dS[i][j] K[j]
+      dk = __builtin_amdgcn_mfma_f32_32x32x2f32(dsb[tt], qb[tt], dk, 0, 0, 0);  // dK[j] = sum_i dS[i][j] Q[i]
+      dv = __builtin_amdgcn_mfma_f32_32x32x2f32(pdb[tt], gb[tt], dv, 0, 0, 0);  // dV[j] = sum_i (P m)[i][j] dO[i]
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int x = acc_row(r, h);
+      if (x < P) {
+        float* dst = dqkv + (row0 + x) * 3 * D + col;
+        dst[0] = dq[r] * scale;
+        dst[D] = dk[r] * scale;
+        dst[2 * D] = dv[r];
+      }
+    }
+  }
+}
+
 // ---- LayerNorm backward -----------------------------------------------------------------------------------------------------
 // dx[row] = resid[row] + rstd * (dh*gamma - mean(dh*gamma) - xhat * mean(dh*gamma*xhat));  one wave per row.
 // Per-block partial sums of dgamma = sum dh*xhat and dbeta = sum dh go to part[block][2][D].
@@ -889,8 +1090,17 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
       g = gemm_args(t.h1, pp[P_WQKV], pp[P_BQKV], t.qkv, M, 3 * Di, Di);
       launch_gemm<EPI_NONE>(g, s);
     }
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, valid, (int)P, Di, (int)H,
-                       drop, site0 + S_ATTN, t.probs, t.o);
+    // q k^T and attn . v on the matrix cores whenever the tokens fit one 32-row tile (the shipped configs: P = 20, head
+    // dim 32); the scalar kernel covers the rest of the envelope (<= 64 tokens, any head dim <= 64)
+    if (P <= 32 && Di / (int)H == 32)
+      hipLaunchKernelGGL(attn_fwd_mfma_kernel<1>, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, valid, (int)P, Di, (int)H,
+                         drop, site0 + S_ATTN, t.probs, t.o);
+    else if (P <= 32 && Di / (int)H == 64)
+      hipLaunchKernelGGL(attn_fwd_mfma_kernel<2>, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, valid, (int)P, Di, (int)H,
+                         drop, site0 + S_ATTN, t.probs, t.o);
+    else
+      hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, valid, (int)P, Di, (int)H,
+                         drop, site0 + S_ATTN, t.probs, t.o);
     g = gemm_args(t.o, pp[P_WO], pp[P_BO], t.x_mid, M, Di, Di);
     g.resid = t.x_in;
     g.drop = drop;
@@ -988,8 +1198,15 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     const float* gdm = dr ? w.gd_mid : g_mid;  // drop-masked g_mid (site S_SA_OUT)
     wl[2] = wgrad_args(gdm, t.o, gp[P_WO], gp[P_BO], M, Di, Di);
     launch_gemm<EPI_NONE, true>(gemm_args(gdm, pp[P_WO], nullptr, spare2, M, Di, Di), s);  // d o
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
-                       (int)H, drop, site0 + S_ATTN, w.dqkv);
+    if (P <= 32 && Di / (int)H == 32)
+      hipLaunchKernelGGL(attn_bwd_mfma_kernel<1>, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
+                         (int)H, drop, site0 + S_ATTN, w.dqkv);
+    else if (P <= 32 && Di / (int)H == 64)
+      hipLaunchKernelGGL(attn_bwd_mfma_kernel<2>, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
+                         (int)H, drop, site0 + S_ATTN, w.dqkv);
+    else
+      hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
+                         (int)H, drop, site0 + S_ATTN, w.dqkv);
     wl[3] = wgrad_args(w.dqkv, t.h1, gp[P_WQKV], gp[P_BQKV], M, 3 * Di, Di);
     launch_gemm<EPI_NONE, true>(gemm_args(w.dqkv, pp[P_WQKV], nullptr, spare2, M, Di, 3 * Di), s);  // d LN1 out
     launch_wgrad_group(wl, 4, s);  // before the kernel below overwrites g's buffer
