@@ -66,6 +66,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"] + sorted(CONFIG_ALIASES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batches", type=int, default=N_BATCHES,
+                    help="distinct synthetic batches rotated through the steps (1: one static batch, as rounds 1-3 did)")
     ap.add_argument("--no-chamfer-standalone", action="store_true",
                     help="skip the stand-alone timing of the drop-in Chamfer operator (the `chamfer_standalone` object)")
     ap.add_argument("--graph", action="store_true",
@@ -100,7 +102,8 @@ def relaunch_distributed(args):
 
 
 # ---- workloads ----------------------------------------------------------------------------------------------------
-N_BATCHES = 4  # distinct synthetic batches rotated through the warm-up and timed steps (batch k: seed 1234 + rank + 1000 k)
+N_BATCHES = 4  # distinct synthetic batches rotated through the warm-up and timed steps (batch k: seed 1234 + rank + 1000 k);
+               # `--batches 1` replays batch 0 alone, the protocol of rounds 1-3 (353 valid parts; the four average 372.5)
 
 
 def workload(name, rank, dev, k=0):
@@ -381,7 +384,9 @@ def chamfer_standalone(dev, reps=20):
 
 
 def main():
+    global N_BATCHES
     args = parse_args()
+    N_BATCHES = max(1, args.batches)
     if args.gpus > 1 and "RANK" not in os.environ:
         relaunch_distributed(args)
     import torch

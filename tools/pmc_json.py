@@ -47,10 +47,14 @@ def main():
         ff, wf = prof / f"{rnd}_{cfg}_pmc_fetch_size.txt", prof / f"{rnd}_{cfg}_pmc_write_size.txt"
         if not (ff.exists() and wf.exists()):
             continue
-        names = [ln.split()[-1] for ln in ff.read_text().splitlines() if "knn" in ln or "rownorm" in ln]
+        names = []
+        for ln in ff.read_text().splitlines():
+            m = re.match(r"\s*\w+\s+avg/launch\s+[\d.]+\s+launches\s+\d+\s+(?:void\s+)?(.*)", ln)
+            if m and ("knn_" in m.group(1) or "rownorm" in m.group(1)) and "knn3" not in m.group(1):
+                names.append(m.group(1).split("(")[0].strip())
         widths = {}
         for C in (128, 64):
-            pats = sorted({re.escape(n.split("(")[0]) for n in names if re.search(rf"<{C}[,>]", n)})
+            pats = sorted({re.escape(n) for n in names if re.search(rf"<{C}[,>]", n)})
             if not pats:
                 continue
             fs = [per_kernel(ff, pat) for pat in pats]
