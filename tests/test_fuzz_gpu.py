@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 FAMILIES = {"loss": 4, "chamfer": 4, "knn": 4, "glue": 6, "repro": 6, "nets": 4, "dgcnn": 3, "step": 3, "gnn": 2, "global": 3,
-            "adam": 6, "graph": 2}
+            "adam": 6, "graph": 2, "cgrid": 12}
 
 
 @pytest.fixture(scope="module")

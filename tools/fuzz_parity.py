@@ -4,6 +4,10 @@ live in tests/).  Every case draws its own sizes, masks and pose regime from the
   loss   grid-pruned whole-shape search vs the brute-force scan of the same library (MPA_SHAPE_SEARCH): arg-mins of both
          directions bit-equal on the valid parts, the five loss terms within 2e-6;
   chamfer  the Chamfer operator (three scan variants) vs oracle/chamfer_ref.c: distances and indices bit-equal;
+  cgrid  the operator's grid-pruned search (variant 3: outlier-trimmed grid, unbounded border cells, run dedupe, hand-back
+         of non-finite samples) vs its exhaustive scan on clouds built to break it — blobs at different scales and offsets,
+         planes and lines, far outliers, runs of repeated points, 1e3-filled padded parts, NaN / inf / huge coordinates,
+         1 to 6000 points per cloud: all four outputs bit-equal (small cases also against oracle/chamfer_ref.c);
   knn    mpa_knn_exact (C = 3, 64, 128) vs oracle/knn_ref.c: every neighbour index, in order;
   glue   the graph-network glue kernels vs float64 library ops;
   nets   PointNet (random part counts, masks, point counts, negative / zero BatchNorm weights) and transformer + pose head
@@ -112,6 +116,59 @@ def case_chamfer(rng):
     for variant in (0, 1, 2):
         out = C.chamfer_forward(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), variant=variant)
         ok = ok and all(np.array_equal(g.cpu().numpy(), w) for g, w in zip(out, ref))
+    return ok, f"B={B} n1={n1} n2={n2}"
+
+
+def _wild_cloud(rng, B, n):
+    """A cloud meant to break a spatial index: a mixture of components at random scales / offsets, then corruptions."""
+    x = np.empty((B, n, 3), np.float32)
+    for b in range(B):
+        k = int(rng.integers(1, 5))
+        centres = rng.standard_normal((k, 3)) * float(rng.choice([0.0, 0.3, 3.0, 300.0]))
+        scales = 10.0 ** rng.uniform(-3, 1, (k, 1))
+        pick = rng.integers(0, k, n)
+        pts = centres[pick] + rng.standard_normal((n, 3)) * scales[pick]
+        shape = rng.random()
+        if shape < 0.15:
+            pts[:, int(rng.integers(3))] = float(rng.standard_normal())  # a plane
+        elif shape < 0.25:
+            pts = centres[0] + np.outer(rng.standard_normal(n), rng.standard_normal(3))  # a line
+        elif shape < 0.35:
+            pts = np.round(pts * 4) / 4  # a lattice: exact ties
+        x[b] = pts.astype(np.float32)
+        if rng.random() < 0.4 and n >= 8:  # far outliers
+            m = int(rng.integers(1, max(2, n // 10)))
+            x[b, rng.integers(0, n, m)] *= np.float32(10.0 ** rng.integers(1, 8))
+        if rng.random() < 0.4 and n >= 8:  # runs of one repeated point (the padded parts of shape_cd_loss)
+            for _ in range(int(rng.integers(1, 6))):
+                s0 = int(rng.integers(0, n - 1))
+                x[b, s0:s0 + int(rng.integers(2, max(3, n // 3)))] = (np.float32(1e3) * rng.choice([0.0, 1.0])
+                                                                      + rng.standard_normal(3).astype(np.float32))
+        if rng.random() < 0.1:  # scattered duplicates of other points
+            m = max(1, n // 5)
+            x[b, rng.integers(0, n, m)] = x[b, rng.integers(0, n, m)]
+        if rng.random() < 0.06:  # what sends a sample to the exhaustive scan
+            x[b, int(rng.integers(n)), int(rng.integers(3))] = rng.choice([np.nan, np.inf, -np.inf, 3e16, -2e20])
+    return x
+
+
+def case_cgrid(rng):
+    B = int(rng.integers(1, 10))
+    big = rng.random() < 0.5
+    n1 = int(rng.integers(1, 6000 if big else 700))
+    n2 = int(rng.integers(1, 6000 if big else 700))
+    a, b = _wild_cloud(rng, B, n1), _wild_cloud(rng, B, n2)
+    if rng.random() < 0.25:
+        m = min(n1, n2)
+        b[:, :m] = a[:, :m]  # coincident clouds: zero distances everywhere
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    with np.errstate(all="ignore"):
+        fast = C.chamfer_forward(ta, tb, variant=3)
+        slow = C.chamfer_forward(ta, tb, variant=2)
+    ok = all(torch.equal(f, s) or np.array_equal(f.cpu().numpy(), s.cpu().numpy(), equal_nan=True) for f, s in zip(fast, slow))
+    if ok and B * n1 * n2 <= 4_000_000:
+        ref = oc.chamfer_forward(a, b)
+        ok = all(np.array_equal(g.cpu().numpy(), w, equal_nan=True) for g, w in zip(fast, ref))
     return ok, f"B={B} n1={n1} n2={n2}"
 
 
@@ -679,7 +736,7 @@ def case_repro(rng):
 families = [("loss", case_loss), ("chamfer", case_chamfer), ("knn", case_knn), ("glue", case_glue), ("repro", case_repro),
             ("nets", case_nets), ("dgcnn", case_dgcnn), ("step", case_step),
             ("gnn", case_gnn), ("global", case_global),
-            ("adam", case_adam), ("graph", case_graph)]
+            ("adam", case_adam), ("graph", case_graph), ("cgrid", case_cgrid)]
 
 
 def run_case(name, seed):
