@@ -26,7 +26,7 @@ around it on its launch stream inside the timed region.  It carries the mandated
 SURVEY.md §8d per launch / time / 8 TB/s) AND the bound that actually binds (`binding`), plus a per-kernel table
 (`kernel_table`) with MFMA / VALU / HBM fractions of the other large kernels.  `cpu_baseline` is the oracle's
 reference-equivalent PyTorch-CPU step of the SAME workload timed on this host (rank 0, N = 1) on a bounded sample: c1 at
-full size, c2 / c4 at B = 4, c3 at B = 2 (scaled linearly in B, labelled), on all physical cores and on one thread.
+full size, c2 / c4 at B = 4, c3 / c5 at B = 2 (scaled linearly in B, labelled), on all physical cores and on one thread.
 With several ranks the line carries `collectives`: bytes of each gradient bucket, its stand-alone all-reduce time, the step
 time without any collective, and the fraction of the collective time that backward hid (`overlap_frac`).
 `--self-check N` appends N more timed steps and reports whether the K-step mean holds over them.
@@ -187,6 +187,9 @@ def cpu_baseline(name, cpu_batch, dev):
     elif name == "c3":
         cfg, full_B, B_all, B_one, label = config.dgl_dgcnn_everyday(), BATCH, cpu_batch or 2, 1, "c3"
         make = lambda B: synthetic.make_batch(B, P, N, preset="everyday", seed=1234, device=dev)
+    elif name == "c5":
+        cfg, full_B, B_all, B_one, label = config.rgl_net_dgcnn_artifact(), BATCH, cpu_batch or 2, 1, "c5"
+        make = lambda B: synthetic.make_batch(B, P, N, preset="artifact", seed=1234, device=dev)
     elif name == "c1":
         cfg = config.global_partnet_chair()
         cfg.data.max_num_part = 2
@@ -214,8 +217,9 @@ def cpu_baseline(name, cpu_batch, dev):
             if label == "c2":
                 losses, _ = on.pn_transformer_loss(sd, batch, cfg.model.transformer_layers,
                                                    cfg.model.transformer_heads, training=True, stats_out=stats)
-            elif label == "c3":
-                losses = oc.dgl_loss(sd, batch, cfg.model.gnn_iter, cfg.model.encoder, True, stats)
+            elif label in ("c3", "c5"):
+                losses = oc.dgl_loss(sd, batch, cfg.model.gnn_iter, cfg.model.encoder, True, stats, recurrent=label == "c5",
+                                     merge_node=cfg.model.merge_node)
             else:
                 losses = oc.global_loss(sd, batch, loss_cfg, cfg.loss.sample_iter, cfg.loss.noise_dim, cfg.model.encoder,
                                         True, stats)
@@ -233,7 +237,7 @@ def cpu_baseline(name, cpu_batch, dev):
         dt = (time.perf_counter() - t0) / timed
         return B * P / dt, dt
 
-    heavy = label == "c3"  # ~8 s per step: 1 warm-up + 1 timed per thread count keeps the default run within minutes
+    heavy = label in ("c3", "c5")  # ~8 s per step: 1 warm-up + 1 timed per thread count keeps the default run within minutes
     # torch's CPU ops do not scale to 128 threads at these sizes (c2: 57 parts/s on 128 threads, 100 on 64): the baseline
     # is the BEST of {all physical cores, 64, 16} threads, and every measured point is reported
     by_threads = {}
@@ -641,7 +645,7 @@ def main():
             "roofline": roofline,
             "kernel_table": kernel_table(kernels, valid_parts, cfg, B, P),
         }
-        if world == 1 and not args.no_cpu_baseline and args.config in ("c1", "c2", "c3", "c4"):
+        if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, dev)
         if world == 1 and not args.no_chamfer_standalone:
             line["chamfer_standalone"] = chamfer_standalone(dev)

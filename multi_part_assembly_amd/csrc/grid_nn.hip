@@ -753,9 +753,13 @@ __device__ __forceinline__ float gap(float a0, float a1, float b0, float b1) {
 // once), and then all lanes scan that list with broadcast LDS reads: two latencies per BATCH.  Long lists are
 // processed in windows of the LDS buffer; single long ranges go to the scalar scan, whose long runs amortise the
 // latency by themselves.
-#ifndef MPA_GRID_GATHER_U
-#define MPA_GRID_GATHER_U 4
+#ifndef MPA_GRID_GATHER_U  // records per lane in flight in a window's gather; a window holds kCand - 16 = 112 records, so 2 covers it
+#define MPA_GRID_GATHER_U 2
 #endif
+// Pins a loaded record in registers at this point of the program.  Without it the compiler sinks the second load of a lane
+// into the `if` that stores it — the ISA of rounds 2-3 read  load, s_waitcnt vmcnt(0), store, branch, load, s_waitcnt
+// vmcnt(0), store : the two gathers of a window, meant to be in flight together, were two dependent memory round trips.
+__device__ __forceinline__ void pin_record(float4& t) { asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w)); }
 #ifndef MPA_GRID_CAND_CHUNK  // candidates per step of the LDS scan: 4 instead of 8 frees 16 registers (94 -> 78: 6 waves per
 #define MPA_GRID_CAND_CHUNK 4  // SIMD instead of 5; 0.279 -> 0.265 ms); 2 costs more LDS instructions than the 7th wave gains
 #endif
@@ -824,6 +828,8 @@ __device__ __forceinline__ void scan_range_coop(LaneState& s, const float4* __re
 #pragma unroll
       for (int u = 0; u < U; ++u) t[u] = trec[w0 + (j0 + 64 * u < wn ? j0 + 64 * u : wn - 1)];
 #pragma unroll
+      for (int u = 0; u < U; ++u) pin_record(t[u]);
+#pragma unroll
       for (int u = 0; u < U; ++u)
         if (j0 + 64 * u < wn) cand[j0 + 64 * u] = t[u];
     }
@@ -889,6 +895,8 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
       float4 t[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) t[u] = trec[sidx[j0 + 64 * u < wn ? j0 + 64 * u : wn - 1]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) pin_record(t[u]);
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (j0 + 64 * u < wn) cand[j0 + 64 * u] = t[u];

@@ -1,8 +1,9 @@
-"""CPU restatement of the hot path's other callers — DGL (models/dgl/network.py:14-297, dgl/modules.py:5-86) and
-B-Global (models/b_global/network.py:7-132) with the loss assembly of models/modules/base_model.py:150-238,240-387
+"""CPU restatement of the hot path's other callers — DGL (models/dgl/network.py:14-297, dgl/modules.py:5-86), RGL-NET
+(models/rgl_net/network.py:14-162, rgl_net/modules.py:5-30, modules/rnn.py:6-46) and B-Global
+(models/b_global/network.py:7-132) with the loss assembly of models/modules/base_model.py:150-238,240-387
 (GT <-> prediction matching inside groups of identical parts, min-of-N sampling).  Stock torch ops on state-dict
 tensors, like oracle/nets.py.  TEST INFRASTRUCTURE: used by tests/ (pinned by the reference's own forward_pass fixtures,
-tests/test_oracle_golden.py) and by bench.py's `cpu_baseline` leg for configs c1 / c3."""
+tests/test_oracle_golden.py) and by bench.py's `cpu_baseline` leg for configs c1 / c3 / c5."""
 from __future__ import annotations
 
 import torch
@@ -54,9 +55,30 @@ def part_features(sd, batch, encoder, prefix, training, stats_out):
     return torch.zeros(B, P, feats.shape[-1], dtype=feats.dtype).index_put((mask,), feats)
 
 
-def dgl_forward(sd, batch, iters, encoder="dgcnn", training=True, stats_out=None):
+def packed_bigru(x, hidden, valids, sd, prefix, training):
+    """RNNWrapper(nn.GRU(bidirectional, batch_first)) of modules/rnn.py:6-46 on state-dict tensors: pack by
+    valids.sum(1), run the GRU on the packed data exactly as nn.GRU.forward does for a PackedSequence (initial state
+    permuted by the packing's sort order), pad back to P steps (zeros behind a sample's last valid part)."""
+    from torch.nn.utils.rnn import PackedSequence, pack_padded_sequence, pad_packed_sequence
+    packed = pack_padded_sequence(x, valids.sum(dim=1).cpu(), batch_first=True, enforce_sorted=False)
+    params = [sd[prefix + n + sfx] for sfx in ("", "_reverse") for n in ("rnn.weight_ih_l0", "rnn.weight_hh_l0",
+                                                                          "rnn.bias_ih_l0", "rnn.bias_hh_l0")]
+    hx = hidden.index_select(1, packed.sorted_indices)
+    data, _ = torch._VF.gru(packed.data, packed.batch_sizes, hx, params, True, 1, 0.0, training, True)
+    out, _ = pad_packed_sequence(PackedSequence(data, packed.batch_sizes, packed.sorted_indices, packed.unsorted_indices),
+                                 batch_first=True, total_length=x.shape[1])
+    return out
+
+
+def dgl_forward(sd, batch, iters, encoder="dgcnn", training=True, stats_out=None, recurrent=False, merge_node=False):
     """DGL.forward for geometric data (dgl/network.py:154-243; no semantic labels, merge_node without effect):
-    -> list of (rot [B,P,4], trans [B,P,3]) per GNN iteration."""
+    -> list of (rot [B,P,4], trans [B,P,3]) per GNN iteration.
+    recurrent: RGLNet.forward (rgl_net/network.py:70-162) — the node update runs [part_feats ; messages] through a
+    packed bidirectional GRU with a random initial state (two draws per iteration on the CPU generator, :50-57) and
+    MLP4 without the last ReLU (rgl_net/modules.py:5-30) instead of DGL's MLP4 on [messages ; part_feats].
+    merge_node (cfg.model.merge_node; on in the RGL-NET everyday config): odd iterations predict the relations with
+    `relation_predictor` instead of `relation_predictor_dense` (dgl/network.py:127-132) — the node merging itself needs
+    semantic labels and does nothing on geometric data (:195)."""
     part_feats = part_features(sd, batch, encoder, "encoder.", training, stats_out)
     valid_matrix = batch["valid_matrix"]
     B, P, Fd = part_feats.shape
@@ -69,20 +91,28 @@ def dgl_forward(sd, batch, iters, encoder="dgcnn", training=True, stats_out=None
         else:
             pf = pose_encoder(pose, sd, "pose_extractor.")
             pair = torch.cat([pf[:, None].expand(B, P, P, -1), pf[:, :, None].expand(B, P, P, -1)], dim=-1)
-            relation = relation_net(pair.reshape(B, P * P, -1), sd, "relation_predictor_dense.").view(B, P, P) * valid_matrix
+            which = "relation_predictor." if merge_node and it % 2 == 1 else "relation_predictor_dense."
+            relation = relation_net(pair.reshape(B, P * P, -1), sd, which).view(B, P, P) * valid_matrix
         pair = torch.cat([part_feats[:, :, None].expand(B, P, P, Fd), part_feats[:, None].expand(B, P, P, Fd)], dim=-1)
         edge = pair_mlp(pair.reshape(B * P, P, 2 * Fd), sd, f"edge_mlps.{it}.", training, stats_out).view(B, P, P, -1)
         msg = (edge * relation[..., None]).sum(dim=2) / (relation.sum(dim=-1, keepdim=True) + 1e-6)
-        part_feats = pair_mlp(torch.cat([msg, part_feats], dim=-1), sd, f"node_mlps.{it}.", training, stats_out)
+        if recurrent:
+            hidden = torch.cat([torch.randn((1, B, Fd)).repeat(2, 1, 1), torch.randn((2, B, Fd))], dim=-1).type_as(msg)
+            gru_out = packed_bigru(torch.cat([part_feats, msg], dim=-1), hidden, batch["part_valids"], sd, f"grus.{it}.",
+                                   training)
+            part_feats = pair_mlp(gru_out, sd, f"node_mlps.{it}.", training, stats_out, final_relu=False)
+        else:
+            part_feats = pair_mlp(torch.cat([msg, part_feats], dim=-1), sd, f"node_mlps.{it}.", training, stats_out)
         rot, trans = on.pose_head(torch.cat([part_feats, pose], dim=-1), sd, f"pose_predictors.{it}.")
         pose = torch.cat([rot, trans], dim=-1)
         preds.append((rot, trans))
     return preds
 
 
-def dgl_loss(sd, batch, iters, encoder="dgcnn", training=True, stats_out=None):
-    """forward_pass of DGL on geometric data: the loss of every iteration's prediction, summed (dgl/network.py:245-297)."""
-    preds = dgl_forward(sd, batch, iters, encoder, training, stats_out)
+def dgl_loss(sd, batch, iters, encoder="dgcnn", training=True, stats_out=None, recurrent=False, merge_node=False):
+    """forward_pass of DGL (recurrent: RGL-NET) on geometric data: the loss of every iteration's prediction, summed
+    (dgl/network.py:245-297, inherited by RGLNet)."""
+    preds = dgl_forward(sd, batch, iters, encoder, training, stats_out, recurrent, merge_node)
     total = {}
     for i, (rot, trans) in enumerate(preds):
         terms = og.calc_loss_geometric(og.checked_quat(rot), trans, batch["part_pcs"], og.checked_quat(batch["part_quat"]),

@@ -391,7 +391,7 @@ def test_gru_exchange_is_stable_over_many_launches(cuda_device):
 
 
 def _against_float64(cuda_device, capsys, cfg, label, oracle_loss, B=4, no_dropout=False, slack=0.17, median_cap=1.2,
-                     abs_cap=None):
+                     abs_cap=None, preset="everyday", reseed=None):
     """One training-mode forward_pass + backward at P = 20, N = 1000 on the HIP path, on the float32 CPU oracle and on the
     same oracle in float64; returns nothing, asserts that the HIP path is as close to float64 as the float32 oracle."""
     from multi_part_assembly_amd import synthetic
@@ -406,9 +406,11 @@ def _against_float64(cuda_device, capsys, cfg, label, oracle_loss, B=4, no_dropo
                 m.dropout = 0.0
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     names = [k for k, _ in model.named_parameters()]
-    batch = synthetic.make_batch(B, 20, 1000, preset="everyday", seed=1234, device=cuda_device)
+    batch = synthetic.make_batch(B, 20, 1000, preset=preset, seed=1234, device=cuda_device)
     batch.pop("num_parts", None)
     model.to(cuda_device).train()
+    if reseed is not None:  # models that draw on the CPU generator inside forward: the same draws for all three evaluations
+        torch.manual_seed(reseed)
     loss = model.training_step(batch, 0)
     loss.backward()
     hip = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters() if p.grad is not None}
@@ -420,6 +422,8 @@ def _against_float64(cuda_device, capsys, cfg, label, oracle_loss, B=4, no_dropo
         sd = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
         params = {k: sd[k].requires_grad_() for k in names}
         cb = {k: (v.cpu().to(dt) if v.is_floating_point() else v.cpu()) for k, v in batch.items() if hasattr(v, "cpu")}
+        if reseed is not None:
+            torch.manual_seed(reseed)
         total = oracle_loss(sd, cb)
         total.backward()
         return float(total.detach()), {k: p.grad.double() for k, p in params.items() if p.grad is not None}
@@ -472,6 +476,19 @@ def test_dgl_dgcnn_step_at_the_benchmark_part_size_against_float64(cuda_device, 
     cfg = config.dgl_dgcnn_everyday()
     _against_float64(cuda_device, capsys, cfg, "DGL + DGCNN",
                      lambda sd, cb: oc.dgl_loss(sd, cb, cfg.model.gnn_iter, cfg.model.encoder, True, {})["loss"])
+
+
+def test_rgl_net_dgcnn_step_at_the_benchmark_part_size_against_float64(cuda_device, capsys):
+    """BASELINE.json configs[4] at its part size (RGL-NET + DGCNN, artifact-like clouds: 12-20 small parts of 1000 points;
+    B = 4): the same float64-anchored bar as the DGL step above, against `oracle/callers.py` with the recurrent node update
+    (pinned by both RGL-NET reference fixtures in tests/test_oracle_golden.py).  All three evaluations see the same GRU
+    initial states (the CPU generator is re-seeded in front of each)."""
+    from oracle import callers as oc
+    cfg = config.rgl_net_dgcnn_artifact()
+    _against_float64(cuda_device, capsys, cfg, "RGL-NET + DGCNN",
+                     lambda sd, cb: oc.dgl_loss(sd, cb, cfg.model.gnn_iter, cfg.model.encoder, True, {}, recurrent=True,
+                                                merge_node=cfg.model.merge_node)["loss"],
+                     preset="artifact", reseed=4321, slack=0.25)
 
 
 def test_pn_transformer_step_at_the_benchmark_part_size_against_float64(cuda_device, capsys):

@@ -239,9 +239,10 @@ def test_knn_oracle_wide_features_are_the_true_neighbours():
         assert (idx[..., 0] == np.arange(150)[None]).all()
 
 
-@pytest.mark.parametrize("name", ["dgl_dgcnn_step", "dgl_step", "global_semantic_step"])
+@pytest.mark.parametrize("name", ["dgl_dgcnn_step", "dgl_step", "global_semantic_step", "rgl_net_step",
+                                  "rgl_net_dgcnn_artifact_step"])
 def test_caller_oracles_match_reference_steps(golden, name):
-    """oracle/callers.py (DGL on both encoders; B-Global with Hungarian matching and min-of-5 sampling) against the
+    """oracle/callers.py (DGL and RGL-NET on both encoders; B-Global with Hungarian matching and min-of-5 sampling) against the
     reference's own training-mode forward_pass fixtures: every loss term of every GNN iteration to 1e-5, and the
     parameter gradients no further from the float64 record than the float32 reference itself is (+1e-4) — the oracle
     that bench.py times as `cpu_baseline` for configs c1 / c3 is the reference's computation."""
@@ -254,7 +255,8 @@ def test_caller_oracles_match_reference_steps(golden, name):
     from oracle import callers as oc
     z = golden(name)
     cfg = {"dgl_dgcnn_step": config.dgl_dgcnn_everyday, "dgl_step": config.dgl_everyday,
-           "global_semantic_step": config.global_partnet_chair}[name]()
+           "global_semantic_step": config.global_partnet_chair, "rgl_net_step": config.rgl_net_everyday,
+           "rgl_net_dgcnn_artifact_step": config.rgl_net_dgcnn_artifact}[name]()
     cfg.model.pc_feat_dim = int(z["cfg"][0])
     cfg.data.max_num_part = 5
     seed = int(z["seed"][0])
@@ -266,8 +268,9 @@ def test_caller_oracles_match_reference_steps(golden, name):
         sd[k].requires_grad_()
     batch = {k[5:]: T(z[k].copy()) for k in z if k.startswith("data.")}
     torch.manual_seed(seed + 1)
-    if name.startswith("dgl"):
-        out = oc.dgl_loss(sd, batch, cfg.model.gnn_iter, cfg.model.encoder, True, {})
+    if name.startswith("dgl") or name.startswith("rgl"):
+        out = oc.dgl_loss(sd, batch, cfg.model.gnn_iter, cfg.model.encoder, True, {}, recurrent=name.startswith("rgl"),
+                          merge_node=cfg.model.merge_node)
     else:
         out = oc.global_loss(sd, batch, {k: cfg.loss[k] for k in cfg.loss}, cfg.loss.sample_iter, cfg.loss.noise_dim,
                              cfg.model.encoder, True, {})
