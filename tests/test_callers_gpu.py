@@ -482,13 +482,14 @@ def test_rgl_net_dgcnn_step_at_the_benchmark_part_size_against_float64(cuda_devi
     """BASELINE.json configs[4] at its part size (RGL-NET + DGCNN, artifact-like clouds: 12-20 small parts of 1000 points;
     B = 4): the same float64-anchored bar as the DGL step above, against `oracle/callers.py` with the recurrent node update
     (pinned by both RGL-NET reference fixtures in tests/test_oracle_golden.py).  All three evaluations see the same GRU
-    initial states (the CPU generator is re-seeded in front of each)."""
+    initial states (the CPU generator is re-seeded in front of each).  Measured: loss 2.702235 (HIP) / 2.704128 (float32
+    oracle) / 2.703485 (float64); median ratio of the per-tensor gradient deviations 0.59 over 135 tensors."""
     from oracle import callers as oc
     cfg = config.rgl_net_dgcnn_artifact()
     _against_float64(cuda_device, capsys, cfg, "RGL-NET + DGCNN",
                      lambda sd, cb: oc.dgl_loss(sd, cb, cfg.model.gnn_iter, cfg.model.encoder, True, {}, recurrent=True,
                                                 merge_node=cfg.model.merge_node)["loss"],
-                     preset="artifact", reseed=4321, slack=0.25)
+                     preset="artifact", reseed=4321, slack=0.21)  # measured need 0.136 (8 of 135 tensors) + 50 %
 
 
 def test_pn_transformer_step_at_the_benchmark_part_size_against_float64(cuda_device, capsys):
