@@ -843,10 +843,42 @@ __device__ __forceinline__ void scan_range_coop(LaneState& s, const float4* __re
 }
 
 #ifdef MPA_GRID_STATS  // instrumented build for tools/probe_grid_stats.py only (never in libmpa_hip.so)
-__device__ unsigned long long g_grid_stats[8];  // items, active lanes, scan_batch calls, candidates, long-range candidates
+__device__ unsigned long long g_grid_stats[24];  // 0-7: items, active lanes, scan_batch calls, candidates, long-range candidates,
+                                                 // outer-ring batches, items without a bound after the seed; 8-15: shader-clock ticks of
+                                                 // a wave's phases: prologue, item header, seed, rings 0-1, outer rings, pads + store,
+                                                 // whole wave, waves
+#ifdef MPA_GRID_TIMING  // phase timing: no counters inside the timed phases, the per-wave sums leave in one batch at the end
+#define MPA_STAT(i, v) do { } while (0)
+#define MPA_TICK(i)                                                        \
+  do {                                                                     \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            \
+    const unsigned long long now_ = __builtin_readcyclecounter();          \
+    tacc_[(i) - 8] += now_ - tick_;                                        \
+    tick_ = now_;                                                          \
+  } while (0)
+#define MPA_TICK_INIT()                                                    \
+  unsigned long long tick_ = __builtin_readcyclecounter(), tacc_[6] = {0, 0, 0, 0, 0, 0}; \
+  const unsigned long long tick0_ = tick_
+#define MPA_TICK_END()                                                                                        \
+  do {                                                                                                        \
+    if (threadIdx.x == 0) {                                                                                   \
+      const unsigned long long end_ = __builtin_readcyclecounter();                                           \
+      for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_grid_stats[8 + k_], tacc_[k_]);                              \
+      atomicAdd(&g_grid_stats[14], end_ - tick0_);                                                            \
+      atomicAdd(&g_grid_stats[15], 1ull);                                                                     \
+    }                                                                                                         \
+  } while (0)
+#else
 #define MPA_STAT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_grid_stats[i], (unsigned long long)(v)); } while (0)
+#define MPA_TICK(i) do { } while (0)
+#define MPA_TICK_INIT() do { } while (0)
+#define MPA_TICK_END() do { } while (0)
+#endif
 #else
 #define MPA_STAT(i, v) do { } while (0)
+#define MPA_TICK(i) do { } while (0)
+#define MPA_TICK_INIT() do { } while (0)
+#define MPA_TICK_END() do { } while (0)
 #endif
 
 __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restrict__ trec, int rb, int re,
@@ -928,6 +960,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     IdxT* __restrict__ idx2, const XcdPlan* __restrict__ plan) {
   __shared__ float4 cand[kCand];
   __shared__ int sidx[kCand];  // record index of every position of the current window
+  MPA_TICK_INIT();
   // block -> (sample, direction, wave): from the XCD-aware plan (grid_assign_plan) or, without one, waves
   // blockIdx.x of pair blockIdx.y
   int pair = (int)blockIdx.y, wid = (int)blockIdx.x, wstride = (int)gridDim.x;
@@ -981,6 +1014,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     }
   }
   const unsigned long long padmask = GENERIC ? 0ull : __ballot(pad);
+  MPA_TICK(8);
 
   for (int work = wid; work < total_work; work += wstride) {  // persistent walk over the work list
     const int sc = worklist[(long long)qslot * work_stride + work];  // super-cell with bst[sc] <= work < bst[sc+1]
@@ -999,6 +1033,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     const int qflat = __float_as_int(qr.w);
     s.best = 1e32f;
     s.bidx = 0x7fffffff;
+    MPA_TICK(9);
     // the queries lie in the super-cell box (inflated by the binning slack)
     float bx0 = OX + (float)(kS * sx) * g.h - slack, bx1 = OX + (float)(kS * sx + kS) * g.h + slack;
     float by0 = OY + (float)(kS * sy) * g.h - slack, by1 = OY + (float)(kS * sy + kS) * g.h + slack;
@@ -1033,6 +1068,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     merge_halves(s);
     float bound = wave_max(s.best) * 1.00001f;
     MPA_STAT(6, bound > 1e31f ? 1 : 0);
+    MPA_TICK(10);
     const int yc0 = kS * sy, yc1 = kS * sy + kS - 1, zc0 = kS * sz, zc1 = kS * sz + kS - 1;
     const int rmax = max(max(yc0, g.gy - 1 - yc1), max(zc0, g.gz - 1 - zc1));
     auto ring_rows = [&](int r) { return r == 0 ? kS * kS : 2 * (kS + 2 * r) + 2 * (kS + 2 * r - 2); };
@@ -1104,6 +1140,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
       merge_halves(s);
       bound = wave_max(s.best) * 1.00001f;  // (ring 1 must see the bound ring 0 found: without one, rows are whole)
     }
+    MPA_TICK(11);
     for (int r = 2; r <= rmax; ++r) {
       const float ring_gap = (float)(r - 1) * g.h - 2.0f * slack;
       if (ring_gap * ring_gap >= bound) break;
@@ -1116,8 +1153,11 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
       }
       merge_halves(s);
       bound = wave_max(s.best) * 1.00001f;  // (two rings per batch were tried: the staler bound costs what the saved
-                                            // round trips gain)
+                                            // round trips gain; round 4: so does requesting batch k + 1's row offsets
+                                            // before batch k is scanned — a software pipeline of the sweep with the stale
+                                            // bound's superset intervals: 0.297 vs 0.266 ms, and 84 registers = 5 waves)
     }
+    MPA_TICK(12);
     {  // padded parts' representatives, in part order (uniform loop over the set bits)
       unsigned long long m = padmask;
       while (m) {
@@ -1131,7 +1171,9 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
       dout[qflat] = s.best;
       iout[qflat] = s.bidx == 0x7fffffff ? (IdxT)-1 : (IdxT)s.bidx;
     }
+    MPA_TICK(13);
   }  // work loop
+  MPA_TICK_END();
 }
 
 // per-part sums of the distances, written where the finalize kernel expects the tile sums (tile 0 of each part;
@@ -1289,10 +1331,10 @@ void launch_cloud_copy_runs(int64_t B, int64_t n1, int64_t n2, float* dist1, int
 }  // namespace mpa
 
 #ifdef MPA_GRID_STATS
-extern "C" int mpa_debug_grid_stats(unsigned long long* out8, int reset) {
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mpa::g_grid_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+extern "C" int mpa_debug_grid_stats(unsigned long long* out24, int reset) {
+  if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(mpa::g_grid_stats), 24 * sizeof(unsigned long long)) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[24] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(mpa::g_grid_stats), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 
 from multi_part_assembly_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = ROOT / "build_variants" / "gridstats.so"
+_lib.LIB_PATH = ROOT / "build_variants" / (sys.argv[1] if len(sys.argv) > 1 else "gridstats.so")
 from multi_part_assembly_amd import chamfer, synthetic  # noqa: E402
 from multi_part_assembly_amd.transforms import pose_apply  # noqa: E402
 
@@ -22,7 +22,7 @@ L.mpa_debug_grid_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
 
 
 def stats(a, b, label):
-    out = (ctypes.c_ulonglong * 8)()
+    out = (ctypes.c_ulonglong * 24)()
     L.mpa_debug_grid_stats(out, 1)
     chamfer.chamfer_forward(a, b, variant=3)
     torch.cuda.synchronize()
@@ -31,6 +31,11 @@ def stats(a, b, label):
     print(f"{label}: items {items}, lanes/item {lanes / max(items, 1):.1f}, scan_batch calls/item {batches / max(items, 1):.1f}, "
           f"candidates/item {cands / max(items, 1):.0f} (long ranges {longc / max(items, 1):.0f}), outer-ring batches/item "
           f"{ringb / max(items, 1):.1f}, items without a bound after the seed {nobound}")
+    t = list(out)[8:16]
+    waves = max(t[7], 1)
+    names = ["prologue", "item header", "seed", "rings 0-1", "outer rings", "pads + store"]
+    print("   shader-clock ticks per wave: " + ", ".join(f"{n} {t[i] / waves:.0f}" for i, n in enumerate(names))
+          + f"; whole wave {t[6] / waves:.0f}; waves {t[7]}, items per wave {items / waves:.2f}")
 
 
 def build(num_parts=None, fill=1e3, seed=1234):
