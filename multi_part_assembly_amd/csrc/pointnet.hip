@@ -1688,7 +1688,9 @@ __global__ __launch_bounds__(NTH, 2) void pn_bwd_fused_kernel(
   // spill: the kernel runs at the 256-register limit of two blocks per CU)
   __shared__ __attribute__((aligned(16))) float w1s[FIRST ? 192 : 4];
   if constexpr (FIRST) {
-    if (threadIdx.x < 192) w1s[threadIdx.x] = wt1[threadIdx.x];  // (published by the first barrier of the unit loop)
+    if (threadIdx.x < 192) w1s[threadIdx.x] = wt1[threadIdx.x];
+    __syncthreads();  // the FIRST unit's stash reads them before the loop's own barrier (without this: a race that
+                      // tools/exp_race_hunt.py caught as one diverging step in ~300 — wrong Y1 rows in a block's first unit)
   }
   auto fetch = [&](int u, int m) {
     const int n0 = (u % TB) * RB;
@@ -1776,14 +1778,29 @@ __global__ __launch_bounds__(NTH, 2) void pn_bwd_fused_kernel(
         }
       }
       const bool full = r0 + 32 <= N;  // wave-uniform: only a part's last tile is ragged
+      // the Yprev values behind the ReLU mask and the BatchNorm sums are read from the panel TWO rows ahead of their use:
+      // read where they are used, their 32 LDS round trips per unit stood exposed (12 of the kernel's 102 us by a
+      // timing-only build without them; the registers for all 32 at once do not exist: the kernel runs at 256)
+      constexpr int LA = 2;
+      float ypq[LA][NT];
+#pragma unroll
+      for (int q = 0; q < LA; ++q)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ypq[q][t] = cp[(rt * 32 + acc_row(q, h)) * LDP + d0 + 32 * t + j];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int rl = rt * 32 + acc_row(r, h), gn = r0 + acc_row(r, h);
+        const int gn = r0 + acc_row(r, h);
         const bool ok = full || gn < N;
         const long long o = ((long long)m * N + gn) * CIN + d0 + j;
+        float ypr[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const float ypv = cp[rl * LDP + d0 + 32 * t + j];
+          ypr[t] = ypq[r % LA][t];
+          if (r + LA < 16) ypq[r % LA][t] = cp[(rt * 32 + acc_row(r + LA, h)) * LDP + d0 + 32 * t + j];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float ypv = ypr[t];
           const float zz = __builtin_fmaf(ypv, scp[t], shp[t]);
           const float d = (ok && zz > 0.0f) ? acc[t][r] : 0.0f;
           if (ok) dz_prev[o + 32 * t] = d;

@@ -597,3 +597,31 @@ def test_gru_reports_grid_residency(cuda_device):
     from multi_part_assembly_amd.gru import supported
     assert supported(256, 32) and supported(128, 3)
     assert not supported(192, 32) and not supported(256, 65)
+
+
+def test_two_trainers_walk_the_same_trajectory_at_the_benchmark_size(cuda_device):
+    """Run-to-run reproducibility of the whole step at BASELINE.json configs[1]'s size (B = 32, P = 20, N = 1000): two
+    trainers with identical initial weights take 600 steps side by side over four rotated batches; their parameter
+    buffers must stay bit-equal after every step.  (tools/exp_race_hunt.py is the long form — it caught an LDS race in a
+    block's FIRST unit of the layer-2 backward kernel, one diverging step in ~300, that no single-step parity test and no
+    run-twice check at small sizes had seen: only a block's first unit at full occupancy was exposed.)"""
+    from multi_part_assembly_amd import synthetic
+    cfg = config.pn_transformer_everyday()
+    batches = []
+    for k in range(4):
+        bt = synthetic.make_batch(32, 20, 1000, preset="everyday", seed=1234 + 1000 * k, device=cuda_device)
+        bt.pop("num_parts")
+        batches.append(bt)
+
+    def make():
+        torch.manual_seed(0)
+        return Trainer(build_model(cfg).to(cuda_device), cfg)
+
+    a, b = make(), make()
+    assert torch.equal(a.flat.flat_param, b.flat.flat_param)
+    for i in range(600):
+        a.train_step(batches[i % 4], i)
+        b.train_step(batches[i % 4], i)
+        if i % 20 == 19 or i < 20:
+            assert torch.equal(a.flat.flat_param, b.flat.flat_param), f"trajectories diverge by step {i}"
+    assert torch.equal(a.flat.flat_param, b.flat.flat_param)
