@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Hunt for run-to-run non-determinism in the c2 training step: two trainers with identical initial weights walk the same
 batch sequence side by side; after every step their flat parameter buffers must be bit-equal.  At the first divergence the
-step's gradients are compared per parameter to name the module.   python tools/exp_race_hunt.py [steps=3000] [config=c2]"""
+step's gradients are compared per parameter to name the module.   python tools/exp_race_hunt.py [steps=3000] [config=c2] [bf16]
+(c5: RGL-NET draws its GRU initial states on the CPU generator — two trainers taking turns would see different draws, so the
+draw is pinned to one fixed tensor per batch size for the hunt; c1 goes through the generic Chamfer backward, whose float
+atomics are unordered BY CONTRACT, as the reference's: its trajectory is not expected to repeat.)"""
 import sys
 from pathlib import Path
 
@@ -15,6 +18,7 @@ from multi_part_assembly_amd.trainer import Trainer  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 name = sys.argv[2] if len(sys.argv) > 2 else "c2"
+bf16 = len(sys.argv) > 3 and sys.argv[3] == "bf16"
 dev = torch.device("cuda", 0)
 cfg, batch0, _, B, P = bench.workload(name, 0, dev)
 batches = [batch0] + [bench.workload(name, 0, dev, k)[1] for k in range(1, 4)]
@@ -22,9 +26,27 @@ for bt in batches:
     bt.pop("num_parts", None)
 
 
+if name == "c5":
+    from multi_part_assembly_amd import gnn
+    _fixed = {}
+
+    def _fixed_hidden(self, B, device=None):
+        if B not in _fixed:
+            _fixed[B] = torch.randn((2, B, 2 * self.pc_feat_dim), generator=torch.Generator().manual_seed(11)).to(device)
+        return _fixed[B]
+
+    gnn.RGLNet._init_gru_hidden = _fixed_hidden
+
+
 def make():
     torch.manual_seed(0)
-    return Trainer(build_model(cfg).to(dev), cfg)
+    model = build_model(cfg).to(dev)
+    if bf16:
+        from multi_part_assembly_amd.encoder import PointNet
+        for m in model.modules():
+            if isinstance(m, PointNet):
+                m.precision = "bf16"
+    return Trainer(model, cfg)
 
 
 a, b = make(), make()
