@@ -121,3 +121,20 @@ def test_no_kernel_uses_scratch_memory(built):
         if u.get("scratch_bytes_per_lane", 0) > limit:
             bad[name] = u
     assert not bad, f"kernels using scratch memory: {bad}"
+
+
+def test_bench_batches_have_representative_part_counts():
+    """bench.py rotates four synthetic batches; except the historical batch 0 of rank 0 their part counts are redrawn until
+    the sum is within 4 of the generator's expectation (the metric counts B x P slots, the work follows the valid parts)."""
+    import importlib.util
+    import pathlib
+    spec = importlib.util.spec_from_file_location("bench", pathlib.Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for preset, want in (("everyday", 352), ("artifact", 512)):
+        for seed in (1234, 2234, 1235, 99999):
+            parts = bench.representative_parts(preset, seed)
+            assert len(parts) == 32 and abs(sum(parts) - want) <= 4
+            assert parts == bench.representative_parts(preset, seed)  # a function of (preset, seed) only
+    lo, hi = 2, 20
+    assert all(lo <= p <= hi for p in bench.representative_parts("everyday", 7))
