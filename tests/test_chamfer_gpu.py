@@ -273,3 +273,19 @@ def test_chamfer_workspace_contract(cuda_device):
     assert torch.equal(d1, want[0]) and torch.equal(i1, want[1]) and torch.equal(i2, want[3])
     assert L.mpa_chamfer_forward_variant(*args, 3, None, 0, s) == _lib.lib().mpa_chamfer_forward_variant(*args, 3, None, 0, s) != 0
     assert b"workspace" in L.mpa_last_error()
+
+
+def test_grid_search_far_beyond_the_loss_sizes(cuda_device):
+    """Clouds ten times the whole-shape call's size (150 000 and 200 000 points, unequal, with far outliers and a long run
+    of one repeated point): the pruned search's work lists, record strides and run heads at sizes the fused loss never
+    reaches — bit-equal to the exhaustive scan."""
+    g = torch.Generator().manual_seed(17)
+    a = torch.randn(2, 150_000, 3, generator=g) * torch.tensor([1.0, 0.3, 2.0])
+    b = torch.randn(2, 200_000, 3, generator=g) * 0.8 + 0.1
+    a[:, 1000:1200] *= 1e4
+    b[0, 50_000:90_000] = torch.tensor([1e3, 1e3, -1e3])
+    a, b = a.to(cuda_device), b.to(cuda_device)
+    fast = C.chamfer_forward(a, b)
+    slow = C.chamfer_forward(a, b, variant=2)
+    for f, s in zip(fast, slow):
+        assert torch.equal(f, s)
