@@ -417,6 +417,11 @@ def main():
     N_BATCHES = max(1, args.batches)
     if args.gpus > 1 and "RANK" not in os.environ:
         relaunch_distributed(args)
+    # ONE line on stdout, whatever the libraries print: RCCL writes a five-line version banner to stdout when the first
+    # communicator comes up.  File descriptor 1 points at stderr for the whole run; the JSON line goes to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -678,7 +683,8 @@ def main():
             line["self_check"] = self_check
         if collectives is not None:
             line["collectives"] = collectives
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 

@@ -52,6 +52,20 @@ def test_bench_line_has_the_contract_keys(cuda_device):
     assert all(x["bit_equal_to_exhaustive_scan"] is True for x in cs[1:])
 
 
+def test_one_stdout_line_under_the_drivers_launcher(cuda_device):
+    """The driver's N>1 form (`python -m torch.distributed.run ... bench.py --gpus N`) with one rank: the process group is
+    RCCL, whose version banner goes to stdout when the first communicator comes up — the bench keeps it off ITS stdout."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-chamfer-standalone"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and d["steps"] == 3
+
+
 def _committed_ms(tag):
     """ms_per_step of the newest committed bench line profiles/rNN_<tag>_bench_line.json."""
     import glob
