@@ -144,11 +144,28 @@ __global__ __launch_bounds__(256) void ml_bwd_sums_kernel(const float* __restric
   for (int c = threadIdx.x; c < C; c += 256) {
     const float mean = bn[2 * C + c], invstd = bn[3 * C + c];
     float s1 = 0.0f, s2 = 0.0f;
-    for (int i = 0; i < rows; ++i) {
-      const long long o = (r0 + i) * C + c;
-      const float d = relu ? (out[o] > 0.0f ? g[o] : 0.0f) : g[o];
-      s1 += d;
-      s2 = __builtin_fmaf(d, (y[o] - mean) * invstd, s2);
+    if (rows == kRT) {  // a full tile: all of its loads in flight at once (a rolled loop waits for three loads per row);
+      float gv[kRT], ov[kRT], yv[kRT];  // the sums run in the same row order either way
+#pragma unroll
+      for (int i = 0; i < kRT; ++i) {
+        const long long o = (r0 + i) * C + c;
+        gv[i] = g[o];
+        ov[i] = out[o];  // (unconditional: a load under `relu ?` becomes a branch with a full wait behind it)
+        yv[i] = y[o];
+      }
+#pragma unroll
+      for (int i = 0; i < kRT; ++i) {
+        const float d = (relu == 0 || ov[i] > 0.0f) ? gv[i] : 0.0f;
+        s1 += d;
+        s2 = __builtin_fmaf(d, (yv[i] - mean) * invstd, s2);
+      }
+    } else {
+      for (int i = 0; i < rows; ++i) {
+        const long long o = (r0 + i) * C + c;
+        const float d = relu ? (out[o] > 0.0f ? g[o] : 0.0f) : g[o];
+        s1 += d;
+        s2 = __builtin_fmaf(d, (y[o] - mean) * invstd, s2);
+      }
     }
     float* p = partial + ((long long)blockIdx.x * C + c) * 2;
     p[0] = s1;
@@ -198,12 +215,30 @@ __global__ __launch_bounds__(256) void ml_bwd_dy_kernel(const float* __restrict_
       betap = coef[2 * C + c];
     }
     float s = 0.0f;
-    for (int i = 0; i < rows; ++i) {
-      const long long o = (r0 + i) * C + c;
-      const float d = relu ? (out[o] > 0.0f ? g[o] : 0.0f) : g[o];
-      const float v = coef != nullptr ? __builtin_fmaf(alpha, d, __builtin_fmaf(gammap, y[o], betap)) : d;
-      dy[o] = v;
-      s += v;
+    if (rows == kRT) {  // full tile: loads up front, as in ml_bwd_sums_kernel
+      float gv[kRT], ov[kRT], yv[kRT];
+#pragma unroll
+      for (int i = 0; i < kRT; ++i) {
+        const long long o = (r0 + i) * C + c;
+        gv[i] = g[o];
+        ov[i] = out[o];  // (unconditional: a load under `relu ?` becomes a branch with a full wait behind it)
+        yv[i] = y[o];
+      }
+#pragma unroll
+      for (int i = 0; i < kRT; ++i) {
+        const float d = (relu == 0 || ov[i] > 0.0f) ? gv[i] : 0.0f;
+        const float v = coef != nullptr ? __builtin_fmaf(alpha, d, __builtin_fmaf(gammap, yv[i], betap)) : d;
+        dy[(r0 + i) * C + c] = v;
+        s += v;
+      }
+    } else {
+      for (int i = 0; i < rows; ++i) {
+        const long long o = (r0 + i) * C + c;
+        const float d = relu ? (out[o] > 0.0f ? g[o] : 0.0f) : g[o];
+        const float v = coef != nullptr ? __builtin_fmaf(alpha, d, __builtin_fmaf(gammap, y[o], betap)) : d;
+        dy[o] = v;
+        s += v;
+      }
     }
     partial[(long long)blockIdx.x * C + c] = s;
   }
