@@ -6,6 +6,26 @@
 
 namespace mpa {
 
+// Row loop of the row-tiled streaming kernels: thread (row group g of G) visits rows g, g + G, ... < rows.  `load(i)`
+// returns what row i needs from memory, `use(i, t)` consumes it — U rows' loads are issued before the first is used.
+// (A rolled `for (i = g; i < rows; i += G)` loop waits for every trip's loads before it issues the next trip's: one row
+// in flight per wave, ~2 TB/s for the whole chip however many waves are resident — tools/isa_serial_loops.py lists
+// such loops.)  The rows are consumed in the same ascending order either way: sums do not change.
+template <int U, typename Load, typename Use>
+__device__ __forceinline__ void batched_rows(int g, int G, int rows, Load load, Use use) {
+  using T = decltype(load(0));
+  int i = g;
+  for (; i + (U - 1) * G < rows; i += U * G) {
+    T t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) t[u] = load(i + u * G);
+#pragma unroll
+    for (int u = 0; u < U; ++u) use(i + u * G, t[u]);
+  }
+  for (; i < rows; i += G) use(i, load(i));
+}
+
+
 constexpr int kSlices = 16;  // row slices per block of the reduction kernels (64 channels x 16 = 1024 threads)
 
 // Sum per-block (sum0, sum1) partial tables over their rows for 64 channels — cooperatively: a single CU
@@ -66,10 +86,12 @@ __device__ __forceinline__ bool coop_colsum(int total, int C, int c, const CoopW
   if (!last) return false;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (acquire only)
   a = b = 0.0;
-  for (int gg = slice; gg < G; gg += kSlices) {
-    a += ws.stage[((long long)gg * C + c) * 2];
-    b += ws.stage[((long long)gg * C + c) * 2 + 1];
-  }
+  batched_rows<4>(slice, kSlices, G,
+                  [&](int gg) { return *reinterpret_cast<const double2*>(ws.stage + ((long long)gg * C + c) * 2); },
+                  [&](int, const double2 t) {
+                    a += t.x;
+                    b += t.y;
+                  });
   sm[slice][cl][0] = a;
   sm[slice][cl][1] = b;
   __syncthreads();

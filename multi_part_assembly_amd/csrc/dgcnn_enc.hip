@@ -55,6 +55,7 @@ using namespace dg;
 using mpa::CoopWs;
 using mpa::coop_colsum;
 using mpa::kEB;
+using mpa::batched_rows;
 using mpa::kSlices;
 
 constexpr int kCat = 512;                     // 64 + 64 + 128 + 256
@@ -473,11 +474,11 @@ __global__ __launch_bounds__(kTileT) void dg_colstats_kernel(const float* __rest
   const int c = threadIdx.x % F, g = threadIdx.x / F, G = kTileT / F;
   float s = 0.0f, ss = 0.0f;
   const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
-  for (int i = g; i < rows; i += G) {
-    const float t = y[(r0 + i) * F + c];
-    s += t;
-    ss = __builtin_fmaf(t, t, ss);
-  }
+  batched_rows<8>(g, G, rows, [&](int i) { return y[(r0 + i) * F + c]; },
+                  [&](int, float t) {
+                    s += t;
+                    ss = __builtin_fmaf(t, t, ss);
+                  });
   tile_pair_out(s, ss, F, g, c, partial);
 }
 
@@ -495,15 +496,16 @@ __global__ __launch_bounds__(1024) void dg_pool_kernel(const float* __restrict__
   const float* yp = y + (long long)v * N * F;
   float best = -__builtin_inff(), sum = 0.0f;
   int at = 0;
-  for (int n = g; n < N; n += G) {
-    const float z = __builtin_fmaf(yp[(long long)n * F + c], scale, shift);
-    const float a = z > 0.0f ? z : kSlope * z;
-    sum += a;
-    if (a > best) {
-      best = a;
-      at = n;
-    }
-  }
+  batched_rows<8>(g, G, N, [&](int n) { return yp[(long long)n * F + c]; },
+                  [&](int n, float t) {
+                    const float z = __builtin_fmaf(t, scale, shift);
+                    const float a = z > 0.0f ? z : kSlope * z;
+                    sum += a;
+                    if (a > best) {
+                      best = a;
+                      at = n;
+                    }
+                  });
   smax[threadIdx.x] = best;
   ssum[threadIdx.x] = sum;
   sarg[threadIdx.x] = at;
@@ -594,6 +596,18 @@ __device__ __forceinline__ float dg_tail_dz(float y, float scale, float shift, f
   return (z > 0.0f ? 1.0f : kSlope) * (dmean_n + (is_arg ? dmax : 0.0f));
 }
 
+// what one (row, channel) of the tail's backward passes reads
+struct DgTailRow {
+  float y, dmax, dmean;
+  bool is_arg;
+};
+__device__ __forceinline__ DgTailRow dg_tail_load(const float* y, const float* __restrict__ dpooled,
+                                                  const int* __restrict__ arg, long long r, int N, int F, int c) {
+  const int v = (int)(r / N), p = (int)(r % N);
+  return DgTailRow{y[r * F + c], dpooled[(long long)v * 2 * F + c], dpooled[(long long)v * 2 * F + F + c],
+                   arg[(long long)v * F + c] == p};
+}
+
 // partial [tiles][F][2] = (sum dz, sum dz*xhat).  grid = ceil(Rmax / kTile), block = kTileT.
 __global__ __launch_bounds__(kTileT) void dg_tail_bwd_sums_kernel(const float* __restrict__ y, int F, int N,
                                                                   const float* __restrict__ bn,
@@ -607,15 +621,12 @@ __global__ __launch_bounds__(kTileT) void dg_tail_bwd_sums_kernel(const float* _
   const float scale = bn[c], shift = bn[F + c], mean = bn[2 * F + c], invstd = bn[3 * F + c];
   const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
   float s1 = 0.0f, s2 = 0.0f;
-  for (int i = g; i < rows; i += G) {
-    const long long r = r0 + i;
-    const int v = (int)(r / N), p = (int)(r % N);
-    const float t = y[r * F + c];
-    const float dz = dg_tail_dz(t, scale, shift, dpooled[(long long)v * 2 * F + c],
-                                dpooled[(long long)v * 2 * F + F + c] / (float)N, arg[(long long)v * F + c] == p);
-    s1 += dz;
-    s2 = __builtin_fmaf(dz, (t - mean) * invstd, s2);
-  }
+  batched_rows<4>(g, G, rows, [&](int i) { return dg_tail_load(y, dpooled, arg, r0 + i, N, F, c); },
+                  [&](int, const DgTailRow t) {
+                    const float dz = dg_tail_dz(t.y, scale, shift, t.dmax, t.dmean / (float)N, t.is_arg);
+                    s1 += dz;
+                    s2 = __builtin_fmaf(dz, (t.y - mean) * invstd, s2);
+                  });
   tile_pair_out(s1, s2, F, g, c, partial);
 }
 
@@ -633,14 +644,11 @@ __global__ __launch_bounds__(kTileT) void dg_tail_bwd_apply_kernel(float* __rest
   const float scale = bn[c], shift = bn[F + c];
   const float alpha = coef[c], gammap = coef[F + c], betap = coef[2 * F + c];
   const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
-  for (int i = g; i < rows; i += G) {
-    const long long r = r0 + i;
-    const int v = (int)(r / N), p = (int)(r % N);
-    const float t = y[r * F + c];
-    const float dz = dg_tail_dz(t, scale, shift, dpooled[(long long)v * 2 * F + c],
-                                dpooled[(long long)v * 2 * F + F + c] / (float)N, arg[(long long)v * F + c] == p);
-    y[r * F + c] = __builtin_fmaf(alpha, dz, __builtin_fmaf(gammap, t, betap));
-  }
+  batched_rows<4>(g, G, rows, [&](int i) { return dg_tail_load(y, dpooled, arg, r0 + i, N, F, c); },
+                  [&](int i, const DgTailRow t) {
+                    const float dz = dg_tail_dz(t.y, scale, shift, t.dmax, t.dmean / (float)N, t.is_arg);
+                    y[(r0 + i) * F + c] = __builtin_fmaf(alpha, dz, __builtin_fmaf(gammap, t.y, betap));
+                  });
 }
 
 // ---- edge aggregation, backward ----------------------------------------------------------------------------------------------
@@ -661,14 +669,17 @@ __global__ __launch_bounds__(512) void dg_agg_bwd_sums_kernel(const float* __res
   const float mean = bn[2 * CO + c], invstd = bn[3 * CO + c];
   const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
   float s1 = 0.0f, s2 = 0.0f;
-  for (int i = g; i < rows; i += G) {
-    const long long r = r0 + i, o = r * CO + c;
-    const float h = hcat[r * kCat + off + c];
-    const float d = dhcat[r * kCat + off + c] * (h > 0.0f ? 1.0f : kSlope);
-    dz[o] = d;
-    s1 += d;
-    s2 = __builtin_fmaf(d, (esel[o] - mean) * invstd, s2);
-  }
+  batched_rows<4>(g, G, rows,
+                  [&](int i) {
+                    const long long r = r0 + i;
+                    return make_float3(hcat[r * kCat + off + c], dhcat[r * kCat + off + c], esel[r * CO + c]);
+                  },
+                  [&](int i, const float3 t) {
+                    const float d = t.y * (t.x > 0.0f ? 1.0f : kSlope);
+                    dz[(r0 + i) * CO + c] = d;
+                    s1 += d;
+                    s2 = __builtin_fmaf(d, (t.z - mean) * invstd, s2);
+                  });
   red[g * CO + c][0] = s1;
   red[g * CO + c][1] = s2;
   __syncthreads();
@@ -824,14 +835,17 @@ __global__ __launch_bounds__(1024) void dg_bwd_head_kernel(const DgRevArgs ra, i
   const float mean = bn[2 * CO + c], invstd = bn[3 * CO + c];
   const int rows = R - r0 < kTile ? (int)(R - r0) : kTile;
   float s1 = 0.0f, s2 = 0.0f;
-  for (int i = g; i < rows; i += G) {
-    const long long r = r0 + i, o = r * CO + c;
-    const float h = hcat[r * kCat + off + c];
-    const float d = dhcat[r * kCat + off + c] * (h > 0.0f ? 1.0f : kSlope);
-    dz[o] = d;
-    s1 += d;
-    s2 = __builtin_fmaf(d, (esel[o] - mean) * invstd, s2);
-  }
+  batched_rows<4>(g, G, rows,
+                  [&](int i) {
+                    const long long r = r0 + i;
+                    return make_float3(hcat[r * kCat + off + c], dhcat[r * kCat + off + c], esel[r * CO + c]);
+                  },
+                  [&](int i, const float3 t) {
+                    const float d = t.y * (t.x > 0.0f ? 1.0f : kSlope);
+                    dz[(r0 + i) * CO + c] = d;
+                    s1 += d;
+                    s2 = __builtin_fmaf(d, (t.z - mean) * invstd, s2);
+                  });
   red[g * CO + c][0] = s1;
   red[g * CO + c][1] = s2;
   __syncthreads();
