@@ -217,212 +217,6 @@ __global__ __launch_bounds__(DG_T3) void knn3_kernel(const float* __restrict__ x
   }
 }
 
-// ---- C = 3, candidates in Morton order -------------------------------------------------------------------------------------
-// The scan above feeds every lane all N candidates in index order: a lane's threshold (its 20th best so far) tightens
-// slowly (~150-200 of 1000 candidates pass it), and since the 64 queries of a wave are unrelated points SOME lane accepts
-// nearly every candidate — the masked push sequence runs for all of them and the queues flush ~30 times.
-// Here the block first sorts the cloud along a Morton curve (7 bits per axis of the cloud's bounding box; a 1024-key
-// bitonic sort in LDS, ~10 us).  Lane = query in SORTED order, so a wave's 64 queries are neighbours in space, and every
-// wave walks the sorted candidates outwards from its own position (groups of 4, alternately above and below): the first
-// few groups hold most true neighbours, the thresholds are close to final after the first flush, and from then on most
-// groups fail the gate in ALL lanes — one ballot skips the push sequence.  Candidates now arrive in arbitrary index
-// order, so the list insertion compares (score, index) lexicographically (best_insert<true>) and the gate lets equal
-// scores through; the result is the same list as the scan's for every input: the k best under (score desc, index asc)
-// do not depend on the order the candidates are seen in.  Scores below every float (-inf) and NaN are never listed, as in
-// the scan: the gate starts at -FLT_MAX.
-#ifndef DG_KNN3_SORTED  // A/B knob (tools/build_variant.sh): 0 = the index-order scan above
-#define DG_KNN3_SORTED 0
-#endif
-#if DG_KNN3_SORTED
-#define DG_KNN3 knn3_sorted_kernel
-#else
-#define DG_KNN3 knn3_kernel
-#endif
-__device__ __forceinline__ unsigned morton_spread7(unsigned x) {  // bit i -> bit 3 i, 7 bits
-  x &= 127u;
-  x = (x | (x << 8)) & 0x0000700Fu;
-  x = (x | (x << 4)) & 0x000430C3u;
-  x = (x | (x << 2)) & 0x00049249u;
-  return x;
-}
-
-template <typename IdxT>
-__global__ __launch_bounds__(DG_T3) void knn3_sorted_kernel(const float* __restrict__ x4, int N, IdxT* __restrict__ idx,
-                                                            const int* __restrict__ hdr) {
-  static_assert(DG_T3 == 256 && kMaxN == 1024, "four keys per thread");
-  constexpr int QN = DG_QN3, CPC = 4, W = DG_T3 / 64;
-  __shared__ __attribute__((aligned(16))) float4 spts[kMaxN + CPC];  // sorted: x, y, z, |p|^2; NaN rows behind the cloud
-  __shared__ __attribute__((aligned(8))) unsigned short sidx[kMaxN + CPC];  // sorted position -> point
-  __shared__ float qs_[W][QN * 64];                                  // (the sort's keys live here first)
-  __shared__ unsigned short qj_[W][QN * 64];
-  __shared__ float box[W][6];
-  static_assert(sizeof(qs_) >= kMaxN * sizeof(unsigned), "keys alias the score queues");
-  unsigned* keys = reinterpret_cast<unsigned*>(&qs_[0][0]);
-  int v, qb;
-  knn_block(v, qb);
-  if (v >= hdr[0]) return;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const float4* xp = reinterpret_cast<const float4*>(x4) + (long long)v * N;
-  // bounding box of the cloud (NaN coordinates are ignored by fmin / fmax)
-  float4 mine[4];
-  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int p = threadIdx.x + DG_T3 * u;
-    mine[u] = xp[p < N ? p : N - 1];
-    lo[0] = __builtin_fminf(lo[0], mine[u].x), hi[0] = __builtin_fmaxf(hi[0], mine[u].x);
-    lo[1] = __builtin_fminf(lo[1], mine[u].y), hi[1] = __builtin_fmaxf(hi[1], mine[u].y);
-    lo[2] = __builtin_fminf(lo[2], mine[u].z), hi[2] = __builtin_fmaxf(hi[2], mine[u].z);
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], off, 64));
-      hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
-    }
-  if (lane == 0) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) box[wave][a] = lo[a], box[wave][3 + a] = hi[a];
-  }
-  __syncthreads();
-  float sc[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float l = box[0][a], h = box[0][3 + a];
-#pragma unroll
-    for (int w = 1; w < W; ++w) l = __builtin_fminf(l, box[w][a]), h = __builtin_fmaxf(h, box[w][3 + a]);
-    lo[a] = l;
-    const float ext = h - l;
-    sc[a] = (ext > 0.0f && ext < __builtin_inff()) ? 127.0f / ext : 0.0f;  // a degenerate or unbounded axis sorts nothing
-  }
-  // keys: Morton code << 10 | point (unique, so the sorted order is the same in every block of the cloud); pads last
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int p = threadIdx.x + DG_T3 * u;
-    const unsigned cx = (unsigned)(int)__builtin_amdgcn_fmed3f((mine[u].x - lo[0]) * sc[0], 0.0f, 127.0f);
-    const unsigned cy = (unsigned)(int)__builtin_amdgcn_fmed3f((mine[u].y - lo[1]) * sc[1], 0.0f, 127.0f);
-    const unsigned cz = (unsigned)(int)__builtin_amdgcn_fmed3f((mine[u].z - lo[2]) * sc[2], 0.0f, 127.0f);
-    const unsigned m = morton_spread7(cx) | (morton_spread7(cy) << 1) | (morton_spread7(cz) << 2);
-    keys[p] = p < N ? (m << 10) | (unsigned)p : 0xFFFFFFFFu;
-  }
-  __syncthreads();
-  // bitonic sort of the 1024 keys, ascending: 512 compare-exchanges per stage, two per thread
-  for (int k = 2; k <= kMaxN; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int t = threadIdx.x + DG_T3 * u;
-        const int l = ((t & ~(j - 1)) << 1) | (t & (j - 1)), r = l | j;
-        const unsigned a = keys[l], b = keys[r];
-        const bool up = (l & k) == 0;
-        if ((a > b) == up) {
-          keys[l] = b;
-          keys[r] = a;
-        }
-      }
-      __syncthreads();
-    }
-  unsigned mykey[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) mykey[u] = keys[threadIdx.x + DG_T3 * u];
-  __syncthreads();  // the keys' storage becomes the score queues
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int r = threadIdx.x + DG_T3 * u;
-    if (r < N) {
-      const int p = (int)(mykey[u] & 1023u);
-      float4 t = xp[p];
-      t.w = (t.x * t.x + t.y * t.y) + t.z * t.z;
-      spts[r] = t;
-      sidx[r] = (unsigned short)p;
-    } else {
-      const float nan = __builtin_nanf("");
-      spts[r] = make_float4(nan, nan, nan, nan);
-      sidx[r] = 0;
-    }
-  }
-  if (threadIdx.x < CPC) {
-    const float nan = __builtin_nanf("");
-    spts[kMaxN + threadIdx.x] = make_float4(nan, nan, nan, nan);
-    sidx[kMaxN + threadIdx.x] = 0;
-  }
-  __syncthreads();
-#ifdef DG_KNN3_ABL  // timing-only builds (tools/build_variant.sh): 1 = no pushes, 2 = index-blind insertion, 3 = sort only
-  if (DG_KNN3_ABL == 3 && hdr[0] != -12345) return;
-#endif
-  const int qi = qb * DG_T3 + threadIdx.x, qc = qi < N ? qi : N - 1;
-  const float4 me = spts[qc];
-  Best b;
-  best_init(b);
-  const float kLowest = -3.402823466e38f;
-  float* qsw = qs_[wave];
-  unsigned short* qjw = qj_[wave];
-  int cnt = 0;
-  float thr = kLowest;
-  auto flush = [&]() {
-    int n = cnt;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const int o = __shfl_xor(n, off, 64);
-      n = o > n ? o : n;
-    }
-    n = __builtin_amdgcn_readfirstlane(n);
-    for (int e = 0; e < n; ++e) {
-      const float raw = qsw[e * 64 + lane];
-      const int cj = qjw[e * 64 + lane];
-      const float cs = e < cnt ? raw : -__builtin_inff();  // (-inf, any index) never goes in front of a slot: all are >= (-inf, 0)
-#if defined(DG_KNN3_ABL) && DG_KNN3_ABL == 2
-      best_insert<false>(b, cs, cj);
-#else
-      best_insert<true>(b, cs, e < cnt ? cj : 0x7fffffff);
-#endif
-    }
-    cnt = 0;
-    thr = b.s[kNbr - 1] > kLowest ? b.s[kNbr - 1] : kLowest;
-  };
-  auto group = [&](int g0) {  // sorted positions g0 .. g0 + 3 (wave-uniform; rows behind the cloud score NaN)
-    float sv[CPC];
-    bool any = false;
-    const ushort4 oj = *reinterpret_cast<const ushort4*>(sidx + g0);
-#pragma unroll
-    for (int u = 0; u < CPC; ++u) {
-      const float4 t = spts[g0 + u];
-      const float dot = __builtin_fmaf(me.z, t.z, __builtin_fmaf(me.y, t.y, me.x * t.x));
-      sv[u] = (-t.w + 2.0f * dot) - me.w;
-      any = any || sv[u] >= thr;
-    }
-#if defined(DG_KNN3_ABL) && DG_KNN3_ABL == 1
-    any = any && hdr[0] == -12345;
-#endif
-    if (__any(any)) {
-      const unsigned short ojv[CPC] = {oj.x, oj.y, oj.z, oj.w};
-#pragma unroll
-      for (int u = 0; u < CPC; ++u) {
-        if (sv[u] >= thr) {
-          qsw[cnt * 64 + lane] = sv[u];
-          qjw[cnt * 64 + lane] = ojv[u];
-          ++cnt;
-        }
-      }
-      if (__any(cnt > QN - CPC)) flush();
-    }
-  };
-  const int base = qb * DG_T3 + wave * 64;  // this wave's first sorted position (a multiple of 4)
-  for (int t = 0;; ++t) {
-    const int up = base + CPC * t, down = base - CPC * (t + 1);
-    if (up >= N && down < 0) break;
-    if (up < N) group(up);
-    if (down >= 0) group(down);
-  }
-  flush();
-  if (qi < N) {
-    IdxT* out = idx + ((long long)v * N + sidx[qi]) * kNbr;
-#pragma unroll
-    for (int t = 0; t < kNbr; ++t) out[t] = (IdxT)b.j[t];
-  }
-}
-
 // ---- row norms in the matrix-core chain order -----------------------------------------------------------------------------
 // x [R][C] (ld), norm [R].  One thread per row (the chain is sequential by definition); rows are staged through LDS in
 // 16 + 16 column slabs so that the global reads stay coalesced.  grid = ceil(Rmax / 256), block 256.

@@ -1326,7 +1326,7 @@ int dgcnn_forward_impl(const float* points, const float* valids, const float* co
       launch(dg_import_graph_kernel, dim3((unsigned)((R * kNbr + 255) / 256)), dim3(256), s, graphs[l], w.idx[l],
              (const int*)w.hdr);
     } else if (l == 0) {
-      launch(DG_KNN3<unsigned short>, dim3((unsigned)((N + DG_T3 - 1) / DG_T3), DG_KNN_GRID_Y(M)), dim3(DG_T3), s,
+      launch(knn3_kernel<unsigned short>, dim3((unsigned)((N + DG_T3 - 1) / DG_T3), DG_KNN_GRID_Y(M)), dim3(DG_T3), s,
              reinterpret_cast<const float*>(w.x0), (int)N, w.idx[0], (const int*)w.hdr);
     } else {
       const float* x = w.hcat + kOff[l - 1];
@@ -1537,7 +1537,7 @@ extern "C" int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, i
   const KnnExactWs w = knn_exact_carve(static_cast<char*>(ws), n, N);  // hdr = {n, n*N}: every cloud is valid here
   launch(dg_set_hdr_kernel, dim3(1), dim3(1), s, w.hdr, (int)n, (int)N);
   if (C == 3) {
-    launch(DG_KNN3<int>, dim3((unsigned)((N + DG_T3 - 1) / DG_T3), DG_KNN_GRID_Y(n)), dim3(DG_T3), s, x, (int)N, idx,
+    launch(knn3_kernel<int>, dim3((unsigned)((N + DG_T3 - 1) / DG_T3), DG_KNN_GRID_Y(n)), dim3(DG_T3), s, x, (int)N, idx,
            (const int*)w.hdr);
   } else if (C == 64) {
     knn_wide<64, int>(x, (int)ld, w.norm, w.knn, n, N, idx, (const int*)w.hdr, s);
