@@ -13,6 +13,7 @@
 #include "coop_reduce.h"
 #include "dg_gemm.h"
 #include "dg_gemm_split.h"
+#include "tf_gemm.h"
 #ifndef DG_GEMM_SPLIT  // 1: fp32-grade GEMMs on the bf16 matrix cores (dg_gemm_split.h); 0: v_mfma_f32_32x32x2_f32 (dg_gemm.h)
 #define DG_GEMM_SPLIT 1
 #endif
@@ -35,6 +36,14 @@ using mpa::kEB;
 using mpa::kSlices;
 
 constexpr int kRT = 16;          // rows per block of the row-tiled kernels
+// Layers of at most this many rows (the node MLPs: B*P = 640) take the GEMMs of tf_gemm.h — one 32 x 32 tile per block,
+// the block's 8 waves split K, exact-fp32 matrix-core products: ~11 us a call where the 128-row tiles of
+// dg_gemm_split.h leave 5 row tiles to walk K = 512 in 16 dependent steps (22-34 us).  Above it the fp32 matrix-core
+// rate (157 TFLOP/s) loses to the split-bf16 kernels.
+#ifndef MPA_ML_SMALL_ROWS
+#define MPA_ML_SMALL_ROWS 2048
+#endif
+constexpr int kSmallRows = MPA_ML_SMALL_ROWS;
 constexpr int kChunks = 64;      // most row chunks of the weight-gradient GEMM (fewer for few rows: >= 256 rows each)
 
 __global__ void ml_set_hdr_kernel(int* hdr, int R, unsigned* tickets) {
@@ -338,6 +347,39 @@ extern "C" int mpa_mlp_layer_forward(const float* x, int64_t ldx, const float* w
   const int tiles = (int)((R + kRT - 1) / kRT);
   const long long total4 = R * N / 4;
   const CoopWs cw{m.stage, m.tickets};
+  if (R <= kSmallRows) {
+    tfg::GemmArgs g{};
+    g.A = x;
+    g.lda = (int)ldx;
+    g.W = w;
+    g.bias = bias;
+    g.M = (int)R;
+    g.N = (int)N;
+    g.K = (int)K;
+    g.zero = m.tickets;
+    if (gamma == nullptr) {
+      g.C = out;
+      g.relu = relu;
+      tfg::launch_gemm<tfg::EPI_BIAS_ACT>(g, s);
+      return mpa::check_launch("mlp_layer_forward");
+    }
+    g.C = m.ypre;
+    if (training) {
+      const int tiles32 = (int)((R + 31) / 32);
+      g.stats = m.partial;
+      tfg::launch_gemm<tfg::EPI_STATS>(g, s);
+      launch(ml_bn_finalize_kernel, dim3((unsigned)(N / 64), (unsigned)((tiles32 + kEB - 1) / kEB)), dim3(64 * kSlices), s,
+             (const float*)m.partial, tiles32, (int)N, (double)R, gamma, beta, running_mean, running_var, momentum, eps,
+             m.bn, cw);
+    } else {
+      tfg::launch_gemm<tfg::EPI_BIAS_ACT>(g, s);  // (g.relu = 0: bias only)
+      launch(ml_bn_from_running_kernel, dim3((unsigned)(N / 64)), dim3(64), s, (int)N, gamma, beta,
+             (const float*)running_mean, (const float*)running_var, eps, m.bn);
+    }
+    launch(ml_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), s, (const float*)m.ypre,
+           (const float*)m.bn, (const float*)nullptr, total4, (int)N, relu, out);
+    return mpa::check_launch("mlp_layer_forward");
+  }
 #if DG_GEMM_SPLIT
   // bias, BatchNorm statistics / activation in the GEMM's output pass: 3 launches with BatchNorm, 1 without
   GsEpi epi;
@@ -438,7 +480,16 @@ extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int
       dg::launch_tn_reduce(m.tnpart, chunks, elems, grad_w, s);
     }
   }
-  if (grad_x != nullptr) {  // dX [R][K] = dY [R][N] . W [N][K]
+  if (grad_x != nullptr && R <= kSmallRows) {  // dX = dY . W with W [N][K] read as the transposed operand [k = N][n = K]
+    tfg::GemmArgs g{};
+    g.A = m.dy;
+    g.W = w;
+    g.C = grad_x;
+    g.M = (int)R;
+    g.N = (int)K;
+    g.K = (int)N;
+    tfg::launch_gemm<tfg::EPI_NONE, true>(g, s);
+  } else if (grad_x != nullptr) {  // dX [R][K] = dY [R][N] . W [N][K]
 #if DG_GEMM_SPLIT
     ml_gemm<0, true>(m.dy, (int)N, w, (int)N, grad_x, (int)K, (int)K, R, GsEpi{}, (int)K, s);
 #else
