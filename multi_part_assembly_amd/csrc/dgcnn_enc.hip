@@ -160,13 +160,17 @@ __global__ __launch_bounds__(512) void dg_first_wgrad_kernel(const float* __rest
   const int g = threadIdx.x >> 7, o = threadIdx.x & 127;
   const long long r0 = (long long)blockIdx.x * kFirstTile + g * (kFirstTile / 4);
   float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-  for (int i = 0; i < kFirstTile / 4 && r0 + i < R; ++i) {
-    const float4 x = x0[r0 + i];
-    const float gv = duv[(r0 + i) * 128 + o];
-    a0 = __builtin_fmaf(gv, x.x, a0);
-    a1 = __builtin_fmaf(gv, x.y, a1);
-    a2 = __builtin_fmaf(gv, x.z, a2);
-  }
+  const int rows = R - r0 < kFirstTile / 4 ? (int)(R - r0) : kFirstTile / 4;  // (<= 0: nothing)
+  struct Row {
+    float g;
+    float4 x;
+  };
+  batched_rows<8>(0, 1, rows, [&](int i) { return Row{duv[(r0 + i) * 128 + o], x0[r0 + i]}; },
+                  [&](int, const Row t) {
+                    a0 = __builtin_fmaf(t.g, t.x.x, a0);
+                    a1 = __builtin_fmaf(t.g, t.x.y, a1);
+                    a2 = __builtin_fmaf(t.g, t.x.z, a2);
+                  });
   red[g][o] = make_float4(a0, a1, a2, 0.0f);
   __syncthreads();
   if (g == 0) {
@@ -572,11 +576,12 @@ __global__ __launch_bounds__(1024) void dg_fc_bwd_w_kernel(const float* __restri
   __shared__ float red[1024], redb[8];
   const int f = blockIdx.x, W = 2 * F, G = 1024 / W, g = threadIdx.x / W, k = threadIdx.x % W, nv = hdr[0];
   float acc = 0.0f, sb = 0.0f;
-  for (int v = g; v < nv; v += G) {
-    const float gv = gfeat[(long long)vlist[v] * F + f];
-    acc = __builtin_fmaf(gv, pooled[(long long)v * W + k], acc);
-    sb += gv;
-  }
+  batched_rows<4>(g, G, nv,
+                  [&](int v) { return make_float2(gfeat[(long long)vlist[v] * F + f], pooled[(long long)v * W + k]); },
+                  [&](int, const float2 t) {
+                    acc = __builtin_fmaf(t.x, t.y, acc);
+                    sb += t.x;
+                  });
   red[threadIdx.x] = acc;
   if (k == 0) redb[g] = sb;
   __syncthreads();
