@@ -435,28 +435,32 @@ __global__ __launch_bounds__(kThreads) void assembly_backward_kernel(
   }
   // C. this part's points as matched TARGETS of any valid GT point of the sample (shape-CD dir 2).
   //    Also runs for padded parts: their representative could, in principle, be somebody's nearest.
-  for (int pp = 0; pp < P; ++pp) {
-    if (vb[pp] == 0.0f) continue;
-    const long long qoff = ((long long)b * P + pp) * N;
-    constexpr int U = 4;  // index loads of U strides in flight (the scan is a chain of L2 latencies otherwise)
-    for (int k0 = n_lo + threadIdx.x; k0 < n_hi; k0 += U * kThreads) {
-      int jj[U];
+  //    The scan is a chain of L2 latencies (one index per thread and GT part, a match is rare): the indices of UP parts
+  //    are requested together.
+  constexpr int UP = 4;
+  for (int pp0 = 0; pp0 < P; pp0 += UP) {
+    for (int k = n_lo + threadIdx.x; k < n_hi; k += kThreads) {
+      int jj[UP];
 #pragma unroll
-      for (int u = 0; u < U; ++u) jj[u] = k0 + u * kThreads < n_hi ? is2[qoff + k0 + u * kThreads] : -1;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-      const int k = k0 + u * kThreads, j = jj[u];
-      if (j < p * N || j >= (p + 1) * N) continue;  // not a point of this part (a range test, not an integer division)
-      const long long o = 3LL * (qoff + k), jt = sbase + 3LL * j;
-      const float gx = -c_s * (S2[o] - S1[jt]), gy = -c_s * (S2[o + 1] - S1[jt + 1]),
-                  gz = -c_s * (S2[o + 2] - S1[jt + 2]);
-      float px = kPadFill, py = kPadFill, pz = kPadFill;
-      if (valid) {
-        px = pcs[jt];
-        py = pcs[jt + 1];
-        pz = pcs[jt + 2];
+      for (int u = 0; u < UP; ++u) {
+        const int pp = pp0 + u < P ? pp0 + u : P - 1;
+        jj[u] = is2[((long long)b * P + pp) * N + k];
       }
-      accumulate(acc, w, ux, uy, uz, px, py, pz, gx, gy, gz, true);
+#pragma unroll
+      for (int u = 0; u < UP; ++u) {
+        const int pp = pp0 + u, j = jj[u];
+        if (pp >= P || vb[pp] == 0.0f) continue;
+        if (j < p * N || j >= (p + 1) * N) continue;  // not a point of this part (a range test, not an integer division)
+        const long long o = 3LL * (((long long)b * P + pp) * N + k), jt = sbase + 3LL * j;
+        const float gx = -c_s * (S2[o] - S1[jt]), gy = -c_s * (S2[o + 1] - S1[jt + 1]),
+                    gz = -c_s * (S2[o + 2] - S1[jt + 2]);
+        float px = kPadFill, py = kPadFill, pz = kPadFill;
+        if (valid) {
+          px = pcs[jt];
+          py = pcs[jt + 1];
+          pz = pcs[jt + 2];
+        }
+        accumulate(acc, w, ux, uy, uz, px, py, pz, gx, gy, gz, true);
       }
     }
   }
