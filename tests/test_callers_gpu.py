@@ -121,11 +121,13 @@ def test_caller_step_matches_reference(golden, cuda_device, capsys, name):
             param_fill.compare(record, "sd1.", k, v.cpu().numpy(), rel=1e-4)
 
 
-@pytest.mark.parametrize("final_relu,rows,L,cin,feat", [(True, 7, 5, 128, 64), (False, 640, 1, 512, 128), (True, 40, 20, 256, 128)])
+@pytest.mark.parametrize("final_relu,rows,L,cin,feat", [(True, 7, 5, 128, 64), (False, 640, 1, 512, 128), (True, 40, 20, 256, 128),
+                                                          (True, 131, 20, 256, 128), (False, 2049, 1, 128, 64)])
 def test_pair_mlp_hip_layers_match_library_ops(cuda_device, final_relu, rows, L, cin, feat):
     """The Conv1d(k=1) + BatchNorm1d + ReLU layers of MLP3 / MLP4 / MLP5 on csrc/mlp.hip against the same module on
     torch's library ops (reference models/dgl/modules.py:5-58, rgl_net/modules.py:5-30): outputs, every gradient,
-    running statistics; and evaluation mode."""
+    running statistics; and evaluation mode.  Row counts on both sides of csrc/mlp.hip's switch between the
+    one-tile-per-block GEMM (<= 2048 rows) and the 128-row-tile split-bf16 GEMM (2620 and 2049 rows here)."""
     import copy
     from multi_part_assembly_amd.gnn import _PairMLP
     torch.manual_seed(rows)
