@@ -193,12 +193,12 @@ class BaseModel(nn.Module):
                 w = [float(self.cfg.loss[f"{k}_w"]) if k.endswith("_loss") else 0.0 for k in keys]
                 cache = (keys, torch.tensor(w, dtype=terms.dtype, device=terms.device))
                 self._loss_weight_cache = cache
-            total = (terms * cache[1][:, None]).sum(dim=0)                                   # [B]
-            means = torch.cat([terms, total[None]], dim=0).mean(dim=1)                       # [K + 1]
+            # mean over the batch of sum_k w_k t_kb = sum_k w_k mean_b t_kb: two launches (mean, dot) and two in backward
+            means = terms.mean(dim=1)                                                        # [K]
             result = {k: means[i] for i, k in enumerate(keys)}
-            result["loss"] = means[len(keys)]
+            result["loss"] = torch.dot(means, cache[1])
             if not self.training:
-                result["batch_size"] = total.shape[0]
+                result["batch_size"] = terms.shape[1]
             return result
         samples, out_dict = None, {}
         for _ in range(self.sample_iter):

@@ -105,11 +105,15 @@ class TransformerEncoder(nn.Module):
                 k += 1
                 m._instance = k
 
-    def advance_seed(self):
-        """New dropout seed for the next forward (a counter hashed with torch's seed), written to device memory."""
+    def _next_seed(self):
         self._calls += 1
-        seed = (torch.initial_seed() * 0x9E3779B1 + self._calls * 0x85EBCA77
+        return (torch.initial_seed() * 0x9E3779B1 + self._calls * 0x85EBCA77
                 + self._instance * 0xC2B2AE3D27D4EB4F) & 0x7FFFFFFFFFFFFFFF
+
+    def advance_seed(self):
+        """New dropout seed for the next replay of a captured step (a counter hashed with torch's seed), written to
+        device memory."""
+        seed = self._next_seed()
         if self._seed_dev is not None:
             self._seed_dev.fill_(seed)
 
@@ -151,19 +155,23 @@ class TransformerEncoder(nn.Module):
         valid = (torch.ones(B * P, device=tokens.device) if valid_masks is None
                  else valid_masks.reshape(-1).float())
         p = self._dropout_p()
-        seed_dev = None
-        if p > 0.0:  # the seed lives in device memory so that a captured step draws fresh masks on every replay
-            if self._seed_dev is None or self._seed_dev.device != tokens.device:
+        seed, seed_dev = 0, None
+        if p > 0.0 and not torch.cuda.is_current_stream_capturing():
+            # eager call: the seed travels BY VALUE with the launches (the backward regenerates the masks from the value
+            # its own forward saved, so a second forward before that backward cannot disturb it) — no device write
+            seed = self._next_seed()
+            self._salt = 0
+            if self._seed_dev is None or self._seed_dev.device != tokens.device:  # (once: ready for a later capture)
                 self._seed_dev = torch.zeros(1, dtype=torch.int64, device=tokens.device)
-            capturing = torch.cuda.is_current_stream_capturing()
-            if not capturing:
-                self.advance_seed()  # (during capture / replays the Trainer calls advance_seed() between replays)
-                self._salt = 0
-            # per-call snapshot: a second forward of this module before the first one's backward (gradient
-            # accumulation, a caller that reuses the module) must not change the masks the first backward regenerates.
-            # Inside a captured step the k-th call of the module reads seed + k * odd constant at replay time.
+        elif p > 0.0:
+            # capture: the seed lives in device memory so that the captured step draws fresh masks on every replay (the
+            # Trainer calls advance_seed() between replays); the k-th call of the module inside one step reads
+            # seed + k * odd constant at replay time
+            if self._seed_dev is None or self._seed_dev.device != tokens.device:
+                raise RuntimeError("TransformerEncoder: run one eager training forward on this device before capturing "
+                                   "a step (the dropout seed's device word is allocated there, outside the graph)")
             seed_dev = self._seed_dev + (getattr(self, "_salt", 0) * 0x632BE59BD9B4E019 & 0x3FFFFFFFFFFFFFFF)
-            self._salt = getattr(self, "_salt", 0) + 1 if capturing else 0
-        out = _TransformerFn.apply(tokens.float().contiguous(), valid.contiguous(), self.num_heads, p, 0, seed_dev,
+            self._salt = getattr(self, "_salt", 0) + 1
+        out = _TransformerFn.apply(tokens.float().contiguous(), valid.contiguous(), self.num_heads, p, seed, seed_dev,
                                    *self._params())
         return self.out_fc(out)
