@@ -275,6 +275,7 @@ class _DGCNNFn(torch.autograd.Function):
         ctx.training = bool(training)
         ctx.want_point_grad = bool(want_point_grad)
         ctx.params = params
+        GradSink.note_use(params)
         ctx.save_for_backward(pts, ws)
         return feat
 
@@ -301,7 +302,9 @@ class _DGCNNFn(torch.autograd.Function):
         M, N, _ = pts.shape
         F_ = fc_w.shape[0]
         dev = pts.device
-        grads = [torch.empty_like(p) for p in params]
+        # with a GradSink the kernels write the parameter gradients straight into the flat gradient buffer (every output
+        # is overwritten in full) instead of 17 AccumulateGrad `add_` launches
+        grads, direct = GradSink.outputs(params)
         gpts = torch.empty_like(pts) if ctx.want_point_grad else None
         grad_feat = grad_feat.contiguous()
         with torch.cuda.device(dev):
@@ -312,6 +315,9 @@ class _DGCNNFn(torch.autograd.Function):
                 _lib.ptr(grads[15]), _lib.ptr(grads[16]), _lib.ptr(gpts), _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_dgcnn_backward")
+        if direct:
+            GradSink.delivered(params)
+            return (gpts,) + (None,) * (7 + len(params))
         return (gpts, None, None, None, None, None, None, None, *grads)
 
 

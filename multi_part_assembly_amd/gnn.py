@@ -31,7 +31,7 @@ from .gnn_ops import (NARROW_MAX_IN, RELATION_MEAN_MAX_PARTS, narrow_linear_relu
                       relation_head, relation_head_supported, relation_mean)
 from .gru import gru_recurrent, supported as gru_supported
 from .loss import LossTerms
-from .mlp import mlp_layer, supported as mlp_supported
+from .mlp import bn_counter_batch, mlp_layer, supported as mlp_supported
 from .regressor import StocasticPoseRegressor
 
 
@@ -222,6 +222,10 @@ class DGLModel(BaseModel):
         return self.node_mlps[iter_ind](torch.cat([messages, part_feats], dim=-1))
 
     def forward(self, data_dict):
+        with bn_counter_batch():  # (the BatchNorm step counters of all MLP layers in one launch)
+            return self._forward(data_dict)
+
+    def _forward(self, data_dict):
         part_feats = data_dict.get("part_feats", None)
         if part_feats is None:
             part_feats = self._extract_part_feats(data_dict["part_pcs"], data_dict["part_valids"])

@@ -32,7 +32,8 @@ class Log(TorchDispatchMode):
         flat, _ = tree_flatten((args, kwargs, out))
         if not any(isinstance(t, torch.Tensor) and t.is_cuda for t in flat):
             return out
-        frame = "(no repo frame: autograd)"
+        shapes = [tuple(t.shape) for t in tree_flatten((args, kwargs))[0] if isinstance(t, torch.Tensor)]
+        frame = f"(no repo frame: autograd) {shapes[:2]}"
         for f in reversed(traceback.extract_stack()):
             if f.filename.startswith(HERE) and "/tools/" not in f.filename:
                 frame = f"{f.filename[len(HERE) + 1:]}:{f.lineno} {f.line[:70]}"
