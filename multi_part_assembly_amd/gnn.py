@@ -316,14 +316,22 @@ class _MaskedBiGRU(nn.Module):
         self.rnn = rnn
         self.batch_first = batch_first
 
-    def forward(self, x, hidden=None, valids=None):
+    @staticmethod
+    def plan(valids, T):
+        """(rev_idx [B, T] int64, mask [B, T, 1] float) of a validity matrix: what every GRU call on the same batch
+        needs — the caller may build it once per step and hand it to each call (`plan=`)."""
+        B = valids.shape[0]
+        lengths = valids.sum(dim=1).long()                                    # [B], stays on the device
+        steps = torch.arange(T, device=valids.device)[None].expand(B, T)
+        inside = steps < lengths[:, None]
+        return torch.where(inside, lengths[:, None] - 1 - steps, steps), inside[..., None].to(torch.float32)
+
+    def forward(self, x, hidden=None, valids=None, plan=None):
         if valids is None:
             return self.rnn(x, hidden)
         B, T, _ = x.shape
         H = self.rnn.hidden_size
-        lengths = valids.sum(dim=1).long()                                    # [B], stays on the device
-        steps = torch.arange(T, device=x.device)[None].expand(B, T)
-        rev_idx = torch.where(steps < lengths[:, None], lengths[:, None] - 1 - steps, steps)
+        rev_idx, mask = plan if plan is not None else self.plan(valids, T)
         x_rev = torch.gather(x, 1, rev_idx[..., None].expand_as(x))
         w = self.rnn
         if x.is_cuda and gru_supported(H, B):
@@ -341,7 +349,7 @@ class _MaskedBiGRU(nn.Module):
                                 [w.weight_ih_l0_reverse, w.weight_hh_l0_reverse, w.bias_ih_l0_reverse,
                                  w.bias_hh_l0_reverse], True, 1, 0.0, self.training, False, True)[0]
         bwd = torch.gather(bwd, 1, rev_idx[..., None].expand(B, T, H))       # back to part order
-        out = torch.cat([fwd, bwd], dim=-1) * (steps < lengths[:, None])[..., None].to(x.dtype)
+        out = torch.cat([fwd, bwd], dim=-1) * mask.to(x.dtype)
         return out, None
 
 
@@ -375,6 +383,10 @@ class RGLNet(DGLModel):
 
     def _node_update(self, part_feats, messages, data_dict, iter_ind):
         hidden = self._init_gru_hidden(part_feats.shape[0], messages.device).type_as(messages)
-        gru_out, _ = self.grus[iter_ind](torch.cat([part_feats, messages], dim=-1), hidden,
-                                         valids=data_dict["part_valids"])
+        valids = data_dict["part_valids"]
+        plan = data_dict.get("_gru_plan")  # the step's dict: one index plan for the three GRU calls of a step
+        if plan is None or plan[0] is not valids:
+            plan = (valids, _MaskedBiGRU.plan(valids, part_feats.shape[1]))
+            data_dict["_gru_plan"] = plan
+        gru_out, _ = self.grus[iter_ind](torch.cat([part_feats, messages], dim=-1), hidden, valids=valids, plan=plan[1])
         return self.node_mlps[iter_ind](gru_out)
