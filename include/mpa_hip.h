@@ -372,8 +372,8 @@ int mpa_gru_backward(const float* grad_out, const float* h0, const float* whh, c
  *   TransformerEncoder.forward : multi_part_assembly/models/pn_transformer/transformer.py:63-79
  *   (nn.TransformerEncoder of pre-LN nn.TransformerEncoderLayer, ReLU FFN, batch_first,
  *    src_key_padding_mask = ~valid, final LayerNorm; transformer.py:20-39)
- * tokens [B,P,D] (P <= 64 parts), valid [B*P] (1/0: padded parts are masked as KEYS; their own rows are
- * still computed, as upstream).  D and FF multiples of 64, head dim D/H <= 64, L <= 16 layers.
+ * tokens [B,P,D] (P <= 64 parts), valid [B*P] (a part is real iff its entry == 1, the reference's
+ * `part_valids == 1`; every other part is masked as a KEY; its own row is still computed, as upstream).  D and FF multiples of 64, head dim D/H <= 64, L <= 16 layers.
  * params: HOST array of 12*L + 2 DEVICE pointers, per layer in nn.TransformerEncoderLayer's
  * named_parameters() order — self_attn.in_proj_weight [3D,D], in_proj_bias [3D], out_proj.weight [D,D],
  * out_proj.bias [D], linear1.weight [FF,D], linear1.bias [FF], linear2.weight [D,FF], linear2.bias [D],

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kAT) void attn_fwd_kernel(const float* __restrict__
     const int i = e / P, jx = e % P;
     float a = 0.0f;
     for (int d = 0; d < dh; ++d) a = __builtin_fmaf(q[i][d], k[jx][d], a);
-    s[i][jx] = valid[b * P + jx] != 0.0f ? a : -__builtin_inff();
+    s[i][jx] = valid[b * P + jx] == 1.0f ? a : -__builtin_inff();  // a real part iff == 1 (network.py: part_valids == 1)
   }
   __syncthreads();
   if (t < P) {  // softmax of row t
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const float* __restri
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int j = acc_row(r, h);
-    kv[r] = j < P ? valid[b * P + j] : 0.0f;
+    kv[r] = (j < P && valid[b * P + j] == 1.0f) ? 1.0f : 0.0f;  // a real part iff == 1 (network.py: part_valids == 1)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       vb[nt][r] = j < P ? qkv[(long long)(b * P + j) * 3 * D + 2 * D + hd * DH + 32 * nt + c] : 0.0f;

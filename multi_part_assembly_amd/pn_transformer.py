@@ -51,7 +51,7 @@ class PNTransformer(BaseModel):
         if feats is None:
             part_valids = data_dict["part_valids"]
             pc_feats = self._extract_part_feats(data_dict["part_pcs"], part_valids)
-            corr = self.corr_module(pc_feats, part_valids == 1)
+            corr = self.corr_module(pc_feats, part_valids)  # (real iff == 1: applied inside the attention kernels)
             feats = torch.cat([corr, data_dict["part_label"].type_as(corr),
                                data_dict["instance_label"].type_as(corr)], dim=-1)
         rot, trans = self.pose_predictor(feats)
@@ -128,7 +128,7 @@ class PNTransformerRefine(PNTransformer):
         inst_label = data_dict["instance_label"].type_as(pc_feats)
         B, P = inst_label.shape[:2]
         pose = self.zero_pose.to(pc_feats).expand(B, P, -1)
-        valid_mask = part_valids == 1
+        valid_mask = part_valids  # (real iff == 1: applied inside the attention kernels)
         tokens, rots, transs = pc_feats, [], []
         for i in range(self.refine_steps):
             tokens = self.corr_module[i](tokens + self.corr_pos_enc(pose), valid_mask)

@@ -176,7 +176,10 @@ class Trainer:
         self.optimizer.zero_grad()
         with self.sink:  # HIP backward kernels write straight into the flat gradient buffer
             loss = self.model.training_step(data_dict, batch_idx)
-            loss.backward()
+            one = getattr(self, "_one", None)  # d loss / d loss, kept: autograd would fill a fresh ones_like every step
+            if one is None or one.device != loss.device or one.dtype != loss.dtype:
+                one = self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+            loss.backward(one)
         self.optimizer.grad_scale = self.reducer.finish()
         self.optimizer.step()
         return loss.detach()

@@ -137,7 +137,9 @@ class TransformerEncoder(nn.Module):
         return ps + [enc.norm.weight, enc.norm.bias]
 
     def forward(self, tokens, valid_masks):
-        """tokens [B, N, C]; valid_masks [B, N] bool (True = real part) or None -> [B, N, C]."""
+        """tokens [B, N, C]; valid_masks [B, N] bool (True = real part), or the float validity matrix itself (a part is
+        real iff its entry == 1: the kernels apply the reference's `part_valids == 1` themselves, which spares the
+        compare and the cast), or None -> [B, N, C]."""
         if not tokens.is_cuda:
             raise RuntimeError("TransformerEncoder: only CUDA (HIP) tensors are supported — no CPU fallback")
         if valid_masks is not None:
@@ -149,7 +151,7 @@ class TransformerEncoder(nn.Module):
                 warnings.warn("TransformerEncoder: configuration outside csrc/transformer.hip (needs pre-LN, widths "
                               "multiple of 64, head dim <= 64, <= 64 tokens, <= 16 layers); running on library ops")
                 self._warned = True
-            pad = None if valid_masks is None else ~valid_masks
+            pad = None if valid_masks is None else ~(valid_masks if valid_masks.dtype == torch.bool else valid_masks == 1)
             return self.out_fc(self.transformer_encoder(tokens, src_key_padding_mask=pad))
         B, P, _ = tokens.shape
         valid = (torch.ones(B * P, device=tokens.device) if valid_masks is None

@@ -350,6 +350,25 @@ def test_grad_sink_direct_writes_equal_autograd_accumulation(cuda_device):
     assert GradSink.active is None
 
 
+def test_transformer_takes_the_float_validity_matrix(cuda_device):
+    """The models hand `part_valids` (float) to the encoder as it is: a part is real iff its entry == 1 — the reference's
+    `part_valids == 1` (pn_transformer/network.py:88-92) applied inside the attention kernels — so any other value,
+    not only 0, masks the part; bit-equal to the same call with the boolean mask."""
+    torch.manual_seed(5)
+    for P, d, heads in ((6, 64, 4), (20, 256, 8), (40, 128, 4)):  # matrix-core attention (P <= 32) and the scalar kernel
+        enc = TransformerEncoder(d, heads, 2 * d, 2, norm_first=True, dropout=0.0).to(cuda_device).train()
+        tok = torch.randn(3, P, d, device=cuda_device)
+        valids = torch.ones(3, P, device=cuda_device)
+        valids[0, P - 2:] = 0.0
+        valids[1, 1] = 0.5   # not a real part under `== 1`
+        valids[2, 0] = 2.0   # neither
+        a = enc(tok, valids)
+        b = enc(tok, valids == 1)
+        assert torch.equal(a, b)
+        changed = enc(tok, torch.ones(3, P, device=cuda_device))
+        assert not torch.equal(a[1], changed[1]) and not torch.equal(a[2], changed[2])
+
+
 def _small_cfg(z):
     d, heads, ffn, layers = (int(v) for v in z["cfg"])
     cfg = config.pn_transformer_everyday()
