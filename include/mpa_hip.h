@@ -25,7 +25,7 @@ extern "C" {
 #define MPA_ELAUNCH (-2) /* hipGetLastError() reported a launch failure */
 
 /* ABI version of this header; bumped whenever a signature changes. */
-#define MPA_ABI_VERSION 6
+#define MPA_ABI_VERSION 7
 int mpa_abi_version(void);
 
 /* Thread-local, NUL-terminated description of the last failure on this thread ("" if none). */
@@ -304,6 +304,29 @@ int mpa_mlp_layer_forward(const float* x, int64_t ldx, const float* w, const flo
 int mpa_mlp_layer_backward(const float* grad_out, const float* x, int64_t ldx, const float* w, const float* gamma,
                            const float* out, int relu, int64_t R, int64_t K, int64_t N, void* ws, float* grad_x,
                            float* grad_w, float* grad_b, float* grad_gamma, float* grad_beta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * First layer of the P x P edge MLP without the pair tensor — replaces, for the edge MLP's first Conv1d(k=1) + BatchNorm1d
+ * + ReLU, the reference's
+ *   torch.cat([part_feats.unsqueeze(2).repeat(..), part_feats.unsqueeze(1).repeat(..)], dim=-1) -> MLP3.conv1 / bn1 / relu
+ *   (multi_part_assembly/models/dgl/network.py:135-152, models/dgl/modules.py:5-31; RGL-NET: models/rgl_net/network.py:70-88).
+ * The layer's input row (s, i, j) is [a[s, i] ; b[s, j]], so x w^T = (a Wa^T + bias)[s, i] + (b Wb^T)[s, j] with
+ * Wa | Wb the column halves of w [N, 2F]: two GEMMs over the B*P part rows instead of one over the B*P*P pair rows, the
+ * BatchNorm statistics taken over all B*P*P rows as the reference's BatchNorm1d does.
+ * a, b [B*P, F] row-major, w [N, 2F], bias [N] or NULL, gamma / beta / running_* [N] (the layer has a BatchNorm);
+ * out [B*P*P, N], row (s, i, j) at (s*P + i)*P + j.  F and N multiples of 64.  `ws`: mpa_pair_layer_workspace bytes,
+ * 256-byte aligned, carried from forward to backward, which overwrites grad_a / grad_b [B*P, F] (each if non-NULL),
+ * grad_w [N, 2F], grad_bias [N] (if non-NULL), grad_gamma / grad_beta [N].  Fixed-order reductions: deterministic.
+ * ---------------------------------------------------------------------------------------------- */
+int mpa_pair_layer_workspace(int64_t B, int64_t P, int64_t F, int64_t N, int64_t* bytes);
+int mpa_pair_layer_forward(const float* a, const float* b, const float* w, const float* bias, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, int training, float momentum,
+                           float eps, int relu, int64_t B, int64_t P, int64_t F, int64_t N, void* ws, float* out,
+                           void* stream);
+int mpa_pair_layer_backward(const float* grad_out, const float* a, const float* b, const float* w, const float* gamma,
+                            const float* out, int relu, int64_t B, int64_t P, int64_t F, int64_t N, void* ws, float* grad_a,
+                            float* grad_b, float* grad_w, float* grad_bias, float* grad_gamma, float* grad_beta,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The small per-iteration pieces of the graph networks between the MLP layers — replace the library element-wise /

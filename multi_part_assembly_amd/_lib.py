@@ -60,6 +60,9 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_mlp_layer_workspace": (_INT, [_I64, _I64, _I64, _P]),
     "mpa_mlp_layer_forward": (_INT, [_P, _I64, _P, _P, _P, _P, _P, _P, _INT, _F32, _F32, _INT, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_mlp_layer_backward": (_INT, [_P, _P, _I64, _P, _P, _P, _INT, _I64, _I64, _I64] + [_P] * 7),
+    "mpa_pair_layer_workspace": (_INT, [_I64, _I64, _I64, _I64, _P]),
+    "mpa_pair_layer_forward": (_INT, [_P] * 8 + [_INT, _F32, _F32, _INT, _I64, _I64, _I64, _I64, _P, _P, _P]),
+    "mpa_pair_layer_backward": (_INT, [_P] * 6 + [_INT, _I64, _I64, _I64, _I64] + [_P] * 8),
     "mpa_pair_rows_forward": (_INT, [_P, _P, _I64, _I64, _I64, _INT, _P, _P]),
     "mpa_pair_rows_backward": (_INT, [_P, _I64, _I64, _I64, _INT, _P, _P, _P]),
     "mpa_narrow_linear_relu_forward": (_INT, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
@@ -86,7 +89,7 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_grad_clip_coef": (_INT, [_P, _I64, _F32, _P, _F32, _P, _P, _P]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

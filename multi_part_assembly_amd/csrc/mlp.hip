@@ -259,6 +259,71 @@ __global__ void ml_transpose_kernel(const float* __restrict__ w, int rows, int c
   wt[(e % cols) * rows + e / cols] = w[e];
 }
 
+// ---- first layer of the P x P edge MLP without the pair tensor --------------------------------------------------------------
+// The layer's input row (b, i, j) is [a_i ; b_j], so  x w^T = pa[(b, i)] + pb[(b, j)]  with  pa = a Wa^T + bias,
+// pb = b Wb^T  (Wa | Wb = the column halves of w): two GEMMs over the B*P part rows instead of one over the B*P*P pair rows.
+// ypre[(b,i,j)][c] = pa[(b,i)][c] + pb[(b,j)][c] and the per-tile column sums (sum, sum of squares; rows ascending) of
+// ml_bias_stats_kernel.  grid = tiles of kRT rows, block 256.
+__global__ __launch_bounds__(256) void pair_sum_stats_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int P,
+                                                             int R, int C, float* __restrict__ ypre,
+                                                             float* __restrict__ partial) {
+  const long long r0 = (long long)blockIdx.x * kRT;
+  const int rows = R - r0 < kRT ? (int)(R - r0) : kRT;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float va[kRT], vb[kRT];
+#pragma unroll
+    for (int i = 0; i < kRT; ++i) {
+      const long long r = r0 + (i < rows ? i : rows - 1);
+      const long long bi = r / P;                        // (sample, part i)
+      const long long bj = (bi / P) * P + r % P;         // (sample, part j)
+      va[i] = pa[bi * C + c];
+      vb[i] = pb[bj * C + c];
+    }
+    float s = 0.0f, ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kRT; ++i) {
+      if (i < rows) {
+        const float t = va[i] + vb[i];
+        ypre[(r0 + i) * C + c] = t;
+        s += t;
+        ss = __builtin_fmaf(t, t, ss);
+      }
+    }
+    float* d = partial + ((long long)blockIdx.x * C + c) * 2;
+    d[0] = s;
+    d[1] = ss;
+  }
+}
+
+// dpa[(b,i)][c] = sum_j dy[(b,i,j)][c] (blocks [0, M)) and dpb[(b,j)][c] = sum_i dy[(b,i,j)][c] (blocks [M, 2M)), both in
+// ascending order of the summed index.  grid = 2 M, block 256.
+__global__ __launch_bounds__(256) void pair_reduce_kernel(const float* __restrict__ dy, int P, int M, int C,
+                                                          float* __restrict__ dpa, float* __restrict__ dpb) {
+  const bool second = (int)blockIdx.x >= M;
+  const int m = second ? (int)blockIdx.x - M : (int)blockIdx.x, b = m / P, q = m % P;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.0f;
+    mpa::batched_rows<8>(0, 1, P,
+                         [&](int t) {
+                           const long long row = second ? ((long long)(b * P + t) * P + q) : ((long long)(b * P + q) * P + t);
+                           return dy[row * C + c];
+                         },
+                         [&](int, float v) { acc += v; });
+    (second ? dpb : dpa)[(long long)m * C + c] = acc;
+  }
+}
+
+// out[n * ldo + k] = sum over the chunks of part[chunk][n * K + k] in chunk order: a weight gradient written into a column
+// block of a wider matrix.  grid = ceil(N K / 256), block 256.
+__global__ __launch_bounds__(256) void ml_reduce_strided_kernel(const float* __restrict__ part, int chunks, int N, int K,
+                                                                int ldo, float* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x, elems = (long long)N * K;
+  if (e >= elems) return;
+  float acc = 0.0f;
+  mpa::batched_rows<8>(0, 1, chunks, [&](int ch) { return part[(long long)ch * elems + e]; }, [&](int, float v) { acc += v; });
+  out[(e / K) * ldo + e % K] = acc;
+}
+
 struct MlWs {
   int* hdr;
   unsigned* tickets;
@@ -498,4 +563,151 @@ extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int
 #endif
   }
   return mpa::check_launch("mlp_layer_backward");
+}
+
+// ---- first layer of the P x P edge MLP on (a_i, b_j) pairs ------------------------------------------------------------------
+namespace {
+
+struct PairWs {
+  MlWs m;                       // the layer's workspace over the R = B P P pair rows (K = 2 F)
+  float *pa, *pb, *dpa, *dpb;   // [B P, N] each
+  int64_t total;
+};
+
+PairWs pair_carve(char* base, int64_t B, int64_t P, int64_t F, int64_t N) {
+  PairWs w;
+  w.m = ml_carve(base, B * P * P, 2 * F, N);
+  char* p = base + w.m.total;
+  auto take = [&](int64_t bytes) {
+    char* r = p;
+    p += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  const int64_t mn = 4 * B * P * N;
+  w.pa = reinterpret_cast<float*>(take(mn));
+  w.pb = reinterpret_cast<float*>(take(mn));
+  w.dpa = reinterpret_cast<float*>(take(mn));
+  w.dpb = reinterpret_cast<float*>(take(mn));
+  w.total = p - base;
+  return w;
+}
+
+int pair_check(int64_t B, int64_t P, int64_t F, int64_t N, const char* who) {
+  MPA_REQUIRE(B >= 1 && P >= 1 && P <= 1024 && B * P <= (1 << 20), "%s: 1 <= B, 1 <= P <= 1024, B P <= 2^20", who);
+  MPA_REQUIRE(F >= 64 && F % 64 == 0 && F <= 2048, "%s: feature width must be a multiple of 64 (<= 2048)", who);
+  return ml_check(B * P * P, 2 * F, N, who);
+}
+
+}  // namespace
+
+extern "C" int mpa_pair_layer_workspace(int64_t B, int64_t P, int64_t F, int64_t N, int64_t* bytes) {
+  if (int st = pair_check(B, P, F, N, "pair_layer_workspace")) return st;
+  MPA_REQUIRE(bytes != nullptr, "pair_layer_workspace: null pointer");
+  *bytes = pair_carve(nullptr, B, P, F, N).total;
+  return MPA_OK;
+}
+
+extern "C" int mpa_pair_layer_forward(const float* a, const float* b, const float* w, const float* bias, const float* gamma,
+                                      const float* beta, float* running_mean, float* running_var, int training,
+                                      float momentum, float eps, int relu, int64_t B, int64_t P, int64_t F, int64_t N,
+                                      void* ws, float* out, void* stream) {
+  if (int st = pair_check(B, P, F, N, "pair_layer_forward")) return st;
+  MPA_REQUIRE(a && b && w && gamma && beta && running_mean && running_var && ws && out,
+              "pair_layer_forward: null pointer (the layer has a BatchNorm)");
+  MPA_REQUIRE((uintptr_t)ws % 256 == 0, "pair_layer_forward: workspace must be 256-byte aligned");
+  hipStream_t s = mpa::as_stream(stream);
+  const PairWs pw = pair_carve(static_cast<char*>(ws), B, P, F, N);
+  const MlWs& m = pw.m;
+  const int64_t M = B * P, R = M * P;
+  const int tiles = (int)((R + kRT - 1) / kRT);
+  const long long total4 = R * N / 4;
+  const CoopWs cw{m.stage, m.tickets};
+  tfg::GemmArgs g{};
+  g.A = a;
+  g.W = w;
+  g.ldw = (int)(2 * F);
+  g.bias = bias;
+  g.C = pw.pa;
+  g.M = (int)M;
+  g.N = (int)N;
+  g.K = (int)F;
+  g.zero = m.tickets;
+  tfg::launch_gemm<tfg::EPI_BIAS_ACT>(g, s);  // pa = a Wa^T + bias   (g.relu = 0)
+  g.A = b;
+  g.W = w + F;
+  g.bias = nullptr;
+  g.C = pw.pb;
+  g.zero = nullptr;
+  tfg::launch_gemm<tfg::EPI_BIAS_ACT>(g, s);  // pb = b Wb^T
+  launch(pair_sum_stats_kernel, dim3((unsigned)tiles), dim3(256), s, (const float*)pw.pa, (const float*)pw.pb, (int)P, (int)R,
+         (int)N, m.ypre, m.partial);
+  if (training)
+    launch(ml_bn_finalize_kernel, dim3((unsigned)(N / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
+           (const float*)m.partial, tiles, (int)N, (double)R, gamma, beta, running_mean, running_var, momentum, eps, m.bn, cw);
+  else
+    launch(ml_bn_from_running_kernel, dim3((unsigned)(N / 64)), dim3(64), s, (int)N, gamma, beta, (const float*)running_mean,
+           (const float*)running_var, eps, m.bn);
+  launch(ml_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), s, (const float*)m.ypre, (const float*)m.bn,
+         (const float*)nullptr, total4, (int)N, relu, out);
+  return mpa::check_launch("pair_layer_forward");
+}
+
+extern "C" int mpa_pair_layer_backward(const float* grad_out, const float* a, const float* b, const float* w,
+                                       const float* gamma, const float* out, int relu, int64_t B, int64_t P, int64_t F,
+                                       int64_t N, void* ws, float* grad_a, float* grad_b, float* grad_w, float* grad_bias,
+                                       float* grad_gamma, float* grad_beta, void* stream) {
+  if (int st = pair_check(B, P, F, N, "pair_layer_backward")) return st;
+  MPA_REQUIRE(grad_out && a && b && w && gamma && out && ws && grad_w && grad_gamma && grad_beta,
+              "pair_layer_backward: null pointer");
+  hipStream_t s = mpa::as_stream(stream);
+  const PairWs pw = pair_carve(static_cast<char*>(ws), B, P, F, N);
+  const MlWs& m = pw.m;
+  const int64_t M = B * P, R = M * P;
+  const int tiles = (int)((R + kRT - 1) / kRT);
+  const CoopWs cw{m.stage, m.tickets};
+  launch(ml_bwd_sums_kernel, dim3((unsigned)tiles), dim3(256), s, grad_out, out, (const float*)m.ypre, (const float*)m.bn,
+         (int)R, (int)N, relu, m.partial);
+  launch(ml_bwd_coef_kernel, dim3((unsigned)(N / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
+         (const float*)m.partial, tiles, (int)N, (double)R, gamma, (const float*)m.bn, m.coef, grad_gamma, grad_beta, cw);
+  launch(ml_bwd_dy_kernel, dim3((unsigned)tiles), dim3(256), s, grad_out, out, (const float*)m.ypre, (const float*)m.coef,
+         (int)R, (int)N, relu, m.dy, m.partial);
+  launch(pair_reduce_kernel, dim3((unsigned)(2 * M)), dim3(256), s, (const float*)m.dy, (int)P, (int)M, (int)N, pw.dpa,
+         pw.dpb);
+  if (grad_bias != nullptr) dg::launch_tn_reduce(m.partial, tiles, (long long)N, grad_bias, s);  // column sums of dY
+  // dW[:, 0:F] = dpa^T a,  dW[:, F:2F] = dpb^T b  (row chunks, fixed-order sums into the column halves of grad_w)
+  {
+    const int out_tiles = (int)(((N + 127) / 128) * (F % 128 == 0 ? F / 128 : F / 64));
+    int chunks = (512 + out_tiles - 1) / out_tiles;
+    if (chunks > (int)(M / 64)) chunks = (int)(M / 64);
+    chunks = chunks < 1 ? 1 : (chunks > kChunks ? kChunks : chunks);
+    if (chunks >= 8) chunks = chunks / 8 * 8;
+    const int rows_per_chunk = (int)(((M + chunks - 1) / chunks + 31) / 32 * 32);
+    const dim3 grid((unsigned)((N + 127) / 128), (unsigned)(F % 128 == 0 ? F / 128 : F / 64), (unsigned)chunks);
+    for (int half = 0; half < 2; ++half) {
+      const float* dY = half ? pw.dpb : pw.dpa;
+      const float* X = half ? b : a;
+      if (F % 128 == 0)
+        launch(gemm_tn_split_kernel<128>, grid, dim3(kGsT), s, dY, (int)N, (int)N, X, (int)F, (int)F, m.tnpart, rows_per_chunk,
+               (const int*)nullptr, (int)M);
+      else
+        launch(gemm_tn_split_kernel<64>, grid, dim3(kGsT), s, dY, (int)N, (int)N, X, (int)F, (int)F, m.tnpart, rows_per_chunk,
+               (const int*)nullptr, (int)M);
+      launch(ml_reduce_strided_kernel, dim3((unsigned)((N * F + 255) / 256)), dim3(256), s, (const float*)m.tnpart, chunks,
+             (int)N, (int)F, (int)(2 * F), grad_w + half * F);
+    }
+  }
+  for (int half = 0; half < 2; ++half) {  // d a = dpa Wa,  d b = dpb Wb: the weight's column half read as the transposed operand
+    float* dst = half ? grad_b : grad_a;
+    if (dst == nullptr) continue;
+    tfg::GemmArgs g{};
+    g.A = half ? pw.dpb : pw.dpa;
+    g.W = w + half * F;
+    g.ldw = (int)(2 * F);
+    g.C = dst;
+    g.M = (int)M;
+    g.N = (int)F;
+    g.K = (int)N;
+    tfg::launch_gemm<tfg::EPI_NONE, true>(g, s);
+  }
+  return mpa::check_launch("pair_layer_backward");
 }

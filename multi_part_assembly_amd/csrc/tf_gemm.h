@@ -47,6 +47,7 @@ struct GemmArgs {
   float* C;            // [M, N]
   int M, N, K;
   int lda;             // row stride of A (0: K)
+  int ldw;             // row stride of W (0: K, or N with WT): a column block of a wider weight matrix
   int relu;            // EPI_BIAS_ACT
   float* stats;        // EPI_STATS: [ceil(M / 32)][N][2]
   unsigned* zero;      // nullable: 64 words cleared by block (0, 0) (the tickets of the caller's cooperative reductions)
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
   const int r0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   const int kp = gemm_phase(g.K), nph = g.K / kp, ld = kp + 4, q4 = kp / 4, cnt = 32 * q4;
   const int lda = g.lda > 0 ? g.lda : g.K;
+  const int ldw = g.ldw > 0 ? g.ldw : (WT ? g.N : g.K);
   if (g.zero != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) g.zero[threadIdx.x] = 0u;
   constexpr int kFI = 32 * (kKP / 4) / kGT;  // float4 per thread, operand and phase
   struct Stage {
@@ -111,9 +113,9 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
         const int ar = r0 + row < g.M ? r0 + row : g.M - 1;
         st.a[i] = *reinterpret_cast<const float4*>(g.A + (long long)ar * lda + ph * kp + 4 * c4);
         if constexpr (WT) {  // [kp, 32] slab of W^T: 8 lanes per 128-byte row
-          st.w[i] = *reinterpret_cast<const float4*>(g.W + (long long)(ph * kp + (idx >> 3)) * g.N + n0 + 4 * (idx & 7));
+          st.w[i] = *reinterpret_cast<const float4*>(g.W + (long long)(ph * kp + (idx >> 3)) * ldw + n0 + 4 * (idx & 7));
         } else {
-          st.w[i] = *reinterpret_cast<const float4*>(g.W + (long long)(n0 + row) * g.K + ph * kp + 4 * c4);
+          st.w[i] = *reinterpret_cast<const float4*>(g.W + (long long)(n0 + row) * ldw + ph * kp + 4 * c4);
         }
       }
     }

@@ -31,7 +31,7 @@ from .gnn_ops import (NARROW_MAX_IN, RELATION_MEAN_MAX_PARTS, narrow_linear_relu
                       relation_head, relation_head_supported, relation_mean)
 from .gru import gru_recurrent, supported as gru_supported
 from .loss import LossTerms
-from .mlp import bn_counter_batch, mlp_layer, supported as mlp_supported
+from .mlp import bn_counter_batch, mlp_layer, pair_layer, pair_layer_supported, supported as mlp_supported
 from .regressor import StocasticPoseRegressor
 
 
@@ -57,6 +57,7 @@ class _PairMLP(nn.Module):
         h = mlp_layer(h, self.conv2.weight, self.conv2.bias, self.bn2, relu=True, training=self.training)
         return mlp_layer(h, self.conv3.weight, self.conv3.bias, self.bn3, relu=self.final_relu, training=self.training)
 
+    PAIR_LAYER = True  # (a knob for A/B runs and tests: False = the first layer as a GEMM over the materialised pair rows)
     MIN_ROWS = 1  # (a knob for A/B runs: tools/probe_node_mlp.py — the HIP layers win from the 640-row node MLP up, and
                   # unlike the library's split-K weight gradients they are deterministic)
 
@@ -83,6 +84,13 @@ class _PairMLP(nn.Module):
     def forward_pairs(self, a, b):
         """Rows = (sample, part i), positions = part j, input [a_i ; b_j]: a, b [B, P, F] -> [B*P, P, F_out]."""
         B, P, F = a.shape
+        if self._hip_ok(a, 2 * F, B * P * P) and self.PAIR_LAYER and pair_layer_supported(F, 512):
+            # conv1 of [a_i ; b_j] = (a Wa^T + bias)_i + (b Wb^T)_j: two GEMMs over the B*P part rows, the pair tensor is
+            # never built (csrc/mlp.hip: mpa_pair_layer_*); BatchNorm statistics over all B*P*P rows as upstream
+            h = pair_layer(a, b, self.conv1.weight, self.conv1.bias, self.bn1, relu=True, training=self.training)
+            h = mlp_layer(h, self.conv2.weight, self.conv2.bias, self.bn2, relu=True, training=self.training)
+            h = mlp_layer(h, self.conv3.weight, self.conv3.bias, self.bn3, relu=self.final_relu, training=self.training)
+            return h.view(B * P, P, -1)
         if self._hip_ok(a, 2 * F, B * P * P):
             if pair_rows_supported(F):
                 pair = pair_rows(a, b)  # one launch; its backward sums the two halves over j / over i in one more

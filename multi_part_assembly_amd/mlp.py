@@ -76,6 +76,87 @@ class _MLPLayerFn(torch.autograd.Function):
         return gx, gw, gb, gg, gbe, None, None, None, None, None
 
 
+class _PairLayerFn(torch.autograd.Function):
+    """First layer of the P x P edge MLP on (a_i, b_j) pairs without the pair tensor (csrc/mlp.hip: mpa_pair_layer_*)."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, bias, gamma, beta, running, training, momentum, eps, relu):
+        B, P, F = a.shape
+        N = weight.shape[0]
+        w = weight.reshape(N, -1)  # Conv1d weight [N, 2F, 1]: the same bytes
+        dev = a.device
+        L = _lib.lib()
+        nbytes = ctypes.c_int64()
+        _lib.check(L.mpa_pair_layer_workspace(B, P, F, N, ctypes.byref(nbytes)), "mpa_pair_layer_workspace")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        out = torch.empty((B * P * P, N), dtype=torch.float32, device=dev)
+        rm, rv = running
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"pair_layer_forward[{B}x{P}x{P}x{2 * F}x{N}]")
+            st = L.mpa_pair_layer_forward(_lib.ptr(a), _lib.ptr(b), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(gamma),
+                                          _lib.ptr(beta), _lib.ptr(rm), _lib.ptr(rv), int(training), float(momentum),
+                                          float(eps), int(relu), B, P, F, N, _lib.ptr(ws), _lib.ptr(out),
+                                          _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_pair_layer_forward")
+        ctx.meta = (bool(relu), bool(training), bias is not None)
+        ctx.params = [p for p in (weight, bias, gamma, beta) if p is not None]
+        GradSink.note_use(ctx.params)
+        ctx.save_for_backward(a, b, w, gamma, out, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("pair layer: the backward pass overwrites its saved workspace: a second backward over the "
+                               "same forward (retain_graph=True) is not supported — run the forward again")
+        ctx.consumed = True
+        a, b, w, gamma, out, ws = ctx.saved_tensors
+        relu, training, has_bias = ctx.meta
+        if not training:
+            raise RuntimeError("pair layer: backward is implemented for training-mode BatchNorm only")
+        B, P, F = a.shape
+        N = w.shape[0]
+        dev = a.device
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        bufs, direct = GradSink.outputs(ctx.params)
+        it = iter(bufs)
+        gw = next(it)
+        gbias = next(it) if has_bias else None
+        gg, gbe = next(it), next(it)
+        grad_out = grad_out.contiguous()
+        with torch.cuda.device(dev):
+            tok = _lib.KernelTimer.start(f"pair_layer_backward[{B}x{P}x{P}x{2 * F}x{N}]")
+            st = _lib.lib().mpa_pair_layer_backward(
+                _lib.ptr(grad_out), _lib.ptr(a), _lib.ptr(b), _lib.ptr(w), _lib.ptr(gamma), _lib.ptr(out), int(relu), B, P, F,
+                N, _lib.ptr(ws), _lib.ptr(ga), _lib.ptr(gb), _lib.ptr(gw), _lib.ptr(gbias), _lib.ptr(gg), _lib.ptr(gbe),
+                _lib.current_stream(dev))
+            _lib.KernelTimer.stop(tok)
+        _lib.check(st, "mpa_pair_layer_backward")
+        if direct:
+            GradSink.delivered(ctx.params)
+            return (ga, gb) + (None,) * 9
+        return ga, gb, gw, gbias, gg, gbe, None, None, None, None, None
+
+
+def pair_layer_supported(feat, out_dim):
+    return feat % 64 == 0 and 64 <= feat <= 2048 and supported(2 * feat, out_dim)
+
+
+def pair_layer(a, b, weight, bias, bn, relu=True, training=True):
+    """a, b [B, P, F] (CUDA) -> [B*P*P, N] = act(bn([a_i ; b_j] W^T + bias)), row (s, i, j) at (s*P + i)*P + j: the first
+    Conv1d(k=1) + BatchNorm1d (+ ReLU) of the edge MLP over all part pairs, computed from two GEMMs over the B*P part rows
+    (the pair tensor of dgl/network.py:135-144 is never built).  `weight` [N, 2F] or the Conv1d weight [N, 2F, 1]."""
+    if not a.is_cuda:
+        raise RuntimeError("pair_layer: only CUDA (HIP) tensors are supported — no CPU fallback")
+    a, b = a.float().contiguous(), b.float().contiguous()
+    if training:
+        _count_batch(bn)
+    return _PairLayerFn.apply(a, b, weight, bias, bn.weight, bn.bias, (bn.running_mean, bn.running_var), training,
+                              bn.momentum, bn.eps, relu)
+
+
 class bn_counter_batch:
     """`with bn_counter_batch():` — the `num_batches_tracked += 1` of every BatchNorm layer that `mlp_layer` runs in
     training mode inside the block becomes ONE multi-tensor launch at its end instead of one launch per layer (18 per
@@ -94,6 +175,16 @@ class bn_counter_batch:
         return False
 
 
+def _count_batch(bn):
+    """bn.num_batches_tracked += 1 — now, or with the other layers' counters at the end of a bn_counter_batch block."""
+    pend, t = bn_counter_batch.pending, bn.num_batches_tracked
+    if pend is not None:
+        pend[id(t)] = (t, pend.get(id(t), (t, 0))[1] + 1)
+    else:
+        with torch.no_grad():
+            t += 1
+
+
 def supported(in_dim, out_dim):
     return in_dim % 64 == 0 and out_dim % 64 == 0 and 64 <= in_dim <= 4096 and 64 <= out_dim <= 4096
 
@@ -109,11 +200,6 @@ def mlp_layer(x, weight, bias=None, bn=None, relu=True, training=True):
     if bn is None:
         return _MLPLayerFn.apply(x, weight, bias, None, None, None, training, 0.0, 0.0, relu)
     if training:
-        pend, t = bn_counter_batch.pending, bn.num_batches_tracked
-        if pend is not None:
-            pend[id(t)] = (t, pend.get(id(t), (t, 0))[1] + 1)
-        else:
-            with torch.no_grad():
-                t += 1
+        _count_batch(bn)
     return _MLPLayerFn.apply(x, weight, bias, bn.weight, bn.bias, (bn.running_mean, bn.running_var), training,
                              bn.momentum, bn.eps, relu)

@@ -177,6 +177,69 @@ def test_pair_mlp_hip_layers_match_library_ops(cuda_device, final_relu, rows, L,
         assert rel(mine(x), ref._tail(ref.conv1(x.transpose(1, 2)))) < 1e-4
 
 
+@pytest.mark.parametrize("B,P,F,same", [(3, 5, 64, False), (32, 20, 128, True), (2, 33, 128, False)])
+def test_edge_mlp_first_layer_without_the_pair_tensor(cuda_device, B, P, F, same):
+    """`_PairMLP.forward_pairs` with the first layer as two part-row GEMMs + a broadcast sum (csrc/mlp.hip:
+    mpa_pair_layer_*) against (1) the same module with the first layer as a GEMM over the materialised [a_i ; b_j] rows
+    and (2) the float64 library composition of the reference (dgl/network.py:135-152, dgl/modules.py:5-31): output, the
+    gradients of both inputs (one tensor in both roles when `same`, as the networks call it) and of every parameter,
+    running statistics and step counters."""
+    import copy
+    from multi_part_assembly_amd.gnn import _PairMLP
+    torch.manual_seed(B * 100 + P)
+    mine = _PairMLP(2 * F, 128).to(cuda_device).train()
+    with torch.no_grad():
+        for bn in (mine.bn1, mine.bn2, mine.bn3):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.1)
+    rows = copy.deepcopy(mine)
+    rows.PAIR_LAYER = False
+    ref64 = copy.deepcopy(mine).double()
+    ref64.MIN_ROWS = 10 ** 12  # library ops
+    a0 = torch.randn(B, P, F, device=cuda_device)
+    b0 = a0 if same else torch.randn(B, P, F, device=cuda_device)
+    w = torch.randn(B * P, P, 128, device=cuda_device)
+    res = []
+    for mod, cast in ((mine, torch.float32), (rows, torch.float32), (ref64, torch.float64)):
+        a = a0.to(cast).clone().requires_grad_()
+        b = a if same else b0.to(cast).clone().requires_grad_()
+        out = mod.forward_pairs(a, b)
+        (out * w.to(cast)).sum().backward()
+        res.append((out.detach(), a.grad, None if same else b.grad, mod))
+    rel = lambda x, y: float((x.double() - y.double()).abs().max() / (y.double().abs().max() + 1e-12))
+    (o1, ga1, gb1, _), (o2, ga2, gb2, _), (o3, ga3, gb3, _) = res
+    assert rel(o1, o3) < 1e-5 and rel(o2, o3) < 1e-5
+
+    def close(x, x_rows, x64, who):
+        """anchored at float64: within 2e-4 of it, or no further from it than twice the materialised-rows path is; a ReLU
+        on the rounding edge (the two paths round the first layer differently: one 2F-term chain there, two F-term chains
+        and a sum here) may move isolated entries — at most 0.5 % of them beyond 2e-3, none beyond 3e-2 (the rule of
+        test_pair_mlp_hip_layers_match_library_ops)"""
+        e, e_rows = rel(x, x64), rel(x_rows, x64)
+        if e < 2e-4 or e <= 2.0 * e_rows:
+            return
+        far = ((x.double() - x64).abs() > 2e-3 * x64.abs().max()).float().mean()
+        assert e < 3e-2 and float(far) <= 0.005, (who, e, e_rows, float(far))
+
+    close(ga1, ga2, ga3, "a")
+    if not same:
+        close(gb1, gb2, gb3, "b")
+    for (k, p1), (_, p2), (_, p3) in zip(mine.named_parameters(), rows.named_parameters(), ref64.named_parameters()):
+        if "conv" in k and "bias" in k:  # a bias in front of a BatchNorm: zero up to rounding
+            assert float(p1.grad.abs().max()) < 1e-3 * float(w.abs().sum())
+        else:
+            close(p1.grad, p2.grad, p3.grad, k)
+    for (k, x), (_, y) in zip(mine.named_buffers(), ref64.named_buffers()):
+        if "running" in k:
+            assert rel(x, y) < 1e-4, k
+        else:
+            assert int(x) == int(y) == 1, k  # num_batches_tracked
+    mine.eval()
+    ref64.eval()
+    with torch.no_grad():
+        assert rel(mine.forward_pairs(a0, b0), ref64.forward_pairs(a0.double(), b0.double())) < 1e-4
+
+
 def test_relation_net_hip_layers_match_library_ops(cuda_device):
     import copy
     from multi_part_assembly_amd.gnn import RelationNet
