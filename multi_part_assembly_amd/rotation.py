@@ -51,7 +51,13 @@ class _SanitizeFn(torch.autograd.Function):
 class Rotation3D:
     ROT_TYPE = ["quat"]
 
-    def __init__(self, rot, rot_type="quat"):
+    def __init__(self, rot, rot_type="quat", _sanitized=False):
+        """`_sanitized` (internal): `rot` is the float32 tensor of another Rotation3D passed through an operation that keeps
+        every quaternion as it is (detach, clone, a change of device) — the constructor rule is idempotent, so applying it
+        again would be one more launch for the same values."""
+        if _sanitized and rot.dtype == torch.float32 and rot.shape[-1] == 4 and rot_type == "quat":
+            self._rot, self._rot_type = rot, rot_type
+            return
         if rot_type != "quat":
             raise NotImplementedError(
                 f"rotation {rot_type!r}: only 'quat' is on the MI355X hot path (every shipped "
@@ -120,9 +126,12 @@ class Rotation3D:
         return Rotation3D._combine(torch.stack, rot_lst, dim)
 
 
+_VALUE_PRESERVING = ("detach", "clone", "contiguous", "cuda", "cpu")  # every quaternion of the result is one of the input
+
+
 def _delegate(name):
     def method(self, *args, **kwargs):
-        return Rotation3D(getattr(self._rot, name)(*args, **kwargs), self._rot_type)
+        return Rotation3D(getattr(self._rot, name)(*args, **kwargs), self._rot_type, _sanitized=name in _VALUE_PRESERVING)
 
     method.__name__ = name
     method.__doc__ = f"torch.Tensor.{name} applied to the wrapped quaternion tensor."
