@@ -1900,6 +1900,47 @@ __global__ __launch_bounds__(64 * kSlices) void pn_wgrad_reduce_kernel(const flo
   }
 }
 
+// The same reduction for up to four weight gradients in ONE launch (the layers' partial tables wait in their own regions of
+// dwpart until the end of the backward pass): blocks [first[k], first[k + 1]) serve problem k.  Same summation order.
+struct WgradReduceGroup {
+  const float* part[4];
+  float* dw[4];
+  int rows[4], elems[4], first[5];
+};
+__global__ __launch_bounds__(64 * kSlices) void pn_wgrad_reduce_group_kernel(const WgradReduceGroup g) {
+  __shared__ float sm[kSlices][64];
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < 4; ++q) k += (int)blockIdx.x >= g.first[q] ? 1 : 0;
+  const float* __restrict__ dwpart = g.part[k];
+  const int M = g.rows[k], elems = g.elems[k];
+  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6, i = ((int)blockIdx.x - g.first[k]) * 64 + el;
+  float s = 0.0f;
+  if (i < elems) {
+    constexpr int U = 8;
+    for (int m0 = slice; m0 < M; m0 += kSlices * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int m = m0 + u * kSlices, mm = m < M ? m : M - 1;
+        v[u] = dwpart[(long long)mm * elems + i];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (m0 + u * kSlices < M) s += v[u];
+    }
+  }
+  sm[slice][el] = s;
+  __syncthreads();
+  if (slice == 0 && i < elems) {
+    float t = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kSlices; ++q) t += sm[q][el];
+    g.dw[k][i] = t;
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------
 struct Dims {
   int64_t M, N, F, rows;
@@ -1978,7 +2019,13 @@ PnWs carve(float* base, const Dims& d) {
   int64_t blocks = d.M * (d.tiles1 > smax ? d.tiles1 : smax);
   if (blocks < 2 * kWF) blocks = 2 * kWF;  // the fused backward kernel leaves one row per persistent block
   w.partial = take(blocks * maxc * 2);
-  w.dwpart = take((int64_t)kWG * (128 * 128 + 128));
+  // the Gram partials of the last layer (reduced at once), then — in the same storage — the partial tables of layers 4..1,
+  // which wait for ONE grouped reduction at the end of the backward pass
+  {
+    const int64_t gram = (int64_t)kWG * (128 * 128 + 128);
+    const int64_t wait = (int64_t)2 * kWF * (128 * 64 + 64 * 64 + 64 * 64) + (int64_t)kWG * (64 * 4);
+    w.dwpart = take(gram > wait ? gram : wait);
+  }
   w.count = take(4);
   w.coop.ticket = reinterpret_cast<unsigned*>(take(4));
   w.coop.stage = reinterpret_cast<double*>(take(2 * 2 * maxc * ((blocks + kEB - 1) / kEB)));
@@ -2176,24 +2223,40 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   hipLaunchKernelGGL(pn_top_wgrad_kernel, dim3((unsigned)F), dim3(1024), 0, s, grad_feat, iw.argmax, valids, w.Y[4],
                      w.bn[4], conv_w[4], w.coef[5], w.gram, (int)M, (int)N, (int)F, grad_conv_w[4]);
   // ---- layers 4..2: fused input + weight gradient, then the next layer's BatchNorm-backward coefficients
+  WgradReduceGroup rg{};
+  int n_wait = 0;
+  long long wait_off = 0;
   for (int l = 4; l >= 2; --l) {
     const int cout = d.C[l], cin = d.C[l - 1];
 #define MPA_FUSED(KK, NT, PN, TH, FI, YP)                                                                              \
   hipLaunchKernelGGL((pn_bwd_fused_kernel<KK, NT, PN, TH, FI>), dim3(nb), dim3(TH), 0, s, w.Y[l], w.dZ[l], w.coef[l],  \
-                     conv_w[l - 1], YP, w.bn[l - 1], iw.vlist, (int)N, w.dZ[l - 1], w.partial, w.dwpart,               \
+                     conv_w[l - 1], YP, w.bn[l - 1], iw.vlist, (int)N, w.dZ[l - 1], w.partial, dwl,                    \
                      (const float*)w.Wt1)
     const int nb = 2 * kWF;                      // two 4-wave blocks per CU
+    float* const dwl = w.dwpart + wait_off;      // this layer's partial table (reduced with the others at the end)
+    rg.part[n_wait] = dwl;
+    rg.dw[n_wait] = grad_conv_w[l - 1];
+    rg.rows[n_wait] = nb;
+    rg.elems[n_wait] = cout * cin;
+    ++n_wait;
+    wait_off += (long long)nb * cout * cin;
     if (l == 2) MPA_FUSED(64, 2, 1, 256, true, points);          // (Yprev = the first layer's output: recomputed)
     else if (cout == 64) MPA_FUSED(64, 2, 1, 256, false, w.Y[l - 1]);  // 64 -> 64: one 64-channel panel, 64-row units
     else MPA_FUSED(128, 1, 2, 256, false, w.Y[l - 1]);                 // 64 -> 128: two 32-channel panels, 32-row units
 #undef MPA_FUSED
-    reduce_dw(nb, cout * cin, grad_conv_w[l - 1]);
     hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(cin / 64), (unsigned)((nb + kEB - 1) / kEB)),
                        dim3(64 * kSlices), 0, s, w.partial, (const float*)nullptr, nb, 1, cin, w.count, bn_w[l - 2],
                        w.bn[l - 1], w.coef[l - 1], grad_bn_w[l - 2], grad_bn_b[l - 2], w.coop);
   }
   hipLaunchKernelGGL((pn_wgrad_mfma_kernel<64, 4, WG_FIRST>), dim3(kWG), dim3(kT), 0, s, (const float*)nullptr, w.dZ[1],
-                     w.coef[1], points, (const float*)nullptr, iw.vlist, (int)N, w.dwpart, 0, (const float*)w.Wt1);
-  reduce_dw(kWG, d.C[1] * 3, grad_conv_w[0]);
+                     w.coef[1], points, (const float*)nullptr, iw.vlist, (int)N, w.dwpart + wait_off, 0, (const float*)w.Wt1);
+  rg.part[n_wait] = w.dwpart + wait_off;
+  rg.dw[n_wait] = grad_conv_w[0];
+  rg.rows[n_wait] = kWG;
+  rg.elems[n_wait] = d.C[1] * 3;
+  ++n_wait;
+  rg.first[0] = 0;
+  for (int k = 0; k < 4; ++k) rg.first[k + 1] = rg.first[k] + (k < n_wait ? (rg.elems[k] + 63) / 64 : 0);
+  hipLaunchKernelGGL(pn_wgrad_reduce_group_kernel, dim3((unsigned)rg.first[4]), dim3(64 * kSlices), 0, s, rg);
   return mpa::check_launch("pointnet_backward");
 }
