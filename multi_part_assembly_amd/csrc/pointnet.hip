@@ -317,11 +317,20 @@ __global__ void pn_top_finalize_kernel(const float* __restrict__ topv, const int
 
 // Per part: the arg-max entries (row, channel, alpha*grad) sorted by 32-row tile (ties: channel order), and the
 // tile offsets — the sparse operand of the last layer's input gradient.  grid = M, block = F threads.
+// Blocks [M, M + C4 + 1) of the same launch compute Q and c0 (pn_top_q below): two small, independent, latency-bound jobs
+// that both wait for the coefficients of the last BatchNorm — side by side instead of one after the other.
+__device__ __forceinline__ void pn_top_q_row(const float* __restrict__ w5, const float* __restrict__ coef, int F, int C4,
+                                             float* __restrict__ q, int k);
 __global__ void pn_top_csr_kernel(const int* __restrict__ argmax, const float* __restrict__ gfeat,
                                   const float* __restrict__ coef, const float* __restrict__ valids, int N, int F,
                                   int* __restrict__ erow, int* __restrict__ ech, float* __restrict__ eval,
-                                  int* __restrict__ tptr) {
+                                  int* __restrict__ tptr, int M, const float* __restrict__ w5, int C4,
+                                  float* __restrict__ q) {
   extern __shared__ int bins[];  // [F]
+  if ((int)blockIdx.x >= M) {
+    pn_top_q_row(w5, coef, F, C4, q, (int)blockIdx.x - M);
+    return;
+  }
   const int m = blockIdx.x, c = threadIdx.x, T = (N + 31) / 32;
   if (valids[m] == 0.0f) return;
   const int arg = argmax[(long long)m * F + c];
@@ -349,19 +358,20 @@ __global__ void pn_top_csr_kernel(const int* __restrict__ argmax, const float* _
 
 // Q[k][d] = sum_c gammap_c W5[c][k] W5[c][d]  (dA4 = A4 Q + c0 + sparse),  c0[d] = sum_c betap_c W5[c][d].
 // grid = C4 + 1 (row k; the extra block writes c0), block = C4 threads (d).
-__global__ void pn_top_q_kernel(const float* __restrict__ w5, const float* __restrict__ coef, int F, int C4,
-                                float* __restrict__ q) {
-  const int k = blockIdx.x, d = threadIdx.x;
-  float acc = 0.0f;
-  if (k < C4) {
+__device__ __forceinline__ void pn_top_q_row(const float* __restrict__ w5, const float* __restrict__ coef, int F, int C4,
+                                             float* __restrict__ q, int k) {
+  for (int d = threadIdx.x; d < C4; d += blockDim.x) {
+    float acc = 0.0f;
+    if (k < C4) {
 #pragma unroll 8
-    for (int c = 0; c < F; ++c)
-      acc = __builtin_fmaf(coef[F + c] * w5[(long long)c * C4 + k], w5[(long long)c * C4 + d], acc);
-  } else {
+      for (int c = 0; c < F; ++c)
+        acc = __builtin_fmaf(coef[F + c] * w5[(long long)c * C4 + k], w5[(long long)c * C4 + d], acc);
+    } else {
 #pragma unroll 8
-    for (int c = 0; c < F; ++c) acc = __builtin_fmaf(coef[2 * F + c], w5[(long long)c * C4 + d], acc);
+      for (int c = 0; c < F; ++c) acc = __builtin_fmaf(coef[2 * F + c], w5[(long long)c * C4 + d], acc);
+    }
+    q[(long long)k * C4 + d] = acc;
   }
-  q[(long long)k * C4 + d] = acc;
 }
 
 // Weight gradient of the last layer:
@@ -2186,10 +2196,9 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   hipLaunchKernelGGL(pn_bwd_top_kernel, dim3((unsigned)(F / 64), (unsigned)((M + kEB - 1) / kEB)), dim3(64 * kSlices),
                      0, s, grad_feat, iw.argmax, w.ybest, valids, (int)M, (int)F, w.count, bn_w[4], w.bn[5],
                      w.coef[5], grad_bn_w[4], grad_bn_b[4], w.coop);
-  hipLaunchKernelGGL(pn_top_csr_kernel, dim3((unsigned)M), dim3((unsigned)F), sizeof(int) * F, s, iw.argmax,
-                     grad_feat, w.coef[5], valids, (int)N, (int)F, iw.erow, iw.ech, w.eval, iw.tptr);
-  hipLaunchKernelGGL(pn_top_q_kernel, dim3((unsigned)(C4 + 1)), dim3((unsigned)C4), 0, s, conv_w[4], w.coef[5], (int)F,
-                     C4, w.q);
+  hipLaunchKernelGGL(pn_top_csr_kernel, dim3((unsigned)(M + C4 + 1)), dim3((unsigned)F), sizeof(int) * F, s, iw.argmax,
+                     grad_feat, w.coef[5], valids, (int)N, (int)F, iw.erow, iw.ech, w.eval, iw.tptr, (int)M, conv_w[4], C4,
+                     w.q);
   {
 #if MPA_PN_SPLIT
 #define MPA_DGRAD_TOP pn_dgrad_split_kernel<128>
