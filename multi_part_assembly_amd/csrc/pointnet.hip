@@ -62,19 +62,17 @@ __device__ __forceinline__ const T* opaque(const T* p) {
 // Backward coefficients [3][C]: alpha, gammap, betap  with  dY = alpha*dZ + gammap*Y + betap.
 
 // ---- small kernels ---------------------------------------------------------------------------------------
-__global__ void pn_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int cin) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < cout * cin) wt[(i % cin) * cout + i / cin] = w[i];
-}
-
 // number of valid points (BatchNorm's sample count), the compact list of valid parts (vlist[0] = how many, part
 // ids from vlist[4] on, ascending) that the persistent backward kernels walk, and the reset of the tickets.
 // one block of 1024 threads.
 __global__ __launch_bounds__(1024) void pn_count_kernel(const float* __restrict__ valids, int M, int N,
                                                         float* __restrict__ count, unsigned* __restrict__ ticket,
-                                                        int* __restrict__ vlist) {
+                                                        int* __restrict__ vlist, const float* __restrict__ w1 = nullptr,
+                                                        float* __restrict__ wt1 = nullptr) {
   __shared__ int wcnt[16];
   if (threadIdx.x < 4) ticket[threadIdx.x] = 0u;  // the cooperative reductions' counters (reset after every use)
+  // (the first layer's 64 x 3 weights transposed for the kernels that recompute that layer: rode in its own launch before)
+  if (w1 != nullptr && threadIdx.x < 192) wt1[(threadIdx.x % 3) * 64 + threadIdx.x / 3] = w1[threadIdx.x];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int base = 0;
   for (int m0 = 0; m0 < M; m0 += 1024) {
@@ -2111,9 +2109,8 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
   const Dims d = make_dims(M, N, F);
   const PnWs w = carve(float_ws, d);
   const PnIws iw = carve_int(int_ws, d);
-  hipLaunchKernelGGL(pn_transpose_kernel, dim3(1), dim3(192), 0, s, conv_w[0], w.Wt1, 64, 3);
   hipLaunchKernelGGL(pn_count_kernel, dim3(1), dim3(1024), 0, s, valids, (int)M, (int)N, w.count, w.coop.ticket,
-                     iw.vlist);
+                     iw.vlist, conv_w[0], w.Wt1);
   for (int l = 1; l <= 5; ++l) {
     int splits;
     if (l == 1) {
