@@ -462,6 +462,12 @@ def main():
     used = [valid_per_batch[i % N_BATCHES] for i in range(max(1, args.steps))]
     valid_parts = sum(used) / len(used)
 
+    # A generation-2 collection (tens of ms with torch loaded) inside K ~2 ms steps would be the measurement, so the collector
+    # is emptied and switched off — BEFORE the warm-up steps: the same collection between warm-up and the timed region left
+    # the GPU idle for those tens of ms, its clocks fell, and the first timed steps ran like the first steps of a process
+    # (tools/exp_step_profile.py: 3.07, 2.37, 2.33, 2.30 ms, then 2.26) — ~1 ms on top of a 20-step region.
+    gc.collect()
+    gc.disable()
     # untimed: W warm-up steps (+ the eager settle steps and the capture itself in graph mode)
     for i in range(args.warmup + (trainer.graph_warmup + 1 if use_graph else 0)):
         trainer.train_step(batches[i % N_BATCHES], i)
@@ -472,8 +478,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    gc.collect()
-    gc.disable()  # a generation-2 collection (tens of ms with torch loaded) inside K ~3 ms steps would be the measurement
     fence()
     # Inside the timed region only the roofline kernel is bracketed by HIP events (recorded by the library right around
     # it: two records per step); the per-phase table of every entry point (~60 records per step, 0.1 ms of gaps in a
