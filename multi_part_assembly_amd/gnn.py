@@ -84,7 +84,8 @@ class _PairMLP(nn.Module):
     def forward_pairs(self, a, b):
         """Rows = (sample, part i), positions = part j, input [a_i ; b_j]: a, b [B, P, F] -> [B*P, P, F_out]."""
         B, P, F = a.shape
-        if self._hip_ok(a, 2 * F, B * P * P) and self.PAIR_LAYER and pair_layer_supported(F, 512):
+        if (self._hip_ok(a, 2 * F, B * P * P) and self.PAIR_LAYER and pair_layer_supported(F, 512)
+                and P <= 1024 and B * P <= (1 << 20)):  # (mpa_pair_layer_*'s envelope; beyond it: the pair rows below)
             # conv1 of [a_i ; b_j] = (a Wa^T + bias)_i + (b Wb^T)_j: two GEMMs over the B*P part rows, the pair tensor is
             # never built (csrc/mlp.hip: mpa_pair_layer_*); BatchNorm statistics over all B*P*P rows as upstream
             h = pair_layer(a, b, self.conv1.weight, self.conv1.bias, self.bn1, relu=True, training=self.training)
