@@ -315,7 +315,8 @@ int mpa_mlp_layer_backward(const float* grad_out, const float* x, int64_t ldx, c
  * BatchNorm statistics taken over all B*P*P rows as the reference's BatchNorm1d does.
  * a, b [B*P, F] row-major, w [N, 2F], bias [N] or NULL, gamma / beta / running_* [N] (the layer has a BatchNorm);
  * out [B*P*P, N], row (s, i, j) at (s*P + i)*P + j.  F and N multiples of 64.  `ws`: mpa_pair_layer_workspace bytes,
- * 256-byte aligned, carried from forward to backward, which overwrites grad_a / grad_b [B*P, F] (each if non-NULL),
+ * 256-byte aligned, carried from forward to backward, which overwrites grad_a / grad_b [B*P, F] (each if non-NULL;
+ * grad_b == grad_a — one tensor in both roles, as the networks call it — receives the sum of the two),
  * grad_w [N, 2F], grad_bias [N] (if non-NULL), grad_gamma / grad_beta [N].  Fixed-order reductions: deterministic.
  * ---------------------------------------------------------------------------------------------- */
 int mpa_pair_layer_workspace(int64_t B, int64_t P, int64_t F, int64_t N, int64_t* bytes);

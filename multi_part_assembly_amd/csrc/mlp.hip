@@ -707,7 +707,12 @@ extern "C" int mpa_pair_layer_backward(const float* grad_out, const float* a, co
     g.M = (int)M;
     g.N = (int)F;
     g.K = (int)N;
-    tfg::launch_gemm<tfg::EPI_NONE, true>(g, s);
+    if (half == 1 && grad_b == grad_a) {  // one tensor in both roles: its gradient is the sum (added in the second GEMM's
+      g.resid = grad_a;                   // output pass: every element is read and written by the same thread)
+      tfg::launch_gemm<tfg::EPI_DROP_RESID, true>(g, s);  // (drop.p = 0: resid + value)
+    } else {
+      tfg::launch_gemm<tfg::EPI_NONE, true>(g, s);
+    }
   }
   return mpa::check_launch("pair_layer_backward");
 }

@@ -100,6 +100,7 @@ class _PairLayerFn(torch.autograd.Function):
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_pair_layer_forward")
         ctx.meta = (bool(relu), bool(training), bias is not None)
+        ctx.same = a.data_ptr() == b.data_ptr() and a.shape == b.shape
         ctx.params = [p for p in (weight, bias, gamma, beta) if p is not None]
         GradSink.note_use(ctx.params)
         ctx.save_for_backward(a, b, w, gamma, out, ws)
@@ -120,6 +121,9 @@ class _PairLayerFn(torch.autograd.Function):
         dev = a.device
         ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        same = ctx.same and ga is not None and gb is not None
+        if same:
+            gb = ga  # one tensor in both roles: the library adds the second half's gradient into the first's buffer
         bufs, direct = GradSink.outputs(ctx.params)
         it = iter(bufs)
         gw = next(it)
@@ -134,6 +138,8 @@ class _PairLayerFn(torch.autograd.Function):
                 _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
         _lib.check(st, "mpa_pair_layer_backward")
+        if same:
+            gb = None  # (already inside ga)
         if direct:
             GradSink.delivered(ctx.params)
             return (ga, gb) + (None,) * 9
