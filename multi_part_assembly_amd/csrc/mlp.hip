@@ -269,15 +269,25 @@ __global__ __launch_bounds__(256) void pair_sum_stats_kernel(const float* __rest
                                                              float* __restrict__ partial) {
   const long long r0 = (long long)blockIdx.x * kRT;
   const int rows = R - r0 < kRT ? (int)(R - r0) : kRT;
+  // (sample s, part i, part j) of the tile's first row, then counted up row by row: three 64-bit divisions per row and
+  // thread were most of this kernel's 20 us
+  const int bi0 = (int)(r0 / P), j0 = (int)(r0 % P), s0 = bi0 / P, i0 = bi0 % P;
   for (int c = threadIdx.x; c < C; c += 256) {
     float va[kRT], vb[kRT];
+    int sidx = s0, ii = i0, j = j0;
 #pragma unroll
     for (int i = 0; i < kRT; ++i) {
-      const long long r = r0 + (i < rows ? i : rows - 1);
-      const long long bi = r / P;                        // (sample, part i)
-      const long long bj = (bi / P) * P + r % P;         // (sample, part j)
-      va[i] = pa[bi * C + c];
-      vb[i] = pb[bj * C + c];
+      va[i] = pa[(long long)(sidx * P + ii) * C + c];
+      vb[i] = pb[(long long)(sidx * P + j) * C + c];
+      if (i + 1 < rows) {  // (rows behind the tile's end repeat the last one: never stored)
+        if (++j == P) {
+          j = 0;
+          if (++ii == P) {
+            ii = 0;
+            ++sidx;
+          }
+        }
+      }
     }
     float s = 0.0f, ss = 0.0f;
 #pragma unroll
