@@ -122,7 +122,9 @@ __global__ void ml_apply_kernel(const float* __restrict__ y, const float* __rest
                                 long long total4, int C, int relu, float* __restrict__ out) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total4) return;
-  const int c = 4 * (int)(e % (C / 4));
+  // column quad of element e = 256 blockIdx.x + threadIdx.x without a 64-bit remainder per thread
+  const unsigned q = (unsigned)(C / 4);
+  const int c = 4 * (int)(((blockIdx.x % q) * (blockDim.x % q) + threadIdx.x) % q);
   const float4 x = reinterpret_cast<const float4*>(y)[e];
   float4 z;
   if (bn != nullptr) {
