@@ -25,7 +25,7 @@ extern "C" {
 #define MPA_ELAUNCH (-2) /* hipGetLastError() reported a launch failure */
 
 /* ABI version of this header; bumped whenever a signature changes. */
-#define MPA_ABI_VERSION 7
+#define MPA_ABI_VERSION 8
 int mpa_abi_version(void);
 
 /* Thread-local, NUL-terminated description of the last failure on this thread ("" if none). */
@@ -154,7 +154,7 @@ int mpa_assembly_loss_forward(const float* part_pcs, const float* valids, const 
                               float* float_ws, int32_t* int_ws, float* losses, void* stream);
 /* Profiling twin: identical launches; `events` (may be NULL) is a host array of 7 hipEvent_t recorded on
  * `stream`: [0] start, [1] after pose kernel, [2] after per-part Chamfer, [3] after the whole-shape Chamfer
- * phase, [4] after finalize, [5]/[6] right before/after the grid search kernel itself — so a benchmark can
+ * phase, [4] after finalize, [5]/[6] right before/after the whole-shape search kernel itself — so a benchmark can
  * time the dominant kernel inside its timed region.  Individual entries may be NULL (e.g. only [5] and [6] set: two
  * records per call instead of seven). */
 int mpa_assembly_loss_forward_timed(const float* part_pcs, const float* valids, const float* quat_pred,
@@ -162,6 +162,23 @@ int mpa_assembly_loss_forward_timed(const float* part_pcs, const float* valids, 
                                     int64_t B, int64_t P, int64_t N, int training, int fill_pad_points,
                                     float* float_ws, int32_t* int_ws, float* losses, void* const* events,
                                     void* stream);
+/* The spatial structure behind both Chamfer searches of the loss.  Every cloud the loss searches — rot_pc / transform_pc of
+ * part_pcs under the predicted and the ground-truth pose (utils/loss.py:127-129,177-183) — is a rigid image of the same
+ * source points, so ONE balanced k-d ordering of each valid part's N points (leaves of 32) serves them all: it depends on
+ * part_pcs and valids only, not on any pose.  mpa_assembly_order writes it (order: mpa_assembly_order_elems floats =
+ * [B*P][Npad] x (local x, y, z, original index), Npad = the power of two >= max(N, 32); 0 floats and a no-op when
+ * N > 2048, where the loss keeps its grid search); mpa_assembly_loss_forward_ordered is mpa_assembly_loss_forward_timed
+ * taking that ordering, so a training step orders its batch once and evaluates the loss as often as the model asks
+ * (3 GNN iterations, min-of-N samples).  order == NULL: computed into the workspace by the call itself.  The ordering
+ * steers speed only — results are the exhaustive scan's, bit for bit, for any permutation. */
+int mpa_assembly_order_elems(int64_t B, int64_t P, int64_t N, int64_t* float_elems);
+int mpa_assembly_order(const float* part_pcs, const float* valids, int64_t B, int64_t P, int64_t N, float* order,
+                       void* stream);
+int mpa_assembly_loss_forward_ordered(const float* part_pcs, const float* valids, const float* quat_pred,
+                                      const float* trans_pred, const float* quat_gt, const float* trans_gt,
+                                      int64_t B, int64_t P, int64_t N, int training, int fill_pad_points,
+                                      const float* order, float* float_ws, int32_t* int_ws, float* losses,
+                                      void* const* events, void* stream);
 /* grad_losses [5,B] = d(objective)/d(losses); writes grad_quat [B,P,4] and grad_trans [B,P,3] of the
  * PREDICTED pose.  Deterministic (no atomics). */
 int mpa_assembly_loss_backward(const float* grad_losses, const float* part_pcs, const float* valids,

@@ -37,4 +37,24 @@ int launch_cloud_grid_search(const float* xyz1, const float* xyz2, int64_t B, in
 void launch_cloud_copy_runs(int64_t B, int64_t n1, int64_t n2, float* dist1, int64_t* idx1, float* dist2, int64_t* idx2,
                             void* workspace, hipStream_t s);
 
+// ---- leaf search (leaf_nn.hip): the Chamfer searches of the fused loss over per-part k-d leaves -------------------------------
+// One transformed cloud as the pose kernel leaves it: records [B*P][Npad] float4 in the parts' k-d order, one box per
+// leaf [B*P][Npad / 32][8] and per part [B*P][8] (lo xyz, -, hi xyz, -), and the cloud in original order [B, P, N, 3].
+struct LeafCloud {
+  const float* rec;
+  const float* leaf;
+  const float* part;
+  const float* orig;
+};
+int leaf_npad(int64_t N);                  // slots per part: the power of two >= max(N, 32)
+bool leaf_supported(int64_t P, int64_t N);  // P <= 64 parts, N <= 2048 points per part
+// k-d order of every valid part's points: sorted [B*P][Npad] float4 (local x, y, z, original index | -1)
+void launch_leaf_order(const float* part_pcs, const float* valids, int64_t B, int64_t P, int64_t N, float* sorted,
+                       hipStream_t s);
+// exact NN of cloud A's valid points in cloud B (idx1) and vice versa (idx2): shape = every point against the sample's whole
+// other shape (indices p * N + n), else every part against its own copy (indices n); per-block distance sums into
+// tile_sums[dir][m * tilesq + tile], tilesq = max(1, Npad / 256)
+void launch_leaf_search(bool shape, const float* valids, const LeafCloud& A, const LeafCloud& B_, int64_t B, int64_t P,
+                        int64_t N, int tilesq, int32_t* idx1, int32_t* idx2, float* tile_sums, hipStream_t s);
+
 }  // namespace mpa

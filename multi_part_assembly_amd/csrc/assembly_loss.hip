@@ -174,6 +174,124 @@ __global__ __launch_bounds__(kThreads) void assembly_pose_kernel(
   }
 }
 
+// ---- pose kernel of the leaf search (leaf_nn.hip) ------------------------------------------------------
+// Same outputs as assembly_pose_kernel, but the part's points are walked in the k-d order of `sorted`
+// ([B*P][Npad] float4: local x, y, z, original index n | -1, leaf_nn.hip) and every cloud additionally leaves what
+// the leaf search reads: records (x, y, z, index) in that order — index n for the rotation-only clouds (per-part
+// Chamfer), p * N + n for the whole shapes — one box per leaf of 32 slots (a half wave) and one per part.  The boxes
+// of the translated clouds are the rotated clouds' boxes plus the translation: fl(a + t) is monotone in a, so this
+// IS the box of the stored translated points.
+struct LeafOut {
+  float4* rec[4];   // R1, R2, S1, S2
+  float* leaf[4];
+  float* part[4];
+};
+
+__global__ __launch_bounds__(kThreads) void assembly_pose_leaf_kernel(
+    const float4* __restrict__ sorted, const float* __restrict__ valids, const float* __restrict__ q1,
+    const float* __restrict__ t1, const float* __restrict__ q2, const float* __restrict__ t2, int P, int N, int Npad,
+    int fill_pads, float* __restrict__ R1, float* __restrict__ R2, float* __restrict__ S1, float* __restrict__ S2,
+    float* __restrict__ partial, LeafOut out) {
+  __shared__ float red[kThreads / 64];
+  __shared__ float box[kThreads / 32][12];
+  const int m = blockIdx.x, p = m % P;
+  const Quat qa = load_quat(q1 + 4 * m), qb = load_quat(q2 + 4 * m);
+  const float ta[3] = {t1[3 * m], t1[3 * m + 1], t1[3 * m + 2]};
+  const float tb[3] = {t2[3 * m], t2[3 * m + 1], t2[3 * m + 2]};
+  const long long base = 3LL * m * N;
+  if (valids[m] == 0.0f) {
+    const int count = fill_pads ? N : 1;
+    for (int n = threadIdx.x; n < count; n += kThreads) {
+      float ax, ay, az, bx, by, bz;
+      quat_apply(qa, kPadFill, kPadFill, kPadFill, ax, ay, az);
+      quat_apply(qb, kPadFill, kPadFill, kPadFill, bx, by, bz);
+      const long long o = base + 3LL * n;
+      S1[o] = ax + ta[0]; S1[o + 1] = ay + ta[1]; S1[o + 2] = az + ta[2];
+      S2[o] = bx + tb[0]; S2[o + 1] = by + tb[1]; S2[o + 2] = bz + tb[2];
+    }
+    if (threadIdx.x < 5) partial[5 * m + threadIdx.x] = 0.0f;
+    return;
+  }
+  const float inf = __builtin_inff();
+  const int NL = Npad / 32;
+  float l2 = 0.0f;
+  float pb[12] = {inf, inf, inf, inf, inf, inf, -inf, -inf, -inf, -inf, -inf, -inf};  // lo a, lo b, hi a, hi b (this half wave's leaves)
+  for (int k0 = 0; k0 < Npad; k0 += kThreads) {
+    const int k = k0 + threadIdx.x;  // (Npad is a power of two >= 32: a half wave is wholly inside or outside)
+    const bool in = k < Npad;
+    const float4 r = sorted[(long long)m * Npad + (in ? k : 0)];
+    const int n = __float_as_int(r.w);
+    const bool real = in && n >= 0;
+    float ax, ay, az, bx, by, bz;
+    quat_apply(qa, r.x, r.y, r.z, ax, ay, az);
+    quat_apply(qb, r.x, r.y, r.z, bx, by, bz);
+    const float s1[3] = {ax + ta[0], ay + ta[1], az + ta[2]}, s2[3] = {bx + tb[0], by + tb[1], bz + tb[2]};
+    if (real) {
+      const long long o = base + 3LL * n;
+      R1[o] = ax; R1[o + 1] = ay; R1[o + 2] = az;
+      R2[o] = bx; R2[o + 1] = by; R2[o + 2] = bz;
+      S1[o] = s1[0]; S1[o + 1] = s1[1]; S1[o + 2] = s1[2];
+      S2[o] = s2[0]; S2[o + 1] = s2[1]; S2[o + 2] = s2[2];
+      const float dx = ax - bx, dy = ay - by, dz = az - bz;
+      l2 += (dx * dx + dy * dy) + dz * dz;
+    }
+    if (in) {
+      const long long e = (long long)m * Npad + k;
+      const float none = __int_as_float(0x7fffffff);
+      out.rec[0][e] = real ? make_float4(ax, ay, az, __int_as_float(n)) : make_float4(inf, inf, inf, none);
+      out.rec[1][e] = real ? make_float4(bx, by, bz, __int_as_float(n)) : make_float4(inf, inf, inf, none);
+      out.rec[2][e] = real ? make_float4(s1[0], s1[1], s1[2], __int_as_float(p * N + n)) : make_float4(inf, inf, inf, none);
+      out.rec[3][e] = real ? make_float4(s2[0], s2[1], s2[2], __int_as_float(p * N + n)) : make_float4(inf, inf, inf, none);
+    }
+    float bb[12] = {real ? ax : inf,  real ? ay : inf,  real ? az : inf,  real ? bx : inf,  real ? by : inf,  real ? bz : inf,
+                    real ? ax : -inf, real ? ay : -inf, real ? az : -inf, real ? bx : -inf, real ? by : -inf, real ? bz : -inf};
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        const float o = __shfl_xor(bb[c], off, 64);
+        bb[c] = c < 6 ? __builtin_fminf(bb[c], o) : __builtin_fmaxf(bb[c], o);
+      }
+      pb[c] = c < 6 ? __builtin_fminf(pb[c], bb[c]) : __builtin_fmaxf(pb[c], bb[c]);
+    }
+    if (in && (threadIdx.x & 31) == 0) {
+      const long long lf = ((long long)m * NL + (k >> 5)) * 8;
+      float4* la = reinterpret_cast<float4*>(out.leaf[0] + lf);
+      float4* lb = reinterpret_cast<float4*>(out.leaf[1] + lf);
+      float4* lc = reinterpret_cast<float4*>(out.leaf[2] + lf);
+      float4* ld = reinterpret_cast<float4*>(out.leaf[3] + lf);
+      la[0] = make_float4(bb[0], bb[1], bb[2], 0.0f);
+      la[1] = make_float4(bb[6], bb[7], bb[8], 0.0f);
+      lb[0] = make_float4(bb[3], bb[4], bb[5], 0.0f);
+      lb[1] = make_float4(bb[9], bb[10], bb[11], 0.0f);
+      lc[0] = make_float4(bb[0] + ta[0], bb[1] + ta[1], bb[2] + ta[2], 0.0f);
+      lc[1] = make_float4(bb[6] + ta[0], bb[7] + ta[1], bb[8] + ta[2], 0.0f);
+      ld[0] = make_float4(bb[3] + tb[0], bb[4] + tb[1], bb[5] + tb[2], 0.0f);
+      ld[1] = make_float4(bb[9] + tb[0], bb[10] + tb[1], bb[11] + tb[2], 0.0f);
+    }
+  }
+  if ((threadIdx.x & 31) == 0) {
+#pragma unroll
+    for (int c = 0; c < 12; ++c) box[threadIdx.x >> 5][c] = pb[c];
+  }
+  const float s = block_sum(l2, red);  // (its barrier also publishes `box`)
+  if (threadIdx.x == 0) partial[5 * m + 0] = s;
+  if (threadIdx.x < 12) {
+    const int c = threadIdx.x;
+    float v = box[0][c];
+#pragma unroll
+    for (int w = 1; w < kThreads / 32; ++w) v = c < 6 ? __builtin_fminf(v, box[w][c]) : __builtin_fmaxf(v, box[w][c]);
+    // c: 0-2 lo a, 3-5 lo b, 6-8 hi a, 9-11 hi b -> box layout (lo xyz, -, hi xyz, -)
+    // (select chains: a runtime index into ta / tb / out.part sends them to scratch memory)
+    const int cloud = (c / 3) & 1, hi = c / 6, ax = c % 3;
+    const float tA = ax == 0 ? ta[0] : (ax == 1 ? ta[1] : ta[2]), tB = ax == 0 ? tb[0] : (ax == 1 ? tb[1] : tb[2]);
+    float* pr = cloud == 0 ? out.part[0] : out.part[1];
+    float* ps = cloud == 0 ? out.part[2] : out.part[3];
+    pr[8LL * m + 4 * hi + ax] = v;
+    ps[8LL * m + 4 * hi + ax] = v + (cloud == 0 ? tA : tB);
+  }
+}
+
 // ---- NN kernels -------------------------------------------------------------------------------------
 // Work decomposition: one block = 64*Q QUERY points of one valid part, shared by the block's 4 waves;
 // the TARGET set is split evenly between the waves (chunk-aligned), each wave runs the
@@ -294,7 +412,7 @@ __global__ __launch_bounds__(64) void assembly_finalize_kernel(
     const float* __restrict__ valids, const float* __restrict__ q1, const float* __restrict__ t1,
     const float* __restrict__ q2, const float* __restrict__ t2, const float* __restrict__ partial,
     const float* __restrict__ part_tiles, const float* __restrict__ shape_tiles, int B, int P, int N,
-    int tiles, int training, float* __restrict__ losses) {
+    int tiles_p, int tiles_s, int training, float* __restrict__ losses) {
   const int b = blockIdx.x, p = threadIdx.x;
   float v = 0.0f, trans = 0.0f, cosine = 0.0f, cd = 0.0f, l2 = 0.0f, scd_slots = 0.0f, scd_parts = 0.0f;
   if (p < P) {
@@ -307,12 +425,15 @@ __global__ __launch_bounds__(64) void assembly_finalize_kernel(
                         q1[4 * m + 3] * q2[4 * m + 3];
       cosine = (1.0f - __builtin_fabsf(dot)) * v;
       float c1 = 0.0f, c2 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-      const long long nblk = (long long)B * P * tiles;
-      for (int t = 0; t < tiles; ++t) {
-        c1 += part_tiles[(long long)m * tiles + t];
-        c2 += part_tiles[nblk + (long long)m * tiles + t];
-        s1 += shape_tiles[(long long)m * tiles + t];
-        s2 += shape_tiles[nblk + (long long)m * tiles + t];
+      // (the two searches may cut a part into different numbers of tiles: brute force / grid vs leaf search)
+      const long long nblk_p = (long long)B * P * tiles_p, nblk_s = (long long)B * P * tiles_s;
+      for (int t = 0; t < tiles_p; ++t) {
+        c1 += part_tiles[(long long)m * tiles_p + t];
+        c2 += part_tiles[nblk_p + (long long)m * tiles_p + t];
+      }
+      for (int t = 0; t < tiles_s; ++t) {
+        s1 += shape_tiles[(long long)m * tiles_s + t];
+        s2 += shape_tiles[nblk_s + (long long)m * tiles_s + t];
       }
       const float inv_n = 1.0f / (float)N;
       cd = (c1 * inv_n + c2 * inv_n) * v;                  // mean_N d1 + mean_N d2   (loss.py:132)
@@ -505,6 +626,13 @@ __global__ void assembly_backward_finish_kernel(const float* __restrict__ go, co
   else gt[3 * m + (k - 4)] = s;
 }
 
+// floats the leaf search adds to the workspace: order + 4 record arrays (float4 per slot), 4 x leaf boxes, 4 x part boxes
+int64_t leaf_workspace_floats(int64_t B, int64_t P, int64_t N) {
+  if (!mpa::leaf_supported(P, N)) return 0;
+  const int64_t npad = mpa::leaf_npad(N);
+  return 20 * B * P * npad + 32 * B * P * (npad / 32) + 32 * B * P;
+}
+
 }  // namespace
 
 extern "C" int mpa_assembly_loss_workspace(int64_t B, int64_t P, int64_t N, int64_t* float_elems,
@@ -512,9 +640,26 @@ extern "C" int mpa_assembly_loss_workspace(int64_t B, int64_t P, int64_t N, int6
   MPA_REQUIRE(B >= 0 && P >= 0 && N >= 0 && float_elems && int_elems, "assembly_loss_workspace: bad args");
   const int64_t tiles = (N + kMinTile - 1) / kMinTile;
   // 4 clouds + partial[5] + 2 tile-sum arrays (2 directions each), rounded to 16 B, + grid-search scratch
-  *float_elems = (4 * B * P * N * 3 + 5 * B * P + 4 * B * P * tiles + 3) / 4 * 4 + mpa::grid_workspace_floats(B, P, N);
+  *float_elems = (4 * B * P * N * 3 + 5 * B * P + 4 * B * P * tiles + 3) / 4 * 4 + mpa::grid_workspace_floats(B, P, N) +
+                 leaf_workspace_floats(B, P, N);
   *int_elems = 4 * B * P * N + mpa::grid_workspace_ints(B);
   return MPA_OK;
+}
+
+extern "C" int mpa_assembly_order_elems(int64_t B, int64_t P, int64_t N, int64_t* float_elems) {
+  MPA_REQUIRE(B >= 0 && P >= 0 && N >= 0 && float_elems, "assembly_order_elems: bad args");
+  *float_elems = mpa::leaf_supported(P, N) ? 4 * B * P * (int64_t)mpa::leaf_npad(N) : 0;
+  return MPA_OK;
+}
+
+extern "C" int mpa_assembly_order(const float* part_pcs, const float* valids, int64_t B, int64_t P, int64_t N,
+                                  float* order, void* stream) {
+  MPA_REQUIRE(B >= 0 && P >= 0 && N >= 0, "assembly_order: negative size");
+  if (B == 0 || !mpa::leaf_supported(P, N)) return MPA_OK;  // (nothing to order: the loss takes its grid search)
+  MPA_REQUIRE(part_pcs && valids && order, "assembly_order: null pointer");
+  MPA_REQUIRE(B * P * (int64_t)mpa::leaf_npad(N) < (1LL << 31), "assembly_order: problem too large");
+  mpa::launch_leaf_order(part_pcs, valids, B, P, N, order, mpa::as_stream(stream));
+  return mpa::check_launch("assembly_order");
 }
 
 namespace {
@@ -522,14 +667,20 @@ struct Workspace {
   float *R1, *R2, *S1, *S2, *partial, *part_tiles, *shape_tiles, *grid_f;
   int *ip1, *ip2, *is1, *is2, *grid_i;
   int tiles;
+  // leaf search (leaf_nn.hip): the library's own k-d order (callers may hand one in), records / leaf boxes / part boxes
+  // of the four clouds R1, R2, S1, S2
+  float *order, *rec[4], *leaf[4], *pbox[4];
 };
 
-// Whole-shape search: exact grid-pruned search (default) or the brute-force scan (MPA_SHAPE_SEARCH=brute);
-// identical results, the brute force stays as the cross-check (tests/test_loss_gpu.py).
-bool use_grid_search() {
+// 0: brute-force scan, 1: grid-pruned search (grid_nn.hip), 2: leaf search (leaf_nn.hip; default).  Identical results;
+// MPA_SHAPE_SEARCH = brute | grid | leaf selects (tests cross-check all three).
+int search_mode(int64_t P, int64_t N) {
   const char* e = getenv("MPA_SHAPE_SEARCH");
-  return !(e && e[0] == 'b');
+  if (e && e[0] == 'b') return 0;
+  if ((e && e[0] == 'g') || !mpa::leaf_supported(P, N)) return P <= 64 ? 1 : 0;  // (the grid keeps one padded part per lane)
+  return 2;
 }
+
 // Queries per lane of the NN scans: 4 (fewer, fatter blocks) when there is enough work to fill the chip,
 // else 2.  MPA_ASSEMBLY_Q=2|4 overrides (tuning only).
 int pick_q(int64_t B, int64_t P, int64_t N) {
@@ -559,16 +710,23 @@ Workspace carve(float* fws, int32_t* iws, int64_t B, int64_t P, int64_t N, int q
   w.grid_i = iws + 4 * pn;
   const int64_t min_tiles = (N + kMinTile - 1) / kMinTile;
   w.grid_f = fws + (4 * cloud + 5 * B * P + 4 * B * P * min_tiles + 3) / 4 * 4;
+  float* lf = w.grid_f + mpa::grid_workspace_floats(B, P, N);
+  const int64_t npad = mpa::leaf_supported(P, N) ? mpa::leaf_npad(N) : 0;
+  w.order = lf;
+  lf += 4 * B * P * npad;
+  for (int c = 0; c < 4; ++c, lf += 4 * B * P * npad) w.rec[c] = lf;
+  for (int c = 0; c < 4; ++c, lf += 8 * B * P * (npad / 32)) w.leaf[c] = lf;
+  for (int c = 0; c < 4; ++c, lf += 8 * B * P) w.pbox[c] = lf;
   return w;
 }
 }  // namespace
 
-extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const float* valids,
-                                               const float* quat_pred, const float* trans_pred,
-                                               const float* quat_gt, const float* trans_gt, int64_t B,
-                                               int64_t P, int64_t N, int training, int fill_pad_points,
-                                               float* float_ws, int32_t* int_ws, float* losses,
-                                               void* const* events, void* stream);
+extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const float* valids,
+                                                 const float* quat_pred, const float* trans_pred,
+                                                 const float* quat_gt, const float* trans_gt, int64_t B,
+                                                 int64_t P, int64_t N, int training, int fill_pad_points,
+                                                 const float* order, float* float_ws, int32_t* int_ws,
+                                                 float* losses, void* const* events, void* stream);
 
 extern "C" int mpa_assembly_loss_forward(const float* part_pcs, const float* valids,
                                          const float* quat_pred, const float* trans_pred,
@@ -576,20 +734,35 @@ extern "C" int mpa_assembly_loss_forward(const float* part_pcs, const float* val
                                          int64_t P, int64_t N, int training, int fill_pad_points,
                                          float* float_ws, int32_t* int_ws, float* losses,
                                          void* stream) {
-  return mpa_assembly_loss_forward_timed(part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, B, P, N,
-                                         training, fill_pad_points, float_ws, int_ws, losses, nullptr, stream);
+  return mpa_assembly_loss_forward_ordered(part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, B, P, N,
+                                           training, fill_pad_points, nullptr, float_ws, int_ws, losses, nullptr,
+                                           stream);
 }
 
-// Same launches; when `events` is non-null it holds 7 hipEvent_t recorded on `stream`: [0] start, [1] after
-// the pose kernel, [2] after the per-part Chamfer, [3] after the whole-shape Chamfer phase (grid build +
-// search + part sums), [4] after the finalize kernel, [5]/[6] immediately before/after the grid search kernel
-// itself (left untouched by the brute-force path).  bench.py times the dominant kernel with them.
 extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const float* valids,
                                                const float* quat_pred, const float* trans_pred,
                                                const float* quat_gt, const float* trans_gt, int64_t B,
                                                int64_t P, int64_t N, int training, int fill_pad_points,
                                                float* float_ws, int32_t* int_ws, float* losses,
                                                void* const* events, void* stream) {
+  return mpa_assembly_loss_forward_ordered(part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, B, P, N,
+                                           training, fill_pad_points, nullptr, float_ws, int_ws, losses, events,
+                                           stream);
+}
+
+// Same launches; when `events` is non-null it holds 7 hipEvent_t recorded on `stream`: [0] start, [1] after
+// the pose kernel (and, when `order` is null, the k-d ordering in front of it), [2] after the per-part Chamfer,
+// [3] after the whole-shape Chamfer phase, [4] after the finalize kernel, [5]/[6] immediately before/after the
+// whole-shape search kernel itself (leaf or grid search; left untouched by the brute-force path).  bench.py times
+// the dominant kernel with them.
+// `order` (nullable): the k-d order of this batch's parts from mpa_assembly_order — a function of part_pcs and valids
+// only, so one ordering serves every loss evaluation of a step (GNN iterations, min-of-N samples); null: computed here.
+extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const float* valids,
+                                                 const float* quat_pred, const float* trans_pred,
+                                                 const float* quat_gt, const float* trans_gt, int64_t B,
+                                                 int64_t P, int64_t N, int training, int fill_pad_points,
+                                                 const float* order, float* float_ws, int32_t* int_ws,
+                                                 float* losses, void* const* events, void* stream) {
   auto mark = [&](int k) {
     if (events != nullptr && events[k] != nullptr)  // (entries may be null: time only some of the phases)
       (void)hipEventRecord(reinterpret_cast<hipEvent_t>(events[k]), mpa::as_stream(stream));
@@ -605,9 +778,43 @@ extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const floa
   const int q = pick_q(B, P, N);
   const Workspace w = carve(float_ws, int_ws, B, P, N, q);
   const unsigned parts = (unsigned)(B * P);
+  const int mode = search_mode(P, N);
   // padded parts never write their tile sums: clear them (2 directions x B*P*tiles, both arrays)
   mpa::zero_words_async(w.part_tiles, 4 * B * P * w.tiles, s);
   mark(0);
+  if (mode == 2) {
+    // ---- leaf search: k-d order (once per batch), pose kernel in that order, both searches over the leaves ----
+    const int npad = mpa::leaf_npad(N);
+    MPA_REQUIRE(B * P * (int64_t)npad < (1LL << 31), "assembly_loss_forward: problem too large");
+    const int tilesq = npad >= 256 ? npad / 256 : 1;  // (<= w.tiles: the tile-sum areas were sized for 128-point tiles)
+    if (order == nullptr) {
+      mpa::launch_leaf_order(part_pcs, valids, B, P, N, w.order, s);
+      order = w.order;
+    }
+    LeafOut lo;
+    for (int c = 0; c < 4; ++c) {
+      lo.rec[c] = reinterpret_cast<float4*>(w.rec[c]);
+      lo.leaf[c] = w.leaf[c];
+      lo.part[c] = w.pbox[c];
+    }
+    hipLaunchKernelGGL(assembly_pose_leaf_kernel, dim3(parts), dim3(kThreads), 0, s,
+                       reinterpret_cast<const float4*>(order), valids, quat_pred, trans_pred, quat_gt, trans_gt, (int)P,
+                       (int)N, npad, fill_pad_points, w.R1, w.R2, w.S1, w.S2, w.partial, lo);
+    mark(1);
+    const mpa::LeafCloud r1{w.rec[0], w.leaf[0], w.pbox[0], w.R1}, r2{w.rec[1], w.leaf[1], w.pbox[1], w.R2};
+    const mpa::LeafCloud s1{w.rec[2], w.leaf[2], w.pbox[2], w.S1}, s2{w.rec[3], w.leaf[3], w.pbox[3], w.S2};
+    mpa::launch_leaf_search(false, valids, r1, r2, B, P, N, tilesq, w.ip1, w.ip2, w.part_tiles, s);
+    mark(2);
+    mark(5);
+    mpa::launch_leaf_search(true, valids, s1, s2, B, P, N, tilesq, w.is1, w.is2, w.shape_tiles, s);
+    mark(6);
+    mark(3);
+    hipLaunchKernelGGL(assembly_finalize_kernel, dim3((unsigned)B), dim3(64), 0, s, valids, quat_pred,
+                       trans_pred, quat_gt, trans_gt, w.partial, w.part_tiles, w.shape_tiles, (int)B,
+                       (int)P, (int)N, tilesq, tilesq, training, losses);
+    mark(4);
+    return mpa::check_launch("assembly_loss_forward");
+  }
   hipLaunchKernelGGL(assembly_pose_kernel, dim3(parts), dim3(kThreads), 0, s, part_pcs, valids,
                      quat_pred, trans_pred, quat_gt, trans_gt, (int)N, fill_pad_points, w.R1, w.R2,
                      w.S1, w.S2, w.partial, mpa::grid_bbox(w.grid_f, B, P, N), mpa::grid_ticket(w.grid_i, B));
@@ -624,7 +831,7 @@ extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const floa
     hipLaunchKernelGGL((assembly_nn_kernel<2, mpa::kChunkMin, false>), grid, dim3(kThreads), 0, s, valids,
                        w.R1, w.R2, (int)B, (int)P, (int)N, w.tiles, remap, w.ip1, w.ip2, w.part_tiles);
   mark(2);
-  if (use_grid_search() && P <= 64)  // (the search keeps one padded-part representative per lane)
+  if (mode == 1)
     mpa::launch_grid_shape_search(valids, w.S1, w.S2, B, P, N, w.tiles, w.grid_f, w.grid_i, w.is1, w.is2,
                                   w.shape_tiles, events ? reinterpret_cast<hipEvent_t>(events[5]) : nullptr,
                                   events ? reinterpret_cast<hipEvent_t>(events[6]) : nullptr, s);
@@ -637,7 +844,7 @@ extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const floa
   mark(3);
   hipLaunchKernelGGL(assembly_finalize_kernel, dim3((unsigned)B), dim3(64), 0, s, valids, quat_pred,
                      trans_pred, quat_gt, trans_gt, w.partial, w.part_tiles, w.shape_tiles, (int)B,
-                     (int)P, (int)N, w.tiles, training, losses);
+                     (int)P, (int)N, w.tiles, w.tiles, training, losses);
   mark(4);
   return mpa::check_launch("assembly_loss_forward");
 }

@@ -15,7 +15,7 @@ from . import _lib
 from .chamfer import chamfer_distance
 from .transforms import pose_apply, rot_pc
 
-__all__ = ["geometric_assembly_loss", "LOSS_TERMS", "trans_l2_loss", "rot_l2_loss", "rot_cosine_loss", "rot_points_l2_loss",
+__all__ = ["geometric_assembly_loss", "part_order", "LOSS_TERMS", "trans_l2_loss", "rot_l2_loss", "rot_cosine_loss", "rot_points_l2_loss",
            "rot_points_cd_loss", "shape_cd_loss", "repulsion_cd_loss"]
 
 PAD_FILL = 1e3  # coordinate given to the points of padded parts in shape_cd_loss (loss.py:173-175)
@@ -113,11 +113,34 @@ class LossTerms(dict):
     stacked = None
 
 
+def part_order(part_pcs, valids):
+    """The k-d order of a batch's parts that both Chamfer searches of the fused loss run on (csrc/leaf_nn.hip,
+    `mpa_assembly_order`): a function of `part_pcs` and `valids` only — not of any pose — so ONE ordering serves every
+    loss evaluation of a step (the GNN iterations of DGL / RGL-NET, the min-of-N samples, both directions).  Returns a
+    float32 tensor to pass as `geometric_assembly_loss(..., order=...)`, or None where the loss keeps its grid search
+    (N > 2048).  Only steers speed: the loss is bit-identical with or without it."""
+    if not part_pcs.is_cuda:
+        raise RuntimeError("part_order: only CUDA (HIP) tensors are supported")
+    B, P, N, _ = part_pcs.shape
+    L = _lib.lib()
+    ne = ctypes.c_int64()
+    _lib.check(L.mpa_assembly_order_elems(B, P, N, ctypes.byref(ne)), "mpa_assembly_order_elems")
+    if ne.value == 0:
+        return None
+    pcs = part_pcs.detach().to(torch.float32).contiguous()
+    v = valids.detach().to(torch.float32).contiguous()
+    order = torch.empty(ne.value, dtype=torch.float32, device=pcs.device)
+    with torch.cuda.device(pcs.device):
+        st = L.mpa_assembly_order(_lib.ptr(pcs), _lib.ptr(v), B, P, N, _lib.ptr(order), _lib.current_stream(pcs.device))
+    _lib.check(st, "mpa_assembly_order")
+    return order
+
+
 class _AssemblyLoss(torch.autograd.Function):
     """All five geometric loss terms in 5 launches forward / 1 launch backward (csrc/assembly_loss.hip)."""
 
     @staticmethod
-    def forward(ctx, part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, training, fill_pads):
+    def forward(ctx, part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, training, fill_pads, order=None):
         B, P, N, _ = part_pcs.shape
         dev = part_pcs.device
         L = _lib.lib()
@@ -133,17 +156,18 @@ class _AssemblyLoss(torch.autograd.Function):
             names = [k + tag for k in ("assembly_pose", "assembly_part_chamfer", "assembly_shape_chamfer",
                                        "assembly_finalize")]
             evs = _lib.KernelTimer.phase_events(names)
-            gs = _lib.KernelTimer.phase_events(["grid_search_kernel" + tag])
+            gs = _lib.KernelTimer.phase_events(["shape_search_kernel" + tag])
             both = None
             if evs is not None or gs is not None:
                 both = (evs if evs is not None else [None] * 5) + (gs if gs is not None else [None] * 2)
-            st = L.mpa_assembly_loss_forward_timed(
+            st = L.mpa_assembly_loss_forward_ordered(
                 _lib.ptr(part_pcs), _lib.ptr(valids), _lib.ptr(quat_pred), _lib.ptr(trans_pred),
                 _lib.ptr(quat_gt), _lib.ptr(trans_gt), B, P, N, int(training), int(fill_pads),
+                _lib.ptr(order) if order is not None else None,
                 _lib.ptr(fws), _lib.ptr(iws), _lib.ptr(losses), _lib.KernelTimer.handles(both),
                 _lib.current_stream(dev))
             _lib.KernelTimer.add_phases(names, evs)
-            _lib.KernelTimer.add_phases(["grid_search_kernel" + tag], gs)
+            _lib.KernelTimer.add_phases(["shape_search_kernel" + tag], gs)
         _lib.check(st, "mpa_assembly_loss_forward")
         ctx.save_for_backward(part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, fws, iws)
         ctx.training = int(training)
@@ -159,7 +183,7 @@ class _AssemblyLoss(torch.autograd.Function):
             raise RuntimeError("assembly loss: the backward pass reuses the forward's tile-sum area as scratch: a second "
                                "backward over the same forward (retain_graph=True) is not supported — run the forward again")
         if grad_losses is None:
-            return (None,) * 8
+            return (None,) * 9
         ctx.consumed = True
         part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, fws, iws = ctx.saved_tensors
         B, P, N, _ = part_pcs.shape
@@ -173,16 +197,18 @@ class _AssemblyLoss(torch.autograd.Function):
                 _lib.ptr(trans_pred), _lib.ptr(quat_gt), _lib.ptr(trans_gt), B, P, N, ctx.training,
                 _lib.ptr(fws), _lib.ptr(iws), _lib.ptr(gq), _lib.ptr(gt), _lib.current_stream(dev))
         _lib.check(st, "mpa_assembly_loss_backward")
-        return None, None, gq, gt, None, None, None, None
+        return None, None, gq, gt, None, None, None, None, None
 
 
 def geometric_assembly_loss(part_pcs, pred_trans, pred_rot, gt_trans, gt_rot, valids, training=True,
-                            ret_pts=False):
+                            ret_pts=False, order=None):
     """The loss terms of `BaseModel._calc_loss` for geometric data, fused (no GT re-matching).
 
     Returns ({name: [B]} for LOSS_TERMS, pts) where pts is None or, with ret_pts,
     (pred_trans_pts, gt_trans_pts) [B,P,N,3] as shape_cd_loss(..., ret_pts=True) returns them.
     Gradients flow to pred_trans and pred_rot only (the GT pose is detached, as in the reference).
+    `order`: `part_order(part_pcs, valids)` of this batch when the caller evaluates the loss more than once per batch
+    (computed by the call itself when None).
     """
     if not part_pcs.is_cuda:
         raise RuntimeError("geometric_assembly_loss: only CUDA (HIP) tensors are supported")
@@ -191,7 +217,7 @@ def geometric_assembly_loss(part_pcs, pred_trans, pred_rot, gt_trans, gt_rot, va
     losses, pts = _AssemblyLoss.apply(
         f(part_pcs), f(valids), _quat(pred_rot).to(torch.float32).contiguous(),
         pred_trans.to(torch.float32).contiguous(), f(_quat(gt_rot)), f(gt_trans), bool(training),
-        bool(ret_pts))
+        bool(ret_pts), order)
     terms = LossTerms((name, losses[i]) for i, name in enumerate(LOSS_TERMS))
     terms.stacked = (LOSS_TERMS, losses)
     return terms, ((pts[2], pts[3]) if ret_pts else None)

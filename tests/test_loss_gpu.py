@@ -143,7 +143,7 @@ def test_fused_loss_equals_composed_path_at_full_size(cuda_device):
     np.testing.assert_allclose(gtf, gtc, rtol=1e-4, atol=1e-6)
 
 
-def _raw_assembly_forward(batch, qp, tp, mode, monkeypatch):
+def _raw_assembly_forward(batch, qp, tp, mode, monkeypatch, with_part=False):
     """Call the C ABI directly so that the arg-min arrays in the int workspace can be inspected."""
     import ctypes
     from multi_part_assembly_amd import _lib
@@ -165,7 +165,21 @@ def _raw_assembly_forward(batch, qp, tp, mode, monkeypatch):
     _lib.check(st, "fwd")
     torch.cuda.synchronize()
     pn = B * P * N
+    if with_part:
+        return losses, [iws[k * pn:(k + 1) * pn].view(B, P, N) for k in range(4)]
     return losses, iws[2 * pn:3 * pn].view(B, P, N), iws[3 * pn:4 * pn].view(B, P, N)
+
+
+def _assert_searches_agree(batch, qp, tp, monkeypatch):
+    """brute-force scan == grid-pruned search == leaf search: all four arg-min arrays (per-part Chamfer both ways,
+    whole-shape Chamfer both ways) bit-equal on the valid parts, the five loss terms to summation order."""
+    lb, ib = _raw_assembly_forward(batch, qp, tp, "brute", monkeypatch, with_part=True)
+    valid = batch["part_valids"].bool()
+    for mode in ("grid", "leaf"):
+        lm, im = _raw_assembly_forward(batch, qp, tp, mode, monkeypatch, with_part=True)
+        for k in range(4):
+            assert torch.equal(ib[k][valid], im[k][valid]), (mode, k, int((ib[k][valid] != im[k][valid]).sum()))
+        np.testing.assert_allclose(lm.cpu().numpy(), lb.cpu().numpy(), rtol=2e-6, atol=1e-9, err_msg=mode)
 
 
 def test_fused_loss_at_benchmark_size_matches_oracle(cuda_device, monkeypatch):
@@ -204,8 +218,11 @@ def test_fused_loss_at_benchmark_size_matches_oracle(cuda_device, monkeypatch):
     assert float((q.grad.cpu() - cq.grad).abs().max()) < 1e-4 * scale_q
     assert float((t.grad.cpu() - ct.grad).abs().max()) < 1e-4 * scale_t
     # arg-min arrays of the two searches, straight from the workspace of the C ABI
-    _, s1, s2 = _raw_assembly_forward(batch, qp.to(cuda_device).contiguous(), tp.to(cuda_device).contiguous(), "grid",
+    _, s1, s2 = _raw_assembly_forward(batch, qp.to(cuda_device).contiguous(), tp.to(cuda_device).contiguous(), "leaf",
                                       monkeypatch)
+    _, g1, g2 = _raw_assembly_forward(batch, qp.to(cuda_device).contiguous(), tp.to(cuda_device).contiguous(), "grid",
+                                      monkeypatch)
+    assert torch.equal(s1[v.bool()], g1[v.bool()]) and torch.equal(s2[v.bool()], g2[v.bool()])
     filled = cpcs.masked_fill(cv[..., None, None] == 0, 1e3)
     c1 = og.transform_pc(tp, og.checked_quat(qp), filled).flatten(1, 2).numpy()
     c2 = og.transform_pc(gtr, gq, filled).flatten(1, 2).numpy()
@@ -226,11 +243,7 @@ def test_grid_pruned_search_is_bit_identical_to_brute_force(cuda_device, monkeyp
     g = torch.Generator().manual_seed(int(spread * 100))
     qp = torch.nn.functional.normalize(torch.randn(8, 20, 4, generator=g), dim=-1).to(cuda_device)
     tp = (torch.randn(8, 20, 3, generator=g) * spread).to(cuda_device)
-    lb, b1, b2 = _raw_assembly_forward(batch, qp, tp, "brute", monkeypatch)
-    lg, g1, g2 = _raw_assembly_forward(batch, qp, tp, "grid", monkeypatch)
-    valid = batch["part_valids"].bool()
-    assert torch.equal(b1[valid], g1[valid]) and torch.equal(b2[valid], g2[valid])
-    np.testing.assert_allclose(lg.cpu().numpy(), lb.cpu().numpy(), rtol=2e-6, atol=1e-9)
+    _assert_searches_agree(batch, qp, tp, monkeypatch)
 
 
 @pytest.mark.parametrize("B", [1, 3, 5, 13])
@@ -249,11 +262,7 @@ def test_grid_search_wave_plan_covers_every_batch_size(cuda_device, monkeypatch,
     g = torch.Generator().manual_seed(B)
     qp = torch.nn.functional.normalize(torch.randn(B, 20, 4, generator=g), dim=-1).to(cuda_device)
     tp = (torch.randn(B, 20, 3, generator=g) * 0.4).to(cuda_device)
-    lb, b1, b2 = _raw_assembly_forward(batch, qp, tp, "brute", monkeypatch)
-    lg, g1, g2 = _raw_assembly_forward(batch, qp, tp, "grid", monkeypatch)
-    valid = batch["part_valids"].bool()
-    assert torch.equal(b1[valid], g1[valid]) and torch.equal(b2[valid], g2[valid])
-    np.testing.assert_allclose(lg.cpu().numpy(), lb.cpu().numpy(), rtol=2e-6, atol=1e-9)
+    _assert_searches_agree(batch, qp, tp, monkeypatch)
 
 
 def test_grid_pruned_search_handles_duplicates_and_flat_clouds(cuda_device, monkeypatch):
@@ -271,11 +280,67 @@ def test_grid_pruned_search_handles_duplicates_and_flat_clouds(cuda_device, monk
              "part_trans": torch.zeros(B, P, 3, device=cuda_device)}
     tp = torch.zeros(B, P, 3, device=cuda_device)
     tp[:, 1, 0] = 0.05  # part 1 shifted by exactly one lattice step
-    lb, b1, b2 = _raw_assembly_forward(batch, ident.contiguous(), tp, "brute", monkeypatch)
-    lg, g1, g2 = _raw_assembly_forward(batch, ident.contiguous(), tp, "grid", monkeypatch)
-    valid = v.bool()
-    assert torch.equal(b1[valid], g1[valid]) and torch.equal(b2[valid], g2[valid])
-    np.testing.assert_allclose(lg.cpu().numpy(), lb.cpu().numpy(), rtol=2e-6, atol=1e-9)
+    _assert_searches_agree(batch, ident.contiguous(), tp, monkeypatch)
+
+
+@pytest.mark.parametrize("N,P", [(1, 3), (16, 5), (33, 4), (100, 20), (257, 7), (1100, 6), (2048, 2), (2049, 2)])
+def test_leaf_search_point_counts_and_masks(cuda_device, monkeypatch, N, P):
+    """The leaf search pads every part to a power of two >= 32 slots (pad slots at the end of the last leaf, whole leaves
+    of padding for N just above a power of two) and falls back to the grid beyond 2048 points: sizes on every side of
+    those edges, with NON-PREFIX valid masks and a sample without any valid part."""
+    from multi_part_assembly_amd import synthetic
+
+    B = 5
+    batch = synthetic.make_batch(B, P, N, seed=100 + N, device=cuda_device, num_parts=[P] * B)
+    g = torch.Generator().manual_seed(N)
+    mask = (torch.rand(B, P, generator=g) < 0.6).float()
+    mask[0] = 1.0
+    mask[1] = 0.0
+    mask[2, 0] = 0.0
+    mask[2, -1] = 1.0
+    batch["part_valids"] = mask.to(cuda_device)
+    qp = torch.nn.functional.normalize(torch.randn(B, P, 4, generator=g), dim=-1).to(cuda_device)
+    tp = (torch.randn(B, P, 3, generator=g) * 0.3).to(cuda_device)
+    _assert_searches_agree(batch, qp, tp, monkeypatch)
+
+
+def test_leaf_search_with_trained_poses_and_given_order(cuda_device, monkeypatch):
+    """Predictions within 2 % of the ground truth (the regime the twin-point seed is for), the order computed ONCE by
+    `part_order` and handed to two evaluations with different poses: identical to the evaluation that orders itself and
+    to the brute-force scan."""
+    from multi_part_assembly_amd import synthetic
+
+    batch = synthetic.make_batch(6, 20, 1000, seed=5, device=cuda_device, num_parts=[20, 3, 11, 1, 17, 8])
+    pcs, v = batch["part_pcs"], batch["part_valids"]
+    g = torch.Generator().manual_seed(8)
+    order = L.part_order(pcs, v)
+    for noise in (0.02, 0.5):
+        qp = torch.nn.functional.normalize(batch["part_quat"].cpu() + noise * torch.randn(6, 20, 4, generator=g), dim=-1)
+        qp = torch.where(v.cpu()[..., None] > 0, qp, torch.tensor([1.0, 0, 0, 0])).to(cuda_device).contiguous()
+        tp = (batch["part_trans"].cpu() + noise * torch.randn(6, 20, 3, generator=g)).to(cuda_device).contiguous()
+        _assert_searches_agree(batch, qp, tp, monkeypatch)
+        monkeypatch.setenv("MPA_SHAPE_SEARCH", "leaf")
+        a, _ = L.geometric_assembly_loss(pcs, tp, Rotation3D(qp), batch["part_trans"], Rotation3D(batch["part_quat"]), v)
+        b, _ = L.geometric_assembly_loss(pcs, tp, Rotation3D(qp), batch["part_trans"], Rotation3D(batch["part_quat"]), v,
+                                         order=order)
+        for k in L.LOSS_TERMS:
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_leaf_search_survives_non_finite_poses(cuda_device, monkeypatch):
+    """A diverged step hands the loss NaN / inf poses: the searches must terminate and agree with the brute-force scan
+    (NaN candidates never win; a query without any candidate below 1e32 keeps index -1)."""
+    from multi_part_assembly_amd import synthetic
+
+    batch = synthetic.make_batch(4, 6, 200, seed=3, device=cuda_device, num_parts=[6, 2, 4, 5])
+    g = torch.Generator().manual_seed(1)
+    qp = torch.nn.functional.normalize(torch.randn(4, 6, 4, generator=g), dim=-1)
+    tp = torch.randn(4, 6, 3, generator=g) * 0.3
+    tp[0, 1, 0] = float("nan")
+    tp[1, 0, 2] = float("inf")
+    qp[2, 3, 1] = float("nan")
+    tp[3, 2] = 1e20
+    _assert_searches_agree(batch, qp.to(cuda_device).contiguous(), tp.to(cuda_device).contiguous(), monkeypatch)
 
 
 def test_rotation3d_constructor_rule_on_device(cuda_device):
