@@ -482,7 +482,7 @@ def main():
     # Inside the timed region only the roofline kernel is bracketed by HIP events (recorded by the library right around
     # it: two records per step); the per-phase table of every entry point (~60 records per step, 0.1 ms of gaps in a
     # 2.7 ms step) is taken in a second, untimed pass over the same K steps.
-    roof_timer = _lib.KernelTimer(only=("grid_search_kernel", "dgcnn_knn") + (("chamfer_forward[",) if args.config == "c1" else ()))
+    roof_timer = _lib.KernelTimer(only=("shape_search_kernel", "dgcnn_knn") + (("chamfer_forward[",) if args.config == "c1" else ()))
     if not use_graph:
         _lib.KernelTimer.active = roof_timer
     t0 = time.perf_counter()
@@ -594,7 +594,7 @@ def main():
                                 if C >= 64 else None},
                     "per_layer": per_layer, "timing": timing}
         else:
-            dom = _find(kernels, "grid_search_kernel[")
+            dom = _find(kernels, "shape_search_kernel[")
             phase = _find(kernels, "assembly_shape_chamfer[")
             if dom:
                 k = dom[0][1]
@@ -613,16 +613,18 @@ def main():
                             and abs(rec["clouds_per_launch"] - valid_parts) < 0.5):
                         traffic, traffic_src = rec["traffic_bytes_per_launch"], f"profiles/{pmc[-1].name}: {rec['correction']}"
                 roofline = {
-                    "kernel": "mpa::grid_search_kernel (exact grid-pruned whole-shape Chamfer search of the fused "
-                              "loss, both directions)",
+                    "kernel": "mpa::leaf_search_kernel<true> + leaf_search_heavy_kernel<true> (exact whole-shape Chamfer "
+                              "search of the fused loss over the parts' k-d leaves, both directions; MPA_SHAPE_SEARCH=grid: "
+                              "mpa::grid_search_kernel)",
                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
                     "algorithmic_bytes_per_launch": alg_bytes,
-                    "binding": {"bound": "latency",
-                                "note": "exact pruned search: short dependent candidate-list round trips, neither HBM "
-                                        "nor VALU throughput binds it (DESIGN.md §4); an exhaustive scan of the same "
-                                        "points would be VALU-bound",
+                    "binding": {"bound": "valu-issue",
+                                "note": "exact pruned search: VALU issue slots of the leaf selection, the per-lane box "
+                                        "tests and the reduction of the matrix cores' 32 x 64 gate tiles bind it, "
+                                        "neither HBM nor the MFMA rate does (DESIGN.md §4); an exhaustive scan of the "
+                                        "same points would be VALU-bound",
                                 "equivalent_brute_force_pair_evals_per_s": brute_pairs / secs,
                                 "valu_frac_if_brute_force": 8.6 * brute_pairs / secs / VALU_PEAK_LANE_OPS},
                     "oracle_note": "quaternion algebra of the loss restated from pytorch3d (un-vendored): parity "

@@ -42,6 +42,15 @@ def sources() -> list[Path]:
     return sorted(CSRC.glob("*.hip"))
 
 
+def file_flags(src: Path) -> list[str]:
+    """Extra hipcc flags a source asks for on a line `// hipcc-flags: ...` (e.g. leaf_nn.hip turns the SLP vectoriser
+    off: packed v_pk_*_f32 arithmetic cannot carry the DPP operand its inner loop is built on)."""
+    for line in src.read_text().splitlines()[:60]:
+        if line.startswith("// hipcc-flags:"):
+            return line.split(":", 1)[1].split()
+    return []
+
+
 _USAGE_KEYS = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
                "Occupancy [waves/SIMD]": "waves_per_simd", "LDS Size [bytes/block]": "lds_bytes", "VGPRs Spill": "vgpr_spill"}
 
@@ -96,7 +105,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc, *HIPCC_FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *HIPCC_FLAGS, *file_flags(src), "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -18,7 +18,7 @@ import torch.nn as nn
 from .chamfer import chamfer_distance
 from .eval_utils import calc_connectivity_acc, calc_part_acc, rot_metrics, trans_metrics
 from .matching import SUBSAMPLE, match_parts
-from .loss import (LossTerms, geometric_assembly_loss, rot_cosine_loss, rot_points_cd_loss,
+from .loss import (LossTerms, geometric_assembly_loss, part_order, rot_cosine_loss, rot_points_cd_loss,
                    rot_points_l2_loss, shape_cd_loss, trans_l2_loss)
 from .rotation import Rotation3D
 from .transforms import transform_pc
@@ -119,7 +119,8 @@ class BaseModel(nn.Module):
         if self.fused_loss and not self.semantic:
             # one fused forward/backward pair instead of the per-function composition below
             terms, pts = geometric_assembly_loss(part_pcs, pred_trans, pred_rot, new_trans, new_rot,
-                                                 valids, training=self.training, ret_pts=self.keep_pts)
+                                                 valids, training=self.training, ret_pts=self.keep_pts,
+                                                 order=self._join_part_order(data_dict))
             loss_dict = LossTerms((k, terms[k]) for k in ("trans_loss", "rot_pt_cd_loss", "transform_pt_cd_loss"))
             if self.cfg.loss.use_rot_loss:
                 loss_dict["rot_loss"] = terms["rot_loss"]
@@ -176,8 +177,54 @@ class BaseModel(nn.Module):
     def _loss_function(self, data_dict, out_dict={}, optimizer_idx=-1):
         raise NotImplementedError
 
+    # ---- the batch's k-d order (csrc/leaf_nn.hip): once per batch, beside the encoder --------------------------------------
+    def _start_part_order(self, data_dict):
+        """Both Chamfer searches of the fused loss run on a k-d order of each part's points that depends on the batch
+        only (`loss.part_order`).  It is computed ONCE per `loss_function` call — every GNN iteration and every min-of-N
+        sample of the step reuses it — and on a side stream, so that it runs beside the encoder instead of in front of
+        the first loss evaluation (works under graph capture: the side stream forks from and joins the capturing one).
+        Returns a shallow copy of `data_dict` carrying the pending order; the caller's dict is never touched (a cached
+        order would go stale when a loader refills its batch tensors in place)."""
+        pcs = data_dict["part_pcs"]
+        if not (self.fused_loss and not self.semantic and pcs.is_cuda):
+            return data_dict
+        dev = pcs.device
+        side = getattr(self, "_order_stream", None)
+        if side is None or side.device != dev:
+            side = self._order_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        side.wait_stream(cur)  # (the batch may have been produced on the current stream)
+        with torch.cuda.stream(side):
+            order = part_order(pcs, data_dict["part_valids"])
+        if order is None:  # N > 2048: the loss keeps its grid search
+            return data_dict
+        out = dict(data_dict)
+        out["_part_order"] = [order, side]
+        return out
+
+    @staticmethod
+    def _join_part_order(data_dict):
+        """The order started by `_start_part_order` (None if there is none); the first caller makes the current stream wait."""
+        pending = data_dict.get("_part_order")
+        if pending is None:
+            return None
+        order, side = pending
+        if side is not None:
+            cur = torch.cuda.current_stream(order.device)
+            cur.wait_stream(side)
+            order.record_stream(cur)
+            pending[1] = None
+        return order
+
     def loss_function(self, data_dict, optimizer_idx=-1):
         """Min-of-N over `sample_iter` stochastic predictions, per sample (base_model.py:348-387)."""
+        data_dict = self._start_part_order(data_dict)
+        try:
+            return self._loss_function_impl(data_dict, optimizer_idx)
+        finally:
+            self._join_part_order(data_dict)  # (a path that never evaluated the fused loss must still join the side stream)
+
+    def _loss_function_impl(self, data_dict, optimizer_idx=-1):
         if self.sample_iter == 1:
             # one prediction: stack the terms once and weight / average them with a handful of launches instead of
             # five per term (the step is ~200 launches, these would be ~40 of them)

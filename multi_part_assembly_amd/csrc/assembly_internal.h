@@ -52,9 +52,12 @@ bool leaf_supported(int64_t P, int64_t N);  // P <= 64 parts, N <= 2048 points p
 void launch_leaf_order(const float* part_pcs, const float* valids, int64_t B, int64_t P, int64_t N, float* sorted,
                        hipStream_t s);
 // exact NN of cloud A's valid points in cloud B (idx1) and vice versa (idx2): shape = every point against the sample's whole
-// other shape (indices p * N + n), else every part against its own copy (indices n); per-block distance sums into
-// tile_sums[dir][m * tilesq + tile], tilesq = max(1, Npad / 256)
+// other shape (indices p * N + n), else every part against its own copy (indices n); per-wave distance sums into
+// wave_sums[dir][m][NW], NW = max(1, Npad / 64).  scratch: leaf_scratch_floats() floats (16-byte aligned), shared by the two
+// searches of a loss evaluation; its two counters (leaf_heavy_counters) must be zero when the first search starts.
+int64_t leaf_scratch_floats(int64_t B, int64_t P, int64_t N);
+int* leaf_heavy_counters(float* scratch);
 void launch_leaf_search(bool shape, const float* valids, const LeafCloud& A, const LeafCloud& B_, int64_t B, int64_t P,
-                        int64_t N, int tilesq, int32_t* idx1, int32_t* idx2, float* tile_sums, hipStream_t s);
+                        int64_t N, int32_t* idx1, int32_t* idx2, float* wave_sums, float* scratch, hipStream_t s);
 
 }  // namespace mpa

@@ -191,10 +191,11 @@ __global__ __launch_bounds__(kThreads) void assembly_pose_leaf_kernel(
     const float4* __restrict__ sorted, const float* __restrict__ valids, const float* __restrict__ q1,
     const float* __restrict__ t1, const float* __restrict__ q2, const float* __restrict__ t2, int P, int N, int Npad,
     int fill_pads, float* __restrict__ R1, float* __restrict__ R2, float* __restrict__ S1, float* __restrict__ S2,
-    float* __restrict__ partial, LeafOut out) {
+    float* __restrict__ partial, LeafOut out, int* __restrict__ heavy_counters) {
   __shared__ float red[kThreads / 64];
   __shared__ float box[kThreads / 32][12];
   const int m = blockIdx.x, p = m % P;
+  if (m == 0 && threadIdx.x < 2) heavy_counters[threadIdx.x] = 0;  // of the two searches' second passes
   const Quat qa = load_quat(q1 + 4 * m), qb = load_quat(q2 + 4 * m);
   const float ta[3] = {t1[3 * m], t1[3 * m + 1], t1[3 * m + 2]};
   const float tb[3] = {t2[3 * m], t2[3 * m + 1], t2[3 * m + 2]};
@@ -629,8 +630,10 @@ __global__ void assembly_backward_finish_kernel(const float* __restrict__ go, co
 // floats the leaf search adds to the workspace: order + 4 record arrays (float4 per slot), 4 x leaf boxes, 4 x part boxes
 int64_t leaf_workspace_floats(int64_t B, int64_t P, int64_t N) {
   if (!mpa::leaf_supported(P, N)) return 0;
-  const int64_t npad = mpa::leaf_npad(N);
-  return 20 * B * P * npad + 32 * B * P * (npad / 32) + 32 * B * P;
+  const int64_t npad = mpa::leaf_npad(N), nw = npad >= 64 ? npad / 64 : 1;
+  // + per-wave distance sums (2 searches x 2 directions) + the searches' scratch
+  return 20 * B * P * npad + 32 * B * P * (npad / 32) + 32 * B * P + (4 * B * P * nw + 3) / 4 * 4 +
+         mpa::leaf_scratch_floats(B, P, N);
 }
 
 }  // namespace
@@ -669,7 +672,7 @@ struct Workspace {
   int tiles;
   // leaf search (leaf_nn.hip): the library's own k-d order (callers may hand one in), records / leaf boxes / part boxes
   // of the four clouds R1, R2, S1, S2
-  float *order, *rec[4], *leaf[4], *pbox[4];
+  float *order, *rec[4], *leaf[4], *pbox[4], *wsum_part, *wsum_shape, *scratch;
 };
 
 // 0: brute-force scan, 1: grid-pruned search (grid_nn.hip), 2: leaf search (leaf_nn.hip; default).  Identical results;
@@ -717,6 +720,10 @@ Workspace carve(float* fws, int32_t* iws, int64_t B, int64_t P, int64_t N, int q
   for (int c = 0; c < 4; ++c, lf += 4 * B * P * npad) w.rec[c] = lf;
   for (int c = 0; c < 4; ++c, lf += 8 * B * P * (npad / 32)) w.leaf[c] = lf;
   for (int c = 0; c < 4; ++c, lf += 8 * B * P) w.pbox[c] = lf;
+  const int64_t nw = npad >= 64 ? npad / 64 : 1;
+  w.wsum_part = lf;
+  w.wsum_shape = lf + 2 * B * P * nw;
+  w.scratch = lf + (4 * B * P * nw + 3) / 4 * 4;
   return w;
 }
 }  // namespace
@@ -786,7 +793,6 @@ extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const fl
     // ---- leaf search: k-d order (once per batch), pose kernel in that order, both searches over the leaves ----
     const int npad = mpa::leaf_npad(N);
     MPA_REQUIRE(B * P * (int64_t)npad < (1LL << 31), "assembly_loss_forward: problem too large");
-    const int tilesq = npad >= 256 ? npad / 256 : 1;  // (<= w.tiles: the tile-sum areas were sized for 128-point tiles)
     if (order == nullptr) {
       mpa::launch_leaf_order(part_pcs, valids, B, P, N, w.order, s);
       order = w.order;
@@ -799,19 +805,21 @@ extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const fl
     }
     hipLaunchKernelGGL(assembly_pose_leaf_kernel, dim3(parts), dim3(kThreads), 0, s,
                        reinterpret_cast<const float4*>(order), valids, quat_pred, trans_pred, quat_gt, trans_gt, (int)P,
-                       (int)N, npad, fill_pad_points, w.R1, w.R2, w.S1, w.S2, w.partial, lo);
+                       (int)N, npad, fill_pad_points, w.R1, w.R2, w.S1, w.S2, w.partial, lo,
+                       mpa::leaf_heavy_counters(w.scratch));
     mark(1);
     const mpa::LeafCloud r1{w.rec[0], w.leaf[0], w.pbox[0], w.R1}, r2{w.rec[1], w.leaf[1], w.pbox[1], w.R2};
     const mpa::LeafCloud s1{w.rec[2], w.leaf[2], w.pbox[2], w.S1}, s2{w.rec[3], w.leaf[3], w.pbox[3], w.S2};
-    mpa::launch_leaf_search(false, valids, r1, r2, B, P, N, tilesq, w.ip1, w.ip2, w.part_tiles, s);
+    mpa::launch_leaf_search(false, valids, r1, r2, B, P, N, w.ip1, w.ip2, w.wsum_part, w.scratch, s);
     mark(2);
     mark(5);
-    mpa::launch_leaf_search(true, valids, s1, s2, B, P, N, tilesq, w.is1, w.is2, w.shape_tiles, s);
+    mpa::launch_leaf_search(true, valids, s1, s2, B, P, N, w.is1, w.is2, w.wsum_shape, w.scratch, s);
     mark(6);
     mark(3);
+    const int nw = npad >= 64 ? npad / 64 : 1;  // every wave of a valid part leaves its distance sum
     hipLaunchKernelGGL(assembly_finalize_kernel, dim3((unsigned)B), dim3(64), 0, s, valids, quat_pred,
-                       trans_pred, quat_gt, trans_gt, w.partial, w.part_tiles, w.shape_tiles, (int)B,
-                       (int)P, (int)N, tilesq, tilesq, training, losses);
+                       trans_pred, quat_gt, trans_gt, w.partial, (const float*)w.wsum_part,
+                       (const float*)w.wsum_shape, (int)B, (int)P, (int)N, nw, nw, training, losses);
     mark(4);
     return mpa::check_launch("assembly_loss_forward");
   }

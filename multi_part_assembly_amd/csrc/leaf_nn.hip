@@ -17,16 +17,23 @@
 //     only if some lane's own point-to-box distance can still beat (or tie) that lane's best.  The box distances are
 //     evaluated with the same expression shape as the point distance — every rounding is monotone — so they are
 //     rigorous lower bounds of the pinned fp32 distance without any slack term.
-//   * Leaf records are walked with wave-uniform addresses: they arrive through the scalar cache as SGPR operands of
-//     the distance arithmetic (no LDS, no barrier, no VGPRs for targets); candidates are not visited in index order,
-//     so updates are lexicographic (smaller distance, then smaller original index) — the answer of the in-order
-//     strict-`<` scan.
+//   * A leaf's records sit in the wave's registers, 16 per row of lanes, and reach the queries through DPP row
+//     rotations on the operand of the subtraction (no LDS, no barrier, no scalar-cache traffic); candidates are not
+//     visited in index order, so updates are lexicographic (smaller distance, then smaller original index) — the
+//     answer of the in-order strict-`<` scan.
+//
+// hipcc-flags: -fno-slp-vectorize
+// (read by _build.py: the SLP vectoriser packs the distance arithmetic into v_pk_*_f32, which cannot take the DPP
+// operand — two thirds of the row rotations became separate v_mov_b32_dpp instructions)
 #include "assembly_internal.h"
 #include "common.h"
 
 namespace mpa {
 namespace {
 
+#ifndef MPA_LEAF_GATE  // 1: leaves are screened on the matrix cores (default); 0: every visited leaf is scanned exactly
+#define MPA_LEAF_GATE 1
+#endif
 constexpr int kLeaf = 32;                 // points per leaf
 constexpr int kLeafMaxPad = 2048;         // padded points per part (<= 64 leaves: one lane per leaf)
 constexpr int kNoIdx = 0x7fffffff;
@@ -55,6 +62,9 @@ __device__ __forceinline__ unsigned wave_max_u(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
 __device__ __forceinline__ float dist3(float dx, float dy, float dz) { return (dx * dx + dy * dy) + dz * dz; }
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
@@ -76,37 +86,41 @@ __device__ __forceinline__ float lb_box_box(const float (&qlo)[3], const float (
 
 // ---- 1. the k-d ordering of a part's points (once per batch) ------------------------------------------------------------
 // One block per part.  Level by level the segment [0, Npad) is halved: every segment is sorted along the widest axis
-// of its own bounding box (bitonic network in LDS, (coordinate, index) keys: a strict total order, so the result is
-// deterministic) and cut in the middle, down to segments of 32 slots = the leaves.  Pad slots (beyond N) carry the
-// largest key and stay at the end of the last segment.  The ordering only steers speed: the search is exact for any
-// permutation.  Output: sorted[m][k] = (x, y, z, original index n as int bits; -1 in pad slots) in LOCAL coordinates.
-__device__ __forceinline__ unsigned orderable(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
+// of its own bounding box and cut in the middle, down to segments of 32 slots = the leaves.  Sort keys are ONE 32-bit
+// word — the coordinate quantised to 21 bits over the segment's extent, the point's index (< 2048) below it: a strict
+// total order (deterministic result), half the LDS traffic of (float, index) pairs and bank-friendly (64-bit keys ran
+// the small-stride stages of the network into 8-way bank conflicts).  Pad slots (beyond N) carry the largest key and
+// stay at the end of the last segment.  The ordering only steers speed: the search is exact for any permutation.
+// Output: sorted[m][k] = (x, y, z, original index n as int bits; -1 in pad slots) in LOCAL coordinates.
+// Barriers: thread t owns the compare-exchange pairs t, t + 512, ...; in every stage whose partner distance is at most
+// 64 (all of a merge's last seven stages, and whole merges up to 128 keys) the 64 pairs of a wave touch exactly the
+// wave's own 128 keys, and LDS operations of one wave execute in order — those stages need no block barrier.
+constexpr int kOrderThreads = 512;
+constexpr unsigned kPadKey = 0xffffffffu;
 
-__global__ __launch_bounds__(1024) void leaf_order_kernel(const float* __restrict__ pcs, const float* __restrict__ valids,
-                                                          int N, int Npad, float4* __restrict__ sorted) {
-  __shared__ unsigned long long key[kLeafMaxPad];
+__global__ __launch_bounds__(kOrderThreads) void leaf_order_kernel(const float* __restrict__ pcs,
+                                                                   const float* __restrict__ valids, int N, int Npad,
+                                                                   float4* __restrict__ sorted) {
+  __shared__ unsigned key[kLeafMaxPad];
   __shared__ float px[kLeafMaxPad], py[kLeafMaxPad], pz[kLeafMaxPad];
   __shared__ float cbox[kLeafMaxPad / kLeaf][6];
   const int m = blockIdx.x;
   if (valids[m] == 0.0f) return;
   const float* src = pcs + 3LL * m * N;
-  for (int n = threadIdx.x; n < Npad; n += 1024) {
+  for (int n = threadIdx.x; n < Npad; n += kOrderThreads) {
     const bool in = n < N;
     px[n] = in ? src[3 * n] : 0.0f;
     py[n] = in ? src[3 * n + 1] : 0.0f;
     pz[n] = in ? src[3 * n + 2] : 0.0f;
-    key[n] = in ? (unsigned long long)n : 0xffffffffffffffffull;  // low word: the point held by this slot
+    key[n] = in ? (unsigned)n : kPadKey;  // low 11 bits: the point held by this slot
   }
   __syncthreads();
   for (int S = Npad; S > kLeaf; S >>= 1) {
     // boxes of the 32-slot chunks, then of the segments
-    for (int k = threadIdx.x; k < Npad; k += 1024) {
-      const unsigned long long e = key[k];
-      const bool real = e != 0xffffffffffffffffull;
-      const int n = real ? (int)(e & 0xffffffffu) : 0;
+    for (int k = threadIdx.x; k < Npad; k += kOrderThreads) {
+      const unsigned e = key[k];
+      const bool real = e != kPadKey;
+      const int n = real ? (int)(e & 2047u) : 0;
       const float inf = __builtin_inff();
       float lo[3] = {real ? px[n] : inf, real ? py[n] : inf, real ? pz[n] : inf};
       float hi[3] = {real ? px[n] : -inf, real ? py[n] : -inf, real ? pz[n] : -inf};
@@ -127,7 +141,7 @@ __global__ __launch_bounds__(1024) void leaf_order_kernel(const float* __restric
       }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < Npad; k += 1024) {
+    for (int k = threadIdx.x; k < Npad; k += kOrderThreads) {
       const int seg = k / S, c0 = seg * (S / kLeaf), c1 = c0 + S / kLeaf;
       float lo[3] = {cbox[c0][0], cbox[c0][1], cbox[c0][2]}, hi[3] = {cbox[c0][3], cbox[c0][4], cbox[c0][5]};
       for (int c = c0 + 1; c < c1; ++c) {
@@ -139,206 +153,534 @@ __global__ __launch_bounds__(1024) void leaf_order_kernel(const float* __restric
       }
       const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
       const int axis = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2);  // (NaN extents fall through to z: any axis is fine)
-      const unsigned long long e = key[k];
-      if (e != 0xffffffffffffffffull) {
-        const int n = (int)(e & 0xffffffffu);
+      const unsigned e = key[k];
+      if (e != kPadKey) {
+        const int n = (int)(e & 2047u);
         const float v = axis == 0 ? px[n] : (axis == 1 ? py[n] : pz[n]);
-        key[k] = ((unsigned long long)orderable(v) << 32) | (unsigned)n;
+        const float l = axis == 0 ? lo[0] : (axis == 1 ? lo[1] : lo[2]), x = axis == 0 ? ex : (axis == 1 ? ey : ez);
+        // position inside the segment's extent, 21 bits (non-finite or degenerate extents: everything in one bucket)
+        const float f = x > 0.0f ? (v - l) / x : 0.0f;
+        const unsigned qv = (unsigned)__builtin_amdgcn_fmed3f(f * 2097151.0f, 0.0f, 2097151.0f);
+        key[k] = ((qv < 2097151u ? qv : 2097150u) << 11) | (unsigned)n;  // (always below the pad key)
       }
     }
     __syncthreads();
     // ascending bitonic sort of every aligned S-segment; Npad / 2 compare-exchange pairs per stage
-    for (int k = 2; k <= S; k <<= 1) {
-      for (int t = threadIdx.x; t < Npad / 2; t += 1024) {  // first stage of a merge: mirror pairs
-        const int half = k >> 1, blk = t / half, off = t % half;
-        const int i = blk * k + off, p = blk * k + (k - 1 - off);
-        const unsigned long long a = key[i], b = key[p];
+    bool prev_cross = false;  // (the barrier above covers the first stage)
+    auto stage_sync = [&](bool cross) {
+      if (cross || prev_cross) __syncthreads();
+      else __builtin_amdgcn_wave_barrier();  // wave-local stage after a wave-local stage: program order suffices
+      prev_cross = cross;
+    };
+#if defined(MPA_ORDER_EXP) && MPA_ORDER_EXP == 1
+    if (S > 0) continue;
+#endif
+    for (int lk = 1; (1 << lk) <= S; ++lk) {  // merge size k = 2^lk (shifts, not divisions: k and j are powers of two)
+      const int k = 1 << lk;
+      if (k > 2) stage_sync(k > 128);
+      for (int t = threadIdx.x; t < Npad / 2; t += kOrderThreads) {  // first stage of a merge: mirror pairs
+        const int base = (t >> (lk - 1)) << lk, off = t & ((k >> 1) - 1);
+        const int i = base + off, p = base + (k - 1 - off);
+        const unsigned a = key[i], b = key[p];
         if (a > b) {
           key[i] = b;
           key[p] = a;
         }
       }
-      __syncthreads();
-      for (int j = k >> 2; j > 0; j >>= 1) {
-        for (int t = threadIdx.x; t < Npad / 2; t += 1024) {
-          const int i = (t / j) * 2 * j + (t % j), p = i + j;
-          const unsigned long long a = key[i], b = key[p];
+      for (int lj = lk - 2; lj >= 0; --lj) {
+        const int j = 1 << lj;
+        stage_sync(j > 64);
+        for (int t = threadIdx.x; t < Npad / 2; t += kOrderThreads) {
+          const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), p = i + j;
+          const unsigned a = key[i], b = key[p];
           if (a > b) {
             key[i] = b;
             key[p] = a;
           }
         }
-        __syncthreads();
       }
     }
+    __syncthreads();
   }
   float4* out = sorted + (long long)m * Npad;
-  for (int k = threadIdx.x; k < Npad; k += 1024) {
-    const unsigned long long e = key[k];
-    const bool real = e != 0xffffffffffffffffull;
-    const int n = real ? (int)(e & 0xffffffffu) : 0;
+  for (int k = threadIdx.x; k < Npad; k += kOrderThreads) {
+    const unsigned e = key[k];
+    const bool real = e != kPadKey;
+    const int n = real ? (int)(e & 2047u) : 0;
     out[k] = make_float4(px[n], py[n], pz[n], __int_as_float(real ? n : -1));
   }
 }
 
+#ifdef MPA_LEAF_STATS  // instrumented build for tools/probe_leaf_stats.py only (never in libmpa_hip.so)
+// [shape][0] wave searches (both passes), [1] leaf tests, [2] leaf scans, [3] part visits, [4] max scans of one wave search,
+// [7] waves deferred to the second pass, [8 + k] wave searches with scans in [2^k, 2^(k+1))
+__device__ unsigned long long g_leaf_stats[2][32];
+#define MPA_LSTAT(var) ++(var)
+#else
+#define MPA_LSTAT(var) do { } while (0)
+#endif
+
 // ---- 2. the search --------------------------------------------------------------------------------------------------------
-// Scan the 32 records of one leaf (wave-uniform address -> scalar loads), exact arithmetic, lexicographic update.
-__device__ __forceinline__ void scan_leaf(const float4* __restrict__ rec, float X, float Y, float Z, float& best,
-                                          int& bidx) {
-#pragma unroll
-  for (int c = 0; c < kLeaf; c += 8) {
-    float4 r[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) r[t] = rec[c + t];
-    float d[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) d[t] = dist3(X - r[t].x, Y - r[t].y, Z - r[t].z);
-    // (fminf ignores NaNs — wanted: a NaN candidate can never win)
-    const float a = __builtin_fminf(__builtin_fminf(d[0], d[1]), d[2]);
-    const float b = __builtin_fminf(__builtin_fminf(d[3], d[4]), d[5]);
-    const float cmin = __builtin_fminf(__builtin_fminf(a, b), __builtin_fminf(d[6], d[7]));
-    if (cmin <= best) {  // rare: an improvement, or a tie that may carry a lower index
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int ti = __float_as_int(r[t].w);
-        if (d[t] < best || (d[t] == best && ti < bidx)) {
-          best = d[t];
-          bidx = ti;
-        }
-      }
-    }
-  }
+// A leaf's 32 records live in the wave's own registers: lane l holds slots (l % 16) and 16 + (l % 16) (two coalesced
+// vector loads), and every lane meets the 16 targets of its ROW of 16 lanes through the DPP network — `row_ror:n` on
+// the operand of the subtraction, no instruction of its own.  (The records as SGPR operands through the scalar cache
+// — the feed of the exhaustive scans in chamfer_core.h, where every wave of a CU streams the same targets — ran this
+// search no faster than LDS staging: here every wave walks its own leaves and the scalar cache serves misses one at a
+// time.)  Two rotations are evaluated per packed instruction (v_pk_mul_f32 / v_pk_add_f32 on register pairs).
+//
+// The running best of a lane is ONE 64-bit key, (distance bits << 32) | index: non-negative floats order like their bit
+// patterns, so the lexicographic rule (smaller distance, then smaller original index) is a single unsigned 64-bit
+// compare per candidate — no chunk minimum, no rare path (with 64 queries per wave SOME lane improves in almost every
+// chunk).  NaN distances have the largest bit patterns and never win; a lane without a query holds key 0.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+
+template <int N>
+__device__ __forceinline__ float ror_f(float v) {
+  if constexpr (N == 0) return v;
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, true));
+}
+template <int N>
+__device__ __forceinline__ unsigned ror_u(unsigned v) {
+  if constexpr (N == 0) return v;
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xf, 0xf, true);
+}
+__device__ __forceinline__ u64 make_key(float d, unsigned idx) { return ((u64)__float_as_uint(d) << 32) | idx; }
+__device__ __forceinline__ float key_dist(u64 k) { return __uint_as_float((unsigned)(k >> 32)); }
+
+// the targets at row rotations N and N + 1 of `t` against this lane's query
+template <int N>
+__device__ __forceinline__ void scan_pair(const float4& t, float X, float Y, float Z, u64& best) {
+  const f32x2 dx = {X - ror_f<N>(t.x), X - ror_f<N + 1>(t.x)};
+  const f32x2 dy = {Y - ror_f<N>(t.y), Y - ror_f<N + 1>(t.y)};
+  const f32x2 dz = {Z - ror_f<N>(t.z), Z - ror_f<N + 1>(t.z)};
+  const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+  const unsigned w = __float_as_uint(t.w);
+  const u64 k0 = make_key(d[0], ror_u<N>(w)), k1 = make_key(d[1], ror_u<N + 1>(w));
+  best = k0 < best ? k0 : best;
+  best = k1 < best ? k1 : best;
+}
+__device__ __forceinline__ void scan16(const float4& t, float X, float Y, float Z, u64& best) {
+  scan_pair<0>(t, X, Y, Z, best);
+  scan_pair<2>(t, X, Y, Z, best);
+  scan_pair<4>(t, X, Y, Z, best);
+  scan_pair<6>(t, X, Y, Z, best);
+  scan_pair<8>(t, X, Y, Z, best);
+  scan_pair<10>(t, X, Y, Z, best);
+  scan_pair<12>(t, X, Y, Z, best);
+  scan_pair<14>(t, X, Y, Z, best);
 }
 
-// Records qrec / trec [B*P][Npad] float4 (x, y, z, index: SHAPE p * N + n, else n; pad slots (inf, inf, inf, kNoIdx)),
-// leaf boxes tleaf / qleaf [B*P][Npad / 32][8] (lo xyz, -, hi xyz, -), part boxes tpart [B*P][8]; reps: the target cloud
-// in original order [B, P, N, 3] (SHAPE: the padded parts' representatives).  grid = (B*P*tilesq, 2), block 256: a
-// block is 256 consecutive sorted slots of part m; dir 0: cloud A queries against cloud B targets.
-template <bool SHAPE>
-__global__ __launch_bounds__(256) void leaf_search_kernel(
-    const float* __restrict__ valids, const float4* __restrict__ recA, const float4* __restrict__ recB,
-    const float* __restrict__ leafA, const float* __restrict__ leafB, const float* __restrict__ partA,
-    const float* __restrict__ partB, const float* __restrict__ origA, const float* __restrict__ origB, int P, int N,
-    int Npad, int tilesq, int* __restrict__ idx1, int* __restrict__ idx2, float* __restrict__ tile_sums) {
-  __shared__ float red[4];
-  const int bid = blockIdx.x, dir = blockIdx.y;
-  const int m = bid / tilesq, tile = bid % tilesq;
-  if (valids[m] == 0.0f) return;
-  const int b = m / P, p = m % P;
-  const int NL = Npad / kLeaf;
+// ---- the matrix-core gate ----------------------------------------------------------------------------------------------------
+// Most of a leaf's 32 x 64 (target, query) pairs cannot matter: per query only the leaf's nearest target can, and only
+// if it beats the query's running best.  The matrix cores find that target without a single VALU distance evaluation:
+//     v(i, j) = (|t_i'|^2 + Q) - 2 q_j' . t_i'  =  |q_j - t_i|^2 + (Q - |q_j'|^2)      (primes: relative to the wave's centre c)
+// is a K = 4 product of the rows (t'x, t'y, t'z, |t'|^2 + Q) with the columns (-2 q'x, -2 q'y, -2 q'z, 1): four
+// v_mfma_f32_32x32x2_f32 per leaf for the wave's two query tiles.  Q = max_j |q_j'|^2 keeps v positive, so it orders
+// like its bit pattern; a lane holds 16 of a query's 32 values per tile, packs the value's register into the low 4 bits,
+// and keeps the smallest and second smallest (v_min_f32 / v_med3_f32); one lane-half swap merges the two halves of a query.
+// The approximation only DECIDES, the pinned arithmetic ANSWERS (E bounds |v - R - d| for every pair of the leaf):
+//   * nearest value - E above the query's best           -> no target of the leaf can win or tie: nothing to do;
+//   * else, runner-up clearly above the nearest value    -> the leaf's exact minimum IS that target (strictly: no tie is
+//     possible): ONE exact distance (pinned arithmetic on the stored coordinates) and the usual lexicographic update;
+//   * else (near-ties, duplicates, non-finite values)    -> the whole wave scans the leaf exactly (scan16, rare).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GateWave {    // per wave, set up once
+  float cx, cy, cz;  // centre of the query box
+  float qq, R, Q;    // |q'|^2 of this lane's query, Q - qq, Q
+  float b0_01, b0_23, b1_01, b1_23;  // B operands of the two query tiles (queries 0-31 / 32-63)
+};
+
+__device__ __forceinline__ void gate_setup(GateWave& w, const float (&qlo)[3], const float (&qhi)[3], float X, float Y,
+                                           float Z, bool has) {
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const float4* qrec = dir == 0 ? recA : recB;
-  const float4* trec = dir == 0 ? recB : recA;
-  const float* qleaf = dir == 0 ? leafA : leafB;
-  const float* tleaf = dir == 0 ? leafB : leafA;
-  const float* tpart = dir == 0 ? partB : partA;
-  const int k0 = (tile * 4 + wave) * 64;  // first sorted slot of this wave
-  float X, Y, Z, best = 0.0f;
-  int qidx = kNoIdx, bidx = kNoIdx;
-  {
-    const float inf = __builtin_inff();
-    X = Y = Z = inf;
+  w.cx = 0.5f * (qlo[0] + qhi[0]), w.cy = 0.5f * (qlo[1] + qhi[1]), w.cz = 0.5f * (qlo[2] + qhi[2]);
+  const float qx = has ? X - w.cx : 0.0f, qy = has ? Y - w.cy : 0.0f, qz = has ? Z - w.cz : 0.0f;
+  w.qq = dist3(qx, qy, qz);
+  // (2 % above the largest |q'|^2: R = Q - qq stays far above the rounding of v even where a target coincides with its query)
+  w.Q = __uint_as_float(wave_max_u(__float_as_uint(w.qq))) * 1.02f + 1e-30f;
+  w.R = w.Q - w.qq;
+  const float ax = -2.0f * qx, ay = -2.0f * qy, az = -2.0f * qz;
+  const float ox = __shfl_xor(ax, 32, 64), oy = __shfl_xor(ay, 32, 64), oz = __shfl_xor(az, 32, 64);
+  const bool lo = lane < 32;
+  // lane (j, h): B[k = h][column j]; tile 0 = the queries of lanes 0-31, tile 1 = of lanes 32-63
+  w.b0_01 = lo ? ax : oy;
+  w.b0_23 = lo ? az : 1.0f;
+  w.b1_01 = lo ? ox : ay;
+  w.b1_23 = lo ? oz : 1.0f;
+}
+
+// smallest and second smallest of a tile's 16 values of this lane, with the value's register 4g + u in the low 4 bits
+// (target row 8g + u, + 4 for the upper lane half).  Positive floats: the packed words still order like the values.
+// Four independent chains (one per g), merged pairwise.
+__device__ __forceinline__ void gate_merge(float& m, float& s, float m2, float s2) {
+  s = __builtin_fminf(__builtin_fmaxf(m, m2), __builtin_fminf(s, s2));
+  m = __builtin_fminf(m, m2);
+}
+__device__ __forceinline__ void gate_reduce(const f32x16& acc, float& m, float& s) {
+  float mg[4], sg[4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    float p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = __int_as_float((__float_as_int(acc[4 * g4 + u]) & ~15) | (4 * g4 + u));
+    mg[g4] = __builtin_fminf(p[0], p[1]);
+    sg[g4] = __builtin_fmaxf(p[0], p[1]);
+    sg[g4] = __builtin_amdgcn_fmed3f(mg[g4], p[2], sg[g4]);
+    mg[g4] = __builtin_fminf(mg[g4], p[2]);
+    sg[g4] = __builtin_amdgcn_fmed3f(mg[g4], p[3], sg[g4]);
+    mg[g4] = __builtin_fminf(mg[g4], p[3]);
   }
-  bool has = false;
-  if (k0 < Npad) {  // (wave-uniform)
-    const int k = k0 + lane;
-    const bool in = k < Npad;
-    const float4 q = qrec[(long long)m * Npad + (in ? k : Npad - 1)];
-    has = in && __float_as_int(q.w) != kNoIdx;
-    if (has) {
-      X = q.x, Y = q.y, Z = q.z;
-      qidx = __float_as_int(q.w);
-      // the twin: this point's own image in the other cloud
-      const float4 t = trec[(long long)m * Npad + k];
-      best = 1e32f;
-      const float d = dist3(X - t.x, Y - t.y, Z - t.z);
-      if (d < best || d == best) {
-        best = d;
-        bidx = __float_as_int(t.w);
-      }
+  gate_merge(mg[0], sg[0], mg[1], sg[1]);
+  gate_merge(mg[2], sg[2], mg[3], sg[3]);
+  gate_merge(mg[0], sg[0], mg[2], sg[2]);
+  m = mg[0], s = sg[0];
+}
+
+// Everything a search launch reads.  Records rec [B*P][Npad] float4 (x, y, z, index: SHAPE p * N + n, else n; pad slots
+// (inf, inf, inf, kNoIdx)), leaf boxes [B*P][Npad / 32][8] (lo xyz, -, hi xyz, -), part boxes [B*P][8], the cloud in
+// original order [B, P, N, 3] (SHAPE: the padded parts' representatives).  Side 0 / 1 = cloud A / B; direction 0:
+// cloud A's points are the queries.
+struct LeafArgs {
+  const float* valids;
+  const float4* rec[2];
+  const float* leaf[2];
+  const float* part[2];
+  const float* orig[2];
+  int P, N, Npad, NW;   // NW = waves per part = max(1, Npad / 64)
+  int* idx[2];          // per direction
+  float* wave_sums;     // [2][B*P][NW]
+  // waves that hit the scan cap of the first pass: their count, ids (((m * NW + w) * 2) + dir) and 64 keys each
+  int* heavy_count;
+  int* heavy_list;
+  u64* heavy_keys;
+  int total_parts;      // B * P
+};
+
+#ifndef MPA_LEAF_CAP
+#define MPA_LEAF_CAP 40
+#endif
+constexpr int kScanCap = MPA_LEAF_CAP;   // leaf scans of one wave in the first pass (the slowest wave bounds the launch)
+constexpr int kSplit = 8;      // waves that share one deferred wave's leaves in the second pass
+
+// One wave's search: queries = the 64 sorted slots k0 .. k0 + 63 of part m, direction dir.  `best` comes in initialised
+// (twin / padded parts / saved state).  Only leaves l with l % split == rem are visited; at most `cap` leaf scans.
+// Returns false if the cap stopped the search early.  No lane-divergent control flow between the first and the last DPP
+// read: every branch is wave-uniform.
+template <bool SHAPE>
+__device__ __forceinline__ bool leaf_search_wave(const LeafArgs& g, int m, int k0, int dir, float X, float Y, float Z,
+                                                 bool has, u64& best, int split, int rem, int cap) {
+  const int P = g.P, Npad = g.Npad, NL = Npad / kLeaf, b = m / P, p = m % P;
+  const int lane = threadIdx.x & 63;
+  const float4* trec = g.rec[1 - dir];
+  const float* qleaf = g.leaf[dir];
+  const float* tleaf = g.leaf[1 - dir];
+  const float* tpart = g.part[1 - dir];
+  // box of this wave's queries: its two leaves
+  float qlo[3], qhi[3];
+  {
+    const int l0 = k0 / kLeaf, l1 = l0 + 1 < NL ? l0 + 1 : l0;
+    const float* a = qleaf + ((long long)m * NL + l0) * 8;
+    const float* c = qleaf + ((long long)m * NL + l1) * 8;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      qlo[x] = __builtin_fminf(a[x], c[x]);
+      qhi[x] = __builtin_fmaxf(a[4 + x], c[4 + x]);
     }
+  }
+  unsigned bound = wave_max_u((unsigned)(best >> 32));
+  int scans = 0;
+  bool done = true;
+  [[maybe_unused]] int st_tests = 0, st_parts = 0, st_exact = 0;
+#if MPA_LEAF_GATE
+  GateWave gw;
+  gate_setup(gw, qlo, qhi, X, Y, Z, has);
+#endif
+  // The leaves of target part tp, nearest first.  Lane l holds leaf l's box and its distance to the query box; the
+  // records of the leaf to come are requested while the current one is scanned.
+  auto search_part = [&](int tp) {
+    const float4* lbx = reinterpret_cast<const float4*>(tleaf + ((long long)(b * P + tp) * NL) * 8);
+    const float4 blo = lbx[2 * (lane < NL ? lane : 0)], bhi = lbx[2 * (lane < NL ? lane : 0) + 1];
+    unsigned lbl = 0xffffffffu;
+    {
+      const float bx[8] = {blo.x, blo.y, blo.z, 0.0f, bhi.x, bhi.y, bhi.z, 0.0f};
+      if (lane < NL && lane % split == rem) lbl = __float_as_uint(lb_box_box(qlo, qhi, bx));
+    }
+    const float4* rec = trec + (long long)(b * P + tp) * Npad;
+    auto pick = [&](unsigned& lm) {  // nearest unvisited leaf within the bound, or -1
+      lm = wave_min_u(lbl);
+      if (!(lm <= bound) || lm > 0x7f800000u) return -1;
+      const int ll = __builtin_ctzll(__ballot(lbl == lm));
+      if (lane == ll) lbl = 0xffffffffu;
+      return ll;
+    };
+    unsigned clm, nlm;
+    int cur = pick(clm);
+#if MPA_LEAF_GATE
+    float4 tG;  // lane l: record l % 32 of the leaf
+    if (cur >= 0) tG = rec[cur * kLeaf + (lane & 31)];
+#else
+    float4 tA, tB;
+    if (cur >= 0) {
+      tA = rec[cur * kLeaf + (lane & 15)];
+      tB = rec[cur * kLeaf + 16 + (lane & 15)];
+    }
+#endif
+    while (cur >= 0) {
+      if (scans >= cap) {  // deferred to the second pass (which visits every leaf again, with this wave's best as bound)
+        done = false;
+        return;
+      }
+      const int nxt = pick(nlm);
+#if MPA_LEAF_GATE
+      float4 nG = tG;
+      if (nxt >= 0) nG = rec[nxt * kLeaf + (lane & 31)];
+#else
+      float4 nA = tA, nB = tB;
+      if (nxt >= 0) {
+        nA = rec[nxt * kLeaf + (lane & 15)];
+        nB = rec[nxt * kLeaf + 16 + (lane & 15)];
+      }
+#endif
+      if (clm <= bound) {  // (the bound may have shrunk since this leaf was picked)
+        const float bx[8] = {readlane_f(blo.x, cur), readlane_f(blo.y, cur), readlane_f(blo.z, cur), 0.0f,
+                             readlane_f(bhi.x, cur), readlane_f(bhi.y, cur), readlane_f(bhi.z, cur), 0.0f};
+        const float mine = lb_point_box(X, Y, Z, bx);
+        MPA_LSTAT(st_tests);
+        if (__ballot(mine <= key_dist(best))) {
+          ++scans;
+#ifdef MPA_LEAF_EXP  // timing experiments: the scan of a visited leaf 0 (wrong results) or 2 times
+          for (int rep_ = 0; rep_ < MPA_LEAF_EXP; ++rep_) {
+            asm volatile("" : "+v"(X));
+#endif
+#if MPA_LEAF_GATE
+          // the gate: 4 matrix instructions, ~12 VALU instructions per 16 values
+          const bool lo = lane < 32;
+          const bool padrec = __float_as_int(tG.w) == kNoIdx;
+          const float tx = padrec ? 1e15f : tG.x - gw.cx, ty = padrec ? 1e15f : tG.y - gw.cy, tz = padrec ? 1e15f : tG.z - gw.cz;
+          const float tt = dist3(tx, ty, tz) + gw.Q;
+          const float a01 = lo ? tx : ty, a23 = lo ? tz : tt;
+          float m0, s0, m1, s1;
+          {  // one query tile at a time: 16 accumulator registers live, not 32
+            f32x16 acc = {0};
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, gw.b0_01, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23, gw.b0_23, acc, 0, 0, 0);
+            gate_reduce(acc, m0, s0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            f32x16 acc = {0};
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, gw.b1_01, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a23, gw.b1_23, acc, 0, 0, 0);
+            gate_reduce(acc, m1, s1);
+          }
+          {  // lanes 0-31 keep tile 0 and receive the upper half's tile 0; lanes 32-63 keep tile 1 and receive the lower half's
+            const auto ms = __builtin_amdgcn_permlane32_swap(__float_as_int(m0), __float_as_int(m1), false, false);
+            const auto ss = __builtin_amdgcn_permlane32_swap(__float_as_int(s0), __float_as_int(s1), false, false);
+            m0 = __int_as_float(ms[0]), m1 = __int_as_float(ms[1]), s0 = __int_as_float(ss[0]), s1 = __int_as_float(ss[1]);
+          }
+          // (now, in every lane, m0 / s0 stem from target rows 8g + u and m1 / s1 from rows 8g + 4 + u of the lane's own query)
+          const bool from1 = m1 < m0;
+          const float Mp = from1 ? m1 : m0, Sp = __builtin_fminf(__builtin_fmaxf(m0, m1), __builtin_fminf(s0, s1));
+          const int c4 = __float_as_int(Mp) & 15;
+          const int code = 8 * (c4 >> 2) + (c4 & 3) + (from1 ? 4 : 0);
+          const float Mf = __int_as_float(__float_as_int(Mp) & ~15) - gw.R, Sf = __int_as_float(__float_as_int(Sp) & ~15) - gw.R;
+          // error bound of the leaf: centre-relative magnitudes of the query and of the leaf's farthest corner
+          const float ex = __builtin_fmaxf(__builtin_fabsf(bx[0] - gw.cx), __builtin_fabsf(bx[4] - gw.cx));
+          const float ey = __builtin_fmaxf(__builtin_fabsf(bx[1] - gw.cy), __builtin_fabsf(bx[5] - gw.cy));
+          const float ez = __builtin_fmaxf(__builtin_fabsf(bx[2] - gw.cz), __builtin_fabsf(bx[6] - gw.cz));
+          const float E = 1.5e-5f * ((gw.qq + gw.Q) + dist3(ex, ey, ez));
+          const float bd = key_dist(best);
+          const bool cand = has && !(Mf - E > bd);             // (negated compares: NaNs take the careful branch)
+          const bool clear = Mp > 0.0f && (Sf - Mf > 4.0f * E);
+          if (__ballot(cand && !clear)) {  // near-ties / non-finite values: the exact scan of the whole leaf
+            MPA_LSTAT(st_exact);
+            const float4 tA = rec[cur * kLeaf + (lane & 15)], tB = rec[cur * kLeaf + 16 + (lane & 15)];
+            scan16(tA, X, Y, Z, best);
+            scan16(tB, X, Y, Z, best);
+          } else if (__ballot(cand)) {  // the leaf's nearest target of every query that wants one, exactly
+            const int src = 4 * code;
+            const float wx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(tG.x)));
+            const float wy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(tG.y)));
+            const float wz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(tG.z)));
+            const unsigned wi = (unsigned)__builtin_amdgcn_ds_bpermute(src, __float_as_int(tG.w));
+            const u64 k = make_key(dist3(X - wx, Y - wy, Z - wz), wi);
+            best = (cand && k < best) ? k : best;
+          }
+#else
+          scan16(tA, X, Y, Z, best);
+          scan16(tB, X, Y, Z, best);
+#endif
+#ifdef MPA_LEAF_EXP
+          }
+#endif
+          bound = wave_max_u((unsigned)(best >> 32));
+        }
+      }
+      cur = nxt;
+      clm = nlm;
+#if MPA_LEAF_GATE
+      tG = nG;
+#else
+      tA = nA;
+      tB = nB;
+#endif
+    }
+  };
+  if constexpr (SHAPE) {
+    const float* vb = g.valids + (long long)b * P;
+    const bool tvalid = lane < P && vb[lane < P ? lane : 0] != 0.0f;
+    const float4* pbx = reinterpret_cast<const float4*>(tpart + (long long)b * P * 8);
+    const float4 plo = pbx[2 * (lane < P ? lane : 0)], phi = pbx[2 * (lane < P ? lane : 0) + 1];
+    unsigned lbp = 0xffffffffu;
+    {
+      const float bx[8] = {plo.x, plo.y, plo.z, 0.0f, phi.x, phi.y, phi.z, 0.0f};
+      if (tvalid) lbp = __float_as_uint(lb_box_box(qlo, qhi, bx));
+    }
+    while (done) {
+      const unsigned pm = wave_min_u(lbp);
+      if (!(pm <= bound) || pm > 0x7f800000u) break;
+      const int pl = __builtin_ctzll(__ballot(lbp == pm));
+      if (lane == pl) lbp = 0xffffffffu;
+      const float bx[8] = {readlane_f(plo.x, pl), readlane_f(plo.y, pl), readlane_f(plo.z, pl), 0.0f,
+                           readlane_f(phi.x, pl), readlane_f(phi.y, pl), readlane_f(phi.z, pl), 0.0f};
+      const float mine = lb_point_box(X, Y, Z, bx);
+      if (__ballot(mine <= key_dist(best)) == 0) continue;
+      MPA_LSTAT(st_parts);
+      search_part(pl);
+    }
+  } else {
+    search_part(p);
+  }
+#ifdef MPA_LEAF_STATS
+  if (lane == 0) {
+    u64* s = g_leaf_stats[SHAPE ? 1 : 0];
+    atomicAdd(&s[0], 1ull);
+    atomicAdd(&s[1], (u64)st_tests);
+    atomicAdd(&s[2], (u64)scans);
+    atomicAdd(&s[3], (u64)st_parts);
+    atomicMax(&s[4], (u64)scans);
+    atomicAdd(&s[7], done ? 0ull : 1ull);
+    atomicAdd(&s[5], (u64)st_exact);
+    int k = 0;
+    while ((2 << k) <= scans) ++k;
+    atomicAdd(&s[8 + k], 1ull);
+  }
+#endif
+  return done;
+}
+
+// this wave's queries: coordinates (infinitely far for a lane without a query) and the flat output position
+__device__ __forceinline__ bool load_queries(const LeafArgs& g, int m, int k0, int dir, float& X, float& Y, float& Z,
+                                             int& qidx, float4& twin) {
+  const int lane = threadIdx.x & 63, k = k0 + lane;
+  const bool in = k < g.Npad;
+  const float4 q = g.rec[dir][(long long)m * g.Npad + (in ? k : g.Npad - 1)];
+  twin = g.rec[1 - dir][(long long)m * g.Npad + (in ? k : g.Npad - 1)];  // this point's own image in the other cloud
+  const bool has = in && __float_as_int(q.w) != kNoIdx;
+  const float inf = __builtin_inff();
+  X = has ? q.x : inf, Y = has ? q.y : inf, Z = has ? q.z : inf;
+  qidx = has ? __float_as_int(q.w) : kNoIdx;
+  return has;
+}
+
+template <bool SHAPE>
+__device__ __forceinline__ void store_result(const LeafArgs& g, int m, int w, int dir, bool has, int qidx, u64 best) {
+  const int lane = threadIdx.x & 63;
+  if (has) {
+    const int b = m / g.P;
+    int* iout = g.idx[dir] + (SHAPE ? (long long)b * g.P * g.N : (long long)m * g.N);
+    const unsigned bi = (unsigned)best;
+    iout[qidx] = bi == (unsigned)kNoIdx ? -1 : (int)bi;
+  }
+  float s = has ? key_dist(best) : 0.0f;  // the wave's distance sum (fixed tree: deterministic)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) g.wave_sums[((long long)dir * g.total_parts + m) * g.NW + w] = s;
+}
+
+// First pass.  grid = (ceil(B*P*NW / 4), 2), block 256: one wave per 64 consecutive sorted slots of a part.
+#ifndef MPA_LEAF_WAVES  // waves per SIMD the first pass is compiled for (register budget 512 / waves)
+#define MPA_LEAF_WAVES 4
+#endif
+template <bool SHAPE>
+__global__ __launch_bounds__(256, MPA_LEAF_WAVES) void leaf_search_kernel(const LeafArgs g) {
+  const int dir = blockIdx.y;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (wid >= g.total_parts * g.NW) return;
+  const int m = wid / g.NW, w = wid % g.NW;
+  if (g.valids[m] == 0.0f) return;
+  const int lane = threadIdx.x & 63, k0 = w * 64;
+  float X, Y, Z;
+  int qidx;
+  float4 twin;
+  const bool has = load_queries(g, m, k0, dir, X, Y, Z, qidx, twin);
+  u64 best = 0;  // (a lane without a query: key 0 is never beaten)
+  {
+    const float d = dist3(X - twin.x, Y - twin.y, Z - twin.z);
+    const u64 none = make_key(1e32f, (unsigned)kNoIdx), k = make_key(d, __float_as_uint(twin.w));
+    if (has) best = k < none ? k : none;
   }
   if (__ballot(has)) {  // (wave-uniform)
-    // box of this wave's queries: its two leaves
-    float qlo[3], qhi[3];
-    {
-      const int l0 = k0 / kLeaf, l1 = l0 + 1 < NL ? l0 + 1 : l0;
-      const float* a = qleaf + ((long long)m * NL + l0) * 8;
-      const float* c = qleaf + ((long long)m * NL + l1) * 8;
-#pragma unroll
-      for (int x = 0; x < 3; ++x) {
-        qlo[x] = __builtin_fminf(a[x], c[x]);
-        qhi[x] = __builtin_fmaxf(a[4 + x], c[4 + x]);
-      }
-    }
-    unsigned bound = wave_max_u(__float_as_uint(best));
-    // the leaves of target part tp, nearest first
-    auto search_part = [&](int tp) {
-      const float* lbx = tleaf + ((long long)(b * P + tp) * NL) * 8;
-      unsigned lbl = 0xffffffffu;
-      if (lane < NL) lbl = __float_as_uint(lb_box_box(qlo, qhi, lbx + lane * 8));
-      for (;;) {
-        const unsigned lm = wave_min_u(lbl);
-        if (!(lm <= bound) || lm > 0x7f800000u) break;
-        const int ll = __builtin_ctzll(__ballot(lbl == lm));
-        if (lane == ll) lbl = 0xffffffffu;
-        const float mine = lb_point_box(X, Y, Z, lbx + ll * 8);
-        if (__ballot(mine <= best) == 0) continue;
-        scan_leaf(trec + ((long long)(b * P + tp) * Npad + ll * kLeaf), X, Y, Z, best, bidx);
-        bound = wave_max_u(__float_as_uint(best));
-      }
-    };
-    if constexpr (SHAPE) {
-      const float* vb = valids + (long long)b * P;
-      const bool tvalid = lane < P && vb[lane < P ? lane : 0] != 0.0f;
-      unsigned lbp = 0xffffffffu;
-      if (tvalid) lbp = __float_as_uint(lb_box_box(qlo, qhi, tpart + (long long)(b * P + lane) * 8));
-      for (;;) {
-        const unsigned pm = wave_min_u(lbp);
-        if (!(pm <= bound) || pm > 0x7f800000u) break;
-        const int pl = __builtin_ctzll(__ballot(lbp == pm));
-        if (lane == pl) lbp = 0xffffffffu;
-        const float mine = lb_point_box(X, Y, Z, tpart + (long long)(b * P + pl) * 8);
-        if (__ballot(mine <= best) == 0) continue;
-        search_part(pl);
-      }
-      // padded parts: one representative target each (index pp * N), in part order
-      const float* tcloud = (dir == 0 ? origB : origA) + 3LL * b * P * N;
-      float rx = 0.0f, ry = 0.0f, rz = 0.0f;
-      const bool pad = lane < P && !tvalid;
-      if (pad) {
-        const float* t = tcloud + 3LL * lane * N;
-        rx = t[0], ry = t[1], rz = t[2];
-      }
-      unsigned long long pm = __ballot(pad);
+    if constexpr (SHAPE) {  // padded parts: one representative target each (index pp * N)
+      const int P = g.P, b = m / P;
+      const float* vb = g.valids + (long long)b * P;
+      const bool pad = lane < P && vb[lane < P ? lane : 0] == 0.0f;
+      const float* t = g.orig[1 - dir] + 3LL * ((long long)b * P + (pad ? lane : 0)) * g.N;
+      const float rx = t[0], ry = t[1], rz = t[2];
+      u64 pm = __ballot(pad);
       while (pm) {
         const int pp = __builtin_ctzll(pm);
         pm &= pm - 1;
-        const float tx = __builtin_amdgcn_readlane(rx, pp), ty = __builtin_amdgcn_readlane(ry, pp),
-                    tz = __builtin_amdgcn_readlane(rz, pp);
-        const float d = dist3(X - tx, Y - ty, Z - tz);
-        const int ti = pp * N;
-        if (d < best || (d == best && ti < bidx)) {
-          best = d;
-          bidx = ti;
-        }
+        const float d = dist3(X - readlane_f(rx, pp), Y - readlane_f(ry, pp), Z - readlane_f(rz, pp));
+        const u64 k = make_key(d, (unsigned)(pp * g.N));
+        best = k < best ? k : best;
       }
-    } else {
-      search_part(p);
     }
-    if (has) {
-      int* iout = (dir == 0 ? idx1 : idx2) + (SHAPE ? (long long)b * P * N : (long long)m * N);
-      iout[qidx] = bidx == kNoIdx ? -1 : bidx;
+    const bool done = leaf_search_wave<SHAPE>(g, m, k0, dir, X, Y, Z, has, best, 1, 0, kScanCap);
+    if (!done) {  // hand the wave to the second pass with what it has found so far
+      int slot = 0;
+      if (lane == 0) slot = atomicAdd(g.heavy_count, 1);
+      slot = __builtin_amdgcn_readfirstlane(slot);
+      if (lane == 0) g.heavy_list[slot] = (m * g.NW + w) * 2 + dir;
+      g.heavy_keys[(long long)slot * 64 + lane] = best;
+      return;
     }
   }
-  // the block's distance sum (fixed tree: deterministic)
-  float s = has ? best : 0.0f;
+  store_result<SHAPE>(g, m, w, dir, has, qidx, best);
+}
+
+// Second pass: the deferred waves, kSplit waves each.  Every wave starts from the saved keys (a bound that is already
+// close to final), takes every kSplit-th leaf of every part it still has to look at, and the block merges the keys.
+// grid = any (blocks stride over the list), block 64 * kSplit.
+template <bool SHAPE>
+__global__ __launch_bounds__(64 * kSplit) void leaf_search_heavy_kernel(const LeafArgs g) {
+  __shared__ u64 keys[kSplit][64];
+  const int count = *g.heavy_count;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (int item = blockIdx.x; item < count; item += gridDim.x) {
+    const int code = g.heavy_list[item];
+    const int dir = code & 1, mw = code >> 1, m = mw / g.NW, w = mw % g.NW, k0 = w * 64;
+    float X, Y, Z;
+    int qidx;
+    float4 twin;
+    const bool has = load_queries(g, m, k0, dir, X, Y, Z, qidx, twin);
+    u64 best = g.heavy_keys[(long long)item * 64 + lane];
+    (void)leaf_search_wave<SHAPE>(g, m, k0, dir, X, Y, Z, has, best, kSplit, wv, 0x7fffffff);
+    __syncthreads();  // (the previous item's readers are done with `keys`)
+    keys[wv][lane] = best;
+    __syncthreads();
+    if (wv == 0) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (lane == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) tile_sums[(long long)dir * gridDim.x + bid] = (red[0] + red[1]) + (red[2] + red[3]);
+      for (int v = 1; v < kSplit; ++v) {
+        const u64 o = keys[v][lane];
+        best = o < best ? o : best;
+      }
+      store_result<SHAPE>(g, m, w, dir, has, qidx, best);
+    }
+  }
 }
 
 }  // namespace
@@ -352,22 +694,54 @@ bool leaf_supported(int64_t P, int64_t N) { return P >= 1 && P <= 64 && N >= 1 &
 
 void launch_leaf_order(const float* part_pcs, const float* valids, int64_t B, int64_t P, int64_t N, float* sorted,
                        hipStream_t s) {
-  hipLaunchKernelGGL(leaf_order_kernel, dim3((unsigned)(B * P)), dim3(1024), 0, s, part_pcs, valids, (int)N, leaf_npad(N),
+  hipLaunchKernelGGL(leaf_order_kernel, dim3((unsigned)(B * P)), dim3(kOrderThreads), 0, s, part_pcs, valids, (int)N, leaf_npad(N),
                      reinterpret_cast<float4*>(sorted));
 }
 
+int64_t leaf_scratch_floats(int64_t B, int64_t P, int64_t N) {  // heavy list + keys + counters, shared by both searches
+  const int64_t nw = leaf_npad(N) >= 64 ? leaf_npad(N) / 64 : 1, items = 2 * B * P * nw;
+  return 16 + (items + 3) / 4 * 4 + items * 64 * 2;
+}
+int* leaf_heavy_counters(float* scratch) { return reinterpret_cast<int*>(scratch); }
+
 void launch_leaf_search(bool shape, const float* valids, const LeafCloud& A, const LeafCloud& Bc, int64_t B, int64_t P,
-                        int64_t N, int tilesq, int32_t* idx1, int32_t* idx2, float* tile_sums, hipStream_t s) {
-  const int Npad = leaf_npad(N);
-  const dim3 grid((unsigned)(B * P * tilesq), 2);
-  if (shape)
-    hipLaunchKernelGGL((leaf_search_kernel<true>), grid, dim3(256), 0, s, valids, reinterpret_cast<const float4*>(A.rec),
-                       reinterpret_cast<const float4*>(Bc.rec), A.leaf, Bc.leaf, A.part, Bc.part, A.orig, Bc.orig, (int)P,
-                       (int)N, Npad, tilesq, idx1, idx2, tile_sums);
-  else
-    hipLaunchKernelGGL((leaf_search_kernel<false>), grid, dim3(256), 0, s, valids, reinterpret_cast<const float4*>(A.rec),
-                       reinterpret_cast<const float4*>(Bc.rec), A.leaf, Bc.leaf, A.part, Bc.part, A.orig, Bc.orig, (int)P,
-                       (int)N, Npad, tilesq, idx1, idx2, tile_sums);
+                        int64_t N, int32_t* idx1, int32_t* idx2, float* wave_sums, float* scratch, hipStream_t s) {
+  LeafArgs g;
+  g.valids = valids;
+  g.rec[0] = reinterpret_cast<const float4*>(A.rec);
+  g.rec[1] = reinterpret_cast<const float4*>(Bc.rec);
+  g.leaf[0] = A.leaf, g.leaf[1] = Bc.leaf;
+  g.part[0] = A.part, g.part[1] = Bc.part;
+  g.orig[0] = A.orig, g.orig[1] = Bc.orig;
+  g.P = (int)P, g.N = (int)N, g.Npad = leaf_npad(N);
+  g.NW = g.Npad >= 64 ? g.Npad / 64 : 1;
+  g.idx[0] = idx1, g.idx[1] = idx2;
+  g.wave_sums = wave_sums;
+  g.total_parts = (int)(B * P);
+  const int64_t items = 2 * B * P * g.NW;
+  g.heavy_count = leaf_heavy_counters(scratch) + (shape ? 1 : 0);  // (zeroed by the producer of the records)
+  g.heavy_list = reinterpret_cast<int*>(scratch) + 16;
+  g.heavy_keys = reinterpret_cast<unsigned long long*>(scratch + 16 + (items + 3) / 4 * 4);
+  const dim3 grid((unsigned)((B * P * g.NW + 3) / 4), 2);
+  const unsigned heavy_blocks = (unsigned)(items < 4096 ? items : 4096);  // (blocks beyond the list's length leave at once)
+  if (shape) {
+    hipLaunchKernelGGL((leaf_search_kernel<true>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((leaf_search_heavy_kernel<true>), dim3(heavy_blocks), dim3(64 * kSplit), 0, s, g);
+  } else {
+    hipLaunchKernelGGL((leaf_search_kernel<false>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((leaf_search_heavy_kernel<false>), dim3(heavy_blocks), dim3(64 * kSplit), 0, s, g);
+  }
 }
 
 }  // namespace mpa
+
+#ifdef MPA_LEAF_STATS
+extern "C" int mpa_debug_leaf_stats(unsigned long long* out64, int reset) {
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(mpa::g_leaf_stats), 64 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mpa::g_leaf_stats), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -124,17 +124,17 @@ def test_self_check_leg_reports_the_ratio(cuda_device, capsys):
 def test_kernel_timer_scope(cuda_device):
     from multi_part_assembly_amd import _lib
 
-    t = _lib.KernelTimer(only=("grid_search_kernel",))
+    t = _lib.KernelTimer(only=("shape_search_kernel",))
     _lib.KernelTimer.active = t
     try:
         assert _lib.KernelTimer.start("pointnet_forward[1x2x3]") is None
         assert _lib.KernelTimer.phase_events(["assembly_pose[x]", "assembly_finalize[x]"]) is None
-        evs = _lib.KernelTimer.phase_events(["grid_search_kernel[x]"])
+        evs = _lib.KernelTimer.phase_events(["shape_search_kernel[x]"])
         assert evs is not None and len(evs) == 2 and all(e is not None for e in evs)
         arr = _lib.KernelTimer.handles([None] * 5 + evs)
         assert len(arr) == 7 and arr[0] is None and arr[5] is not None
-        _lib.KernelTimer.add_phases(["grid_search_kernel[x]"], evs)
+        _lib.KernelTimer.add_phases(["shape_search_kernel[x]"], evs)
         torch.cuda.synchronize()
-        assert list(t.summary()) == ["grid_search_kernel[x]"]
+        assert list(t.summary()) == ["shape_search_kernel[x]"]
     finally:
         _lib.KernelTimer.active = None

@@ -10,7 +10,10 @@ dev = torch.device("cuda:0")
 B, P, N = 32, 20, 1000
 L = _lib.lib()
 modes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["grid", "leaf"]
+ONLY = os.environ.get("PROBE_ONLY", "")  # e.g. "everyday:untrained" (for a profiler run of one case)
 for preset in ("everyday", "artifact"):
+    if ONLY and not ONLY.startswith(preset):
+        continue
     batch = synthetic.make_batch(B, P, N, seed=1234, preset=preset, device=dev)
     pcs, v = batch["part_pcs"], batch["part_valids"]
     qg, tg = Rotation3D(batch["part_quat"]).rot.contiguous(), batch["part_trans"].contiguous()
@@ -27,6 +30,8 @@ for preset in ("everyday", "artifact"):
     e1.record(); torch.cuda.synchronize()
     print(f"{preset}: valid parts {int(v.sum())}, part_order {e0.elapsed_time(e1) / 5:.3f} ms", flush=True)
     for regime in ("untrained", "trained"):
+        if ONLY and ONLY.split(":")[1] != regime:
+            continue
         if regime == "untrained":
             qp = torch.nn.functional.normalize(noise_q, dim=-1).contiguous(); tp = (0.1 * noise_t).contiguous()
         else:
