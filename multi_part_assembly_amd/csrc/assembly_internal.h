@@ -19,9 +19,11 @@ unsigned* grid_ticket(int32_t* iws, int64_t B);
 // one representative).  Writes idx1/idx2 [B,P,N] (index within the sample, -1 if none) and the per-part
 // distance sums into tile_sums[dir][m*tiles + 0].  fws/iws: scratch sized by the functions above.
 // before_search / after_search (nullable) are recorded around the search kernel proper.
+// route (nullable) [B]: samples with route[b] == 0 are left to the leaf search (no work, no sums written for them).
 int launch_grid_shape_search(const float* valids, const float* S1, const float* S2, int64_t B, int64_t P,
                              int64_t N, int tiles, float* fws, int32_t* iws, int32_t* idx1, int32_t* idx2,
-                             float* tile_sums, hipEvent_t before_search, hipEvent_t after_search, hipStream_t s);
+                             float* tile_sums, hipEvent_t before_search, hipEvent_t after_search, hipStream_t s,
+                             const int* route = nullptr);
 
 // ---- the same exact pruned search for two plain clouds per sample (the generic operator, chamfer.hip) -----------------
 // xyz1 [B, n1, 3], xyz2 [B, n2, 3] -> dist / idx of mpa_chamfer_forward's contract, bit for bit, for every sample whose
@@ -55,9 +57,16 @@ void launch_leaf_order(const float* part_pcs, const float* valids, int64_t B, in
 // other shape (indices p * N + n), else every part against its own copy (indices n); per-wave distance sums into
 // wave_sums[dir][m][NW], NW = max(1, Npad / 64).  scratch: leaf_scratch_floats() floats (16-byte aligned), shared by the two
 // searches of a loss evaluation; its two counters (leaf_heavy_counters) must be zero when the first search starts.
+// route (nullable) [B]: the whole-shape search skips samples with route[b] != 0 (searched by the grid, grid_nn.hip).
 int64_t leaf_scratch_floats(int64_t B, int64_t P, int64_t N);
 int* leaf_heavy_counters(float* scratch);
+int* leaf_route(float* scratch);  // [B] ints inside the scratch
 void launch_leaf_search(bool shape, const float* valids, const LeafCloud& A, const LeafCloud& B_, int64_t B, int64_t P,
-                        int64_t N, int32_t* idx1, int32_t* idx2, float* wave_sums, float* scratch, hipStream_t s);
+                        int64_t N, int32_t* idx1, int32_t* idx2, float* wave_sums, float* scratch, hipStream_t s,
+                        const int* route = nullptr);
+// Which search answers each sample's whole-shape term (route[b]: 1 = grid, 0 = leaf).  force < 0: by the sample itself —
+// the share of the ground-truth shape's bounding box that its parts' boxes fill (part boxes pbox [B*P][8]); many small
+// parts in a large box (a clumpy cloud) is where a uniform grid loses and the leaves win.  force 0 / 1: every sample alike.
+void launch_leaf_route(const float* valids, const float* pbox, int64_t B, int64_t P, int force, int* route, hipStream_t s);
 
 }  // namespace mpa

@@ -191,11 +191,13 @@ __global__ __launch_bounds__(kThreads) void assembly_pose_leaf_kernel(
     const float4* __restrict__ sorted, const float* __restrict__ valids, const float* __restrict__ q1,
     const float* __restrict__ t1, const float* __restrict__ q2, const float* __restrict__ t2, int P, int N, int Npad,
     int fill_pads, float* __restrict__ R1, float* __restrict__ R2, float* __restrict__ S1, float* __restrict__ S2,
-    float* __restrict__ partial, LeafOut out, int* __restrict__ heavy_counters) {
+    float* __restrict__ partial, LeafOut out, int* __restrict__ heavy_counters, float* __restrict__ bbox,
+    unsigned* __restrict__ ticket) {
   __shared__ float red[kThreads / 64];
   __shared__ float box[kThreads / 32][12];
   const int m = blockIdx.x, p = m % P;
   if (m == 0 && threadIdx.x < 2) heavy_counters[threadIdx.x] = 0;  // of the two searches' second passes
+  if (m == 0 && threadIdx.x == 0 && ticket != nullptr) *ticket = 0u;  // of the grid sorts' "last block" election
   const Quat qa = load_quat(q1 + 4 * m), qb = load_quat(q2 + 4 * m);
   const float ta[3] = {t1[3 * m], t1[3 * m + 1], t1[3 * m + 2]};
   const float tb[3] = {t2[3 * m], t2[3 * m + 1], t2[3 * m + 2]};
@@ -290,6 +292,8 @@ __global__ __launch_bounds__(kThreads) void assembly_pose_leaf_kernel(
     float* ps = cloud == 0 ? out.part[2] : out.part[3];
     pr[8LL * m + 4 * hi + ax] = v;
     ps[8LL * m + 4 * hi + ax] = v + (cloud == 0 ? tA : tB);
+    // the grid search's per-part boxes (lo1, lo2, hi1, hi2 of the translated clouds): c is already in that order
+    if (bbox != nullptr) bbox[12LL * m + c] = v + (cloud == 0 ? tA : tB);
   }
 }
 
@@ -413,7 +417,8 @@ __global__ __launch_bounds__(64) void assembly_finalize_kernel(
     const float* __restrict__ valids, const float* __restrict__ q1, const float* __restrict__ t1,
     const float* __restrict__ q2, const float* __restrict__ t2, const float* __restrict__ partial,
     const float* __restrict__ part_tiles, const float* __restrict__ shape_tiles, int B, int P, int N,
-    int tiles_p, int tiles_s, int training, float* __restrict__ losses) {
+    int tiles_p, int tiles_s, int training, float* __restrict__ losses, const float* __restrict__ shape_tiles_grid,
+    int tiles_grid, const int* __restrict__ route) {
   const int b = blockIdx.x, p = threadIdx.x;
   float v = 0.0f, trans = 0.0f, cosine = 0.0f, cd = 0.0f, l2 = 0.0f, scd_slots = 0.0f, scd_parts = 0.0f;
   if (p < P) {
@@ -432,9 +437,17 @@ __global__ __launch_bounds__(64) void assembly_finalize_kernel(
         c1 += part_tiles[(long long)m * tiles_p + t];
         c2 += part_tiles[nblk_p + (long long)m * tiles_p + t];
       }
-      for (int t = 0; t < tiles_s; ++t) {
-        s1 += shape_tiles[(long long)m * tiles_s + t];
-        s2 += shape_tiles[nblk_s + (long long)m * tiles_s + t];
+      if (route != nullptr && route[b] != 0) {  // this sample's whole-shape sums come from the grid search
+        const long long nblk_g = (long long)B * P * tiles_grid;
+        for (int t = 0; t < tiles_grid; ++t) {
+          s1 += shape_tiles_grid[(long long)m * tiles_grid + t];
+          s2 += shape_tiles_grid[nblk_g + (long long)m * tiles_grid + t];
+        }
+      } else {
+        for (int t = 0; t < tiles_s; ++t) {
+          s1 += shape_tiles[(long long)m * tiles_s + t];
+          s2 += shape_tiles[nblk_s + (long long)m * tiles_s + t];
+        }
       }
       const float inv_n = 1.0f / (float)N;
       cd = (c1 * inv_n + c2 * inv_n) * v;                  // mean_N d1 + mean_N d2   (loss.py:132)
@@ -675,13 +688,16 @@ struct Workspace {
   float *order, *rec[4], *leaf[4], *pbox[4], *wsum_part, *wsum_shape, *scratch;
 };
 
-// 0: brute-force scan, 1: grid-pruned search (grid_nn.hip), 2: leaf search (leaf_nn.hip; default).  Identical results;
-// MPA_SHAPE_SEARCH = brute | grid | leaf selects (tests cross-check all three).
+// 0: brute-force scans, 1: brute-force per-part scan + grid-pruned whole-shape search (grid_nn.hip), 2: leaf search for
+// both (leaf_nn.hip), 3 (default): leaf search for the per-part term, and for the whole-shape term of every SAMPLE the
+// search its geometry favours (leaf_route_kernel: grid where the parts fill the shape's box, leaves where they are many and
+// small).  Identical results; MPA_SHAPE_SEARCH = brute | grid | leaf | auto selects (tests cross-check all of them).
 int search_mode(int64_t P, int64_t N) {
   const char* e = getenv("MPA_SHAPE_SEARCH");
   if (e && e[0] == 'b') return 0;
   if ((e && e[0] == 'g') || !mpa::leaf_supported(P, N)) return P <= 64 ? 1 : 0;  // (the grid keeps one padded part per lane)
-  return 2;
+  if (e && e[0] == 'l') return 2;
+  return 3;
 }
 
 // Queries per lane of the NN scans: 4 (fewer, fatter blocks) when there is enough work to fill the chip,
@@ -789,8 +805,9 @@ extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const fl
   // padded parts never write their tile sums: clear them (2 directions x B*P*tiles, both arrays)
   mpa::zero_words_async(w.part_tiles, 4 * B * P * w.tiles, s);
   mark(0);
-  if (mode == 2) {
+  if (mode >= 2) {
     // ---- leaf search: k-d order (once per batch), pose kernel in that order, both searches over the leaves ----
+    int* route = mpa::leaf_route(w.scratch);
     const int npad = mpa::leaf_npad(N);
     MPA_REQUIRE(B * P * (int64_t)npad < (1LL << 31), "assembly_loss_forward: problem too large");
     if (order == nullptr) {
@@ -806,20 +823,26 @@ extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const fl
     hipLaunchKernelGGL(assembly_pose_leaf_kernel, dim3(parts), dim3(kThreads), 0, s,
                        reinterpret_cast<const float4*>(order), valids, quat_pred, trans_pred, quat_gt, trans_gt, (int)P,
                        (int)N, npad, fill_pad_points, w.R1, w.R2, w.S1, w.S2, w.partial, lo,
-                       mpa::leaf_heavy_counters(w.scratch));
+                       mpa::leaf_heavy_counters(w.scratch), mode == 3 ? mpa::grid_bbox(w.grid_f, B, P, N) : (float*)nullptr,
+                       mode == 3 ? mpa::grid_ticket(w.grid_i, B) : (unsigned*)nullptr);
+    mpa::launch_leaf_route(valids, w.pbox[3], B, P, mode == 3 ? -1 : 0, route, s);
     mark(1);
     const mpa::LeafCloud r1{w.rec[0], w.leaf[0], w.pbox[0], w.R1}, r2{w.rec[1], w.leaf[1], w.pbox[1], w.R2};
     const mpa::LeafCloud s1{w.rec[2], w.leaf[2], w.pbox[2], w.S1}, s2{w.rec[3], w.leaf[3], w.pbox[3], w.S2};
     mpa::launch_leaf_search(false, valids, r1, r2, B, P, N, w.ip1, w.ip2, w.wsum_part, w.scratch, s);
     mark(2);
     mark(5);
-    mpa::launch_leaf_search(true, valids, s1, s2, B, P, N, w.is1, w.is2, w.wsum_shape, w.scratch, s);
+    if (mode == 3)  // (samples routed to the leaf search cost these launches a header each)
+      mpa::launch_grid_shape_search(valids, w.S1, w.S2, B, P, N, w.tiles, w.grid_f, w.grid_i, w.is1, w.is2,
+                                    w.shape_tiles, nullptr, nullptr, s, route);
+    mpa::launch_leaf_search(true, valids, s1, s2, B, P, N, w.is1, w.is2, w.wsum_shape, w.scratch, s, route);
     mark(6);
     mark(3);
     const int nw = npad >= 64 ? npad / 64 : 1;  // every wave of a valid part leaves its distance sum
     hipLaunchKernelGGL(assembly_finalize_kernel, dim3((unsigned)B), dim3(64), 0, s, valids, quat_pred,
                        trans_pred, quat_gt, trans_gt, w.partial, (const float*)w.wsum_part,
-                       (const float*)w.wsum_shape, (int)B, (int)P, (int)N, nw, nw, training, losses);
+                       (const float*)w.wsum_shape, (int)B, (int)P, (int)N, nw, nw, training, losses,
+                       (const float*)w.shape_tiles, w.tiles, (const int*)route);
     mark(4);
     return mpa::check_launch("assembly_loss_forward");
   }
@@ -852,7 +875,7 @@ extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const fl
   mark(3);
   hipLaunchKernelGGL(assembly_finalize_kernel, dim3((unsigned)B), dim3(64), 0, s, valids, quat_pred,
                      trans_pred, quat_gt, trans_gt, w.partial, w.part_tiles, w.shape_tiles, (int)B,
-                     (int)P, (int)N, w.tiles, w.tiles, training, losses);
+                     (int)P, (int)N, w.tiles, w.tiles, training, losses, (const float*)nullptr, 0, (const int*)nullptr);
   mark(4);
   return mpa::check_launch("assembly_loss_forward");
 }

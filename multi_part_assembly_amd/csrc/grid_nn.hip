@@ -372,7 +372,8 @@ __global__ __launch_bounds__(1024) void grid_sort_kernel(const float* __restrict
                                                          int* __restrict__ starts, int* __restrict__ batches,
                                                          int* __restrict__ worklist, float4* __restrict__ records,
                                                          int rec_stride, unsigned* __restrict__ ticket,
-                                                         XcdPlan* __restrict__ plan, int nwaves) {
+                                                         XcdPlan* __restrict__ plan, int nwaves,
+                                                         const int* __restrict__ route) {
   __shared__ int cnt[kMaxCells + kMaxCells / 32 + 1];
   __shared__ int wsum[16][2];
   __shared__ GridParams gsm;
@@ -421,8 +422,15 @@ __global__ __launch_bounds__(1024) void grid_sort_kernel(const float* __restrict
   const int slot = (b * 2 + c) * 2 + role;
   const float* shape = (c == 0 ? S1 : S2) + 3LL * b * P * N;
   const PartsSource src{vsm, shape, N, P * N};
-  if (role == 0) grid_sort_role<0, false>(src, g, slot, starts, batches, worklist, kWorkStride, records, rec_stride, cnt, wsum);
-  else grid_sort_role<1, false>(src, g, slot, starts, batches, worklist, kWorkStride, records, rec_stride, cnt, wsum);
+  if (route != nullptr && route[b] == 0) {
+    // this sample's whole-shape search is the leaf search's (leaf_nn.hip): no records, and a work list of length zero —
+    // the search waves of its two pairs find nothing to do (bst[nsuper] = 0)
+    if (role == 1 && threadIdx.x == 0) batches[(long long)slot * kStartStride + g.nsuper] = 0;
+  } else if (role == 0) {
+    grid_sort_role<0, false>(src, g, slot, starts, batches, worklist, kWorkStride, records, rec_stride, cnt, wsum);
+  } else {
+    grid_sort_role<1, false>(src, g, slot, starts, batches, worklist, kWorkStride, records, rec_stride, cnt, wsum);
+  }
   if (plan == nullptr) return;
   // the last block of the launch plans the search's waves: everybody's batch counts are in global memory by then
   __syncthreads();
@@ -1181,10 +1189,12 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
 __global__ __launch_bounds__(256) void grid_part_sum_kernel(const float* __restrict__ valids,
                                                             const float* __restrict__ dist1,
                                                             const float* __restrict__ dist2, int N, int tiles,
-                                                            float* __restrict__ tile_sums) {
+                                                            float* __restrict__ tile_sums, int P,
+                                                            const int* __restrict__ route) {
   __shared__ float red[4];
   const int m = blockIdx.x, dir = blockIdx.y;
   if (valids[m] == 0.0f) return;
+  if (route != nullptr && route[m / P] == 0) return;  // (searched by the leaf search)
   const float* d = (dir == 0 ? dist1 : dist2) + (long long)m * N;
   float s = 0.0f;
   for (int n = threadIdx.x; n < N; n += 256) s += d[n];
@@ -1216,7 +1226,8 @@ unsigned* grid_ticket(int32_t* iws, int64_t B) {
 
 int launch_grid_shape_search(const float* valids, const float* S1, const float* S2, int64_t B, int64_t P,
                              int64_t N, int tiles, float* fws, int32_t* iws, int32_t* idx1, int32_t* idx2,
-                             float* tile_sums, hipEvent_t before_search, hipEvent_t after_search, hipStream_t s) {
+                             float* tile_sums, hipEvent_t before_search, hipEvent_t after_search, hipStream_t s,
+                             const int* route) {
   const int rec_stride = (int)(P * N + 8);
   float4* records = reinterpret_cast<float4*>(fws);
   GridParams* params = reinterpret_cast<GridParams*>(fws + 4 * B * (int64_t)rec_stride * 4);
@@ -1231,7 +1242,7 @@ int launch_grid_shape_search(const float* valids, const float* S1, const float* 
   const int nwaves = (int)(MPA_GRID_WAVES * 2 * B);
   hipLaunchKernelGGL(grid_sort_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N,
                      (const float*)grid_bbox(fws, B, P, N), params, starts, batches, worklist, records, rec_stride,
-                     grid_ticket(iws, B), xcd_table ? plan : (XcdPlan*)nullptr, nwaves);
+                     grid_ticket(iws, B), xcd_table ? plan : (XcdPlan*)nullptr, nwaves, route);
   if (before_search != nullptr) (void)hipEventRecord(before_search, s);
   if (xcd_table)
     hipLaunchKernelGGL((grid_search_kernel<false, int>), dim3((unsigned)nwaves), dim3(64), 0, s, valids, S1, S2, (int)P,
@@ -1243,7 +1254,7 @@ int launch_grid_shape_search(const float* valids, const float* S1, const float* 
                        idx1, idx2, (const XcdPlan*)nullptr);
   if (after_search != nullptr) (void)hipEventRecord(after_search, s);
   hipLaunchKernelGGL(grid_part_sum_kernel, dim3((unsigned)(B * P), 2), dim3(256), 0, s, valids, dist1, dist2, (int)N,
-                     tiles, tile_sums);
+                     tiles, tile_sums, (int)P, route);
   return MPA_OK;
 }
 

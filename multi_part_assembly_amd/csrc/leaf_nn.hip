@@ -356,6 +356,7 @@ struct LeafArgs {
   int* heavy_list;
   u64* heavy_keys;
   int total_parts;      // B * P
+  const int* route;     // nullable [B]: SHAPE skips samples with route[b] != 0 (the grid search's)
 };
 
 #ifndef MPA_LEAF_CAP
@@ -611,6 +612,7 @@ __global__ __launch_bounds__(256, MPA_LEAF_WAVES) void leaf_search_kernel(const 
   if (wid >= g.total_parts * g.NW) return;
   const int m = wid / g.NW, w = wid % g.NW;
   if (g.valids[m] == 0.0f) return;
+  if (SHAPE && g.route != nullptr && g.route[m / g.P] != 0) return;
   const int lane = threadIdx.x & 63, k0 = w * 64;
   float X, Y, Z;
   int qidx;
@@ -700,13 +702,53 @@ void launch_leaf_order(const float* part_pcs, const float* valids, int64_t B, in
 
 int64_t leaf_scratch_floats(int64_t B, int64_t P, int64_t N) {  // heavy list + keys + counters, shared by both searches
   const int64_t nw = leaf_npad(N) >= 64 ? leaf_npad(N) / 64 : 1, items = 2 * B * P * nw;
-  return 16 + (items + 3) / 4 * 4 + items * 64 * 2;
+  return 16 + (B + 3) / 4 * 4 + (items + 3) / 4 * 4 + items * 64 * 2;  // counters, route, list, keys
 }
 int* leaf_heavy_counters(float* scratch) { return reinterpret_cast<int*>(scratch); }
+int* leaf_route(float* scratch) { return reinterpret_cast<int*>(scratch) + 16; }
+
+namespace {
+constexpr float kRouteFill = 0.075f;  // parts' boxes fill at least this share of the shape's box: the grid answers
+__global__ __launch_bounds__(64) void leaf_route_kernel(const float* __restrict__ valids, const float* __restrict__ pbox,
+                                                        int P, int force, int* __restrict__ route) {
+  const int b = blockIdx.x, p = threadIdx.x;
+  if (force >= 0) {
+    if (p == 0) route[b] = force;
+    return;
+  }
+  const bool on = p < P && valids[(long long)b * P + (p < P ? p : 0)] != 0.0f;
+  const float inf = __builtin_inff();
+  float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, vol = 0.0f;
+  if (on) {
+    const float* bx = pbox + ((long long)b * P + p) * 8;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) lo[a] = bx[a], hi[a] = bx[4 + a];
+    vol = __builtin_fmaxf(hi[0] - lo[0], 0.0f) * __builtin_fmaxf(hi[1] - lo[1], 0.0f) * __builtin_fmaxf(hi[2] - lo[2], 0.0f);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], off, 64));
+      hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+    }
+    vol += __shfl_xor(vol, off, 64);
+  }
+  const float all = (hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]);
+  // (non-finite or empty boxes: the comparison is false -> leaf search, which is exact for anything)
+  if (p == 0) route[b] = vol >= kRouteFill * all && all > 0.0f ? 1 : 0;
+}
+}  // namespace
+
+void launch_leaf_route(const float* valids, const float* pbox, int64_t B, int64_t P, int force, int* route, hipStream_t s) {
+  hipLaunchKernelGGL(leaf_route_kernel, dim3((unsigned)B), dim3(64), 0, s, valids, pbox, (int)P, force, route);
+}
 
 void launch_leaf_search(bool shape, const float* valids, const LeafCloud& A, const LeafCloud& Bc, int64_t B, int64_t P,
-                        int64_t N, int32_t* idx1, int32_t* idx2, float* wave_sums, float* scratch, hipStream_t s) {
+                        int64_t N, int32_t* idx1, int32_t* idx2, float* wave_sums, float* scratch, hipStream_t s,
+                        const int* route) {
   LeafArgs g;
+  g.route = route;
   g.valids = valids;
   g.rec[0] = reinterpret_cast<const float4*>(A.rec);
   g.rec[1] = reinterpret_cast<const float4*>(Bc.rec);
@@ -720,8 +762,8 @@ void launch_leaf_search(bool shape, const float* valids, const LeafCloud& A, con
   g.total_parts = (int)(B * P);
   const int64_t items = 2 * B * P * g.NW;
   g.heavy_count = leaf_heavy_counters(scratch) + (shape ? 1 : 0);  // (zeroed by the producer of the records)
-  g.heavy_list = reinterpret_cast<int*>(scratch) + 16;
-  g.heavy_keys = reinterpret_cast<unsigned long long*>(scratch + 16 + (items + 3) / 4 * 4);
+  g.heavy_list = reinterpret_cast<int*>(scratch) + 16 + (B + 3) / 4 * 4;
+  g.heavy_keys = reinterpret_cast<unsigned long long*>(scratch + 16 + (B + 3) / 4 * 4 + (items + 3) / 4 * 4);
   const dim3 grid((unsigned)((B * P * g.NW + 3) / 4), 2);
   const unsigned heavy_blocks = (unsigned)(items < 4096 ? items : 4096);  // (blocks beyond the list's length leave at once)
   if (shape) {

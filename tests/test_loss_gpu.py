@@ -171,11 +171,11 @@ def _raw_assembly_forward(batch, qp, tp, mode, monkeypatch, with_part=False):
 
 
 def _assert_searches_agree(batch, qp, tp, monkeypatch):
-    """brute-force scan == grid-pruned search == leaf search: all four arg-min arrays (per-part Chamfer both ways,
+    """brute-force scan == grid-pruned search == leaf search == per-sample choice of the two: all four arg-min arrays (per-part Chamfer both ways,
     whole-shape Chamfer both ways) bit-equal on the valid parts, the five loss terms to summation order."""
     lb, ib = _raw_assembly_forward(batch, qp, tp, "brute", monkeypatch, with_part=True)
     valid = batch["part_valids"].bool()
-    for mode in ("grid", "leaf"):
+    for mode in ("grid", "leaf", "auto"):  # (auto: per sample, the grid or the leaves)
         lm, im = _raw_assembly_forward(batch, qp, tp, mode, monkeypatch, with_part=True)
         for k in range(4):
             assert torch.equal(ib[k][valid], im[k][valid]), (mode, k, int((ib[k][valid] != im[k][valid]).sum()))
@@ -220,9 +220,10 @@ def test_fused_loss_at_benchmark_size_matches_oracle(cuda_device, monkeypatch):
     # arg-min arrays of the two searches, straight from the workspace of the C ABI
     _, s1, s2 = _raw_assembly_forward(batch, qp.to(cuda_device).contiguous(), tp.to(cuda_device).contiguous(), "leaf",
                                       monkeypatch)
-    _, g1, g2 = _raw_assembly_forward(batch, qp.to(cuda_device).contiguous(), tp.to(cuda_device).contiguous(), "grid",
-                                      monkeypatch)
-    assert torch.equal(s1[v.bool()], g1[v.bool()]) and torch.equal(s2[v.bool()], g2[v.bool()])
+    for other in ("grid", "auto"):
+        _, g1, g2 = _raw_assembly_forward(batch, qp.to(cuda_device).contiguous(), tp.to(cuda_device).contiguous(), other,
+                                          monkeypatch)
+        assert torch.equal(s1[v.bool()], g1[v.bool()]) and torch.equal(s2[v.bool()], g2[v.bool()]), other
     filled = cpcs.masked_fill(cv[..., None, None] == 0, 1e3)
     c1 = og.transform_pc(tp, og.checked_quat(qp), filled).flatten(1, 2).numpy()
     c2 = og.transform_pc(gtr, gq, filled).flatten(1, 2).numpy()
@@ -325,6 +326,21 @@ def test_leaf_search_with_trained_poses_and_given_order(cuda_device, monkeypatch
                                          order=order)
         for k in L.LOSS_TERMS:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_auto_search_routes_samples_both_ways(cuda_device, monkeypatch):
+    """One batch whose samples fall on both sides of the routing rule (few large parts -> grid, many small parts -> leaf
+    search): the per-sample choice must give the brute-force answer for every sample."""
+    from multi_part_assembly_amd import synthetic
+
+    a = synthetic.make_batch(4, 20, 500, preset="everyday", seed=31, device=cuda_device, num_parts=[3, 20, 9, 14])
+    b = synthetic.make_batch(4, 20, 500, preset="artifact", seed=32, device=cuda_device, num_parts=[20, 12, 16, 13])
+    batch = {k: torch.cat([a[k], b[k]])[[0, 4, 1, 5, 2, 6, 3, 7]].contiguous()
+             for k in ("part_pcs", "part_valids", "part_quat", "part_trans")}
+    g = torch.Generator().manual_seed(5)
+    qp = torch.nn.functional.normalize(torch.randn(8, 20, 4, generator=g), dim=-1).to(cuda_device)
+    tp = (torch.randn(8, 20, 3, generator=g) * 0.2).to(cuda_device)
+    _assert_searches_agree(batch, qp, tp, monkeypatch)
 
 
 def test_leaf_search_survives_non_finite_poses(cuda_device, monkeypatch):
