@@ -55,11 +55,14 @@ const char* mpa_last_error(void);
  *     [32, 20000, 3] against itself (utils/loss.py:173-199), is 2.56e10 pair evaluations exhaustively and a few
  *     dozen candidates per query pruned.  It needs scratch memory, which the CALLER provides (the library never
  *     allocates): `workspace` = mpa_chamfer_workspace() bytes, 16-byte aligned, contents irrelevant before and
- *     after the call.  With workspace == NULL (or too small) every size is answered by the exhaustive scan.
+ *     after the call (0 bytes for the sizes the exhaustive scan answers anyway; mpa_chamfer_workspace_variant sizes
+ *     a pinned search of mpa_chamfer_forward_variant).  With workspace == NULL (or too small) every size is answered
+ *     by the exhaustive scan.
  *   The pruned search is chosen when min(n1, n2) >= 512 and n1 * n2 >= 9e6.  Samples that hold a non-finite
  *   coordinate, or one beyond 1e15 in magnitude, are always answered by the exhaustive scan.
  * ---------------------------------------------------------------------------------------------- */
 int mpa_chamfer_workspace(int64_t batch, int64_t n1, int64_t n2, int64_t* bytes);
+int mpa_chamfer_workspace_variant(int64_t batch, int64_t n1, int64_t n2, int variant, int64_t* bytes);
 int mpa_chamfer_forward(const float* xyz1, const float* xyz2, int64_t batch, int64_t n1, int64_t n2,
                         float* dist1, int64_t* idx1, float* dist2, int64_t* idx2, void* workspace,
                         int64_t workspace_bytes, void* stream);

@@ -29,6 +29,7 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_abi_version": (_INT, []),
     "mpa_last_error": (_c.c_char_p, []),
     "mpa_chamfer_workspace": (_INT, [_I64, _I64, _I64, _P]),
+    "mpa_chamfer_workspace_variant": (_INT, [_I64, _I64, _I64, _INT, _P]),
     "mpa_chamfer_forward": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _I64, _P]),
     "mpa_chamfer_forward_variant": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _INT, _P, _I64, _P]),
     "mpa_chamfer_backward": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),

@@ -35,12 +35,14 @@ def _check_cloud(name: str, t: torch.Tensor) -> None:
         raise RuntimeError(f"{name}: only float32/float64 are dispatched, got {t.dtype}")
 
 
-def _workspace(B: int, n1: int, n2: int, dev) -> tuple[torch.Tensor | None, int]:
-    """Scratch for the grid-pruned search, sized by the library (the library itself never allocates); torch's caching
-    allocator makes the per-call request free after the first."""
+def _workspace(B: int, n1: int, n2: int, dev, variant: int = -1) -> tuple[torch.Tensor | None, int]:
+    """Scratch for the grid-pruned search, sized by the library (the library itself never allocates) for the search the
+    call will actually take — nothing for the sizes the exhaustive scan answers; torch's caching allocator makes the
+    per-call request free after the first."""
     import ctypes
     nbytes = ctypes.c_int64(0)
-    _lib.check(_lib.lib().mpa_chamfer_workspace(B, n1, n2, ctypes.byref(nbytes)), "mpa_chamfer_workspace")
+    _lib.check(_lib.lib().mpa_chamfer_workspace_variant(B, n1, n2, int(variant), ctypes.byref(nbytes)),
+               "mpa_chamfer_workspace_variant")
     if nbytes.value == 0:
         return None, 0
     return torch.empty(nbytes.value, dtype=torch.uint8, device=dev), nbytes.value
@@ -75,7 +77,7 @@ def chamfer_forward(xyz1: torch.Tensor, xyz2: torch.Tensor, variant: int | None 
             tok = _lib.KernelTimer.start(f"chamfer_forward[{B}x{n1}x{n2}]")
             st = L.mpa_chamfer_forward_f64(*args, s)
         else:
-            ws, nbytes = _workspace(B, n1, n2, dev) if variant in (None, 3, -1) else (None, 0)
+            ws, nbytes = _workspace(B, n1, n2, dev, -1 if variant is None else variant) if variant in (None, 3, -1) else (None, 0)
             tok = _lib.KernelTimer.start(f"chamfer_forward[{B}x{n1}x{n2}]")
             if variant is None:
                 st = L.mpa_chamfer_forward(*args, _lib.ptr(ws) if ws is not None else None, nbytes, s)

@@ -232,7 +232,18 @@ extern "C" int mpa_chamfer_forward_variant(const float* xyz1, const float* xyz2,
 extern "C" int mpa_chamfer_workspace(int64_t batch, int64_t n1, int64_t n2, int64_t* bytes) {
   MPA_REQUIRE(bytes != nullptr, "chamfer_workspace: null pointer");
   MPA_REQUIRE(batch >= 0 && n1 >= 0 && n2 >= 0, "chamfer_workspace: negative size");
-  *bytes = mpa::cloud_grid_supported(batch, n1, n2) ? mpa::cloud_grid_workspace_bytes(batch, n1, n2) : 0;
+  // what the DEFAULT call will use: nothing where the size rule sends the call to the exhaustive scan (the per-part
+  // call [640, 1000, 3]^2 would otherwise reserve 725 MiB of cell tables it never touches)
+  *bytes = grid_pays(batch, n1, n2) ? mpa::cloud_grid_workspace_bytes(batch, n1, n2) : 0;
+  return MPA_OK;
+}
+
+extern "C" int mpa_chamfer_workspace_variant(int64_t batch, int64_t n1, int64_t n2, int variant, int64_t* bytes) {
+  MPA_REQUIRE(bytes != nullptr, "chamfer_workspace_variant: null pointer");
+  MPA_REQUIRE(batch >= 0 && n1 >= 0 && n2 >= 0, "chamfer_workspace_variant: negative size");
+  MPA_REQUIRE(variant >= -1 && variant <= 3, "chamfer_workspace_variant: unknown variant %d", variant);
+  if (variant == -1) return mpa_chamfer_workspace(batch, n1, n2, bytes);
+  *bytes = variant == 3 && mpa::cloud_grid_supported(batch, n1, n2) ? mpa::cloud_grid_workspace_bytes(batch, n1, n2) : 0;
   return MPA_OK;
 }
 

@@ -537,11 +537,9 @@ extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int
     if (chunks >= 8) chunks = chunks / 8 * 8;  // (a multiple of 8 gets the kernel's XCD-aware chunk mapping)
     const int rows_per_chunk = (int)(((R + chunks - 1) / chunks + 31) / 32 * 32);
     const dim3 grid((unsigned)((N + 127) / 128), (unsigned)(K % 128 == 0 ? K / 128 : K / 64), (unsigned)chunks);
-#if DG_GEMM_SPLIT
-    const int* hdr = nullptr;  // the row count travels by value
-#else
-    const int* hdr = m.hdr;    // (written by the forward call)
-#endif
+    // the row count travels by value in both builds (both kernels take `rows` when hdr is null): the forward's
+    // small-row path never writes the header
+    const int* hdr = nullptr;
     if (K % 128 == 0)
       launch(DG_TN_KERNEL<128>, grid, dim3(DG_GEMM_THREADS), s, (const float*)m.dy, (int)N, (int)N, x, (int)ldx, (int)K, m.tnpart,
              rows_per_chunk, hdr, (int)R);

@@ -235,6 +235,9 @@ class DGLModel(BaseModel):
             return self._forward(data_dict)
 
     def _forward(self, data_dict):
+        # per-forward scratch (RGL-NET keeps its GRU index plan here): a shallow copy, so that nothing is left in — or
+        # later trusted from — the caller's batch dict, whose tensors a loader may refill in place
+        data_dict = dict(data_dict)
         part_feats = data_dict.get("part_feats", None)
         if part_feats is None:
             part_feats = self._extract_part_feats(data_dict["part_pcs"], data_dict["part_valids"])
@@ -393,9 +396,8 @@ class RGLNet(DGLModel):
     def _node_update(self, part_feats, messages, data_dict, iter_ind):
         hidden = self._init_gru_hidden(part_feats.shape[0], messages.device).type_as(messages)
         valids = data_dict["part_valids"]
-        plan = data_dict.get("_gru_plan")  # the step's dict: one index plan for the three GRU calls of a step
-        if plan is None or plan[0] is not valids:
-            plan = (valids, _MaskedBiGRU.plan(valids, part_feats.shape[1]))
-            data_dict["_gru_plan"] = plan
-        gru_out, _ = self.grus[iter_ind](torch.cat([part_feats, messages], dim=-1), hidden, valids=valids, plan=plan[1])
+        plan = data_dict.get("_gru_plan")  # `_forward`'s own scratch dict: one index plan for the GRU calls of ONE forward
+        if plan is None:
+            plan = data_dict["_gru_plan"] = _MaskedBiGRU.plan(valids, part_feats.shape[1])
+        gru_out, _ = self.grus[iter_ind](torch.cat([part_feats, messages], dim=-1), hidden, valids=valids, plan=plan)
         return self.node_mlps[iter_ind](gru_out)

@@ -260,6 +260,13 @@ def test_chamfer_workspace_contract(cuda_device):
     nb = ctypes.c_int64(-1)
     assert L.mpa_chamfer_workspace(32, 20000, 20000, ctypes.byref(nb)) == 0 and nb.value > 0
     assert L.mpa_chamfer_workspace(4, 0, 100, ctypes.byref(nb)) == 0 and nb.value == 0
+    # sizes the exhaustive scan answers reserve nothing (the per-part call used to ask for 725 MiB of cell tables) ...
+    assert L.mpa_chamfer_workspace(640, 1000, 1000, ctypes.byref(nb)) == 0 and nb.value == 0
+    assert L.mpa_chamfer_workspace(8000, 100, 100, ctypes.byref(nb)) == 0 and nb.value == 0
+    # ... unless the pruned search is pinned for them
+    assert L.mpa_chamfer_workspace_variant(640, 1000, 1000, 3, ctypes.byref(nb)) == 0 and nb.value > 0
+    assert L.mpa_chamfer_workspace_variant(640, 1000, 1000, 2, ctypes.byref(nb)) == 0 and nb.value == 0
+    assert L.mpa_chamfer_workspace_variant(32, 20000, 20000, -1, ctypes.byref(nb)) == 0 and nb.value > 0
     a = torch.rand(2, 4000, 3, device=cuda_device)
     b = torch.rand(2, 4000, 3, device=cuda_device)
     d1 = torch.empty(2, 4000, device=cuda_device)
