@@ -406,10 +406,19 @@ int mpa_gru_workspace(int64_t D, int64_t B, int64_t T, int64_t H, int64_t* float
 /* *ok = 1 iff the shapes are instantiated AND the current device can hold the whole grid of both kernels at once (their
  * blocks poll for each other's per-step words; forward / backward return an error instead of stalling when it cannot). */
 int mpa_gru_resident(int64_t D, int64_t B, int64_t H, int* ok);
+/* `status` (device memory, one int32 the caller keeps at 0; NULL: the kernel traps instead): raised to 1 by a launch whose
+ * blocks could not all wait for each other — a block that was never dispatched because another stream's kernels (a
+ * collective beside the step, say) held its CU makes the waiting blocks give up after a few seconds (MPA_GRU_POLL_BUDGET
+ * polls of ~1 us; default 2^22).  The launch then ends on its own with undefined outputs; the caller reads the word when
+ * it next synchronises (gru.py raises a RuntimeError from it) — no trap, no hang, the HIP context stays usable. */
 int mpa_gru_forward(const float* gi, const float* h0, const float* whh, const float* bhh, int64_t D, int64_t B, int64_t T,
-                    int64_t H, float* ws, float* out, void* stream);
+                    int64_t H, float* ws, float* out, int32_t* status, void* stream);
 int mpa_gru_backward(const float* grad_out, const float* h0, const float* whh, const float* out, int64_t D, int64_t B,
-                     int64_t T, int64_t H, float* ws, float* grad_gi, float* grad_whh, float* grad_bhh, void* stream);
+                     int64_t T, int64_t H, float* ws, float* grad_gi, float* grad_whh, float* grad_bhh, int32_t* status,
+                     void* stream);
+/* Test support: `blocks` workgroups that each hold `lds_bytes` of LDS and do nothing for `usec` microseconds — CUs no other
+ * stream can use meanwhile (how tests/test_gru_gpu.py provokes the co-residency failure above). */
+int mpa_debug_occupy(int64_t blocks, int64_t lds_bytes, int64_t usec, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Part-relation transformer encoder — replaces

@@ -79,8 +79,9 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_relation_mean_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
     "mpa_gru_workspace": (_INT, [_I64, _I64, _I64, _I64, _P]),
     "mpa_gru_resident": (_INT, [_I64, _I64, _I64, _P]),
-    "mpa_gru_forward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P]),
-    "mpa_gru_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
+    "mpa_gru_forward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "mpa_gru_backward": (_INT, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "mpa_debug_occupy": (_INT, [_I64, _I64, _I64, _P]),
     "mpa_transformer_workspace": (_INT, [_I64] * 6 + [_P]),
     "mpa_transformer_forward": (_INT, [_P, _P, _P] + [_I64] * 6 + [_F32, _U64, _P, _P, _P, _P]),
     "mpa_transformer_backward": (_INT, [_P, _P, _P] + [_I64] * 6 + [_F32, _U64, _P, _P, _P, _P, _P]),

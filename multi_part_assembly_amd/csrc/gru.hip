@@ -16,6 +16,8 @@
 // 24 x H slice of dW_hh in registers, hands the partial dL/dh_{t-1} of its rows to the other blocks the same way and sums
 // the partials in block order: no atomics on floats, bit-reproducible.  All blocks must be co-resident (2 * H/8 <= 256
 // CUs): a consumer polls for words only a running producer can write.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -45,24 +47,39 @@ __device__ __forceinline__ void tagged_store(tagged_t* p, float v, unsigned tag)
 __device__ __forceinline__ tagged_t tagged_peek(const tagged_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the value of *p once it carries `tag` (first poll result given).  `budget`: polls the thread may still spend on this
-// wait — a producer that never shows up (a grid that is not co-resident after all) exhausts it after a few seconds and
-// the kernel TRAPS: the launch fails loudly instead of hanging the device or returning garbage.
-__device__ __forceinline__ float tagged_wait(const tagged_t* p, tagged_t first, unsigned tag, int& budget) {
+// the value of *p once it carries `tag` (first poll result given).  A producer that never shows up (a grid that is not
+// co-resident after all — e.g. another stream's kernels hold the CUs the missing blocks need) exhausts the wait's poll
+// budget after a few seconds.  Then the launch gives up CLEANLY: the waiting thread raises the launch's status word (device
+// memory of the caller), every other wait of every block sees it within 1024 polls and stops too, the kernel runs to its
+// end on whatever values it has, and the host side turns the status word into an error (gru.py) — no trap (which
+// takes the process's HIP context with it), no hang.  Without a status word (NULL) the kernel traps as before.
+struct Poll {
+  int budget, limit;
+  int* status;
+  bool dead;
+};
+__device__ __forceinline__ float tagged_wait(const tagged_t* p, tagged_t first, unsigned tag, Poll& pl) {
   tagged_t v = first;
-  while ((unsigned)(v >> 32) != tag) {
-    if (--budget < 0) __builtin_trap();
+  while ((unsigned)(v >> 32) != tag && !pl.dead) {
+    --pl.budget;
+    if (pl.budget < 0 || ((pl.budget & 1023) == 0 && pl.status != nullptr &&
+                          __hip_atomic_load(pl.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      if (pl.status == nullptr) __builtin_trap();
+      __hip_atomic_store(pl.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pl.dead = true;
+      break;
+    }
     __builtin_amdgcn_s_sleep(2);
     v = tagged_peek(p);
   }
-  budget = kPollBudget;  // the budget bounds ONE wait (a few seconds), not the launch's total polling
+  pl.budget = pl.limit;  // the budget bounds ONE wait (a few seconds), not the launch's total polling
   return __uint_as_float((unsigned)v);
 }
 // PF words p[q * stride] (q < n valid): wait for the first one alone (ONE polled word per thread while the producers
 // are still busy: the pollers' traffic delays the very stores they wait for — re-loading whole batches until every tag
 // had arrived was 4x slower), then load the others together, and wait singly for a straggler.
 template <int PF>
-__device__ __forceinline__ void tagged_wait_all(const tagged_t* p, long long stride, int n, unsigned tag, int& budget,
+__device__ __forceinline__ void tagged_wait_all(const tagged_t* p, long long stride, int n, unsigned tag, Poll& budget,
                                                 float (&out)[PF]) {
   out[0] = tagged_wait(p, tagged_peek(p), tag, budget);
   tagged_t v[PF];
@@ -77,7 +94,8 @@ template <int H>
 __global__ __launch_bounds__(kGT) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ h0,
                                                       const float* __restrict__ whh, const float* __restrict__ bhh,
                                                       int B, int T, float* __restrict__ out,
-                                                      float* __restrict__ saved, tagged_t* __restrict__ xch) {
+                                                      float* __restrict__ saved, tagged_t* __restrict__ xch,
+                                                      int* __restrict__ status, int poll_limit) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LD = H + 4;              // rows padded by one 16-byte slot: the rows a ds_read_b128 lane group touches
   float* W = smem;                       // (4 samples, 8 units) start 4 banks apart  ([3 * kU][LD]: rows r(u0..), z(..), n(..))
@@ -92,7 +110,7 @@ __global__ __launch_bounds__(kGT) void gru_fwd_kernel(const float* __restrict__ 
   float* od = out + (long long)d * B * T * H;
   float* sd = saved + (long long)d * B * T * 4 * H;
   tagged_t* xd = xch + (long long)d * 2 * B * H;  // [2 (step parity)][B][H]
-  int budget = kPollBudget;
+  Poll budget{poll_limit, poll_limit, status, false};
   for (int t = 0; t < T; ++t) {
     // previous hidden state of ALL units: h0, or the tagged words the blocks of this direction published in step t - 1
     if (t == 0) {
@@ -166,7 +184,8 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ whh, const float* __restrict__ out,
                                                       const float* __restrict__ saved, int B, int T,
                                                       float* __restrict__ dgi, float* __restrict__ dwhh,
-                                                      float* __restrict__ dbhh, tagged_t* __restrict__ part) {
+                                                      float* __restrict__ dbhh, tagged_t* __restrict__ part,
+                                                      int* __restrict__ status, int poll_limit) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W = smem;                        // [3 * kU][H]
   float* hp = smem + 3 * kU * H;          // [B][H] h_{t-1}
@@ -184,7 +203,7 @@ __global__ __launch_bounds__(kGT) void gru_bwd_kernel(const float* __restrict__ 
   const float* sd = saved + (long long)d * B * T * 4 * H;
   float* dgid = dgi + (long long)d * B * T * 3 * H;
   tagged_t* pd = part + (long long)d * 2 * nblk * B * H;  // tagged words, see tagged_store
-  int budget = kPollBudget;
+  Poll budget{poll_limit, poll_limit, status, false};
   // own slice of dW_hh (3 * kU rows x H columns) and of W_hh, column-wise in registers: thread -> column(s) k0 + 256 c of
   // the rows rbase .. rbase + RPT - 1, so that per sample one h value and RPT/4 broadcast 16-byte reads of the gate
   // gradients feed RPT FMAs (a row-major spread cost two LDS reads per FMA)
@@ -344,6 +363,40 @@ int gru_resident(Kern kern, size_t smem, int blocks, const char* who) {
 }
 }  // namespace
 
+namespace {
+// polls one wait may spend (~1 us each) before the launch gives up; MPA_GRU_POLL_BUDGET overrides (tests shorten it)
+int poll_limit() {
+  if (const char* e = getenv("MPA_GRU_POLL_BUDGET")) {
+    const long v = strtol(e, nullptr, 10);
+    if (v >= 1024 && v <= (1L << 30)) return (int)v;
+  }
+  return kPollBudget;
+}
+
+// test support: `blocks` blocks that each hold `lds_bytes` of LDS and spin for `usec` microseconds of the constant
+// 100 MHz clock — CUs that another stream cannot use meanwhile (tests/test_gru_gpu.py shows the GRU's co-residency failure
+// as a Python error with it)
+__global__ __launch_bounds__(64) void occupy_kernel(long long ticks, int* sink) {
+  extern __shared__ int lds[];
+  lds[threadIdx.x] = (int)threadIdx.x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(32);
+  if (lds[threadIdx.x] < 0) *sink = 1;
+}
+}  // namespace
+
+extern "C" int mpa_debug_occupy(int64_t blocks, int64_t lds_bytes, int64_t usec, void* stream) {
+  MPA_REQUIRE(blocks >= 1 && blocks <= 4096 && lds_bytes >= 256 && lds_bytes <= 160 * 1024 && usec >= 0 && usec <= 5000000,
+              "debug_occupy: bad args");
+  if (lds_bytes > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds_bytes) != hipSuccess)
+    return mpa::fail(MPA_EINVAL, "debug_occupy: cannot reserve %lld bytes of LDS", (long long)lds_bytes);
+  hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)blocks), dim3(64), (size_t)lds_bytes, mpa::as_stream(stream),
+                     (long long)usec * 100, (int*)nullptr);
+  return mpa::check_launch("debug_occupy");
+}
+
 extern "C" int mpa_gru_resident(int64_t D, int64_t B, int64_t H, int* ok) {
   MPA_REQUIRE(ok != nullptr, "gru_resident: null pointer");
   *ok = 0;
@@ -368,7 +421,7 @@ extern "C" int mpa_gru_workspace(int64_t D, int64_t B, int64_t T, int64_t H, int
 }
 
 extern "C" int mpa_gru_forward(const float* gi, const float* h0, const float* whh, const float* bhh, int64_t D, int64_t B,
-                               int64_t T, int64_t H, float* ws, float* out, void* stream) {
+                               int64_t T, int64_t H, float* ws, float* out, int32_t* status, void* stream) {
   if (int st = gru_check(D, B, T, H, "gru_forward")) return st;
   MPA_REQUIRE(gi && h0 && whh && bhh && ws && out, "gru_forward: null pointer");
   hipStream_t s = mpa::as_stream(stream);
@@ -389,7 +442,7 @@ extern "C" int mpa_gru_forward(const float* gi, const float* h0, const float* wh
       checked = smem;                                                                                                 \
     }                                                                                                                 \
     hipLaunchKernelGGL(gru_fwd_kernel<HH>, grid, dim3(kGT), smem, s, gi, h0, whh, bhh, (int)B, (int)T, out, saved,     \
-                       xch);                                                                                          \
+                       xch, (int*)status, poll_limit());                                                              \
   }
   if (H == 128) MPA_GRU_FWD(128) else MPA_GRU_FWD(256)
 #undef MPA_GRU_FWD
@@ -398,7 +451,7 @@ extern "C" int mpa_gru_forward(const float* gi, const float* h0, const float* wh
 
 extern "C" int mpa_gru_backward(const float* grad_out, const float* h0, const float* whh, const float* out, int64_t D,
                                 int64_t B, int64_t T, int64_t H, float* ws, float* grad_gi, float* grad_whh,
-                                float* grad_bhh, void* stream) {
+                                float* grad_bhh, int32_t* status, void* stream) {
   if (int st = gru_check(D, B, T, H, "gru_backward")) return st;
   MPA_REQUIRE(grad_out && h0 && whh && out && ws && grad_gi && grad_whh && grad_bhh, "gru_backward: null pointer");
   hipStream_t s = mpa::as_stream(stream);
@@ -417,7 +470,7 @@ extern "C" int mpa_gru_backward(const float* grad_out, const float* h0, const fl
       checked = smem;                                                                                                 \
     }                                                                                                                 \
     hipLaunchKernelGGL(gru_bwd_kernel<HH>, grid, dim3(kGT), smem, s, grad_out, h0, whh, out, saved, (int)B, (int)T,    \
-                       grad_gi, grad_whh, grad_bhh, part);                                                            \
+                       grad_gi, grad_whh, grad_bhh, part, (int*)status, poll_limit());                                \
   }
   if (H == 128) MPA_GRU_BWD(128) else MPA_GRU_BWD(256)
 #undef MPA_GRU_BWD

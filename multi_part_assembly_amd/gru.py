@@ -4,10 +4,47 @@ keys); the input projections stay library GEMMs (autograd handles them)."""
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
 from . import _lib
+
+
+# ---- the launches' status word ------------------------------------------------------------------------------------------
+# The kernels' blocks wait for each other (csrc/gru.hip).  A launch whose blocks could not all be resident — another stream's
+# kernels held the CUs the missing ones needed — gives up after its poll budget and raises ONE int32 in device memory instead
+# of trapping.  That word lives here, per device, for the life of the process; every launch is followed by an asynchronous
+# copy of it into pinned host memory (a graph node under capture), and the host looks at the pinned copy — a plain memory
+# read, no synchronisation — in front of every later GRU call and in `raise_if_failed()`.
+_STATUS: dict = {}
+
+
+def _status(dev):
+    st = _STATUS.get(dev.index)
+    if st is None:
+        st = _STATUS[dev.index] = (torch.zeros(1, dtype=torch.int32, device=dev),
+                                   torch.zeros(1, dtype=torch.int32).pin_memory())
+    return st
+
+
+def raise_if_failed(device=None, synchronize=False):
+    """RuntimeError if a GRU launch on `device` (default: every device used so far) gave up because its blocks were not
+    co-resident.  The outputs of such a launch are undefined.  `synchronize=True` first waits for the device, so that
+    the answer covers every launch issued so far (otherwise: every launch whose status copy has already arrived)."""
+    for idx, (word, host) in list(_STATUS.items()):
+        if device is not None and torch.device(device).index not in (None, idx):
+            continue
+        if synchronize:
+            torch.cuda.synchronize(idx)
+        if int(host[0]) != 0:
+            word.zero_()
+            host.zero_()
+            raise RuntimeError(
+                "gru: a launch of csrc/gru.hip gave up — its blocks exchange one word per step and must all be resident at "
+                "once, but some were never dispatched while the others waited (kernels of another stream holding the "
+                "compute units?).  The outputs of that step are undefined; rerun it without the competing work, or set "
+                "MPA_GRU=library to keep the library GRU")
 
 
 class _GRURecurrentFn(torch.autograd.Function):
@@ -21,11 +58,14 @@ class _GRURecurrentFn(torch.autograd.Function):
         _lib.check(L.mpa_gru_workspace(D, B, T, H, ctypes.byref(n)), "mpa_gru_workspace")
         ws = torch.empty(n.value, dtype=torch.float32, device=dev)
         out = torch.empty((D, B, T, H), dtype=torch.float32, device=dev)
+        raise_if_failed(dev)
+        word, host = _status(dev)
         with torch.cuda.device(dev):
             tok = _lib.KernelTimer.start(f"gru_forward[{D}x{B}x{T}x{H}]")
             st = L.mpa_gru_forward(_lib.ptr(gi), _lib.ptr(h0), _lib.ptr(whh), _lib.ptr(bhh), D, B, T, H, _lib.ptr(ws),
-                                   _lib.ptr(out), _lib.current_stream(dev))
+                                   _lib.ptr(out), _lib.ptr(word), _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
+            host.copy_(word, non_blocking=True)
         _lib.check(st, "mpa_gru_forward")
         ctx.save_for_backward(h0, whh, out, ws)
         return out
@@ -39,12 +79,15 @@ class _GRURecurrentFn(torch.autograd.Function):
         gw = torch.empty_like(whh)
         gb = torch.empty((D, 3 * H), dtype=torch.float32, device=dev)
         grad_out = grad_out.contiguous()
+        raise_if_failed(dev)
+        word, host = _status(dev)
         with torch.cuda.device(dev):
             tok = _lib.KernelTimer.start(f"gru_backward[{D}x{B}x{T}x{H}]")
             st = _lib.lib().mpa_gru_backward(_lib.ptr(grad_out), _lib.ptr(h0), _lib.ptr(whh), _lib.ptr(out), D, B, T, H,
-                                             _lib.ptr(ws), _lib.ptr(ggi), _lib.ptr(gw), _lib.ptr(gb),
+                                             _lib.ptr(ws), _lib.ptr(ggi), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(word),
                                              _lib.current_stream(dev))
             _lib.KernelTimer.stop(tok)
+            host.copy_(word, non_blocking=True)
         _lib.check(st, "mpa_gru_backward")
         return ggi, None, gw, gb
 
@@ -56,6 +99,8 @@ def supported(hidden, batch, directions=2):
     """Shapes csrc/gru.hip is built for AND a device that can hold the kernels' whole grid at once (their per-step
     exchange needs every block resident: mpa_gru_resident asks the runtime's occupancy calculator; a partitioned or
     smaller device answers no and the caller keeps the library GRU)."""
+    if os.environ.get("MPA_GRU", "") == "library":  # the way out when other streams' kernels keep the grid from being
+        return False                                 # co-resident (see raise_if_failed)
     if not (hidden in (128, 256) and batch <= 64 and (48 * hidden + batch * hidden + batch * 64) * 4 <= 160 * 1024):
         return False
     key = (hidden, batch, directions, torch.cuda.current_device())

@@ -23,12 +23,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _small_model():
+def _small_model(kind="pn"):
+    """kind: "pn" = PNTransformer + PointNet (configs[3]); "dgl" / "rgl" = the graph networks with the DGCNN encoder
+    (configs[2] / configs[4]: RGL-NET's GRU kernels wait for each other across blocks — beside an in-flight all-reduce
+    here), small widths."""
     from multi_part_assembly_amd import config
     from multi_part_assembly_amd.pn_transformer import build_model
-    cfg = config.pn_transformer_everyday()
-    cfg.model.pc_feat_dim, cfg.model.transformer_heads = 64, 4
-    cfg.model.transformer_feat_dim, cfg.model.transformer_layers = 128, 2
+    if kind == "pn":
+        cfg = config.pn_transformer_everyday()
+        cfg.model.pc_feat_dim, cfg.model.transformer_heads = 64, 4
+        cfg.model.transformer_feat_dim, cfg.model.transformer_layers = 128, 2
+    else:
+        cfg = config.dgl_dgcnn_everyday() if kind == "dgl" else config.rgl_net_dgcnn_artifact()
     cfg.data.max_num_part = 5
     torch.manual_seed(7)
     model = build_model(cfg)
@@ -40,14 +46,21 @@ def _small_model():
     return model, cfg
 
 
-def _shard(rank, dev):
+def _shard(rank, dev, kind="pn"):
     from multi_part_assembly_amd import synthetic
-    batch = synthetic.make_batch(3, 5, 64, preset="everyday", seed=50 + rank, device=dev)
+    batch = synthetic.make_batch(3, 5, 64, preset="artifact" if kind == "rgl" else "everyday", seed=50 + rank, device=dev)
     batch.pop("num_parts")
     return batch
 
 
-def _worker(rank, world, port, out_dir, use_graph, steps, backend="gloo"):
+def _seed_step(kind, rank, step):
+    """RGL-NET draws its GRU's initial state from torch's generator every forward: both sides of the comparison seed it
+    per (rank, step), so that the emulation sees the draws of the rank it stands in for."""
+    if kind == "rgl":
+        torch.manual_seed(1000 + 10 * step + rank)
+
+
+def _worker(rank, world, port, out_dir, use_graph, steps, backend="gloo", kind="pn"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from multi_part_assembly_amd.trainer import Trainer
     if backend == "nccl":  # RCCL: one rank per GPU (scripts/train.py:81-95 `strategy='ddp'`)
@@ -57,10 +70,16 @@ def _worker(rank, world, port, out_dir, use_graph, steps, backend="gloo"):
     else:
         dev = torch.device("cuda", 0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    model, cfg = _small_model()
+    model, cfg = _small_model(kind)
     model.to(dev)
     trainer = Trainer(model, cfg, use_graph=use_graph)
-    losses = [float(trainer.train_step(_shard(rank, dev), i)) for i in range(steps)]
+    losses = []
+    for i in range(steps):
+        _seed_step(kind, rank, i)
+        losses.append(float(trainer.train_step(_shard(rank, dev, kind), i)))
+    if kind == "rgl":
+        from multi_part_assembly_amd import gru
+        gru.raise_if_failed(dev, synchronize=True)  # no launch gave up beside the collectives
     assert not use_graph or trainer._graph is not None  # the last steps were HIP-graph replays
     # after a step the flat gradient buffer holds the all-reduced SUM; 1/world is folded into the Adam kernel
     grad = (trainer.flat.flat_grad * trainer.optimizer.grad_scale).cpu()
@@ -69,19 +88,22 @@ def _worker(rank, world, port, out_dir, use_graph, steps, backend="gloo"):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("kind", ["pn", "dgl", "rgl"])
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
-def test_two_rank_training_equals_gradient_averaging(cuda_device, use_graph, backend):
+def test_two_rank_training_equals_gradient_averaging(cuda_device, use_graph, backend, kind):
     """eager: bucketed all-reduce overlapped with backward; graph: captured forward+backward replayed, one all-reduce
     and the optimiser step behind it.  backend "gloo": both ranks on the one GPU of the test box; "nccl": RCCL with
     one rank per GPU — needs two GPUs, skipped on a one-GPU box."""
     if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("RCCL with two ranks needs two GPUs")
+    if kind == "rgl" and use_graph:
+        pytest.skip("under capture RGL-NET draws the GRU's initial state on the device: no per-(rank, step) seeding to compare by")
     steps = 2
     if use_graph:
         steps = 6  # Trainer's 3 eager settle steps, then the capture and three replays
     with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_worker, args=(2, _free_port(), out_dir, use_graph, steps, backend), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), out_dir, use_graph, steps, backend, kind), nprocs=2, join=True)
         got = [torch.load(os.path.join(out_dir, f"rank{r}.pt")) for r in range(2)]
     assert torch.equal(got[0]["param"], got[1]["param"])  # replicas stay in lock-step
     # single-process emulation: per-shard forward/backward on replicas sharing the weights, averaged gradients
@@ -89,7 +111,7 @@ def test_two_rank_training_equals_gradient_averaging(cuda_device, use_graph, bac
     from multi_part_assembly_amd.dp import ordered_parameters
     models = []
     for r in range(2):
-        m, cfg = _small_model()
+        m, cfg = _small_model(kind)
         models.append(m.to(cuda_device).train())
     flats = [FlatBuffers(ordered_parameters(m)) for m in models]
     opt = FusedAdam(flats[0], lr=cfg.optimizer.lr)
@@ -101,14 +123,17 @@ def test_two_rank_training_equals_gradient_averaging(cuda_device, use_graph, bac
     for step in range(steps):
         for r in range(2):
             flats[r].zero_grad()
-            models[r].training_step(_shard(r, cuda_device), step).backward()
+            _seed_step(kind, r, step)
+            models[r].training_step(_shard(r, cuda_device, kind), step).backward()
         flats[0].flat_grad.add_(flats[1].flat_grad).mul_(0.5)
         mean_grad = flats[0].flat_grad.cpu().clone()
         opt.step(lr=lr0)
         flats[1].flat_param.copy_(flats[0].flat_param)
     assert torch.equal(got[0]["grad"], got[1]["grad"])
     gerr = (got[0]["grad"] - mean_grad).abs().max() / mean_grad.abs().max()
-    assert gerr < 1e-4, gerr  # the second step's averaged gradient (a missing 1/world would be a factor 2)
+    # the last step's averaged gradient (a missing 1/world would be a factor 2).  The graph networks' step-2 gradient is
+    # taken at parameters that already differ by Adam's amplification of step 1's rounding (below): looser there
+    assert gerr < (1e-4 if kind == "pn" else 5e-3), gerr
     want = flats[0].flat_param.cpu()
     err = (got[0]["param"] - want).abs().max() / want.abs().max()
-    assert err < 2e-4, err  # Adam's g / sqrt(v) turns rounding-level gradient differences into O(lr) steps
+    assert err < (2e-4 if kind == "pn" else 2e-3), err  # Adam's g / sqrt(v) turns rounding-level gradient differences into O(lr) steps
