@@ -48,7 +48,10 @@ def _small_model(kind="pn"):
 
 def _shard(rank, dev, kind="pn"):
     from multi_part_assembly_amd import synthetic
-    batch = synthetic.make_batch(3, 5, 64, preset="artifact" if kind == "rgl" else "everyday", seed=50 + rank, device=dev)
+    if kind == "rgl":  # (the artifact preset's own part counts start at 12: given here)
+        batch = synthetic.make_batch(3, 5, 64, preset="artifact", seed=50 + rank, device=dev, num_parts=[5, 2 + rank, 4])
+    else:
+        batch = synthetic.make_batch(3, 5, 64, preset="everyday", seed=50 + rank, device=dev)
     batch.pop("num_parts")
     return batch
 
