@@ -44,13 +44,13 @@ CASES = {
 #       tools/debug_flip.py on RGL-NET + DGCNN: the site is edge_mlps.0.bn3 channel 1, |z64| = 3e-6 of its scale; its
 #       own bias gradient moves 1.05e-2, conv3.weight's row 1 by 1.6e-2, conv2.weight by up to 1.26e-2 in 2 entries,
 #       everything else of the MLP < 7e-3).  Under this clause a tensor may deviate by at most 5e-2, at most 2 of its
-#       recorded entries by more than 1e-2 unless it is the site's own layer, at most FLIP_TENSORS tensors per model.
-#       The test prints the site(s) and every tensor it excuses.
+#       recorded entries by more than 1e-2 unless it is the site's own layer, and it must lie at or below (towards the
+#       input of) a qualifying site of its own MLP — the number of excused tensors follows from the sites found, not
+#       from a constant.  The test prints the site(s) and every tensor it excuses.
 # A bias in front of a BatchNorm has a structurally zero gradient: there the bar is absolute, 1e-5 of the layer's
 # weight-gradient scale (the float32 reference leaves 5e-7 there).
 GRAD_REL = {"dgl_step": 1e-2, "rgl_net_step": 1e-2, "global_semantic_step": 2e-3, "pn_refine_step": 2e-3,
             "dgl_dgcnn_step": 1e-2, "rgl_net_dgcnn_artifact_step": 1e-2}
-FLIP_TENSORS = 3
 FLIP_PREACT = 5e-6  # |float64 pre-activation| / channel scale below which a float32 evaluation may land on the other side
 
 
@@ -78,9 +78,17 @@ def test_caller_step_matches_reference(golden, cuda_device, capsys, name):
     torch.manual_seed(seed + 1)
     res = model.forward_pass(data, mode="train")
     res["loss"].backward()
+    loss_err = {}
     for k in z:
         if k.startswith("loss."):
-            np.testing.assert_allclose(float(res[k[5:]]), float(z[k]), rtol=2e-4, atol=1e-6, err_msg=k)
+            loss_err[k[5:]] = abs(float(res[k[5:]]) - float(z[k])) / max(abs(float(z[k])), 1e-6)
+    with capsys.disabled():
+        worst_term = max(loss_err, key=loss_err.get)
+        print(f"\n  {name}: {len(loss_err)} loss terms vs the reference: worst relative deviation {loss_err[worst_term]:.2e} "
+              f"({worst_term})", end="")
+    for k in z:
+        if k.startswith("loss."):  # north_star's bar: 1e-4 relative, every term of every GNN iteration
+            np.testing.assert_allclose(float(res[k[5:]]), float(z[k]), rtol=1e-4, atol=1e-6, err_msg=k)
     record = dict(z)
     rows, flips, used_sites = [], [], set()
     # ReLU sites where a float32 evaluation may flip: float64 pre-activations at the rounding level of zero
@@ -115,7 +123,15 @@ def test_caller_step_matches_reference(golden, cuda_device, capsys, name):
               f"reference there: {worst[1]:.2e}), median {med:.2e}; float32 reference worst {max(r[1] for r in rows):.2e}"
               f"; clause (c): {len(sites)} float64 pre-activations within {FLIP_PREACT:g} of zero in the model, used "
               f"(module, channel, |z64|, channel scale): {sorted(used_sites)}; tensors excused: {flips}", end="")
-    assert len(flips) <= FLIP_TENSORS, flips
+    # how many tensors clause (c) may excuse follows from the sites, not from a constant: a flip at layer L of an MLP
+    # can only reach that MLP's parameter gradients at and below L (the unit's upstream gradient appears or vanishes on
+    # its way back through layers L, L - 1, ...), so every excused tensor must be one of those — however many sites the
+    # box at hand turns up
+    for k, *_ in flips:
+        mlp = ".".join(k.split(".")[:2]) + "."
+        layer = int(k.rsplit(".", 2)[-2][-1])
+        reach = max(int(m[-1]) for (m, ch, lo, hi) in sites if m.startswith(mlp))
+        assert layer <= reach, (k, "upstream of every near-zero pre-activation of its MLP", [s_ for s_ in sites if s_[0].startswith(mlp)])
     for k, v in model.state_dict().items():
         if "running_" in k:
             param_fill.compare(record, "sd1.", k, v.cpu().numpy(), rel=1e-4)
@@ -569,7 +585,12 @@ def test_pn_transformer_step_at_the_benchmark_part_size_against_float64(cuda_dev
     fed the SAME predicted poses, the fused loss backward is within 1e-7 of float64 per term, like the oracle — except the
     per-part Chamfer term, 6e-5 for BOTH float32 evaluations (nearest-neighbour near-ties resolve differently in float64).
     The predicted poses themselves differ from float64 by 3e-6 (HIP) / 2e-6 (oracle), and which near-ties those shifts
-    flip decides the offset; evaluating the pose head's normalisation backward in double changes nothing."""
+    flip decides the offset; evaluating the pose head's normalisation backward in double changes nothing.
+    A/B, round 5: is it the fp32-grade split-bf16 products (the 128 / 256-wide PointNet layers)?  The same test against a
+    build with every PointNet GEMM on `v_mfma_f32_32x32x2_f32` (tools/build_variant.sh pn_exact pointnet.hip
+    -DMPA_PN_SPLIT=0; the transformer and the pose head are exact-fp32 matrix products in both builds): median ratio
+    5.49 (split: 6.70), 64 of 73 tensors beyond twice the oracle's deviation (66), largest 8.00e-4 (8.02e-4) on the same
+    tensor.  The split products account for a fifth of the ratio; the offset is there without them."""
     from oracle import nets as on
     cfg = config.pn_transformer_everyday()
     _against_float64(cuda_device, capsys, cfg, "PNTransformer + PointNet",
