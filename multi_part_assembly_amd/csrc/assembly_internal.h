@@ -20,10 +20,12 @@ unsigned* grid_ticket(int32_t* iws, int64_t B);
 // distance sums into tile_sums[dir][m*tiles + 0].  fws/iws: scratch sized by the functions above.
 // before_search / after_search (nullable) are recorded around the search kernel proper.
 // route (nullable) [B]: samples with route[b] == 0 are left to the leaf search (no work, no sums written for them).
+// phases: 1 = build the grid, 2 = the search kernel, 4 = per-part distance sums (a caller that puts another search's
+// launches between the search kernel and the sums calls three times).
 int launch_grid_shape_search(const float* valids, const float* S1, const float* S2, int64_t B, int64_t P,
                              int64_t N, int tiles, float* fws, int32_t* iws, int32_t* idx1, int32_t* idx2,
                              float* tile_sums, hipEvent_t before_search, hipEvent_t after_search, hipStream_t s,
-                             const int* route = nullptr);
+                             const int* route = nullptr, int phases = 7);
 
 // ---- the same exact pruned search for two plain clouds per sample (the generic operator, chamfer.hip) -----------------
 // xyz1 [B, n1, 3], xyz2 [B, n2, 3] -> dist / idx of mpa_chamfer_forward's contract, bit for bit, for every sample whose

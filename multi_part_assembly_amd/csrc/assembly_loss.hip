@@ -831,12 +831,20 @@ extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const fl
     const mpa::LeafCloud s1{w.rec[2], w.leaf[2], w.pbox[2], w.S1}, s2{w.rec[3], w.leaf[3], w.pbox[3], w.S2};
     mpa::launch_leaf_search(false, valids, r1, r2, B, P, N, w.ip1, w.ip2, w.wsum_part, w.scratch, s);
     mark(2);
-    mark(5);
-    if (mode == 3)  // (samples routed to the leaf search cost these launches a header each)
+    // [5] .. [6] bracket the search kernels proper of BOTH routes (grid search, leaf search + its second pass) — not the
+    // grid's build and its distance sums, as in rounds 1-4.  A route no sample takes costs its launches a header each.
+    if (mode == 3)
       mpa::launch_grid_shape_search(valids, w.S1, w.S2, B, P, N, w.tiles, w.grid_f, w.grid_i, w.is1, w.is2,
-                                    w.shape_tiles, nullptr, nullptr, s, route);
+                                    w.shape_tiles, nullptr, nullptr, s, route, 1);
+    mark(5);
+    if (mode == 3)
+      mpa::launch_grid_shape_search(valids, w.S1, w.S2, B, P, N, w.tiles, w.grid_f, w.grid_i, w.is1, w.is2,
+                                    w.shape_tiles, nullptr, nullptr, s, route, 2);
     mpa::launch_leaf_search(true, valids, s1, s2, B, P, N, w.is1, w.is2, w.wsum_shape, w.scratch, s, route);
     mark(6);
+    if (mode == 3)
+      mpa::launch_grid_shape_search(valids, w.S1, w.S2, B, P, N, w.tiles, w.grid_f, w.grid_i, w.is1, w.is2,
+                                    w.shape_tiles, nullptr, nullptr, s, route, 4);
     mark(3);
     const int nw = npad >= 64 ? npad / 64 : 1;  // every wave of a valid part leaves its distance sum
     hipLaunchKernelGGL(assembly_finalize_kernel, dim3((unsigned)B), dim3(64), 0, s, valids, quat_pred,

@@ -1227,7 +1227,7 @@ unsigned* grid_ticket(int32_t* iws, int64_t B) {
 int launch_grid_shape_search(const float* valids, const float* S1, const float* S2, int64_t B, int64_t P,
                              int64_t N, int tiles, float* fws, int32_t* iws, int32_t* idx1, int32_t* idx2,
                              float* tile_sums, hipEvent_t before_search, hipEvent_t after_search, hipStream_t s,
-                             const int* route) {
+                             const int* route, int phases) {
   const int rec_stride = (int)(P * N + 8);
   float4* records = reinterpret_cast<float4*>(fws);
   GridParams* params = reinterpret_cast<GridParams*>(fws + 4 * B * (int64_t)rec_stride * 4);
@@ -1240,21 +1240,25 @@ int launch_grid_shape_search(const float* valids, const float* S1, const float* 
   XcdPlan* plan = reinterpret_cast<XcdPlan*>(worklist + 4 * B * (int64_t)kWorkStride);
   const bool xcd_table = MPA_GRID_XCD && 2 * B >= 8 && 2 * B <= kMaxPairs;
   const int nwaves = (int)(MPA_GRID_WAVES * 2 * B);
-  hipLaunchKernelGGL(grid_sort_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N,
-                     (const float*)grid_bbox(fws, B, P, N), params, starts, batches, worklist, records, rec_stride,
-                     grid_ticket(iws, B), xcd_table ? plan : (XcdPlan*)nullptr, nwaves, route);
-  if (before_search != nullptr) (void)hipEventRecord(before_search, s);
-  if (xcd_table)
-    hipLaunchKernelGGL((grid_search_kernel<false, int>), dim3((unsigned)nwaves), dim3(64), 0, s, valids, S1, S2, (int)P,
-                       (int)N, params, records, starts, batches, worklist, kWorkStride, rec_stride, dist1, dist2, idx1, idx2,
-                       (const XcdPlan*)plan);
-  else
-    hipLaunchKernelGGL((grid_search_kernel<false, int>), dim3(MPA_GRID_WAVES, (unsigned)(2 * B)), dim3(64), 0, s, valids, S1,
-                       S2, (int)P, (int)N, params, records, starts, batches, worklist, kWorkStride, rec_stride, dist1, dist2,
-                       idx1, idx2, (const XcdPlan*)nullptr);
-  if (after_search != nullptr) (void)hipEventRecord(after_search, s);
-  hipLaunchKernelGGL(grid_part_sum_kernel, dim3((unsigned)(B * P), 2), dim3(256), 0, s, valids, dist1, dist2, (int)N,
-                     tiles, tile_sums, (int)P, route);
+  if (phases & 1)
+    hipLaunchKernelGGL(grid_sort_kernel, dim3((unsigned)(4 * B)), dim3(1024), 0, s, valids, S1, S2, (int)P, (int)N,
+                       (const float*)grid_bbox(fws, B, P, N), params, starts, batches, worklist, records, rec_stride,
+                       grid_ticket(iws, B), xcd_table ? plan : (XcdPlan*)nullptr, nwaves, route);
+  if (phases & 2) {
+    if (before_search != nullptr) (void)hipEventRecord(before_search, s);
+    if (xcd_table)
+      hipLaunchKernelGGL((grid_search_kernel<false, int>), dim3((unsigned)nwaves), dim3(64), 0, s, valids, S1, S2, (int)P,
+                         (int)N, params, records, starts, batches, worklist, kWorkStride, rec_stride, dist1, dist2, idx1, idx2,
+                         (const XcdPlan*)plan);
+    else
+      hipLaunchKernelGGL((grid_search_kernel<false, int>), dim3(MPA_GRID_WAVES, (unsigned)(2 * B)), dim3(64), 0, s, valids, S1,
+                         S2, (int)P, (int)N, params, records, starts, batches, worklist, kWorkStride, rec_stride, dist1, dist2,
+                         idx1, idx2, (const XcdPlan*)nullptr);
+    if (after_search != nullptr) (void)hipEventRecord(after_search, s);
+  }
+  if (phases & 4)
+    hipLaunchKernelGGL(grid_part_sum_kernel, dim3((unsigned)(B * P), 2), dim3(256), 0, s, valids, dist1, dist2, (int)N,
+                       tiles, tile_sums, (int)P, route);
   return MPA_OK;
 }
 

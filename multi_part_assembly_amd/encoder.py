@@ -158,21 +158,45 @@ class _PointNetBF16Fn(torch.autograd.Function):
         return (None, None, None, None, None, None, *grads)
 
 
+# ---- configurations outside the HIP kernels' instantiation ------------------------------------------------------------------
+# ONE policy for every module of the package (encoders here, TransformerEncoder in transformer.py): a configuration the
+# hand-written kernels are not instantiated for — which the reference accepts (encoder/pointnet.py:6-41, dgcnn.py:41-109:
+# any feat_dim, per-point features, any number of points) — runs on PyTorch-ROCm library operators through the module's
+# own Conv / BatchNorm / Linear sub-modules, said aloud ONCE per module with a warning.  It is a slow path (the
+# reference's own op sequence: edge tensors, one launch per op, a host sync to compact the valid parts), it is never taken
+# by a shipped configuration, and it is still device-only: CPU tensors are rejected as everywhere else.
+def _warn_library_path(module, what):
+    if not getattr(module, "_warned_library", False):
+        import warnings
+        warnings.warn(f"{type(module).__name__}: {what} is outside the HIP kernels' instantiation; running this module on "
+                      "library operators (slow path)")
+        module._warned_library = True
+
+
+def _run_valid_parts(fn, part_pcs, valids, feat_dim, per_point):
+    """fn on the valid parts only, zeros elsewhere (the reference's `_extract_part_feats`: boolean-mask compaction — a
+    host sync, accepted on the slow path)."""
+    M, N, _ = part_pcs.shape
+    keep = valids.reshape(-1) != 0
+    out = part_pcs.new_zeros((M, N, feat_dim) if per_point else (M, feat_dim))
+    if bool(keep.any()):
+        out[keep] = fn(part_pcs[keep].float())
+    return out
+
+
 class PointNet(nn.Module):
     """Shared MLP 3-64-64-64-128-F (1x1 conv, no bias, BN, ReLU except after the last) + max over N.
 
     The Conv1d / BatchNorm1d sub-modules only hold the parameters and buffers (so state_dict keys and
     shapes equal the reference's); the computation runs on csrc/pointnet.hip.  `forward_parts` is the
-    sync-free entry the assembly models use: all B*P part slots plus the validity mask."""
+    sync-free entry the assembly models use: all B*P part slots plus the validity mask.
+    feat_dim outside {64, 128, 256} or per-point features (`global_feat=False`): library operators, see above."""
 
     WIDTHS = (3, 64, 64, 64, 128)
 
     def __init__(self, feat_dim, global_feat=True):
         super().__init__()
-        if not global_feat:
-            raise NotImplementedError("per-point PointNet features are outside the hot path")
-        if feat_dim not in (64, 128, 256):
-            raise NotImplementedError("the HIP PointNet is instantiated for feat_dim 64, 128 and 256")
+        self.feat_dim = feat_dim
         dims = (*self.WIDTHS, feat_dim)
         for i in range(5):
             setattr(self, f"conv{i + 1}", nn.Conv1d(dims[i], dims[i + 1], kernel_size=1, bias=False))
@@ -187,6 +211,9 @@ class PointNet(nn.Module):
         """part_pcs [M, N, 3], valids [M] (1/0) -> [M, feat_dim]; rows of padded parts are zero."""
         if not part_pcs.is_cuda:
             raise RuntimeError("PointNet: only CUDA (HIP) tensors are supported — no CPU fallback")
+        if not self._fused_ok():
+            _warn_library_path(self, f"feat_dim = {self.feat_dim}, global_feat = {self.global_feat}")
+            return _run_valid_parts(self._library_forward, part_pcs, valids, self.feat_dim, not self.global_feat)
         convs = [getattr(self, f"conv{i}") for i in range(1, 6)]
         bns = [getattr(self, f"bn{i}") for i in range(1, 6)]
         if self.training:
@@ -201,8 +228,20 @@ class PointNet(nn.Module):
             bns[0].momentum, bns[0].eps, running, *[c.weight for c in convs], *[b.weight for b in bns],
             *[b.bias for b in bns])
 
+    def _fused_ok(self):
+        return self.global_feat and self.feat_dim in (64, 128, 256) and not getattr(self, "force_library", False)
+
+    def _library_forward(self, x):
+        """[n, N, 3] -> [n, feat_dim] | [n, N, feat_dim] on library operators (pointnet.py:29-41)."""
+        h = x.transpose(1, 2)
+        for i in range(1, 6):
+            h = getattr(self, f"bn{i}")(getattr(self, f"conv{i}")(h))
+            if i < 5:
+                h = F.relu(h)
+        return h.amax(dim=-1) if self.global_feat else h.transpose(1, 2).contiguous()
+
     def forward(self, x):
-        """x [n, N, 3] (every part valid) -> [n, feat_dim]; the reference's signature."""
+        """x [n, N, 3] (every part valid) -> [n, feat_dim] ([n, N, feat_dim] per point); the reference's signature."""
         return self.forward_parts(x, torch.ones(x.shape[0], device=x.device))
 
 
@@ -331,9 +370,10 @@ class DGCNN(nn.Module):
     gather / BatchNorm2d / LeakyReLU / max, HIP tail).  `forward_parts` is the sync-free entry of the assembly
     models: all part slots plus the validity mask, zeros out for padded parts.
 
-    Outside the kernels' instantiation (per-point features, fewer than 20 or more than 1024 points per cloud, feat_dim
-    not in {64, 128, 256}) the module raises: there is no second, slower path (every shipped configuration — 1000
-    points per part, global feature — is inside)."""
+    Outside the kernels' instantiation (per-point features, more than 1024 points per cloud, feat_dim not in
+    {64, 128, 256}) the module runs on library operators (the policy stated above PointNet; every shipped
+    configuration — 1000 points per part, global feature — is inside).  Fewer than 20 points per cloud fail as they do
+    upstream: a 20-nearest-neighbour graph does not exist."""
 
     MAX_POINTS = 1024
 
@@ -357,7 +397,35 @@ class DGCNN(nn.Module):
         self.graph_hooks = None
 
     def _fused_ok(self, N):
-        return self.global_feat and self.feat_dim in (64, 128, 256) and 20 <= N <= self.MAX_POINTS
+        return (self.global_feat and self.feat_dim in (64, 128, 256) and 20 <= N <= self.MAX_POINTS
+                and not getattr(self, "force_library", False))
+
+    @staticmethod
+    def _edge_tensor(h, k=20):
+        """h [n, C, N] -> [n, 2C, N, k]: (neighbour - centre ; centre) over the k best of 2 x.y - |x|^2 - |y|^2
+        (dgcnn.py:8-38)."""
+        rows = h.transpose(1, 2)                                     # [n, N, C]
+        sq = (rows * rows).sum(dim=-1)                               # [n, N]
+        score = 2.0 * torch.matmul(rows, h) - sq[:, :, None] - sq[:, None, :]
+        idx = score.topk(k, dim=-1).indices                         # [n, N, k] (the centre itself included)
+        n, N, C = rows.shape
+        nb = torch.gather(rows[:, None].expand(n, N, N, C), 2, idx[..., None].expand(n, N, k, C))
+        centre = rows[:, :, None].expand(n, N, k, C)
+        return torch.cat([nb - centre, centre], dim=-1).permute(0, 3, 1, 2)
+
+    def _library_forward(self, x):
+        """[n, N, 3] -> [n, feat_dim] | [n, N, feat_dim] on library operators (dgcnn.py:73-109)."""
+        if x.shape[1] < 20:
+            raise RuntimeError(f"DGCNN: a 20-nearest-neighbour graph needs at least 20 points per cloud, got {x.shape[1]}")
+        h = x.transpose(1, 2)
+        stages = []
+        for conv in (self.conv1, self.conv2, self.conv3, self.conv4):
+            h = conv(self._edge_tensor(h)).amax(dim=-1)
+            stages.append(h)
+        h = self.conv5(torch.cat(stages, dim=1))
+        if not self.global_feat:
+            return h.transpose(1, 2).contiguous()
+        return self.out_fc(torch.cat([h.amax(dim=-1), h.mean(dim=-1)], dim=1))
 
     def forward_parts(self, part_pcs, valids):
         """part_pcs [M, N, 3], valids [M] (1/0) -> [M, feat_dim]; rows of padded parts are zero."""
@@ -365,9 +433,8 @@ class DGCNN(nn.Module):
             raise RuntimeError("DGCNN: only CUDA (HIP) tensors are supported — no CPU fallback")
         M, N, _ = part_pcs.shape
         if not self._fused_ok(N):
-            raise NotImplementedError(
-                f"DGCNN: csrc/dgcnn_enc.hip is built for the global feature, 20..{self.MAX_POINTS} points per cloud and "
-                f"feat_dim 64 / 128 / 256 (got N = {N}, feat_dim = {self.feat_dim}, global_feat = {self.global_feat})")
+            _warn_library_path(self, f"N = {N}, feat_dim = {self.feat_dim}, global_feat = {self.global_feat}")
+            return _run_valid_parts(self._library_forward, part_pcs, valids, self.feat_dim, not self.global_feat)
         bns = [self.bn1, self.bn2, self.bn3, self.bn4, self.bn5]
         convs = [self.conv1[0], self.conv2[0], self.conv3[0], self.conv4[0], self.conv5[0]]
         if self.training:

@@ -94,12 +94,47 @@ def test_knn_kernel_selects_the_k_best(golden, cuda_device, C):
     assert (idx[..., 0] == torch.arange(N)[None]).all()                        # the point itself comes first
 
 
-def test_dgcnn_outside_the_fused_range_raises(cuda_device):
-    """There is no second DGCNN path: sizes the one-call encoder is not built for are refused, loudly."""
-    enc = build_encoder("dgcnn", 128).to(cuda_device)
-    for N in (19, 1025):
-        with pytest.raises(NotImplementedError):
-            enc(torch.zeros(2, N, 3, device=cuda_device))
+def test_encoders_outside_the_kernels_instantiation_take_the_library_path(cuda_device):
+    """One policy for every module (encoder.py, transformer.py): what the hand-written kernels are not instantiated for —
+    but the reference accepts (encoder/pointnet.py:6-41, dgcnn.py:41-109: any feat_dim, per-point features, any number of
+    points) — runs on library operators, with one warning per module.  (a) The library path IS the module's function:
+    forced on an in-envelope configuration (`force_library`) it reproduces the HIP path's features, parameter gradients
+    and running statistics, masked parts included.  (b) Out-of-envelope configurations run and have the reference's
+    output shapes.  (c) Fewer than 20 points per DGCNN cloud fail as upstream (no 20-neighbour graph exists)."""
+    import warnings
+
+    torch.manual_seed(5)
+    for arch, N in (("pointnet", 300), ("dgcnn", 96)):
+        a, b = build_encoder(arch, 128).to(cuda_device), build_encoder(arch, 128).to(cuda_device)
+        b.load_state_dict(a.state_dict())
+        b.force_library = True
+        x = (torch.randn(5, N, 3) * 0.3).to(cuda_device)
+        valid = torch.tensor([1, 0, 1, 1, 0.0], device=cuda_device)
+        w = torch.randn(5, 128, device=cuda_device)
+        fa = a.forward_parts(x, valid)
+        (fa * w).sum().backward()
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            fb = b.forward_parts(x, valid)
+            fb2 = b.forward_parts(x, valid)  # (one warning per module, not per call)
+        assert sum("library operators" in str(r.message) for r in rec) == 1
+        (fb * w).sum().backward()
+        assert torch.equal(fb[valid == 0], torch.zeros_like(fb[valid == 0]))
+        np.testing.assert_allclose(fa.detach().cpu().numpy(), fb.detach().cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=arch)
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            assert _rel(p.grad.cpu().numpy(), q.grad.cpu().numpy()) < 5e-3, (arch, k)
+        del fb2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x = torch.randn(3, 40, 3, device=cuda_device)
+        assert build_encoder("pointnet", 96).to(cuda_device)(x).shape == (3, 96)
+        assert build_encoder("pointnet", 128, global_feat=False).to(cuda_device)(x).shape == (3, 40, 128)
+        assert build_encoder("dgcnn", 80).to(cuda_device)(x).shape == (3, 80)
+        assert build_encoder("dgcnn", 128, global_feat=False).to(cuda_device)(x).shape == (3, 40, 128)
+        big = build_encoder("dgcnn", 128).to(cuda_device)
+        assert big(torch.randn(1, 1025, 3, device=cuda_device)).shape == (1, 128)  # beyond the fused kernels' 1024 points
+        with pytest.raises(RuntimeError, match="at least 20 points"):
+            big(torch.zeros(2, 19, 3, device=cuda_device))
 
 
 def test_pointnet_masked_parts_equal_compacted(cuda_device):
