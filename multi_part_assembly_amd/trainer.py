@@ -116,12 +116,22 @@ class Trainer:
         buckets = self.reducer.buckets
         if len(buckets) < 2:
             return
+        if len(buckets) > 2:  # (checked here, before the second graph is captured — not at the first replay)
+            raise RuntimeError(f"graph-mode data parallelism overlaps exactly two gradient buckets, the reducer made "
+                               f"{len(buckets)}; use use_graph=False for this model")
         last = buckets[-1]["slice"]
-        lo, hi = last.data_ptr(), last.data_ptr() + last.numel() * last.element_size()
+        base = self.flat.flat_grad.data_ptr()
+        lo = (last.data_ptr() - base) // last.element_size()
+        hi = lo + last.numel()
+        # by the parameters' SLOTS in the flat gradient buffer, not by p.grad: a parameter whose .grad is still None (or
+        # that autograd accumulates elsewhere) must not pass unchecked
+        slot = {id(p): off for p, off in zip(self.flat.params, self.flat.offsets)}
         for _, _, params in parked:
             for p in params:
-                g = p.grad if isinstance(p, torch.Tensor) else None
-                if g is not None and not (lo <= g.data_ptr() < hi):
+                if not isinstance(p, torch.Tensor):
+                    continue
+                off = slot.get(id(p))
+                if off is None or not (lo <= off < hi):
                     raise RuntimeError("graph-mode data parallelism: a deferred encoder backward owns a parameter "
                                        "outside the last gradient bucket (an encoder module outside model.encoder?); "
                                        "use use_graph=False for this model")

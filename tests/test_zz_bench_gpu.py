@@ -90,6 +90,10 @@ def test_other_configs_hold_their_committed_step_time(cuda_device, capsys, tag, 
         print(f"\n  BENCH {tag}: {json.dumps(slim)}  (committed: {want:.3f} ms in profiles/{src}; "
               f"ratio {d['ms_per_step'] / want:.3f}, recorded not asserted)", end="")
     assert d["ms_per_step"] > 0
+    if d["ms_per_step"] > 2.0 * want:  # a stopwatch never fails the run (round-3 verdict), but a 2x regression is said aloud
+        import warnings
+        warnings.warn(f"BENCH {tag}: {d['ms_per_step']:.3f} ms/step is more than twice the committed {want:.3f} ms "
+                      f"(profiles/{src})")
     if tag == "c2_bf16":
         assert d["dtype"] == "bf16" and "precision_note" in d["config"] and "cpu_baseline" not in d
     else:
