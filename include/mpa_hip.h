@@ -173,14 +173,18 @@ int mpa_assembly_loss_forward_timed(const float* part_pcs, const float* valids, 
  * N > 2048, where the loss keeps its grid search); mpa_assembly_loss_forward_ordered is mpa_assembly_loss_forward_timed
  * taking that ordering, so a training step orders its batch once and evaluates the loss as often as the model asks
  * (3 GNN iterations, min-of-N samples).  order == NULL: computed into the workspace by the call itself.  The ordering
- * steers speed only — results are the exhaustive scan's, bit for bit, for any permutation. */
+ * steers speed only — results are the exhaustive scan's, bit for bit, for any permutation.
+ * `search` picks the searches behind the two Chamfer terms (identical results): 0 exhaustive scans, 1 exhaustive per-part
+ * scan + grid-pruned whole-shape search (rounds 1-4; the default), 2 k-d leaves for both, 3 "auto" = leaves for the per-part
+ * term and, per sample on the device, grid or leaves for the whole-shape term; -1 = MPA_SHAPE_SEARCH (brute | grid | leaf
+ * | auto) or the default.  The leaf structure wins where parts are many and small; only modes 2 / 3 use `order`. */
 int mpa_assembly_order_elems(int64_t B, int64_t P, int64_t N, int64_t* float_elems);
 int mpa_assembly_order(const float* part_pcs, const float* valids, int64_t B, int64_t P, int64_t N, float* order,
                        void* stream);
 int mpa_assembly_loss_forward_ordered(const float* part_pcs, const float* valids, const float* quat_pred,
                                       const float* trans_pred, const float* quat_gt, const float* trans_gt,
                                       int64_t B, int64_t P, int64_t N, int training, int fill_pad_points,
-                                      const float* order, float* float_ws, int32_t* int_ws, float* losses,
+                                      const float* order, int search, float* float_ws, int32_t* int_ws, float* losses,
                                       void* const* events, void* stream);
 /* grad_losses [5,B] = d(objective)/d(losses); writes grad_quat [B,P,4] and grad_trans [B,P,3] of the
  * PREDICTED pose.  Deterministic (no atomics). */

@@ -47,7 +47,7 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_assembly_loss_backward": (_INT, [_P] * 7 + [_I64, _I64, _I64, _INT, _P, _P, _P, _P, _P]),
     "mpa_assembly_order_elems": (_INT, [_I64, _I64, _I64, _P]),
     "mpa_assembly_order": (_INT, [_P, _P, _I64, _I64, _I64, _P, _P]),
-    "mpa_assembly_loss_forward_ordered": (_INT, [_P] * 6 + [_I64, _I64, _I64, _INT, _INT, _P, _P, _P, _P, _P, _P]),
+    "mpa_assembly_loss_forward_ordered": (_INT, [_P] * 6 + [_I64, _I64, _I64, _INT, _INT, _P, _INT, _P, _P, _P, _P, _P]),
     "mpa_pointnet_workspace": (_INT, [_I64, _I64, _I64, _P, _P]),
     "mpa_pointnet_forward": (_INT, [_P] * 7 + [_INT, _F32, _F32, _I64, _I64, _I64, _P, _P, _P, _P]),
     "mpa_pointnet_backward": (_INT, [_P] * 5 + [_I64, _I64, _I64] + [_P] * 6),

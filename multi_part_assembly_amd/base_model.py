@@ -18,7 +18,7 @@ import torch.nn as nn
 from .chamfer import chamfer_distance
 from .eval_utils import calc_connectivity_acc, calc_part_acc, rot_metrics, trans_metrics
 from .matching import SUBSAMPLE, match_parts
-from .loss import (LossTerms, geometric_assembly_loss, part_order, rot_cosine_loss, rot_points_cd_loss,
+from .loss import (LossTerms, geometric_assembly_loss, part_order, search_mode, rot_cosine_loss, rot_points_cd_loss,
                    rot_points_l2_loss, shape_cd_loss, trans_l2_loss)
 from .rotation import Rotation3D
 from .transforms import transform_pc
@@ -120,7 +120,7 @@ class BaseModel(nn.Module):
             # one fused forward/backward pair instead of the per-function composition below
             terms, pts = geometric_assembly_loss(part_pcs, pred_trans, pred_rot, new_trans, new_rot,
                                                  valids, training=self.training, ret_pts=self.keep_pts,
-                                                 order=self._join_part_order(data_dict))
+                                                 order=self._join_part_order(data_dict), search=self._shape_search())
             loss_dict = LossTerms((k, terms[k]) for k in ("trans_loss", "rot_pt_cd_loss", "transform_pt_cd_loss"))
             if self.cfg.loss.use_rot_loss:
                 loss_dict["rot_loss"] = terms["rot_loss"]
@@ -177,6 +177,11 @@ class BaseModel(nn.Module):
     def _loss_function(self, data_dict, out_dict={}, optimizer_idx=-1):
         raise NotImplementedError
 
+    def _shape_search(self):
+        """`cfg.loss.shape_search` ("brute" | "grid" | "leaf" | "auto"; None: MPA_SHAPE_SEARCH, else "grid"): the exact
+        searches behind the fused loss's Chamfer terms.  Configurations for data with many small parts ask for "auto"."""
+        return self.cfg.loss.get("shape_search", None)
+
     # ---- the batch's k-d order (csrc/leaf_nn.hip): once per batch, beside the encoder --------------------------------------
     def _start_part_order(self, data_dict):
         """Both Chamfer searches of the fused loss run on a k-d order of each part's points that depends on the batch
@@ -186,8 +191,8 @@ class BaseModel(nn.Module):
         Returns a shallow copy of `data_dict` carrying the pending order; the caller's dict is never touched (a cached
         order would go stale when a loader refills its batch tensors in place)."""
         pcs = data_dict["part_pcs"]
-        if not (self.fused_loss and not self.semantic and pcs.is_cuda):
-            return data_dict
+        if not (self.fused_loss and not self.semantic and pcs.is_cuda) or search_mode(self._shape_search()) < 2:
+            return data_dict  # (the grid / brute-force searches need no order)
         dev = pcs.device
         side = getattr(self, "_order_stream", None)
         if side is None or side.device != dev:

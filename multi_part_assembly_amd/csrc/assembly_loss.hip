@@ -688,16 +688,22 @@ struct Workspace {
   float *order, *rec[4], *leaf[4], *pbox[4], *wsum_part, *wsum_shape, *scratch;
 };
 
-// 0: brute-force scans, 1: brute-force per-part scan + grid-pruned whole-shape search (grid_nn.hip), 2: leaf search for
-// both (leaf_nn.hip), 3 (default): leaf search for the per-part term, and for the whole-shape term of every SAMPLE the
-// search its geometry favours (leaf_route_kernel: grid where the parts fill the shape's box, leaves where they are many and
-// small).  Identical results; MPA_SHAPE_SEARCH = brute | grid | leaf | auto selects (tests cross-check all of them).
-int search_mode(int64_t P, int64_t N) {
-  const char* e = getenv("MPA_SHAPE_SEARCH");
-  if (e && e[0] == 'b') return 0;
-  if ((e && e[0] == 'g') || !mpa::leaf_supported(P, N)) return P <= 64 ? 1 : 0;  // (the grid keeps one padded part per lane)
-  if (e && e[0] == 'l') return 2;
-  return 3;
+// Which searches answer the two Chamfer terms.  0: brute-force scans; 1 (default): brute-force per-part scan +
+// grid-pruned whole-shape search (grid_nn.hip) — the path of rounds 1-4; 2: leaf search for both (leaf_nn.hip); 3 "auto":
+// leaf search for the per-part term, and for the whole-shape term of every SAMPLE the search its geometry favours
+// (leaf_route_kernel: grid where the parts fill the shape's box, leaves where they are many and small).  Identical
+// results.  The caller's `search` argument (>= 0) decides, else MPA_SHAPE_SEARCH = brute | grid | leaf | auto, else 1:
+// the leaf structure pays where parts are many and small (artifact-like data: configs that say so ask for "auto"), and
+// costs a k-d ordering per batch where they are few and large.
+int search_mode(int64_t P, int64_t N, int search) {
+  int want = search;
+  if (want < 0) {
+    const char* e = getenv("MPA_SHAPE_SEARCH");
+    want = !e ? 1 : (e[0] == 'b' ? 0 : (e[0] == 'l' ? 2 : (e[0] == 'a' ? 3 : 1)));
+  }
+  if (want >= 2 && !mpa::leaf_supported(P, N)) want = 1;
+  if (want == 1 && P > 64) want = 0;  // (the grid keeps one padded part per lane)
+  return want;
 }
 
 // Queries per lane of the NN scans: 4 (fewer, fatter blocks) when there is enough work to fill the chip,
@@ -748,7 +754,7 @@ extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const fl
                                                  const float* quat_pred, const float* trans_pred,
                                                  const float* quat_gt, const float* trans_gt, int64_t B,
                                                  int64_t P, int64_t N, int training, int fill_pad_points,
-                                                 const float* order, float* float_ws, int32_t* int_ws,
+                                                 const float* order, int search, float* float_ws, int32_t* int_ws,
                                                  float* losses, void* const* events, void* stream);
 
 extern "C" int mpa_assembly_loss_forward(const float* part_pcs, const float* valids,
@@ -758,7 +764,7 @@ extern "C" int mpa_assembly_loss_forward(const float* part_pcs, const float* val
                                          float* float_ws, int32_t* int_ws, float* losses,
                                          void* stream) {
   return mpa_assembly_loss_forward_ordered(part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, B, P, N,
-                                           training, fill_pad_points, nullptr, float_ws, int_ws, losses, nullptr,
+                                           training, fill_pad_points, nullptr, -1, float_ws, int_ws, losses, nullptr,
                                            stream);
 }
 
@@ -769,7 +775,7 @@ extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const floa
                                                float* float_ws, int32_t* int_ws, float* losses,
                                                void* const* events, void* stream) {
   return mpa_assembly_loss_forward_ordered(part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, B, P, N,
-                                           training, fill_pad_points, nullptr, float_ws, int_ws, losses, events,
+                                           training, fill_pad_points, nullptr, -1, float_ws, int_ws, losses, events,
                                            stream);
 }
 
@@ -778,13 +784,14 @@ extern "C" int mpa_assembly_loss_forward_timed(const float* part_pcs, const floa
 // [3] after the whole-shape Chamfer phase, [4] after the finalize kernel, [5]/[6] immediately before/after the
 // whole-shape search kernel itself (leaf or grid search; left untouched by the brute-force path).  bench.py times
 // the dominant kernel with them.
+// `search`: -1 = MPA_SHAPE_SEARCH or the default (see search_mode), 0 brute, 1 grid, 2 leaf, 3 auto.
 // `order` (nullable): the k-d order of this batch's parts from mpa_assembly_order — a function of part_pcs and valids
 // only, so one ordering serves every loss evaluation of a step (GNN iterations, min-of-N samples); null: computed here.
 extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const float* valids,
                                                  const float* quat_pred, const float* trans_pred,
                                                  const float* quat_gt, const float* trans_gt, int64_t B,
                                                  int64_t P, int64_t N, int training, int fill_pad_points,
-                                                 const float* order, float* float_ws, int32_t* int_ws,
+                                                 const float* order, int search, float* float_ws, int32_t* int_ws,
                                                  float* losses, void* const* events, void* stream) {
   auto mark = [&](int k) {
     if (events != nullptr && events[k] != nullptr)  // (entries may be null: time only some of the phases)
@@ -801,7 +808,7 @@ extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const fl
   const int q = pick_q(B, P, N);
   const Workspace w = carve(float_ws, int_ws, B, P, N, q);
   const unsigned parts = (unsigned)(B * P);
-  const int mode = search_mode(P, N);
+  const int mode = search_mode(P, N, search);
   // padded parts never write their tile sums: clear them (2 directions x B*P*tiles, both arrays)
   mpa::zero_words_async(w.part_tiles, 4 * B * P * w.tiles, s);
   mark(0);

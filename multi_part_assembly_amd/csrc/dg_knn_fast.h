@@ -82,63 +82,6 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float* __restrict_
   }
 }
 
-// ---- row norms AND split in one pass over x (round 5) ---------------------------------------------------------------------
-// rownorm_kernel (dg_knn.h) stages each row's slabs of 16 + 16 columns through LDS for the pinned norm chain; the very
-// float4 a thread stages is also everything the split needs of those four columns — so the thread writes their hi / lo
-// bf16 words on the spot and the separate knn_split_kernel's re-read of x (181 MB at C = 128, 353 x 1000 rows) and its
-// launch go away.  Same outputs, bit for bit: norm (pinned chain), xs (hi | lo rows), nl / nu.  grid = ceil(Rmax / 256).
-template <int C>
-__global__ __launch_bounds__(256) void rownorm_split_kernel(const float* __restrict__ x, int ld, float* __restrict__ norm,
-                                                            unsigned short* __restrict__ xs, float* __restrict__ nl,
-                                                            float* __restrict__ nu, const int* __restrict__ hdr) {
-  __shared__ float slab[256][33];
-  const int R = hdr[1];
-  const long long r0 = (long long)blockIdx.x * 256;
-  if (r0 >= R) return;
-  float acc = 0.0f;
-  const int c4 = threadIdx.x & 7, rl = threadIdx.x >> 3;  // float4 column (8 per 32-float slab row), rows rl + 32 i
-  for (int u = 0; u < C / 32; ++u) {  // chain positions 32u .. 32u+31 = columns 16u+s (even) and C/2+16u+s (odd)
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const long long r = r0 + rl + 32 * i;
-      const int col = (c4 < 4 ? 16 * u + 4 * c4 : C / 2 + 16 * u + 4 * (c4 - 4));
-      const float4 t = r < R ? *reinterpret_cast<const float4*>(x + r * ld + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-      float* d = &slab[rl + 32 * i][4 * c4];
-      d[0] = t.x;
-      d[1] = t.y;
-      d[2] = t.z;
-      d[3] = t.w;
-      if (r < R) {
-        const float f[4] = {t.x, t.y, t.z, t.w};
-        kf_bf16x4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          hi[e] = (__bf16)f[e];
-          lo[e] = (__bf16)(f[e] - (float)hi[e]);
-        }
-        unsigned short* row = xs + r * (2 * C);
-        *reinterpret_cast<kf_bf16x4*>(row + col) = hi;
-        *reinterpret_cast<kf_bf16x4*>(row + C + col) = lo;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const float lo = slab[threadIdx.x][s], hi = slab[threadIdx.x][16 + s];
-      acc = __builtin_fmaf(lo, lo, acc);
-      acc = __builtin_fmaf(hi, hi, acc);
-    }
-  }
-  if (r0 + threadIdx.x < R) {
-    const long long r = r0 + threadIdx.x;
-    const float k = KnnFast<C>::kappa;
-    norm[r] = acc;
-    nl[r] = next_float(__builtin_fmaf(acc, k, acc));
-    nu[r] = prev_float(__builtin_fmaf(acc, -k, acc));
-  }
-}
-
 // ---- shared Gram-tile machinery of the bound / collect kernels ------------------------------------------------------------
 // Block = WAVES waves handling 256 queries; a wave owns SETS sets of 32 queries (B operands hi / lo, register-resident:
 // SETS * C / 2 VGPRs); candidate tiles of 32 rows (hi | lo, 4C bytes per row) go through a double-buffered LDS panel

@@ -1114,14 +1114,12 @@ void knn_wide(const float* x, int ld, float* norm, const KnnWs& k, int64_t M, in
   const int64_t R = M * N;
   constexpr int SETS = 1, WAVES = 8;
   const dim3 ggram((unsigned)((N + kKfQB - 1) / kKfQB), DG_KNN_GRID_Y(M));
-#if defined(MPA_KNN_SEPARATE_SPLIT)  // (A/B builds: the two-pass form of rounds 3-4)
+  // (round 5: one fused pass — norm chain + split from the same staged float4 — was built and measured 0.03-0.05 ms SLOWER
+  // per C = 128 search on one box, three alternations: its hi / lo stores are 32-byte segments per row and slab, where this
+  // split kernel writes full lines; LABBOOK 5.2)
   hipLaunchKernelGGL(rownorm_kernel<C>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, x, ld, norm, hdr);
   hipLaunchKernelGGL(knn_split_kernel<C>, dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, x, ld,
                      (const float*)norm, k.xs, k.nl, k.nu, hdr);
-#else
-  hipLaunchKernelGGL(rownorm_split_kernel<C>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, x, ld, norm, k.xs, k.nl,
-                     k.nu, hdr);
-#endif
   hipLaunchKernelGGL((knn_gram_kernel<C, false, SETS, WAVES>), ggram, dim3(64 * WAVES), 0, s, (const unsigned short*)k.xs,
                      (const float*)k.nl, (const float*)k.nl, (const float*)k.nu, (int)N, k.theta, k.surv, k.scnt, hdr);
   hipLaunchKernelGGL((knn_gram_kernel<C, true, SETS, WAVES>), ggram, dim3(64 * WAVES), 0, s, (const unsigned short*)k.xs,

@@ -85,129 +85,144 @@ __device__ __forceinline__ float lb_box_box(const float (&qlo)[3], const float (
 }
 
 // ---- 1. the k-d ordering of a part's points (once per batch) ------------------------------------------------------------
-// One block per part.  Level by level the segment [0, Npad) is halved: every segment is sorted along the widest axis
-// of its own bounding box and cut in the middle, down to segments of 32 slots = the leaves.  Sort keys are ONE 32-bit
-// word — the coordinate quantised to 21 bits over the segment's extent, the point's index (< 2048) below it: a strict
-// total order (deterministic result), half the LDS traffic of (float, index) pairs and bank-friendly (64-bit keys ran
-// the small-stride stages of the network into 8-way bank conflicts).  Pad slots (beyond N) carry the largest key and
-// stay at the end of the last segment.  The ordering only steers speed: the search is exact for any permutation.
+// ONE WAVE per part.  Level by level the segment [0, Npad) is halved: every segment is sorted along the widest axis of
+// its own bounding box and cut in the middle, down to segments of 32 slots = the leaves.  Everything after the first
+// pass over the points is integer: coordinates quantised to 16 bits over the part's box (three u16 arrays in LDS), sort
+// keys ONE 32-bit word (coordinate << 11 | point index: a strict total order, so the result is deterministic), segment
+// boxes as integer minima / maxima.  Pad slots (beyond N) carry the largest key and stay at the end of the last segment.
+// The ordering only steers speed: the search is exact for any permutation.
+// Why one wave: the bitonic network is a chain of ~185 dependent stages whatever the block size.  A block of 16 waves
+// spends it on barriers and holds 33 KB of LDS for 110 us — enough to push a PointNet block off its CU when the kernel
+// runs beside the encoder (pn_fwd_mfma 47 -> 82 us, measured).  A single wave needs no barrier at all (LDS operations of
+// one wave execute in order), 10 bytes of LDS per slot, and leaves the chip to whoever runs beside it.
 // Output: sorted[m][k] = (x, y, z, original index n as int bits; -1 in pad slots) in LOCAL coordinates.
-// Barriers: thread t owns the compare-exchange pairs t, t + 512, ...; in every stage whose partner distance is at most
-// 64 (all of a merge's last seven stages, and whole merges up to 128 keys) the 64 pairs of a wave touch exactly the
-// wave's own 128 keys, and LDS operations of one wave execute in order — those stages need no block barrier.
-constexpr int kOrderThreads = 512;
 constexpr unsigned kPadKey = 0xffffffffu;
 
-__global__ __launch_bounds__(kOrderThreads) void leaf_order_kernel(const float* __restrict__ pcs,
-                                                                   const float* __restrict__ valids, int N, int Npad,
-                                                                   float4* __restrict__ sorted) {
-  __shared__ unsigned key[kLeafMaxPad];
-  __shared__ float px[kLeafMaxPad], py[kLeafMaxPad], pz[kLeafMaxPad];
-  __shared__ float cbox[kLeafMaxPad / kLeaf][6];
-  const int m = blockIdx.x;
+__global__ __launch_bounds__(64) void leaf_order_kernel(const float* __restrict__ pcs, const float* __restrict__ valids,
+                                                        int N, int Npad, float4* __restrict__ sorted) {
+  extern __shared__ unsigned order_lds[];
+  unsigned* key = order_lds;                                                   // [Npad]
+  unsigned short* qc = reinterpret_cast<unsigned short*>(order_lds + Npad);  // [3][Npad] quantised x | y | z
+  const int m = blockIdx.x, lane = threadIdx.x;
   if (valids[m] == 0.0f) return;
   const float* src = pcs + 3LL * m * N;
-  for (int n = threadIdx.x; n < Npad; n += kOrderThreads) {
+  float4* out = sorted + (long long)m * Npad;
+  if (Npad <= kLeaf) {  // one leaf: any order
+    if (lane < Npad)
+      out[lane] = lane < N ? make_float4(src[3 * lane], src[3 * lane + 1], src[3 * lane + 2], __int_as_float(lane))
+                           : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    return;
+  }
+  // the part's box, then the quantised coordinates
+  const float inf = __builtin_inff();
+  float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+  for (int n = lane; n < N; n += 64) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = src[3 * n + a];
+      lo[a] = __builtin_fminf(lo[a], v);
+      hi[a] = __builtin_fmaxf(hi[a], v);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], off, 64));
+      hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+    }
+  }
+  float sc[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) sc[a] = hi[a] > lo[a] ? 65535.0f / (hi[a] - lo[a]) : 0.0f;  // (degenerate / non-finite: one bucket)
+  for (int n = lane; n < Npad; n += 64) {
     const bool in = n < N;
-    px[n] = in ? src[3 * n] : 0.0f;
-    py[n] = in ? src[3 * n + 1] : 0.0f;
-    pz[n] = in ? src[3 * n + 2] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = in ? src[3 * n + a] : 0.0f;
+      qc[a * Npad + n] = (unsigned short)__builtin_amdgcn_fmed3f((v - lo[a]) * sc[a], 0.0f, 65535.0f);
+    }
     key[n] = in ? (unsigned)n : kPadKey;  // low 11 bits: the point held by this slot
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
+  const int PER = Npad / 64;  // consecutive slots per lane in the box / key phases (>= 1; a lane's slots share a segment)
   for (int S = Npad; S > kLeaf; S >>= 1) {
-    // boxes of the 32-slot chunks, then of the segments
-    for (int k = threadIdx.x; k < Npad; k += kOrderThreads) {
-      const unsigned e = key[k];
-      const bool real = e != kPadKey;
-      const int n = real ? (int)(e & 2047u) : 0;
-      const float inf = __builtin_inff();
-      float lo[3] = {real ? px[n] : inf, real ? py[n] : inf, real ? pz[n] : inf};
-      float hi[3] = {real ? px[n] : -inf, real ? py[n] : -inf, real ? pz[n] : -inf};
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], off, 64));
-          hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
-        }
-      }
-      if ((k & 31) == 0) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          cbox[k >> 5][a] = lo[a];
-          cbox[k >> 5][3 + a] = hi[a];
-        }
-      }
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < Npad; k += kOrderThreads) {
-      const int seg = k / S, c0 = seg * (S / kLeaf), c1 = c0 + S / kLeaf;
-      float lo[3] = {cbox[c0][0], cbox[c0][1], cbox[c0][2]}, hi[3] = {cbox[c0][3], cbox[c0][4], cbox[c0][5]};
-      for (int c = c0 + 1; c < c1; ++c) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          lo[a] = __builtin_fminf(lo[a], cbox[c][a]);
-          hi[a] = __builtin_fmaxf(hi[a], cbox[c][3 + a]);
-        }
-      }
-      const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-      const int axis = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2);  // (NaN extents fall through to z: any axis is fine)
-      const unsigned e = key[k];
+    // integer box of this lane's slots, then of its segment (the G = S / PER lanes that hold it: xor-shuffles below G)
+    unsigned blo[3] = {0xffffu, 0xffffu, 0xffffu}, bhi[3] = {0u, 0u, 0u};
+    for (int r = 0; r < PER; ++r) {
+      const unsigned e = key[lane * PER + r];
       if (e != kPadKey) {
         const int n = (int)(e & 2047u);
-        const float v = axis == 0 ? px[n] : (axis == 1 ? py[n] : pz[n]);
-        const float l = axis == 0 ? lo[0] : (axis == 1 ? lo[1] : lo[2]), x = axis == 0 ? ex : (axis == 1 ? ey : ez);
-        // position inside the segment's extent, 21 bits (non-finite or degenerate extents: everything in one bucket)
-        const float f = x > 0.0f ? (v - l) / x : 0.0f;
-        const unsigned qv = (unsigned)__builtin_amdgcn_fmed3f(f * 2097151.0f, 0.0f, 2097151.0f);
-        key[k] = ((qv < 2097151u ? qv : 2097150u) << 11) | (unsigned)n;  // (always below the pad key)
-      }
-    }
-    __syncthreads();
-    // ascending bitonic sort of every aligned S-segment; Npad / 2 compare-exchange pairs per stage
-    bool prev_cross = false;  // (the barrier above covers the first stage)
-    auto stage_sync = [&](bool cross) {
-      if (cross || prev_cross) __syncthreads();
-      else __builtin_amdgcn_wave_barrier();  // wave-local stage after a wave-local stage: program order suffices
-      prev_cross = cross;
-    };
-#if defined(MPA_ORDER_EXP) && MPA_ORDER_EXP == 1
-    if (S > 0) continue;
-#endif
-    for (int lk = 1; (1 << lk) <= S; ++lk) {  // merge size k = 2^lk (shifts, not divisions: k and j are powers of two)
-      const int k = 1 << lk;
-      if (k > 2) stage_sync(k > 128);
-      for (int t = threadIdx.x; t < Npad / 2; t += kOrderThreads) {  // first stage of a merge: mirror pairs
-        const int base = (t >> (lk - 1)) << lk, off = t & ((k >> 1) - 1);
-        const int i = base + off, p = base + (k - 1 - off);
-        const unsigned a = key[i], b = key[p];
-        if (a > b) {
-          key[i] = b;
-          key[p] = a;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const unsigned v = qc[a * Npad + n];
+          blo[a] = min(blo[a], v);
+          bhi[a] = max(bhi[a], v);
         }
       }
-      for (int lj = lk - 2; lj >= 0; --lj) {
-        const int j = 1 << lj;
-        stage_sync(j > 64);
-        for (int t = threadIdx.x; t < Npad / 2; t += kOrderThreads) {
-          const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), p = i + j;
-          const unsigned a = key[i], b = key[p];
-          if (a > b) {
-            key[i] = b;
-            key[p] = a;
+    }
+    const int G = S / PER;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      if (off < G) {  // (wave-uniform)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          blo[a] = min(blo[a], (unsigned)__shfl_xor((int)blo[a], off, 64));
+          bhi[a] = max(bhi[a], (unsigned)__shfl_xor((int)bhi[a], off, 64));
+        }
+      }
+    }
+    const int ex = (int)bhi[0] - (int)blo[0], ey = (int)bhi[1] - (int)blo[1], ez = (int)bhi[2] - (int)blo[2];
+    const int axis = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2);
+    for (int r = 0; r < PER; ++r) {
+      const unsigned e = key[lane * PER + r];
+      if (e != kPadKey) {
+        const unsigned n = e & 2047u;
+        key[lane * PER + r] = ((unsigned)qc[axis * Npad + n] << 11) | n;  // (always below the pad key)
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ascending bitonic sort of every aligned S-segment: Npad / 2 compare-exchange pairs per stage, pair t of lane
+    // t % 64; up to 8 pairs' loads in flight
+    const int npairs = Npad / 2;
+    auto stage = [&](int lk, int lj) {  // lj < 0: the mirror stage of merge size 2^lk; else partner distance 2^lj
+      for (int t0 = lane; t0 < npairs; t0 += 64 * 8) {
+        unsigned a[8], b[8];
+        int ia[8], ib[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = t0 + 64 * u;
+          const int tc = t < npairs ? t : t0;  // (clamped: a duplicate of pair t0, rewritten with the same values)
+          if (lj < 0) {
+            const int k = 1 << lk, base = (tc >> (lk - 1)) << lk, off = tc & ((k >> 1) - 1);
+            ia[u] = base + off;
+            ib[u] = base + (k - 1 - off);
+          } else {
+            const int j = 1 << lj;
+            ia[u] = ((tc >> lj) << (lj + 1)) + (tc & (j - 1));
+            ib[u] = ia[u] + j;
           }
+          a[u] = key[ia[u]];
+          b[u] = key[ib[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          key[ia[u]] = min(a[u], b[u]);
+          key[ib[u]] = max(a[u], b[u]);
         }
       }
+      __builtin_amdgcn_wave_barrier();  // (one wave: program order is all the synchronisation LDS needs)
+    };
+    for (int lk = 1; (1 << lk) <= S; ++lk) {
+      stage(lk, -1);
+      for (int lj = lk - 2; lj >= 0; --lj) stage(lk, lj);
     }
-    __syncthreads();
   }
-  float4* out = sorted + (long long)m * Npad;
-  for (int k = threadIdx.x; k < Npad; k += kOrderThreads) {
+  for (int k = lane; k < Npad; k += 64) {
     const unsigned e = key[k];
     const bool real = e != kPadKey;
     const int n = real ? (int)(e & 2047u) : 0;
-    out[k] = make_float4(px[n], py[n], pz[n], __int_as_float(real ? n : -1));
+    out[k] = make_float4(src[3 * n], src[3 * n + 1], src[3 * n + 2], __int_as_float(real ? n : -1));
   }
 }
 
@@ -696,8 +711,9 @@ bool leaf_supported(int64_t P, int64_t N) { return P >= 1 && P <= 64 && N >= 1 &
 
 void launch_leaf_order(const float* part_pcs, const float* valids, int64_t B, int64_t P, int64_t N, float* sorted,
                        hipStream_t s) {
-  hipLaunchKernelGGL(leaf_order_kernel, dim3((unsigned)(B * P)), dim3(kOrderThreads), 0, s, part_pcs, valids, (int)N, leaf_npad(N),
-                     reinterpret_cast<float4*>(sorted));
+  const int npad = leaf_npad(N);
+  hipLaunchKernelGGL(leaf_order_kernel, dim3((unsigned)(B * P)), dim3(64), (size_t)npad * 10, s, part_pcs, valids, (int)N,
+                     npad, reinterpret_cast<float4*>(sorted));
 }
 
 int64_t leaf_scratch_floats(int64_t B, int64_t P, int64_t N) {  // heavy list + keys + counters, shared by both searches

@@ -15,7 +15,7 @@ from . import _lib
 from .chamfer import chamfer_distance
 from .transforms import pose_apply, rot_pc
 
-__all__ = ["geometric_assembly_loss", "part_order", "LOSS_TERMS", "trans_l2_loss", "rot_l2_loss", "rot_cosine_loss", "rot_points_l2_loss",
+__all__ = ["geometric_assembly_loss", "part_order", "search_mode", "SEARCH_MODES", "LOSS_TERMS", "trans_l2_loss", "rot_l2_loss", "rot_cosine_loss", "rot_points_l2_loss",
            "rot_points_cd_loss", "shape_cd_loss", "repulsion_cd_loss"]
 
 PAD_FILL = 1e3  # coordinate given to the points of padded parts in shape_cd_loss (loss.py:173-175)
@@ -140,7 +140,8 @@ class _AssemblyLoss(torch.autograd.Function):
     """All five geometric loss terms in 5 launches forward / 1 launch backward (csrc/assembly_loss.hip)."""
 
     @staticmethod
-    def forward(ctx, part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, training, fill_pads, order=None):
+    def forward(ctx, part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, training, fill_pads, order=None,
+                search=-1):
         B, P, N, _ = part_pcs.shape
         dev = part_pcs.device
         L = _lib.lib()
@@ -163,7 +164,7 @@ class _AssemblyLoss(torch.autograd.Function):
             st = L.mpa_assembly_loss_forward_ordered(
                 _lib.ptr(part_pcs), _lib.ptr(valids), _lib.ptr(quat_pred), _lib.ptr(trans_pred),
                 _lib.ptr(quat_gt), _lib.ptr(trans_gt), B, P, N, int(training), int(fill_pads),
-                _lib.ptr(order) if order is not None else None,
+                _lib.ptr(order) if order is not None else None, int(search),
                 _lib.ptr(fws), _lib.ptr(iws), _lib.ptr(losses), _lib.KernelTimer.handles(both),
                 _lib.current_stream(dev))
             _lib.KernelTimer.add_phases(names, evs)
@@ -183,7 +184,7 @@ class _AssemblyLoss(torch.autograd.Function):
             raise RuntimeError("assembly loss: the backward pass reuses the forward's tile-sum area as scratch: a second "
                                "backward over the same forward (retain_graph=True) is not supported — run the forward again")
         if grad_losses is None:
-            return (None,) * 9
+            return (None,) * 10
         ctx.consumed = True
         part_pcs, valids, quat_pred, trans_pred, quat_gt, trans_gt, fws, iws = ctx.saved_tensors
         B, P, N, _ = part_pcs.shape
@@ -197,18 +198,33 @@ class _AssemblyLoss(torch.autograd.Function):
                 _lib.ptr(trans_pred), _lib.ptr(quat_gt), _lib.ptr(trans_gt), B, P, N, ctx.training,
                 _lib.ptr(fws), _lib.ptr(iws), _lib.ptr(gq), _lib.ptr(gt), _lib.current_stream(dev))
         _lib.check(st, "mpa_assembly_loss_backward")
-        return None, None, gq, gt, None, None, None, None, None
+        return None, None, gq, gt, None, None, None, None, None, None
+
+
+SEARCH_MODES = {"brute": 0, "grid": 1, "leaf": 2, "auto": 3}
+
+
+def search_mode(name=None):
+    """The search behind the loss's two Chamfer terms as the C ABI's code: MPA_SHAPE_SEARCH if set (the override for tests
+    and A/B runs), else `name` (a key of SEARCH_MODES; what a configuration asks for), else "grid".  Identical results all;
+    "leaf" / "auto" pay where parts are many and small and need the batch's `part_order`."""
+    import os
+    name = os.environ.get("MPA_SHAPE_SEARCH") or name or "grid"
+    if name not in SEARCH_MODES:
+        raise ValueError(f"shape search must be one of {sorted(SEARCH_MODES)}, not {name!r}")
+    return SEARCH_MODES[name]
 
 
 def geometric_assembly_loss(part_pcs, pred_trans, pred_rot, gt_trans, gt_rot, valids, training=True,
-                            ret_pts=False, order=None):
+                            ret_pts=False, order=None, search=None):
     """The loss terms of `BaseModel._calc_loss` for geometric data, fused (no GT re-matching).
 
     Returns ({name: [B]} for LOSS_TERMS, pts) where pts is None or, with ret_pts,
     (pred_trans_pts, gt_trans_pts) [B,P,N,3] as shape_cd_loss(..., ret_pts=True) returns them.
     Gradients flow to pred_trans and pred_rot only (the GT pose is detached, as in the reference).
-    `order`: `part_order(part_pcs, valids)` of this batch when the caller evaluates the loss more than once per batch
-    (computed by the call itself when None).
+    `search`: "brute" | "grid" | "leaf" | "auto" (None: MPA_SHAPE_SEARCH, else "grid"): which exact searches run the two
+    Chamfer terms — identical results.  `order`: `part_order(part_pcs, valids)` of this batch for "leaf" / "auto" when the
+    caller evaluates the loss more than once per batch (computed by the call itself when None).
     """
     if not part_pcs.is_cuda:
         raise RuntimeError("geometric_assembly_loss: only CUDA (HIP) tensors are supported")
@@ -217,7 +233,7 @@ def geometric_assembly_loss(part_pcs, pred_trans, pred_rot, gt_trans, gt_rot, va
     losses, pts = _AssemblyLoss.apply(
         f(part_pcs), f(valids), _quat(pred_rot).to(torch.float32).contiguous(),
         pred_trans.to(torch.float32).contiguous(), f(_quat(gt_rot)), f(gt_trans), bool(training),
-        bool(ret_pts), order)
+        bool(ret_pts), order, search_mode(search))
     terms = LossTerms((name, losses[i]) for i, name in enumerate(LOSS_TERMS))
     terms.stacked = (LOSS_TERMS, losses)
     return terms, ((pts[2], pts[3]) if ret_pts else None)

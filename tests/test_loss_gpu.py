@@ -320,10 +320,14 @@ def test_leaf_search_with_trained_poses_and_given_order(cuda_device, monkeypatch
         qp = torch.where(v.cpu()[..., None] > 0, qp, torch.tensor([1.0, 0, 0, 0])).to(cuda_device).contiguous()
         tp = (batch["part_trans"].cpu() + noise * torch.randn(6, 20, 3, generator=g)).to(cuda_device).contiguous()
         _assert_searches_agree(batch, qp, tp, monkeypatch)
-        monkeypatch.setenv("MPA_SHAPE_SEARCH", "leaf")
-        a, _ = L.geometric_assembly_loss(pcs, tp, Rotation3D(qp), batch["part_trans"], Rotation3D(batch["part_quat"]), v)
+        monkeypatch.delenv("MPA_SHAPE_SEARCH", raising=False)
+        a, _ = L.geometric_assembly_loss(pcs, tp, Rotation3D(qp), batch["part_trans"], Rotation3D(batch["part_quat"]), v,
+                                         search="leaf")
         b, _ = L.geometric_assembly_loss(pcs, tp, Rotation3D(qp), batch["part_trans"], Rotation3D(batch["part_quat"]), v,
-                                         order=order)
+                                         order=order, search="leaf")
+        g_, _ = L.geometric_assembly_loss(pcs, tp, Rotation3D(qp), batch["part_trans"], Rotation3D(batch["part_quat"]), v)
+        for k in L.LOSS_TERMS:  # (the default search, the grid of rounds 1-4: same terms to summation order)
+            np.testing.assert_allclose(g_[k].cpu().numpy(), a[k].cpu().numpy(), rtol=2e-6, atol=1e-9, err_msg=k)
         for k in L.LOSS_TERMS:
             assert torch.equal(a[k], b[k]), k
 

@@ -47,7 +47,7 @@ for preset in ("everyday", "artifact"):
                 for it in range(reps + 1):
                     h = (ctypes.c_void_p * 7)(*[e.cuda_event for e in evs])
                     st = L.mpa_assembly_loss_forward_ordered(_lib.ptr(pcs), _lib.ptr(v), _lib.ptr(qp), _lib.ptr(tp), _lib.ptr(qg), _lib.ptr(tg),
-                                                            B, P, N, 1, 0, _lib.ptr(order) if with_order else None, _lib.ptr(fws), _lib.ptr(iws),
+                                                            B, P, N, 1, 0, _lib.ptr(order) if with_order else None, -1, _lib.ptr(fws), _lib.ptr(iws),
                                                             _lib.ptr(losses), h, _lib.current_stream(dev))
                     _lib.check(st, "fwd")
                     torch.cuda.synchronize()
