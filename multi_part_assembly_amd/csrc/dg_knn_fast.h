@@ -3,20 +3,22 @@
 // dg_knn.h computes every candidate score exactly (fp32 MFMA chain, 1/16 of the bf16 rate) and keeps a sorted list of
 // 20 per lane: 0.87 / 1.46 ms per stage at 353 x 1000 points.  Here the exact arithmetic is spent only on a SHORTLIST:
 //
-//   split   x = hi + lo + r, hi = bf16(x), lo = bf16(x - hi)  (|r| <= 2^-16 |x|), row norms n_j in the pinned chain order
-//   BOUND   (knn_bound_kernel)   Gram tiles  a^ = hi.hi + hi.lo + lo.hi  on v_mfma_f32_32x32x16_bf16 (3 products: 16/3 of
-//           the fp32-MFMA rate).  |score(i,j) - (2 a^ - n_j - n_i)| <= kappa (n_i + n_j)  [derivation below], so
-//               lower(i,j) = 2 a^ - (1 + kappa) n_j - (1 + kappa) n_i  <=  score(i,j)  <=  upper(i,j) = 2 a^ - (1 - kappa)(n_j + n_i).
+//   split   (round 5, default) y = x - mu of the cloud, hi = bf16(y); row norms n_j in the pinned chain order, centred norms m_j
+//           (rounds 3-4, MPA_KNN_PRODUCTS=3: x = hi + lo + r on the raw features, three products per tile)
+//   BOUND   (knn_bound = knn_gram_kernel<.., false>)   Gram tiles  a^ = hi.hi  on v_mfma_f32_32x32x16_bf16 (ONE product: 16x
+//           the fp32-MFMA rate).  lower(i,j) = 2 a^ - NL_j - NL_i <= score(i,j) <= upper(i,j) = 2 a^ - NU_j - NU_i with the
+//           per-row scaled norms NL / NU derived next to KnnFast below.
 //           No list: every lane keeps the running MAXIMUM of `lower` per accumulator slot — 32 disjoint candidate groups
 //           per query (16 slots x 2 lane halves).  The 20th largest of the 32 group maxima, tau_i, is a lower bound of
 //           the true 20th best score T_i (20 distinct candidates reach it).  2 VALU operations per candidate.
-//   COLLECT (knn_collect_kernel) the same Gram tiles again; a candidate survives iff upper(i,j) >= tau_i.  Every true
-//           neighbour survives (upper >= score >= T_i >= tau_i), ties included; typically 30-35 of 1000 do.  Survivor
-//           indices go to a per-lane list in LDS, then to HBM.
+//   COLLECT (knn_gram_kernel<.., true>) the same Gram tiles again; a candidate survives iff upper(i,j) >= tau_i.  Every true
+//           neighbour survives (upper >= score >= T_i >= tau_i), ties included; 27-30 of 1000 do with one product (three
+//           products: ~21).  Survivor indices go to a per-lane list in LDS, then to HBM.
 //   RERANK  (knn_rerank_kernel)  the pinned score — fmaf chain in the matrix-core order, exactly dg_knn.h's / the
 //           oracle's arithmetic — of the survivors only, and the 20 best by (score descending, index ascending).
-//   A query whose survivor list overflows (mass ties: duplicated points, lattices; about one list in 10^4 on random
-//   data) is marked; the rerank kernel scores ALL N candidates of such a query with the pinned chain instead.
+//   A query whose survivor list overflows (mass ties: duplicated points, lattices; with one product ~1 list in 10^3 of the
+//   benchmark's features) is marked; the rerank kernel scores ALL N candidates of such a query with the pinned chain
+//   and ranks those at or above tau_i.
 // Result: bit-identical indices to dg_knn.h on every input (tests/test_dgcnn_gpu.py: index-exact against oracle/knn_ref.c
 // and against the reference's own graphs).
 //
@@ -39,13 +41,38 @@ namespace dg {
 typedef __bf16 kf_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 kf_bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MPA_KNN_PRODUCTS  // 1 (round 5): centred one-product Gram tiles; 3: the hi.hi + hi.lo + lo.hi tiles of rounds 3-4
+#define MPA_KNN_PRODUCTS 1
+#endif
+constexpr int kKfProducts = MPA_KNN_PRODUCTS;
+static_assert(kKfProducts == 1 || kKfProducts == 3, "MPA_KNN_PRODUCTS is 1 or 3");
+
+// ONE product (round 5).  The score is a distance: -|x_i - x_j|^2 does not move when every row of a cloud is shifted by
+// the same vector mu, and the bound's slack is proportional to the rows' squared norms — so the tiles are built on
+// y = x - mu (mu = the mean of the cloud's first 16 rows: any vector is valid, this one takes the features' common
+// offset out and the norms down ~2.3x) and a single bf16 product hi_i . hi_j suffices:
+//   y^ = fl(x - mu) = y (1 + t), |t| <= 2^-24;  hi = bf16(y^): |y - hi| <= u |y|, u = 2^-8 (1 + 2^-15)
+//   |y_i.y_j - hi_i.hi_j| <= u (2 + u) sum_k |y_ik y_jk| <= u (2 + u) (M_i + M_j) / 2          (M = |y|^2)
+//   accumulation inside the matrix core: <= C 2^-23 1.03 (M_i + M_j) / 2  (as charged for three products below)
+//   => |2 a^ - 2 y_i.y_j| <= kg (M_i + M_j),  kg = 7.845e-3 (C = 128), 7.836e-3 (C = 64)
+//   m = fp32 sum of y^_k^2 (fixed order) is within (C + 3) 2^-24 of M; evaluating lower / upper in fp32 adds 4 * 2^-24.
+//   kappa_g = 7.9e-3 covers kg and those with 0.6 % to spare.
+// The PINNED score (fmaf chain on the RAW features, dg_knn.h) is within kappa_raw (n_i + n_j) of the true -|x_i - x_j|^2:
+//   chain vs exact dot product C 2^-24 1.01 sum |x x|, twice; the two norms C 2^-24 each; forming the score 5.02 * 2^-24
+//   => (2C + 5) 2^-24 1.02 = 1.59e-5 (C = 128), 8.1e-6 (C = 64); kappa_raw = 1.75e-5 / 9e-6.
+// So, with NL = (1 + kappa_g) m + kappa_raw n (rounded up) and NU = (1 - kappa_g) m - kappa_raw n (rounded down):
+//   lower(i,j) = 2 a^ - NL_j - NL_i <= score(i,j) <= upper(i,j) = 2 a^ - NU_j - NU_i
+// — the same two per-row arrays the three-product form hands the Gram kernels.  Looser bounds, more survivors (the
+// benchmark's features: ~21 per lane half instead of ~16), a third of the matrix-core work and half of the operand bytes.
 template <int C>
 struct KnnFast {
-  static constexpr float kappa = C > 64 ? 1.15e-4f : 8.5e-5f;
+  static constexpr float kappa = C > 64 ? 1.15e-4f : 8.5e-5f;      // three products, raw features
+  static constexpr float kappa_g = 7.9e-3f;                         // one product, centred features
+  static constexpr float kappa_raw = C > 64 ? 1.75e-5f : 9.0e-6f;   // pinned chain vs exact, raw features
 };
 
-constexpr int kKfCap = 32;     // survivor slots per (query, lane half): the expected load is ~10.5, the largest of 2.5 M lists
-                               // of the benchmark's features 27; a list that overflows costs its query an exhaustive scan
+constexpr int kKfCap = kKfProducts == 1 ? 48 : 32;  // survivor slots per (query, lane half): expected load ~16 (three products) /
+                               // ~21 (one product); a list that overflows costs its query an exhaustive scan
                                // in the rerank kernel (~0.2 ms for the launch: one block's tail)
 constexpr int kKfQB = 256;     // queries per block of the bound / collect kernels (4 waves x 2 sets of 32)
 constexpr int kKfOverflow = 255;  // survivor count of a list that overflowed: the rerank kernel scans that query exhaustively
@@ -82,6 +109,49 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float* __restrict_
   }
 }
 
+// ---- one product: the cloud's centre, then hi(x - mu) rows and the two scaled norms -------------------------------------------
+// mu [clouds][C] = mean of the cloud's first 16 rows (N >= 20 always).  grid = clouds (worst case; past hdr[0]: exit), block C.
+template <int C>
+__global__ __launch_bounds__(C) void knn_centre_kernel(const float* __restrict__ x, int ld, int N, float* __restrict__ mu,
+                                                       const int* __restrict__ hdr) {
+  const int v = blockIdx.x, c = threadIdx.x;
+  if (v >= hdr[0]) return;
+  const float* xp = x + (long long)v * N * ld + c;
+  float a = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a += xp[(long long)r * ld];  // fixed order
+  mu[v * C + c] = a * 0.0625f;
+}
+// xs [R][C] bf16 = hi(x - mu), nl / nu [R] as derived at the top.  One thread per 4 elements, the C / 4 threads of a row
+// sum the centred norm with xor-shuffles (fixed tree).  grid = ceil(Rmax * C / 4 / 256).
+template <int C>
+__global__ __launch_bounds__(256) void knn_split1_kernel(const float* __restrict__ x, int ld, const float* __restrict__ norm,
+                                                         const float* __restrict__ mu, int N, unsigned short* __restrict__ xs,
+                                                         float* __restrict__ nl, float* __restrict__ nu,
+                                                         const int* __restrict__ hdr) {
+  constexpr int TPR = C / 4;  // threads per row (16 or 32: a row never straddles a wave)
+  const long long R = hdr[1];
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long r = t / TPR, rc = r < R ? r : R - 1;  // (threads past the last row shadow it: the shuffles below need them)
+  const int c4 = (int)(t % TPR);
+  const float4 v = *reinterpret_cast<const float4*>(x + rc * ld + 4 * c4);
+  const float4 m4 = *reinterpret_cast<const float4*>(mu + (rc / N) * C + 4 * c4);
+  const float y[4] = {v.x - m4.x, v.y - m4.y, v.z - m4.z, v.w - m4.w};
+  kf_bf16x4 hi;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) hi[u] = (__bf16)y[u];
+  float m = (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+#pragma unroll
+  for (int off = 1; off < TPR; off <<= 1) m += __shfl_xor(m, off, 64);
+  if (r >= R) return;
+  *reinterpret_cast<kf_bf16x4*>(xs + r * C + 4 * c4) = hi;
+  if (c4 == 0) {
+    const float n = norm[r], kg = KnnFast<C>::kappa_g, kr = KnnFast<C>::kappa_raw;
+    nl[r] = next_float(next_float(__builtin_fmaf(m, kg, m)) + next_float(kr * n));
+    nu[r] = prev_float(prev_float(__builtin_fmaf(m, -kg, m)) - next_float(kr * n));
+  }
+}
+
 // ---- shared Gram-tile machinery of the bound / collect kernels ------------------------------------------------------------
 // Block = WAVES waves handling 256 queries; a wave owns SETS sets of 32 queries (B operands hi / lo, register-resident:
 // SETS * C / 2 VGPRs); candidate tiles of 32 rows (hi | lo, 4C bytes per row) go through a double-buffered LDS panel
@@ -89,7 +159,8 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float* __restrict_
 // acc_row(r, h).  (C = 128 with two sets per wave needs more than 256 registers: it runs 8 waves x 1 set.)
 template <int C>
 struct KfTile {
-  static constexpr int ROWB = 4 * C + 16;          // LDS row stride in bytes (odd multiple of 16: conflict-free b128 reads)
+  static constexpr int XW = kKfProducts == 1 ? C : 2 * C;  // bf16 words per row of xs: hi, or hi | lo
+  static constexpr int ROWB = 2 * XW + 16;         // LDS row stride in bytes (odd multiple of 16: conflict-free b128 reads)
   static constexpr int KS = C / 16;                // MFMA k-steps
 };
 
@@ -124,10 +195,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void knn_gram_kerne
     unsigned char* __restrict__ scnt, const int* __restrict__ hdr) {
   using TL = KfTile<C>;
   static_assert(SETS * WAVES * 32 == kKfQB, "a block handles 256 queries");
-  constexpr int KS = TL::KS, ROWB = TL::ROWB, NT = 64 * WAVES;
-  constexpr int CPR = 4 * C / 16;            // 16-byte chunks per row
-  constexpr int CH = 32 * CPR / NT;          // chunks per thread and tile
-  static_assert(CH >= 1 && 32 * CPR % NT == 0, "staging layout");
+  constexpr int KS = TL::KS, ROWB = TL::ROWB, NT = 64 * WAVES, XW = TL::XW;
+  constexpr int CPR = 2 * XW / 16;           // 16-byte chunks per row
+  constexpr int NCH = 32 * CPR;              // chunks per tile
+  constexpr int CH = (NCH + NT - 1) / NT;    // chunks per thread and tile (the last round may be partial: NCH < NT at C = 64, one product)
+  static_assert(NCH % NT == 0 || NCH < NT, "staging layout");
+  const bool stager = NCH >= NT || (int)threadIdx.x < NCH;
   __shared__ __attribute__((aligned(16))) unsigned char tile[2][32 * ROWB];
   __shared__ __attribute__((aligned(16))) float tn[2][32];
   __shared__ unsigned short lst[COLLECT ? WAVES * SETS * kKfCap * 64 : 1];
@@ -135,20 +208,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void knn_gram_kerne
   knn_block(v, qb);
   if (v >= hdr[0]) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const unsigned short* xp = xs + (long long)v * N * (2 * C);
+  const unsigned short* xp = xs + (long long)v * N * XW;
   const float* np_ = nsc + (long long)v * N;   // the scaled candidate norms this pass uses (nl: bound, nu: collect)
   const int q0 = qb * kKfQB + wave * (32 * SETS);
   // query operands: hi / lo fragments of the k-steps
-  kf_bf16x8 bh[SETS][KS], bl[SETS][KS];
+  kf_bf16x8 bh[SETS][KS], bl[SETS][kKfProducts == 3 ? KS : 1];
   float thr[SETS];
 #pragma unroll
   for (int s = 0; s < SETS; ++s) {
     const int qrow = q0 + 32 * s + j < N ? q0 + 32 * s + j : N - 1;
-    const unsigned short* src = xp + (long long)qrow * (2 * C) + 8 * h;
+    const unsigned short* src = xp + (long long)qrow * XW + 8 * h;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       bh[s][kk] = *reinterpret_cast<const kf_bf16x8*>(src + 16 * kk);
-      bl[s][kk] = *reinterpret_cast<const kf_bf16x8*>(src + C + 16 * kk);
+      if constexpr (kKfProducts == 3) bl[s][kk] = *reinterpret_cast<const kf_bf16x8*>(src + C + 16 * kk);
     }
     // (a threshold of -inf would let the -inf scores of the rows past N through: clamp)
     thr[s] = COLLECT ? __builtin_fmaxf(theta[(long long)v * N + qrow], -3.0e38f) : 0.0f;
@@ -165,16 +238,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void knn_gram_kerne
   unsigned short* mylst = lst + (COLLECT ? wave * SETS * kKfCap * 64 : 0);
   // staged chunks as named registers (an indexed uint4 array ends up in scratch memory and every load is waited for at once)
   static_assert(CH == 1 || CH == 2 || CH == 4, "staging layout");
-  uint4 raw0, raw1 = {}, raw2 = {}, raw3 = {};
+  uint4 raw0 = {}, raw1 = {}, raw2 = {}, raw3 = {};
   float rn = 0.0f;
   // rows past N: any valid row (unconditional loads: a select makes the compiler wait for the load right away); their
   // scaled norm is +inf: lower = -inf (bound pass), upper = -inf (collect pass): never selected
 #define KF_SRC(t, i) \
-  (xp + (long long)((t) * 32 + (threadIdx.x + NT * (i)) / CPR < N ? (t) * 32 + (threadIdx.x + NT * (i)) / CPR : N - 1) * (2 * C) + \
+  (xp + (long long)((t) * 32 + (threadIdx.x + NT * (i)) / CPR < N ? (t) * 32 + (threadIdx.x + NT * (i)) / CPR : N - 1) * XW + \
    8 * ((threadIdx.x + NT * (i)) % CPR))
 #define KF_FETCH(t)                                                                   \
   do {                                                                                \
-    raw0 = *reinterpret_cast<const uint4*>(KF_SRC(t, 0));                             \
+    if (stager) raw0 = *reinterpret_cast<const uint4*>(KF_SRC(t, 0));                 \
     if constexpr (CH > 1) raw1 = *reinterpret_cast<const uint4*>(KF_SRC(t, 1));       \
     if constexpr (CH > 2) {                                                           \
       raw2 = *reinterpret_cast<const uint4*>(KF_SRC(t, 2));                           \
@@ -189,7 +262,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void knn_gram_kerne
 #define KF_DST(buf, i) (&tile[buf][((threadIdx.x + NT * (i)) / CPR) * ROWB + 16 * ((threadIdx.x + NT * (i)) % CPR)])
 #define KF_STASH(buf)                                                                 \
   do {                                                                                \
-    *reinterpret_cast<uint4*>(KF_DST(buf, 0)) = raw0;                                 \
+    if (stager) *reinterpret_cast<uint4*>(KF_DST(buf, 0)) = raw0;                     \
     if constexpr (CH > 1) *reinterpret_cast<uint4*>(KF_DST(buf, 1)) = raw1;           \
     if constexpr (CH > 2) {                                                           \
       *reinterpret_cast<uint4*>(KF_DST(buf, 2)) = raw2;                               \
@@ -213,13 +286,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void knn_gram_kerne
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const kf_bf16x8 ah = *reinterpret_cast<const kf_bf16x8*>(arow + 32 * kk);
-      const kf_bf16x8 al = *reinterpret_cast<const kf_bf16x8*>(arow + 2 * C + 32 * kk);
 #pragma unroll
       for (int s = 0; s < SETS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s][kk], acc[s], 0, 0, 0);
+      if constexpr (kKfProducts == 3) {
+        const kf_bf16x8 al = *reinterpret_cast<const kf_bf16x8*>(arow + 2 * C + 32 * kk);
 #pragma unroll
-      for (int s = 0; s < SETS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s][kk], acc[s], 0, 0, 0);
+        for (int s = 0; s < SETS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s][kk], acc[s], 0, 0, 0);
 #pragma unroll
-      for (int s = 0; s < SETS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s][kk], acc[s], 0, 0, 0);
+        for (int s = 0; s < SETS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s][kk], acc[s], 0, 0, 0);
+      }
     }
     if constexpr ((MODE & 1) != 0) {
 #pragma unroll
@@ -323,7 +398,8 @@ template <int C, typename IdxT>
 __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict__ x, int ld, const float* __restrict__ norm,
                                                          int N, const unsigned short* __restrict__ surv,
                                                          const unsigned char* __restrict__ scnt, IdxT* __restrict__ idx,
-                                                         const int* __restrict__ hdr) {
+                                                         const int* __restrict__ hdr, const float* __restrict__ theta,
+                                                         const float* __restrict__ nu) {
   constexpr int KH = C / 2, MAXS = 2 * kKfCap, SL = KH / 16;  // slices of 16 + 16 chain positions
   __shared__ __attribute__((aligned(16))) float qrow[kRrQ][C + 4];
   __shared__ float qnorm[kRrQ];
@@ -465,15 +541,46 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
       if (ql == 0) skey[cj] = kf_ordered((-np_[cj] + 2.0f * acc) - qnorm[q]);
     }
     __syncthreads();
-    for (int cj = quad; cj < N; cj += 64) {
-      const unsigned ms = skey[cj];
-      int rank = 0;
-      for (int m = ql; m < N; m += 4) {
-        const unsigned os = skey[m];
-        rank += (os > ms || (os == ms && m < cj)) ? 1 : 0;
+    // Ranking all N against all N is N^2 / 4 compares per quad — 40 us a query, and the one-product passes overflow a few
+    // hundred lists per launch.  The bound pass left a valid lower bound of this query's 20th best PINNED score
+    // (tau = kth - NL_i = theta - NU_i): only candidates at or above it can be among the 20, and they are few.
+    __shared__ int ocnt;
+    unsigned* olist = pq;  // (the pair table is done with)
+    constexpr int kOvCap = kRrQ * MAXS;
+    const long long rowq = (long long)v * N + (qbase + q < N ? qbase + q : N - 1);
+    const unsigned tkey = kf_ordered(prev_float(theta[rowq] - nu[rowq]));
+    if (threadIdx.x == 0) ocnt = 0;
+    __syncthreads();
+    for (int cj = threadIdx.x; cj < N; cj += 256) {
+      if (skey[cj] >= tkey) {
+        const int pos = atomicAdd(&ocnt, 1);  // (list order is free: ranks go by (score, index))
+        if (pos < kOvCap) olist[pos] = (unsigned)cj;
       }
-      rank = kf_quad_sum(rank);
-      if (ql == 0 && rank < kNbr) idx[((long long)v * N + qbase + q) * kNbr + rank] = (IdxT)cj;
+    }
+    __syncthreads();
+    const int L = ocnt;
+    if (L <= kOvCap) {
+      for (int e = quad; e < L; e += 64) {
+        const unsigned cj = olist[e], ms = skey[cj];
+        int rank = 0;
+        for (int m = ql; m < L; m += 4) {
+          const unsigned oj = olist[m], os = skey[oj];
+          rank += (os > ms || (os == ms && oj < cj)) ? 1 : 0;
+        }
+        rank = kf_quad_sum(rank);
+        if (ql == 0 && rank < kNbr) idx[((long long)v * N + qbase + q) * kNbr + rank] = (IdxT)cj;
+      }
+    } else {  // (mass ties beyond the list: every candidate against every candidate)
+      for (int cj = quad; cj < N; cj += 64) {
+        const unsigned ms = skey[cj];
+        int rank = 0;
+        for (int m = ql; m < N; m += 4) {
+          const unsigned os = skey[m];
+          rank += (os > ms || (os == ms && m < cj)) ? 1 : 0;
+        }
+        rank = kf_quad_sum(rank);
+        if (ql == 0 && rank < kNbr) idx[((long long)v * N + qbase + q) * kNbr + rank] = (IdxT)cj;
+      }
     }
   }
 }

@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(AT) void dg_agg_bwd_kernel(const float* __restrict_
 // scratch of the shortlist kNN search (dg_knn_fast.h) for clouds of N points, R rows in total, width <= 128
 struct KnnWs {
   unsigned short *xs, *surv;
-  float *nl, *nu, *theta;
+  float *nl, *nu, *theta, *mu;
   unsigned char* scnt;
 };
 
@@ -1101,6 +1101,7 @@ KnnWs knn_carve(Take&& take, int64_t M, int64_t N) {
   k.nu = reinterpret_cast<float*>(take(4 * R));
   k.theta = reinterpret_cast<float*>(take(4 * R));
   k.scnt = reinterpret_cast<unsigned char*>(take(2 * R));
+  k.mu = reinterpret_cast<float*>(take(4 * M * 128));  // one-product form: the clouds' centres
   return k;
 }
 
@@ -1115,18 +1116,24 @@ void knn_wide(const float* x, int ld, float* norm, const KnnWs& k, int64_t M, in
   constexpr int SETS = 1, WAVES = 8;
   const dim3 ggram((unsigned)((N + kKfQB - 1) / kKfQB), DG_KNN_GRID_Y(M));
   // (round 5: one fused pass — norm chain + split from the same staged float4 — was built and measured 0.03-0.05 ms SLOWER
-  // per C = 128 search on one box, three alternations: its hi / lo stores are 32-byte segments per row and slab, where this
-  // split kernel writes full lines; LABBOOK 5.2)
+  // per C = 128 search on one box, three alternations: its hi / lo stores are 32-byte segments per row and slab, where the
+  // split kernels write full lines; LABBOOK 5.2)
   hipLaunchKernelGGL(rownorm_kernel<C>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, x, ld, norm, hdr);
-  hipLaunchKernelGGL(knn_split_kernel<C>, dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, x, ld,
-                     (const float*)norm, k.xs, k.nl, k.nu, hdr);
+  if constexpr (kKfProducts == 1) {
+    hipLaunchKernelGGL(knn_centre_kernel<C>, dim3((unsigned)M), dim3(C), 0, s, x, ld, (int)N, k.mu, hdr);
+    hipLaunchKernelGGL(knn_split1_kernel<C>, dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, x, ld,
+                       (const float*)norm, (const float*)k.mu, (int)N, k.xs, k.nl, k.nu, hdr);
+  } else {
+    hipLaunchKernelGGL(knn_split_kernel<C>, dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, x, ld,
+                       (const float*)norm, k.xs, k.nl, k.nu, hdr);
+  }
   hipLaunchKernelGGL((knn_gram_kernel<C, false, SETS, WAVES>), ggram, dim3(64 * WAVES), 0, s, (const unsigned short*)k.xs,
                      (const float*)k.nl, (const float*)k.nl, (const float*)k.nu, (int)N, k.theta, k.surv, k.scnt, hdr);
   hipLaunchKernelGGL((knn_gram_kernel<C, true, SETS, WAVES>), ggram, dim3(64 * WAVES), 0, s, (const unsigned short*)k.xs,
                      (const float*)k.nu, (const float*)k.nl, (const float*)k.nu, (int)N, k.theta, k.surv, k.scnt, hdr);
   hipLaunchKernelGGL((knn_rerank_kernel<C, IdxT>), dim3((unsigned)((N + kRrQ - 1) / kRrQ), DG_KNN_GRID_Y(M)), dim3(256), 0,
                      s, x, ld, (const float*)norm, (int)N, (const unsigned short*)k.surv, (const unsigned char*)k.scnt, idx,
-                     hdr);
+                     hdr, (const float*)k.theta, (const float*)k.nu);
 #ifdef MPA_KNN_STATS  // instrumentation build (tools/build_variant.sh ... -DMPA_KNN_STATS=1): survivor statistics of this search
   {
     hipStreamSynchronize(s);
