@@ -52,7 +52,7 @@ bad = []
 edge = []  # cases at which the float64 oracle itself is discontinuous (a 2e-6 .. 2e-5 relative input change moves its gradients by > 1e-3)
 
 
-def raw_loss(batch, qp, tp, mode):
+def raw_loss(batch, qp, tp, mode, all_four=False):
     os.environ["MPA_SHAPE_SEARCH"] = mode
     pcs, v = batch["part_pcs"], batch["part_valids"]
     qg, tg = Rotation3D(batch["part_quat"]).rot.contiguous(), batch["part_trans"].contiguous()
@@ -68,13 +68,15 @@ def raw_loss(batch, qp, tp, mode):
                                            _lib.current_stream(dev)), "fwd")
     torch.cuda.synchronize()
     pn = B * P * N
+    if all_four:  # per-part arg-mins (both directions) too
+        return losses, [iws[k * pn:(k + 1) * pn].view(B, P, N).clone() for k in range(4)]
     return losses, iws[2 * pn:3 * pn].view(B, P, N).clone(), iws[3 * pn:4 * pn].view(B, P, N).clone()
 
 
 def case_loss(rng):
     B = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 33]))
     P = int(rng.integers(1, 21))
-    N = int(rng.choice([16, 33, 64, 100, 255, 256, 500, 777, 1000, 1200]))
+    N = int(rng.choice([1, 16, 33, 64, 100, 255, 256, 500, 777, 1000, 1200, 2048, 2100]))  # (> 2048: leaf -> grid fallback)
     counts = [int(rng.integers(1, P + 1)) for _ in range(B)]
     batch = synthetic.make_batch(B, P, N, seed=int(rng.integers(1 << 30)), device=dev, num_parts=counts,
                                  preset=str(rng.choice(["everyday", "artifact"])))
@@ -91,14 +93,23 @@ def case_loss(rng):
     tp = (torch.randn(B, P, 3, generator=g) * spread).to(dev)
     if rng.random() < 0.15:  # duplicated points: exact ties
         batch["part_pcs"][:, :, 1::2] = batch["part_pcs"][:, :, 0::2][:, :, : batch["part_pcs"][:, :, 1::2].shape[2]]
-    lb, b1, b2 = raw_loss(batch, qp, tp, "brute")
-    lg, g1, g2 = raw_loss(batch, qp, tp, "grid")
+    regime = "random"
+    if rng.random() < 0.35:  # predictions close to (or exactly at) the ground truth: the twin-point seed / the matrix-core
+        eps = float(rng.choice([0.0, 1e-6, 1e-3, 0.02]))  # gate of the leaf search at near-coincident clouds
+        qg = Rotation3D(batch["part_quat"]).rot
+        qp = torch.nn.functional.normalize(qg + eps * torch.randn(B, P, 4, generator=g).to(dev), dim=-1).contiguous()
+        tp = (batch["part_trans"] + eps * torch.randn(B, P, 3, generator=g).to(dev)).contiguous()
+        regime = f"near-gt eps={eps}"
+    lb, ib = raw_loss(batch, qp, tp, "brute", all_four=True)
     valid = batch["part_valids"].bool()
-    ok = torch.equal(b1[valid], g1[valid]) and torch.equal(b2[valid], g2[valid])
     fin = torch.isfinite(lb)
-    ok = ok and bool(torch.equal(fin, torch.isfinite(lg)))
-    ok = ok and bool(((lg[fin] - lb[fin]).abs() <= 2e-6 * lb[fin].abs() + 1e-9).all())
-    return ok, f"B={B} P={P} N={N} spread={spread}"
+    ok = True
+    for mode in ("grid", "leaf", "auto"):  # the grid of rounds 1-4, the k-d leaves (round 5), the per-sample route
+        lm, im = raw_loss(batch, qp, tp, mode, all_four=True)
+        ok = ok and all(torch.equal(ib[k][valid], im[k][valid]) for k in range(4))
+        ok = ok and bool(torch.equal(fin, torch.isfinite(lm)))
+        ok = ok and bool(((lm[fin] - lb[fin]).abs() <= 2e-6 * lb[fin].abs() + 1e-9).all())
+    return ok, f"B={B} P={P} N={N} spread={spread} {regime}"
 
 
 def case_chamfer(rng):
