@@ -582,13 +582,14 @@ def main():
                     "frac": alg / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": k["avg_ms"], "launches": k["launches"], "algorithmic_bytes_per_launch": alg,
                     "binding": {"bound": "mfma_bf16" if C >= 64 else "valu",
-                                "note": "exact top-20 as a shortlist search (csrc/dg_knn_fast.h): two passes of 3-product "
-                                        "split-bf16 Gram tiles (bound + collect: 12 C FLOP per pair) on the bf16 matrix "
-                                        "cores, then the pinned fp32 chain for ~21 survivors per query; HBM is not what "
-                                        "binds it (SURVEY.md §7 hard part 1)" if C >= 64 else
+                                "note": "exact top-20 as a shortlist search (csrc/dg_knn_fast.h): two passes (bound + "
+                                        "collect) of ONE-product bf16 Gram tiles over the centred rows (4 C FLOP per pair) "
+                                        "on the bf16 matrix cores, then the pinned fp32 chain for the survivors (~25 per "
+                                        "query); the survivors' row gathers through the L2 and the tiles' staging bind "
+                                        "it, neither HBM nor the MFMA rate does (SURVEY.md §7 hard part 1)" if C >= 64 else
                                         "exhaustive exact top-20 on the VALU (12 lane-slots per pair)",
-                                "gram_flops_per_launch": pairs * 12.0 * C if C >= 64 else None,
-                                "frac": (pairs * 12.0 * C / secs / MFMA_BF16_PEAK) if C >= 64 else
+                                "gram_flops_per_launch": pairs * 4.0 * C if C >= 64 else None,
+                                "frac": (pairs * 4.0 * C / secs / MFMA_BF16_PEAK) if C >= 64 else
                                         (pairs * 12.0 / secs / VALU_PEAK_LANE_OPS),
                                 "frac_of_fp32_mfma_if_exhaustive": (pairs * (2 * C + 1) / secs / MFMA_F32_PEAK)
                                 if C >= 64 else None},
@@ -612,19 +613,30 @@ def main():
                     if (args.config in ("c2", "c4") and rec.get("clouds_per_launch") is not None
                             and abs(rec["clouds_per_launch"] - valid_parts) < 0.5):
                         traffic, traffic_src = rec["traffic_bytes_per_launch"], f"profiles/{pmc[-1].name}: {rec['correction']}"
+                from multi_part_assembly_amd.loss import search_mode, SEARCH_MODES
+                mode = {v: k for k, v in SEARCH_MODES.items()}[search_mode(cfg.loss.get("shape_search", None))]
+                kname = {"grid": "mpa::grid_search_kernel (exact grid-pruned whole-shape Chamfer search of the fused loss, both "
+                                 "directions; cfg.loss.shape_search / MPA_SHAPE_SEARCH = leaf | auto: mpa::leaf_search_kernel)",
+                         "leaf": "mpa::leaf_search_kernel<true> + leaf_search_heavy_kernel<true> (exact whole-shape Chamfer "
+                                 "search of the fused loss over the parts' k-d leaves, both directions)",
+                         "auto": "mpa::leaf_search_kernel<true> + leaf_search_heavy_kernel<true> + grid_search_kernel (exact "
+                                 "whole-shape Chamfer search of the fused loss, routed per sample)",
+                         "brute": "assembly_nn_kernel<SHAPE> (exhaustive whole-shape Chamfer scan of the fused loss)"}[mode]
+                bnote = {"grid": "exact pruned search: dependent latency and VALU issue of short candidate lists bind it "
+                                 "(SQ counters: ~40 % of wave cycles waiting, ~40 % issuing), neither HBM nor the MFMA rate "
+                                 "does (DESIGN.md §4); an exhaustive scan of the same points would be VALU-bound",
+                         "brute": "exhaustive scan: VALU-bound"}.get(mode,
+                         "exact pruned search: VALU issue slots of the leaf selection, the per-lane box tests and the "
+                         "reduction of the matrix cores' 32 x 64 gate tiles bind it, neither HBM nor the MFMA rate does "
+                         "(DESIGN.md §4); an exhaustive scan of the same points would be VALU-bound")
                 roofline = {
-                    "kernel": "mpa::leaf_search_kernel<true> + leaf_search_heavy_kernel<true> (exact whole-shape Chamfer "
-                              "search of the fused loss over the parts' k-d leaves, both directions; MPA_SHAPE_SEARCH=grid: "
-                              "mpa::grid_search_kernel)",
+                    "kernel": kname, "shape_search": mode,
                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
                     "algorithmic_bytes_per_launch": alg_bytes,
-                    "binding": {"bound": "valu-issue",
-                                "note": "exact pruned search: VALU issue slots of the leaf selection, the per-lane box "
-                                        "tests and the reduction of the matrix cores' 32 x 64 gate tiles bind it, "
-                                        "neither HBM nor the MFMA rate does (DESIGN.md §4); an exhaustive scan of the "
-                                        "same points would be VALU-bound",
+                    "binding": {"bound": "latency / valu-issue" if mode == "grid" else "valu-issue",
+                                "note": bnote,
                                 "equivalent_brute_force_pair_evals_per_s": brute_pairs / secs,
                                 "valu_frac_if_brute_force": 8.6 * brute_pairs / secs / VALU_PEAK_LANE_OPS},
                     "oracle_note": "quaternion algebra of the loss restated from pytorch3d (un-vendored): parity "

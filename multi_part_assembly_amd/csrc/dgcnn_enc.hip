@@ -865,118 +865,275 @@ __global__ __launch_bounds__(1024) void dg_bwd_head_kernel(const DgRevArgs ra, i
   }
 }
 
-// d(uv) [R][2CO] in ONE pass over the transposed graph.  grid = (CO / 16, M), block 512.  LDS panels of a 16-channel
-// slice of the part: V, W = alpha * dz and the selected slots (rows 0..N-1, row N = neutral: zeros / slot 255), the
-// in-edge offsets, and per wave a scratch run of in-edge entries.  Lane = (point of 16, channel quad): for every
-// in-edge (source i, slot t) of its point j it adds V_i to the neighbour sum and W_i[c] to the selected-edge sum of the
-// channels whose selected slot at i is t — i.e. whose selected neighbour is j.  No atomics, no second pass:
-//   dU_j = gammap (deg_j U_j + sum V_i) + deg_j betap + sum_sel W_i,   dV_j = W_j + gammap (S1_j + k V_j) + k betap
-// with every sum taken in ascending source order (bit-reproducible).
+// d(uv) [R][2CO]:  dU_j = gammap (deg_j U_j + sum V_i) + deg_j betap + sum_sel W_i,   dV_j = W_j + gammap (S1_j + k V_j) + k betap
+// with W = alpha * dz, `sum V_i` over the in-edges (i -> j) of point j and `sum_sel W_i[c]` over the sources whose
+// SELECTED neighbour at channel c is j.  grid = (CO / 16, M), block 1024, one 16-channel slice of one part.
+//   Phase A, from the source side: every (source, channel) has exactly one selected neighbour, so the selected-edge sum
+//   is N x 16 contributions per block — a twentieth of the (in-edge, channel) tests the transposed-graph walk of rounds
+//   2-4 spent on it.  They are scattered with LDS atomics on 64-bit FIXED-POINT words (integer addition commutes: the
+//   result does not depend on the order the atomics land in, so the pass stays bit-reproducible; no float atomics).  The
+//   scale is a power of two per channel, 2^40 / (the next power of two above the part's largest |W|): every addend is
+//   exact to 2^-40 of the channel's largest value (truncated there), the sum is rounded to fp32 once.  A non-finite W turns the channel's
+//   sums of the part into NaN (the float chain would have propagated it to some rows).
+//   Phase B, over the transposed graph: lane = (point of 16, channel quad) adds V_i of its point's in-edges in ascending
+//   source order (one 16-byte LDS read and four additions per in-edge), then writes both gradients.
 #ifdef MPA_AGG_STATS  // instrumented build for tools/probe_agg_stats.py only (never in libmpa_hip.so)
-__device__ unsigned long long g_agg_stats[8];  // blocks, ticks: panel load, passes (sum over waves / waves), total; wave passes, loop iterations
+constexpr int kAggRec = 1 << 16;
+__device__ unsigned long long g_agg_rec[kAggRec][8];  // one record per block (plain stores: shared counters would congest the memory system and distort what they measure)
+__device__ unsigned long long g_agg_stats[8];  // blocks, ticks: phase A, passes (sum over waves), total; wave passes, loop iterations; ticks to phase A's first / second barrier
 #define AGG_TICK() __builtin_readcyclecounter()
 #else
 #define AGG_TICK() 0ull
 #endif
-constexpr int kBS = 16;          // channels per slice
-constexpr int kRun = 512;        // scratch entries per wave (16 points x ~20 in-edges, with room for hubs)
-// LDS of a block of AT threads for parts of N points (dynamic: the 16-wave variant needs all 160 KB at N = 1000)
-constexpr size_t agg_bwd_lds(int AT, int N) {
-  return (size_t)(N + 1) * kBS * (2 * sizeof(float) + 1) + (size_t)(AT / 64) * kRun * 2 + (size_t)(N + 2) * 2;
+#ifndef MPA_AGG_BWD_UNROLL
+#define MPA_AGG_BWD_UNROLL 4  // in-edges per trip of the walk: their scratch reads, then their panel reads, go out together
+#endif
+#ifndef MPA_AGG_BS
+#define MPA_AGG_BS 16
+#endif
+constexpr int kBS = MPA_AGG_BS;   // channels per slice (16 | 8)
+constexpr int kCQ = kBS / 4;      // lanes per point (a lane owns four channels)
+constexpr int kPts = 64 / kCQ;    // points per wave pass
+constexpr int kRun = kBS == 16 ? 512 : 768;  // scratch entries per wave (a pass's points x ~20 in-edges, with room; hubs overflow to global reads)
+constexpr int kAggT = 64 * kBS;   // threads: N * kCQ <= 4 * kAggT elements in phase A
+// dynamic LDS for parts of N points: phase A's accumulators [N][16] u64; phase B's panels Sd | V [(N + 1)][16] float, a
+// scratch run per wave and the in-edge offsets
+constexpr size_t agg_bwd_lds(int N) {
+  const size_t a = (size_t)N * kBS * 8;
+  const size_t b = (size_t)(N + 1) * kBS * 2 * sizeof(float) + (size_t)(kAggT / 64) * kRun * 2 + (size_t)(2 * N + 2) * 2;
+  return a > b ? a : b;
 }
-// AT = 1024 (16 waves, four per SIMD: the loop is two dependent LDS round trips per four in-edges, and 59 % of the wave
-// cycles of the 8-wave variant were waits) whenever its panels fit; AT = 512 otherwise.
-template <int AT>
-__global__ __launch_bounds__(AT) void dg_agg_bwd_kernel(const float* __restrict__ uv, int CO,
-                                                        const int* __restrict__ rptr, const int* __restrict__ order,
-                                                        const unsigned short* __restrict__ rlist,
-                                                        const float* __restrict__ dz,
-                                                        const unsigned char* __restrict__ ssel,
-                                                        const float* __restrict__ s1in, const float* __restrict__ coef,
-                                                        int N, float* __restrict__ guv, const int* __restrict__ hdr) {
+// Block barrier for exchanges through LDS only: waits for the wave's LDS traffic, NOT for its global loads in flight
+// (__syncthreads() drains vmcnt too, which would stall every prefetch of the kernel below at the next barrier).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__global__ __launch_bounds__(kAggT) void dg_agg_bwd_kernel(const float* __restrict__ uv, int CO,
+                                                           const int* __restrict__ rptr, const int* __restrict__ order,
+                                                           const unsigned short* __restrict__ rlist,
+                                                           const unsigned short* __restrict__ idx,
+                                                           const float* __restrict__ dz,
+                                                           const unsigned char* __restrict__ ssel,
+                                                           const float* __restrict__ s1in, const float* __restrict__ coef,
+                                                           int M, int N, float* __restrict__ guv,
+                                                           const int* __restrict__ hdr) {
+  constexpr int AT = kAggT;
   extern __shared__ __attribute__((aligned(16))) unsigned char agg_lds[];
   __shared__ int pass_ctr;
-  float* Vp = reinterpret_cast<float*>(agg_lds);                                   // [(N + 1)][kBS]
-  float* Wp = Vp + (N + 1) * kBS;                                                  // [(N + 1)][kBS]
-  unsigned char* Sp = reinterpret_cast<unsigned char*>(Wp + (N + 1) * kBS);       // [(N + 1)][kBS]
-  unsigned short* scr_all = reinterpret_cast<unsigned short*>(Sp + (N + 1) * kBS);  // [AT / 64][kRun]
+  __shared__ __attribute__((aligned(16))) unsigned amax_s[AT / 64][kBS];
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(agg_lds);         // phase A: [N][kBS]
+  float* Sd = reinterpret_cast<float*>(agg_lds);                                   // phase B: [(N + 1)][kBS]
+  float* Vp = Sd + (N + 1) * kBS;                                                  // [(N + 1)][kBS]
+  unsigned short* scr_all = reinterpret_cast<unsigned short*>(Vp + (N + 1) * kBS);  // [AT / 64][kRun]
   unsigned short* rps = scr_all + (AT / 64) * kRun;                                // [N + 2]: offsets < 20 N <= 20480
+  unsigned short* ordl = rps + (N + 2);                                            // [N]: the point of every degree rank
   // the 16-channel slices of one part run on ONE XCD (dg::knn_block): a slice's rows are 64-byte halves (V, dz) and
-  // 16-byte eighths (selected slots) of cache lines whose other parts the neighbouring slices read — spread over the
-  // eight L2s, every line was fetched from HBM once per slice (1.8 GB per launch measured against 0.77 GB of operands)
+  // 16-byte eighths (selected slots) of cache lines whose other parts the neighbouring slices read
+  // Everything the block reads from global memory before its first pass is requested in TWO rounds, up front: with all
+  // 160 KB of LDS taken, a CU holds one block and nothing else hides a round trip (three in a row per phase cost a
+  // third of the kernel).  Round 1 goes out before the valid-part count arrives (a part slot behind it is allocated:
+  // the loads are harmless), round 2 (the selected neighbours, the first pass's lists and rows) as soon as round 1 is in.
   int v, sl;
   dg::knn_block(v, sl);
-  if (v >= hdr[0]) return;
+  const int nv = hdr[0];
+  const int vc = v < M ? v : M - 1;
   const unsigned long long tk0 = AGG_TICK();
-  const int c0 = sl * kBS;
-  const float* up = uv + (long long)v * N * 2 * CO;
-  float* gp = guv + (long long)v * N * 2 * CO;
-  const float* dzp = dz + (long long)v * N * CO;
-  const unsigned char* sp = ssel + (long long)v * N * CO;
-  // panels: four requests in flight per thread
-  for (int e0 = threadIdx.x; e0 < N * 4; e0 += 4 * AT) {
-    float4 tv[4], tw[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * AT, ec = e < N * 4 ? e : N * 4 - 1;
-      tv[u] = *reinterpret_cast<const float4*>(up + (long long)(ec >> 2) * 2 * CO + CO + c0 + 4 * (ec & 3));
-      tw[u] = *reinterpret_cast<const float4*>(dzp + (long long)(ec >> 2) * CO + c0 + 4 * (ec & 3));
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * AT;
-      if (e < N * 4) {
-        const float4 al = *reinterpret_cast<const float4*>(coef + c0 + 4 * (e & 3));
-        *reinterpret_cast<float4*>(&Vp[4 * e]) = tv[u];
-        *reinterpret_cast<float4*>(&Wp[4 * e]) = make_float4(al.x * tw[u].x, al.y * tw[u].y, al.z * tw[u].z, al.w * tw[u].w);
-      }
-    }
-  }
-  for (int r = threadIdx.x; r < N; r += AT)
-    *reinterpret_cast<uint4*>(&Sp[r * kBS]) = *reinterpret_cast<const uint4*>(sp + (long long)r * CO + c0);
-  if (threadIdx.x < kBS) {
-    Vp[N * kBS + threadIdx.x] = 0.0f;
-    Wp[N * kBS + threadIdx.x] = 0.0f;
-    Sp[N * kBS + threadIdx.x] = 255;
-  }
-  for (int e = threadIdx.x; e <= N; e += AT) rps[e] = (unsigned short)rptr[(long long)v * (N + 1) + e];
-  if (threadIdx.x == 0) pass_ctr = 0;
-  __syncthreads();
-  const unsigned long long tk1 = AGG_TICK();
   unsigned long long n_pass = 0, n_iter = 0;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cq = lane & 3, q = lane >> 2;
+  const int c0 = sl * kBS;
+  const float* up = uv + (long long)vc * N * 2 * CO;
+  float* gp = guv + (long long)vc * N * 2 * CO;
+  const float* dzp = dz + (long long)vc * N * CO;
+  const unsigned char* sp = ssel + (long long)vc * N * CO;
+  const unsigned short* ip = idx + (long long)vc * N * kNbr;
+  const int* rpg = rptr + (long long)vc * (N + 1);
+  const int* ord = order + (long long)vc * N;
+  const unsigned short* rl = rlist + (long long)vc * N * kNbr;
+  const float* s1p = s1in + (long long)vc * N * CO;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cq = lane % kCQ, q = lane / kCQ;
+  // ---- phase A.  Element e = (source e / kCQ, channel quad e % kCQ = cq); N <= 1024: at most four per thread.
+  // Loads return in issue order: the chain the scatter waits for (selected slots -> selected neighbours) goes first, what
+  // is needed later (V, the neighbour sums, the first pass's lists) behind it.
+  float4 tw[4];
+  unsigned ts[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = threadIdx.x + u * AT, ec = e < N * kCQ ? e : N * kCQ - 1;
+    ts[u] = *reinterpret_cast<const unsigned*>(sp + (long long)(ec / kCQ) * CO + c0 + 4 * cq);
+  }
+  // the first pass of every wave is fixed (pass = wave), the others are handed out by a counter: its lists and rows
+  const int r_first = kPts * wave;
+  const int base_f = rpg[r_first < N ? r_first : N];
+  int jn = ord[r_first + q < N ? r_first + q : N - 1];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = threadIdx.x + u * AT, ec = e < N * kCQ ? e : N * kCQ - 1;
+    tw[u] = *reinterpret_cast<const float4*>(dzp + (long long)(ec / kCQ) * CO + c0 + 4 * cq);
+  }
+  const float4 alpha = *reinterpret_cast<const float4*>(coef + c0 + 4 * cq);
   const float4 gammap = *reinterpret_cast<const float4*>(coef + CO + c0 + 4 * cq);
   const float4 betap = *reinterpret_cast<const float4*>(coef + 2 * CO + c0 + 4 * cq);
-  const unsigned short* rl = rlist + (long long)v * N * kNbr;
-  unsigned short* sc = scr_all + wave * kRun;
+  const int rp_a = rpg[threadIdx.x < N ? threadIdx.x : N];      // the in-edge offsets and the rank order, for the LDS tables
+  const int rp_b = threadIdx.x == 0 ? rpg[N] : 0;
+  const int or_a = ord[threadIdx.x < N ? threadIdx.x : N - 1];
+  if (v >= nv) return;
+  unsigned short tj[4][4];  // the selected neighbours
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = threadIdx.x + u * AT, ec = e < N * kCQ ? e : N * kCQ - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned slot = (ts[u] >> (8 * k)) & 0xffu;
+      tj[u][k] = ip[(ec / kCQ) * kNbr + (slot < (unsigned)kNbr ? slot : 0u)];
+    }
+  }
+  unsigned tjp[4][2];  // (two to a register)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    tjp[u][0] = (unsigned)tj[u][0] | ((unsigned)tj[u][1] << 16);
+    tjp[u][1] = (unsigned)tj[u][2] | ((unsigned)tj[u][3] << 16);
+  }
   const int last = N * kNbr - 1;
-  const unsigned short kNeutral = (unsigned short)(N * 32 + 31);
-  // the in-edge lists of a wave pass's 16 consecutive points are ONE contiguous run of rlist: requested a pass ahead
-  // with coalesced loads, copied to the wave's scratch, read from there by every lane
   unsigned short pre[kRun / 64];
-  float4 un, sn;
-  // A pass = 16 consecutive RANKS of the degree order (equally long lists); the passes are dealt to the waves round
-  // robin so that every wave gets long and short ones.
-  const int* ord = order + (long long)v * N;
-  int jn = 0;
+  float4 un;
+#pragma unroll
+  for (int u = 0; u < kRun / 64; ++u) pre[u] = rl[base_f + 64 * u + lane < last ? base_f + 64 * u + lane : last];
+  auto request_rows = [&]() { un = *reinterpret_cast<const float4*>(up + (long long)jn * 2 * CO + c0 + 4 * cq); };
+  request_rows();
+  auto load_v = [&](int u) {  // V of the same elements
+    const int e = threadIdx.x + u * AT, ec = e < N * kCQ ? e : N * kCQ - 1;
+    return *reinterpret_cast<const float4*>(up + (long long)(ec / kCQ) * 2 * CO + CO + c0 + 4 * cq);
+  };
+  const float4 tv0 = load_v(0), tv1 = load_v(1), tv2 = load_v(2), tv3 = load_v(3);
+  auto load_s1 = [&](int u) {  // the forward's neighbour sum of the same elements
+    const int e = threadIdx.x + u * AT, ec = e < N * kCQ ? e : N * kCQ - 1;
+    return *reinterpret_cast<const float4*>(s1p + (long long)(ec / kCQ) * CO + c0 + 4 * cq);
+  };
+  const float4 ts0 = load_s1(0), ts1 = load_s1(1), ts2 = load_s1(2), ts3 = load_s1(3);
+  for (int e = threadIdx.x; e < N * kBS / 2; e += AT) reinterpret_cast<uint4*>(acc)[e] = make_uint4(0u, 0u, 0u, 0u);
+  unsigned mx[4] = {0u, 0u, 0u, 0u};  // the bit pattern of |W| orders like its value, NaN above infinity
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    tw[u] = make_float4(alpha.x * tw[u].x, alpha.y * tw[u].y, alpha.z * tw[u].z, alpha.w * tw[u].w);
+    if (threadIdx.x + u * AT < N * kCQ) {
+      const unsigned b[4] = {__float_as_uint(tw[u].x) & 0x7fffffffu, __float_as_uint(tw[u].y) & 0x7fffffffu,
+                             __float_as_uint(tw[u].z) & 0x7fffffffu, __float_as_uint(tw[u].w) & 0x7fffffffu};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) mx[k] = b[k] > mx[k] ? b[k] : mx[k];
+    }
+  }
+  // dV needs nothing of the graph: written here, rows in storage order, from the operands phase A holds anyway
+  auto put_dv = [&](int u, const float4 w, const float4 vv, const float4 s4) {
+    const int e = threadIdx.x + u * AT;
+    if (e < N * kCQ) {
+      const float kf = (float)kNbr;
+      float4 dv;
+      dv.x = w.x + __builtin_fmaf(gammap.x, s4.x + kf * vv.x, kf * betap.x);
+      dv.y = w.y + __builtin_fmaf(gammap.y, s4.y + kf * vv.y, kf * betap.y);
+      dv.z = w.z + __builtin_fmaf(gammap.z, s4.z + kf * vv.z, kf * betap.z);
+      dv.w = w.w + __builtin_fmaf(gammap.w, s4.w + kf * vv.w, kf * betap.w);
+      *reinterpret_cast<float4*>(gp + (long long)(e / kCQ) * 2 * CO + CO + c0 + 4 * cq) = dv;
+    }
+  };
+#pragma unroll
+  for (int off = kCQ; off < 64; off <<= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned t = (unsigned)__shfl_xor((int)mx[k], off, 64);
+      mx[k] = t > mx[k] ? t : mx[k];
+    }
+  if (lane < kCQ) *reinterpret_cast<uint4*>(&amax_s[wave][4 * lane]) = make_uint4(mx[0], mx[1], mx[2], mx[3]);
+  lds_barrier();  // the accumulators are zero, the waves' maxima are in
+  const unsigned long long tka = AGG_TICK();
+  // |W| < 2^(ex - 126) for every W of the channel (ex: the biased exponent of the largest |W|, a denormal counts as 1):
+  // addend = W * 2^(166 - ex), truncated towards zero — integer arithmetic on the float's fields, |addend| < 2^40
+  int ex0, ex1, ex2, ex3;
+  {
+    uint4 m = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int w = 0; w < AT / 64; ++w) {
+      const uint4 t = *reinterpret_cast<const uint4*>(&amax_s[w][4 * cq]);
+      m.x = t.x > m.x ? t.x : m.x;
+      m.y = t.y > m.y ? t.y : m.y;
+      m.z = t.z > m.z ? t.z : m.z;
+      m.w = t.w > m.w ? t.w : m.w;
+    }
+    auto fix = [](unsigned mb) {
+      const int ex = (int)(mb >> 23);
+      return ex >= 255 ? 1 << 20 : (ex < 1 ? 1 : ex);  // a channel holding a NaN / infinity: every addend shifts out
+    };
+    ex0 = fix(m.x), ex1 = fix(m.y), ex2 = fix(m.z), ex3 = fix(m.w);
+  }
+  auto unfix = [](unsigned long long a, int ex) {  // the sum back in fp32 (one rounding); NaN for a poisoned channel
+    const double iv = __longlong_as_double((long long)(1023 - 166 + (ex > 255 ? 1 : ex)) << 52);
+    return (float)((double)(long long)a * iv) + (ex > 255 ? __builtin_nanf("") : 0.0f);
+  };
+  auto add = [&](int j, int k, float w, int exm) {
+    const unsigned bits = __float_as_uint(w);
+    const int e8 = (int)((bits >> 23) & 0xffu);
+    const unsigned mant = (bits & 0x7fffffu) | (e8 ? 0x800000u : 0u);
+    const int sh = (e8 ? e8 : 1) + 16 - exm;  // W = mant * 2^(e8 - 150);  <= 16
+    const int down = -sh < 31 ? -sh : 31;
+    const unsigned long long mag = sh >= 0 ? (unsigned long long)mant << sh : (unsigned long long)(mant >> down);
+    const long long x = (bits >> 31) ? -(long long)mag : (long long)mag;
+    __hip_atomic_fetch_add(&acc[j * kBS + 4 * cq + k], (unsigned long long)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (threadIdx.x + u * AT < N * kCQ) {
+      add((int)(tjp[u][0] & 0xffffu), 0, tw[u].x, ex0);
+      add((int)(tjp[u][0] >> 16), 1, tw[u].y, ex1);
+      add((int)(tjp[u][1] & 0xffffu), 2, tw[u].z, ex2);
+      add((int)(tjp[u][1] >> 16), 3, tw[u].w, ex3);
+    }
+  }
+  put_dv(0, tw[0], tv0, ts0), put_dv(1, tw[1], tv1, ts1), put_dv(2, tw[2], tv2, ts2), put_dv(3, tw[3], tv3, ts3);
+  lds_barrier();
+  const unsigned long long tkb = AGG_TICK();
+  auto read_sd = [&](int u) {
+    const int e = threadIdx.x + u * AT, ec = e < N * kCQ ? e : N * kCQ - 1;
+    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(&acc[ec * 4]);
+    const ulonglong2 a1 = *reinterpret_cast<const ulonglong2*>(&acc[ec * 4 + 2]);
+    return make_float4(unfix(a0.x, ex0), unfix(a0.y, ex1), unfix(a1.x, ex2), unfix(a1.y, ex3));
+  };
+  const float4 sd0 = read_sd(0), sd1 = read_sd(1), sd2 = read_sd(2), sd3 = read_sd(3);
+  lds_barrier();  // every accumulator has been read: the panels of phase B take their place
+  auto stash = [&](int u, const float4 sdv, const float4 tv) {
+    const int e = threadIdx.x + u * AT;
+    if (e < N * kCQ) {
+      *reinterpret_cast<float4*>(&Sd[4 * e]) = sdv;
+      *reinterpret_cast<float4*>(&Vp[4 * e]) = tv;
+    }
+  };
+  stash(0, sd0, tv0), stash(1, sd1, tv1), stash(2, sd2, tv2), stash(3, sd3, tv3);
+  if (threadIdx.x < kBS) Vp[N * kBS + threadIdx.x] = 0.0f;  // the neutral row (padding in-edges)
+  if (threadIdx.x < N) {
+    rps[threadIdx.x] = (unsigned short)rp_a;
+    ordl[threadIdx.x] = (unsigned short)or_a;
+  }
+  if (threadIdx.x == 0) {
+    rps[N] = (unsigned short)rp_b;
+    pass_ctr = AT / 64;
+  }
+  lds_barrier();
+  const unsigned long long tk1 = AGG_TICK();
+  // ---- phase B
+  unsigned short* sc = scr_all + wave * kRun;
+  const unsigned short kNeutral = (unsigned short)(N * 32 + 31);
+  // the in-edge lists of a wave pass's consecutive ranks are ONE contiguous run of rlist: requested a pass ahead with
+  // coalesced loads, copied to the wave's scratch, read from there by every lane.  A pass = kPts consecutive RANKS of the
+  // degree order (equally long lists), longest lists first.  The rank -> point table sits in LDS, so the rows of the next
+  // pass's points go out in the same round as its lists (through a global table they waited a round trip for it).
   auto request = [&](int r0) {  // r0: first rank of the pass (wave-uniform)
     const int base = rps[r0 < N ? r0 : N];
 #pragma unroll
     for (int u = 0; u < kRun / 64; ++u) pre[u] = rl[base + 64 * u + lane < last ? base + 64 * u + lane : last];
-    jn = ord[r0 + q < N ? r0 + q : N - 1];
-    un = *reinterpret_cast<const float4*>(up + (long long)jn * 2 * CO + c0 + 4 * cq);
-    sn = *reinterpret_cast<const float4*>(s1in + ((long long)v * N + jn) * CO + c0 + 4 * cq);
+    jn = ordl[r0 + q < N ? r0 + q : N - 1];
+    request_rows();
   };
-  // Passes are handed out by a counter in LDS, longest lists first (the ranks are in descending degree) instead of round
-  // robin: −2 % on the kernel.  (Splitting the two or three hub passes of a part — lists past the staged run, read from
-  // global memory inside the loop — into passes of 8 / 4 ranks was measured too: +4 %.)
   auto next_pass = [&]() {
     int t = 0;
     if (lane == 0) t = __hip_atomic_fetch_add(&pass_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return 16 * __builtin_amdgcn_readfirstlane(t);
+    return kPts * __builtin_amdgcn_readfirstlane(t);
   };
-  int j0 = next_pass();
-  request(j0);
+  int j0 = r_first;
   while (j0 < N) {
     const int j0n = next_pass();
     const int rk = j0 + q, j = jn;
@@ -984,59 +1141,47 @@ __global__ __launch_bounds__(AT) void dg_agg_bwd_kernel(const float* __restrict_
     const int b = rk < N ? rps[rk] : base, e = rk < N ? rps[rk + 1] : base;
 #pragma unroll
     for (int u = 0; u < kRun / 64; ++u) sc[64 * u + lane] = pre[u];
-    const float4 u4 = un, s4 = sn;
+    const float4 u4 = un;
     request(j0n);
     __builtin_amdgcn_wave_barrier();  // the scratch is private to the wave; LDS keeps a wave's accesses in order
     int kmax = e - b;
 #pragma unroll
-    for (int o = 4; o < 64; o <<= 1) {
+    for (int o = kCQ; o < 64; o <<= 1) {
       const int t = __shfl_xor(kmax, o, 64);
       kmax = t > kmax ? t : kmax;
     }
     kmax = __builtin_amdgcn_readfirstlane(kmax);
-    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f), sd = make_float4(0.f, 0.f, 0.f, 0.f);
-    // four in-edges per pass of the loop: their scratch reads, then their twelve panel reads, are issued together —
-    // one in-edge at a time is two dependent LDS round trips per pass with two waves per SIMD to hide them
+    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool hub = __any(e - base > kRun);  // a point whose in-edges reach past the staged run (rare)
-    // Two copies of the loop, chosen per pass: only the hub one loads entries from global memory.  With the load in
-    // the one loop, every iteration carried an `s_waitcnt vmcnt(0)` for it — which also waits for the NEXT pass's
-    // prefetch (request) issued just above, so the prefetch never overlapped the loop it was meant to hide behind.
+    // Two copies of the loop, chosen per pass: only the hub one loads entries from global memory (with the load in the
+    // one loop, every iteration waited for the NEXT pass's prefetch issued just above).
     auto scan = [&](auto with_hub) {
-      for (int k = 0; k < kmax; k += 4) {  // ascending sources: fixed summation order
-        unsigned ent[4];
+      for (int k = 0; k < kmax; k += MPA_AGG_BWD_UNROLL) {  // ascending sources: fixed summation order
+        unsigned ent[MPA_AGG_BWD_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < MPA_AGG_BWD_UNROLL; ++u) {
           const int off = b + k + u - base;
           ent[u] = sc[off < kRun ? off : kRun - 1];
         }
         if constexpr (decltype(with_hub)::value) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < MPA_AGG_BWD_UNROLL; ++u) {
             const int a = b + k + u;
             if (a < e && a - base >= kRun) ent[u] = rl[a];
           }
         }
-        float4 tv[4], tw[4];
-        unsigned ts[4], slot[4];
+        float4 t4[MPA_AGG_BWD_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < MPA_AGG_BWD_UNROLL; ++u) {
           const unsigned en = b + k + u < e ? ent[u] : (unsigned)kNeutral;
-          const int src = en >> 5;
-          slot[u] = en & 31u;
-          tv[u] = *reinterpret_cast<const float4*>(&Vp[src * kBS + 4 * cq]);
-          tw[u] = *reinterpret_cast<const float4*>(&Wp[src * kBS + 4 * cq]);
-          ts[u] = *reinterpret_cast<const unsigned*>(&Sp[src * kBS + 4 * cq]);
+          t4[u] = *reinterpret_cast<const float4*>(&Vp[(en >> 5) * kBS + 4 * cq]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          sv.x += tv[u].x;
-          sv.y += tv[u].y;
-          sv.z += tv[u].z;
-          sv.w += tv[u].w;
-          sd.x += (ts[u] & 0xffu) == slot[u] ? tw[u].x : 0.0f;
-          sd.y += ((ts[u] >> 8) & 0xffu) == slot[u] ? tw[u].y : 0.0f;
-          sd.z += ((ts[u] >> 16) & 0xffu) == slot[u] ? tw[u].z : 0.0f;
-          sd.w += (ts[u] >> 24) == slot[u] ? tw[u].w : 0.0f;
+        for (int u = 0; u < MPA_AGG_BWD_UNROLL; ++u) {
+          sv.x += t4[u].x;
+          sv.y += t4[u].y;
+          sv.z += t4[u].z;
+          sv.w += t4[u].w;
         }
       }
     };
@@ -1044,40 +1189,37 @@ __global__ __launch_bounds__(AT) void dg_agg_bwd_kernel(const float* __restrict_
     else scan(std::false_type{});
 #ifdef MPA_AGG_STATS
     ++n_pass;
-    n_iter += (kmax + 3) / 4;
+    n_iter += (kmax + MPA_AGG_BWD_UNROLL - 1) / MPA_AGG_BWD_UNROLL;
 #endif
     __builtin_amdgcn_wave_barrier();
     if (rk < N) {
-      const float deg = (float)(e - b), kf = (float)kNbr;
-      const float4 vv = *reinterpret_cast<const float4*>(&Vp[j * kBS + 4 * cq]);
-      const float4 wj = *reinterpret_cast<const float4*>(&Wp[j * kBS + 4 * cq]);
-      float4 du, dv;
+      const float deg = (float)(e - b);
+      const float4 sd = *reinterpret_cast<const float4*>(&Sd[j * kBS + 4 * cq]);
+      float4 du;
       du.x = __builtin_fmaf(gammap.x, __builtin_fmaf(deg, u4.x, sv.x), deg * betap.x) + sd.x;
       du.y = __builtin_fmaf(gammap.y, __builtin_fmaf(deg, u4.y, sv.y), deg * betap.y) + sd.y;
       du.z = __builtin_fmaf(gammap.z, __builtin_fmaf(deg, u4.z, sv.z), deg * betap.z) + sd.z;
       du.w = __builtin_fmaf(gammap.w, __builtin_fmaf(deg, u4.w, sv.w), deg * betap.w) + sd.w;
-      dv.x = wj.x + __builtin_fmaf(gammap.x, s4.x + kf * vv.x, kf * betap.x);
-      dv.y = wj.y + __builtin_fmaf(gammap.y, s4.y + kf * vv.y, kf * betap.y);
-      dv.z = wj.z + __builtin_fmaf(gammap.z, s4.z + kf * vv.z, kf * betap.z);
-      dv.w = wj.w + __builtin_fmaf(gammap.w, s4.w + kf * vv.w, kf * betap.w);
       *reinterpret_cast<float4*>(gp + (long long)j * 2 * CO + c0 + 4 * cq) = du;
-      *reinterpret_cast<float4*>(gp + (long long)j * 2 * CO + CO + c0 + 4 * cq) = dv;
     }
     j0 = j0n;
   }
 #ifdef MPA_AGG_STATS
   {
+    __shared__ unsigned long long st_s[4];
     const unsigned long long tk2 = AGG_TICK();
+    if (threadIdx.x < 4) st_s[threadIdx.x] = 0ull;
+    __syncthreads();
     if (lane == 0) {
-      atomicAdd(&g_agg_stats[2], tk2 - tk1);  // per wave: time in the passes
-      atomicAdd(&g_agg_stats[4], n_pass);
-      atomicAdd(&g_agg_stats[5], n_iter);
+      atomicAdd(&st_s[0], tk2 - tk1);  // per wave: time in the passes
+      atomicAdd(&st_s[1], n_pass);
+      atomicAdd(&st_s[2], n_iter);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      atomicAdd(&g_agg_stats[0], 1ull);
-      atomicAdd(&g_agg_stats[1], tk1 - tk0);
-      atomicAdd(&g_agg_stats[3], AGG_TICK() - tk0);
+      unsigned long long* r = g_agg_rec[((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) % kAggRec];
+      r[0] += 1ull, r[1] += tk1 - tk0, r[2] += st_s[0], r[3] += AGG_TICK() - tk0, r[4] += st_s[1], r[5] += st_s[2];
+      r[6] += tka - tk0, r[7] += tkb - tk0;
     }
   }
 #endif
@@ -1238,27 +1380,18 @@ void launch(Kern kern, dim3 grid, dim3 block, hipStream_t s, Args... args) {
   hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
 }
 
-// the transposed-graph pass with as many waves as its LDS panels leave room for (see dg_agg_bwd_kernel)
-#ifndef MPA_AGG_BWD_AT
-#define MPA_AGG_BWD_AT 1024
-#endif
-template <int AT, typename... Args>
-void launch_agg_bwd_as(dim3 grid, hipStream_t s, int N, Args... args) {
+inline void launch_agg_bwd(dim3 grid, hipStream_t s, const float* uv, int CO, const int* rptr, const int* order,
+                    const unsigned short* rlist, const unsigned short* idx, const float* dz, const unsigned char* ssel,
+                    const float* s1, const float* coef, int M, int N, float* guv, const int* hdr) {
+  static_assert(agg_bwd_lds(kMaxN) + 2048 <= 160 * 1024, "dg_agg_bwd_kernel: the panels of the largest part must fit the LDS");
   static bool reserved = false;  // the opt-in to more than 64 KB of dynamic LDS is per kernel, once
   if (!reserved) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(dg_agg_bwd_kernel<AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)(agg_bwd_lds(AT, kMaxN) + 64 < 160 * 1024 ? agg_bwd_lds(AT, kMaxN) : 160 * 1024 - 64));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(dg_agg_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)agg_bwd_lds(kMaxN));
     reserved = true;
   }
-  hipLaunchKernelGGL(dg_agg_bwd_kernel<AT>, grid, dim3(AT), agg_bwd_lds(AT, N), s, args...);
-}
-inline void launch_agg_bwd(dim3 grid, hipStream_t s, const float* uv, int CO, const int* rptr, const int* order,
-                    const unsigned short* rlist, const float* dz, const unsigned char* ssel, const float* s1,
-                    const float* coef, int N, float* guv, const int* hdr) {
-  if (agg_bwd_lds(MPA_AGG_BWD_AT, N) + 64 <= 160 * 1024)  // (+ the kernel's static words)
-    launch_agg_bwd_as<MPA_AGG_BWD_AT>(grid, s, N, uv, CO, rptr, order, rlist, dz, ssel, s1, coef, N, guv, hdr);
-  else
-    launch_agg_bwd_as<512>(grid, s, N, uv, CO, rptr, order, rlist, dz, ssel, s1, coef, N, guv, hdr);
+  hipLaunchKernelGGL(dg_agg_bwd_kernel, grid, dim3(kAggT), agg_bwd_lds(N), s, uv, CO, rptr, order, rlist, idx, dz, ssel, s1,
+                     coef, M, N, guv, hdr);
 }
 
 // C (+)= A . W^T on the matrix cores (see dg_gemm.h); Nout a multiple of 64
@@ -1482,8 +1615,9 @@ extern "C" int mpa_dgcnn_backward(const float* grad_feat, const float* const* co
            (const float*)w.partial, (int)tiles, CO, kNbr, bn_w[l], (const float*)w.bn[l], w.coef, grad_bn_w[l],
            grad_bn_b[l], cw, hdr);
     launch_agg_bwd(dim3((unsigned)(CO / kBS), DG_KNN_GRID_Y(M)), s, (const float*)w.uv[l], CO, (const int*)w.rptr[l],
-                   (const int*)w.order[l], (const unsigned short*)w.rlist[l], (const float*)w.dz,
-                   (const unsigned char*)w.ssel[l], (const float*)w.s1[l], (const float*)w.coef, (int)N, w.duv, hdr);
+                   (const int*)w.order[l], (const unsigned short*)w.rlist[l], (const unsigned short*)w.idx[l],
+                   (const float*)w.dz,
+                   (const unsigned char*)w.ssel[l], (const float*)w.s1[l], (const float*)w.coef, (int)M, (int)N, w.duv, hdr);
     if (l == 0) {
       const int t1 = (int)((R + kFirstTile - 1) / kFirstTile);
       launch(dg_first_wgrad_kernel, dim3((unsigned)t1), dim3(512), s, (const float*)w.duv, (const float4*)w.x0, w.tnpart,
@@ -1563,12 +1697,18 @@ extern "C" int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, i
 }
 
 #ifdef MPA_AGG_STATS
-extern "C" int mpa_debug_agg_stats(unsigned long long* out8, int reset) {
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_agg_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_agg_stats), z, sizeof(z)) != hipSuccess) return -1;
+__global__ void agg_stats_fold_kernel(int reset) {  // <<<1, 8>>>: sums the records (and clears them)
+  unsigned long long t = 0;
+  for (int b = 0; b < kAggRec; ++b) {
+    t += g_agg_rec[b][threadIdx.x];
+    if (reset) g_agg_rec[b][threadIdx.x] = 0ull;
   }
+  g_agg_stats[threadIdx.x] = t;
+}
+extern "C" int mpa_debug_agg_stats(unsigned long long* out8, int reset) {
+  hipLaunchKernelGGL(agg_stats_fold_kernel, dim3(1), dim3(8), 0, 0, reset);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_agg_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
   return 0;
 }
 #endif

@@ -1,5 +1,5 @@
 """Phase times inside dg_agg_bwd_kernel (needs the instrumented build: tools/build_variant.sh agg_stats dgcnn_enc.hip
--DMPA_AGG_STATS, copied over libmpa_hip.so on the GPU box): per block, cycles of the panel load, of the passes (per
+-DMPA_AGG_STATS, copied over libmpa_hip.so on the GPU box): per block, cycles of phase A (loads + fixed-point scatter), of the passes (per
 wave) and in total; passes and loop iterations per wave."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +17,10 @@ def step():
     (enc(x) * w).sum().backward()
 for _ in range(2): step()
 torch.cuda.synchronize()
+if not hasattr(_lib.lib(), "mpa_debug_agg_stats"):  # a regular build: just run the steps (for rocprofv3 around this script)
+    for _ in range(5): step()
+    torch.cuda.synchronize()
+    sys.exit(0)
 fn = _lib.lib().mpa_debug_agg_stats
 fn.restype = ctypes.c_int
 buf = (ctypes.c_ulonglong * 8)()
@@ -24,7 +28,7 @@ fn(buf, 1)
 step(); torch.cuda.synchronize()
 fn(buf, 1)
 blocks, t_load, t_pass, t_tot, passes, iters = buf[0], buf[1], buf[2], buf[3], buf[4], buf[5]
-waves = 16
-print(f"blocks {blocks}: cycles per block: panel load {t_load / blocks:.0f}, passes (mean over waves) {t_pass / blocks / waves:.0f}, "
+waves = int(os.environ.get('WAVES', '16'))
+print(f"blocks {blocks}: cycles per block: phase A {t_load / blocks:.0f}, passes (mean over waves) {t_pass / blocks / waves:.0f}, "
       f"total {t_tot / blocks:.0f}; passes per wave {passes / blocks / waves:.2f}, loop iterations per pass {iters / max(1, passes):.2f}, "
-      f"cycles per pass {t_pass / max(1, passes):.0f}")
+      f"cycles per pass {t_pass / max(1, passes):.0f}; phase A: loads + maxima {buf[6] / blocks:.0f}, + scatter {buf[7] / blocks:.0f}")
