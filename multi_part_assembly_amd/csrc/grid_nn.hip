@@ -738,14 +738,45 @@ __device__ __forceinline__ void consider(LaneState& s, float tx, float ty, float
   }
 }
 
+// Wave-wide reductions and the prefix sum on the DPP network (quad permutes, row mirrors, row broadcasts): ~7 VALU
+// instructions each, no LDS.  As `__shfl_xor` / `__shfl_up` loops (ds_bpermute + select + op per step) they were a
+// fifth of the search kernel's VALU instructions — and that kernel's VALU pipe is 90 % busy
+// (profiles/r05_c2_grid_search_sq_inst_mix.txt).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_self(int v) {  // rows outside ROW_MASK (and lanes without a source) keep v
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_zero(int v) {  // ... read 0
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+  auto mx = [](float a, int b) { return __builtin_fmaxf(a, __int_as_float(b)); };
+  v = mx(v, dpp_self<0xB1, 0xf>(__float_as_int(v)));   // quad_perm [1,0,3,2]
+  v = mx(v, dpp_self<0x4E, 0xf>(__float_as_int(v)));   // quad_perm [2,3,0,1]
+  v = mx(v, dpp_self<0x141, 0xf>(__float_as_int(v)));  // row_half_mirror
+  v = mx(v, dpp_self<0x140, 0xf>(__float_as_int(v)));  // row_mirror: every row of 16 holds its maximum
+  v = mx(v, dpp_self<0x142, 0xa>(__float_as_int(v)));  // row_bcast15 into rows 1, 3
+  v = mx(v, dpp_self<0x143, 0xc>(__float_as_int(v)));  // row_bcast31 into rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  v = max(v, dpp_self<0xB1, 0xf>(v));
+  v = max(v, dpp_self<0x4E, 0xf>(v));
+  v = max(v, dpp_self<0x141, 0xf>(v));
+  v = max(v, dpp_self<0x140, 0xf>(v));
+  v = max(v, dpp_self<0x142, 0xa>(v));
+  v = max(v, dpp_self<0x143, 0xc>(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// inclusive prefix sum over the lanes
+__device__ __forceinline__ int wave_prefix_sum(int v) {
+  v += dpp_zero<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_zero<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_zero<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_zero<0x118, 0xf>(v);  // row_shr:8: every row of 16 holds its own prefix sums
+  v += dpp_zero<0x142, 0xa>(v);  // row_bcast15: rows 1, 3 += the total of the row before
+  v += dpp_zero<0x143, 0xc>(v);  // row_bcast31: rows 2, 3 += the total of rows 0-1
   return v;
 }
 
@@ -912,13 +943,8 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
     scan_range_coop(s, trec, __builtin_amdgcn_readlane(rb, l), __builtin_amdgcn_readlane(re, l), cand);
   }
   if (len > kLongRange) len = 0;
-  int incl = len;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += t;
-  }
-  const int total = __shfl(incl, 63, 64), off0 = incl - len;
+  const int incl = wave_prefix_sum(len);
+  const int total = __builtin_amdgcn_readlane(incl, 63), off0 = incl - len;
   constexpr int T = 4 * MPA_GRID_CAND_CHUNK, kCap = kCand - T;  // (4x: a split-4 scan reads up to that far past the end)
   for (int w0 = 0; w0 < total; w0 += kCap) {  // windows of the concatenated list that fit the LDS buffer
     const int wn = total - w0 < kCap ? total - w0 : kCap;
@@ -927,7 +953,8 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
     __syncthreads();  // the previous window's readers are done with `cand` / `sidx` (one wave per block: cheap)
     // balanced gather: every lane first lists the record indices of its own (short) range in LDS, then the wave
     // fetches the concatenated list position by position — 64 records per instruction, several in flight — instead
-    // of each lane walking its own range two records per memory round trip
+    // of each lane walking its own range two records per memory round trip (round 5, again: per-lane copies with four
+    // records in flight per round and wave-uniform rounds: 0.253 vs 0.230 ms)
     for (int k = 0; k < cnt; ++k) sidx[lo - w0 + k] = rb + (lo - off0) + k;
     __syncthreads();
     constexpr int U = MPA_GRID_GATHER_U;
@@ -1140,13 +1167,26 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
         re = tst[row + xb + 1];
       }
     };
-    for (int r = 0; r <= 1 && r <= rmax; ++r) {  // rings 0 and 1: both flanks of every row in one batch
-      static_assert(2 * (2 * (kS + 2) + 2 * kS) <= 64, "both flanks of ring 1 fit one batch");
+    static_assert(2 * kS * kS + 2 * (2 * (kS + 2) + 2 * kS) <= 64, "both flanks of rings 0 and 1 fit one batch");
+    if (bound <= 1e31f && rmax >= 1) {
+      // the seed left a bound: rings 0 and 1, both flanks of every row, are ONE batch under it (lanes [0, 8): ring 0,
+      // [8, 32): ring 1) — a batch is two dependent memory round trips and ~260 VALU instructions of bookkeeping,
+      // which ring 1's slightly staler bound does not cost
+      constexpr int kL0 = 2 * kS * kS;
+      const int rr = lane >= kL0 ? 1 : 0, li = lane - rr * kL0;
       int rb, re;
-      row_range(r, lane & 1, lane >> 1, lane < 2 * ring_rows(r), rb, re);
+      row_range(rr, li & 1, li >> 1, li < 2 * ring_rows(rr), rb, re);
       scan_batch(s, trec, rb, re, cand, sidx);
       merge_halves(s);
-      bound = wave_max(s.best) * 1.00001f;  // (ring 1 must see the bound ring 0 found: without one, rows are whole)
+      bound = wave_max(s.best) * 1.00001f;
+    } else {
+      for (int r = 0; r <= 1 && r <= rmax; ++r) {  // rings 0 and 1: both flanks of every row in one batch
+        int rb, re;
+        row_range(r, lane & 1, lane >> 1, lane < 2 * ring_rows(r), rb, re);
+        scan_batch(s, trec, rb, re, cand, sidx);
+        merge_halves(s);
+        bound = wave_max(s.best) * 1.00001f;  // (ring 1 must see the bound ring 0 found: without one, rows are whole)
+      }
     }
     MPA_TICK(11);
     for (int r = 2; r <= rmax; ++r) {
@@ -1171,7 +1211,8 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
       while (m) {
         const int p = __builtin_ctzll(m);
         m &= m - 1;
-        consider(s, __shfl(px, p, 64), __shfl(py, p, 64), __shfl(pz, p, 64), p * N);
+        auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+        consider(s, rl(px, p), rl(py, p), rl(pz, p), p * N);  // (p is wave-uniform: a register read, not an LDS permute)
       }
     }
     if (has && lane < 64 / s.split) {  // (every group holds the merged result; the padded parts' representatives
