@@ -71,4 +71,15 @@ void launch_leaf_search(bool shape, const float* valids, const LeafCloud& A, con
 // parts in a large box (a clumpy cloud) is where a uniform grid loses and the leaves win.  force 0 / 1: every sample alike.
 void launch_leaf_route(const float* valids, const float* pbox, int64_t B, int64_t P, int force, int* route, hipStream_t s);
 
+// ---- matrix-core gated exact NN between two mid-sized clouds (gate_nn.hip) ---------------------------------------------------
+// Per-part Chamfer of the fused loss: part m of C1 against part m of C2 (both [B, P, N, 3]; padded parts skipped), arg-mins
+// into idx1 / idx2 [B, P, N] and per-block distance sums into tile_sums[dir][m][gate_tiles(N, N)].
+int gate_tiles(int64_t na, int64_t nb);
+bool gate_supported(int64_t na, int64_t nb);
+void launch_gate_part_search(const float* valids, const float* C1, const float* C2, int64_t B, int64_t P, int64_t N,
+                             int32_t* idx1, int32_t* idx2, float* tile_sums, hipStream_t s);
+// The generic operator's contract (mpa_chamfer_forward) for xyz1 [batch, n1, 3], xyz2 [batch, n2, 3]; no workspace.
+void launch_gate_cloud_search(const float* xyz1, const float* xyz2, int64_t batch, int64_t n1, int64_t n2, float* dist1,
+                              int64_t* idx1, float* dist2, int64_t* idx2, hipStream_t s);
+
 }  // namespace mpa

@@ -716,6 +716,13 @@ int pick_q(int64_t B, int64_t P, int64_t N) {
   return 2;
 }
 
+// the per-part Chamfer of the brute / grid modes: matrix-core gated search (default) or the exhaustive scan
+bool part_search_gate(int64_t N) {
+  const char* e = getenv("MPA_PART_SEARCH");
+  if (e != nullptr && e[0] == 's') return false;
+  return mpa::gate_supported(N, N) && (N >= 64 || (e != nullptr && e[0] == 'g'));
+}
+
 Workspace carve(float* fws, int32_t* iws, int64_t B, int64_t P, int64_t N, int q) {
   Workspace w;
   const int64_t cloud = B * P * N * 3, pn = B * P * N;
@@ -870,7 +877,13 @@ extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const fl
   // XCDs than it gains (measured 2.56 vs 2.21 ms at B=32, P=20, N=1000): off unless MPA_XCD_REMAP=1.
   const char* re = getenv("MPA_XCD_REMAP");
   const int remap = re ? (re[0] != '0') : 0;
-  if (q == 4)
+  // per-part Chamfer: the matrix-core gated search (gate_nn.hip) unless MPA_PART_SEARCH=scan asks for the exhaustive scan
+  // of rounds 1-4 (identical results; the knob exists for A/B timing and the cross-check tests)
+  const bool part_gate = part_search_gate(N);
+  const int tiles_part = part_gate ? mpa::gate_tiles(N, N) : w.tiles;
+  if (part_gate)
+    mpa::launch_gate_part_search(valids, w.R1, w.R2, B, P, N, w.ip1, w.ip2, w.part_tiles, s);
+  else if (q == 4)
     hipLaunchKernelGGL((assembly_nn_kernel<4, mpa::kChunkMin, false>), grid, dim3(kThreads), 0, s, valids,
                        w.R1, w.R2, (int)B, (int)P, (int)N, w.tiles, remap, w.ip1, w.ip2, w.part_tiles);
   else
@@ -890,7 +903,7 @@ extern "C" int mpa_assembly_loss_forward_ordered(const float* part_pcs, const fl
   mark(3);
   hipLaunchKernelGGL(assembly_finalize_kernel, dim3((unsigned)B), dim3(64), 0, s, valids, quat_pred,
                      trans_pred, quat_gt, trans_gt, w.partial, w.part_tiles, w.shape_tiles, (int)B,
-                     (int)P, (int)N, w.tiles, w.tiles, training, losses, (const float*)nullptr, 0, (const int*)nullptr);
+                     (int)P, (int)N, tiles_part, w.tiles, training, losses, (const float*)nullptr, 0, (const int*)nullptr);
   mark(4);
   return mpa::check_launch("assembly_loss_forward");
 }

@@ -156,6 +156,17 @@ bool grid_pays(int64_t batch, int64_t n1, int64_t n2) {
   return nmin >= 512 && n1 * n2 >= MPA_CHAMFER_GRID_MIN_PAIRS && mpa::cloud_grid_supported(batch, n1, n2);
 }
 
+// ... and between the two, the matrix-core gated search (gate_nn.hip): one bf16 MFMA per 32 x 32 pairs decides which
+// few targets get the pinned arithmetic.  It needs no workspace; below a few hundred points the scan's blocks are too
+// short for the gate's set-up (panel staging, two passes) to pay.
+#ifndef MPA_CHAMFER_GATE_MIN
+#define MPA_CHAMFER_GATE_MIN 192
+#endif
+bool gate_pays(int64_t n1, int64_t n2) {
+  const int64_t nmin = n1 < n2 ? n1 : n2;
+  return nmin >= MPA_CHAMFER_GATE_MIN && mpa::gate_supported(n1, n2);
+}
+
 int check_forward_args(const void* xyz1, const void* xyz2, int64_t batch, int64_t n1, int64_t n2,
                        const void* dist1, const void* idx1, const void* dist2, const void* idx2) {
   MPA_REQUIRE(batch >= 0 && n1 >= 0 && n2 >= 0, "chamfer_forward: negative size");
@@ -195,20 +206,22 @@ int chamfer_backward_impl(const S* grad_dist1, const S* grad_dist2, const S* xyz
 
 }  // namespace
 
-// variant: 0 = direct, 1 = fused-form gate, 2 = exact chunk-min, 3 = grid-pruned (needs the workspace), -1 = by size
-// — see chamfer_core.h / grid_nn.hip.
+// variant: 0 = direct, 1 = fused-form gate, 2 = exact chunk-min, 3 = grid-pruned (needs the workspace), 4 = matrix-core
+// gated (gate_nn.hip), -1 = by size — see chamfer_core.h / grid_nn.hip / gate_nn.hip.
 extern "C" int mpa_chamfer_forward_variant(const float* xyz1, const float* xyz2, int64_t batch,
                                            int64_t n1, int64_t n2, float* dist1, int64_t* idx1,
                                            float* dist2, int64_t* idx2, int variant, void* workspace,
                                            int64_t workspace_bytes, void* stream) {
-  MPA_REQUIRE(variant >= -1 && variant <= 3, "chamfer_forward: unknown variant %d", variant);
+  MPA_REQUIRE(variant >= -1 && variant <= 4, "chamfer_forward: unknown variant %d", variant);
   const int st = check_forward_args(xyz1, xyz2, batch, n1, n2, dist1, idx1, dist2, idx2);
   if (st != MPA_OK) return st < 0 ? st : MPA_OK;
   hipStream_t s = mpa::as_stream(stream);
   const int a = (int)n1, b = (int)n2;
   if (variant == 3)
     MPA_REQUIRE(mpa::cloud_grid_supported(batch, n1, n2), "chamfer_forward: the grid-pruned search needs two non-empty clouds");
-  if (variant == -1) variant = grid_pays(batch, n1, n2) && workspace != nullptr ? 3 : 2;
+  if (variant == 4)
+    MPA_REQUIRE(mpa::gate_supported(n1, n2), "chamfer_forward: the matrix-core gated search needs two non-empty clouds of <= 32768 points");
+  if (variant == -1) variant = grid_pays(batch, n1, n2) && workspace != nullptr ? 3 : (gate_pays(n1, n2) ? 4 : 2);
   if (variant == 3) {
     MPA_REQUIRE(workspace != nullptr && workspace_bytes >= mpa::cloud_grid_workspace_bytes(batch, n1, n2),
                 "chamfer_forward: the grid-pruned search needs mpa_chamfer_workspace() bytes of workspace");
@@ -219,6 +232,8 @@ extern "C" int mpa_chamfer_forward_variant(const float* xyz1, const float* xyz2,
     // samples the pruned search handed back (non-finite / huge coordinates): the exhaustive scan, for those only
     launch_nn_sized<mpa::kChunkMin>(xyz1, xyz2, batch, a, b, dist1, idx1, dist2, idx2, s, flagged);
     mpa::launch_cloud_copy_runs(batch, n1, n2, dist1, idx1, dist2, idx2, workspace, s);
+  } else if (variant == 4) {
+    mpa::launch_gate_cloud_search(xyz1, xyz2, batch, n1, n2, dist1, idx1, dist2, idx2, s);
   } else if (variant == 0) {
     launch_nn_sized<mpa::kDirect>(xyz1, xyz2, batch, a, b, dist1, idx1, dist2, idx2, s);
   } else if (variant == 1) {
@@ -241,7 +256,7 @@ extern "C" int mpa_chamfer_workspace(int64_t batch, int64_t n1, int64_t n2, int6
 extern "C" int mpa_chamfer_workspace_variant(int64_t batch, int64_t n1, int64_t n2, int variant, int64_t* bytes) {
   MPA_REQUIRE(bytes != nullptr, "chamfer_workspace_variant: null pointer");
   MPA_REQUIRE(batch >= 0 && n1 >= 0 && n2 >= 0, "chamfer_workspace_variant: negative size");
-  MPA_REQUIRE(variant >= -1 && variant <= 3, "chamfer_workspace_variant: unknown variant %d", variant);
+  MPA_REQUIRE(variant >= -1 && variant <= 4, "chamfer_workspace_variant: unknown variant %d", variant);
   if (variant == -1) return mpa_chamfer_workspace(batch, n1, n2, bytes);
   *bytes = variant == 3 && mpa::cloud_grid_supported(batch, n1, n2) ? mpa::cloud_grid_workspace_bytes(batch, n1, n2) : 0;
   return MPA_OK;
