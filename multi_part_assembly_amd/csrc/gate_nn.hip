@@ -7,37 +7,39 @@
 // rounded, lowest target index on ties, (1e32, -1) for a query that sees nothing below 1e32.
 //
 // The exhaustive scan spends ~4.5 VALU operations per (query, target) pair.  Here the pair work is ONE
-// v_mfma_f32_32x32x16_bf16 per 32 x 32 pairs and half a VALU operation (pass 1) / one compare (pass 2) per pair; the
-// pinned fp32 arithmetic is spent only on the handful of targets that can be the answer:
+// v_mfma_f32_32x32x16_bf16 per 32 x 32 pairs plus half a VALU operation per pair (v_min3 trees); the pinned fp32
+// arithmetic is spent only on the few CELLS (16 targets of one tile, as a lane's accumulator registers hold them) that
+// can contain a query's answer:
 //
 //   operands   y = x - c (c: any vector, here the mean of the first targets) is cut into bf16 pieces y = h + l + r.
-//              Target row (16 bf16):  hx hy hz | hx hy hz | lx ly lz | NU (3 pieces) | NL (3 pieces) | 0
-//              Query column, pass 1:  -2h      | -2l      | -2h      | 1 1 1         | 0 0 0         | 0
-//                            pass 2:  -2h      | -2l      | -2h      | 0 0 0         | 1 1 1         | 0
-//              so one K = 16 product gives  a(i,j) = N*_j - 2 (h_i.h_j + l_i.h_j + h_i.l_j)  ~  |y_j|^2 - 2 y_i.y_j
-//              = d(i,j) - |y_i|^2.  NU / NL are the target's squared norm scaled up / down by kappa (an fp32 number is
-//              exactly three bf16 pieces), so that with the query's own scaled norms QU / QL
-//                  a_L(i,j) + QL_i  <=  d(i,j)  <=  a_U(i,j) + QU_i          (d: the PINNED distance)     ... (*)
-//   pass 1     tau_i = min_j a_U(i,j): 8 x v_min3 per 16 accumulator values.  d(i, nearest) <= tau_i + QU_i.
-//   pass 2     the same tiles with the NL columns; target j survives iff a_L(i,j) <= tau_i + (QU_i - QL_i).  By (*) every
-//              target that attains the minimum of the pinned distance survives (ties included); typically 1-2 of a
-//              thousand do.  Survivor indices go to a per-lane list in LDS.
-//   answer     pinned distance of every survivor from the stored fp32 coordinates, lexicographic (distance, index) update.
-//   A wave in which some query ends with no survivor or an overflowed list (non-finite values, coincident or lattice
-//   clouds, out-of-range magnitudes) scans all targets in index order with the pinned arithmetic instead: the gate only
-//   ever DECIDES which pairs get the exact evaluation, it never contributes a digit to a result.  A target cloud whose
-//   points all coincide (the zero-padded parts of the reference's per-part call) is answered directly.
+//              Target row (16 bf16):  hx hy hz | hx hy hz | lx ly lz | n (3 pieces) | 0 0 0 0      n = fp32 |y|^2, exact
+//              Query column:          -2h      | -2l      | -2h      | 1 1 1        | 0 0 0 0      in three bf16 pieces
+//              so one K = 16 product gives  a(i,j) = n_j - 2 (h_i.h_j + l_i.h_j + h_i.l_j)  ~  |y_j|^2 - 2 y_i.y_j
+//              = d(i,j) - |y_i|^2, with   | a(i,j) - (d(i,j) - M_i) |  <=  kappa (M_i + M_j)          ... (*)
+//              (d: the PINNED distance; M = |y|^2 in real arithmetic).
+//   bound      every lane keeps the minimum of each of its cells (8 x v_min3 per 16 accumulator values) in a register,
+//              and the running minimum tau_i = min_j a(i,j).  By (*) every target that attains the minimum of the pinned
+//              distance has  a(i,j) <= tau_i + 2 kappa (M_i + Mmax)  =: thr_i   (Mmax: the largest target norm).
+//   answer     a cell whose minimum is <= thr_i is evaluated exactly: pinned distances of its 16 targets from the fp32
+//              coordinates (kept in LDS beside the bf16 panel), lexicographic (distance, index) update as one 64-bit
+//              compare.  Typically 1-2 of a query's 64 cells qualify.  The two lanes that share a query (one per half of a
+//              tile's rows) merge their keys at the end.
+//   Magnitudes beyond 1e30 (overflowing squares) or non-finite norms send the wave to the textbook scan of all targets
+//   in index order; NaN / inf coordinates of single points need nothing special (their a is NaN or +inf: never a
+//   minimum; their pinned distance is NaN or inf: never below the running best).  The gate only ever DECIDES which
+//   pairs get the exact evaluation, it never contributes a digit to a result.  A target cloud whose points all coincide
+//   (the zero-padded parts of the reference's per-part call) is answered directly.
 //
-// kappa (per unit of M_i + M_j, M = |y|^2 in real arithmetic).  bf16 keeps 8 significant bits: |y - h| <= 2^-8 |y|,
-// |l| <= 2^-8 |y|, |r| <= 2^-16 |y| per coordinate, so y_i.y_j - (hh + lh + hl) = l.l + r_i.y_j + (h + l)_i.r_j is at most
+// kappa (per unit of M_i + M_j).  bf16 keeps 8 significant bits: |y - h| <= 2^-8 |y|, |l| <= 2^-8 |y|, |r| <= 2^-16 |y|
+// per coordinate, so y_i.y_j - (hh + lh + hl) = l.l + r_i.y_j + (h + l)_i.r_j is at most
 // 3.02 * 2^-16 sum_k |y_ik y_jk| <= 3.02 * 2^-16 (M_i + M_j) / 2; it enters a twice:              4.61e-5
-// The 16 bf16 products are exact in fp32; their accumulation inside the matrix core is charged 2^-23 per term (the
-// internal order and rounding are not documented) on sum |terms| <= 2.03 (M_i + M_j):                 3.9e-6
+// The 12 bf16 products are exact in fp32; their accumulation inside the matrix core is charged 2^-23 per term of a
+// 16-term sum (the internal order and rounding are not documented) on sum |terms| <= 2.03 (M_i + M_j):  3.9e-6
 // y = fl(x - c) moves |y_i - y_j|^2 away from |x_i - x_j|^2 by <= 4.04 * 2^-24 (M_i + M_j):          2.4e-7
 // the pinned chain is within 6 * 2^-24 of the real |x_i - x_j|^2 <= 2 (M_i + M_j):                    7.2e-7
-// the fp32 norms m (three squares, two additions) are within 3 * 2^-24 of M, on either side:           3.6e-7
-// Sum 5.13e-5; kappa = 6e-5.  NU = m (1 + kappa) rounded up, NL = m (1 - kappa) rounded down, QU / QL likewise; the
-// threshold is rounded up and carries 1e-30 of absolute slack for products that underflow.
+// the fp32 norms (three squares, two additions) are within 3 * 2^-24 of M, on either side:             3.6e-7
+// Sum 5.13e-5; kappa = 6e-5.  The threshold is rounded up at every step and carries 1e-30 of absolute slack for
+// products that underflow.
 #include "assembly_internal.h"
 #include "common.h"
 
@@ -46,30 +48,32 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned long long u64;
 
 constexpr int kGW = 4;                 // waves per block: 256 queries
 constexpr int kGQ = 64 * kGW;
-constexpr int kGT = 1024;              // targets per LDS panel (32 KB)
-constexpr int kGCap = 6;               // survivor slots per (query, lane half)
+constexpr int kGT = 1024;              // targets per LDS panel (32 KB of bf16 rows + 16 KB of fp32 coordinates)
+constexpr int kGTiles = kGT / 32;
 constexpr float kGKappa = 6.0e-5f;
+constexpr float kGMaxNorm = 1e30f;     // beyond: squares may overflow -> the textbook scan
 
-__device__ __forceinline__ float g_next(float x) {  // the next float above a finite x (x >= 0 here or anything finite)
-  return x >= 0.0f ? __uint_as_float(__float_as_uint(x + 0.0f) + 1u) : __uint_as_float(__float_as_uint(x) - 1u);
+// the next float above x (+inf stays +inf; NaN stays NaN)
+__device__ __forceinline__ float g_next(float x) {
+  const float up = x >= 0.0f ? __uint_as_float(__float_as_uint(x + 0.0f) + 1u) : __uint_as_float(__float_as_uint(x) - 1u);
+  return x < __builtin_inff() ? up : x;
 }
-__device__ __forceinline__ float g_prev(float x) { return -g_next(-x); }
 __device__ __forceinline__ float g_dist3(float dx, float dy, float dz) { return (dx * dx + dy * dy) + dz * dz; }
 __device__ __forceinline__ unsigned g_bf(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float g_bf_f(float x) { return (float)(__bf16)x; }
 __device__ __forceinline__ unsigned g_pk(float lo, float hi) { return g_bf(lo) | (g_bf(hi) << 16); }
-__device__ __forceinline__ int g_acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 __device__ __forceinline__ bf16x8 g_as_bf(const uint4 v) { return __builtin_bit_cast(bf16x8, v); }
-// min(run, the 16 values): 8 x v_min3_f32 (three-operand minima only: the two-operand v_min_f32 makes the compiler
-// canonicalise every accumulator register first, 8 more instructions per tile)
+// three-operand minima only: the two-operand v_min_f32 makes the compiler canonicalise every accumulator register first
 __device__ __forceinline__ float g_min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
-__device__ __forceinline__ float g_min16(float run, const f32x16& a) {
+__device__ __forceinline__ void g_min16(const f32x16& a, float& x, float& y) {  // min of the 16 = min(x, y): 7 x v_min3
   const float m0 = g_min3(a[0], a[1], a[2]), m1 = g_min3(a[3], a[4], a[5]), m2 = g_min3(a[6], a[7], a[8]);
   const float m3 = g_min3(a[9], a[10], a[11]), m4 = g_min3(a[12], a[13], a[14]);
-  return g_min3(run, g_min3(m0, m1, m2), g_min3(m3, m4, a[15]));
+  x = g_min3(m0, m1, m2);
+  y = g_min3(m3, m4, a[15]);
 }
 // x = p0 + p1 + p2 exactly (three bf16 pieces of a finite fp32 number)
 __device__ __forceinline__ void g_split3(float x, float& p0, float& p1, float& p2) {
@@ -78,6 +82,7 @@ __device__ __forceinline__ void g_split3(float x, float& p0, float& p1, float& p
   p1 = g_bf_f(r1);
   p2 = r1 - p1;
 }
+__device__ __forceinline__ u64 g_key(float d, unsigned idx) { return ((u64)__float_as_uint(d) << 32) | idx; }
 
 struct GateArgs {
   const float* a;        // cloud A [M][na][3]
@@ -94,11 +99,10 @@ struct GateArgs {
 
 // grid = (M * tiles, 2), block 256.  blockIdx.y = direction (0: A's points are the queries).
 template <bool LOSS>
-__global__ __launch_bounds__(kGQ, 4) void gate_nn_kernel(const GateArgs g) {
-  __shared__ uint4 panel[2][kGT];                      // plane k-half h: row r -> 8 bf16
-  __shared__ unsigned short lst[kGW * 2 * kGCap * 64];  // [(wave * 2 + set) * cap + slot][lane]
-  __shared__ unsigned char cntl[kGW * 2 * 64];
-  __shared__ float red[kGW];
+__global__ __launch_bounds__(kGQ, 3) void gate_nn_kernel(const GateArgs g) {
+  __shared__ uint4 panel[2][kGT];   // plane k-half h: row r -> 8 bf16
+  __shared__ float4 raw[kGT];       // the same targets' fp32 coordinates (NaN past the cloud's end)
+  __shared__ float red[kGW], redm[kGW];
   const int m = blockIdx.x / g.tiles, tile = blockIdx.x % g.tiles, dir = blockIdx.y;
   if (g.valids != nullptr && g.valids[m] == 0.0f) return;
   const int nq = dir == 0 ? g.na : g.nb, nt = dir == 0 ? g.nb : g.na;
@@ -134,17 +138,6 @@ __global__ __launch_bounds__(kGQ, 4) void gate_nn_kernel(const GateArgs g) {
       g.idx64[dir][(long long)m * nq + qi] = (long long)bi;
     }
   };
-  auto exact_scan = [&]() {  // all targets, index order, strict `<`: the textbook loop (rare)
-    bd = 1e32f;
-    bi = -1;
-    for (int t = 0; t < nt; ++t) {
-      const float d = g_dist3(X - tb[3LL * t], Y - tb[3LL * t + 1], Z - tb[3LL * t + 2]);
-      if (d < bd) {
-        bd = d;
-        bi = t;
-      }
-    }
-  };
   if (nt == 0) {  // (block-uniform)
     store();
     return;
@@ -164,60 +157,93 @@ __global__ __launch_bounds__(kGQ, 4) void gate_nn_kernel(const GateArgs g) {
   }
 
   // ---- this lane's query as a column of the product, then the two query tiles of the wave --------------------------------
-  // (tile s = queries 32 s + j of the wave; lane (j, h) supplies k-half h of column j)
-  uint4 b1[2], b2[2];
-  float slack;
+  // (tile s = queries 32 s + j of the wave; lane (j, h) supplies k-half h of column j and keeps that query's coordinates)
+  uint4 bq[2];
+  float OX, OY, OZ;  // the query of the OTHER tile that this lane serves (tile 1 - h, column j); tile h's is its own
+  float mq;
   {
     const float yx = X - cx, yy = Y - cy, yz = Z - cz;
     const float hx = g_bf_f(yx), hy = g_bf_f(yy), hz = g_bf_f(yz);
     const float lx = yx - hx, ly = yy - hy, lz = yz - hz;
-    const float mq = g_dist3(yx, yy, yz);
-    const float QU = g_next(__builtin_fmaf(mq, kGKappa, mq)), QL = g_prev(__builtin_fmaf(mq, -kGKappa, mq));
-    slack = g_next(g_next(QU - QL) + 1e-30f);
+    mq = g_dist3(yx, yy, yz);
     const float a = -2.0f;
     const uint4 k0 = {g_pk(a * hx, a * hy), g_pk(a * hz, a * lx), g_pk(a * ly, a * lz), g_pk(a * hx, a * hy)};
-    const unsigned one = 0x3f80u, z8 = g_bf(a * hz);
-    const uint4 k1u = {z8 | (one << 16), one | (one << 16), 0u, 0u};
-    const uint4 k1l = {z8, 0u, one | (one << 16), one};
+    const unsigned one = 0x3f80u;
+    const uint4 k1 = {g_bf(a * hz) | (one << 16), one | (one << 16), 0u, 0u};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int src = 32 * s + j;
-      uint4 v0, vu, vl;
+      uint4 v0, v1;
       v0.x = __shfl(k0.x, src, 64), v0.y = __shfl(k0.y, src, 64), v0.z = __shfl(k0.z, src, 64), v0.w = __shfl(k0.w, src, 64);
-      vu.x = __shfl(k1u.x, src, 64), vu.y = __shfl(k1u.y, src, 64), vu.z = __shfl(k1u.z, src, 64), vu.w = __shfl(k1u.w, src, 64);
-      vl.x = __shfl(k1l.x, src, 64), vl.y = __shfl(k1l.y, src, 64), vl.z = __shfl(k1l.z, src, 64), vl.w = __shfl(k1l.w, src, 64);
-      b1[s] = uint4{h ? vu.x : v0.x, h ? vu.y : v0.y, h ? vu.z : v0.z, h ? vu.w : v0.w};
-      b2[s] = uint4{h ? vl.x : v0.x, h ? vl.y : v0.y, h ? vl.z : v0.z, h ? vl.w : v0.w};
+      v1.x = __shfl(k1.x, src, 64), v1.y = __shfl(k1.y, src, 64), v1.z = __shfl(k1.z, src, 64), v1.w = __shfl(k1.w, src, 64);
+      bq[s] = uint4{h ? v1.x : v0.x, h ? v1.y : v0.y, h ? v1.z : v0.z, h ? v1.w : v0.w};
     }
+    OX = __shfl(X, 32 * (1 - h) + j, 64), OY = __shfl(Y, 32 * (1 - h) + j, 64), OZ = __shfl(Z, 32 * (1 - h) + j, 64);
   }
 
   // ---- target panel: rows chunk * kGT + r, r < kGT ------------------------------------------------------------------------------
   const float t0x = tb[0], t0y = tb[1], t0z = tb[2];
   bool same = true;
+  float mmax = 0.0f;
+  const float nanf_ = __builtin_nanf("");
   auto stage = [&](int chunk) {
     for (int r = threadIdx.x; r < kGT; r += kGQ) {
       const int t = chunk * kGT + r;
       uint4 p0 = {0u, 0u, 0u, 0u}, p1;
-      float NU = 3.0e38f, NL = 3.0e38f;  // rows past the cloud: never the minimum, never below a threshold
+      float n = 3.0e38f;  // rows past the cloud: never a minimum, never below a threshold
       unsigned lzb = 0u;
+      float4 rw = {nanf_, nanf_, nanf_, 0.0f};
       if (t < nt) {
         const float x = tb[3LL * t], y = tb[3LL * t + 1], z = tb[3LL * t + 2];
+        rw = float4{x, y, z, 0.0f};
         same = same && x == t0x && y == t0y && z == t0z;
         const float yx = x - cx, yy = y - cy, yz = z - cz;
         const float hx = g_bf_f(yx), hy = g_bf_f(yy), hz = g_bf_f(yz);
         const float lx = yx - hx, ly = yy - hy, lz = yz - hz;
-        const float mt = g_dist3(yx, yy, yz);
-        NU = g_next(__builtin_fmaf(mt, kGKappa, mt));
-        NL = g_prev(__builtin_fmaf(mt, -kGKappa, mt));
+        n = g_dist3(yx, yy, yz);
+        mmax = n > mmax || n != n ? n : mmax;  // (a NaN norm sticks: the guard below sees it)
         p0 = uint4{g_pk(hx, hy), g_pk(hz, hx), g_pk(hy, hz), g_pk(lx, ly)};
         lzb = g_bf(lz);
       }
-      float u0, u1, u2, l0, l1, l2;
-      g_split3(NU, u0, u1, u2);
-      g_split3(NL, l0, l1, l2);
-      p1 = uint4{lzb | (g_bf(u0) << 16), g_pk(u1, u2), g_pk(l0, l1), g_bf(l2)};
+      float n0, n1, n2;
+      g_split3(n, n0, n1, n2);
+      p1 = uint4{lzb | (g_bf(n0) << 16), g_pk(n1, n2), 0u, 0u};
       panel[0][r] = p0;
       panel[1][r] = p1;
+      raw[r] = rw;
+    }
+  };
+  // the cells of the panel in LDS: per lane and query tile the minimum of a over each tile's 16 rows of this lane half
+  float tm0[kGTiles], tm1[kGTiles];
+  float run0 = __builtin_inff(), run1 = __builtin_inff();
+  auto bound = [&](int c) {
+    const int rows = nt - c * kGT < kGT ? nt - c * kGT : kGT;
+    const int nti = (rows + 31) / 32;
+    const uint4* pl = &panel[h][j];
+#pragma unroll
+    for (int t8 = 0; t8 < kGTiles; t8 += 8) {
+      if (t8 < nti) {  // (wave-uniform; the panel is padded to full tiles, so a group of 8 is always safe to process)
+        uint4 nx = pl[32 * t8];
+#pragma unroll
+        for (int t = t8; t < t8 + 8; ++t) {
+          const bf16x8 a = g_as_bf(nx);
+          if (t + 1 < t8 + 8) nx = pl[32 * (t + 1)];  // (the next tile's rows are on their way while this one is reduced)
+          const f32x16 z = {0};
+          const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, g_as_bf(bq[0]), z, 0, 0, 0);
+          const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, g_as_bf(bq[1]), z, 0, 0, 0);
+          float x, y;
+          g_min16(acc0, x, y);
+          tm0[t] = g_min3(x, y, __builtin_inff());
+          run0 = g_min3(run0, x, y);
+          g_min16(acc1, x, y);
+          tm1[t] = g_min3(x, y, __builtin_inff());
+          run1 = g_min3(run1, x, y);
+          __builtin_amdgcn_sched_barrier(0);  // (tiles kept apart: hoisting the panel reads of many tiles spills registers)
+        }
+      } else {
+#pragma unroll
+        for (int t = t8; t < t8 + 8; ++t) tm0[t] = tm1[t] = __builtin_inff();
+      }
     }
   };
   const int chunks = (nt + kGT - 1) / kGT;
@@ -232,107 +258,95 @@ __global__ __launch_bounds__(kGQ, 4) void gate_nn_kernel(const GateArgs g) {
     store();
     return;
   }
-
-  // ---- pass 1: tau = min_j a_U --------------------------------------------------------------------------------------------------
-  float m0 = __builtin_inff(), m1 = __builtin_inff();
-  for (int c = 0; c < chunks; ++c) {
-    if (c > 0) {
-      __syncthreads();
-      stage(c);
-      __syncthreads();
-    }
-    const int rows = nt - c * kGT < kGT ? nt - c * kGT : kGT;
-    const int nti = (rows + 31) / 32;
-    const uint4* pl = &panel[h][j];
-
-    for (int t = 0; t < nti; ++t) {
-      const bf16x8 a = g_as_bf(pl[32 * t]);
-      const f32x16 z = {0};
-      const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, g_as_bf(b1[0]), z, 0, 0, 0);
-      const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, g_as_bf(b1[1]), z, 0, 0, 0);
-      m0 = g_min16(m0, acc0);
-      m1 = g_min16(m1, acc1);
+  // One panel: bound, thresholds, answer.  Several panels: a first sweep over all of them for tau and Mmax, a second
+  // one that bounds each panel again and answers from it.
+  const u64 none = g_key(1e32f, 0xffffffffu);
+  u64 best0 = none, best1 = none;
+  float thr0 = 0.0f, thr1 = 0.0f;
+  bool wave_exact = false;
+  const int sweeps = chunks == 1 ? 1 : 2;
+  for (int sw = 0; sw < sweeps; ++sw) {
+    const bool last = sw == sweeps - 1;
+    for (int c = 0; c < chunks; ++c) {
+      if (sw > 0 || c > 0) {
+        __syncthreads();
+        stage(c);
+        __syncthreads();
+      }
+      bound(c);
+      if (!last) continue;
+      if (c == 0) {  // (tau and this thread's share of Mmax are complete)
+        float v = mmax;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const float o = __shfl_xor(v, off, 64);
+          v = o > v || o != o ? o : v;
+        }
+        if (lane == 0) redm[wave] = v;
+        __syncthreads();
+        mmax = redm[0];
+#pragma unroll
+        for (int w = 1; w < kGW; ++w) mmax = redm[w] > mmax || redm[w] != redm[w] ? redm[w] : mmax;
+        // thresholds: the owner of a query (lane 32 h + j holds query 32 h + j = column j of tile h) forms it, rounding up
+        const float tau0 = g_min3(run0, __shfl_xor(run0, 32, 64), __builtin_inff());
+        const float tau1 = g_min3(run1, __shfl_xor(run1, 32, 64), __builtin_inff());
+        float sl = g_next(g_next(mq + mmax) * (2.0f * kGKappa));
+        sl = g_next(sl + 1e-30f);
+        const float thr_own = g_next((h ? tau1 : tau0) + sl);
+        thr0 = __shfl(thr_own, j, 64), thr1 = __shfl(thr_own, 32 + j, 64);
+        const bool risky = has && !(mq <= kGMaxNorm && mmax <= kGMaxNorm);  // (negated: NaNs are risky)
+        wave_exact = __ballot(risky) != 0;
+      }
+      if (wave_exact) continue;
+      // ---- the answer: the qualifying cells, exactly ---------------------------------------------------------------------------
+      unsigned k0 = 0u, k1 = 0u;
+#pragma unroll
+      for (int t = kGTiles - 1; t >= 0; --t) {  // (shifted in from the top: no 32 bit constants in registers)
+        k0 = (k0 << 1) | (tm0[t] <= thr0 ? 1u : 0u);
+        k1 = (k1 << 1) | (tm1[t] <= thr1 ? 1u : 0u);
+      }
+      while (__ballot((k0 | k1) != 0u)) {
+        const bool act = (k0 | k1) != 0u, from1 = k0 == 0u;
+        const unsigned mm = from1 ? k1 : k0;
+        const int t = act ? __builtin_ctz(mm) : 0;
+        k0 = from1 ? k0 : k0 & (k0 - 1u);
+        k1 = from1 && act ? k1 & (k1 - 1u) : k1;
+        // (a lane without a cell computes on a NaN query: its distances never beat anything)
+        const bool own = from1 == (h == 1);
+        const float qx = act ? (own ? X : OX) : nanf_, qy = own ? Y : OY, qz = own ? Z : OZ;
+        u64 cur = from1 ? best1 : best0;
+        const int row0 = 32 * t + 4 * h;
+        const unsigned gidx = (unsigned)(c * kGT + row0);
+#pragma unroll
+        for (int g2 = 0; g2 < 8; ++g2) {  // rows 8 (g2 / 2) + 2 (g2 % 2) + u, two at a time (registers)
+          const int ro = 8 * (g2 >> 1) + 2 * (g2 & 1);
+          const float4 pa = raw[row0 + ro], pb = raw[row0 + ro + 1];
+          const u64 ka = g_key(g_dist3(qx - pa.x, qy - pa.y, qz - pa.z), gidx + ro);
+          const u64 kb = g_key(g_dist3(qx - pb.x, qy - pb.y, qz - pb.z), gidx + ro + 1);
+          cur = ka < cur ? ka : cur;
+          cur = kb < cur ? kb : cur;
+        }
+        best0 = from1 ? best0 : cur;
+        best1 = from1 ? cur : best1;
+      }
     }
   }
-  m0 = __builtin_fminf(m0, __shfl_xor(m0, 32, 64));
-  m1 = __builtin_fminf(m1, __shfl_xor(m1, 32, 64));
-  // the owner of a query (lane 32 h + j holds query 32 h + j = column j of tile h) forms its threshold
-  const float thr_own = g_next((h ? m1 : m0) + slack);
-  const float thr0 = __shfl(thr_own, j, 64), thr1 = __shfl(thr_own, 32 + j, 64);
-
-  // ---- pass 2: survivors a_L <= thr ------------------------------------------------------------------------------------------------
-  int cnt0 = 0, cnt1 = 0;
-  unsigned short* l0p = lst + ((wave * 2 + 0) * kGCap) * 64 + lane;
-  unsigned short* l1p = lst + ((wave * 2 + 1) * kGCap) * 64 + lane;
-  for (int c = 0; c < chunks; ++c) {
-    if (chunks > 1) {  // (one panel: still in LDS)
-      __syncthreads();
-      stage(c);
-      __syncthreads();
-    }
-    const int rows = nt - c * kGT < kGT ? nt - c * kGT : kGT;
-    const int nti = (rows + 31) / 32;
-    const uint4* pl = &panel[h][j];
-
-    for (int t = 0; t < nti; ++t) {
-      const bf16x8 a = g_as_bf(pl[32 * t]);
-      const f32x16 z = {0};
-      const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, g_as_bf(b2[0]), z, 0, 0, 0);
-      const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, g_as_bf(b2[1]), z, 0, 0, 0);
-      const int base = c * kGT + 32 * t + 4 * h;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (acc0[r] <= thr0) {
-          l0p[(cnt0 < kGCap ? cnt0 : kGCap - 1) * 64] = (unsigned short)(base + (r & 3) + 8 * (r >> 2));
-          ++cnt0;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (acc1[r] <= thr1) {
-          l1p[(cnt1 < kGCap ? cnt1 : kGCap - 1) * 64] = (unsigned short)(base + (r & 3) + 8 * (r >> 2));
-          ++cnt1;
-        }
+  if (wave_exact) {  // all targets, index order, strict `<`: the textbook loop (magnitudes the bound does not cover)
+    for (int t = 0; t < nt; ++t) {
+      const float d = g_dist3(X - tb[3LL * t], Y - tb[3LL * t + 1], Z - tb[3LL * t + 2]);
+      if (d < bd) {
+        bd = d;
+        bi = t;
       }
     }
-  }
-  cntl[(wave * 2 + 0) * 64 + lane] = (unsigned char)(cnt0 < 255 ? cnt0 : 255);
-  cntl[(wave * 2 + 1) * 64 + lane] = (unsigned char)(cnt1 < 255 ? cnt1 : 255);
-  __syncthreads();
-
-  // ---- the answer: pinned distances of the survivors (owner lane: its query is column j of tile h) -----------------------------
-  const int c0 = cntl[(wave * 2 + h) * 64 + j], c1 = cntl[(wave * 2 + h) * 64 + 32 + j];
-  const bool bad = has && (c0 + c1 == 0 || c0 > kGCap || c1 > kGCap);
-  if (__ballot(bad)) {
-    exact_scan();
-  } else {
-    const int total = has ? c0 + c1 : 0;
-    const unsigned short* la = lst + ((wave * 2 + h) * kGCap) * 64 + j;
-    int tmax = total;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const int o = __shfl_xor(tmax, off, 64);
-      tmax = o > tmax ? o : tmax;
-    }
-    for (int e0 = 0; e0 < tmax; e0 += 4) {
-      int ti[4];
-      float tx[4], ty[4], tz[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u;
-        const int ec = e < total ? e : 0;
-        ti[u] = total > 0 ? (int)(ec < c0 ? la[ec * 64] : la[(ec - c0) * 64 + 32]) : 0;
-        tx[u] = tb[3LL * ti[u]];
-        ty[u] = tb[3LL * ti[u] + 1];
-        tz[u] = tb[3LL * ti[u] + 2];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float d = g_dist3(X - tx[u], Y - ty[u], Z - tz[u]);
-        const bool better = e0 + u < total && (d < bd || (d == bd && bi >= 0 && ti[u] < bi));
-        bd = better ? d : bd;
-        bi = better ? ti[u] : bi;
-      }
+  } else {  // the two lanes of a query merge; the owner keeps the result
+    const u64 o0 = __shfl_xor(best0, 32, 64), o1 = __shfl_xor(best1, 32, 64);
+    const u64 m0 = o0 < best0 ? o0 : best0, m1 = o1 < best1 ? o1 : best1;
+    const u64 mine = h ? m1 : m0;
+    const unsigned db = (unsigned)(mine >> 32);
+    if (db != __float_as_uint(1e32f)) {  // (a key at exactly 1e32 is the initial one, or a candidate the strict `<` refuses)
+      bd = __uint_as_float(db);
+      bi = (int)(unsigned)mine;
     }
   }
   store();
