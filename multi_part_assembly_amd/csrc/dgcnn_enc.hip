@@ -47,11 +47,21 @@
 #include <vector>
 
 #include "dg_knn.h"
+#include <stdlib.h>
+
 #include "dg_knn_fast.h"
+#include "dg_knn3_gate.h"
 
 namespace {
 
 using namespace dg;
+
+// EdgeConv stage 1's graph (C = 3): the matrix-core gated search (dg_knn3_gate.h) unless MPA_KNN3=scan asks for the
+// exhaustive knn3_kernel of rounds 2-5 (identical indices; the knob exists for A/B timing and the cross-check test)
+bool knn3_gate() {
+  const char* e = getenv("MPA_KNN3");
+  return !(e != nullptr && e[0] == 's');
+}
 using mpa::CoopWs;
 using mpa::coop_colsum;
 using mpa::kEB;
@@ -1474,8 +1484,12 @@ int dgcnn_forward_impl(const float* points, const float* valids, const float* co
       launch(dg_import_graph_kernel, dim3((unsigned)((R * kNbr + 255) / 256)), dim3(256), s, graphs[l], w.idx[l],
              (const int*)w.hdr);
     } else if (l == 0) {
-      launch(knn3_kernel<unsigned short>, dim3((unsigned)((N + DG_T3 - 1) / DG_T3), DG_KNN_GRID_Y(M)), dim3(DG_T3), s,
-             reinterpret_cast<const float*>(w.x0), (int)N, w.idx[0], (const int*)w.hdr);
+      if (knn3_gate())
+        launch(knn3_gate_kernel<unsigned short>, dim3((unsigned)((N + 255) / 256), DG_KNN_GRID_Y(M)), dim3(256), s,
+               reinterpret_cast<const float*>(w.x0), (int)N, w.idx[0], (const int*)w.hdr);
+      else
+        launch(knn3_kernel<unsigned short>, dim3((unsigned)((N + DG_T3 - 1) / DG_T3), DG_KNN_GRID_Y(M)), dim3(DG_T3), s,
+               reinterpret_cast<const float*>(w.x0), (int)N, w.idx[0], (const int*)w.hdr);
     } else {
       const float* x = w.hcat + kOff[l - 1];
       if (C == 64) knn_wide<64, unsigned short>(x, kCat, w.norm, w.knn, M, N, w.idx[l], (const int*)w.hdr, s);
@@ -1686,8 +1700,12 @@ extern "C" int mpa_knn_exact(const float* x, int64_t ld, int64_t n, int64_t N, i
   const KnnExactWs w = knn_exact_carve(static_cast<char*>(ws), n, N);  // hdr = {n, n*N}: every cloud is valid here
   launch(dg_set_hdr_kernel, dim3(1), dim3(1), s, w.hdr, (int)n, (int)N);
   if (C == 3) {
-    launch(knn3_kernel<int>, dim3((unsigned)((N + DG_T3 - 1) / DG_T3), DG_KNN_GRID_Y(n)), dim3(DG_T3), s, x, (int)N, idx,
-           (const int*)w.hdr);
+    if (knn3_gate())
+      launch(knn3_gate_kernel<int>, dim3((unsigned)((N + 255) / 256), DG_KNN_GRID_Y(n)), dim3(256), s, x, (int)N, idx,
+             (const int*)w.hdr);
+    else
+      launch(knn3_kernel<int>, dim3((unsigned)((N + DG_T3 - 1) / DG_T3), DG_KNN_GRID_Y(n)), dim3(DG_T3), s, x, (int)N, idx,
+             (const int*)w.hdr);
   } else if (C == 64) {
     knn_wide<64, int>(x, (int)ld, w.norm, w.knn, n, N, idx, (const int*)w.hdr, s);
   } else {

@@ -302,3 +302,39 @@ def test_fused_dgcnn_edge_sizes(cuda_device, M, N, valid):
         if int(v.sum()) * N > 64:  # (one 20-point cloud: the statistics of 20 rows make the gradients ill-conditioned)
             assert _rel(p.grad, q.grad) < 5e-3, k
         assert torch.isfinite(p.grad).all()
+
+
+@pytest.mark.parametrize("kind", ["surface", "offset", "tiny", "lattice", "dups", "line", "huge", "nan"])
+def test_knn3_gated_search_equals_the_exhaustive_kernel(cuda_device, monkeypatch, kind):
+    """C = 3: the matrix-core gated search (csrc/dg_knn3_gate.h, the default) against the exhaustive knn3_kernel
+    (MPA_KNN3=scan) — every index, in order — on clouds its bound has to survive: thin surfaces, clouds far from the origin
+    (the centring), 1e-3-sized parts, lattices and duplicated points (mass ties at the 20th place), collinear points, magnitudes
+    that switch the bound off, NaN coordinates; sizes from the smallest legal cloud to the largest."""
+    from oracle.knn import knn_exact as oracle_knn
+    g = torch.Generator().manual_seed(abs(hash(kind)) % 1000)
+    for n, N in ((2, 20), (3, 33), (2, 257), (4, 1000), (1, 1024)):
+        x = torch.randn(n, N, 3, generator=g) * 0.3
+        if kind == "surface":
+            x[..., 2] = 0.05 * torch.sin(7 * x[..., 0])
+        elif kind == "offset":
+            x = x * 0.1 + torch.tensor([300.0, -500.0, 40.0])
+        elif kind == "tiny":
+            x = x * 1e-3
+        elif kind == "lattice":
+            x = torch.randint(0, 5, (n, N, 3), generator=g).float() * 0.25
+        elif kind == "dups":
+            x[:, N // 2:] = x[:, : N - N // 2]
+        elif kind == "line":
+            x[..., 1:] = 0.0
+        elif kind == "huge":
+            x[:, 3] = 1e17
+        elif kind == "nan":
+            x[:, 5, 1] = float("nan")
+        monkeypatch.setenv("MPA_KNN3", "gate")
+        got = _hip_knn(x, 3)
+        monkeypatch.setenv("MPA_KNN3", "scan")
+        want = _hip_knn(x, 3)
+        assert torch.equal(got, want), (kind, n, N, float((got != want).float().mean()))
+        if kind not in ("huge", "nan") and N <= 257:
+            assert torch.equal(got, T(oracle_knn(x.numpy())).long()), (kind, n, N)
+    monkeypatch.delenv("MPA_KNN3", raising=False)

@@ -143,12 +143,14 @@ def test_fused_loss_equals_composed_path_at_full_size(cuda_device):
     np.testing.assert_allclose(gtf, gtc, rtol=1e-4, atol=1e-6)
 
 
-def _raw_assembly_forward(batch, qp, tp, mode, monkeypatch, with_part=False):
-    """Call the C ABI directly so that the arg-min arrays in the int workspace can be inspected."""
+def _raw_assembly_forward(batch, qp, tp, mode, monkeypatch, with_part=False, part="gate"):
+    """Call the C ABI directly so that the arg-min arrays in the int workspace can be inspected.  `part`: the per-part
+    Chamfer on the matrix-core gated search (csrc/gate_nn.hip, the default) or on the scan / leaf search of `mode`."""
     import ctypes
     from multi_part_assembly_amd import _lib
 
     monkeypatch.setenv("MPA_SHAPE_SEARCH", mode)
+    monkeypatch.setenv("MPA_PART_SEARCH", part)
     pcs, v = batch["part_pcs"], batch["part_valids"]
     qg, tg = Rotation3D(batch["part_quat"]).rot.contiguous(), batch["part_trans"].contiguous()
     B, P, N, _ = pcs.shape
@@ -173,13 +175,17 @@ def _raw_assembly_forward(batch, qp, tp, mode, monkeypatch, with_part=False):
 def _assert_searches_agree(batch, qp, tp, monkeypatch):
     """brute-force scan == grid-pruned search == leaf search == per-sample choice of the two: all four arg-min arrays (per-part Chamfer both ways,
     whole-shape Chamfer both ways) bit-equal on the valid parts, the five loss terms to summation order."""
-    lb, ib = _raw_assembly_forward(batch, qp, tp, "brute", monkeypatch, with_part=True)
+    lb, ib = _raw_assembly_forward(batch, qp, tp, "brute", monkeypatch, with_part=True, part="scan")
     valid = batch["part_valids"].bool()
-    for mode in ("grid", "leaf", "auto"):  # (auto: per sample, the grid or the leaves)
-        lm, im = _raw_assembly_forward(batch, qp, tp, mode, monkeypatch, with_part=True)
+    # (auto: per sample, the grid or the leaves; part = gate: the per-part term on the matrix-core gated search, scan: on
+    # the exhaustive scan (brute, grid) / the leaf search (leaf, auto))
+    for mode, part in (("brute", "gate"), ("grid", "gate"), ("grid", "scan"), ("leaf", "gate"), ("leaf", "scan"),
+                       ("auto", "gate"), ("auto", "scan")):
+        lm, im = _raw_assembly_forward(batch, qp, tp, mode, monkeypatch, with_part=True, part=part)
         for k in range(4):
-            assert torch.equal(ib[k][valid], im[k][valid]), (mode, k, int((ib[k][valid] != im[k][valid]).sum()))
-        np.testing.assert_allclose(lm.cpu().numpy(), lb.cpu().numpy(), rtol=2e-6, atol=1e-9, err_msg=mode)
+            assert torch.equal(ib[k][valid], im[k][valid]), (mode, part, k, int((ib[k][valid] != im[k][valid]).sum()))
+        np.testing.assert_allclose(lm.cpu().numpy(), lb.cpu().numpy(), rtol=2e-6, atol=1e-9, err_msg=f"{mode}/{part}")
+    monkeypatch.delenv("MPA_PART_SEARCH", raising=False)
 
 
 def test_fused_loss_at_benchmark_size_matches_oracle(cuda_device, monkeypatch):
