@@ -59,7 +59,9 @@ template <typename IdxT>
 __global__ __launch_bounds__(256, 3) void knn3_gate_kernel(const float* __restrict__ x4, int N, IdxT* __restrict__ idx,
                                                            const int* __restrict__ hdr) {
   constexpr int NT = kMaxN / 32;
-  __shared__ __attribute__((aligned(16))) float4 pts[kMaxN];     // x, y, z, |p|^2 (pinned); NaN past the cloud's end
+  // x, y, z, |p|^2 (pinned); NaN past the cloud's end.  Row r sits at r + r / 32: in the answer phase every lane reads its
+  // OWN tile, and tiles 512 bytes apart would all fall on the same four banks (a 64-way conflict, measured: 3x the kernel)
+  __shared__ __attribute__((aligned(16))) float4 pts[kMaxN + kMaxN / 32];
   __shared__ __attribute__((aligned(16))) uint4 panel[2][kMaxN];  // bf16 rows, plane = k-half; later the waves' queues
   __shared__ float redm[4], redn[4];
   static_assert(kK3QN * 64 * 6 <= 8192 && NT * 64 * 4 <= 8192, "a wave's scratch is a quarter of the panel");
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256, 3) void knn3_gate_kernel(const float* __restri
       lzb = k3_bf(lz);
     }
     const float m0 = k3_bf_f(m), r1 = m - m0, m1 = k3_bf_f(r1), m2 = r1 - m1;  // m = m0 + m1 + m2 exactly
-    pts[r] = rw;
+    pts[r + (r >> 5)] = rw;
     panel[0][r] = p0;
     panel[1][r] = uint4{lzb | (k3_bf(m0) << 16), k3_pk(m1, m2), 0u, 0u};
   }
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256, 3) void knn3_gate_kernel(const float* __restri
 
   // ---- this lane's query (thread = query; lanes past N shadow the last point and never store) ------------------------------
   const int qi = qb * 256 + (int)threadIdx.x, qc = qi < N ? qi : N - 1;
-  const float4 me = pts[qc];
+  const float4 me = pts[qc + (qc >> 5)];
   float mq;
   uint4 bq[2];
   {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256, 3) void knn3_gate_kernel(const float* __restri
       const int row = 32 * t + 8 * g4;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const float4 p = pts[row + u];
+        const float4 p = pts[33 * t + 8 * g4 + u];
         const float dot = __builtin_fmaf(me.z, p.z, __builtin_fmaf(me.y, p.y, me.x * p.x));
         const float s = (-p.w + 2.0f * dot) - me.w;
         queue_push(q, (u < 4 ? lo : hi) ? s : ninf, row + u);  // (rows past N: NaN scores, never pushed)

@@ -101,7 +101,9 @@ struct GateArgs {
 template <bool LOSS>
 __global__ __launch_bounds__(kGQ, 3) void gate_nn_kernel(const GateArgs g) {
   __shared__ uint4 panel[2][kGT];   // plane k-half h: row r -> 8 bf16
-  __shared__ float4 raw[kGT];       // the same targets' fp32 coordinates (NaN past the cloud's end)
+  // the same targets' fp32 coordinates (NaN past the cloud's end); row r at r + r / 32: in the answer phase every lane
+  // reads its own tile, and tiles 512 bytes apart would all fall on the same banks
+  __shared__ float4 raw[kGT + kGT / 32];
   __shared__ float red[kGW], redm[kGW];
   const int m = blockIdx.x / g.tiles, tile = blockIdx.x % g.tiles, dir = blockIdx.y;
   if (g.valids != nullptr && g.valids[m] == 0.0f) return;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(kGQ, 3) void gate_nn_kernel(const GateArgs g) {
       p1 = uint4{lzb | (g_bf(n0) << 16), g_pk(n1, n2), 0u, 0u};
       panel[0][r] = p0;
       panel[1][r] = p1;
-      raw[r] = rw;
+      raw[r + (r >> 5)] = rw;
     }
   };
   // the cells of the panel in LDS: per lane and query tile the minimum of a over each tile's 16 rows of this lane half
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(kGQ, 3) void gate_nn_kernel(const GateArgs g) {
 #pragma unroll
         for (int g2 = 0; g2 < 8; ++g2) {  // rows 8 (g2 / 2) + 2 (g2 % 2) + u, two at a time (registers)
           const int ro = 8 * (g2 >> 1) + 2 * (g2 & 1);
-          const float4 pa = raw[row0 + ro], pb = raw[row0 + ro + 1];
+          const float4 pa = raw[row0 + t + ro], pb = raw[row0 + t + ro + 1];
           const u64 ka = g_key(g_dist3(qx - pa.x, qy - pa.y, qz - pa.z), gidx + ro);
           const u64 kb = g_key(g_dist3(qx - pb.x, qy - pb.y, qz - pb.z), gidx + ro + 1);
           cur = ka < cur ? ka : cur;
