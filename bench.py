@@ -332,7 +332,9 @@ def kernel_table(kernels, nv, cfg, B, P):
         tf = L * (2.0 * M * D * 3 * D + 2.0 * M * D * D + 4.0 * M * D * FF + 4.0 * B * H * P * P * (D // H))
         add("transformer_forward", "transformer_forward", flops=tf)
         add("transformer_backward", "transformer_backward", flops=2.0 * tf)
-    # per-part Chamfer: 2 directions x N^2 pairs per valid part, 8.6 VALU lane-slots per pair
+    # per-part Chamfer: 2 directions x N^2 pairs per valid part.  lane_ops = what the exhaustive scan it replaced spends
+    # (8.6 VALU lane-slots per pair): the gated search (gate_nn.hip) bounds a pair with 1 / 1024 of a bf16
+    # matrix instruction and half a v_min3, so its "fraction" of that budget is a speed-up figure, not a utilisation
     add("assembly_part_chamfer", "assembly_part_chamfer", lane_ops=8.6 * 2.0 * nv * N * N, bytes=24.0 * 2 * nv * N)
     return rows
 
@@ -396,8 +398,11 @@ def chamfer_standalone(dev, reps=20):
                "GBps": alg / (ms * 1e-3) / 1e9, "hbm_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                "exhaustive_pair_evals_per_call": pairs}
         pruned = n1 * n2 >= 9_000_000
-        row["search"] = "grid-pruned exact (sort + search + hand-back scan, 3 launches)" if pruned else "exhaustive scan"
-        if pruned:
+        gated = not pruned and min(n1, n2) >= 192  # (chamfer.hip: MPA_CHAMFER_GATE_MIN)
+        row["search"] = ("grid-pruned exact (sort + search + hand-back scan, 3 launches)" if pruned else
+                         "matrix-core gated exact (gate_nn.hip: one bf16 MFMA per 32 x 32 pairs bounds them, the pinned "
+                         "arithmetic answers; 1 launch)" if gated else "exhaustive scan")
+        if pruned or gated:
             ms2, _, out2 = timed(a, b, 2, 3)
             row["exhaustive_scan_ms"] = ms2
             row["exhaustive_scan_valu_frac"] = 8.6 * pairs / (ms2 * 1e-3) / VALU_PEAK_LANE_OPS

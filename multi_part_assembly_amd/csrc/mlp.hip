@@ -9,6 +9,8 @@
 //   dY = alpha * dz + gammap * Y + betap,  dz = dOut * [out > 0]
 // followed by dW = dY^T X (row-chunked, fixed order), db = column sums of dY, dX = dY W.  No atomics: bit-reproducible.
 // Padded pairs are rows like any other (the reference's BatchNorm sees them too, dgl/network.py:139-144).
+#include <stdlib.h>
+
 #include "common.h"
 #include "coop_reduce.h"
 #include "dg_gemm.h"
@@ -255,6 +257,147 @@ __global__ __launch_bounds__(256) void ml_bwd_dy_kernel(const float* __restrict_
   }
 }
 
+// ---- few rows (R <= kSmallRows: the node MLPs' 640 rows): BatchNorm's reductions inside ONE launch each way ----------------
+// A block owns 32 channels and ALL rows (32 row lanes x 32 channel lanes), so the column sums need no second launch: the
+// three launches of the row-tiled path (sums -> coefficients -> dY; 8 + 7 + 10 us of launch and dependency latency for
+// 0.6 MB of data) become one, the forward's two (statistics -> apply) likewise.  Fixed-order sums: fp32 over a lane's
+// rows, double across the 32 row lanes.
+constexpr int kSbT = 1024;
+
+// forward: statistics from the GEMM's per-32-row table partial [tiles][C][2] -> bn [4][C] (+ running statistics), then
+// out = act(y * scale + shift) for the block's row slab.  grid = (C / 32, slabs): every slab recomputes its channels'
+// statistics (a few hundred additions); slab 0 writes them.
+__global__ __launch_bounds__(kSbT) void ml_small_bn_apply_kernel(
+    const float* __restrict__ partial, int tiles, const float* __restrict__ y, int R, int C, double count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float momentum, float eps, int relu, float* __restrict__ bn, float* __restrict__ out) {
+  __shared__ double red[32][32][2];
+  __shared__ float ss_[2][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  double s = 0.0, ss = 0.0;
+  for (int t = rl; t < tiles; t += 32) {
+    const float2 v = *reinterpret_cast<const float2*>(partial + ((long long)t * C + c) * 2);
+    s += (double)v.x;
+    ss += (double)v.y;
+  }
+  red[rl][cl][0] = s;
+  red[rl][cl][1] = ss;
+  __syncthreads();
+  if (rl == 0) {
+    s = ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      s += red[k][cl][0];
+      ss += red[k][cl][1];
+    }
+    const double mean = s / count;
+    double var = ss / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / __builtin_sqrt(var + (double)eps));
+    const float scale = gamma[c] * invstd, shift = beta[c] - (float)mean * scale;
+    ss_[0][cl] = scale;
+    ss_[1][cl] = shift;
+    if (blockIdx.y == 0) {
+      bn[c] = scale;
+      bn[C + c] = shift;
+      bn[2 * C + c] = (float)mean;
+      bn[3 * C + c] = invstd;
+      if (running_mean != nullptr) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+      }
+    }
+  }
+  __syncthreads();
+  const float scale = ss_[0][cl], shift = ss_[1][cl];
+  const int rows_per = (R + (int)gridDim.y - 1) / (int)gridDim.y, r0 = blockIdx.y * rows_per;
+  const int r1 = r0 + rows_per < R ? r0 + rows_per : R;
+#pragma unroll 8
+  for (int r = r0 + rl; r < r1; r += 32) {
+    float z = __builtin_fmaf(y[(long long)r * C + c], scale, shift);
+    if (relu) z = z > 0.0f ? z : 0.0f;
+    out[(long long)r * C + c] = z;
+  }
+}
+
+// backward: column sums of dz and dz * xhat -> coefficients (+ dgamma, dbeta) -> dY = alpha dz + gammap y + betap and its
+// column sums (the bias gradient, colsum [C]).  grid = C / 32.
+__global__ __launch_bounds__(kSbT) void ml_small_bn_bwd_kernel(
+    const float* __restrict__ g, const float* __restrict__ out, const float* __restrict__ y, const float* __restrict__ bn,
+    int R, int C, int relu, double count, const float* __restrict__ gamma, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, float* __restrict__ dy, float* __restrict__ colsum) {
+  __shared__ double red[32][32][2];
+  __shared__ float cf[3][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  const float mean = bn[2 * C + c], invstd = bn[3 * C + c];
+  float s1 = 0.0f, s2 = 0.0f;
+  constexpr int U = 8;  // rows in flight per lane (a rolled loop waits for its three loads row by row)
+  for (int r0 = rl; r0 < R; r0 += 32 * U) {
+    float gv[U], ov[U], yv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + 32 * u < R ? r0 + 32 * u : rl;  // (clamped: a valid row, masked below)
+      const long long o = (long long)r * C + c;
+      gv[u] = g[o], ov[u] = out[o], yv[u] = y[o];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float d = (r0 + 32 * u < R && (relu == 0 || ov[u] > 0.0f)) ? gv[u] : 0.0f;
+      s1 += d;
+      s2 = __builtin_fmaf(d, (yv[u] - mean) * invstd, s2);
+    }
+  }
+  red[rl][cl][0] = (double)s1;
+  red[rl][cl][1] = (double)s2;
+  __syncthreads();
+  if (rl == 0) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      a += red[k][cl][0];
+      b += red[k][cl][1];
+    }
+    const float alpha = gamma[c] * invstd;
+    const float gammap = (float)(-(double)alpha * b / count * (double)invstd);
+    cf[0][cl] = alpha;
+    cf[1][cl] = gammap;
+    cf[2][cl] = (float)(-(double)alpha * a / count - (double)gammap * (double)mean);
+    dgamma[c] = (float)b;
+    dbeta[c] = (float)a;
+  }
+  __syncthreads();
+  const float alpha = cf[0][cl], gammap = cf[1][cl], betap = cf[2][cl];
+  float sd = 0.0f;
+  for (int r0 = rl; r0 < R; r0 += 32 * U) {
+    float gv[U], ov[U], yv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + 32 * u < R ? r0 + 32 * u : rl;
+      const long long o = (long long)r * C + c;
+      gv[u] = g[o], ov[u] = out[o], yv[u] = y[o];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r0 + 32 * u < R) {
+        const float d = (relu == 0 || ov[u] > 0.0f) ? gv[u] : 0.0f;
+        const float v = __builtin_fmaf(alpha, d, __builtin_fmaf(gammap, yv[u], betap));
+        dy[(long long)(r0 + 32 * u) * C + c] = v;
+        sd += v;
+      }
+    }
+  }
+  __syncthreads();  // (red is reused)
+  red[rl][cl][0] = (double)sd;
+  __syncthreads();
+  if (rl == 0) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) a += red[k][cl][0];
+    colsum[c] = (float)a;
+  }
+}
+
 __global__ void ml_transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= rows * cols) return;
@@ -374,6 +517,12 @@ int ml_check(int64_t R, int64_t K, int64_t N, const char* who) {
   return MPA_OK;
 }
 
+// MPA_ML_SMALL=tiled: the row-tiled BatchNorm launches for every row count (A/B timing and the cross-check test)
+bool ml_small_fused() {
+  const char* e = getenv("MPA_ML_SMALL");
+  return !(e != nullptr && e[0] == 't');
+}
+
 template <typename Kern, typename... Args>
 void launch(Kern kern, dim3 grid, dim3 block, hipStream_t s, Args... args) {
   hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
@@ -445,6 +594,12 @@ extern "C" int mpa_mlp_layer_forward(const float* x, int64_t ldx, const float* w
       const int tiles32 = (int)((R + 31) / 32);
       g.stats = m.partial;
       tfg::launch_gemm<tfg::EPI_STATS>(g, s);
+      if (ml_small_fused()) {  // statistics and activation in one launch
+        launch(ml_small_bn_apply_kernel, dim3((unsigned)(N / 32), (unsigned)((R + 255) / 256)), dim3(kSbT), s,
+               (const float*)m.partial, tiles32, (const float*)m.ypre, (int)R, (int)N, (double)R, gamma, beta, running_mean,
+               running_var, momentum, eps, relu, m.bn, out);
+        return mpa::check_launch("mlp_layer_forward");
+      }
       launch(ml_bn_finalize_kernel, dim3((unsigned)(N / 64), (unsigned)((tiles32 + kEB - 1) / kEB)), dim3(64 * kSlices), s,
              (const float*)m.partial, tiles32, (int)N, (double)R, gamma, beta, running_mean, running_var, momentum, eps,
              m.bn, cw);
@@ -519,14 +674,21 @@ extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int
   const MlWs m = ml_carve(static_cast<char*>(ws), R, K, N);
   const int tiles = (int)((R + kRT - 1) / kRT);
   const CoopWs cw{m.stage, m.tickets};
-  if (gamma != nullptr) {
-    launch(ml_bwd_sums_kernel, dim3((unsigned)tiles), dim3(256), s, grad_out, out, (const float*)m.ypre,
-           (const float*)m.bn, (int)R, (int)N, relu, m.partial);
-    launch(ml_bwd_coef_kernel, dim3((unsigned)(N / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
-           (const float*)m.partial, tiles, (int)N, (double)R, gamma, (const float*)m.bn, m.coef, grad_gamma, grad_beta, cw);
+  int bias_tiles = tiles;  // rows of the column-sum table the bias gradient is reduced from
+  if (gamma != nullptr && R <= kSmallRows && ml_small_fused()) {  // sums, coefficients, dY and its column sums: one launch
+    launch(ml_small_bn_bwd_kernel, dim3((unsigned)(N / 32)), dim3(kSbT), s, grad_out, out, (const float*)m.ypre,
+           (const float*)m.bn, (int)R, (int)N, relu, (double)R, gamma, grad_gamma, grad_beta, m.dy, m.partial);
+    bias_tiles = 1;
+  } else {
+    if (gamma != nullptr) {
+      launch(ml_bwd_sums_kernel, dim3((unsigned)tiles), dim3(256), s, grad_out, out, (const float*)m.ypre,
+             (const float*)m.bn, (int)R, (int)N, relu, m.partial);
+      launch(ml_bwd_coef_kernel, dim3((unsigned)(N / 64), (unsigned)((tiles + kEB - 1) / kEB)), dim3(64 * kSlices), s,
+             (const float*)m.partial, tiles, (int)N, (double)R, gamma, (const float*)m.bn, m.coef, grad_gamma, grad_beta, cw);
+    }
+    launch(ml_bwd_dy_kernel, dim3((unsigned)tiles), dim3(256), s, grad_out, out, (const float*)m.ypre,
+           gamma != nullptr ? (const float*)m.coef : (const float*)nullptr, (int)R, (int)N, relu, m.dy, m.partial);
   }
-  launch(ml_bwd_dy_kernel, dim3((unsigned)tiles), dim3(256), s, grad_out, out, (const float*)m.ypre,
-         gamma != nullptr ? (const float*)m.coef : (const float*)nullptr, (int)R, (int)N, relu, m.dy, m.partial);
   // dW [N][K] = dY^T X (row chunks, then a fixed-order sum) and db = the column sums of dY's per-tile table
   {
     // enough chunks for ~512 blocks in the launch, each at least 64 rows
@@ -550,7 +712,7 @@ extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int
     if (grad_b != nullptr) {
       const int blocks_w = (int)((elems + 31) / 32);
       launch(dg::gemm_tn_reduce2_kernel, dim3((unsigned)(blocks_w + (N + 31) / 32)), dim3(256), s, (const float*)m.tnpart,
-             chunks, elems, grad_w, blocks_w, (const float*)m.partial, tiles, (long long)N, grad_b);
+             chunks, elems, grad_w, blocks_w, (const float*)m.partial, bias_tiles, (long long)N, grad_b);
     } else {
       dg::launch_tn_reduce(m.tnpart, chunks, elems, grad_w, s);
     }
