@@ -49,8 +49,12 @@ const char* mpa_last_error(void);
  *   candidate below 1e32 (n2 == 0, NaN/huge input) gets dist = 1e32f, idx = -1 (:60-61).
  *   dist2/idx2: the same with the roles of the clouds swapped.
  *
- * Two searches stand behind the call, with identical results (tests/test_chamfer_gpu.py):
+ * Three searches stand behind the call, with identical results (tests/test_chamfer_gpu.py, tests/test_gate_gpu.py):
  *   - the exhaustive scan: n1 * n2 pair evaluations per sample and direction (what the reference does);
+ *   - the matrix-core gated search (csrc/gate_nn.hip) for clouds of a few hundred to a few thousand points — the per-part
+ *     call of rot_points_cd_loss, [B*P, N, 3] against itself (utils/loss.py:113-138): one bf16 matrix instruction per
+ *     32 x 32 pairs bounds every pair, the pinned fp32 arithmetic answers from the few candidates that can win.  No
+ *     workspace.  Chosen when min(n1, n2) >= 192 and the grid-pruned search below is not;
  *   - an exact grid-pruned search (csrc/grid_nn.hip) for large clouds — the whole-shape call of shape_cd_loss,
  *     [32, 20000, 3] against itself (utils/loss.py:173-199), is 2.56e10 pair evaluations exhaustively and a few
  *     dozen candidates per query pruned.  It needs scratch memory, which the CALLER provides (the library never
@@ -70,7 +74,8 @@ int mpa_chamfer_forward(const float* xyz1, const float* xyz2, int64_t batch, int
 /* Diagnostic twin of mpa_chamfer_forward that pins the search (all bit-identical in their results):
  * 0 = direct compare/select per pair, 1 = fused-form gate + exact recheck (fastest on tie-free clouds),
  * 2 = exact chunk-minimum scan (the exhaustive default: insensitive to duplicated points), 3 = the grid-pruned
- * search at ANY size (needs the workspace), -1 = by size as mpa_chamfer_forward does. */
+ * search at ANY size (needs the workspace), 4 = the matrix-core gated search (any n1, n2 in 1 .. 32768; no workspace),
+ * -1 = by size as mpa_chamfer_forward does. */
 int mpa_chamfer_forward_variant(const float* xyz1, const float* xyz2, int64_t batch, int64_t n1,
                                 int64_t n2, float* dist1, int64_t* idx1, float* dist2,
                                 int64_t* idx2, int variant, void* workspace, int64_t workspace_bytes,

@@ -53,8 +53,10 @@ def chamfer_forward(xyz1: torch.Tensor, xyz2: torch.Tensor, variant: int | None 
 
     xyz1 (B, N1, 3), xyz2 (B, N2, 3); dist in the input dtype, idx int64 (chamfer_kernel.cu:129-132).
     Large fp32 clouds (min(N1, N2) >= 512 and N1 * N2 >= 9e6: the whole-shape call of shape_cd_loss) are answered by
-    the exact grid-pruned search, everything else by the exhaustive scan — same results, bit for bit.
-    `variant` (fp32 only) pins the search for tests and A/B timing: 0 / 1 / 2 exhaustive scan variants, 3 grid-pruned.
+    the exact grid-pruned search, mid-sized ones (min(N1, N2) >= 192: the per-part call of rot_points_cd_loss) by the
+    matrix-core gated search, small ones by the exhaustive scan — same results, bit for bit.
+    `variant` (fp32 only) pins the search for tests and A/B timing: 0 / 1 / 2 exhaustive scan variants, 3 grid-pruned,
+    4 matrix-core gated.
     """
     _check_cloud("xyz1", xyz1)
     _check_cloud("xyz2", xyz2)

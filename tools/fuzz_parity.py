@@ -8,7 +8,10 @@ live in tests/).  Every case draws its own sizes, masks and pose regime from the
          of non-finite samples) vs its exhaustive scan on clouds built to break it — blobs at different scales and offsets,
          planes and lines, far outliers, runs of repeated points, 1e3-filled padded parts, NaN / inf / huge coordinates,
          1 to 6000 points per cloud: all four outputs bit-equal (small cases also against oracle/chamfer_ref.c);
+  cgate  the operator's matrix-core gated search (variant 4, csrc/gate_nn.hip) vs the exhaustive scan on the same clouds,
+         1 to 3000 points (several LDS panels), coincident clouds, one-distinct-target clouds: all four outputs bit-equal;
   knn    mpa_knn_exact (C = 3, 64, 128) vs oracle/knn_ref.c: every neighbour index, in order;
+  knn3g  C = 3: the gated search (csrc/dg_knn3_gate.h) vs the exhaustive knn3_kernel on those clouds, index for index;
   glue   the graph-network glue kernels vs float64 library ops;
   nets   PointNet (random part counts, masks, point counts, negative / zero BatchNorm weights) and transformer + pose head
          (random widths, depths, masks, odd head widths) vs oracle/nets.py evaluated in float64: features and every
@@ -52,8 +55,9 @@ bad = []
 edge = []  # cases at which the float64 oracle itself is discontinuous (a 2e-6 .. 2e-5 relative input change moves its gradients by > 1e-3)
 
 
-def raw_loss(batch, qp, tp, mode, all_four=False):
+def raw_loss(batch, qp, tp, mode, all_four=False, part="gate"):
     os.environ["MPA_SHAPE_SEARCH"] = mode
+    os.environ["MPA_PART_SEARCH"] = part  # the per-part term: matrix-core gated search (default) | the scan / leaves of `mode`
     pcs, v = batch["part_pcs"], batch["part_valids"]
     qg, tg = Rotation3D(batch["part_quat"]).rot.contiguous(), batch["part_trans"].contiguous()
     B, P, N, _ = pcs.shape
@@ -100,12 +104,14 @@ def case_loss(rng):
         qp = torch.nn.functional.normalize(qg + eps * torch.randn(B, P, 4, generator=g).to(dev), dim=-1).contiguous()
         tp = (batch["part_trans"] + eps * torch.randn(B, P, 3, generator=g).to(dev)).contiguous()
         regime = f"near-gt eps={eps}"
-    lb, ib = raw_loss(batch, qp, tp, "brute", all_four=True)
+    lb, ib = raw_loss(batch, qp, tp, "brute", all_four=True, part="scan")
     valid = batch["part_valids"].bool()
     fin = torch.isfinite(lb)
     ok = True
-    for mode in ("grid", "leaf", "auto"):  # the grid of rounds 1-4, the k-d leaves (round 5), the per-sample route
-        lm, im = raw_loss(batch, qp, tp, mode, all_four=True)
+    # the grid of rounds 1-4, the k-d leaves (round 5), the per-sample route; the per-part term on the gated search
+    # (gate_nn.hip) and, for the leaves, on the leaf search as well
+    for mode, part in (("brute", "gate"), ("grid", "gate"), ("leaf", "gate"), ("leaf", "scan"), ("auto", "gate")):
+        lm, im = raw_loss(batch, qp, tp, mode, all_four=True, part=part)
         ok = ok and all(torch.equal(ib[k][valid], im[k][valid]) for k in range(4))
         ok = ok and bool(torch.equal(fin, torch.isfinite(lm)))
         ok = ok and bool(((lm[fin] - lb[fin]).abs() <= 2e-6 * lb[fin].abs() + 1e-9).all())
@@ -181,6 +187,45 @@ def case_cgrid(rng):
         ref = oc.chamfer_forward(a, b)
         ok = all(np.array_equal(g.cpu().numpy(), w, equal_nan=True) for g, w in zip(fast, ref))
     return ok, f"B={B} n1={n1} n2={n2}"
+
+
+def case_cgate(rng):
+    """The matrix-core gated search (variant 4, csrc/gate_nn.hip) on the clouds built to break a spatial index — here: to
+    break a BOUND (scales from 1e-3 to 1e8 in one cloud, offsets of hundreds of units, planes, lines, lattices, runs of
+    repeated points, coincident clouds, NaN / inf / huge coordinates), 1 to 3000 points, several LDS panels per cloud."""
+    B = int(rng.integers(1, 10))
+    big = rng.random() < 0.4
+    n1 = int(rng.integers(1, 3000 if big else 700))
+    n2 = int(rng.integers(1, 3000 if big else 700))
+    a, b = _wild_cloud(rng, B, n1), _wild_cloud(rng, B, n2)
+    r = rng.random()
+    if r < 0.25:
+        m = min(n1, n2)
+        b[:, :m] = a[:, :m]  # coincident clouds: zero distances everywhere
+    elif r < 0.35:
+        b[:] = b[:, :1]  # one distinct target (the zero-padded parts of the per-part call)
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    with np.errstate(all="ignore"):
+        fast = C.chamfer_forward(ta, tb, variant=4)
+        slow = C.chamfer_forward(ta, tb, variant=2)
+    ok = all(torch.equal(f, s) or np.array_equal(f.cpu().numpy(), s.cpu().numpy(), equal_nan=True) for f, s in zip(fast, slow))
+    if ok and B * n1 * n2 <= 4_000_000:
+        ref = oc.chamfer_forward(a, b)
+        ok = all(np.array_equal(g.cpu().numpy(), w, equal_nan=True) for g, w in zip(fast, ref))
+    return ok, f"B={B} n1={n1} n2={n2}"
+
+
+def case_knn3g(rng):
+    """C = 3 kNN: the gated search (dg_knn3_gate.h) vs the exhaustive knn3_kernel on the same wild clouds, index for index."""
+    n, N = int(rng.integers(1, 6)), int(rng.integers(20, 1025))
+    x = torch.from_numpy(_wild_cloud(rng, n, N))
+    rows = torch.cat([x.reshape(n * N, 3), torch.zeros(n * N, 1)], dim=1).to(dev).contiguous()
+    os.environ["MPA_KNN3"] = "gate"
+    got = knn_exact(rows, n, N, 3).cpu()
+    os.environ["MPA_KNN3"] = "scan"
+    want = knn_exact(rows, n, N, 3).cpu()
+    os.environ.pop("MPA_KNN3")
+    return bool(torch.equal(got, want)), f"n={n} N={N}"
 
 
 def case_knn(rng):
@@ -747,7 +792,7 @@ def case_repro(rng):
 families = [("loss", case_loss), ("chamfer", case_chamfer), ("knn", case_knn), ("glue", case_glue), ("repro", case_repro),
             ("nets", case_nets), ("dgcnn", case_dgcnn), ("step", case_step),
             ("gnn", case_gnn), ("global", case_global),
-            ("adam", case_adam), ("graph", case_graph), ("cgrid", case_cgrid)]
+            ("adam", case_adam), ("graph", case_graph), ("cgrid", case_cgrid), ("cgate", case_cgate), ("knn3g", case_knn3g)]
 
 
 def run_case(name, seed):
