@@ -15,8 +15,6 @@
 //     dropout and the value product never leave LDS/registers.
 //   * dropout masks come from a counter-based hash of (seed, site, element) and are REGENERATED in backward.
 // All reductions are fixed-order (no atomics): the step stays bit-reproducible.
-#include <stdlib.h>
-
 #include "common.h"
 #include "tf_gemm.h"
 
@@ -758,7 +756,6 @@ struct TfLayout {
   float *x_final, *stats_f;
   // backward scratch
   float *g_a, *g_b, *g_c, *gd_out, *gd_mid, *dz, *dqkv, *lnpart;
-  float *gd_out2, *gd_mid2, *dz2, *dqkv2;
   int64_t total;
 };
 
@@ -791,45 +788,9 @@ TfLayout tf_carve(float* base, const TfDims& d) {
   w.gd_mid = take(d.M * d.D);
   w.dz = take(d.M * d.FF);
   w.dqkv = take(d.M * 3 * d.D);
-  // second set (odd layers) of what a layer's weight gradients read, so that they can run on a side stream beside the
-  // next layer's chain (mpa_transformer_backward)
-  w.gd_out2 = take(d.M * d.D);
-  w.gd_mid2 = take(d.M * d.D);
-  w.dz2 = take(d.M * d.FF);
-  w.dqkv2 = take(d.M * 3 * d.D);
   w.lnpart = take((2 * d.L + 1) * ((d.M + 3) / 4) * 2 * d.D);  // one partial table per LayerNorm
   w.total = p - base;
   return w;
-}
-
-// The library's side stream for the weight gradients of the backward pass (off the critical path: nothing needs them
-// before the optimiser) with one fork / done event pair per layer.  Created on first use outside a stream capture; if
-// that fails, or MPA_TF_WGRAD=inline, the weight gradients stay in line as in rounds 1-5a.
-struct SideLane {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork[16] = {}, done[16] = {};
-  int device = -1;
-  bool ok = false, tried = false;
-};
-SideLane* side_lane(hipStream_t s) {
-  static SideLane L;
-  if (const char* e = getenv("MPA_TF_WGRAD"))
-    if (e[0] == 'i') return nullptr;
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  if (!L.tried) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;  // not now
-    L.tried = true;
-    bool ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; ok && i < 16; ++i)
-      ok = hipEventCreateWithFlags(&L.fork[i], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&L.done[i], hipEventDisableTiming) == hipSuccess;
-    L.ok = ok;
-    L.device = dev;
-    if (!ok) (void)hipGetLastError();
-  }
-  return L.ok && L.device == dev ? &L : nullptr;
 }
 
 int tf_check(const TfDims& d, const char* who) {
@@ -961,17 +922,10 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
   // final LayerNorm backward -> g_a = d x_final
   // every LayerNorm backward below also leaves the dropout-masked copy its consumers need (see ln_bwd_kernel)
   const bool dr = dropout_p > 0.0f;
-  // With dropout on, everything a layer's weight gradients read (the two masked gradient copies, dz, dqkv and the
-  // layer's saved activations) is written once per layer and by nothing else: two sets of those buffers (even / odd
-  // layers) let the grouped weight-gradient launch of layer l run on the side stream beside layer l - 1's chain of small
-  // dependent kernels, which leaves most of the chip idle.  It must be done before layer l - 1's last kernel writes the
-  // masked copy for layer l - 2 (the same set again).  Without dropout the operands are the rotating g buffers: in line.
-  SideLane* lane = dr ? side_lane(s) : nullptr;
-  auto set = [&](int l, float* even, float* odd) { return lane != nullptr && (l & 1) ? odd : even; };
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, grad_out, w.x_final, w.stats_f, fin[0],
                      (const float*)nullptr, M, Di, w.g_a, ln_site((int)(2 * L), gfin[0], gfin[1]), drop,
                      (unsigned)((L - 1) * S_PER_LAYER + S_FFN_OUT),
-                     dr ? set((int)L - 1, w.gd_out, w.gd_out2) : (float*)nullptr);
+                     dr ? w.gd_out : (float*)nullptr);
   float* g = w.g_a;      // gradient w.r.t. the current layer's output
   float* spare = w.g_b;  // rotating buffers
   float* spare2 = w.g_c;
@@ -980,62 +934,49 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     float* const* gp = grad_params + l * P_PER_LAYER;
     const TfWs& t = w.layer[l];
     const unsigned site0 = (unsigned)(l * S_PER_LAYER);
-    float* const dz = set(l, w.dz, w.dz2);
-    float* const dqkv = set(l, w.dqkv, w.dqkv2);
-    float* const gd_mid = set(l, w.gd_mid, w.gd_mid2);
     // ---- FFN: x_out = x_mid + drop(f . W2^T + b2),  f = drop(relu(LN2(x_mid) . W1^T + b1));  the dropout mask of
     // the incoming gradient is regenerated inside the consumers (no masked copy is materialised)
     // (the layer's four weight gradients are off the critical path and all their operands stay intact until the
-    // layer's last LayerNorm backward: they go out as ONE launch — on the side stream, or just before that kernel)
+    // layer's last LayerNorm backward: they go out as ONE launch just before it)
     WgradArgs wl[4];
-    const float* gdo = dr ? set(l, w.gd_out, w.gd_out2) : g;  // drop-masked g (site S_FFN_OUT of this layer)
+    const float* gdo = dr ? w.gd_out : g;  // drop-masked g (site S_FFN_OUT of this layer)
     wl[0] = wgrad_args(gdo, t.f, gp[P_W2], gp[P_B2], M, Di, FFi);
-    GemmArgs ga = gemm_args(gdo, pp[P_W2], nullptr, dz, M, FFi, Di);  // W2 is [D, FF] = [K, N]
+    GemmArgs ga = gemm_args(gdo, pp[P_W2], nullptr, w.dz, M, FFi, Di);  // W2 is [D, FF] = [K, N]
     ga.resid = t.f;
     ga.drop = drop;  // the epilogue's keep-scale of the hidden layer's dropout (f > 0 <=> kept and active)
     launch_gemm<EPI_RELU_MASK, true>(ga, s);  // dz = d(pre-activation)
-    wl[1] = wgrad_args(dz, t.h2, gp[P_W1], gp[P_B1], M, FFi, Di);
-    launch_gemm<EPI_NONE, true>(gemm_args(dz, pp[P_W1], nullptr, spare2, M, Di, FFi), s);  // d LN2 output
+    wl[1] = wgrad_args(w.dz, t.h2, gp[P_W1], gp[P_B1], M, FFi, Di);
+    launch_gemm<EPI_NONE, true>(gemm_args(w.dz, pp[P_W1], nullptr, spare2, M, Di, FFi), s);  // d LN2 output
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, spare2, t.x_mid, t.stats2, pp[P_G2], g,
                        M, Di, spare, ln_site(2 * l + 1, gp[P_G2], gp[P_BE2]), drop, site0 + S_SA_OUT,
-                       dr ? gd_mid : (float*)nullptr);  // spare = d x_mid
+                       dr ? w.gd_mid : (float*)nullptr);  // spare = d x_mid
     float* g_mid = spare;
     spare = g;
     // ---- attention block: x_mid = x_in + drop(o . Wo^T + bo)
-    const float* gdm = dr ? gd_mid : g_mid;  // drop-masked g_mid (site S_SA_OUT)
+    const float* gdm = dr ? w.gd_mid : g_mid;  // drop-masked g_mid (site S_SA_OUT)
     wl[2] = wgrad_args(gdm, t.o, gp[P_WO], gp[P_BO], M, Di, Di);
     launch_gemm<EPI_NONE, true>(gemm_args(gdm, pp[P_WO], nullptr, spare2, M, Di, Di), s);  // d o
     if (P <= 32 && Di / (int)H == 32)
       hipLaunchKernelGGL(attn_bwd_mfma_kernel<1>, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
-                         (int)H, drop, site0 + S_ATTN, dqkv);
+                         (int)H, drop, site0 + S_ATTN, w.dqkv);
     else if (P <= 32 && Di / (int)H == 64)
       hipLaunchKernelGGL(attn_bwd_mfma_kernel<2>, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
-                         (int)H, drop, site0 + S_ATTN, dqkv);
+                         (int)H, drop, site0 + S_ATTN, w.dqkv);
     else
       hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
-                         (int)H, drop, site0 + S_ATTN, dqkv);
-    wl[3] = wgrad_args(dqkv, t.h1, gp[P_WQKV], gp[P_BQKV], M, 3 * Di, Di);
-    if (lane != nullptr) {  // every operand of the four exists now: fork
-      (void)hipEventRecord(lane->fork[l], s);
-      (void)hipStreamWaitEvent(lane->stream, lane->fork[l], 0);
-      launch_wgrad_group(wl, 4, lane->stream);
-      (void)hipEventRecord(lane->done[l], lane->stream);
-    }
-    launch_gemm<EPI_NONE, true>(gemm_args(dqkv, pp[P_WQKV], nullptr, spare2, M, Di, 3 * Di), s);  // d LN1 out
-    if (lane == nullptr) launch_wgrad_group(wl, 4, s);  // before the kernel below overwrites g's buffer
-    // the kernel below writes the masked copy of layer l - 1's incoming gradient into the set layer l + 1's weight
-    // gradients read from
-    if (lane != nullptr && l + 1 < (int)L) (void)hipStreamWaitEvent(s, lane->done[l + 1], 0);
+                         (int)H, drop, site0 + S_ATTN, w.dqkv);
+    wl[3] = wgrad_args(w.dqkv, t.h1, gp[P_WQKV], gp[P_BQKV], M, 3 * Di, Di);
+    launch_gemm<EPI_NONE, true>(gemm_args(w.dqkv, pp[P_WQKV], nullptr, spare2, M, Di, 3 * Di), s);  // d LN1 out
+    launch_wgrad_group(wl, 4, s);  // before the kernel below overwrites g's buffer
     float* g_in = l == 0 ? grad_tokens : spare;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, spare2, t.x_in, t.stats1, pp[P_G1], g_mid,
                        M, Di, g_in, ln_site(2 * l, gp[P_G1], gp[P_BE1]), drop, (unsigned)((l - 1) * S_PER_LAYER + S_FFN_OUT),
-                       dr && l > 0 ? set(l - 1, w.gd_out, w.gd_out2) : (float*)nullptr);
+                       dr && l > 0 ? w.gd_out : (float*)nullptr);  // (the grouped launch above has read gd_out)
     if (l > 0) {  // next layer down: its output gradient is g_in; g_mid's buffer is free again
       g = spare;
       spare = g_mid;
     }
   }
-  if (lane != nullptr) (void)hipStreamWaitEvent(s, lane->done[0], 0);  // join: the call's work is ordered on `s` again
   hipLaunchKernelGGL(ln_reduce_kernel, dim3((unsigned)(2 * D / 64), (unsigned)(2 * L + 1)), dim3(1024), 0, s,
                      (const float*)w.lnpart, ln_stride, (int)lnblocks, Di, sites);
   return mpa::check_launch("transformer_backward");

@@ -680,38 +680,3 @@ def test_two_trainers_walk_the_same_trajectory_at_the_benchmark_size(cuda_device
             assert torch.equal(a.flat.flat_param, b.flat.flat_param), f"trajectories diverge by step {i}"
     assert torch.equal(a.flat.flat_param, b.flat.flat_param)
 
-
-def test_transformer_weight_gradients_on_the_side_stream_equal_the_inline_launches(cuda_device, monkeypatch):
-    """Dropout on (the training configuration): the layers' weight-gradient launches run on the library's side stream beside
-    the next layer's chain, reading the even / odd buffer sets (csrc/transformer.hip).  Same kernels, same operands: every
-    gradient bit-equal to MPA_TF_WGRAD=inline, over several back-to-back steps (the buffer sets are reused every second
-    layer and every step), for even and odd layer counts and a single layer."""
-    from multi_part_assembly_amd.transformer import _TransformerFn
-    for L in (1, 3, 4):
-        torch.manual_seed(11 + L)
-        B, P, D, H, FF = 32, 20, 256, 8, 1024
-        enc = TransformerEncoder(D, H, FF, L, norm_first=True, dropout=0.1).to(cuda_device).train()
-        g = torch.Generator().manual_seed(L)
-        num = torch.randint(2, P + 1, (B,), generator=g)
-        valid = (torch.arange(P)[None] < num[:, None]).reshape(-1).float().to(cuda_device)
-        toks = [torch.randn(B, P, D, generator=g).to(cuda_device) for _ in range(3)]
-        w = torch.randn(B, P, D, generator=g).to(cuda_device)
-
-        def run(mode):
-            monkeypatch.setenv("MPA_TF_WGRAD", mode)
-            res = []
-            for step, t in enumerate(toks):
-                for p in enc.parameters():
-                    p.grad = None
-                x = t.clone().requires_grad_()
-                out = _TransformerFn.apply(x, valid, H, 0.1, 1234 + step, None, *enc._params())
-                (out * w).sum().backward()
-                res.append([x.grad.clone()] + [p.grad.clone() for p in enc.parameters()])
-            torch.cuda.synchronize()
-            return res
-
-        a, b = run("inline"), run("overlap")
-        for sa, sb in zip(a, b):
-            for x, y in zip(sa, sb):
-                assert torch.equal(x, y), L
-    monkeypatch.delenv("MPA_TF_WGRAD", raising=False)
