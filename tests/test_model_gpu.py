@@ -121,8 +121,21 @@ def test_encoders_outside_the_kernels_instantiation_take_the_library_path(cuda_d
         (fb * w).sum().backward()
         assert torch.equal(fb[valid == 0], torch.zeros_like(fb[valid == 0]))
         np.testing.assert_allclose(fa.detach().cpu().numpy(), fb.detach().cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=arch)
-        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
-            assert _rel(p.grad.cpu().numpy(), q.grad.cpu().numpy()) < 5e-3, (arch, k)
+        # The library path's backward scatters with float atomics (index / gather gradients of PyTorch-ROCm): its own
+        # gradients move in the last bits from run to run, and a max over 20 neighbours that sits on a rounding edge then
+        # routes a gradient elsewhere (seen once in ~25 runs of this test, bn2.bias of the DGCNN: 5e-3 exceeded).  The HIP
+        # path is bit-reproducible (tests/test_fuzz_gpu.py `repro`): the library side is re-evaluated, at most twice more.
+        for attempt in range(3):
+            worst = max((_rel(p.grad.cpu().numpy(), q.grad.cpu().numpy()), k)
+                        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()))
+            if worst[0] < 5e-3:
+                break
+            for q in b.parameters():
+                q.grad = None
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                (b.forward_parts(x, valid) * w).sum().backward()
+        assert worst[0] < 5e-3, (arch, worst)
         del fb2
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
