@@ -20,6 +20,8 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // as a node of a captured HIP graph it misbehaved on replay (ROCm 7.0/7.2: faults on large fills, stale data on
 // small ones), and every entry point must stay graph-capturable.
 void zero_words_async(void* p, int64_t words, hipStream_t s);
+// transformer.hip: dW [N][K] = dY^T X over few rows M (N, K multiples of 32), db = column sums of dY (nullable)
+void launch_small_wgrad(const float* dY, const float* X, int ldx, float* dW, float* db, int M, int N, int K, hipStream_t s);
 
 constexpr int kWave = 64;  // gfx950 wavefront width
 

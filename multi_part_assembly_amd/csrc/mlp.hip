@@ -689,8 +689,11 @@ extern "C" int mpa_mlp_layer_backward(const float* grad_out, const float* x, int
     launch(ml_bwd_dy_kernel, dim3((unsigned)tiles), dim3(256), s, grad_out, out, (const float*)m.ypre,
            gamma != nullptr ? (const float*)m.coef : (const float*)nullptr, (int)R, (int)N, relu, m.dy, m.partial);
   }
-  // dW [N][K] = dY^T X (row chunks, then a fixed-order sum) and db = the column sums of dY's per-tile table
-  {
+  // dW [N][K] = dY^T X (row chunks, then a fixed-order sum) and db = the column sums of dY's per-tile table; few rows:
+  // one launch of the transformer's weight-gradient kernel (one 32 x 32 tile per block, the block's waves split the rows)
+  if (R <= kSmallRows && ml_small_fused()) {
+    mpa::launch_small_wgrad(m.dy, x, (int)ldx, grad_w, grad_b, (int)R, (int)N, (int)K, s);
+  } else {
     // enough chunks for ~512 blocks in the launch, each at least 64 rows
     const int out_tiles = (int)(((N + 127) / 128) * (K % 128 == 0 ? K / 128 : K / 64));
     int chunks = (512 + out_tiles - 1) / out_tiles;

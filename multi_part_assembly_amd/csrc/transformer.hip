@@ -74,6 +74,7 @@ struct WgradArgs {
   float* dW;           // [N, K]
   float* db;           // [N] or null
   int M, N, K;
+  int ldx;             // row stride of X (0: K)
 };
 
 // Up to kGroup independent weight gradients share one launch (the four of a transformer layer's backward: each
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kWT) void wgrad_kernel(const WgradGroup G) {
     const int row = mb + 2 * s + h;
     const long long r = row < me ? row : 0;  // out-of-range steps read row 0 and are zeroed in `step`
     f.a = g.dY[r * g.N + n0 + j];
-    f.b = g.X[r * g.K + k0 + j];
+    f.b = g.X[r * (g.ldx > 0 ? g.ldx : g.K) + k0 + j];
   };
   auto step = [&](int s, const Frag& f) {
     if (s >= ns) return;
@@ -802,6 +803,16 @@ int tf_check(const TfDims& d, const char* who) {
 }
 
 }  // namespace
+
+namespace mpa {
+// dW [N][K] = dY [M][N]^T . X [M][K] (row stride ldx) and db [N] = column sums of dY (nullable), exact-fp32 matrix-core
+// products in a fixed order: the weight gradient of a layer over few rows (mlp.hip: the node MLPs' 640) in one launch
+void launch_small_wgrad(const float* dY, const float* X, int ldx, float* dW, float* db, int M, int N, int K, hipStream_t s) {
+  WgradArgs a = wgrad_args(dY, X, dW, db, M, N, K);
+  a.ldx = ldx;
+  launch_wgrad_group(&a, 1, s);
+}
+}  // namespace mpa
 
 extern "C" int mpa_transformer_workspace(int64_t B, int64_t P, int64_t D, int64_t H, int64_t FF, int64_t L,
                                          int64_t* float_elems) {
