@@ -58,6 +58,12 @@ using namespace dg;
 
 // EdgeConv stage 1's graph (C = 3): the matrix-core gated search (dg_knn3_gate.h) unless MPA_KNN3=scan asks for the
 // exhaustive knn3_kernel of rounds 2-5 (identical indices; the knob exists for A/B timing and the cross-check test)
+// the kernel that writes a stage's output also leaves the next stage's kNN operands (MPA_KNN_PRODUCER=0: the separate
+// rownorm / centre / split kernels of rounds 3-5a; identical operands either way)
+bool knn_producer() {
+  const char* e = getenv("MPA_KNN_PRODUCER");
+  return !(e != nullptr && e[0] == '0');
+}
 bool knn3_gate() {
   const char* e = getenv("MPA_KNN3");
   return !(e != nullptr && e[0] == 's');
@@ -455,6 +461,91 @@ __global__ void dg_apply_kernel(const float* __restrict__ esel, int CO, const fl
   z.z = z.z > 0.0f ? z.z : kSlope * z.z;
   z.w = z.w > 0.0f ? z.w : kSlope * z.w;
   *reinterpret_cast<float4*>(hcat + r * kCat + off + c) = z;
+}
+
+// ---- the same pass as the PRODUCER of the next stage's kNN operands (stages whose output is 64 or 128 wide) -------------------
+// knn_wide (dg_knn_fast.h) needs, per row of the next stage's input x: the pinned norm n (fmaf chain in matrix-core
+// order), the bf16 row hi(x - mu), and the scaled centred norms nl / nu.  rownorm_kernel + knn_centre_kernel +
+// knn_split1_kernel read x twice more for that (171 + 92 MB at C = 128).  Here the kernel that WRITES x produces them
+// from the registers it holds: a row is owned by C / 4 consecutive lanes (full-line stores of x and of the bf16 row), the
+// centred norm is the split kernel's own shuffle tree, and the sequential norm chain is walked by one thread per row
+// over the block's rows staged in LDS (odd row stride: conflict-free).  Same values as the three kernels, bit for bit
+// (tests/test_dgcnn_gpu.py compares the graphs the encoder builds with mpa_knn_exact's on the same rows).
+// mu [clouds][C] first: the mean of the cloud's first 16 OUTPUT rows, from the pre-activation rows (knn_centre_kernel's sum).
+template <int C>
+__global__ __launch_bounds__(C) void dg_apply_centre_kernel(const float* __restrict__ esel, const float* __restrict__ bn,
+                                                            int N, float* __restrict__ mu, const int* __restrict__ hdr) {
+  const int v = blockIdx.x, c = threadIdx.x;
+  if (v >= hdr[0]) return;
+  const float sc = bn[c], sh = bn[C + c];
+  const float* xp = esel + (long long)v * N * C + c;
+  float a = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {  // fixed order
+    float z = __builtin_fmaf(xp[(long long)r * C], sc, sh);
+    z = z > 0.0f ? z : kSlope * z;
+    a += z;
+  }
+  mu[v * C + c] = a * 0.0625f;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void dg_apply_knn_kernel(const float* __restrict__ esel, const float* __restrict__ bn,
+                                                           float* __restrict__ hcat, int off, const float* __restrict__ mu,
+                                                           int N, float* __restrict__ norm, unsigned short* __restrict__ xs,
+                                                           float* __restrict__ nl, float* __restrict__ nu,
+                                                           const int* __restrict__ hdr) {
+  constexpr int TPR = C / 4, RPP = 256 / TPR, PASSES = 4, RB = RPP * PASSES, LD = C + 1;
+  __shared__ float rowbuf[RB * LD];
+  __shared__ float msum[RB];
+  const long long R = hdr[1];
+  const long long r0 = (long long)blockIdx.x * RB;
+  if (r0 >= R) return;
+  const int c4 = threadIdx.x % TPR, rl = threadIdx.x / TPR, c = 4 * c4;
+  const float4 sc = *reinterpret_cast<const float4*>(bn + c), sh = *reinterpret_cast<const float4*>(bn + C + c);
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int row = ps * RPP + rl;
+    const long long r = r0 + row, rc = r < R ? r : R - 1;  // (rows past the end shadow the last one: the shuffles need them)
+    const float4 x = *reinterpret_cast<const float4*>(esel + rc * C + c);
+    float4 z = make_float4(__builtin_fmaf(x.x, sc.x, sh.x), __builtin_fmaf(x.y, sc.y, sh.y),
+                           __builtin_fmaf(x.z, sc.z, sh.z), __builtin_fmaf(x.w, sc.w, sh.w));
+    z.x = z.x > 0.0f ? z.x : kSlope * z.x;
+    z.y = z.y > 0.0f ? z.y : kSlope * z.y;
+    z.z = z.z > 0.0f ? z.z : kSlope * z.z;
+    z.w = z.w > 0.0f ? z.w : kSlope * z.w;
+    const float4 m4 = *reinterpret_cast<const float4*>(mu + (rc / N) * C + c);
+    const float y[4] = {z.x - m4.x, z.y - m4.y, z.z - m4.z, z.w - m4.w};
+    kf_bf16x4 hi;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) hi[u] = (__bf16)y[u];
+    float m = (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);  // (knn_split1_kernel's tree)
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) m += __shfl_xor(m, o, 64);
+    float* d = &rowbuf[row * LD + c];
+    d[0] = z.x, d[1] = z.y, d[2] = z.z, d[3] = z.w;
+    if (c4 == 0) msum[row] = m;
+    if (r < R) {
+      *reinterpret_cast<float4*>(hcat + r * kCat + off + c) = z;
+      *reinterpret_cast<kf_bf16x4*>(xs + r * C + c) = hi;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < RB && r0 + threadIdx.x < R) {  // the pinned chain: positions i, C/2 + i for i = 0 .. C/2 - 1
+    const float* x = &rowbuf[threadIdx.x * LD];
+    float n = 0.0f;
+#pragma unroll 16
+    for (int i = 0; i < C / 2; ++i) {
+      const float lo = x[i], hh = x[C / 2 + i];
+      n = __builtin_fmaf(lo, lo, n);
+      n = __builtin_fmaf(hh, hh, n);
+    }
+    const long long r = r0 + threadIdx.x;
+    const float m = msum[threadIdx.x], kg = KnnFast<C>::kappa_g, kr = KnnFast<C>::kappa_raw;
+    norm[r] = n;
+    nl[r] = next_float(next_float(__builtin_fmaf(m, kg, m)) + next_float(kr * n));
+    nu[r] = prev_float(prev_float(__builtin_fmaf(m, -kg, m)) - next_float(kr * n));
+  }
 }
 
 // ---- tail: column statistics of y5, pooling, linear ----------------------------------------------------------------------------
@@ -1263,10 +1354,11 @@ KnnWs knn_carve(Take&& take, int64_t M, int64_t N) {
 // at 353 x 1000; tools/probes/knn_fast.hip compares the two index for index).
 template <int C, typename IdxT>
 void knn_wide(const float* x, int ld, float* norm, const KnnWs& k, int64_t M, int64_t N, IdxT* idx, const int* hdr,
-              hipStream_t s) {
+              hipStream_t s, bool prepared = false) {
   const int64_t R = M * N;
   constexpr int SETS = 1, WAVES = 8;
   const dim3 ggram((unsigned)((N + kKfQB - 1) / kKfQB), DG_KNN_GRID_Y(M));
+  if (!(prepared && kKfProducts == 1)) {  // prepared: the producer of x left norm, xs, nl, nu (dg_apply_knn_kernel)
   // (round 5: one fused pass — norm chain + split from the same staged float4 — was built and measured 0.03-0.05 ms SLOWER
   // per C = 128 search on one box, three alternations: its hi / lo stores are 32-byte segments per row and slab, where the
   // split kernels write full lines; LABBOOK 5.2)
@@ -1278,6 +1370,7 @@ void knn_wide(const float* x, int ld, float* norm, const KnnWs& k, int64_t M, in
   } else {
     hipLaunchKernelGGL(knn_split_kernel<C>, dim3((unsigned)((R * (C / 4) + 255) / 256)), dim3(256), 0, s, x, ld,
                        (const float*)norm, k.xs, k.nl, k.nu, hdr);
+  }
   }
   hipLaunchKernelGGL((knn_gram_kernel<C, false, SETS, WAVES>), ggram, dim3(64 * WAVES), 0, s, (const unsigned short*)k.xs,
                      (const float*)k.nl, (const float*)k.nl, (const float*)k.nu, (int)N, k.theta, k.surv, k.scnt, hdr);
@@ -1492,8 +1585,9 @@ int dgcnn_forward_impl(const float* points, const float* valids, const float* co
                reinterpret_cast<const float*>(w.x0), (int)N, w.idx[0], (const int*)w.hdr);
     } else {
       const float* x = w.hcat + kOff[l - 1];
-      if (C == 64) knn_wide<64, unsigned short>(x, kCat, w.norm, w.knn, M, N, w.idx[l], (const int*)w.hdr, s);
-      else knn_wide<128, unsigned short>(x, kCat, w.norm, w.knn, M, N, w.idx[l], (const int*)w.hdr, s);
+      // (the operands were left by stage l - 1's apply pass below unless MPA_KNN_PRODUCER=0)
+      if (C == 64) knn_wide<64, unsigned short>(x, kCat, w.norm, w.knn, M, N, w.idx[l], (const int*)w.hdr, s, knn_producer());
+      else knn_wide<128, unsigned short>(x, kCat, w.norm, w.knn, M, N, w.idx[l], (const int*)w.hdr, s, knn_producer());
     }
     record(events, 2 * l + 1, s);
     // [U | V] = X . [Wa ; Wb - Wa]^T
@@ -1523,8 +1617,24 @@ int dgcnn_forward_impl(const float* points, const float* valids, const float* co
       launch(dg_bn_from_running_kernel, dim3((unsigned)(CO / 64)), dim3(64), s, CO, bn_w[l], bn_b[l],
              (const float*)running_mean[l], (const float*)running_var[l], eps, w.bn[l]);
     }
-    launch(dg_apply_kernel, dim3((unsigned)((R * (CO / 4) + 255) / 256)), dim3(256), s, (const float*)w.esel[l], CO,
-           (const float*)w.bn[l], w.hcat, kOff[l], (const int*)w.hdr);
+    // BatchNorm + LeakyReLU into the concatenation; stages 1-3 also leave the next stage's kNN operands
+    const bool feeds_knn = l < 3 && kKfProducts == 1 && knn_producer() && !(graphs != nullptr && graphs[l + 1] != nullptr);
+    if (feeds_knn && CO == 64) {
+      launch(dg_apply_centre_kernel<64>, dim3((unsigned)M), dim3(64), s, (const float*)w.esel[l], (const float*)w.bn[l],
+             (int)N, w.knn.mu, (const int*)w.hdr);
+      launch(dg_apply_knn_kernel<64>, dim3((unsigned)((R + 63) / 64)), dim3(256), s, (const float*)w.esel[l],
+             (const float*)w.bn[l], w.hcat, kOff[l], (const float*)w.knn.mu, (int)N, w.norm, w.knn.xs, w.knn.nl, w.knn.nu,
+             (const int*)w.hdr);
+    } else if (feeds_knn && CO == 128) {
+      launch(dg_apply_centre_kernel<128>, dim3((unsigned)M), dim3(128), s, (const float*)w.esel[l], (const float*)w.bn[l],
+             (int)N, w.knn.mu, (const int*)w.hdr);
+      launch(dg_apply_knn_kernel<128>, dim3((unsigned)((R + 31) / 32)), dim3(256), s, (const float*)w.esel[l],
+             (const float*)w.bn[l], w.hcat, kOff[l], (const float*)w.knn.mu, (int)N, w.norm, w.knn.xs, w.knn.nl, w.knn.nu,
+             (const int*)w.hdr);
+    } else {
+      launch(dg_apply_kernel, dim3((unsigned)((R * (CO / 4) + 255) / 256)), dim3(256), s, (const float*)w.esel[l], CO,
+             (const float*)w.bn[l], w.hcat, kOff[l], (const int*)w.hdr);
+    }
   }
   // tail: 512 -> F convolution, BatchNorm1d, LeakyReLU, [max ; mean] over the points, Linear
   gemm_nt(w.hcat, kCat, conv_w[4], kCat, w.y5, (int)F, (int)F, false, R, w.hdr, s);

@@ -338,3 +338,34 @@ def test_knn3_gated_search_equals_the_exhaustive_kernel(cuda_device, monkeypatch
         if kind not in ("huge", "nan") and N <= 257:
             assert torch.equal(got, T(oracle_knn(x.numpy())).long()), (kind, n, N)
     monkeypatch.delenv("MPA_KNN3", raising=False)
+
+
+@pytest.mark.parametrize("n,N,feat", [(3, 1000, 128), (5, 97, 256), (2, 20, 64)])
+def test_knn_operands_from_the_producing_kernel_equal_the_separate_passes(cuda_device, monkeypatch, n, N, feat):
+    """The apply pass of EdgeConv stages 1-3 also leaves the next stage's kNN operands (pinned row norms, centred bf16 rows,
+    scaled norms: dg_apply_knn_kernel) instead of three more passes over the features (MPA_KNN_PRODUCER=0): the exported
+    graphs of all four stages, the features and every gradient are bit-equal, with masked parts and ragged sizes."""
+    torch.manual_seed(n * 1000 + N)
+    enc = DGCNN(feat).to(cuda_device).train()
+    enc.graph_hooks = {"export": True}
+    g = torch.Generator().manual_seed(N)
+    x = (torch.randn(n, N, 3, generator=g) * 0.3).to(cuda_device)
+    valid = torch.ones(n, device=cuda_device)
+    if n > 2:
+        valid[1] = 0.0
+    w = torch.randn(n, feat, generator=g).to(cuda_device)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MPA_KNN_PRODUCER", mode)
+        for p in enc.parameters():
+            p.grad = None
+        f = enc.forward_parts(x, valid)
+        (f * w).sum().backward()
+        res[mode] = (f.detach().clone(), [t.clone() for t in enc.graph_hooks["exported"]],
+                     [p.grad.clone() for p in enc.parameters() if p.grad is not None])
+    monkeypatch.delenv("MPA_KNN_PRODUCER", raising=False)
+    assert torch.equal(res["0"][0], res["1"][0])
+    for a, b in zip(res["0"][1], res["1"][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(res["0"][2], res["1"][2]):
+        assert torch.equal(a, b)
