@@ -48,8 +48,10 @@ def test_bench_line_has_the_contract_keys(cuda_device):
     cs = d["chamfer_standalone"]["cases"]
     assert len(cs) == 3 and all(x["GBps"] > 0 and x["calls"] == 20 for x in cs)
     assert cs[0]["algorithmic_bytes_per_call"] == 24.0 * 640 * 2000 and cs[1]["algorithmic_bytes_per_call"] == 24.0 * 32 * 40000
-    assert cs[0]["search"].startswith("exhaustive") and all(x["search"].startswith("grid") for x in cs[1:])
-    assert all(x["bit_equal_to_exhaustive_scan"] is True for x in cs[1:])
+    # the per-part call goes to the matrix-core gated search (gate_nn.hip), the whole-shape calls to the grid-pruned one;
+    # every case carries the exhaustive scan's time and the bit-equality of all four outputs with it
+    assert cs[0]["search"].startswith("matrix-core gated") and all(x["search"].startswith("grid") for x in cs[1:])
+    assert all(x["bit_equal_to_exhaustive_scan"] is True and x["exhaustive_scan_ms"] > x["avg_call_ms"] for x in cs)
 
 
 def test_one_stdout_line_under_the_drivers_launcher(cuda_device):

@@ -62,18 +62,29 @@ def main():
             missing = [pat for pat, a, b in zip(pats, fs, ws) if a is None or b is None]
             fs = [0.0 if v is None else v for v in fs]  # a kernel below the summary's cut-off moved (almost) nothing
             ws = [0.0 if v is None else v for v in ws]
+            # round 5b: the pass that writes the stage's output (dg_apply_knn_kernel<C>) also writes the search's operands
+            # (bf16 rows, norms).  Its reads of the pre-activation rows and its write of the output exist with or without
+            # a kNN search behind it; what the search adds is what the pass writes BEYOND the output it reads in:
+            # WRITE_SIZE - 2 x FETCH_SIZE (input and output have the same element count).
+            pf = per_kernel(ff, re.escape(f"dg_apply_knn_kernel<{C}>"))
+            pw = per_kernel(wf, re.escape(f"dg_apply_knn_kernel<{C}>"))
+            extra = max(0.0, pw - 2.0 * pf) if pf is not None and pw is not None else 0.0
             widths[str(C)] = {"fetch_size_kb_per_launch": sum(fs), "write_size_kb_per_launch": sum(ws),
                               "per_kernel_fetch_kb": dict(zip(pats, fs)), "per_kernel_write_kb": dict(zip(pats, ws)),
                               "below_the_summary_cutoff": missing,
-                              "traffic_bytes_per_launch": (2.0 * sum(fs) + sum(ws)) * 1024.0}
+                              "producer_pass": None if pf is None else {
+                                  "kernel": f"dg_apply_knn_kernel<{C}>", "fetch_size_kb_per_launch": pf,
+                                  "write_size_kb_per_launch": pw, "operand_bytes_written_for_the_search_kb": extra},
+                              "traffic_bytes_per_launch": (2.0 * sum(fs) + sum(ws) + extra) * 1024.0}
         if widths:
             rec = {"kernel": "dg::knn_wide = every kernel of one wide kNN search (names in per_kernel_*)",
                    "config": cfg, "clouds_per_launch": clouds_of(prof, rnd, cfg),
                    "command": f"python bench.py --config {cfg} --no-cpu-baseline --steps 4 --warmup 2 (rocprofv3 --pmc "
                               "FETCH_SIZE and --pmc WRITE_SIZE, separate passes; tools/gpu_full_pass.sh)",
                    "correction": note, "per_width": widths,
-                   "note": "sum over the kernels of one search; the query blocks of a cloud run on one XCD (dg_knn.h: "
-                           "knn_block), so one L2 streams the cloud's split features in both Gram passes"}
+                   "note": "sum over the kernels of one search (+ the operand bytes the producing pass writes for it, "
+                           "producer_pass); the query blocks of a cloud run on one XCD (dg_knn.h: knn_block), so one L2 "
+                           "streams the cloud's split features in both Gram passes"}
             (prof / out).write_text(json.dumps(rec, indent=1))
             print(rec)
 
