@@ -34,6 +34,9 @@ typedef __bf16 gs_bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef DG_GS_WAVES  // A/B knob: waves per block (4: the 2 x 2 arrangement of dg_gemm.h; 8: 2 x 4 / 4 x 2)
 #define DG_GS_WAVES 4
 #endif
+#ifndef DG_GS_ROWPERM  // 1: staging threads take panel rows four apart (conflict-free stores); 0: consecutive rows (rounds 3-5a)
+#define DG_GS_ROWPERM 1
+#endif
 constexpr int kGsT = 64 * DG_GS_WAVES;  // threads per block
 constexpr int kGsRow = 208;             // bytes per LDS row: 3 planes x 32 bf16 + 16 pad
 
@@ -160,7 +163,12 @@ __global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_nt_split_
   if (r0 >= R) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int wr = wave / WV::WC, wc = wave % WV::WC;
-  const int c4 = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  // Panel row of a staging thread.  Eight threads share a row; the 32 lanes of one LDS write cycle hold four rows, and with
+  // 208-byte rows (52 dwords) CONSECUTIVE rows start 52 banks apart: their 16-dword runs overlap pairwise, a 2-way conflict
+  // on every plane's store (a third of the kernel's LDS cycles: profiles/r05b_c3_pmc_lds_counters.txt).  Rows four apart
+  // start 16 banks apart — four disjoint runs — so slot g of a pass takes row 4 (g % 4) + (g / 4) % 4 + 16 (g / 16).
+  const int c4 = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const int rl = DG_GS_ROWPERM ? ((rg & 3) << 2) + ((rg >> 2) & 3) + (rg & ~15) : rg;
   float4 ra[A4], rb[B4];
   const float* ap_[A4];
 #pragma unroll
