@@ -64,12 +64,27 @@ static_assert(kKfProducts == 1 || kKfProducts == 3, "MPA_KNN_PRODUCTS is 1 or 3"
 //   lower(i,j) = 2 a^ - NL_j - NL_i <= score(i,j) <= upper(i,j) = 2 a^ - NU_j - NU_i
 // — the same two per-row arrays the three-product form hands the Gram kernels.  Looser bounds, more survivors (the
 // benchmark's features: ~21 per lane half instead of ~16), a third of the matrix-core work and half of the operand bytes.
+//
+// Round 5b: the bf16 truncation term per ROW instead of the worst case.  With e = y^ - hi (exact in fp32),
+//   y^_i.y^_j - hi_i.hi_j = e_i.y^_j + hi_i.e_j,   |.| <= E_i Y_j + H_i E_j     (E = |e|, Y = |y^|, H = |hi| <= 1.004 Y)
+// and for any lambda > 0 (AM-GM):  E_i Y_j + H_i E_j <= P_i + P_j,  P = (E^2 / lambda + 1.01 lambda Y^2) / 2.
+// Round-to-nearest leaves E ~ 2^-10 Y on real features where the worst case above charges 2^-8 Y: with lambda = 2^-10 the
+// truncation slack 2 (P_i + P_j) is ~2e-3 (M_i + M_j) instead of 7.8e-3 — a quarter — and rows that happen to truncate badly pay
+// for themselves.  What remains per unit of M is kappa_acc: accumulation inside the matrix core on 2 a^ (C 2^-23 1.03), the
+// fp32 norm ((C + 3) 2^-24), centring (4.04 * 2^-24) and the fp32 evaluation of lower / upper (4 * 2^-24):
+//   C = 128: 1.57e-5 + 7.8e-6 + 4.8e-7 = 2.4e-5 -> 2.7e-5;   C = 64: 7.9e-6 + 4.0e-6 + 4.8e-7 = 1.24e-5 -> 1.4e-5.
+//   NL = m + 2P + kappa_acc m + kappa_raw n (rounded up),  NU = m - 2P - kappa_acc m - kappa_raw n (rounded down);
+// E^2 is an fp32 sum of C squares (relative error < (C + 1) 2^-24): inflated by 2e-5.  Survivors per query: ~22 (was 27-30).
 template <int C>
 struct KnnFast {
   static constexpr float kappa = C > 64 ? 1.15e-4f : 8.5e-5f;      // three products, raw features
-  static constexpr float kappa_g = 7.9e-3f;                         // one product, centred features
+  static constexpr float kappa_g = 7.9e-3f;                         // one product, centred features: worst-case truncation (rounds 5a)
+  static constexpr float kappa_acc = C > 64 ? 2.7e-5f : 1.4e-5f;    // one product: everything but the truncation
   static constexpr float kappa_raw = C > 64 ? 1.75e-5f : 9.0e-6f;   // pinned chain vs exact, raw features
 };
+#ifndef MPA_KNN_ROWSLACK  // 1: per-row truncation slack (round 5b); 0: kappa_g (M_i + M_j)
+#define MPA_KNN_ROWSLACK 1
+#endif
 
 constexpr int kKfCap = kKfProducts == 1 ? 48 : 32;  // survivor slots per (query, lane half): expected load ~16 (three products) /
                                // ~21 (one product); a list that overflows costs its query an exhaustive scan
@@ -78,6 +93,24 @@ constexpr int kKfQB = 256;     // queries per block of the bound / collect kerne
 constexpr int kKfOverflow = 255;  // survivor count of a list that overflowed: the rerank kernel scans that query exhaustively
 
 __device__ __forceinline__ float next_float(float x) { return -prev_float(-x); }
+
+// the two scaled norms of a row of the one-product form: m = fp32 |y^|^2, e2 = fp32 |y^ - hi|^2, n = the pinned raw norm
+template <int C>
+__device__ __forceinline__ void kf_scaled_norms(float m, float e2, float n, float& nl, float& nu) {
+  const float kr = KnnFast<C>::kappa_raw;
+#if MPA_KNN_ROWSLACK
+  constexpr float kLam = 0.0009765625f;  // lambda = 2^-10 (the division below is an exact scaling)
+  // 2P = e2 / lambda (1 + 2e-5) + 1.01 lambda m, every step rounded up
+  const float p2 = next_float(next_float(e2 * 1024.0f * 1.00002f) + next_float(m * (1.01f * kLam)));
+  const float slack = next_float(next_float(p2 + next_float(m * KnnFast<C>::kappa_acc)) + next_float(kr * n));
+  nl = next_float(m + slack);
+  nu = prev_float(m - slack);
+#else
+  const float kg = KnnFast<C>::kappa_g;
+  nl = next_float(next_float(__builtin_fmaf(m, kg, m)) + next_float(kr * n));
+  nu = prev_float(prev_float(__builtin_fmaf(m, -kg, m)) - next_float(kr * n));
+#endif
+}
 
 // ---- split: x -> (hi | lo) bf16 rows, scaled norms ----------------------------------------------------------------------
 // x [R][ld] (first C columns), norm [R] (rownorm_kernel), xs [R][2C] bf16 = hi(0..C-1) | lo(0..C-1), nl / nu [R].
@@ -141,15 +174,16 @@ __global__ __launch_bounds__(256) void knn_split1_kernel(const float* __restrict
 #pragma unroll
   for (int u = 0; u < 4; ++u) hi[u] = (__bf16)y[u];
   float m = (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+  const float e[4] = {y[0] - (float)hi[0], y[1] - (float)hi[1], y[2] - (float)hi[2], y[3] - (float)hi[3]};  // exact
+  float e2 = (e[0] * e[0] + e[1] * e[1]) + (e[2] * e[2] + e[3] * e[3]);
 #pragma unroll
-  for (int off = 1; off < TPR; off <<= 1) m += __shfl_xor(m, off, 64);
+  for (int off = 1; off < TPR; off <<= 1) {
+    m += __shfl_xor(m, off, 64);
+    e2 += __shfl_xor(e2, off, 64);
+  }
   if (r >= R) return;
   *reinterpret_cast<kf_bf16x4*>(xs + r * C + 4 * c4) = hi;
-  if (c4 == 0) {
-    const float n = norm[r], kg = KnnFast<C>::kappa_g, kr = KnnFast<C>::kappa_raw;
-    nl[r] = next_float(next_float(__builtin_fmaf(m, kg, m)) + next_float(kr * n));
-    nu[r] = prev_float(prev_float(__builtin_fmaf(m, -kg, m)) - next_float(kr * n));
-  }
+  if (c4 == 0) kf_scaled_norms<C>(m, e2, norm[r], nl[r], nu[r]);
 }
 
 // ---- shared Gram-tile machinery of the bound / collect kernels ------------------------------------------------------------

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void dg_apply_knn_kernel(const float* __restri
                                                            const int* __restrict__ hdr) {
   constexpr int TPR = C / 4, RPP = 256 / TPR, PASSES = 4, RB = RPP * PASSES, LD = C + 1;
   __shared__ float rowbuf[RB * LD];
-  __shared__ float msum[RB];
+  __shared__ float msum[RB], esum[RB];
   const long long R = hdr[1];
   const long long r0 = (long long)blockIdx.x * RB;
   if (r0 >= R) return;
@@ -519,12 +519,17 @@ __global__ __launch_bounds__(256) void dg_apply_knn_kernel(const float* __restri
     kf_bf16x4 hi;
 #pragma unroll
     for (int u = 0; u < 4; ++u) hi[u] = (__bf16)y[u];
-    float m = (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);  // (knn_split1_kernel's tree)
+    float m = (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);  // (knn_split1_kernel's trees)
+    const float e[4] = {y[0] - (float)hi[0], y[1] - (float)hi[1], y[2] - (float)hi[2], y[3] - (float)hi[3]};
+    float e2 = (e[0] * e[0] + e[1] * e[1]) + (e[2] * e[2] + e[3] * e[3]);
 #pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) m += __shfl_xor(m, o, 64);
+    for (int o = 1; o < TPR; o <<= 1) {
+      m += __shfl_xor(m, o, 64);
+      e2 += __shfl_xor(e2, o, 64);
+    }
     float* d = &rowbuf[row * LD + c];
     d[0] = z.x, d[1] = z.y, d[2] = z.z, d[3] = z.w;
-    if (c4 == 0) msum[row] = m;
+    if (c4 == 0) msum[row] = m, esum[row] = e2;
     if (r < R) {
       *reinterpret_cast<float4*>(hcat + r * kCat + off + c) = z;
       *reinterpret_cast<kf_bf16x4*>(xs + r * C + c) = hi;
@@ -541,10 +546,8 @@ __global__ __launch_bounds__(256) void dg_apply_knn_kernel(const float* __restri
       n = __builtin_fmaf(hh, hh, n);
     }
     const long long r = r0 + threadIdx.x;
-    const float m = msum[threadIdx.x], kg = KnnFast<C>::kappa_g, kr = KnnFast<C>::kappa_raw;
     norm[r] = n;
-    nl[r] = next_float(next_float(__builtin_fmaf(m, kg, m)) + next_float(kr * n));
-    nu[r] = prev_float(prev_float(__builtin_fmaf(m, -kg, m)) - next_float(kr * n));
+    kf_scaled_norms<C>(msum[threadIdx.x], esum[threadIdx.x], n, nl[r], nu[r]);
   }
 }
 
