@@ -86,7 +86,10 @@ struct KnnFast {
 #define MPA_KNN_ROWSLACK 1
 #endif
 
-constexpr int kKfCap = kKfProducts == 1 ? 48 : 32;  // survivor slots per (query, lane half): expected load ~16 (three products) /
+#ifndef MPA_KNN_CAP
+#define MPA_KNN_CAP 32
+#endif
+constexpr int kKfCap = MPA_KNN_CAP;  // survivor slots per (query, lane half): expected load ~16 (three products) /
                                // ~21 (one product); a list that overflows costs its query an exhaustive scan
                                // in the rerank kernel (~0.2 ms for the launch: one block's tail)
 constexpr int kKfQB = 256;     // queries per block of the bound / collect kernels (4 waves x 2 sets of 32)
