@@ -1375,7 +1375,10 @@ void knn_wide(const float* x, int ld, float* norm, const KnnWs& k, int64_t M, in
                        (const float*)norm, k.xs, k.nl, k.nu, hdr);
   }
   }
-  hipLaunchKernelGGL((knn_gram_kernel<C, false, SETS, WAVES>), ggram, dim3(64 * WAVES), 0, s, (const unsigned short*)k.xs,
+#ifndef KF_BOUND_MODE  // timing probes only (tools/build_variant.sh): see knn_gram_kernel's MODE
+#define KF_BOUND_MODE 0
+#endif
+  hipLaunchKernelGGL((knn_gram_kernel<C, false, SETS, WAVES, KF_BOUND_MODE>), ggram, dim3(64 * WAVES), 0, s, (const unsigned short*)k.xs,
                      (const float*)k.nl, (const float*)k.nl, (const float*)k.nu, (int)N, k.theta, k.surv, k.scnt, hdr);
   hipLaunchKernelGGL((knn_gram_kernel<C, true, SETS, WAVES>), ggram, dim3(64 * WAVES), 0, s, (const unsigned short*)k.xs,
                      (const float*)k.nu, (const float*)k.nl, (const float*)k.nu, (int)N, k.theta, k.surv, k.scnt, hdr);
