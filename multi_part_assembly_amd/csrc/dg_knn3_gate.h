@@ -29,29 +29,15 @@
 
 #include "dg_knn.h"
 #include "dg_knn_fast.h"
+#include "gate_common.h"
 
 namespace dg {
-
-typedef __bf16 k3_bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float kK3Kappa = 6.0e-5f;
 constexpr float kK3KappaRaw = 1.0e-6f;
 constexpr int kK3QN = 20;   // queue slots per lane (the queues live in the panel's 32 KB once the bound is done)
 constexpr int kK3R = 8;     // candidates between two queue checks
 
-__device__ __forceinline__ float k3_next(float x) {  // the next float above x (+inf, NaN unchanged)
-  const float up = x >= 0.0f ? __uint_as_float(__float_as_uint(x + 0.0f) + 1u) : __uint_as_float(__float_as_uint(x) - 1u);
-  return x < __builtin_inff() ? up : x;
-}
-__device__ __forceinline__ unsigned k3_bf(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
-__device__ __forceinline__ float k3_bf_f(float x) { return (float)(__bf16)x; }
-__device__ __forceinline__ unsigned k3_pk(float lo, float hi) { return k3_bf(lo) | (k3_bf(hi) << 16); }
-__device__ __forceinline__ float k3_min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
-__device__ __forceinline__ float k3_min16(const f32x16& a) {
-  const float m0 = k3_min3(a[0], a[1], a[2]), m1 = k3_min3(a[3], a[4], a[5]), m2 = k3_min3(a[6], a[7], a[8]);
-  const float m3 = k3_min3(a[9], a[10], a[11]), m4 = k3_min3(a[12], a[13], a[14]);
-  return k3_min3(k3_min3(m0, m1, m2), k3_min3(m3, m4, a[15]), __builtin_inff());
-}
 __device__ __forceinline__ float k3_sticky_max(float a, float b) { return b > a || b != b ? b : a; }  // NaN wins
 
 // x4 [R][4] (xyz0), idx [R][20].  grid = (ceil(N / 256), DG_KNN_GRID_Y(parts)), block 256: thread = query.
@@ -82,26 +68,21 @@ __global__ __launch_bounds__(256, 3) void knn3_gate_kernel(const float* __restri
   float mmax = 0.0f, nmax = 0.0f;
   const float nanv = __builtin_nanf("");
   for (int r = threadIdx.x; r < kMaxN; r += 256) {
-    uint4 p0 = {0u, 0u, 0u, 0u};
-    float m = 3.0e38f;  // rows past the cloud: never a minimum
-    unsigned lzb = 0u;
+    float yx = 0.0f, yy = 0.0f, yz = 0.0f, m = 3.0e38f;  // rows past the cloud: never a minimum
     float4 rw = {nanv, nanv, nanv, nanv};
     if (r < N) {
       rw = xp[r];
       rw.w = (rw.x * rw.x + rw.y * rw.y) + rw.z * rw.z;
       nmax = k3_sticky_max(nmax, rw.w);
-      const float yx = rw.x - cx, yy = rw.y - cy, yz = rw.z - cz;
-      const float hx = k3_bf_f(yx), hy = k3_bf_f(yy), hz = k3_bf_f(yz);
-      const float lx = yx - hx, ly = yy - hy, lz = yz - hz;
+      yx = rw.x - cx, yy = rw.y - cy, yz = rw.z - cz;
       m = (yx * yx + yy * yy) + yz * yz;
       mmax = k3_sticky_max(mmax, m);
-      p0 = uint4{k3_pk(hx, hy), k3_pk(hz, hx), k3_pk(hy, hz), k3_pk(lx, ly)};
-      lzb = k3_bf(lz);
     }
-    const float m0 = k3_bf_f(m), r1 = m - m0, m1 = k3_bf_f(r1), m2 = r1 - m1;  // m = m0 + m1 + m2 exactly
+    uint4 p0, p1;
+    mpa::gate::target_row(yx, yy, yz, m, p0, p1);
     pts[r + (r >> 5)] = rw;
     panel[0][r] = p0;
-    panel[1][r] = uint4{lzb | (k3_bf(m0) << 16), k3_pk(m1, m2), 0u, 0u};
+    panel[1][r] = p1;
   }
   {
     float a = mmax, b = nmax;
@@ -123,21 +104,10 @@ __global__ __launch_bounds__(256, 3) void knn3_gate_kernel(const float* __restri
   uint4 bq[2];
   {
     const float yx = me.x - cx, yy = me.y - cy, yz = me.z - cz;
-    const float hx = k3_bf_f(yx), hy = k3_bf_f(yy), hz = k3_bf_f(yz);
-    const float lx = yx - hx, ly = yy - hy, lz = yz - hz;
     mq = (yx * yx + yy * yy) + yz * yz;
-    const float a = -2.0f;
-    const uint4 k0 = {k3_pk(a * hx, a * hy), k3_pk(a * hz, a * lx), k3_pk(a * ly, a * lz), k3_pk(a * hx, a * hy)};
-    const unsigned one = 0x3f80u;
-    const uint4 k1 = {k3_bf(a * hz) | (one << 16), one | (one << 16), 0u, 0u};
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {  // tile s = queries 32 s + j of the wave; lane (j, h) supplies k-half h of column j
-      const int src = 32 * s + j;
-      uint4 v0, v1;
-      v0.x = __shfl(k0.x, src, 64), v0.y = __shfl(k0.y, src, 64), v0.z = __shfl(k0.z, src, 64), v0.w = __shfl(k0.w, src, 64);
-      v1.x = __shfl(k1.x, src, 64), v1.y = __shfl(k1.y, src, 64), v1.z = __shfl(k1.z, src, 64), v1.w = __shfl(k1.w, src, 64);
-      bq[s] = uint4{h ? v1.x : v0.x, h ? v1.y : v0.y, h ? v1.z : v0.z, h ? v1.w : v0.w};
-    }
+    uint4 k0, k1;
+    mpa::gate::query_column(yx, yy, yz, k0, k1);
+    mpa::gate::wave_columns(k0, k1, j, h, bq);
   }
 
   // ---- bound: cell minima.  tmA = cells of THIS lane's own query (tile h of the wave, rows of lane half h), tmB = cells of the
@@ -152,12 +122,15 @@ __global__ __launch_bounds__(256, 3) void knn3_gate_kernel(const float* __restri
         uint4 nx = pl[32 * t8];
 #pragma unroll
         for (int t = t8; t < t8 + 8; ++t) {
-          const k3_bf16x8 a = __builtin_bit_cast(k3_bf16x8, nx);
+          const mpa::gate::bf16x8 a = mpa::gate::as_bf16x8(nx);
           if (t + 1 < t8 + 8) nx = pl[32 * (t + 1)];
           const f32x16 z = {0};
-          const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(k3_bf16x8, bq[0]), z, 0, 0, 0);
-          const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(k3_bf16x8, bq[1]), z, 0, 0, 0);
-          const float c0 = k3_min16(acc0), c1 = k3_min16(acc1);
+          const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, mpa::gate::as_bf16x8(bq[0]), z, 0, 0, 0);
+          const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, mpa::gate::as_bf16x8(bq[1]), z, 0, 0, 0);
+          float x0, y0, x1, y1;
+          mpa::gate::min16(acc0, x0, y0);
+          mpa::gate::min16(acc1, x1, y1);
+          const float c0 = mpa::gate::min3(x0, y0, __builtin_inff()), c1 = mpa::gate::min3(x1, y1, __builtin_inff());
           tmA[t] = h ? c1 : c0;
           tmB[t] = h ? c0 : c1;
           __builtin_amdgcn_sched_barrier(0);
@@ -196,11 +169,11 @@ __global__ __launch_bounds__(256, 3) void knn3_gate_kernel(const float* __restri
   }
   // thresholds, every step rounded towards "keep more"; risky magnitudes: no pruning at all
   const bool safe = mq <= 1e30f && mmax <= 1e30f && nmax <= 1e30f && me.w <= 1e30f;  // (false for NaNs)
-  float E = k3_next(k3_next(k3_next(mq + mmax) * kK3Kappa) + k3_next(k3_next(me.w + nmax) * kK3KappaRaw));
-  E = k3_next(E + 1e-30f);
-  const float thr = safe ? k3_next(c20 + k3_next(2.0f * E)) : __builtin_inff();
+  float E = mpa::gate::next_up(mpa::gate::next_up(mpa::gate::next_up(mq + mmax) * kK3Kappa) + mpa::gate::next_up(mpa::gate::next_up(me.w + nmax) * kK3KappaRaw));
+  E = mpa::gate::next_up(E + 1e-30f);
+  const float thr = safe ? mpa::gate::next_up(c20 + mpa::gate::next_up(2.0f * E)) : __builtin_inff();
   // 20th smallest D <= c20 + M_i + E  =>  20th best score >= -(that); the gate starts strictly below it
-  const float dub = k3_next(k3_next(c20 + k3_next(mq * (1.0f + 1e-6f))) + E);
+  const float dub = mpa::gate::next_up(mpa::gate::next_up(c20 + mpa::gate::next_up(mq * (1.0f + 1e-6f))) + E);
   const float sthr = safe ? prev_float(prev_float(-dub)) : -__builtin_inff();
   unsigned kOwn = 0u, kPar = 0u;
 #pragma unroll

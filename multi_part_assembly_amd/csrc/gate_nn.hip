@@ -42,12 +42,12 @@
 // products that underflow.
 #include "assembly_internal.h"
 #include "common.h"
+#include "gate_common.h"
 
 namespace mpa {
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+using gate::f32x16;
 typedef unsigned long long u64;
 
 constexpr int kGW = 4;                 // waves per block: 256 queries
@@ -57,31 +57,7 @@ constexpr int kGTiles = kGT / 32;
 constexpr float kGKappa = 6.0e-5f;
 constexpr float kGMaxNorm = 1e30f;     // beyond: squares may overflow -> the textbook scan
 
-// the next float above x (+inf stays +inf; NaN stays NaN)
-__device__ __forceinline__ float g_next(float x) {
-  const float up = x >= 0.0f ? __uint_as_float(__float_as_uint(x + 0.0f) + 1u) : __uint_as_float(__float_as_uint(x) - 1u);
-  return x < __builtin_inff() ? up : x;
-}
 __device__ __forceinline__ float g_dist3(float dx, float dy, float dz) { return (dx * dx + dy * dy) + dz * dz; }
-__device__ __forceinline__ unsigned g_bf(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
-__device__ __forceinline__ float g_bf_f(float x) { return (float)(__bf16)x; }
-__device__ __forceinline__ unsigned g_pk(float lo, float hi) { return g_bf(lo) | (g_bf(hi) << 16); }
-__device__ __forceinline__ bf16x8 g_as_bf(const uint4 v) { return __builtin_bit_cast(bf16x8, v); }
-// three-operand minima only: the two-operand v_min_f32 makes the compiler canonicalise every accumulator register first
-__device__ __forceinline__ float g_min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
-__device__ __forceinline__ void g_min16(const f32x16& a, float& x, float& y) {  // min of the 16 = min(x, y): 7 x v_min3
-  const float m0 = g_min3(a[0], a[1], a[2]), m1 = g_min3(a[3], a[4], a[5]), m2 = g_min3(a[6], a[7], a[8]);
-  const float m3 = g_min3(a[9], a[10], a[11]), m4 = g_min3(a[12], a[13], a[14]);
-  x = g_min3(m0, m1, m2);
-  y = g_min3(m3, m4, a[15]);
-}
-// x = p0 + p1 + p2 exactly (three bf16 pieces of a finite fp32 number)
-__device__ __forceinline__ void g_split3(float x, float& p0, float& p1, float& p2) {
-  p0 = g_bf_f(x);
-  const float r1 = x - p0;
-  p1 = g_bf_f(r1);
-  p2 = r1 - p1;
-}
 __device__ __forceinline__ u64 g_key(float d, unsigned idx) { return ((u64)__float_as_uint(d) << 32) | idx; }
 
 struct GateArgs {
@@ -165,21 +141,10 @@ __global__ __launch_bounds__(kGQ, 3) void gate_nn_kernel(const GateArgs g) {
   float mq;
   {
     const float yx = X - cx, yy = Y - cy, yz = Z - cz;
-    const float hx = g_bf_f(yx), hy = g_bf_f(yy), hz = g_bf_f(yz);
-    const float lx = yx - hx, ly = yy - hy, lz = yz - hz;
     mq = g_dist3(yx, yy, yz);
-    const float a = -2.0f;
-    const uint4 k0 = {g_pk(a * hx, a * hy), g_pk(a * hz, a * lx), g_pk(a * ly, a * lz), g_pk(a * hx, a * hy)};
-    const unsigned one = 0x3f80u;
-    const uint4 k1 = {g_bf(a * hz) | (one << 16), one | (one << 16), 0u, 0u};
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int src = 32 * s + j;
-      uint4 v0, v1;
-      v0.x = __shfl(k0.x, src, 64), v0.y = __shfl(k0.y, src, 64), v0.z = __shfl(k0.z, src, 64), v0.w = __shfl(k0.w, src, 64);
-      v1.x = __shfl(k1.x, src, 64), v1.y = __shfl(k1.y, src, 64), v1.z = __shfl(k1.z, src, 64), v1.w = __shfl(k1.w, src, 64);
-      bq[s] = uint4{h ? v1.x : v0.x, h ? v1.y : v0.y, h ? v1.z : v0.z, h ? v1.w : v0.w};
-    }
+    uint4 k0, k1;
+    gate::query_column(yx, yy, yz, k0, k1);
+    gate::wave_columns(k0, k1, j, h, bq);
     OX = __shfl(X, 32 * (1 - h) + j, 64), OY = __shfl(Y, 32 * (1 - h) + j, 64), OZ = __shfl(Z, 32 * (1 - h) + j, 64);
   }
 
@@ -191,25 +156,18 @@ __global__ __launch_bounds__(kGQ, 3) void gate_nn_kernel(const GateArgs g) {
   auto stage = [&](int chunk) {
     for (int r = threadIdx.x; r < kGT; r += kGQ) {
       const int t = chunk * kGT + r;
-      uint4 p0 = {0u, 0u, 0u, 0u}, p1;
-      float n = 3.0e38f;  // rows past the cloud: never a minimum, never below a threshold
-      unsigned lzb = 0u;
+      float yx = 0.0f, yy = 0.0f, yz = 0.0f, n = 3.0e38f;  // rows past the cloud: never a minimum, never below a threshold
       float4 rw = {nanf_, nanf_, nanf_, 0.0f};
       if (t < nt) {
         const float x = tb[3LL * t], y = tb[3LL * t + 1], z = tb[3LL * t + 2];
         rw = float4{x, y, z, 0.0f};
         same = same && x == t0x && y == t0y && z == t0z;
-        const float yx = x - cx, yy = y - cy, yz = z - cz;
-        const float hx = g_bf_f(yx), hy = g_bf_f(yy), hz = g_bf_f(yz);
-        const float lx = yx - hx, ly = yy - hy, lz = yz - hz;
+        yx = x - cx, yy = y - cy, yz = z - cz;
         n = g_dist3(yx, yy, yz);
         mmax = n > mmax || n != n ? n : mmax;  // (a NaN norm sticks: the guard below sees it)
-        p0 = uint4{g_pk(hx, hy), g_pk(hz, hx), g_pk(hy, hz), g_pk(lx, ly)};
-        lzb = g_bf(lz);
       }
-      float n0, n1, n2;
-      g_split3(n, n0, n1, n2);
-      p1 = uint4{lzb | (g_bf(n0) << 16), g_pk(n1, n2), 0u, 0u};
+      uint4 p0, p1;
+      gate::target_row(yx, yy, yz, n, p0, p1);
       panel[0][r] = p0;
       panel[1][r] = p1;
       raw[r + (r >> 5)] = rw;
@@ -228,18 +186,18 @@ __global__ __launch_bounds__(kGQ, 3) void gate_nn_kernel(const GateArgs g) {
         uint4 nx = pl[32 * t8];
 #pragma unroll
         for (int t = t8; t < t8 + 8; ++t) {
-          const bf16x8 a = g_as_bf(nx);
+          const gate::bf16x8 a = gate::as_bf16x8(nx);
           if (t + 1 < t8 + 8) nx = pl[32 * (t + 1)];  // (the next tile's rows are on their way while this one is reduced)
           const f32x16 z = {0};
-          const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, g_as_bf(bq[0]), z, 0, 0, 0);
-          const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, g_as_bf(bq[1]), z, 0, 0, 0);
+          const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, gate::as_bf16x8(bq[0]), z, 0, 0, 0);
+          const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, gate::as_bf16x8(bq[1]), z, 0, 0, 0);
           float x, y;
-          g_min16(acc0, x, y);
-          tm0[t] = g_min3(x, y, __builtin_inff());
-          run0 = g_min3(run0, x, y);
-          g_min16(acc1, x, y);
-          tm1[t] = g_min3(x, y, __builtin_inff());
-          run1 = g_min3(run1, x, y);
+          gate::min16(acc0, x, y);
+          tm0[t] = gate::min3(x, y, __builtin_inff());
+          run0 = gate::min3(run0, x, y);
+          gate::min16(acc1, x, y);
+          tm1[t] = gate::min3(x, y, __builtin_inff());
+          run1 = gate::min3(run1, x, y);
           __builtin_amdgcn_sched_barrier(0);  // (tiles kept apart: hoisting the panel reads of many tiles spills registers)
         }
       } else {
@@ -290,11 +248,11 @@ __global__ __launch_bounds__(kGQ, 3) void gate_nn_kernel(const GateArgs g) {
 #pragma unroll
         for (int w = 1; w < kGW; ++w) mmax = redm[w] > mmax || redm[w] != redm[w] ? redm[w] : mmax;
         // thresholds: the owner of a query (lane 32 h + j holds query 32 h + j = column j of tile h) forms it, rounding up
-        const float tau0 = g_min3(run0, __shfl_xor(run0, 32, 64), __builtin_inff());
-        const float tau1 = g_min3(run1, __shfl_xor(run1, 32, 64), __builtin_inff());
-        float sl = g_next(g_next(mq + mmax) * (2.0f * kGKappa));
-        sl = g_next(sl + 1e-30f);
-        const float thr_own = g_next((h ? tau1 : tau0) + sl);
+        const float tau0 = gate::min3(run0, __shfl_xor(run0, 32, 64), __builtin_inff());
+        const float tau1 = gate::min3(run1, __shfl_xor(run1, 32, 64), __builtin_inff());
+        float sl = gate::next_up(gate::next_up(mq + mmax) * (2.0f * kGKappa));
+        sl = gate::next_up(sl + 1e-30f);
+        const float thr_own = gate::next_up((h ? tau1 : tau0) + sl);
         thr0 = __shfl(thr_own, j, 64), thr1 = __shfl(thr_own, 32 + j, 64);
         const bool risky = has && !(mq <= kGMaxNorm && mmax <= kGMaxNorm);  // (negated: NaNs are risky)
         wave_exact = __ballot(risky) != 0;
