@@ -62,6 +62,16 @@ struct GemmArgs {
   float* ln_stats;   // [M][2] mean, rstd
   float* ln_h;       // [M, K] the normalised rows (the weight gradient's operand)
   float* ln_xcopy;   // nullable: x itself (the first layer keeps its input)
+  // LNM == 2 (LayerNorm BACKWARD fused into the operand load, K = 256 only): A is d(LayerNorm output); the block
+  // turns its 32 rows into d x = resid + rstd (dh gamma - mean(dh gamma) - xhat mean(dh gamma xhat)) in registers
+  // (ln_stats is read here) and multiplies the dropout-masked d x; the blocks of column 0 also write what the
+  // standalone kernel would have written: d x, its masked copy and the tile's dgamma / dbeta partial sums
+  const float* ln_x;      // [M, K] the LayerNorm's input
+  const float* ln_resid;  // nullable [M, K]: the gradient arriving over the residual connection
+  float* ln_dx;           // [M, K]
+  float* ln_dxdrop;       // nullable [M, K]: d x under the dropout mask of ln_site (null: the operand is d x itself)
+  float* ln_part;         // [row tiles][2 K]: sum dh xhat | sum dh over the tile's rows
+  unsigned ln_site;
 };
 
 // grid = (ceil(M/32), N/32), block = 8 waves: the block owns ONE 32 x 32 MFMA tile and the waves split K.
@@ -87,9 +97,11 @@ __host__ __device__ inline int gemm_phase(int K) {
 // NPH > 0: K is exactly NPH phases and ALL global loads of the block are issued up front (NPH * 16 B * 2 per
 // thread in registers), so the block pays the L2/HBM latency once instead of once per phase; with NPH >= 3 the LDS
 // panels are double-buffered (one barrier per phase).  NPH == 0: any K, loads one phase ahead.
-template <int EPI, bool WT, int NPH, bool LNF = false>
+// LNM: 0 plain operand, 1 LayerNorm forward in the operand load, 2 LayerNorm backward in the operand load.
+template <int EPI, bool WT, int NPH, int LNM = 0>
 __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
-  static_assert(!LNF || (NPH == 2 && !WT), "the fused LayerNorm needs the whole K = 2 x 128 row in registers");
+  constexpr bool LNF = LNM == 1;
+  static_assert(LNM == 0 || NPH == 2, "the fused LayerNorm needs the whole K = 2 x 128 row in registers");
   constexpr int kBuf = NPH >= 3 ? 2 : 1, kPanel = 2 * 32 * kLD;
   __shared__ __attribute__((aligned(16))) float lds[kBuf * kPanel];  // A panel | W panel; later the 8 partial tiles
   float* la = lds;
@@ -201,6 +213,90 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
             if (g.ln_xcopy != nullptr) *reinterpret_cast<float4*>(g.ln_xcopy + o) = x;
           }
         }
+      }
+    }
+    if constexpr (LNM == 2) {
+      // same ownership as above: thread t holds columns 4 (t % 32) .. + 3 of rows t / 32 and 16 + t / 32 per phase
+      const int c4 = threadIdx.x & 31;
+      const bool col0 = blockIdx.y == 0;
+      float4 gm[NPH], pxh[NPH], pg[NPH];  // gamma; this thread's column partials of dh xhat and dh
+#pragma unroll
+      for (int ph = 0; ph < NPH; ++ph) {
+        gm[ph] = *reinterpret_cast<const float4*>(g.ln_gamma + ph * kKP + 4 * c4);
+        pxh[ph] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        pg[ph] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+#pragma unroll
+      for (int i = 0; i < kFI; ++i) {
+        const int row = r0 + (threadIdx.x >> 5) + 16 * i, rr = row < g.M ? row : g.M - 1;
+        const float mean = g.ln_stats[2 * rr], rstd = g.ln_stats[2 * rr + 1];
+        const long long o = (long long)rr * g.K + 4 * c4;
+        float4 xh[NPH];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+          const float4 x = *reinterpret_cast<const float4*>(g.ln_x + o + ph * kKP);
+          const float4 dh = st[ph].a[i];
+          xh[ph] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
+          const float dx = dh.x * gm[ph].x, dy = dh.y * gm[ph].y, dz = dh.z * gm[ph].z, dw = dh.w * gm[ph].w;
+          s1 += (dx + dy) + (dz + dw);
+          s2 += (dx * xh[ph].x + dy * xh[ph].y) + (dz * xh[ph].z + dw * xh[ph].w);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+          s1 += __shfl_xor(s1, off, 64);
+          s2 += __shfl_xor(s2, off, 64);
+        }
+        s1 /= (float)(NPH * kKP);
+        s2 /= (float)(NPH * kKP);
+        const bool save = col0 && row < g.M;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+          const float4 dh = st[ph].a[i];
+          float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (g.ln_resid != nullptr) v = *reinterpret_cast<const float4*>(g.ln_resid + o + ph * kKP);
+          v.x += rstd * (dh.x * gm[ph].x - s1 - xh[ph].x * s2);
+          v.y += rstd * (dh.y * gm[ph].y - s1 - xh[ph].y * s2);
+          v.z += rstd * (dh.z * gm[ph].z - s1 - xh[ph].z * s2);
+          v.w += rstd * (dh.w * gm[ph].w - s1 - xh[ph].w * s2);
+          float4 m = v;
+          if (g.ln_dxdrop != nullptr) {
+            const unsigned long long e = (unsigned long long)(o + ph * kKP);
+            m.x *= drop_scale(g.drop, g.ln_site, e);
+            m.y *= drop_scale(g.drop, g.ln_site, e + 1);
+            m.z *= drop_scale(g.drop, g.ln_site, e + 2);
+            m.w *= drop_scale(g.drop, g.ln_site, e + 3);
+          }
+          st[ph].a[i] = m;
+          if (save) {
+            *reinterpret_cast<float4*>(g.ln_dx + o + ph * kKP) = v;
+            if (g.ln_dxdrop != nullptr) *reinterpret_cast<float4*>(g.ln_dxdrop + o + ph * kKP) = m;
+            pxh[ph].x += dh.x * xh[ph].x;
+            pxh[ph].y += dh.y * xh[ph].y;
+            pxh[ph].z += dh.z * xh[ph].z;
+            pxh[ph].w += dh.w * xh[ph].w;
+            pg[ph].x += dh.x;
+            pg[ph].y += dh.y;
+            pg[ph].z += dh.z;
+            pg[ph].w += dh.w;
+          }
+        }
+      }
+      if (col0) {  // (block-uniform) the 16 row groups meet in LDS in a fixed order: [group][2 K]
+        constexpr int kW = 2 * NPH * kKP;
+        static_assert(16 * kW <= kBuf * kPanel && kW == kGT, "the partial table fits the panels, one column per thread");
+        float* pl = lds + (threadIdx.x >> 5) * kW + 4 * c4;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+          *reinterpret_cast<float4*>(pl + ph * kKP) = pxh[ph];
+          *reinterpret_cast<float4*>(pl + NPH * kKP + ph * kKP) = pg[ph];
+        }
+        __syncthreads();
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += lds[q * kW + threadIdx.x];
+        g.ln_part[(long long)blockIdx.x * kW + threadIdx.x] = t;
+        __syncthreads();
       }
     }
 #pragma unroll

@@ -354,8 +354,11 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const float* __restri
     const int j = acc_row(r, h);
     const bool in = c < P && j < P;
     const float pj = t[r] * inv;
-    if (in) probs[prow + j] = pj;
-    t[r] = in ? pj * drop_scale(drop, site, (unsigned long long)(prow + j)) : 0.0f;
+    const float keep = in ? drop_scale(drop, site, (unsigned long long)(prow + j)) : 0.0f;
+    // the saved probability carries the dropout decision in its sign bit (p >= 0, so the bit is free; -0.0 for a dropped
+    // zero): the backward kernel needs the mask in two orientations and would hash every element twice (2.5 of its 10.6 us)
+    if (in) probs[prow + j] = keep != 0.0f ? pj : -pj;
+    t[r] = pj * keep;
   }
   // O[i][d] = sum_j S[i][j] V[j][d]
 #pragma unroll
@@ -406,14 +409,15 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const float* __restri
   for (int r = 0; r < 16; ++r) {
     const int x = acc_row(r, h);
     const bool in = c < P && x < P;
-    pa_[r] = in ? probs[pbase + (long long)c * P + x] : 0.0f;
-    pb_[r] = in ? probs[pbase + (long long)x * P + c] : 0.0f;
+    pa_[r] = in ? probs[pbase + (long long)c * P + x] : -0.0f;  // sign bit set: dropped (see the forward kernel)
+    pb_[r] = in ? probs[pbase + (long long)x * P + c] : -0.0f;
     const long long tok = row0 + (x < P ? x : 0);
     const float on = x < P ? 1.0f : 0.0f;
     qb0[r] = qkv[tok * 3 * D + hd * DH + c] * on;
     kb0[r] = qkv[tok * 3 * D + D + hd * DH + c] * on;
     gb0[r] = dout[tok * D + hd * DH + c] * on;
   }
+  const float keep = drop.p > 0.0f ? drop.scale : 1.0f;  // keep-scale of the elements the forward pass did not drop
   f32x16 ga_acc = {0}, gb_acc = {0};  // lane = query: dP[i][j], j = acc_row(r, h);  lane = key: dP[i][j], i = acc_row(r, h)
 #pragma unroll
   for (int s2 = 0; s2 < KH; ++s2) {
@@ -424,11 +428,8 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const float* __restri
   float dsa[16], rowdot = 0.0f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int j = acc_row(r, h);
-    const bool in = c < P && j < P;
-    const long long e = pbase + (long long)(in ? c : 0) * P + (in ? j : 0);
-    const float pa = pa_[r];
-    const float dp = in ? ga_acc[r] * drop_scale(drop, site, (unsigned long long)e) : 0.0f;
+    const float pa = __builtin_fabsf(pa_[r]);
+    const float dp = ga_acc[r] * (__float_as_uint(pa_[r]) >> 31 ? 0.0f : keep);
     rowdot = __builtin_fmaf(dp, pa, rowdot);
     dsa[r] = dp;
     ga_acc[r] = pa;
@@ -441,10 +442,8 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const float* __restri
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = acc_row(r, h);
-    const bool in = i < P && c < P;
-    const long long e = pbase + (long long)(in ? i : 0) * P + (in ? c : 0);
-    const float pb = pb_[r];
-    const float mk = in ? drop_scale(drop, site, (unsigned long long)e) : 0.0f;
+    const float pb = __builtin_fabsf(pb_[r]);
+    const float mk = __float_as_uint(pb_[r]) >> 31 ? 0.0f : keep;
     const float rd = __shfl(rowdot, i, 64);  // (lane i holds query i's inner product, both halves)
     dsb[r] = pb * (gb_acc[r] * mk - rd);
     pdb[r] = pb * mk;
@@ -540,11 +539,12 @@ __global__ __launch_bounds__(kT) void ln_bwd_kernel(const float* __restrict__ dh
 struct LnSites {
   float* dgamma[2 * 16 + 1];
   float* dbeta[2 * 16 + 1];
+  int blocks[2 * 16 + 1];  // rows of the site's partial table (the fused backward leaves one per 32-row tile)
 };
-__global__ __launch_bounds__(1024) void ln_reduce_kernel(const float* __restrict__ part, long long site_stride, int blocks,
-                                                         int D, const LnSites out) {
+__global__ __launch_bounds__(1024) void ln_reduce_kernel(const float* __restrict__ part, long long site_stride, int D,
+                                                         const LnSites out) {
   __shared__ float sm[16][64];
-  const int c = threadIdx.x & 63, q = threadIdx.x >> 6, k = blockIdx.x * 64 + c;
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6, k = blockIdx.x * 64 + c, blocks = out.blocks[blockIdx.y];
   const float* p = part + (long long)blockIdx.y * site_stride;
   float s = 0.0f;
 #pragma unroll 4
@@ -699,6 +699,23 @@ void launch_gemm_ln(const GemmArgs& g, hipStream_t s) {
   hipLaunchKernelGGL((gemm_kernel<EPI, false, 2, true>), grid, block, 0, s, g);
 }
 
+// C = epi(m(d x) . W + ...) for K = 2 x kKP with W given as [K, N]: the LayerNorm BACKWARD that produces d x rides in the
+// GEMM's operand load (g.ln_* set, see tf_gemm.h)
+template <int EPI>
+void launch_gemm_lnb(const GemmArgs& g, hipStream_t s) {
+  const dim3 grid((g.M + 31) / 32, g.N / 32), block(kGT);
+  hipLaunchKernelGGL((gemm_kernel<EPI, true, 2, 2>), grid, block, 0, s, g);
+}
+
+// MPA_TF_LNB=0: every LayerNorm backward as its own launch (the A/B switch of the fusion above)
+bool lnb_fused() {
+  static const bool on = [] {
+    const char* e = getenv("MPA_TF_LNB");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
+}
+
 // one launch for n <= kGroup weight gradients
 void launch_wgrad_group(const WgradArgs* list, int n, hipStream_t s) {
   WgradGroup G{};
@@ -756,7 +773,7 @@ struct TfLayout {
   TfWs layer[16];
   float *x_final, *stats_f;
   // backward scratch
-  float *g_a, *g_b, *g_c, *gd_out, *gd_mid, *dz, *dqkv, *lnpart;
+  float *g_a, *g_b, *g_c, *g_d, *gd_out, *gd_mid, *dz, *dqkv, *lnpart;
   int64_t total;
 };
 
@@ -785,6 +802,7 @@ TfLayout tf_carve(float* base, const TfDims& d) {
   w.g_a = take(d.M * d.D);
   w.g_b = take(d.M * d.D);
   w.g_c = take(d.M * d.D);
+  w.g_d = take(d.M * d.D);  // d(attention output): the fused LayerNorm backward reads g_c while this is written
   w.gd_out = take(d.M * d.D);  // dropout-masked copies of the gradients at the two residual branches' outputs
   w.gd_mid = take(d.M * d.D);
   w.dz = take(d.M * d.FF);
@@ -923,20 +941,44 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
   const size_t ln_smem = sizeof(float) * 4 * 2 * D;
   const long long ln_stride = (long long)lnblocks * 2 * D;  // partial table of one LayerNorm
   LnSites sites{};
-  auto ln_site = [&](int idx, float* dgamma, float* dbeta) {  // 2l: LN1 of layer l, 2l + 1: LN2, 2L: the final one
+  // D = 256: LN2's backward rides in the operand load of the d o GEMM that consumes its d x (one partial row per 32-row
+  // tile).  The other LayerNorm backwards stay launches of their own: the GEMM below them has 32 column tiles, and 32
+  // blocks regenerating the same row tile's dropout mask cost more than the launch (19.3 vs 9.9 + 5.8 us, LABBOOK 5.3)
+  const bool fuse = Di == 2 * kKP && lnb_fused();
+  auto ln_site = [&](int idx, float* dgamma, float* dbeta, bool fused) {  // 2l: LN1 of layer l, 2l + 1: LN2, 2L: the final one
     sites.dgamma[idx] = dgamma;
     sites.dbeta[idx] = dbeta;
+    sites.blocks[idx] = fused ? (M + 31) / 32 : (int)lnblocks;
     return w.lnpart + idx * ln_stride;
+  };
+  struct LnB {  // one LayerNorm backward: d x = resid + J^T dh, its masked copy (site) and the dgamma / dbeta partials
+    const float *dh, *x, *stats, *gamma, *resid;
+    float *dx, *part, *dx_drop;
+    unsigned site;
+  };
+  auto ln_alone = [&](const LnB& b) {
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, b.dh, b.x, b.stats, b.gamma, b.resid, M, Di, b.dx,
+                       b.part, drop, b.site, b.dx_drop);
+  };
+  auto ln_ride = [&](GemmArgs& ga, const LnB& b) {  // ga.A becomes dh; the GEMM multiplies the masked d x
+    ga.A = b.dh;
+    ga.ln_x = b.x;
+    ga.ln_stats = const_cast<float*>(b.stats);
+    ga.ln_gamma = b.gamma;
+    ga.ln_resid = b.resid;
+    ga.ln_dx = b.dx;
+    ga.ln_dxdrop = b.dx_drop;
+    ga.ln_part = b.part;
+    ga.ln_site = b.site;
+    ga.drop = drop;
   };
   const float* const* fin = params + L * P_PER_LAYER;
   float* const* gfin = grad_params + L * P_PER_LAYER;
   // final LayerNorm backward -> g_a = d x_final
   // every LayerNorm backward below also leaves the dropout-masked copy its consumers need (see ln_bwd_kernel)
   const bool dr = dropout_p > 0.0f;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, grad_out, w.x_final, w.stats_f, fin[0],
-                     (const float*)nullptr, M, Di, w.g_a, ln_site((int)(2 * L), gfin[0], gfin[1]), drop,
-                     (unsigned)((L - 1) * S_PER_LAYER + S_FFN_OUT),
-                     dr ? w.gd_out : (float*)nullptr);
+  ln_alone(LnB{grad_out, w.x_final, w.stats_f, fin[0], nullptr, w.g_a, ln_site((int)(2 * L), gfin[0], gfin[1], false),
+                 dr ? w.gd_out : (float*)nullptr, (unsigned)((L - 1) * S_PER_LAYER + S_FFN_OUT)});
   float* g = w.g_a;      // gradient w.r.t. the current layer's output
   float* spare = w.g_b;  // rotating buffers
   float* spare2 = w.g_c;
@@ -945,8 +987,7 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     float* const* gp = grad_params + l * P_PER_LAYER;
     const TfWs& t = w.layer[l];
     const unsigned site0 = (unsigned)(l * S_PER_LAYER);
-    // ---- FFN: x_out = x_mid + drop(f . W2^T + b2),  f = drop(relu(LN2(x_mid) . W1^T + b1));  the dropout mask of
-    // the incoming gradient is regenerated inside the consumers (no masked copy is materialised)
+    // ---- FFN: x_out = x_mid + drop(f . W2^T + b2),  f = drop(relu(LN2(x_mid) . W1^T + b1))
     // (the layer's four weight gradients are off the critical path and all their operands stay intact until the
     // layer's last LayerNorm backward: they go out as ONE launch just before it)
     WgradArgs wl[4];
@@ -958,38 +999,45 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     launch_gemm<EPI_RELU_MASK, true>(ga, s);  // dz = d(pre-activation)
     wl[1] = wgrad_args(w.dz, t.h2, gp[P_W1], gp[P_B1], M, FFi, Di);
     launch_gemm<EPI_NONE, true>(gemm_args(w.dz, pp[P_W1], nullptr, spare2, M, Di, FFi), s);  // d LN2 output
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, spare2, t.x_mid, t.stats2, pp[P_G2], g,
-                       M, Di, spare, ln_site(2 * l + 1, gp[P_G2], gp[P_BE2]), drop, site0 + S_SA_OUT,
-                       dr ? w.gd_mid : (float*)nullptr);  // spare = d x_mid
+    const LnB ln2{spare2, t.x_mid, t.stats2, pp[P_G2], g, spare, ln_site(2 * l + 1, gp[P_G2], gp[P_BE2], fuse),
+                  dr ? w.gd_mid : (float*)nullptr, site0 + S_SA_OUT};  // spare = d x_mid
     float* g_mid = spare;
     spare = g;
     // ---- attention block: x_mid = x_in + drop(o . Wo^T + bo)
     const float* gdm = dr ? w.gd_mid : g_mid;  // drop-masked g_mid (site S_SA_OUT)
     wl[2] = wgrad_args(gdm, t.o, gp[P_WO], gp[P_BO], M, Di, Di);
-    launch_gemm<EPI_NONE, true>(gemm_args(gdm, pp[P_WO], nullptr, spare2, M, Di, Di), s);  // d o
+    float* d_o = spare2;
+    if (fuse) {  // LN2's backward inside the d o GEMM: its operand spare2 is still being read, so d o gets its own buffer
+      d_o = w.g_d;
+      ga = gemm_args(gdm, pp[P_WO], nullptr, d_o, M, Di, Di);
+      ln_ride(ga, ln2);
+      launch_gemm_lnb<EPI_NONE>(ga, s);
+    } else {
+      ln_alone(ln2);
+      launch_gemm<EPI_NONE, true>(gemm_args(gdm, pp[P_WO], nullptr, d_o, M, Di, Di), s);
+    }
     if (P <= 32 && Di / (int)H == 32)
-      hipLaunchKernelGGL(attn_bwd_mfma_kernel<1>, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
+      hipLaunchKernelGGL(attn_bwd_mfma_kernel<1>, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, t.probs, d_o, (int)P, Di,
                          (int)H, drop, site0 + S_ATTN, w.dqkv);
     else if (P <= 32 && Di / (int)H == 64)
-      hipLaunchKernelGGL(attn_bwd_mfma_kernel<2>, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
+      hipLaunchKernelGGL(attn_bwd_mfma_kernel<2>, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, t.probs, d_o, (int)P, Di,
                          (int)H, drop, site0 + S_ATTN, w.dqkv);
     else
-      hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, t.probs, spare2, (int)P, Di,
+      hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, t.probs, d_o, (int)P, Di,
                          (int)H, drop, site0 + S_ATTN, w.dqkv);
     wl[3] = wgrad_args(w.dqkv, t.h1, gp[P_WQKV], gp[P_BQKV], M, 3 * Di, Di);
     launch_gemm<EPI_NONE, true>(gemm_args(w.dqkv, pp[P_WQKV], nullptr, spare2, M, Di, 3 * Di), s);  // d LN1 out
-    launch_wgrad_group(wl, 4, s);  // before the kernel below overwrites g's buffer
+    launch_wgrad_group(wl, 4, s);  // before LN1's backward overwrites g's buffer and gd_out
     float* g_in = l == 0 ? grad_tokens : spare;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(lnblocks), dim3(kT), ln_smem, s, spare2, t.x_in, t.stats1, pp[P_G1], g_mid,
-                       M, Di, g_in, ln_site(2 * l, gp[P_G1], gp[P_BE1]), drop, (unsigned)((l - 1) * S_PER_LAYER + S_FFN_OUT),
-                       dr && l > 0 ? w.gd_out : (float*)nullptr);  // (the grouped launch above has read gd_out)
+    ln_alone(LnB{spare2, t.x_in, t.stats1, pp[P_G1], g_mid, g_in, ln_site(2 * l, gp[P_G1], gp[P_BE1], false),
+                 dr && l > 0 ? w.gd_out : (float*)nullptr, (unsigned)((l - 1) * S_PER_LAYER + S_FFN_OUT)});
     if (l > 0) {  // next layer down: its output gradient is g_in; g_mid's buffer is free again
       g = spare;
       spare = g_mid;
     }
   }
   hipLaunchKernelGGL(ln_reduce_kernel, dim3((unsigned)(2 * D / 64), (unsigned)(2 * L + 1)), dim3(1024), 0, s,
-                     (const float*)w.lnpart, ln_stride, (int)lnblocks, Di, sites);
+                     (const float*)w.lnpart, ln_stride, Di, sites);
   return mpa::check_launch("transformer_backward");
 }
 

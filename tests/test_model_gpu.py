@@ -267,6 +267,40 @@ def test_transformer_dropout_matches_oracle_with_same_masks(golden, cuda_device)
         assert _rel(a.cpu().numpy(), clean.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("B,P", [(3, 7), (5, 14)])
+def test_transformer_width_256_dropout_matches_oracle_with_same_masks(cuda_device, B, P):
+    """D = 256 is the width at which both LayerNorm passes ride in GEMM operand loads (tf_gemm.h LNM = 1 / 2): forward,
+    the d x / masked d x / dgamma / dbeta of every fused LayerNorm backward and the ragged last 32-row tile (M = 21, 70)
+    against the oracle regenerating the same counter-based masks."""
+    from multi_part_assembly_amd.transformer import _TransformerFn
+    from oracle import nets as on
+    torch.manual_seed(11)
+    D, H, FF, L = 256, 8, 512, 3
+    enc = TransformerEncoder(D, H, FF, L, norm_first=True, dropout=0.1)
+    with torch.no_grad():
+        for p in enc.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    p_drop, seed = 0.1, 0xFEED5EED77
+    sd = {k: v.detach().clone().requires_grad_() for k, v in enc.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    num = torch.randint(2, P + 1, (B,), generator=g)
+    valid = torch.arange(P)[None] < num[:, None]
+    tok0 = torch.randn(B, P, D, generator=g) * valid[..., None]
+    w = torch.randn(B, P, D, generator=g)
+    tok_ref = tok0.clone().requires_grad_()
+    ref = on.transformer_encoder(tok_ref, valid, sd, "", L, H, dropout_p=p_drop, seed=seed)
+    (ref * w).sum().backward()
+    enc.to(cuda_device).train()
+    tok = tok0.to(cuda_device).requires_grad_()
+    out = _TransformerFn.apply(tok, valid.reshape(-1).float().to(cuda_device), H, p_drop, seed, None, *enc._params())
+    (out * w.to(cuda_device)).sum().backward()
+    assert _rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
+    assert _rel(tok.grad.cpu().numpy(), tok_ref.grad.numpy()) < 1e-3
+    for k, p in enc.named_parameters():
+        assert _rel(p.grad.cpu().numpy(), sd[k].grad.numpy()) < 1e-3, k
+
+
 def test_transformer_and_pose_head_full_size_match_library_ops(cuda_device):
     """BASELINE.json configs[1] shapes (B=32, P=20, D=256, 8 heads, FF=1024, 4 layers; head F=256): the HIP
     kernels against PyTorch-ROCm's nn.TransformerEncoder / Linear stack on the same device, dropout off."""
