@@ -275,7 +275,7 @@ def test_transformer_width_256_dropout_matches_oracle_with_same_masks(cuda_devic
     from multi_part_assembly_amd.transformer import _TransformerFn
     from oracle import nets as on
     torch.manual_seed(11)
-    D, H, FF, L = 256, 8, 512, 3
+    D, H, FF, L = 256, 8, 1024, 3
     enc = TransformerEncoder(D, H, FF, L, norm_first=True, dropout=0.1)
     with torch.no_grad():
         for p in enc.parameters():
