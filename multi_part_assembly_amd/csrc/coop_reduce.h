@@ -35,6 +35,18 @@ constexpr int kSlices = 16;  // row slices per block of the reduction kernels (6
 // order: deterministic, one launch.  Returns true in that block only (totals valid for threads < 64).
 constexpr int kEB = 64;  // table rows per block
 
+#ifndef MPA_COOP_FENCE
+#define MPA_COOP_FENCE 0  // 1: plain stores + agent-scope release / acquire fences (the form of rounds 2-5a; A/B builds)
+#endif
+__device__ __forceinline__ void coop_store(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double coop_load(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+
 struct CoopWs {
   double* stage;       // [G][C][2]
   unsigned* ticket;    // [C/64], zero between launches
@@ -75,19 +87,37 @@ __device__ __forceinline__ bool coop_colsum(int total, int C, int c, const CoopW
       a += sm[k][cl][0];
       b += sm[k][cl][1];
     }
+#if MPA_COOP_FENCE
     ws.stage[((long long)g * C + c) * 2] = a;
     ws.stage[((long long)g * C + c) * 2 + 1] = b;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the group sums are visible device-wide before the ticket is
                                                         // taken (release only: no invalidate needed on this side)
+#else
+    // the group sums go out as agent-scope atomic stores (written through to the level every XCD sees) and are
+    // acknowledged before the ticket is taken.  An agent-scope release FENCE would do the same by writing back the
+    // XCD's whole L2 (buffer_wbl2) once per block — measured at ~30 us per launch of 320 blocks (LABBOOK 5.3 xvii)
+    coop_store(ws.stage + ((long long)g * C + c) * 2, a);
+    coop_store(ws.stage + ((long long)g * C + c) * 2 + 1, b);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   }
   __syncthreads();
   if (threadIdx.x == 0) last = atomicAdd(ws.ticket + blockIdx.x, 1u) == (unsigned)(G - 1);
   __syncthreads();
   if (!last) return false;
+#if MPA_COOP_FENCE
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (acquire only)
+#endif
   a = b = 0.0;
   batched_rows<4>(slice, kSlices, G,
-                  [&](int gg) { return *reinterpret_cast<const double2*>(ws.stage + ((long long)gg * C + c) * 2); },
+                  [&](int gg) {
+#if MPA_COOP_FENCE
+                    return *reinterpret_cast<const double2*>(ws.stage + ((long long)gg * C + c) * 2);
+#else
+                    const double* p = ws.stage + ((long long)gg * C + c) * 2;  // (agent-scope loads: past this XCD's L2)
+                    return make_double2(coop_load(p), coop_load(p + 1));
+#endif
+                  },
                   [&](int, const double2 t) {
                     a += t.x;
                     b += t.y;
