@@ -161,17 +161,15 @@ struct XcdPlan {
   int cnt[8];
   int lst[8][kPlanCap];
   int first[8][kPlanCap + 1];
+  int work[kMaxPairs];  // batches of every (sample, direction): published by its query-side sort block (see sort_hand_over)
 };
 // one block of 1024 threads: the LAST sort block of the launch (grid_sort_kernel), once every pair's batch count is there
-__device__ __forceinline__ void grid_assign_plan(const GridParams* __restrict__ params, const int* __restrict__ batches,
-                                                 int npairs, int nwaves, XcdPlan* __restrict__ plan) {
+__device__ __forceinline__ void grid_assign_plan(int npairs, int nwaves, XcdPlan* __restrict__ plan) {
   __shared__ int work[kMaxPairs];
   __shared__ int lst[8][kPlanCap], cnt[8];
   const int t = threadIdx.x;
-  for (int p = t; p < npairs; p += 1024) {
-    const int b = p >> 1, dir = p & 1, qslot = (b * 2 + dir) * 2 + 1;
-    work[p] = batches[(long long)qslot * kStartStride + params[b].nsuper];
-  }
+  for (int p = t; p < npairs; p += 1024)  // (agent-scope loads: the counts were written through by other XCDs' blocks)
+    work[p] = __hip_atomic_load(plan->work + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (t < 8) cnt[t] = 0;
   __syncthreads();
   for (int p = t; p < npairs; p += 1024) {  // rank by descending work (ties: lower pair first), snake over the XCDs
@@ -268,6 +266,7 @@ __device__ __forceinline__ void block_scan(int* __restrict__ cnt, int nkeys, int
   if (threadIdx.x == 1023) {
     st_out[nkeys] = run;
     if (WORK) ba_out[nkeys] = brun;
+    if (WORK) wsum[16][0] = brun;  // the total, for sort_hand_over (a row of its own: rows 0..15 are still being read)
   }
   __syncthreads();
   // the starts, coalesced (written from the loop above every store instruction touched 64 different cache lines)
@@ -362,6 +361,25 @@ __device__ __forceinline__ void grid_sort_role(const Src& src, const GridParams&
   }
 }
 
+// The end of a sort block when the launch also plans the search's waves: the query-side block of pair (b, c) publishes
+// its batch count, every block takes a ticket, and the last one plans.  The count goes out as ONE agent-scope atomic
+// store (written through, acknowledged before the ticket) and is read with agent-scope loads — an agent-scope release
+// fence here is a write-back of the XCD's whole L2 behind 320 KB of freshly sorted records per block: 10 of the
+// launch's 58 us (LABBOOK 5.3 xviii).  Returns true in the last block.
+__device__ __forceinline__ bool sort_hand_over(int role, int pair, int total, unsigned* __restrict__ ticket,
+                                               XcdPlan* __restrict__ plan, bool* last) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (role == 1) {
+      __hip_atomic_store(plan->work + pair, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  return *last;
+}
+
 // bbox [B*P][12]: per part lo1[3], lo2[3], hi1[3], hi2[3] of its points in the two shapes (valid parts; written by the
 // pose kernel of the loss).  ticket: one word, zero at launch (the pose kernel clears it).  plan != NULL: the block that
 // finishes last builds the search's wave plan (grid_assign_plan).
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(1024) void grid_sort_kernel(const float* __restrict
                                                          XcdPlan* __restrict__ plan, int nwaves,
                                                          const int* __restrict__ route) {
   __shared__ int cnt[kMaxCells + kMaxCells / 32 + 1];
-  __shared__ int wsum[16][2];
+  __shared__ int wsum[17][2];  // 16 wave totals of the scans + the query side's batch total
   __shared__ GridParams gsm;
   __shared__ bool last;
   __shared__ float vsm[64];  // the sample's valid flags
@@ -432,16 +450,10 @@ __global__ __launch_bounds__(1024) void grid_sort_kernel(const float* __restrict
     grid_sort_role<1, false>(src, g, slot, starts, batches, worklist, kWorkStride, records, rec_stride, cnt, wsum);
   }
   if (plan == nullptr) return;
-  // the last block of the launch plans the search's waves: everybody's batch counts are in global memory by then
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  grid_assign_plan(params, batches, (int)(gridDim.x / 2), nwaves, plan);
+  // the last block of the launch plans the search's waves
+  const bool routed_away = route != nullptr && route[b] == 0;
+  if (!sort_hand_over(role, b * 2 + c, routed_away ? 0 : wsum[16][0], ticket, plan, &last)) return;
+  grid_assign_plan((int)(gridDim.x / 2), nwaves, plan);
 }
 
 // ---- 2c. the generic operator's sort: two plain clouds per sample (chamfer.hip, mpa_chamfer_forward) -------------------
@@ -644,7 +656,7 @@ __global__ __launch_bounds__(1024) void cloud_sort_kernel(const float* __restric
                                                           unsigned* __restrict__ ticket, XcdPlan* __restrict__ plan,
                                                           int nwaves) {
   __shared__ int cnt[kMaxCells + kMaxCells / 32 + 1];
-  __shared__ int wsum[16][2];
+  __shared__ int wsum[17][2];  // 16 wave totals of the scans + the query side's batch total
   __shared__ GridParams gsm;
   __shared__ bool last;
   const int role = blockIdx.x & 1, c = (blockIdx.x >> 1) & 1, b = blockIdx.x >> 2;
@@ -688,15 +700,8 @@ __global__ __launch_bounds__(1024) void cloud_sort_kernel(const float* __restric
   else
     grid_sort_role<1, true>(src, g, slot, starts, batches, worklist, work_stride, records, rec_stride, cnt, wsum);
   if (plan == nullptr) return;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  grid_assign_plan(params, batches, (int)(gridDim.x / 2), nwaves, plan);
+  if (!sort_hand_over(role, b * 2 + c, wsum[16][0], ticket, plan, &last)) return;
+  grid_assign_plan((int)(gridDim.x / 2), nwaves, plan);
 }
 
 // behind the search (and the hand-back scan): every point that repeats its predecessor takes the answer of its run's head
