@@ -134,6 +134,15 @@ int mpa_pose_apply_backward(const float* grad_out, const float* pc, const float*
  * was kept (the gradient gate).  One launch instead of norm + compare + where. */
 int mpa_quat_sanitize(const float* quat, int64_t count, float* out, float* keep, void* stream);
 
+/* The weighting of the loss terms for one stochastic sample (multi_part_assembly/models/modules/base_model.py:348-387:
+ * `loss = sum_k w_k * mean_b term_k[b]`): terms [K, B] row-major, weights [K] -> means [K] (what the reference logs per
+ * term) and loss [1], in ONE launch instead of mean + dot; fixed reduction order.  1 <= K <= 64.
+ * Backward: grad_terms [K, B] = (grad_loss[0] * w_k + grad_means[k]) / B; grad_loss and grad_means may each be NULL. */
+int mpa_loss_reduce_forward(const float* terms, const float* weights, int64_t K, int64_t B, float* means, float* loss,
+                            void* stream);
+int mpa_loss_reduce_backward(const float* grad_loss, const float* grad_means, const float* weights, int64_t K, int64_t B,
+                             float* grad_terms, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused geometric-assembly loss — replaces, for the geometric datasets, the loss half of
  *   BaseModel._calc_loss : multi_part_assembly/models/modules/base_model.py:240-314

@@ -41,6 +41,8 @@ SIGNATURES: dict[str, tuple] = {
     "mpa_linear_sum_assignment": (_INT, [_P, _P, _I64, _I64, _P, _P]),
     "mpa_match_parts": (_INT, [_P] * 7 + [_I64] * 5 + [_P] * 6),
     "mpa_quat_sanitize": (_INT, [_P, _I64, _P, _P, _P]),
+    "mpa_loss_reduce_forward": (_INT, [_P, _P, _I64, _I64, _P, _P, _P]),
+    "mpa_loss_reduce_backward": (_INT, [_P, _P, _P, _I64, _I64, _P, _P]),
     "mpa_part_batch_transform": (_INT, [_P] * 4 + [_I64, _I64, _P, _P, _P]),
     "mpa_assembly_loss_forward": (_INT, [_P] * 6 + [_I64, _I64, _I64, _INT, _INT, _P, _P, _P, _P]),
     "mpa_assembly_loss_forward_timed": (_INT, [_P] * 6 + [_I64, _I64, _I64, _INT, _INT, _P, _P, _P, _P, _P]),

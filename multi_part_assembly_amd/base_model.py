@@ -245,10 +245,16 @@ class BaseModel(nn.Module):
                 w = [float(self.cfg.loss[f"{k}_w"]) if k.endswith("_loss") else 0.0 for k in keys]
                 cache = (keys, torch.tensor(w, dtype=terms.dtype, device=terms.device))
                 self._loss_weight_cache = cache
-            # mean over the batch of sum_k w_k t_kb = sum_k w_k mean_b t_kb: two launches (mean, dot) and two in backward
-            means = terms.mean(dim=1)                                                        # [K]
+            # mean over the batch of sum_k w_k t_kb = sum_k w_k mean_b t_kb: one launch each way on the device the fused
+            # loss runs on (mean + dot and their two backward kernels were 23 us of the 2.07 ms step)
+            if terms.is_cuda and terms.dtype == torch.float32:
+                from .loss import weighted_term_means
+                means, total = weighted_term_means(terms, cache[1])
+            else:
+                means = terms.mean(dim=1)                                                    # [K]
+                total = torch.dot(means, cache[1])
             result = {k: means[i] for i, k in enumerate(keys)}
-            result["loss"] = torch.dot(means, cache[1])
+            result["loss"] = total
             if not self.training:
                 result["batch_size"] = terms.shape[1]
             return result

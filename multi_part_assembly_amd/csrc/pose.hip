@@ -168,6 +168,62 @@ extern "C" int mpa_quat_sanitize(const float* quat, int64_t count, float* out, f
   return mpa::check_launch("quat_sanitize");
 }
 
+// ---- the weighted batch mean of the loss terms (base_model.py:348-387 with one sample: loss = sum_k w_k mean_b t_kb) ----------
+// One block; wave w reduces terms k = w, w + 4, ... over the batch (lane-strided partial sums, then the fixed xor tree),
+// thread 0 adds the weighted means in term order.
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ terms, const float* __restrict__ w, int K,
+                                                          int B, float* __restrict__ means, float* __restrict__ loss) {
+  __shared__ float sm[64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = wave; k < K; k += 4) {
+    float s = 0.0f;
+    for (int b = lane; b < B; b += 64) s += terms[(long long)k * B + b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) {
+      const float m = s / (float)B;
+      sm[k] = m;
+      means[k] = m;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int k = 0; k < K; ++k) t += w[k] * sm[k];
+    loss[0] = t;
+  }
+}
+
+// d terms[k][b] = (g_loss w_k + g_means[k]) / B  (either incoming gradient may be absent)
+__global__ __launch_bounds__(256) void loss_reduce_bwd_kernel(const float* __restrict__ g_loss, const float* __restrict__ g_means,
+                                                              const float* __restrict__ w, int K, int B,
+                                                              float* __restrict__ g_terms) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)K * B) return;
+  const int k = (int)(i / B);
+  float g = g_loss != nullptr ? g_loss[0] * w[k] : 0.0f;
+  if (g_means != nullptr) g += g_means[k];
+  g_terms[i] = g / (float)B;
+}
+
+extern "C" int mpa_loss_reduce_forward(const float* terms, const float* weights, int64_t K, int64_t B, float* means,
+                                       float* loss, void* stream) {
+  MPA_REQUIRE(K >= 1 && K <= 64 && B >= 1 && B < (1LL << 31), "loss_reduce_forward: need 1 <= K <= 64 terms and B >= 1");
+  MPA_REQUIRE(terms && weights && means && loss, "loss_reduce_forward: null pointer");
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, mpa::as_stream(stream), terms, weights, (int)K, (int)B, means,
+                     loss);
+  return mpa::check_launch("loss_reduce_forward");
+}
+
+extern "C" int mpa_loss_reduce_backward(const float* grad_loss, const float* grad_means, const float* weights, int64_t K,
+                                        int64_t B, float* grad_terms, void* stream) {
+  MPA_REQUIRE(K >= 1 && K <= 64 && B >= 1 && B < (1LL << 31), "loss_reduce_backward: need 1 <= K <= 64 terms and B >= 1");
+  MPA_REQUIRE(weights && grad_terms, "loss_reduce_backward: null pointer");
+  hipLaunchKernelGGL(loss_reduce_bwd_kernel, dim3((unsigned)((K * B + 255) / 256)), dim3(256), 0, mpa::as_stream(stream),
+                     grad_loss, grad_means, weights, (int)K, (int)B, grad_terms);
+  return mpa::check_launch("loss_reduce_backward");
+}
+
 extern "C" int mpa_pose_apply_forward(const float* pc, const float* quat, const float* trans,
                                       const float* mask, float fill, int64_t num_parts,
                                       int64_t num_points, float* out, void* stream) {

@@ -204,6 +204,47 @@ class _AssemblyLoss(torch.autograd.Function):
 SEARCH_MODES = {"brute": 0, "grid": 1, "leaf": 2, "auto": 3}
 
 
+class _LossReduce(torch.autograd.Function):
+    """loss = sum_k w_k mean_b terms[k, b] and the per-term means, one launch each way (csrc/pose.hip
+    mpa_loss_reduce_*; the reference: base_model.py:348-387 with one stochastic sample)."""
+
+    @staticmethod
+    def forward(ctx, terms, weights):
+        terms = terms.contiguous()
+        K, B = terms.shape
+        means = torch.empty(K, dtype=torch.float32, device=terms.device)
+        loss = torch.empty((), dtype=torch.float32, device=terms.device)
+        with torch.cuda.device(terms.device):
+            st = _lib.lib().mpa_loss_reduce_forward(_lib.ptr(terms), _lib.ptr(weights), K, B, _lib.ptr(means),
+                                                    _lib.ptr(loss), _lib.current_stream(terms.device))
+        _lib.check(st, "mpa_loss_reduce_forward")
+        ctx.save_for_backward(weights)
+        ctx.shape = (K, B)
+        ctx.set_materialize_grads(False)
+        return means, loss
+
+    @staticmethod
+    def backward(ctx, g_means, g_loss):
+        if g_means is None and g_loss is None:
+            return None, None
+        (weights,) = ctx.saved_tensors
+        K, B = ctx.shape
+        g_terms = torch.empty((K, B), dtype=torch.float32, device=weights.device)
+        gm = g_means.contiguous() if g_means is not None else None
+        gl = g_loss.contiguous() if g_loss is not None else None
+        with torch.cuda.device(weights.device):
+            st = _lib.lib().mpa_loss_reduce_backward(_lib.ptr(gl) if gl is not None else None,
+                                                     _lib.ptr(gm) if gm is not None else None, _lib.ptr(weights), K, B,
+                                                     _lib.ptr(g_terms), _lib.current_stream(weights.device))
+        _lib.check(st, "mpa_loss_reduce_backward")
+        return g_terms, None
+
+
+def weighted_term_means(terms, weights):
+    """terms [K, B], weights [K] (float32, same CUDA device) -> (means [K], loss scalar) through the library."""
+    return _LossReduce.apply(terms, weights)
+
+
 def search_mode(name=None):
     """The search behind the loss's two Chamfer terms as the C ABI's code: MPA_SHAPE_SEARCH if set (the override for tests
     and A/B runs), else `name` (a key of SEARCH_MODES; what a configuration asks for), else "grid".  Identical results all;

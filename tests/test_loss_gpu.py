@@ -387,3 +387,30 @@ def test_rotation3d_constructor_rule_on_device(cuda_device):
     assert torch.equal(rb.detach().cpu(), Rotation3D(q).rot)
     assert torch.equal(b.grad.cpu(), a.grad)
     assert torch.equal(rb[0, 0].cpu(), torch.tensor([1.0, 0, 0, 0])) and b.grad[0, 0].abs().sum() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,B", [(5, 32), (1, 1), (7, 200), (64, 3)])
+def test_weighted_term_means_equal_mean_and_dot(K, B):
+    """mpa_loss_reduce_* against the two library ops it replaces (base_model.py:348-387, one sample): the per-term batch means,
+    the weighted total, and the gradient with either or both outputs used."""
+    from multi_part_assembly_amd.loss import weighted_term_means
+    g = torch.Generator().manual_seed(K * 1000 + B)
+    terms = torch.randn(K, B, generator=g).cuda()
+    w = torch.rand(K, generator=g).cuda()
+    cm = torch.randn(K, generator=g).cuda()
+    a = terms.clone().requires_grad_()
+    means, loss = weighted_term_means(a, w)
+    ref = terms.clone().requires_grad_()
+    rmeans = ref.mean(dim=1)
+    rloss = torch.dot(rmeans, w)
+    torch.testing.assert_close(means, rmeans, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(loss, rloss, rtol=1e-5, atol=1e-6)
+    (3.0 * loss + (means * cm).sum()).backward()
+    (3.0 * rloss + (rmeans * cm).sum()).backward()
+    torch.testing.assert_close(a.grad, ref.grad, rtol=1e-5, atol=1e-7)
+    b = terms.clone().requires_grad_()
+    weighted_term_means(b, w)[1].backward()  # the training path: only the total is differentiated
+    torch.testing.assert_close(b.grad, (w / B)[:, None].expand(K, B), rtol=1e-6, atol=0)
+    means2, loss2 = weighted_term_means(terms, w)  # fixed reduction order: bit-reproducible
+    assert torch.equal(means2, means.detach()) and torch.equal(loss2, loss.detach())
