@@ -72,6 +72,14 @@ struct GemmArgs {
   float* ln_dxdrop;       // nullable [M, K]: d x under the dropout mask of ln_site (null: the operand is d x itself)
   float* ln_part;         // [row tiles][2 K]: sum dh xhat | sum dh over the tile's rows
   unsigned ln_site;
+  // SK (split-K over two blocks per output tile, gridDim.z = 2): each block multiplies one half of K, leaves its 32 x 32
+  // partial tile in sk_buf and takes the tile's ticket; the second block to arrive adds the two halves (lower half first,
+  // whichever arrived first) and runs the epilogue.  The half tiles cross XCDs as agent-scope atomic stores / loads ordered
+  // by the ticket (coop_reduce.h's hand-over: a release FENCE per block is a write-back of the XCD's L2 and made this
+  // kernel 3 x slower, LABBOOK 5.3 xvii).  Tickets are zero between launches (reset after use).
+  float* sk_buf;        // [tiles][2][1024]
+  unsigned* sk_ticket;  // [tiles]
+  int zero_n;           // words of `zero` to clear (0: 64)
 };
 
 // grid = (ceil(M/32), N/32), block = 8 waves: the block owns ONE 32 x 32 MFMA tile and the waves split K.
@@ -98,8 +106,10 @@ __host__ __device__ inline int gemm_phase(int K) {
 // thread in registers), so the block pays the L2/HBM latency once instead of once per phase; with NPH >= 3 the LDS
 // panels are double-buffered (one barrier per phase).  NPH == 0: any K, loads one phase ahead.
 // LNM: 0 plain operand, 1 LayerNorm forward in the operand load, 2 LayerNorm backward in the operand load.
-template <int EPI, bool WT, int NPH, int LNM = 0>
+template <int EPI, bool WT, int NPH, int LNM = 0, bool SK = false>
 __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
+  static_assert(!SK || (NPH > 0 && LNM == 0 && EPI != EPI_STATS), "split-K: whole phases, plain operands");
+  const int kz = SK ? (int)blockIdx.z * NPH : 0;  // first K phase of this block
   constexpr bool LNF = LNM == 1;
   static_assert(LNM == 0 || NPH == 2, "the fused LayerNorm needs the whole K = 2 x 128 row in registers");
   constexpr int kBuf = NPH >= 3 ? 2 : 1, kPanel = 2 * 32 * kLD;
@@ -108,10 +118,11 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
   float* lw = lds + 32 * kLD;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int r0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-  const int kp = gemm_phase(g.K), nph = g.K / kp, ld = kp + 4, q4 = kp / 4, cnt = 32 * q4;
+  const int kp = SK ? kKP : gemm_phase(g.K), nph = g.K / kp, ld = kp + 4, q4 = kp / 4, cnt = 32 * q4;
   const int lda = g.lda > 0 ? g.lda : g.K;
   const int ldw = g.ldw > 0 ? g.ldw : (WT ? g.N : g.K);
-  if (g.zero != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) g.zero[threadIdx.x] = 0u;
+  if (g.zero != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)threadIdx.x < (g.zero_n > 0 ? g.zero_n : 64))
+    g.zero[threadIdx.x] = 0u;
   constexpr int kFI = 32 * (kKP / 4) / kGT;  // float4 per thread, operand and phase
   struct Stage {
     float4 a[kFI], w[kFI];
@@ -123,11 +134,11 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
       if (idx < cnt) {
         const int row = idx / q4, c4 = idx % q4;
         const int ar = r0 + row < g.M ? r0 + row : g.M - 1;
-        st.a[i] = *reinterpret_cast<const float4*>(g.A + (long long)ar * lda + ph * kp + 4 * c4);
+        st.a[i] = *reinterpret_cast<const float4*>(g.A + (long long)ar * lda + (kz + ph) * kp + 4 * c4);
         if constexpr (WT) {  // [kp, 32] slab of W^T: 8 lanes per 128-byte row
-          st.w[i] = *reinterpret_cast<const float4*>(g.W + (long long)(ph * kp + (idx >> 3)) * ldw + n0 + 4 * (idx & 7));
+          st.w[i] = *reinterpret_cast<const float4*>(g.W + (long long)((kz + ph) * kp + (idx >> 3)) * ldw + n0 + 4 * (idx & 7));
         } else {
-          st.w[i] = *reinterpret_cast<const float4*>(g.W + (long long)(n0 + row) * ldw + ph * kp + 4 * c4);
+          st.w[i] = *reinterpret_cast<const float4*>(g.W + (long long)(n0 + row) * ldw + (kz + ph) * kp + 4 * c4);
         }
       }
     }
@@ -326,15 +337,42 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
   const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const float bias = g.bias ? g.bias[n0 + col] : 0.0f;
   float sv[2] = {0.0f, 0.0f};  // EPI_STATS: this thread's two output values (0 for rows behind M)
+  float tot[2];                // the tile's two values of this thread, summed over the waves
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    const int rl = it * 16 + rg, orow = r0 + rl;
-    if (orow >= g.M) continue;
+    const int rl = it * 16 + rg;
     const int reg = (rl & 3) + 4 * (rl >> 3), src = ((rl >> 2) & 1) * 32 + col;
     float v = 0.0f;
 #pragma unroll
     for (int w = 0; w < kGW; ++w) v += red[w][reg][src];
-    v += bias;
+    tot[it] = v;
+  }
+  if constexpr (SK) {
+    __shared__ int sk_last;
+    const long long tile = (long long)blockIdx.x * gridDim.y + blockIdx.y;
+    float* mine = g.sk_buf + (tile * 2 + blockIdx.z) * 1024;
+    __hip_atomic_store(mine + threadIdx.x, tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + kGT + threadIdx.x, tot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through and acknowledged before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned old = atomicAdd(g.sk_ticket + tile, 1u);
+      sk_last = old == 1u;
+      if (old == 1u) g.sk_ticket[tile] = 0u;  // ready for the next launch
+    }
+    __syncthreads();
+    if (!sk_last) return;
+    const float* other = g.sk_buf + (tile * 2 + (1 - blockIdx.z)) * 1024;
+    const float o0 = __hip_atomic_load(other + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float o1 = __hip_atomic_load(other + kGT + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot[0] = blockIdx.z == 0 ? tot[0] + o0 : o0 + tot[0];  // lower half of K first, whoever finishes
+    tot[1] = blockIdx.z == 0 ? tot[1] + o1 : o1 + tot[1];
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int rl = it * 16 + rg, orow = r0 + rl;
+    if (orow >= g.M) continue;
+    float v = tot[it] + bias;
     const long long o = (long long)orow * g.N + n0 + col;
     if constexpr (EPI == EPI_RELU_DROP) {
       v = __builtin_fmaxf(v, 0.0f) * drop_scale(g.drop, g.epi_site, (unsigned long long)o);
@@ -387,6 +425,19 @@ void launch_gemm(const GemmArgs& g, hipStream_t s) {
     case 8: hipLaunchKernelGGL((gemm_kernel<EPI, WT, 8>), grid, block, 0, s, g); break;
     default: hipLaunchKernelGGL((gemm_kernel<EPI, WT, 0>), grid, block, 0, s, g); break;
   }
+}
+
+// The same product with K split over two blocks per tile when the tiles alone cannot fill the chip (g.sk_buf set, at
+// most kSkTiles tiles, K = 6 or 8 full phases): twice the blocks, half the phases each — a block's phases run one
+// after the other (loads -> LDS -> MFMA chain), and with one block per CU nothing else hides them.
+constexpr int kSkTiles = 256;
+template <int EPI, bool WT = false>
+void launch_gemm_sk(const GemmArgs& g, hipStream_t s) {
+  const int tiles = ((g.M + 31) / 32) * (g.N / 32), nph = g.K % kKP == 0 ? g.K / kKP : 0;
+  if (g.sk_buf == nullptr || tiles > kSkTiles || (nph != 6 && nph != 8)) return launch_gemm<EPI, WT>(g, s);
+  const dim3 grid((g.M + 31) / 32, g.N / 32, 2), block(kGT);
+  if (nph == 8) hipLaunchKernelGGL((gemm_kernel<EPI, WT, 4, 0, true>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((gemm_kernel<EPI, WT, 3, 0, true>), grid, block, 0, s, g);
 }
 
 }  // namespace tfg

@@ -716,6 +716,15 @@ bool lnb_fused() {
   return on;
 }
 
+// MPA_TF_SPLITK=0: the K >= 768 GEMMs as one block per tile (the A/B switch of tf_gemm.h's split-K)
+bool splitk_on() {
+  static const bool on = [] {
+    const char* e = getenv("MPA_TF_SPLITK");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
+}
+
 // one launch for n <= kGroup weight gradients
 void launch_wgrad_group(const WgradArgs* list, int n, hipStream_t s) {
   WgradGroup G{};
@@ -774,6 +783,8 @@ struct TfLayout {
   float *x_final, *stats_f;
   // backward scratch
   float *g_a, *g_b, *g_c, *g_d, *gd_out, *gd_mid, *dz, *dqkv, *lnpart;
+  float* sk_buf;        // split-K half tiles of the K >= 768 GEMMs (tf_gemm.h)
+  unsigned* sk_ticket;  // their tickets: cleared by the first GEMM of every forward / backward call, reset after each use
   int64_t total;
 };
 
@@ -808,6 +819,8 @@ TfLayout tf_carve(float* base, const TfDims& d) {
   w.dz = take(d.M * d.FF);
   w.dqkv = take(d.M * 3 * d.D);
   w.lnpart = take((2 * d.L + 1) * ((d.M + 3) / 4) * 2 * d.D);  // one partial table per LayerNorm
+  w.sk_buf = take((int64_t)tfg::kSkTiles * 2048);
+  w.sk_ticket = reinterpret_cast<unsigned*>(take(tfg::kSkTiles));
   w.total = p - base;
   return w;
 }
@@ -856,6 +869,7 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
   const int M = (int)d.M, Di = (int)D, FFi = (int)FF;
   const float eps = 1e-5f;
   const dim3 rows((M + 3) / 4);
+  const bool sk = splitk_on();
   const bool fuse_ln = Di == 2 * kKP;  // D = 256: a block's 32 rows fit its registers, LayerNorm rides in the next GEMM
   for (int l = 0; l < L; ++l) {  // layer l + 1 finds its input already in its own x_in slot
     const float* const* pp = params + l * P_PER_LAYER;
@@ -870,11 +884,13 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
       g.ln_stats = t.stats1;
       g.ln_h = t.h1;
       g.ln_xcopy = l == 0 ? t.x_in : (float*)nullptr;
+      if (l == 0) g.zero = w.sk_ticket, g.zero_n = tfg::kSkTiles;  // (the call's first GEMM: split-K tickets)
       launch_gemm_ln<EPI_NONE>(g, s);
     } else {
       hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, l == 0 ? tokens : t.x_in, pp[P_G1], pp[P_BE1], M, Di, eps,
                          t.stats1, t.h1, l == 0 ? t.x_in : (float*)nullptr);
       g = gemm_args(t.h1, pp[P_WQKV], pp[P_BQKV], t.qkv, M, 3 * Di, Di);
+      if (l == 0) g.zero = w.sk_ticket, g.zero_n = tfg::kSkTiles;
       launch_gemm<EPI_NONE>(g, s);
     }
     // q k^T and attn . v on the matrix cores whenever the tokens fit one 32-row tile (the shipped configs: P = 20, head
@@ -916,7 +932,8 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
     g.resid = t.x_mid;
     g.drop = drop;
     g.epi_site = site0 + S_FFN_OUT;
-    launch_gemm<EPI_DROP_RESID>(g, s);
+    if (sk) g.sk_buf = w.sk_buf, g.sk_ticket = w.sk_ticket;
+    launch_gemm_sk<EPI_DROP_RESID>(g, s);
   }
   const float* const* fin = params + L * P_PER_LAYER;
   hipLaunchKernelGGL(ln_fwd_kernel, rows, dim3(kT), 0, s, w.x_final, fin[0], fin[1], M, Di, eps, w.stats_f, out,
@@ -944,6 +961,7 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
   // D = 256: LN2's backward rides in the operand load of the d o GEMM that consumes its d x (one partial row per 32-row
   // tile).  The other LayerNorm backwards stay launches of their own: the GEMM below them has 32 column tiles, and 32
   // blocks regenerating the same row tile's dropout mask cost more than the launch (19.3 vs 9.9 + 5.8 us, LABBOOK 5.3)
+  const bool sk = splitk_on();
   const bool fuse = Di == 2 * kKP && lnb_fused();
   auto ln_site = [&](int idx, float* dgamma, float* dbeta, bool fused) {  // 2l: LN1 of layer l, 2l + 1: LN2, 2L: the final one
     sites.dgamma[idx] = dgamma;
@@ -996,9 +1014,12 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     GemmArgs ga = gemm_args(gdo, pp[P_W2], nullptr, w.dz, M, FFi, Di);  // W2 is [D, FF] = [K, N]
     ga.resid = t.f;
     ga.drop = drop;  // the epilogue's keep-scale of the hidden layer's dropout (f > 0 <=> kept and active)
+    if (l == (int)L - 1) ga.zero = w.sk_ticket, ga.zero_n = tfg::kSkTiles;  // (the call's first GEMM: split-K tickets)
     launch_gemm<EPI_RELU_MASK, true>(ga, s);  // dz = d(pre-activation)
     wl[1] = wgrad_args(w.dz, t.h2, gp[P_W1], gp[P_B1], M, FFi, Di);
-    launch_gemm<EPI_NONE, true>(gemm_args(w.dz, pp[P_W1], nullptr, spare2, M, Di, FFi), s);  // d LN2 output
+    ga = gemm_args(w.dz, pp[P_W1], nullptr, spare2, M, Di, FFi);
+    if (sk) ga.sk_buf = w.sk_buf, ga.sk_ticket = w.sk_ticket;
+    launch_gemm_sk<EPI_NONE, true>(ga, s);  // d LN2 output
     const LnB ln2{spare2, t.x_mid, t.stats2, pp[P_G2], g, spare, ln_site(2 * l + 1, gp[P_G2], gp[P_BE2], fuse),
                   dr ? w.gd_mid : (float*)nullptr, site0 + S_SA_OUT};  // spare = d x_mid
     float* g_mid = spare;
@@ -1026,7 +1047,9 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
       hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * H)), dim3(kAT), 0, s, t.qkv, t.probs, d_o, (int)P, Di,
                          (int)H, drop, site0 + S_ATTN, w.dqkv);
     wl[3] = wgrad_args(w.dqkv, t.h1, gp[P_WQKV], gp[P_BQKV], M, 3 * Di, Di);
-    launch_gemm<EPI_NONE, true>(gemm_args(w.dqkv, pp[P_WQKV], nullptr, spare2, M, Di, 3 * Di), s);  // d LN1 out
+    ga = gemm_args(w.dqkv, pp[P_WQKV], nullptr, spare2, M, Di, 3 * Di);
+    if (sk) ga.sk_buf = w.sk_buf, ga.sk_ticket = w.sk_ticket;
+    launch_gemm_sk<EPI_NONE, true>(ga, s);  // d LN1 out
     launch_wgrad_group(wl, 4, s);  // before LN1's backward overwrites g's buffer and gd_out
     float* g_in = l == 0 ? grad_tokens : spare;
     ln_alone(LnB{spare2, t.x_in, t.stats1, pp[P_G1], g_mid, g_in, ln_site(2 * l, gp[P_G1], gp[P_BE1], false),
