@@ -86,11 +86,21 @@ def parse_args():
     return args
 
 
+def dp_backend():
+    """`MPA_DP_BACKEND=gloo` runs the N > 1 path (process group, bucketed all-reduce under backward, the `collectives`
+    object) over gloo with the ranks dealt round-robin onto the visible GPUs: every line of the data-parallel branch
+    executes on a 1-GPU box (tests/test_zz_bench_gpu.py).  Default `nccl` (= RCCL over xGMI), one rank per GPU."""
+    b = os.environ.get("MPA_DP_BACKEND", "nccl").lower()
+    if b not in ("nccl", "gloo"):
+        sys.exit(f"bench.py: MPA_DP_BACKEND={b!r} (nccl or gloo)")
+    return b
+
+
 def relaunch_distributed(args):
     """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start one rank per GPU ourselves."""
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and dp_backend() == "nccl":  # (gloo: ranks may share a GPU — the N > 1 code path without N GPUs)
         sys.exit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -434,10 +444,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
+    backend = dp_backend() if distributed else None
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":  # ranks share the visible GPUs
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local_rank)
@@ -671,7 +687,7 @@ def main():
                                             "call is far too small to fill the chip (launch-latency territory)"},
                         "timing": timing}
         rccl = None
-        if distributed:
+        if distributed and backend == "nccl":
             try:
                 rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception:  # noqa: BLE001
@@ -688,7 +704,8 @@ def main():
                                   "in step i of warm-up and timed region alike; part counts redrawn until their sum is within "
                                   "4 of its expectation (352 everyday / 512 artifact) except the historical batch 0 of rank 0",
                        "parallelism": f"dp{world}",
-                       "rccl_ranks": world if distributed else 0, "rccl_version": rccl,
+                       "rccl_ranks": world if distributed and backend == "nccl" else 0, "rccl_version": rccl,
+                       "dp_backend": backend,
                        "launch": "hip-graph replay" if use_graph else "eager",
                        **({"precision_note": "performance variant: PointNet encoder with bf16 stored activations and "
                            "v_mfma_f32_32x32x16_bf16 GEMMs, fp32 BatchNorm statistics and gradients; everything else "

@@ -183,6 +183,14 @@ class BaseModel(nn.Module):
         return self.cfg.loss.get("shape_search", None)
 
     # ---- the batch's k-d order (csrc/leaf_nn.hip): once per batch, beside the encoder --------------------------------------
+    def prepare_streams(self, dev):
+        """Create the side stream of `_start_part_order` now (Trainer.__init__ calls this): a capture then forks to a
+        stream that already exists instead of creating one mid-capture."""
+        dev = torch.device(dev)
+        side = getattr(self, "_order_stream", None)
+        if dev.type == "cuda" and (side is None or side.device != dev):
+            self._order_stream = torch.cuda.Stream(device=dev)
+
     def _start_part_order(self, data_dict):
         """Both Chamfer searches of the fused loss run on a k-d order of each part's points that depends on the batch
         only (`loss.part_order`).  It is computed ONCE per `loss_function` call — every GNN iteration and every min-of-N

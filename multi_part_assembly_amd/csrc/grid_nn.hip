@@ -1256,7 +1256,9 @@ __global__ __launch_bounds__(256) void grid_part_sum_kernel(const float* __restr
 
 int64_t grid_workspace_floats(int64_t B, int64_t P, int64_t N) {
   const int64_t rec = (P * N + 8) * 4;  // float4 records (+ sentinels) per slot
-  return 4 * B * rec + B * (int64_t)(sizeof(GridParams) / 4) + 2 * B * P * N + 12 * B * P;  // + 2 distance arrays + boxes
+  // + 2 distance arrays + boxes; a multiple of 4 floats: the leaf search's float4 arrays start right behind this region
+  // (odd B * P * N used to leave them 8-byte aligned)
+  return (4 * B * rec + B * (int64_t)(sizeof(GridParams) / 4) + 2 * B * P * N + 12 * B * P + 3) / 4 * 4;
 }
 int64_t grid_workspace_ints(int64_t B) {  // starts, batches, work list, wave table, ticket
   return 2 * 4 * B * (int64_t)kStartStride + 4 * B * (int64_t)kWorkStride + (int64_t)(sizeof(XcdPlan) / 4) + 16;

@@ -21,11 +21,22 @@ _STATUS: dict = {}
 
 
 def _status(dev):
-    st = _STATUS.get(dev.index)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _STATUS.get(idx)
     if st is None:
-        st = _STATUS[dev.index] = (torch.zeros(1, dtype=torch.int32, device=dev),
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("gru: the status word must be allocated before a HIP-graph capture (gru.prepare(device), "
+                               "done by Trainer.__init__, or one eager warm-up step)")
+        dev = torch.device("cuda", idx)
+        st = _STATUS[idx] = (torch.zeros(1, dtype=torch.int32, device=dev),
                                    torch.zeros(1, dtype=torch.int32).pin_memory())
     return st
+
+
+def prepare(dev):
+    """Allocate the device's status word and its pinned copy now (Trainer.__init__ calls this): both must exist before a
+    HIP-graph capture reaches the first GRU launch."""
+    return _status(torch.device(dev) if not isinstance(dev, torch.device) else dev)
 
 
 def raise_if_failed(device=None, synchronize=False):

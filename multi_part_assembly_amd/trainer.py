@@ -26,6 +26,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from . import gru as _gru
 from .gradsink import DeferredBackward, GradSink
 from .dp import BucketedGradReducer, broadcast_from_rank0, bucket_sizes_for, ordered_parameters
 from .optim import FlatBuffers, FusedAdam, cosine_warmup_lr, decay_mask_for
@@ -60,7 +61,30 @@ class Trainer:
             self.reducer.enabled = False
         self._graph_b = None
         self.sink = GradSink(on_ready=self.reducer._on_grad if not use_graph and self.world > 1 else None)
+        # buffers the step allocates lazily (the GRU launches' status word + its pinned copy, the loss's side stream)
+        # exist BEFORE a capture can see them: a pinned allocation is illegal under capture and a device word born there
+        # would live in the graph's private pool
+        dev = self.flat.flat_param.device
+        if dev.type == "cuda":
+            _gru.prepare(dev)
+            for mod in model.modules():
+                if hasattr(mod, "prepare_streams"):
+                    mod.prepare_streams(dev)
         self.set_epoch(0)
+
+    def check_health(self, synchronize=False):
+        """RuntimeError if a cooperative launch of this step (csrc/gru.hip) gave up: its outputs, and every gradient
+        behind them, are undefined.  Without `synchronize` the answer covers every launch whose status copy has already
+        arrived (a plain read of pinned memory: this runs after every step and replay); with it — in front of
+        checkpoints and evaluation reports — every launch issued so far."""
+        _gru.raise_if_failed(self.flat.flat_param.device, synchronize=synchronize)
+
+    def state_dict(self):
+        """Model + optimiser state for a checkpoint; refuses (RuntimeError) if a launch behind the current parameters
+        gave up."""
+        self.check_health(synchronize=True)
+        return {"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict()
+                if hasattr(self.optimizer, "state_dict") else None, "epoch": self.epoch}
 
     def set_epoch(self, epoch):
         self.epoch = epoch
@@ -157,6 +181,7 @@ class Trainer:
                 loss = self._fwd_bwd(self._tensor_items(data_dict))
                 if self.world > 1:
                     dist.all_reduce(self.flat.flat_grad, group=self.group)
+                self.check_health()
                 self.optimizer.prepare_hyper()
                 self.optimizer.step_dev()
                 return loss
@@ -175,7 +200,11 @@ class Trainer:
                 self._reduce_buckets_around(self._graph_b.replay)
             else:  # nothing was deferred (an encoder outside the fused kernels): one all-reduce behind the replay
                 dist.all_reduce(self.flat.flat_grad, group=self.group)
+            self.check_health()  # before the (uncaptured) optimiser step consumes the gradients
             self.optimizer.step_dev()
+        # the captured status copy refreshes the pinned word on every replay: a replay that gave up is reported here, at
+        # the latest one replay later (the copy is asynchronous), and the word is cleared so that later replays run
+        self.check_health()
         return self._static_loss
 
     def train_step(self, data_dict, batch_idx=0):
@@ -191,5 +220,6 @@ class Trainer:
                 one = self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
             loss.backward(one)
         self.optimizer.grad_scale = self.reducer.finish()
+        self.check_health()  # a launch that gave up must not reach the parameters (csrc/gru.hip's status word)
         self.optimizer.step()
         return loss.detach()

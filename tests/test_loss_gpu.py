@@ -311,6 +311,20 @@ def test_leaf_search_point_counts_and_masks(cuda_device, monkeypatch, N, P):
     _assert_searches_agree(batch, qp, tp, monkeypatch)
 
 
+@pytest.mark.parametrize("B,P,N", [(1, 3, 33), (1, 5, 101), (3, 1, 7)])
+def test_leaf_search_with_odd_total_point_count(cuda_device, monkeypatch, B, P, N):
+    """B * P * N odd: the grid region of the workspace used to end 8 bytes past a 16-byte boundary, which left the leaf
+    search's float4 arrays behind it misaligned (now rounded up in grid_workspace_floats) — leaf and auto against the scan."""
+    from multi_part_assembly_amd import synthetic
+
+    assert (B * P * N) % 2 == 1
+    batch = synthetic.make_batch(B, P, N, seed=7 + N, device=cuda_device, num_parts=[P] * B)
+    g = torch.Generator().manual_seed(N)
+    qp = torch.nn.functional.normalize(torch.randn(B, P, 4, generator=g), dim=-1).to(cuda_device)
+    tp = (torch.randn(B, P, 3, generator=g) * 0.3).to(cuda_device)
+    _assert_searches_agree(batch, qp, tp, monkeypatch)
+
+
 def test_leaf_search_with_trained_poses_and_given_order(cuda_device, monkeypatch):
     """Predictions within 2 % of the ground truth (the regime the twin-point seed is for), the order computed ONCE by
     `part_order` and handed to two evaluations with different poses: identical to the evaluation that orders itself and

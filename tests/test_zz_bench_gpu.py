@@ -68,6 +68,30 @@ def test_one_stdout_line_under_the_drivers_launcher(cuda_device):
     assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and d["steps"] == 3
 
 
+def test_two_rank_branch_runs_on_one_gpu_over_gloo(cuda_device):
+    """bench.py's world > 1 branch (process group, bucketed all-reduce hooks, `measure_collectives`, the `collectives`
+    object, max-over-ranks timing, one stdout line) executed end to end: `--gpus 2` under the driver's launcher with
+    MPA_DP_BACKEND=gloo, both ranks on this box's one GPU.  No RCCL rank exists here, and the line says so."""
+    env = dict(os.environ, MPA_DP_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["rccl_ranks"] == 0 and d["config"]["dp_backend"] == "gloo" and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * 32 * 20 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # whole-job aggregate
+    c = d["collectives"]
+    assert c["world"] == 2 and len(c["bucket_bytes"]) == 2 and all(b > 0 for b in c["bucket_bytes"])
+    assert len(c["allreduce_ms"]) == 2 and all(t > 0 for t in c["allreduce_ms"])
+    assert c["local_ms_per_step"] > 0 and c["exposed_ms"] >= 0 and 0.0 <= c["overlap_frac"] <= 1.0
+    assert "cpu_baseline" not in d and "chamfer_standalone" not in d  # rank-0-at-N=1 legs only
+    assert d["roofline"] is not None and d["roofline"]["launches"] == 3
+
+
 def _committed_ms(tag):
     """ms_per_step of the newest committed bench line profiles/rNN_<tag>_bench_line.json."""
     import glob
