@@ -25,6 +25,8 @@
 //     GEMM (dA = dY W) and of the weight-gradient GEMM (dW = dY^T A, K = points, one part per block,
 //     parts summed by a second deterministic stage).  The 3-channel first layer uses scalar-operand
 //     VALU panels (weights through the scalar cache), K = 3 being far too thin for a matrix core.
+#include <type_traits>
+
 #include "common.h"
 #include "coop_reduce.h"
 
@@ -1949,6 +1951,15 @@ __global__ __launch_bounds__(64 * kSlices) void pn_wgrad_reduce_group_kernel(con
   }
 }
 
+#ifndef MPA_PN_QFORM  // 1: conv2..conv4 backward in Q form on the bf16 matrix cores (pn_bwd_q.h); 0: pn_bwd_fused_kernel
+#define MPA_PN_QFORM 1
+#endif
+#include "pn_bwd_q.h"
+constexpr int kQB = 512;  // persistent blocks of pn_bwd_q_kernel: at most two per CU (MPA_PN_QB2)
+#ifndef MPA_PN_QB2  // 1: the 64 -> 64 layers as two 6-wave blocks per CU on 32-row units; 0: one 12-wave block on 64-row units
+#define MPA_PN_QB2 0
+#endif
+
 // ---- host side ------------------------------------------------------------------------------------------------
 struct Dims {
   int64_t M, N, F, rows;
@@ -1993,6 +2004,8 @@ struct PnWs {
   float* eval;    // [M][F] CSR values alpha*grad_feat
   float* q;       // [129][128] Q then c0
   float* gram;    // [129][128] Gram matrix then column sums of A4
+  float* ql[5];   // Q form of conv2..conv4: [CIN + 1][CIN] Q then c0 of layer l
+  float* red[5];  // ... and the layer's reduced tables [T | G | asum | (S, P^T P, psum)]
   int64_t total;
 };
 
@@ -2017,7 +2030,8 @@ PnWs carve(float* base, const Dims& d) {
   w.Y[1] = nullptr;  // never stored: recomputed from the points by its consumers (pn_fwd_first_kernel)
   for (int l = 2; l <= 4; ++l) w.Y[l] = take(d.rows * d.C[l]);
   w.Y[5] = nullptr;
-  for (int l = 1; l <= 4; ++l) w.dZ[l] = take(d.rows * d.C[l]);
+  for (int l = 1; l <= 4; ++l)  // (Q form: dZ1 never leaves the conv2 kernel)
+    w.dZ[l] = (MPA_PN_QFORM && l == 1) ? nullptr : take(d.rows * d.C[l]);
   w.Wt1 = take(192);
   for (int l = 1; l <= 5; ++l) w.bn[l] = take(4LL * d.C[l]);
   for (int l = 1; l <= 5; ++l) w.coef[l] = take(4LL * d.C[l]);
@@ -2031,8 +2045,14 @@ PnWs carve(float* base, const Dims& d) {
   // which wait for ONE grouped reduction at the end of the backward pass
   {
     const int64_t gram = (int64_t)kWG * (128 * 128 + 128);
-    const int64_t wait = (int64_t)2 * kWF * (128 * 64 + 64 * 64 + 64 * 64) + (int64_t)kWG * (64 * 4);
+    int64_t wait = (int64_t)2 * kWF * (128 * 64 + 64 * 64 + 64 * 64) + (int64_t)kWG * (64 * 4);
+    if (MPA_PN_QFORM)
+      wait = (int64_t)kQB * (pn_bwd_q_elems(128, 64, false) + pn_bwd_q_elems(64, 64, false) + pn_bwd_q_elems(64, 64, true));
     w.dwpart = take(gram > wait ? gram : wait);
+  }
+  for (int l = 2; l <= 4; ++l) {
+    w.ql[l] = take((int64_t)(d.C[l - 1] + 1) * d.C[l - 1]);
+    w.red[l] = take(pn_bwd_q_elems(d.C[l], d.C[l - 1], l == 2));
   }
   w.count = take(4);
   w.coop.ticket = reinterpret_cast<unsigned*>(take(4));
@@ -2228,6 +2248,58 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   reduce_dw(kWG, C4 * C4 + C4, w.gram);
   hipLaunchKernelGGL(pn_top_wgrad_kernel, dim3((unsigned)F), dim3(1024), 0, s, grad_feat, iw.argmax, valids, w.Y[4],
                      w.bn[4], conv_w[4], w.coef[5], w.gram, (int)M, (int)N, (int)F, grad_conv_w[4]);
+#if MPA_PN_QFORM
+  // ---- layers 4..2 in Q form (pn_bwd_q.h): Q / c0 of the layer, then input gradient + weight-gradient tables in one pass,
+  //      then the next layer's BatchNorm-backward coefficients; the weight gradients themselves at the very end
+  WgradReduceGroup rg{};
+  PnFinish fin{};
+  long long part_off = 0;
+  for (int l = 4, i = 0; l >= 2; --l, ++i) {
+    const int cout = d.C[l], cin = d.C[l - 1], elems = pn_bwd_q_elems(cout, cin, l == 2);
+    hipLaunchKernelGGL(pn_bwd_q_prep_kernel, dim3((unsigned)(cin + 1)), dim3((unsigned)cin), 0, s, conv_w[l - 1], w.coef[l],
+                       cout, cin, w.ql[l]);
+    float* const dwl = w.dwpart + part_off;
+#define MPA_QK(KK, RBB, NSS, NDD, NWW, FI, BPC, YP)                                                                   \
+  hipLaunchKernelGGL((pn_bwd_q_kernel<KK, 64, RBB, NSS, NDD, NWW, FI, (KK == 128 ? 2 : 1)>), dim3(nb),                  \
+                     dim3(64 * (NSS + NDD + NWW)), 0,                                                                   \
+                     s, w.dZ[l], YP, w.bn[l - 1], conv_w[l - 1], w.coef[l], w.ql[l], iw.vlist, (int)N, w.dZ[l - 1],    \
+                     w.partial, dwl, (const float*)w.Wt1)
+    const int nb = (cout == 64 && MPA_PN_QB2) ? 512 : 256;
+#if MPA_PN_QB2
+    if (l == 2) MPA_QK(64, 32, 2, 2, 2, true, 2, points);              // Yprev = conv1's output: recomputed from the points
+    else if (cout == 64) MPA_QK(64, 32, 2, 2, 2, false, 2, w.Y[l - 1]);  // 64 -> 64: two blocks per CU, 32-row units
+#else
+    if (l == 2) MPA_QK(64, 64, 4, 4, 4, true, 1, points);
+    else if (cout == 64) MPA_QK(64, 64, 4, 4, 4, false, 1, w.Y[l - 1]);  // 64 -> 64: 64-row units, four input-gradient tiles
+#endif
+    else MPA_QK(128, 32, 4, 4, 4, false, 1, w.Y[l - 1]);               // 64 -> 128: 32-row units, k-split input-gradient pairs
+#undef MPA_QK
+    hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(cin / 64), (unsigned)((nb + kEB - 1) / kEB)),
+                       dim3(64 * kSlices), 0, s, w.partial, (const float*)nullptr, nb, 1, cin, w.count, bn_w[l - 2],
+                       w.bn[l - 1], w.coef[l - 1], grad_bn_w[l - 2], grad_bn_b[l - 2], w.coop);
+    rg.part[i] = dwl;
+    rg.dw[i] = w.red[l];
+    rg.rows[i] = nb;
+    rg.elems[i] = elems;
+    fin.red[i] = w.red[l];
+    fin.w[i] = conv_w[l - 1];
+    fin.coef[i] = w.coef[l];
+    fin.dw[i] = grad_conv_w[l - 1];
+    fin.K[i] = cout;
+    fin.CIN[i] = cin;
+    part_off += (long long)nb * elems;
+  }
+  rg.first[0] = 0;
+  fin.first[0] = 0;
+  for (int k = 0; k < 4; ++k) rg.first[k + 1] = rg.first[k] + (k < 3 ? (rg.elems[k] + 63) / 64 : 0);
+  for (int k = 0; k < 3; ++k) fin.first[k + 1] = fin.first[k] + (fin.K[k] * fin.CIN[k] + 255) / 256;
+  fin.w1 = conv_w[0];
+  fin.coef1 = w.coef[1];
+  fin.dw1 = grad_conv_w[0];
+  fin.first_layer = 2;  // conv2's table carries S = dZ1^T P, P^T P and psum
+  hipLaunchKernelGGL(pn_wgrad_reduce_group_kernel, dim3((unsigned)rg.first[4]), dim3(64 * kSlices), 0, s, rg);
+  hipLaunchKernelGGL(pn_bwd_finish_kernel, dim3((unsigned)(fin.first[3] + 1)), dim3(256), 0, s, fin);
+#else
   // ---- layers 4..2: fused input + weight gradient, then the next layer's BatchNorm-backward coefficients
   WgradReduceGroup rg{};
   int n_wait = 0;
@@ -2264,5 +2336,6 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   rg.first[0] = 0;
   for (int k = 0; k < 4; ++k) rg.first[k + 1] = rg.first[k] + (k < n_wait ? (rg.elems[k] + 63) / 64 : 0);
   hipLaunchKernelGGL(pn_wgrad_reduce_group_kernel, dim3((unsigned)rg.first[4]), dim3(64 * kSlices), 0, s, rg);
+#endif
   return mpa::check_launch("pointnet_backward");
 }
