@@ -209,13 +209,15 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
     *reinterpret_cast<pn_bf16x4*>(p + 4 * K) = pl;
   }
 
-  if (wave < NS) {
-    // ================================================ stager waves ==========================================================
-    // per iteration `it`:  epilogue of unit it - 1 (the input-gradient waves left its dA tiles in LDS one barrier ago): ReLU
-    // mask from the re-fetched Yprev rows, dZ_{l-1} as coalesced 16-byte stores, BatchNorm-backward sums;  conversion of unit
-    // it + 1 into the other panel;  requests for unit it + 2 and for the Yprev rows of unit it.
-    const int t = threadIdx.x;
-    const int cz4 = t % QK, rz0 = t / QK, cy4 = t % QC, ry0 = t / QC;
+  // ---- the input gradient's epilogue, shared by the two kinds of matrix waves (each is half idle between its LDS round trips) ----
+  // The input-gradient waves leave a unit's dA tiles raw in LDS; one barrier later, at the top of the next iteration, the
+  // input-gradient waves finish the first half of the unit's rows and the weight-gradient waves the second: ReLU mask from the
+  // re-fetched Yprev rows (requested an iteration earlier), dZ_{l-1} as coalesced 16-byte stores, BatchNorm-backward sums.
+  // Thread -> (row group, 4 columns) as in the stagers.
+  static_assert(NW == NS && ND == NS && NLY % 2 == 0, "the epilogue uses the stagers' thread -> (row, 4 columns) map in both roles");
+  constexpr int EH = NLY / 2;  // float4 rows per thread, role and unit
+    const int te = threadIdx.x & (NTS - 1);
+    const int cy4 = te % QC, ry0 = te / QC;
     const float4 sc = reinterpret_cast<const float4*>(bn_prev)[cy4];
     const float4 sh = reinterpret_cast<const float4*>(bn_prev + CIN)[cy4];
     const float4 mn = reinterpret_cast<const float4*>(bn_prev + 2 * CIN)[cy4];
@@ -225,15 +227,114 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
       w1b = reinterpret_cast<const float4*>(wt1 + 64)[cy4];
       w1c = reinterpret_cast<const float4*>(wt1 + 128)[cy4];
     }
-    float4 rz[NLZ], ry[NLY], ye[NLY];
-    float4 colsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f), s1v = colsum, t2v = colsum;
-    float4 sax = colsum, say = colsum, saz = colsum;                         // FIRST: S[c][k] = sum dZ1[., c] p_k of this thread's 4 channels
-    float pp[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // FIRST: xx xy xz yy yz zz, x y z
     auto first4 = [&](float4 p) {
       return make_float4(first_layer_y(p.x, p.y, p.z, w1a.x, w1b.x, w1c.x), first_layer_y(p.x, p.y, p.z, w1a.y, w1b.y, w1c.y),
                          first_layer_y(p.x, p.y, p.z, w1a.z, w1b.z, w1c.z), first_layer_y(p.x, p.y, p.z, w1a.w, w1b.w, w1c.w));
     };
-    auto load_y = [&](int it, int m, float4 (&dst)[NLY]) {  // rows past the part's end: any row of the part (dropped by the users)
+    float4 ye[EH];
+    float4 s1v = make_float4(0.0f, 0.0f, 0.0f, 0.0f), t2v = s1v;
+    float4 sax = s1v, say = s1v, saz = s1v;  // FIRST: S[c][k] = sum dZ1[., c] p_k of this thread's 4 channels
+    auto load_y = [&](int it, int m, auto half_tag) {  // rows past the part's end: any row of the part (dropped below)
+      constexpr int HALF = decltype(half_tag)::value;
+      const int n0 = n0_of(it);
+      const long long row0 = (long long)m * N + n0;
+#pragma unroll
+      for (int i = 0; i < EH; ++i) {
+        const int rl = ry0 + (HALF * EH + i) * RG;
+        const int rr = n0 + rl < N ? rl : N - 1 - n0;
+        if constexpr (FIRST) {
+          const float* p = y_prev + (row0 + rr) * 3;
+          ye[i] = make_float4(p[0], p[1], p[2], 0.0f);
+        } else {
+          ye[i] = reinterpret_cast<const float4*>(y_prev)[(row0 + rr) * QC + cy4];
+        }
+      }
+    };
+    // the epilogue of unit `it` (its dA tiles in outp[it & 1], its Yprev rows / points in `ye`)
+    auto epilogue = [&](int it, int m, auto half_tag) {
+      constexpr int HALF = decltype(half_tag)::value;
+      const int n0 = n0_of(it);
+      const long long row0 = (long long)m * N + n0;
+      const float* ob = &outp[it & 1][0][0];
+#pragma unroll
+      for (int i = 0; i < EH; ++i) {
+        const int rl = ry0 + (HALF * EH + i) * RG;
+        const bool ok = n0 + rl < N;
+        float4 o = *reinterpret_cast<const float4*>(ob + rl * CIN + 4 * cy4);
+        if constexpr (KPN == 2) {
+          const float4 o2 = *reinterpret_cast<const float4*>(ob + OUTP + rl * CIN + 4 * cy4);
+          o.x += o2.x;
+          o.y += o2.y;
+          o.z += o2.z;
+          o.w += o2.w;
+        }
+        float4 yv = ye[i];
+        float px = 0.0f, py = 0.0f, pzc = 0.0f;
+        if constexpr (FIRST) {
+          px = yv.x;
+          py = yv.y;
+          pzc = yv.z;
+          yv = first4(yv);
+        }
+        float4 d;  // the mask is the forward's own expression: relu(fma(y, scale, shift)) > 0
+        d.x = (ok && __builtin_fmaf(yv.x, sc.x, sh.x) > 0.0f) ? o.x : 0.0f;
+        d.y = (ok && __builtin_fmaf(yv.y, sc.y, sh.y) > 0.0f) ? o.y : 0.0f;
+        d.z = (ok && __builtin_fmaf(yv.z, sc.z, sh.z) > 0.0f) ? o.z : 0.0f;
+        d.w = (ok && __builtin_fmaf(yv.w, sc.w, sh.w) > 0.0f) ? o.w : 0.0f;
+        if constexpr (FIRST) {
+          sax.x = __builtin_fmaf(d.x, px, sax.x);
+          sax.y = __builtin_fmaf(d.y, px, sax.y);
+          sax.z = __builtin_fmaf(d.z, px, sax.z);
+          sax.w = __builtin_fmaf(d.w, px, sax.w);
+          say.x = __builtin_fmaf(d.x, py, say.x);
+          say.y = __builtin_fmaf(d.y, py, say.y);
+          say.z = __builtin_fmaf(d.z, py, say.z);
+          say.w = __builtin_fmaf(d.w, py, say.w);
+          saz.x = __builtin_fmaf(d.x, pzc, saz.x);
+          saz.y = __builtin_fmaf(d.y, pzc, saz.y);
+          saz.z = __builtin_fmaf(d.z, pzc, saz.z);
+          saz.w = __builtin_fmaf(d.w, pzc, saz.w);
+        } else {
+          if (ok) reinterpret_cast<float4*>(dz_prev)[(row0 + rl) * QC + cy4] = d;
+        }
+        s1v.x += d.x;
+        s1v.y += d.y;
+        s1v.z += d.z;
+        s1v.w += d.w;
+        t2v.x = __builtin_fmaf(d.x, yv.x - mn.x, t2v.x);  // sum d (yprev - mean): scaled by invstd at the end
+        t2v.y = __builtin_fmaf(d.y, yv.y - mn.y, t2v.y);
+        t2v.z = __builtin_fmaf(d.z, yv.z - mn.z, t2v.z);
+        t2v.w = __builtin_fmaf(d.w, yv.w - mn.w, t2v.w);
+      }
+    };
+    auto put_sums = [&](int role) {  // scratch rows [(q * 2 + role) * RG + row group]: q = 1 s1, 2 s2, 3..5 S's columns
+      float* scr = reinterpret_cast<float*>(&pz[0][0]);
+      const float4 is4 = reinterpret_cast<const float4*>(bn_prev + 3 * CIN)[cy4];
+      t2v.x *= is4.x;
+      t2v.y *= is4.y;
+      t2v.z *= is4.z;
+      t2v.w *= is4.w;
+      *reinterpret_cast<float4*>(scr + ((1 * 2 + role) * RG + ry0) * CIN + 4 * cy4) = s1v;
+      *reinterpret_cast<float4*>(scr + ((2 * 2 + role) * RG + ry0) * CIN + 4 * cy4) = t2v;
+      if constexpr (FIRST) {
+        *reinterpret_cast<float4*>(scr + ((3 * 2 + role) * RG + ry0) * CIN + 4 * cy4) = sax;
+        *reinterpret_cast<float4*>(scr + ((4 * 2 + role) * RG + ry0) * CIN + 4 * cy4) = say;
+        *reinterpret_cast<float4*>(scr + ((5 * 2 + role) * RG + ry0) * CIN + 4 * cy4) = saz;
+      }
+    };
+    using Half0 = std::integral_constant<int, 0>;
+    using Half1 = std::integral_constant<int, 1>;
+
+  if (wave < NS) {
+    // ================================================ stager waves ==========================================================
+    // per iteration `it`: conversion of unit it + 1 into the other panel (its rows were requested a whole iteration ago), then
+    // the requests for unit it + 2.
+    const int t = threadIdx.x;
+    const int cz4 = t % QK, rz0 = t / QK;
+    float4 rz[NLZ], ry[NLY];
+    float4 colsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float pp[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // FIRST: xx xy xz yy yz zz, x y z
+    auto load_rows = [&](int it, int m, float4 (&dst)[NLY]) {  // rows past the part's end: any row of the part (dropped by the users)
       const int n0 = n0_of(it);
       const long long row0 = (long long)m * N + n0;
 #pragma unroll
@@ -257,7 +358,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
         const int rr = n0 + rl < N ? rl : N - 1 - n0;
         rz[i] = reinterpret_cast<const float4*>(dz)[(row0 + rr) * QK + cz4];
       }
-      load_y(it, m, ry);
+      load_rows(it, m, ry);
     };
     const pn_f32x2 sc01 = {sc.x, sc.y}, sc23 = {sc.z, sc.w}, sh01 = {sh.x, sh.y}, sh23 = {sh.z, sh.w}, zero2 = {0.0f, 0.0f};
     auto stash_t = [&](int it, int b, auto full_tag) {
@@ -317,102 +418,29 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
       if (n0_of(it) + RB <= N) stash_t(it, b, std::true_type{});
       else stash_t(it, b, std::false_type{});
     };
-    // the epilogue of unit `it` (its dA tiles in outp[it & 1], its Yprev rows / points in `ye`)
-    auto epilogue = [&](int it, int m) {
-      const int n0 = n0_of(it);
-      const long long row0 = (long long)m * N + n0;
-      const float* ob = &outp[it & 1][0][0];
-#pragma unroll
-      for (int i = 0; i < NLY; ++i) {
-        const int rl = ry0 + i * RG;
-        const bool ok = n0 + rl < N;
-        float4 o = *reinterpret_cast<const float4*>(ob + rl * CIN + 4 * cy4);
-        if constexpr (KPN == 2) {
-          const float4 o2 = *reinterpret_cast<const float4*>(ob + OUTP + rl * CIN + 4 * cy4);
-          o.x += o2.x;
-          o.y += o2.y;
-          o.z += o2.z;
-          o.w += o2.w;
-        }
-        float4 yv = ye[i];
-        float px = 0.0f, py = 0.0f, pzc = 0.0f;
-        if constexpr (FIRST) {
-          px = yv.x;
-          py = yv.y;
-          pzc = yv.z;
-          yv = first4(yv);
-        }
-        float4 d;  // the mask is the forward's own expression: relu(fma(y, scale, shift)) > 0
-        d.x = (ok && __builtin_fmaf(yv.x, sc.x, sh.x) > 0.0f) ? o.x : 0.0f;
-        d.y = (ok && __builtin_fmaf(yv.y, sc.y, sh.y) > 0.0f) ? o.y : 0.0f;
-        d.z = (ok && __builtin_fmaf(yv.z, sc.z, sh.z) > 0.0f) ? o.z : 0.0f;
-        d.w = (ok && __builtin_fmaf(yv.w, sc.w, sh.w) > 0.0f) ? o.w : 0.0f;
-        if constexpr (FIRST) {
-          sax.x = __builtin_fmaf(d.x, px, sax.x);
-          sax.y = __builtin_fmaf(d.y, px, sax.y);
-          sax.z = __builtin_fmaf(d.z, px, sax.z);
-          sax.w = __builtin_fmaf(d.w, px, sax.w);
-          say.x = __builtin_fmaf(d.x, py, say.x);
-          say.y = __builtin_fmaf(d.y, py, say.y);
-          say.z = __builtin_fmaf(d.z, py, say.z);
-          say.w = __builtin_fmaf(d.w, py, say.w);
-          saz.x = __builtin_fmaf(d.x, pzc, saz.x);
-          saz.y = __builtin_fmaf(d.y, pzc, saz.y);
-          saz.z = __builtin_fmaf(d.z, pzc, saz.z);
-          saz.w = __builtin_fmaf(d.w, pzc, saz.w);
-        } else {
-          if (ok) reinterpret_cast<float4*>(dz_prev)[(row0 + rl) * QC + cy4] = d;
-        }
-        s1v.x += d.x;
-        s1v.y += d.y;
-        s1v.z += d.z;
-        s1v.w += d.w;
-        t2v.x = __builtin_fmaf(d.x, yv.x - mn.x, t2v.x);  // sum d (yprev - mean): scaled by invstd at the end
-        t2v.y = __builtin_fmaf(d.y, yv.y - mn.y, t2v.y);
-        t2v.z = __builtin_fmaf(d.z, yv.z - mn.z, t2v.z);
-        t2v.w = __builtin_fmaf(d.w, yv.w - mn.w, t2v.w);
-      }
-    };
-    int m_prev = 0, m_cur = part_of(0), m2 = part_of(2);
+    int m2 = part_of(2);
     if (n_it > 0) {
-      fetch(0, m_cur);
+      fetch(0, part_of(0));
       stash(0, 0);
       if (n_it > 1) fetch(1, part_of(1));
-      load_y(0, m_cur, ye);
     }
     __syncthreads();  // panel 0 and the weight image are complete
     PN_T_DECL
     for (int it = 0; it < n_it; ++it) {
       const int m3 = part_of(it + 3);  // (the part id of a unit is looked up two iterations before its rows are requested)
-      const int m_next = part_of(it + 1);
-      if (it > 0) epilogue(it - 1, m_prev);
       if (it + 1 < n_it) stash(it + 1, (it + 1) & 1);
       if (it + 2 < n_it) fetch(it + 2, m2);
-      if (it > 0) load_y(it, m_cur, ye);  // (unit 0's rows were requested in the prologue)
       m2 = m3;
-      m_prev = m_cur;
-      m_cur = m_next;
       PN_BAR
     }
-    if (n_it > 0) epilogue(n_it - 1, m_prev);
     PN_T_REPORT("stager")
     // ---- block totals (fixed order): column sums of A, BatchNorm-backward sums (FIRST: S, P^T P, psum) ----------------------
     float* scr = reinterpret_cast<float*>(&pz[0][0]);
-    const float4 is4 = reinterpret_cast<const float4*>(bn_prev + 3 * CIN)[cy4];
-    t2v.x *= is4.x;
-    t2v.y *= is4.y;
-    t2v.z *= is4.z;
-    t2v.w *= is4.w;
     *reinterpret_cast<float4*>(scr + (0 * RG + ry0) * CIN + 4 * cy4) = colsum;
-    *reinterpret_cast<float4*>(scr + (1 * RG + ry0) * CIN + 4 * cy4) = s1v;
-    *reinterpret_cast<float4*>(scr + (2 * RG + ry0) * CIN + 4 * cy4) = t2v;
     if constexpr (FIRST) {
-      *reinterpret_cast<float4*>(scr + (3 * RG + ry0) * CIN + 4 * cy4) = sax;
-      *reinterpret_cast<float4*>(scr + (4 * RG + ry0) * CIN + 4 * cy4) = say;
-      *reinterpret_cast<float4*>(scr + (5 * RG + ry0) * CIN + 4 * cy4) = saz;
       if (cy4 == 0) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e) scr[6 * RG * CIN + ry0 * 12 + e] = pp[e];
+        for (int e = 0; e < 9; ++e) scr[12 * RG * CIN + ry0 * 12 + e] = pp[e];
       }
     }
   } else if (wave < NS + ND) {
@@ -436,8 +464,14 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
     const float c0v = kp == KPN - 1 ? q[(long long)CIN * CIN + d0 + j] : 0.0f;  // c0 rides in one wave's accumulator
     __syncthreads();
     PN_T_DECL
+    int m_prev = 0, m_cur = part_of(0);
     for (int it = 0; it < n_it; ++it) {
       const int b = it & 1;
+      const int m_next = part_of(it + 1);
+      if (it > 0) epilogue(it - 1, m_prev, Half0{});  // (the first half of the previous unit's rows)
+      load_y(it, m_cur, Half0{});
+      m_prev = m_cur;
+      m_cur = m_next;
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = c0v;
@@ -483,7 +517,9 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
       for (int r = 0; r < 16; ++r) o[acc_row(r, hh) * CIN] = acc[r];
       PN_BAR
     }
+    if (n_it > 0) epilogue(n_it - 1, m_prev, Half0{});
     PN_T_REPORT("dgrad")
+    put_sums(0);
   } else {
     // ============================================ weight-gradient waves =======================================================
     // Wave ww owns the output tiles PnWPlan<K>::t[ww][*] (compile-time lists chosen so that a wave's tiles share operand
@@ -505,8 +541,14 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
       constexpr int W = decltype(w_tag)::value;
       constexpr int ZC = Plan::zc[W];                                  // the wave's dZ column tile
       constexpr bool A0 = Plan::uses(W, 8), A1 = Plan::uses(W, 9);     // which A column tiles it reads
+      int m_prev = 0, m_cur = part_of(0);
       for (int it = 0; it < n_it; ++it) {
         const int b = it & 1;
+        const int m_next = part_of(it + 1);
+        if (it > 0) epilogue(it - 1, m_prev, Half1{});  // (the second half of the previous unit's rows)
+        load_y(it, m_cur, Half1{});
+        m_prev = m_cur;
+        m_cur = m_next;
         const unsigned char* bz = pz[b] + offz + 64 * ZC;
         const unsigned char* ba = pa[b] + offa;
         pn_bf16x8 fz[2][3], f0[2][3], f1[2][3];
@@ -535,6 +577,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
         }
         PN_BAR
       }
+      if (n_it > 0) epilogue(n_it - 1, m_prev, Half1{});
       float* out = dwpart + (long long)blockIdx.x * ELEMS;
       pn_static_for<TPW>([&](auto i_tag) {
         constexpr int i = decltype(i_tag)::value;
@@ -551,10 +594,12 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
     else if (ww == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 3>{});
     PN_T_REPORT("wgrad")
+    put_sums(1);
   }
   __syncthreads();  // the end-of-block scratch (aliasing panel 0, which nobody reads any more) is complete
   {
-    // scratch rows [q * RG + g][CIN]: q = 0 column sums of A, 1 s1, 2 s2 (FIRST: 3..5 S's three columns), RG stager row groups g
+    // scratch rows [(q * 2 + role) * RG + g][CIN]: q = 0 column sums of A (stagers: role 0 only), 1 s1, 2 s2, FIRST: 3..5 S's three
+    // columns (role 0 input-gradient, role 1 weight-gradient waves), RG row groups g — added in this fixed order
     const float* scr = reinterpret_cast<const float*>(&pz[0][0]);
     float* out = dwpart + (long long)blockIdx.x * ELEMS;
     const int t = threadIdx.x;
@@ -563,7 +608,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
       const int qq = t / CIN, c = t % CIN;
       float s = 0.0f;
 #pragma unroll
-      for (int g = 0; g < RG; ++g) s += scr[(qq * RG + g) * CIN + c];
+      for (int g = 0; g < (qq == 0 ? 1 : 2) * RG; ++g) s += scr[(qq * 2 * RG + g) * CIN + c];
       if (qq == 0) out[K * CIN + CIN * CIN + c] = s;
       else if (qq <= 2) partial[((long long)blockIdx.x * CIN + c) * 2 + (qq - 1)] = s;
       else out[K * CIN + CIN * CIN + CIN + 3 * c + (qq - 3)] = s;
@@ -571,7 +616,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
       const int e = t - NQ * CIN;
       float s = 0.0f;
 #pragma unroll
-      for (int g = 0; g < RG; ++g) s += scr[6 * RG * CIN + g * 12 + e];
+      for (int g = 0; g < RG; ++g) s += scr[12 * RG * CIN + g * 12 + e];
       out[K * CIN + CIN * CIN + CIN + 192 + e] = s;
     }
   }
