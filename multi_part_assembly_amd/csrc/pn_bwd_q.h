@@ -622,6 +622,364 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
   }
 }
 
+// ---- the never-stored last layer in the same form ---------------------------------------------------------------------------
+// conv5's output Y5 is never stored (pointnet.hip: top-2 records), so its backward always was  dA4 = A4 Q + c0 + S W5  with S the
+// sparse arg-max gradient (CSR by 32-row tile: erow, ech, eval, tptr) and  dW5  from the Gram matrix G = A4^T A4.  This kernel
+// does the input gradient AND the Gram matrix in one pass over Y4 (pn_dgrad_split_kernel + pn_gram_split_kernel read it once
+// each: 139 + 79 us) with the wave roles of pn_bwd_q_kernel: stagers convert Y4 rows into the A panel and stage the unit's
+// CSR entries (three-stage request pipeline: tile offsets, entries, LDS); four input-gradient waves (one 32-column tile each,
+// Q register-resident) leave A Q + c0 raw in LDS; four weight-gradient waves accumulate the ten upper tiles of G; both kinds
+// then finish the previous unit: sparse rows added from the staged entries, ReLU mask, dZ4 stores, BatchNorm-backward sums.
+struct PnGTile {
+  signed char a, b;  // column tiles of A: row tile and column tile of G (a <= b)
+};
+struct PnGPlan {
+  static constexpr int TPW = 3;
+  static constexpr PnGTile t[4][3] = {{{0, 0}, {0, 1}, {0, 2}}, {{1, 1}, {1, 2}, {1, 3}}, {{0, 3}, {3, 3}, {-1, -1}}, {{2, 2}, {2, 3}, {-1, -1}}};
+  static constexpr bool uses(int w, int tile) {
+    for (int i = 0; i < TPW; ++i)
+      if (t[w][i].a >= 0 && (t[w][i].a == tile || t[w][i].b == tile)) return true;
+    return false;
+  }
+};
+constexpr int kTopES = 32;  // CSR entries of a 32-row tile staged in LDS (more: read from memory by the epilogue, rare)
+
+template <int CIN, int NS, int ND, int NW>
+__global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void pn_bwd_top_q_kernel(
+    const float* __restrict__ y_prev, const float* __restrict__ bn_prev, const float* __restrict__ q,
+    const int* __restrict__ vlist, int N, float* __restrict__ dz_prev, float* __restrict__ partial,
+    float* __restrict__ dwpart, const int* __restrict__ erow, const int* __restrict__ ech,
+    const float* __restrict__ eval, const int* __restrict__ tptr, const float* __restrict__ w5, int F) {
+  constexpr int K = 0;  // (PN_T_REPORT prints them)
+  constexpr bool FIRST = false;
+  constexpr int RB = 32, SA = 6 * CIN + 16, CT = CIN / 32, KA = CIN / 16, KW = RB / 16;
+  constexpr int NTS = 64 * NS, QC = CIN / 4, RG = NTS / QC, NLY = RB * QC / NTS, EH = NLY;  // (the Gram waves run the whole epilogue: the
+  // input-gradient waves hold Q — 96 registers — and spilled with the epilogue's state on top)
+  constexpr int ELEMS = CIN * CIN + CIN;
+  static_assert(CIN == 128 && ND == CT && NW == 4 && NS == 4 && NLY % 2 == 0, "shapes");
+  __shared__ __attribute__((aligned(16))) unsigned char pa[2][RB * SA];  // A planes h | m | l
+  __shared__ __attribute__((aligned(16))) float outp[2][RB * CIN];       // A Q + c0 of a unit, row-major
+  __shared__ __attribute__((aligned(16))) float rowsum[3][RB * CIN];     // S W5 of a unit, row-major: [unit % 3] (built by the stagers)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
+  const int TB = (N + RB - 1) / RB, U = vlist[0] * TB, G = gridDim.x;
+  const int n_it = (int)blockIdx.x < U ? (U - (int)blockIdx.x + G - 1) / G : 0;
+  auto part_of = [&](int it) {
+    const int u = (int)blockIdx.x + it * G;
+    return u < U && it >= 0 ? vlist[4 + u / TB] : 0;
+  };
+  auto n0_of = [&](int it) { return (((int)blockIdx.x + it * G) % TB) * RB; };
+  // ---- the input gradient's epilogue (see pn_bwd_q_kernel), run by the Gram waves ---------------------------------------------
+  const int te = threadIdx.x & (NTS - 1);
+  const int cy4 = te % QC, ry0 = te / QC;
+  const float4 sc = reinterpret_cast<const float4*>(bn_prev)[cy4];
+  const float4 sh = reinterpret_cast<const float4*>(bn_prev + CIN)[cy4];
+  const float4 mn = reinterpret_cast<const float4*>(bn_prev + 2 * CIN)[cy4];
+  float4 ye[EH];
+  float4 s1v = make_float4(0.0f, 0.0f, 0.0f, 0.0f), t2v = s1v;
+  auto load_y = [&](int it, int m, auto half_tag) {
+    constexpr int HALF = decltype(half_tag)::value;
+    const int n0 = n0_of(it);
+    const long long row0 = (long long)m * N + n0;
+#pragma unroll
+    for (int i = 0; i < EH; ++i) {
+      const int rl = ry0 + (HALF * EH + i) * RG;
+      const int rr = n0 + rl < N ? rl : N - 1 - n0;
+      ye[i] = reinterpret_cast<const float4*>(y_prev)[(row0 + rr) * QC + cy4];
+    }
+  };
+  auto epilogue = [&](int it, int m, auto half_tag) {
+    constexpr int HALF = decltype(half_tag)::value;
+    const int n0 = n0_of(it), slot = it % 3;
+    const long long row0 = (long long)m * N + n0;
+    const float* ob = &outp[it & 1][0];
+#pragma unroll
+    for (int i = 0; i < EH; ++i) {  // one row at a time: its dense part, + S W5 (summed per row by the stagers an iteration ago)
+      const int rl = ry0 + (HALF * EH + i) * RG;
+      const bool ok = n0 + rl < N;
+      float4 o = *reinterpret_cast<const float4*>(ob + rl * CIN + 4 * cy4);
+      const float4 sp = *reinterpret_cast<const float4*>(&rowsum[slot][rl * CIN + 4 * cy4]);
+      o.x += sp.x;
+      o.y += sp.y;
+      o.z += sp.z;
+      o.w += sp.w;
+      const float4 yv = ye[i];
+      float4 d;
+      d.x = (ok && __builtin_fmaf(yv.x, sc.x, sh.x) > 0.0f) ? o.x : 0.0f;
+      d.y = (ok && __builtin_fmaf(yv.y, sc.y, sh.y) > 0.0f) ? o.y : 0.0f;
+      d.z = (ok && __builtin_fmaf(yv.z, sc.z, sh.z) > 0.0f) ? o.z : 0.0f;
+      d.w = (ok && __builtin_fmaf(yv.w, sc.w, sh.w) > 0.0f) ? o.w : 0.0f;
+      if (ok) reinterpret_cast<float4*>(dz_prev)[(row0 + rl) * QC + cy4] = d;
+      s1v.x += d.x;
+      s1v.y += d.y;
+      s1v.z += d.z;
+      s1v.w += d.w;
+      t2v.x = __builtin_fmaf(d.x, yv.x - mn.x, t2v.x);
+      t2v.y = __builtin_fmaf(d.y, yv.y - mn.y, t2v.y);
+      t2v.z = __builtin_fmaf(d.z, yv.z - mn.z, t2v.z);
+      t2v.w = __builtin_fmaf(d.w, yv.w - mn.w, t2v.w);
+    }
+  };
+  auto put_sums = [&]() {  // scratch rows [q * RG + row group]: q = 1 s1, 2 s2
+    float* scr = reinterpret_cast<float*>(&pa[0][0]);
+    const float4 is4 = reinterpret_cast<const float4*>(bn_prev + 3 * CIN)[cy4];
+    t2v.x *= is4.x;
+    t2v.y *= is4.y;
+    t2v.z *= is4.z;
+    t2v.w *= is4.w;
+    *reinterpret_cast<float4*>(scr + (1 * RG + ry0) * CIN + 4 * cy4) = s1v;
+    *reinterpret_cast<float4*>(scr + (2 * RG + ry0) * CIN + 4 * cy4) = t2v;
+  };
+  using Half0 = std::integral_constant<int, 0>;
+  using Half1 = std::integral_constant<int, 1>;
+
+  if (wave < NS) {
+    // ================================================ stager waves ==========================================================
+    const int t = threadIdx.x;
+    const int T1 = (N + 31) / 32 + 1;
+    float4 ry[NLY];
+    float4 colsum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const pn_f32x2 sc01 = {sc.x, sc.y}, sc23 = {sc.z, sc.w}, sh01 = {sh.x, sh.y}, sh23 = {sh.z, sh.w}, zero2 = {0.0f, 0.0f};
+    auto fetch = [&](int it, int m) {
+      const int n0 = n0_of(it);
+      const long long row0 = (long long)m * N + n0;
+#pragma unroll
+      for (int i = 0; i < NLY; ++i) {
+        const int rl = ry0 + i * RG;
+        const int rr = n0 + rl < N ? rl : N - 1 - n0;
+        ry[i] = reinterpret_cast<const float4*>(y_prev)[(row0 + rr) * QC + cy4];
+      }
+    };
+    auto stash = [&](int it, int b) {
+      const int n0 = n0_of(it);
+#pragma unroll
+      for (int i = 0; i < NLY; ++i) {
+        const int rl = ry0 + i * RG;
+        const bool ok = n0 + rl < N;
+        pn_f32x2 v01 = __builtin_elementwise_max(__builtin_elementwise_fma(pn_f32x2{ry[i].x, ry[i].y}, sc01, sh01), zero2);
+        pn_f32x2 v23 = __builtin_elementwise_max(__builtin_elementwise_fma(pn_f32x2{ry[i].z, ry[i].w}, sc23, sh23), zero2);
+        if (!ok) v01 = v23 = zero2;  // rows past the part's end enter every product as zeros
+        colsum.x += v01[0];
+        colsum.y += v01[1];
+        colsum.z += v23[0];
+        colsum.w += v23[1];
+        pn_bf16x4 ph, pm, pl;
+        pn_split4v(v01, v23, ph, pm, pl);
+        unsigned char* p = pa[b] + rl * SA + 8 * cy4;
+        *reinterpret_cast<pn_bf16x4*>(p) = ph;
+        *reinterpret_cast<pn_bf16x4*>(p + 2 * CIN) = pm;
+        *reinterpret_cast<pn_bf16x4*>(p + 4 * CIN) = pl;
+      }
+    };
+    // S W5 of a unit, per row: request pipeline inside every stager wave (no cross-wave hand-over): tile offsets of unit u at
+    // iteration u - 3, its entries at u - 2 (lane l holds entry l & 31: row, channel, alpha * grad), the row sums at u - 1 —
+    // entry e is broadcast with v_readlane, a matching row costs one weight-row load from the L2, here, in the waves that wait
+    // for memory anyway.  Entry order = channel order, fixed.  The epilogue reads the sums at u + 1: three slots.
+    int tp0 = 0, tp1 = 0, e_row = 0, e_ch = 0, e_cnt = 0, e_pb = 0;
+    float e_val = 0.0f;
+    auto tp_fetch = [&](int it, int m) {
+      const int st = n0_of(it) >> 5;
+      tp0 = tptr[(long long)m * T1 + st];
+      tp1 = tptr[(long long)m * T1 + st + 1];
+    };
+    auto ent_fetch = [&](int it, int m) {  // uses the offsets of this unit (tp0 / tp1 hold them now)
+      e_cnt = tp1 - tp0;
+      e_pb = tp0;
+      const int l = lane & 31, e = l < e_cnt ? l : 0;
+      const long long g = (long long)m * F + tp0 + e;
+      const bool has = e_cnt > 0;
+      e_row = has ? erow[g] - n0_of(it) : -1;
+      e_ch = has ? ech[g] : 0;
+      e_val = has ? eval[g] : 0.0f;
+    };
+    auto rowsum_build = [&](int it, int m) {  // this thread's NLY rows x 4 columns (e_* hold this unit's entries now)
+      const int slot = it % 3, n0 = n0_of(it);
+      const int cnt = __builtin_amdgcn_readfirstlane(e_cnt), pb = __builtin_amdgcn_readfirstlane(e_pb);
+      float4 acc[NLY];
+#pragma unroll
+      for (int i = 0; i < NLY; ++i) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      for (int e = 0; e < cnt; ++e) {
+        int er, ec;
+        float ev;
+        if (e < kTopES) {
+          er = __builtin_amdgcn_readlane(e_row, e);
+          ec = __builtin_amdgcn_readlane(e_ch, e);
+          ev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e_val), e));
+        } else {  // unusually crowded tile
+          const long long g = (long long)m * F + pb + e;
+          er = erow[g] - n0;
+          ec = ech[g];
+          ev = eval[g];
+        }
+#pragma unroll
+        for (int i = 0; i < NLY; ++i)
+          if (er == ry0 + i * RG) {
+            const float4 wv = reinterpret_cast<const float4*>(w5 + (long long)ec * CIN)[cy4];
+            acc[i].x = __builtin_fmaf(ev, wv.x, acc[i].x);
+            acc[i].y = __builtin_fmaf(ev, wv.y, acc[i].y);
+            acc[i].z = __builtin_fmaf(ev, wv.z, acc[i].z);
+            acc[i].w = __builtin_fmaf(ev, wv.w, acc[i].w);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < NLY; ++i) *reinterpret_cast<float4*>(&rowsum[slot][(ry0 + i * RG) * CIN + 4 * cy4]) = acc[i];
+    };
+    int m1 = part_of(1), m2 = part_of(2), m3 = part_of(3);
+    if (n_it > 0) {
+      const int m0 = part_of(0);
+      tp_fetch(0, m0);
+      fetch(0, m0);
+      ent_fetch(0, m0);
+      if (n_it > 1) tp_fetch(1, m1);
+      rowsum_build(0, m0);
+      if (n_it > 1) ent_fetch(1, m1);
+      if (n_it > 2) tp_fetch(2, m2);
+      stash(0, 0);
+      if (n_it > 1) fetch(1, m1);
+    }
+    __syncthreads();  // panel 0 and unit 0's sparse rows are complete
+    PN_T_DECL
+    for (int it = 0; it < n_it; ++it) {
+      const int m4 = part_of(it + 4);
+      if (it + 1 < n_it) {
+        rowsum_build(it + 1, m1);  // (its entries were requested an iteration ago, its offsets two)
+        stash(it + 1, (it + 1) & 1);
+      }
+      if (it + 2 < n_it) {
+        ent_fetch(it + 2, m2);
+        fetch(it + 2, m2);
+      }
+      if (it + 3 < n_it) tp_fetch(it + 3, m3);
+      m1 = m2;
+      m2 = m3;
+      m3 = m4;
+      PN_BAR
+    }
+    PN_T_REPORT("stager")
+    float* scr = reinterpret_cast<float*>(&pa[0][0]);
+    *reinterpret_cast<float4*>(scr + (0 * RG + ry0) * CIN + 4 * cy4) = colsum;
+  } else if (wave < NS + ND) {
+    // ============================================ input-gradient waves ========================================================
+    const int ct = wave - NS, d0 = 32 * ct;
+    pn_bf16x8 qh[KA], qm[KA], ql[KA];  // Q[16 ks + 8 hh + u][d0 + j] as h / m / l
+#pragma unroll
+    for (int ks = 0; ks < KA; ++ks)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float f = q[(long long)(16 * ks + 8 * hh + u) * CIN + d0 + j];
+        qh[ks][u] = (__bf16)f;
+        const float r1 = f - (float)qh[ks][u];
+        qm[ks][u] = (__bf16)r1;
+        ql[ks][u] = (__bf16)(r1 - (float)qm[ks][u]);
+      }
+    const float c0v = q[(long long)CIN * CIN + d0 + j];
+    __syncthreads();
+    PN_T_DECL
+    for (int it = 0; it < n_it; ++it) {
+      const int b = it & 1;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = c0v;
+      const unsigned char* qrow = pa[b] + j * SA + 16 * hh;
+      pn_bf16x8 fa[2][3];
+#pragma unroll
+      for (int i = 0; i <= KA; ++i) {
+        if (i < KA) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) fa[i & 1][pl] = *reinterpret_cast<const pn_bf16x8*>(qrow + 2 * CIN * pl + 32 * i);
+        }
+        if (i > 0) {
+          const int sb = (i - 1) & 1;
+          PN_MFMA6(acc, fa[sb][0], fa[sb][1], fa[sb][2], qh[i - 1], qm[i - 1], ql[i - 1])
+        }
+      }
+      float* o = &outp[b][0] + d0 + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[acc_row(r, hh) * CIN] = acc[r];
+      PN_BAR
+    }
+    PN_T_REPORT("dgrad")
+  } else {
+    // ============================================ Gram waves ==================================================================
+    const int ww = wave - NS - ND;
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int trow = 8 * (g16 >> 1) + (i16 >> 2), tcol = 16 * (g16 & 1) + 4 * (i16 & 3);
+    const int offa = trow * SA + 2 * tcol;
+    constexpr int TPW = PnGPlan::TPW;
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = f32x16{0};
+    __syncthreads();
+    PN_T_DECL
+    auto run = [&](auto w_tag) {
+      constexpr int W = decltype(w_tag)::value;
+      int m_prev = 0, m_cur = part_of(0);
+      for (int it = 0; it < n_it; ++it) {
+        const int b = it & 1;
+        const int m_next = part_of(it + 1);
+        if (it > 0) epilogue(it - 1, m_prev, Half0{});
+        load_y(it, m_cur, Half0{});
+        m_prev = m_cur;
+        m_cur = m_next;
+        const unsigned char* ba = pa[b] + offa;
+        pn_bf16x8 f[4][3];  // fragments of A's four column tiles (only the ones this wave's tiles use are loaded; one
+        // k-step at a time: these waves have the slack, and the registers go to the epilogue's state)
+#pragma unroll
+        for (int ks = 0; ks < KW; ++ks) {
+          pn_static_for<4>([&](auto c_tag) {
+            constexpr int c = decltype(c_tag)::value;
+            if constexpr (PnGPlan::uses(W, c)) {
+#pragma unroll
+              for (int pl = 0; pl < 3; ++pl) f[c][pl] = pn_tr_frag(ba + 16 * ks * SA + 2 * CIN * pl + 64 * c, SA);
+            }
+          });
+          pn_static_for<TPW>([&](auto i_tag) {
+            constexpr int i = decltype(i_tag)::value;
+            constexpr PnGTile tl = PnGPlan::t[W][i];
+            if constexpr (tl.a >= 0) {
+              PN_MFMA6(acc[i], f[tl.a][0], f[tl.a][1], f[tl.a][2], f[tl.b][0], f[tl.b][1], f[tl.b][2])
+            }
+          });
+        }
+        PN_BAR
+      }
+      if (n_it > 0) epilogue(n_it - 1, m_prev, Half0{});
+      float* out = dwpart + (long long)blockIdx.x * ELEMS;  // the full matrix: upper tiles and their mirror images
+      pn_static_for<TPW>([&](auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;
+        constexpr PnGTile tl = PnGPlan::t[W][i];
+        if constexpr (tl.a >= 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ra = 32 * tl.a + acc_row(r, hh), cb = 32 * tl.b + j;
+            out[ra * CIN + cb] = acc[i][r];
+            if (tl.a != tl.b) out[cb * CIN + ra] = acc[i][r];
+          }
+        }
+      });
+    };
+    if (ww == 0) run(std::integral_constant<int, 0>{});
+    else if (ww == 1) run(std::integral_constant<int, 1>{});
+    else if (ww == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 3>{});
+    PN_T_REPORT("gram")
+    put_sums();
+  }
+  __syncthreads();  // the end-of-block scratch (aliasing the panels, which nobody reads any more) is complete
+  {
+    const float* scr = reinterpret_cast<const float*>(&pa[0][0]);
+    float* out = dwpart + (long long)blockIdx.x * ELEMS;
+    const int t = threadIdx.x;
+    if (t < 3 * CIN) {
+      const int qq = t / CIN, c = t % CIN;
+      float s = 0.0f;
+#pragma unroll
+      for (int g = 0; g < RG; ++g) s += scr[(qq * RG + g) * CIN + c];
+      if (qq == 0) out[CIN * CIN + c] = s;
+      else partial[((long long)blockIdx.x * CIN + c) * 2 + (qq - 1)] = s;
+    }
+  }
+}
+
 // The end of the pass: weight gradients of conv4..conv2 (and conv1) from the reduced tables of their layers,
 //     dW_l[c][d] = alpha_c T[c][d] + gammap_c sum_k W_l[c][k] G[k][d] + betap_c asum[d]
 //     dW_1[c][k] = alpha_c S[c][k]  + gammap_c sum_j W_1[c][j] (P^T P)[j][k] + betap_c psum[k].

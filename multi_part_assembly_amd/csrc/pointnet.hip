@@ -2216,6 +2216,21 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   hipLaunchKernelGGL(pn_top_csr_kernel, dim3((unsigned)(M + C4 + 1)), dim3((unsigned)F), sizeof(int) * F, s, iw.argmax,
                      grad_feat, w.coef[5], valids, (int)N, (int)F, iw.erow, iw.ech, w.eval, iw.tptr, (int)M, conv_w[4], C4,
                      w.q);
+#ifndef MPA_PN_TOPQ  // 1: conv5's input gradient + Gram matrix in one wave-specialised pass (pn_bwd_top_q_kernel); 0: two kernels
+#define MPA_PN_TOPQ 1
+#endif
+  auto reduce_dw = [&](int blocks, int elems, float* dst) {
+    hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * kSlices), 0, s, w.dwpart,
+                       (const float*)nullptr, blocks, elems, dst);
+  };
+#if MPA_PN_TOPQ
+  hipLaunchKernelGGL((pn_bwd_top_q_kernel<128, 4, 4, 4>), dim3(256), dim3(768), 0, s, w.Y[4], w.bn[4], w.q, iw.vlist, (int)N,
+                     w.dZ[4], w.partial, w.dwpart, iw.erow, iw.ech, w.eval, iw.tptr, conv_w[4], (int)F);
+  hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(C4 / 64), (unsigned)((256 + kEB - 1) / kEB)), dim3(64 * kSlices), 0, s,
+                     w.partial, (const float*)nullptr, 256, 1, C4, w.count, bn_w[3], w.bn[4], w.coef[4], grad_bn_w[3],
+                     grad_bn_b[3], w.coop);
+  reduce_dw(256, C4 * C4 + C4, w.gram);
+#else
   {
 #if MPA_PN_SPLIT
 #define MPA_DGRAD_TOP pn_dgrad_split_kernel<128>
@@ -2232,10 +2247,6 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
   hipLaunchKernelGGL(pn_bwd_coef_kernel, dim3((unsigned)(C4 / 64), (unsigned)((M * d.splits_dtop + kEB - 1) / kEB)),
                      dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, d.splits_dtop, C4, w.count, bn_w[3], w.bn[4],
                      w.coef[4], grad_bn_w[3], grad_bn_b[3], w.coop);
-  auto reduce_dw = [&](int blocks, int elems, float* dst) {
-    hipLaunchKernelGGL(pn_wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(64 * kSlices), 0, s, w.dwpart,
-                       (const float*)nullptr, blocks, elems, dst);
-  };
 #ifndef MPA_PN_GRAM_SPLIT
 #define MPA_PN_GRAM_SPLIT MPA_PN_SPLIT
 #endif
@@ -2246,6 +2257,7 @@ extern "C" int mpa_pointnet_backward(const float* grad_feat, const float* points
                      (const float*)nullptr, (const float*)nullptr, w.Y[4], w.bn[4], iw.vlist, (int)N, w.dwpart, 0);
 #endif
   reduce_dw(kWG, C4 * C4 + C4, w.gram);
+#endif
   hipLaunchKernelGGL(pn_top_wgrad_kernel, dim3((unsigned)F), dim3(1024), 0, s, grad_feat, iw.argmax, valids, w.Y[4],
                      w.bn[4], conv_w[4], w.coef[5], w.gram, (int)M, (int)N, (int)F, grad_conv_w[4]);
 #if MPA_PN_QFORM
