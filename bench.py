@@ -296,56 +296,90 @@ def _find(kernels, prefix):
 
 
 def kernel_table(kernels, nv, cfg, B, P):
-    """Per-kernel fractions of the bound that binds each of the large kernels (algorithmic work / measured time);
-    nv = valid parts per step (mean over the rotated batches)."""
+    """Per-entry-point fractions of the bound that binds each of the large kernels (algorithmic work / measured time); nv =
+    valid parts per step (mean over the rotated batches).  Every row names its peak (`peak`) and what `frac` is a fraction
+    of; matrix-core rows count the instructions the kernels actually issue (the fp32-grade split-bf16 products cost SIX bf16
+    matrix instructions per fp32 product, so their `frac` is matrix-pipe occupancy at the bf16 rate, and `fp32_equiv_tflops`
+    is the useful rate)."""
     N = POINTS
     F = cfg.model.pc_feat_dim
     rows = {}
 
-    def add(prefix, name, **kw):
+    def per_step(prefix):
         hit = _find(kernels, prefix)
         if not hit:
+            return None
+        return sum(v["total_ms"] for _, v in hit) / max(1, hit[0][1]["launches"])
+
+    def add_mfma(prefix, name, flops_f32=0.0, flops_split=0.0, useful=None, note=None):
+        """flops_f32: FLOP issued as v_mfma_f32_32x32x2_f32; flops_split: fp32-grade FLOP issued as 6 bf16 products."""
+        ms = per_step(prefix)
+        if ms is None:
             return
-        ms = sum(v["total_ms"] for _, v in hit) / max(1, hit[0][1]["launches"])  # per step
-        rec = {"ms_per_step": ms}
         secs = ms * 1e-3
-        if "flops" in kw:
-            rec.update(bound="mfma_f32", flops=kw["flops"], achieved_tflops=kw["flops"] / secs / 1e12,
-                       frac=kw["flops"] / secs / MFMA_F32_PEAK)
-        if "lane_ops" in kw:
-            rec.update(bound="valu", lane_ops=kw["lane_ops"], frac=kw["lane_ops"] / secs / VALU_PEAK_LANE_OPS)
-        if "bytes" in kw:
-            rec.update(hbm_bytes=kw["bytes"], hbm_frac=kw["bytes"] / secs / 1e9 / HBM_PEAK_GBS)
-        if kw.get("bf16"):  # bf16 matrix cores (2.5 PFLOP/s dense): the variant is bound by the bf16 activations it moves
-            rec.update(bound="hbm", frac=rec["hbm_frac"], mfma_bf16_frac=kw["flops"] / secs / 2.5e15)
-        rows[name] = rec
+        pipe_s = flops_f32 / MFMA_F32_PEAK + 6.0 * flops_split / MFMA_BF16_PEAK  # matrix-pipe seconds at the two peaks
+        useful = useful if useful is not None else flops_f32 + flops_split
+        rows[name] = {"ms_per_step": ms, "bound": "matrix-pipe", "frac": pipe_s / secs,
+                      "peak": "time the issued matrix instructions need at their peak rates (v_mfma_f32_32x32x2_f32 157.3 "
+                              "TFLOP/s; v_mfma_f32_32x32x16_bf16 2.5 PFLOP/s, six products per fp32-grade product) / "
+                              "measured time = matrix-pipe occupancy",
+                      "flops_exact_f32_mfma": flops_f32, "flops_fp32_grade_split_bf16": flops_split,
+                      "bf16_products_per_fp32_product": 6, "fp32_equiv_tflops": useful / secs / 1e12,
+                      **({"note": note} if note else {})}
 
     if cfg.model.encoder == "pointnet":
-        fwd = 2.0 * nv * N * (3 * 64 + 64 * 64 + 64 * 64 + 64 * 128 + 128 * F)
-        add("pointnet_forward[", "pointnet_forward", flops=fwd)
-        add("pointnet_backward[", "pointnet_backward", flops=2.0 * fwd)
+        r = nv * N
+        # forward: conv1 on the VALU (negligible), conv2..conv4 exact-fp32 MFMA, conv5 split-bf16
+        add_mfma("pointnet_forward[", "pointnet_forward", flops_f32=2.0 * r * (64 * 64 + 64 * 64 + 64 * 128),
+                 flops_split=2.0 * r * 128 * F)
+        # backward in Q form (csrc/pn_bwd_q.h), every product split-bf16: per hidden layer dZ.(alpha W) [K x CIN], A.Q
+        # [CIN x CIN], T = dZ^T A [K x CIN], the upper triangle of G = A^T A; conv5: A4.Q [128 x 128] + 10 of G's 16 tiles
+        hidden = sum(2.0 * r * (k * c + c * c + k * c + c * c * 3 / 4) for k, c in ((128, 64), (64, 64), (64, 64)))
+        top = 2.0 * r * (128 * 128 + 128 * 128 * 10 / 16)
+        plain = 2.0 * 2.0 * r * (64 * 64 + 64 * 64 + 64 * 128 + 128 * F)  # textbook input + weight gradients
+        add_mfma("pointnet_backward[", "pointnet_backward", flops_split=hidden + top, useful=plain,
+                 note="Q form: issues A.Q and Gram products instead of re-reading the layers' outputs; `fp32_equiv_tflops` "
+                      "counts the textbook 2 x forward FLOP")
         # the bf16 variant is bound by HBM: bytes of the bf16 activations it must move (written once forward; read by
         # the next layer, by both gradient kernels of its own layer and by the gradient kernels of the next)
-        rows_b = 2.0 * nv * N
-        add("pointnet_forward_bf16", "pointnet_forward_bf16", flops=fwd, bf16=True,
-            bytes=rows_b * (2 * (64 * 3) + 2 * 128 + 2 * F) + 12.0 * nv * N)
-        add("pointnet_backward_bf16", "pointnet_backward_bf16", flops=2.0 * fwd, bf16=True,
-            bytes=rows_b * (2 * F + 2112))  # per layer: both gradient kernels read (G, y) of the layer and y of the
-        # one below, the input-gradient kernel writes G of the one below (DESIGN.md §4)
+        fwd = 2.0 * r * (3 * 64 + 64 * 64 + 64 * 64 + 64 * 128 + 128 * F)
+        for prefix, name, flops, byts in (
+                ("pointnet_forward_bf16", "pointnet_forward_bf16", fwd, 2.0 * r * (2 * (64 * 3) + 2 * 128 + 2 * F) + 12.0 * r),
+                ("pointnet_backward_bf16", "pointnet_backward_bf16", 2.0 * fwd, 2.0 * r * (2 * F + 2112))):
+            ms = per_step(prefix)
+            if ms is not None:
+                secs = ms * 1e-3
+                rows[name] = {"ms_per_step": ms, "bound": "hbm", "frac": byts / secs / 1e9 / HBM_PEAK_GBS,
+                              "peak": "8 TB/s HBM (bf16 activation bytes that must move / time)", "hbm_bytes": byts,
+                              "mfma_bf16_frac": flops / secs / MFMA_BF16_PEAK}
     else:
         gemm = 2.0 * nv * N * (3 * 128 + 64 * 128 + 64 * 256 + 128 * 512 + 512 * F)
-        add("dgcnn_forward", "dgcnn_forward", flops=gemm + 2.0 * nv * N * N * (3 + 64 + 64 + 128))
-        add("dgcnn_backward", "dgcnn_backward", flops=2.0 * gemm)
+        add_mfma("dgcnn_forward", "dgcnn_forward", flops_split=gemm,
+                 note="row GEMMs only (split-bf16); the kNN stages have their own `roofline` entry")
+        add_mfma("dgcnn_backward", "dgcnn_backward", flops_split=2.0 * gemm)
     if "transformer_layers" in cfg.model:
         D, FF, L, H = F, cfg.model.transformer_feat_dim, cfg.model.transformer_layers, cfg.model.transformer_heads
         M = B * P
         tf = L * (2.0 * M * D * 3 * D + 2.0 * M * D * D + 4.0 * M * D * FF + 4.0 * B * H * P * P * (D // H))
-        add("transformer_forward", "transformer_forward", flops=tf)
-        add("transformer_backward", "transformer_backward", flops=2.0 * tf)
-    # per-part Chamfer: 2 directions x N^2 pairs per valid part.  lane_ops = what the exhaustive scan it replaced spends
-    # (8.6 VALU lane-slots per pair, DESIGN.md §4): the gated search (gate_nn.hip) bounds a pair with 1 / 1024 of a bf16
-    # matrix instruction and half a v_min3, so its "fraction" of that budget is a speed-up figure, not a utilisation
-    add("assembly_part_chamfer", "assembly_part_chamfer", lane_ops=8.6 * 2.0 * nv * N * N, bytes=24.0 * 2 * nv * N)
+        add_mfma("transformer_forward", "transformer_forward", flops_f32=tf,
+                 note="launch / dependency latency bound: 21 launches of 5-13 us")
+        add_mfma("transformer_backward", "transformer_backward", flops_f32=2.0 * tf)
+    # per-part Chamfer (csrc/gate_nn.hip): every pair of a part's two clouds is BOUNDED by 1 / 1024 of a bf16 matrix
+    # instruction (32 x 32 x 16: 32 FLOP per pair), then ~1.5 % of the pairs are evaluated with the pinned arithmetic
+    ms = per_step("assembly_part_chamfer")
+    if ms is not None:
+        secs = ms * 1e-3
+        pairs = 2.0 * nv * N * N
+        alg = 24.0 * 2 * nv * N
+        rows["assembly_part_chamfer"] = {
+            "ms_per_step": ms, "bound": "issue (v_min3 trees of the bound + the answer phase)",
+            "frac": 32.0 * pairs / secs / MFMA_BF16_PEAK,
+            "peak": "2.5 PFLOP/s bf16 matrix rate (the bound's Gram products: 32 FLOP per pair)",
+            "pairs_bounded_per_step": pairs, "hbm_bytes": alg, "hbm_frac": alg / secs / 1e9 / HBM_PEAK_GBS,
+            "exhaustive_equivalent": {"lane_ops": 8.6 * pairs, "seconds_at_valu_peak": 8.6 * pairs / VALU_PEAK_LANE_OPS,
+                                      "speedup_over_valu_peak_scan": 8.6 * pairs / VALU_PEAK_LANE_OPS / secs,
+                                      "note": "what the exhaustive scan it replaced would need at the full VALU issue rate: "
+                                              "a speed-up figure, NOT a utilisation"}}
     return rows
 
 

@@ -44,6 +44,13 @@ def test_bench_line_has_the_contract_keys(cuda_device):
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # every row of the per-kernel table names the peak its fraction refers to, and no fraction exceeds 1 (round-5 verdict: a
+    # fraction above 1 means the denominator is not what the kernel does)
+    kt = d["kernel_table"]
+    assert {"pointnet_forward", "pointnet_backward", "transformer_forward", "assembly_part_chamfer"} <= set(kt)
+    for name, row in kt.items():
+        assert "peak" in row and 0.0 < row["frac"] <= 1.0, (name, row)
+    assert kt["assembly_part_chamfer"]["exhaustive_equivalent"]["speedup_over_valu_peak_scan"] > 0
     # the drop-in operator on its own: SURVEY.md 8(d)'s two standalone shapes through the C ABI
     cs = d["chamfer_standalone"]["cases"]
     assert len(cs) == 3 and all(x["GBps"] > 0 and x["calls"] == 20 for x in cs)
