@@ -1955,6 +1955,10 @@ __global__ __launch_bounds__(64 * kSlices) void pn_wgrad_reduce_group_kernel(con
 #define MPA_PN_QFORM 1
 #endif
 #include "pn_bwd_q.h"
+#include "pn_fwd_ws.h"
+#ifndef MPA_PN_FWD_WS  // 1: conv2..conv4 forward wave-specialised on the bf16 matrix cores (pn_fwd_ws.h); 0: pn_fwd_mfma_kernel
+#define MPA_PN_FWD_WS 1
+#endif
 constexpr int kQB = 512;  // persistent blocks of pn_bwd_q_kernel: at most two per CU (MPA_PN_QB2)
 #ifndef MPA_PN_QB2  // 1: the 64 -> 64 layers as two 6-wave blocks per CU on 32-row units; 0: one 12-wave block on 64-row units
 #define MPA_PN_QB2 0
@@ -2133,7 +2137,22 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
                      iw.vlist, conv_w[0], w.Wt1);
   for (int l = 1; l <= 5; ++l) {
     int splits;
-    if (l == 1) {
+    int prow_m = (int)M;              // rows of `partial`: (part, split) pairs with the validity mask, or persistent blocks
+    const float* prow_valid = valids;
+    if (MPA_PN_FWD_WS && l >= 2 && l <= 4) {
+      splits = 1;
+      prow_m = 256;
+      prow_valid = nullptr;
+      if (l == 2)
+        hipLaunchKernelGGL((pn_fwd_ws_kernel<64, 64, 64, true>), dim3(256), dim3(768), 0, s, points, w.bn[1], conv_w[1], iw.vlist,
+                           (int)N, w.Y[2], w.partial, (const float*)w.Wt1);
+      else if (l == 3)
+        hipLaunchKernelGGL((pn_fwd_ws_kernel<64, 64, 64, false>), dim3(256), dim3(768), 0, s, w.Y[2], w.bn[2], conv_w[2],
+                           iw.vlist, (int)N, w.Y[3], w.partial, (const float*)nullptr);
+      else
+        hipLaunchKernelGGL((pn_fwd_ws_kernel<64, 128, 32, false>), dim3(256), dim3(768), 0, s, w.Y[3], w.bn[3], conv_w[3],
+                           iw.vlist, (int)N, w.Y[4], w.partial, (const float*)nullptr);
+    } else if (l == 1) {
       splits = d.tiles1;
       hipLaunchKernelGGL(pn_fwd_first_kernel<false>, dim3((unsigned)d.tiles1, (unsigned)M), dim3(kT), 0, s, points,
                          w.Wt1, valids, (int)N, (float*)nullptr, w.partial);
@@ -2160,7 +2179,15 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
                        0, s, w.Y[4], w.bn[4], conv_w[4], d.C[5], iw.vlist, (int)N, splits, w.partial, w.topv,        \
                        iw.topn, bn_w[4]);                                                                            \
   }
-      if (l == 5 && MPA_PN_SPLIT) {
+      if (l == 5 && MPA_PN_FWD_WS) {
+#define MPA_FWD_TOP_WS(NWV)                                                                                               \
+  hipLaunchKernelGGL((pn_fwd_ws_top_kernel<128, NWV>), dim3(256), dim3(64 * (4 + NWV)), 0, s, w.Y[4], w.bn[4], conv_w[4],  \
+                     d.C[5], iw.vlist, (int)N, splits, w.partial, w.topv, iw.topn, bn_w[4])
+        if (F == 256) MPA_FWD_TOP_WS(8);
+        else if (F == 128) MPA_FWD_TOP_WS(4);
+        else MPA_FWD_TOP_WS(2);
+#undef MPA_FWD_TOP_WS
+      } else if (l == 5 && MPA_PN_SPLIT) {
         if (F == 256) MPA_FWD_SPLIT(8)
         else if (F == 128) MPA_FWD_SPLIT(4)
         else MPA_FWD_SPLIT(2)
@@ -2181,8 +2208,8 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
     }
     const dim3 cg((unsigned)(d.C[l] / 64));
     if (training)
-      hipLaunchKernelGGL(pn_bn_finalize_kernel, dim3(cg.x, (unsigned)((M * splits + kEB - 1) / kEB)),
-                         dim3(64 * kSlices), 0, s, w.partial, valids, (int)M, splits, d.C[l], w.count, bn_w[l - 1],
+      hipLaunchKernelGGL(pn_bn_finalize_kernel, dim3(cg.x, (unsigned)(((long long)prow_m * splits + kEB - 1) / kEB)),
+                         dim3(64 * kSlices), 0, s, w.partial, prow_valid, prow_m, splits, d.C[l], w.count, bn_w[l - 1],
                          bn_b[l - 1], running_mean[l - 1], running_var[l - 1], momentum, eps, w.bn[l], w.coop);
     else
       hipLaunchKernelGGL(pn_bn_from_running_kernel, cg, dim3(64), 0, s, d.C[l], bn_w[l - 1], bn_b[l - 1],
