@@ -329,9 +329,8 @@ def kernel_table(kernels, nv, cfg, B, P):
 
     if cfg.model.encoder == "pointnet":
         r = nv * N
-        # forward: conv1 on the VALU (negligible), conv2..conv4 exact-fp32 MFMA, conv5 split-bf16
-        add_mfma("pointnet_forward[", "pointnet_forward", flops_f32=2.0 * r * (64 * 64 + 64 * 64 + 64 * 128),
-                 flops_split=2.0 * r * 128 * F)
+        # forward: conv1 on the VALU (negligible), conv2..conv5 split-bf16 (csrc/pn_fwd_ws.h)
+        add_mfma("pointnet_forward[", "pointnet_forward", flops_split=2.0 * r * (64 * 64 + 64 * 64 + 64 * 128 + 128 * F))
         # backward in Q form (csrc/pn_bwd_q.h), every product split-bf16: per hidden layer dZ.(alpha W) [K x CIN], A.Q
         # [CIN x CIN], T = dZ^T A [K x CIN], the upper triangle of G = A^T A; conv5: A4.Q [128 x 128] + 10 of G's 16 tiles
         hidden = sum(2.0 * r * (k * c + c * c + k * c + c * c * 3 / 4) for k, c in ((128, 64), (64, 64), (64, 64)))
