@@ -15,15 +15,15 @@
 //     column sums in their accumulator layout (pn_fwd_split_kernel's epilogue).
 // Per block: one (sum, sum) row of `partial` per channel (fixed order), reduced by pn_bn_finalize_kernel.
 
-template <int CIN, int COUT, int RB, bool FIRST>
-__global__ __launch_bounds__(768, 3) void pn_fwd_ws_kernel(const float* __restrict__ in, const float* __restrict__ bn_prev,
+template <int CIN, int COUT, int RB, bool FIRST, int BPC = 1>
+__global__ __launch_bounds__(64 * (8 + (RB / 32) * (COUT / 32)), ((8 + (RB / 32) * (COUT / 32)) * BPC + 3) / 4) void pn_fwd_ws_kernel(const float* __restrict__ in, const float* __restrict__ bn_prev,
                                                           const float* __restrict__ w, const int* __restrict__ vlist, int N,
                                                           float* __restrict__ y_out, float* __restrict__ partial,
                                                           const float* __restrict__ wt1) {
-  constexpr int NS = 4, ND = 4, SA = 6 * CIN + 16, RT = RB / 32, CT = COUT / 32, KA = CIN / 16;
+  constexpr int NS = 4, SA = 6 * CIN + 16, RT = RB / 32, CT = COUT / 32, ND = RT * CT, KA = CIN / 16;  // (BPC blocks per CU)
   constexpr int NTS = 64 * NS, QC = CIN / 4, RG = NTS / QC, NLY = RB * QC / NTS;  // stagers: float4 per thread and unit
   constexpr int QO = COUT / 4, RGO = NTS / QO, NLO = RB * QO / NTS;               // store waves: float4 per thread and unit
-  static_assert(RT * CT == ND && RB * QC % NTS == 0 && RB * QO % NTS == 0 && NTS % QC == 0 && NTS % QO == 0, "shapes");
+  static_assert(RB * QC % NTS == 0 && RB * QO % NTS == 0 && NTS % QC == 0 && NTS % QO == 0, "shapes");
   static_assert(!FIRST || CIN == 64, "the recomputed input is the 64-channel first layer");
   __shared__ __attribute__((aligned(16))) unsigned char pa[2][RB * SA];  // A planes h | m | l
   __shared__ __attribute__((aligned(16))) float outp[2][RB * COUT];      // a unit's output tiles, row-major

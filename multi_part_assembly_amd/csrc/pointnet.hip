@@ -1956,6 +1956,9 @@ __global__ __launch_bounds__(64 * kSlices) void pn_wgrad_reduce_group_kernel(con
 #endif
 #include "pn_bwd_q.h"
 #include "pn_fwd_ws.h"
+#ifndef MPA_PN_FWD4_BLOCKS
+#define MPA_PN_FWD4_BLOCKS 512
+#endif
 #ifndef MPA_PN_FWD_WS  // 1: conv2..conv4 forward wave-specialised on the bf16 matrix cores (pn_fwd_ws.h); 0: pn_fwd_mfma_kernel
 #define MPA_PN_FWD_WS 1
 #endif
@@ -2143,15 +2146,17 @@ extern "C" int mpa_pointnet_forward(const float* points, const float* valids, co
       splits = 1;
       prow_m = 256;
       prow_valid = nullptr;
-      if (l == 2)
+      if (l == 2)  // (64-row units, one 12-wave block per CU; 32-row units in two 10-wave blocks per CU measured 48 vs 38 us)
         hipLaunchKernelGGL((pn_fwd_ws_kernel<64, 64, 64, true>), dim3(256), dim3(768), 0, s, points, w.bn[1], conv_w[1], iw.vlist,
                            (int)N, w.Y[2], w.partial, (const float*)w.Wt1);
       else if (l == 3)
         hipLaunchKernelGGL((pn_fwd_ws_kernel<64, 64, 64, false>), dim3(256), dim3(768), 0, s, w.Y[2], w.bn[2], conv_w[2],
                            iw.vlist, (int)N, w.Y[3], w.partial, (const float*)nullptr);
-      else
-        hipLaunchKernelGGL((pn_fwd_ws_kernel<64, 128, 32, false>), dim3(256), dim3(768), 0, s, w.Y[3], w.bn[3], conv_w[3],
-                           iw.vlist, (int)N, w.Y[4], w.partial, (const float*)nullptr);
+      else {  // (58 KB of LDS and 76 registers: two blocks per CU)
+        prow_m = MPA_PN_FWD4_BLOCKS;
+        hipLaunchKernelGGL((pn_fwd_ws_kernel<64, 128, 32, false, 2>), dim3(MPA_PN_FWD4_BLOCKS), dim3(768), 0, s, w.Y[3], w.bn[3],
+                           conv_w[3], iw.vlist, (int)N, w.Y[4], w.partial, (const float*)nullptr);
+      }
     } else if (l == 1) {
       splits = d.tiles1;
       hipLaunchKernelGGL(pn_fwd_first_kernel<false>, dim3((unsigned)d.tiles1, (unsigned)M), dim3(kT), 0, s, points,
