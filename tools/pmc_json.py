@@ -37,8 +37,13 @@ def main():
                           "and --pmc WRITE_SIZE, separate passes; tools/gpu_full_pass.sh)",
                "config": "c2", "clouds_per_launch": clouds_of(prof, rnd, "c2"),
                "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
-               "correction": note + " (scattered 4-byte result stores count a full 64-byte line each)",
-               "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0}
+               "correction": "FETCH_SIZE at face value: the kernel gathers 16-byte records, and tools/probes/gather16.hip "
+                             "(profiles/r06_gather16_fetch_size.txt) shows rocprofv3 counting one 64-byte fetch per gathered "
+                             "record with NO halving (a coalesced stream of the same bytes is reported at 1/2); WRITE_SIZE as "
+                             "reported (scattered 4-byte result stores count a full 64-byte line each); upper bound with the "
+                             "streaming correction (FETCH x 2): traffic_bytes_per_launch_upper",
+               "traffic_bytes_per_launch": (1.0 * f + w) * 1024.0,
+               "traffic_bytes_per_launch_upper": (2.0 * f + w) * 1024.0}
         (prof / f"{rnd}_pmc_dominant_kernel.json").write_text(json.dumps(rec, indent=1))
         print(rec)
     # the wide kNN stages are a pipeline of kernels (csrc/dg_knn_fast.h): sum them per feature width; one record per
