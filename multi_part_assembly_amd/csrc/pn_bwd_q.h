@@ -309,7 +309,9 @@ __global__ __launch_bounds__(64 * (NS + ND + NW), (NS + ND + NW + 3) / 4) void p
     };
     auto put_sums = [&](int role) {  // scratch rows [(q * 2 + role) * RG + row group]: q = 1 s1, 2 s2, 3..5 S's columns
       float* scr = reinterpret_cast<float*>(&pz[0][0]);
-      const float4 is4 = reinterpret_cast<const float4*>(bn_prev + 3 * CIN)[cy4];
+      const float* isd = bn_prev + 3 * CIN;
+      asm volatile("" : "+s"(isd));  // rebuilt here from the scalar base: not a lane address kept alive across the unit loop
+      const float4 is4 = reinterpret_cast<const float4*>(isd)[cy4];
       t2v.x *= is4.x;
       t2v.y *= is4.y;
       t2v.z *= is4.z;
