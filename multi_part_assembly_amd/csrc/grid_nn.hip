@@ -730,7 +730,45 @@ struct LaneState {
   int split;  // wave-uniform, 1 / 2 / 4: with <= 32 (16) queries in the work item, 2 (4) groups of lanes hold the SAME
               // queries and each group scans every 2nd (4th) candidate; the groups are merged, lexicographically,
               // wherever the best is used
+  float qnlo;  // a lower bound of |q|^2 (scan_cand's gate)
 };
+
+// ---- the scan's gate ------------------------------------------------------------------------------------------------------------
+// The pinned distance costs 8 VALU operations per pair (3 sub, 3 mul, 2 add: no FMA, by contract), and the scan is where the
+// kernel's VALU time goes.  Almost every candidate loses, and THAT can be decided with three FMAs: a staged candidate
+// carries  tn' = fl(|t|^2) (1 - c)  in its fourth word, the lane computes
+//     f = fma(qz, -2 tz, fma(qy, -2 ty, fma(qx, -2 tx, tn')))  ~  |t|^2 - 2 q.t  =  D - |q|^2        (D = |q - t|^2)
+// (the staged record holds -2 t: exact, and the pinned path gets fl(qx - tx) back as fma(0.5, -2 tx, qx))
+// and only candidates with  f <= thr = best - qnlo  (qnlo = fl(|q|^2) (1 - c), thr rounded up) get the pinned arithmetic and the
+// lexicographic update.  The gate never contributes a digit to a result; it must only never reject a candidate whose pinned
+// distance d is <= best.  With u = 2^-24, Qn = |q|^2, Tn = |t|^2 in real arithmetic:
+//     tn' <= Tn (1 - c + 4 u);  three FMA roundings of partial sums bounded by 2 (Qn + Tn):  f <= Tn - 2 q.t - c Tn + 10 u (Qn + Tn);
+//     the pinned chain is within 6 u of D <= 2 (Qn + Tn):  D <= d + 12 u (Qn + Tn);
+//     so d <= best implies  f <= best - Qn + 22 u (Qn + Tn) - c Tn  <=  best - Qn (1 - 22 u)   for c >= 22 u,
+//     and qnlo = fl(Qn)(1 - c) <= Qn (1 + 3 u)(1 - c)(1 + u) <= Qn (1 - 22 u)   for c >= 27 u = 1.6e-6.        c = 4e-6.
+// Magnitudes whose squares may overflow take the pinned path unconditionally (tn' = -inf / qnlo = -inf); a NaN gate value
+// (inf - inf, 0 * inf) belongs to a pair whose pinned distance is inf or NaN, which never wins; 1e-30 of absolute slack covers
+// underflowing products.  The sentinel records (inf, inf, inf, +inf) give f = +inf or NaN.
+#ifndef MPA_GRID_EXP  // 3: every scan runs twice (same results) — the time difference is what the scans cost (LABBOOK 6.3)
+#define MPA_GRID_EXP 0
+#endif
+#ifndef MPA_GRID_FMA_GATE
+#define MPA_GRID_FMA_GATE 1  // 0: the pinned distance for every pair (the scan of rounds 2-5; A/B builds)
+#endif
+constexpr float kGateC = 4e-6f;
+__device__ __forceinline__ float gate_norm_lo(float x, float y, float z) {
+  const float n = (x * x + y * y) + z * z;
+  return n < 1e30f ? n * (1.0f - kGateC) : -__builtin_inff();  // (NaN: -inf as well — the pinned path decides)
+}
+// the LDS form of a target record: coordinates and tn'; the original point index goes to a list of its own (read only by the
+// few pairs that pass the gate)
+__device__ __forceinline__ float4 gate_record(const float4 t) {
+#if MPA_GRID_FMA_GATE
+  return make_float4(-2.0f * t.x, -2.0f * t.y, -2.0f * t.z, gate_norm_lo(t.x, t.y, t.z));
+#else
+  return t;
+#endif
+}
 
 __device__ __forceinline__ float dist_exact_s(float dx, float dy, float dz) { return (dx * dx + dy * dy) + dz * dz; }
 
@@ -797,8 +835,8 @@ __device__ __forceinline__ float gap(float a0, float a1, float b0, float b1) {
 // once), and then all lanes scan that list with broadcast LDS reads: two latencies per BATCH.  Long lists are
 // processed in windows of the LDS buffer; single long ranges go to the scalar scan, whose long runs amortise the
 // latency by themselves.
-#ifndef MPA_GRID_GATHER_U  // records per lane in flight in a window's gather; a window holds kCand - 16 = 112 records, so 2 covers it
-#define MPA_GRID_GATHER_U 2
+#ifndef MPA_GRID_GATHER_U  // records per lane in flight in a window's gather.  A window holds kCand - 16 = 112 records, so 2 covers
+#define MPA_GRID_GATHER_U 1  // it in one round — and costs 8 registers = the sixth wave per SIMD: 226 vs 212 us with the gated scan (round 6)
 #endif
 // Pins a loaded record in registers at this point of the program.  Without it the compiler sinks the second load of a lane
 // into the `if` that stores it — the ISA of rounds 2-3 read  load, s_waitcnt vmcnt(0), store, branch, load, s_waitcnt
@@ -806,6 +844,9 @@ __device__ __forceinline__ float gap(float a0, float a1, float b0, float b1) {
 __device__ __forceinline__ void pin_record(float4& t) { asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w)); }
 #ifndef MPA_GRID_CAND_CHUNK  // candidates per step of the LDS scan: 4 instead of 8 frees 16 registers (94 -> 78: 6 waves per
 #define MPA_GRID_CAND_CHUNK 4  // SIMD instead of 5; 0.279 -> 0.265 ms); 2 costs more LDS instructions than the 7th wave gains
+#endif
+#ifndef MPA_GRID_CAND_CHUNK_GENERIC
+#define MPA_GRID_CAND_CHUNK_GENERIC 3
 #endif
 #ifndef MPA_GRID_CAND
 #define MPA_GRID_CAND 128
@@ -817,10 +858,65 @@ constexpr int kCand = MPA_GRID_CAND;  // candidate records per LDS window (2.5 K
 constexpr int kLongRange = 32;  // ranges longer than this are fetched by the whole wave, one range at a time
 
 // every lane scans the wn candidate records staged in LDS (padded to a multiple of 8 with sentinels)
-__device__ __forceinline__ void scan_cand(LaneState& s, const float4* __restrict__ cand, int wn) {
-  constexpr int T = MPA_GRID_CAND_CHUNK;
+#if MPA_GRID_FMA_GATE
+// STEP = s.split as a constant: the T reads of a chunk are one address register plus immediate offsets
+template <int T, int STEP>
+__device__ __forceinline__ void scan_cand_step(LaneState& s, const float4* __restrict__ cand, const int* __restrict__ cidx,
+                                               int wn) {
+  const int sub = (int)threadIdx.x / (64 / STEP);
+  auto threshold = [&]() {  // best - qnlo, rounded up
+    const float t0 = s.best - s.qnlo;
+    return __builtin_fmaf(__builtin_fabsf(t0), 2.4e-7f, t0) + 1e-30f;
+  };
+  float thr = threshold();
+  const float4* p = cand + sub;
+  for (int j0 = 0; j0 < wn; j0 += T * STEP, p += T * STEP) {
+    float4 cur[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) cur[t] = p[t * STEP];
+    float f[T];  // (the staged record holds -2 t and tn')
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      f[t] = __builtin_fmaf(s.Z, cur[t].z, __builtin_fmaf(s.Y, cur[t].y, __builtin_fmaf(s.X, cur[t].x, cur[t].w)));
+    float fmin = f[0];
+#pragma unroll
+    for (int t = 1; t < T; ++t) fmin = __builtin_fminf(fmin, f[t]);
+    if (fmin <= thr) {  // a candidate that may improve on the best, or tie with it
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        if (f[t] <= thr) {
+          // X - t with t = -cur / 2: the product is exact, the sum rounds once — fl(X - tx)
+          const float d = dist_exact_s(__builtin_fmaf(0.5f, cur[t].x, s.X), __builtin_fmaf(0.5f, cur[t].y, s.Y),
+                                       __builtin_fmaf(0.5f, cur[t].z, s.Z));
+          const int ti = cidx[j0 + t * STEP + sub];
+          if (d < s.best || (d == s.best && ti < s.bidx)) {
+            s.best = d;
+            s.bidx = ti;
+            thr = threshold();
+          }
+        }
+      }
+    }
+  }
+}
+template <int T>
+__device__ __forceinline__ void scan_cand(LaneState& s, const float4* __restrict__ cand, const int* __restrict__ cidx, int wn) {
+#if MPA_GRID_EXP == 3  // (timing experiment: every scan twice)
+  if (s.split == 1) scan_cand_step<T, 1>(s, cand, cidx, wn);
+  else if (s.split == 2) scan_cand_step<T, 2>(s, cand, cidx, wn);
+  else scan_cand_step<T, 4>(s, cand, cidx, wn);
+  asm volatile("" : "+v"(s.best), "+v"(s.bidx));
+#endif
+  if (s.split == 1) scan_cand_step<T, 1>(s, cand, cidx, wn);  // (wave-uniform)
+  else if (s.split == 2) scan_cand_step<T, 2>(s, cand, cidx, wn);
+  else scan_cand_step<T, 4>(s, cand, cidx, wn);
+}
+#else
+template <int T>
+__device__ __forceinline__ void scan_cand(LaneState& s, const float4* __restrict__ cand, const int* __restrict__ cidx, int wn) {
   // split > 1: this group of lanes takes candidates sub, sub + split, ... (split LDS addresses per read, not one)
   const int step = s.split, sub = (int)threadIdx.x / (64 / s.split);
+  for (int rep = 0; rep < (MPA_GRID_EXP == 3 ? 2 : 1); ++rep)
   for (int j0 = 0; j0 < wn; j0 += T * step) {
     float4 cur[T];
 #pragma unroll
@@ -843,6 +939,7 @@ __device__ __forceinline__ void scan_cand(LaneState& s, const float4* __restrict
     }
   }
 }
+#endif
 
 // split mode: every group ends up with the best (distance, index) of all groups
 __device__ __forceinline__ void merge_halves(LaneState& s) {
@@ -859,9 +956,10 @@ __device__ __forceinline__ void merge_halves(LaneState& s) {
 // One long contiguous range [begin, end) of the target records (wave-uniform): ALL lanes fetch it together — 64
 // records per memory round trip and instruction, several in flight — into the LDS window, then scan it.  (A lane
 // copying its own long range alone moves 2 records per round trip; the scalar-operand scan moves 8.)
+template <int TC>
 __device__ __forceinline__ void scan_range_coop(LaneState& s, const float4* __restrict__ trec, int begin, int end,
-                                                float4* __restrict__ cand) {
-  constexpr int T = 4 * MPA_GRID_CAND_CHUNK, kCap = kCand - T;  // (4x: a split-4 scan reads up to that far past the end)
+                                                float4* __restrict__ cand, int* __restrict__ cidx) {
+  constexpr int T = 4 * TC, kCap = kCand - T;  // (4x: a split-4 scan reads up to that far past the end)
   const int lane = threadIdx.x;
   for (int w0 = begin; w0 < end; w0 += kCap) {
     const int wn = end - w0 < kCap ? end - w0 : kCap;
@@ -875,14 +973,18 @@ __device__ __forceinline__ void scan_range_coop(LaneState& s, const float4* __re
       for (int u = 0; u < U; ++u) pin_record(t[u]);
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (j0 + 64 * u < wn) cand[j0 + 64 * u] = t[u];
+        if (j0 + 64 * u < wn) {
+          cand[j0 + 64 * u] = gate_record(t[u]);
+          if (MPA_GRID_FMA_GATE) cidx[j0 + 64 * u] = __float_as_int(t[u].w);
+        }
     }
     if (lane < T) {
       const float inf = __builtin_inff();
-      cand[wn + lane] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
+      cand[wn + lane] = make_float4(inf, inf, inf, MPA_GRID_FMA_GATE ? inf : __int_as_float(0x7fffffff));
+      if (MPA_GRID_FMA_GATE) cidx[wn + lane] = 0x7fffffff;
     }
     __syncthreads();
-    scan_cand(s, cand, wn);
+    scan_cand<TC>(s, cand, cidx, wn);
   }
 }
 
@@ -925,8 +1027,9 @@ __device__ unsigned long long g_grid_stats[24];  // 0-7: items, active lanes, sc
 #define MPA_TICK_END() do { } while (0)
 #endif
 
+template <int TC>
 __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restrict__ trec, int rb, int re,
-                                           float4* __restrict__ cand, int* __restrict__ sidx) {
+                                           float4* __restrict__ cand, int* __restrict__ sidx, int* __restrict__ cidx) {
   const int lane = threadIdx.x;
   int len = re > rb ? re - rb : 0;
 #ifdef MPA_GRID_STATS
@@ -945,12 +1048,12 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
   while (big) {
     const int l = __builtin_ctzll(big);
     big &= big - 1;
-    scan_range_coop(s, trec, __builtin_amdgcn_readlane(rb, l), __builtin_amdgcn_readlane(re, l), cand);
+    scan_range_coop<TC>(s, trec, __builtin_amdgcn_readlane(rb, l), __builtin_amdgcn_readlane(re, l), cand, cidx);
   }
   if (len > kLongRange) len = 0;
   const int incl = wave_prefix_sum(len);
   const int total = __builtin_amdgcn_readlane(incl, 63), off0 = incl - len;
-  constexpr int T = 4 * MPA_GRID_CAND_CHUNK, kCap = kCand - T;  // (4x: a split-4 scan reads up to that far past the end)
+  constexpr int T = 4 * TC, kCap = kCand - T;  // (4x: a split-4 scan reads up to that far past the end)
   for (int w0 = 0; w0 < total; w0 += kCap) {  // windows of the concatenated list that fit the LDS buffer
     const int wn = total - w0 < kCap ? total - w0 : kCap;
     const int lo = off0 > w0 ? off0 : w0, hi = off0 + len < w0 + wn ? off0 + len : w0 + wn;
@@ -971,14 +1074,18 @@ __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restric
       for (int u = 0; u < U; ++u) pin_record(t[u]);
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (j0 + 64 * u < wn) cand[j0 + 64 * u] = t[u];
+        if (j0 + 64 * u < wn) {
+          cand[j0 + 64 * u] = gate_record(t[u]);
+          if (MPA_GRID_FMA_GATE) cidx[j0 + 64 * u] = __float_as_int(t[u].w);
+        }
     }
     if (lane < T) {  // pad the last chunk of 8 with records that can never win
       const float inf = __builtin_inff();
-      cand[wn + lane] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
+      cand[wn + lane] = make_float4(inf, inf, inf, MPA_GRID_FMA_GATE ? inf : __int_as_float(0x7fffffff));
+      if (MPA_GRID_FMA_GATE) cidx[wn + lane] = 0x7fffffff;
     }
     __syncthreads();
-    scan_cand(s, cand, wn);
+    scan_cand<TC>(s, cand, cidx, wn);
   }
 }
 
@@ -1000,6 +1107,10 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     IdxT* __restrict__ idx2, const XcdPlan* __restrict__ plan) {
   __shared__ float4 cand[kCand];
   __shared__ int sidx[kCand];  // record index of every position of the current window
+  __shared__ int cidx[MPA_GRID_FMA_GATE ? kCand : 1];  // original point index of every candidate of the window
+  // candidates per step of the LDS scan: the operator's instantiation carries a few more registers (relative geometry, border
+  // cells) and reaches six waves per SIMD with 3 (77 registers; 4: 81)
+  constexpr int TC = GENERIC ? MPA_GRID_CAND_CHUNK_GENERIC : MPA_GRID_CAND_CHUNK;
   MPA_TICK_INIT();
   // block -> (sample, direction, wave): from the XCD-aware plan (grid_assign_plan) or, without one, waves
   // blockIdx.x of pair blockIdx.y
@@ -1073,6 +1184,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
     const int qflat = __float_as_int(qr.w);
     s.best = 1e32f;
     s.bidx = 0x7fffffff;
+    s.qnlo = gate_norm_lo(s.X, s.Y, s.Z);
     MPA_TICK(9);
     // the queries lie in the super-cell box (inflated by the binning slack)
     float bx0 = OX + (float)(kS * sx) * g.h - slack, bx1 = OX + (float)(kS * sx + kS) * g.h + slack;
@@ -1097,7 +1209,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
       const bool ok = lane < kSeedW * kSeedW && z <= z1 && y <= y1 && z >= tz0 && z <= tz1 && y >= ty0 && y <= ty1 && xa <= xb;
       const int row = (z * g.gy + y) * g.gx;
       const int rb = ok ? tst[row + xa] : 0, re = ok ? tst[row + xb + 1] : 0;
-      scan_batch(s, trec, rb, re, cand, sidx);
+      scan_batch<TC>(s, trec, rb, re, cand, sidx, cidx);
     }
     // sweep: every cell whose box can hold a point closer than the worst best-distance of this wave.  Rows (y, z)
     // are visited nearest-first, as square rings around the super-cell's own kS x kS rows (lane = row of a ring), so
@@ -1181,14 +1293,14 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
       const int rr = lane >= kL0 ? 1 : 0, li = lane - rr * kL0;
       int rb, re;
       row_range(rr, li & 1, li >> 1, li < 2 * ring_rows(rr), rb, re);
-      scan_batch(s, trec, rb, re, cand, sidx);
+      scan_batch<TC>(s, trec, rb, re, cand, sidx, cidx);
       merge_halves(s);
       bound = wave_max(s.best) * 1.00001f;
     } else {
       for (int r = 0; r <= 1 && r <= rmax; ++r) {  // rings 0 and 1: both flanks of every row in one batch
         int rb, re;
         row_range(r, lane & 1, lane >> 1, lane < 2 * ring_rows(r), rb, re);
-        scan_batch(s, trec, rb, re, cand, sidx);
+        scan_batch<TC>(s, trec, rb, re, cand, sidx, cidx);
         merge_halves(s);
         bound = wave_max(s.best) * 1.00001f;  // (ring 1 must see the bound ring 0 found: without one, rows are whole)
       }
@@ -1202,7 +1314,7 @@ __global__ __launch_bounds__(64) void grid_search_kernel(
         int rb, re;
         row_range(r, 0, i0 + lane, i0 + lane < nrows, rb, re);
         MPA_STAT(5, 1);
-        scan_batch(s, trec, rb, re, cand, sidx);
+        scan_batch<TC>(s, trec, rb, re, cand, sidx, cidx);
       }
       merge_halves(s);
       bound = wave_max(s.best) * 1.00001f;  // (two rings per batch were tried: the staler bound costs what the saved

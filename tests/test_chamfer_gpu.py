@@ -208,6 +208,25 @@ def test_grid_search_matches_oracle(cuda_device, kind1, kind2):
             np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"{name} {kind1} {kind2} {(B, n1, n2)}")
 
 
+@pytest.mark.parametrize("offset, spacing", [(0.0, 1.0), (30.0, 1e-2), (1000.0, 1e-3), (-3e4, 0.5), (2e7, 4.0), (1e12, 1e6)])
+def test_grid_search_gate_far_from_the_origin(cuda_device, offset, spacing):
+    """The scan of the pruned search rejects candidates with three FMAs on |t|^2 - 2 q.t (grid_nn.hip: scan_cand); the
+    cancellation in that form grows with the distance of the clouds from the origin, and the gate's margin must grow with
+    it.  Lattice points (many exact ties, lowest index wins) and jittered points at offsets where one ulp of a coordinate is
+    a sizeable fraction of the spacing: every output bit-equal to the oracle's in-order scan."""
+    rng = np.random.default_rng(int(abs(offset)) % 1000 + 7)
+    n1, n2 = 700, 640
+    lat = rng.integers(0, 9, (2, n1 + n2, 3)).astype(np.float32) * np.float32(spacing)
+    jit = (rng.standard_normal((2, n1 + n2, 3)) * spacing * 3).astype(np.float32)
+    pts = np.concatenate([lat[:1], jit[1:]], 0) + np.float32(offset) * np.array([1.0, -0.5, 0.25], np.float32)
+    a = np.ascontiguousarray(pts[:, :n1]).astype(np.float32)
+    b = np.ascontiguousarray(pts[:, n1:]).astype(np.float32)
+    ref = oc.chamfer_forward(a, b)
+    out = C.chamfer_forward(_dev(a, cuda_device), _dev(b, cuda_device), variant=3)
+    for got, want, name in zip(out, ref, ("dist1", "idx1", "dist2", "idx2")):
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"{name} offset {offset} spacing {spacing}")
+
+
 def test_grid_search_hands_non_finite_samples_to_the_scan(cuda_device):
     """A sample with a NaN / inf / > 1e15 coordinate is answered by the exhaustive scan (same contract as the scan's own
     special-value test); its neighbours in the batch still go through the grid."""
