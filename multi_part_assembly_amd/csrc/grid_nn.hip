@@ -277,10 +277,12 @@ __device__ __forceinline__ void block_scan(int* __restrict__ cnt, int nkeys, int
 // blocks (each reads the shape's points itself: 240 KB from L2) — 128 instead of 64 blocks on 256 CUs, and neither
 // waits for the other's scan.
 constexpr int kSortU = 4;
+constexpr int kSortKeep = 20;  // points per thread held in registers by the sort blocks (1024 x 20 slots: the shipped P N)
 
 // Where a sort block's points come from.  fetch(i, x, y, z): the point in flat slot i (unconditional load of a clamped
 // position: conditional loads send the unrolled arrays to scratch) and whether it takes part.
 struct PartsSource {  // the fused loss: P parts of N points, padded parts out
+  static constexpr bool kKeep = true;  // the sort holds a thread's points in registers (grid_sort_role)
   const float* vsm;   // the sample's valid flags (LDS)
   const float* shape;
   int N, total;
@@ -300,6 +302,7 @@ struct PartsSource {  // the fused loss: P parts of N points, padded parts out
 // A sample routed to the exhaustive scan sorts nothing.
 template <bool DEDUPE>
 struct CloudSource {
+  static constexpr bool kKeep = false;  // (its fetch reads the predecessor too: the register form spills)
   const float* cloud;
   int total;
   bool off;
@@ -321,6 +324,41 @@ __device__ __forceinline__ void grid_sort_role(const Src& src, const GridParams&
   const int nkeys = ROLE == 0 ? g.ncells : g.nsuper;
   for (int i = threadIdx.x; i < padk(nkeys) + 1; i += 1024) cnt[i] = 0;
   __syncthreads();
+  float4* out = records + (long long)slot * rec_stride;
+  auto scan_keys = [&]() {
+    if (ROLE == 0)
+      block_scan<kMaxCells / 1024, false>(cnt, nkeys, starts + (long long)slot * kStartStride, nullptr, nullptr, wsum);
+    else
+      block_scan<kMaxSuper / 1024, true>(cnt, nkeys, starts + (long long)slot * kStartStride,
+                                         batches + (long long)slot * kStartStride, worklist + (long long)slot * work_stride,
+                                         wsum);
+    __syncthreads();
+    if (ROLE == 0 && threadIdx.x < 8) {  // sentinels: chunked reads may run past the last record
+      const float inf = __builtin_inff();
+      // (generic: the record count is what the scan left behind the last key — written by this block, in front of a barrier)
+      const int nrec = GENERIC ? starts[(long long)slot * kStartStride + nkeys] : g.nvalid;
+      out[nrec + threadIdx.x] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
+    }
+  };
+  if (Src::kKeep && src.total <= 1024 * kSortKeep) {
+    // the shipped sizes (P N = 20 000 slots): a thread's <= 20 points stay in registers between the histogram and the scatter,
+    // and all of their loads are in flight at once — the two passes of the loop below are ten dependent L2 round trips
+    float x[kSortKeep], y[kSortKeep], z[kSortKeep];
+    unsigned okm = 0u;
+#pragma unroll
+    for (int u = 0; u < kSortKeep; ++u) okm |= src.fetch(threadIdx.x + 1024 * u, x[u], y[u], z[u]) ? 1u << u : 0u;
+#pragma unroll
+    for (int u = 0; u < kSortKeep; ++u)
+      if ((okm >> u) & 1u) atomicAdd(&cnt[padk(key_of(g, ROLE, x[u], y[u], z[u]))], 1);
+    __syncthreads();
+    scan_keys();
+#pragma unroll
+    for (int u = 0; u < kSortKeep; ++u)
+      if ((okm >> u) & 1u)
+        out[atomicAdd(&cnt[padk(key_of(g, ROLE, x[u], y[u], z[u]))], 1)] =
+            make_float4(x[u], y[u], z[u], __int_as_float((int)threadIdx.x + 1024 * u));  // (the flat slot p * N + n)
+    return;
+  }
   // all point slots in one flat loop, kSortU loads per thread in flight (a loop over the parts was one dependent
   // memory round trip per valid part and pass)
   const int total = src.total;
@@ -334,20 +372,7 @@ __device__ __forceinline__ void grid_sort_role(const Src& src, const GridParams&
       if (ok[u]) atomicAdd(&cnt[padk(key_of(g, ROLE, x[u], y[u], z[u]))], 1);
   }
   __syncthreads();
-  if (ROLE == 0)
-    block_scan<kMaxCells / 1024, false>(cnt, nkeys, starts + (long long)slot * kStartStride, nullptr, nullptr, wsum);
-  else
-    block_scan<kMaxSuper / 1024, true>(cnt, nkeys, starts + (long long)slot * kStartStride,
-                                       batches + (long long)slot * kStartStride, worklist + (long long)slot * work_stride,
-                                       wsum);
-  __syncthreads();
-  float4* out = records + (long long)slot * rec_stride;
-  if (ROLE == 0 && threadIdx.x < 8) {  // sentinels: chunked reads may run past the last record
-    const float inf = __builtin_inff();
-    // (generic: the record count is what the scan left behind the last key — written by this block, in front of a barrier)
-    const int nrec = GENERIC ? starts[(long long)slot * kStartStride + nkeys] : g.nvalid;
-    out[nrec + threadIdx.x] = make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
-  }
+  scan_keys();
   for (int i0 = threadIdx.x; i0 < total; i0 += 1024 * kSortU) {
     float x[kSortU], y[kSortU], z[kSortU];
     bool ok[kSortU];
@@ -857,6 +882,46 @@ constexpr int kCand = MPA_GRID_CAND;  // candidate records per LDS window (2.5 K
                                       // the kernel from 0.44 to 0.28 ms; tools/variant_bench.sh)
 constexpr int kLongRange = 32;  // ranges longer than this are fetched by the whole wave, one range at a time
 
+#ifdef MPA_GRID_STATS  // instrumented build for tools/probe_grid_stats.py only (never in libmpa_hip.so)
+__device__ unsigned long long g_grid_stats[24];  // 0-7: items, active lanes, scan_batch calls, candidates, long-range candidates,
+                                                 // outer-ring batches, items without a bound after the seed; 8-15: shader-clock ticks of
+                                                 // a wave's phases: prologue, item header, seed, rings 0-1, outer rings, pads + store,
+                                                 // whole wave, waves; 16-18: scan chunks, chunks with a lane past the gate, pinned
+                                                 // evaluations (wave-level: a candidate slot with such a lane)
+#ifdef MPA_GRID_TIMING  // phase timing: no counters inside the timed phases, the per-wave sums leave in one batch at the end
+#define MPA_STAT(i, v) do { } while (0)
+#define MPA_TICK(i)                                                        \
+  do {                                                                     \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            \
+    const unsigned long long now_ = __builtin_readcyclecounter();          \
+    tacc_[(i) - 8] += now_ - tick_;                                        \
+    tick_ = now_;                                                          \
+  } while (0)
+#define MPA_TICK_INIT()                                                    \
+  unsigned long long tick_ = __builtin_readcyclecounter(), tacc_[6] = {0, 0, 0, 0, 0, 0}; \
+  const unsigned long long tick0_ = tick_
+#define MPA_TICK_END()                                                                                        \
+  do {                                                                                                        \
+    if (threadIdx.x == 0) {                                                                                   \
+      const unsigned long long end_ = __builtin_readcyclecounter();                                           \
+      for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_grid_stats[8 + k_], tacc_[k_]);                              \
+      atomicAdd(&g_grid_stats[14], end_ - tick0_);                                                            \
+      atomicAdd(&g_grid_stats[15], 1ull);                                                                     \
+    }                                                                                                         \
+  } while (0)
+#else
+#define MPA_STAT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_grid_stats[i], (unsigned long long)(v)); } while (0)
+#define MPA_TICK(i) do { } while (0)
+#define MPA_TICK_INIT() do { } while (0)
+#define MPA_TICK_END() do { } while (0)
+#endif
+#else
+#define MPA_STAT(i, v) do { } while (0)
+#define MPA_TICK(i) do { } while (0)
+#define MPA_TICK_INIT() do { } while (0)
+#define MPA_TICK_END() do { } while (0)
+#endif
+
 // every lane scans the wn candidate records staged in LDS (padded to a multiple of 8 with sentinels)
 #if MPA_GRID_FMA_GATE
 // STEP = s.split as a constant: the T reads of a chunk are one address register plus immediate offsets
@@ -881,9 +946,12 @@ __device__ __forceinline__ void scan_cand_step(LaneState& s, const float4* __res
     float fmin = f[0];
 #pragma unroll
     for (int t = 1; t < T; ++t) fmin = __builtin_fminf(fmin, f[t]);
+    MPA_STAT(16, 1);
+    MPA_STAT(17, __ballot(fmin <= thr) != 0 ? 1 : 0);
     if (fmin <= thr) {  // a candidate that may improve on the best, or tie with it
 #pragma unroll
       for (int t = 0; t < T; ++t) {
+        MPA_STAT(18, __ballot(f[t] <= thr) != 0 ? 1 : 0);
         if (f[t] <= thr) {
           // X - t with t = -cur / 2: the product is exact, the sum rounds once — fl(X - tx)
           const float d = dist_exact_s(__builtin_fmaf(0.5f, cur[t].x, s.X), __builtin_fmaf(0.5f, cur[t].y, s.Y),
@@ -987,45 +1055,6 @@ __device__ __forceinline__ void scan_range_coop(LaneState& s, const float4* __re
     scan_cand<TC>(s, cand, cidx, wn);
   }
 }
-
-#ifdef MPA_GRID_STATS  // instrumented build for tools/probe_grid_stats.py only (never in libmpa_hip.so)
-__device__ unsigned long long g_grid_stats[24];  // 0-7: items, active lanes, scan_batch calls, candidates, long-range candidates,
-                                                 // outer-ring batches, items without a bound after the seed; 8-15: shader-clock ticks of
-                                                 // a wave's phases: prologue, item header, seed, rings 0-1, outer rings, pads + store,
-                                                 // whole wave, waves
-#ifdef MPA_GRID_TIMING  // phase timing: no counters inside the timed phases, the per-wave sums leave in one batch at the end
-#define MPA_STAT(i, v) do { } while (0)
-#define MPA_TICK(i)                                                        \
-  do {                                                                     \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            \
-    const unsigned long long now_ = __builtin_readcyclecounter();          \
-    tacc_[(i) - 8] += now_ - tick_;                                        \
-    tick_ = now_;                                                          \
-  } while (0)
-#define MPA_TICK_INIT()                                                    \
-  unsigned long long tick_ = __builtin_readcyclecounter(), tacc_[6] = {0, 0, 0, 0, 0, 0}; \
-  const unsigned long long tick0_ = tick_
-#define MPA_TICK_END()                                                                                        \
-  do {                                                                                                        \
-    if (threadIdx.x == 0) {                                                                                   \
-      const unsigned long long end_ = __builtin_readcyclecounter();                                           \
-      for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_grid_stats[8 + k_], tacc_[k_]);                              \
-      atomicAdd(&g_grid_stats[14], end_ - tick0_);                                                            \
-      atomicAdd(&g_grid_stats[15], 1ull);                                                                     \
-    }                                                                                                         \
-  } while (0)
-#else
-#define MPA_STAT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_grid_stats[i], (unsigned long long)(v)); } while (0)
-#define MPA_TICK(i) do { } while (0)
-#define MPA_TICK_INIT() do { } while (0)
-#define MPA_TICK_END() do { } while (0)
-#endif
-#else
-#define MPA_STAT(i, v) do { } while (0)
-#define MPA_TICK(i) do { } while (0)
-#define MPA_TICK_INIT() do { } while (0)
-#define MPA_TICK_END() do { } while (0)
-#endif
 
 template <int TC>
 __device__ __forceinline__ void scan_batch(LaneState& s, const float4* __restrict__ trec, int rb, int re,

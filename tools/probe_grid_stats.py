@@ -22,7 +22,7 @@ num_parts = batch.pop("num_parts")
 L = _lib.lib()
 fn = L.mpa_debug_grid_stats
 fn.restype = ctypes.c_int
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 24)()
 for i in range(5):
     trainer.train_step(batch, i)
 torch.cuda.synchronize()
@@ -35,3 +35,12 @@ queries = 2 * 1000 * sum(num_parts)
 print(f"queries {queries}  work items {items}  active lanes/item {lanes / items:.1f} of 64  scan batches/item {calls / items:.1f}")
 print(f"candidate records per item {cand / items:.0f} ({lng / max(1, cand):.0%} in long contiguous ranges)  "
       f"pair evaluations: useful {cand / items * lanes / items * items:.3e}, issued {cand * 64:.3e}")
+chunks, hit, pinned = buf[16], buf[17], buf[18]
+if chunks:
+    print(f"scan chunks per item {chunks / items:.0f}; with a lane past the gate {hit / chunks:.1%}; pinned evaluations (wave-level "
+          f"candidate slots) per chunk {pinned / chunks:.2f}")
+t = list(buf)[8:16]
+if t[7]:
+    names = ["prologue", "item header", "seed", "rings 0-1", "outer rings", "pads + store"]
+    print("shader-clock ticks per wave: " + ", ".join(f"{n} {t[i] / t[7]:.0f}" for i, n in enumerate(names))
+          + f"; whole wave {t[6] / t[7]:.0f}; waves {t[7]}")
