@@ -32,6 +32,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// the same sum on the DPP network (quad permutes, row mirrors, row broadcasts: six VALU operations, no LDS round trips; the
+// addition order differs from wave_sum's butterfly)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto add = [](float a, int bits) { return a + __int_as_float(bits); };
+  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror: a row's 16 lanes hold its sum
+  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false)); // row_bcast15 into rows 1, 3
+  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false)); // row_bcast31 into rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 template <typename T>
 __device__ __forceinline__ const T* opaque(const T* p) {
   asm volatile("" : "+v"(p));
@@ -372,6 +385,265 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const float* __restri
       if (i < P) out[(long long)(b * P + i) * D + hd * DH + 32 * nt + c] = o[r];
     }
   }
+}
+
+// ---- LayerNorm + q / k / v projection + attention of ONE (sample, head) in one block (D = 256, head dim 32, P <= 32) -------------
+// The qkv GEMM and the attention kernel are two launches of ~9 us each that are mostly latency, and a (sample, head) needs
+// only 96 of the 768 qkv columns of its own <= 32 tokens: a 32 x 96 x 256 product.  One block of 8 waves:
+//   staging   the sample's token rows (a wave holds a whole 1 KB row per load: LayerNorm is two DPP sums) and the head's 96
+//             weight rows (global_load_lds: straight into the LDS panel, one row per instruction) — everything requested at
+//             once, the key mask, the biases and the dropout seed of a graph replay included;
+//   chains    the waves split K = 256 (32 each); per wave three MFMA chains on lane-per-row fragments of the padded panel:
+//             Q~, K~ TRANSPOSED (A = weight row, B = token row): lane (c, h) ends up with features acc_row(r, h) of token c —
+//             exactly the operand registers of T = K Q^T (that product's k index is enumerated (step, half) <-> feature
+//             acc_row(step, half)); V straight (A = token row, B = weight row): V[token acc_row(r, h)][feature c], the B
+//             operand of S V;
+//   reduction the 8 partial tiles meet in LDS (the panels' memory); waves 0..2 sum one tile each in wave order, add the bias
+//             and write it to qkv (for backward); waves 3..6 hash the dropout keep-scales of the probabilities meanwhile;
+//   attention wave 0, as attn_fwd_mfma_kernel, on registers.
+// The normalised rows and their statistics are written by head 0's block as the standalone kernels wrote them.
+// 13.7 us against 9.5 + 9.0 us and a launch boundary (s_memtime stamps of a block, -DMPA_QKV_EXP=9: loads 2.4 us, LayerNorm +
+// panel 2.0, chains 1.9, reduction 2.9, attention 2.9).
+#ifndef MPA_QKV_EXP  // timing experiments: 1 stop after the staging, 2 after the chains, 3 after the reduction (wrong results)
+#define MPA_QKV_EXP 0
+#endif
+constexpr int kQT = 512, kQLD = 256 + 4;  // (padded rows: the lane-per-row fragment reads are conflict-free)
+__global__ __launch_bounds__(kQT, 2) void attn_qkv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wqkv,
+                                                           const float* __restrict__ bqkv, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           const float* __restrict__ valid, int P, int H, Drop drop,
+                                                           unsigned site, float* __restrict__ qkv, float* __restrict__ ln_stats,
+                                                           float* __restrict__ ln_h, float* __restrict__ ln_xcopy,
+                                                           float* __restrict__ probs, float* __restrict__ out,
+                                                           unsigned* __restrict__ zero, int zero_n) {
+  constexpr int D = 256, DH = 32;
+  // rows 0..31: the normalised token rows, 32..127: the q / k / v weight rows of this head; later (aliased) the 8 waves'
+  // partial tiles: part[tile][register group][wave][lane]
+  __shared__ __attribute__((aligned(16))) float panel[128 * kQLD];
+  __shared__ float4 hand[2][4][64];  // the reduced k~ and v tiles on their way to wave 0
+  __shared__ float keepm[16][64];    // dropout keep-scales of the probabilities, register r of lane
+  float4(*part)[4][8][64] = reinterpret_cast<float4(*)[4][8][64]>(panel);
+  static_assert(sizeof(float4) * 3 * 4 * 8 * 64 <= sizeof(float) * 128 * kQLD, "the partial tiles fit the panels");
+  const int b = blockIdx.x / H, hd = blockIdx.x % H;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  if (zero != nullptr && blockIdx.x == 0 && (int)threadIdx.x < zero_n) zero[threadIdx.x] = 0u;
+#if MPA_QKV_EXP == 9
+  unsigned long long ts[8];
+  int nts = 0;
+#define QKV_STAMP() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[nts++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QKV_STAMP() do { } while (0)
+#endif
+  QKV_STAMP();
+  // ---- loads, all in flight at once and fully coalesced: a wave reads one 1 KB row per instruction
+  float4 xr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // token rows wave + 8 i (rows >= P: the sample's first row, dropped below)
+    const int row = wave + 8 * i;
+    xr[i] = *reinterpret_cast<const float4*>(x + ((long long)b * P + (row < P ? row : 0)) * D + 4 * lane);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {  // weight rows: panel row 32 + wave + 8 i = tile (i / 4), feature wave + 8 (i % 4)
+    // straight into LDS (global_load_lds_dwordx4: wave-uniform LDS row + 16 B per lane — one 1 KB row per instruction, no
+    // registers in between; they count in vmcnt, which the barrier below drains)
+    const int pr = wave + 8 * i, tile = pr >> 5, f = pr & 31;
+    __builtin_amdgcn_global_load_lds(wqkv + ((long long)tile * D + hd * DH + f) * D + 4 * lane,
+                                     (__attribute__((address_space(3))) void*)(panel + (32 + pr) * kQLD), 16, 0, 0);
+  }
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * lane), bt = *reinterpret_cast<const float4*>(beta + 4 * lane);
+  // (the dropout seed of a graph replay lives in device memory: requested here, with everything else — read where the hash
+  // needs it, it is a memory round trip in the middle of the reduction)
+  Drop dl = drop;
+  if (drop.p > 0.0f && drop.seed_dev != nullptr) dl.seed = *drop.seed_dev;
+  dl.seed_dev = nullptr;
+  // wave 0 also requests what its attention needs later: the key mask and the three bias runs
+  // (every wave, unconditional loads of clamped positions: behind `wave == 0` and `j < P &&` the compiler made each of the
+  // sixteen mask loads a branch of its own with a full wait — 9 us of dependent round trips)
+  float kv[16], bq[16], bk[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = acc_row(r, h);
+    kv[r] = valid[b * P + (j < P ? j : 0)];
+    bq[r] = bqkv[hd * DH + j];
+    bk[r] = bqkv[D + hd * DH + j];
+  }
+  const float bv = bqkv[2 * D + hd * DH + c];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kv[r] = (acc_row(r, h) < P && kv[r] == 1.0f) ? 1.0f : 0.0f;
+  QKV_STAMP();
+  // ---- LayerNorm: a wave holds a whole row (two passes, as ln_fwd_kernel: mean, then the variance of the deviations)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave + 8 * i;
+    const float mean = wave_sum_dpp((xr[i].x + xr[i].y) + (xr[i].z + xr[i].w)) * (1.0f / (float)D);
+    const float dx = xr[i].x - mean, dy = xr[i].y - mean, dz = xr[i].z - mean, dw = xr[i].w - mean;
+    const float rstd = 1.0f / __builtin_sqrtf(wave_sum_dpp((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / (float)D) + eps);
+    const float4 hn = make_float4(dx * rstd * gm.x + bt.x, dy * rstd * gm.y + bt.y, dz * rstd * gm.z + bt.z, dw * rstd * gm.w + bt.w);
+    *reinterpret_cast<float4*>(panel + row * kQLD + 4 * lane) = hn;
+    if (hd == 0 && row < P) {  // what the standalone LayerNorm would have written
+      const long long tok = (long long)b * P + row;
+      if (lane == 0) {
+        ln_stats[2 * tok] = mean;
+        ln_stats[2 * tok + 1] = rstd;
+      }
+      *reinterpret_cast<float4*>(ln_h + tok * D + 4 * lane) = hn;
+      if (ln_xcopy != nullptr) *reinterpret_cast<float4*>(ln_xcopy + tok * D + 4 * lane) = xr[i];
+    }
+  }
+  __syncthreads();
+  QKV_STAMP();
+#if MPA_QKV_EXP == 1
+  return;
+#endif
+  // ---- three chains per wave over its eighth of K: k = 32 wave + 8 v + 4 h + e
+  f32x16 aq = {0}, ak = {0}, av = {0};
+  {
+    const float* ph = panel + c * kQLD + 32 * wave + 4 * h;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float4 hv = *reinterpret_cast<const float4*>(ph + 8 * v);
+      const float4 q4 = *reinterpret_cast<const float4*>(ph + 32 * kQLD + 8 * v);
+      const float4 k4 = *reinterpret_cast<const float4*>(ph + 64 * kQLD + 8 * v);
+      const float4 v4 = *reinterpret_cast<const float4*>(ph + 96 * kQLD + 8 * v);
+      aq = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, hv.x, aq, 0, 0, 0);
+      ak = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, hv.x, ak, 0, 0, 0);
+      av = __builtin_amdgcn_mfma_f32_32x32x2f32(hv.x, v4.x, av, 0, 0, 0);
+      aq = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, hv.y, aq, 0, 0, 0);
+      ak = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, hv.y, ak, 0, 0, 0);
+      av = __builtin_amdgcn_mfma_f32_32x32x2f32(hv.y, v4.y, av, 0, 0, 0);
+      aq = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, hv.z, aq, 0, 0, 0);
+      ak = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, hv.z, ak, 0, 0, 0);
+      av = __builtin_amdgcn_mfma_f32_32x32x2f32(hv.z, v4.z, av, 0, 0, 0);
+      aq = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, hv.w, aq, 0, 0, 0);
+      ak = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, hv.w, ak, 0, 0, 0);
+      av = __builtin_amdgcn_mfma_f32_32x32x2f32(hv.w, v4.w, av, 0, 0, 0);
+    }
+  }
+  QKV_STAMP();
+#if MPA_QKV_EXP == 2
+  if (aq[0] + ak[1] + av[2] != 12345.0f) return;
+#endif
+  __syncthreads();  // every wave is done with the panels: their memory takes the partial tiles
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    part[0][g][wave][lane] = make_float4(aq[4 * g], aq[4 * g + 1], aq[4 * g + 2], aq[4 * g + 3]);
+    part[1][g][wave][lane] = make_float4(ak[4 * g], ak[4 * g + 1], ak[4 * g + 2], ak[4 * g + 3]);
+    part[2][g][wave][lane] = make_float4(av[4 * g], av[4 * g + 1], av[4 * g + 2], av[4 * g + 3]);
+  }
+  __syncthreads();
+  if (wave >= 7) return;  // (the barrier below is reached by the seven waves that are left: finished waves do not count)
+  const bool on = c < P;
+  const long long tok = (long long)b * P + (on ? c : 0);
+  const long long prow = ((long long)(b * H + hd) * P + c) * P;
+  float tl[16];
+  if (wave >= 3) {
+    // the dropout keep-scales of the probabilities (a 64-bit hash per element), four registers' worth per wave 3..6 —
+    // beside the reduction instead of inside wave 0's chain
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * (wave - 3) + e, j = acc_row(r, h);
+      keepm[r][lane] = (c < P && j < P) ? drop_scale(dl, site, (unsigned long long)(prow + j)) : 0.0f;
+    }
+  } else {
+    // wave t sums tile t over the 8 waves, in wave order; waves 1 and 2 write their tile (k~, v) out and hand it to wave 0
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 a = part[wave][g][0][lane];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) {
+        const float4 p4 = part[wave][g][w][lane];
+        a.x += p4.x, a.y += p4.y, a.z += p4.z, a.w += p4.w;
+      }
+      if (wave == 0) {
+        a.x += bq[4 * g], a.y += bq[4 * g + 1], a.z += bq[4 * g + 2], a.w += bq[4 * g + 3];
+      } else if (wave == 1) {
+        a.x += bk[4 * g], a.y += bk[4 * g + 1], a.z += bk[4 * g + 2], a.w += bk[4 * g + 3];
+      } else {
+        a.x += bv, a.y += bv, a.z += bv, a.w += bv;
+      }
+      tl[4 * g] = a.x, tl[4 * g + 1] = a.y, tl[4 * g + 2] = a.z, tl[4 * g + 3] = a.w;
+      if (wave > 0) hand[wave - 1][g][lane] = a;
+    }
+  }
+  __syncthreads();
+  if (wave < 3) {  // the tiles go out behind the barrier (in front of it, it would wait for the stores to be acknowledged)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (wave < 2) {  // q~ / k~: four consecutive features 8 g + 4 h .. of token c
+        if (on)
+          *reinterpret_cast<float4*>(qkv + tok * 3 * D + wave * D + hd * DH + 8 * g + 4 * h) =
+              make_float4(tl[4 * g], tl[4 * g + 1], tl[4 * g + 2], tl[4 * g + 3]);
+      } else {  // v: row acc_row(r, h), feature c
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = acc_row(4 * g + e, h);
+          if (j < P) qkv[((long long)b * P + j) * 3 * D + 2 * D + hd * DH + c] = tl[4 * g + e];
+        }
+      }
+    }
+  }
+  if (wave != 0) return;
+  QKV_STAMP();
+#if MPA_QKV_EXP == 3
+  if (tl[0] != 12345.0f) return;
+#endif
+  float ka[16], qb[16], vb[16];
+  const float scale = 1.0f / __builtin_sqrtf((float)DH);
+  const float onf = on ? 1.0f : 0.0f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 k4 = hand[0][g][lane], v4 = hand[1][g][lane];
+    const float kk[4] = {k4.x, k4.y, k4.z, k4.w}, vq[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * g + e;
+      qb[r] = tl[r] * scale * onf;  // torch scales q before the product
+      ka[r] = kk[e] * onf;
+      vb[r] = acc_row(r, h) < P ? vq[e] : 0.0f;
+    }
+  }
+  f32x16 acc = {0};
+#pragma unroll
+  for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s2], qb[s2], acc, 0, 0, 0);
+  // mask + softmax over the keys of query c (as attn_fwd_mfma_kernel)
+  float t[16], m = -__builtin_inff();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    t[r] = kv[r] != 0.0f ? acc[r] : -__builtin_inff();
+    m = __builtin_fmaxf(m, t[r]);
+  }
+  m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+  float z = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    t[r] = __expf(t[r] - m);
+    z += t[r];
+  }
+  z += __shfl_xor(z, 32, 64);
+  const float inv = 1.0f / z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = acc_row(r, h);
+    const bool in = c < P && j < P;
+    const float pj = t[r] * inv;
+    const float keep = keepm[r][lane];
+    if (in) probs[prow + j] = keep != 0.0f ? pj : -pj;  // (the dropout decision rides in the sign bit)
+    t[r] = pj * keep;
+  }
+  f32x16 o = {0};
+#pragma unroll
+  for (int tt = 0; tt < 16; ++tt) o = __builtin_amdgcn_mfma_f32_32x32x2f32(t[tt], vb[tt], o, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = acc_row(r, h);
+    if (i < P) out[((long long)b * P + i) * D + hd * DH + c] = o[r];
+  }
+#if MPA_QKV_EXP == 9
+  QKV_STAMP();
+  if (blockIdx.x == 100 && lane == 0)
+    printf("attn_qkv stamps (s_memtime ticks): loads %llu, LN+stage %llu, chains %llu, reduce %llu, attention %llu\n", ts[1] - ts[0],
+           ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4]);
+#endif
 }
 
 // Backward of the same.  dP = dO V^T is taken in BOTH orientations (two chains over the head dimension): lane = query i
@@ -716,6 +988,15 @@ bool lnb_fused() {
   return on;
 }
 
+// MPA_TF_QKVATTN=0: the qkv GEMM and the attention as two launches (the A/B switch of attn_qkv_fwd_kernel)
+bool qkv_attn_fused() {
+  static const bool on = [] {
+    const char* e = getenv("MPA_TF_QKVATTN");
+    return e == nullptr || e[0] != '0';
+  }();
+  return on;
+}
+
 // MPA_TF_SPLITK=0: the K >= 768 GEMMs as one block per tile (the A/B switch of tf_gemm.h's split-K)
 bool splitk_on() {
   static const bool on = [] {
@@ -876,7 +1157,13 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
     const TfWs& t = w.layer[l];
     const unsigned site0 = (unsigned)(l * S_PER_LAYER);
     GemmArgs g;
-    if (fuse_ln) {  // LN1 inside the qkv GEMM
+    const bool qkv_attn = fuse_ln && P <= 32 && Di / (int)H == 32 && qkv_attn_fused();
+    if (qkv_attn) {  // LN1, the q / k / v projection and the attention of a (sample, head) in one block
+      hipLaunchKernelGGL(attn_qkv_fwd_kernel, dim3((unsigned)(B * H)), dim3(kQT), 0, s, l == 0 ? tokens : t.x_in, pp[P_WQKV],
+                         pp[P_BQKV], pp[P_G1], pp[P_BE1], eps, valid, (int)P, (int)H, drop, site0 + S_ATTN, t.qkv, t.stats1, t.h1,
+                         l == 0 ? t.x_in : (float*)nullptr, t.probs, t.o, l == 0 ? w.sk_ticket : (unsigned*)nullptr,
+                         (int)tfg::kSkTiles);
+    } else if (fuse_ln) {  // LN1 inside the qkv GEMM
       g = gemm_args(l == 0 ? tokens : t.x_in, pp[P_WQKV], pp[P_BQKV], t.qkv, M, 3 * Di, Di);
       g.ln_gamma = pp[P_G1];
       g.ln_beta = pp[P_BE1];
@@ -895,7 +1182,8 @@ extern "C" int mpa_transformer_forward(const float* tokens, const float* valid, 
     }
     // q k^T and attn . v on the matrix cores whenever the tokens fit one 32-row tile (the shipped configs: P = 20, head
     // dim 32); the scalar kernel covers the rest of the envelope (<= 64 tokens, any head dim <= 64)
-    if (P <= 32 && Di / (int)H == 32)
+    if (qkv_attn) {
+    } else if (P <= 32 && Di / (int)H == 32)
       hipLaunchKernelGGL(attn_fwd_mfma_kernel<1>, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, valid, (int)P, Di, (int)H,
                          drop, site0 + S_ATTN, t.probs, t.o);
     else if (P <= 32 && Di / (int)H == 64)
