@@ -383,36 +383,63 @@ __global__ __launch_bounds__(1024) void pn_top_wgrad_kernel(
     const float* __restrict__ y4, const float* __restrict__ bn4, const float* __restrict__ w5,
     const float* __restrict__ coef, const float* __restrict__ gram, int M, int N, int F,
     float* __restrict__ dw5) {
-  constexpr int C4 = 128, S = 8, U = 20;  // 640 slots -> 4 rounds of two dependent load levels per thread
-  __shared__ float sm[S][C4];
+  constexpr int C4 = 128, S = 8, U = 80, CH = S * U;  // parts per chunk: the shipped M = 640 is one
+  __shared__ float sm[2][S][C4];
+  __shared__ int arg_s[CH];    // arg-max row of part m (of this output channel), -1: no contribution
+  __shared__ float g_s[CH];
   const int c = blockIdx.x, ci = threadIdx.x & (C4 - 1), slice = threadIdx.x >> 7;
   const float sc = bn4[ci], sh = bn4[C4 + ci];
-  float acc = 0.0f;
-  for (int m0 = slice; m0 < M; m0 += S * U) {
-    float g[U], yv[U];
-    bool ok[U];
+  // the dense term W5 G of this output channel: every slice takes 16 of the 128 k (requested now, used at the end — on
+  // slice 0 alone it was a chain of 128 dependent FMAs behind four batches of loads at the end of a latency-bound kernel)
+  float wk[C4 / S], gk[C4 / S];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int m = m0 + u * S, mm = m < M ? m : M - 1;
-      const int arg = argmax[(long long)mm * F + c];
-      ok[u] = m < M && valids[mm] != 0.0f && arg >= 0;
-      g[u] = gfeat[(long long)mm * F + c];
-      yv[u] = y4[((long long)mm * N + (arg >= 0 ? arg : 0)) * C4 + ci];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (ok[u]) acc = __builtin_fmaf(g[u], __builtin_fmaxf(__builtin_fmaf(yv[u], sc, sh), 0.0f), acc);
+  for (int k = 0; k < C4 / S; ++k) {
+    wk[k] = w5[(long long)c * C4 + slice * (C4 / S) + k];
+    gk[k] = gram[(slice * (C4 / S) + k) * C4 + ci];
   }
-  sm[slice][ci] = acc;
+  float acc = 0.0f;
+  for (int m0 = 0; m0 < M; m0 += CH) {
+    // level 1, once per part instead of once per (part, input channel): arg-max row and gradient of the chunk's parts
+    if ((int)threadIdx.x < CH) {
+      const int m = m0 + (int)threadIdx.x, mm = m < M ? m : M - 1;
+      const int arg = argmax[(long long)mm * F + c];
+      arg_s[threadIdx.x] = (m < M && valids[mm] != 0.0f && arg >= 0) ? arg : -1;
+      g_s[threadIdx.x] = gfeat[(long long)mm * F + c];
+    }
+    __syncthreads();
+    // level 2: the rows themselves, UB of a thread's requests in flight together (all 80 would need 160 address registers)
+    constexpr int UB = 40;
+#pragma unroll 1
+    for (int u0 = 0; u0 < U; u0 += UB) {
+      float yv[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int i = slice + (u0 + u) * S, arg = arg_s[i], mm = m0 + i < M ? m0 + i : M - 1;
+        yv[u] = y4[((long long)mm * N + (arg >= 0 ? arg : 0)) * C4 + ci];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int i = slice + (u0 + u) * S;
+        if (arg_s[i] >= 0) acc = __builtin_fmaf(g_s[i], __builtin_fmaxf(__builtin_fmaf(yv[u], sc, sh), 0.0f), acc);
+      }
+    }
+    __syncthreads();
+  }
+  float wg = 0.0f;
+#pragma unroll
+  for (int k = 0; k < C4 / S; ++k) wg = __builtin_fmaf(wk[k], gk[k], wg);
+  sm[0][slice][ci] = acc;
+  sm[1][slice][ci] = wg;
   __syncthreads();
   if (slice != 0) return;
   float sparse = 0.0f;
+  wg = 0.0f;
 #pragma unroll
-  for (int k = 0; k < S; ++k) sparse += sm[k][ci];
-  float wg = 0.0f;
-#pragma unroll 32
-  for (int k = 0; k < C4; ++k) wg = __builtin_fmaf(w5[(long long)c * C4 + k], gram[k * C4 + ci], wg);
+  for (int k = 0; k < S; ++k) {
+    sparse += sm[0][k][ci];
+    wg += sm[1][k][ci];
+  }
   dw5[(long long)c * C4 + ci] = coef[c] * sparse + coef[F + c] * wg + coef[2 * F + c] * gram[C4 * C4 + ci];
 }
 
