@@ -19,6 +19,15 @@ struct Drop {
   const unsigned long long* seed_dev;  // if set, the seed is read from device memory (HIP-graph replays)
 };
 
+// The seed of a graph replay lives in device memory.  Kernels resolve it ONCE, at their very top, with this: read inside
+// drop_scale — behind its `p <= 0` test, in unrolled per-element code — every call became a vector load of its own followed by a
+// full wait: sixteen dependent memory round trips in the LayerNorm-backward prologue of the d o GEMM (tools/isa_latency_scan.py).
+__device__ __forceinline__ Drop resolve_seed(Drop d) {
+  if (d.p > 0.0f && d.seed_dev != nullptr) d.seed = *d.seed_dev;  // (wave-uniform address)
+  d.seed_dev = nullptr;
+  return d;
+}
+
 __device__ __forceinline__ float drop_scale(const Drop d, unsigned site, unsigned long long idx) {
   if (d.p <= 0.0f) return 1.0f;
   const unsigned long long seed = d.seed_dev != nullptr ? *d.seed_dev : d.seed;  // wave-uniform scalar load
@@ -30,6 +39,18 @@ __device__ __forceinline__ float drop_scale(const Drop d, unsigned site, unsigne
   x ^= x >> 31;
   const float u = (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f);  // 24 random bits -> [0, 1)
   return u < d.p ? 0.0f : d.scale;
+}
+
+// Sum over the 32 lanes of a half-wave, returned to all of them: four DPP additions inside the rows of 16 and ONE exchange
+// between the two rows (the five-step `__shfl_xor` butterfly is five dependent LDS permutes, ~100 cycles each — the fused
+// LayerNorm prologues run four of those chains per row pair).
+__device__ __forceinline__ float half_sum(float v) {
+  auto add = [](float a, int bits) { return a + __int_as_float(bits); };
+  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v + __shfl_xor(v, 16, 64);
 }
 
 // ---- GEMM  C[M,N] = epi(A[M,K] . W[N,K]^T + bias) ---------------------------------------------------------------------
@@ -109,6 +130,7 @@ __host__ __device__ inline int gemm_phase(int K) {
 template <int EPI, bool WT, int NPH, int LNM = 0, bool SK = false>
 __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
   static_assert(!SK || (NPH > 0 && LNM == 0 && EPI != EPI_STATS), "split-K: whole phases, plain operands");
+  const Drop drop = (EPI == EPI_RELU_DROP || EPI == EPI_DROP_RESID || LNM == 2) ? resolve_seed(g.drop) : g.drop;
   const int kz = SK ? (int)blockIdx.z * NPH : 0;  // first K phase of this block
   constexpr bool LNF = LNM == 1;
   static_assert(LNM == 0 || NPH == 2, "the fused LayerNorm needs the whole K = 2 x 128 row in registers");
@@ -190,8 +212,7 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
         float sum = 0.0f;
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) sum += (st[ph].a[i].x + st[ph].a[i].y) + (st[ph].a[i].z + st[ph].a[i].w);
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        sum = half_sum(sum);
         const float mean = sum / (float)(NPH * kKP);
         float var = 0.0f;
 #pragma unroll
@@ -200,8 +221,7 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
                       dw = st[ph].a[i].w - mean;
           var += (dx * dx + dy * dy) + (dz * dz + dw * dw);
         }
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) var += __shfl_xor(var, off, 64);
+        var = half_sum(var);
         const float rstd = 1.0f / __builtin_sqrtf(var / (float)(NPH * kKP) + g.ln_eps);
         const int row = r0 + (threadIdx.x >> 5) + 16 * i;
         const bool save = blockIdx.y == 0 && row < g.M;
@@ -237,35 +257,48 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
         pxh[ph] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         pg[ph] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
+      // every operand of the prologue is requested here, in one round trip (read where they are used — the residual behind
+      // its null test, inside the loops — they were a dozen dependent waits in front of the block's MFMA chain)
+      float4 lx[kFI][NPH], lr[kFI][NPH];
+      float lmean[kFI], lrstd[kFI];
+      const float* rsrc = g.ln_resid != nullptr ? g.ln_resid : g.ln_x;  // (no residual: a valid address, the value is dropped)
 #pragma unroll
       for (int i = 0; i < kFI; ++i) {
         const int row = r0 + (threadIdx.x >> 5) + 16 * i, rr = row < g.M ? row : g.M - 1;
-        const float mean = g.ln_stats[2 * rr], rstd = g.ln_stats[2 * rr + 1];
+        const long long o = (long long)rr * g.K + 4 * c4;
+        lmean[i] = g.ln_stats[2 * rr];
+        lrstd[i] = g.ln_stats[2 * rr + 1];
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+          lx[i][ph] = *reinterpret_cast<const float4*>(g.ln_x + o + ph * kKP);
+          lr[i][ph] = *reinterpret_cast<const float4*>(rsrc + o + ph * kKP);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kFI; ++i) {
+        const int row = r0 + (threadIdx.x >> 5) + 16 * i, rr = row < g.M ? row : g.M - 1;
+        const float mean = lmean[i], rstd = lrstd[i];
         const long long o = (long long)rr * g.K + 4 * c4;
         float4 xh[NPH];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
-          const float4 x = *reinterpret_cast<const float4*>(g.ln_x + o + ph * kKP);
+          const float4 x = lx[i][ph];
           const float4 dh = st[ph].a[i];
           xh[ph] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
           const float dx = dh.x * gm[ph].x, dy = dh.y * gm[ph].y, dz = dh.z * gm[ph].z, dw = dh.w * gm[ph].w;
           s1 += (dx + dy) + (dz + dw);
           s2 += (dx * xh[ph].x + dy * xh[ph].y) + (dz * xh[ph].z + dw * xh[ph].w);
         }
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-          s1 += __shfl_xor(s1, off, 64);
-          s2 += __shfl_xor(s2, off, 64);
-        }
+        s1 = half_sum(s1);
+        s2 = half_sum(s2);
         s1 /= (float)(NPH * kKP);
         s2 /= (float)(NPH * kKP);
         const bool save = col0 && row < g.M;
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
           const float4 dh = st[ph].a[i];
-          float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          if (g.ln_resid != nullptr) v = *reinterpret_cast<const float4*>(g.ln_resid + o + ph * kKP);
+          float4 v = g.ln_resid != nullptr ? lr[i][ph] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           v.x += rstd * (dh.x * gm[ph].x - s1 - xh[ph].x * s2);
           v.y += rstd * (dh.y * gm[ph].y - s1 - xh[ph].y * s2);
           v.z += rstd * (dh.z * gm[ph].z - s1 - xh[ph].z * s2);
@@ -273,10 +306,10 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
           float4 m = v;
           if (g.ln_dxdrop != nullptr) {
             const unsigned long long e = (unsigned long long)(o + ph * kKP);
-            m.x *= drop_scale(g.drop, g.ln_site, e);
-            m.y *= drop_scale(g.drop, g.ln_site, e + 1);
-            m.z *= drop_scale(g.drop, g.ln_site, e + 2);
-            m.w *= drop_scale(g.drop, g.ln_site, e + 3);
+            m.x *= drop_scale(drop, g.ln_site, e);
+            m.y *= drop_scale(drop, g.ln_site, e + 1);
+            m.z *= drop_scale(drop, g.ln_site, e + 2);
+            m.w *= drop_scale(drop, g.ln_site, e + 3);
           }
           st[ph].a[i] = m;
           if (save) {
@@ -375,9 +408,9 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
     float v = tot[it] + bias;
     const long long o = (long long)orow * g.N + n0 + col;
     if constexpr (EPI == EPI_RELU_DROP) {
-      v = __builtin_fmaxf(v, 0.0f) * drop_scale(g.drop, g.epi_site, (unsigned long long)o);
+      v = __builtin_fmaxf(v, 0.0f) * drop_scale(drop, g.epi_site, (unsigned long long)o);
     } else if constexpr (EPI == EPI_DROP_RESID) {
-      v = g.resid[o] + v * drop_scale(g.drop, g.epi_site, (unsigned long long)o);
+      v = g.resid[o] + v * drop_scale(drop, g.epi_site, (unsigned long long)o);
     } else if constexpr (EPI == EPI_LEAKY) {
       v = v > 0.0f ? v : 0.2f * v;
     } else if constexpr (EPI == EPI_RELU_MASK) {

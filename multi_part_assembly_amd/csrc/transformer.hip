@@ -26,25 +26,9 @@ constexpr int kT = 256;
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return mpa::wave_sum_dpp(v); }  // (common.h: DPP, no LDS permutes)
 
-// the same sum on the DPP network (quad permutes, row mirrors, row broadcasts: six VALU operations, no LDS round trips; the
-// addition order differs from wave_sum's butterfly)
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  auto add = [](float a, int bits) { return a + __int_as_float(bits); };
-  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
-  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror: a row's 16 lanes hold its sum
-  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false)); // row_bcast15 into rows 1, 3
-  v = add(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false)); // row_bcast31 into rows 2, 3
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
+using mpa::wave_sum_dpp;
 template <typename T>
 __device__ __forceinline__ const T* opaque(const T* p) {
   asm volatile("" : "+v"(p));
@@ -196,8 +180,9 @@ constexpr int kMaxP = 64, kMaxDh = 64, kAT = 256;
 // qkv [B*P, 3D] (q | k | v), valid [B*P]; probs [B, H, P, P] (post-softmax, pre-dropout); out [B*P, D]
 __global__ __launch_bounds__(kAT) void attn_fwd_kernel(const float* __restrict__ qkv,
                                                       const float* __restrict__ valid, int P, int D, int H,
-                                                      Drop drop, unsigned site, float* __restrict__ probs,
+                                                      Drop drop_in, unsigned site, float* __restrict__ probs,
                                                       float* __restrict__ out) {
+  const Drop drop = resolve_seed(drop_in);
   __shared__ float q[kMaxP][kMaxDh + 1], k[kMaxP][kMaxDh + 1], v[kMaxP][kMaxDh + 1], s[kMaxP][kMaxP + 1];
   const int b = blockIdx.x / H, hd = blockIdx.x % H, dh = D / H, t = threadIdx.x;
   const float scale = 1.0f / __builtin_sqrtf((float)dh);
@@ -246,7 +231,8 @@ __global__ __launch_bounds__(kAT) void attn_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(kAT) void attn_bwd_kernel(const float* __restrict__ qkv,
                                                       const float* __restrict__ probs,
                                                       const float* __restrict__ dout, int P, int D, int H,
-                                                      Drop drop, unsigned site, float* __restrict__ dqkv) {
+                                                      Drop drop_in, unsigned site, float* __restrict__ dqkv) {
+  const Drop drop = resolve_seed(drop_in);
   __shared__ float q[kMaxP][kMaxDh + 1], k[kMaxP][kMaxDh + 1], v[kMaxP][kMaxDh + 1], go[kMaxP][kMaxDh + 1];
   __shared__ float pd[kMaxP][kMaxP + 1], ds[kMaxP][kMaxP + 1];
   const int b = blockIdx.x / H, hd = blockIdx.x % H, dh = D / H, t = threadIdx.x;
@@ -311,8 +297,9 @@ __global__ __launch_bounds__(kAT) void attn_bwd_kernel(const float* __restrict__
 // Rows / keys >= P of the padded tile are zeros / masked; padded keys (valid == 0) are masked as in the reference.
 template <int NT>
 __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ valid,
-                                                           int P, int D, int H, Drop drop, unsigned site,
+                                                           int P, int D, int H, Drop drop_in, unsigned site,
                                                            float* __restrict__ probs, float* __restrict__ out) {
+  const Drop drop = resolve_seed(drop_in);
   constexpr int DH = 32 * NT, KH = DH / 2;
   const int b = blockIdx.x / H, hd = blockIdx.x % H, lane = threadIdx.x, c = lane & 31, h = lane >> 5;
   const float scale = 1.0f / __builtin_sqrtf((float)DH);
@@ -337,7 +324,9 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const float* __restri
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int j = acc_row(r, h);
-    kv[r] = (j < P && valid[b * P + j] == 1.0f) ? 1.0f : 0.0f;  // a real part iff == 1 (network.py: part_valids == 1)
+    // a real part iff == 1 (network.py: part_valids == 1).  An unconditional load of a clamped position: behind `j < P &&`
+    // each of the sixteen was a branch with a full wait of its own
+    kv[r] = (valid[b * P + (j < P ? j : 0)] == 1.0f && j < P) ? 1.0f : 0.0f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       vb[nt][r] = j < P ? qkv[(long long)(b * P + j) * 3 * D + 2 * D + hd * DH + 32 * nt + c] : 0.0f;
@@ -453,9 +442,7 @@ __global__ __launch_bounds__(kQT, 2) void attn_qkv_fwd_kernel(const float* __res
   const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * lane), bt = *reinterpret_cast<const float4*>(beta + 4 * lane);
   // (the dropout seed of a graph replay lives in device memory: requested here, with everything else — read where the hash
   // needs it, it is a memory round trip in the middle of the reduction)
-  Drop dl = drop;
-  if (drop.p > 0.0f && drop.seed_dev != nullptr) dl.seed = *drop.seed_dev;
-  dl.seed_dev = nullptr;
+  const Drop dl = resolve_seed(drop);
   // wave 0 also requests what its attention needs later: the key mask and the three bias runs
   // (every wave, unconditional loads of clamped positions: behind `wave == 0` and `j < P &&` the compiler made each of the
   // sixteen mask loads a branch of its own with a full wait — 9 us of dependent round trips)
@@ -769,7 +756,8 @@ __global__ __launch_bounds__(kT) void ln_bwd_kernel(const float* __restrict__ dh
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ resid, int M, int D,
                                                     float* __restrict__ dx, float* __restrict__ part,
-                                                    const Drop drop, unsigned site, float* __restrict__ dx_drop) {
+                                                    const Drop drop_in, unsigned site, float* __restrict__ dx_drop) {
+  const Drop drop = resolve_seed(drop_in);
   extern __shared__ float sm[];  // [4 waves][2][D]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * (kT / 64) + wave;
