@@ -131,6 +131,15 @@ template <int EPI, bool WT, int NPH, int LNM = 0, bool SK = false>
 __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
   static_assert(!SK || (NPH > 0 && LNM == 0 && EPI != EPI_STATS), "split-K: whole phases, plain operands");
   const Drop drop = (EPI == EPI_RELU_DROP || EPI == EPI_DROP_RESID || LNM == 2) ? resolve_seed(g.drop) : g.drop;
+#ifdef MPA_GEMM_STAMPS  // s_memtime stamps of one block of the FFN-up GEMM (EPI_RELU_DROP with the fused LayerNorm), printed
+  constexpr bool kStamp = EPI == EPI_RELU_DROP && LNM == 1;
+  unsigned long long ts[8];
+  int nts = 0;
+#define GEMM_STAMP() do { if (kStamp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[nts++] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define GEMM_STAMP() do { } while (0)
+#endif
+  GEMM_STAMP();
   const int kz = SK ? (int)blockIdx.z * NPH : 0;  // first K phase of this block
   constexpr bool LNF = LNM == 1;
   static_assert(LNM == 0 || NPH == 2, "the fused LayerNorm needs the whole K = 2 x 128 row in registers");
@@ -198,6 +207,7 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
     Stage st[NPH];
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) fetch(ph, st[ph]);
+    GEMM_STAMP();
     if constexpr (LNF) {
       // thread t holds, per phase, columns 4 (t % 32) .. + 3 of rows t / 32 and 16 + t / 32: a row lives in one half-wave
       const int c4 = threadIdx.x & 31;
@@ -343,6 +353,7 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
         __syncthreads();
       }
     }
+    GEMM_STAMP();
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
       stash(ph, st[ph], ph % kBuf);
@@ -362,6 +373,7 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
       __syncthreads();
     }
   }
+  GEMM_STAMP();
   float(*red)[16][64] = reinterpret_cast<float(*)[16][64]>(lds);  // 32 KB, the panels are dead
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
@@ -425,6 +437,12 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
     }
     g.C[o] = v;
   }
+#ifdef MPA_GEMM_STAMPS
+  GEMM_STAMP();
+  if (kStamp && ((blockIdx.x == 5 && blockIdx.y == 7) || (blockIdx.x + blockIdx.y * gridDim.x) % 97 == 0) && threadIdx.x == 0)
+    printf("gemm stamps block (%d, %d) start %llu (s_memtime ticks): loads %llu, prologue %llu, stash + chains %llu, reduce + epilogue %llu\n",
+           (int)blockIdx.x, (int)blockIdx.y, ts[0] % 10000000ull, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3]);
+#endif
   if constexpr (EPI == EPI_STATS) {  // column sums of the 32 x 32 tile, rows in ascending order
     __syncthreads();                 // every partial tile has been read
     float(*tile)[33] = reinterpret_cast<float(*)[33]>(lds);
