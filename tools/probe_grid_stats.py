@@ -30,7 +30,7 @@ fn(buf, 1)
 trainer.train_step(batch, 5)
 torch.cuda.synchronize()
 fn(buf, 1)
-items, lanes, calls, cand, lng = buf[0], buf[1], buf[2], buf[3], buf[4]
+items, lanes, calls, cand, lng = max(buf[0], 1), buf[1], buf[2], buf[3], buf[4]
 queries = 2 * 1000 * sum(num_parts)
 print(f"queries {queries}  work items {items}  active lanes/item {lanes / items:.1f} of 64  scan batches/item {calls / items:.1f}")
 print(f"candidate records per item {cand / items:.0f} ({lng / max(1, cand):.0%} in long contiguous ranges)  "
