@@ -97,7 +97,9 @@ struct GemmArgs {
   // partial tile in sk_buf and takes the tile's ticket; the second block to arrive adds the two halves (lower half first,
   // whichever arrived first) and runs the epilogue.  The half tiles cross XCDs as agent-scope atomic stores / loads ordered
   // by the ticket (coop_reduce.h's hand-over: a release FENCE per block is a write-back of the XCD's L2 and made this
-  // kernel 3 x slower, LABBOOK 5.3 xvii).  Tickets are zero between launches (reset after use).
+  // kernel 3 x slower, LABBOOK 5.3 xvii; -DMPA_TF_SK_FENCE=1 builds that textbook form: the fallback should a part or a
+  // compiler ever stop acknowledging sc1 stores at agent scope — tests/test_model_gpu.py holds the hand-over to bit-equal
+  // results over hundreds of launches).  Tickets are zero between launches (reset after use).
   float* sk_buf;        // [tiles][2][1024]
   unsigned* sk_ticket;  // [tiles]
   int zero_n;           // words of `zero` to clear (0: 64)
@@ -114,6 +116,9 @@ struct GemmArgs {
 // partial tiles meet in LDS (fixed order) and the epilogue writes 128-byte row segments.
 // Requires N % 32 == 0 and K % 64 == 0.
 // WT: the weight is given as W^T, i.e. [K, N] row-major (input gradients reuse the forward weights untransposed).
+#ifndef MPA_TF_SK_FENCE
+#define MPA_TF_SK_FENCE 0
+#endif
 constexpr int kGW = 8, kGT = kGW * 64, kKP = 128, kLD = kKP + 4;
 
 __host__ __device__ inline int gemm_phase(int K) {
@@ -396,9 +401,15 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
     __shared__ int sk_last;
     const long long tile = (long long)blockIdx.x * gridDim.y + blockIdx.y;
     float* mine = g.sk_buf + (tile * 2 + blockIdx.z) * 1024;
+#if MPA_TF_SK_FENCE  // the textbook form (A/B and fallback builds): plain stores, agent-scope release / acquire fences
+    mine[threadIdx.x] = tot[0];
+    mine[kGT + threadIdx.x] = tot[1];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
     __hip_atomic_store(mine + threadIdx.x, tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(mine + kGT + threadIdx.x, tot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through and acknowledged before the ticket is taken
+#endif
     __syncthreads();
     if (threadIdx.x == 0) {
       const unsigned old = atomicAdd(g.sk_ticket + tile, 1u);
@@ -408,8 +419,13 @@ __global__ __launch_bounds__(kGT) void gemm_kernel(const GemmArgs g) {
     __syncthreads();
     if (!sk_last) return;
     const float* other = g.sk_buf + (tile * 2 + (1 - blockIdx.z)) * 1024;
+#if MPA_TF_SK_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const float o0 = other[threadIdx.x], o1 = other[kGT + threadIdx.x];
+#else
     const float o0 = __hip_atomic_load(other + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float o1 = __hip_atomic_load(other + kGT + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     tot[0] = blockIdx.z == 0 ? tot[0] + o0 : o0 + tot[0];  // lower half of K first, whoever finishes
     tot[1] = blockIdx.z == 0 ? tot[1] + o1 : o1 + tot[1];
   }

@@ -343,6 +343,37 @@ def test_transformer_and_pose_head_full_size_match_library_ops(cuda_device):
     assert torch.equal(f1, f2) and torch.equal(gx1, gx2) and all(torch.equal(g1[k], g2[k]) for k in g1)
 
 
+def test_transformer_cross_block_hand_overs_are_stable_over_many_launches(cuda_device):
+    """The split-K GEMMs hand half tiles from block to block (and XCD to XCD) with agent-scope stores ordered by a ticket —
+    no fence (tf_gemm.h); the fused attention kernel hands tiles from wave to wave through LDS.  A stale tile would be a
+    silent numeric error that differs from launch to launch: 300 forward + backward launches at the benchmark's shape with
+    dropout ON and a fixed seed, every output and gradient bit-equal to the first launch's."""
+    torch.manual_seed(11)
+    B, P, D, H, FF, L = 32, 20, 256, 8, 1024, 4
+    enc = TransformerEncoder(D, H, FF, L, norm_first=True, dropout=0.1).to(cuda_device).train()
+    g = torch.Generator().manual_seed(5)
+    num = torch.randint(2, P + 1, (B,), generator=g)
+    valid = (torch.arange(P)[None] < num[:, None]).to(cuda_device)
+    tok = (torch.randn(B, P, D, generator=g) * valid.cpu()[..., None]).to(cuda_device)
+    w = torch.randn(B, P, D, generator=g).to(cuda_device)
+
+    def run():
+        for p in enc.parameters():
+            p.grad = None
+        enc._calls = 0  # the call's dropout seed is a hash of torch's seed and this counter: the same masks every time
+        x = tok.clone().requires_grad_()
+        feats = enc(x, valid)
+        (feats * w * valid[..., None].float()).sum().backward()
+        return [feats.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in enc.parameters()]
+
+    first = run()
+    assert all(torch.isfinite(t).all() for t in first)
+    for it in range(300):
+        again = run()
+        for k, (a, b) in enumerate(zip(first, again)):
+            assert torch.equal(a, b), (it, k)
+
+
 @pytest.mark.parametrize("arch,N", [("pointnet", 333), ("dgcnn", 200)])
 def test_encoders_without_any_valid_part_give_zeros(cuda_device, arch, N):
     """A call in which every part is padding (found by tools/fuzz_parity.py: PointNet's BatchNorm divided by the zero
