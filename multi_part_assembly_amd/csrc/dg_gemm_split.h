@@ -55,9 +55,29 @@ constexpr int kGsRow = 208;             // bytes per LDS row: 3 planes x 32 bf16
 struct Split4 {
   gs_bf16x4 h, m, l;
 };
+#ifndef DG_GS_SPLIT_PK  // 1: the split on register pairs (v_cvt_pk_bf16_f32 + v_pk_add_f32: ~4.5 VALU operations per element,
+#define DG_GS_SPLIT_PK 1  // the same bits); 0: element by element (~8; rounds 3-5)
+#endif
+typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 gs_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Split4 gs_split(const float4 v) {
-  const float f[4] = {v.x, v.y, v.z, v.w};
   Split4 s;
+#if DG_GS_SPLIT_PK
+  auto split2 = [](gs_f32x2 x, gs_bf16x2& h, gs_bf16x2& m, gs_bf16x2& l) {
+    h = __builtin_convertvector(x, gs_bf16x2);
+    const gs_f32x2 r = x - __builtin_convertvector(h, gs_f32x2);
+    m = __builtin_convertvector(r, gs_bf16x2);
+    const gs_f32x2 t = r - __builtin_convertvector(m, gs_f32x2);
+    l = __builtin_convertvector(t, gs_bf16x2);
+  };
+  gs_bf16x2 h0, m0, l0, h1, m1, l1;
+  split2(gs_f32x2{v.x, v.y}, h0, m0, l0);
+  split2(gs_f32x2{v.z, v.w}, h1, m1, l1);
+  s.h = gs_bf16x4{h0[0], h0[1], h1[0], h1[1]};
+  s.m = gs_bf16x4{m0[0], m0[1], m1[0], m1[1]};
+  s.l = gs_bf16x4{l0[0], l0[1], l1[0], l1[1]};
+#else
+  const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     s.h[u] = (__bf16)f[u];
@@ -65,6 +85,7 @@ __device__ __forceinline__ Split4 gs_split(const float4 v) {
     s.m[u] = (__bf16)r1;
     s.l[u] = (__bf16)(r1 - (float)s.m[u]);
   }
+#endif
   return s;
 }
 // one thread's float4 (columns 4 c4 .. 4 c4 + 3 of the chunk) -> the three planes of LDS row `row`
