@@ -744,6 +744,246 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const float* __restri
   }
 }
 
+// ---- LayerNorm-2 backward + d o product + attention backward of ONE (sample, head) in one block (D = 256, head dim 32, P <= 32) ----
+// The backward twin of attn_qkv_fwd_kernel.  The attention's gradient needs d o [tokens of the sample][32 columns of the head]
+// = (masked d x_mid) [tokens][256] . Wo[256][head's columns], and d x_mid is the LayerNorm backward of rows the block can
+// normalise itself.  Eight waves: rows by coalesced loads (a wave holds a whole row: the two row means are DPP sums), the
+// dropout mask regenerated per element (as the LayerNorm-backward prologue of the d o GEMM did: the same redundancy, 8 heads
+// per sample against 8 column tiles per row tile), the masked rows and the head's Wo slice (transposed while it is stored) in
+// padded LDS panels, K = 256 split over the waves, TWO MFMA chains per wave: d o straight (A = token row, B = weight row:
+// lane (c, h) ends with d o[token acc_row(r, h)][feature c], the B operand of the three token-index chains) and d o
+// TRANSPOSED (lane = token c, features acc_row(r, h): the operand of the two head-dimension chains, whose k index is
+// enumerated in that order on both operands).  Partial tiles meet in LDS; wave 0 runs attn_bwd_mfma_kernel's arithmetic.
+// Head 0's block writes what the standalone LayerNorm backward would have written: d x_mid, its masked copy, and the
+// sample's dgamma / dbeta partial row (ln_part[sample]: the reduction kernel is told B rows for this site).
+// 14.6 us against 9.0 + 7.8 us and a launch boundary (-DMPA_QKV_EXP=9 stamps of a block, in us: requests 3.7 — the saved
+// probabilities come from HBM —, LayerNorm backward + masks + panels 2.6, chains 0.6, reduction 2.2, attention 3.9).
+constexpr int kBT = 512;
+__global__ __launch_bounds__(kBT, 2) void attn_do_bwd_kernel(
+    const float* __restrict__ dh, const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+    const float* __restrict__ resid, float* __restrict__ ln_dx, float* __restrict__ ln_dxdrop, float* __restrict__ ln_part,
+    unsigned ln_site, const float* __restrict__ wo, const float* __restrict__ qkv, const float* __restrict__ probs, int P, int H,
+    Drop drop_in, unsigned site, float* __restrict__ dqkv) {
+  constexpr int D = 256, DH = 32;
+  __shared__ __attribute__((aligned(16))) float panel[64 * kQLD];  // rows 0..31: masked d x rows; 32..63: Wo^T slice [feature][k]
+  __shared__ float4 hand[4][64];
+  __shared__ float colp[8][2][D];  // head 0: the waves' column partials of dh xhat | dh
+  float4(*part)[4][8][64] = reinterpret_cast<float4(*)[4][8][64]>(panel);
+  static_assert(sizeof(float4) * 2 * 4 * 8 * 64 <= sizeof(float) * 64 * kQLD, "the partial tiles fit the panels");
+  const Drop drop = resolve_seed(drop_in);
+#if MPA_QKV_EXP == 9
+  unsigned long long ts[8];
+  int nts = 0;
+#endif
+  QKV_STAMP();
+  const int b = blockIdx.x / H, hd = blockIdx.x % H;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const long long row0 = (long long)b * P;
+  // ---- requests: the block's rows (wave + 8 i), the weight slice, and what wave 0's attention needs
+  float4 dh4[4], x4[4], r4[4];
+  float mean[4], rstd[4];
+  const float* rsrc = resid != nullptr ? resid : x;  // (no residual: a valid address, the value is dropped — a conditional load is a
+                                                     // branch with a full wait per row)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave + 8 * i;
+    const long long tok = row0 + (row < P ? row : 0);
+    dh4[i] = *reinterpret_cast<const float4*>(dh + tok * D + 4 * lane);
+    x4[i] = *reinterpret_cast<const float4*>(x + tok * D + 4 * lane);
+    r4[i] = *reinterpret_cast<const float4*>(rsrc + tok * D + 4 * lane);
+    mean[i] = stats[2 * tok];
+    rstd[i] = stats[2 * tok + 1];
+  }
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * lane);
+  float4 wv[4];  // Wo rows k = (t + 512 i) / 8, columns hd DH + 4 ((t + 512 i) % 8) .. + 3
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = threadIdx.x + kBT * i;
+    wv[i] = *reinterpret_cast<const float4*>(wo + (long long)(f >> 3) * D + hd * DH + 4 * (f & 7));
+  }
+  const bool on = c < P;
+  const long long tokc = row0 + (on ? c : 0);
+  const long long pbase = (long long)(b * H + hd) * P * P;
+  float va[16], pa_[16], pb_[16], kb0[16], qb0[16];
+  if (wave == 0) {  // (wave-uniform; unconditional loads of clamped positions inside)
+    const float onf = on ? 1.0f : 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // V[token c][features 8 g + 4 h ..]: the enumeration of the transposed d o tile
+      const float4 v4 = *reinterpret_cast<const float4*>(qkv + tokc * 3 * D + 2 * D + hd * DH + 8 * g + 4 * h);
+      va[4 * g] = v4.x * onf, va[4 * g + 1] = v4.y * onf, va[4 * g + 2] = v4.z * onf, va[4 * g + 3] = v4.w * onf;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int xr = acc_row(r, h), xc = xr < P ? xr : 0;
+      const bool in = c < P && xr < P;
+      const float p1 = probs[pbase + (long long)(on ? c : 0) * P + xc], p2 = probs[pbase + (long long)xc * P + (on ? c : 0)];
+      pa_[r] = in ? p1 : -0.0f;  // sign bit set: dropped (see the forward kernel)
+      pb_[r] = in ? p2 : -0.0f;
+      const long long tk = row0 + xc;
+      const float o2 = xr < P ? 1.0f : 0.0f;
+      qb0[r] = qkv[tk * 3 * D + hd * DH + c] * o2;
+      kb0[r] = qkv[tk * 3 * D + D + hd * DH + c] * o2;
+    }
+  }
+  QKV_STAMP();
+  // ---- LayerNorm backward of the rows, dropout mask, panel
+  float4 pxh = make_float4(0.f, 0.f, 0.f, 0.f), pg = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave + 8 * i;
+    const bool live = row < P;
+    const float4 d4 = dh4[i];
+    const float4 xh = make_float4((x4[i].x - mean[i]) * rstd[i], (x4[i].y - mean[i]) * rstd[i], (x4[i].z - mean[i]) * rstd[i],
+                                  (x4[i].w - mean[i]) * rstd[i]);
+    const float dx = d4.x * gm.x, dy = d4.y * gm.y, dz = d4.z * gm.z, dw = d4.w * gm.w;
+    const float s1 = wave_sum_dpp((dx + dy) + (dz + dw)) * (1.0f / (float)D);
+    const float s2 = wave_sum_dpp((dx * xh.x + dy * xh.y) + (dz * xh.z + dw * xh.w)) * (1.0f / (float)D);
+    float4 v = resid != nullptr ? r4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    v.x += rstd[i] * (dx - s1 - xh.x * s2);
+    v.y += rstd[i] * (dy - s1 - xh.y * s2);
+    v.z += rstd[i] * (dz - s1 - xh.z * s2);
+    v.w += rstd[i] * (dw - s1 - xh.w * s2);
+    float4 m = v;
+    const long long o = (row0 + (live ? row : 0)) * D + 4 * lane;
+    if (ln_dxdrop != nullptr) {
+      m.x *= drop_scale(drop, ln_site, (unsigned long long)o);
+      m.y *= drop_scale(drop, ln_site, (unsigned long long)o + 1);
+      m.z *= drop_scale(drop, ln_site, (unsigned long long)o + 2);
+      m.w *= drop_scale(drop, ln_site, (unsigned long long)o + 3);
+    }
+    *reinterpret_cast<float4*>(panel + row * kQLD + 4 * lane) = live ? m : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hd == 0 && live) {
+      *reinterpret_cast<float4*>(ln_dx + o) = v;
+      if (ln_dxdrop != nullptr) *reinterpret_cast<float4*>(ln_dxdrop + o) = m;
+      pxh.x += d4.x * xh.x, pxh.y += d4.y * xh.y, pxh.z += d4.z * xh.z, pxh.w += d4.w * xh.w;
+      pg.x += d4.x, pg.y += d4.y, pg.z += d4.z, pg.w += d4.w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // Wo^T slice: panel row 32 + feature, column k
+    const int f = threadIdx.x + kBT * i, k = f >> 3, n = 4 * (f & 7);
+    panel[(32 + n) * kQLD + k] = wv[i].x;
+    panel[(33 + n) * kQLD + k] = wv[i].y;
+    panel[(34 + n) * kQLD + k] = wv[i].z;
+    panel[(35 + n) * kQLD + k] = wv[i].w;
+  }
+  if (hd == 0) {
+    *reinterpret_cast<float4*>(&colp[wave][0][4 * lane]) = pxh;
+    *reinterpret_cast<float4*>(&colp[wave][1][4 * lane]) = pg;
+  }
+  __syncthreads();
+  if (hd == 0) {  // the sample's partial row of dgamma | dbeta: the eight waves in order (thread = column of [2 D])
+    const int k = threadIdx.x;
+    float sm = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sm += colp[w][k >> 8][k & 255];
+    ln_part[(long long)b * 2 * D + k] = sm;
+  }
+  QKV_STAMP();
+  // ---- two chains per wave over its eighth of K: k = 32 wave + 8 v + 4 h + e
+  f32x16 as = {0}, at = {0};
+  {
+    const float* pm = panel + c * kQLD + 32 * wave + 4 * h;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float4 m4 = *reinterpret_cast<const float4*>(pm + 8 * v);
+      const float4 w4 = *reinterpret_cast<const float4*>(pm + 32 * kQLD + 8 * v);
+      as = __builtin_amdgcn_mfma_f32_32x32x2f32(m4.x, w4.x, as, 0, 0, 0);
+      at = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, m4.x, at, 0, 0, 0);
+      as = __builtin_amdgcn_mfma_f32_32x32x2f32(m4.y, w4.y, as, 0, 0, 0);
+      at = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, m4.y, at, 0, 0, 0);
+      as = __builtin_amdgcn_mfma_f32_32x32x2f32(m4.z, w4.z, as, 0, 0, 0);
+      at = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, m4.z, at, 0, 0, 0);
+      as = __builtin_amdgcn_mfma_f32_32x32x2f32(m4.w, w4.w, as, 0, 0, 0);
+      at = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, m4.w, at, 0, 0, 0);
+    }
+  }
+  QKV_STAMP();
+  __syncthreads();  // every wave is done with the panels: their memory takes the partial tiles
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    part[0][g][wave][lane] = make_float4(as[4 * g], as[4 * g + 1], as[4 * g + 2], as[4 * g + 3]);
+    part[1][g][wave][lane] = make_float4(at[4 * g], at[4 * g + 1], at[4 * g + 2], at[4 * g + 3]);
+  }
+  __syncthreads();
+  if (wave >= 2) return;  // (the barrier below is reached by the two waves that are left)
+  float tl[16];  // wave 0: d o transposed (the head-dimension chains' operand); wave 1: d o straight, handed over
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float4 a = part[1 - wave][g][0][lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {
+      const float4 p4 = part[1 - wave][g][w][lane];
+      a.x += p4.x, a.y += p4.y, a.z += p4.z, a.w += p4.w;
+    }
+    tl[4 * g] = a.x, tl[4 * g + 1] = a.y, tl[4 * g + 2] = a.z, tl[4 * g + 3] = a.w;
+    if (wave == 1) hand[g][lane] = a;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  QKV_STAMP();
+  float gb0[16];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 t4 = hand[g][lane];
+    gb0[4 * g] = t4.x, gb0[4 * g + 1] = t4.y, gb0[4 * g + 2] = t4.z, gb0[4 * g + 3] = t4.w;
+  }
+  // ---- attention backward (attn_bwd_mfma_kernel<1>, with the head-dimension index enumerated in accumulator order)
+  const float scale = 1.0f / __builtin_sqrtf((float)DH);
+  const float keep = drop.p > 0.0f ? drop.scale : 1.0f;
+  f32x16 ga_acc = {0}, gb_acc = {0};
+#pragma unroll
+  for (int s2 = 0; s2 < 16; ++s2) {
+    ga_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s2], tl[s2], ga_acc, 0, 0, 0);
+    gb_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tl[s2], va[s2], gb_acc, 0, 0, 0);
+  }
+  float dsa[16], rowdot = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float pa = __builtin_fabsf(pa_[r]);
+    const float dp = ga_acc[r] * (__float_as_uint(pa_[r]) >> 31 ? 0.0f : keep);
+    rowdot = __builtin_fmaf(dp, pa, rowdot);
+    dsa[r] = dp;
+    ga_acc[r] = pa;
+  }
+  rowdot += __shfl_xor(rowdot, 32, 64);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dsa[r] = ga_acc[r] * (dsa[r] - rowdot);
+  float dsb[16], pdb[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = acc_row(r, h);
+    const float pb = __builtin_fabsf(pb_[r]);
+    const float mk = __float_as_uint(pb_[r]) >> 31 ? 0.0f : keep;
+    const float rd = __shfl(rowdot, i, 64);
+    dsb[r] = pb * (gb_acc[r] * mk - rd);
+    pdb[r] = pb * mk;
+  }
+  f32x16 dq = {0}, dk = {0}, dv = {0};
+#pragma unroll
+  for (int tt = 0; tt < 16; ++tt) {
+    dq = __builtin_amdgcn_mfma_f32_32x32x2f32(dsa[tt], kb0[tt], dq, 0, 0, 0);
+    dk = __builtin_amdgcn_mfma_f32_32x32x2f32(dsb[tt], qb0[tt], dk, 0, 0, 0);
+    dv = __builtin_amdgcn_mfma_f32_32x32x2f32(pdb[tt], gb0[tt], dv, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int xr = acc_row(r, h);
+    if (xr < P) {
+      float* dst = dqkv + (row0 + xr) * 3 * D + hd * DH + c;
+      dst[0] = dq[r] * scale;
+      dst[D] = dk[r] * scale;
+      dst[2 * D] = dv[r];
+    }
+  }
+#if MPA_QKV_EXP == 9
+  QKV_STAMP();
+  if (blockIdx.x == 100 && lane == 0)
+    printf("attn_do_bwd stamps (s_memtime ticks): loads %llu, LN backward + panels %llu, chains %llu, reduce %llu, attention %llu\n",
+           ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4]);
+#endif
+}
+
 // ---- LayerNorm backward -----------------------------------------------------------------------------------------------------
 // dx[row] = resid[row] + rstd * (dh*gamma - mean(dh*gamma) - xhat * mean(dh*gamma*xhat));  one wave per row.
 // Per-block partial sums of dgamma = sum dh*xhat and dbeta = sum dh go to part[block][2][D].
@@ -980,6 +1220,15 @@ bool lnb_fused() {
 bool qkv_attn_fused() {
   static const bool on = [] {
     const char* e = getenv("MPA_TF_QKVATTN");
+    return e == nullptr || e[0] != '0';
+  }();
+  return on;
+}
+
+// MPA_TF_DOATTN=0: the d o GEMM (with LN2's backward) and the attention backward as two launches (attn_do_bwd_kernel's switch)
+bool do_attn_fused() {
+  static const bool on = [] {
+    const char* e = getenv("MPA_TF_DOATTN");
     return e == nullptr || e[0] != '0';
   }();
   return on;
@@ -1239,10 +1488,12 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
   // blocks regenerating the same row tile's dropout mask cost more than the launch (19.3 vs 9.9 + 5.8 us, LABBOOK 5.3)
   const bool sk = splitk_on();
   const bool fuse = Di == 2 * kKP && lnb_fused();
+  // d o product + LN2 backward + attention backward per (sample, head) in one block (attn_do_bwd_kernel)
+  const bool do_attn = fuse && P <= 32 && Di / (int)H == 32 && do_attn_fused() && B <= (int64_t)lnblocks;
   auto ln_site = [&](int idx, float* dgamma, float* dbeta, bool fused) {  // 2l: LN1 of layer l, 2l + 1: LN2, 2L: the final one
     sites.dgamma[idx] = dgamma;
     sites.dbeta[idx] = dbeta;
-    sites.blocks[idx] = fused ? (M + 31) / 32 : (int)lnblocks;
+    sites.blocks[idx] = fused ? (do_attn ? (int)B : (M + 31) / 32) : (int)lnblocks;  // partial rows of the site
     return w.lnpart + idx * ln_stride;
   };
   struct LnB {  // one LayerNorm backward: d x = resid + J^T dh, its masked copy (site) and the dgamma / dbeta partials
@@ -1304,7 +1555,11 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     const float* gdm = dr ? w.gd_mid : g_mid;  // drop-masked g_mid (site S_SA_OUT)
     wl[2] = wgrad_args(gdm, t.o, gp[P_WO], gp[P_BO], M, Di, Di);
     float* d_o = spare2;
-    if (fuse) {  // LN2's backward inside the d o GEMM: its operand spare2 is still being read, so d o gets its own buffer
+    if (do_attn) {
+      hipLaunchKernelGGL(attn_do_bwd_kernel, dim3((unsigned)(B * H)), dim3(kBT), 0, s, ln2.dh, ln2.x, ln2.stats, ln2.gamma, ln2.resid,
+                         ln2.dx, ln2.dx_drop, ln2.part, ln2.site, pp[P_WO], t.qkv, t.probs, (int)P, (int)H, drop, site0 + S_ATTN,
+                         w.dqkv);
+    } else if (fuse) {  // LN2's backward inside the d o GEMM: its operand spare2 is still being read, so d o gets its own buffer
       d_o = w.g_d;
       ga = gemm_args(gdm, pp[P_WO], nullptr, d_o, M, Di, Di);
       ln_ride(ga, ln2);
@@ -1313,7 +1568,8 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
       ln_alone(ln2);
       launch_gemm<EPI_NONE, true>(gemm_args(gdm, pp[P_WO], nullptr, d_o, M, Di, Di), s);
     }
-    if (P <= 32 && Di / (int)H == 32)
+    if (do_attn) {
+    } else if (P <= 32 && Di / (int)H == 32)
       hipLaunchKernelGGL(attn_bwd_mfma_kernel<1>, dim3((unsigned)(B * H)), dim3(64), 0, s, t.qkv, t.probs, d_o, (int)P, Di,
                          (int)H, drop, site0 + S_ATTN, w.dqkv);
     else if (P <= 32 && Di / (int)H == 64)
