@@ -758,13 +758,53 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const float* __restri
 // sample's dgamma / dbeta partial row (ln_part[sample]: the reduction kernel is told B rows for this site).
 // 14.6 us against 9.0 + 7.8 us and a launch boundary (-DMPA_QKV_EXP=9 stamps of a block, in us: requests 3.7 — the saved
 // probabilities come from HBM —, LayerNorm backward + masks + panels 2.6, chains 0.6, reduction 2.2, attention 3.9).
+// CHAIN: the kernel goes on with what follows the attention's gradient on the way down — rows of a sample again:
+//   d(LN1 output)[tokens][256] = dqkv[tokens][768] . Wqkv[768][256] is a sum over the heads, so every (sample, head) block adds
+//   its 96-column slice's product (its d q | d k | d v tiles go back through LDS as lane-per-row operands, the weight rows
+//   arrive as coalesced B operands requested at the top of the kernel; wave w owns output columns 32 w ..) as a partial tile in
+//   `hp`, written through to agent scope and ordered by a per-sample ticket (tf_gemm.h's split-K hand-over); the block that
+//   takes the sample's LAST ticket adds the eight partial tiles in head order and runs LN1's backward on the rows — the
+//   residual is the d x_mid this block computed itself — writing the layer's input gradient, its masked copy for the layer
+//   below and the sample's dgamma / dbeta partial row.  Replaces the split-K GEMM and the LayerNorm-backward launch behind the
+//   attention (8.8 + 5.6 us and two boundaries per layer).
+struct ChainArgs {
+  const float* wqkv;    // [3 D][D]
+  const float* x_in;    // [M][D] LN1's input
+  const float* stats1;  // [M][2]
+  const float* gamma1;  // [D]
+  float* g_in;          // [M][D] gradient at the layer's input
+  float* gd_next;       // nullable [M][D]: g_in under the dropout mask of site_next (the layer below's FFN output)
+  unsigned site_next;
+  float* ln1_part;      // [B][2 D]
+  float* hp;            // [B][H][32][D] partial tiles of d(LN1 output)
+  unsigned* ticket;     // [B], zero between launches
+};
+typedef float tf_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ tf_f4 ld_agent4(const float* p) {  // past this XCD's L2 (the other blocks' write-through stores)
+  tf_f4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// the loads above are invisible to the compiler's own wait insertion: this wait names the registers, so that no use of them
+// is scheduled in front of it
+__device__ __forceinline__ void wait_agent8(tf_f4 (&v)[8]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+               :
+               : "memory");
+}
+
 constexpr int kBT = 512;
+template <bool CHAIN>
 __global__ __launch_bounds__(kBT, 2) void attn_do_bwd_kernel(
     const float* __restrict__ dh, const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ resid, float* __restrict__ ln_dx, float* __restrict__ ln_dxdrop, float* __restrict__ ln_part,
     unsigned ln_site, const float* __restrict__ wo, const float* __restrict__ qkv, const float* __restrict__ probs, int P, int H,
-    Drop drop_in, unsigned site, float* __restrict__ dqkv) {
+    Drop drop_in, unsigned site, float* __restrict__ dqkv, const ChainArgs ch) {
   constexpr int D = 256, DH = 32;
+  __shared__ float dq_s[CHAIN ? 3 : 1][32][36];  // CHAIN: the head's d q | d k | d v tiles, row = token
+  __shared__ int last_s;
+  __shared__ float wq0[CHAIN ? 48 : 1][64];  // CHAIN: wave 0's weight operands, fetched by wave 7
   __shared__ __attribute__((aligned(16))) float panel[64 * kQLD];  // rows 0..31: masked d x rows; 32..63: Wo^T slice [feature][k]
   __shared__ float4 hand[4][64];
   __shared__ float colp[8][2][D];  // head 0: the waves' column partials of dh xhat | dh
@@ -801,6 +841,21 @@ __global__ __launch_bounds__(kBT, 2) void attn_do_bwd_kernel(
     const int f = threadIdx.x + kBT * i;
     wv[i] = *reinterpret_cast<const float4*>(wo + (long long)(f >> 3) * D + hd * DH + 4 * (f & 7));
   }
+  // CHAIN: B operands of the chain product, Wqkv[t D + hd DH + k][32 wv + c] with k = 8 v + 4 h + e (the enumeration of the A
+  // reads).  They are requested behind the hand-over barrier, by the seven waves that idle through wave 0's attention — wave 7
+  // also fetches wave 0's tile and parks it in LDS (held from the top of the kernel they cost wave 0 its registers: spills)
+  float wq[CHAIN ? 48 : 1];
+  auto load_wq = [&](int wvt, float (&dst)[CHAIN ? 48 : 1]) {
+    if constexpr (CHAIN) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            dst[16 * t + 4 * v + e] = ch.wqkv[(long long)(t * D + hd * DH + 8 * v + 4 * h + e) * D + 32 * wvt + c];
+    }
+  };
   const bool on = c < P;
   const long long tokc = row0 + (on ? c : 0);
   const long long pbase = (long long)(b * H + hd) * P * P;
@@ -828,6 +883,7 @@ __global__ __launch_bounds__(kBT, 2) void attn_do_bwd_kernel(
   QKV_STAMP();
   // ---- LayerNorm backward of the rows, dropout mask, panel
   float4 pxh = make_float4(0.f, 0.f, 0.f, 0.f), pg = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 vrow[4];  // d x_mid of the block's rows (CHAIN: the residual of LN1's backward)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = wave + 8 * i;
@@ -843,6 +899,7 @@ __global__ __launch_bounds__(kBT, 2) void attn_do_bwd_kernel(
     v.y += rstd[i] * (dy - s1 - xh.y * s2);
     v.z += rstd[i] * (dz - s1 - xh.z * s2);
     v.w += rstd[i] * (dw - s1 - xh.w * s2);
+    vrow[i] = v;
     float4 m = v;
     const long long o = (row0 + (live ? row : 0)) * D + 4 * lane;
     if (ln_dxdrop != nullptr) {
@@ -906,21 +963,37 @@ __global__ __launch_bounds__(kBT, 2) void attn_do_bwd_kernel(
     part[1][g][wave][lane] = make_float4(at[4 * g], at[4 * g + 1], at[4 * g + 2], at[4 * g + 3]);
   }
   __syncthreads();
-  if (wave >= 2) return;  // (the barrier below is reached by the two waves that are left)
+  if constexpr (!CHAIN) {
+    if (wave >= 2) return;  // (the barrier below is reached by the two waves that are left)
+  }
   float tl[16];  // wave 0: d o transposed (the head-dimension chains' operand); wave 1: d o straight, handed over
+  if (wave < 2) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float4 a = part[1 - wave][g][0][lane];
+    for (int g = 0; g < 4; ++g) {
+      float4 a = part[1 - wave][g][0][lane];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) {
-      const float4 p4 = part[1 - wave][g][w][lane];
-      a.x += p4.x, a.y += p4.y, a.z += p4.z, a.w += p4.w;
+      for (int w = 1; w < 8; ++w) {
+        const float4 p4 = part[1 - wave][g][w][lane];
+        a.x += p4.x, a.y += p4.y, a.z += p4.z, a.w += p4.w;
+      }
+      tl[4 * g] = a.x, tl[4 * g + 1] = a.y, tl[4 * g + 2] = a.z, tl[4 * g + 3] = a.w;
+      if (wave == 1) hand[g][lane] = a;
     }
-    tl[4 * g] = a.x, tl[4 * g + 1] = a.y, tl[4 * g + 2] = a.z, tl[4 * g + 3] = a.w;
-    if (wave == 1) hand[g][lane] = a;
   }
   __syncthreads();
-  if (wave != 0) return;
+  if constexpr (!CHAIN) {
+    if (wave != 0) return;
+  }
+  if constexpr (CHAIN) {
+    if (wave != 0) load_wq(wave, wq);
+    if (wave == 7) {
+      float w0[48];
+      load_wq(0, w0);
+#pragma unroll
+      for (int k = 0; k < 48; ++k) wq0[k][lane] = w0[k];
+    }
+  }
+  if (wave == 0) {
   QKV_STAMP();
   float gb0[16];
 #pragma unroll
@@ -969,19 +1042,155 @@ __global__ __launch_bounds__(kBT, 2) void attn_do_bwd_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int xr = acc_row(r, h);
+    const float q_ = dq[r] * scale, k_ = dk[r] * scale, v_ = dv[r];
     if (xr < P) {
       float* dst = dqkv + (row0 + xr) * 3 * D + hd * DH + c;
-      dst[0] = dq[r] * scale;
-      dst[D] = dk[r] * scale;
-      dst[2 * D] = dv[r];
+      dst[0] = q_;
+      dst[D] = k_;
+      dst[2 * D] = v_;
+    }
+    if constexpr (CHAIN) {  // (rows >= P are zeros: their d o rows were)
+      dq_s[0][xr][c] = q_;
+      dq_s[1][xr][c] = k_;
+      dq_s[2][xr][c] = v_;
     }
   }
+  }  // wave 0
 #if MPA_QKV_EXP == 9
-  QKV_STAMP();
-  if (blockIdx.x == 100 && lane == 0)
+  if (wave == 0) QKV_STAMP();
+  if (blockIdx.x == 100 && lane == 0 && wave == 0)
     printf("attn_do_bwd stamps (s_memtime ticks): loads %llu, LN backward + panels %llu, chains %llu, reduce %llu, attention %llu\n",
            ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4]);
 #endif
+  if constexpr (CHAIN) {
+    __syncthreads();  // the head's d q | d k | d v tiles are in LDS
+    // what the sample's last block needs for LN1's backward (requested by every block: one of eight uses it, none waits —
+    // the product and the ticket below cover the latency)
+    float4 x1[4];
+    float mean1[4], rstd1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave + 8 * i;
+      const long long tok = row0 + (row < P ? row : 0);
+      x1[i] = *reinterpret_cast<const float4*>(ch.x_in + tok * D + 4 * lane);
+      mean1[i] = ch.stats1[2 * tok];
+      rstd1[i] = ch.stats1[2 * tok + 1];
+    }
+    const float4 g1 = *reinterpret_cast<const float4*>(ch.gamma1 + 4 * lane);
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < 48; ++k) wq[k] = wq0[k][lane];
+    }
+#if MPA_QKV_EXP == 9
+    unsigned long long tc[6];
+    tc[0] = __builtin_amdgcn_s_memtime();
+#endif
+    f32x16 acc = {0};
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float4 a4 = *reinterpret_cast<const float4*>(&dq_s[t][c][8 * v + 4 * h]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, wq[16 * t + 4 * v], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, wq[16 * t + 4 * v + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, wq[16 * t + 4 * v + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, wq[16 * t + 4 * v + 3], acc, 0, 0, 0);
+      }
+    float* mine = ch.hp + ((long long)(b * H + hd) * 32) * D + 32 * wave + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int xr = acc_row(r, h);
+      if (xr < P) __hip_atomic_store(mine + (long long)xr * D, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#if MPA_QKV_EXP == 9
+    tc[1] = __builtin_amdgcn_s_memtime();
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through and acknowledged before the ticket is taken
+#if MPA_QKV_EXP == 9
+    tc[2] = __builtin_amdgcn_s_memtime();
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned old = atomicAdd(ch.ticket + b, 1u);
+      last_s = old == (unsigned)(H - 1);
+      if (old == (unsigned)(H - 1)) ch.ticket[b] = 0u;  // ready for the next launch
+    }
+    __syncthreads();
+#if MPA_QKV_EXP == 9
+    tc[3] = __builtin_amdgcn_s_memtime();
+#endif
+    if (!last_s) return;
+    // ---- the sample's last block: the eight heads' partial tiles in head order, then LN1's backward on the rows
+    float4 dl[4];
+    {
+      tf_f4 hv[4][8];  // all 32 requests of the thread in flight together (row by row it was four dependent round trips)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave + 8 * i, rr = row < P ? row : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hv[i][q] = ld_agent4(ch.hp + ((long long)(b * H + (q < H ? q : 0)) * 32 + rr) * D + 4 * lane);
+      }
+      wait_agent8(hv[0]);
+      wait_agent8(hv[1]);  // (vmcnt is already zero: these only name the registers)
+      wait_agent8(hv[2]);
+      wait_agent8(hv[3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tf_f4 a = hv[i][0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+          if (q < H) a += hv[i][q];
+        dl[i] = make_float4(a.x, a.y, a.z, a.w);
+      }
+    }
+#if MPA_QKV_EXP == 9
+    tc[4] = __builtin_amdgcn_s_memtime();
+#endif
+    float4 qxh = make_float4(0.f, 0.f, 0.f, 0.f), qg = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave + 8 * i;
+      if (row >= P) continue;  // (wave-uniform)
+      const float4 d4 = dl[i];
+      const float4 xh = make_float4((x1[i].x - mean1[i]) * rstd1[i], (x1[i].y - mean1[i]) * rstd1[i],
+                                    (x1[i].z - mean1[i]) * rstd1[i], (x1[i].w - mean1[i]) * rstd1[i]);
+      const float dx = d4.x * g1.x, dy = d4.y * g1.y, dz = d4.z * g1.z, dw = d4.w * g1.w;
+      const float s1 = wave_sum_dpp((dx + dy) + (dz + dw)) * (1.0f / (float)D);
+      const float s2 = wave_sum_dpp((dx * xh.x + dy * xh.y) + (dz * xh.z + dw * xh.w)) * (1.0f / (float)D);
+      float4 v = vrow[i];
+      v.x += rstd1[i] * (dx - s1 - xh.x * s2);
+      v.y += rstd1[i] * (dy - s1 - xh.y * s2);
+      v.z += rstd1[i] * (dz - s1 - xh.z * s2);
+      v.w += rstd1[i] * (dw - s1 - xh.w * s2);
+      const long long o = (row0 + row) * D + 4 * lane;
+      *reinterpret_cast<float4*>(ch.g_in + o) = v;
+      if (ch.gd_next != nullptr) {
+        float4 m = v;
+        m.x *= drop_scale(drop, ch.site_next, (unsigned long long)o);
+        m.y *= drop_scale(drop, ch.site_next, (unsigned long long)o + 1);
+        m.z *= drop_scale(drop, ch.site_next, (unsigned long long)o + 2);
+        m.w *= drop_scale(drop, ch.site_next, (unsigned long long)o + 3);
+        *reinterpret_cast<float4*>(ch.gd_next + o) = m;
+      }
+      qxh.x += d4.x * xh.x, qxh.y += d4.y * xh.y, qxh.z += d4.z * xh.z, qxh.w += d4.w * xh.w;
+      qg.x += d4.x, qg.y += d4.y, qg.z += d4.z, qg.w += d4.w;
+    }
+    *reinterpret_cast<float4*>(&colp[wave][0][4 * lane]) = qxh;  // (colp is free: head 0's sums left it two barriers ago)
+    *reinterpret_cast<float4*>(&colp[wave][1][4 * lane]) = qg;
+    __syncthreads();
+    {
+      const int k = threadIdx.x;
+      float sm = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sm += colp[w][k >> 8][k & 255];
+      ch.ln1_part[(long long)b * 2 * D + k] = sm;
+    }
+#if MPA_QKV_EXP == 9
+    if (b == 12 && threadIdx.x == 0)
+      printf("attn chain stamps (ticks): product + stores %llu, store acknowledge %llu, ticket %llu, partial tiles %llu, LN1 backward %llu\n",
+             tc[1] - tc[0], tc[2] - tc[1], tc[3] - tc[2], tc[4] - tc[3], __builtin_amdgcn_s_memtime() - tc[4]);
+#endif
+  }
 }
 
 // ---- LayerNorm backward -----------------------------------------------------------------------------------------------------
@@ -1225,6 +1434,15 @@ bool qkv_attn_fused() {
   return on;
 }
 
+// MPA_TF_CHAIN=0: the d(LN1 output) GEMM and LN1's backward as launches of their own (attn_do_bwd_kernel<true>'s switch)
+bool chain_fused() {
+  static const bool on = [] {
+    const char* e = getenv("MPA_TF_CHAIN");
+    return e == nullptr || e[0] != '0';
+  }();
+  return on;
+}
+
 // MPA_TF_DOATTN=0: the d o GEMM (with LN2's backward) and the attention backward as two launches (attn_do_bwd_kernel's switch)
 bool do_attn_fused() {
   static const bool on = [] {
@@ -1301,6 +1519,7 @@ struct TfLayout {
   float *x_final, *stats_f;
   // backward scratch
   float *g_a, *g_b, *g_c, *g_d, *gd_out, *gd_mid, *dz, *dqkv, *lnpart;
+  float *gd_alt, *hp;   // attn_do_bwd_kernel<CHAIN>: the second masked-gradient buffer, the heads' partial tiles [B][H][32][D]
   float* sk_buf;        // split-K half tiles of the K >= 768 GEMMs (tf_gemm.h)
   unsigned* sk_ticket;  // their tickets: cleared by the first GEMM of every forward / backward call, reset after each use
   int64_t total;
@@ -1337,6 +1556,8 @@ TfLayout tf_carve(float* base, const TfDims& d) {
   w.dz = take(d.M * d.FF);
   w.dqkv = take(d.M * 3 * d.D);
   w.lnpart = take((2 * d.L + 1) * ((d.M + 3) / 4) * 2 * d.D);  // one partial table per LayerNorm
+  w.gd_alt = take(d.M * d.D);
+  w.hp = take(d.B * d.H * 32 * d.D);
   w.sk_buf = take((int64_t)tfg::kSkTiles * 2048);
   w.sk_ticket = reinterpret_cast<unsigned*>(take(tfg::kSkTiles));
   w.total = p - base;
@@ -1527,6 +1748,11 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
   float* g = w.g_a;      // gradient w.r.t. the current layer's output
   float* spare = w.g_b;  // rotating buffers
   float* spare2 = w.g_c;
+  // attn_do_bwd_kernel<true>: the d(LN1 output) product and LN1's backward ride behind the attention's gradient; the masked
+  // gradient for the layer below then goes to the OTHER of two buffers (this layer's weight gradients still read the first)
+  const bool chain = do_attn && chain_fused() && B <= (int64_t)tfg::kSkTiles && H <= 8;
+  float* gd_cur = w.gd_out;
+  float* gd_nxt = w.gd_alt;
   for (int l = (int)L - 1; l >= 0; --l) {
     const float* const* pp = params + l * P_PER_LAYER;
     float* const* gp = grad_params + l * P_PER_LAYER;
@@ -1536,7 +1762,7 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     // (the layer's four weight gradients are off the critical path and all their operands stay intact until the
     // layer's last LayerNorm backward: they go out as ONE launch just before it)
     WgradArgs wl[4];
-    const float* gdo = dr ? w.gd_out : g;  // drop-masked g (site S_FFN_OUT of this layer)
+    const float* gdo = dr ? gd_cur : g;  // drop-masked g (site S_FFN_OUT of this layer)
     wl[0] = wgrad_args(gdo, t.f, gp[P_W2], gp[P_B2], M, Di, FFi);
     GemmArgs ga = gemm_args(gdo, pp[P_W2], nullptr, w.dz, M, FFi, Di);  // W2 is [D, FF] = [K, N]
     ga.resid = t.f;
@@ -1555,10 +1781,39 @@ extern "C" int mpa_transformer_backward(const float* grad_out, const float* vali
     const float* gdm = dr ? w.gd_mid : g_mid;  // drop-masked g_mid (site S_SA_OUT)
     wl[2] = wgrad_args(gdm, t.o, gp[P_WO], gp[P_BO], M, Di, Di);
     float* d_o = spare2;
+    if (chain) {
+      // the layer's input gradient lands in the buffer of d(LN2 output): a sample's rows of it are read only by that sample's
+      // blocks, all of them before its last ticket
+      ChainArgs ch{};
+      ch.wqkv = pp[P_WQKV];
+      ch.x_in = t.x_in;
+      ch.stats1 = t.stats1;
+      ch.gamma1 = pp[P_G1];
+      ch.g_in = l == 0 ? grad_tokens : spare2;
+      ch.gd_next = dr && l > 0 ? gd_nxt : (float*)nullptr;
+      ch.site_next = (unsigned)((l - 1) * S_PER_LAYER + S_FFN_OUT);
+      ch.ln1_part = ln_site(2 * l, gp[P_G1], gp[P_BE1], true);
+      ch.hp = w.hp;
+      ch.ticket = w.sk_ticket;
+      hipLaunchKernelGGL(attn_do_bwd_kernel<true>, dim3((unsigned)(B * H)), dim3(kBT), 0, s, ln2.dh, ln2.x, ln2.stats, ln2.gamma,
+                         ln2.resid, ln2.dx, ln2.dx_drop, ln2.part, ln2.site, pp[P_WO], t.qkv, t.probs, (int)P, (int)H, drop,
+                         site0 + S_ATTN, w.dqkv, ch);
+      wl[3] = wgrad_args(w.dqkv, t.h1, gp[P_WQKV], gp[P_BQKV], M, 3 * Di, Di);
+      launch_wgrad_group(wl, 4, s);
+      if (l > 0) {  // next layer down: g = the buffer just written; the old g (now `spare`) and g_mid's buffer are free
+        float* g_new = spare2;
+        spare2 = g_mid;
+        g = g_new;
+        float* tmp = gd_cur;
+        gd_cur = gd_nxt;
+        gd_nxt = tmp;
+      }
+      continue;
+    }
     if (do_attn) {
-      hipLaunchKernelGGL(attn_do_bwd_kernel, dim3((unsigned)(B * H)), dim3(kBT), 0, s, ln2.dh, ln2.x, ln2.stats, ln2.gamma, ln2.resid,
-                         ln2.dx, ln2.dx_drop, ln2.part, ln2.site, pp[P_WO], t.qkv, t.probs, (int)P, (int)H, drop, site0 + S_ATTN,
-                         w.dqkv);
+      hipLaunchKernelGGL(attn_do_bwd_kernel<false>, dim3((unsigned)(B * H)), dim3(kBT), 0, s, ln2.dh, ln2.x, ln2.stats, ln2.gamma,
+                         ln2.resid, ln2.dx, ln2.dx_drop, ln2.part, ln2.site, pp[P_WO], t.qkv, t.probs, (int)P, (int)H, drop,
+                         site0 + S_ATTN, w.dqkv, ChainArgs{});
     } else if (fuse) {  // LN2's backward inside the d o GEMM: its operand spare2 is still being read, so d o gets its own buffer
       d_o = w.g_d;
       ga = gemm_args(gdm, pp[P_WO], nullptr, d_o, M, Di, Di);
