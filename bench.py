@@ -361,7 +361,7 @@ def kernel_table(kernels, nv, cfg, B, P):
         M = B * P
         tf = L * (2.0 * M * D * 3 * D + 2.0 * M * D * D + 4.0 * M * D * FF + 4.0 * B * H * P * P * (D // H))
         add_mfma("transformer_forward", "transformer_forward", flops_f32=tf,
-                 note="launch / dependency latency bound: 21 launches of 5-13 us")
+                 note="launch / dependency latency bound: 17 launches of 4-13 us (a persistent form loses: LABBOOK 6.3)")
         add_mfma("transformer_backward", "transformer_backward", flops_f32=2.0 * tf)
     # per-part Chamfer (csrc/gate_nn.hip): every pair of a part's two clouds is BOUNDED by 1 / 1024 of a bf16 matrix
     # instruction (32 x 32 x 16: 32 FLOP per pair), then ~1.5 % of the pairs are evaluated with the pinned arithmetic
