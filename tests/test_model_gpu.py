@@ -375,6 +375,38 @@ def test_transformer_cross_block_hand_overs_are_stable_over_many_launches(cuda_d
             assert torch.equal(a, b), (it, k)
 
 
+@pytest.mark.parametrize("B,P", [(1, 1), (3, 2), (5, 31), (2, 32), (33, 7), (40, 20)])
+def test_transformer_fused_kernels_at_the_edges_of_their_envelope(cuda_device, B, P):
+    """attn_qkv_fwd_kernel / attn_do_bwd_kernel hold a sample's tokens in one 32-row tile and hand tiles between blocks per
+    sample: one token, a full tile, more samples than row tiles, a batch that is not a multiple of anything — against
+    PyTorch-ROCm's own TransformerEncoder on the same device (dropout off), every gradient."""
+    torch.manual_seed(100 * B + P)
+    D, H, FF, L = 256, 8, 1024, 2
+    enc = TransformerEncoder(D, H, FF, L, norm_first=True, dropout=0.0).to(cuda_device).train()
+    g = torch.Generator().manual_seed(B + 7 * P)
+    num = torch.randint(1, P + 1, (B,), generator=g)
+    valid = (torch.arange(P)[None] < num[:, None]).to(cuda_device)
+    tok = (torch.randn(B, P, D, generator=g) * valid.cpu()[..., None]).to(cuda_device)
+    w = torch.randn(B, P, D, generator=g).to(cuda_device)
+
+    def run(native):
+        enc.native = native
+        for p_ in enc.parameters():
+            p_.grad = None
+        x = tok.clone().requires_grad_()
+        out = enc(x, valid)
+        (out * w * valid[..., None].float()).sum().backward()
+        return out.detach(), x.grad.clone(), {k: p_.grad.clone() for k, p_ in enc.named_parameters()}
+
+    o1, gx1, g1 = run(True)
+    o0, gx0, g0 = run(False)
+    v = valid.cpu().numpy()
+    assert _rel(o1.cpu().numpy()[v], o0.cpu().numpy()[v]) < 1e-4
+    assert _rel(gx1.cpu().numpy()[v], gx0.cpu().numpy()[v]) < 1e-3
+    for k in g0:
+        assert _rel(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 1e-3, k
+
+
 _TF_KNOB_SCRIPT = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[2])
