@@ -320,6 +320,145 @@ __global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_nt_split_
 // stores take 12 ds_write_b16.  A 16-lane store group is 8 columns x 2 row groups = 32 different banks.  The four 8-row
 // groups of a panel row are XOR-swizzled by (column >> 4) & 3 (a fragment = 8 consecutive rows = one aligned 16-byte
 // group).
+#ifndef DG_GS_TN_TR  // 1: row-major panels + transposed fragment reads (ds_read_b64_tr_b16, round 6); 0: the quad-transpose staging
+#define DG_GS_TN_TR 1
+#endif
+#if DG_GS_TN_TR
+// Round 6: the panels hold the step's 32 rows AS THEY ARE LOADED — row = [h | m | l] planes of the tile's columns — and the
+// fragments come out transposed from the LDS (ds_read_b64_tr_b16: two reads per plane and k-step, pn_bwd_q.h's lane map).  The
+// 4 x 4 quad transposes of the staging (two DPP moves, two byte permutes and a select per plane and float4, on top of the
+// split) are gone: the staging waves' VALU issue is what bounds these kernels (LABBOOK 6.3).
+template <int BK>
+__global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_tn_split_kernel(const float* __restrict__ Y, int ldy, int Nout,
+                                                            const float* __restrict__ X, int ldx, int K,
+                                                            float* __restrict__ part, int rows_per_chunk,
+                                                            const int* __restrict__ hdr, int rows) {
+  constexpr int BNT = 128, RC = 32;
+  constexpr int WKW = DG_GS_WAVES == 4 ? 2 : (BK == 128 ? 4 : 2), WNW = DG_GS_WAVES / WKW;
+  constexpr int TNn = BNT / WNW / 32, TK = BK / WKW / 32;
+  constexpr int YC = BNT / 4, XC = BK / 4;              // column quads per row
+  constexpr int YP = kGsT / YC, XP = kGsT / XC;         // rows staged per pass of the block
+  constexpr int Y4 = RC / YP, X4 = RC / XP;             // float4 per thread and step
+  constexpr int YROW = 6 * BNT + 16, XROW = 6 * BK + 16;  // panel row bytes: three planes + pad (odd multiples of 16)
+  static_assert(YP >= 1 && XP >= 1 && RC % YP == 0 && RC % XP == 0, "staging layout");
+  __shared__ __attribute__((aligned(16))) unsigned char Ys[RC * YROW];
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[RC * XROW];
+  const int R = hdr != nullptr ? hdr[1] : rows;
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+  if (gridDim.z % 8 == 0) {  // (a chunk's tiles on ONE XCD: see the note on the block -> tile mapping above)
+    const int gx = (int)gridDim.x, tiles = gx * (int)gridDim.y, L = (bz * (int)gridDim.y + by) * gx + bx;
+    const int q = L >> 3, t = q % tiles;
+    bz = (q / tiles) * 8 + (L & 7);
+    bx = t % gx;
+    by = t / gx;
+  }
+  const int n0 = bx * BNT, k0 = by * BK;
+  const int rpc = rows_per_chunk > 0 ? rows_per_chunk : (int)((((long long)R + gridDim.z - 1) / gridDim.z + 31) / 32 * 32);
+  const long long rb = (long long)bz * rpc;
+  long long re = rb + rpc;
+  if (re > R) re = R;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int wn = wave / WKW, wk = wave % WKW;
+  float4 ry[Y4], rx[X4];
+  // thread -> (row tid / C + P i of the step, column quad tid % C)
+  const int yc4 = threadIdx.x % YC, yr = threadIdx.x / YC;
+  const int xc4 = threadIdx.x % XC, xr = threadIdx.x / XC;
+  const bool ycol_ok = n0 + 4 * yc4 < Nout;
+  const float* ybase = Y + (ycol_ok ? n0 + 4 * yc4 : 0);
+  const float* xbase = X + k0 + 4 * xc4;
+  // loads are unconditional (rows clamped to the chunk's last one); what lies past the chunk is zeroed when it is staged
+  auto fetch = [&](long long r) {
+#pragma unroll
+    for (int i = 0; i < Y4; ++i) {
+      const long long row = r + yr + YP * i;
+      ry[i] = *reinterpret_cast<const float4*>(ybase + (row < re ? row : re - 1) * ldy);
+    }
+#pragma unroll
+    for (int i = 0; i < X4; ++i) {
+      const long long row = r + xr + XP * i;
+      rx[i] = *reinterpret_cast<const float4*>(xbase + (row < re ? row : re - 1) * ldx);
+    }
+  };
+  auto put = [&](unsigned char* prow, int plane_bytes, int c4, const float4 v0, bool ok) {
+    const float4 v = make_float4(ok ? v0.x : 0.f, ok ? v0.y : 0.f, ok ? v0.z : 0.f, ok ? v0.w : 0.f);
+    const Split4 s = gs_split(v);
+    unsigned char* p = prow + 8 * c4;
+    *reinterpret_cast<gs_bf16x4*>(p) = s.h;
+    *reinterpret_cast<gs_bf16x4*>(p + plane_bytes) = s.m;
+    *reinterpret_cast<gs_bf16x4*>(p + 2 * plane_bytes) = s.l;
+  };
+  // transposed fragment of column tile `ct` (32 columns), k-step s (16 rows): lane's address = row 8 (g >> 1) + (i >> 2),
+  // column 16 (g & 1) + 4 (i & 3)  (i = lane & 15, g = lane >> 4); the second read 4 rows further
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int trow = 8 * (g16 >> 1) + (i16 >> 2), tcol = 16 * (g16 & 1) + 4 * (i16 & 3);
+  typedef short gs_s16x4 __attribute__((ext_vector_type(4)));
+  typedef short gs_s16x8 __attribute__((ext_vector_type(8)));
+  auto tr1 = [&](const unsigned char* p, int rowb) {
+    const gs_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gs_s16x4*)p);
+    const gs_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gs_s16x4*)(p + 4 * rowb));
+    const gs_s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(gs_bf16x8, v);
+  };
+  auto frag = [&](const unsigned char* panel, int rowb, int plane_bytes, int ct, int s) {
+    const unsigned char* p = panel + (16 * s + trow) * rowb + 2 * (32 * ct + tcol);
+    Frag3 f;
+    f.h = tr1(p, rowb);
+    f.m = tr1(p + plane_bytes, rowb);
+    f.l = tr1(p + 2 * plane_bytes, rowb);
+    return f;
+  };
+  f32x16 acc[TNn][TK];
+#pragma unroll
+  for (int a = 0; a < TNn; ++a)
+#pragma unroll
+    for (int b = 0; b < TK; ++b) acc[a][b] = f32x16{0};
+  if (rb < re) {
+    fetch(rb);
+    for (long long r = rb; r < re; r += RC) {
+      if (r > rb) __syncthreads();  // the previous step's fragment reads are done
+      if (GS_STASH_ON) {
+#pragma unroll
+        for (int i = 0; i < Y4; ++i) {
+          const int rl = yr + YP * i;
+          put(Ys + rl * YROW, 2 * BNT, yc4, ry[i], ycol_ok && r + rl < re);
+        }
+#pragma unroll
+        for (int i = 0; i < X4; ++i) {
+          const int rl = xr + XP * i;
+          put(Xs + rl * XROW, 2 * BK, xc4, rx[i], r + rl < re);
+        }
+      }
+      __syncthreads();
+      if (r + RC < re && GS_LOAD_ON) fetch(r + RC);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frag3 fy[TNn], fx[TK];
+#pragma unroll
+        for (int a = 0; a < TNn; ++a) fy[a] = frag(Ys, YROW, 2 * BNT, wn * TNn + a, s);
+#pragma unroll
+        for (int b = 0; b < TK; ++b) fx[b] = frag(Xs, XROW, 2 * BK, wk * TK + b, s);
+#pragma unroll
+        for (int a = 0; a < TNn; ++a)
+#pragma unroll
+          for (int b = 0; b < TK; ++b) {
+            GS_MMA6(acc[a][b], fy[a], fx[b])
+          }
+      }
+    }
+  }
+  float* out = part + (long long)bz * Nout * K;
+#pragma unroll
+  for (int a = 0; a < TNn; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * (32 * TNn) + a * 32 + acc_row(r, h);
+      if (n < Nout) {
+#pragma unroll
+        for (int b = 0; b < TK; ++b) out[(long long)n * K + k0 + wk * (32 * TK) + 32 * b + j] = acc[a][b][r];
+      }
+    }
+}
+#else
 template <int BK>
 __global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_tn_split_kernel(const float* __restrict__ Y, int ldy, int Nout,
                                                             const float* __restrict__ X, int ldx, int K,
@@ -447,5 +586,7 @@ __global__ __launch_bounds__(kGsT, DG_GS_WAVES == 8 ? 4 : 2) void gemm_tn_split_
       }
     }
 }
+
+#endif  // DG_GS_TN_TR
 
 }  // namespace dg
