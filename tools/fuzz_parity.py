@@ -823,6 +823,10 @@ def main(argv):
                 bad.append((name, seed, what))
                 print(f"MISMATCH {name} seed {seed}: {what}", flush=True)
         seed += 1
+    if edge and os.environ.get("MPA_FUZZ_LIST_EDGE"):
+        from collections import Counter
+        print("set aside by kind:", dict(Counter(e.split()[0] for e in edge)))
+        print("set aside:", "; ".join(edge[:60]))
     if edge:
         print(f"nets / dgcnn / step / gnn / global: {len(edge)} cases set aside: the float64 oracle's own gradients move by > 1e-3 "
               f"under a 2e-6 .. 2e-5 relative input change (a ReLU / max on the rounding edge)")
