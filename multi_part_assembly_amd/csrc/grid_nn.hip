@@ -880,7 +880,10 @@ constexpr int kCand = MPA_GRID_CAND;  // candidate records per LDS window (2.5 K
                                       // waves per CU, and this latency-bound search wants all of them — 512 -> 128 records
                                       // together with 768 instead of 128 persistent waves per (sample, direction) took
                                       // the kernel from 0.44 to 0.28 ms; tools/variant_bench.sh)
-constexpr int kLongRange = 32;  // ranges longer than this are fetched by the whole wave, one range at a time
+#ifndef MPA_GRID_LONG
+#define MPA_GRID_LONG 32
+#endif
+constexpr int kLongRange = MPA_GRID_LONG;  // ranges longer than this are fetched by the whole wave, one range at a time
 
 #ifdef MPA_GRID_STATS  // instrumented build for tools/probe_grid_stats.py only (never in libmpa_hip.so)
 __device__ unsigned long long g_grid_stats[24];  // 0-7: items, active lanes, scan_batch calls, candidates, long-range candidates,
