@@ -509,6 +509,7 @@ def main():
             m.precision = "bf16"
     use_graph = args.graph and not args.eager
     trainer = Trainer(model, cfg, use_graph=use_graph)
+    use_graph = bool(trainer.use_graph)  # (semantic-matching models refuse the capture and run eager: the line says what ran)
     parts_of = [bt.pop("num_parts") for bt in batches]
     num_parts = parts_of[0]
     valid_per_batch = [int(sum(n)) for n in parts_of]

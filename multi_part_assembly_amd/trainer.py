@@ -35,6 +35,14 @@ from .optim import FlatBuffers, FusedAdam, cosine_warmup_lr, decay_mask_for
 class Trainer:
     def __init__(self, model, cfg=None, process_group=None, use_graph=False, graph_warmup=3):
         self.model = model
+        if use_graph and getattr(model, "semantic", False):
+            # identical-part matching draws its point sample on the host every step (base_model._match_parts; reference
+            # base_model.py:196-238): a captured step would replay ONE draw for ever, and the capture itself would hit the
+            # host copy of the match ids.  Such models keep their launches eager.
+            import warnings
+            warnings.warn("Trainer: use_graph=True is not available for models with semantic part matching (the matching's "
+                          "point sample is drawn on the host every step); running eager launches")
+            use_graph = False
         self.use_graph, self.graph_warmup = use_graph, graph_warmup
         self._graph, self._static_batch, self._static_loss, self._eager_steps = None, None, None, 0
         cfg = cfg if cfg is not None else model.cfg

@@ -692,3 +692,23 @@ def test_graph_replay_equals_eager_steps_of_graph_networks(golden, cuda_device, 
     assert graph._graph is not None
     assert torch.equal(graph.flat.flat_param, eager.flat.flat_param), \
         float((graph.flat.flat_param - eager.flat.flat_param).abs().max())
+
+
+def test_graph_mode_falls_back_to_eager_for_semantic_matching(cuda_device):
+    """B-Global (BASELINE.json configs[0]) matches identical parts on a point sample drawn on the host every step
+    (base_model.py:196-238 of the reference): a captured step cannot carry that.  Trainer(use_graph=True) says so and runs
+    eager launches instead of failing inside the capture; the steps train as the eager trainer's do."""
+    import warnings
+
+    import bench
+    from multi_part_assembly_amd.trainer import Trainer
+    cfg, batch, _, B, P = bench.workload("c1", 0, cuda_device)
+    batch.pop("num_parts", None)
+    torch.manual_seed(0)
+    model = build_model(cfg).to(cuda_device)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        tr = Trainer(model, cfg, use_graph=True)
+    assert not tr.use_graph and any("semantic part matching" in str(w.message) for w in caught)
+    losses = [float(tr.train_step(batch, i)) for i in range(4)]
+    assert all(np.isfinite(losses))
