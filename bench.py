@@ -700,6 +700,7 @@ def main():
                     "whole_phase_avg_ms": phase[0][1]["avg_ms"] if phase else None,
                 }
             elif args.config == "c1":
+                # (only with MPA_FUSED_SEMANTIC=0: since round 6 the semantic models run the fused loss and take the branch above)
                 # plumbing case (P = 2: no grid phase): the loss runs the drop-in operator itself, 5 min-of-N samples x
                 # (whole-shape call [B, P*N, 3]^2 + per-part call) per step; the whole-shape call dominates
                 hit = _find(kernels, f"chamfer_forward[{B}x{P * N}x{P * N}]")

@@ -12,6 +12,8 @@ SURVEY.md §8 row N2) are in eval_utils.py.
 from __future__ import annotations
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -116,10 +118,12 @@ class BaseModel(nn.Module):
                                                    data_dict["match_ids"], data_dict["_match_ids_host"])
         else:
             new_trans, new_rot = gt_trans.detach(), gt_rot.detach()
-        if self.fused_loss and not self.semantic:
-            # one fused forward/backward pair instead of the per-function composition below
+        if self.fused_loss and (not self.semantic or os.environ.get("MPA_FUSED_SEMANTIC", "1") != "0"):
+            # one fused forward/backward pair instead of the per-function composition below (semantic data: the matched
+            # poses are plain inputs of the same five terms; its whole-shape term always normalises as in training,
+            # base_model.py:281 of the reference)
             terms, pts = geometric_assembly_loss(part_pcs, pred_trans, pred_rot, new_trans, new_rot,
-                                                 valids, training=self.training, ret_pts=self.keep_pts,
+                                                 valids, training=self.semantic or self.training, ret_pts=self.keep_pts,
                                                  order=self._join_part_order(data_dict), search=self._shape_search())
             loss_dict = LossTerms((k, terms[k]) for k in ("trans_loss", "rot_pt_cd_loss", "transform_pt_cd_loss"))
             if self.cfg.loss.use_rot_loss:

@@ -140,8 +140,8 @@ def test_plumbing_config_with_its_cpu_baseline_and_self_check(cuda_device, capsy
     d = _run("--config", "c1", "--steps", "10", "--warmup", "5", "--no-chamfer-standalone")
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "B=4," in c["sample"]
-    r = d["roofline"]  # the drop-in operator's whole-shape call: 5 min-of-N samples per step
-    assert "mpa_chamfer_forward" in r["kernel"] and r["launches"] == 50 and r["algorithmic_bytes_per_launch"] == 24.0 * 4 * 4000
+    r = d["roofline"]  # the whole-shape search of the fused loss (round 6: semantic models use it too): 5 min-of-N samples per step
+    assert "fused loss" in r["kernel"] and r["launches"] == 50 and r["algorithmic_bytes_per_launch"] == 24.0 * 4 * 4000
     with capsys.disabled():
         print(f"\n  BENCH c1: {d['ms_per_step']:.3f} ms/step, {d['value']:.0f} parts/s; CPU {c['value']:.1f} parts/s on "
               f"{c['cores']} cores", end="")
